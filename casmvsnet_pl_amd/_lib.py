@@ -1,0 +1,67 @@
+"""ctypes binding of libcasmvs_hip.so (C ABI declared in include/casmvs.h).
+
+This is the stub a maintainer of the reference would add to call the MI355X engine from
+`models/modules.py` / `models/mvsnet.py`.  There is no CPU fallback: if the
+library is missing the import of any op raises, and on a machine without a gfx950 device the
+launches return CASMVS_ERR_HIP which is raised as RuntimeError.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libcasmvs_hip.so")
+ABI_VERSION = 1
+
+CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
+
+# every symbol include/casmvs.h declares: name -> (restype, argtypes)
+_FP = c_void_p  # device / host float* passed as integer addresses
+SYMBOLS = {
+    "casmvs_abi_version": (c_int, []),
+    "casmvs_last_error": (c_char_p, []),
+    "casmvs_depth_hypotheses_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_homo_warp_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_costvol_var_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_costvol_gwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_conv3d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
+    "casmvs_conv3d_pack_f32": (c_int, [c_int, c_int, c_int, _FP, _FP, _FP, _FP]),
+    "casmvs_conv3d_forward_f32": (c_int, [c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "casmvs_costreg_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "casmvs_costreg_forward_f32": (c_int, [POINTER(c_void_p), _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "casmvs_softmax_regress_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_selftest_mfma": (c_int, [_FP]),
+}
+
+_lib = None
+
+
+class CasMVSLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise CasMVSLibraryError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -m casmvsnet_pl_amd.build). "
+            "casmvsnet_pl_amd has no CPU/PyTorch fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.casmvs_abi_version()
+    if got != ABI_VERSION:
+        raise CasMVSLibraryError(f"libcasmvs_hip.so ABI version {got}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().casmvs_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

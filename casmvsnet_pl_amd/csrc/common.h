@@ -1,0 +1,29 @@
+// Shared host-side helpers of libcasmvs_hip.so (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "casmvs.h"
+
+namespace casmvs {
+
+char *error_buffer();  // thread-local, 512 bytes
+int fail(int code, const char *fmt, ...);
+void clear_error();
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CASMVS_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return CASMVS_OK;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace casmvs
+
+#define CASMVS_REQUIRE(cond, ...)                                            \
+  do {                                                                       \
+    if (!(cond)) return casmvs::fail(CASMVS_ERR_INVALID_ARG, __VA_ARGS__);   \
+  } while (0)

@@ -1,0 +1,172 @@
+// Depth-hypothesis generation and softmax / soft-argmin regression / confidence kernels.
+//
+// Reference semantics: models/mvsnet.py:213-235 + models/modules.py:34-49 (hypotheses),
+// models/mvsnet.py:174-193 + models/modules.py:95-104 (softmax, regression, confidence).
+// Both are HBM-bound streaming kernels: one thread per pixel, lanes along the image row so every
+// (D, h, w) plane access is a coalesced 256 B wavefront transaction; the D values of a pixel stay
+// in registers between the max / exp-sum / regression passes (one read of the cost volume).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---- hypotheses ------------------------------------------------------------------------------
+// Coarsest level (prev == nullptr): d_k = depth_min[b] + interval[b] * k      (mvsnet.py:216-229)
+// Finer levels: u = bilinear x2 upsample (align_corners=True) of prev (mvsnet.py:232-234, ATen
+// UpSample.h area_pixel_compute_source_index / compute_source_index_and_lambda), then
+// d_min = max(u - half_range[b], 1e-7), d_k = d_min + interval[b] * k          (modules.py:44-48)
+__global__ __launch_bounds__(kThreads) void hypotheses_kernel(
+    const float *__restrict__ prev, const float *__restrict__ depth_min_b,
+    const float *__restrict__ interval_b, const float *__restrict__ half_range_b,
+    float *__restrict__ out, int D, int h, int w, int hp, int wp) {
+  const int b = blockIdx.y;
+  const int hw = h * w;
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= hw) return;
+  const float delta = interval_b[b];
+  float dmin;
+  if (prev == nullptr) {
+    dmin = depth_min_b[b];
+  } else {
+    const int y = p / w, x = p - y * w;
+    // ATen: scale = (in - 1) / (out - 1) computed in float; src = scale * dst
+    const float sy = (h > 1) ? (float)(hp - 1) / (float)(h - 1) : 0.0f;
+    const float sx = (w > 1) ? (float)(wp - 1) / (float)(w - 1) : 0.0f;
+    const float fy = __fmul_rn(sy, (float)y), fx = __fmul_rn(sx, (float)x);
+    const int y0 = (int)fy, x0 = (int)fx;  // fy, fx >= 0: truncation == floor
+    const int y1 = y0 + ((y0 < hp - 1) ? 1 : 0), x1 = x0 + ((x0 < wp - 1) ? 1 : 0);
+    const float ly1 = __fsub_rn(fy, (float)y0), ly0 = __fsub_rn(1.0f, ly1);
+    const float lx1 = __fsub_rn(fx, (float)x0), lx0 = __fsub_rn(1.0f, lx1);
+    const float *pp = prev + (size_t)b * hp * wp;
+    const float v00 = pp[y0 * wp + x0], v01 = pp[y0 * wp + x1];
+    const float v10 = pp[y1 * wp + x0], v11 = pp[y1 * wp + x1];
+    // ATen upsample_bilinear2d: h0lambda * (w0lambda * v00 + w1lambda * v01) + h1lambda * (...)
+    const float top = __fadd_rn(__fmul_rn(lx0, v00), __fmul_rn(lx1, v01));
+    const float bot = __fadd_rn(__fmul_rn(lx0, v10), __fmul_rn(lx1, v11));
+    const float u = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+    dmin = fmaxf(__fsub_rn(u, half_range_b[b]), 1e-7f);  // torch.clamp_min (NaN propagates below)
+    if (u != u) dmin = u;
+  }
+  float *op = out + (size_t)b * D * hw + p;
+  for (int k = 0; k < D; ++k) op[(size_t)k * hw] = __fadd_rn(dmin, __fmul_rn(delta, (float)k));
+}
+
+// ---- softmax + regression + confidence ---------------------------------------------------------
+template <int DT>  // DT > 0: D == DT, values cached in registers; DT == 0: generic 3-pass
+__global__ __launch_bounds__(kThreads) void softmax_regress_kernel(
+    const float *__restrict__ cost, const float *__restrict__ dvals, float *__restrict__ depth,
+    float *__restrict__ conf, int32_t *__restrict__ index, int Drt, int hw) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= hw) return;
+  const int D = DT > 0 ? DT : Drt;
+  const float *cp = cost + (size_t)b * D * hw + p;
+  const float *dp = dvals + (size_t)b * D * hw + p;
+  constexpr int NR = DT > 0 ? DT : 1;
+  float e[NR];
+  float mx = -INFINITY;
+  if (DT > 0) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      e[k] = cp[(size_t)k * hw];
+      mx = fmaxf(mx, e[k]);
+    }
+  } else {
+    for (int k = 0; k < D; ++k) mx = fmaxf(mx, cp[(size_t)k * hw]);
+  }
+  // p_k = exp(x_k - max) / sum                                   (F.softmax, mvsnet.py:175)
+  float sum = 0.0f;
+  if (DT > 0) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      e[k] = expf(__fsub_rn(e[k], mx));
+      sum = __fadd_rn(sum, e[k]);
+    }
+  } else {
+    for (int k = 0; k < D; ++k) sum = __fadd_rn(sum, expf(__fsub_rn(cp[(size_t)k * hw], mx)));
+  }
+  // depth = sum_k p_k d_k (modules.py:103); expected index = sum_k p_k k  (mvsnet.py:185-189)
+  float dsum = 0.0f, isum = 0.0f;
+  if (DT > 0) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      e[k] = __fdiv_rn(e[k], sum);
+      dsum = __fadd_rn(dsum, __fmul_rn(e[k], dp[(size_t)k * hw]));
+      isum = __fadd_rn(isum, __fmul_rn(e[k], (float)k));
+    }
+  } else {
+    for (int k = 0; k < D; ++k) {
+      float pk = __fdiv_rn(expf(__fsub_rn(cp[(size_t)k * hw], mx)), sum);
+      dsum = __fadd_rn(dsum, __fmul_rn(pk, dp[(size_t)k * hw]));
+      isum = __fadd_rn(isum, __fmul_rn(pk, (float)k));
+    }
+  }
+  // .long() truncates toward zero; isum >= 0 so this is floor; clamp to [0, D-1] (mvsnet.py:189-190)
+  int idx;
+  if (!(isum == isum)) {
+    idx = 0;  // NaN: torch's float->int64 cast of NaN is INT64_MIN, clamped to 0
+  } else {
+    float cl = fminf(fmaxf(isum, 0.0f), (float)(D - 1));
+    idx = (int)cl;
+  }
+  // confidence = p[idx-1] + p[idx] + p[idx+1] + p[idx+2], zeros outside [0, D) (mvsnet.py:181-193:
+  // 4 * avg_pool3d of the (1, 2)-padded volume, window 4, then gather at idx)
+  float c4 = 0.0f;
+  if (DT > 0) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+      if (k >= idx - 1 && k <= idx + 2) c4 = __fadd_rn(c4, e[k]);
+  } else {
+    for (int k = max(idx - 1, 0); k <= min(idx + 2, D - 1); ++k)
+      c4 = __fadd_rn(c4, __fdiv_rn(expf(__fsub_rn(cp[(size_t)k * hw], mx)), sum));
+  }
+  depth[(size_t)b * hw + p] = dsum;
+  conf[(size_t)b * hw + p] = c4;
+  if (index) index[(size_t)b * hw + p] = idx;
+}
+
+}  // namespace
+
+extern "C" int casmvs_depth_hypotheses_f32(const float *prev_depth, const float *depth_min_b,
+                                           const float *interval_b, const float *half_range_b,
+                                           float *out, int B, int D, int h, int w, int hp, int wp,
+                                           void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(interval_b && out, "depth_hypotheses: null pointer");
+  CASMVS_REQUIRE(B > 0 && B <= 65535 && D > 0 && h > 0 && w > 0, "depth_hypotheses: bad shape B=%d D=%d h=%d w=%d", B, D, h, w);
+  if (prev_depth) {
+    CASMVS_REQUIRE(half_range_b, "depth_hypotheses: half_range_b is required with prev_depth");
+    CASMVS_REQUIRE(hp > 0 && wp > 0, "depth_hypotheses: bad previous shape hp=%d wp=%d", hp, wp);
+  } else {
+    CASMVS_REQUIRE(depth_min_b, "depth_hypotheses: depth_min_b is required without prev_depth");
+  }
+  dim3 grid((unsigned)casmvs::ceil_div(h * w, kThreads), (unsigned)B);
+  hipLaunchKernelGGL(hypotheses_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, prev_depth,
+                     depth_min_b, interval_b, half_range_b, out, D, h, w, hp, wp);
+  return casmvs::check_launch("hypotheses_kernel");
+}
+
+extern "C" int casmvs_softmax_regress_f32(const float *cost, const float *depth_values,
+                                          float *depth, float *confidence, int32_t *index, int B,
+                                          int D, int h, int w, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(cost && depth_values && depth && confidence, "softmax_regress: null pointer");
+  CASMVS_REQUIRE(B > 0 && B <= 65535 && D > 0 && h > 0 && w > 0, "softmax_regress: bad shape B=%d D=%d h=%d w=%d", B, D, h, w);
+  const int hw = h * w;
+  dim3 grid((unsigned)casmvs::ceil_div(hw, kThreads), (unsigned)B), blk(kThreads);
+  hipStream_t st = (hipStream_t)stream;
+#define CASMVS_SR(DT)                                                                            \
+  hipLaunchKernelGGL((softmax_regress_kernel<DT>), grid, blk, 0, st, cost, depth_values, depth, \
+                     confidence, index, D, hw)
+  switch (D) {
+    case 8: CASMVS_SR(8); break;
+    case 16: CASMVS_SR(16); break;
+    case 32: CASMVS_SR(32); break;
+    case 48: CASMVS_SR(48); break;
+    case 64: CASMVS_SR(64); break;
+    default: CASMVS_SR(0); break;
+  }
+#undef CASMVS_SR
+  return casmvs::check_launch("softmax_regress_kernel");
+}

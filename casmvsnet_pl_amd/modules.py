@@ -1,0 +1,70 @@
+"""Host-side mirror of the reference's `models/modules.py` (same names, argument meaning and
+return shapes), with the arithmetic done by the HIP engine through the C ABI.
+
+reference                      here
+modules.py:8-18   ConvBnReLU    parameter container (FeatureNet, PyTorch-ROCm ops)
+modules.py:21-31  ConvBnReLU3D  parameter container (folded into the MFMA conv epilogue)
+modules.py:34-49  get_depth_values  -> casmvs_depth_hypotheses_f32 (on an already-upsampled map)
+modules.py:52-92  homo_warp         -> casmvs_homo_warp_f32
+modules.py:95-104 depth_regression  -> torch reduction (not on the fused hot path: the engine
+                                       fuses softmax + regression in casmvs_softmax_regress_f32)
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .inplace_abn import InPlaceABN
+
+
+class ConvBnReLU(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1, norm_act=InPlaceABN):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = norm_act(out_channels)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+class ConvBnReLU3D(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1, norm_act=InPlaceABN):
+        super().__init__()
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = norm_act(out_channels)
+
+    def forward(self, x):
+        raise RuntimeError("ConvBnReLU3D is executed by the fused MI355X CostRegNet engine "
+                           "(casmvsnet_pl_amd.mvsnet.CostRegNet.forward), not layer by layer")
+
+
+def _per_sample(value, B, device):
+    """float or (B,1)/(B,) tensor -> (B,) float32 device vector."""
+    if isinstance(value, torch.Tensor):
+        return value.reshape(B).to(device=device, dtype=torch.float32)
+    return torch.full((B,), float(value), dtype=torch.float32, device=device)
+
+
+def get_depth_values(current_depth, n_depths, depth_interval):
+    """current_depth (B,1,H,W); depth_interval (B,1) or float -> (B,D,H,W)   (modules.py:34-49)."""
+    B, _, H, W = current_depth.shape
+    dev = current_depth.device
+    if isinstance(depth_interval, torch.Tensor):
+        interval_b = depth_interval.reshape(B).float()
+        half_b = (n_depths / 2) * interval_b
+    else:
+        interval_b = _per_sample(depth_interval, B, dev)
+        half_b = _per_sample(n_depths / 2 * depth_interval, B, dev)  # python-double product, then fp32
+    # prev (B,H,W) with hp == H, wp == W: the align_corners x1 "upsample" is the identity
+    return ops.depth_hypotheses(current_depth.reshape(B, H, W), None, interval_b, half_b, n_depths, H, W)
+
+
+def homo_warp(src_feat, proj_mat, depth_values):
+    """src_feat (B,C,H,W), proj_mat (B,3,4), depth_values (B,D,H,W) -> (B,C,D,H,W)  (modules.py:52-92)."""
+    return ops.homo_warp(src_feat, proj_mat, depth_values)
+
+
+def depth_regression(p, depth_values):
+    """p (B,D,H,W); depth_values (B,D,H,W) or (D) -> (B,H,W)   (modules.py:95-104)."""
+    if depth_values.dim() == 1:
+        depth_values = depth_values.view(1, -1, 1, 1)
+    return (p * depth_values).sum(1).to(depth_values.dtype)

@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference's `models/mvsnet.py`: same classes, constructor arguments,
+attribute names, state-dict keys (206 tensors) and `forward` contract, with the hot path
+(plane-sweep warp, cost volume, CostRegNet, softmax regression) executed by the hand-written
+gfx950 kernels of libcasmvs_hip.so.
+
+reference                                   here
+mvsnet.py:7-57     FeatureNet                same layers, PyTorch-ROCm (MIOpen) ops for now
+mvsnet.py:60-104   CostRegNet                parameter container + casmvs_costreg_forward_f32
+mvsnet.py:125-195  CascadeMVSNet.predict_depth  casmvs_costvol_{var,gwc}_f32 -> CostRegNet ->
+                                             casmvs_softmax_regress_f32
+mvsnet.py:197-244  CascadeMVSNet.forward     same loop; hypotheses by casmvs_depth_hypotheses_f32
+
+The engine is inference-only (eval-mode ABN folded into the conv epilogue, no autograd); calling
+it in training mode or on CPU tensors raises instead of silently falling back.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .inplace_abn import InPlaceABN
+from .modules import ConvBnReLU, ConvBnReLU3D, _per_sample
+
+
+class FeatureNet(nn.Module):
+    """3-level FPN feature extractor (mvsnet.py:7-57)."""
+
+    def __init__(self, norm_act=InPlaceABN):
+        super().__init__()
+        self.conv0 = nn.Sequential(
+            ConvBnReLU(3, 8, 3, 1, 1, norm_act=norm_act),
+            ConvBnReLU(8, 8, 3, 1, 1, norm_act=norm_act))
+        self.conv1 = nn.Sequential(
+            ConvBnReLU(8, 16, 5, 2, 2, norm_act=norm_act),
+            ConvBnReLU(16, 16, 3, 1, 1, norm_act=norm_act),
+            ConvBnReLU(16, 16, 3, 1, 1, norm_act=norm_act))
+        self.conv2 = nn.Sequential(
+            ConvBnReLU(16, 32, 5, 2, 2, norm_act=norm_act),
+            ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act),
+            ConvBnReLU(32, 32, 3, 1, 1, norm_act=norm_act))
+        self.toplayer = nn.Conv2d(32, 32, 1)
+        self.lat1 = nn.Conv2d(16, 32, 1)
+        self.lat0 = nn.Conv2d(8, 32, 1)
+        self.smooth1 = nn.Conv2d(32, 16, 3, padding=1)
+        self.smooth0 = nn.Conv2d(32, 8, 3, padding=1)
+
+    @staticmethod
+    def _upsample_add(x, y):
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) + y
+
+    def forward(self, x):
+        conv0 = self.conv0(x)
+        conv1 = self.conv1(conv0)
+        conv2 = self.conv2(conv1)
+        feat2 = self.toplayer(conv2)
+        feat1 = self._upsample_add(feat2, self.lat1(conv1))
+        feat0 = self._upsample_add(feat1, self.lat0(conv0))
+        feat1 = self.smooth1(feat1)
+        feat0 = self.smooth0(feat0)
+        return {"level_0": feat0, "level_1": feat1, "level_2": feat2}
+
+
+class CostRegNet(nn.Module):
+    """3D U-Net regulariser (mvsnet.py:60-104).  Parameters live in torch modules with the
+    reference's names; `forward` runs the fused MFMA engine on folded, pre-packed weights."""
+
+    # (attribute, kind, has_abn) in the order casmvs_costreg_forward_f32 expects
+    _LAYERS = (("conv0", ops.CONV_S1), ("conv1", ops.CONV_S2), ("conv2", ops.CONV_S1),
+               ("conv3", ops.CONV_S2), ("conv4", ops.CONV_S1), ("conv5", ops.CONV_S2),
+               ("conv6", ops.CONV_S1), ("conv7", ops.CONV_T2), ("conv9", ops.CONV_T2),
+               ("conv11", ops.CONV_T2), ("prob", ops.CONV_S1))
+
+    def __init__(self, in_channels, norm_act=InPlaceABN):
+        super().__init__()
+        self.conv0 = ConvBnReLU3D(in_channels, 8, norm_act=norm_act)
+        self.conv1 = ConvBnReLU3D(8, 16, stride=2, norm_act=norm_act)
+        self.conv2 = ConvBnReLU3D(16, 16, norm_act=norm_act)
+        self.conv3 = ConvBnReLU3D(16, 32, stride=2, norm_act=norm_act)
+        self.conv4 = ConvBnReLU3D(32, 32, norm_act=norm_act)
+        self.conv5 = ConvBnReLU3D(32, 64, stride=2, norm_act=norm_act)
+        self.conv6 = ConvBnReLU3D(64, 64, norm_act=norm_act)
+        self.conv7 = nn.Sequential(
+            nn.ConvTranspose3d(64, 32, 3, padding=1, output_padding=1, stride=2, bias=False),
+            norm_act(32))
+        self.conv9 = nn.Sequential(
+            nn.ConvTranspose3d(32, 16, 3, padding=1, output_padding=1, stride=2, bias=False),
+            norm_act(16))
+        self.conv11 = nn.Sequential(
+            nn.ConvTranspose3d(16, 8, 3, padding=1, output_padding=1, stride=2, bias=False),
+            norm_act(8))
+        self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
+        self._packed = None       # list of 11 device tensors
+        self._packed_key = None
+        self._workspace = None
+
+    # -- weight folding / packing -------------------------------------------------------------
+    def _layer_tensors(self, name):
+        m = getattr(self, name)
+        if name == "prob":
+            return m.weight, None, m.bias
+        if isinstance(m, ConvBnReLU3D):
+            return m.conv.weight, m.bn, None
+        return m[0].weight, m[1], None
+
+    def _cache_key(self, device):
+        key = [str(device)]
+        for _, t in self.state_dict(keep_vars=True).items():
+            key.append((t.data_ptr(), t._version))
+        return tuple(key)
+
+    def packed_layers(self, device):
+        """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
+        key = self._cache_key(device)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        packed, slopes = [], set()
+        for name, kind in self._LAYERS:
+            weight, norm, bias = self._layer_tensors(name)
+            if norm is not None:
+                if not hasattr(norm, "running_mean"):
+                    raise RuntimeError(f"CostRegNet.{name}: norm_act {type(norm).__name__} has no running statistics to fold")
+                if hasattr(norm, "folded_scale_shift"):
+                    scale, shift = norm.folded_scale_shift()
+                else:  # any ABN-like module: weight/bias/running_mean/running_var/eps
+                    var = norm.running_var.detach().double()
+                    scale64 = norm.weight.detach().double() / torch.sqrt(var + norm.eps)
+                    shift = (norm.bias.detach().double() - norm.running_mean.detach().double() * scale64).float().cpu()
+                    scale = scale64.float().cpu()
+                slopes.add(norm.leaky_slope() if hasattr(norm, "leaky_slope") else float(getattr(norm, "activation_param", 0.01)))
+            else:
+                scale, shift = None, bias
+            packed.append(ops.conv3d_pack(kind, weight, scale, shift).to(device))
+        if len(slopes) > 1:
+            raise RuntimeError("CostRegNet: all ABN layers must share one activation slope")
+        self._slope = slopes.pop() if slopes else 0.01
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    def forward(self, x):
+        """x (B, Cin, D, h, w) -> (B, 1, D, h, w)."""
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("casmvsnet_pl_amd.CostRegNet is an inference engine (eval-mode ABN folded into the "
+                               "MFMA conv epilogue); call model.eval() / torch.no_grad(). Training support is the "
+                               "next scope row (SURVEY 8f-2).")
+        B, _, D, h, w = x.shape
+        packed = self.packed_layers(x.device)
+        need = ops.costreg_workspace_bytes(B, D, h, w)
+        ws = self._workspace
+        if ws is None or ws.device != x.device or ws.numel() < need:
+            ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        cost = ops.costreg_forward(packed, x, ws, slope=self._slope)
+        return cost.unsqueeze(1)
+
+
+class CascadeMVSNet(nn.Module):
+    """Cascade MVSNet with the reference's constructor / forward signature (mvsnet.py:107-244)."""
+
+    def __init__(self, n_depths=[8, 32, 48], interval_ratios=[1, 2, 4], num_groups=1, norm_act=InPlaceABN):
+        super().__init__()
+        self.levels = 3
+        self.n_depths = n_depths
+        self.interval_ratios = interval_ratios
+        self.G = num_groups
+        self.feature = FeatureNet(norm_act)
+        for l in range(self.levels):
+            cost_reg_l = CostRegNet(self.G if self.G > 1 else 8 * 2 ** l, norm_act)
+            setattr(self, f"cost_reg_{l}", cost_reg_l)
+
+    def predict_depth(self, feats, proj_mats, depth_values, cost_reg):
+        """feats (B,V,C,h,w), proj_mats (B,V-1,3,4), depth_values (B,D,h,w) -> depth, confidence (B,h,w)."""
+        volume = ops.costvol(feats, proj_mats, depth_values, self.G)        # mvsnet.py:134-172
+        cost = cost_reg(volume).squeeze(1)                                  # mvsnet.py:174
+        depth, confidence = ops.softmax_regress(cost, depth_values)         # mvsnet.py:175-193
+        return depth, confidence
+
+    def forward(self, imgs, proj_mats, init_depth_min, depth_interval):
+        """imgs (B,V,3,H,W); proj_mats (B,V-1,levels,3,4) fine->coarse; init_depth_min,
+        depth_interval: float or (B,1) tensor.  Returns {"depth_l", "confidence_l"} for l in 0..2."""
+        if not imgs.is_cuda:
+            raise RuntimeError("casmvsnet_pl_amd.CascadeMVSNet runs on the MI355X only: move the model and inputs "
+                               "to 'cuda' (ROCm). There is no CPU fallback.")
+        B, V, _, H, W = imgs.shape
+        dev = imgs.device
+        results = {}
+        imgs = imgs.reshape(B * V, 3, H, W).float()
+        proj_mats = proj_mats.float()
+        with torch.no_grad():
+            feats = self.feature(imgs)
+            depth_l = None
+            for l in reversed(range(self.levels)):
+                feats_l = feats[f"level_{l}"]
+                C, h, w = feats_l.shape[1:]
+                feats_l = feats_l.reshape(B, V, C, h, w)
+                proj_mats_l = proj_mats[:, :, l].contiguous()
+                D = self.n_depths[l]
+                ratio = self.interval_ratios[l]
+                if isinstance(depth_interval, torch.Tensor):
+                    interval_b = depth_interval.reshape(B).to(dev, torch.float32) * ratio  # mvsnet.py:211
+                    half_b = (D / 2) * interval_b                                          # modules.py:44
+                else:
+                    depth_interval_l = depth_interval * ratio
+                    interval_b = _per_sample(depth_interval_l, B, dev)
+                    half_b = _per_sample(D / 2 * depth_interval_l, B, dev)
+                if l == self.levels - 1:
+                    depth_values = ops.depth_hypotheses(None, _per_sample(init_depth_min, B, dev), interval_b,
+                                                        None, D, h, w)
+                else:
+                    depth_values = ops.depth_hypotheses(depth_l, None, interval_b, half_b, D, h, w)
+                depth_l, confidence_l = self.predict_depth(feats_l, proj_mats_l, depth_values,
+                                                           getattr(self, f"cost_reg_{l}"))
+                results[f"depth_{l}"] = depth_l
+                results[f"confidence_{l}"] = confidence_l
+        return results

@@ -1,0 +1,183 @@
+"""Tensor-level wrappers over the C ABI (include/casmvs.h): torch is used only for device memory
+and the current HIP stream; every op below is one call into libcasmvs_hip.so.
+
+All inputs must be float32 tensors on a ROCm device ("cuda" in torch); nothing here runs on CPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import CONV_S1, CONV_S2, CONV_T2  # noqa: F401  (re-exported)
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: casmvsnet_pl_amd ops run on the MI355X only (got a {t.device} tensor); "
+                           "there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def homo_warp(src_feat, proj_mat, depth_values):
+    """modules.py:52-92.  (B,C,H,W), (B,3,4), (B,D,H,W) -> (B,C,D,H,W)."""
+    src_feat, proj_mat, depth_values = _dev(src_feat, "src_feat"), _dev(proj_mat, "proj_mat"), _dev(depth_values, "depth_values")
+    B, C, H, W = src_feat.shape
+    D = depth_values.shape[1]
+    if proj_mat.shape != (B, 3, 4) or depth_values.shape != (B, D, H, W):
+        raise ValueError(f"homo_warp: shapes {tuple(src_feat.shape)} {tuple(proj_mat.shape)} {tuple(depth_values.shape)}")
+    out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=src_feat.device)
+    with torch.cuda.device(src_feat.device):
+        rc = _lib.load().casmvs_homo_warp_f32(_ptr(src_feat), _ptr(proj_mat), _ptr(depth_values), _ptr(out),
+                                              B, C, H, W, D, _stream(src_feat))
+    _lib.check(rc, "casmvs_homo_warp_f32")
+    return out
+
+
+def costvol(feats, proj_mats, depth_values, num_groups=1):
+    """Fused plane sweep + aggregation (mvsnet.py:134-172).
+    feats (B,V,C,h,w), proj_mats (B,V-1,3,4), depth_values (B,D,h,w) ->
+    (B,C,D,h,w) variance volume (num_groups == 1) or (B,G,D,h,w) group-wise correlation."""
+    feats, proj_mats, depth_values = _dev(feats, "feats"), _dev(proj_mats, "proj_mats"), _dev(depth_values, "depth_values")
+    B, V, C, h, w = feats.shape
+    D = depth_values.shape[1]
+    if proj_mats.shape != (B, V - 1, 3, 4) or depth_values.shape != (B, D, h, w):
+        raise ValueError(f"costvol: shapes {tuple(feats.shape)} {tuple(proj_mats.shape)} {tuple(depth_values.shape)}")
+    lib = _lib.load()
+    with torch.cuda.device(feats.device):
+        if num_groups == 1:
+            out = torch.empty((B, C, D, h, w), dtype=torch.float32, device=feats.device)
+            rc = lib.casmvs_costvol_var_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(out),
+                                            B, V, C, h, w, D, _stream(feats))
+            _lib.check(rc, "casmvs_costvol_var_f32")
+        else:
+            out = torch.empty((B, num_groups, D, h, w), dtype=torch.float32, device=feats.device)
+            rc = lib.casmvs_costvol_gwc_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(out),
+                                            B, V, C, num_groups, h, w, D, _stream(feats))
+            _lib.check(rc, "casmvs_costvol_gwc_f32")
+    return out
+
+
+def depth_hypotheses(prev_depth, depth_min_b, interval_b, half_range_b, D, h, w):
+    """mvsnet.py:213-235 + modules.py:34-49.  Per-sample (B,) float32 device vectors; prev_depth
+    (B,hp,wp) or None (coarsest level) -> (B,D,h,w)."""
+    interval_b = _dev(interval_b, "interval_b")
+    B = interval_b.shape[0]
+    if prev_depth is not None:
+        prev_depth = _dev(prev_depth, "prev_depth")
+        half_range_b = _dev(half_range_b, "half_range_b")
+        hp, wp = prev_depth.shape[-2:]
+    else:
+        depth_min_b = _dev(depth_min_b, "depth_min_b")
+        hp = wp = 0
+    out = torch.empty((B, D, h, w), dtype=torch.float32, device=interval_b.device)
+    with torch.cuda.device(interval_b.device):
+        rc = _lib.load().casmvs_depth_hypotheses_f32(_ptr(prev_depth), _ptr(depth_min_b), _ptr(interval_b),
+                                                     _ptr(half_range_b), _ptr(out), B, D, h, w, hp, wp,
+                                                     _stream(interval_b))
+    _lib.check(rc, "casmvs_depth_hypotheses_f32")
+    return out
+
+
+def softmax_regress(cost, depth_values, return_index=False):
+    """mvsnet.py:174-193.  cost, depth_values (B,D,h,w) -> depth (B,h,w), confidence (B,h,w)
+    [, index (B,h,w) int32]."""
+    cost, depth_values = _dev(cost, "cost"), _dev(depth_values, "depth_values")
+    if cost.shape != depth_values.shape or cost.dim() != 4:
+        raise ValueError(f"softmax_regress: shapes {tuple(cost.shape)} {tuple(depth_values.shape)}")
+    B, D, h, w = cost.shape
+    depth = torch.empty((B, h, w), dtype=torch.float32, device=cost.device)
+    conf = torch.empty((B, h, w), dtype=torch.float32, device=cost.device)
+    index = torch.empty((B, h, w), dtype=torch.int32, device=cost.device) if return_index else None
+    with torch.cuda.device(cost.device):
+        rc = _lib.load().casmvs_softmax_regress_f32(_ptr(cost), _ptr(depth_values), _ptr(depth), _ptr(conf),
+                                                    _ptr(index), B, D, h, w, _stream(cost))
+    _lib.check(rc, "casmvs_softmax_regress_f32")
+    return (depth, conf, index) if return_index else (depth, conf)
+
+
+def conv3d_pack(kind, weight, scale=None, shift=None):
+    """Host-side packing of one layer (casmvs_conv3d_pack_f32).  CPU tensors in, CPU tensor out."""
+    weight = weight.detach().to("cpu", torch.float32).contiguous()
+    if kind == CONV_T2:
+        cin, cout = weight.shape[:2]
+    else:
+        cout, cin = weight.shape[:2]
+    if tuple(weight.shape[2:]) != (3, 3, 3):
+        raise ValueError(f"conv3d_pack: kernel {tuple(weight.shape[2:])}, only 3x3x3 is supported")
+    lib = _lib.load()
+    n = lib.casmvs_conv3d_packed_floats(kind, cin, cout)
+    if n == 0:
+        raise RuntimeError(f"conv3d_pack: unsupported layer kind={kind} cin={cin} cout={cout}")
+    packed = torch.empty(n, dtype=torch.float32)
+    sc = None if scale is None else scale.detach().to("cpu", torch.float32).contiguous()
+    sh = None if shift is None else shift.detach().to("cpu", torch.float32).contiguous()
+    rc = lib.casmvs_conv3d_pack_f32(kind, cin, cout, _ptr(weight), _ptr(sc), _ptr(sh), _ptr(packed))
+    _lib.check(rc, "casmvs_conv3d_pack_f32")
+    return packed
+
+
+def conv3d_forward(kind, packed, x, cout, skip=None, slope=0.01):
+    """One CostRegNet layer on the matrix cores (casmvs_conv3d_forward_f32)."""
+    x, packed = _dev(x, "x"), _dev(packed, "packed")
+    B, cin, D, H, W = x.shape
+    if kind == CONV_S1:
+        oshape = (B, cout, D, H, W)
+    elif kind == CONV_S2:
+        oshape = (B, cout, D // 2, H // 2, W // 2)
+    else:
+        oshape = (B, cout, 2 * D, 2 * H, 2 * W)
+    if skip is not None:
+        skip = _dev(skip, "skip")
+        if tuple(skip.shape) != oshape:
+            raise ValueError(f"conv3d_forward: skip shape {tuple(skip.shape)} != {oshape}")
+    out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_conv3d_forward_f32(kind, _ptr(packed), _ptr(x), _ptr(skip), _ptr(out), B, cin, cout,
+                                                   D, H, W, float(slope), _stream(x))
+    _lib.check(rc, "casmvs_conv3d_forward_f32")
+    return out
+
+
+def costreg_workspace_bytes(B, D, h, w):
+    n = _lib.load().casmvs_costreg_workspace_bytes(B, D, h, w)
+    if n == 0:
+        raise ValueError(f"CostRegNet: D, h, w must be positive multiples of 8 (got {D}, {h}, {w})")
+    return n
+
+
+def costreg_forward(packed_layers, vol, workspace, slope=0.01):
+    """Whole CostRegNet (mvsnet.py:91-104).  packed_layers: 11 device tensors (conv0..conv6, conv7,
+    conv9, conv11, prob); vol (B,cin,D,h,w) -> cost (B,D,h,w)."""
+    vol = _dev(vol, "vol")
+    B, cin, D, h, w = vol.shape
+    if len(packed_layers) != 11:
+        raise ValueError("costreg_forward: need 11 packed layers")
+    arr = (ctypes.c_void_p * 11)(*[p.data_ptr() for p in packed_layers])
+    cost = torch.empty((B, D, h, w), dtype=torch.float32, device=vol.device)
+    need = costreg_workspace_bytes(B, D, h, w)
+    if workspace.numel() * workspace.element_size() < need:
+        raise ValueError("costreg_forward: workspace too small")
+    with torch.cuda.device(vol.device):
+        rc = _lib.load().casmvs_costreg_forward_f32(arr, _ptr(vol), _ptr(cost), ctypes.c_void_p(workspace.data_ptr()),
+                                                    B, cin, D, h, w, float(slope), _stream(vol))
+    _lib.check(rc, "casmvs_costreg_forward_f32")
+    return cost
+
+
+def selftest_mfma():
+    """MFMA lane-mapping probe; returns the raw (4 variants, 4 regs, 64 lanes) dump."""
+    dump = torch.zeros(16 * 64, dtype=torch.float32)
+    rc = _lib.load().casmvs_selftest_mfma(_ptr(dump))
+    return rc, dump.view(4, 4, 64), _lib.load().casmvs_last_error().decode()

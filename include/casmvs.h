@@ -1,0 +1,163 @@
+/*
+ * casmvs.h - C ABI of libcasmvs_hip.so: the MI355X (gfx950) cascade-MVS depth engine.
+ *
+ * This is the drop-in boundary for the hot path of kwea123/CasMVSNet_pl
+ * (`models/mvsnet.py::CascadeMVSNet.forward` and the `models/modules.py` functions it calls).
+ * The reference has no FFI layer of its own (it is 100 % Python on torch ops), so every entry
+ * point below names the reference function (file:line under /root/reference) it replaces; the
+ * Python host side (`casmvsnet_pl_amd/`) binds them with ctypes and mirrors the reference's
+ * Python API on top.
+ *
+ * Conventions (all entry points):
+ *   - return 0 (CASMVS_OK) or a negative CASMVS_ERR_* code; never throw across the ABI.
+ *     `casmvs_last_error()` returns a thread-local human readable message for the last failure.
+ *   - every tensor is fp32, contiguous, row-major in the reference's own layout (NCHW / NCDHW).
+ *   - the CALLER owns every buffer (inputs, outputs, workspace, packed weights).  The library
+ *     allocates no device memory and keeps no pointer after return.
+ *   - device pointers are raw `hipDeviceptr`-style `float*` on the calling thread's current
+ *     device; `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).
+ *   - fully asynchronous on `stream`: no internal synchronisation, re-entrant, no global mutable
+ *     state.  Inputs are `const`; outputs must not alias inputs.
+ *   - built with `hipcc --offload-arch=gfx950` only.  No CPU fallback exists: on a machine
+ *     without a gfx950 device the launch entry points fail with CASMVS_ERR_HIP.
+ */
+#ifndef CASMVS_H
+#define CASMVS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CASMVS_ABI_VERSION 1
+
+#define CASMVS_OK 0
+#define CASMVS_ERR_INVALID_ARG (-1) /* null pointer / non-positive size / unsupported combination */
+#define CASMVS_ERR_UNSUPPORTED (-2) /* shape outside what the kernels were built for             */
+#define CASMVS_ERR_HIP (-3)         /* HIP runtime / launch error (message has hipGetErrorString) */
+
+/* ---- housekeeping ------------------------------------------------------------------------ */
+
+/* ABI version of the loaded library (== CASMVS_ABI_VERSION of the header it was built with). */
+int casmvs_abi_version(void);
+
+/* Thread-local message describing the last non-zero return on this thread ("" if none). */
+const char *casmvs_last_error(void);
+
+/* ---- (a3)/(a4) depth hypotheses ------------------------------------------------------------
+ * Replaces: models/mvsnet.py:213-229 (coarsest level: d_k = init_depth_min + k*interval) and
+ *           models/mvsnet.py:231-235 + models/modules.py:34-49 (finer levels: bilinear x2
+ *           upsample of the previous depth with align_corners=True, then
+ *           d_min = max(u - half_range, 1e-7), d_k = d_min + k*interval).
+ *
+ * prev_depth  : device (B, hp, wp) previous-level depth, or NULL for the coarsest level.
+ * depth_min_b : device (B) per-sample init_depth_min (used only when prev_depth == NULL).
+ * interval_b  : device (B) per-sample depth interval of THIS level (depth_interval*ratio[l]).
+ * half_range_b: device (B) per-sample (n_depths/2)*interval (used only when prev_depth != NULL).
+ * out         : device (B, D, h, w).  When prev_depth != NULL, (h, w) is the x2 grid of
+ *               (hp, wp) in the reference; any h >= 2, w >= 2 works (ATen align_corners rule).
+ */
+int casmvs_depth_hypotheses_f32(const float *prev_depth, const float *depth_min_b,
+                                const float *interval_b, const float *half_range_b, float *out,
+                                int B, int D, int h, int w, int hp, int wp, void *stream);
+
+/* ---- (a5) homo_warp ------------------------------------------------------------------------
+ * Replaces: models/modules.py:52-92 `homo_warp(src_feat, proj_mat, depth_values)`.
+ * src   : device (B, C, H, W)     source-view feature map
+ * proj  : device (B, 3, 4)        (P_src @ inv(P_ref))[:3]
+ * depth : device (B, D, H, W)     per-pixel depth hypotheses of the reference view
+ * out   : device (B, C, D, H, W)  warped source volume (bilinear, zeros padding, align_corners)
+ */
+int casmvs_homo_warp_f32(const float *src, const float *proj, const float *depth, float *out,
+                         int B, int C, int H, int W, int D, void *stream);
+
+/* ---- (a5)+(a6) fused plane sweep + variance cost volume ------------------------------------
+ * Replaces: models/mvsnet.py:134-168 for G == 1 (ref broadcast, the V-1 homo_warp calls, the
+ *           sum / sum-of-squares accumulation and `var = sq/V - (sum/V)^2`), without ever
+ *           materialising a warped volume.
+ * feats : device (B, V, C, h, w)   view 0 is the reference view
+ * proj  : device (B, V-1, 3, 4)
+ * depth : device (B, D, h, w)
+ * out   : device (B, C, D, h, w)
+ */
+int casmvs_costvol_var_f32(const float *feats, const float *proj, const float *depth, float *out,
+                           int B, int V, int C, int h, int w, int D, void *stream);
+
+/* ---- (a5)+(a7) fused plane sweep + group-wise correlation cost volume ----------------------
+ * Replaces: models/mvsnet.py:142-144,157-162,169-172 for G > 1.
+ * out   : device (B, G, D, h, w); channels are split contiguously C -> (G, C/G).
+ * Supported: C in {8, 16, 32}, G divides C.
+ */
+int casmvs_costvol_gwc_f32(const float *feats, const float *proj, const float *depth, float *out,
+                           int B, int V, int C, int G, int h, int w, int D, void *stream);
+
+/* ---- (a8) CostRegNet 3D convolutions (fp32 MFMA) -------------------------------------------
+ * Replaces: models/mvsnet.py:60-104 `CostRegNet` and models/modules.py:21-31 `ConvBnReLU3D`
+ *           (nn.Conv3d / nn.ConvTranspose3d, k=3, pad=1, followed by eval-mode ABN =
+ *           BatchNorm(running stats) + leaky_relu, optionally followed by a skip add).
+ *
+ * Layer kinds.  Every kind computes
+ *      y = lrelu_slope( conv(x) * scale[co] + shift[co] ) (+ skip)
+ * where (scale, shift) is the folded eval-mode ABN (or scale = 1, shift = bias for `prob`).
+ */
+#define CASMVS_CONV_S1 0     /* Conv3d k3 s1 p1              : (B,Cin,D,H,W) -> (B,Cout,D,H,W)       */
+#define CASMVS_CONV_S2 1     /* Conv3d k3 s2 p1              : (B,Cin,D,H,W) -> (B,Cout,D/2,H/2,W/2) */
+#define CASMVS_CONV_T2 2     /* ConvTranspose3d k3 s2 p1 op1 : (B,Cin,D,H,W) -> (B,Cout,2D,2H,2W)    */
+
+/* Number of floats of the packed (device-layout) image of one layer's parameters. */
+size_t casmvs_conv3d_packed_floats(int kind, int cin, int cout);
+
+/* HOST-side packing of one layer (pure CPU, no HIP calls): permutes the torch-layout weight into
+ * the MFMA A-operand images the kernels stream, and appends scale[cout], shift[cout].
+ * weight : host; Conv3d (cout, cin, 3,3,3) for S1/S2, ConvTranspose3d (cin, cout, 3,3,3) for T2
+ * scale, shift : host (cout) or NULL (=> 1 and 0)
+ * packed : host, casmvs_conv3d_packed_floats(kind, cin, cout) floats
+ */
+int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *weight, const float *scale,
+                           const float *shift, float *packed);
+
+/* One layer.  `packed` is the device copy of the image produced by casmvs_conv3d_pack_f32.
+ * in   : device (B, cin, D, H, W);  skip : device, shape of out, or NULL;  out : device.
+ * D, H, W are the INPUT dims.  For S2 they must be even.
+ * slope: leaky-relu negative slope (0.01 for ABN, 1.0 for no activation).
+ * Supported cout: S1 {1, 8, 16, 32, 64}; S2 {16, 32, 64}; T2 {8, 16, 32}.  Any cin >= 1.
+ */
+int casmvs_conv3d_forward_f32(int kind, const float *packed, const float *in, const float *skip,
+                              float *out, int B, int cin, int cout, int D, int H, int W,
+                              float slope, void *stream);
+
+/* Whole CostRegNet (mvsnet.py:91-104).  `packed_layers[11]` are the device images of
+ * conv0..conv6, conv7, conv9, conv11, prob (in that order).  `workspace` holds the intermediate
+ * activations; its size comes from casmvs_costreg_workspace_bytes.
+ * vol : device (B, cin, D, h, w)  ->  cost : device (B, D, h, w)   (the `prob` head, 1 channel)
+ * D, h, w must be divisible by 8.  slope: leaky-relu slope of every ABN (0.01 in the reference).
+ */
+size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w);
+int casmvs_costreg_forward_f32(const float *const *packed_layers, const float *vol, float *cost,
+                               void *workspace, int B, int cin, int D, int h, int w, float slope,
+                               void *stream);
+
+/* ---- (a9) softmax over depth + soft-argmin regression + confidence --------------------------
+ * Replaces: models/mvsnet.py:174-193 and models/modules.py:95-104:
+ *   p = softmax_D(cost); depth = sum_k p_k d_k; idx = clamp(trunc(sum_k p_k k), 0, D-1);
+ *   confidence = p[idx-1] + p[idx] + p[idx+1] + p[idx+2]  (zeros outside [0, D)).
+ * cost, depth_values : device (B, D, h, w);  depth, confidence : device (B, h, w)
+ * index : device (B, h, w) int32 or NULL (optional debug/parity output of idx).
+ */
+int casmvs_softmax_regress_f32(const float *cost, const float *depth_values, float *depth,
+                               float *confidence, int32_t *index, int B, int D, int h, int w,
+                               void *stream);
+
+/* ---- self test ------------------------------------------------------------------------------
+ * Runs the MFMA lane-mapping probe the conv kernels rely on (v_mfma_f32_4x4x1_16b_f32 with
+ * A-block broadcast).  Returns 0 when the hardware semantics match the kernels' assumptions.
+ * Needs a gfx950 device.  `dump` (host, 64*4*4 floats, may be NULL) receives raw probe outputs.
+ */
+int casmvs_selftest_mfma(float *dump);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASMVS_H */

@@ -1,0 +1,86 @@
+"""CPU tests that pin the oracle (oracle/cpu_restatement.py):
+  * against the committed golden fixtures = outputs of the REAL reference (oracle/make_golden.py),
+  * against the live reference when /root/reference is present (build container only),
+  * self-tests of documented semantics (identity homography, negative depth, sum4 window).
+"""
+import pytest
+import torch
+
+from oracle import cpu_restatement as R
+from oracle.reference_loader import build_reference_model, reference_available
+from util import GOLDEN_CASES, Golden, max_abs, rel_err, scaled_err
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_restatement_matches_golden_end_to_end(case):
+    g = Golden(case)
+    imgs, proj = g.inputs()
+    res, inter = R.cascade_forward(g.state_dict(), imgs, proj, g.init_depth_min, g.depth_interval, g.n_depths,
+                                   g.interval_ratios, g.G, return_intermediates=True)
+    for l in (2, 1, 0):
+        # same torch ops in the same order on the same machine class: (near) bit-exact
+        assert max_abs(inter[f"depth_values_{l}"], g.t(f"depth_values_{l}")) == 0.0
+        assert scaled_err(inter[f"cost_{l}"], g.t(f"cost_{l}")) < 1e-5
+        assert rel_err(res[f"depth_{l}"], g.t(f"depth_{l}")) < 1e-5
+        assert max_abs(res[f"confidence_{l}"], g.t(f"confidence_{l}")) < 1e-4
+        if g.has(f"volume_{l}"):
+            assert scaled_err(inter[f"volume_{l}"], g.t(f"volume_{l}")) < 1e-6
+
+
+@pytest.mark.parametrize("case", [c for c in GOLDEN_CASES if Golden(c).has("warp_2_v1")])
+def test_restated_homo_warp_matches_golden(case):
+    g = Golden(case)
+    imgs, proj = g.inputs()
+    sd = g.state_dict()
+    feats = R.feature_net(imgs.reshape(g.V, 3, g.H, g.W), sd)["level_2"]
+    warped = R.homo_warp(feats[1:2], proj[:, 0, 2], g.t("depth_values_2"))
+    assert scaled_err(warped, g.t("warp_2_v1")) < 1e-6
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("G,V,geometry", [(1, 3, "dtu"), (8, 3, "dtu"), (1, 4, "random"), (2, 2, "dtu")])
+def test_restatement_matches_live_reference(G, V, geometry):
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet
+    from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
+    sd = randomize_state_dict(CascadeMVSNet(num_groups=G, norm_act=ABN).state_dict(), seed=7 + G)
+    imgs, proj, dmin, dint = make_inputs(2, V, 32, 32, seed=3, geometry=geometry)
+    ref = build_reference_model([8, 32, 48], [1.0, 2.0, 4.0], G, sd)
+    # tensor-valued depth range, as the DataLoader collates it (dtu.py:177,190 -> (B,1))
+    dmin_t = torch.tensor([[dmin], [dmin + 30.0]])
+    dint_t = torch.tensor([[dint], [dint * 0.8]])
+    with torch.no_grad():
+        want = ref(imgs, proj, dmin_t, dint_t)
+    got = R.cascade_forward(sd, imgs, proj, dmin_t, dint_t, (8, 32, 48), (1.0, 2.0, 4.0), G)
+    for k in want:
+        assert rel_err(got[k], want[k]) < 1e-5 if k.startswith("depth") else max_abs(got[k], want[k]) < 1e-4, k
+
+
+def test_identity_homography_returns_input():
+    torch.manual_seed(0)
+    src = torch.randn(1, 4, 12, 20)
+    P = torch.eye(4)[:3].unsqueeze(0)
+    depth = torch.rand(1, 3, 12, 20) + 1.0
+    out = R.homo_warp(src, P, depth)
+    assert max_abs(out, src.unsqueeze(2).expand_as(out)) < 2e-5  # coordinate round-trip noise x feature gradient
+
+
+def test_negative_depth_plane_is_all_zero():
+    src = torch.ones(1, 2, 8, 8)
+    P = torch.eye(4)[:3].unsqueeze(0).clone()
+    P[0, 2, 2] = -1.0  # q_z = -1 <= 1e-7 everywhere -> forced to (W, H, 1) -> all taps out of range
+    out = R.homo_warp(src, P, torch.ones(1, 2, 8, 8))
+    assert float(out.abs().max()) == 0.0
+
+
+def test_sum4_window_and_index():
+    D = 8
+    p = torch.arange(1, D + 1, dtype=torch.float32)
+    cost = torch.log(p / p.sum()).reshape(1, D, 1, 1)
+    dv = torch.arange(D, dtype=torch.float32).reshape(1, D, 1, 1) * 2.0 + 10.0
+    depth, conf, idx = R.softmax_regress(cost, dv)
+    e = float((p / p.sum() * torch.arange(D)).sum())
+    assert int(idx) == int(e)
+    i = int(idx)
+    want = sum(float(p[k]) for k in range(i - 1, i + 3) if 0 <= k < D) / float(p.sum())
+    assert abs(float(conf) - want) < 1e-6
+    assert abs(float(depth) - (10.0 + 2.0 * e)) < 1e-4

@@ -1,0 +1,67 @@
+"""Shared helpers of the test-suite: golden fixtures + bit-identical regeneration of their inputs."""
+import os
+
+import numpy as np
+import torch
+
+from casmvsnet_pl_amd import ABN, CascadeMVSNet
+from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict, tensor_checksum
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+class Golden:
+    """One fixture written by oracle/make_golden.py (outputs of the real reference)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.H, self.W, self.V, self.G = (int(x) for x in self.z["meta_hwvg"])
+        self.seed, self.wseed = (int(x) for x in self.z["meta_seeds"])
+        self.geometry = str(self.z["meta_geometry"])
+        self.n_depths = [int(x) for x in self.z["meta_n_depths"]]
+        self.interval_ratios = [float(x) for x in self.z["meta_interval_ratios"]]
+        self.init_depth_min, self.depth_interval = (float(x) for x in self.z["meta_depth"])
+        self.prob_gain = tuple(float(x) for x in self.z["meta_prob_gain"])
+
+    def has(self, key):
+        return key in self.z.files
+
+    def t(self, key):
+        return torch.from_numpy(self.z[key])
+
+    def inputs(self):
+        imgs, proj, _, _ = make_inputs(1, self.V, self.H, self.W, seed=self.seed, geometry=self.geometry)
+        assert tensor_checksum(imgs) == float(self.z["chk_imgs"]), "regenerated images drifted from the fixture"
+        assert tensor_checksum(proj) == float(self.z["chk_proj"]), "regenerated proj_mats drifted from the fixture"
+        return imgs, proj
+
+    def state_dict(self):
+        sd = CascadeMVSNet(n_depths=self.n_depths, num_groups=self.G, norm_act=ABN).state_dict()
+        randomize_state_dict(sd, self.wseed, prob_gain=self.prob_gain)
+        chk = sum(tensor_checksum(v) for v in sd.values())
+        assert chk == float(self.z["chk_weights"]), "regenerated weights drifted from the fixture"
+        return sd
+
+    def model(self, device="cpu"):
+        m = CascadeMVSNet(n_depths=self.n_depths, interval_ratios=self.interval_ratios, num_groups=self.G, norm_act=ABN)
+        m.load_state_dict(self.state_dict())
+        return m.to(device).eval()
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|, tiny) over finite entries (float64)."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return float(((a - b).abs() / b.abs().clamp_min(1e-6)).max())
+
+
+def max_abs(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+def scaled_err(a, b):
+    """max |a-b| / max|b|: error relative to the tensor's dynamic range."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
