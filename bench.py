@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: depth-maps/sec of CascadeMVSNet.forward on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward pass (FeatureNet + 3 cascade levels) over one reference view with its
+source views: DTU 640x512, 3 views, n_depths [8,32,48], variance cost volume, fp32, synthetic
+inputs already resident in HBM, random-init weights.  With N GPUs every rank processes its own
+depth maps (the path shards at depth-map granularity, SURVEY 8e: no data-path collective) ->
+weak scaling; value = depth maps all ranks produced / max-over-ranks wall time.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events recorded on the
+launch stream inside the timed region; `cpu_baseline` is the oracle (a CPU port of the
+reference's forward, oracle/cpu_restatement.py) timed on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from casmvsnet_pl_amd import ABN, CascadeMVSNet  # noqa: E402
+from casmvsnet_pl_amd.profiling import StageTimer  # noqa: E402
+from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA dense peak (MI355X_MICROARCH.md)
+
+CONFIGS = {
+    # name: (H, W, V, num_groups, n_depths, interval_ratios)
+    "dtu_640x512_v3_var": (512, 640, 3, 1, (8, 32, 48), (1.0, 2.0, 4.0)),
+    "dtu_640x512_v3_gwc8": (512, 640, 3, 8, (8, 32, 48), (1.0, 2.0, 4.0)),
+    "dtu_1152x864_v5_var": (864, 1152, 5, 1, (8, 32, 48), (1.0, 2.0, 4.0)),
+    "blended_768x576_v7_var": (576, 768, 7, 1, (8, 32, 48), (1.0, 2.0, 4.0)),
+}
+LAYER_NAMES = ["conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11", "prob"]
+
+
+def algorithmic_work(H, W, V, G, n_depths, B=1):
+    """Per-depth-map algorithmic bytes / FLOPs, per level."""
+    work = {}
+    for l in range(3):
+        C, D = 8 * 2 ** l, n_depths[l]
+        h, w = H // 2 ** l, W // 2 ** l
+        n = D * h * w
+        cin = G if G > 1 else C
+        cout_vol = G if G > 1 else C
+        work[l] = {
+            "costvol_bytes": 4 * B * (V * C * h * w + D * h * w + cout_vol * n),
+            "softmax_bytes": 4 * B * (2 * n + 2 * h * w),
+            "conv0_flops": 2 * 27 * cin * 8 * n * B,
+            "costreg_flops": (2 * 27 * cin * 8 + 6480) * n * B,
+        }
+    return work
+
+
+def cpu_baseline(cfg_name, repeats=3):
+    """Oracle (CPU port of the reference forward) on the same synthetic workload, host cores."""
+    from oracle import cpu_restatement as R
+    H, W, V, G, n_depths, ratios = CONFIGS[cfg_name]
+    model = CascadeMVSNet(n_depths=list(n_depths), interval_ratios=list(ratios), num_groups=G, norm_act=ABN)
+    sd = randomize_state_dict(model.state_dict(), seed=0)
+    imgs, proj, dmin, dint = make_inputs(1, V, H, W, seed=0)
+    R.cascade_forward(sd, imgs, proj, dmin, dint, n_depths, ratios, G)  # warm-up
+    times = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        R.cascade_forward(sd, imgs, proj, dmin, dint, n_depths, ratios, G)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "depth-maps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{repeats} timed forwards (median {med:.3f} s) of the same {cfg_name} workload after 1 warm-up, "
+                      f"torch CPU fp32, {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="dtu_640x512_v3_var", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=1, help="depth maps per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    H, W, V, G, n_depths, ratios = CONFIGS[args.config]
+    B = args.batch
+    model = CascadeMVSNet(n_depths=list(n_depths), interval_ratios=list(ratios), num_groups=G, norm_act=ABN)
+    randomize_state_dict(model.state_dict(), seed=0)
+    model = model.to(dev).eval()
+    # every rank works on its own depth maps (different seeds -> different images / cameras)
+    imgs, proj, dmin, dint = make_inputs(B, V, H, W, seed=rank)
+    imgs, proj = imgs.to(dev), proj.to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model(imgs, proj, dmin, dint)
+    timer = None if args.no_events else StageTimer()
+    model.set_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model(imgs, proj, dmin, dint)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    assert torch.isfinite(out["depth_0"]).all()
+
+    if rank == 0:
+        K = args.steps
+        value = world * B * K / elapsed
+        line = {
+            "metric": "depth-maps/sec at 640x512, 3 views, n_depths=[8,32,48]" if args.config == "dtu_640x512_v3_var"
+                      else f"depth-maps/sec ({args.config})",
+            "value": value, "unit": "depth-maps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.config, "H": H, "W": W, "views": V, "n_depths": list(n_depths),
+                       "interval_ratios": list(ratios), "num_groups": G, "depth_maps_per_step_per_gpu": B,
+                       "parallelism": f"replica x{world} (one depth map stream per GPU, no data-path collective)",
+                       "feature_net": "PyTorch-ROCm ops (outside the north_star kernel list)"},
+        }
+        if timer is not None:
+            summ = timer.summary(LAYER_NAMES)
+            work = algorithmic_work(H, W, V, G, n_depths, B)
+            per_step = {k: v["ms"] / K for k, v in summ.items()}
+            # dominant kernel: conv3d_kernel<S1, Cout 8> = CostRegNet.conv0 (3 launches per depth map)
+            conv0_ms = sum(summ[f"costreg_{l}/conv0"]["ms"] for l in range(3))
+            conv0_flops = sum(work[l]["conv0_flops"] for l in range(3)) * K
+            ach = conv0_flops / (conv0_ms * 1e-3) / 1e12
+            line["roofline"] = {"kernel": "conv3d_kernel<stride 1, Cout 8> (CostRegNet.conv0, 3 launches per depth map)",
+                                "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                                "avg_launch_ms": conv0_ms / (3 * K)}
+            cr_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("costreg_"))
+            cr_flops = sum(work[l]["costreg_flops"] for l in range(3)) * K
+            line["roofline_costreg"] = {"kernel": "all 33 CostRegNet launches", "bound": "mfma",
+                                        "achieved": cr_flops / (cr_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": cr_flops / (cr_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                        "ms_per_depth_map": cr_ms / K / B}
+            cv_ms = sum(summ[f"costvol_{l}"]["ms"] for l in range(3))
+            cv_bytes = sum(work[l]["costvol_bytes"] for l in range(3)) * K
+            line["roofline_costvol"] = {"kernel": "costvol_kernel (fused homo_warp + aggregation, 3 launches)",
+                                        "bound": "hbm", "achieved": cv_bytes / (cv_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": cv_bytes / (cv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "traffic": None, "ms_per_depth_map": cv_ms / K / B,
+                                        "per_level_frac": {str(l): work[l]["costvol_bytes"] * K / (summ[f"costvol_{l}"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS for l in range(3)}}
+            sm_ms = sum(summ[f"softmax_{l}"]["ms"] for l in range(3))
+            sm_bytes = sum(work[l]["softmax_bytes"] for l in range(3)) * K
+            line["roofline_softmax"] = {"kernel": "softmax_regress_kernel (3 launches)", "bound": "hbm",
+                                        "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            line["stage_ms_per_step"] = {k: round(v, 4) for k, v in per_step.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -471,7 +471,8 @@ extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
 
 extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, const float *vol,
                                           float *cost, void *workspace, int B, int cin, int D,
-                                          int h, int w, float slope, void *stream) {
+                                          int h, int w, float slope, void *const *layer_events,
+                                          void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(packed_layers && vol && cost && workspace, "costreg_forward: null pointer");
   CASMVS_REQUIRE(B > 0 && cin > 0 && D > 0 && h > 0 && w > 0 && D % 8 == 0 && h % 8 == 0 && w % 8 == 0,
@@ -492,8 +493,11 @@ extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, con
   const float sl = slope;  // ABN leaky_relu slope (activation_param, 0.01 in the reference)
   const float *const *P = packed_layers;
   int rc;
-#define CASMVS_L(...)                      \
-  rc = casmvs_conv3d_forward_f32(__VA_ARGS__); \
+  int li = 0;
+#define CASMVS_L(...)                                                                          \
+  if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);   \
+  ++li;                                                                                        \
+  rc = casmvs_conv3d_forward_f32(__VA_ARGS__);                                                 \
   if (rc != CASMVS_OK) return rc
   CASMVS_L(CASMVS_CONV_S1, P[0], vol, nullptr, c0, B, cin, 8, D, h, w, sl, stream);                 // conv0
   CASMVS_L(CASMVS_CONV_S2, P[1], c0, nullptr, c1, B, 8, 16, D, h, w, sl, stream);                   // conv1
@@ -507,6 +511,7 @@ extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, con
   CASMVS_L(CASMVS_CONV_T2, P[9], u9, c0, u11, B, 16, 8, D / 2, h / 2, w / 2, sl, stream);           // conv0 + conv11
   CASMVS_L(CASMVS_CONV_S1, P[10], u11, nullptr, cost, B, 8, 1, D, h, w, 1.0f, stream);              // prob
 #undef CASMVS_L
+  if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[11], (hipStream_t)stream);
   return CASMVS_OK;
 }
 
@@ -518,7 +523,7 @@ extern "C" int casmvs_selftest_mfma(float *dump) {
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, 0, d);
   float h[16 * 64];
   hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-  hipFree(d);
+  (void)hipFree(d);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "selftest: %s", hipGetErrorString(e));
   if (dump)
     for (int i = 0; i < 16 * 64; ++i) dump[i] = h[i];

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from . import ops
 from .inplace_abn import InPlaceABN
 from .modules import ConvBnReLU, ConvBnReLU3D, _per_sample
+from .profiling import stage
 
 
 class FeatureNet(nn.Module):
@@ -92,6 +93,8 @@ class CostRegNet(nn.Module):
         self._packed = None       # list of 11 device tensors
         self._packed_key = None
         self._workspace = None
+        self.timer = None         # optional profiling.StageTimer (bench.py)
+        self.timer_name = "costreg"
 
     # -- weight folding / packing -------------------------------------------------------------
     def _layer_tensors(self, name):
@@ -148,7 +151,8 @@ class CostRegNet(nn.Module):
         ws = self._workspace
         if ws is None or ws.device != x.device or ws.numel() < need:
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
-        cost = ops.costreg_forward(packed, x, ws, slope=self._slope)
+        events = self.timer.layer_events(self.timer_name) if self.timer is not None else None
+        cost = ops.costreg_forward(packed, x, ws, slope=self._slope, layer_events=events)
         return cost.unsqueeze(1)
 
 
@@ -165,12 +169,28 @@ class CascadeMVSNet(nn.Module):
         for l in range(self.levels):
             cost_reg_l = CostRegNet(self.G if self.G > 1 else 8 * 2 ** l, norm_act)
             setattr(self, f"cost_reg_{l}", cost_reg_l)
+        self.timer = None        # optional profiling.StageTimer: HIP events around every stage
+        self.last_index = {}     # level -> (B,h,w) int32 depth index, filled when keep_index is set
+        self.keep_index = False
 
-    def predict_depth(self, feats, proj_mats, depth_values, cost_reg):
+    def set_timer(self, timer):
+        self.timer = timer
+        for l in range(self.levels):
+            m = getattr(self, f"cost_reg_{l}")
+            m.timer, m.timer_name = timer, f"costreg_{l}"
+
+    def predict_depth(self, feats, proj_mats, depth_values, cost_reg, level=None):
         """feats (B,V,C,h,w), proj_mats (B,V-1,3,4), depth_values (B,D,h,w) -> depth, confidence (B,h,w)."""
-        volume = ops.costvol(feats, proj_mats, depth_values, self.G)        # mvsnet.py:134-172
+        t = self.timer
+        with stage(t, f"costvol_{level}"):
+            volume = ops.costvol(feats, proj_mats, depth_values, self.G)    # mvsnet.py:134-172
         cost = cost_reg(volume).squeeze(1)                                  # mvsnet.py:174
-        depth, confidence = ops.softmax_regress(cost, depth_values)         # mvsnet.py:175-193
+        with stage(t, f"softmax_{level}"):
+            if self.keep_index:
+                depth, confidence, index = ops.softmax_regress(cost, depth_values, return_index=True)
+                self.last_index[level] = index
+            else:
+                depth, confidence = ops.softmax_regress(cost, depth_values)  # mvsnet.py:175-193
         return depth, confidence
 
     def forward(self, imgs, proj_mats, init_depth_min, depth_interval):
@@ -184,8 +204,10 @@ class CascadeMVSNet(nn.Module):
         results = {}
         imgs = imgs.reshape(B * V, 3, H, W).float()
         proj_mats = proj_mats.float()
+        t = self.timer
         with torch.no_grad():
-            feats = self.feature(imgs)
+            with stage(t, "feature"):
+                feats = self.feature(imgs)
             depth_l = None
             for l in reversed(range(self.levels)):
                 feats_l = feats[f"level_{l}"]
@@ -201,13 +223,14 @@ class CascadeMVSNet(nn.Module):
                     depth_interval_l = depth_interval * ratio
                     interval_b = _per_sample(depth_interval_l, B, dev)
                     half_b = _per_sample(D / 2 * depth_interval_l, B, dev)
-                if l == self.levels - 1:
-                    depth_values = ops.depth_hypotheses(None, _per_sample(init_depth_min, B, dev), interval_b,
-                                                        None, D, h, w)
-                else:
-                    depth_values = ops.depth_hypotheses(depth_l, None, interval_b, half_b, D, h, w)
+                with stage(t, f"hypotheses_{l}"):
+                    if l == self.levels - 1:
+                        depth_values = ops.depth_hypotheses(None, _per_sample(init_depth_min, B, dev), interval_b,
+                                                            None, D, h, w)
+                    else:
+                        depth_values = ops.depth_hypotheses(depth_l, None, interval_b, half_b, D, h, w)
                 depth_l, confidence_l = self.predict_depth(feats_l, proj_mats_l, depth_values,
-                                                           getattr(self, f"cost_reg_{l}"))
+                                                           getattr(self, f"cost_reg_{l}"), level=l)
                 results[f"depth_{l}"] = depth_l
                 results[f"confidence_{l}"] = confidence_l
         return results

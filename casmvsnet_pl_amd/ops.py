@@ -157,9 +157,10 @@ def costreg_workspace_bytes(B, D, h, w):
     return n
 
 
-def costreg_forward(packed_layers, vol, workspace, slope=0.01):
+def costreg_forward(packed_layers, vol, workspace, slope=0.01, layer_events=None):
     """Whole CostRegNet (mvsnet.py:91-104).  packed_layers: 11 device tensors (conv0..conv6, conv7,
-    conv9, conv11, prob); vol (B,cin,D,h,w) -> cost (B,D,h,w)."""
+    conv9, conv11, prob); vol (B,cin,D,h,w) -> cost (B,D,h,w).  layer_events: optional list of 12
+    already-created torch.cuda.Event(enable_timing=True) recorded around the 11 launches."""
     vol = _dev(vol, "vol")
     B, cin, D, h, w = vol.shape
     if len(packed_layers) != 11:
@@ -169,9 +170,14 @@ def costreg_forward(packed_layers, vol, workspace, slope=0.01):
     need = costreg_workspace_bytes(B, D, h, w)
     if workspace.numel() * workspace.element_size() < need:
         raise ValueError("costreg_forward: workspace too small")
+    ev = None
+    if layer_events is not None:
+        if len(layer_events) != 12:
+            raise ValueError("costreg_forward: need 12 events")
+        ev = (ctypes.c_void_p * 12)(*[e.cuda_event for e in layer_events])
     with torch.cuda.device(vol.device):
         rc = _lib.load().casmvs_costreg_forward_f32(arr, _ptr(vol), _ptr(cost), ctypes.c_void_p(workspace.data_ptr()),
-                                                    B, cin, D, h, w, float(slope), _stream(vol))
+                                                    B, cin, D, h, w, float(slope), ev, _stream(vol))
     _lib.check(rc, "casmvs_costreg_forward_f32")
     return cost
 

@@ -1,0 +1,57 @@
+"""HIP-event stage timer used by bench.py: records events on torch's current stream (the stream
+every kernel of the engine is launched on) around each stage / kernel of a forward pass, without
+any synchronisation inside the timed region.  `summary()` synchronises once at the end."""
+import contextlib
+from collections import OrderedDict
+
+import torch
+
+
+class StageTimer:
+    def __init__(self):
+        self._ranges = []        # (name, start, end)
+        self._layer_sets = []    # (name, [12 events])
+
+    @contextlib.contextmanager
+    def range(self, name):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        try:
+            yield
+        finally:
+            e.record()
+            self._ranges.append((name, s, e))
+
+    def layer_events(self, name, n=12):
+        """n events whose hipEvent_t handles exist (torch creates them lazily on first record)."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for ev in evs:
+            ev.record()
+        self._layer_sets.append((name, evs))
+        return evs
+
+    def summary(self, layer_names=None):
+        """-> OrderedDict name -> {"ms": total, "calls": n}."""
+        torch.cuda.synchronize()
+        out = OrderedDict()
+
+        def add(name, ms):
+            d = out.setdefault(name, {"ms": 0.0, "calls": 0})
+            d["ms"] += ms
+            d["calls"] += 1
+        for name, s, e in self._ranges:
+            add(name, s.elapsed_time(e))
+        for name, evs in self._layer_sets:
+            for i in range(len(evs) - 1):
+                lname = layer_names[i] if layer_names else str(i)
+                add(f"{name}/{lname}", evs[i].elapsed_time(evs[i + 1]))
+        return out
+
+    def reset(self):
+        self._ranges.clear()
+        self._layer_sets.clear()
+
+
+def stage(timer, name):
+    return timer.range(name) if timer is not None else contextlib.nullcontext()

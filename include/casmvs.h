@@ -133,11 +133,14 @@ int casmvs_conv3d_forward_f32(int kind, const float *packed, const float *in, co
  * activations; its size comes from casmvs_costreg_workspace_bytes.
  * vol : device (B, cin, D, h, w)  ->  cost : device (B, D, h, w)   (the `prob` head, 1 channel)
  * D, h, w must be divisible by 8.  slope: leaky-relu slope of every ABN (0.01 in the reference).
+ * layer_events: NULL, or 12 caller-created `hipEvent_t` handles: event i is recorded on `stream`
+ *               right before layer i is launched and event 11 after the last layer, so a caller
+ *               can time each kernel (hipEventElapsedTime) without any synchronisation in here.
  */
 size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w);
 int casmvs_costreg_forward_f32(const float *const *packed_layers, const float *vol, float *cost,
                                void *workspace, int B, int cin, int D, int h, int w, float slope,
-                               void *stream);
+                               void *const *layer_events, void *stream);
 
 /* ---- (a9) softmax over depth + soft-argmin regression + confidence --------------------------
  * Replaces: models/mvsnet.py:174-193 and models/modules.py:95-104:

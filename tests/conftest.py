@@ -15,3 +15,23 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+_REPORT = []
+
+
+@pytest.fixture
+def report():
+    """Collects measured parity errors; written to gpurun_out/parity_report.json at session end."""
+    def add(name, **vals):
+        _REPORT.append(dict(name=name, **vals))
+    return add
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _REPORT:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(_REPORT, f, indent=1)

@@ -1,0 +1,89 @@
+"""CPU tests of the C-ABI library as a binary artefact: it loads, exports every symbol that
+include/casmvs.h declares, reports the right ABI version, and its HOST-side functions (packed
+sizes, weight packing, workspace size, argument validation) behave.  No GPU compute is called."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from casmvsnet_pl_amd import _lib, ops
+from casmvsnet_pl_amd.build import build_library
+import kernel_model as KM
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    build_library()
+
+
+def test_header_symbols_are_all_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "casmvs.h")).read()
+    declared = set(re.findall(r"\b(casmvs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), "ctypes binding table and include/casmvs.h disagree"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libcasmvs_hip.so does not export {name}"
+
+
+def test_abi_version_and_error_string():
+    lib = _lib.load()
+    assert lib.casmvs_abi_version() == 1
+    rc = lib.casmvs_homo_warp_f32(None, None, None, None, 1, 1, 8, 8, 1, None)
+    assert rc == -1 and b"null pointer" in lib.casmvs_last_error()
+    rc = lib.casmvs_costvol_gwc_f32(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8),
+                                    1, 3, 12, 5, 8, 8, 4, None)
+    assert rc == -2 and b"C=12" in lib.casmvs_last_error()
+
+
+def test_packed_sizes_and_workspace():
+    lib = _lib.load()
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 32, 8) == 4 * 27 * 64 + 16
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 64, 64) == 4 * 8 * 27 * 2 * 64 + 2 * 64
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 8, 1) == 27 * 64 + 8
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S2, 8, 16) == 2 * 27 * 64 + 32
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_T2, 64, 32) == 2 * 8 * 27 * 2 * 64 + 64
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S2, 8, 8) == 0  # unsupported
+    n = 8 * 16 * 24
+    assert lib.casmvs_costreg_workspace_bytes(2, 8, 16, 24) == 2 * 4 * int(23.75 * n)
+    assert lib.casmvs_costreg_workspace_bytes(1, 8, 16, 20) == 0  # w not a multiple of 8
+
+
+CASES = [(ops.CONV_S1, 32, 8), (ops.CONV_S1, 5, 8), (ops.CONV_S1, 8, 1), (ops.CONV_S1, 16, 16), (ops.CONV_S1, 20, 32),
+         (ops.CONV_S2, 8, 16), (ops.CONV_S2, 6, 32), (ops.CONV_T2, 16, 8), (ops.CONV_T2, 12, 32)]
+
+
+@pytest.mark.parametrize("kind,cin,cout", CASES)
+def test_packed_image_drives_the_kernel_index_model_to_the_right_convolution(kind, cin, cout):
+    """C packer + Python model of the kernel's (stage, tap, c, q) -> (image, ABID) walk == torch conv."""
+    g = torch.Generator().manual_seed(kind * 100 + cin + cout)
+    x = torch.randn(2, cin, 4, 6, 6, generator=g)
+    wshape = (cin, cout, 3, 3, 3) if kind == ops.CONV_T2 else (cout, cin, 3, 3, 3)
+    w = torch.randn(wshape, generator=g) * 0.2
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    packed = ops.conv3d_pack(kind, w, scale, shift)
+    if kind == ops.CONV_T2:
+        ref = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+    else:
+        ref = F.conv3d(x, w, None, stride=1 if kind == ops.CONV_S1 else 2, padding=1)
+    ref = F.leaky_relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1), 0.01)
+    skip = torch.randn(ref.shape, generator=g)
+    got = KM.emulate(kind, packed, x, cout, skip=skip, slope=0.01)
+    assert float((got - (ref + skip)).abs().max()) < 1e-4
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.CasMVSLibraryError):
+        _lib.load()
+
+
+def test_ops_reject_cpu_tensors():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.homo_warp(torch.zeros(1, 1, 4, 4), torch.zeros(1, 3, 4), torch.ones(1, 1, 4, 4))
