@@ -31,7 +31,7 @@ def build_library(force=False, verbose=False):
     if not force and not is_stale():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC] + _sources() + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -108,6 +108,66 @@ inline bool layer_cfg(int kind, int cin, int cout, LayerCfg &c) {
   return true;
 }
 
+
+// Cooperative global -> LDS staging of one CK-channel chunk of a zero-padded halo tile.
+// The tile is CK*IZ planes of IY*IX floats; a thread copies the same NPASS in-plane positions of
+// every plane, so the (iy, ix) decode, the bounds tests and the in-plane global offset are
+// computed ONCE per kernel (StagePlan) and a plane costs one add + load + ds_write per position.
+// Loads of UB planes are issued back to back before the first LDS write: UB*NPASS loads in
+// flight per thread hide the L2/HBM latency that a load-store-load-store loop would serialise.
+template <int IY, int IX>
+struct StagePlan {
+  static constexpr int PLANE = IY * IX;
+  static constexpr int NPASS = (PLANE + kThreads - 1) / kThreads;
+  int goff[NPASS];   // gy * Wi + gx of this thread's position (valid only if inb)
+  bool inb[NPASS];   // position inside the image in y and x
+  __device__ __forceinline__ void init(int iy0, int ix0, int Hi, int Wi) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int pe = threadIdx.x + p * kThreads;
+      const int iy = pe / IX, ix = pe - iy * IX;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      inb[p] = pe < PLANE && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+      goff[p] = gy * Wi + gx;
+    }
+  }
+};
+
+template <int CK, int IZ, int IY, int IX>
+__device__ __forceinline__ void stage_chunk(float *tile, const StagePlan<IY, IX> &plan,
+                                            const float *__restrict__ inb, size_t in_cs, int cin,
+                                            int ci0, int iz0, int Di, int HiWi) {
+  constexpr int PLANE = IY * IX, NPASS = StagePlan<IY, IX>::NPASS, NPL = CK * IZ;
+  constexpr int UB = NPASS >= 3 ? 4 : 8;  // planes per batch
+  for (int pl0 = 0; pl0 < NPL; pl0 += UB) {
+    float v[UB][NPASS];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int pl = pl0 + u;
+      const int cil = pl / IZ, iz = pl - cil * IZ;
+      const int ci = ci0 + cil, gz = iz0 + iz;
+      const bool plane_ok = pl < NPL && ci < cin && gz >= 0 && gz < Di;  // wave-uniform
+      // branch-free: out-of-range positions read element 0 of the tensor and are zeroed after
+      const float *src = plane_ok ? inb + (size_t)ci * in_cs + (size_t)gz * HiWi : inb;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const bool ok = plane_ok && plan.inb[p];
+        const float x = src[ok ? plan.goff[p] : 0];
+        v[u][p] = ok ? x : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int pl = pl0 + u;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int pe = threadIdx.x + p * kThreads;
+        if (pl < NPL && pe < PLANE) tile[pl * PLANE + pe] = v[u][p];
+      }
+    }
+  }
+}
+
 // ---- Conv3d k3 p1, stride 1 or 2 -------------------------------------------------------------
 template <int STRIDE, int COUTB, int CK, int G, int TZ, int TY, int TX>
 __global__ __launch_bounds__(kThreads) void conv3d_kernel(
@@ -159,25 +219,15 @@ __global__ __launch_bounds__(kThreads) void conv3d_kernel(
   constexpr int NI = CK * G;                // items per tap
   constexpr int P = NI < 8 ? NI : 8;        // read-ahead distance (items)
   auto tap_off = [&](int tap) -> int { return (tap / 9) * SZ + ((tap / 3) % 3) * SY + (tap % 3); };
+  StagePlan<IY, IX> plan;
+  plan.init(iy0, ix0, Hi, Wi);
   int t = 0;
   float a_cur[NV], a_nxt[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) a_cur[j] = wp[j * 64];
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();  // every wave is done reading the previous chunk
-    for (int e = threadIdx.x; e < CK * IZ * IY * IX; e += kThreads) {
-      const int cil = e / (IZ * IY * IX);
-      const int r = e - cil * (IZ * IY * IX);
-      const int iz = r / (IY * IX);
-      const int r2 = r - iz * (IY * IX);
-      const int iy = r2 / IX;
-      const int ix = r2 - iy * IX;
-      const int gz = iz0 + iz, gy = iy0 + iy, gx = ix0 + ix, ci = s * CK + cil;
-      float val = 0.0f;  // zero padding (p = 1) and channel padding
-      if (ci < cin && gz >= 0 && gz < Di && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi)
-        val = inb[(size_t)ci * in_cs + ((size_t)gz * Hi + gy) * Wi + gx];
-      tile[cil * SC + iz * SZ + iy * SY + ix] = val;
-    }
+    stage_chunk<CK, IZ, IY, IX>(tile, plan, inb, in_cs, cin, s * CK, iz0, Di, Hi * Wi);
     __syncthreads();
     int ad_c[G], ad_n[G];  // per-group LDS word address of the current / next tap
 #pragma unroll
@@ -276,22 +326,12 @@ __global__ __launch_bounds__(kThreads) void deconv3d_kernel(
   const int T = nstages * 27;
   const float *wp = wpk + (size_t)slice * T * NV * 64 + lane;
   const int nzt = pz ? 2 : 1, nyt = py ? 2 : 1;
+  StagePlan<IY, IX> plan;
+  plan.init(ty0, tx0, Hi, Wi);
 
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
-    for (int e = threadIdx.x; e < CK * IZ * IY * IX; e += kThreads) {
-      const int cil = e / (IZ * IY * IX);
-      const int r = e - cil * (IZ * IY * IX);
-      const int iz = r / (IY * IX);
-      const int r2 = r - iz * (IY * IX);
-      const int iy = r2 / IX;
-      const int ix = r2 - iy * IX;
-      const int gz = tz0 + iz, gy = ty0 + iy, gx = tx0 + ix, ci = s * CK + cil;
-      float val = 0.0f;
-      if (ci < cin && gz < Di && gy < Hi && gx < Wi)
-        val = inb[(size_t)ci * in_cs + ((size_t)gz * Hi + gy) * Wi + gx];
-      tile[cil * SC + iz * SZ + iy * SY + ix] = val;
-    }
+    stage_chunk<CK, IZ, IY, IX>(tile, plan, inb, in_cs, cin, s * CK, tz0, Di, Hi * Wi);
     __syncthreads();
     for (int zt = 0; zt < nzt; ++zt) {
       const int kz = pz ? (zt == 0 ? 2 : 0) : 1, dz = (pz && zt == 1) ? 1 : 0;

@@ -5,6 +5,8 @@
 // Both are HBM-bound streaming kernels: one thread per pixel, lanes along the image row so every
 // (D, h, w) plane access is a coalesced 256 B wavefront transaction; the D values of a pixel stay
 // in registers between the max / exp-sum / regression passes (one read of the cost volume).
+// Built with -ffp-contract=off: every * and + below is a separately rounded fp32 operation, in
+// the reference's (torch's) order.
 #include "common.h"
 
 namespace {
@@ -33,23 +35,23 @@ __global__ __launch_bounds__(kThreads) void hypotheses_kernel(
     // ATen: scale = (in - 1) / (out - 1) computed in float; src = scale * dst
     const float sy = (h > 1) ? (float)(hp - 1) / (float)(h - 1) : 0.0f;
     const float sx = (w > 1) ? (float)(wp - 1) / (float)(w - 1) : 0.0f;
-    const float fy = __fmul_rn(sy, (float)y), fx = __fmul_rn(sx, (float)x);
+    const float fy = sy * (float)y, fx = sx * (float)x;
     const int y0 = (int)fy, x0 = (int)fx;  // fy, fx >= 0: truncation == floor
     const int y1 = y0 + ((y0 < hp - 1) ? 1 : 0), x1 = x0 + ((x0 < wp - 1) ? 1 : 0);
-    const float ly1 = __fsub_rn(fy, (float)y0), ly0 = __fsub_rn(1.0f, ly1);
-    const float lx1 = __fsub_rn(fx, (float)x0), lx0 = __fsub_rn(1.0f, lx1);
+    const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+    const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
     const float *pp = prev + (size_t)b * hp * wp;
     const float v00 = pp[y0 * wp + x0], v01 = pp[y0 * wp + x1];
     const float v10 = pp[y1 * wp + x0], v11 = pp[y1 * wp + x1];
     // ATen upsample_bilinear2d: h0lambda * (w0lambda * v00 + w1lambda * v01) + h1lambda * (...)
-    const float top = __fadd_rn(__fmul_rn(lx0, v00), __fmul_rn(lx1, v01));
-    const float bot = __fadd_rn(__fmul_rn(lx0, v10), __fmul_rn(lx1, v11));
-    const float u = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
-    dmin = fmaxf(__fsub_rn(u, half_range_b[b]), 1e-7f);  // torch.clamp_min (NaN propagates below)
+    const float top = lx0 * v00 + lx1 * v01;
+    const float bot = lx0 * v10 + lx1 * v11;
+    const float u = ly0 * top + ly1 * bot;
+    dmin = fmaxf(u - half_range_b[b], 1e-7f);  // torch.clamp_min (NaN propagates below)
     if (u != u) dmin = u;
   }
   float *op = out + (size_t)b * D * hw + p;
-  for (int k = 0; k < D; ++k) op[(size_t)k * hw] = __fadd_rn(dmin, __fmul_rn(delta, (float)k));
+  for (int k = 0; k < D; ++k) op[(size_t)k * hw] = dmin + delta * (float)k;
 }
 
 // ---- softmax + regression + confidence ---------------------------------------------------------
@@ -80,26 +82,26 @@ __global__ __launch_bounds__(kThreads) void softmax_regress_kernel(
   if (DT > 0) {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      e[k] = expf(__fsub_rn(e[k], mx));
-      sum = __fadd_rn(sum, e[k]);
+      e[k] = expf(e[k] - mx);
+      sum = sum + e[k];
     }
   } else {
-    for (int k = 0; k < D; ++k) sum = __fadd_rn(sum, expf(__fsub_rn(cp[(size_t)k * hw], mx)));
+    for (int k = 0; k < D; ++k) sum = sum + expf(cp[(size_t)k * hw] - mx);
   }
   // depth = sum_k p_k d_k (modules.py:103); expected index = sum_k p_k k  (mvsnet.py:185-189)
   float dsum = 0.0f, isum = 0.0f;
   if (DT > 0) {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      e[k] = __fdiv_rn(e[k], sum);
-      dsum = __fadd_rn(dsum, __fmul_rn(e[k], dp[(size_t)k * hw]));
-      isum = __fadd_rn(isum, __fmul_rn(e[k], (float)k));
+      e[k] = e[k] / sum;
+      dsum = dsum + e[k] * dp[(size_t)k * hw];
+      isum = isum + e[k] * (float)k;
     }
   } else {
     for (int k = 0; k < D; ++k) {
-      float pk = __fdiv_rn(expf(__fsub_rn(cp[(size_t)k * hw], mx)), sum);
-      dsum = __fadd_rn(dsum, __fmul_rn(pk, dp[(size_t)k * hw]));
-      isum = __fadd_rn(isum, __fmul_rn(pk, (float)k));
+      const float pk = expf(cp[(size_t)k * hw] - mx) / sum;
+      dsum = dsum + pk * dp[(size_t)k * hw];
+      isum = isum + pk * (float)k;
     }
   }
   // .long() truncates toward zero; isum >= 0 so this is floor; clamp to [0, D-1] (mvsnet.py:189-190)
@@ -116,10 +118,10 @@ __global__ __launch_bounds__(kThreads) void softmax_regress_kernel(
   if (DT > 0) {
 #pragma unroll
     for (int k = 0; k < NR; ++k)
-      if (k >= idx - 1 && k <= idx + 2) c4 = __fadd_rn(c4, e[k]);
+      if (k >= idx - 1 && k <= idx + 2) c4 = c4 + e[k];
   } else {
     for (int k = max(idx - 1, 0); k <= min(idx + 2, D - 1); ++k)
-      c4 = __fadd_rn(c4, __fdiv_rn(expf(__fsub_rn(cp[(size_t)k * hw], mx)), sum));
+      c4 = c4 + expf(cp[(size_t)k * hw] - mx) / sum;
   }
   depth[(size_t)b * hw + p] = dsum;
   conf[(size_t)b * hw + p] = c4;

@@ -15,7 +15,7 @@ cp gpurun_out/parity_report.json $OUT/ 2>/dev/null
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit: $?" >> $OUT/bench.err
 if [ "$2" != "noprof" ]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o stats -- python $ROOTDIR/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-events > $OUT/prof_bench.json 2> $OUT/prof.err)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o stats -- python $ROOTDIR/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-events > $OUT/prof_bench.json 2> $OUT/prof.err)
   echo "rocprof exit: $?" >> $OUT/prof.err
   # keep only the small csv summaries
   find $OUT/prof -name "*.db" -delete 2>/dev/null
