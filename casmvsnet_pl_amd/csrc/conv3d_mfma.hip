@@ -23,7 +23,8 @@
 // Cout > 16 is split into 16-channel slices over blockIdx.z.
 //
 // Packed parameter image (built on the host by casmvs_conv3d_pack_f32):
-//   [slice][stage][tap 0..26][j 0..NV-1][64 lanes]  then  scale[slices*COUTB], shift[slices*COUTB]
+//   [slice][stage][tap 0..26][j 0..NV-1][64 lanes]  then  scale[slices*COUTB], shift[slices*COUTB],
+//   then 64 zero floats (target of out-of-range staging loads)
 //   image (stage, tap, j), lane l: n = 16*j + l/4, cil = n / Q, q = n % Q, i = l % 4
 //   holds w[co = slice*COUTB + 4q + i][ci = stage*CK + cil][tap]  (0 outside cin/cout).
 #include <type_traits>
@@ -109,12 +110,16 @@ inline bool layer_cfg(int kind, int cin, int cout, LayerCfg &c) {
 }
 
 
-// Cooperative global -> LDS staging of one CK-channel chunk of a zero-padded halo tile.
-// The tile is CK*IZ planes of IY*IX floats; a thread copies the same NPASS in-plane positions of
-// every plane, so the (iy, ix) decode, the bounds tests and the in-plane global offset are
-// computed ONCE per kernel (StagePlan) and a plane costs one add + load + ds_write per position.
-// Loads of UB planes are issued back to back before the first LDS write: UB*NPASS loads in
-// flight per thread hide the L2/HBM latency that a load-store-load-store loop would serialise.
+// ---- staging: global -> registers -> LDS, software-pipelined one chunk ahead -------------------
+// A chunk = CK input channels of the zero-padded halo tile (CK*IZ planes of IY*IX floats) plus
+// the chunk's 27*NV weight images.  A thread copies the same NPASS in-plane positions of every
+// plane, so the (iy, ix) decode, the bounds tests and the in-plane global offset are computed
+// ONCE per kernel (StagePlan); a plane then costs one add + load per position.  The loads of
+// chunk s+1 are issued right after the barrier that publishes chunk s and land in registers
+// while the MFMA loop of chunk s runs (5-6 us of cover for ~2 us of L2/HBM latency); they are
+// written to LDS after the next barrier.  Weights go through LDS too, so that the MFMA loop
+// contains no vector-memory instruction (an in-loop global load would make the compiler's
+// in-order vmcnt wait drain the whole prefetch at the first tap).
 template <int IY, int IX>
 struct StagePlan {
   static constexpr int PLANE = IY * IX;
@@ -133,53 +138,80 @@ struct StagePlan {
   }
 };
 
-template <int CK, int IZ, int IY, int IX>
-__device__ __forceinline__ void stage_chunk(float *tile, const StagePlan<IY, IX> &plan,
-                                            const float *__restrict__ inb, size_t in_cs, int cin,
-                                            int ci0, int iz0, int Di, int HiWi) {
-  constexpr int PLANE = IY * IX, NPASS = StagePlan<IY, IX>::NPASS, NPL = CK * IZ;
-  constexpr int UB = NPASS >= 3 ? 4 : 8;  // planes per batch
-  for (int pl0 = 0; pl0 < NPL; pl0 += UB) {
-    float v[UB][NPASS];
+template <int CK, int IZ, int IY, int IX, int NW>
+struct StageRegs {
+  static constexpr int NPL = CK * IZ, NPASS = StagePlan<IY, IX>::NPASS;
+  static constexpr int NWR = (NW + kThreads - 1) / kThreads;
+  float v[NPL][NPASS];
+  float w[NWR];
+
+  // issue every load of chunk `ci0 / CK`; nothing here waits
+  __device__ __forceinline__ void load(const StagePlan<IY, IX> &plan, const float *__restrict__ inb,
+                                       size_t in_cs, int cin, int ci0, int iz0, int Di, int HiWi,
+                                       const float *__restrict__ wchunk, const float *__restrict__ zero) {
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int pl = pl0 + u;
+    for (int i = 0; i < NWR; ++i) {
+      const int e = threadIdx.x + i * kThreads;
+      w[i] = wchunk[e < NW ? e : 0];
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
       const int cil = pl / IZ, iz = pl - cil * IZ;
       const int ci = ci0 + cil, gz = iz0 + iz;
-      const bool plane_ok = pl < NPL && ci < cin && gz >= 0 && gz < Di;  // wave-uniform
-      // branch-free: out-of-range positions read element 0 of the tensor and are zeroed after
-      const float *src = plane_ok ? inb + (size_t)ci * in_cs + (size_t)gz * HiWi : inb;
+      const bool plane_ok = ci < cin && gz >= 0 && gz < Di;  // wave-uniform
+      // branch-free and mask-free: out-of-range positions load from a zero word that the packed
+      // parameter image carries at its end, so no predicate has to survive until the data lands.
+      // 32-bit element offsets (one sample's input is < 2^31 floats).
+      const int poff = ci * (int)in_cs + gz * HiWi;
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         const bool ok = plane_ok && plan.inb[p];
-        const float x = src[ok ? plan.goff[p] : 0];
-        v[u][p] = ok ? x : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int pl = pl0 + u;
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const int pe = threadIdx.x + p * kThreads;
-        if (pl < NPL && pe < PLANE) tile[pl * PLANE + pe] = v[u][p];
+        const float *ptr = ok ? inb + (poff + plan.goff[p]) : zero;
+        v[pl][p] = *ptr;
       }
     }
   }
-}
+
+  __device__ __forceinline__ void store(float *tile, float *wts) const {
+    constexpr int PLANE = IY * IX;
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+      const int e = threadIdx.x + i * kThreads;
+      if (e < NW) wts[e] = w[i];
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int pe = threadIdx.x + p * kThreads;
+        if (pe < PLANE) tile[pl * PLANE + pe] = v[pl][p];
+      }
+  }
+};
 
 // ---- Conv3d k3 p1, stride 1 or 2 -------------------------------------------------------------
+template <int STRIDE, int COUTB, int CK, int G, int TZ, int TY, int TX>
+struct ConvCfg {
+  static constexpr int Q = COUTB / 4;
+  static constexpr int NV = (CK * Q + 15) / 16;
+  static constexpr int IZ = STRIDE * (TZ - 1) + 3, IY = STRIDE * (TY - 1) + 3, IX = STRIDE * (TX - 1) + 3;
+  static constexpr int SY = IX, SZ = IY * SY, SC = IZ * SZ;
+  static constexpr int NW = 27 * NV * 64;                       // weight floats per chunk
+  static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
+};
+
 template <int STRIDE, int COUTB, int CK, int G, int TZ, int TY, int TX>
 __global__ __launch_bounds__(kThreads) void conv3d_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
     int nstages, int tiles_x, int tiles_y, float slope) {
   static_assert(TZ * TY * TX == 4 * G * 64, "tile must hold 4 waves x G groups x 64 voxels");
-  constexpr int Q = COUTB / 4;
-  constexpr int NV = (CK * Q + 15) / 16;
-  constexpr int IZ = STRIDE * (TZ - 1) + 3, IY = STRIDE * (TY - 1) + 3, IX = STRIDE * (TX - 1) + 3;
-  constexpr int SY = IX, SZ = IY * SY, SC = IZ * SZ;
-  __shared__ float tile[CK * SC];
+  using Cfg = ConvCfg<STRIDE, COUTB, CK, G, TZ, TY, TX>;
+  constexpr int Q = Cfg::Q, NV = Cfg::NV, IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX;
+  constexpr int SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, NW = Cfg::NW;
+  extern __shared__ float smem[];
+  float *tile = smem;            // [CK][IZ][IY][IX]
+  float *wts = smem + CK * SC;   // [27][NV][64]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bid = blockIdx.x;
@@ -208,38 +240,44 @@ __global__ __launch_bounds__(kThreads) void conv3d_kernel(
   const float *inb = in + (size_t)b * cin * in_cs;
   const int iz0 = tz0 * STRIDE - 1, iy0 = ty0 * STRIDE - 1, ix0 = tx0 * STRIDE - 1;
   const int T = nstages * 27;
-  const float *wp = wpk + (size_t)slice * T * NV * 64 + lane;
+  const float *wslice = wpk + (size_t)slice * T * NV * 64;
+  const float *zero = wpk + (size_t)slices * T * NV * 64 + 2 * slices * COUTB;  // 64 zero floats
 
-  // Software pipeline, written out in issue order and pinned with sched_barrier: within a tap,
-  // item i = (c, g) needs one B operand (ds_read_b32, immediate offset c * SC) and feeds Q MFMAs.
-  // The read of item i + P is issued right before the MFMAs of item i (wrapping into the next
-  // tap), so P items (>= 128 MFMA cycles) of LDS latency are always covered and the waitcnt
+  // MFMA loop of one chunk, written out in issue order and pinned with sched_barrier: within a
+  // tap, item i = (c, g) needs one B operand (ds_read_b32, immediate offset c * SC) and feeds Q
+  // MFMAs.  The read of item i + P is issued right before the MFMAs of item i (wrapping into the
+  // next tap), so P items (>= 128 MFMA cycles) of LDS latency are always covered and the waitcnt
   // pass emits counted lgkmcnt waits instead of draining after every read.  The A images of the
-  // next tap are fetched (L1/L2 hits: every workgroup streams the same few KB) a whole tap ahead.
+  // next tap are read from LDS a whole tap ahead.
   constexpr int NI = CK * G;                // items per tap
   constexpr int P = NI < 8 ? NI : 8;        // read-ahead distance (items)
   auto tap_off = [&](int tap) -> int { return (tap / 9) * SZ + ((tap / 3) % 3) * SY + (tap % 3); };
+
   StagePlan<IY, IX> plan;
   plan.init(iy0, ix0, Hi, Wi);
-  int t = 0;
-  float a_cur[NV], a_nxt[NV];
-#pragma unroll
-  for (int j = 0; j < NV; ++j) a_cur[j] = wp[j * 64];
+  StageRegs<CK, IZ, IY, IX, NW> regs;
+  regs.load(plan, inb, in_cs, cin, 0, iz0, Di, Hi * Wi, wslice, zero);
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();  // every wave is done reading the previous chunk
-    stage_chunk<CK, IZ, IY, IX>(tile, plan, inb, in_cs, cin, s * CK, iz0, Di, Hi * Wi);
+    regs.store(tile, wts);
     __syncthreads();
+    if (s + 1 < nstages)  // prefetch the next chunk; consumed after the next barrier
+      regs.load(plan, inb, in_cs, cin, (s + 1) * CK, iz0, Di, Hi * Wi, wslice + (size_t)(s + 1) * NW, zero);
+
+    float a_cur[NV], a_nxt[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) a_cur[j] = wts[j * 64 + lane];
     int ad_c[G], ad_n[G];  // per-group LDS word address of the current / next tap
 #pragma unroll
     for (int g = 0; g < G; ++g) ad_c[g] = base[g];  // tap 0: offset 0
     float ring[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) ring[i] = tile[ad_c[i % G] + (i / G) * SC];
-    for (int tap = 0; tap < 27; ++tap, ++t) {
-      const int tn = (t + 1 < T) ? t + 1 : t;
+    for (int tap = 0; tap < 27; ++tap) {
+      const int tapn = tap < 26 ? tap + 1 : 26;  // last tap: harmless re-read
 #pragma unroll
-      for (int j = 0; j < NV; ++j) a_nxt[j] = wp[((size_t)tn * NV + j) * 64];
-      const int toff_n = tap_off(tap < 26 ? tap + 1 : 26);  // last tap: harmless re-read
+      for (int j = 0; j < NV; ++j) a_nxt[j] = wts[(tapn * NV + j) * 64 + lane];
+      const int toff_n = tap_off(tapn);
 #pragma unroll
       for (int g = 0; g < G; ++g) ad_n[g] = base[g] + toff_n;
 #pragma unroll
@@ -293,16 +331,27 @@ __global__ __launch_bounds__(kThreads) void conv3d_kernel(
 // o = 2m + 1 take (k = 2, i = m) and (k = 0, i = m + 1).  Each lane owns one input cell m and
 // produces the two x-parities of output row (2mz + pz, 2my + py); (pz, py) comes from blockIdx.
 template <int COUTB, int CK, int TZ, int TY, int TX>
+struct DeconvCfg {
+  static constexpr int Q = COUTB / 4;
+  static constexpr int NV = (CK * Q + 15) / 16;
+  static constexpr int IZ = TZ + 1, IY = TY + 1, IX = TX + 1;
+  static constexpr int SY = IX, SZ = IY * SY, SC = IZ * SZ;
+  static constexpr int NW = 27 * NV * 64;
+  static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
+};
+
+template <int COUTB, int CK, int TZ, int TY, int TX>
 __global__ __launch_bounds__(kThreads) void deconv3d_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int cin, int cout, int Di, int Hi, int Wi, int nstages, int tiles_x,
     int tiles_y, int ntiles, float slope) {
   static_assert(TZ * TY * TX == 256, "tile must hold 4 waves x 64 cells");
-  constexpr int Q = COUTB / 4;
-  constexpr int NV = (CK * Q + 15) / 16;
-  constexpr int IZ = TZ + 1, IY = TY + 1, IX = TX + 1;
-  constexpr int SY = IX, SZ = IY * SY, SC = IZ * SZ;
-  __shared__ float tile[CK * SC];
+  using Cfg = DeconvCfg<COUTB, CK, TZ, TY, TX>;
+  constexpr int Q = Cfg::Q, NV = Cfg::NV, IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX;
+  constexpr int SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, NW = Cfg::NW;
+  extern __shared__ float smem[];
+  float *tile = smem;
+  float *wts = smem + CK * SC;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pass = blockIdx.x / ntiles, bid = blockIdx.x - pass * ntiles;
@@ -324,26 +373,31 @@ __global__ __launch_bounds__(kThreads) void deconv3d_kernel(
   const size_t in_cs = (size_t)Di * Hi * Wi;
   const float *inb = in + (size_t)b * cin * in_cs;
   const int T = nstages * 27;
-  const float *wp = wpk + (size_t)slice * T * NV * 64 + lane;
+  const float *wslice = wpk + (size_t)slice * T * NV * 64;
+  const float *zero = wpk + (size_t)slices * T * NV * 64 + 2 * slices * COUTB;  // 64 zero floats
   const int nzt = pz ? 2 : 1, nyt = py ? 2 : 1;
   StagePlan<IY, IX> plan;
   plan.init(ty0, tx0, Hi, Wi);
+  StageRegs<CK, IZ, IY, IX, NW> regs;
+  regs.load(plan, inb, in_cs, cin, 0, tz0, Di, Hi * Wi, wslice, zero);
 
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
-    stage_chunk<CK, IZ, IY, IX>(tile, plan, inb, in_cs, cin, s * CK, tz0, Di, Hi * Wi);
+    regs.store(tile, wts);
     __syncthreads();
+    if (s + 1 < nstages)
+      regs.load(plan, inb, in_cs, cin, (s + 1) * CK, tz0, Di, Hi * Wi, wslice + (size_t)(s + 1) * NW, zero);
     for (int zt = 0; zt < nzt; ++zt) {
       const int kz = pz ? (zt == 0 ? 2 : 0) : 1, dz = (pz && zt == 1) ? 1 : 0;
       for (int yt = 0; yt < nyt; ++yt) {
         const int ky = py ? (yt == 0 ? 2 : 0) : 1, dy = (py && yt == 1) ? 1 : 0;
-        const int tap0 = s * 27 + (kz * 3 + ky) * 3;  // kx = 0, 1, 2 follow
+        const int tap0 = (kz * 3 + ky) * 3;  // kx = 0, 1, 2 follow
         float a0[NV], a1[NV], a2[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-          a0[j] = wp[((size_t)(tap0 + 0) * NV + j) * 64];
-          a1[j] = wp[((size_t)(tap0 + 1) * NV + j) * 64];
-          a2[j] = wp[((size_t)(tap0 + 2) * NV + j) * 64];
+          a0[j] = wts[((tap0 + 0) * NV + j) * 64 + lane];
+          a1[j] = wts[((tap0 + 1) * NV + j) * 64 + lane];
+          a2[j] = wts[((tap0 + 2) * NV + j) * 64 + lane];
         }
         const int toff = dz * SZ + dy * SY;
         float b0[CK], b1[CK];
@@ -409,16 +463,31 @@ __global__ void mfma_probe_kernel(float *out) {
   }
 }
 
+// Kernels that need more than the default 64 KiB of LDS must opt in once per process.
+template <class K>
+int ensure_lds(K kernel, size_t bytes, const char *what) {
+  static bool done = false;  // one instance per kernel instantiation (template)
+  if (!done && bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "%s: hipFuncSetAttribute(%zu B LDS): %s", what, bytes, hipGetErrorString(e));
+  }
+  done = true;
+  return CASMVS_OK;
+}
+
 template <int STRIDE, int COUTB, int CK, int G, int TZ, int TY, int TX>
 int launch_conv(const LayerCfg &c, const float *packed, const float *in, const float *skip,
                 float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                 float slope, hipStream_t st) {
+  using Cfg = ConvCfg<STRIDE, COUTB, CK, G, TZ, TY, TX>;
+  auto kernel = conv3d_kernel<STRIDE, COUTB, CK, G, TZ, TY, TX>;
+  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv3d_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wo, TX), tiles_y = casmvs::ceil_div(Ho, TY),
             tiles_z = casmvs::ceil_div(Do, TZ);
   dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, (unsigned)c.slices);
-  hipLaunchKernelGGL((conv3d_kernel<STRIDE, COUTB, CK, G, TZ, TY, TX>), grid, dim3(kThreads), 0, st,
-                     in, packed, skip, out, cin, cout, Di, Hi, Wi, Do, Ho, Wo, c.nstages, tiles_x,
-                     tiles_y, slope);
+  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, cin, cout,
+                     Di, Hi, Wi, Do, Ho, Wo, c.nstages, tiles_x, tiles_y, slope);
   return casmvs::check_launch("conv3d_kernel");
 }
 
@@ -426,13 +495,15 @@ template <int COUTB, int CK, int TZ, int TY, int TX>
 int launch_deconv(const LayerCfg &c, const float *packed, const float *in, const float *skip,
                   float *out, int B, int cin, int cout, int Di, int Hi, int Wi, float slope,
                   hipStream_t st) {
+  using Cfg = DeconvCfg<COUTB, CK, TZ, TY, TX>;
+  auto kernel = deconv3d_kernel<COUTB, CK, TZ, TY, TX>;
+  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "deconv3d_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wi, TX), tiles_y = casmvs::ceil_div(Hi, TY),
             tiles_z = casmvs::ceil_div(Di, TZ);
   const int ntiles = tiles_x * tiles_y * tiles_z;
   dim3 grid((unsigned)(4 * ntiles), (unsigned)B, (unsigned)c.slices);
-  hipLaunchKernelGGL((deconv3d_kernel<COUTB, CK, TZ, TY, TX>), grid, dim3(kThreads), 0, st, in,
-                     packed, skip, out, cin, cout, Di, Hi, Wi, c.nstages, tiles_x, tiles_y, ntiles,
-                     slope);
+  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, cin, cout,
+                     Di, Hi, Wi, c.nstages, tiles_x, tiles_y, ntiles, slope);
   return casmvs::check_launch("deconv3d_kernel");
 }
 
@@ -441,7 +512,7 @@ int launch_deconv(const LayerCfg &c, const float *packed, const float *in, const
 extern "C" size_t casmvs_conv3d_packed_floats(int kind, int cin, int cout) {
   LayerCfg c;
   if (!layer_cfg(kind, cin, cout, c)) return 0;
-  return (size_t)c.slices * c.nstages * 27 * c.nv * 64 + 2 * (size_t)c.slices * c.coutb;
+  return (size_t)c.slices * c.nstages * 27 * c.nv * 64 + 2 * (size_t)c.slices * c.coutb + 64;
 }
 
 extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *weight,
@@ -471,6 +542,7 @@ extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *
   const int cp = c.slices * c.coutb;
   for (int co = 0; co < cp; ++co) p[co] = (co < cout) ? (scale ? scale[co] : 1.0f) : 0.0f;
   for (int co = 0; co < cp; ++co) p[cp + co] = (co < cout) ? (shift ? shift[co] : 0.0f) : 0.0f;
+  for (int i = 0; i < 64; ++i) p[2 * cp + i] = 0.0f;  // zero words the staging loads point out-of-range lanes at
   return CASMVS_OK;
 }
 
@@ -485,8 +557,8 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
     return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv3d_forward: kind=%d cin=%d cout=%d", kind, cin, cout);
   hipStream_t st = (hipStream_t)stream;
   if (kind == CASMVS_CONV_S1) {
-    if (c.coutb == 4) return launch_conv<1, 4, 8, 4, 4, 8, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
-    if (c.coutb == 8) return launch_conv<1, 8, 8, 4, 4, 8, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
+    if (c.coutb == 4) return launch_conv<1, 4, 8, 4, 8, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
+    if (c.coutb == 8) return launch_conv<1, 8, 8, 4, 8, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
     // coutb == 16: large volumes use 512-voxel tiles, small (deep) volumes 256-voxel tiles
     const long big_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 4) * c.slices * B;
     if (big_blocks >= 1024) return launch_conv<1, 16, 8, 2, 4, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);

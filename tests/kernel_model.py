@@ -33,7 +33,8 @@ def emulate(kind, packed, x, cout, skip=None, slope=0.01):
     T = nstages * 27
     img = packed[: slices * T * nv * 64].reshape(slices, T, nv, 64)
     scale = packed[slices * T * nv * 64: slices * T * nv * 64 + slices * coutb]
-    shift = packed[slices * T * nv * 64 + slices * coutb:]
+    shift = packed[slices * T * nv * 64 + slices * coutb: slices * T * nv * 64 + 2 * slices * coutb]
+    assert float(packed[slices * T * nv * 64 + 2 * slices * coutb:].abs().sum()) == 0.0 and packed.numel() == slices * T * nv * 64 + 2 * slices * coutb + 64
     if kind == T2:
         Do, Ho, Wo = 2 * D, 2 * H, 2 * W
     elif kind == S2:
