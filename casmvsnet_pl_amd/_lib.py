@@ -31,6 +31,7 @@ SYMBOLS = {
     "casmvs_costreg_forward_f32": (c_int, [POINTER(c_void_p), _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
     "casmvs_softmax_regress_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_selftest_mfma": (c_int, [_FP]),
+    "casmvs_selftest_mfma_rate": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
 }
 
 _lib = None

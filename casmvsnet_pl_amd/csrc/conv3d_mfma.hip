@@ -3,30 +3,34 @@
 // Reference semantics: models/mvsnet.py:60-104 (CostRegNet), models/modules.py:21-31
 // (ConvBnReLU3D): Conv3d / ConvTranspose3d (k3, p1) -> eval-mode ABN -> (+ skip).
 //
-// Formulation.  The channel counts are tiny (Cout in {1, 8, 16, 32, 64}), so the usual
-// "voxels x Cout" 16x16 / 32x32 MFMA tiles would waste half of the matrix pipe on the
-// full-resolution layers (Cout = 8) that hold most of the FLOPs.  Instead every layer runs on
-//     v_mfma_f32_4x4x1_16b_f32  with  CBSZ = 4 (broadcast ONE A block to all 16 blocks):
-//         D[co 0..3][voxel = lane] += A[co 0..3] * B[voxel = lane]          (K = 1)
-// i.e. each LANE owns one output voxel, the 4 accumulator registers are 4 output channels, the B
-// operand is the (tap-shifted) input value of the lane's voxel and the A operand is a 4-float
-// weight column that ABID picks out of a 64-lane VGPR holding 16 such columns.  512 FLOP per
-// 8-cycle instruction = the full fp32 MFMA rate with zero padding waste for any Cout % 4 == 0,
-// coalesced NCDHW loads/stores (a wavefront = 64 consecutive voxels of a tile), and the
-// epilogue (folded ABN, leaky-relu, skip add) is a plain per-lane FMA.
+// Instruction choice (measured on MI355X with casmvs_selftest_mfma_rate): the
+// fp32 MFMA that runs at the full 64 FLOP/clk/SIMD is v_mfma_f32_16x16x4_f32 (32 cycles);
+// the 16-block v_mfma_f32_4x4x1_16b_f32 form, attractive for tiny Cout, issues at HALF that
+// rate (68 TFLOP/s chip-wide), so it is only kept for the 1-channel `prob` head.
 //
-// Data flow per workgroup (256 threads = 4 wavefronts, G groups of 64 voxels per wavefront):
-//   for each chunk of CK input channels:  stage the zero-padded halo tile of the chunk in LDS
-//     for each of the 27 taps:  A images (prefetched one tap ahead, straight from L1/L2 - every
-//       workgroup streams the same few KB), G*CK conflict-free ds_read_b32 B operands,
-//       G*CK*Q MFMAs (Q = Cout-per-block / 4).
-// Cout > 16 is split into 16-channel slices over blockIdx.z.
+// Formulation.  D[16 rows][16 cols] += A[16][4] * B[4][16] per instruction with
+//   cols = 16 output voxels that are consecutive along x (one "column tile"),
+//   rows = 16 output features, K = 4 contraction steps.  Two row/K assignments are used:
+//   CI  (Cout % 16 == 0): rows = 16 output channels, K = 4 input channels of one tap.
+//   PX  (Cout == 8, the full-resolution layers that hold most FLOPs): rows = (co, s) = 8 output
+//       channels x 2 x-phases - the column tile covers 32 consecutive x as (x0 + 2j + s) - and
+//       K = 4 input x-offsets u of one (ci, kz, ky): out[x0+2j+s] += in[x0+2j+u-1] * w[kx = u-s].
+//       3 of the 4 K steps are non-zero for every row: 75 % of the matrix pipe does useful work
+//       (padding Cout 8 -> 16 would give 50 %).
+//   The transposed convolutions use the same two forms with rows = (co, x-parity) for Cout = 8.
+// Lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15] and receives
+// D[row = 4 * (l >> 4) + reg][col = l & 15] (reg = 0..3).
+//
+// Data flow per workgroup (256 threads = 4 wavefronts, NT column tiles per wavefront):
+//   for each chunk of CK input channels: the zero-padded halo tile of the chunk and the chunk's
+//   weight images are staged in LDS (global -> registers one chunk ahead -> LDS), then per
+//   (tap | row-tap) iteration: NA A-images (ds_read_b32, lane-linear) and NA*NT B operands
+//   (ds_read_b32, bank-conflict-free by construction of the channel stride) feed NA*NT MFMAs.
 //
 // Packed parameter image (built on the host by casmvs_conv3d_pack_f32):
-//   [slice][stage][tap 0..26][j 0..NV-1][64 lanes]  then  scale[slices*COUTB], shift[slices*COUTB],
-//   then 64 zero floats (target of out-of-range staging loads)
-//   image (stage, tap, j), lane l: n = 16*j + l/4, cil = n / Q, q = n % Q, i = l % 4
-//   holds w[co = slice*COUTB + 4q + i][ci = stage*CK + cil][tap]  (0 outside cin/cout).
+//   [slice][chunk][NW floats of 64-lane A images]  scale[slices*coutb]  shift[slices*coutb]
+//   zero[64] (target of out-of-range staging loads).  Image order inside a chunk, and the
+//   lane -> (row, k) -> weight mapping, are documented at each format in pack_weight().
 #include <type_traits>
 
 #include "common.h"
@@ -46,80 +50,94 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
-// One K = 1 step for 4 output channels x 64 voxels: acc[r] (lane) += a[4*ABID + r] * b[lane].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// 4x4x1 with A-block broadcast: acc[r] (lane) += a[4*ABID + r] * b[lane]   (prob head only)
 template <int ABID>
 __device__ __forceinline__ f32x4 mfma_bcast(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, /*cbsz=*/4, /*abid=*/ABID, /*blgp=*/0);
 }
 
-// Same with a loop-variable ABID: every call site sits in a fully unrolled loop, so the switch
-// folds to the single matching instruction.
-__device__ __forceinline__ f32x4 mfma_sel(int abid, float a, float b, f32x4 c) {
-  switch (abid) {
-    case 0: return mfma_bcast<0>(a, b, c);
-    case 1: return mfma_bcast<1>(a, b, c);
-    case 2: return mfma_bcast<2>(a, b, c);
-    case 3: return mfma_bcast<3>(a, b, c);
-    case 4: return mfma_bcast<4>(a, b, c);
-    case 5: return mfma_bcast<5>(a, b, c);
-    case 6: return mfma_bcast<6>(a, b, c);
-    case 7: return mfma_bcast<7>(a, b, c);
-    case 8: return mfma_bcast<8>(a, b, c);
-    case 9: return mfma_bcast<9>(a, b, c);
-    case 10: return mfma_bcast<10>(a, b, c);
-    case 11: return mfma_bcast<11>(a, b, c);
-    case 12: return mfma_bcast<12>(a, b, c);
-    case 13: return mfma_bcast<13>(a, b, c);
-    case 14: return mfma_bcast<14>(a, b, c);
-    default: return mfma_bcast<15>(a, b, c);
-  }
-}
+// ---- layer formats -------------------------------------------------------------------------------
+enum Fmt { FMT_B4 = 0, FMT_CI = 1, FMT_PX = 2, FMT_TCI = 3, FMT_TPX = 4 };
 
 struct LayerCfg {
-  int coutb;   // output channels per block (multiple of 4)
-  int ck;      // input channels per LDS stage
-  int slices;  // ceil(cout / coutb)
-  int nv;      // A images (64-lane VGPRs) per (stage, tap)
-  int nstages;
+  int fmt;
+  int coutb;    // output channels per slice: 16 (CI, TCI), 8 (PX, TPX), 4 (B4)
+  int ck;       // input channels per LDS chunk
+  int slices;   // ceil(cout / coutb), blockIdx.z
+  int nstages;  // ceil(cin / ck)
+  int nw;       // weight floats per (slice, chunk)
 };
 
 inline bool layer_cfg(int kind, int cin, int cout, LayerCfg &c) {
   if (cin < 1 || cout < 1) return false;
   if (kind == CASMVS_CONV_S1) {
-    if (cout == 1) c.coutb = 4;
-    else if (cout == 8) c.coutb = 8;
-    else if (cout % 16 == 0) c.coutb = 16;
+    if (cout == 1) { c.fmt = FMT_B4; c.coutb = 4; c.ck = 8; c.nw = 27 * 64; }
+    else if (cout == 8) { c.fmt = FMT_PX; c.coutb = 8; c.ck = 4; c.nw = 9 * 4 * 64; }
+    else if (cout % 16 == 0) { c.fmt = FMT_CI; c.coutb = 16; c.ck = 8; c.nw = 27 * 2 * 64; }
     else return false;
-    c.ck = 8;
   } else if (kind == CASMVS_CONV_S2) {
     if (cout % 16 != 0) return false;
-    c.coutb = 16;
-    c.ck = 4;
+    c.fmt = FMT_CI; c.coutb = 16; c.ck = 4; c.nw = 27 * 1 * 64;
   } else if (kind == CASMVS_CONV_T2) {
-    if (cout == 8) c.coutb = 8;
-    else if (cout % 16 == 0) c.coutb = 16;
+    if (cout == 8) { c.fmt = FMT_TPX; c.coutb = 8; c.ck = 8; c.nw = 9 * 2 * 2 * 64; }
+    else if (cout % 16 == 0) { c.fmt = FMT_TCI; c.coutb = 16; c.ck = 8; c.nw = 27 * 2 * 64; }
     else return false;
-    c.ck = 8;
   } else {
     return false;
   }
   c.slices = (cout + c.coutb - 1) / c.coutb;
-  c.nv = (c.ck * (c.coutb / 4) + 15) / 16;
   c.nstages = (cin + c.ck - 1) / c.ck;
   return true;
 }
 
+// Value of lane `l` of A image `img` of chunk `stage`, slice `sl` (host side).
+inline float pack_weight(const LayerCfg &c, int kind, int cin, int cout, const float *w, int sl,
+                         int stage, int img, int l) {
+  auto conv_w = [&](int co, int ci, int tap) -> float {
+    if (co >= cout || ci >= cin || tap < 0) return 0.0f;
+    return kind == CASMVS_CONV_T2 ? w[((size_t)ci * cout + co) * 27 + tap]   // (cin, cout, 3,3,3)
+                                  : w[((size_t)co * cin + ci) * 27 + tap];  // (cout, cin, 3,3,3)
+  };
+  const int i = l & 15, k = l >> 4;
+  switch (c.fmt) {
+    case FMT_B4: {  // img = tap; lane: block n = l / 4 = local input channel, row l % 4 = co
+      const int cil = l / 4, co = l % 4;
+      return cil < c.ck ? conv_w(co, stage * c.ck + cil, img) : 0.0f;
+    }
+    case FMT_CI:     // img = tap * (ck/4) + ciq; row i = co, k = input channel of the quad
+    case FMT_TCI: {
+      const int nq = c.ck / 4, tap = img / nq, ciq = img % nq;
+      return conv_w(sl * 16 + i, stage * c.ck + ciq * 4 + k, tap);
+    }
+    case FMT_PX: {   // img = (kz*3+ky) * ck + cil; row i = (co, s), k = x-offset u, kx = u - s
+      const int r9 = img / c.ck, cil = img % c.ck;
+      const int co = i >> 1, s = i & 1, kx = k - s;
+      return (kx >= 0 && kx <= 2) ? conv_w(co, stage * c.ck + cil, r9 * 3 + kx) : 0.0f;
+    }
+    case FMT_TPX: {  // img = ((kz*3+ky) * 2 + dx) * (ck/4) + ciq; row i = (co, px), k = ci
+      const int nq = c.ck / 4, ciq = img % nq, dx = (img / nq) % 2, r9 = img / (2 * nq);
+      const int co = i >> 1, px = i & 1;
+      // even output x = 2m takes (kx = 1, cell m); odd x = 2m+1 takes (kx = 2, m), (kx = 0, m+1)
+      const int kx = dx == 0 ? (px == 0 ? 1 : 2) : (px == 1 ? 0 : -1);
+      return kx >= 0 ? conv_w(co, stage * c.ck + ciq * 4 + k, r9 * 3 + kx) : 0.0f;
+    }
+  }
+  return 0.0f;
+}
 
 // ---- staging: global -> registers -> LDS, software-pipelined one chunk ahead -------------------
 // A chunk = CK input channels of the zero-padded halo tile (CK*IZ planes of IY*IX floats) plus
-// the chunk's 27*NV weight images.  A thread copies the same NPASS in-plane positions of every
+// the chunk's NW weight floats.  A thread copies the same NPASS in-plane positions of every
 // plane, so the (iy, ix) decode, the bounds tests and the in-plane global offset are computed
 // ONCE per kernel (StagePlan); a plane then costs one add + load per position.  The loads of
 // chunk s+1 are issued right after the barrier that publishes chunk s and land in registers
-// while the MFMA loop of chunk s runs (5-6 us of cover for ~2 us of L2/HBM latency); they are
-// written to LDS after the next barrier.  Weights go through LDS too, so that the MFMA loop
-// contains no vector-memory instruction (an in-loop global load would make the compiler's
-// in-order vmcnt wait drain the whole prefetch at the first tap).
+// while the MFMA loop of chunk s runs; they are written to LDS after the next barrier.  Weights
+// go through LDS too, so that the MFMA loop contains no vector-memory instruction (an in-loop
+// global load would make the compiler's in-order vmcnt wait drain the whole prefetch).
 template <int IY, int IX>
 struct StagePlan {
   static constexpr int PLANE = IY * IX;
@@ -138,14 +156,14 @@ struct StagePlan {
   }
 };
 
-template <int CK, int IZ, int IY, int IX, int NW>
+template <int CK, int IZ, int IY, int IX, int SC, int NW>
 struct StageRegs {
-  static constexpr int NPL = CK * IZ, NPASS = StagePlan<IY, IX>::NPASS;
+  static constexpr int NPL = CK * IZ, NPASS = StagePlan<IY, IX>::NPASS, PLANE = IY * IX;
   static constexpr int NWR = (NW + kThreads - 1) / kThreads;
   float v[NPL][NPASS];
   float w[NWR];
 
-  // issue every load of chunk `ci0 / CK`; nothing here waits
+  // issue every load of the chunk that starts at input channel ci0; nothing here waits
   __device__ __forceinline__ void load(const StagePlan<IY, IX> &plan, const float *__restrict__ inb,
                                        size_t in_cs, int cin, int ci0, int iz0, int Di, int HiWi,
                                        const float *__restrict__ wchunk, const float *__restrict__ zero) {
@@ -172,48 +190,62 @@ struct StageRegs {
     }
   }
 
+  // tile layout: [cil][iz][iy][ix] with channel stride SC (>= IZ*PLANE, padded for the banks)
   __device__ __forceinline__ void store(float *tile, float *wts) const {
-    constexpr int PLANE = IY * IX;
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
       const int e = threadIdx.x + i * kThreads;
       if (e < NW) wts[e] = w[i];
     }
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
+    for (int pl = 0; pl < NPL; ++pl) {
+      const int cil = pl / IZ, iz = pl - cil * IZ;
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         const int pe = threadIdx.x + p * kThreads;
-        if (pe < PLANE) tile[pl * PLANE + pe] = v[pl][p];
+        if (pe < PLANE) tile[cil * SC + iz * PLANE + pe] = v[pl][p];
       }
+    }
   }
 };
 
-// ---- Conv3d k3 p1, stride 1 or 2 -------------------------------------------------------------
-template <int STRIDE, int COUTB, int CK, int G, int TZ, int TY, int TX>
-struct ConvCfg {
-  static constexpr int Q = COUTB / 4;
-  static constexpr int NV = (CK * Q + 15) / 16;
+constexpr int round_up_to_16_mod_32(int x) { return x + ((16 - x % 32) + 32) % 32; }
+
+// ---- Conv3d k3 p1 (stride 1 or 2) on 16x16x4 ----------------------------------------------------
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
+struct Conv16Cfg {
+  static_assert(MODE == FMT_CI || MODE == FMT_PX, "conv16: CI or PX");
+  static constexpr int XW = MODE == FMT_PX ? 32 : 16;  // output voxels along x per column tile
+  static constexpr int NXG = TX / XW;
+  static_assert(TX % XW == 0 && TZ * TY * NXG == 4 * NT, "tile = 4 waves x NT column tiles");
   static constexpr int IZ = STRIDE * (TZ - 1) + 3, IY = STRIDE * (TY - 1) + 3, IX = STRIDE * (TX - 1) + 3;
-  static constexpr int SY = IX, SZ = IY * SY, SC = IZ * SZ;
-  static constexpr int NW = 27 * NV * 64;                       // weight floats per chunk
+  static constexpr int SY = IX, SZ = IY * IX;
+  // channel stride: B lanes k = 0..3 read 4 channels (CI) -> k * SC must land on disjoint banks:
+  // stride 1: 16 consecutive words per k -> SC == 16 (mod 32); stride 2: even words -> SC odd.
+  static constexpr int SC = MODE == FMT_PX ? IZ * SZ
+                            : (STRIDE == 1 ? round_up_to_16_mod_32(IZ * SZ) : (IZ * SZ) | 1);
+  static constexpr int NA = MODE == FMT_PX ? CK : CK / 4;      // A images per iteration
+  static constexpr int NITER = MODE == FMT_PX ? 9 : 27;        // (kz,ky) | (kz,ky,kx)
+  static constexpr int ASTEP = MODE == FMT_PX ? SC : 4 * SC;   // B offset between A images
+  static constexpr int NW = NITER * NA * 64;
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
 
-template <int STRIDE, int COUTB, int CK, int G, int TZ, int TY, int TX>
-__global__ __launch_bounds__(kThreads) void conv3d_kernel(
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
+__global__ __launch_bounds__(kThreads) void conv16_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
     int nstages, int tiles_x, int tiles_y, float slope) {
-  static_assert(TZ * TY * TX == 4 * G * 64, "tile must hold 4 waves x G groups x 64 voxels");
-  using Cfg = ConvCfg<STRIDE, COUTB, CK, G, TZ, TY, TX>;
-  constexpr int Q = Cfg::Q, NV = Cfg::NV, IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX;
-  constexpr int SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, NW = Cfg::NW;
+  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX>;
+  constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
+  constexpr int NA = Cfg::NA, NITER = Cfg::NITER, ASTEP = Cfg::ASTEP, NW = Cfg::NW, NXG = Cfg::NXG;
+  constexpr int COUTB = MODE == FMT_PX ? 8 : 16;
   extern __shared__ float smem[];
-  float *tile = smem;            // [CK][IZ][IY][IX]
-  float *wts = smem + CK * SC;   // [27][NV][64]
+  float *tile = smem;            // [CK][IZ][IY][IX], channel stride SC
+  float *wts = smem + CK * SC;   // [NITER][NA][64]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jcol = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
   const int tx0 = (bid % tiles_x) * TX;
   const int ty0 = ((bid / tiles_x) % tiles_y) * TY;
@@ -221,41 +253,43 @@ __global__ __launch_bounds__(kThreads) void conv3d_kernel(
   const int b = blockIdx.y, slice = blockIdx.z;
   const int slices = gridDim.z;
 
-  int base[G], vx[G], vy[G], vz[G];
+  // column tile t of this wave -> (cz, cy, cx) inside the block tile and the lane's LDS base
+  int base[NT];
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int v = (wave * G + g) * 64 + lane;
-    vx[g] = v % TX;
-    vy[g] = (v / TX) % TY;
-    vz[g] = v / (TX * TY);
-    base[g] = vz[g] * STRIDE * SZ + vy[g] * STRIDE * SY + vx[g] * STRIDE;
+  for (int t = 0; t < NT; ++t) {
+    const int ct = wave * NT + t;
+    const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
+    if (MODE == FMT_PX) base[t] = cz * SZ + cy * SY + cx * 32 + 2 * jcol + kq;                   // k = x-offset u
+    else base[t] = kq * SC + (cz * STRIDE) * SZ + (cy * STRIDE) * SY + (cx * 16 + jcol) * STRIDE;  // k = channel
   }
-  f32x4 acc[G][Q];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int q = 0; q < Q; ++q) acc[g][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const size_t in_cs = (size_t)Di * Hi * Wi;  // input channel stride
   const float *inb = in + (size_t)b * cin * in_cs;
   const int iz0 = tz0 * STRIDE - 1, iy0 = ty0 * STRIDE - 1, ix0 = tx0 * STRIDE - 1;
-  const int T = nstages * 27;
-  const float *wslice = wpk + (size_t)slice * T * NV * 64;
-  const float *zero = wpk + (size_t)slices * T * NV * 64 + 2 * slices * COUTB;  // 64 zero floats
+  const float *wslice = wpk + (size_t)slice * nstages * NW;
+  const float *scale = wpk + (size_t)slices * nstages * NW + slice * COUTB;
+  const float *shift = scale + slices * COUTB;
+  const float *zero = wpk + (size_t)slices * nstages * NW + 2 * slices * COUTB;  // 64 zero floats
 
-  // MFMA loop of one chunk, written out in issue order and pinned with sched_barrier: within a
-  // tap, item i = (c, g) needs one B operand (ds_read_b32, immediate offset c * SC) and feeds Q
-  // MFMAs.  The read of item i + P is issued right before the MFMAs of item i (wrapping into the
-  // next tap), so P items (>= 128 MFMA cycles) of LDS latency are always covered and the waitcnt
-  // pass emits counted lgkmcnt waits instead of draining after every read.  The A images of the
-  // next tap are read from LDS a whole tap ahead.
-  constexpr int NI = CK * G;                // items per tap
-  constexpr int P = NI < 8 ? NI : 8;        // read-ahead distance (items)
-  auto tap_off = [&](int tap) -> int { return (tap / 9) * SZ + ((tap / 3) % 3) * SY + (tap % 3); };
+  // MFMA loop of one chunk, written out in issue order and pinned with sched_barrier.  Step
+  // s = (a, t) of an iteration needs one B operand (ds_read_b32, immediate offset a * ASTEP) and
+  // feeds one MFMA.  The read of step s + P is issued right before the MFMA of step s (wrapping
+  // into the next iteration), so P * 32 MFMA cycles of LDS latency are always covered and the
+  // waitcnt pass emits counted lgkmcnt waits.  The A images of the next iteration are read a
+  // whole iteration ahead.
+  constexpr int NS = NA * NT;              // steps per iteration
+  constexpr int P = NS % 8 == 0 ? 8 : (NS % 4 == 0 ? 4 : NS);  // read-ahead distance (steps)
+  static_assert(NS % P == 0, "ring slots must line up across iterations");
+  auto it_off = [&](int it) -> int {
+    return MODE == FMT_PX ? (it / 3) * SZ + (it % 3) * SY : (it / 9) * SZ + ((it / 3) % 3) * SY + (it % 3);
+  };
 
   StagePlan<IY, IX> plan;
   plan.init(iy0, ix0, Hi, Wi);
-  StageRegs<CK, IZ, IY, IX, NW> regs;
+  StageRegs<CK, IZ, IY, IX, SC, NW> regs;
   regs.load(plan, inb, in_cs, cin, 0, iz0, Di, Hi * Wi, wslice, zero);
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();  // every wave is done reading the previous chunk
@@ -264,96 +298,127 @@ __global__ __launch_bounds__(kThreads) void conv3d_kernel(
     if (s + 1 < nstages)  // prefetch the next chunk; consumed after the next barrier
       regs.load(plan, inb, in_cs, cin, (s + 1) * CK, iz0, Di, Hi * Wi, wslice + (size_t)(s + 1) * NW, zero);
 
-    float a_cur[NV], a_nxt[NV];
+    float a_cur[NA], a_nxt[NA];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) a_cur[j] = wts[j * 64 + lane];
-    int ad_c[G], ad_n[G];  // per-group LDS word address of the current / next tap
+    for (int a = 0; a < NA; ++a) a_cur[a] = wts[a * 64 + lane];
+    int ad_c[NT], ad_n[NT];  // per-tile LDS word address of the current / next iteration
 #pragma unroll
-    for (int g = 0; g < G; ++g) ad_c[g] = base[g];  // tap 0: offset 0
+    for (int t = 0; t < NT; ++t) ad_c[t] = base[t];  // iteration 0: offset 0
     float ring[P];
 #pragma unroll
-    for (int i = 0; i < P; ++i) ring[i] = tile[ad_c[i % G] + (i / G) * SC];
-    for (int tap = 0; tap < 27; ++tap) {
-      const int tapn = tap < 26 ? tap + 1 : 26;  // last tap: harmless re-read
+    for (int i = 0; i < P; ++i) ring[i] = tile[ad_c[i % NT] + (i / NT) * ASTEP];
+    for (int it = 0; it < NITER; ++it) {
+      const int itn = it < NITER - 1 ? it + 1 : NITER - 1;  // last iteration: harmless re-read
 #pragma unroll
-      for (int j = 0; j < NV; ++j) a_nxt[j] = wts[(tapn * NV + j) * 64 + lane];
-      const int toff_n = tap_off(tapn);
+      for (int a = 0; a < NA; ++a) a_nxt[a] = wts[(itn * NA + a) * 64 + lane];
+      const int off_n = it_off(itn);
 #pragma unroll
-      for (int g = 0; g < G; ++g) ad_n[g] = base[g] + toff_n;
+      for (int t = 0; t < NT; ++t) ad_n[t] = base[t] + off_n;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int c = i / G, g = i % G;
+      for (int i = 0; i < NS; ++i) {
+        const int a = i / NT, t = i % NT;
         const float bcur = ring[i % P];
         const int ii = i + P;
-        if (ii < NI) ring[i % P] = tile[ad_c[ii % G] + (ii / G) * SC];
-        else ring[i % P] = tile[ad_n[(ii - NI) % G] + ((ii - NI) / G) * SC];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-          const int n = c * Q + q;
-          acc[g][q] = mfma_sel(n % 16, a_cur[n / 16], bcur, acc[g][q]);
-        }
+        if (ii < NS) ring[i % P] = tile[ad_c[ii % NT] + (ii / NT) * ASTEP];
+        else ring[i % P] = tile[ad_n[(ii - NS) % NT] + ((ii - NS) / NT) * ASTEP];
+        acc[t] = mfma16(a_cur[a], bcur, acc[t]);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int j = 0; j < NV; ++j) a_cur[j] = a_nxt[j];
+      for (int a = 0; a < NA; ++a) a_cur[a] = a_nxt[a];
 #pragma unroll
-      for (int g = 0; g < G; ++g) ad_c[g] = ad_n[g];
+      for (int t = 0; t < NT; ++t) ad_c[t] = ad_n[t];
     }
   }
 
-  // epilogue: y = lrelu(acc * scale + shift) (+ skip)
-  const float *scale = wpk + (size_t)slices * T * NV * 64 + slice * COUTB;
-  const float *shift = scale + slices * COUTB;
+  // epilogue: y = lrelu(acc * scale + shift) (+ skip); lane holds rows 4*kq + r of column jcol
   const size_t out_cs = (size_t)Do * Ho * Wo;
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int oz = tz0 + vz[g], oy = ty0 + vy[g], ox = tx0 + vx[g];
-    if (oz >= Do || oy >= Ho || ox >= Wo) continue;
-    const size_t vo = ((size_t)oz * Ho + oy) * Wo + ox;
+  for (int t = 0; t < NT; ++t) {
+    const int ct = wave * NT + t;
+    const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
+    const int oz = tz0 + cz, oy = ty0 + cy;
+    if (oz >= Do || oy >= Ho) continue;
+    if (MODE == FMT_PX) {
+      const int ox = tx0 + cx * 32 + 2 * jcol;  // rows (co, s): r = 2 * h + s
+      if (ox >= Wo) continue;
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+      for (int h = 0; h < 2; ++h) {
+        const int co = 2 * kq + h;
+        float v0 = fmaf(acc[t][2 * h], scale[co], shift[co]);
+        float v1 = fmaf(acc[t][2 * h + 1], scale[co], shift[co]);
+        v0 = v0 > 0.0f ? v0 : v0 * slope;
+        v1 = v1 > 0.0f ? v1 : v1 * slope;
+        const size_t o = ((size_t)b * cout + co) * out_cs + ((size_t)oz * Ho + oy) * Wo + ox;
+        if ((Wo & 1) == 0) {  // ox even and Wo even: 8-byte aligned pair, both in range
+          if (skip) {
+            const f32x2 sk = *reinterpret_cast<const f32x2 *>(skip + o);
+            v0 += sk[0];
+            v1 += sk[1];
+          }
+          *reinterpret_cast<f32x2 *>(out + o) = f32x2{v0, v1};
+        } else {
+          if (skip) v0 += skip[o];
+          out[o] = v0;
+          if (ox + 1 < Wo) {
+            if (skip) v1 += skip[o + 1];
+            out[o + 1] = v1;
+          }
+        }
+      }
+    } else {
+      const int ox = tx0 + cx * 16 + jcol;
+      if (ox >= Wo) continue;
+      const size_t vo = ((size_t)oz * Ho + oy) * Wo + ox;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int col = 4 * q + r, co = slice * COUTB + col;
+        const int col = 4 * kq + r, co = slice * 16 + col;
         if (co < cout) {
-          float v = fmaf(acc[g][q][r], scale[col], shift[col]);
+          float v = fmaf(acc[t][r], scale[col], shift[col]);
           v = v > 0.0f ? v : v * slope;
           const size_t o = ((size_t)b * cout + co) * out_cs + vo;
           if (skip) v += skip[o];
           out[o] = v;
         }
       }
+    }
   }
 }
 
-// ---- ConvTranspose3d k3 s2 p1 op1 --------------------------------------------------------------
+// ---- ConvTranspose3d k3 s2 p1 op1 on 16x16x4 -------------------------------------------------------
 // out[2i - 1 + k] += in[i] * w[k] per axis: even outputs o = 2m take (k = 1, i = m); odd outputs
-// o = 2m + 1 take (k = 2, i = m) and (k = 0, i = m + 1).  Each lane owns one input cell m and
-// produces the two x-parities of output row (2mz + pz, 2my + py); (pz, py) comes from blockIdx.
-template <int COUTB, int CK, int TZ, int TY, int TX>
-struct DeconvCfg {
-  static constexpr int Q = COUTB / 4;
-  static constexpr int NV = (CK * Q + 15) / 16;
+// o = 2m + 1 take (k = 2, i = m) and (k = 0, i = m + 1).  A column tile is 16 input cells m along
+// x; a workgroup produces output rows (2mz + pz, 2my + py) with (pz, py) from blockIdx, and both
+// x parities: TCI keeps two accumulators (rows = 16 channels), TPX folds the parity into the rows.
+template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+struct Deconv16Cfg {
+  static_assert(MODE == FMT_TCI || MODE == FMT_TPX, "deconv16: TCI or TPX");
+  static constexpr int NXG = TX / 16;
+  static_assert(TX % 16 == 0 && TZ * TY * NXG == 4 * NT, "tile = 4 waves x NT column tiles");
   static constexpr int IZ = TZ + 1, IY = TY + 1, IX = TX + 1;
-  static constexpr int SY = IX, SZ = IY * SY, SC = IZ * SZ;
-  static constexpr int NW = 27 * NV * 64;
+  static constexpr int SY = IX, SZ = IY * IX;
+  static constexpr int SC = round_up_to_16_mod_32(IZ * SZ);
+  static constexpr int NQ = CK / 4;
+  static constexpr int NW = MODE == FMT_TCI ? 27 * NQ * 64 : 9 * 2 * NQ * 64;
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
 
-template <int COUTB, int CK, int TZ, int TY, int TX>
-__global__ __launch_bounds__(kThreads) void deconv3d_kernel(
+template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+__global__ __launch_bounds__(kThreads) void deconv16_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int cin, int cout, int Di, int Hi, int Wi, int nstages, int tiles_x,
     int tiles_y, int ntiles, float slope) {
-  static_assert(TZ * TY * TX == 256, "tile must hold 4 waves x 64 cells");
-  using Cfg = DeconvCfg<COUTB, CK, TZ, TY, TX>;
-  constexpr int Q = Cfg::Q, NV = Cfg::NV, IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX;
-  constexpr int SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, NW = Cfg::NW;
+  using Cfg = Deconv16Cfg<MODE, CK, NT, TZ, TY, TX>;
+  constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
+  constexpr int NQ = Cfg::NQ, NW = Cfg::NW, NXG = Cfg::NXG;
+  constexpr int COUTB = MODE == FMT_TPX ? 8 : 16;
+  constexpr int NACC = MODE == FMT_TCI ? 2 : 1;
   extern __shared__ float smem[];
   float *tile = smem;
   float *wts = smem + CK * SC;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jcol = lane & 15, kq = lane >> 4;
   const int pass = blockIdx.x / ntiles, bid = blockIdx.x - pass * ntiles;
   const int pz = pass >> 1, py = pass & 1;
   const int tx0 = (bid % tiles_x) * TX;
@@ -362,23 +427,29 @@ __global__ __launch_bounds__(kThreads) void deconv3d_kernel(
   const int b = blockIdx.y, slice = blockIdx.z;
   const int slices = gridDim.z;
 
-  const int v = wave * 64 + lane;
-  const int vx = v % TX, vy = (v / TX) % TY, vz = v / (TX * TY);
-  const int base = vz * SZ + vy * SY + vx;
-
-  f32x4 acc0[Q], acc1[Q];  // x parity 0 / 1
+  int base[NT];
 #pragma unroll
-  for (int q = 0; q < Q; ++q) acc0[q] = acc1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) {
+    const int ct = wave * NT + t;
+    const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
+    base[t] = kq * SC + cz * SZ + cy * SY + cx * 16 + jcol;
+  }
+  f32x4 acc[NACC][NT];  // TCI: [x parity][tile]; TPX: [0][tile] with rows (co, px)
+#pragma unroll
+  for (int p = 0; p < NACC; ++p)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const size_t in_cs = (size_t)Di * Hi * Wi;
   const float *inb = in + (size_t)b * cin * in_cs;
-  const int T = nstages * 27;
-  const float *wslice = wpk + (size_t)slice * T * NV * 64;
-  const float *zero = wpk + (size_t)slices * T * NV * 64 + 2 * slices * COUTB;  // 64 zero floats
+  const float *wslice = wpk + (size_t)slice * nstages * NW;
+  const float *scale = wpk + (size_t)slices * nstages * NW + slice * COUTB;
+  const float *shift = scale + slices * COUTB;
+  const float *zero = wpk + (size_t)slices * nstages * NW + 2 * slices * COUTB;
   const int nzt = pz ? 2 : 1, nyt = py ? 2 : 1;
   StagePlan<IY, IX> plan;
   plan.init(ty0, tx0, Hi, Wi);
-  StageRegs<CK, IZ, IY, IX, NW> regs;
+  StageRegs<CK, IZ, IY, IX, SC, NW> regs;
   regs.load(plan, inb, in_cs, cin, 0, tz0, Di, Hi * Wi, wslice, zero);
 
   for (int s = 0; s < nstages; ++s) {
@@ -391,76 +462,211 @@ __global__ __launch_bounds__(kThreads) void deconv3d_kernel(
       const int kz = pz ? (zt == 0 ? 2 : 0) : 1, dz = (pz && zt == 1) ? 1 : 0;
       for (int yt = 0; yt < nyt; ++yt) {
         const int ky = py ? (yt == 0 ? 2 : 0) : 1, dy = (py && yt == 1) ? 1 : 0;
-        const int tap0 = (kz * 3 + ky) * 3;  // kx = 0, 1, 2 follow
-        float a0[NV], a1[NV], a2[NV];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          a0[j] = wts[((tap0 + 0) * NV + j) * 64 + lane];
-          a1[j] = wts[((tap0 + 1) * NV + j) * 64 + lane];
-          a2[j] = wts[((tap0 + 2) * NV + j) * 64 + lane];
-        }
+        const int r9 = kz * 3 + ky;
         const int toff = dz * SZ + dy * SY;
-        float b0[CK], b1[CK];
 #pragma unroll
-        for (int c = 0; c < CK; ++c) {
-          b0[c] = tile[c * SC + base + toff];
-          b1[c] = tile[c * SC + base + toff + 1];
+        for (int q = 0; q < NQ; ++q) {
+          float b0[NT], b1[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            b0[t] = tile[base[t] + toff + q * 4 * SC];      // cell m
+            b1[t] = tile[base[t] + toff + q * 4 * SC + 1];  // cell m + 1
+          }
+          if (MODE == FMT_TCI) {
+            const float a0 = wts[((r9 * 3 + 0) * NQ + q) * 64 + lane];
+            const float a1 = wts[((r9 * 3 + 1) * NQ + q) * 64 + lane];
+            const float a2 = wts[((r9 * 3 + 2) * NQ + q) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              acc[0][t] = mfma16(a1, b0[t], acc[0][t]);                // px = 0: k = 1, i = m
+              acc[NACC - 1][t] = mfma16(a2, b0[t], acc[NACC - 1][t]);  // px = 1: k = 2, i = m
+              acc[NACC - 1][t] = mfma16(a0, b1[t], acc[NACC - 1][t]);  // px = 1: k = 0, i = m + 1
+            }
+          } else {
+            const float ad0 = wts[((r9 * 2 + 0) * NQ + q) * 64 + lane];
+            const float ad1 = wts[((r9 * 2 + 1) * NQ + q) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              acc[0][t] = mfma16(ad0, b0[t], acc[0][t]);
+              acc[0][t] = mfma16(ad1, b1[t], acc[0][t]);
+            }
+          }
         }
-        static_for<CK>([&](auto c_) {
-          constexpr int c = decltype(c_)::value;
-          static_for<Q>([&](auto q_) {
-            constexpr int q = decltype(q_)::value;
-            constexpr int n = c * Q + q;
-            acc0[q] = mfma_bcast<n % 16>(a1[n / 16], b0[c], acc0[q]);  // px = 0: k = 1, i = m
-            acc1[q] = mfma_bcast<n % 16>(a2[n / 16], b0[c], acc1[q]);  // px = 1: k = 2, i = m
-            acc1[q] = mfma_bcast<n % 16>(a0[n / 16], b1[c], acc1[q]);  // px = 1: k = 0, i = m + 1
-          });
-        });
       }
     }
   }
 
-  const float *scale = wpk + (size_t)slices * T * NV * 64 + slice * COUTB;
-  const float *shift = scale + slices * COUTB;
-  const int mz = tz0 + vz, my = ty0 + vy, mx = tx0 + vx;
-  if (mz >= Di || my >= Hi || mx >= Wi) return;
   const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
   const size_t out_cs = (size_t)Do * Ho * Wo;
-  const size_t vo = ((size_t)(2 * mz + pz) * Ho + (2 * my + py)) * Wo + 2 * mx;
 #pragma unroll
-  for (int q = 0; q < Q; ++q)
+  for (int t = 0; t < NT; ++t) {
+    const int ct = wave * NT + t;
+    const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
+    const int mz = tz0 + cz, my = ty0 + cy, mx = tx0 + cx * 16 + jcol;
+    if (mz >= Di || my >= Hi || mx >= Wi) continue;
+    const size_t vo = ((size_t)(2 * mz + pz) * Ho + (2 * my + py)) * Wo + 2 * mx;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int col = 4 * q + r, co = slice * COUTB + col;
-      if (co < cout) {
-        float v0 = fmaf(acc0[q][r], scale[col], shift[col]);
-        float v1 = fmaf(acc1[q][r], scale[col], shift[col]);
-        v0 = v0 > 0.0f ? v0 : v0 * slope;
-        v1 = v1 > 0.0f ? v1 : v1 * slope;
-        const size_t o = ((size_t)b * cout + co) * out_cs + vo;
-        if (skip) {
-          const f32x2 sk = *reinterpret_cast<const f32x2 *>(skip + o);
-          v0 += sk[0];
-          v1 += sk[1];
-        }
-        *reinterpret_cast<f32x2 *>(out + o) = f32x2{v0, v1};
+    for (int h = 0; h < (MODE == FMT_TCI ? 4 : 2); ++h) {
+      // TCI: h = row r -> channel 4*kq + r, pair = (parity 0, parity 1) accumulators
+      // TPX: h -> channel 2*kq + h, pair = rows (2h, 2h+1) of the single accumulator
+      const int col = MODE == FMT_TCI ? 4 * kq + h : 2 * kq + h;
+      const int co = slice * COUTB + col;
+      if (co >= cout) continue;
+      float v0 = MODE == FMT_TCI ? acc[0][t][h] : acc[0][t][(2 * h) & 3];
+      float v1 = MODE == FMT_TCI ? acc[NACC - 1][t][h] : acc[0][t][(2 * h + 1) & 3];
+      v0 = fmaf(v0, scale[col], shift[col]);
+      v1 = fmaf(v1, scale[col], shift[col]);
+      v0 = v0 > 0.0f ? v0 : v0 * slope;
+      v1 = v1 > 0.0f ? v1 : v1 * slope;
+      const size_t o = ((size_t)b * cout + co) * out_cs + vo;
+      if (skip) {
+        const f32x2 sk = *reinterpret_cast<const f32x2 *>(skip + o);
+        v0 += sk[0];
+        v1 += sk[1];
       }
+      *reinterpret_cast<f32x2 *>(out + o) = f32x2{v0, v1};
     }
+  }
 }
 
-// ---- MFMA lane-mapping probe ---------------------------------------------------------------------
+// ---- `prob` head (Cout = 1) on the 4x4x1 broadcast form --------------------------------------------
+// Each LANE owns one output voxel; acc register r is output channel r (only r = 0 is real), the
+// B operand is the tap-shifted input value of the lane's voxel and ABID picks the input channel's
+// weight column out of the tap's 64-lane image.  Half-rate instruction, 1 of 4 rows useful: this
+// head is 2 % of the FLOPs and is slated to move to a VALU kernel fused with the softmax.
+template <int CK, int G, int TZ, int TY, int TX>
+struct ProbCfg {
+  static constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
+  static constexpr int SY = IX, SZ = IY * IX, SC = IZ * SZ;
+  static constexpr int NW = 27 * 64;
+  static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
+};
+
+template <int CK, int G, int TZ, int TY, int TX>
+__global__ __launch_bounds__(kThreads) void prob_kernel(
+    const float *__restrict__ in, const float *__restrict__ wpk, float *__restrict__ out, int cin,
+    int Di, int Hi, int Wi, int nstages, int tiles_x, int tiles_y, float slope) {
+  static_assert(TZ * TY * TX == 4 * G * 64 && CK == 8, "tile = 4 waves x G groups x 64 voxels");
+  using Cfg = ProbCfg<CK, G, TZ, TY, TX>;
+  constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, NW = Cfg::NW;
+  extern __shared__ float smem[];
+  float *tile = smem;
+  float *wts = smem + CK * SC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bid = blockIdx.x;
+  const int tx0 = (bid % tiles_x) * TX;
+  const int ty0 = ((bid / tiles_x) % tiles_y) * TY;
+  const int tz0 = (bid / (tiles_x * tiles_y)) * TZ;
+  const int b = blockIdx.y;
+  int base[G], vx[G], vy[G], vz[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int v = (wave * G + g) * 64 + lane;
+    vx[g] = v % TX;
+    vy[g] = (v / TX) % TY;
+    vz[g] = v / (TX * TY);
+    base[g] = vz[g] * SZ + vy[g] * SY + vx[g];
+  }
+  f32x4 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const size_t in_cs = (size_t)Di * Hi * Wi;
+  const float *inb = in + (size_t)b * cin * in_cs;
+  const float *scale = wpk + (size_t)nstages * NW;
+  const float *shift = scale + 4;
+  const float *zero = scale + 8;
+  StagePlan<IY, IX> plan;
+  plan.init(ty0 - 1, tx0 - 1, Hi, Wi);
+  StageRegs<CK, IZ, IY, IX, SC, NW> regs;
+  regs.load(plan, inb, in_cs, cin, 0, tz0 - 1, Di, Hi * Wi, wpk, zero);
+  for (int s = 0; s < nstages; ++s) {
+    __syncthreads();
+    regs.store(tile, wts);
+    __syncthreads();
+    if (s + 1 < nstages)
+      regs.load(plan, inb, in_cs, cin, (s + 1) * CK, tz0 - 1, Di, Hi * Wi, wpk + (size_t)(s + 1) * NW, zero);
+    for (int tap = 0; tap < 27; ++tap) {
+      const float a = wts[tap * 64 + lane];
+      const int toff = (tap / 9) * SZ + ((tap / 3) % 3) * SY + (tap % 3);
+      float bv[G][CK];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int c = 0; c < CK; ++c) bv[g][c] = tile[c * SC + base[g] + toff];
+      static_for<CK>([&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        static_for<G>([&](auto g_) {
+          constexpr int g = decltype(g_)::value;
+          acc[g] = mfma_bcast<c>(a, bv[g][c], acc[g]);
+        });
+      });
+    }
+  }
+  const size_t out_cs = in_cs;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int oz = tz0 + vz[g], oy = ty0 + vy[g], ox = tx0 + vx[g];
+    if (oz >= Di || oy >= Hi || ox >= Wi) continue;
+    float v = fmaf(acc[g][0], scale[0], shift[0]);
+    v = v > 0.0f ? v : v * slope;
+    out[(size_t)b * out_cs + ((size_t)oz * Hi + oy) * Wi + ox] = v;
+  }
+}
+
+// ---- MFMA probes ----------------------------------------------------------------------------------
+// Lane-mapping probe: D = A * B for A[i][k] = 1 + i + 16 k, B[k][j] = (1 + k) * (3 + j) on 16x16x4
+// (dump rows 0..3 = the 4 accumulator registers), then the 4x4x1 broadcast form with ABID 0/5/15.
 __global__ void mfma_probe_kernel(float *out) {
   const int lane = threadIdx.x;
-  const float a = (float)(lane + 1), b = (float)(100 + lane);
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  f32x4 d0 = mfma_bcast<0>(a, b, z), d5 = mfma_bcast<5>(a, b, z), d15 = mfma_bcast<15>(a, b, z);
-  f32x4 dn = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, z, 0, 0, 0);
+  const int i = lane & 15, k = lane >> 4;
+  const f32x4 d16 = mfma16((float)(1 + i + 16 * k), (float)((1 + k) * (3 + i)), z);
+  const float a = (float)(lane + 1), b = (float)(100 + lane);
+  const f32x4 d0 = mfma_bcast<0>(a, b, z), d5 = mfma_bcast<5>(a, b, z), d15 = mfma_bcast<15>(a, b, z);
   for (int r = 0; r < 4; ++r) {
-    out[(0 * 4 + r) * 64 + lane] = d0[r];
-    out[(1 * 4 + r) * 64 + lane] = d5[r];
-    out[(2 * 4 + r) * 64 + lane] = d15[r];
-    out[(3 * 4 + r) * 64 + lane] = dn[r];
+    out[(0 * 4 + r) * 64 + lane] = d16[r];
+    out[(1 * 4 + r) * 64 + lane] = d0[r];
+    out[(2 * 4 + r) * 64 + lane] = d5[r];
+    out[(3 * 4 + r) * 64 + lane] = d15[r];
   }
+}
+
+// Issue-rate probe: every wave runs `iters` x 16 MFMAs on 8 independent accumulators.
+template <int SHAPE>
+__global__ __launch_bounds__(kThreads) void mfma_rate_kernel(float *out, int iters) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
+  float s = 0.f;
+  if constexpr (SHAPE == 0 || SHAPE == 1) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if constexpr (SHAPE == 0) acc[i & 7] = mfma_bcast<1>(a, b, acc[i & 7]);
+        else acc[i & 7] = mfma16(a, b, acc[i & 7]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+  } else {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if constexpr (SHAPE == 2) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i & 3], 0, 0, 0);
+        else acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc[i & 3], 2, 1, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
+  }
+  if (s == 123.456f) out[0] = s;  // keep the chains live
 }
 
 // Kernels that need more than the default 64 KiB of LDS must opt in once per process.
@@ -476,35 +682,47 @@ int ensure_lds(K kernel, size_t bytes, const char *what) {
   return CASMVS_OK;
 }
 
-template <int STRIDE, int COUTB, int CK, int G, int TZ, int TY, int TX>
-int launch_conv(const LayerCfg &c, const float *packed, const float *in, const float *skip,
-                float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                float slope, hipStream_t st) {
-  using Cfg = ConvCfg<STRIDE, COUTB, CK, G, TZ, TY, TX>;
-  auto kernel = conv3d_kernel<STRIDE, COUTB, CK, G, TZ, TY, TX>;
-  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv3d_kernel")) return rc;
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
+int launch_conv16(const LayerCfg &c, const float *packed, const float *in, const float *skip,
+                  float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                  float slope, hipStream_t st) {
+  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX>;
+  auto kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX>;
+  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv16_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wo, TX), tiles_y = casmvs::ceil_div(Ho, TY),
             tiles_z = casmvs::ceil_div(Do, TZ);
   dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, (unsigned)c.slices);
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, cin, cout,
                      Di, Hi, Wi, Do, Ho, Wo, c.nstages, tiles_x, tiles_y, slope);
-  return casmvs::check_launch("conv3d_kernel");
+  return casmvs::check_launch("conv16_kernel");
 }
 
-template <int COUTB, int CK, int TZ, int TY, int TX>
-int launch_deconv(const LayerCfg &c, const float *packed, const float *in, const float *skip,
-                  float *out, int B, int cin, int cout, int Di, int Hi, int Wi, float slope,
-                  hipStream_t st) {
-  using Cfg = DeconvCfg<COUTB, CK, TZ, TY, TX>;
-  auto kernel = deconv3d_kernel<COUTB, CK, TZ, TY, TX>;
-  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "deconv3d_kernel")) return rc;
+template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+int launch_deconv16(const LayerCfg &c, const float *packed, const float *in, const float *skip,
+                    float *out, int B, int cin, int cout, int Di, int Hi, int Wi, float slope,
+                    hipStream_t st) {
+  using Cfg = Deconv16Cfg<MODE, CK, NT, TZ, TY, TX>;
+  auto kernel = deconv16_kernel<MODE, CK, NT, TZ, TY, TX>;
+  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "deconv16_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wi, TX), tiles_y = casmvs::ceil_div(Hi, TY),
             tiles_z = casmvs::ceil_div(Di, TZ);
   const int ntiles = tiles_x * tiles_y * tiles_z;
   dim3 grid((unsigned)(4 * ntiles), (unsigned)B, (unsigned)c.slices);
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, cin, cout,
                      Di, Hi, Wi, c.nstages, tiles_x, tiles_y, ntiles, slope);
-  return casmvs::check_launch("deconv3d_kernel");
+  return casmvs::check_launch("deconv16_kernel");
+}
+
+int launch_prob(const LayerCfg &c, const float *packed, const float *in, float *out, int B, int cin,
+                int D, int H, int W, float slope, hipStream_t st) {
+  using Cfg = ProbCfg<8, 4, 8, 4, 32>;
+  auto kernel = prob_kernel<8, 4, 8, 4, 32>;
+  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "prob_kernel")) return rc;
+  const int tiles_x = casmvs::ceil_div(W, 32), tiles_y = casmvs::ceil_div(H, 4), tiles_z = casmvs::ceil_div(D, 8);
+  dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, 1);
+  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, out, cin, D, H, W,
+                     c.nstages, tiles_x, tiles_y, slope);
+  return casmvs::check_launch("prob_kernel");
 }
 
 }  // namespace
@@ -512,7 +730,7 @@ int launch_deconv(const LayerCfg &c, const float *packed, const float *in, const
 extern "C" size_t casmvs_conv3d_packed_floats(int kind, int cin, int cout) {
   LayerCfg c;
   if (!layer_cfg(kind, cin, cout, c)) return 0;
-  return (size_t)c.slices * c.nstages * 27 * c.nv * 64 + 2 * (size_t)c.slices * c.coutb + 64;
+  return (size_t)c.slices * c.nstages * c.nw + 2 * (size_t)c.slices * c.coutb + 64;
 }
 
 extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *weight,
@@ -522,23 +740,12 @@ extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *
   LayerCfg c;
   if (!layer_cfg(kind, cin, cout, c))
     return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv3d_pack: kind=%d cin=%d cout=%d", kind, cin, cout);
-  const int Q = c.coutb / 4;
   float *p = packed;
+  const int nimg = c.nw / 64;
   for (int sl = 0; sl < c.slices; ++sl)
     for (int s = 0; s < c.nstages; ++s)
-      for (int tap = 0; tap < 27; ++tap)
-        for (int j = 0; j < c.nv; ++j)
-          for (int l = 0; l < 64; ++l) {
-            const int n = 16 * j + l / 4, i = l % 4;
-            const int cil = n / Q, q = n % Q;
-            const int ci = s * c.ck + cil, co = sl * c.coutb + 4 * q + i;
-            float w = 0.0f;
-            if (cil < c.ck && ci < cin && co < cout) {
-              w = (kind == CASMVS_CONV_T2) ? weight[((size_t)ci * cout + co) * 27 + tap]
-                                           : weight[((size_t)co * cin + ci) * 27 + tap];
-            }
-            *p++ = w;
-          }
+      for (int img = 0; img < nimg; ++img)
+        for (int l = 0; l < 64; ++l) *p++ = pack_weight(c, kind, cin, cout, weight, sl, s, img, l);
   const int cp = c.slices * c.coutb;
   for (int co = 0; co < cp; ++co) p[co] = (co < cout) ? (scale ? scale[co] : 1.0f) : 0.0f;
   for (int co = 0; co < cp; ++co) p[cp + co] = (co < cout) ? (shift ? shift[co] : 0.0f) : 0.0f;
@@ -555,21 +762,25 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
   LayerCfg c;
   if (!layer_cfg(kind, cin, cout, c))
     return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv3d_forward: kind=%d cin=%d cout=%d", kind, cin, cout);
+  CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 31), "conv3d_forward: one sample's input must hold < 2^31 floats");
   hipStream_t st = (hipStream_t)stream;
   if (kind == CASMVS_CONV_S1) {
-    if (c.coutb == 4) return launch_conv<1, 4, 8, 4, 8, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
-    if (c.coutb == 8) return launch_conv<1, 8, 8, 4, 8, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
-    // coutb == 16: large volumes use 512-voxel tiles, small (deep) volumes 256-voxel tiles
+    if (c.fmt == FMT_B4) {
+      CASMVS_REQUIRE(skip == nullptr, "conv3d_forward: the 1-channel head takes no skip input");
+      return launch_prob(c, packed, in, out, B, cin, D, H, W, slope, st);
+    }
+    if (c.fmt == FMT_PX) return launch_conv16<FMT_PX, 1, 4, 8, 8, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
+    // CI: large volumes use 32-column-tile workgroups, small (deep) volumes 16
     const long big_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 4) * c.slices * B;
-    if (big_blocks >= 1024) return launch_conv<1, 16, 8, 2, 4, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
-    return launch_conv<1, 16, 8, 1, 1, 16, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
+    if (big_blocks >= 1024) return launch_conv16<FMT_CI, 1, 8, 8, 4, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
+    return launch_conv16<FMT_CI, 1, 8, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
   }
   if (kind == CASMVS_CONV_S2) {
     CASMVS_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_forward(S2): odd input dims %dx%dx%d", D, H, W);
-    return launch_conv<2, 16, 4, 1, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
+    return launch_conv16<FMT_CI, 2, 4, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
   }
-  if (c.coutb == 8) return launch_deconv<8, 8, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
-  return launch_deconv<16, 8, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+  if (c.fmt == FMT_TPX) return launch_deconv16<FMT_TPX, 8, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+  return launch_deconv16<FMT_TCI, 8, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
 }
 
 extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
@@ -627,6 +838,39 @@ extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, con
   return CASMVS_OK;
 }
 
+extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float *tflops) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(shape >= 0 && shape <= 3 && blocks > 0 && iters > 0 && tflops, "selftest_mfma_rate: bad arguments");
+  float *d = nullptr;
+  hipEvent_t e0, e1;
+  if (hipMalloc(&d, 64) != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "selftest_mfma_rate: hipMalloc failed");
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  auto launch = [&](int n) {
+    switch (shape) {
+      case 0: hipLaunchKernelGGL(mfma_rate_kernel<0>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
+      case 1: hipLaunchKernelGGL(mfma_rate_kernel<1>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
+      case 2: hipLaunchKernelGGL(mfma_rate_kernel<2>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
+      default: hipLaunchKernelGGL(mfma_rate_kernel<3>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
+    }
+  };
+  launch(16);  // warm-up
+  (void)hipEventRecord(e0, 0);
+  launch(iters);
+  (void)hipEventRecord(e1, 0);
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d);
+  if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "selftest_mfma_rate: %s", hipGetErrorString(e));
+  const double flop_per_mfma[4] = {512.0, 2048.0, 4096.0, 2048.0};  // 4x4x1_16b, 16x16x4, 32x32x2, 16x16x1_4b
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 * flop_per_mfma[shape];
+  *tflops = (float)(flops / (ms * 1e-3) / 1e12);
+  return CASMVS_OK;
+}
+
 extern "C" int casmvs_selftest_mfma(float *dump) {
   casmvs::clear_error();
   float *d = nullptr;
@@ -639,12 +883,22 @@ extern "C" int casmvs_selftest_mfma(float *dump) {
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "selftest: %s", hipGetErrorString(e));
   if (dump)
     for (int i = 0; i < 16 * 64; ++i) dump[i] = h[i];
+  // 16x16x4: lane l reg r holds D[row = 4*(l>>4) + r][col = l&15], D = A * B
+  for (int r = 0; r < 4; ++r)
+    for (int l = 0; l < 64; ++l) {
+      const int row = 4 * (l >> 4) + r, col = l & 15;
+      float want = 0.f;
+      for (int k = 0; k < 4; ++k) want += (float)(1 + row + 16 * k) * (float)((1 + k) * (3 + col));
+      const float got = h[(0 * 4 + r) * 64 + l];
+      if (got != want)
+        return casmvs::fail(CASMVS_ERR_HIP, "selftest: mfma_16x16x4 reg=%d lane=%d: got %g want %g", r, l, got, want);
+    }
   const int abids[3] = {0, 5, 15};
   for (int k = 0; k < 3; ++k)
     for (int r = 0; r < 4; ++r)
       for (int l = 0; l < 64; ++l) {
         const float want = (float)(4 * abids[k] + r + 1) * (float)(100 + l);
-        const float got = h[(k * 4 + r) * 64 + l];
+        const float got = h[((k + 1) * 4 + r) * 64 + l];
         if (got != want)
           return casmvs::fail(CASMVS_ERR_HIP, "selftest: mfma_4x4x1 cbsz=4 abid=%d reg=%d lane=%d: got %g want %g", abids[k], r, l, got, want);
       }

@@ -187,3 +187,12 @@ def selftest_mfma():
     dump = torch.zeros(16 * 64, dtype=torch.float32)
     rc = _lib.load().casmvs_selftest_mfma(_ptr(dump))
     return rc, dump.view(4, 4, 64), _lib.load().casmvs_last_error().decode()
+
+
+def selftest_mfma_rate(shape=1, blocks=2048, iters=4096):
+    """Measured TFLOP/s of back-to-back fp32 MFMAs (shape 0: 4x4x1_16b, 1: 16x16x4, 2: 32x32x2,
+    3: 16x16x1_4b) - the ceilings the conv kernels are judged against."""
+    out = ctypes.c_float(0.0)
+    rc = _lib.load().casmvs_selftest_mfma_rate(shape, blocks, iters, ctypes.byref(out))
+    _lib.check(rc, "casmvs_selftest_mfma_rate")
+    return out.value

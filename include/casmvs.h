@@ -154,11 +154,16 @@ int casmvs_softmax_regress_f32(const float *cost, const float *depth_values, flo
                                void *stream);
 
 /* ---- self test ------------------------------------------------------------------------------
- * Runs the MFMA lane-mapping probe the conv kernels rely on (v_mfma_f32_4x4x1_16b_f32 with
- * A-block broadcast).  Returns 0 when the hardware semantics match the kernels' assumptions.
+ * Runs the MFMA lane-mapping probes the conv kernels rely on (v_mfma_f32_16x16x4_f32 operand /
+ * result layout, and v_mfma_f32_4x4x1_16b_f32 with A-block broadcast).  Returns 0 when the hardware semantics match the kernels' assumptions.
  * Needs a gfx950 device.  `dump` (host, 64*4*4 floats, may be NULL) receives raw probe outputs.
  */
 int casmvs_selftest_mfma(float *dump);
+
+/* Issue-rate probe: `blocks` workgroups x 4 wavefronts x `iters` x 16 back-to-back MFMAs on
+ * independent accumulators; writes the achieved TFLOP/s.
+ * shape: 0 = v_mfma_f32_4x4x1_16b_f32 (cbsz 4), 1 = 16x16x4_f32, 2 = 32x32x2_f32, 3 = 16x16x1_4b_f32. */
+int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float *tflops);
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,10 @@
 """Executable model (torch CPU) of the index logic of csrc/conv3d_mfma.hip: it consumes the PACKED
 parameter image produced by the C packer (casmvs_conv3d_pack_f32, pure host code) and walks the
-same (slice, stage, tap, c, q) -> (A image j, ABID) -> output-channel mapping and the same
-transposed-conv parity decomposition as the kernels, assuming the documented MFMA semantics
-    v_mfma_f32_4x4x1_16b_f32, CBSZ=4:  D[r][lane] += A[4*ABID + r] * B[lane].
+same (slice, chunk, image) -> (row, k) -> (output feature, contraction index) mapping and the same
+polyphase / transposed-conv parity decompositions as the kernels, assuming the documented MFMA
+semantics
+    v_mfma_f32_16x16x4_f32:  lane l supplies A[i = l & 15][k = l >> 4], D[row][col] += sum_k A[row][k] B[k][col]
+    v_mfma_f32_4x4x1_16b_f32, CBSZ = 4:  D[r][lane] += A[4*ABID + r] * B[lane].
 Used by the CPU tests to validate packing + indexing without a GPU (the GPU tests then validate
 the MFMA semantics themselves via casmvs_selftest_mfma and full parity).
 """
@@ -10,31 +12,29 @@ import torch
 import torch.nn.functional as F
 
 S1, S2, T2 = 0, 1, 2
+B4, CI, PX, TCI, TPX = 0, 1, 2, 3, 4
 
 
 def layer_cfg(kind, cin, cout):
     if kind == S1:
-        coutb = 4 if cout == 1 else 8 if cout == 8 else 16
-        ck = 8
+        fmt, coutb, ck, nw = (B4, 4, 8, 27 * 64) if cout == 1 else (PX, 8, 4, 9 * 4 * 64) if cout == 8 else (CI, 16, 8, 27 * 2 * 64)
     elif kind == S2:
-        coutb, ck = 16, 4
+        fmt, coutb, ck, nw = CI, 16, 4, 27 * 64
     else:
-        coutb, ck = (8 if cout == 8 else 16), 8
-    slices = (cout + coutb - 1) // coutb
-    nv = (ck * (coutb // 4) + 15) // 16
-    nstages = (cin + ck - 1) // ck
-    return coutb, ck, slices, nv, nstages
+        fmt, coutb, ck, nw = (TPX, 8, 8, 9 * 2 * 2 * 64) if cout == 8 else (TCI, 16, 8, 27 * 2 * 64)
+    return fmt, coutb, ck, (cout + coutb - 1) // coutb, (cin + ck - 1) // ck, nw
 
 
 def emulate(kind, packed, x, cout, skip=None, slope=0.01):
     B, cin, D, H, W = x.shape
-    coutb, ck, slices, nv, nstages = layer_cfg(kind, cin, cout)
-    Q = coutb // 4
-    T = nstages * 27
-    img = packed[: slices * T * nv * 64].reshape(slices, T, nv, 64)
-    scale = packed[slices * T * nv * 64: slices * T * nv * 64 + slices * coutb]
-    shift = packed[slices * T * nv * 64 + slices * coutb: slices * T * nv * 64 + 2 * slices * coutb]
-    assert float(packed[slices * T * nv * 64 + 2 * slices * coutb:].abs().sum()) == 0.0 and packed.numel() == slices * T * nv * 64 + 2 * slices * coutb + 64
+    fmt, coutb, ck, slices, nstages, nw = layer_cfg(kind, cin, cout)
+    nimg = nw // 64
+    body = slices * nstages * nw
+    assert packed.numel() == body + 2 * slices * coutb + 64
+    img = packed[:body].reshape(slices, nstages, nimg, 64).double()
+    scale = packed[body: body + slices * coutb].double()
+    shift = packed[body + slices * coutb: body + 2 * slices * coutb].double()
+    assert float(packed[body + 2 * slices * coutb:].abs().sum()) == 0.0
     if kind == T2:
         Do, Ho, Wo = 2 * D, 2 * H, 2 * W
     elif kind == S2:
@@ -43,24 +43,50 @@ def emulate(kind, packed, x, cout, skip=None, slope=0.01):
         Do, Ho, Wo = D, H, W
     acc = torch.zeros(B, slices * coutb, Do, Ho, Wo, dtype=torch.float64)
     xd = x.double()
-    if kind != T2:
+
+    def chan(xp, ci):  # staged tile: channels >= cin are zero-filled
+        return xp[:, ci] if ci < cin else torch.zeros_like(xp[:, 0])
+
+    if fmt == B4:
+        xp = F.pad(xd, (1, 1, 1, 1, 1, 1))
+        for s in range(nstages):
+            for tap in range(27):
+                kz, ky, kx = tap // 9, (tap // 3) % 3, tap % 3
+                a = img[0, s, tap]
+                for c in range(ck):  # ABID = c picks lanes 4c..4c+3 = rows (co 0..3) of channel c
+                    bval = chan(xp, s * ck + c)[:, kz:kz + D, ky:ky + H, kx:kx + W]
+                    for r in range(4):
+                        acc[:, r] += a[4 * c + r] * bval
+    elif fmt == CI:
         st = 1 if kind == S1 else 2
+        nq = ck // 4
         xp = F.pad(xd, (1, 1, 1, 1, 1, 1))
         for sl in range(slices):
             for s in range(nstages):
                 for tap in range(27):
                     kz, ky, kx = tap // 9, (tap // 3) % 3, tap % 3
-                    for c in range(ck):
-                        ci = s * ck + c
-                        if ci >= cin:
-                            continue  # the kernel multiplies staged zeros here
-                        bval = xp[:, ci, kz:kz + st * (Do - 1) + 1:st, ky:ky + st * (Ho - 1) + 1:st, kx:kx + st * (Wo - 1) + 1:st]
-                        for q in range(Q):
-                            n = c * Q + q
-                            a = img[sl, s * 27 + tap, n // 16].double()
-                            for r in range(4):
-                                acc[:, sl * coutb + 4 * q + r] += a[4 * (n % 16) + r] * bval
-    else:
+                    for q in range(nq):
+                        A = img[sl, s, tap * nq + q].reshape(4, 16)  # [k][i]
+                        for k in range(4):
+                            bval = chan(xp, s * ck + q * 4 + k)[:, kz:kz + st * (Do - 1) + 1:st, ky:ky + st * (Ho - 1) + 1:st,
+                                                                kx:kx + st * (Wo - 1) + 1:st]
+                            for i in range(16):
+                                acc[:, sl * 16 + i] += A[k, i] * bval
+    elif fmt == PX:
+        assert W % 2 == 0, "model handles even W only"
+        xp = F.pad(xd, (1, 3, 1, 1, 1, 1))
+        for s in range(nstages):
+            for r9 in range(9):
+                kz, ky = r9 // 3, r9 % 3
+                for c in range(ck):
+                    A = img[0, s, r9 * ck + c].reshape(4, 16)  # [u][i = 2*co + sx]
+                    plane = chan(xp, s * ck + c)[:, kz:kz + D, ky:ky + H]
+                    for u in range(4):
+                        bval = plane[..., u:u + W:2]  # in[x0 + 2j + u - 1], j = 0..W/2-1
+                        for i in range(16):
+                            acc[:, i >> 1, :, :, (i & 1)::2] += A[u, i] * bval
+    elif fmt in (TCI, TPX):
+        nq = ck // 4
         xp = F.pad(xd, (0, 1, 0, 1, 0, 1))  # cell m + 1 beyond the edge reads zero
         for sl in range(slices):
             for pz in (0, 1):
@@ -70,22 +96,24 @@ def emulate(kind, packed, x, cout, skip=None, slope=0.01):
                             kz, dz = ((2, 0) if zt == 0 else (0, 1)) if pz else (1, 0)
                             for yt in range(2 if py else 1):
                                 ky, dy = ((2, 0) if yt == 0 else (0, 1)) if py else (1, 0)
-                                tap0 = s * 27 + (kz * 3 + ky) * 3
-                                for c in range(ck):
-                                    ci = s * ck + c
-                                    if ci >= cin:
-                                        continue
-                                    b0 = xp[:, ci, dz:dz + D, dy:dy + H, 0:W]
-                                    b1 = xp[:, ci, dz:dz + D, dy:dy + H, 1:W + 1]
-                                    for q in range(Q):
-                                        n = c * Q + q
-                                        a0, a1, a2 = (img[sl, tap0 + k, n // 16].double() for k in range(3))
-                                        for r in range(4):
-                                            co = sl * coutb + 4 * q + r
-                                            w0, w1, w2 = (a[4 * (n % 16) + r] for a in (a0, a1, a2))
-                                            acc[:, co, pz::2, py::2, 0::2] += w1 * b0
-                                            acc[:, co, pz::2, py::2, 1::2] += w2 * b0 + w0 * b1
-    y = acc * scale.double().reshape(1, -1, 1, 1, 1) + shift.double().reshape(1, -1, 1, 1, 1)
+                                r9 = kz * 3 + ky
+                                for q in range(nq):
+                                    for k in range(4):
+                                        pl = chan(xp, s * ck + q * 4 + k)
+                                        b0 = pl[:, dz:dz + D, dy:dy + H, 0:W]
+                                        b1 = pl[:, dz:dz + D, dy:dy + H, 1:W + 1]
+                                        if fmt == TCI:
+                                            a0, a1, a2 = (img[sl, s, (r9 * 3 + kx) * nq + q].reshape(4, 16)[k] for kx in range(3))
+                                            for i in range(16):
+                                                co = sl * 16 + i
+                                                acc[:, co, pz::2, py::2, 0::2] += a1[i] * b0
+                                                acc[:, co, pz::2, py::2, 1::2] += a2[i] * b0 + a0[i] * b1
+                                        else:
+                                            ad0 = img[sl, s, (r9 * 2 + 0) * nq + q].reshape(4, 16)[k]
+                                            ad1 = img[sl, s, (r9 * 2 + 1) * nq + q].reshape(4, 16)[k]
+                                            for i in range(16):
+                                                acc[:, i >> 1, pz::2, py::2, (i & 1)::2] += ad0[i] * b0 + ad1[i] * b1
+    y = acc * scale.reshape(1, -1, 1, 1, 1) + shift.reshape(1, -1, 1, 1, 1)
     y = torch.where(y > 0, y, y * slope)[:, :cout]
     if skip is not None:
         y = y + skip.double()
