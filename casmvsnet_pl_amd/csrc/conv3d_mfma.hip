@@ -65,38 +65,45 @@ enum Fmt { FMT_B4 = 0, FMT_CI = 1, FMT_PX = 2, FMT_TCI = 3, FMT_TPX = 4 };
 
 struct LayerCfg {
   int fmt;
-  int coutb;    // output channels per slice: 16 (CI, TCI), 8 (PX, TPX), 4 (B4)
-  int ck;       // input channels per LDS chunk
-  int slices;   // ceil(cout / coutb), blockIdx.z
-  int nstages;  // ceil(cin / ck)
-  int nw;       // weight floats per (slice, chunk)
+  int coutb;        // output channels per slice: 16 (CI, TCI), 8 (PX, TPX), 4 (B4)
+  int slices;       // ceil(cout / coutb), blockIdx.z
+  int units;        // contraction units per slice (padded so that any kernel chunking stays in range)
+  int unit_floats;  // floats per unit
+  size_t per_slice() const { return (size_t)units * unit_floats; }
 };
 
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// The weight image of a slice is a sequence of contraction UNITS, so that a kernel may chunk the
+// input channels by any CK it likes (chunk s = units [s*CK/q, (s+1)*CK/q)):
+//   CI / TCI : unit = 4 input channels (one "ci quad"), 27 tap images     -> [quad][tap][64]
+//   PX       : unit = 1 input channel, 9 (kz,ky) images                   -> [ci][kz*3+ky][64]
+//   TPX      : unit = 4 input channels, 9 (kz,ky) x 2 (dx) images         -> [quad][kz*3+ky][dx][64]
+//   B4       : unit = 8 input channels, 27 tap images                     -> [chunk][tap][64]
 inline bool layer_cfg(int kind, int cin, int cout, LayerCfg &c) {
   if (cin < 1 || cout < 1) return false;
   if (kind == CASMVS_CONV_S1) {
-    if (cout == 1) { c.fmt = FMT_B4; c.coutb = 4; c.ck = 8; c.nw = 27 * 64; }
-    else if (cout == 8) { c.fmt = FMT_PX; c.coutb = 8; c.ck = 4; c.nw = 9 * 4 * 64; }
-    else if (cout % 16 == 0) { c.fmt = FMT_CI; c.coutb = 16; c.ck = 8; c.nw = 27 * 2 * 64; }
+    if (cout == 1) { c.fmt = FMT_B4; c.coutb = 4; c.units = (cin + 7) / 8; c.unit_floats = 27 * 64; }
+    else if (cout == 8) { c.fmt = FMT_PX; c.coutb = 8; c.units = round_up(cin, 8); c.unit_floats = 9 * 64; }
+    else if (cout % 16 == 0) { c.fmt = FMT_CI; c.coutb = 16; c.units = round_up((cin + 3) / 4, 4); c.unit_floats = 27 * 64; }
     else return false;
   } else if (kind == CASMVS_CONV_S2) {
     if (cout % 16 != 0) return false;
-    c.fmt = FMT_CI; c.coutb = 16; c.ck = 4; c.nw = 27 * 1 * 64;
+    c.fmt = FMT_CI; c.coutb = 16; c.units = round_up((cin + 3) / 4, 4); c.unit_floats = 27 * 64;
   } else if (kind == CASMVS_CONV_T2) {
-    if (cout == 8) { c.fmt = FMT_TPX; c.coutb = 8; c.ck = 8; c.nw = 9 * 2 * 2 * 64; }
-    else if (cout % 16 == 0) { c.fmt = FMT_TCI; c.coutb = 16; c.ck = 8; c.nw = 27 * 2 * 64; }
+    if (cout == 8) { c.fmt = FMT_TPX; c.coutb = 8; c.units = round_up((cin + 3) / 4, 4); c.unit_floats = 18 * 64; }
+    else if (cout % 16 == 0) { c.fmt = FMT_TCI; c.coutb = 16; c.units = round_up((cin + 3) / 4, 4); c.unit_floats = 27 * 64; }
     else return false;
   } else {
     return false;
   }
   c.slices = (cout + c.coutb - 1) / c.coutb;
-  c.nstages = (cin + c.ck - 1) / c.ck;
   return true;
 }
 
-// Value of lane `l` of A image `img` of chunk `stage`, slice `sl` (host side).
+// Value of lane `l` of image `img` of unit `unit`, slice `sl` (host side).
 inline float pack_weight(const LayerCfg &c, int kind, int cin, int cout, const float *w, int sl,
-                         int stage, int img, int l) {
+                         int unit, int img, int l) {
   auto conv_w = [&](int co, int ci, int tap) -> float {
     if (co >= cout || ci >= cin || tap < 0) return 0.0f;
     return kind == CASMVS_CONV_T2 ? w[((size_t)ci * cout + co) * 27 + tap]   // (cin, cout, 3,3,3)
@@ -104,26 +111,23 @@ inline float pack_weight(const LayerCfg &c, int kind, int cin, int cout, const f
   };
   const int i = l & 15, k = l >> 4;
   switch (c.fmt) {
-    case FMT_B4: {  // img = tap; lane: block n = l / 4 = local input channel, row l % 4 = co
+    case FMT_B4: {  // img = tap; lane: block l / 4 = local input channel (8 used), row l % 4 = co
       const int cil = l / 4, co = l % 4;
-      return cil < c.ck ? conv_w(co, stage * c.ck + cil, img) : 0.0f;
+      return cil < 8 ? conv_w(co, unit * 8 + cil, img) : 0.0f;
     }
-    case FMT_CI:     // img = tap * (ck/4) + ciq; row i = co, k = input channel of the quad
-    case FMT_TCI: {
-      const int nq = c.ck / 4, tap = img / nq, ciq = img % nq;
-      return conv_w(sl * 16 + i, stage * c.ck + ciq * 4 + k, tap);
-    }
-    case FMT_PX: {   // img = (kz*3+ky) * ck + cil; row i = (co, s), k = x-offset u, kx = u - s
-      const int r9 = img / c.ck, cil = img % c.ck;
+    case FMT_CI:     // img = tap; row i = co, k = input channel of the quad
+    case FMT_TCI:
+      return conv_w(sl * 16 + i, unit * 4 + k, img);
+    case FMT_PX: {   // img = kz*3+ky; row i = (co, s), k = x-offset u, kx = u - s
       const int co = i >> 1, s = i & 1, kx = k - s;
-      return (kx >= 0 && kx <= 2) ? conv_w(co, stage * c.ck + cil, r9 * 3 + kx) : 0.0f;
+      return (kx >= 0 && kx <= 2) ? conv_w(co, unit, img * 3 + kx) : 0.0f;
     }
-    case FMT_TPX: {  // img = ((kz*3+ky) * 2 + dx) * (ck/4) + ciq; row i = (co, px), k = ci
-      const int nq = c.ck / 4, ciq = img % nq, dx = (img / nq) % 2, r9 = img / (2 * nq);
+    case FMT_TPX: {  // img = (kz*3+ky) * 2 + dx; row i = (co, px), k = input channel of the quad
+      const int dx = img % 2, r9 = img / 2;
       const int co = i >> 1, px = i & 1;
       // even output x = 2m takes (kx = 1, cell m); odd x = 2m+1 takes (kx = 2, m), (kx = 0, m+1)
       const int kx = dx == 0 ? (px == 0 ? 1 : 2) : (px == 1 ? 0 : -1);
-      return kx >= 0 ? conv_w(co, stage * c.ck + ciq * 4 + k, r9 * 3 + kx) : 0.0f;
+      return kx >= 0 ? conv_w(co, unit * 4 + k, r9 * 3 + kx) : 0.0f;
     }
   }
   return 0.0f;
@@ -235,14 +239,15 @@ template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
 __global__ __launch_bounds__(kThreads) void conv16_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-    int nstages, int tiles_x, int tiles_y, float slope) {
+    int per_slice, int tiles_x, int tiles_y, float slope) {
   using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX>;
+  const int nstages = (cin + CK - 1) / CK;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
   constexpr int NA = Cfg::NA, NITER = Cfg::NITER, ASTEP = Cfg::ASTEP, NW = Cfg::NW, NXG = Cfg::NXG;
   constexpr int COUTB = MODE == FMT_PX ? 8 : 16;
   extern __shared__ float smem[];
   float *tile = smem;            // [CK][IZ][IY][IX], channel stride SC
-  float *wts = smem + CK * SC;   // [NITER][NA][64]
+  float *wts = smem + CK * SC;   // [NA][NITER][64]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jcol = lane & 15, kq = lane >> 4;
@@ -269,10 +274,10 @@ __global__ __launch_bounds__(kThreads) void conv16_kernel(
   const size_t in_cs = (size_t)Di * Hi * Wi;  // input channel stride
   const float *inb = in + (size_t)b * cin * in_cs;
   const int iz0 = tz0 * STRIDE - 1, iy0 = ty0 * STRIDE - 1, ix0 = tx0 * STRIDE - 1;
-  const float *wslice = wpk + (size_t)slice * nstages * NW;
-  const float *scale = wpk + (size_t)slices * nstages * NW + slice * COUTB;
+  const float *wslice = wpk + (size_t)slice * per_slice;
+  const float *scale = wpk + (size_t)slices * per_slice + slice * COUTB;
   const float *shift = scale + slices * COUTB;
-  const float *zero = wpk + (size_t)slices * nstages * NW + 2 * slices * COUTB;  // 64 zero floats
+  const float *zero = wpk + (size_t)slices * per_slice + 2 * slices * COUTB;  // 64 zero floats
 
   // MFMA loop of one chunk, written out in issue order and pinned with sched_barrier.  Step
   // s = (a, t) of an iteration needs one B operand (ds_read_b32, immediate offset a * ASTEP) and
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void conv16_kernel(
 
     float a_cur[NA], a_nxt[NA];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) a_cur[a] = wts[a * 64 + lane];
+    for (int a = 0; a < NA; ++a) a_cur[a] = wts[(a * NITER) * 64 + lane];
     int ad_c[NT], ad_n[NT];  // per-tile LDS word address of the current / next iteration
 #pragma unroll
     for (int t = 0; t < NT; ++t) ad_c[t] = base[t];  // iteration 0: offset 0
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(kThreads) void conv16_kernel(
     for (int it = 0; it < NITER; ++it) {
       const int itn = it < NITER - 1 ? it + 1 : NITER - 1;  // last iteration: harmless re-read
 #pragma unroll
-      for (int a = 0; a < NA; ++a) a_nxt[a] = wts[(itn * NA + a) * 64 + lane];
+      for (int a = 0; a < NA; ++a) a_nxt[a] = wts[(a * NITER + itn) * 64 + lane];
       const int off_n = it_off(itn);
 #pragma unroll
       for (int t = 0; t < NT; ++t) ad_n[t] = base[t] + off_n;
@@ -388,8 +393,10 @@ __global__ __launch_bounds__(kThreads) void conv16_kernel(
 // ---- ConvTranspose3d k3 s2 p1 op1 on 16x16x4 -------------------------------------------------------
 // out[2i - 1 + k] += in[i] * w[k] per axis: even outputs o = 2m take (k = 1, i = m); odd outputs
 // o = 2m + 1 take (k = 2, i = m) and (k = 0, i = m + 1).  A column tile is 16 input cells m along
-// x; a workgroup produces output rows (2mz + pz, 2my + py) with (pz, py) from blockIdx, and both
-// x parities: TCI keeps two accumulators (rows = 16 channels), TPX folds the parity into the rows.
+// x; for every cell a workgroup produces all 8 output parities: the 2 x 2 x 2 neighbourhood
+// (m + d) of a cell is read ONCE from LDS (8 B operands per channel quad) and feeds the 27 (TCI)
+// / 18 (TPX) MFMAs of the four (pz, py) passes.  TCI keeps two accumulators per pass (x parity),
+// TPX folds the x parity into the rows (co, px).
 template <int MODE, int CK, int NT, int TZ, int TY, int TX>
 struct Deconv16Cfg {
   static_assert(MODE == FMT_TCI || MODE == FMT_TPX, "deconv16: TCI or TPX");
@@ -399,28 +406,29 @@ struct Deconv16Cfg {
   static constexpr int SY = IX, SZ = IY * IX;
   static constexpr int SC = round_up_to_16_mod_32(IZ * SZ);
   static constexpr int NQ = CK / 4;
-  static constexpr int NW = MODE == FMT_TCI ? 27 * NQ * 64 : 9 * 2 * NQ * 64;
+  static constexpr int UI = MODE == FMT_TCI ? 27 : 18;  // images per channel quad
+  static constexpr int NW = NQ * UI * 64;
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
 
 template <int MODE, int CK, int NT, int TZ, int TY, int TX>
 __global__ __launch_bounds__(kThreads) void deconv16_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
-    float *__restrict__ out, int cin, int cout, int Di, int Hi, int Wi, int nstages, int tiles_x,
-    int tiles_y, int ntiles, float slope) {
+    float *__restrict__ out, int cin, int cout, int Di, int Hi, int Wi, int per_slice, int tiles_x,
+    int tiles_y, float slope) {
   using Cfg = Deconv16Cfg<MODE, CK, NT, TZ, TY, TX>;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
-  constexpr int NQ = Cfg::NQ, NW = Cfg::NW, NXG = Cfg::NXG;
+  constexpr int NQ = Cfg::NQ, NW = Cfg::NW, NXG = Cfg::NXG, UI = Cfg::UI;
   constexpr int COUTB = MODE == FMT_TPX ? 8 : 16;
   constexpr int NACC = MODE == FMT_TCI ? 2 : 1;
   extern __shared__ float smem[];
   float *tile = smem;
-  float *wts = smem + CK * SC;
+  float *wts = smem + CK * SC;  // [NQ][UI][64]
+  const int nstages = (cin + CK - 1) / CK;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jcol = lane & 15, kq = lane >> 4;
-  const int pass = blockIdx.x / ntiles, bid = blockIdx.x - pass * ntiles;
-  const int pz = pass >> 1, py = pass & 1;
+  const int bid = blockIdx.x;
   const int tx0 = (bid % tiles_x) * TX;
   const int ty0 = ((bid / tiles_x) % tiles_y) * TY;
   const int tz0 = (bid / (tiles_x * tiles_y)) * TZ;
@@ -434,19 +442,20 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
     const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
     base[t] = kq * SC + cz * SZ + cy * SY + cx * 16 + jcol;
   }
-  f32x4 acc[NACC][NT];  // TCI: [x parity][tile]; TPX: [0][tile] with rows (co, px)
+  f32x4 acc[4][NACC][NT];  // [pass = 2*pz + py][x parity (TCI)][tile]
 #pragma unroll
-  for (int p = 0; p < NACC; ++p)
+  for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < NACC; ++p)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[ps][p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const size_t in_cs = (size_t)Di * Hi * Wi;
   const float *inb = in + (size_t)b * cin * in_cs;
-  const float *wslice = wpk + (size_t)slice * nstages * NW;
-  const float *scale = wpk + (size_t)slices * nstages * NW + slice * COUTB;
+  const float *wslice = wpk + (size_t)slice * per_slice;
+  const float *scale = wpk + (size_t)slices * per_slice + slice * COUTB;
   const float *shift = scale + slices * COUTB;
-  const float *zero = wpk + (size_t)slices * nstages * NW + 2 * slices * COUTB;
-  const int nzt = pz ? 2 : 1, nyt = py ? 2 : 1;
+  const float *zero = wpk + (size_t)slices * per_slice + 2 * slices * COUTB;
   StagePlan<IY, IX> plan;
   plan.init(ty0, tx0, Hi, Wi);
   StageRegs<CK, IZ, IY, IX, SC, NW> regs;
@@ -458,37 +467,35 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
     __syncthreads();
     if (s + 1 < nstages)
       regs.load(plan, inb, in_cs, cin, (s + 1) * CK, tz0, Di, Hi * Wi, wslice + (size_t)(s + 1) * NW, zero);
-    for (int zt = 0; zt < nzt; ++zt) {
-      const int kz = pz ? (zt == 0 ? 2 : 0) : 1, dz = (pz && zt == 1) ? 1 : 0;
-      for (int yt = 0; yt < nyt; ++yt) {
-        const int ky = py ? (yt == 0 ? 2 : 0) : 1, dy = (py && yt == 1) ? 1 : 0;
-        const int r9 = kz * 3 + ky;
-        const int toff = dz * SZ + dy * SY;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          float b0[NT], b1[NT];
+    for (int q = 0; q < NQ; ++q) {
+      float aw[UI];  // this quad's images
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            b0[t] = tile[base[t] + toff + q * 4 * SC];      // cell m
-            b1[t] = tile[base[t] + toff + q * 4 * SC + 1];  // cell m + 1
-          }
-          if (MODE == FMT_TCI) {
-            const float a0 = wts[((r9 * 3 + 0) * NQ + q) * 64 + lane];
-            const float a1 = wts[((r9 * 3 + 1) * NQ + q) * 64 + lane];
-            const float a2 = wts[((r9 * 3 + 2) * NQ + q) * 64 + lane];
+      for (int i = 0; i < UI; ++i) aw[i] = wts[(q * UI + i) * 64 + lane];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              acc[0][t] = mfma16(a1, b0[t], acc[0][t]);                // px = 0: k = 1, i = m
-              acc[NACC - 1][t] = mfma16(a2, b0[t], acc[NACC - 1][t]);  // px = 1: k = 2, i = m
-              acc[NACC - 1][t] = mfma16(a0, b1[t], acc[NACC - 1][t]);  // px = 1: k = 0, i = m + 1
-            }
-          } else {
-            const float ad0 = wts[((r9 * 2 + 0) * NQ + q) * 64 + lane];
-            const float ad1 = wts[((r9 * 2 + 1) * NQ + q) * 64 + lane];
+      for (int t = 0; t < NT; ++t) {
+        float bv[2][2][2];  // [dz][dy][dx]: cells m + d
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              acc[0][t] = mfma16(ad0, b0[t], acc[0][t]);
-              acc[0][t] = mfma16(ad1, b1[t], acc[0][t]);
+        for (int d = 0; d < 8; ++d)
+          bv[d >> 2][(d >> 1) & 1][d & 1] = tile[base[t] + q * 4 * SC + (d >> 2) * SZ + ((d >> 1) & 1) * SY + (d & 1)];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int pz = ps >> 1, py = ps & 1;
+#pragma unroll
+          for (int zt = 0; zt < (pz ? 2 : 1); ++zt) {
+            const int kz = pz ? (zt == 0 ? 2 : 0) : 1, dz = (pz && zt == 1) ? 1 : 0;
+#pragma unroll
+            for (int yt = 0; yt < (py ? 2 : 1); ++yt) {
+              const int ky = py ? (yt == 0 ? 2 : 0) : 1, dy = (py && yt == 1) ? 1 : 0;
+              const int r9 = kz * 3 + ky;
+              if (MODE == FMT_TCI) {
+                acc[ps][0][t] = mfma16(aw[(r9 * 3 + 1) % UI], bv[dz][dy][0], acc[ps][0][t]);                // px 0: k = 1, i = m
+                acc[ps][NACC - 1][t] = mfma16(aw[(r9 * 3 + 2) % UI], bv[dz][dy][0], acc[ps][NACC - 1][t]);  // px 1: k = 2, i = m
+                acc[ps][NACC - 1][t] = mfma16(aw[(r9 * 3 + 0) % UI], bv[dz][dy][1], acc[ps][NACC - 1][t]);  // px 1: k = 0, i = m+1
+              } else {
+                acc[ps][0][t] = mfma16(aw[(r9 * 2 + 0) % UI], bv[dz][dy][0], acc[ps][0][t]);
+                acc[ps][0][t] = mfma16(aw[(r9 * 2 + 1) % UI], bv[dz][dy][1], acc[ps][0][t]);
+              }
             }
           }
         }
@@ -504,27 +511,31 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
     const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
     const int mz = tz0 + cz, my = ty0 + cy, mx = tx0 + cx * 16 + jcol;
     if (mz >= Di || my >= Hi || mx >= Wi) continue;
-    const size_t vo = ((size_t)(2 * mz + pz) * Ho + (2 * my + py)) * Wo + 2 * mx;
 #pragma unroll
-    for (int h = 0; h < (MODE == FMT_TCI ? 4 : 2); ++h) {
-      // TCI: h = row r -> channel 4*kq + r, pair = (parity 0, parity 1) accumulators
-      // TPX: h -> channel 2*kq + h, pair = rows (2h, 2h+1) of the single accumulator
-      const int col = MODE == FMT_TCI ? 4 * kq + h : 2 * kq + h;
-      const int co = slice * COUTB + col;
-      if (co >= cout) continue;
-      float v0 = MODE == FMT_TCI ? acc[0][t][h] : acc[0][t][(2 * h) & 3];
-      float v1 = MODE == FMT_TCI ? acc[NACC - 1][t][h] : acc[0][t][(2 * h + 1) & 3];
-      v0 = fmaf(v0, scale[col], shift[col]);
-      v1 = fmaf(v1, scale[col], shift[col]);
-      v0 = v0 > 0.0f ? v0 : v0 * slope;
-      v1 = v1 > 0.0f ? v1 : v1 * slope;
-      const size_t o = ((size_t)b * cout + co) * out_cs + vo;
-      if (skip) {
-        const f32x2 sk = *reinterpret_cast<const f32x2 *>(skip + o);
-        v0 += sk[0];
-        v1 += sk[1];
+    for (int ps = 0; ps < 4; ++ps) {
+      const int pz = ps >> 1, py = ps & 1;
+      const size_t vo = ((size_t)(2 * mz + pz) * Ho + (2 * my + py)) * Wo + 2 * mx;
+#pragma unroll
+      for (int h = 0; h < (MODE == FMT_TCI ? 4 : 2); ++h) {
+        // TCI: h = row r -> channel 4*kq + r, pair = (parity 0, parity 1) accumulators
+        // TPX: h -> channel 2*kq + h, pair = rows (2h, 2h+1) of the single accumulator
+        const int col = MODE == FMT_TCI ? 4 * kq + h : 2 * kq + h;
+        const int co = slice * COUTB + col;
+        if (co >= cout) continue;
+        float v0 = MODE == FMT_TCI ? acc[ps][0][t][h] : acc[ps][0][t][(2 * h) & 3];
+        float v1 = MODE == FMT_TCI ? acc[ps][NACC - 1][t][h] : acc[ps][0][t][(2 * h + 1) & 3];
+        v0 = fmaf(v0, scale[col], shift[col]);
+        v1 = fmaf(v1, scale[col], shift[col]);
+        v0 = v0 > 0.0f ? v0 : v0 * slope;
+        v1 = v1 > 0.0f ? v1 : v1 * slope;
+        const size_t o = ((size_t)b * cout + co) * out_cs + vo;
+        if (skip) {
+          const f32x2 sk = *reinterpret_cast<const f32x2 *>(skip + o);
+          v0 += sk[0];
+          v1 += sk[1];
+        }
+        *reinterpret_cast<f32x2 *>(out + o) = f32x2{v0, v1};
       }
-      *reinterpret_cast<f32x2 *>(out + o) = f32x2{v0, v1};
     }
   }
 }
@@ -545,8 +556,9 @@ struct ProbCfg {
 template <int CK, int G, int TZ, int TY, int TX>
 __global__ __launch_bounds__(kThreads) void prob_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, float *__restrict__ out, int cin,
-    int Di, int Hi, int Wi, int nstages, int tiles_x, int tiles_y, float slope) {
+    int Di, int Hi, int Wi, int tiles_x, int tiles_y, float slope) {
   static_assert(TZ * TY * TX == 4 * G * 64 && CK == 8, "tile = 4 waves x G groups x 64 voxels");
+  const int nstages = (cin + CK - 1) / CK;
   using Cfg = ProbCfg<CK, G, TZ, TY, TX>;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, NW = Cfg::NW;
   extern __shared__ float smem[];
@@ -693,7 +705,7 @@ int launch_conv16(const LayerCfg &c, const float *packed, const float *in, const
             tiles_z = casmvs::ceil_div(Do, TZ);
   dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, (unsigned)c.slices);
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, cin, cout,
-                     Di, Hi, Wi, Do, Ho, Wo, c.nstages, tiles_x, tiles_y, slope);
+                     Di, Hi, Wi, Do, Ho, Wo, (int)c.per_slice(), tiles_x, tiles_y, slope);
   return casmvs::check_launch("conv16_kernel");
 }
 
@@ -706,10 +718,9 @@ int launch_deconv16(const LayerCfg &c, const float *packed, const float *in, con
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "deconv16_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wi, TX), tiles_y = casmvs::ceil_div(Hi, TY),
             tiles_z = casmvs::ceil_div(Di, TZ);
-  const int ntiles = tiles_x * tiles_y * tiles_z;
-  dim3 grid((unsigned)(4 * ntiles), (unsigned)B, (unsigned)c.slices);
+  dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, (unsigned)c.slices);
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, cin, cout,
-                     Di, Hi, Wi, c.nstages, tiles_x, tiles_y, ntiles, slope);
+                     Di, Hi, Wi, (int)c.per_slice(), tiles_x, tiles_y, slope);
   return casmvs::check_launch("deconv16_kernel");
 }
 
@@ -721,7 +732,7 @@ int launch_prob(const LayerCfg &c, const float *packed, const float *in, float *
   const int tiles_x = casmvs::ceil_div(W, 32), tiles_y = casmvs::ceil_div(H, 4), tiles_z = casmvs::ceil_div(D, 8);
   dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, 1);
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, out, cin, D, H, W,
-                     c.nstages, tiles_x, tiles_y, slope);
+                     tiles_x, tiles_y, slope);
   return casmvs::check_launch("prob_kernel");
 }
 
@@ -730,7 +741,7 @@ int launch_prob(const LayerCfg &c, const float *packed, const float *in, float *
 extern "C" size_t casmvs_conv3d_packed_floats(int kind, int cin, int cout) {
   LayerCfg c;
   if (!layer_cfg(kind, cin, cout, c)) return 0;
-  return (size_t)c.slices * c.nstages * c.nw + 2 * (size_t)c.slices * c.coutb + 64;
+  return (size_t)c.slices * c.per_slice() + 2 * (size_t)c.slices * c.coutb + 64;
 }
 
 extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *weight,
@@ -741,11 +752,11 @@ extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *
   if (!layer_cfg(kind, cin, cout, c))
     return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv3d_pack: kind=%d cin=%d cout=%d", kind, cin, cout);
   float *p = packed;
-  const int nimg = c.nw / 64;
+  const int nimg = c.unit_floats / 64;
   for (int sl = 0; sl < c.slices; ++sl)
-    for (int s = 0; s < c.nstages; ++s)
+    for (int u = 0; u < c.units; ++u)
       for (int img = 0; img < nimg; ++img)
-        for (int l = 0; l < 64; ++l) *p++ = pack_weight(c, kind, cin, cout, weight, sl, s, img, l);
+        for (int l = 0; l < 64; ++l) *p++ = pack_weight(c, kind, cin, cout, weight, sl, u, img, l);
   const int cp = c.slices * c.coutb;
   for (int co = 0; co < cp; ++co) p[co] = (co < cout) ? (scale ? scale[co] : 1.0f) : 0.0f;
   for (int co = 0; co < cp; ++co) p[cp + co] = (co < cout) ? (shift ? shift[co] : 0.0f) : 0.0f;
@@ -764,23 +775,30 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
     return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv3d_forward: kind=%d cin=%d cout=%d", kind, cin, cout);
   CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 31), "conv3d_forward: one sample's input must hold < 2^31 floats");
   hipStream_t st = (hipStream_t)stream;
+  // Workgroup shapes.  "wide" variants (many column tiles per wave, small CK) maximise operand
+  // reuse for the big full-resolution layers; "deep" variants (1 column tile per wave, CK = 16:
+  // a 4x shorter stage chain and 4x more workgroups) serve the low-resolution layers, whose
+  // cost is the latency of the chain, not FLOPs.
   if (kind == CASMVS_CONV_S1) {
     if (c.fmt == FMT_B4) {
       CASMVS_REQUIRE(skip == nullptr, "conv3d_forward: the 1-channel head takes no skip input");
       return launch_prob(c, packed, in, out, B, cin, D, H, W, slope, st);
     }
     if (c.fmt == FMT_PX) return launch_conv16<FMT_PX, 1, 4, 8, 8, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
-    // CI: large volumes use 32-column-tile workgroups, small (deep) volumes 16
-    const long big_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 4) * c.slices * B;
-    if (big_blocks >= 1024) return launch_conv16<FMT_CI, 1, 8, 8, 4, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
-    return launch_conv16<FMT_CI, 1, 8, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
+    const long wide_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 4) * c.slices * B;
+    if (wide_blocks >= 512) return launch_conv16<FMT_CI, 1, 8, 8, 4, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
+    return launch_conv16<FMT_CI, 1, 16, 1, 1, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
   }
   if (kind == CASMVS_CONV_S2) {
     CASMVS_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_forward(S2): odd input dims %dx%dx%d", D, H, W);
-    return launch_conv16<FMT_CI, 2, 4, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
+    const long wide_blocks = (long)casmvs::ceil_div(W / 2, 16) * casmvs::ceil_div(H / 2, 8) * casmvs::ceil_div(D / 2, 2) * c.slices * B;
+    if (wide_blocks >= 512) return launch_conv16<FMT_CI, 2, 4, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
+    return launch_conv16<FMT_CI, 2, 8, 1, 1, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
   }
   if (c.fmt == FMT_TPX) return launch_deconv16<FMT_TPX, 8, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
-  return launch_deconv16<FMT_TCI, 8, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+  const long wide_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 1) * c.slices * B;
+  if (wide_blocks >= 512) return launch_deconv16<FMT_TCI, 8, 2, 1, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+  return launch_deconv16<FMT_TCI, 16, 1, 1, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
 }
 
 extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {

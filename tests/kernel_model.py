@@ -15,23 +15,29 @@ S1, S2, T2 = 0, 1, 2
 B4, CI, PX, TCI, TPX = 0, 1, 2, 3, 4
 
 
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
 def layer_cfg(kind, cin, cout):
+    """-> fmt, coutb, slices, units, unit_floats (mirrors layer_cfg in conv3d_mfma.hip)."""
+    q = _ru((cin + 3) // 4, 4)
     if kind == S1:
-        fmt, coutb, ck, nw = (B4, 4, 8, 27 * 64) if cout == 1 else (PX, 8, 4, 9 * 4 * 64) if cout == 8 else (CI, 16, 8, 27 * 2 * 64)
+        fmt, coutb, units, uf = (B4, 4, (cin + 7) // 8, 27 * 64) if cout == 1 else (PX, 8, _ru(cin, 8), 9 * 64) if cout == 8 else (CI, 16, q, 27 * 64)
     elif kind == S2:
-        fmt, coutb, ck, nw = CI, 16, 4, 27 * 64
+        fmt, coutb, units, uf = CI, 16, q, 27 * 64
     else:
-        fmt, coutb, ck, nw = (TPX, 8, 8, 9 * 2 * 2 * 64) if cout == 8 else (TCI, 16, 8, 27 * 2 * 64)
-    return fmt, coutb, ck, (cout + coutb - 1) // coutb, (cin + ck - 1) // ck, nw
+        fmt, coutb, units, uf = (TPX, 8, q, 18 * 64) if cout == 8 else (TCI, 16, q, 27 * 64)
+    return fmt, coutb, (cout + coutb - 1) // coutb, units, uf
 
 
 def emulate(kind, packed, x, cout, skip=None, slope=0.01):
     B, cin, D, H, W = x.shape
-    fmt, coutb, ck, slices, nstages, nw = layer_cfg(kind, cin, cout)
-    nimg = nw // 64
-    body = slices * nstages * nw
+    fmt, coutb, slices, units, uf = layer_cfg(kind, cin, cout)
+    nimg = uf // 64
+    body = slices * units * uf
     assert packed.numel() == body + 2 * slices * coutb + 64
-    img = packed[:body].reshape(slices, nstages, nimg, 64).double()
+    img = packed[:body].reshape(slices, units, nimg, 64).double()   # [slice][unit][image][lane]
     scale = packed[body: body + slices * coutb].double()
     shift = packed[body + slices * coutb: body + 2 * slices * coutb].double()
     assert float(packed[body + 2 * slices * coutb:].abs().sum()) == 0.0
@@ -49,70 +55,65 @@ def emulate(kind, packed, x, cout, skip=None, slope=0.01):
 
     if fmt == B4:
         xp = F.pad(xd, (1, 1, 1, 1, 1, 1))
-        for s in range(nstages):
+        for u in range(units):
             for tap in range(27):
                 kz, ky, kx = tap // 9, (tap // 3) % 3, tap % 3
-                a = img[0, s, tap]
-                for c in range(ck):  # ABID = c picks lanes 4c..4c+3 = rows (co 0..3) of channel c
-                    bval = chan(xp, s * ck + c)[:, kz:kz + D, ky:ky + H, kx:kx + W]
+                a = img[0, u, tap]
+                for c in range(8):  # ABID = c picks lanes 4c..4c+3 = rows (co 0..3) of channel c
+                    bval = chan(xp, u * 8 + c)[:, kz:kz + D, ky:ky + H, kx:kx + W]
                     for r in range(4):
                         acc[:, r] += a[4 * c + r] * bval
     elif fmt == CI:
         st = 1 if kind == S1 else 2
-        nq = ck // 4
         xp = F.pad(xd, (1, 1, 1, 1, 1, 1))
         for sl in range(slices):
-            for s in range(nstages):
+            for u in range(units):
                 for tap in range(27):
                     kz, ky, kx = tap // 9, (tap // 3) % 3, tap % 3
-                    for q in range(nq):
-                        A = img[sl, s, tap * nq + q].reshape(4, 16)  # [k][i]
-                        for k in range(4):
-                            bval = chan(xp, s * ck + q * 4 + k)[:, kz:kz + st * (Do - 1) + 1:st, ky:ky + st * (Ho - 1) + 1:st,
-                                                                kx:kx + st * (Wo - 1) + 1:st]
-                            for i in range(16):
-                                acc[:, sl * 16 + i] += A[k, i] * bval
+                    A = img[sl, u, tap].reshape(4, 16)  # [k][i]
+                    for k in range(4):
+                        bval = chan(xp, u * 4 + k)[:, kz:kz + st * (Do - 1) + 1:st, ky:ky + st * (Ho - 1) + 1:st,
+                                                   kx:kx + st * (Wo - 1) + 1:st]
+                        for i in range(16):
+                            acc[:, sl * 16 + i] += A[k, i] * bval
     elif fmt == PX:
         assert W % 2 == 0, "model handles even W only"
         xp = F.pad(xd, (1, 3, 1, 1, 1, 1))
-        for s in range(nstages):
+        for u in range(units):
             for r9 in range(9):
                 kz, ky = r9 // 3, r9 % 3
-                for c in range(ck):
-                    A = img[0, s, r9 * ck + c].reshape(4, 16)  # [u][i = 2*co + sx]
-                    plane = chan(xp, s * ck + c)[:, kz:kz + D, ky:ky + H]
-                    for u in range(4):
-                        bval = plane[..., u:u + W:2]  # in[x0 + 2j + u - 1], j = 0..W/2-1
-                        for i in range(16):
-                            acc[:, i >> 1, :, :, (i & 1)::2] += A[u, i] * bval
+                A = img[0, u, r9].reshape(4, 16)  # [x-offset][i = 2*co + sx]
+                plane = chan(xp, u)[:, kz:kz + D, ky:ky + H]
+                for xo in range(4):
+                    bval = plane[..., xo:xo + W:2]  # in[x0 + 2j + xo - 1], j = 0..W/2-1
+                    for i in range(16):
+                        acc[:, i >> 1, :, :, (i & 1)::2] += A[xo, i] * bval
     elif fmt in (TCI, TPX):
-        nq = ck // 4
         xp = F.pad(xd, (0, 1, 0, 1, 0, 1))  # cell m + 1 beyond the edge reads zero
         for sl in range(slices):
             for pz in (0, 1):
                 for py in (0, 1):
-                    for s in range(nstages):
+                    for u in range(units):
                         for zt in range(2 if pz else 1):
                             kz, dz = ((2, 0) if zt == 0 else (0, 1)) if pz else (1, 0)
                             for yt in range(2 if py else 1):
                                 ky, dy = ((2, 0) if yt == 0 else (0, 1)) if py else (1, 0)
                                 r9 = kz * 3 + ky
-                                for q in range(nq):
-                                    for k in range(4):
-                                        pl = chan(xp, s * ck + q * 4 + k)
-                                        b0 = pl[:, dz:dz + D, dy:dy + H, 0:W]
-                                        b1 = pl[:, dz:dz + D, dy:dy + H, 1:W + 1]
-                                        if fmt == TCI:
-                                            a0, a1, a2 = (img[sl, s, (r9 * 3 + kx) * nq + q].reshape(4, 16)[k] for kx in range(3))
-                                            for i in range(16):
-                                                co = sl * 16 + i
-                                                acc[:, co, pz::2, py::2, 0::2] += a1[i] * b0
-                                                acc[:, co, pz::2, py::2, 1::2] += a2[i] * b0 + a0[i] * b1
-                                        else:
-                                            ad0 = img[sl, s, (r9 * 2 + 0) * nq + q].reshape(4, 16)[k]
-                                            ad1 = img[sl, s, (r9 * 2 + 1) * nq + q].reshape(4, 16)[k]
-                                            for i in range(16):
-                                                acc[:, i >> 1, pz::2, py::2, (i & 1)::2] += ad0[i] * b0 + ad1[i] * b1
+                                for k in range(4):
+                                    pl = chan(xp, u * 4 + k)
+                                    b0 = pl[:, dz:dz + D, dy:dy + H, 0:W]
+                                    b1 = pl[:, dz:dz + D, dy:dy + H, 1:W + 1]
+                                    if fmt == TCI:
+                                        a0, a1, a2 = (img[sl, u, r9 * 3 + kx].reshape(4, 16)[k] for kx in range(3))
+                                        for i in range(16):
+                                            co = sl * 16 + i
+                                            acc[:, co, pz::2, py::2, 0::2] += a1[i] * b0
+                                            acc[:, co, pz::2, py::2, 1::2] += a2[i] * b0 + a0[i] * b1
+                                    else:
+                                        ad0 = img[sl, u, r9 * 2 + 0].reshape(4, 16)[k]
+                                        ad1 = img[sl, u, r9 * 2 + 1].reshape(4, 16)[k]
+                                        for i in range(16):
+                                            acc[:, i >> 1, pz::2, py::2, (i & 1)::2] += ad0[i] * b0 + ad1[i] * b1
     y = acc * scale.reshape(1, -1, 1, 1, 1) + shift.reshape(1, -1, 1, 1, 1)
     y = torch.where(y > 0, y, y * slope)[:, :cout]
     if skip is not None:

@@ -42,12 +42,13 @@ def test_abi_version_and_error_string():
 
 def test_packed_sizes_and_workspace():
     lib = _lib.load()
-    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 32, 8) == 8 * 9 * 4 * 64 + 16 + 64          # PX, 8 chunks of 4
-    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 64, 64) == 4 * 8 * 27 * 2 * 64 + 128 + 64   # CI, 4 slices
-    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 8, 1) == 27 * 64 + 8 + 64                    # B4
-    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S2, 8, 16) == 2 * 27 * 64 + 32 + 64              # CI stride 2
-    assert lib.casmvs_conv3d_packed_floats(ops.CONV_T2, 64, 32) == 2 * 8 * 27 * 2 * 64 + 64 + 64     # TCI
-    assert lib.casmvs_conv3d_packed_floats(ops.CONV_T2, 16, 8) == 2 * 9 * 2 * 2 * 64 + 16 + 64       # TPX
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 32, 8) == 32 * 9 * 64 + 16 + 64             # PX: 32 channel units
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 5, 8) == 8 * 9 * 64 + 16 + 64               # PX: padded to 8 channels
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 64, 64) == 4 * 16 * 27 * 64 + 128 + 64      # CI: 4 slices x 16 quads
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 8, 1) == 27 * 64 + 8 + 64                   # B4
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S2, 8, 16) == 4 * 27 * 64 + 32 + 64            # CI: 2 quads padded to 4
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_T2, 64, 32) == 2 * 16 * 27 * 64 + 64 + 64       # TCI
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_T2, 16, 8) == 4 * 18 * 64 + 16 + 64            # TPX
     assert lib.casmvs_conv3d_packed_floats(ops.CONV_S2, 8, 8) == 0  # unsupported
     n = 8 * 16 * 24
     assert lib.casmvs_costreg_workspace_bytes(2, 8, 16, 24) == 2 * 4 * int(23.75 * n)

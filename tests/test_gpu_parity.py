@@ -147,7 +147,10 @@ CONV_CASES = [  # kind, cin, cout, B, D, H, W, with_skip
     (0, 32, 32, 1, 6, 16, 20, False), (0, 64, 64, 1, 2, 16, 20, False), (0, 64, 64, 1, 1, 8, 10, False),
     (1, 8, 16, 1, 8, 16, 40, False), (1, 16, 32, 2, 4, 16, 24, False), (1, 32, 64, 1, 2, 8, 12, False),
     (2, 64, 32, 1, 1, 8, 10, True), (2, 32, 16, 1, 2, 8, 12, True), (2, 16, 8, 2, 4, 8, 20, True),
-    (2, 16, 8, 1, 3, 5, 7, False)]
+    (2, 16, 8, 1, 3, 5, 7, False),
+    # large enough for the "wide" workgroup variants (>= 512 wide blocks)
+    (0, 16, 32, 1, 16, 64, 128, True), (1, 8, 16, 1, 16, 256, 256, False), (2, 32, 16, 1, 8, 64, 128, True),
+    (0, 3, 16, 1, 5, 9, 21, False), (2, 6, 32, 1, 2, 5, 19, False)]
 
 
 @pytest.mark.parametrize("kind,cin,cout,B,D,H,W,with_skip", CONV_CASES)
