@@ -31,6 +31,7 @@
 //   [slice][chunk][NW floats of 64-lane A images]  scale[slices*coutb]  shift[slices*coutb]
 //   zero[64] (target of out-of-range staging loads).  Image order inside a chunk, and the
 //   lane -> (row, k) -> weight mapping, are documented at each format in pack_weight().
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -235,11 +236,35 @@ struct Conv16Cfg {
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
 
-template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
-__global__ __launch_bounds__(kThreads) void conv16_kernel(
+// Work item (= one output tile of one slice of one sample) decoded from a flat index; x fastest so
+// that workgroups resident at the same time touch neighbouring input.
+struct TileCoord {
+  int tx0, ty0, tz0, b, slice;
+};
+template <int TZ, int TY, int TX>
+__device__ __forceinline__ TileCoord decode_tile(int item, int tiles_x, int tiles_y, int tiles_z, int B) {
+  TileCoord c;
+  c.tx0 = (item % tiles_x) * TX;
+  item /= tiles_x;
+  c.ty0 = (item % tiles_y) * TY;
+  item /= tiles_y;
+  c.tz0 = (item % tiles_z) * TZ;
+  item /= tiles_z;
+  c.b = item % B;
+  c.slice = item / B;
+  return c;
+}
+
+// Persistent workgroups: the grid is sized to the number of resident workgroups and each one walks
+// tiles item, item + gridDim.x, ...  The first chunk of the NEXT tile is prefetched during the last
+// chunk of the current one, so the global-load latency, the address set-up and the epilogue
+// stores of a tile all overlap MFMA work - measured per-workgroup fixed cost before: ~13 us.
+// ABL (ablation, profiling only): 0 = normal, 1 = staging only (no MFMA loop), 2 = MFMA loop only.
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int ABL = 0>
+__global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
-    float *__restrict__ out, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-    int per_slice, int tiles_x, int tiles_y, float slope) {
+    float *__restrict__ out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+    int per_slice, int slices, int tiles_x, int tiles_y, int tiles_z, float slope) {
   using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX>;
   const int nstages = (cin + CK - 1) / CK;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
@@ -251,12 +276,9 @@ __global__ __launch_bounds__(kThreads) void conv16_kernel(
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jcol = lane & 15, kq = lane >> 4;
-  const int bid = blockIdx.x;
-  const int tx0 = (bid % tiles_x) * TX;
-  const int ty0 = ((bid / tiles_x) % tiles_y) * TY;
-  const int tz0 = (bid / (tiles_x * tiles_y)) * TZ;
-  const int b = blockIdx.y, slice = blockIdx.z;
-  const int slices = gridDim.z;
+  const int total = tiles_x * tiles_y * tiles_z * B * slices;
+  int item = blockIdx.x;
+  if (item >= total) return;
 
   // column tile t of this wave -> (cz, cy, cx) inside the block tile and the lane's LDS base
   int base[NT];
@@ -272,12 +294,9 @@ __global__ __launch_bounds__(kThreads) void conv16_kernel(
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const size_t in_cs = (size_t)Di * Hi * Wi;  // input channel stride
-  const float *inb = in + (size_t)b * cin * in_cs;
-  const int iz0 = tz0 * STRIDE - 1, iy0 = ty0 * STRIDE - 1, ix0 = tx0 * STRIDE - 1;
-  const float *wslice = wpk + (size_t)slice * per_slice;
-  const float *scale = wpk + (size_t)slices * per_slice + slice * COUTB;
-  const float *shift = scale + slices * COUTB;
-  const float *zero = wpk + (size_t)slices * per_slice + 2 * slices * COUTB;  // 64 zero floats
+  const size_t out_cs = (size_t)Do * Ho * Wo;
+  const float *tail = wpk + (size_t)slices * per_slice;     // scale | shift | zero
+  const float *zero = tail + 2 * slices * COUTB;            // 64 zero floats
 
   // MFMA loop of one chunk, written out in issue order and pinned with sched_barrier.  Step
   // s = (a, t) of an iteration needs one B operand (ds_read_b32, immediate offset a * ASTEP) and
@@ -292,101 +311,135 @@ __global__ __launch_bounds__(kThreads) void conv16_kernel(
     return MODE == FMT_PX ? (it / 3) * SZ + (it % 3) * SY : (it / 9) * SZ + ((it / 3) % 3) * SY + (it % 3);
   };
 
+  TileCoord cur = decode_tile<TZ, TY, TX>(item, tiles_x, tiles_y, tiles_z, B);
   StagePlan<IY, IX> plan;
-  plan.init(iy0, ix0, Hi, Wi);
+  plan.init(cur.ty0 * STRIDE - 1, cur.tx0 * STRIDE - 1, Hi, Wi);
   StageRegs<CK, IZ, IY, IX, SC, NW> regs;
-  regs.load(plan, inb, in_cs, cin, 0, iz0, Di, Hi * Wi, wslice, zero);
-  for (int s = 0; s < nstages; ++s) {
-    __syncthreads();  // every wave is done reading the previous chunk
-    regs.store(tile, wts);
-    __syncthreads();
-    if (s + 1 < nstages)  // prefetch the next chunk; consumed after the next barrier
-      regs.load(plan, inb, in_cs, cin, (s + 1) * CK, iz0, Di, Hi * Wi, wslice + (size_t)(s + 1) * NW, zero);
-
-    float a_cur[NA], a_nxt[NA];
-#pragma unroll
-    for (int a = 0; a < NA; ++a) a_cur[a] = wts[(a * NITER) * 64 + lane];
-    int ad_c[NT], ad_n[NT];  // per-tile LDS word address of the current / next iteration
-#pragma unroll
-    for (int t = 0; t < NT; ++t) ad_c[t] = base[t];  // iteration 0: offset 0
-    float ring[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) ring[i] = tile[ad_c[i % NT] + (i / NT) * ASTEP];
-    for (int it = 0; it < NITER; ++it) {
-      const int itn = it < NITER - 1 ? it + 1 : NITER - 1;  // last iteration: harmless re-read
-#pragma unroll
-      for (int a = 0; a < NA; ++a) a_nxt[a] = wts[(a * NITER + itn) * 64 + lane];
-      const int off_n = it_off(itn);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) ad_n[t] = base[t] + off_n;
-#pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const int a = i / NT, t = i % NT;
-        const float bcur = ring[i % P];
-        const int ii = i + P;
-        if (ii < NS) ring[i % P] = tile[ad_c[ii % NT] + (ii / NT) * ASTEP];
-        else ring[i % P] = tile[ad_n[(ii - NS) % NT] + ((ii - NS) / NT) * ASTEP];
-        acc[t] = mfma16(a_cur[a], bcur, acc[t]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int a = 0; a < NA; ++a) a_cur[a] = a_nxt[a];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) ad_c[t] = ad_n[t];
-    }
-  }
-
-  // epilogue: y = lrelu(acc * scale + shift) (+ skip); lane holds rows 4*kq + r of column jcol
-  const size_t out_cs = (size_t)Do * Ho * Wo;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int ct = wave * NT + t;
-    const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
-    const int oz = tz0 + cz, oy = ty0 + cy;
-    if (oz >= Do || oy >= Ho) continue;
-    if (MODE == FMT_PX) {
-      const int ox = tx0 + cx * 32 + 2 * jcol;  // rows (co, s): r = 2 * h + s
-      if (ox >= Wo) continue;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int co = 2 * kq + h;
-        float v0 = fmaf(acc[t][2 * h], scale[co], shift[co]);
-        float v1 = fmaf(acc[t][2 * h + 1], scale[co], shift[co]);
-        v0 = v0 > 0.0f ? v0 : v0 * slope;
-        v1 = v1 > 0.0f ? v1 : v1 * slope;
-        const size_t o = ((size_t)b * cout + co) * out_cs + ((size_t)oz * Ho + oy) * Wo + ox;
-        if ((Wo & 1) == 0) {  // ox even and Wo even: 8-byte aligned pair, both in range
-          if (skip) {
-            const f32x2 sk = *reinterpret_cast<const f32x2 *>(skip + o);
-            v0 += sk[0];
-            v1 += sk[1];
+  regs.load(plan, in + (size_t)cur.b * cin * in_cs, in_cs, cin, 0, cur.tz0 * STRIDE - 1, Di, Hi * Wi,
+            wpk + (size_t)cur.slice * per_slice, zero);
+  for (;;) {
+    const int next_item = item + gridDim.x;
+    TileCoord nxt = cur;
+    for (int s = 0; s < nstages; ++s) {
+      if (ABL != 2 || s == 0) {
+        __syncthreads();  // every wave is done reading the previous chunk
+        regs.store(tile, wts);
+        __syncthreads();
+        if (ABL != 2) {
+          // prefetch the next chunk - or chunk 0 of the next tile - through ONE load site;
+          // it is consumed after the next barrier
+          int n_ci0 = (s + 1) * CK;
+          bool have_next = true;
+          if (s + 1 == nstages) {
+            n_ci0 = 0;
+            have_next = next_item < total;
+            if (have_next) {
+              nxt = decode_tile<TZ, TY, TX>(next_item, tiles_x, tiles_y, tiles_z, B);
+              plan.init(nxt.ty0 * STRIDE - 1, nxt.tx0 * STRIDE - 1, Hi, Wi);
+            }
           }
-          *reinterpret_cast<f32x2 *>(out + o) = f32x2{v0, v1};
-        } else {
-          if (skip) v0 += skip[o];
-          out[o] = v0;
-          if (ox + 1 < Wo) {
-            if (skip) v1 += skip[o + 1];
-            out[o + 1] = v1;
+          if (have_next)
+            regs.load(plan, in + (size_t)nxt.b * cin * in_cs, in_cs, cin, n_ci0, nxt.tz0 * STRIDE - 1, Di, Hi * Wi,
+                      wpk + (size_t)nxt.slice * per_slice + (size_t)(n_ci0 / CK) * NW, zero);
+        }
+      }
+      if (ABL == 1) {
+        acc[0][0] += tile[lane + s];  // keep the staged data live
+        continue;
+      }
+
+      float a_cur[NA], a_nxt[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) a_cur[a] = wts[(a * NITER) * 64 + lane];
+      int ad_c[NT], ad_n[NT];  // per-tile LDS word address of the current / next iteration
+#pragma unroll
+      for (int t = 0; t < NT; ++t) ad_c[t] = base[t];  // iteration 0: offset 0
+      float ring[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) ring[i] = tile[ad_c[i % NT] + (i / NT) * ASTEP];
+      for (int it = 0; it < NITER; ++it) {
+        const int itn = it < NITER - 1 ? it + 1 : NITER - 1;  // last iteration: harmless re-read
+#pragma unroll
+        for (int a = 0; a < NA; ++a) a_nxt[a] = wts[(a * NITER + itn) * 64 + lane];
+        const int off_n = it_off(itn);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ad_n[t] = base[t] + off_n;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int a = i / NT, t = i % NT;
+          const float bcur = ring[i % P];
+          const int ii = i + P;
+          if (ii < NS) ring[i % P] = tile[ad_c[ii % NT] + (ii / NT) * ASTEP];
+          else ring[i % P] = tile[ad_n[(ii - NS) % NT] + ((ii - NS) / NT) * ASTEP];
+          acc[t] = mfma16(a_cur[a], bcur, acc[t]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a) a_cur[a] = a_nxt[a];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ad_c[t] = ad_n[t];
+      }
+    }
+
+    // epilogue of tile `cur`: y = lrelu(acc * scale + shift) (+ skip); the lane holds rows
+    // 4*kq + r of column jcol.  The accumulators are cleared for the next tile.
+    const float *scale = tail + cur.slice * COUTB;
+    const float *shift = scale + slices * COUTB;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int ct = wave * NT + t;
+      const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
+      const int oz = cur.tz0 + cz, oy = cur.ty0 + cy;
+      const f32x4 av = acc[t];
+      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (oz >= Do || oy >= Ho) continue;
+      if (MODE == FMT_PX) {
+        const int ox = cur.tx0 + cx * 32 + 2 * jcol;  // rows (co, s): r = 2 * h + s
+        if (ox >= Wo) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int co = 2 * kq + h;
+          float v0 = fmaf(av[2 * h], scale[co], shift[co]);
+          float v1 = fmaf(av[2 * h + 1], scale[co], shift[co]);
+          v0 = v0 > 0.0f ? v0 : v0 * slope;
+          v1 = v1 > 0.0f ? v1 : v1 * slope;
+          const size_t o = ((size_t)cur.b * cout + co) * out_cs + ((size_t)oz * Ho + oy) * Wo + ox;
+          if ((Wo & 1) == 0) {  // ox even and Wo even: 8-byte aligned pair, both in range
+            if (skip) {
+              const f32x2 sk = *reinterpret_cast<const f32x2 *>(skip + o);
+              v0 += sk[0];
+              v1 += sk[1];
+            }
+            *reinterpret_cast<f32x2 *>(out + o) = f32x2{v0, v1};
+          } else {
+            if (skip) v0 += skip[o];
+            out[o] = v0;
+            if (ox + 1 < Wo) {
+              if (skip) v1 += skip[o + 1];
+              out[o + 1] = v1;
+            }
+          }
+        }
+      } else {
+        const int ox = cur.tx0 + cx * 16 + jcol;
+        if (ox >= Wo) continue;
+        const size_t vo = ((size_t)oz * Ho + oy) * Wo + ox;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = 4 * kq + r, co = cur.slice * 16 + col;
+          if (co < cout) {
+            float v = fmaf(av[r], scale[col], shift[col]);
+            v = v > 0.0f ? v : v * slope;
+            const size_t o = ((size_t)cur.b * cout + co) * out_cs + vo;
+            if (skip) v += skip[o];
+            out[o] = v;
           }
         }
       }
-    } else {
-      const int ox = tx0 + cx * 16 + jcol;
-      if (ox >= Wo) continue;
-      const size_t vo = ((size_t)oz * Ho + oy) * Wo + ox;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = 4 * kq + r, co = slice * 16 + col;
-        if (co < cout) {
-          float v = fmaf(acc[t][r], scale[col], shift[col]);
-          v = v > 0.0f ? v : v * slope;
-          const size_t o = ((size_t)b * cout + co) * out_cs + vo;
-          if (skip) v += skip[o];
-          out[o] = v;
-        }
-      }
     }
+    if (next_item >= total) break;
+    item = next_item;
+    cur = nxt;
   }
 }
 
@@ -681,6 +734,35 @@ __global__ __launch_bounds__(kThreads) void mfma_rate_kernel(float *out, int ite
   if (s == 123.456f) out[0] = s;  // keep the chains live
 }
 
+// Shape 4: the conv inner loop in isolation - one ds_read_b32 (ring, 8 steps ahead) per 16x16x4 MFMA.
+__global__ __launch_bounds__(kThreads) void mfma_lds_rate_kernel(float *out, int iters) {
+  __shared__ float lds[8192];
+  for (int i = threadIdx.x; i < 8192; i += kThreads) lds[i] = 1.0f + i * 1e-6f;
+  __syncthreads();
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float a = 1.0f + threadIdx.x * 1e-6f;
+  const int lane_off = (threadIdx.x & 63) + (threadIdx.x >> 6) * 1024;
+  float ring[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ring[i] = lds[lane_off + i * 64];
+  for (int it = 0; it < iters; ++it) {
+    const int o = lane_off + ((it & 7) << 6);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float b = ring[i & 7];
+      ring[i & 7] = lds[o + ((i * 37) & 511)];
+      acc[i & 7] = mfma16(a, b, acc[i & 7]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+  if (s == 123.456f) out[0] = s;
+}
+
 // Kernels that need more than the default 64 KiB of LDS must opt in once per process.
 template <class K>
 int ensure_lds(K kernel, size_t bytes, const char *what) {
@@ -694,18 +776,41 @@ int ensure_lds(K kernel, size_t bytes, const char *what) {
   return CASMVS_OK;
 }
 
+// Number of workgroups of `kernel` that are resident on the whole device at once (cached per
+// kernel instantiation): the persistent kernels launch exactly that many.
+template <class K>
+int resident_blocks(K kernel, size_t lds_bytes) {
+  static int cached = 0;
+  if (cached == 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cached = per_cu * cus;
+  }
+  return cached;
+}
+
 template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
 int launch_conv16(const LayerCfg &c, const float *packed, const float *in, const float *skip,
                   float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                   float slope, hipStream_t st) {
   using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX>;
   auto kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX>;
+  if (MODE == FMT_PX) {  // profiling-only ablations of the dominant kernel (results are wrong)
+    static const int abl = getenv("CASMVS_ABLATE") ? atoi(getenv("CASMVS_ABLATE")) : 0;
+    if (abl == 1) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, 1>;
+    if (abl == 2) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, 2>;
+  }
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv16_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wo, TX), tiles_y = casmvs::ceil_div(Ho, TY),
             tiles_z = casmvs::ceil_div(Do, TZ);
-  dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, (unsigned)c.slices);
-  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, cin, cout,
-                     Di, Hi, Wi, Do, Ho, Wo, (int)c.per_slice(), tiles_x, tiles_y, slope);
+  const long total = (long)tiles_x * tiles_y * tiles_z * B * c.slices;
+  CASMVS_REQUIRE(total < (1L << 31), "conv3d_forward: too many tiles");
+  const int resident = resident_blocks(conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX>, Cfg::LDS_BYTES);
+  dim3 grid((unsigned)(total < resident ? total : resident));
+  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, B, cin, cout,
+                     Di, Hi, Wi, Do, Ho, Wo, (int)c.per_slice(), c.slices, tiles_x, tiles_y, tiles_z, slope);
   return casmvs::check_launch("conv16_kernel");
 }
 
@@ -858,7 +963,7 @@ extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, con
 
 extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float *tflops) {
   casmvs::clear_error();
-  CASMVS_REQUIRE(shape >= 0 && shape <= 3 && blocks > 0 && iters > 0 && tflops, "selftest_mfma_rate: bad arguments");
+  CASMVS_REQUIRE(shape >= 0 && shape <= 4 && blocks > 0 && iters > 0 && tflops, "selftest_mfma_rate: bad arguments");
   float *d = nullptr;
   hipEvent_t e0, e1;
   if (hipMalloc(&d, 64) != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "selftest_mfma_rate: hipMalloc failed");
@@ -869,7 +974,8 @@ extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float
       case 0: hipLaunchKernelGGL(mfma_rate_kernel<0>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
       case 1: hipLaunchKernelGGL(mfma_rate_kernel<1>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
       case 2: hipLaunchKernelGGL(mfma_rate_kernel<2>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
-      default: hipLaunchKernelGGL(mfma_rate_kernel<3>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
+      case 3: hipLaunchKernelGGL(mfma_rate_kernel<3>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
+      default: hipLaunchKernelGGL(mfma_lds_rate_kernel, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
     }
   };
   launch(16);  // warm-up
@@ -883,7 +989,7 @@ extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float
   (void)hipEventDestroy(e1);
   (void)hipFree(d);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "selftest_mfma_rate: %s", hipGetErrorString(e));
-  const double flop_per_mfma[4] = {512.0, 2048.0, 4096.0, 2048.0};  // 4x4x1_16b, 16x16x4, 32x32x2, 16x16x1_4b
+  const double flop_per_mfma[5] = {512.0, 2048.0, 4096.0, 2048.0, 2048.0};  // 4x4x1_16b, 16x16x4, 32x32x2, 16x16x1_4b, 16x16x4 + ds_read
   const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 * flop_per_mfma[shape];
   *tflops = (float)(flops / (ms * 1e-3) / 1e12);
   return CASMVS_OK;

@@ -162,7 +162,8 @@ int casmvs_selftest_mfma(float *dump);
 
 /* Issue-rate probe: `blocks` workgroups x 4 wavefronts x `iters` x 16 back-to-back MFMAs on
  * independent accumulators; writes the achieved TFLOP/s.
- * shape: 0 = v_mfma_f32_4x4x1_16b_f32 (cbsz 4), 1 = 16x16x4_f32, 2 = 32x32x2_f32, 3 = 16x16x1_4b_f32. */
+ * shape: 0 = v_mfma_f32_4x4x1_16b_f32 (cbsz 4), 1 = 16x16x4_f32, 2 = 32x32x2_f32, 3 = 16x16x1_4b_f32,
+ * 4 = 16x16x4_f32 interleaved with one ds_read_b32 per MFMA (the conv inner loop in isolation). */
 int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float *tflops);
 
 #ifdef __cplusplus
