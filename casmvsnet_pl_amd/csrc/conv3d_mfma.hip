@@ -134,6 +134,32 @@ inline float pack_weight(const LayerCfg &c, int kind, int cin, int cout, const f
   return 0.0f;
 }
 
+// ---- buffer addressing ---------------------------------------------------------------------------
+// Tiles are staged with raw buffer loads/stores: address = descriptor base (SGPRs) + per-lane byte
+// offset (VGPR, invariant for a whole tile) + per-plane byte offset (SGPR).  A load then costs one
+// scalar add and one buffer_load - no per-lane 64-bit address arithmetic, no predicate - and a
+// lane whose position is outside the image carries the offset kOOB >= num_records, for which the
+// hardware returns 0 (loads) or drops the access (stores): the convolution's zero padding for free.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int kOOB = (int)0x80000000u;  // needs num_records <= 2^31 bytes (checked on the host)
+
+__device__ __forceinline__ rsrc_t make_rsrc(const float *base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load2(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store2(f32x2 v, rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+}
+
 // ---- staging: global -> registers -> LDS, software-pipelined one chunk ahead -------------------
 // A chunk = CK input channels of the zero-padded halo tile (CK*IZ planes of IY*IX floats) plus
 // the chunk's NW weight floats.  A thread copies the same NPASS in-plane positions of every
@@ -147,16 +173,15 @@ template <int IY, int IX>
 struct StagePlan {
   static constexpr int PLANE = IY * IX;
   static constexpr int NPASS = (PLANE + kThreads - 1) / kThreads;
-  int goff[NPASS];   // gy * Wi + gx of this thread's position (valid only if inb)
-  bool inb[NPASS];   // position inside the image in y and x
+  int voff[NPASS];   // byte offset (gy * Wi + gx) * 4 of this thread's position, or kOOB
   __device__ __forceinline__ void init(int iy0, int ix0, int Hi, int Wi) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const int pe = threadIdx.x + p * kThreads;
       const int iy = pe / IX, ix = pe - iy * IX;
       const int gy = iy0 + iy, gx = ix0 + ix;
-      inb[p] = pe < PLANE && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
-      goff[p] = gy * Wi + gx;
+      const bool inb = pe < PLANE && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+      voff[p] = inb ? (gy * Wi + gx) * 4 : kOOB;
     }
   }
 };
@@ -169,9 +194,8 @@ struct StageRegs {
   float w[NWR];
 
   // issue every load of the chunk that starts at input channel ci0; nothing here waits
-  __device__ __forceinline__ void load(const StagePlan<IY, IX> &plan, const float *__restrict__ inb,
-                                       size_t in_cs, int cin, int ci0, int iz0, int Di, int HiWi,
-                                       const float *__restrict__ wchunk, const float *__restrict__ zero) {
+  __device__ __forceinline__ void load(const StagePlan<IY, IX> &plan, rsrc_t src, int in_cs, int cin, int ci0,
+                                       int iz0, int Di, int HiWi, const float *__restrict__ wchunk) {
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
       const int e = threadIdx.x + i * kThreads;
@@ -182,16 +206,9 @@ struct StageRegs {
       const int cil = pl / IZ, iz = pl - cil * IZ;
       const int ci = ci0 + cil, gz = iz0 + iz;
       const bool plane_ok = ci < cin && gz >= 0 && gz < Di;  // wave-uniform
-      // branch-free and mask-free: out-of-range positions load from a zero word that the packed
-      // parameter image carries at its end, so no predicate has to survive until the data lands.
-      // 32-bit element offsets (one sample's input is < 2^31 floats).
-      const int poff = ci * (int)in_cs + gz * HiWi;
+      const int soff = plane_ok ? (ci * in_cs + gz * HiWi) * 4 : 0;
 #pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const bool ok = plane_ok && plan.inb[p];
-        const float *ptr = ok ? inb + (poff + plan.goff[p]) : zero;
-        v[pl][p] = *ptr;
-      }
+      for (int p = 0; p < NPASS; ++p) v[pl][p] = buf_load(src, plane_ok ? plan.voff[p] : kOOB, soff);
     }
   }
 
@@ -235,6 +252,19 @@ struct Conv16Cfg {
   static constexpr int NW = NITER * NA * 64;
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
+
+#ifdef CASMVS_TRACE
+// Profiling build only (tools/gpu_trace.sh): wave 0 of the first 64 workgroups of conv16_kernel
+// stamps the shader clock at phase boundaries into a device buffer read back by casmvs_trace_read.
+__device__ unsigned long long g_trace[64 * 128];
+#define TRACE_STAMP()                                                                 \
+  do {                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 64 && tr_n < 128)                            \
+      g_trace[blockIdx.x * 128 + tr_n++] = __builtin_readcyclecounter();              \
+  } while (0)
+#else
+#define TRACE_STAMP() do {} while (0)
+#endif
 
 // Work item (= one output tile of one slice of one sample) decoded from a flat index; x fastest so
 // that workgroups resident at the same time touch neighbouring input.
@@ -293,10 +323,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const size_t in_cs = (size_t)Di * Hi * Wi;  // input channel stride
-  const size_t out_cs = (size_t)Do * Ho * Wo;
+  const int in_cs = Di * Hi * Wi;    // input / output channel strides (floats); one sample of
+  const int out_cs = Do * Ho * Wo;   // either tensor is < 2^29 floats (checked on the host)
+  const size_t in_ss = (size_t)cin * in_cs, out_ss = (size_t)cout * out_cs;  // sample strides
   const float *tail = wpk + (size_t)slices * per_slice;     // scale | shift | zero
-  const float *zero = tail + 2 * slices * COUTB;            // 64 zero floats
 
   // MFMA loop of one chunk, written out in issue order and pinned with sched_barrier.  Step
   // s = (a, t) of an iteration needs one B operand (ds_read_b32, immediate offset a * ASTEP) and
@@ -311,20 +341,41 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
     return MODE == FMT_PX ? (it / 3) * SZ + (it % 3) * SY : (it / 9) * SZ + ((it / 3) % 3) * SY + (it % 3);
   };
 
+#ifdef CASMVS_TRACE
+  int tr_n = 0;
+#endif
+  TRACE_STAMP();  // kernel start
   TileCoord cur = decode_tile<TZ, TY, TX>(item, tiles_x, tiles_y, tiles_z, B);
   StagePlan<IY, IX> plan;
   plan.init(cur.ty0 * STRIDE - 1, cur.tx0 * STRIDE - 1, Hi, Wi);
   StageRegs<CK, IZ, IY, IX, SC, NW> regs;
-  regs.load(plan, in + (size_t)cur.b * cin * in_cs, in_cs, cin, 0, cur.tz0 * STRIDE - 1, Di, Hi * Wi,
-            wpk + (size_t)cur.slice * per_slice, zero);
+  regs.load(plan, make_rsrc(in + cur.b * in_ss, in_ss * 4), in_cs, cin, 0, cur.tz0 * STRIDE - 1, Di, Hi * Wi,
+            wpk + (size_t)cur.slice * per_slice);
   for (;;) {
     const int next_item = item + gridDim.x;
     TileCoord nxt = cur;
+    // this lane's folded-ABN coefficients, fetched now so that the epilogue issues no load (the
+    // in-order vmcnt wait of an epilogue load would also wait for the next tile's prefetch)
+    constexpr int NCO = MODE == FMT_PX ? 2 : 4;
+    float sc[NCO], sh[NCO];
+    {
+      const float *scale = tail + cur.slice * COUTB;
+      const float *shift = scale + slices * COUTB;
+#pragma unroll
+      for (int r = 0; r < NCO; ++r) {
+        const int col = (MODE == FMT_PX ? 2 : 4) * kq + r;
+        sc[r] = scale[col];
+        sh[r] = shift[col];
+      }
+    }
     for (int s = 0; s < nstages; ++s) {
       if (ABL != 2 || s == 0) {
+        TRACE_STAMP();  // chunk begin (before barrier 1)
         __syncthreads();  // every wave is done reading the previous chunk
+        TRACE_STAMP();  // after barrier 1
         regs.store(tile, wts);
         __syncthreads();
+        TRACE_STAMP();  // after store + barrier 2
         if (ABL != 2) {
           // prefetch the next chunk - or chunk 0 of the next tile - through ONE load site;
           // it is consumed after the next barrier
@@ -339,8 +390,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
             }
           }
           if (have_next)
-            regs.load(plan, in + (size_t)nxt.b * cin * in_cs, in_cs, cin, n_ci0, nxt.tz0 * STRIDE - 1, Di, Hi * Wi,
-                      wpk + (size_t)nxt.slice * per_slice + (size_t)(n_ci0 / CK) * NW, zero);
+            regs.load(plan, make_rsrc(in + nxt.b * in_ss, in_ss * 4), in_cs, cin, n_ci0, nxt.tz0 * STRIDE - 1, Di,
+                      Hi * Wi, wpk + (size_t)nxt.slice * per_slice + (size_t)(n_ci0 / CK) * NW);
         }
       }
       if (ABL == 1) {
@@ -348,6 +399,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
         continue;
       }
 
+      TRACE_STAMP();  // prefetch issued, MFMA loop begins
       float a_cur[NA], a_nxt[NA];
 #pragma unroll
       for (int a = 0; a < NA; ++a) a_cur[a] = wts[(a * NITER) * 64 + lane];
@@ -381,10 +433,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
       }
     }
 
+    TRACE_STAMP();  // last chunk's MFMA loop done, epilogue begins
     // epilogue of tile `cur`: y = lrelu(acc * scale + shift) (+ skip); the lane holds rows
     // 4*kq + r of column jcol.  The accumulators are cleared for the next tile.
-    const float *scale = tail + cur.slice * COUTB;
-    const float *shift = scale + slices * COUTB;
+    // Buffer stores: per-lane byte offset = (this lane's first channel, voxel), scalar offset =
+    // remaining channel stride; lanes outside the volume / beyond cout carry kOOB and are dropped.
+    const rsrc_t dst = make_rsrc(out + cur.b * out_ss, out_ss * 4);
+    const rsrc_t skp = make_rsrc(skip ? skip + cur.b * out_ss : out, out_ss * 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int ct = wave * NT + t;
@@ -392,51 +447,49 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
       const int oz = cur.tz0 + cz, oy = cur.ty0 + cy;
       const f32x4 av = acc[t];
       acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (oz >= Do || oy >= Ho) continue;
       if (MODE == FMT_PX) {
-        const int ox = cur.tx0 + cx * 32 + 2 * jcol;  // rows (co, s): r = 2 * h + s
-        if (ox >= Wo) continue;
+        const int ox = cur.tx0 + cx * 32 + 2 * jcol;  // rows (co, s): r = 2 * h + s; channels 2*kq + h
+        const bool ok = oz < Do && oy < Ho && ox < Wo;
+        const int voff = ok ? (2 * kq * out_cs + (oz * Ho + oy) * Wo + ox) * 4 : kOOB;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int co = 2 * kq + h;
-          float v0 = fmaf(av[2 * h], scale[co], shift[co]);
-          float v1 = fmaf(av[2 * h + 1], scale[co], shift[co]);
+          float v0 = fmaf(av[2 * h], sc[h % NCO], sh[h % NCO]);
+          float v1 = fmaf(av[2 * h + 1], sc[h % NCO], sh[h % NCO]);
           v0 = v0 > 0.0f ? v0 : v0 * slope;
           v1 = v1 > 0.0f ? v1 : v1 * slope;
-          const size_t o = ((size_t)cur.b * cout + co) * out_cs + ((size_t)oz * Ho + oy) * Wo + ox;
+          const int soff = h * out_cs * 4;
           if ((Wo & 1) == 0) {  // ox even and Wo even: 8-byte aligned pair, both in range
             if (skip) {
-              const f32x2 sk = *reinterpret_cast<const f32x2 *>(skip + o);
+              const f32x2 sk = buf_load2(skp, voff, soff);
               v0 += sk[0];
               v1 += sk[1];
             }
-            *reinterpret_cast<f32x2 *>(out + o) = f32x2{v0, v1};
+            buf_store2(f32x2{v0, v1}, dst, voff, soff);
           } else {
-            if (skip) v0 += skip[o];
-            out[o] = v0;
-            if (ox + 1 < Wo) {
-              if (skip) v1 += skip[o + 1];
-              out[o + 1] = v1;
+            const int voff1 = (ok && ox + 1 < Wo) ? voff + 4 : kOOB;
+            if (skip) {
+              v0 += buf_load(skp, voff, soff);
+              v1 += buf_load(skp, voff1, soff);
             }
+            buf_store(v0, dst, voff, soff);
+            buf_store(v1, dst, voff1, soff);
           }
         }
       } else {
-        const int ox = cur.tx0 + cx * 16 + jcol;
-        if (ox >= Wo) continue;
-        const size_t vo = ((size_t)oz * Ho + oy) * Wo + ox;
+        const int ox = cur.tx0 + cx * 16 + jcol;  // channels slice*16 + 4*kq + r
+        const bool ok = oz < Do && oy < Ho && ox < Wo;
+        const int vbase = ((cur.slice * 16 + 4 * kq) * out_cs + (oz * Ho + oy) * Wo + ox) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int col = 4 * kq + r, co = cur.slice * 16 + col;
-          if (co < cout) {
-            float v = fmaf(av[r], scale[col], shift[col]);
-            v = v > 0.0f ? v : v * slope;
-            const size_t o = ((size_t)cur.b * cout + co) * out_cs + vo;
-            if (skip) v += skip[o];
-            out[o] = v;
-          }
+          const int voff = (ok && cur.slice * 16 + 4 * kq + r < cout) ? vbase : kOOB;
+          float v = fmaf(av[r], sc[r % NCO], sh[r % NCO]);
+          v = v > 0.0f ? v : v * slope;
+          if (skip) v += buf_load(skp, voff, r * out_cs * 4);
+          buf_store(v, dst, voff, r * out_cs * 4);
         }
       }
     }
+    TRACE_STAMP();  // epilogue done
     if (next_item >= total) break;
     item = next_item;
     cur = nxt;
@@ -503,23 +556,23 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[ps][p][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const size_t in_cs = (size_t)Di * Hi * Wi;
-  const float *inb = in + (size_t)b * cin * in_cs;
+  const int in_cs = Di * Hi * Wi;
+  const size_t in_ss = (size_t)cin * in_cs;
+  const rsrc_t src = make_rsrc(in + b * in_ss, in_ss * 4);
   const float *wslice = wpk + (size_t)slice * per_slice;
   const float *scale = wpk + (size_t)slices * per_slice + slice * COUTB;
   const float *shift = scale + slices * COUTB;
-  const float *zero = wpk + (size_t)slices * per_slice + 2 * slices * COUTB;
   StagePlan<IY, IX> plan;
   plan.init(ty0, tx0, Hi, Wi);
   StageRegs<CK, IZ, IY, IX, SC, NW> regs;
-  regs.load(plan, inb, in_cs, cin, 0, tz0, Di, Hi * Wi, wslice, zero);
+  regs.load(plan, src, in_cs, cin, 0, tz0, Di, Hi * Wi, wslice);
 
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
     regs.store(tile, wts);
     __syncthreads();
     if (s + 1 < nstages)
-      regs.load(plan, inb, in_cs, cin, (s + 1) * CK, tz0, Di, Hi * Wi, wslice + (size_t)(s + 1) * NW, zero);
+      regs.load(plan, src, in_cs, cin, (s + 1) * CK, tz0, Di, Hi * Wi, wslice + (size_t)(s + 1) * NW);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       float aw[UI];  // this quad's images
@@ -557,37 +610,46 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
   }
 
   const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
-  const size_t out_cs = (size_t)Do * Ho * Wo;
+  const int out_cs = Do * Ho * Wo;
+  const size_t out_ss = (size_t)cout * out_cs;
+  const rsrc_t dst = make_rsrc(out + b * out_ss, out_ss * 4);
+  const rsrc_t skp = make_rsrc(skip ? skip + b * out_ss : out, out_ss * 4);
+  constexpr int NCO = MODE == FMT_TCI ? 4 : 2;
+  float sc[NCO], sh[NCO];
+#pragma unroll
+  for (int h = 0; h < NCO; ++h) {
+    sc[h] = scale[NCO * kq + h];
+    sh[h] = shift[NCO * kq + h];
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int ct = wave * NT + t;
     const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
     const int mz = tz0 + cz, my = ty0 + cy, mx = tx0 + cx * 16 + jcol;
-    if (mz >= Di || my >= Hi || mx >= Wi) continue;
+    const bool ok = mz < Di && my < Hi && mx < Wi;
+    // per-lane part: first channel of the lane (slice*COUTB + NCO*kq) and the cell's even-corner voxel
+    const int vcell = ((slice * COUTB + NCO * kq) * out_cs + (2 * mz * Ho + 2 * my) * Wo + 2 * mx) * 4;
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int pz = ps >> 1, py = ps & 1;
-      const size_t vo = ((size_t)(2 * mz + pz) * Ho + (2 * my + py)) * Wo + 2 * mx;
 #pragma unroll
-      for (int h = 0; h < (MODE == FMT_TCI ? 4 : 2); ++h) {
+      for (int h = 0; h < NCO; ++h) {
         // TCI: h = row r -> channel 4*kq + r, pair = (parity 0, parity 1) accumulators
         // TPX: h -> channel 2*kq + h, pair = rows (2h, 2h+1) of the single accumulator
-        const int col = MODE == FMT_TCI ? 4 * kq + h : 2 * kq + h;
-        const int co = slice * COUTB + col;
-        if (co >= cout) continue;
+        const int voff = (ok && slice * COUTB + NCO * kq + h < cout) ? vcell : kOOB;
+        const int soff = (h * out_cs + (pz * Ho + py) * Wo) * 4;
         float v0 = MODE == FMT_TCI ? acc[ps][0][t][h] : acc[ps][0][t][(2 * h) & 3];
         float v1 = MODE == FMT_TCI ? acc[ps][NACC - 1][t][h] : acc[ps][0][t][(2 * h + 1) & 3];
-        v0 = fmaf(v0, scale[col], shift[col]);
-        v1 = fmaf(v1, scale[col], shift[col]);
+        v0 = fmaf(v0, sc[h], sh[h]);
+        v1 = fmaf(v1, sc[h], sh[h]);
         v0 = v0 > 0.0f ? v0 : v0 * slope;
         v1 = v1 > 0.0f ? v1 : v1 * slope;
-        const size_t o = ((size_t)b * cout + co) * out_cs + vo;
         if (skip) {
-          const f32x2 sk = *reinterpret_cast<const f32x2 *>(skip + o);
+          const f32x2 sk = buf_load2(skp, voff, soff);
           v0 += sk[0];
           v1 += sk[1];
         }
-        *reinterpret_cast<f32x2 *>(out + o) = f32x2{v0, v1};
+        buf_store2(f32x2{v0, v1}, dst, voff, soff);
       }
     }
   }
@@ -635,21 +697,21 @@ __global__ __launch_bounds__(kThreads) void prob_kernel(
   f32x4 acc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const size_t in_cs = (size_t)Di * Hi * Wi;
-  const float *inb = in + (size_t)b * cin * in_cs;
+  const int in_cs = Di * Hi * Wi;
+  const size_t in_ss = (size_t)cin * in_cs;
+  const rsrc_t src = make_rsrc(in + b * in_ss, in_ss * 4);
   const float *scale = wpk + (size_t)nstages * NW;
   const float *shift = scale + 4;
-  const float *zero = scale + 8;
   StagePlan<IY, IX> plan;
   plan.init(ty0 - 1, tx0 - 1, Hi, Wi);
   StageRegs<CK, IZ, IY, IX, SC, NW> regs;
-  regs.load(plan, inb, in_cs, cin, 0, tz0 - 1, Di, Hi * Wi, wpk, zero);
+  regs.load(plan, src, in_cs, cin, 0, tz0 - 1, Di, Hi * Wi, wpk);
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
     regs.store(tile, wts);
     __syncthreads();
     if (s + 1 < nstages)
-      regs.load(plan, inb, in_cs, cin, (s + 1) * CK, tz0 - 1, Di, Hi * Wi, wpk + (size_t)(s + 1) * NW, zero);
+      regs.load(plan, src, in_cs, cin, (s + 1) * CK, tz0 - 1, Di, Hi * Wi, wpk + (size_t)(s + 1) * NW);
     for (int tap = 0; tap < 27; ++tap) {
       const float a = wts[tap * 64 + lane];
       const int toff = (tap / 9) * SZ + ((tap / 3) % 3) * SY + (tap % 3);
@@ -667,7 +729,7 @@ __global__ __launch_bounds__(kThreads) void prob_kernel(
       });
     }
   }
-  const size_t out_cs = in_cs;
+  const size_t out_cs = (size_t)in_cs;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int oz = tz0 + vz[g], oy = ty0 + vy[g], ox = tx0 + vx[g];
@@ -878,7 +940,13 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
   LayerCfg c;
   if (!layer_cfg(kind, cin, cout, c))
     return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv3d_forward: kind=%d cin=%d cout=%d", kind, cin, cout);
-  CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 31), "conv3d_forward: one sample's input must hold < 2^31 floats");
+  // buffer descriptors address one sample's tensor with 31-bit byte offsets
+  {
+    const size_t in_floats = (size_t)cin * D * H * W;
+    const size_t out_floats = (size_t)cout * D * H * W * (kind == CASMVS_CONV_T2 ? 8 : 1) / (kind == CASMVS_CONV_S2 ? 8 : 1);
+    CASMVS_REQUIRE(in_floats < ((size_t)1 << 29) && out_floats < ((size_t)1 << 29),
+                   "conv3d_forward: one sample's input / output tensor must hold < 2^29 floats");
+  }
   hipStream_t st = (hipStream_t)stream;
   // Workgroup shapes.  "wide" variants (many column tiles per wave, small CK) maximise operand
   // reuse for the big full-resolution layers; "deep" variants (1 column tile per wave, CK = 16:
@@ -1028,3 +1096,15 @@ extern "C" int casmvs_selftest_mfma(float *dump) {
       }
   return CASMVS_OK;
 }
+
+#ifdef CASMVS_TRACE
+extern "C" int casmvs_trace_read(unsigned long long *host, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return -3;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 64 * 128) != hipSuccess) return -3;
+  if (clear) {
+    static unsigned long long z[64 * 128];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace), z, sizeof(z)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#endif
