@@ -169,33 +169,50 @@ __device__ __forceinline__ void buf_store2(f32x2 v, rsrc_t r, int voff, int soff
 // while the MFMA loop of chunk s runs; they are written to LDS after the next barrier.  Weights
 // go through LDS too, so that the MFMA loop contains no vector-memory instruction (an in-loop
 // global load would make the compiler's in-order vmcnt wait drain the whole prefetch).
-template <int IY, int IX>
-struct StagePlan {
-  static constexpr int PLANE = IY * IX;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v buf_load4(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// Stager<VEC = 1>: one float per load.  A thread copies the same NPASS in-plane positions of
+// every plane; per-lane byte offsets are tile constants, the plane offset is scalar.
+// Stager<VEC = 4>: 16-byte loads / ds_write_b128 (needs Wi % 4 == 0 and 4-aligned tile origins; rows
+// are widened to aligned 16-byte groups).  The chunk's float4 groups are flattened over the 256
+// threads (group e = tid + 256 k), so a chunk costs ceil(groups / 256) vector-memory instructions
+// per thread - 4x fewer than VEC = 1, which is what bounds the staging phase: the texture
+// addresser retires ~1 wave-instruction per 16 cycles regardless of its width (measured).
+template <int VEC, int CK, int IZ, int IY, int IXR, int SC, int NW>
+struct Stager;
+
+template <int CK, int IZ, int IY, int IXR, int SC, int NW>
+struct Stager<1, CK, IZ, IY, IXR, SC, NW> {
+  static constexpr int PLANE = IY * IXR, NPL = CK * IZ;
   static constexpr int NPASS = (PLANE + kThreads - 1) / kThreads;
+  static constexpr int NWR = (NW + kThreads - 1) / kThreads;
+  int in_cs, HiWi, Di, iz0;
   int voff[NPASS];   // byte offset (gy * Wi + gx) * 4 of this thread's position, or kOOB
-  __device__ __forceinline__ void init(int iy0, int ix0, int Hi, int Wi) {
+  float v[NPL][NPASS];
+  float w[NWR];
+
+  __device__ __forceinline__ void init_kernel(int in_cs_, int HiWi_, int Di_) {
+    in_cs = in_cs_;
+    HiWi = HiWi_;
+    Di = Di_;
+  }
+  __device__ __forceinline__ void init_tile(int iz0_, int iy0, int ix0, int Hi, int Wi) {
+    iz0 = iz0_;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       const int pe = threadIdx.x + p * kThreads;
-      const int iy = pe / IX, ix = pe - iy * IX;
+      const int iy = pe / IXR, ix = pe - iy * IXR;
       const int gy = iy0 + iy, gx = ix0 + ix;
       const bool inb = pe < PLANE && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
       voff[p] = inb ? (gy * Wi + gx) * 4 : kOOB;
     }
   }
-};
-
-template <int CK, int IZ, int IY, int IX, int SC, int NW>
-struct StageRegs {
-  static constexpr int NPL = CK * IZ, NPASS = StagePlan<IY, IX>::NPASS, PLANE = IY * IX;
-  static constexpr int NWR = (NW + kThreads - 1) / kThreads;
-  float v[NPL][NPASS];
-  float w[NWR];
-
   // issue every load of the chunk that starts at input channel ci0; nothing here waits
-  __device__ __forceinline__ void load(const StagePlan<IY, IX> &plan, rsrc_t src, int in_cs, int cin, int ci0,
-                                       int iz0, int Di, int HiWi, const float *__restrict__ wchunk) {
+  __device__ __forceinline__ void load(rsrc_t src, int cin, int ci0, const float *__restrict__ wchunk) {
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
       const int e = threadIdx.x + i * kThreads;
@@ -208,10 +225,9 @@ struct StageRegs {
       const bool plane_ok = ci < cin && gz >= 0 && gz < Di;  // wave-uniform
       const int soff = plane_ok ? (ci * in_cs + gz * HiWi) * 4 : 0;
 #pragma unroll
-      for (int p = 0; p < NPASS; ++p) v[pl][p] = buf_load(src, plane_ok ? plan.voff[p] : kOOB, soff);
+      for (int p = 0; p < NPASS; ++p) v[pl][p] = buf_load(src, plane_ok ? voff[p] : kOOB, soff);
     }
   }
-
   // tile layout: [cil][iz][iy][ix] with channel stride SC (>= IZ*PLANE, padded for the banks)
   __device__ __forceinline__ void store(float *tile, float *wts) const {
 #pragma unroll
@@ -231,16 +247,94 @@ struct StageRegs {
   }
 };
 
+template <int CK, int IZ, int IY, int IXR, int SC, int NW>
+struct Stager<4, CK, IZ, IY, IXR, SC, NW> {
+  static_assert(IXR % 4 == 0 && SC % 4 == 0 && NW % 4 == 0, "16-byte groups");
+  static constexpr int ROWV = IXR / 4, PLV = IY * ROWV, TOTV = CK * IZ * PLV;
+  static constexpr int NK = (TOTV + kThreads - 1) / kThreads;
+  static constexpr int NWV = NW / 4, NWR = (NWV + kThreads - 1) / kThreads;
+  int in_cs, HiWi, Di;
+  int voff[NK];      // byte offset of group k inside the sample for chunk channel 0, or kOOB (tile constant)
+  f32x4v v[NK];
+  f32x4v w[NWR];
+
+  // group e = tid + 256 k -> (cil, iz, iy, xv); compile-time divisors, recomputed where needed
+  // instead of being kept in registers
+  struct Pos {
+    int cil, iz, iy, xv;
+    bool valid;
+  };
+  static __device__ __forceinline__ Pos pos_of(int k) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // opaque: keeps the compiler from hoisting 4 * NK decoded ints into registers
+    const int e = tid + k * kThreads;
+    const int pl = e / PLV, r = e - pl * PLV;
+    Pos p;
+    p.cil = pl / IZ;
+    p.iz = pl - p.cil * IZ;
+    p.iy = r / ROWV;
+    p.xv = r - p.iy * ROWV;
+    p.valid = e < TOTV;
+    return p;
+  }
+
+  __device__ __forceinline__ void init_kernel(int in_cs_, int HiWi_, int Di_) {
+    in_cs = in_cs_;
+    HiWi = HiWi_;
+    Di = Di_;
+  }
+  __device__ __forceinline__ void init_tile(int iz0, int iy0, int ix0, int Hi, int Wi) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const Pos p = pos_of(k);
+      const int gz = iz0 + p.iz, gy = iy0 + p.iy, gx = ix0 + 4 * p.xv;
+      const bool inb = p.valid && gz >= 0 && gz < Di && gy >= 0 && gy < Hi && gx >= 0 && gx + 3 < Wi;
+      voff[k] = inb ? (p.cil * in_cs + gz * HiWi + gy * Wi + gx) * 4 : kOOB;
+    }
+  }
+  __device__ __forceinline__ void load(rsrc_t src, int cin, int ci0, const float *__restrict__ wchunk) {
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+      const int e = threadIdx.x + i * kThreads;
+      w[i] = *reinterpret_cast<const f32x4v *>(wchunk + 4 * (e < NWV ? e : 0));
+    }
+    const int soff = ci0 * in_cs * 4;
+    const bool full = ci0 + CK <= cin;  // wave-uniform: only the last chunk can be channel-padded
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const bool ok = full || ci0 + pos_of(k).cil < cin;
+      v[k] = buf_load4(src, ok ? voff[k] : kOOB, soff);
+    }
+  }
+  __device__ __forceinline__ void store(float *tile, float *wts) const {
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+      const int e = threadIdx.x + i * kThreads;
+      if (e < NWV) *reinterpret_cast<f32x4v *>(wts + 4 * e) = w[i];
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const Pos p = pos_of(k);
+      if (p.valid) *reinterpret_cast<f32x4v *>(tile + p.cil * SC + p.iz * (IY * IXR) + p.iy * IXR + 4 * p.xv) = v[k];
+    }
+  }
+};
+
 constexpr int round_up_to_16_mod_32(int x) { return x + ((16 - x % 32) + 32) % 32; }
 
 // ---- Conv3d k3 p1 (stride 1 or 2) on 16x16x4 ----------------------------------------------------
-template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC>
 struct Conv16Cfg {
   static_assert(MODE == FMT_CI || MODE == FMT_PX, "conv16: CI or PX");
+  static_assert(VEC == 1 || (VEC == 4 && STRIDE == 1), "16-byte staging: stride-1 layers only");
   static constexpr int XW = MODE == FMT_PX ? 32 : 16;  // output voxels along x per column tile
   static constexpr int NXG = TX / XW;
   static_assert(TX % XW == 0 && TZ * TY * NXG == 4 * NT, "tile = 4 waves x NT column tiles");
-  static constexpr int IZ = STRIDE * (TZ - 1) + 3, IY = STRIDE * (TY - 1) + 3, IX = STRIDE * (TX - 1) + 3;
+  static constexpr int IZ = STRIDE * (TZ - 1) + 3, IY = STRIDE * (TY - 1) + 3;
+  // staged row: VEC 1: x in [x0 - 1, x0 + S(TX-1) + 2); VEC 4: widened to the aligned [x0 - 4, x0 + TX + 4)
+  static constexpr int IX = VEC == 4 ? TX + 8 : STRIDE * (TX - 1) + 3;
+  static constexpr int XLO = VEC == 4 ? 4 : 1;    // tile row starts at global x = S * x0 - XLO
+  static constexpr int XOFF = XLO - 1;            // local x of (output x0, tap kx = 0)
   static constexpr int SY = IX, SZ = IY * IX;
   // channel stride: B lanes k = 0..3 read 4 channels (CI) -> k * SC must land on disjoint banks:
   // stride 1: 16 consecutive words per k -> SC == 16 (mod 32); stride 2: even words -> SC odd.
@@ -290,14 +384,15 @@ __device__ __forceinline__ TileCoord decode_tile(int item, int tiles_x, int tile
 // chunk of the current one, so the global-load latency, the address set-up and the epilogue
 // stores of a tile all overlap MFMA work - measured per-workgroup fixed cost before: ~13 us.
 // ABL (ablation, profiling only): 0 = normal, 1 = staging only (no MFMA loop), 2 = MFMA loop only.
-template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int ABL = 0>
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
     int per_slice, int slices, int tiles_x, int tiles_y, int tiles_z, float slope) {
-  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX>;
+  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC>;
   const int nstages = (cin + CK - 1) / CK;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
+  constexpr int XLO = Cfg::XLO, XOFF = Cfg::XOFF;
   constexpr int NA = Cfg::NA, NITER = Cfg::NITER, ASTEP = Cfg::ASTEP, NW = Cfg::NW, NXG = Cfg::NXG;
   constexpr int COUTB = MODE == FMT_PX ? 8 : 16;
   extern __shared__ float smem[];
@@ -316,8 +411,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
   for (int t = 0; t < NT; ++t) {
     const int ct = wave * NT + t;
     const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
-    if (MODE == FMT_PX) base[t] = cz * SZ + cy * SY + cx * 32 + 2 * jcol + kq;                   // k = x-offset u
-    else base[t] = kq * SC + (cz * STRIDE) * SZ + (cy * STRIDE) * SY + (cx * 16 + jcol) * STRIDE;  // k = channel
+    if (MODE == FMT_PX) base[t] = cz * SZ + cy * SY + cx * 32 + 2 * jcol + kq + XOFF;                   // k = x-offset u
+    else base[t] = kq * SC + (cz * STRIDE) * SZ + (cy * STRIDE) * SY + (cx * 16 + jcol) * STRIDE + XOFF;  // k = channel
   }
   f32x4 acc[NT];
 #pragma unroll
@@ -346,11 +441,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
 #endif
   TRACE_STAMP();  // kernel start
   TileCoord cur = decode_tile<TZ, TY, TX>(item, tiles_x, tiles_y, tiles_z, B);
-  StagePlan<IY, IX> plan;
-  plan.init(cur.ty0 * STRIDE - 1, cur.tx0 * STRIDE - 1, Hi, Wi);
-  StageRegs<CK, IZ, IY, IX, SC, NW> regs;
-  regs.load(plan, make_rsrc(in + cur.b * in_ss, in_ss * 4), in_cs, cin, 0, cur.tz0 * STRIDE - 1, Di, Hi * Wi,
-            wpk + (size_t)cur.slice * per_slice);
+  Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
+  regs.init_kernel(in_cs, Hi * Wi, Di);
+  regs.init_tile(cur.tz0 * STRIDE - 1, cur.ty0 * STRIDE - 1, cur.tx0 * STRIDE - XLO, Hi, Wi);
+  regs.load(make_rsrc(in + cur.b * in_ss, in_ss * 4), cin, 0, wpk + (size_t)cur.slice * per_slice);
   for (;;) {
     const int next_item = item + gridDim.x;
     TileCoord nxt = cur;
@@ -386,12 +480,12 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
             have_next = next_item < total;
             if (have_next) {
               nxt = decode_tile<TZ, TY, TX>(next_item, tiles_x, tiles_y, tiles_z, B);
-              plan.init(nxt.ty0 * STRIDE - 1, nxt.tx0 * STRIDE - 1, Hi, Wi);
+              regs.init_tile(nxt.tz0 * STRIDE - 1, nxt.ty0 * STRIDE - 1, nxt.tx0 * STRIDE - XLO, Hi, Wi);
             }
           }
           if (have_next)
-            regs.load(plan, make_rsrc(in + nxt.b * in_ss, in_ss * 4), in_cs, cin, n_ci0, nxt.tz0 * STRIDE - 1, Di,
-                      Hi * Wi, wpk + (size_t)nxt.slice * per_slice + (size_t)(n_ci0 / CK) * NW);
+            regs.load(make_rsrc(in + nxt.b * in_ss, in_ss * 4), cin, n_ci0,
+                      wpk + (size_t)nxt.slice * per_slice + (size_t)(n_ci0 / CK) * NW);
         }
       }
       if (ABL == 1) {
@@ -503,12 +597,12 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
 // (m + d) of a cell is read ONCE from LDS (8 B operands per channel quad) and feeds the 27 (TCI)
 // / 18 (TPX) MFMAs of the four (pz, py) passes.  TCI keeps two accumulators per pass (x parity),
 // TPX folds the x parity into the rows (co, px).
-template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+template <int MODE, int CK, int NT, int TZ, int TY, int TX, int VEC>
 struct Deconv16Cfg {
   static_assert(MODE == FMT_TCI || MODE == FMT_TPX, "deconv16: TCI or TPX");
   static constexpr int NXG = TX / 16;
   static_assert(TX % 16 == 0 && TZ * TY * NXG == 4 * NT, "tile = 4 waves x NT column tiles");
-  static constexpr int IZ = TZ + 1, IY = TY + 1, IX = TX + 1;
+  static constexpr int IZ = TZ + 1, IY = TY + 1, IX = VEC == 4 ? TX + 4 : TX + 1;  // cells m .. m + 1
   static constexpr int SY = IX, SZ = IY * IX;
   static constexpr int SC = round_up_to_16_mod_32(IZ * SZ);
   static constexpr int NQ = CK / 4;
@@ -517,12 +611,12 @@ struct Deconv16Cfg {
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
 
-template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+template <int MODE, int CK, int NT, int TZ, int TY, int TX, int VEC>
 __global__ __launch_bounds__(kThreads) void deconv16_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int cin, int cout, int Di, int Hi, int Wi, int per_slice, int tiles_x,
     int tiles_y, float slope) {
-  using Cfg = Deconv16Cfg<MODE, CK, NT, TZ, TY, TX>;
+  using Cfg = Deconv16Cfg<MODE, CK, NT, TZ, TY, TX, VEC>;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
   constexpr int NQ = Cfg::NQ, NW = Cfg::NW, NXG = Cfg::NXG, UI = Cfg::UI;
   constexpr int COUTB = MODE == FMT_TPX ? 8 : 16;
@@ -562,17 +656,17 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
   const float *wslice = wpk + (size_t)slice * per_slice;
   const float *scale = wpk + (size_t)slices * per_slice + slice * COUTB;
   const float *shift = scale + slices * COUTB;
-  StagePlan<IY, IX> plan;
-  plan.init(ty0, tx0, Hi, Wi);
-  StageRegs<CK, IZ, IY, IX, SC, NW> regs;
-  regs.load(plan, src, in_cs, cin, 0, tz0, Di, Hi * Wi, wslice);
+  Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
+  regs.init_kernel(in_cs, Hi * Wi, Di);
+  regs.init_tile(tz0, ty0, tx0, Hi, Wi);
+  regs.load(src, cin, 0, wslice);
 
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
     regs.store(tile, wts);
     __syncthreads();
     if (s + 1 < nstages)
-      regs.load(plan, src, in_cs, cin, (s + 1) * CK, tz0, Di, Hi * Wi, wslice + (size_t)(s + 1) * NW);
+      regs.load(src, cin, (s + 1) * CK, wslice + (size_t)(s + 1) * NW);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       float aw[UI];  // this quad's images
@@ -660,21 +754,22 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
 // B operand is the tap-shifted input value of the lane's voxel and ABID picks the input channel's
 // weight column out of the tap's 64-lane image.  Half-rate instruction, 1 of 4 rows useful: this
 // head is 2 % of the FLOPs and is slated to move to a VALU kernel fused with the softmax.
-template <int CK, int G, int TZ, int TY, int TX>
+template <int CK, int G, int TZ, int TY, int TX, int VEC>
 struct ProbCfg {
-  static constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
+  static constexpr int IZ = TZ + 2, IY = TY + 2, IX = VEC == 4 ? TX + 8 : TX + 2;
+  static constexpr int XLO = VEC == 4 ? 4 : 1, XOFF = XLO - 1;
   static constexpr int SY = IX, SZ = IY * IX, SC = IZ * SZ;
   static constexpr int NW = 27 * 64;
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
 
-template <int CK, int G, int TZ, int TY, int TX>
+template <int CK, int G, int TZ, int TY, int TX, int VEC>
 __global__ __launch_bounds__(kThreads) void prob_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, float *__restrict__ out, int cin,
     int Di, int Hi, int Wi, int tiles_x, int tiles_y, float slope) {
   static_assert(TZ * TY * TX == 4 * G * 64 && CK == 8, "tile = 4 waves x G groups x 64 voxels");
   const int nstages = (cin + CK - 1) / CK;
-  using Cfg = ProbCfg<CK, G, TZ, TY, TX>;
+  using Cfg = ProbCfg<CK, G, TZ, TY, TX, VEC>;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, NW = Cfg::NW;
   extern __shared__ float smem[];
   float *tile = smem;
@@ -692,7 +787,7 @@ __global__ __launch_bounds__(kThreads) void prob_kernel(
     vx[g] = v % TX;
     vy[g] = (v / TX) % TY;
     vz[g] = v / (TX * TY);
-    base[g] = vz[g] * SZ + vy[g] * SY + vx[g];
+    base[g] = vz[g] * SZ + vy[g] * SY + vx[g] + Cfg::XOFF;
   }
   f32x4 acc[G];
 #pragma unroll
@@ -702,16 +797,16 @@ __global__ __launch_bounds__(kThreads) void prob_kernel(
   const rsrc_t src = make_rsrc(in + b * in_ss, in_ss * 4);
   const float *scale = wpk + (size_t)nstages * NW;
   const float *shift = scale + 4;
-  StagePlan<IY, IX> plan;
-  plan.init(ty0 - 1, tx0 - 1, Hi, Wi);
-  StageRegs<CK, IZ, IY, IX, SC, NW> regs;
-  regs.load(plan, src, in_cs, cin, 0, tz0 - 1, Di, Hi * Wi, wpk);
+  Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
+  regs.init_kernel(in_cs, Hi * Wi, Di);
+  regs.init_tile(tz0 - 1, ty0 - 1, tx0 - Cfg::XLO, Hi, Wi);
+  regs.load(src, cin, 0, wpk);
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
     regs.store(tile, wts);
     __syncthreads();
     if (s + 1 < nstages)
-      regs.load(plan, src, in_cs, cin, (s + 1) * CK, tz0 - 1, Di, Hi * Wi, wpk + (size_t)(s + 1) * NW);
+      regs.load(src, cin, (s + 1) * CK, wpk + (size_t)(s + 1) * NW);
     for (int tap = 0; tap < 27; ++tap) {
       const float a = wts[tap * 64 + lane];
       const int toff = (tap / 9) * SZ + ((tap / 3) % 3) * SY + (tap % 3);
@@ -853,35 +948,49 @@ int resident_blocks(K kernel, size_t lds_bytes) {
   return cached;
 }
 
-template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
-int launch_conv16(const LayerCfg &c, const float *packed, const float *in, const float *skip,
-                  float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
-                  float slope, hipStream_t st) {
-  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX>;
-  auto kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX>;
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC>
+int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, const float *skip,
+                    float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                    float slope, hipStream_t st) {
+  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC>;
+  auto kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC>;
   if (MODE == FMT_PX) {  // profiling-only ablations of the dominant kernel (results are wrong)
     static const int abl = getenv("CASMVS_ABLATE") ? atoi(getenv("CASMVS_ABLATE")) : 0;
-    if (abl == 1) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, 1>;
-    if (abl == 2) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, 2>;
+    if (abl == 1) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 1>;
+    if (abl == 2) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 2>;
   }
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv16_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wo, TX), tiles_y = casmvs::ceil_div(Ho, TY),
             tiles_z = casmvs::ceil_div(Do, TZ);
   const long total = (long)tiles_x * tiles_y * tiles_z * B * c.slices;
   CASMVS_REQUIRE(total < (1L << 31), "conv3d_forward: too many tiles");
-  const int resident = resident_blocks(conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX>, Cfg::LDS_BYTES);
+  const int resident = resident_blocks(conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC>, Cfg::LDS_BYTES);
   dim3 grid((unsigned)(total < resident ? total : resident));
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, B, cin, cout,
                      Di, Hi, Wi, Do, Ho, Wo, (int)c.per_slice(), c.slices, tiles_x, tiles_y, tiles_z, slope);
   return casmvs::check_launch("conv16_kernel");
 }
 
-template <int MODE, int CK, int NT, int TZ, int TY, int TX>
-int launch_deconv16(const LayerCfg &c, const float *packed, const float *in, const float *skip,
-                    float *out, int B, int cin, int cout, int Di, int Hi, int Wi, float slope,
-                    hipStream_t st) {
-  using Cfg = Deconv16Cfg<MODE, CK, NT, TZ, TY, TX>;
-  auto kernel = deconv16_kernel<MODE, CK, NT, TZ, TY, TX>;
+// 16-byte staging needs rows that start 16-byte aligned: Wi % 4 == 0 (and 16-byte aligned tensors).
+inline bool vec4_ok(const float *in, int Wi) { return Wi % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0; }
+
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
+int launch_conv16(const LayerCfg &c, const float *packed, const float *in, const float *skip,
+                  float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                  float slope, hipStream_t st) {
+  if constexpr (STRIDE == 1) {
+    if (vec4_ok(in, Wi))
+      return launch_conv16_v<MODE, STRIDE, CK, NT, TZ, TY, TX, 4>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, Do, Ho, Wo, slope, st);
+  }
+  return launch_conv16_v<MODE, STRIDE, CK, NT, TZ, TY, TX, 1>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, Do, Ho, Wo, slope, st);
+}
+
+template <int MODE, int CK, int NT, int TZ, int TY, int TX, int VEC>
+int launch_deconv16_v(const LayerCfg &c, const float *packed, const float *in, const float *skip,
+                      float *out, int B, int cin, int cout, int Di, int Hi, int Wi, float slope,
+                      hipStream_t st) {
+  using Cfg = Deconv16Cfg<MODE, CK, NT, TZ, TY, TX, VEC>;
+  auto kernel = deconv16_kernel<MODE, CK, NT, TZ, TY, TX, VEC>;
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "deconv16_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wi, TX), tiles_y = casmvs::ceil_div(Hi, TY),
             tiles_z = casmvs::ceil_div(Di, TZ);
@@ -891,16 +1000,32 @@ int launch_deconv16(const LayerCfg &c, const float *packed, const float *in, con
   return casmvs::check_launch("deconv16_kernel");
 }
 
-int launch_prob(const LayerCfg &c, const float *packed, const float *in, float *out, int B, int cin,
-                int D, int H, int W, float slope, hipStream_t st) {
-  using Cfg = ProbCfg<8, 4, 8, 4, 32>;
-  auto kernel = prob_kernel<8, 4, 8, 4, 32>;
+template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+int launch_deconv16(const LayerCfg &c, const float *packed, const float *in, const float *skip,
+                    float *out, int B, int cin, int cout, int Di, int Hi, int Wi, float slope,
+                    hipStream_t st) {
+  if (vec4_ok(in, Wi))
+    return launch_deconv16_v<MODE, CK, NT, TZ, TY, TX, 4>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, slope, st);
+  return launch_deconv16_v<MODE, CK, NT, TZ, TY, TX, 1>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, slope, st);
+}
+
+template <int VEC>
+int launch_prob_v(const LayerCfg &c, const float *packed, const float *in, float *out, int B, int cin,
+                  int D, int H, int W, float slope, hipStream_t st) {
+  using Cfg = ProbCfg<8, 4, 8, 4, 32, VEC>;
+  auto kernel = prob_kernel<8, 4, 8, 4, 32, VEC>;
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "prob_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(W, 32), tiles_y = casmvs::ceil_div(H, 4), tiles_z = casmvs::ceil_div(D, 8);
   dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, 1);
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, out, cin, D, H, W,
                      tiles_x, tiles_y, slope);
   return casmvs::check_launch("prob_kernel");
+}
+
+int launch_prob(const LayerCfg &c, const float *packed, const float *in, float *out, int B, int cin,
+                int D, int H, int W, float slope, hipStream_t st) {
+  if (vec4_ok(in, W)) return launch_prob_v<4>(c, packed, in, out, B, cin, D, H, W, slope, st);
+  return launch_prob_v<1>(c, packed, in, out, B, cin, D, H, W, slope, st);
 }
 
 }  // namespace
