@@ -318,6 +318,31 @@ struct Stager<4, CK, IZ, IY, IXR, SC, NW> {
       if (p.valid) *reinterpret_cast<f32x4v *>(tile + p.cil * SC + p.iz * (IY * IXR) + p.iy * IXR + 4 * p.xv) = v[k];
     }
   }
+  // Single-operation forms, used by the double-buffered kernel to spread the staging work over the
+  // issue slots of the MFMA loop: op j in [0, NOPS) is one 16-byte load (resp. one ds_write_b128).
+  static constexpr int NOPS = NK + NWR;
+  template <int J>
+  __device__ __forceinline__ void load_op(rsrc_t src, int cin, int ci0, const float *__restrict__ wchunk) {
+    if constexpr (J < NWR) {
+      const int e = threadIdx.x + J * kThreads;
+      w[J] = *reinterpret_cast<const f32x4v *>(wchunk + 4 * (e < NWV ? e : 0));
+    } else {
+      constexpr int k = J - NWR;
+      const bool ok = ci0 + CK <= cin || ci0 + pos_of(k).cil < cin;
+      v[k] = buf_load4(src, ok ? voff[k] : kOOB, ci0 * in_cs * 4);
+    }
+  }
+  template <int J>
+  __device__ __forceinline__ void store_op(float *tile, float *wts) const {
+    if constexpr (J < NWR) {
+      const int e = threadIdx.x + J * kThreads;
+      if (e < NWV) *reinterpret_cast<f32x4v *>(wts + 4 * e) = w[J];
+    } else {
+      constexpr int k = J - NWR;
+      const Pos p = pos_of(k);
+      if (p.valid) *reinterpret_cast<f32x4v *>(tile + p.cil * SC + p.iz * (IY * IXR) + p.iy * IXR + 4 * p.xv) = v[k];
+    }
+  }
 };
 
 constexpr int round_up_to_16_mod_32(int x) { return x + ((16 - x % 32) + 32) % 32; }
@@ -348,13 +373,13 @@ struct Conv16Cfg {
 };
 
 #ifdef CASMVS_TRACE
-// Profiling build only (tools/gpu_trace.sh): wave 0 of the first 64 workgroups of conv16_kernel
+// Profiling build only (tools/gpu_trace.sh): wave 0 of the every 16th workgroup (of the first 1024) of conv16_kernel
 // stamps the shader clock at phase boundaries into a device buffer read back by casmvs_trace_read.
 __device__ unsigned long long g_trace[64 * 128];
 #define TRACE_STAMP()                                                                 \
   do {                                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < 64 && tr_n < 128)                            \
-      g_trace[blockIdx.x * 128 + tr_n++] = __builtin_readcyclecounter();              \
+    if (threadIdx.x == 0 && (blockIdx.x & 15) == 0 && blockIdx.x < 1024 && tr_n < 128) \
+      g_trace[(blockIdx.x >> 4) * 128 + tr_n++] = __builtin_readcyclecounter();       \
   } while (0)
 #else
 #define TRACE_STAMP() do {} while (0)
@@ -587,6 +612,235 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
     if (next_item >= total) break;
     item = next_item;
     cur = nxt;
+  }
+}
+
+// ---- double-buffered variant: staging hidden inside the MFMA loop --------------------------------
+// Measured on the single-buffer kernel above (tools/gpu_trace.py): per chunk a wave spends ~20-30 %
+// of its time outside the MFMA loop (ds_write + 2 barriers, issuing the prefetch, tile set-up), and
+// three co-resident waves do not cover each other's gaps well enough (matrix pipe ~65 % busy).
+// Here the tile lives in two LDS buffers: while chunk w is multiplied out of buffer w & 1, the
+// registers holding chunk w + 1 are written to the other buffer by ds_write_b128s placed in the
+// issue slots of the first MFMA steps, and the loads of chunk w + 2 are issued from the slots of the
+// later steps.  One barrier per chunk, no separate staging phase.  VEC = 4 staging only.
+template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+struct Conv16DbCfg : Conv16Cfg<MODE, 1, CK, NT, TZ, TY, TX, 4> {
+  using Base = Conv16Cfg<MODE, 1, CK, NT, TZ, TY, TX, 4>;
+  static constexpr int BUF = CK * Base::SC + Base::NW;  // floats per buffer
+  static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(float);
+};
+
+template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+__global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
+    const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
+    float *__restrict__ out, int B, int cin, int cout, int Di, int Hi, int Wi, int per_slice, int slices,
+    int tiles_x, int tiles_y, int tiles_z, float slope) {
+  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX>;
+  constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
+  constexpr int NA = Cfg::NA, NITER = Cfg::NITER, ASTEP = Cfg::ASTEP, NW = Cfg::NW, NXG = Cfg::NXG;
+  constexpr int XLO = Cfg::XLO, XOFF = Cfg::XOFF, BUF = Cfg::BUF;
+  constexpr int COUTB = MODE == FMT_PX ? 8 : 16;
+  const int Do = Di, Ho = Hi, Wo = Wi;
+  const int nstages = (cin + CK - 1) / CK;
+  extern __shared__ float smem[];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jcol = lane & 15, kq = lane >> 4;
+  const int total = tiles_x * tiles_y * tiles_z * B * slices;
+  if ((int)blockIdx.x >= total) return;
+
+  int base[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ct = wave * NT + t;
+    const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
+    if (MODE == FMT_PX) base[t] = cz * SZ + cy * SY + cx * 32 + 2 * jcol + kq + XOFF;
+    else base[t] = kq * SC + cz * SZ + cy * SY + cx * 16 + jcol + XOFF;
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int in_cs = Di * Hi * Wi, out_cs = in_cs;
+  const size_t in_ss = (size_t)cin * in_cs, out_ss = (size_t)cout * out_cs;
+  const float *tail = wpk + (size_t)slices * per_slice;
+
+  constexpr int NS = NA * NT;
+  constexpr int P = NS % 8 == 0 ? 8 : (NS % 4 == 0 ? 4 : NS);
+  static_assert(NS % P == 0, "ring slots must line up across iterations");
+  auto it_off = [&](int it) -> int {
+    return MODE == FMT_PX ? (it / 3) * SZ + (it % 3) * SY : (it / 9) * SZ + ((it / 3) % 3) * SY + (it % 3);
+  };
+  using St = Stager<4, CK, IZ, IY, IX, SC, NW>;
+  constexpr int NOPS = St::NOPS;
+  // side-work schedule: store op j at flattened step j * SST, load op j at step LD0 + j * SLD
+  constexpr int TOTAL_STEPS = NITER * NS;
+  static_assert(2 * NOPS + 2 <= TOTAL_STEPS, "not enough MFMA steps to hide the staging operations");
+  constexpr int SST = (TOTAL_STEPS / 2) / NOPS, LD0 = TOTAL_STEPS / 2, SLD = (TOTAL_STEPS - LD0 - 1) / NOPS;
+
+  // prefetch cursor: (tile, chunk) whose data is in `regs`
+  struct Cursor {
+    TileCoord tc;
+    int item, chunk;
+    bool valid;
+  };
+  auto advance = [&](Cursor &c, St &regs) {  // -> next work item; re-derives the tile plan when the tile changes
+    if (++c.chunk == nstages) {
+      c.chunk = 0;
+      c.item += gridDim.x;
+      c.valid = c.item < total;
+      if (c.valid) {
+        c.tc = decode_tile<TZ, TY, TX>(c.item, tiles_x, tiles_y, tiles_z, B);
+        regs.init_tile(c.tc.tz0 - 1, c.tc.ty0 - 1, c.tc.tx0 - XLO, Hi, Wi);
+      }
+    }
+  };
+  auto wchunk_of = [&](const Cursor &c) { return wpk + (size_t)c.tc.slice * per_slice + (size_t)c.chunk * NW; };
+
+  St regs;
+  regs.init_kernel(in_cs, Hi * Wi, Di);
+  Cursor pf;  // prefetch cursor
+  pf.item = blockIdx.x;
+  pf.chunk = 0;
+  pf.valid = true;
+  pf.tc = decode_tile<TZ, TY, TX>(pf.item, tiles_x, tiles_y, tiles_z, B);
+  regs.init_tile(pf.tc.tz0 - 1, pf.tc.ty0 - 1, pf.tc.tx0 - XLO, Hi, Wi);
+  TileCoord cur = pf.tc;  // tile being computed
+  int cur_chunk = 0;
+  // prologue: chunk 0 -> buffer 0, then the loads of work item 1 are put in flight
+  regs.load(make_rsrc(in + pf.tc.b * in_ss, in_ss * 4), cin, 0, wchunk_of(pf));
+  regs.store(smem, smem + CK * SC);
+  __syncthreads();
+  advance(pf, regs);
+  if (pf.valid) regs.load(make_rsrc(in + pf.tc.b * in_ss, in_ss * 4), cin, pf.chunk * CK, wchunk_of(pf));
+
+  constexpr int NCO = MODE == FMT_PX ? 2 : 4;
+  float sc[NCO], sh[NCO];
+  auto load_coeffs = [&](int slice) {
+    const float *scale = tail + slice * COUTB;
+    const float *shift = scale + slices * COUTB;
+#pragma unroll
+    for (int r = 0; r < NCO; ++r) {
+      sc[r] = scale[NCO * kq + r];
+      sh[r] = shift[NCO * kq + r];
+    }
+  };
+  load_coeffs(cur.slice);
+
+  for (int w = 0;; ++w) {
+    float *tile = smem + (w & 1) * BUF, *wts = tile + CK * SC;
+    float *ntile = smem + ((w + 1) & 1) * BUF, *nwts = ntile + CK * SC;
+    const bool store_next = pf.valid;  // regs hold work item w + 1
+    // cursor of work item w + 2 (derived lazily at the first load op)
+    rsrc_t lsrc = make_rsrc(in, 4);
+    const float *lw = wpk;
+    int lci0 = 0;
+    bool load_next = false;
+
+    float a_cur[NA], a_nxt[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) a_cur[a] = wts[(a * NITER) * 64 + lane];
+    int ad_c[NT], ad_n[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ad_c[t] = base[t];
+    float ring[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) ring[i] = tile[ad_c[i % NT] + (i / NT) * ASTEP];
+    // one flattened, fully unrolled loop over the NITER * NS steps: every index below is a
+    // compile-time constant, so the staging registers never leave the register file
+    static_for<TOTAL_STEPS>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;
+      constexpr int it = g / NS, i = g % NS;
+      constexpr int a = i / NT, t = i % NT;
+      if constexpr (i == 0) {
+        constexpr int itn = it < NITER - 1 ? it + 1 : NITER - 1;
+#pragma unroll
+        for (int aa = 0; aa < NA; ++aa) a_nxt[aa] = wts[(aa * NITER + itn) * 64 + lane];
+        const int off_n = it_off(itn);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) ad_n[tt] = base[tt] + off_n;
+      }
+      const float bcur = ring[i % P];
+      constexpr int ii = i + P;
+      if constexpr (ii < NS) ring[i % P] = tile[ad_c[ii % NT] + (ii / NT) * ASTEP];
+      else ring[i % P] = tile[ad_n[(ii - NS) % NT] + ((ii - NS) / NT) * ASTEP];
+      acc[t] = mfma16(a_cur[a], bcur, acc[t]);
+      // ---- side work in this step's spare issue slots ----
+      if constexpr (g < LD0 && g % SST == 0 && g / SST < NOPS) {
+        if (store_next) regs.template store_op<g / SST>(ntile, nwts);  // chunk w + 1 -> the other buffer
+      }
+      if constexpr (g == LD0) {  // all store ops are issued: the registers are free for work item w + 2
+        if (store_next) {
+          advance(pf, regs);
+          load_next = pf.valid;
+          if (load_next) {
+            lsrc = make_rsrc(in + pf.tc.b * in_ss, in_ss * 4);
+            lw = wchunk_of(pf);
+            lci0 = pf.chunk * CK;
+          }
+        }
+      }
+      if constexpr (g > LD0 && (g - LD0 - 1) % SLD == 0 && (g - LD0 - 1) / SLD < NOPS) {
+        if (load_next) regs.template load_op<(g - LD0 - 1) / SLD>(lsrc, cin, lci0, lw);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i == NS - 1) {
+#pragma unroll
+        for (int aa = 0; aa < NA; ++aa) a_cur[aa] = a_nxt[aa];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) ad_c[tt] = ad_n[tt];
+      }
+    });
+
+    if (++cur_chunk == nstages) {  // tile finished: epilogue, then switch to the next tile
+      const rsrc_t dst = make_rsrc(out + cur.b * out_ss, out_ss * 4);
+      const rsrc_t skp = make_rsrc(skip ? skip + cur.b * out_ss : out, out_ss * 4);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int ct = wave * NT + t;
+        const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
+        const int oz = cur.tz0 + cz, oy = cur.ty0 + cy;
+        const f32x4 av = acc[t];
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (MODE == FMT_PX) {
+          const int ox = cur.tx0 + cx * 32 + 2 * jcol;
+          const bool ok = oz < Do && oy < Ho && ox < Wo;  // Wo % 4 == 0 here: the pair is in range
+          const int voff = ok ? (2 * kq * out_cs + (oz * Ho + oy) * Wo + ox) * 4 : kOOB;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float v0 = fmaf(av[2 * h], sc[h % NCO], sh[h % NCO]);
+            float v1 = fmaf(av[2 * h + 1], sc[h % NCO], sh[h % NCO]);
+            v0 = v0 > 0.0f ? v0 : v0 * slope;
+            v1 = v1 > 0.0f ? v1 : v1 * slope;
+            const int soff = h * out_cs * 4;
+            if (skip) {
+              const f32x2 sk = buf_load2(skp, voff, soff);
+              v0 += sk[0];
+              v1 += sk[1];
+            }
+            buf_store2(f32x2{v0, v1}, dst, voff, soff);
+          }
+        } else {
+          const int ox = cur.tx0 + cx * 16 + jcol;
+          const bool ok = oz < Do && oy < Ho && ox < Wo;
+          const int vbase = ((cur.slice * 16 + 4 * kq) * out_cs + (oz * Ho + oy) * Wo + ox) * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int voff = (ok && cur.slice * 16 + 4 * kq + r < cout) ? vbase : kOOB;
+            float v = fmaf(av[r], sc[r % NCO], sh[r % NCO]);
+            v = v > 0.0f ? v : v * slope;
+            if (skip) v += buf_load(skp, voff, r * out_cs * 4);
+            buf_store(v, dst, voff, r * out_cs * 4);
+          }
+        }
+      }
+      cur_chunk = 0;
+      if (!store_next) break;  // no work item w + 1: this was the last tile
+      const int next_item = (w + 1) / nstages;  // tile index in this workgroup's sequence
+      cur = decode_tile<TZ, TY, TX>(blockIdx.x + next_item * gridDim.x, tiles_x, tiles_y, tiles_z, B);
+      load_coeffs(cur.slice);
+    }
+    __syncthreads();  // buffer (w + 1) & 1 is published, buffer w & 1 is free
   }
 }
 
@@ -971,6 +1225,22 @@ int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, con
   return casmvs::check_launch("conv16_kernel");
 }
 
+template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+int launch_conv16db(const LayerCfg &c, const float *packed, const float *in, const float *skip, float *out,
+                    int B, int cin, int cout, int D, int H, int W, float slope, hipStream_t st) {
+  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX>;
+  auto kernel = conv16db_kernel<MODE, CK, NT, TZ, TY, TX>;
+  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv16db_kernel")) return rc;
+  const int tiles_x = casmvs::ceil_div(W, TX), tiles_y = casmvs::ceil_div(H, TY), tiles_z = casmvs::ceil_div(D, TZ);
+  const long total = (long)tiles_x * tiles_y * tiles_z * B * c.slices;
+  CASMVS_REQUIRE(total < (1L << 31), "conv3d_forward: too many tiles");
+  const int resident = resident_blocks(kernel, Cfg::LDS_BYTES);
+  dim3 grid((unsigned)(total < resident ? total : resident));
+  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, B, cin, cout,
+                     D, H, W, (int)c.per_slice(), c.slices, tiles_x, tiles_y, tiles_z, slope);
+  return casmvs::check_launch("conv16db_kernel");
+}
+
 // 16-byte staging needs rows that start 16-byte aligned: Wi % 4 == 0 (and 16-byte aligned tensors).
 inline bool vec4_ok(const float *in, int Wi) { return Wi % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0; }
 
@@ -1082,7 +1352,12 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
       CASMVS_REQUIRE(skip == nullptr, "conv3d_forward: the 1-channel head takes no skip input");
       return launch_prob(c, packed, in, out, B, cin, D, H, W, slope, st);
     }
-    if (c.fmt == FMT_PX) return launch_conv16<FMT_PX, 1, 4, 8, 8, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
+    if (c.fmt == FMT_PX) {
+      static const bool no_db = getenv("CASMVS_NO_DB") != nullptr;  // A/B switch (profiling)
+      if (!no_db && W % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0)
+        return launch_conv16db<FMT_PX, 4, 4, 4, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+      return launch_conv16<FMT_PX, 1, 4, 8, 8, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
+    }
     const long wide_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 4) * c.slices * B;
     if (wide_blocks >= 512) return launch_conv16<FMT_CI, 1, 8, 8, 4, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
     return launch_conv16<FMT_CI, 1, 16, 1, 1, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);

@@ -26,8 +26,22 @@ for it in range(3):
     L.casmvs_trace_read(buf, 1)
 import numpy as np
 t = np.array(buf, dtype=np.uint64).reshape(64, 128).astype(np.int64)
-for blk in (0, 1, 7, 63):
-    row = t[blk]; n = int((row > 0).sum()); row = row[:n]
+t0 = min(int(t[b][0]) for b in range(64) if t[b][0] > 0)
+for slot in (0, 1, 15, 16, 17, 30, 40, 47):
+    row = t[slot]; n = int((row > 0).sum())
+    if n == 0:
+        continue
+    row = row[:n]
     d = np.diff(row)
-    print("block", blk, "stamps", n, "total cycles", int(row[-1] - row[0]))
-    print("  deltas:", d[:60].tolist())
+    # stamps: 0 kernel start, then per chunk: begin, after barrier1, after store, mfma begin; per tile end: epilogue begin, epilogue done
+    nch = 4 if len(sys.argv) < 2 else (int(sys.argv[1]) + 3) // 4
+    per_tile = 4 * nch + 2
+    ntiles = (n - 1) // per_tile
+    print("block", slot * 16, "stamps", n, "tiles", ntiles, "start", int(row[0] - t0), "end", int(row[-1] - t0))
+    for ti in range(ntiles):
+        seg = d[ti * per_tile: (ti + 1) * per_tile]
+        mf = [int(seg[4 * c + 3]) if 4 * c + 3 < len(seg) else -1 for c in range(nch)]
+        pf = [int(seg[4 * c + 2]) for c in range(nch)]
+        st = [int(seg[4 * c + 1]) for c in range(nch)]
+        b1 = [int(seg[4 * c]) for c in range(nch)]
+        print("   tile", ti, "wait/b1", b1, "store", st, "prefetch", pf, "mfma", mf, "epilogue", int(seg[-1]) if len(seg) == per_tile else -1)
