@@ -455,7 +455,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
   // waitcnt pass emits counted lgkmcnt waits.  The A images of the next iteration are read a
   // whole iteration ahead.
   constexpr int NS = NA * NT;              // steps per iteration
-  constexpr int P = NS % 8 == 0 ? 8 : (NS % 4 == 0 ? 4 : NS);  // read-ahead distance (steps)
+  constexpr int P0 = NS % 8 == 0 ? 8 : (NS % 4 == 0 ? 4 : NS);  // read-ahead distance (steps)
+  constexpr int P = (ABL == 16 || ABL == 32) ? (NS % ABL == 0 ? ABL : P0) : P0;  // profiling override
   static_assert(NS % P == 0, "ring slots must line up across iterations");
   auto it_off = [&](int it) -> int {
     return MODE == FMT_PX ? (it / 3) * SZ + (it % 3) * SY : (it / 9) * SZ + ((it / 3) % 3) * SY + (it % 3);
@@ -616,18 +617,99 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
 }
 
 // ---- double-buffered variant: staging hidden inside the MFMA loop --------------------------------
-// Measured on the single-buffer kernel above (tools/gpu_trace.py): per chunk a wave spends ~20-30 %
-// of its time outside the MFMA loop (ds_write + 2 barriers, issuing the prefetch, tile set-up), and
-// three co-resident waves do not cover each other's gaps well enough (matrix pipe ~65 % busy).
-// Here the tile lives in two LDS buffers: while chunk w is multiplied out of buffer w & 1, the
-// registers holding chunk w + 1 are written to the other buffer by ds_write_b128s placed in the
-// issue slots of the first MFMA steps, and the loads of chunk w + 2 are issued from the slots of the
-// later steps.  One barrier per chunk, no separate staging phase.  VEC = 4 staging only.
+// Measured on the single-buffer kernel above (tools/gpu_trace.py, PMC): the MFMA + ds_read loop in
+// isolation sustains ~95 % of the matrix pipe (casmvs_selftest_mfma_rate shapes 4..7), but every
+// VALU instruction issued by ANY wave of the SIMD - staging address math, predicate selects,
+// register copies at iteration boundaries - takes MFMA issue time (SQ_VALU_MFMA_COEXEC_CYCLES = 0),
+// and at ~2 VALU per MFMA the pipe was only ~65 % busy.  This variant is built to issue almost no
+// VALU in steady state:
+//   * the tile lives in two LDS buffers; while chunk w is multiplied out of buffer w & 1, the
+//     registers holding chunk w + 1 are written to the other buffer (ds_write_b128, address register
+//     precomputed per thread, buffer selected by an immediate) and the loads of chunk w + 2 are
+//     issued (buffer_load_dwordx4: per-thread offset register + scalar offset) from the spare issue
+//     slots of the MFMA steps: one barrier per chunk, no staging phase, no address arithmetic;
+//   * the whole chunk loop is one flattened, fully unrolled sequence (all LDS offsets immediates,
+//     no loop-carried register copies), instantiated once per buffer parity.
+// VEC = 4 staging only (Wi % 4 == 0).
 template <int MODE, int CK, int NT, int TZ, int TY, int TX>
 struct Conv16DbCfg : Conv16Cfg<MODE, 1, CK, NT, TZ, TY, TX, 4> {
   using Base = Conv16Cfg<MODE, 1, CK, NT, TZ, TY, TX, 4>;
   static constexpr int BUF = CK * Base::SC + Base::NW;  // floats per buffer
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(float);
+};
+
+// Staging registers of the double-buffered kernel: like Stager<4>, but every address is a
+// precomputed register so that a load / store operation is exactly one memory instruction.
+template <int CK, int IZ, int IY, int IXR, int SC, int NW>
+struct DbStager {
+  static_assert(IXR % 4 == 0 && SC % 4 == 0 && NW % 4 == 0, "16-byte groups");
+  static constexpr int ROWV = IXR / 4, PLV = IY * ROWV, TOTV = CK * IZ * PLV;
+  static constexpr int NK = (TOTV + kThreads - 1) / kThreads;
+  static constexpr int NWV = NW / 4, NWR = (NWV + kThreads - 1) / kThreads;
+  static constexpr int NOPS = NK + NWR;
+  int in_cs, HiWi, Di;
+  float *lds_t[NK];   // destination of group k in LDS buffer 0 (kernel constant; nullptr-like sentinel = smem)
+  int cil[NK];        // local channel of group k (kernel constant; only read for channel-padded chunks)
+  int voff[NK];       // byte offset of group k inside the sample for chunk channel 0, or kOOB (tile constant)
+  float *lds_w[NWR];  // destination of weight group i in LDS buffer 0
+  int woff[NWR];      // byte offset of weight group i inside a chunk's weight block
+  f32x4v v[NK];
+  f32x4v w[NWR];
+
+  __device__ __forceinline__ void init_kernel(float *tile0, float *wts0, int in_cs_, int HiWi_, int Di_) {
+    in_cs = in_cs_;
+    HiWi = HiWi_;
+    Di = Di_;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int e = threadIdx.x + k * kThreads;
+      const int pl = e / PLV, r = e - pl * PLV;
+      const int c = pl / IZ, iz = pl - c * IZ, iy = r / ROWV, xv = r - iy * ROWV;
+      cil[k] = c;
+      // groups beyond the chunk (last pass) are parked on group 0's slot of this thread's own
+      // earlier pass: they carry kOOB and therefore rewrite ... nothing is loaded for them
+      lds_t[k] = tile0 + (e < TOTV ? c * SC + iz * (IY * IXR) + iy * IXR + 4 * xv : -4);
+    }
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+      const int e = threadIdx.x + i * kThreads;
+      woff[i] = (e < NWV ? e : 0) * 16;
+      lds_w[i] = wts0 + (e < NWV ? 4 * e : -4);
+    }
+  }
+  __device__ __forceinline__ void init_tile(int iz0, int iy0, int ix0, int Hi, int Wi) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int e = threadIdx.x + k * kThreads;
+      const int pl = e / PLV, r = e - pl * PLV;
+      const int c = pl / IZ, iz = pl - c * IZ, iy = r / ROWV, xv = r - iy * ROWV;
+      const int gz = iz0 + iz, gy = iy0 + iy, gx = ix0 + 4 * xv;
+      const bool inb = e < TOTV && gz >= 0 && gz < Di && gy >= 0 && gy < Hi && gx >= 0 && gx + 3 < Wi;
+      voff[k] = inb ? (c * in_cs + gz * HiWi + gy * Wi + gx) * 4 : kOOB;
+    }
+  }
+  template <int J>
+  __device__ __forceinline__ void load_op(rsrc_t src, rsrc_t wsrc, int cin, int ci0, int wsoff) {
+    if constexpr (J < NWR) {
+      w[J] = buf_load4(wsrc, woff[J], wsoff);
+    } else {
+      constexpr int k = J - NWR;
+      if (ci0 + CK <= cin) {  // wave-uniform; false only for a channel-padded last chunk
+        v[k] = buf_load4(src, voff[k], ci0 * in_cs * 4);
+      } else {
+        v[k] = buf_load4(src, ci0 + cil[k] < cin ? voff[k] : kOOB, ci0 * in_cs * 4);
+      }
+    }
+  }
+  template <int J, int BUFOFF>  // BUFOFF: float offset of the destination buffer (immediate)
+  __device__ __forceinline__ void store_op(const float *smem_lo) const {
+    if constexpr (J < NWR) {
+      if (lds_w[J] >= smem_lo) *reinterpret_cast<f32x4v *>(lds_w[J] + BUFOFF) = w[J];
+    } else {
+      constexpr int k = J - NWR;
+      if (lds_t[k] >= smem_lo) *reinterpret_cast<f32x4v *>(lds_t[k] + BUFOFF) = v[k];
+    }
+  }
 };
 
 template <int MODE, int CK, int NT, int TZ, int TY, int TX>
@@ -649,14 +731,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   const int total = tiles_x * tiles_y * tiles_z * B * slices;
   if ((int)blockIdx.x >= total) return;
 
-  int base[NT];
+  // lane's LDS read pointers (buffer 0): B operand of column tile t, A image 0
+  const float *bptr[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int ct = wave * NT + t;
     const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
-    if (MODE == FMT_PX) base[t] = cz * SZ + cy * SY + cx * 32 + 2 * jcol + kq + XOFF;
-    else base[t] = kq * SC + cz * SZ + cy * SY + cx * 16 + jcol + XOFF;
+    if (MODE == FMT_PX) bptr[t] = smem + cz * SZ + cy * SY + cx * 32 + 2 * jcol + kq + XOFF;
+    else bptr[t] = smem + kq * SC + cz * SZ + cy * SY + cx * 16 + jcol + XOFF;
   }
+  const float *aptr = smem + CK * SC + lane;
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -664,16 +748,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   const int in_cs = Di * Hi * Wi, out_cs = in_cs;
   const size_t in_ss = (size_t)cin * in_cs, out_ss = (size_t)cout * out_cs;
   const float *tail = wpk + (size_t)slices * per_slice;
+  const rsrc_t wsrc = make_rsrc(wpk, ((size_t)slices * per_slice) * 4);
 
   constexpr int NS = NA * NT;
   constexpr int P = NS % 8 == 0 ? 8 : (NS % 4 == 0 ? 4 : NS);
   static_assert(NS % P == 0, "ring slots must line up across iterations");
-  auto it_off = [&](int it) -> int {
+  constexpr auto it_off = [](int it) constexpr -> int {
     return MODE == FMT_PX ? (it / 3) * SZ + (it % 3) * SY : (it / 9) * SZ + ((it / 3) % 3) * SY + (it % 3);
   };
-  using St = Stager<4, CK, IZ, IY, IX, SC, NW>;
+  using St = DbStager<CK, IZ, IY, IX, SC, NW>;
   constexpr int NOPS = St::NOPS;
-  // side-work schedule: store op j at flattened step j * SST, load op j at step LD0 + j * SLD
+  // side-work schedule: store op j at flattened step j * SST, load op j at step LD0 + 1 + j * SLD
   constexpr int TOTAL_STEPS = NITER * NS;
   static_assert(2 * NOPS + 2 <= TOTAL_STEPS, "not enough MFMA steps to hide the staging operations");
   constexpr int SST = (TOTAL_STEPS / 2) / NOPS, LD0 = TOTAL_STEPS / 2, SLD = (TOTAL_STEPS - LD0 - 1) / NOPS;
@@ -684,7 +769,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
     int item, chunk;
     bool valid;
   };
-  auto advance = [&](Cursor &c, St &regs) {  // -> next work item; re-derives the tile plan when the tile changes
+  St regs;
+  auto advance = [&](Cursor &c) {  // -> next work item; re-derives the tile plan when the tile changes
     if (++c.chunk == nstages) {
       c.chunk = 0;
       c.item += gridDim.x;
@@ -695,10 +781,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       }
     }
   };
-  auto wchunk_of = [&](const Cursor &c) { return wpk + (size_t)c.tc.slice * per_slice + (size_t)c.chunk * NW; };
+  auto wsoff_of = [&](const Cursor &c) { return (int)(((size_t)c.tc.slice * per_slice + (size_t)c.chunk * NW) * 4); };
 
-  St regs;
-  regs.init_kernel(in_cs, Hi * Wi, Di);
+  regs.init_kernel(smem, smem + CK * SC, in_cs, Hi * Wi, Di);
   Cursor pf;  // prefetch cursor
   pf.item = blockIdx.x;
   pf.chunk = 0;
@@ -706,13 +791,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   pf.tc = decode_tile<TZ, TY, TX>(pf.item, tiles_x, tiles_y, tiles_z, B);
   regs.init_tile(pf.tc.tz0 - 1, pf.tc.ty0 - 1, pf.tc.tx0 - XLO, Hi, Wi);
   TileCoord cur = pf.tc;  // tile being computed
-  int cur_chunk = 0;
+  int cur_chunk = 0, tiles_done = 0;
   // prologue: chunk 0 -> buffer 0, then the loads of work item 1 are put in flight
-  regs.load(make_rsrc(in + pf.tc.b * in_ss, in_ss * 4), cin, 0, wchunk_of(pf));
-  regs.store(smem, smem + CK * SC);
+  {
+    const rsrc_t src = make_rsrc(in + pf.tc.b * in_ss, in_ss * 4);
+    const int ws = wsoff_of(pf);
+    static_for<NOPS>([&](auto j_) { regs.template load_op<decltype(j_)::value>(src, wsrc, cin, 0, ws); });
+    static_for<NOPS>([&](auto j_) { regs.template store_op<decltype(j_)::value, 0>(smem); });
+  }
   __syncthreads();
-  advance(pf, regs);
-  if (pf.valid) regs.load(make_rsrc(in + pf.tc.b * in_ss, in_ss * 4), cin, pf.chunk * CK, wchunk_of(pf));
+  advance(pf);
+  if (pf.valid) {
+    const rsrc_t src = make_rsrc(in + pf.tc.b * in_ss, in_ss * 4);
+    const int ws = wsoff_of(pf), ci0 = pf.chunk * CK;
+    static_for<NOPS>([&](auto j_) { regs.template load_op<decltype(j_)::value>(src, wsrc, cin, ci0, ws); });
+  }
 
   constexpr int NCO = MODE == FMT_PX ? 2 : 4;
   float sc[NCO], sh[NCO];
@@ -727,71 +820,63 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   };
   load_coeffs(cur.slice);
 
-  for (int w = 0;; ++w) {
-    float *tile = smem + (w & 1) * BUF, *wts = tile + CK * SC;
-    float *ntile = smem + ((w + 1) & 1) * BUF, *nwts = ntile + CK * SC;
-    const bool store_next = pf.valid;  // regs hold work item w + 1
-    // cursor of work item w + 2 (derived lazily at the first load op)
-    rsrc_t lsrc = make_rsrc(in, 4);
-    const float *lw = wpk;
-    int lci0 = 0;
+  // one work item (chunk) computed out of buffer PAR; returns false after the last tile
+  auto run_item = [&](auto par_) -> bool {
+    constexpr int PAR = decltype(par_)::value;
+    constexpr int RD = PAR * BUF, WR = (1 - PAR) * BUF;  // float offsets of the read / write buffers
+    const bool store_next = pf.valid;  // regs hold the next work item
+    rsrc_t lsrc = wsrc;
+    int lws = 0, lci0 = 0;
     bool load_next = false;
 
     float a_cur[NA], a_nxt[NA];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) a_cur[a] = wts[(a * NITER) * 64 + lane];
-    int ad_c[NT], ad_n[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) ad_c[t] = base[t];
+    for (int a = 0; a < NA; ++a) a_cur[a] = aptr[RD + (a * NITER) * 64];
     float ring[P];
 #pragma unroll
-    for (int i = 0; i < P; ++i) ring[i] = tile[ad_c[i % NT] + (i / NT) * ASTEP];
-    // one flattened, fully unrolled loop over the NITER * NS steps: every index below is a
-    // compile-time constant, so the staging registers never leave the register file
+    for (int i = 0; i < P; ++i) ring[i] = bptr[i % NT][RD + (i / NT) * ASTEP];
+    // one flattened, fully unrolled loop over the NITER * NS steps: every index and every LDS
+    // offset below is a compile-time constant
     static_for<TOTAL_STEPS>([&](auto g_) {
       constexpr int g = decltype(g_)::value;
       constexpr int it = g / NS, i = g % NS;
       constexpr int a = i / NT, t = i % NT;
+      constexpr int itn = it < NITER - 1 ? it + 1 : NITER - 1;
       if constexpr (i == 0) {
-        constexpr int itn = it < NITER - 1 ? it + 1 : NITER - 1;
 #pragma unroll
-        for (int aa = 0; aa < NA; ++aa) a_nxt[aa] = wts[(aa * NITER + itn) * 64 + lane];
-        const int off_n = it_off(itn);
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) ad_n[tt] = base[tt] + off_n;
+        for (int aa = 0; aa < NA; ++aa) a_nxt[aa] = aptr[RD + (aa * NITER + itn) * 64];
       }
       const float bcur = ring[i % P];
       constexpr int ii = i + P;
-      if constexpr (ii < NS) ring[i % P] = tile[ad_c[ii % NT] + (ii / NT) * ASTEP];
-      else ring[i % P] = tile[ad_n[(ii - NS) % NT] + ((ii - NS) / NT) * ASTEP];
+      if constexpr (ii < NS) ring[i % P] = bptr[ii % NT][RD + it_off(it) + (ii / NT) * ASTEP];
+      else ring[i % P] = bptr[(ii - NS) % NT][RD + it_off(itn) + ((ii - NS) / NT) * ASTEP];
       acc[t] = mfma16(a_cur[a], bcur, acc[t]);
       // ---- side work in this step's spare issue slots ----
       if constexpr (g < LD0 && g % SST == 0 && g / SST < NOPS) {
-        if (store_next) regs.template store_op<g / SST>(ntile, nwts);  // chunk w + 1 -> the other buffer
+        if (store_next) regs.template store_op<g / SST, WR>(smem);  // next chunk -> the other buffer
       }
-      if constexpr (g == LD0) {  // all store ops are issued: the registers are free for work item w + 2
+      if constexpr (g == LD0) {  // all store ops are issued: the registers are free for the chunk after
         if (store_next) {
-          advance(pf, regs);
+          advance(pf);
           load_next = pf.valid;
           if (load_next) {
             lsrc = make_rsrc(in + pf.tc.b * in_ss, in_ss * 4);
-            lw = wchunk_of(pf);
+            lws = wsoff_of(pf);
             lci0 = pf.chunk * CK;
           }
         }
       }
       if constexpr (g > LD0 && (g - LD0 - 1) % SLD == 0 && (g - LD0 - 1) / SLD < NOPS) {
-        if (load_next) regs.template load_op<(g - LD0 - 1) / SLD>(lsrc, cin, lci0, lw);
+        if (load_next) regs.template load_op<(g - LD0 - 1) / SLD>(lsrc, wsrc, cin, lci0, lws);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (i == NS - 1) {
 #pragma unroll
         for (int aa = 0; aa < NA; ++aa) a_cur[aa] = a_nxt[aa];
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) ad_c[tt] = ad_n[tt];
       }
     });
 
+    bool more = true;
     if (++cur_chunk == nstages) {  // tile finished: epilogue, then switch to the next tile
       const rsrc_t dst = make_rsrc(out + cur.b * out_ss, out_ss * 4);
       const rsrc_t skp = make_rsrc(skip ? skip + cur.b * out_ss : out, out_ss * 4);
@@ -835,12 +920,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
         }
       }
       cur_chunk = 0;
-      if (!store_next) break;  // no work item w + 1: this was the last tile
-      const int next_item = (w + 1) / nstages;  // tile index in this workgroup's sequence
-      cur = decode_tile<TZ, TY, TX>(blockIdx.x + next_item * gridDim.x, tiles_x, tiles_y, tiles_z, B);
-      load_coeffs(cur.slice);
+      ++tiles_done;
+      if (!store_next) {
+        more = false;  // no further work item: this was the last tile
+      } else {
+        cur = decode_tile<TZ, TY, TX>(blockIdx.x + tiles_done * gridDim.x, tiles_x, tiles_y, tiles_z, B);
+        load_coeffs(cur.slice);
+      }
     }
-    __syncthreads();  // buffer (w + 1) & 1 is published, buffer w & 1 is free
+    __syncthreads();  // the other buffer is published, this one is free
+    return more;
+  };
+  for (;;) {
+    if (!run_item(std::integral_constant<int, 0>{})) break;
+    if (!run_item(std::integral_constant<int, 1>{})) break;
   }
 }
 
@@ -1174,6 +1267,42 @@ __global__ __launch_bounds__(kThreads) void mfma_lds_rate_kernel(float *out, int
   if (s == 123.456f) out[0] = s;
 }
 
+// Shapes 5..7: the same loop with the PX operand pattern (lane (j, u) reads word 2j + u), with a
+// 42 KiB tile (3 workgroups per CU like the real kernel), and with random-ish data.
+template <int VARIANT>
+__global__ __launch_bounds__(kThreads) void mfma_lds_rate2_kernel(float *out, int iters) {
+  extern __shared__ float lds2[];
+  constexpr int N = VARIANT >= 6 ? 10496 : 8192;
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    unsigned h = (i * 2654435761u) ^ (blockIdx.x * 40503u);
+    lds2[i] = VARIANT >= 7 ? (float)((int)(h >> 9) - (1 << 22)) * (1.0f / (1 << 22)) : 1.0f + i * 1e-6f;
+  }
+  __syncthreads();
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lane = threadIdx.x & 63;
+  float a = VARIANT >= 7 ? lds2[lane + 64] : 1.0f + threadIdx.x * 1e-6f;
+  const int lane_off = 2 * (lane & 15) + (lane >> 4) + (threadIdx.x >> 6) * 1024;
+  float ring[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ring[i] = lds2[lane_off + i * 34];
+  for (int it = 0; it < iters; ++it) {
+    const int o = lane_off + ((it & 7) * 204);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float b = ring[i & 7];
+      ring[i & 7] = lds2[o + (i & 7) * 34 + (i >> 3) * 2040];
+      acc[i & 7] = mfma16(a, b, acc[i & 7]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+  if (s == 123.456f) out[0] = s;
+}
+
 // Kernels that need more than the default 64 KiB of LDS must opt in once per process.
 template <class K>
 int ensure_lds(K kernel, size_t bytes, const char *what) {
@@ -1212,6 +1341,8 @@ int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, con
     static const int abl = getenv("CASMVS_ABLATE") ? atoi(getenv("CASMVS_ABLATE")) : 0;
     if (abl == 1) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 1>;
     if (abl == 2) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 2>;
+    if (abl == 16) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 16>;
+    if (abl == 32) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 32>;
   }
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv16_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wo, TX), tiles_y = casmvs::ceil_div(Ho, TY),
@@ -1242,7 +1373,10 @@ int launch_conv16db(const LayerCfg &c, const float *packed, const float *in, con
 }
 
 // 16-byte staging needs rows that start 16-byte aligned: Wi % 4 == 0 (and 16-byte aligned tensors).
-inline bool vec4_ok(const float *in, int Wi) { return Wi % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0; }
+inline bool vec4_ok(const float *in, int Wi) {
+  static const bool disabled = getenv("CASMVS_NO_VEC4") != nullptr;  // A/B switch (profiling)
+  return !disabled && Wi % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
+}
 
 template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
 int launch_conv16(const LayerCfg &c, const float *packed, const float *in, const float *skip,
@@ -1431,7 +1565,7 @@ extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, con
 
 extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float *tflops) {
   casmvs::clear_error();
-  CASMVS_REQUIRE(shape >= 0 && shape <= 4 && blocks > 0 && iters > 0 && tflops, "selftest_mfma_rate: bad arguments");
+  CASMVS_REQUIRE(shape >= 0 && shape <= 7 && blocks > 0 && iters > 0 && tflops, "selftest_mfma_rate: bad arguments");
   float *d = nullptr;
   hipEvent_t e0, e1;
   if (hipMalloc(&d, 64) != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "selftest_mfma_rate: hipMalloc failed");
@@ -1443,7 +1577,10 @@ extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float
       case 1: hipLaunchKernelGGL(mfma_rate_kernel<1>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
       case 2: hipLaunchKernelGGL(mfma_rate_kernel<2>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
       case 3: hipLaunchKernelGGL(mfma_rate_kernel<3>, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
-      default: hipLaunchKernelGGL(mfma_lds_rate_kernel, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
+      case 4: hipLaunchKernelGGL(mfma_lds_rate_kernel, dim3(blocks), dim3(kThreads), 0, 0, d, n); break;
+      case 5: hipLaunchKernelGGL(mfma_lds_rate2_kernel<5>, dim3(blocks), dim3(kThreads), 8192 * 4, 0, d, n / 2); break;
+      case 6: hipLaunchKernelGGL(mfma_lds_rate2_kernel<6>, dim3(blocks), dim3(kThreads), 10496 * 4, 0, d, n / 2); break;
+      default: hipLaunchKernelGGL(mfma_lds_rate2_kernel<7>, dim3(blocks), dim3(kThreads), 10496 * 4, 0, d, n / 2); break;
     }
   };
   launch(16);  // warm-up
@@ -1457,7 +1594,7 @@ extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float
   (void)hipEventDestroy(e1);
   (void)hipFree(d);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "selftest_mfma_rate: %s", hipGetErrorString(e));
-  const double flop_per_mfma[5] = {512.0, 2048.0, 4096.0, 2048.0, 2048.0};  // 4x4x1_16b, 16x16x4, 32x32x2, 16x16x1_4b, 16x16x4 + ds_read
+  const double flop_per_mfma[8] = {512.0, 2048.0, 4096.0, 2048.0, 2048.0, 2048.0, 2048.0, 2048.0};  // 4x4x1_16b, 16x16x4, 32x32x2, 16x16x1_4b, 16x16x4 + ds_read
   const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 * flop_per_mfma[shape];
   *tflops = (float)(flops / (ms * 1e-3) / 1e12);
   return CASMVS_OK;
