@@ -650,11 +650,13 @@ struct DbStager {
   int in_cs, HiWi, Di;
   float *lds_t[NK];   // destination of group k in LDS buffer 0 (kernel constant; nullptr-like sentinel = smem)
   int cil[NK];        // local channel of group k (kernel constant; only read for channel-padded chunks)
-  int voff[NK];       // byte offset of group k inside the sample for chunk channel 0, or kOOB (tile constant)
+  int voff[2][NK];    // [set] byte offset of group k inside the sample for chunk channel 0, or kOOB
   float *lds_w[NWR];  // destination of weight group i in LDS buffer 0
   int woff[NWR];      // byte offset of weight group i inside a chunk's weight block
-  f32x4v v[NK];
-  f32x4v w[NWR];
+  // two register sets: while set s is being written to LDS, the loads of the chunk after are
+  // already in flight into set 1 - s, i.e. every load has a whole chunk (~4 us) to land
+  f32x4v v[2][NK];
+  f32x4v w[2][NWR];
 
   __device__ __forceinline__ void init_kernel(float *tile0, float *wts0, int in_cs_, int HiWi_, int Di_) {
     in_cs = in_cs_;
@@ -677,6 +679,7 @@ struct DbStager {
       lds_w[i] = wts0 + (e < NWV ? 4 * e : -4);
     }
   }
+  template <int S>
   __device__ __forceinline__ void init_tile(int iz0, int iy0, int ix0, int Hi, int Wi) {
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -685,29 +688,39 @@ struct DbStager {
       const int c = pl / IZ, iz = pl - c * IZ, iy = r / ROWV, xv = r - iy * ROWV;
       const int gz = iz0 + iz, gy = iy0 + iy, gx = ix0 + 4 * xv;
       const bool inb = e < TOTV && gz >= 0 && gz < Di && gy >= 0 && gy < Hi && gx >= 0 && gx + 3 < Wi;
-      voff[k] = inb ? (c * in_cs + gz * HiWi + gy * Wi + gx) * 4 : kOOB;
+      voff[S][k] = inb ? (c * in_cs + gz * HiWi + gy * Wi + gx) * 4 : kOOB;
     }
   }
-  template <int J>
+  template <int S>
+  __device__ __forceinline__ void kill_plan() {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) voff[S][k] = kOOB;
+  }
+  template <int S>
+  __device__ __forceinline__ void copy_plan_from_other() {  // same tile, next chunk: the plan carries over
+#pragma unroll
+    for (int k = 0; k < NK; ++k) voff[S][k] = voff[1 - S][k];
+  }
+  template <int S, int J>
   __device__ __forceinline__ void load_op(rsrc_t src, rsrc_t wsrc, int cin, int ci0, int wsoff) {
     if constexpr (J < NWR) {
-      w[J] = buf_load4(wsrc, woff[J], wsoff);
+      w[S][J] = buf_load4(wsrc, woff[J], wsoff);
     } else {
       constexpr int k = J - NWR;
       if (ci0 + CK <= cin) {  // wave-uniform; false only for a channel-padded last chunk
-        v[k] = buf_load4(src, voff[k], ci0 * in_cs * 4);
+        v[S][k] = buf_load4(src, voff[S][k], ci0 * in_cs * 4);
       } else {
-        v[k] = buf_load4(src, ci0 + cil[k] < cin ? voff[k] : kOOB, ci0 * in_cs * 4);
+        v[S][k] = buf_load4(src, ci0 + cil[k] < cin ? voff[S][k] : kOOB, ci0 * in_cs * 4);
       }
     }
   }
-  template <int J, int BUFOFF>  // BUFOFF: float offset of the destination buffer (immediate)
+  template <int S, int J, int BUFOFF>  // BUFOFF: float offset of the destination buffer (immediate)
   __device__ __forceinline__ void store_op(const float *smem_lo) const {
     if constexpr (J < NWR) {
-      if (lds_w[J] >= smem_lo) *reinterpret_cast<f32x4v *>(lds_w[J] + BUFOFF) = w[J];
+      if (lds_w[J] >= smem_lo) *reinterpret_cast<f32x4v *>(lds_w[J] + BUFOFF) = w[S][J];
     } else {
       constexpr int k = J - NWR;
-      if (lds_t[k] >= smem_lo) *reinterpret_cast<f32x4v *>(lds_t[k] + BUFOFF) = v[k];
+      if (lds_t[k] >= smem_lo) *reinterpret_cast<f32x4v *>(lds_t[k] + BUFOFF) = v[S][k];
     }
   }
 };
@@ -758,27 +771,35 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   };
   using St = DbStager<CK, IZ, IY, IX, SC, NW>;
   constexpr int NOPS = St::NOPS;
-  // side-work schedule: store op j at flattened step j * SST, load op j at step LD0 + 1 + j * SLD
+  // side-work schedule of work item w (register set / LDS buffer parity PAR = w & 1):
+  //   steps 1 .. NOPS        : load op j of item w + 2  -> register set PAR (free since item w - 1)
+  //   steps ST0 + j * SST     : store op j of item w + 1 (set 1 - PAR, loaded during item w - 1)
+  //                             -> LDS buffer 1 - PAR
   constexpr int TOTAL_STEPS = NITER * NS;
-  static_assert(2 * NOPS + 2 <= TOTAL_STEPS, "not enough MFMA steps to hide the staging operations");
-  constexpr int SST = (TOTAL_STEPS / 2) / NOPS, LD0 = TOTAL_STEPS / 2, SLD = (TOTAL_STEPS - LD0 - 1) / NOPS;
+  static_assert(2 * NOPS + 4 <= TOTAL_STEPS, "not enough MFMA steps to hide the staging operations");
+  constexpr int ST0 = NOPS + 2, SST = (TOTAL_STEPS - ST0 - 1) / NOPS;
 
-  // prefetch cursor: (tile, chunk) whose data is in `regs`
+  // prefetch cursor: the (tile, chunk) most recently put in flight
   struct Cursor {
     TileCoord tc;
     int item, chunk;
     bool valid;
   };
   St regs;
-  auto advance = [&](Cursor &c) {  // -> next work item; re-derives the tile plan when the tile changes
+  auto advance = [&](Cursor &c, auto set_) {  // -> next work item; plan of register set S for it
+    constexpr int S = decltype(set_)::value;
     if (++c.chunk == nstages) {
       c.chunk = 0;
       c.item += gridDim.x;
       c.valid = c.item < total;
       if (c.valid) {
         c.tc = decode_tile<TZ, TY, TX>(c.item, tiles_x, tiles_y, tiles_z, B);
-        regs.init_tile(c.tc.tz0 - 1, c.tc.ty0 - 1, c.tc.tx0 - XLO, Hi, Wi);
+        regs.template init_tile<S>(c.tc.tz0 - 1, c.tc.ty0 - 1, c.tc.tx0 - XLO, Hi, Wi);
+      } else {
+        regs.template kill_plan<S>();  // no more work: the (unconditional) loads of this set read nothing
       }
+    } else {
+      regs.template copy_plan_from_other<S>();
     }
   };
   auto wsoff_of = [&](const Cursor &c) { return (int)(((size_t)c.tc.slice * per_slice + (size_t)c.chunk * NW) * 4); };
@@ -789,22 +810,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   pf.chunk = 0;
   pf.valid = true;
   pf.tc = decode_tile<TZ, TY, TX>(pf.item, tiles_x, tiles_y, tiles_z, B);
-  regs.init_tile(pf.tc.tz0 - 1, pf.tc.ty0 - 1, pf.tc.tx0 - XLO, Hi, Wi);
+  regs.template init_tile<0>(pf.tc.tz0 - 1, pf.tc.ty0 - 1, pf.tc.tx0 - XLO, Hi, Wi);
   TileCoord cur = pf.tc;  // tile being computed
   int cur_chunk = 0, tiles_done = 0;
-  // prologue: chunk 0 -> buffer 0, then the loads of work item 1 are put in flight
+  // prologue: work item 0 -> set 0 -> buffer 0; work item 1 -> set 1 (in flight)
   {
     const rsrc_t src = make_rsrc(in + pf.tc.b * in_ss, in_ss * 4);
     const int ws = wsoff_of(pf);
-    static_for<NOPS>([&](auto j_) { regs.template load_op<decltype(j_)::value>(src, wsrc, cin, 0, ws); });
-    static_for<NOPS>([&](auto j_) { regs.template store_op<decltype(j_)::value, 0>(smem); });
+    static_for<NOPS>([&](auto j_) { regs.template load_op<0, decltype(j_)::value>(src, wsrc, cin, 0, ws); });
+    static_for<NOPS>([&](auto j_) { regs.template store_op<0, decltype(j_)::value, 0>(smem); });
   }
   __syncthreads();
-  advance(pf);
+  advance(pf, std::integral_constant<int, 1>{});
+  bool next_valid = pf.valid;  // work item w + 1 exists (its loads are in flight / landed)
   if (pf.valid) {
     const rsrc_t src = make_rsrc(in + pf.tc.b * in_ss, in_ss * 4);
     const int ws = wsoff_of(pf), ci0 = pf.chunk * CK;
-    static_for<NOPS>([&](auto j_) { regs.template load_op<decltype(j_)::value>(src, wsrc, cin, ci0, ws); });
+    static_for<NOPS>([&](auto j_) { regs.template load_op<1, decltype(j_)::value>(src, wsrc, cin, ci0, ws); });
   }
 
   constexpr int NCO = MODE == FMT_PX ? 2 : 4;
@@ -824,10 +846,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   auto run_item = [&](auto par_) -> bool {
     constexpr int PAR = decltype(par_)::value;
     constexpr int RD = PAR * BUF, WR = (1 - PAR) * BUF;  // float offsets of the read / write buffers
-    const bool store_next = pf.valid;  // regs hold the next work item
-    rsrc_t lsrc = wsrc;
-    int lws = 0, lci0 = 0;
+    const bool store_next = next_valid;  // register set 1 - PAR holds work item w + 1
+    // put work item w + 2 in flight into register set PAR right away (a whole chunk to land)
     bool load_next = false;
+    if (store_next) {
+      advance(pf, std::integral_constant<int, PAR>{});
+      load_next = pf.valid;
+    }
+    const TileCoord ltc = load_next ? pf.tc : cur;
+    const rsrc_t lsrc = make_rsrc(in + ltc.b * in_ss, in_ss * 4);
+    const int lws = load_next ? wsoff_of(pf) : 0, lci0 = load_next ? pf.chunk * CK : 0;
+    next_valid = load_next;
 
     float a_cur[NA], a_nxt[NA];
 #pragma unroll
@@ -852,23 +881,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       else ring[i % P] = bptr[(ii - NS) % NT][RD + it_off(itn) + ((ii - NS) / NT) * ASTEP];
       acc[t] = mfma16(a_cur[a], bcur, acc[t]);
       // ---- side work in this step's spare issue slots ----
-      if constexpr (g < LD0 && g % SST == 0 && g / SST < NOPS) {
-        if (store_next) regs.template store_op<g / SST, WR>(smem);  // next chunk -> the other buffer
-      }
-      if constexpr (g == LD0) {  // all store ops are issued: the registers are free for the chunk after
-        if (store_next) {
-          advance(pf);
-          load_next = pf.valid;
-          if (load_next) {
-            lsrc = make_rsrc(in + pf.tc.b * in_ss, in_ss * 4);
-            lws = wsoff_of(pf);
-            lci0 = pf.chunk * CK;
-          }
-        }
-      }
-      if constexpr (g > LD0 && (g - LD0 - 1) % SLD == 0 && (g - LD0 - 1) / SLD < NOPS) {
-        if (load_next) regs.template load_op<(g - LD0 - 1) / SLD>(lsrc, wsrc, cin, lci0, lws);
-      }
+      // (issued unconditionally - a dead set loads with out-of-range offsets and its stores land in
+      // the buffer nobody reads - so that the code stays branch-free and the compiler can emit
+      // counted vmcnt waits instead of draining the loads it has just issued)
+      if constexpr (g >= 1 && g <= NOPS) regs.template load_op<PAR, g - 1>(lsrc, wsrc, cin, lci0, lws);
+      if constexpr (g >= ST0 && (g - ST0) % SST == 0 && (g - ST0) / SST < NOPS)
+        regs.template store_op<1 - PAR, (g - ST0) / SST, WR>(smem);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (i == NS - 1) {
 #pragma unroll
