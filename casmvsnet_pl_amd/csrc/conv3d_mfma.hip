@@ -648,7 +648,9 @@ struct DbStager {
   static constexpr int NWV = NW / 4, NWR = (NWV + kThreads - 1) / kThreads;
   static constexpr int NOPS = NK + NWR;
   int in_cs, HiWi, Di;
-  float *lds_t[NK];   // destination of group k in LDS buffer 0 (kernel constant; nullptr-like sentinel = smem)
+  float *lds_t[NK];   // destination of group k in LDS buffer 0 (kernel constant)
+  bool t_ok[NK];      // group k exists (the last pass is partial); wave-level masks, live in SGPRs
+  bool w_ok[NWR];
   int cil[NK];        // local channel of group k (kernel constant; only read for channel-padded chunks)
   int voff[2][NK];    // [set] byte offset of group k inside the sample for chunk channel 0, or kOOB
   float *lds_w[NWR];  // destination of weight group i in LDS buffer 0
@@ -668,15 +670,15 @@ struct DbStager {
       const int pl = e / PLV, r = e - pl * PLV;
       const int c = pl / IZ, iz = pl - c * IZ, iy = r / ROWV, xv = r - iy * ROWV;
       cil[k] = c;
-      // groups beyond the chunk (last pass) are parked on group 0's slot of this thread's own
-      // earlier pass: they carry kOOB and therefore rewrite ... nothing is loaded for them
-      lds_t[k] = tile0 + (e < TOTV ? c * SC + iz * (IY * IXR) + iy * IXR + 4 * xv : -4);
+      t_ok[k] = e < TOTV;
+      lds_t[k] = tile0 + (e < TOTV ? c * SC + iz * (IY * IXR) + iy * IXR + 4 * xv : 0);
     }
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
       const int e = threadIdx.x + i * kThreads;
       woff[i] = (e < NWV ? e : 0) * 16;
-      lds_w[i] = wts0 + (e < NWV ? 4 * e : -4);
+      w_ok[i] = e < NWV;
+      lds_w[i] = wts0 + (e < NWV ? 4 * e : 0);
     }
   }
   template <int S>
@@ -715,12 +717,12 @@ struct DbStager {
     }
   }
   template <int S, int J, int BUFOFF>  // BUFOFF: float offset of the destination buffer (immediate)
-  __device__ __forceinline__ void store_op(const float *smem_lo) const {
+  __device__ __forceinline__ void store_op() const {
     if constexpr (J < NWR) {
-      if (lds_w[J] >= smem_lo) *reinterpret_cast<f32x4v *>(lds_w[J] + BUFOFF) = w[S][J];
+      if (w_ok[J]) *reinterpret_cast<f32x4v *>(lds_w[J] + BUFOFF) = w[S][J];
     } else {
       constexpr int k = J - NWR;
-      if (lds_t[k] >= smem_lo) *reinterpret_cast<f32x4v *>(lds_t[k] + BUFOFF) = v[S][k];
+      if (t_ok[k]) *reinterpret_cast<f32x4v *>(lds_t[k] + BUFOFF) = v[S][k];
     }
   }
 };
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
     const rsrc_t src = make_rsrc(in + pf.tc.b * in_ss, in_ss * 4);
     const int ws = wsoff_of(pf);
     static_for<NOPS>([&](auto j_) { regs.template load_op<0, decltype(j_)::value>(src, wsrc, cin, 0, ws); });
-    static_for<NOPS>([&](auto j_) { regs.template store_op<0, decltype(j_)::value, 0>(smem); });
+    static_for<NOPS>([&](auto j_) { regs.template store_op<0, decltype(j_)::value, 0>(); });
   }
   __syncthreads();
   advance(pf, std::integral_constant<int, 1>{});
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       // counted vmcnt waits instead of draining the loads it has just issued)
       if constexpr (g >= 1 && g <= NOPS) regs.template load_op<PAR, g - 1>(lsrc, wsrc, cin, lci0, lws);
       if constexpr (g >= ST0 && (g - ST0) % SST == 0 && (g - ST0) / SST < NOPS)
-        regs.template store_op<1 - PAR, (g - ST0) / SST, WR>(smem);
+        regs.template store_op<1 - PAR, (g - ST0) / SST, WR>();
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (i == NS - 1) {
 #pragma unroll
@@ -1400,7 +1402,9 @@ template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX>
 int launch_conv16(const LayerCfg &c, const float *packed, const float *in, const float *skip,
                   float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                   float slope, hipStream_t st) {
-  if constexpr (STRIDE == 1) {
+  // 16-byte staging widens the LDS rows (TX + 8): measured slower for the wide CI tile (one
+  // workgroup fewer per CU) and faster for the deep one
+  if constexpr (STRIDE == 1 && NT == 1) {
     if (vec4_ok(in, Wi))
       return launch_conv16_v<MODE, STRIDE, CK, NT, TZ, TY, TX, 4>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, Do, Ho, Wo, slope, st);
   }
@@ -1446,7 +1450,7 @@ int launch_prob_v(const LayerCfg &c, const float *packed, const float *in, float
 
 int launch_prob(const LayerCfg &c, const float *packed, const float *in, float *out, int B, int cin,
                 int D, int H, int W, float slope, hipStream_t st) {
-  if (vec4_ok(in, W)) return launch_prob_v<4>(c, packed, in, out, B, cin, D, H, W, slope, st);
+  // (16-byte staging costs this kernel its second workgroup per CU: measured 1.7x slower)
   return launch_prob_v<1>(c, packed, in, out, B, cin, D, H, W, slope, st);
 }
 
