@@ -61,6 +61,15 @@ def algorithmic_work(H, W, V, G, n_depths, B=1):
     return work
 
 
+def feature_flops(H, W):
+    """FeatureNet FLOPs per image (mvsnet.py:14-34): 2 * k*k * cin * cout per output pixel."""
+    hw = H * W
+    full = 2 * hw * (9 * 3 * 8 + 9 * 8 * 8 + 8 * 32 + 9 * 32 * 8)                      # conv0.0/1, lat0, smooth0
+    half = 2 * (hw // 4) * (25 * 8 * 16 + 2 * 9 * 16 * 16 + 16 * 32 + 9 * 32 * 16)      # conv1.*, lat1, smooth1
+    quarter = 2 * (hw // 16) * (25 * 16 * 32 + 2 * 9 * 32 * 32 + 32 * 32)               # conv2.*, toplayer
+    return full + half + quarter
+
+
 def cpu_baseline(cfg_name, repeats=3):
     """Oracle (CPU port of the reference forward) on the same synthetic workload, host cores."""
     from oracle import cpu_restatement as R
@@ -148,7 +157,7 @@ def main():
             "config": {"workload": args.config, "H": H, "W": W, "views": V, "n_depths": list(n_depths),
                        "interval_ratios": list(ratios), "num_groups": G, "depth_maps_per_step_per_gpu": B,
                        "parallelism": f"replica x{world} (one depth map stream per GPU, no data-path collective)",
-                       "feature_net": "PyTorch-ROCm ops (outside the north_star kernel list)"},
+                       "feature_net": "HIP MFMA kernels (casmvs_featurenet_forward_f32)"},
         }
         if timer is not None:
             summ = timer.summary(LAYER_NAMES)
@@ -180,6 +189,13 @@ def main():
             line["roofline_softmax"] = {"kernel": "softmax_regress_kernel (3 launches)", "bound": "hbm",
                                         "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            ft_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("feature/"))
+            if ft_ms > 0:
+                ft_flops = feature_flops(H, W) * V * B * K
+                line["roofline_feature"] = {"kernel": "all 13 FeatureNet launches", "bound": "mfma",
+                                            "achieved": ft_flops / (ft_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                                            "unit": "TFLOP/s", "frac": ft_flops / (ft_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                            "ms_per_depth_map": ft_ms / K / B}
             line["stage_ms_per_step"] = {k: round(v, 4) for k, v in per_step.items()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)

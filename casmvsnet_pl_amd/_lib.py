@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libcasmvs_hip.so")
 ABI_VERSION = 1
 
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
+CONV2D_K3, CONV2D_K5S2, CONV2D_K1, CONV2D_K1_UP = 3, 4, 5, 6
 
 # every symbol include/casmvs.h declares: name -> (restype, argtypes)
 _FP = c_void_p  # device / host float* passed as integer addresses
@@ -29,6 +30,11 @@ SYMBOLS = {
     "casmvs_conv3d_forward_f32": (c_int, [c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_costreg_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "casmvs_costreg_forward_f32": (c_int, [POINTER(c_void_p), _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
+    "casmvs_conv2d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
+    "casmvs_conv2d_pack_f32": (c_int, [c_int, c_int, c_int, _FP, _FP, _FP, _FP]),
+    "casmvs_conv2d_forward_f32": (c_int, [c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "casmvs_featurenet_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "casmvs_featurenet_forward_f32": (c_int, [POINTER(c_void_p), _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
     "casmvs_softmax_regress_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_selftest_mfma": (c_int, [_FP]),
     "casmvs_selftest_mfma_rate": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),

@@ -6,7 +6,8 @@
 // Instruction choice (measured on MI355X with casmvs_selftest_mfma_rate): the
 // fp32 MFMA that runs at the full 64 FLOP/clk/SIMD is v_mfma_f32_16x16x4_f32 (32 cycles);
 // the 16-block v_mfma_f32_4x4x1_16b_f32 form, attractive for tiny Cout, issues at HALF that
-// rate (68 TFLOP/s chip-wide), so it is only kept for the 1-channel `prob` head.
+// rate when its accumulators are reused back to back; it is not used by any kernel any more (the
+// 1-channel `prob` head is a VALU kernel) and survives only in the rate probes.
 //
 // Formulation.  D[16 rows][16 cols] += A[16][4] * B[4][16] per instruction with
 //   cols = 16 output voxels that are consecutive along x (one "column tile"),
@@ -70,6 +71,8 @@ struct LayerCfg {
   int slices;       // ceil(cout / coutb), blockIdx.z
   int units;        // contraction units per slice (padded so that any kernel chunking stays in range)
   int unit_floats;  // floats per unit
+  int kz, ks;       // kernel extent along z and along y / x (3,3 for the 3D layers; 1,{1,3,5} for the 2D ones)
+  int taps() const { return kz * ks * ks; }
   size_t per_slice() const { return (size_t)units * unit_floats; }
 };
 
@@ -77,24 +80,39 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // The weight image of a slice is a sequence of contraction UNITS, so that a kernel may chunk the
 // input channels by any CK it likes (chunk s = units [s*CK/q, (s+1)*CK/q)):
-//   CI / TCI : unit = 4 input channels (one "ci quad"), 27 tap images     -> [quad][tap][64]
-//   PX       : unit = 1 input channel, 9 (kz,ky) images                   -> [ci][kz*3+ky][64]
-//   TPX      : unit = 4 input channels, 9 (kz,ky) x 2 (dx) images         -> [quad][kz*3+ky][dx][64]
-//   B4       : unit = 8 input channels, 27 tap images                     -> [chunk][tap][64]
+//   CI / TCI : unit = 4 input channels (one "ci quad"), kz*ks*ks tap images -> [quad][tap][64]
+//   PX       : unit = 1 input channel, kz*ks (kz,ky) images                 -> [ci][kz*3+ky][64]
+//   TPX      : unit = 4 input channels, 9 (kz,ky) x 2 (dx) images           -> [quad][kz*3+ky][dx][64]
+//   B4       : unit = 8 input channels, 27 tap images                       -> [chunk][tap][64]
+// The 2D layers of FeatureNet (kinds CASMVS_CONV2D_*) are the same formats with kz = 1.
 inline bool layer_cfg(int kind, int cin, int cout, LayerCfg &c) {
   if (cin < 1 || cout < 1) return false;
+  c.kz = 3;
+  c.ks = 3;
+  const int quads = round_up((cin + 3) / 4, 4);
   if (kind == CASMVS_CONV_S1) {
     if (cout == 1) { c.fmt = FMT_B4; c.coutb = 4; c.units = (cin + 7) / 8; c.unit_floats = 27 * 64; }
     else if (cout == 8) { c.fmt = FMT_PX; c.coutb = 8; c.units = round_up(cin, 8); c.unit_floats = 9 * 64; }
-    else if (cout % 16 == 0) { c.fmt = FMT_CI; c.coutb = 16; c.units = round_up((cin + 3) / 4, 4); c.unit_floats = 27 * 64; }
+    else if (cout % 16 == 0) { c.fmt = FMT_CI; c.coutb = 16; c.units = quads; c.unit_floats = 27 * 64; }
     else return false;
   } else if (kind == CASMVS_CONV_S2) {
     if (cout % 16 != 0) return false;
-    c.fmt = FMT_CI; c.coutb = 16; c.units = round_up((cin + 3) / 4, 4); c.unit_floats = 27 * 64;
+    c.fmt = FMT_CI; c.coutb = 16; c.units = quads; c.unit_floats = 27 * 64;
   } else if (kind == CASMVS_CONV_T2) {
-    if (cout == 8) { c.fmt = FMT_TPX; c.coutb = 8; c.units = round_up((cin + 3) / 4, 4); c.unit_floats = 18 * 64; }
-    else if (cout % 16 == 0) { c.fmt = FMT_TCI; c.coutb = 16; c.units = round_up((cin + 3) / 4, 4); c.unit_floats = 27 * 64; }
+    if (cout == 8) { c.fmt = FMT_TPX; c.coutb = 8; c.units = quads; c.unit_floats = 18 * 64; }
+    else if (cout % 16 == 0) { c.fmt = FMT_TCI; c.coutb = 16; c.units = quads; c.unit_floats = 27 * 64; }
     else return false;
+  } else if (kind == CASMVS_CONV2D_K3) {
+    c.kz = 1;
+    if (cout == 8) { c.fmt = FMT_PX; c.coutb = 8; c.units = round_up(cin, 8); c.unit_floats = 3 * 64; }
+    else if (cout % 16 == 0) { c.fmt = FMT_CI; c.coutb = 16; c.units = quads; c.unit_floats = 9 * 64; }
+    else return false;
+  } else if (kind == CASMVS_CONV2D_K5S2) {
+    if (cout % 16 != 0) return false;
+    c.kz = 1; c.ks = 5; c.fmt = FMT_CI; c.coutb = 16; c.units = quads; c.unit_floats = 25 * 64;
+  } else if (kind == CASMVS_CONV2D_K1 || kind == CASMVS_CONV2D_K1_UP) {
+    if (cout % 16 != 0) return false;
+    c.kz = 1; c.ks = 1; c.fmt = FMT_CI; c.coutb = 16; c.units = quads; c.unit_floats = 64;
   } else {
     return false;
   }
@@ -107,8 +125,9 @@ inline float pack_weight(const LayerCfg &c, int kind, int cin, int cout, const f
                          int unit, int img, int l) {
   auto conv_w = [&](int co, int ci, int tap) -> float {
     if (co >= cout || ci >= cin || tap < 0) return 0.0f;
-    return kind == CASMVS_CONV_T2 ? w[((size_t)ci * cout + co) * 27 + tap]   // (cin, cout, 3,3,3)
-                                  : w[((size_t)co * cin + ci) * 27 + tap];  // (cout, cin, 3,3,3)
+    const int nt = c.taps();
+    return kind == CASMVS_CONV_T2 ? w[((size_t)ci * cout + co) * nt + tap]   // (cin, cout, 3,3,3)
+                                  : w[((size_t)co * cin + ci) * nt + tap];  // (cout, cin, [kz,] ks, ks)
   };
   const int i = l & 15, k = l >> 4;
   switch (c.fmt) {
@@ -348,26 +367,29 @@ struct Stager<4, CK, IZ, IY, IXR, SC, NW> {
 constexpr int round_up_to_16_mod_32(int x) { return x + ((16 - x % 32) + 32) % 32; }
 
 // ---- Conv3d k3 p1 (stride 1 or 2) on 16x16x4 ----------------------------------------------------
-template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC>
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int KZ = 3, int KS = 3>
 struct Conv16Cfg {
   static_assert(MODE == FMT_CI || MODE == FMT_PX, "conv16: CI or PX");
-  static_assert(VEC == 1 || (VEC == 4 && STRIDE == 1), "16-byte staging: stride-1 layers only");
+  static_assert(VEC == 1 || (VEC == 4 && STRIDE == 1 && KS == 3), "16-byte staging: stride-1 k3 layers only");
+  static_assert((KZ == 3 || (KZ == 1 && TZ == 1)) && (KS == 1 || KS == 3 || KS == 5), "kernel extents");
+  static_assert(MODE != FMT_PX || KS == 3, "PX form: 3 taps along x");
+  static constexpr int PZ = KZ / 2, PS = KS / 2;       // "same" padding
   static constexpr int XW = MODE == FMT_PX ? 32 : 16;  // output voxels along x per column tile
   static constexpr int NXG = TX / XW;
   static_assert(TX % XW == 0 && TZ * TY * NXG == 4 * NT, "tile = 4 waves x NT column tiles");
-  static constexpr int IZ = STRIDE * (TZ - 1) + 3, IY = STRIDE * (TY - 1) + 3;
-  // staged row: VEC 1: x in [x0 - 1, x0 + S(TX-1) + 2); VEC 4: widened to the aligned [x0 - 4, x0 + TX + 4)
-  static constexpr int IX = VEC == 4 ? TX + 8 : STRIDE * (TX - 1) + 3;
-  static constexpr int XLO = VEC == 4 ? 4 : 1;    // tile row starts at global x = S * x0 - XLO
-  static constexpr int XOFF = XLO - 1;            // local x of (output x0, tap kx = 0)
+  static constexpr int IZ = STRIDE * (TZ - 1) + KZ, IY = STRIDE * (TY - 1) + KS;
+  // staged row: VEC 1: x in [S x0 - PS, S (x0 + TX - 1) + PS]; VEC 4: widened to the aligned [x0 - 4, x0 + TX + 4)
+  static constexpr int IX = VEC == 4 ? TX + 8 : STRIDE * (TX - 1) + KS;
+  static constexpr int XLO = VEC == 4 ? 4 : PS;   // tile row starts at global x = S * x0 - XLO
+  static constexpr int XOFF = XLO - PS;           // local x of (output x0, tap kx = 0)
   static constexpr int SY = IX, SZ = IY * IX;
   // channel stride: B lanes k = 0..3 read 4 channels (CI) -> k * SC must land on disjoint banks:
   // stride 1: 16 consecutive words per k -> SC == 16 (mod 32); stride 2: even words -> SC odd.
   static constexpr int SC = MODE == FMT_PX ? IZ * SZ
                             : (STRIDE == 1 ? round_up_to_16_mod_32(IZ * SZ) : (IZ * SZ) | 1);
-  static constexpr int NA = MODE == FMT_PX ? CK : CK / 4;      // A images per iteration
-  static constexpr int NITER = MODE == FMT_PX ? 9 : 27;        // (kz,ky) | (kz,ky,kx)
-  static constexpr int ASTEP = MODE == FMT_PX ? SC : 4 * SC;   // B offset between A images
+  static constexpr int NA = MODE == FMT_PX ? CK : CK / 4;              // A images per iteration
+  static constexpr int NITER = MODE == FMT_PX ? KZ * KS : KZ * KS * KS;  // (kz,ky) | (kz,ky,kx)
+  static constexpr int ASTEP = MODE == FMT_PX ? SC : 4 * SC;           // B offset between A images
   static constexpr int NW = NITER * NA * 64;
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
@@ -409,12 +431,18 @@ __device__ __forceinline__ TileCoord decode_tile(int item, int tiles_x, int tile
 // chunk of the current one, so the global-load latency, the address set-up and the epilogue
 // stores of a tile all overlap MFMA work - measured per-workgroup fixed cost before: ~13 us.
 // ABL (ablation, profiling only): 0 = normal, 1 = staging only (no MFMA loop), 2 = MFMA loop only.
-template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int ABL = 0>
+// KZ / KS: kernel extent along z and along y, x ("same" padding).  KZ = 1 (with TZ = 1, D = 1) turns
+// the kernel into the 2D convolutions of FeatureNet; UPS = 1 makes the epilogue add the bilinear x2
+// upsampling (align_corners = True) of `skip` (B, Cout, Ho/2, Wo/2) instead of `skip` itself - the
+// FPN top-down step F.interpolate(coarse) + lateral(x) of mvsnet.py:36-38,53-54.
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int ABL = 0, int KZ = 3,
+          int KS = 3, int UPS = 0>
 __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
     int per_slice, int slices, int tiles_x, int tiles_y, int tiles_z, float slope) {
-  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC>;
+  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, KZ, KS>;
+  constexpr int PZ = Cfg::PZ, PS = Cfg::PS;
   const int nstages = (cin + CK - 1) / CK;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
   constexpr int XLO = Cfg::XLO, XOFF = Cfg::XOFF;
@@ -459,7 +487,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
   constexpr int P = (ABL == 16 || ABL == 32) ? (NS % ABL == 0 ? ABL : P0) : P0;  // profiling override
   static_assert(NS % P == 0, "ring slots must line up across iterations");
   auto it_off = [&](int it) -> int {
-    return MODE == FMT_PX ? (it / 3) * SZ + (it % 3) * SY : (it / 9) * SZ + ((it / 3) % 3) * SY + (it % 3);
+    return MODE == FMT_PX ? (it / KS) * SZ + (it % KS) * SY : (it / (KS * KS)) * SZ + ((it / KS) % KS) * SY + (it % KS);
   };
 
 #ifdef CASMVS_TRACE
@@ -469,7 +497,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
   TileCoord cur = decode_tile<TZ, TY, TX>(item, tiles_x, tiles_y, tiles_z, B);
   Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
   regs.init_kernel(in_cs, Hi * Wi, Di);
-  regs.init_tile(cur.tz0 * STRIDE - 1, cur.ty0 * STRIDE - 1, cur.tx0 * STRIDE - XLO, Hi, Wi);
+  regs.init_tile(cur.tz0 * STRIDE - PZ, cur.ty0 * STRIDE - PS, cur.tx0 * STRIDE - XLO, Hi, Wi);
   regs.load(make_rsrc(in + cur.b * in_ss, in_ss * 4), cin, 0, wpk + (size_t)cur.slice * per_slice);
   for (;;) {
     const int next_item = item + gridDim.x;
@@ -506,7 +534,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
             have_next = next_item < total;
             if (have_next) {
               nxt = decode_tile<TZ, TY, TX>(next_item, tiles_x, tiles_y, tiles_z, B);
-              regs.init_tile(nxt.tz0 * STRIDE - 1, nxt.ty0 * STRIDE - 1, nxt.tx0 * STRIDE - XLO, Hi, Wi);
+              regs.init_tile(nxt.tz0 * STRIDE - PZ, nxt.ty0 * STRIDE - PS, nxt.tx0 * STRIDE - XLO, Hi, Wi);
             }
           }
           if (have_next)
@@ -559,7 +587,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
     // Buffer stores: per-lane byte offset = (this lane's first channel, voxel), scalar offset =
     // remaining channel stride; lanes outside the volume / beyond cout carry kOOB and are dropped.
     const rsrc_t dst = make_rsrc(out + cur.b * out_ss, out_ss * 4);
-    const rsrc_t skp = make_rsrc(skip ? skip + cur.b * out_ss : out, out_ss * 4);
+    const rsrc_t skp = make_rsrc((skip && !UPS) ? skip + cur.b * out_ss : out, out_ss * 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int ct = wave * NT + t;
@@ -599,13 +627,40 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
         const int ox = cur.tx0 + cx * 16 + jcol;  // channels slice*16 + 4*kq + r
         const bool ok = oz < Do && oy < Ho && ox < Wo;
         const int vbase = ((cur.slice * 16 + 4 * kq) * out_cs + (oz * Ho + oy) * Wo + ox) * 4;
+        if constexpr (UPS) {
+          // ATen upsample_bilinear2d, align_corners: src = dst * (in - 1) / (out - 1); the coarse
+          // tensor is (B, cout, Ho/2, Wo/2); value = hy0 * (hx0 v00 + hx1 v01) + hy1 * (hx0 v10 + hx1 v11)
+          const int hc = Ho >> 1, wc = Wo >> 1;
+          const float sy = Ho > 1 ? (float)(hc - 1) / (float)(Ho - 1) : 0.0f;
+          const float sx = Wo > 1 ? (float)(wc - 1) / (float)(Wo - 1) : 0.0f;
+          const float fy = sy * (float)oy, fx = sx * (float)ox;
+          const int y0 = (int)fy, x0 = (int)fx;
+          const int y1 = y0 + (y0 < hc - 1 ? 1 : 0), x1 = x0 + (x0 < wc - 1 ? 1 : 0);
+          const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+          const rsrc_t cs = make_rsrc(skip + (size_t)cur.b * cout * hc * wc, (size_t)cout * hc * wc * 4);
+          const int cbase = (cur.slice * 16 + 4 * kq) * hc * wc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int voff = (ok && cur.slice * 16 + 4 * kq + r < cout) ? vbase : kOOB;
-          float v = fmaf(av[r], sc[r % NCO], sh[r % NCO]);
-          v = v > 0.0f ? v : v * slope;
-          if (skip) v += buf_load(skp, voff, r * out_cs * 4);
-          buf_store(v, dst, voff, r * out_cs * 4);
+          for (int r = 0; r < 4; ++r) {
+            const bool okr = ok && cur.slice * 16 + 4 * kq + r < cout;
+            const int soff = r * hc * wc * 4;
+            const float v00 = buf_load(cs, okr ? (cbase + y0 * wc + x0) * 4 : kOOB, soff);
+            const float v01 = buf_load(cs, okr ? (cbase + y0 * wc + x1) * 4 : kOOB, soff);
+            const float v10 = buf_load(cs, okr ? (cbase + y1 * wc + x0) * 4 : kOOB, soff);
+            const float v11 = buf_load(cs, okr ? (cbase + y1 * wc + x1) * 4 : kOOB, soff);
+            float v = fmaf(av[r], sc[r % NCO], sh[r % NCO]);
+            v = v > 0.0f ? v : v * slope;
+            v += ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+            buf_store(v, dst, okr ? vbase : kOOB, r * out_cs * 4);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int voff = (ok && cur.slice * 16 + 4 * kq + r < cout) ? vbase : kOOB;
+            float v = fmaf(av[r], sc[r % NCO], sh[r % NCO]);
+            v = v > 0.0f ? v : v * slope;
+            if (skip) v += buf_load(skp, voff, r * out_cs * 4);
+            buf_store(v, dst, voff, r * out_cs * 4);
+          }
         }
       }
     }
@@ -1116,89 +1171,90 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
   }
 }
 
-// ---- `prob` head (Cout = 1) on the 4x4x1 broadcast form --------------------------------------------
-// Each LANE owns one output voxel; acc register r is output channel r (only r = 0 is real), the
-// B operand is the tap-shifted input value of the lane's voxel and ABID picks the input channel's
-// weight column out of the tap's 64-lane image.  Half-rate instruction, 1 of 4 rows useful: this
-// head is 2 % of the FLOPs and is slated to move to a VALU kernel fused with the softmax.
-template <int CK, int G, int TZ, int TY, int TX, int VEC>
+// ---- `prob` head (Cout = 1, with bias, no activation): VALU kernel -----------------------------------
+// One output channel is not a matrix problem (the MFMA forms would waste >= 75 % of their rows and
+// were measured at 5 TFLOP/s): each thread produces 4 consecutive x of one (z, y) with fp32 FMAs.
+// Per (ci, kz, ky) it reads 6 consecutive inputs from the LDS halo tile as one ds_read_b128 + one
+// ds_read_b64 (rows are stored so that the group starts 16-byte aligned) and does 12 FMAs with 3
+// weights that live in SGPRs (uniform scalar loads from the packed image).  Memory-bound by design:
+// 8 input channels + 1 output per voxel.
+template <int CK, int TZ, int TY, int TX>
 struct ProbCfg {
-  static constexpr int IZ = TZ + 2, IY = TY + 2, IX = VEC == 4 ? TX + 8 : TX + 2;
-  static constexpr int XLO = VEC == 4 ? 4 : 1, XOFF = XLO - 1;
+  static_assert(TX == 32 && TY == 8 && TZ == 4, "thread map: 8 x-groups x 8 y x 4 z");
+  static constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 4;  // TX + 2 needed, padded to a multiple of 4
   static constexpr int SY = IX, SZ = IY * IX, SC = IZ * SZ;
-  static constexpr int NW = 27 * 64;
+  static constexpr int NW = 64;  // Stager carries a (dummy) weight block; the weights are read as scalars
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
 
-template <int CK, int G, int TZ, int TY, int TX, int VEC>
-__global__ __launch_bounds__(kThreads) void prob_kernel(
+template <int CK, int TZ, int TY, int TX>
+__global__ __launch_bounds__(kThreads) void prob_valu_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, float *__restrict__ out, int cin,
     int Di, int Hi, int Wi, int tiles_x, int tiles_y, float slope) {
-  static_assert(TZ * TY * TX == 4 * G * 64 && CK == 8, "tile = 4 waves x G groups x 64 voxels");
-  const int nstages = (cin + CK - 1) / CK;
-  using Cfg = ProbCfg<CK, G, TZ, TY, TX, VEC>;
+  using Cfg = ProbCfg<CK, TZ, TY, TX>;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, NW = Cfg::NW;
   extern __shared__ float smem[];
   float *tile = smem;
   float *wts = smem + CK * SC;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nstages = (cin + CK - 1) / CK;
   const int bid = blockIdx.x;
   const int tx0 = (bid % tiles_x) * TX;
   const int ty0 = ((bid / tiles_x) % tiles_y) * TY;
   const int tz0 = (bid / (tiles_x * tiles_y)) * TZ;
   const int b = blockIdx.y;
-  int base[G], vx[G], vy[G], vz[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int v = (wave * G + g) * 64 + lane;
-    vx[g] = v % TX;
-    vy[g] = (v / TX) % TY;
-    vz[g] = v / (TX * TY);
-    base[g] = vz[g] * SZ + vy[g] * SY + vx[g] + Cfg::XOFF;
-  }
-  f32x4 acc[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xi = threadIdx.x & 7, yi = (threadIdx.x >> 3) & 7, zi = threadIdx.x >> 6;
+  const float *row0 = tile + zi * SZ + yi * SY + 4 * xi;  // (kz, ky, cil) = 0; local x of (x0 - 1) is 0
+
   const int in_cs = Di * Hi * Wi;
   const size_t in_ss = (size_t)cin * in_cs;
   const rsrc_t src = make_rsrc(in + b * in_ss, in_ss * 4);
-  const float *scale = wpk + (size_t)nstages * NW;
+  const int units = (cin + 7) / 8;  // packed image: [unit of 8 channels][tap][64 lanes], weight of
+  const float *scale = wpk + (size_t)units * 27 * 64;  // (ci, tap) at lane 4 * (ci % 8)
   const float *shift = scale + 4;
-  Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
+  Stager<1, CK, IZ, IY, IX, SC, NW> regs;
   regs.init_kernel(in_cs, Hi * Wi, Di);
-  regs.init_tile(tz0 - 1, ty0 - 1, tx0 - Cfg::XLO, Hi, Wi);
+  regs.init_tile(tz0 - 1, ty0 - 1, tx0 - 1, Hi, Wi);
   regs.load(src, cin, 0, wpk);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
     regs.store(tile, wts);
     __syncthreads();
-    if (s + 1 < nstages)
-      regs.load(src, cin, (s + 1) * CK, wpk + (size_t)(s + 1) * NW);
-    for (int tap = 0; tap < 27; ++tap) {
-      const float a = wts[tap * 64 + lane];
-      const int toff = (tap / 9) * SZ + ((tap / 3) % 3) * SY + (tap % 3);
-      float bv[G][CK];
+    if (s + 1 < nstages) regs.load(src, cin, (s + 1) * CK, wpk);
 #pragma unroll
-      for (int g = 0; g < G; ++g)
+    for (int c = 0; c < CK; ++c) {
+      const int ci = s * CK + c;  // channels >= cin: staged zeros x zero weights
+      const float *wci = wpk + ((size_t)(ci >> 3) * 27) * 64 + 4 * (ci & 7);
 #pragma unroll
-        for (int c = 0; c < CK; ++c) bv[g][c] = tile[c * SC + base[g] + toff];
-      static_for<CK>([&](auto c_) {
-        constexpr int c = decltype(c_)::value;
-        static_for<G>([&](auto g_) {
-          constexpr int g = decltype(g_)::value;
-          acc[g] = mfma_bcast<c>(a, bv[g][c], acc[g]);
-        });
-      });
+      for (int r9 = 0; r9 < 9; ++r9) {
+        const float *row = row0 + c * SC + (r9 / 3) * SZ + (r9 % 3) * SY;
+        const f32x4v a = *reinterpret_cast<const f32x4v *>(row);
+        const f32x2 e = *reinterpret_cast<const f32x2 *>(row + 4);
+        const float w0 = wci[(r9 * 3 + 0) * 64], w1 = wci[(r9 * 3 + 1) * 64], w2 = wci[(r9 * 3 + 2) * 64];
+        acc[0] = fmaf(a[2], w2, fmaf(a[1], w1, fmaf(a[0], w0, acc[0])));
+        acc[1] = fmaf(a[3], w2, fmaf(a[2], w1, fmaf(a[1], w0, acc[1])));
+        acc[2] = fmaf(e[0], w2, fmaf(a[3], w1, fmaf(a[2], w0, acc[2])));
+        acc[3] = fmaf(e[1], w2, fmaf(e[0], w1, fmaf(a[3], w0, acc[3])));
+      }
     }
   }
-  const size_t out_cs = (size_t)in_cs;
+  const int oz = tz0 + zi, oy = ty0 + yi, ox = tx0 + 4 * xi;
+  const rsrc_t dst = make_rsrc(out + (size_t)b * in_cs, (size_t)in_cs * 4);
+  const float sc0 = scale[0], sh0 = shift[0];
+  float v[4];
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int oz = tz0 + vz[g], oy = ty0 + vy[g], ox = tx0 + vx[g];
-    if (oz >= Di || oy >= Hi || ox >= Wi) continue;
-    float v = fmaf(acc[g][0], scale[0], shift[0]);
-    v = v > 0.0f ? v : v * slope;
-    out[(size_t)b * out_cs + ((size_t)oz * Hi + oy) * Wi + ox] = v;
+  for (int i = 0; i < 4; ++i) {
+    v[i] = fmaf(acc[i], sc0, sh0);
+    v[i] = v[i] > 0.0f ? v[i] : v[i] * slope;
+  }
+  const bool ok = oz < Di && oy < Hi;
+  const int vbase = ((oz * Hi + oy) * Wi + ox) * 4;
+  if ((Wi & 3) == 0) {  // 16-byte aligned group, entirely inside or outside the row
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4v{v[0], v[1], v[2], v[3]}), dst,
+                                           (ok && ox < Wi) ? vbase : kOOB, 0, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) buf_store(v[i], dst, (ok && ox + i < Wi) ? vbase + 4 * i : kOOB, 0);
   }
 }
 
@@ -1351,13 +1407,13 @@ int resident_blocks(K kernel, size_t lds_bytes) {
   return cached;
 }
 
-template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC>
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int KZ = 3, int KS = 3, int UPS = 0>
 int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, const float *skip,
                     float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                     float slope, hipStream_t st) {
-  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC>;
-  auto kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC>;
-  if (MODE == FMT_PX) {  // profiling-only ablations of the dominant kernel (results are wrong)
+  using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, KZ, KS>;
+  auto kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 0, KZ, KS, UPS>;
+  if constexpr (MODE == FMT_PX && KZ == 3) {  // profiling-only ablations of the dominant kernel (results are wrong)
     static const int abl = getenv("CASMVS_ABLATE") ? atoi(getenv("CASMVS_ABLATE")) : 0;
     if (abl == 1) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 1>;
     if (abl == 2) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 2>;
@@ -1368,8 +1424,8 @@ int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, con
   const int tiles_x = casmvs::ceil_div(Wo, TX), tiles_y = casmvs::ceil_div(Ho, TY),
             tiles_z = casmvs::ceil_div(Do, TZ);
   const long total = (long)tiles_x * tiles_y * tiles_z * B * c.slices;
-  CASMVS_REQUIRE(total < (1L << 31), "conv3d_forward: too many tiles");
-  const int resident = resident_blocks(conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC>, Cfg::LDS_BYTES);
+  CASMVS_REQUIRE(total < (1L << 31), "conv_forward: too many tiles");
+  const int resident = resident_blocks(conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 0, KZ, KS, UPS>, Cfg::LDS_BYTES);
   dim3 grid((unsigned)(total < resident ? total : resident));
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, B, cin, cout,
                      Di, Hi, Wi, Do, Ho, Wo, (int)c.per_slice(), c.slices, tiles_x, tiles_y, tiles_z, slope);
@@ -1435,40 +1491,36 @@ int launch_deconv16(const LayerCfg &c, const float *packed, const float *in, con
   return launch_deconv16_v<MODE, CK, NT, TZ, TY, TX, 1>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, slope, st);
 }
 
-template <int VEC>
-int launch_prob_v(const LayerCfg &c, const float *packed, const float *in, float *out, int B, int cin,
-                  int D, int H, int W, float slope, hipStream_t st) {
-  using Cfg = ProbCfg<8, 4, 8, 4, 32, VEC>;
-  auto kernel = prob_kernel<8, 4, 8, 4, 32, VEC>;
-  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "prob_kernel")) return rc;
-  const int tiles_x = casmvs::ceil_div(W, 32), tiles_y = casmvs::ceil_div(H, 4), tiles_z = casmvs::ceil_div(D, 8);
+int launch_prob(const LayerCfg &c, const float *packed, const float *in, float *out, int B, int cin,
+                int D, int H, int W, float slope, hipStream_t st) {
+  using Cfg = ProbCfg<4, 4, 8, 32>;
+  auto kernel = prob_valu_kernel<4, 4, 8, 32>;
+  if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "prob_valu_kernel")) return rc;
+  const int tiles_x = casmvs::ceil_div(W, 32), tiles_y = casmvs::ceil_div(H, 8), tiles_z = casmvs::ceil_div(D, 4);
   dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, 1);
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, out, cin, D, H, W,
                      tiles_x, tiles_y, slope);
-  return casmvs::check_launch("prob_kernel");
-}
-
-int launch_prob(const LayerCfg &c, const float *packed, const float *in, float *out, int B, int cin,
-                int D, int H, int W, float slope, hipStream_t st) {
-  // (16-byte staging costs this kernel its second workgroup per CU: measured 1.7x slower)
-  return launch_prob_v<1>(c, packed, in, out, B, cin, D, H, W, slope, st);
+  return casmvs::check_launch("prob_valu_kernel");
 }
 
 }  // namespace
 
-extern "C" size_t casmvs_conv3d_packed_floats(int kind, int cin, int cout) {
+namespace {
+inline bool is_3d_kind(int kind) { return kind >= CASMVS_CONV_S1 && kind <= CASMVS_CONV_T2; }
+inline bool is_2d_kind(int kind) { return kind >= CASMVS_CONV2D_K3 && kind <= CASMVS_CONV2D_K1_UP; }
+
+size_t packed_floats(int kind, int cin, int cout) {
   LayerCfg c;
   if (!layer_cfg(kind, cin, cout, c)) return 0;
   return (size_t)c.slices * c.per_slice() + 2 * (size_t)c.slices * c.coutb + 64;
 }
 
-extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *weight,
-                                      const float *scale, const float *shift, float *packed) {
-  casmvs::clear_error();
-  CASMVS_REQUIRE(weight && packed, "conv3d_pack: null pointer");
+int pack_layer(const char *who, int kind, int cin, int cout, const float *weight, const float *scale,
+               const float *shift, float *packed) {
+  CASMVS_REQUIRE(weight && packed, "%s: null pointer", who);
   LayerCfg c;
   if (!layer_cfg(kind, cin, cout, c))
-    return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv3d_pack: kind=%d cin=%d cout=%d", kind, cin, cout);
+    return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "%s: kind=%d cin=%d cout=%d", who, kind, cin, cout);
   float *p = packed;
   const int nimg = c.unit_floats / 64;
   for (int sl = 0; sl < c.slices; ++sl)
@@ -1481,6 +1533,29 @@ extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *
   for (int i = 0; i < 64; ++i) p[2 * cp + i] = 0.0f;  // zero words the staging loads point out-of-range lanes at
   return CASMVS_OK;
 }
+}  // namespace
+
+extern "C" size_t casmvs_conv3d_packed_floats(int kind, int cin, int cout) {
+  return is_3d_kind(kind) ? packed_floats(kind, cin, cout) : 0;
+}
+
+extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *weight,
+                                      const float *scale, const float *shift, float *packed) {
+  casmvs::clear_error();
+  if (!is_3d_kind(kind)) return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv3d_pack: kind=%d", kind);
+  return pack_layer("conv3d_pack", kind, cin, cout, weight, scale, shift, packed);
+}
+
+extern "C" size_t casmvs_conv2d_packed_floats(int kind, int cin, int cout) {
+  return is_2d_kind(kind) ? packed_floats(kind, cin, cout) : 0;
+}
+
+extern "C" int casmvs_conv2d_pack_f32(int kind, int cin, int cout, const float *weight,
+                                      const float *scale, const float *shift, float *packed) {
+  casmvs::clear_error();
+  if (!is_2d_kind(kind)) return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv2d_pack: kind=%d", kind);
+  return pack_layer("conv2d_pack", kind, cin, cout, weight, scale, shift, packed);
+}
 
 extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const float *in,
                                          const float *skip, float *out, int B, int cin, int cout,
@@ -1489,7 +1564,7 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
   CASMVS_REQUIRE(packed && in && out, "conv3d_forward: null pointer");
   CASMVS_REQUIRE(B > 0 && B <= 65535 && D > 0 && H > 0 && W > 0, "conv3d_forward: bad shape B=%d D=%d H=%d W=%d", B, D, H, W);
   LayerCfg c;
-  if (!layer_cfg(kind, cin, cout, c))
+  if (!is_3d_kind(kind) || !layer_cfg(kind, cin, cout, c))
     return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv3d_forward: kind=%d cin=%d cout=%d", kind, cin, cout);
   // buffer descriptors address one sample's tensor with 31-bit byte offsets
   {
@@ -1534,6 +1609,92 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
   const long wide_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 1) * c.slices * B;
   if (wide_blocks >= 512) return launch_deconv16<FMT_TCI, 8, 2, 1, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
   return launch_deconv16<FMT_TCI, 16, 1, 1, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+}
+
+// ---- FeatureNet (2D) -------------------------------------------------------------------------------
+// Tile shapes: TZ = 1 (the N images are the batch), 8 rows x 32 / 64 columns per workgroup.  The
+// layers are small (<= 1.5 GFLOP per image), so the shapes favour many work items over operand reuse.
+extern "C" int casmvs_conv2d_forward_f32(int kind, const float *packed, const float *in, const float *up,
+                                         float *out, int N, int cin, int cout, int H, int W, float slope,
+                                         void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(packed && in && out, "conv2d_forward: null pointer");
+  CASMVS_REQUIRE(N > 0 && H > 0 && W > 0, "conv2d_forward: bad shape N=%d H=%d W=%d", N, H, W);
+  LayerCfg c;
+  if (!is_2d_kind(kind) || !layer_cfg(kind, cin, cout, c))
+    return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv2d_forward: kind=%d cin=%d cout=%d", kind, cin, cout);
+  CASMVS_REQUIRE((size_t)cin * H * W < ((size_t)1 << 29) && (size_t)cout * H * W < ((size_t)1 << 29),
+                 "conv2d_forward: one image's input / output tensor must hold < 2^29 floats");
+  CASMVS_REQUIRE((kind == CASMVS_CONV2D_K1_UP) == (up != nullptr), "conv2d_forward: `up` goes with CASMVS_CONV2D_K1_UP only");
+  hipStream_t st = (hipStream_t)stream;
+  switch (kind) {
+    case CASMVS_CONV2D_K3:
+      if (c.fmt == FMT_PX)
+        return launch_conv16_v<FMT_PX, 1, 4, 4, 1, 8, 64, 1, 1, 3>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
+      return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 3>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
+    case CASMVS_CONV2D_K5S2:
+      CASMVS_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv2d_forward(K5S2): odd input dims %dx%d", H, W);
+      return launch_conv16_v<FMT_CI, 2, 4, 4, 1, 8, 32, 1, 1, 5>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H / 2, W / 2, slope, st);
+    case CASMVS_CONV2D_K1:
+      return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 1>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
+    default:
+      CASMVS_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv2d_forward(K1_UP): odd dims %dx%d", H, W);
+      return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 1, 1>(c, packed, in, up, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
+  }
+}
+
+extern "C" size_t casmvs_featurenet_workspace_bytes(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0 || H % 4 || W % 4) return 0;
+  const size_t hw = (size_t)H * W;
+  // full res: conv0.0 8, conv0 8, feat0' 32 | half: conv1.0, conv1.1, conv1 16 each, feat1' 32 | quarter: 3 x 32
+  return (size_t)N * (48 * hw + 80 * (hw / 4) + 96 * (hw / 16)) * sizeof(float);
+}
+
+extern "C" int casmvs_featurenet_forward_f32(const float *const *packed_layers, const float *imgs,
+                                             float *feat0, float *feat1, float *feat2, void *workspace,
+                                             int N, int H, int W, float slope, void *const *layer_events,
+                                             void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(packed_layers && imgs && feat0 && feat1 && feat2 && workspace, "featurenet_forward: null pointer");
+  CASMVS_REQUIRE(N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0,
+                 "featurenet_forward: N=%d H=%d W=%d (H, W must be multiples of 4)", N, H, W);
+  for (int i = 0; i < 13; ++i) CASMVS_REQUIRE(packed_layers[i], "featurenet_forward: packed_layers[%d] is null", i);
+  const size_t hw = (size_t)N * H * W;
+  float *ws = (float *)workspace;
+  float *a0 = ws;  ws += 8 * hw;          // conv0.0
+  float *c0 = ws;  ws += 8 * hw;          // conv0
+  float *f0 = ws;  ws += 32 * hw;         // up(feat1') + lat0(conv0)
+  float *a1 = ws;  ws += 16 * (hw / 4);   // conv1.0
+  float *b1 = ws;  ws += 16 * (hw / 4);   // conv1.1
+  float *c1 = ws;  ws += 16 * (hw / 4);   // conv1
+  float *f1 = ws;  ws += 32 * (hw / 4);   // up(feat2) + lat1(conv1)
+  float *a2 = ws;  ws += 32 * (hw / 16);  // conv2.0
+  float *b2 = ws;  ws += 32 * (hw / 16);  // conv2.1
+  float *c2 = ws;                         // conv2
+  const float *const *P = packed_layers;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+  int rc, li = 0;
+#define CASMVS_L(...)                                                                          \
+  if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);   \
+  ++li;                                                                                        \
+  rc = casmvs_conv2d_forward_f32(__VA_ARGS__);                                                 \
+  if (rc != CASMVS_OK) return rc
+  CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
+  CASMVS_L(CASMVS_CONV2D_K3, P[1], a0, nullptr, c0, N, 8, 8, H, W, slope, stream);            // conv0.1  :15
+  CASMVS_L(CASMVS_CONV2D_K5S2, P[2], c0, nullptr, a1, N, 8, 16, H, W, slope, stream);         // conv1.0  :18
+  CASMVS_L(CASMVS_CONV2D_K3, P[3], a1, nullptr, b1, N, 16, 16, H2, W2, slope, stream);        // conv1.1  :19
+  CASMVS_L(CASMVS_CONV2D_K3, P[4], b1, nullptr, c1, N, 16, 16, H2, W2, slope, stream);        // conv1.2  :20
+  CASMVS_L(CASMVS_CONV2D_K5S2, P[5], c1, nullptr, a2, N, 16, 32, H2, W2, slope, stream);      // conv2.0  :23
+  CASMVS_L(CASMVS_CONV2D_K3, P[6], a2, nullptr, b2, N, 32, 32, H4, W4, slope, stream);        // conv2.1  :24
+  CASMVS_L(CASMVS_CONV2D_K3, P[7], b2, nullptr, c2, N, 32, 32, H4, W4, slope, stream);        // conv2.2  :25
+  CASMVS_L(CASMVS_CONV2D_K1, P[8], c2, nullptr, feat2, N, 32, 32, H4, W4, 1.0f, stream);      // toplayer :48
+  CASMVS_L(CASMVS_CONV2D_K1_UP, P[9], c1, feat2, f1, N, 16, 32, H2, W2, 1.0f, stream);        // lat1 + up :49
+  CASMVS_L(CASMVS_CONV2D_K1_UP, P[10], c0, f1, f0, N, 8, 32, H, W, 1.0f, stream);             // lat0 + up :50
+  CASMVS_L(CASMVS_CONV2D_K3, P[11], f1, nullptr, feat1, N, 32, 16, H2, W2, 1.0f, stream);     // smooth1  :53
+  CASMVS_L(CASMVS_CONV2D_K3, P[12], f0, nullptr, feat0, N, 32, 8, H, W, 1.0f, stream);        // smooth0  :54
+#undef CASMVS_L
+  if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[13], (hipStream_t)stream);
+  return CASMVS_OK;
 }
 
 extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {

@@ -4,7 +4,7 @@ attribute names, state-dict keys (206 tensors) and `forward` contract, with the 
 gfx950 kernels of libcasmvs_hip.so.
 
 reference                                   here
-mvsnet.py:7-57     FeatureNet                same layers, PyTorch-ROCm (MIOpen) ops for now
+mvsnet.py:7-57     FeatureNet                parameter container + casmvs_featurenet_forward_f32
 mvsnet.py:60-104   CostRegNet                parameter container + casmvs_costreg_forward_f32
 mvsnet.py:125-195  CascadeMVSNet.predict_depth  casmvs_costvol_{var,gwc}_f32 -> CostRegNet ->
                                              casmvs_softmax_regress_f32
@@ -15,7 +15,6 @@ it in training mode or on CPU tensors raises instead of silently falling back.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from .inplace_abn import InPlaceABN
@@ -23,8 +22,40 @@ from .modules import ConvBnReLU, ConvBnReLU3D, _per_sample
 from .profiling import stage
 
 
+def _fold_norm(owner, norm):
+    """Eval-mode ABN -> per-channel (scale, shift) on the host and the activation slope."""
+    if not hasattr(norm, "running_mean"):
+        raise RuntimeError(f"{owner}: norm_act {type(norm).__name__} has no running statistics to fold")
+    if hasattr(norm, "folded_scale_shift"):
+        scale, shift = norm.folded_scale_shift()
+    else:  # any ABN-like module: weight/bias/running_mean/running_var/eps
+        var = norm.running_var.detach().double()
+        scale64 = norm.weight.detach().double() / torch.sqrt(var + norm.eps)
+        shift = (norm.bias.detach().double() - norm.running_mean.detach().double() * scale64).float().cpu()
+        scale = scale64.float().cpu()
+    slope = norm.leaky_slope() if hasattr(norm, "leaky_slope") else float(getattr(norm, "activation_param", 0.01))
+    return scale, shift, slope
+
+
+def _state_key(module, device):
+    key = [str(device)]
+    for _, t in module.state_dict(keep_vars=True).items():
+        key.append((t.data_ptr(), t._version))
+    return tuple(key)
+
+
 class FeatureNet(nn.Module):
-    """3-level FPN feature extractor (mvsnet.py:7-57)."""
+    """3-level FPN feature extractor (mvsnet.py:7-57): same layers / state-dict keys as the reference;
+    `forward` runs the 13 layers as MFMA kernels (casmvs_featurenet_forward_f32) with eval-mode ABN
+    folded into the conv epilogue and each FPN upsample-add fused into its lateral 1x1 conv."""
+
+    # (attribute path, kind) in the order casmvs_featurenet_forward_f32 expects
+    _LAYERS = (("conv0.0", ops.CONV2D_K3), ("conv0.1", ops.CONV2D_K3),
+               ("conv1.0", ops.CONV2D_K5S2), ("conv1.1", ops.CONV2D_K3), ("conv1.2", ops.CONV2D_K3),
+               ("conv2.0", ops.CONV2D_K5S2), ("conv2.1", ops.CONV2D_K3), ("conv2.2", ops.CONV2D_K3),
+               ("toplayer", ops.CONV2D_K1), ("lat1", ops.CONV2D_K1_UP), ("lat0", ops.CONV2D_K1_UP),
+               ("smooth1", ops.CONV2D_K3), ("smooth0", ops.CONV2D_K3))
+    LAYER_NAMES = tuple(n for n, _ in _LAYERS)
 
     def __init__(self, norm_act=InPlaceABN):
         super().__init__()
@@ -44,20 +75,47 @@ class FeatureNet(nn.Module):
         self.lat0 = nn.Conv2d(8, 32, 1)
         self.smooth1 = nn.Conv2d(32, 16, 3, padding=1)
         self.smooth0 = nn.Conv2d(32, 8, 3, padding=1)
+        self._packed = None
+        self._packed_key = None
+        self._workspace = None
+        self._slope = 0.01
+        self.timer = None         # optional profiling.StageTimer (bench.py)
 
-    @staticmethod
-    def _upsample_add(x, y):
-        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) + y
+    def packed_layers(self, device):
+        """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
+        key = _state_key(self, device)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        packed, slopes = [], set()
+        for name, kind in self._LAYERS:
+            m = self.get_submodule(name)
+            if isinstance(m, ConvBnReLU):
+                scale, shift, slope = _fold_norm(f"FeatureNet.{name}", m.bn)
+                slopes.add(slope)
+                packed.append(ops.conv2d_pack(kind, m.conv.weight, scale, shift).to(device))
+            else:
+                packed.append(ops.conv2d_pack(kind, m.weight, None, m.bias).to(device))
+        if len(slopes) > 1:
+            raise RuntimeError("FeatureNet: all ABN layers must share one activation slope")
+        self._slope = slopes.pop() if slopes else 0.01
+        self._packed, self._packed_key = packed, key
+        return packed
 
     def forward(self, x):
-        conv0 = self.conv0(x)
-        conv1 = self.conv1(conv0)
-        conv2 = self.conv2(conv1)
-        feat2 = self.toplayer(conv2)
-        feat1 = self._upsample_add(feat2, self.lat1(conv1))
-        feat0 = self._upsample_add(feat1, self.lat0(conv0))
-        feat1 = self.smooth1(feat1)
-        feat0 = self.smooth0(feat0)
+        """x (N, 3, H, W) -> {"level_0": (N,8,H,W), "level_1": (N,16,H/2,W/2), "level_2": (N,32,H/4,W/4)}."""
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("casmvsnet_pl_amd.FeatureNet is an inference engine (eval-mode ABN folded into the "
+                               "MFMA conv epilogue); call model.eval() / torch.no_grad().")
+        if not x.is_cuda:
+            raise RuntimeError("casmvsnet_pl_amd.FeatureNet runs on the MI355X only; there is no CPU fallback")
+        N, _, H, W = x.shape
+        packed = self.packed_layers(x.device)
+        need = ops.featurenet_workspace_bytes(N, H, W)
+        ws = self._workspace
+        if ws is None or ws.device != x.device or ws.numel() < need:
+            ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        events = self.timer.layer_events("feature", 14, self.LAYER_NAMES) if self.timer is not None else None
+        feat0, feat1, feat2 = ops.featurenet_forward(packed, x.float(), ws, slope=self._slope, layer_events=events)
         return {"level_0": feat0, "level_1": feat1, "level_2": feat2}
 
 
@@ -105,31 +163,17 @@ class CostRegNet(nn.Module):
             return m.conv.weight, m.bn, None
         return m[0].weight, m[1], None
 
-    def _cache_key(self, device):
-        key = [str(device)]
-        for _, t in self.state_dict(keep_vars=True).items():
-            key.append((t.data_ptr(), t._version))
-        return tuple(key)
-
     def packed_layers(self, device):
         """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
-        key = self._cache_key(device)
+        key = _state_key(self, device)
         if self._packed is not None and key == self._packed_key:
             return self._packed
         packed, slopes = [], set()
         for name, kind in self._LAYERS:
             weight, norm, bias = self._layer_tensors(name)
             if norm is not None:
-                if not hasattr(norm, "running_mean"):
-                    raise RuntimeError(f"CostRegNet.{name}: norm_act {type(norm).__name__} has no running statistics to fold")
-                if hasattr(norm, "folded_scale_shift"):
-                    scale, shift = norm.folded_scale_shift()
-                else:  # any ABN-like module: weight/bias/running_mean/running_var/eps
-                    var = norm.running_var.detach().double()
-                    scale64 = norm.weight.detach().double() / torch.sqrt(var + norm.eps)
-                    shift = (norm.bias.detach().double() - norm.running_mean.detach().double() * scale64).float().cpu()
-                    scale = scale64.float().cpu()
-                slopes.add(norm.leaky_slope() if hasattr(norm, "leaky_slope") else float(getattr(norm, "activation_param", 0.01)))
+                scale, shift, slope = _fold_norm(f"CostRegNet.{name}", norm)
+                slopes.add(slope)
             else:
                 scale, shift = None, bias
             packed.append(ops.conv3d_pack(kind, weight, scale, shift).to(device))
@@ -175,6 +219,7 @@ class CascadeMVSNet(nn.Module):
 
     def set_timer(self, timer):
         self.timer = timer
+        self.feature.timer = timer
         for l in range(self.levels):
             m = getattr(self, f"cost_reg_{l}")
             m.timer, m.timer_name = timer, f"costreg_{l}"

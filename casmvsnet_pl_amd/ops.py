@@ -8,7 +8,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import CONV_S1, CONV_S2, CONV_T2  # noqa: F401  (re-exported)
+from ._lib import (CONV_S1, CONV_S2, CONV_T2, CONV2D_K3, CONV2D_K5S2, CONV2D_K1,  # noqa: F401  (re-exported)
+                   CONV2D_K1_UP)
 
 
 def _dev(t, name):
@@ -180,6 +181,82 @@ def costreg_forward(packed_layers, vol, workspace, slope=0.01, layer_events=None
                                                     B, cin, D, h, w, float(slope), ev, _stream(vol))
     _lib.check(rc, "casmvs_costreg_forward_f32")
     return cost
+
+
+_CONV2D_KSIZE = {CONV2D_K3: 3, CONV2D_K5S2: 5, CONV2D_K1: 1, CONV2D_K1_UP: 1}
+
+
+def conv2d_pack(kind, weight, scale=None, shift=None):
+    """Host-side packing of one FeatureNet layer (casmvs_conv2d_pack_f32).  CPU tensors in / out."""
+    weight = weight.detach().to("cpu", torch.float32).contiguous()
+    cout, cin = weight.shape[:2]
+    k = _CONV2D_KSIZE.get(kind)
+    if k is None or tuple(weight.shape[2:]) != (k, k):
+        raise ValueError(f"conv2d_pack: kind {kind} with kernel {tuple(weight.shape[2:])}")
+    lib = _lib.load()
+    n = lib.casmvs_conv2d_packed_floats(kind, cin, cout)
+    if n == 0:
+        raise RuntimeError(f"conv2d_pack: unsupported layer kind={kind} cin={cin} cout={cout}")
+    packed = torch.empty(n, dtype=torch.float32)
+    sc = None if scale is None else scale.detach().to("cpu", torch.float32).contiguous()
+    sh = None if shift is None else shift.detach().to("cpu", torch.float32).contiguous()
+    rc = lib.casmvs_conv2d_pack_f32(kind, cin, cout, _ptr(weight), _ptr(sc), _ptr(sh), _ptr(packed))
+    _lib.check(rc, "casmvs_conv2d_pack_f32")
+    return packed
+
+
+def conv2d_forward(kind, packed, x, cout, up=None, slope=0.01):
+    """One FeatureNet layer on the matrix cores (casmvs_conv2d_forward_f32).  `up`: the coarser FPN
+    level (N, cout, H/2, W/2) whose bilinear x2 upsampling is added (CONV2D_K1_UP only)."""
+    x, packed = _dev(x, "x"), _dev(packed, "packed")
+    N, cin, H, W = x.shape
+    oshape = (N, cout, H // 2, W // 2) if kind == CONV2D_K5S2 else (N, cout, H, W)
+    if up is not None:
+        up = _dev(up, "up")
+        if tuple(up.shape) != (N, cout, H // 2, W // 2):
+            raise ValueError(f"conv2d_forward: up shape {tuple(up.shape)} != {(N, cout, H // 2, W // 2)}")
+    out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_conv2d_forward_f32(kind, _ptr(packed), _ptr(x), _ptr(up), _ptr(out), N, cin, cout,
+                                                   H, W, float(slope), _stream(x))
+    _lib.check(rc, "casmvs_conv2d_forward_f32")
+    return out
+
+
+def featurenet_workspace_bytes(N, H, W):
+    n = _lib.load().casmvs_featurenet_workspace_bytes(N, H, W)
+    if n == 0:
+        raise ValueError(f"FeatureNet: H, W must be positive multiples of 4 (got {H}, {W})")
+    return n
+
+
+def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None):
+    """Whole FeatureNet (mvsnet.py:40-57).  packed_layers: 13 device tensors (conv0.0 .. conv2.2,
+    toplayer, lat1, lat0, smooth1, smooth0); imgs (N,3,H,W) -> feat0 (N,8,H,W), feat1 (N,16,H/2,W/2),
+    feat2 (N,32,H/4,W/4).  layer_events: optional 14 recorded torch.cuda.Event."""
+    imgs = _dev(imgs, "imgs")
+    N, c, H, W = imgs.shape
+    if c != 3 or len(packed_layers) != 13:
+        raise ValueError("featurenet_forward: need (N,3,H,W) images and 13 packed layers")
+    need = featurenet_workspace_bytes(N, H, W)
+    if workspace.numel() * workspace.element_size() < need:
+        raise ValueError("featurenet_forward: workspace too small")
+    arr = (ctypes.c_void_p * 13)(*[p.data_ptr() for p in packed_layers])
+    dev = imgs.device
+    feat0 = torch.empty((N, 8, H, W), dtype=torch.float32, device=dev)
+    feat1 = torch.empty((N, 16, H // 2, W // 2), dtype=torch.float32, device=dev)
+    feat2 = torch.empty((N, 32, H // 4, W // 4), dtype=torch.float32, device=dev)
+    ev = None
+    if layer_events is not None:
+        if len(layer_events) != 14:
+            raise ValueError("featurenet_forward: need 14 events")
+        ev = (ctypes.c_void_p * 14)(*[e.cuda_event for e in layer_events])
+    with torch.cuda.device(dev):
+        rc = _lib.load().casmvs_featurenet_forward_f32(arr, _ptr(imgs), _ptr(feat0), _ptr(feat1), _ptr(feat2),
+                                                       ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope),
+                                                       ev, _stream(imgs))
+    _lib.check(rc, "casmvs_featurenet_forward_f32")
+    return feat0, feat1, feat2
 
 
 def selftest_mfma():

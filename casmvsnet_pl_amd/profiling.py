@@ -10,7 +10,7 @@ import torch
 class StageTimer:
     def __init__(self):
         self._ranges = []        # (name, start, end)
-        self._layer_sets = []    # (name, [12 events])
+        self._layer_sets = []    # (name, [events], interval names | None)
 
     @contextlib.contextmanager
     def range(self, name):
@@ -23,12 +23,13 @@ class StageTimer:
             e.record()
             self._ranges.append((name, s, e))
 
-    def layer_events(self, name, n=12):
-        """n events whose hipEvent_t handles exist (torch creates them lazily on first record)."""
+    def layer_events(self, name, n=12, names=None):
+        """n events whose hipEvent_t handles exist (torch creates them lazily on first record).
+        names: the n-1 interval labels (default: summary()'s layer_names)."""
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
         for ev in evs:
             ev.record()
-        self._layer_sets.append((name, evs))
+        self._layer_sets.append((name, evs, names))
         return evs
 
     def summary(self, layer_names=None):
@@ -42,9 +43,10 @@ class StageTimer:
             d["calls"] += 1
         for name, s, e in self._ranges:
             add(name, s.elapsed_time(e))
-        for name, evs in self._layer_sets:
+        for name, evs, names in self._layer_sets:
+            names = names or layer_names
             for i in range(len(evs) - 1):
-                lname = layer_names[i] if layer_names else str(i)
+                lname = names[i] if names else str(i)
                 add(f"{name}/{lname}", evs[i].elapsed_time(evs[i + 1]))
         return out
 

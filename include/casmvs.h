@@ -142,6 +142,38 @@ int casmvs_costreg_forward_f32(const float *const *packed_layers, const float *v
                                void *workspace, int B, int cin, int D, int h, int w, float slope,
                                void *const *layer_events, void *stream);
 
+/* ---- (f-1) FeatureNet: 2D convolutions on the same MFMA kernels ------------------------------
+ * Replaces: models/mvsnet.py:7-57 (FeatureNet) and models/modules.py:5-18 (ConvBnReLU):
+ *   y = lrelu_slope( conv2d(x) * scale[co] + shift[co] ) (+ up), x (N, cin, H, W), "same" padding.
+ * The 2D layers run on the 3D kernels with a 1-deep kernel (kz = 1, D = 1).
+ */
+#define CASMVS_CONV2D_K3 3     /* Conv2d k3 s1 p1 : (N,Cin,H,W) -> (N,Cout,H,W);    cout 8 or % 16 == 0 */
+#define CASMVS_CONV2D_K5S2 4   /* Conv2d k5 s2 p2 : (N,Cin,H,W) -> (N,Cout,H/2,W/2); cout % 16 == 0     */
+#define CASMVS_CONV2D_K1 5     /* Conv2d k1       : (N,Cin,H,W) -> (N,Cout,H,W);    cout % 16 == 0      */
+#define CASMVS_CONV2D_K1_UP 6  /* Conv2d k1 + bilinear x2 (align_corners) upsampling of `up` added:
+                                  the FPN top-down step of mvsnet.py:36-38; `up` is (N,Cout,H/2,W/2)  */
+
+/* Packing: as casmvs_conv3d_pack_f32 with weight (cout, cin, k, k).  Host only. */
+size_t casmvs_conv2d_packed_floats(int kind, int cin, int cout);
+int casmvs_conv2d_pack_f32(int kind, int cin, int cout, const float *weight, const float *scale,
+                           const float *shift, float *packed);
+
+/* One 2D layer.  in : device (N, cin, H, W) with H, W the INPUT dims (even for K5S2 and K1_UP);
+ * up : device (N, cout, H/2, W/2) for K1_UP, otherwise NULL;  out : device. */
+int casmvs_conv2d_forward_f32(int kind, const float *packed, const float *in, const float *up,
+                              float *out, int N, int cin, int cout, int H, int W, float slope,
+                              void *stream);
+
+/* Whole FeatureNet (mvsnet.py:40-57).  packed_layers[13]: conv0.0, conv0.1, conv1.0, conv1.1, conv1.2,
+ * conv2.0, conv2.1, conv2.2 (ABN folded), toplayer, lat1, lat0, smooth1, smooth0 (bias as shift).
+ * imgs : device (N, 3, H, W), H % 4 == 0, W % 4 == 0
+ * feat0 (N, 8, H, W), feat1 (N, 16, H/2, W/2), feat2 (N, 32, H/4, W/4) : device outputs
+ * layer_events: NULL or 14 hipEvent_t handles (event i before layer i, event 13 after the last). */
+size_t casmvs_featurenet_workspace_bytes(int N, int H, int W);
+int casmvs_featurenet_forward_f32(const float *const *packed_layers, const float *imgs, float *feat0,
+                                  float *feat1, float *feat2, void *workspace, int N, int H, int W,
+                                  float slope, void *const *layer_events, void *stream);
+
 /* ---- (a9) softmax over depth + soft-argmin regression + confidence --------------------------
  * Replaces: models/mvsnet.py:174-193 and models/modules.py:95-104:
  *   p = softmax_D(cost); depth = sum_k p_k d_k; idx = clamp(trunc(sum_k p_k k), 0, D-1);

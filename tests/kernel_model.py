@@ -119,3 +119,65 @@ def emulate(kind, packed, x, cout, skip=None, slope=0.01):
     if skip is not None:
         y = y + skip.double()
     return y.float()
+
+
+# ---- FeatureNet 2D layers: the same CI / PX formats with a 1-deep kernel (kz = 1) ----------------
+K3, K5S2, K1, K1_UP = 3, 4, 5, 6
+
+
+def layer_cfg2d(kind, cin, cout):
+    """-> fmt, coutb, slices, units, unit_floats, ks, stride (mirrors layer_cfg in conv3d_mfma.hip)."""
+    q = _ru((cin + 3) // 4, 4)
+    if kind == K3:
+        fmt, coutb, units, uf, ks, st = (PX, 8, _ru(cin, 8), 3 * 64, 3, 1) if cout == 8 else (CI, 16, q, 9 * 64, 3, 1)
+    elif kind == K5S2:
+        fmt, coutb, units, uf, ks, st = CI, 16, q, 25 * 64, 5, 2
+    else:
+        fmt, coutb, units, uf, ks, st = CI, 16, q, 64, 1, 1
+    return fmt, coutb, (cout + coutb - 1) // coutb, units, uf, ks, st
+
+
+def emulate2d(kind, packed, x, cout, up=None, slope=0.01):
+    N, cin, H, W = x.shape
+    fmt, coutb, slices, units, uf, ks, st = layer_cfg2d(kind, cin, cout)
+    nimg = uf // 64
+    body = slices * units * uf
+    assert packed.numel() == body + 2 * slices * coutb + 64
+    img = packed[:body].reshape(slices, units, nimg, 64).double()
+    scale = packed[body: body + slices * coutb].double()
+    shift = packed[body + slices * coutb: body + 2 * slices * coutb].double()
+    Ho, Wo = H // st, W // st
+    acc = torch.zeros(N, slices * coutb, Ho, Wo, dtype=torch.float64)
+    xd = x.double()
+    pad = ks // 2
+
+    def chan(xp, ci):
+        return xp[:, ci] if ci < cin else torch.zeros_like(xp[:, 0])
+
+    if fmt == CI:
+        xp = F.pad(xd, (pad, pad, pad, pad))
+        for sl in range(slices):
+            for u in range(units):
+                for tap in range(ks * ks):
+                    ky, kx = tap // ks, tap % ks
+                    A = img[sl, u, tap].reshape(4, 16)
+                    for k in range(4):
+                        bval = chan(xp, u * 4 + k)[:, ky:ky + st * (Ho - 1) + 1:st, kx:kx + st * (Wo - 1) + 1:st]
+                        for i in range(16):
+                            acc[:, sl * 16 + i] += A[k, i] * bval
+    else:
+        assert W % 2 == 0
+        xp = F.pad(xd, (1, 3, 1, 1))
+        for u in range(units):
+            for ky in range(3):
+                A = img[0, u, ky].reshape(4, 16)
+                plane = chan(xp, u)[:, ky:ky + H]
+                for xo in range(4):
+                    bval = plane[..., xo:xo + W:2]
+                    for i in range(16):
+                        acc[:, i >> 1, :, (i & 1)::2] += A[xo, i] * bval
+    y = acc * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+    y = torch.where(y > 0, y, y * slope)[:, :cout]
+    if up is not None:
+        y = y + F.interpolate(up.double(), scale_factor=2, mode="bilinear", align_corners=True)
+    return y.float()

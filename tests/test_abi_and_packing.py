@@ -79,6 +79,44 @@ def test_packed_image_drives_the_kernel_index_model_to_the_right_convolution(kin
     assert float((got - (ref + skip)).abs().max()) < 1e-4
 
 
+CASES_2D = [(ops.CONV2D_K3, 3, 8), (ops.CONV2D_K3, 8, 8), (ops.CONV2D_K3, 32, 8), (ops.CONV2D_K3, 16, 16),
+            (ops.CONV2D_K3, 32, 32), (ops.CONV2D_K5S2, 8, 16), (ops.CONV2D_K5S2, 16, 32), (ops.CONV2D_K1, 32, 32),
+            (ops.CONV2D_K1_UP, 8, 32), (ops.CONV2D_K1_UP, 16, 32)]
+
+
+@pytest.mark.parametrize("kind,cin,cout", CASES_2D)
+def test_packed_2d_image_drives_the_kernel_index_model_to_the_right_convolution(kind, cin, cout):
+    """FeatureNet layers: C packer + model of the kz = 1 kernel walk == torch conv2d (+ upsample-add)."""
+    g = torch.Generator().manual_seed(kind * 100 + cin + cout)
+    x = torch.randn(2, cin, 8, 12, generator=g)
+    k = {ops.CONV2D_K3: 3, ops.CONV2D_K5S2: 5}.get(kind, 1)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.2
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    packed = ops.conv2d_pack(kind, w, scale, shift)
+    ref = F.conv2d(x, w, None, stride=2 if kind == ops.CONV2D_K5S2 else 1, padding=k // 2)
+    ref = F.leaky_relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.01)
+    up = None
+    if kind == ops.CONV2D_K1_UP:
+        up = torch.randn(2, cout, 4, 6, generator=g)
+        ref = ref + F.interpolate(up, scale_factor=2, mode="bilinear", align_corners=True)
+    got = KM.emulate2d(kind, packed, x, cout, up=up, slope=0.01)
+    assert float((got - ref).abs().max()) < 1e-4
+
+
+def test_2d_packed_sizes_and_workspace():
+    lib = _lib.load()
+    assert lib.casmvs_conv2d_packed_floats(ops.CONV2D_K3, 3, 8) == 8 * 3 * 64 + 16 + 64          # PX, 1-deep kernel
+    assert lib.casmvs_conv2d_packed_floats(ops.CONV2D_K3, 32, 16) == 8 * 9 * 64 + 32 + 64        # CI
+    assert lib.casmvs_conv2d_packed_floats(ops.CONV2D_K5S2, 16, 32) == 2 * 4 * 25 * 64 + 64 + 64
+    assert lib.casmvs_conv2d_packed_floats(ops.CONV2D_K1_UP, 8, 32) == 2 * 4 * 64 + 64 + 64
+    assert lib.casmvs_conv2d_packed_floats(ops.CONV2D_K5S2, 8, 8) == 0       # unsupported
+    assert lib.casmvs_conv2d_packed_floats(ops.CONV_S1, 8, 8) == 0           # a 3D kind
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV2D_K3, 8, 8) == 0         # a 2D kind
+    assert lib.casmvs_featurenet_workspace_bytes(3, 32, 64) == 3 * 4 * (48 + 20 + 6) * 32 * 64
+    assert lib.casmvs_featurenet_workspace_bytes(1, 30, 64) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

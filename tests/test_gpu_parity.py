@@ -193,6 +193,59 @@ def test_costreg_matches_oracle(dev, report, cin, B, D, h, w):
     assert err < 5e-5
 
 
+CONV2D_CASES = [  # kind, cin, cout, N, H, W
+    (3, 3, 8, 3, 64, 96), (3, 8, 8, 2, 40, 72), (3, 32, 8, 1, 37, 50), (3, 16, 16, 2, 32, 48), (3, 32, 16, 1, 24, 70),
+    (3, 32, 32, 3, 16, 20), (3, 5, 16, 1, 9, 21), (3, 8, 8, 1, 10, 23), (4, 8, 16, 2, 64, 96), (4, 16, 32, 1, 36, 52), (5, 32, 32, 2, 16, 24),
+    (5, 16, 32, 1, 11, 13), (6, 16, 32, 2, 32, 48), (6, 8, 32, 1, 64, 96), (6, 8, 32, 1, 2, 2),
+    # big enough to leave more work items than resident workgroups (persistent loop, cross-tile prefetch)
+    (3, 8, 8, 3, 512, 640), (4, 8, 16, 3, 512, 640), (6, 8, 32, 1, 512, 640)]
+
+
+@pytest.mark.parametrize("kind,cin,cout,N,H,W", CONV2D_CASES)
+def test_conv2d_layer_matches_torch_cpu(dev, report, kind, cin, cout, N, H, W):
+    ops = _ops()
+    g = torch.Generator().manual_seed(kind * 1000 + cin * 10 + cout + H)
+    k = {ops.CONV2D_K3: 3, ops.CONV2D_K5S2: 5}.get(kind, 1)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    slope = 0.01 if kind in (ops.CONV2D_K3, ops.CONV2D_K5S2) else 1.0
+    want = F.conv2d(x, w, None, stride=2 if kind == ops.CONV2D_K5S2 else 1, padding=k // 2)
+    want = want * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    want = torch.where(want > 0, want, want * slope)
+    up = None
+    if kind == ops.CONV2D_K1_UP:
+        up = torch.randn(N, cout, H // 2, W // 2, generator=g)
+        want = want + F.interpolate(up, scale_factor=2, mode="bilinear", align_corners=True)
+    packed = ops.conv2d_pack(kind, w, scale, shift).to(dev)
+    got = ops.conv2d_forward(kind, packed, x.to(dev), cout, None if up is None else up.to(dev), slope).cpu()
+    err = scaled_err(got, want)
+    report("conv2d", kind=kind, cin=cin, cout=cout, shape=[N, H, W], scaled_err=err, max_abs=max_abs(got, want))
+    assert got.shape == want.shape
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 64, 96), (2, 32, 64), (5, 160, 128), (1, 36, 44)])
+def test_featurenet_matches_oracle(dev, report, N, H, W):
+    from casmvsnet_pl_amd import ABN, FeatureNet
+    from casmvsnet_pl_amd.synthetic import randomize_state_dict
+    net = FeatureNet(ABN)
+    randomize_state_dict({("feature." + k): v for k, v in net.state_dict().items()}, seed=H)
+    net.eval()
+    x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(W)) * 2 - 1
+    want = R.feature_net(x, {"feature." + k: v for k, v in net.state_dict().items()})
+    with torch.no_grad():
+        got = net.to(dev)(x.to(dev))
+    errs = {}
+    for l in range(3):
+        g_l, w_l = got[f"level_{l}"].cpu(), want[f"level_{l}"]
+        assert g_l.shape == w_l.shape
+        errs[l] = scaled_err(g_l, w_l)
+    report("featurenet", shape=[N, H, W], scaled_err=errs)
+    assert max(errs.values()) < 5e-5
+
+
 def _index_report(g, model, inter_or_golden_index):
     out = {}
     for l in (2, 1, 0):
