@@ -435,8 +435,10 @@ __device__ __forceinline__ TileCoord decode_tile(int item, int tiles_x, int tile
 // the kernel into the 2D convolutions of FeatureNet; UPS = 1 makes the epilogue add the bilinear x2
 // upsampling (align_corners = True) of `skip` (B, Cout, Ho/2, Wo/2) instead of `skip` itself - the
 // FPN top-down step F.interpolate(coarse) + lateral(x) of mvsnet.py:36-38,53-54.
+// OUT2 = 1 (2D layers, no skip input): `skip` is instead a SECOND output that receives the same result
+// pixel-major, (B, Ho, Wo, Cout) - the layout the cost-volume gather wants - next to the NCHW one.
 template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int ABL = 0, int KZ = 3,
-          int KS = 3, int UPS = 0>
+          int KS = 3, int UPS = 0, int OUT2 = 0>
 __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
     // Buffer stores: per-lane byte offset = (this lane's first channel, voxel), scalar offset =
     // remaining channel stride; lanes outside the volume / beyond cout carry kOOB and are dropped.
     const rsrc_t dst = make_rsrc(out + cur.b * out_ss, out_ss * 4);
-    const rsrc_t skp = make_rsrc((skip && !UPS) ? skip + cur.b * out_ss : out, out_ss * 4);
+    const rsrc_t skp = make_rsrc((skip && !UPS && !OUT2) ? skip + cur.b * out_ss : out, out_ss * 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int ct = wave * NT + t;
@@ -599,6 +601,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
         const int ox = cur.tx0 + cx * 32 + 2 * jcol;  // rows (co, s): r = 2 * h + s; channels 2*kq + h
         const bool ok = oz < Do && oy < Ho && ox < Wo;
         const int voff = ok ? (2 * kq * out_cs + (oz * Ho + oy) * Wo + ox) * 4 : kOOB;
+        [[maybe_unused]] float o2[2][2];  // [x phase][channel 2*kq + h]
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           float v0 = fmaf(av[2 * h], sc[h % NCO], sh[h % NCO]);
@@ -606,8 +609,12 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
           v0 = v0 > 0.0f ? v0 : v0 * slope;
           v1 = v1 > 0.0f ? v1 : v1 * slope;
           const int soff = h * out_cs * 4;
+          if constexpr (OUT2) {
+            o2[0][h] = v0;
+            o2[1][h] = v1;
+          }
           if ((Wo & 1) == 0) {  // ox even and Wo even: 8-byte aligned pair, both in range
-            if (skip) {
+            if (skip && !OUT2) {
               const f32x2 sk = buf_load2(skp, voff, soff);
               v0 += sk[0];
               v1 += sk[1];
@@ -615,13 +622,19 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
             buf_store2(f32x2{v0, v1}, dst, voff, soff);
           } else {
             const int voff1 = (ok && ox + 1 < Wo) ? voff + 4 : kOOB;
-            if (skip) {
+            if (skip && !OUT2) {
               v0 += buf_load(skp, voff, soff);
               v1 += buf_load(skp, voff1, soff);
             }
             buf_store(v0, dst, voff, soff);
             buf_store(v1, dst, voff1, soff);
           }
+        }
+        if constexpr (OUT2) {  // pixel-major copy: channels (2 kq, 2 kq + 1) of pixels ox, ox + 1
+          const rsrc_t d2 = make_rsrc(const_cast<float *>(skip) + cur.b * out_ss, out_ss * 4);
+          const int pbase = (((oz * Ho + oy) * Wo + ox) * cout + 2 * kq) * 4;
+          buf_store2(f32x2{o2[0][0], o2[0][1]}, d2, ok ? pbase : kOOB, 0);
+          buf_store2(f32x2{o2[1][0], o2[1][1]}, d2, (ok && ox + 1 < Wo) ? pbase + cout * 4 : kOOB, 0);
         }
       } else {
         const int ox = cur.tx0 + cx * 16 + jcol;  // channels slice*16 + 4*kq + r
@@ -653,13 +666,20 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
             buf_store(v, dst, okr ? vbase : kOOB, r * out_cs * 4);
           }
         } else {
+          [[maybe_unused]] f32x4 o4;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int voff = (ok && cur.slice * 16 + 4 * kq + r < cout) ? vbase : kOOB;
             float v = fmaf(av[r], sc[r % NCO], sh[r % NCO]);
             v = v > 0.0f ? v : v * slope;
-            if (skip) v += buf_load(skp, voff, r * out_cs * 4);
+            if (skip && !OUT2) v += buf_load(skp, voff, r * out_cs * 4);
+            if constexpr (OUT2) o4[r] = v;
             buf_store(v, dst, voff, r * out_cs * 4);
+          }
+          if constexpr (OUT2) {  // pixel-major copy: this lane's 4 consecutive channels in one store (cout % 16 == 0)
+            const rsrc_t d2 = make_rsrc(const_cast<float *>(skip) + cur.b * out_ss, out_ss * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), d2,
+                ok ? (((oz * Ho + oy) * Wo + ox) * cout + cur.slice * 16 + 4 * kq) * 4 : kOOB, 0, 0);
           }
         }
       }
@@ -1080,13 +1100,20 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
   const float *shift = scale + slices * COUTB;
   Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
   regs.init_kernel(in_cs, Hi * Wi, Di);
+#ifdef CASMVS_TRACE
+  int tr_n = 0;
+#endif
+  TRACE_STAMP();  // kernel start
   regs.init_tile(tz0, ty0, tx0, Hi, Wi);
   regs.load(src, cin, 0, wslice);
+  TRACE_STAMP();  // first loads issued
 
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
+    TRACE_STAMP();  // after barrier 1
     regs.store(tile, wts);
     __syncthreads();
+    TRACE_STAMP();  // after store + barrier 2
     if (s + 1 < nstages)
       regs.load(src, cin, (s + 1) * CK, wslice + (size_t)(s + 1) * NW);
 #pragma unroll
@@ -1125,6 +1152,7 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
     }
   }
 
+  TRACE_STAMP();  // MFMA loops done
   const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
   const int out_cs = Do * Ho * Wo;
   const size_t out_ss = (size_t)cout * out_cs;
@@ -1137,6 +1165,10 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
     sc[h] = scale[NCO * kq + h];
     sh[h] = shift[NCO * kq + h];
   }
+  // Two passes: ALL skip loads first, then compute + store.  Interleaved (load, wait, add, store per
+  // element) the in-order vmcnt wait of load i also waits for store i-1: 32 serial memory round trips
+  // per wave - measured 38k of the 61k cycles of a conv11 workgroup (tools/gpu_trace2.py).
+  int vcell[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int ct = wave * NT + t;
@@ -1144,7 +1176,22 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
     const int mz = tz0 + cz, my = ty0 + cy, mx = tx0 + cx * 16 + jcol;
     const bool ok = mz < Di && my < Hi && mx < Wi;
     // per-lane part: first channel of the lane (slice*COUTB + NCO*kq) and the cell's even-corner voxel
-    const int vcell = ((slice * COUTB + NCO * kq) * out_cs + (2 * mz * Ho + 2 * my) * Wo + 2 * mx) * 4;
+    vcell[t] = ok ? ((slice * COUTB + NCO * kq) * out_cs + (2 * mz * Ho + 2 * my) * Wo + 2 * mx) * 4 : kOOB;
+  }
+  f32x2 sk[NT][4][NCO];
+  if (skip) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int h = 0; h < NCO; ++h) {
+          const int voff = (slice * COUTB + NCO * kq + h < cout) ? vcell[t] : kOOB;
+          sk[t][ps][h] = buf_load2(skp, voff, (h * out_cs + ((ps >> 1) * Ho + (ps & 1)) * Wo) * 4);
+        }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int pz = ps >> 1, py = ps & 1;
@@ -1152,7 +1199,7 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
       for (int h = 0; h < NCO; ++h) {
         // TCI: h = row r -> channel 4*kq + r, pair = (parity 0, parity 1) accumulators
         // TPX: h -> channel 2*kq + h, pair = rows (2h, 2h+1) of the single accumulator
-        const int voff = (ok && slice * COUTB + NCO * kq + h < cout) ? vcell : kOOB;
+        const int voff = (slice * COUTB + NCO * kq + h < cout) ? vcell[t] : kOOB;
         const int soff = (h * out_cs + (pz * Ho + py) * Wo) * 4;
         float v0 = MODE == FMT_TCI ? acc[ps][0][t][h] : acc[ps][0][t][(2 * h) & 3];
         float v1 = MODE == FMT_TCI ? acc[ps][NACC - 1][t][h] : acc[ps][0][t][(2 * h + 1) & 3];
@@ -1161,14 +1208,18 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
         v0 = v0 > 0.0f ? v0 : v0 * slope;
         v1 = v1 > 0.0f ? v1 : v1 * slope;
         if (skip) {
-          const f32x2 sk = buf_load2(skp, voff, soff);
-          v0 += sk[0];
-          v1 += sk[1];
+          v0 += sk[t][ps][h][0];
+          v1 += sk[t][ps][h][1];
         }
         buf_store2(f32x2{v0, v1}, dst, voff, soff);
       }
     }
   }
+  TRACE_STAMP();  // epilogue issued
+#ifdef CASMVS_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  TRACE_STAMP();  // epilogue drained
 }
 
 // ---- `prob` head (Cout = 1, with bias, no activation): VALU kernel -----------------------------------
@@ -1178,20 +1229,23 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
 // ds_read_b64 (rows are stored so that the group starts 16-byte aligned) and does 12 FMAs with 3
 // weights that live in SGPRs (uniform scalar loads from the packed image).  Memory-bound by design:
 // 8 input channels + 1 output per voxel.
-template <int CK, int TZ, int TY, int TX>
+template <int CK, int TZ, int TY, int TX, int VEC>
 struct ProbCfg {
   static_assert(TX == 32 && TY == 8 && TZ == 4, "thread map: 8 x-groups x 8 y x 4 z");
-  static constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 4;  // TX + 2 needed, padded to a multiple of 4
+  static constexpr int IZ = TZ + 2, IY = TY + 2;
+  // VEC 1: rows start at x0 - 1 (TX + 2 needed, padded to TX + 4); VEC 4: at the aligned x0 - 4 (TX + 8)
+  static constexpr int IX = VEC == 4 ? TX + 8 : TX + 4;
+  static constexpr int XLO = VEC == 4 ? 4 : 1;
   static constexpr int SY = IX, SZ = IY * IX, SC = IZ * SZ;
   static constexpr int NW = 64;  // Stager carries a (dummy) weight block; the weights are read as scalars
   static constexpr size_t LDS_BYTES = (size_t)(CK * SC + NW) * sizeof(float);
 };
 
-template <int CK, int TZ, int TY, int TX>
-__global__ __launch_bounds__(kThreads) void prob_valu_kernel(
+template <int CK, int TZ, int TY, int TX, int VEC>
+__global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, float *__restrict__ out, int cin,
     int Di, int Hi, int Wi, int tiles_x, int tiles_y, float slope) {
-  using Cfg = ProbCfg<CK, TZ, TY, TX>;
+  using Cfg = ProbCfg<CK, TZ, TY, TX, VEC>;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, NW = Cfg::NW;
   extern __shared__ float smem[];
   float *tile = smem;
@@ -1203,7 +1257,9 @@ __global__ __launch_bounds__(kThreads) void prob_valu_kernel(
   const int tz0 = (bid / (tiles_x * tiles_y)) * TZ;
   const int b = blockIdx.y;
   const int xi = threadIdx.x & 7, yi = (threadIdx.x >> 3) & 7, zi = threadIdx.x >> 6;
-  const float *row0 = tile + zi * SZ + yi * SY + 4 * xi;  // (kz, ky, cil) = 0; local x of (x0 - 1) is 0
+  // (kz, ky, cil) = 0; VEC 1: the 6 inputs x-1 .. x+4 start at local 4 xi (16-byte aligned);
+  // VEC 4: they start at local 4 xi + 3, i.e. one word, the aligned group 4 xi + 4, one word
+  const float *row0 = tile + zi * SZ + yi * SY + 4 * xi;
 
   const int in_cs = Di * Hi * Wi;
   const size_t in_ss = (size_t)cin * in_cs;
@@ -1211,9 +1267,9 @@ __global__ __launch_bounds__(kThreads) void prob_valu_kernel(
   const int units = (cin + 7) / 8;  // packed image: [unit of 8 channels][tap][64 lanes], weight of
   const float *scale = wpk + (size_t)units * 27 * 64;  // (ci, tap) at lane 4 * (ci % 8)
   const float *shift = scale + 4;
-  Stager<1, CK, IZ, IY, IX, SC, NW> regs;
+  Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
   regs.init_kernel(in_cs, Hi * Wi, Di);
-  regs.init_tile(tz0 - 1, ty0 - 1, tx0 - 1, Hi, Wi);
+  regs.init_tile(tz0 - 1, ty0 - 1, tx0 - Cfg::XLO, Hi, Wi);
   regs.load(src, cin, 0, wpk);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < nstages; ++s) {
@@ -1228,13 +1284,24 @@ __global__ __launch_bounds__(kThreads) void prob_valu_kernel(
 #pragma unroll
       for (int r9 = 0; r9 < 9; ++r9) {
         const float *row = row0 + c * SC + (r9 / 3) * SZ + (r9 % 3) * SY;
-        const f32x4v a = *reinterpret_cast<const f32x4v *>(row);
-        const f32x2 e = *reinterpret_cast<const f32x2 *>(row + 4);
+        float i0, i5;
+        f32x4v m;
+        if constexpr (VEC == 4) {
+          i0 = row[3];
+          m = *reinterpret_cast<const f32x4v *>(row + 4);
+          i5 = row[8];
+        } else {
+          const f32x4v a = *reinterpret_cast<const f32x4v *>(row);
+          const f32x2 e = *reinterpret_cast<const f32x2 *>(row + 4);
+          i0 = a[0];
+          m = f32x4v{a[1], a[2], a[3], e[0]};
+          i5 = e[1];
+        }
         const float w0 = wci[(r9 * 3 + 0) * 64], w1 = wci[(r9 * 3 + 1) * 64], w2 = wci[(r9 * 3 + 2) * 64];
-        acc[0] = fmaf(a[2], w2, fmaf(a[1], w1, fmaf(a[0], w0, acc[0])));
-        acc[1] = fmaf(a[3], w2, fmaf(a[2], w1, fmaf(a[1], w0, acc[1])));
-        acc[2] = fmaf(e[0], w2, fmaf(a[3], w1, fmaf(a[2], w0, acc[2])));
-        acc[3] = fmaf(e[1], w2, fmaf(e[0], w1, fmaf(a[3], w0, acc[3])));
+        acc[0] = fmaf(m[1], w2, fmaf(m[0], w1, fmaf(i0, w0, acc[0])));
+        acc[1] = fmaf(m[2], w2, fmaf(m[1], w1, fmaf(m[0], w0, acc[1])));
+        acc[2] = fmaf(m[3], w2, fmaf(m[2], w1, fmaf(m[1], w0, acc[2])));
+        acc[3] = fmaf(i5, w2, fmaf(m[3], w1, fmaf(m[2], w0, acc[3])));
       }
     }
   }
@@ -1407,12 +1474,12 @@ int resident_blocks(K kernel, size_t lds_bytes) {
   return cached;
 }
 
-template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int KZ = 3, int KS = 3, int UPS = 0>
+template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int KZ = 3, int KS = 3, int UPS = 0, int OUT2 = 0>
 int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, const float *skip,
                     float *out, int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                     float slope, hipStream_t st) {
   using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, KZ, KS>;
-  auto kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 0, KZ, KS, UPS>;
+  auto kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 0, KZ, KS, UPS, OUT2>;
   if constexpr (MODE == FMT_PX && KZ == 3) {  // profiling-only ablations of the dominant kernel (results are wrong)
     static const int abl = getenv("CASMVS_ABLATE") ? atoi(getenv("CASMVS_ABLATE")) : 0;
     if (abl == 1) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 1>;
@@ -1425,7 +1492,7 @@ int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, con
             tiles_z = casmvs::ceil_div(Do, TZ);
   const long total = (long)tiles_x * tiles_y * tiles_z * B * c.slices;
   CASMVS_REQUIRE(total < (1L << 31), "conv_forward: too many tiles");
-  const int resident = resident_blocks(conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 0, KZ, KS, UPS>, Cfg::LDS_BYTES);
+  const int resident = resident_blocks(conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 0, KZ, KS, UPS, OUT2>, Cfg::LDS_BYTES);
   dim3 grid((unsigned)(total < resident ? total : resident));
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, skip, out, B, cin, cout,
                      Di, Hi, Wi, Do, Ho, Wo, (int)c.per_slice(), c.slices, tiles_x, tiles_y, tiles_z, slope);
@@ -1491,16 +1558,23 @@ int launch_deconv16(const LayerCfg &c, const float *packed, const float *in, con
   return launch_deconv16_v<MODE, CK, NT, TZ, TY, TX, 1>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, slope, st);
 }
 
-int launch_prob(const LayerCfg &c, const float *packed, const float *in, float *out, int B, int cin,
-                int D, int H, int W, float slope, hipStream_t st) {
-  using Cfg = ProbCfg<4, 4, 8, 32>;
-  auto kernel = prob_valu_kernel<4, 4, 8, 32>;
+template <int VEC>
+int launch_prob_v(const float *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
+                  float slope, hipStream_t st) {
+  using Cfg = ProbCfg<4, 4, 8, 32, VEC>;
+  auto kernel = prob_valu_kernel<4, 4, 8, 32, VEC>;
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "prob_valu_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(W, 32), tiles_y = casmvs::ceil_div(H, 8), tiles_z = casmvs::ceil_div(D, 4);
   dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, 1);
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads), Cfg::LDS_BYTES, st, in, packed, out, cin, D, H, W,
                      tiles_x, tiles_y, slope);
   return casmvs::check_launch("prob_valu_kernel");
+}
+
+int launch_prob(const LayerCfg &, const float *packed, const float *in, float *out, int B, int cin,
+                int D, int H, int W, float slope, hipStream_t st) {
+  if (vec4_ok(in, W)) return launch_prob_v<4>(packed, in, out, B, cin, D, H, W, slope, st);
+  return launch_prob_v<1>(packed, in, out, B, cin, D, H, W, slope, st);
 }
 
 }  // namespace
@@ -1614,10 +1688,10 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
 // ---- FeatureNet (2D) -------------------------------------------------------------------------------
 // Tile shapes: TZ = 1 (the N images are the batch), 8 rows x 32 / 64 columns per workgroup.  The
 // layers are small (<= 1.5 GFLOP per image), so the shapes favour many work items over operand reuse.
-extern "C" int casmvs_conv2d_forward_f32(int kind, const float *packed, const float *in, const float *up,
-                                         float *out, int N, int cin, int cout, int H, int W, float slope,
-                                         void *stream) {
-  casmvs::clear_error();
+namespace {
+// out2: optional pixel-major (N, H, W, cout) copy of the result (K3 and K1 only)
+int conv2d_forward(int kind, const float *packed, const float *in, const float *up, float *out, float *out2,
+                   int N, int cin, int cout, int H, int W, float slope, void *stream) {
   CASMVS_REQUIRE(packed && in && out, "conv2d_forward: null pointer");
   CASMVS_REQUIRE(N > 0 && H > 0 && W > 0, "conv2d_forward: bad shape N=%d H=%d W=%d", N, H, W);
   LayerCfg c;
@@ -1626,21 +1700,35 @@ extern "C" int casmvs_conv2d_forward_f32(int kind, const float *packed, const fl
   CASMVS_REQUIRE((size_t)cin * H * W < ((size_t)1 << 29) && (size_t)cout * H * W < ((size_t)1 << 29),
                  "conv2d_forward: one image's input / output tensor must hold < 2^29 floats");
   CASMVS_REQUIRE((kind == CASMVS_CONV2D_K1_UP) == (up != nullptr), "conv2d_forward: `up` goes with CASMVS_CONV2D_K1_UP only");
+  CASMVS_REQUIRE(!out2 || kind == CASMVS_CONV2D_K3 || kind == CASMVS_CONV2D_K1, "conv2d_forward: pixel-major copy: K3 / K1 layers only");
+  CASMVS_REQUIRE(!out2 || (reinterpret_cast<size_t>(out2) & 15) == 0, "conv2d_forward: out2 must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   switch (kind) {
     case CASMVS_CONV2D_K3:
-      if (c.fmt == FMT_PX)
+      if (c.fmt == FMT_PX) {
+        if (out2) return launch_conv16_v<FMT_PX, 1, 4, 4, 1, 8, 64, 1, 1, 3, 0, 1>(c, packed, in, out2, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
         return launch_conv16_v<FMT_PX, 1, 4, 4, 1, 8, 64, 1, 1, 3>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
+      }
+      if (out2) return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 3, 0, 1>(c, packed, in, out2, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
       return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 3>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
     case CASMVS_CONV2D_K5S2:
       CASMVS_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv2d_forward(K5S2): odd input dims %dx%d", H, W);
       return launch_conv16_v<FMT_CI, 2, 4, 4, 1, 8, 32, 1, 1, 5>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H / 2, W / 2, slope, st);
     case CASMVS_CONV2D_K1:
+      if (out2) return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 1, 0, 1>(c, packed, in, out2, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
       return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 1>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
     default:
       CASMVS_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv2d_forward(K1_UP): odd dims %dx%d", H, W);
       return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 1, 1>(c, packed, in, up, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
   }
+}
+}  // namespace
+
+extern "C" int casmvs_conv2d_forward_f32(int kind, const float *packed, const float *in, const float *up,
+                                         float *out, int N, int cin, int cout, int H, int W, float slope,
+                                         void *stream) {
+  casmvs::clear_error();
+  return conv2d_forward(kind, packed, in, up, out, nullptr, N, cin, cout, H, W, slope, stream);
 }
 
 extern "C" size_t casmvs_featurenet_workspace_bytes(int N, int H, int W) {
@@ -1651,8 +1739,9 @@ extern "C" size_t casmvs_featurenet_workspace_bytes(int N, int H, int W) {
 }
 
 extern "C" int casmvs_featurenet_forward_f32(const float *const *packed_layers, const float *imgs,
-                                             float *feat0, float *feat1, float *feat2, void *workspace,
-                                             int N, int H, int W, float slope, void *const *layer_events,
+                                             float *feat0, float *feat1, float *feat2, float *feat0_nhwc,
+                                             float *feat1_nhwc, float *feat2_nhwc, void *workspace, int N,
+                                             int H, int W, float slope, void *const *layer_events,
                                              void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(packed_layers && imgs && feat0 && feat1 && feat2 && workspace, "featurenet_forward: null pointer");
@@ -1677,21 +1766,21 @@ extern "C" int casmvs_featurenet_forward_f32(const float *const *packed_layers, 
 #define CASMVS_L(...)                                                                          \
   if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);   \
   ++li;                                                                                        \
-  rc = casmvs_conv2d_forward_f32(__VA_ARGS__);                                                 \
+  rc = conv2d_forward(__VA_ARGS__);                                                            \
   if (rc != CASMVS_OK) return rc
-  CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
-  CASMVS_L(CASMVS_CONV2D_K3, P[1], a0, nullptr, c0, N, 8, 8, H, W, slope, stream);            // conv0.1  :15
-  CASMVS_L(CASMVS_CONV2D_K5S2, P[2], c0, nullptr, a1, N, 8, 16, H, W, slope, stream);         // conv1.0  :18
-  CASMVS_L(CASMVS_CONV2D_K3, P[3], a1, nullptr, b1, N, 16, 16, H2, W2, slope, stream);        // conv1.1  :19
-  CASMVS_L(CASMVS_CONV2D_K3, P[4], b1, nullptr, c1, N, 16, 16, H2, W2, slope, stream);        // conv1.2  :20
-  CASMVS_L(CASMVS_CONV2D_K5S2, P[5], c1, nullptr, a2, N, 16, 32, H2, W2, slope, stream);      // conv2.0  :23
-  CASMVS_L(CASMVS_CONV2D_K3, P[6], a2, nullptr, b2, N, 32, 32, H4, W4, slope, stream);        // conv2.1  :24
-  CASMVS_L(CASMVS_CONV2D_K3, P[7], b2, nullptr, c2, N, 32, 32, H4, W4, slope, stream);        // conv2.2  :25
-  CASMVS_L(CASMVS_CONV2D_K1, P[8], c2, nullptr, feat2, N, 32, 32, H4, W4, 1.0f, stream);      // toplayer :48
-  CASMVS_L(CASMVS_CONV2D_K1_UP, P[9], c1, feat2, f1, N, 16, 32, H2, W2, 1.0f, stream);        // lat1 + up :49
-  CASMVS_L(CASMVS_CONV2D_K1_UP, P[10], c0, f1, f0, N, 8, 32, H, W, 1.0f, stream);             // lat0 + up :50
-  CASMVS_L(CASMVS_CONV2D_K3, P[11], f1, nullptr, feat1, N, 32, 16, H2, W2, 1.0f, stream);     // smooth1  :53
-  CASMVS_L(CASMVS_CONV2D_K3, P[12], f0, nullptr, feat0, N, 32, 8, H, W, 1.0f, stream);        // smooth0  :54
+  CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, nullptr, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
+  CASMVS_L(CASMVS_CONV2D_K3, P[1], a0, nullptr, c0, nullptr, N, 8, 8, H, W, slope, stream);            // conv0.1  :15
+  CASMVS_L(CASMVS_CONV2D_K5S2, P[2], c0, nullptr, a1, nullptr, N, 8, 16, H, W, slope, stream);         // conv1.0  :18
+  CASMVS_L(CASMVS_CONV2D_K3, P[3], a1, nullptr, b1, nullptr, N, 16, 16, H2, W2, slope, stream);        // conv1.1  :19
+  CASMVS_L(CASMVS_CONV2D_K3, P[4], b1, nullptr, c1, nullptr, N, 16, 16, H2, W2, slope, stream);        // conv1.2  :20
+  CASMVS_L(CASMVS_CONV2D_K5S2, P[5], c1, nullptr, a2, nullptr, N, 16, 32, H2, W2, slope, stream);      // conv2.0  :23
+  CASMVS_L(CASMVS_CONV2D_K3, P[6], a2, nullptr, b2, nullptr, N, 32, 32, H4, W4, slope, stream);        // conv2.1  :24
+  CASMVS_L(CASMVS_CONV2D_K3, P[7], b2, nullptr, c2, nullptr, N, 32, 32, H4, W4, slope, stream);        // conv2.2  :25
+  CASMVS_L(CASMVS_CONV2D_K1, P[8], c2, nullptr, feat2, feat2_nhwc, N, 32, 32, H4, W4, 1.0f, stream);      // toplayer :48
+  CASMVS_L(CASMVS_CONV2D_K1_UP, P[9], c1, feat2, f1, nullptr, N, 16, 32, H2, W2, 1.0f, stream);        // lat1 + up :49
+  CASMVS_L(CASMVS_CONV2D_K1_UP, P[10], c0, f1, f0, nullptr, N, 8, 32, H, W, 1.0f, stream);             // lat0 + up :50
+  CASMVS_L(CASMVS_CONV2D_K3, P[11], f1, nullptr, feat1, feat1_nhwc, N, 32, 16, H2, W2, 1.0f, stream);     // smooth1  :53
+  CASMVS_L(CASMVS_CONV2D_K3, P[12], f0, nullptr, feat0, feat0_nhwc, N, 32, 8, H, W, 1.0f, stream);        // smooth0  :54
 #undef CASMVS_L
   if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[13], (hipStream_t)stream);
   return CASMVS_OK;

@@ -27,6 +27,16 @@ struct Taps {
 
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));  // 4-byte aligned pair
 
+// a / b from r = v_rcp_f32(b) (1 ulp) and one Newton step on the quotient: <= 1 ulp from the correctly
+// rounded result (usually equal to it) at 1/3 of the instruction slots of the IEEE expansion.  The seven
+// divisions of a tap set were a third of this VALU-bound kernel's instructions (PMC: ~540 VALU / wave).
+// Non-finite intermediates (depth ~ 0) end as NaN / inf coordinates either way and drop the tap.
+__device__ __forceinline__ float div_by(float a, float b, float rcp_b) {
+  const float q = a * rcp_b;
+  const float r = fmaf(-b, q, a);
+  return fmaf(r, rcp_b, q);
+}
+
 // Coordinates + bilinear taps of ref pixel (x, y) at depth dv in the source view whose
 // (P_src @ inv(P_ref))[:3] is P (12 floats, row-major 3x4).  Follows modules.py:59-89 and
 // ATen's grid_sampler (bilinear, zeros padding, align_corners=True) operation by operation.
@@ -36,20 +46,23 @@ __device__ __forceinline__ Taps plane_sweep_taps(const float *__restrict__ P, fl
   float rx = fmaf(P[2], 1.0f, fmaf(P[1], yf, P[0] * xf));
   float ry = fmaf(P[6], 1.0f, fmaf(P[5], yf, P[4] * xf));
   float rz = fmaf(P[10], 1.0f, fmaf(P[9], yf, P[8] * xf));
-  float qx = rx + P[3] / dv;
-  float qy = ry + P[7] / dv;
-  float qz = rz + P[11] / dv;
+  const float rdv = __builtin_amdgcn_rcpf(dv);
+  float qx = rx + div_by(P[3], dv, rdv);
+  float qy = ry + div_by(P[7], dv, rdv);
+  float qz = rz + div_by(P[11], dv, rdv);
   // negative depth -> somewhere outside the image                  (modules.py:76-79)
   if (qz <= 1e-7f) {
     qx = (float)W;
     qy = (float)H;
     qz = 1.0f;
   }
-  float u = qx / qz;  // modules.py:81
-  float v = qy / qz;
+  const float rqz = __builtin_amdgcn_rcpf(qz);
+  float u = div_by(qx, qz, rqz);  // modules.py:81
+  float v = div_by(qy, qz, rqz);
   // scale to [-1, 1] (modules.py:83-84) and ATen's un-normalisation (align_corners=True)
-  float gx = u / ((float)(W - 1) * 0.5f) - 1.0f;
-  float gy = v / ((float)(H - 1) * 0.5f) - 1.0f;
+  const float hx = (float)(W - 1) * 0.5f, hy = (float)(H - 1) * 0.5f;
+  float gx = div_by(u, hx, __builtin_amdgcn_rcpf(hx)) - 1.0f;
+  float gy = div_by(v, hy, __builtin_amdgcn_rcpf(hy)) - 1.0f;
   float ix = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
   float iy = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
   float x0 = floorf(ix), y0 = floorf(iy);
@@ -194,6 +207,186 @@ __global__ __launch_bounds__(kThreads) void costvol_kernel(
   }
 }
 
+// ---- channel-last variant ---------------------------------------------------------------------
+// Measured on MI355X (tools/gpu_costvol_probe.py, profiles/): the NCHW kernel above is bound by the
+// rate at which the texture addresser retires gather instructions (~20 cycles per wave-instruction
+// whatever its width, with perfect tap locality as well as with noisy depth), not by HBM.  With the
+// feature maps stored pixel-major (B, V, h, w, C) one bilinear tap of 4 channels is ONE 16-byte load,
+// so a voxel needs C loads per source view instead of 2 C.  Same taps, same weights, same order of
+// operations per channel as costvol_kernel: results are bit-identical.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + imm, 0, 0));
+}
+
+// Lane roles.  A WAVEFRONT owns 64 consecutive pixels of one depth plane and all C channels; the four
+// wavefronts of a workgroup never synchronise with each other:
+//   taps:    lane = pixel computes the source view's taps once;
+//   gather:  lane = (pixel, group of 4 channels), the C/4 lanes of a pixel adjacent, so that one
+//            wave-wide 16-byte gather reads 64/(C/4) pixels x C contiguous floats = whole cache
+//            lines (the addresser's cost grows with the number of lines an instruction touches:
+//            measured ~1 cycle/line on top of the ~16-cycle floor).  The taps reach the gather
+//            lanes by ds_bpermute (no LDS storage, no barrier); sums stay in registers over views;
+//   store:   the variance (or the per-channel products of the group-wise correlation) goes through
+//            a wave-private LDS transpose so that the volume is written with lane = (channel,
+//            4 pixels): 16-byte stores, 256 B contiguous per channel.
+// A pointer the compiler must treat as wave-uniform (SGPRs).  Without it LLVM carries the map bases
+// through a divergent region in VGPRs and wraps EVERY buffer load in a waterfall loop (measured:
+// 637 VALU instructions per wave instead of ~300, the kernel became VALU-bound).
+__device__ __forceinline__ const float *uniform_ptr(const float *p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ int lane_bcast_i(int src_lane, int v) {
+  return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
+}
+__device__ __forceinline__ float lane_bcast_f(int src_lane, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+}
+
+template <int C, int MODE>
+__global__ __launch_bounds__(kThreads) void costvol_nhwc_kernel(
+    const float *__restrict__ feats, const float *__restrict__ proj,
+    const float *__restrict__ depth, float *__restrict__ out, int V, int G, int h, int w, int D,
+    int tiles, int tiles_per_xcd) {
+  constexpr int GL = C / 4;     // lanes per pixel
+  constexpr int PPI = 64 / GL;  // pixels per gather iteration
+  constexpr int NI = GL;        // iterations covering the wave's 64 pixels
+  constexpr int RS = 65;        // row stride of the transpose buffer (odd: conflict-free)
+  __shared__ float tr_all[4 * C * RS];
+  int tile, d;
+  if (!block_to_tile(D, tiles, tiles_per_xcd, tile, d)) return;
+  const int b = blockIdx.y;
+  const int hw = h * w;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *tr = tr_all + wave * (C * RS);
+  const int pw0 = tile * kThreads + wave * 64;
+  if (pw0 >= hw) return;  // wave-uniform
+  const int pa = pw0 + lane;  // taps role
+  const int ya = pa / w, xa = pa - ya * w;
+  const float dv = depth[((size_t)b * D + d) * hw + (pa < hw ? pa : hw - 1)];
+  const int g = lane % GL, pxi = lane / GL;
+  const size_t view_floats = (size_t)hw * C;
+  const float *fb = uniform_ptr(feats + (size_t)b * V * view_floats);  // view 0 = reference view
+  float ref[NI][4], s[NI][4], q[NI][4];
+  {
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(fb), 0, __builtin_amdgcn_readfirstlane((int)(view_floats * 4)), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const f32x4 r = buf_load4(r0, ((pw0 + it * PPI + pxi) * C + 4 * g) * 4, 0);  // beyond the map: 0
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ref[it][i] = r[i];
+        s[it][i] = MODE == 0 ? r[i] : 0.0f;   // mvsnet.py:140 / :144
+        q[it][i] = r[i] * r[i];                // mvsnet.py:141
+      }
+    }
+  }
+  for (int v = 1; v < V; ++v) {
+    Taps t = plane_sweep_taps(proj + ((size_t)b * (V - 1) + (v - 1)) * 12, (float)xa, (float)ya, dv, w, h);
+    if (pa >= hw) t = Taps{0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(uniform_ptr(fb + (size_t)v * view_floats)), 0,
+        __builtin_amdgcn_readfirstlane((int)(view_floats * 4)), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int pl = it * PPI + pxi;  // the wave-local pixel this lane gathers for
+      const int on0 = (lane_bcast_i(pl, t.o_n) * C + 4 * g) * 4, os0 = (lane_bcast_i(pl, t.o_s) * C + 4 * g) * 4;
+      const float w_nl = lane_bcast_f(pl, t.w_nl), w_nr = lane_bcast_f(pl, t.w_nr);
+      const float w_sl = lane_bcast_f(pl, t.w_sl), w_sr = lane_bcast_f(pl, t.w_sr);
+      const f32x4 n0 = buf_load4(src, on0, 0), n1 = buf_load4(src, on0, C * 4);
+      const f32x4 s0 = buf_load4(src, os0, 0), s1 = buf_load4(src, os0, C * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float val = fmaf(s1[i], w_sr, fmaf(s0[i], w_sl, fmaf(n1[i], w_nr, n0[i] * w_nl)));
+        s[it][i] = s[it][i] + val;
+        if (MODE == 0) q[it][i] = fmaf(val, val, q[it][i]);
+      }
+    }
+  }
+  // transpose through the wave's LDS rows (same-wave LDS operations execute in order)
+  const float rV = 1.0f / (float)V;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int pl = it * PPI + pxi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float o;
+      if (MODE == 0) {
+        const float m = s[it][i] * rV;  // sq/V - (sum/V)^2 (mvsnet.py:167), x/V as x * (1/V)
+        o = q[it][i] * rV - m * m;
+      } else {
+        o = s[it][i] * ref[it][i];      // volume_sum * ref_volume (mvsnet.py:170)
+      }
+      tr[(4 * g + i) * RS + pl] = o;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (MODE == 0) {
+    const int q4 = lane & 15, cw = lane >> 4;  // 4 pixels x channels cw, cw + 4, ...
+    const int p = pw0 + 4 * q4;
+    float *ob = out + ((size_t)b * C * D + d) * hw + p;
+#pragma unroll
+    for (int j = 0; j < C / 4; ++j) {
+      const int c = cw + 4 * j;
+      const float *row = tr + c * RS + 4 * q4;
+      const f32x4 o{row[0], row[1], row[2], row[3]};
+      float *op = ob + (size_t)c * D * hw;
+      if ((hw & 3) == 0) {
+        if (p < hw) *reinterpret_cast<f32x4 *>(op) = o;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (p + i < hw) op[i] = o[i];
+      }
+    }
+  } else {
+    if (pa < hw) {
+      const int cpg = C / G;
+      const float fn = (float)cpg, fv = (float)(V - 1);
+      float *op = out + ((size_t)b * G * D + d) * hw + pa;
+      float acc = 0.0f;
+      int cnt = 0;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        acc = acc + tr[c * RS + lane];
+        if (++cnt == cpg) {
+          *op = (acc / fn) / fv;  // mean over C/G, then / (V-1)
+          op += (size_t)D * hw;
+          acc = 0.0f;
+          cnt = 0;
+        }
+      }
+    }
+  }
+}
+
+// (N, C, h, w) -> (N, h, w, C): thread = pixel, C coalesced dword loads, C/4 16-byte stores
+template <int C>
+__global__ __launch_bounds__(kThreads) void nchw_to_nhwc_kernel(const float *__restrict__ in,
+                                                                float *__restrict__ out, int hw) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= hw) return;
+  const float *ip = in + (size_t)n * C * hw + p;
+  float *op = out + ((size_t)n * hw + p) * C;
+#pragma unroll
+  for (int g = 0; g < C / 4; ++g) {
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ip[(size_t)(4 * g + i) * hw];
+    *reinterpret_cast<f32x4 *>(op + 4 * g) = v;
+  }
+}
+
 struct Grid {
   int tiles, tiles_per_xcd;
   dim3 grid;
@@ -265,4 +458,66 @@ extern "C" int casmvs_costvol_gwc_f32(const float *feats, const float *proj, con
   else
     hipLaunchKernelGGL((costvol_kernel<8, 1>), g.grid, blk, 0, st, feats, proj, depth, out, V, C, G, h, w, D, g.tiles, g.tiles_per_xcd);
   return casmvs::check_launch("costvol_gwc_kernel");
+}
+
+extern "C" int casmvs_nchw_to_nhwc_f32(const float *in, float *out, int N, int C, int h, int w, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(in && out, "nchw_to_nhwc: null pointer");
+  CASMVS_REQUIRE(N > 0 && N <= 65535 && h > 0 && w > 0, "nchw_to_nhwc: bad shape N=%d h=%d w=%d", N, h, w);
+  const int hw = h * w;
+  dim3 grid((unsigned)casmvs::ceil_div(hw, kThreads), (unsigned)N), blk(kThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 8) hipLaunchKernelGGL(nchw_to_nhwc_kernel<8>, grid, blk, 0, st, in, out, hw);
+  else if (C == 16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<16>, grid, blk, 0, st, in, out, hw);
+  else if (C == 32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<32>, grid, blk, 0, st, in, out, hw);
+  else return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "nchw_to_nhwc: C=%d (need 8, 16 or 32)", C);
+  return casmvs::check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int casmvs_costvol_var_nhwc_f32(const float *feats, const float *proj, const float *depth,
+                                           float *out, int B, int V, int C, int h, int w, int D,
+                                           void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(feats && proj && depth && out, "costvol_var_nhwc: null pointer");
+  CASMVS_REQUIRE(B > 0 && V >= 2 && h > 1 && w > 1 && D > 0,
+                 "costvol_var_nhwc: bad shape B=%d V=%d C=%d h=%d w=%d D=%d", B, V, C, h, w, D);
+  CASMVS_REQUIRE(B <= 65535, "costvol_var_nhwc: B > 65535");
+  CASMVS_REQUIRE(((reinterpret_cast<size_t>(feats) | reinterpret_cast<size_t>(out)) & 15) == 0, "costvol_var_nhwc: feats and out must be 16-byte aligned");
+  CASMVS_REQUIRE((size_t)h * w * C < ((size_t)1 << 29), "costvol_var_nhwc: one view's map must hold < 2^29 floats");
+  Grid g = make_grid(B, h * w, D, 1);
+  dim3 blk(kThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 32)
+    hipLaunchKernelGGL((costvol_nhwc_kernel<32, 0>), g.grid, blk, 0, st, feats, proj, depth, out, V, 1, h, w, D, g.tiles, g.tiles_per_xcd);
+  else if (C == 16)
+    hipLaunchKernelGGL((costvol_nhwc_kernel<16, 0>), g.grid, blk, 0, st, feats, proj, depth, out, V, 1, h, w, D, g.tiles, g.tiles_per_xcd);
+  else if (C == 8)
+    hipLaunchKernelGGL((costvol_nhwc_kernel<8, 0>), g.grid, blk, 0, st, feats, proj, depth, out, V, 1, h, w, D, g.tiles, g.tiles_per_xcd);
+  else
+    return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_var_nhwc: C=%d (need 8, 16 or 32)", C);
+  return casmvs::check_launch("costvol_var_nhwc_kernel");
+}
+
+extern "C" int casmvs_costvol_gwc_nhwc_f32(const float *feats, const float *proj, const float *depth,
+                                           float *out, int B, int V, int C, int G, int h, int w, int D,
+                                           void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(feats && proj && depth && out, "costvol_gwc_nhwc: null pointer");
+  CASMVS_REQUIRE(B > 0 && V >= 2 && h > 1 && w > 1 && D > 0 && G > 0,
+                 "costvol_gwc_nhwc: bad shape B=%d V=%d G=%d h=%d w=%d D=%d", B, V, G, h, w, D);
+  CASMVS_REQUIRE(B <= 65535, "costvol_gwc_nhwc: B > 65535");
+  CASMVS_REQUIRE((reinterpret_cast<size_t>(feats) & 15) == 0, "costvol_gwc_nhwc: feats must be 16-byte aligned");
+  CASMVS_REQUIRE((size_t)h * w * C < ((size_t)1 << 29), "costvol_gwc_nhwc: one view's map must hold < 2^29 floats");
+  if ((C != 8 && C != 16 && C != 32) || C % G != 0)
+    return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_gwc_nhwc: C=%d G=%d (need C in {8,16,32}, G | C)", C, G);
+  Grid g = make_grid(B, h * w, D, 1);
+  dim3 blk(kThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 32)
+    hipLaunchKernelGGL((costvol_nhwc_kernel<32, 1>), g.grid, blk, 0, st, feats, proj, depth, out, V, G, h, w, D, g.tiles, g.tiles_per_xcd);
+  else if (C == 16)
+    hipLaunchKernelGGL((costvol_nhwc_kernel<16, 1>), g.grid, blk, 0, st, feats, proj, depth, out, V, G, h, w, D, g.tiles, g.tiles_per_xcd);
+  else
+    hipLaunchKernelGGL((costvol_nhwc_kernel<8, 1>), g.grid, blk, 0, st, feats, proj, depth, out, V, G, h, w, D, g.tiles, g.tiles_per_xcd);
+  return casmvs::check_launch("costvol_gwc_nhwc_kernel");
 }

@@ -80,6 +80,7 @@ class FeatureNet(nn.Module):
         self._workspace = None
         self._slope = 0.01
         self.timer = None         # optional profiling.StageTimer (bench.py)
+        self.last_channels_last = None
 
     def packed_layers(self, device):
         """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
@@ -115,7 +116,10 @@ class FeatureNet(nn.Module):
         if ws is None or ws.device != x.device or ws.numel() < need:
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         events = self.timer.layer_events("feature", 14, self.LAYER_NAMES) if self.timer is not None else None
-        feat0, feat1, feat2 = ops.featurenet_forward(packed, x.float(), ws, slope=self._slope, layer_events=events)
+        feat0, feat1, feat2, cl = ops.featurenet_forward(packed, x.float(), ws, slope=self._slope, layer_events=events,
+                                                         channels_last_copies=True)
+        # pixel-major copies of the three maps (same kernels, second store): what the cost-volume gather reads
+        self.last_channels_last = {"level_0": cl[0], "level_1": cl[1], "level_2": cl[2]}
         return {"level_0": feat0, "level_1": feat1, "level_2": feat2}
 
 
@@ -224,11 +228,18 @@ class CascadeMVSNet(nn.Module):
             m = getattr(self, f"cost_reg_{l}")
             m.timer, m.timer_name = timer, f"costreg_{l}"
 
-    def predict_depth(self, feats, proj_mats, depth_values, cost_reg, level=None):
-        """feats (B,V,C,h,w), proj_mats (B,V-1,3,4), depth_values (B,D,h,w) -> depth, confidence (B,h,w)."""
+    def predict_depth(self, feats, proj_mats, depth_values, cost_reg, level=None, feats_channels_last=None):
+        """feats (B,V,C,h,w), proj_mats (B,V-1,3,4), depth_values (B,D,h,w) -> depth, confidence (B,h,w).
+        feats_channels_last: optional (B,V,h,w,C) copy of feats (FeatureNet writes one): the faster gather."""
         t = self.timer
-        with stage(t, f"costvol_{level}"):
-            volume = ops.costvol(feats, proj_mats, depth_values, self.G)    # mvsnet.py:134-172
+        with stage(t, f"costvol_{level}"):                                  # mvsnet.py:134-172
+            B, V, C, h, w = feats.shape
+            if feats_channels_last is None and C in (8, 16, 32):
+                feats_channels_last = ops.nchw_to_nhwc(feats.reshape(B * V, C, h, w)).view(B, V, h, w, C)
+            if feats_channels_last is not None:
+                volume = ops.costvol(feats_channels_last, proj_mats, depth_values, self.G, channels_last=True)
+            else:
+                volume = ops.costvol(feats, proj_mats, depth_values, self.G)
         cost = cost_reg(volume).squeeze(1)                                  # mvsnet.py:174
         with stage(t, f"softmax_{level}"):
             if self.keep_index:
@@ -274,8 +285,10 @@ class CascadeMVSNet(nn.Module):
                                                             None, D, h, w)
                     else:
                         depth_values = ops.depth_hypotheses(depth_l, None, interval_b, half_b, D, h, w)
+                cl = self.feature.last_channels_last[f"level_{l}"].view(B, V, h, w, C)
                 depth_l, confidence_l = self.predict_depth(feats_l, proj_mats_l, depth_values,
-                                                           getattr(self, f"cost_reg_{l}"), level=l)
+                                                           getattr(self, f"cost_reg_{l}"), level=l,
+                                                           feats_channels_last=cl)
                 results[f"depth_{l}"] = depth_l
                 results[f"confidence_{l}"] = confidence_l
         return results

@@ -46,27 +46,43 @@ def homo_warp(src_feat, proj_mat, depth_values):
     return out
 
 
-def costvol(feats, proj_mats, depth_values, num_groups=1):
+def nchw_to_nhwc(x):
+    """(N, C, h, w) -> (N, h, w, C) device copy (casmvs_nchw_to_nhwc_f32), C in {8, 16, 32}."""
+    x = _dev(x, "x")
+    N, C, h, w = x.shape
+    out = torch.empty((N, h, w, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_nchw_to_nhwc_f32(_ptr(x), _ptr(out), N, C, h, w, _stream(x))
+    _lib.check(rc, "casmvs_nchw_to_nhwc_f32")
+    return out
+
+
+def costvol(feats, proj_mats, depth_values, num_groups=1, channels_last=False):
     """Fused plane sweep + aggregation (mvsnet.py:134-172).
-    feats (B,V,C,h,w), proj_mats (B,V-1,3,4), depth_values (B,D,h,w) ->
+    feats (B,V,C,h,w) - or (B,V,h,w,C) with channels_last=True, the faster kernel -,
+    proj_mats (B,V-1,3,4), depth_values (B,D,h,w) ->
     (B,C,D,h,w) variance volume (num_groups == 1) or (B,G,D,h,w) group-wise correlation."""
     feats, proj_mats, depth_values = _dev(feats, "feats"), _dev(proj_mats, "proj_mats"), _dev(depth_values, "depth_values")
-    B, V, C, h, w = feats.shape
+    if channels_last:
+        B, V, h, w, C = feats.shape
+    else:
+        B, V, C, h, w = feats.shape
     D = depth_values.shape[1]
     if proj_mats.shape != (B, V - 1, 3, 4) or depth_values.shape != (B, D, h, w):
         raise ValueError(f"costvol: shapes {tuple(feats.shape)} {tuple(proj_mats.shape)} {tuple(depth_values.shape)}")
     lib = _lib.load()
+    sfx = "_nhwc" if channels_last else ""
     with torch.cuda.device(feats.device):
         if num_groups == 1:
             out = torch.empty((B, C, D, h, w), dtype=torch.float32, device=feats.device)
-            rc = lib.casmvs_costvol_var_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(out),
-                                            B, V, C, h, w, D, _stream(feats))
-            _lib.check(rc, "casmvs_costvol_var_f32")
+            rc = getattr(lib, f"casmvs_costvol_var{sfx}_f32")(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(out),
+                                                              B, V, C, h, w, D, _stream(feats))
+            _lib.check(rc, f"casmvs_costvol_var{sfx}_f32")
         else:
             out = torch.empty((B, num_groups, D, h, w), dtype=torch.float32, device=feats.device)
-            rc = lib.casmvs_costvol_gwc_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(out),
-                                            B, V, C, num_groups, h, w, D, _stream(feats))
-            _lib.check(rc, "casmvs_costvol_gwc_f32")
+            rc = getattr(lib, f"casmvs_costvol_gwc{sfx}_f32")(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(out),
+                                                              B, V, C, num_groups, h, w, D, _stream(feats))
+            _lib.check(rc, f"casmvs_costvol_gwc{sfx}_f32")
     return out
 
 
@@ -230,10 +246,12 @@ def featurenet_workspace_bytes(N, H, W):
     return n
 
 
-def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None):
+def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None, channels_last_copies=False):
     """Whole FeatureNet (mvsnet.py:40-57).  packed_layers: 13 device tensors (conv0.0 .. conv2.2,
     toplayer, lat1, lat0, smooth1, smooth0); imgs (N,3,H,W) -> feat0 (N,8,H,W), feat1 (N,16,H/2,W/2),
-    feat2 (N,32,H/4,W/4).  layer_events: optional 14 recorded torch.cuda.Event."""
+    feat2 (N,32,H/4,W/4).  layer_events: optional 14 recorded torch.cuda.Event.
+    channels_last_copies: also return the three maps pixel-major (N,h,w,C) (written by the same
+    kernels) -> (feat0, feat1, feat2, (nhwc0, nhwc1, nhwc2))."""
     imgs = _dev(imgs, "imgs")
     N, c, H, W = imgs.shape
     if c != 3 or len(packed_layers) != 13:
@@ -246,6 +264,11 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
     feat0 = torch.empty((N, 8, H, W), dtype=torch.float32, device=dev)
     feat1 = torch.empty((N, 16, H // 2, W // 2), dtype=torch.float32, device=dev)
     feat2 = torch.empty((N, 32, H // 4, W // 4), dtype=torch.float32, device=dev)
+    cl = (None, None, None)
+    if channels_last_copies:
+        cl = (torch.empty((N, H, W, 8), dtype=torch.float32, device=dev),
+              torch.empty((N, H // 2, W // 2, 16), dtype=torch.float32, device=dev),
+              torch.empty((N, H // 4, W // 4, 32), dtype=torch.float32, device=dev))
     ev = None
     if layer_events is not None:
         if len(layer_events) != 14:
@@ -253,10 +276,11 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
         ev = (ctypes.c_void_p * 14)(*[e.cuda_event for e in layer_events])
     with torch.cuda.device(dev):
         rc = _lib.load().casmvs_featurenet_forward_f32(arr, _ptr(imgs), _ptr(feat0), _ptr(feat1), _ptr(feat2),
+                                                       _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
                                                        ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope),
                                                        ev, _stream(imgs))
     _lib.check(rc, "casmvs_featurenet_forward_f32")
-    return feat0, feat1, feat2
+    return (feat0, feat1, feat2, cl) if channels_last_copies else (feat0, feat1, feat2)
 
 
 def selftest_mfma():

@@ -11,11 +11,26 @@ class StageTimer:
     def __init__(self):
         self._ranges = []        # (name, start, end)
         self._layer_sets = []    # (name, [events], interval names | None)
+        self._pool = []          # events created (and recorded once, so that their hipEvent_t exists) ahead of time
+
+    def reserve(self, n):
+        """Create n events NOW (outside any timed region): creating an event and its first record cost
+        CPU time and a GPU marker each; inside a timed loop that starves the launch queue."""
+        for _ in range(n):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._pool.append(ev)
+
+    def _event(self):
+        if self._pool:
+            return self._pool.pop()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
 
     @contextlib.contextmanager
     def range(self, name):
-        s = torch.cuda.Event(enable_timing=True)
-        e = torch.cuda.Event(enable_timing=True)
+        s, e = self._event(), self._event()
         s.record()
         try:
             yield
@@ -26,9 +41,7 @@ class StageTimer:
     def layer_events(self, name, n=12, names=None):
         """n events whose hipEvent_t handles exist (torch creates them lazily on first record).
         names: the n-1 interval labels (default: summary()'s layer_names)."""
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
-        for ev in evs:
-            ev.record()
+        evs = [self._event() for _ in range(n)]
         self._layer_sets.append((name, evs, names))
         return evs
 
@@ -53,6 +66,7 @@ class StageTimer:
     def reset(self):
         self._ranges.clear()
         self._layer_sets.clear()
+        self._pool.clear()
 
 
 def stage(timer, name):

@@ -93,6 +93,16 @@ int casmvs_costvol_var_f32(const float *feats, const float *proj, const float *d
 int casmvs_costvol_gwc_f32(const float *feats, const float *proj, const float *depth, float *out,
                            int B, int V, int C, int G, int h, int w, int D, void *stream);
 
+/* Channel-last variants of the two cost-volume builders: feats is (B, V, h, w, C) - every pixel's C
+ * features contiguous, 16-byte aligned - so that a bilinear tap of 4 channels is one 16-byte load
+ * (half the gather instructions of the NCHW kernels, whole cache lines per gather; bit-identical
+ * results).  C in {8, 16, 32}.  casmvs_nchw_to_nhwc_f32 converts a (N, C, h, w) map, C in {8,16,32}. */
+int casmvs_nchw_to_nhwc_f32(const float *in, float *out, int N, int C, int h, int w, void *stream);
+int casmvs_costvol_var_nhwc_f32(const float *feats, const float *proj, const float *depth, float *out,
+                                int B, int V, int C, int h, int w, int D, void *stream);
+int casmvs_costvol_gwc_nhwc_f32(const float *feats, const float *proj, const float *depth, float *out,
+                                int B, int V, int C, int G, int h, int w, int D, void *stream);
+
 /* ---- (a8) CostRegNet 3D convolutions (fp32 MFMA) -------------------------------------------
  * Replaces: models/mvsnet.py:60-104 `CostRegNet` and models/modules.py:21-31 `ConvBnReLU3D`
  *           (nn.Conv3d / nn.ConvTranspose3d, k=3, pad=1, followed by eval-mode ABN =
@@ -168,11 +178,14 @@ int casmvs_conv2d_forward_f32(int kind, const float *packed, const float *in, co
  * conv2.0, conv2.1, conv2.2 (ABN folded), toplayer, lat1, lat0, smooth1, smooth0 (bias as shift).
  * imgs : device (N, 3, H, W), H % 4 == 0, W % 4 == 0
  * feat0 (N, 8, H, W), feat1 (N, 16, H/2, W/2), feat2 (N, 32, H/4, W/4) : device outputs
+ * feat{0,1,2}_nhwc : NULL, or device (N, H, W, 8), (N, H/2, W/2, 16), (N, H/4, W/4, 32), 16-byte aligned:
+ *                    the same maps pixel-major, written by the same kernels, for casmvs_costvol_*_nhwc_f32
  * layer_events: NULL or 14 hipEvent_t handles (event i before layer i, event 13 after the last). */
 size_t casmvs_featurenet_workspace_bytes(int N, int H, int W);
 int casmvs_featurenet_forward_f32(const float *const *packed_layers, const float *imgs, float *feat0,
-                                  float *feat1, float *feat2, void *workspace, int N, int H, int W,
-                                  float slope, void *const *layer_events, void *stream);
+                                  float *feat1, float *feat2, float *feat0_nhwc, float *feat1_nhwc,
+                                  float *feat2_nhwc, void *workspace, int N, int H, int W, float slope,
+                                  void *const *layer_events, void *stream);
 
 /* ---- (a9) softmax over depth + soft-argmin regression + confidence --------------------------
  * Replaces: models/mvsnet.py:174-193 and models/modules.py:95-104:

@@ -76,6 +76,11 @@ def test_costvol_matches_oracle(dev, report, B, V, C, G, h, w, D, geometry):
     report("costvol", shape=[B, V, C, G, h, w, D], geometry=geometry, max_abs=err, ref_absmax=float(want.abs().max()))
     assert got.shape == want.shape and torch.isfinite(got).all()
     assert err < 5e-3 * max(1.0, float(want.abs().max()))
+    if C in (8, 16, 32):  # the channel-last kernel does the same arithmetic in the same order: bit-identical
+        nhwc = _ops().nchw_to_nhwc(feats.reshape(B * V, C, h, w).to(dev))
+        assert torch.equal(nhwc.cpu(), feats.reshape(B * V, C, h, w).permute(0, 2, 3, 1).contiguous())
+        got2 = _ops().costvol(nhwc.view(B, V, h, w, C), proj.to(dev), depth.to(dev), G, channels_last=True).cpu()
+        assert torch.equal(got2, got)
 
 
 def test_costvol_identical_views_have_zero_variance(dev):
@@ -242,6 +247,7 @@ def test_featurenet_matches_oracle(dev, report, N, H, W):
         g_l, w_l = got[f"level_{l}"].cpu(), want[f"level_{l}"]
         assert g_l.shape == w_l.shape
         errs[l] = scaled_err(g_l, w_l)
+        assert torch.equal(net.last_channels_last[f"level_{l}"].cpu(), g_l.permute(0, 2, 3, 1).contiguous())
     report("featurenet", shape=[N, H, W], scaled_err=errs)
     assert max(errs.values()) < 5e-5
 
