@@ -63,11 +63,11 @@ __device__ __forceinline__ f32x4 mfma_bcast(float a, float b, f32x4 c) {
 }
 
 // ---- layer formats -------------------------------------------------------------------------------
-enum Fmt { FMT_B4 = 0, FMT_CI = 1, FMT_PX = 2, FMT_TCI = 3, FMT_TPX = 4 };
+enum Fmt { FMT_P1 = 0, FMT_CI = 1, FMT_PX = 2, FMT_TCI = 3, FMT_TPX = 4 };
 
 struct LayerCfg {
   int fmt;
-  int coutb;        // output channels per slice: 16 (CI, TCI), 8 (PX, TPX), 4 (B4)
+  int coutb;        // output channels per slice: 16 (CI, TCI), 8 (PX, TPX), 4 (P1: 1 used)
   int slices;       // ceil(cout / coutb), blockIdx.z
   int units;        // contraction units per slice (padded so that any kernel chunking stays in range)
   int unit_floats;  // floats per unit
@@ -83,7 +83,8 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 //   CI / TCI : unit = 4 input channels (one "ci quad"), kz*ks*ks tap images -> [quad][tap][64]
 //   PX       : unit = 1 input channel, kz*ks (kz,ky) images                 -> [ci][kz*3+ky][64]
 //   TPX      : unit = 4 input channels, 9 (kz,ky) x 2 (dx) images           -> [quad][kz*3+ky][dx][64]
-//   B4       : unit = 8 input channels, 27 tap images                       -> [chunk][tap][64]
+//   P1       : unit = 1 input channel, its 27 taps contiguous (+ 5 zeros): no lane images - the
+//              1-channel `prob` head is a VALU kernel that reads its weights as wave-uniform scalars
 // The 2D layers of FeatureNet (kinds CASMVS_CONV2D_*) are the same formats with kz = 1.
 inline bool layer_cfg(int kind, int cin, int cout, LayerCfg &c) {
   if (cin < 1 || cout < 1) return false;
@@ -91,7 +92,7 @@ inline bool layer_cfg(int kind, int cin, int cout, LayerCfg &c) {
   c.ks = 3;
   const int quads = round_up((cin + 3) / 4, 4);
   if (kind == CASMVS_CONV_S1) {
-    if (cout == 1) { c.fmt = FMT_B4; c.coutb = 4; c.units = (cin + 7) / 8; c.unit_floats = 27 * 64; }
+    if (cout == 1) { c.fmt = FMT_P1; c.coutb = 4; c.units = round_up(cin, 8); c.unit_floats = 32; }
     else if (cout == 8) { c.fmt = FMT_PX; c.coutb = 8; c.units = round_up(cin, 8); c.unit_floats = 9 * 64; }
     else if (cout % 16 == 0) { c.fmt = FMT_CI; c.coutb = 16; c.units = quads; c.unit_floats = 27 * 64; }
     else return false;
@@ -131,10 +132,8 @@ inline float pack_weight(const LayerCfg &c, int kind, int cin, int cout, const f
   };
   const int i = l & 15, k = l >> 4;
   switch (c.fmt) {
-    case FMT_B4: {  // img = tap; lane: block l / 4 = local input channel (8 used), row l % 4 = co
-      const int cil = l / 4, co = l % 4;
-      return cil < 8 ? conv_w(co, unit * 8 + cil, img) : 0.0f;
-    }
+    case FMT_P1:     // one 32-float row per input channel: l = tap
+      return l < 27 ? conv_w(0, unit, l) : 0.0f;
     case FMT_CI:     // img = tap; row i = co, k = input channel of the quad
     case FMT_TCI:
       return conv_w(sl * 16 + i, unit * 4 + k, img);
@@ -364,13 +363,41 @@ struct Stager<4, CK, IZ, IY, IXR, SC, NW> {
   }
 };
 
+// Stager<VEC = 5>: the 16-byte loads of Stager<4>, but every row is stored DE-INTERLEAVED in x -
+// [even columns | odd columns], IXR / 2 each - for the stride-2 layers: tap kx of output column j
+// reads input column 2 j + kx - 1, i.e. a unit-stride walk through one parity half (bank-conflict free
+// like the stride-1 layers; the interleaved row gives 4-way conflicts once the channel stride is a
+// multiple of 4, which 16-byte LDS writes need).
+template <int CK, int IZ, int IY, int IXR, int SC, int NW>
+struct Stager<5, CK, IZ, IY, IXR, SC, NW> : Stager<4, CK, IZ, IY, IXR, SC, NW> {
+  using Base = Stager<4, CK, IZ, IY, IXR, SC, NW>;
+  static_assert(IXR % 8 == 0 || (IXR / 2) % 2 == 0, "8-byte aligned halves");
+  __device__ __forceinline__ void store(float *tile, float *wts) const {
+#pragma unroll
+    for (int i = 0; i < Base::NWR; ++i) {
+      const int e = threadIdx.x + i * kThreads;
+      if (e < Base::NWV) *reinterpret_cast<f32x4v *>(wts + 4 * e) = this->w[i];
+    }
+#pragma unroll
+    for (int k = 0; k < Base::NK; ++k) {
+      const typename Base::Pos p = Base::pos_of(k);
+      if (p.valid) {
+        float *row = tile + p.cil * SC + p.iz * (IY * IXR) + p.iy * IXR + 2 * p.xv;
+        *reinterpret_cast<f32x2 *>(row) = f32x2{this->v[k][0], this->v[k][2]};            // columns 4 xv, 4 xv + 2
+        *reinterpret_cast<f32x2 *>(row + IXR / 2) = f32x2{this->v[k][1], this->v[k][3]};  // columns 4 xv + 1, + 3
+      }
+    }
+  }
+};
+
 constexpr int round_up_to_16_mod_32(int x) { return x + ((16 - x % 32) + 32) % 32; }
 
 // ---- Conv3d k3 p1 (stride 1 or 2) on 16x16x4 ----------------------------------------------------
 template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int KZ = 3, int KS = 3>
 struct Conv16Cfg {
   static_assert(MODE == FMT_CI || MODE == FMT_PX, "conv16: CI or PX");
-  static_assert(VEC == 1 || (VEC == 4 && STRIDE == 1 && KS == 3), "16-byte staging: stride-1 k3 layers only");
+  static_assert(VEC == 1 || (VEC == 4 && KS == 3 && (STRIDE == 1 || MODE == FMT_CI)), "16-byte staging: k3 layers only");
+  static constexpr bool DEINT = VEC == 4 && STRIDE == 2;  // rows stored [even x | odd x] (Stager<5>)
   static_assert((KZ == 3 || (KZ == 1 && TZ == 1)) && (KS == 1 || KS == 3 || KS == 5), "kernel extents");
   static_assert(MODE != FMT_PX || KS == 3, "PX form: 3 taps along x");
   static constexpr int PZ = KZ / 2, PS = KS / 2;       // "same" padding
@@ -379,14 +406,14 @@ struct Conv16Cfg {
   static_assert(TX % XW == 0 && TZ * TY * NXG == 4 * NT, "tile = 4 waves x NT column tiles");
   static constexpr int IZ = STRIDE * (TZ - 1) + KZ, IY = STRIDE * (TY - 1) + KS;
   // staged row: VEC 1: x in [S x0 - PS, S (x0 + TX - 1) + PS]; VEC 4: widened to the aligned [x0 - 4, x0 + TX + 4)
-  static constexpr int IX = VEC == 4 ? TX + 8 : STRIDE * (TX - 1) + KS;
+  static constexpr int IX = VEC == 4 ? (STRIDE == 1 ? TX + 8 : (4 + 2 * (TX - 1) + 2 + 3) / 4 * 4) : STRIDE * (TX - 1) + KS;
   static constexpr int XLO = VEC == 4 ? 4 : PS;   // tile row starts at global x = S * x0 - XLO
   static constexpr int XOFF = XLO - PS;           // local x of (output x0, tap kx = 0)
   static constexpr int SY = IX, SZ = IY * IX;
   // channel stride: B lanes k = 0..3 read 4 channels (CI) -> k * SC must land on disjoint banks:
   // stride 1: 16 consecutive words per k -> SC == 16 (mod 32); stride 2: even words -> SC odd.
   static constexpr int SC = MODE == FMT_PX ? IZ * SZ
-                            : (STRIDE == 1 ? round_up_to_16_mod_32(IZ * SZ) : (IZ * SZ) | 1);
+                            : ((STRIDE == 1 || DEINT) ? round_up_to_16_mod_32(IZ * SZ) : (IZ * SZ) | 1);
   static constexpr int NA = MODE == FMT_PX ? CK : CK / 4;              // A images per iteration
   static constexpr int NITER = MODE == FMT_PX ? KZ * KS : KZ * KS * KS;  // (kz,ky) | (kz,ky,kx)
   static constexpr int ASTEP = MODE == FMT_PX ? SC : 4 * SC;           // B offset between A images
@@ -467,6 +494,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
     const int ct = wave * NT + t;
     const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
     if (MODE == FMT_PX) base[t] = cz * SZ + cy * SY + cx * 32 + 2 * jcol + kq + XOFF;                   // k = x-offset u
+    else if (Cfg::DEINT) base[t] = kq * SC + (cz * 2) * SZ + (cy * 2) * SY + cx * 16 + jcol;             // parity halves: unit stride
     else base[t] = kq * SC + (cz * STRIDE) * SZ + (cy * STRIDE) * SY + (cx * 16 + jcol) * STRIDE + XOFF;  // k = channel
   }
   f32x4 acc[NT];
@@ -489,6 +517,12 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
   constexpr int P = (ABL == 16 || ABL == 32) ? (NS % ABL == 0 ? ABL : P0) : P0;  // profiling override
   static_assert(NS % P == 0, "ring slots must line up across iterations");
   auto it_off = [&](int it) -> int {
+    if (Cfg::DEINT) {
+      // row starts at input column 2 x0 - 4: tap kx of output j reads column 2 j + kx + 3 of the row:
+      // kx = 1 -> even half, index j + 2; kx = 0 / 2 -> odd half, index j + 1 / j + 2
+      const int kx = it % 3;
+      return (it / 9) * SZ + ((it / 3) % 3) * SY + (kx == 1 ? 2 : IX / 2 + (kx == 0 ? 1 : 2));
+    }
     return MODE == FMT_PX ? (it / KS) * SZ + (it % KS) * SY : (it / (KS * KS)) * SZ + ((it / KS) % KS) * SY + (it % KS);
   };
 
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
 #endif
   TRACE_STAMP();  // kernel start
   TileCoord cur = decode_tile<TZ, TY, TX>(item, tiles_x, tiles_y, tiles_z, B);
-  Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
+  Stager<Cfg::DEINT ? 5 : VEC, CK, IZ, IY, IX, SC, NW> regs;
   regs.init_kernel(in_cs, Hi * Wi, Di);
   regs.init_tile(cur.tz0 * STRIDE - PZ, cur.ty0 * STRIDE - PS, cur.tx0 * STRIDE - XLO, Hi, Wi);
   regs.load(make_rsrc(in + cur.b * in_ss, in_ss * 4), cin, 0, wpk + (size_t)cur.slice * per_slice);
@@ -555,7 +589,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
       for (int a = 0; a < NA; ++a) a_cur[a] = wts[(a * NITER) * 64 + lane];
       int ad_c[NT], ad_n[NT];  // per-tile LDS word address of the current / next iteration
 #pragma unroll
-      for (int t = 0; t < NT; ++t) ad_c[t] = base[t];  // iteration 0: offset 0
+      for (int t = 0; t < NT; ++t) ad_c[t] = base[t] + it_off(0);
       float ring[P];
 #pragma unroll
       for (int i = 0; i < P; ++i) ring[i] = tile[ad_c[i % NT] + (i / NT) * ASTEP];
@@ -1108,6 +1142,13 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
   regs.load(src, cin, 0, wslice);
   TRACE_STAMP();  // first loads issued
 
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+  const int out_cs = Do * Ho * Wo;
+  const size_t out_ss = (size_t)cout * out_cs;
+  constexpr int NCO = MODE == FMT_TCI ? 4 : 2;
+  // (Tried: warming the skip tensor's cache lines with fire-and-forget loads issued here - the
+  // in-order vmcnt made the first stage wait for them and the epilogue did not get faster.)
+
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
     TRACE_STAMP();  // after barrier 1
@@ -1153,21 +1194,9 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
   }
 
   TRACE_STAMP();  // MFMA loops done
-  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
-  const int out_cs = Do * Ho * Wo;
-  const size_t out_ss = (size_t)cout * out_cs;
   const rsrc_t dst = make_rsrc(out + b * out_ss, out_ss * 4);
   const rsrc_t skp = make_rsrc(skip ? skip + b * out_ss : out, out_ss * 4);
-  constexpr int NCO = MODE == FMT_TCI ? 4 : 2;
   float sc[NCO], sh[NCO];
-#pragma unroll
-  for (int h = 0; h < NCO; ++h) {
-    sc[h] = scale[NCO * kq + h];
-    sh[h] = shift[NCO * kq + h];
-  }
-  // Two passes: ALL skip loads first, then compute + store.  Interleaved (load, wait, add, store per
-  // element) the in-order vmcnt wait of load i also waits for store i-1: 32 serial memory round trips
-  // per wave - measured 38k of the 61k cycles of a conv11 workgroup (tools/gpu_trace2.py).
   int vcell[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -1178,22 +1207,34 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
     // per-lane part: first channel of the lane (slice*COUTB + NCO*kq) and the cell's even-corner voxel
     vcell[t] = ok ? ((slice * COUTB + NCO * kq) * out_cs + (2 * mz * Ho + 2 * my) * Wo + 2 * mx) * 4 : kOOB;
   }
-  f32x2 sk[NT][4][NCO];
-  if (skip) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+  for (int h = 0; h < NCO; ++h) {
+    sc[h] = scale[NCO * kq + h];
+    sh[h] = shift[NCO * kq + h];
+  }
+  // Skip loads are issued in batches ahead of the stores.  Interleaved (load, wait, add, store per
+  // element) the in-order vmcnt wait of load i also waits for store i-1: 32 serial memory round trips
+  // per wave - measured 38k of the 61k cycles of a conv11 workgroup (tools/gpu_trace2.py).
+  // (tile, pass) pairs per batch of skip loads: TPX 16 x 8 bytes in flight per lane, TCI 8 (its two x-parity
+  // accumulators leave fewer registers: a 16-load batch would cost a resident workgroup per CU)
+  constexpr int BP = MODE == FMT_TCI ? 2 : 8;
+  static_assert((NT * 4) % BP == 0, "batches cover the tile x pass pairs");
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps)
+  for (int b0 = 0; b0 < NT * 4; b0 += BP) {
+    f32x2 sk[BP][NCO];
+    if (skip) {
+#pragma unroll
+      for (int bi = 0; bi < BP; ++bi)
 #pragma unroll
         for (int h = 0; h < NCO; ++h) {
+          const int t = (b0 + bi) / 4, ps = (b0 + bi) % 4;
           const int voff = (slice * COUTB + NCO * kq + h < cout) ? vcell[t] : kOOB;
-          sk[t][ps][h] = buf_load2(skp, voff, (h * out_cs + ((ps >> 1) * Ho + (ps & 1)) * Wo) * 4);
+          sk[bi][h] = buf_load2(skp, voff, (h * out_cs + ((ps >> 1) * Ho + (ps & 1)) * Wo) * 4);
         }
-  }
+    }
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int bi = 0; bi < BP; ++bi) {
+      const int t = (b0 + bi) / 4, ps = (b0 + bi) % 4;
       const int pz = ps >> 1, py = ps & 1;
 #pragma unroll
       for (int h = 0; h < NCO; ++h) {
@@ -1208,8 +1249,8 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
         v0 = v0 > 0.0f ? v0 : v0 * slope;
         v1 = v1 > 0.0f ? v1 : v1 * slope;
         if (skip) {
-          v0 += sk[t][ps][h][0];
-          v1 += sk[t][ps][h][1];
+          v0 += sk[bi][h][0];
+          v1 += sk[bi][h][1];
         }
         buf_store2(f32x2{v0, v1}, dst, voff, soff);
       }
@@ -1227,7 +1268,7 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
 // were measured at 5 TFLOP/s): each thread produces 4 consecutive x of one (z, y) with fp32 FMAs.
 // Per (ci, kz, ky) it reads 6 consecutive inputs from the LDS halo tile as one ds_read_b128 + one
 // ds_read_b64 (rows are stored so that the group starts 16-byte aligned) and does 12 FMAs with 3
-// weights that live in SGPRs (uniform scalar loads from the packed image).  Memory-bound by design:
+// weights that live in SGPRs (wide uniform scalar loads from the channel's contiguous 27-tap row).  Memory-bound by design:
 // 8 input channels + 1 output per voxel.
 template <int CK, int TZ, int TY, int TX, int VEC>
 struct ProbCfg {
@@ -1264,23 +1305,47 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
   const int in_cs = Di * Hi * Wi;
   const size_t in_ss = (size_t)cin * in_cs;
   const rsrc_t src = make_rsrc(in + b * in_ss, in_ss * 4);
-  const int units = (cin + 7) / 8;  // packed image: [unit of 8 channels][tap][64 lanes], weight of
-  const float *scale = wpk + (size_t)units * 27 * 64;  // (ci, tap) at lane 4 * (ci % 8)
+  const int rows = (cin + 7) / 8 * 8;  // packed image: [input channel][32]: the channel's 27 taps, contiguous
+  const float *scale = wpk + (size_t)rows * 32;
   const float *shift = scale + 4;
   Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
   regs.init_kernel(in_cs, Hi * Wi, Di);
+#ifdef CASMVS_TRACE
+  int tr_n = 0;
+#endif
+  TRACE_STAMP();  // kernel start
   regs.init_tile(tz0 - 1, ty0 - 1, tx0 - Cfg::XLO, Hi, Wi);
   regs.load(src, cin, 0, wpk);
+  TRACE_STAMP();  // first loads issued
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // VEC 4: the LDS offset of each staged 16-byte group is a kernel constant: keep it in a register instead
+  // of re-deriving it (divisions by constants) at every stage - this kernel has the registers to spare
+  [[maybe_unused]] int lds_off[VEC == 4 ? Stager<4, CK, IZ, IY, IX, SC, NW>::NK : 1];
+  if constexpr (VEC == 4) {
+    using S4 = Stager<4, CK, IZ, IY, IX, SC, NW>;
+#pragma unroll
+    for (int k = 0; k < S4::NK; ++k) {
+      const auto p = S4::pos_of(k);
+      lds_off[k] = p.valid ? p.cil * SC + p.iz * (IY * IX) + p.iy * IX + 4 * p.xv : -1;
+    }
+  }
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
-    regs.store(tile, wts);
+    TRACE_STAMP();  // after barrier 1
+    if constexpr (VEC == 4) {
+#pragma unroll
+      for (int k = 0; k < Stager<4, CK, IZ, IY, IX, SC, NW>::NK; ++k)
+        if (lds_off[k] >= 0) *reinterpret_cast<f32x4v *>(tile + lds_off[k]) = regs.v[k];
+    } else {
+      regs.store(tile, wts);
+    }
     __syncthreads();
+    TRACE_STAMP();  // after store + barrier 2
     if (s + 1 < nstages) regs.load(src, cin, (s + 1) * CK, wpk);
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
       const int ci = s * CK + c;  // channels >= cin: staged zeros x zero weights
-      const float *wci = wpk + ((size_t)(ci >> 3) * 27) * 64 + 4 * (ci & 7);
+      const float *wci = wpk + ci * 32;  // wave-uniform: s_load_dwordx8 / x16
 #pragma unroll
       for (int r9 = 0; r9 < 9; ++r9) {
         const float *row = row0 + c * SC + (r9 / 3) * SZ + (r9 % 3) * SY;
@@ -1297,7 +1362,7 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
           m = f32x4v{a[1], a[2], a[3], e[0]};
           i5 = e[1];
         }
-        const float w0 = wci[(r9 * 3 + 0) * 64], w1 = wci[(r9 * 3 + 1) * 64], w2 = wci[(r9 * 3 + 2) * 64];
+        const float w0 = wci[r9 * 3 + 0], w1 = wci[r9 * 3 + 1], w2 = wci[r9 * 3 + 2];
         acc[0] = fmaf(m[1], w2, fmaf(m[0], w1, fmaf(i0, w0, acc[0])));
         acc[1] = fmaf(m[2], w2, fmaf(m[1], w1, fmaf(m[0], w0, acc[1])));
         acc[2] = fmaf(m[3], w2, fmaf(m[2], w1, fmaf(m[1], w0, acc[2])));
@@ -1305,6 +1370,7 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
       }
     }
   }
+  TRACE_STAMP();  // FMA loops done
   const int oz = tz0 + zi, oy = ty0 + yi, ox = tx0 + 4 * xi;
   const rsrc_t dst = make_rsrc(out + (size_t)b * in_cs, (size_t)in_cs * 4);
   const float sc0 = scale[0], sh0 = shift[0];
@@ -1531,6 +1597,14 @@ int launch_conv16(const LayerCfg &c, const float *packed, const float *in, const
     if (vec4_ok(in, Wi))
       return launch_conv16_v<MODE, STRIDE, CK, NT, TZ, TY, TX, 4>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, Do, Ho, Wo, slope, st);
   }
+  if constexpr (STRIDE == 2) {
+    // 16-byte staging into x-de-interleaved rows (Stager<5>): correct and bank-conflict free, but measured
+    // 10-15 % slower on conv1 / conv3 (wider rows -> one resident workgroup fewer; the per-tile set-up
+    // of the flattened stager costs more VALU next to the MFMAs).  Kept for A/B runs: CASMVS_S2_VEC4=1.
+    static const bool s2_vec4 = getenv("CASMVS_S2_VEC4") != nullptr;
+    if (s2_vec4 && vec4_ok(in, Wi))
+      return launch_conv16_v<MODE, STRIDE, CK, NT, TZ, TY, TX, 4>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, Do, Ho, Wo, slope, st);
+  }
   return launch_conv16_v<MODE, STRIDE, CK, NT, TZ, TY, TX, 1>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, Do, Ho, Wo, slope, st);
 }
 
@@ -1598,9 +1672,11 @@ int pack_layer(const char *who, int kind, int cin, int cout, const float *weight
   float *p = packed;
   const int nimg = c.unit_floats / 64;
   for (int sl = 0; sl < c.slices; ++sl)
-    for (int u = 0; u < c.units; ++u)
+    for (int u = 0; u < c.units; ++u) {
       for (int img = 0; img < nimg; ++img)
         for (int l = 0; l < 64; ++l) *p++ = pack_weight(c, kind, cin, cout, weight, sl, u, img, l);
+      for (int l = 0; l < c.unit_floats - nimg * 64; ++l) *p++ = pack_weight(c, kind, cin, cout, weight, sl, u, 0, l);  // P1 rows
+    }
   const int cp = c.slices * c.coutb;
   for (int co = 0; co < cp; ++co) p[co] = (co < cout) ? (scale ? scale[co] : 1.0f) : 0.0f;
   for (int co = 0; co < cp; ++co) p[cp + co] = (co < cout) ? (shift ? shift[co] : 0.0f) : 0.0f;
@@ -1653,7 +1729,7 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
   // a 4x shorter stage chain and 4x more workgroups) serve the low-resolution layers, whose
   // cost is the latency of the chain, not FLOPs.
   if (kind == CASMVS_CONV_S1) {
-    if (c.fmt == FMT_B4) {
+    if (c.fmt == FMT_P1) {
       CASMVS_REQUIRE(skip == nullptr, "conv3d_forward: the 1-channel head takes no skip input");
       return launch_prob(c, packed, in, out, B, cin, D, H, W, slope, st);
     }
@@ -1679,7 +1755,7 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
     if (wide_blocks >= 512) return launch_conv16<FMT_CI, 2, 4, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
     return launch_conv16<FMT_CI, 2, 8, 1, 1, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
   }
-  if (c.fmt == FMT_TPX) return launch_deconv16<FMT_TPX, 8, 4, 2, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+  if (c.fmt == FMT_TPX) return launch_deconv16<FMT_TPX, 8, 2, 2, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
   const long wide_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 1) * c.slices * B;
   if (wide_blocks >= 512) return launch_deconv16<FMT_TCI, 8, 2, 1, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
   return launch_deconv16<FMT_TCI, 16, 1, 1, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);

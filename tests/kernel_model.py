@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 S1, S2, T2 = 0, 1, 2
-B4, CI, PX, TCI, TPX = 0, 1, 2, 3, 4
+P1, CI, PX, TCI, TPX = 0, 1, 2, 3, 4
 
 
 def _ru(x, m):
@@ -23,7 +23,7 @@ def layer_cfg(kind, cin, cout):
     """-> fmt, coutb, slices, units, unit_floats (mirrors layer_cfg in conv3d_mfma.hip)."""
     q = _ru((cin + 3) // 4, 4)
     if kind == S1:
-        fmt, coutb, units, uf = (B4, 4, (cin + 7) // 8, 27 * 64) if cout == 1 else (PX, 8, _ru(cin, 8), 9 * 64) if cout == 8 else (CI, 16, q, 27 * 64)
+        fmt, coutb, units, uf = (P1, 4, _ru(cin, 8), 32) if cout == 1 else (PX, 8, _ru(cin, 8), 9 * 64) if cout == 8 else (CI, 16, q, 27 * 64)
     elif kind == S2:
         fmt, coutb, units, uf = CI, 16, q, 27 * 64
     else:
@@ -37,7 +37,8 @@ def emulate(kind, packed, x, cout, skip=None, slope=0.01):
     nimg = uf // 64
     body = slices * units * uf
     assert packed.numel() == body + 2 * slices * coutb + 64
-    img = packed[:body].reshape(slices, units, nimg, 64).double()   # [slice][unit][image][lane]
+    if fmt != P1:
+        img = packed[:body].reshape(slices, units, nimg, 64).double()   # [slice][unit][image][lane]
     scale = packed[body: body + slices * coutb].double()
     shift = packed[body + slices * coutb: body + 2 * slices * coutb].double()
     assert float(packed[body + 2 * slices * coutb:].abs().sum()) == 0.0
@@ -53,16 +54,14 @@ def emulate(kind, packed, x, cout, skip=None, slope=0.01):
     def chan(xp, ci):  # staged tile: channels >= cin are zero-filled
         return xp[:, ci] if ci < cin else torch.zeros_like(xp[:, 0])
 
-    if fmt == B4:
+    if fmt == P1:  # VALU kernel: row ci of the image = the channel's 27 taps (+ 5 zeros)
+        rows = packed[:body].reshape(units, 32).double()
+        assert float(rows[:, 27:].abs().sum()) == 0.0
         xp = F.pad(xd, (1, 1, 1, 1, 1, 1))
-        for u in range(units):
+        for ci in range(units):
             for tap in range(27):
                 kz, ky, kx = tap // 9, (tap // 3) % 3, tap % 3
-                a = img[0, u, tap]
-                for c in range(8):  # ABID = c picks lanes 4c..4c+3 = rows (co 0..3) of channel c
-                    bval = chan(xp, u * 8 + c)[:, kz:kz + D, ky:ky + H, kx:kx + W]
-                    for r in range(4):
-                        acc[:, r] += a[4 * c + r] * bval
+                acc[:, 0] += rows[ci, tap] * chan(xp, ci)[:, kz:kz + D, ky:ky + H, kx:kx + W]
     elif fmt == CI:
         st = 1 if kind == S1 else 2
         xp = F.pad(xd, (1, 1, 1, 1, 1, 1))

@@ -45,7 +45,7 @@ def test_packed_sizes_and_workspace():
     assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 32, 8) == 32 * 9 * 64 + 16 + 64             # PX: 32 channel units
     assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 5, 8) == 8 * 9 * 64 + 16 + 64               # PX: padded to 8 channels
     assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 64, 64) == 4 * 16 * 27 * 64 + 128 + 64      # CI: 4 slices x 16 quads
-    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 8, 1) == 27 * 64 + 8 + 64                   # B4
+    assert lib.casmvs_conv3d_packed_floats(ops.CONV_S1, 8, 1) == 8 * 32 + 8 + 64                    # P1: 8 rows of 27 (+5) taps
     assert lib.casmvs_conv3d_packed_floats(ops.CONV_S2, 8, 16) == 4 * 27 * 64 + 32 + 64            # CI: 2 quads padded to 4
     assert lib.casmvs_conv3d_packed_floats(ops.CONV_T2, 64, 32) == 2 * 16 * 27 * 64 + 64 + 64       # TCI
     assert lib.casmvs_conv3d_packed_floats(ops.CONV_T2, 16, 8) == 4 * 18 * 64 + 16 + 64            # TPX

@@ -155,7 +155,9 @@ CONV_CASES = [  # kind, cin, cout, B, D, H, W, with_skip
     (2, 16, 8, 1, 3, 5, 7, False),
     # large enough for the "wide" workgroup variants (>= 512 wide blocks)
     (0, 16, 32, 1, 16, 64, 128, True), (1, 8, 16, 1, 16, 256, 256, False), (2, 32, 16, 1, 8, 64, 128, True),
-    (0, 3, 16, 1, 5, 9, 21, False), (2, 6, 32, 1, 2, 5, 19, False)]
+    (0, 3, 16, 1, 5, 9, 21, False), (2, 6, 32, 1, 2, 5, 19, False),
+    # stride 2 with W % 4 != 0 (dword staging path) and a wide one with W % 4 == 0 whose tiles are ragged
+    (1, 8, 16, 1, 4, 8, 10, False), (1, 16, 16, 1, 6, 44, 72, False)]
 
 
 @pytest.mark.parametrize("kind,cin,cout,B,D,H,W,with_skip", CONV_CASES)
