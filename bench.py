@@ -5,9 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one forward pass (FeatureNet + 3 cascade levels) over one reference view with its
-source views: DTU 640x512, 3 views, n_depths [8,32,48], variance cost volume, fp32, synthetic
-inputs already resident in HBM, random-init weights.  With N GPUs every rank processes its own
+A "step" is one forward pass (FeatureNet + 3 cascade levels) over one batch of --batch reference views
+(default 2) with their source views: DTU 640x512, 3 views, n_depths [8,32,48], variance cost volume,
+fp32, synthetic inputs already resident in HBM, random-init weights.  With N GPUs every rank processes its own
 depth maps (the path shards at depth-map granularity, SURVEY 8e: no data-path collective) ->
 weak scaling; value = depth maps all ranks produced / max-over-ranks wall time.
 
@@ -96,7 +96,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="dtu_640x512_v3_var", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=1, help="depth maps per step per GPU")
+    ap.add_argument("--batch", type=int, default=2,
+                    help="depth maps per step per GPU (reference views batched like the reference's train.py --batch_size 2; "
+                         "--batch 1 = the reference's eval.py loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--event-every", type=int, default=4,

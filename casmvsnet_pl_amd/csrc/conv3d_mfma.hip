@@ -434,20 +434,31 @@ __device__ unsigned long long g_trace[64 * 128];
 #define TRACE_STAMP() do {} while (0)
 #endif
 
-// Work item (= one output tile of one slice of one sample) decoded from a flat index; x fastest so
-// that workgroups resident at the same time touch neighbouring input.
+// Work item (= one output tile of one slice of one sample) of the v-th (block, iteration) pair,
+// v = blockIdx.x + n * gridDim.x < total.  Workgroup b runs on XCD b % 8 and each XCD has its own
+// 4 MiB L2, so the items are dealt XCD-major: XCD x owns the contiguous range [start(x), start(x+1)) and
+// the workgroups resident on it at one time walk neighbouring tiles (z fastest, then x, then y:
+// ~80-100 concurrent tiles = one z-x slab, whose halos are then shared inside that L2).  With the
+// plain v -> tile map neighbouring tiles ran on 8 different XCDs and every L2 fetched every halo:
+// PMC FETCH_SIZE of conv0 was 5x the algorithmic input bytes (profiles/r01_pmc_traffic.md).
+__device__ __forceinline__ int xcd_major(int v, int total) {  // bijection on [0, total)
+  const int xcd = v & 7, idx = v >> 3;
+  const int q = total >> 3, r = total & 7;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+}
 struct TileCoord {
   int tx0, ty0, tz0, b, slice;
 };
 template <int TZ, int TY, int TX>
-__device__ __forceinline__ TileCoord decode_tile(int item, int tiles_x, int tiles_y, int tiles_z, int B) {
+__device__ __forceinline__ TileCoord decode_tile(int v, int total, int tiles_x, int tiles_y, int tiles_z, int B) {
+  int item = xcd_major(v, total);
   TileCoord c;
+  c.tz0 = (item % tiles_z) * TZ;
+  item /= tiles_z;
   c.tx0 = (item % tiles_x) * TX;
   item /= tiles_x;
   c.ty0 = (item % tiles_y) * TY;
   item /= tiles_y;
-  c.tz0 = (item % tiles_z) * TZ;
-  item /= tiles_z;
   c.b = item % B;
   c.slice = item / B;
   return c;
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
   int tr_n = 0;
 #endif
   TRACE_STAMP();  // kernel start
-  TileCoord cur = decode_tile<TZ, TY, TX>(item, tiles_x, tiles_y, tiles_z, B);
+  TileCoord cur = decode_tile<TZ, TY, TX>(item, total, tiles_x, tiles_y, tiles_z, B);
   Stager<Cfg::DEINT ? 5 : VEC, CK, IZ, IY, IX, SC, NW> regs;
   regs.init_kernel(in_cs, Hi * Wi, Di);
   regs.init_tile(cur.tz0 * STRIDE - PZ, cur.ty0 * STRIDE - PS, cur.tx0 * STRIDE - XLO, Hi, Wi);
@@ -569,7 +580,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
             n_ci0 = 0;
             have_next = next_item < total;
             if (have_next) {
-              nxt = decode_tile<TZ, TY, TX>(next_item, tiles_x, tiles_y, tiles_z, B);
+              nxt = decode_tile<TZ, TY, TX>(next_item, total, tiles_x, tiles_y, tiles_z, B);
               regs.init_tile(nxt.tz0 * STRIDE - PZ, nxt.ty0 * STRIDE - PS, nxt.tx0 * STRIDE - XLO, Hi, Wi);
             }
           }
@@ -686,14 +697,29 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
           const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
           const rsrc_t cs = make_rsrc(skip + (size_t)cur.b * cout * hc * wc, (size_t)cout * hc * wc * 4);
           const int cbase = (cur.slice * 16 + 4 * kq) * hc * wc;
+          // the two columns x0, x1 = x0 + 1 of a row come in ONE 8-byte load (half the gather instructions,
+          // which bound this layer); at the last column x1 == x0 and the pair is (x0 - 1, x0)
+          const bool pair = wc >= 2;  // uniform
+          const int xl = x0 < wc - 1 ? x0 : wc - 2;
+          const bool last = x0 != xl;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool okr = ok && cur.slice * 16 + 4 * kq + r < cout;
             const int soff = r * hc * wc * 4;
-            const float v00 = buf_load(cs, okr ? (cbase + y0 * wc + x0) * 4 : kOOB, soff);
-            const float v01 = buf_load(cs, okr ? (cbase + y0 * wc + x1) * 4 : kOOB, soff);
-            const float v10 = buf_load(cs, okr ? (cbase + y1 * wc + x0) * 4 : kOOB, soff);
-            const float v11 = buf_load(cs, okr ? (cbase + y1 * wc + x1) * 4 : kOOB, soff);
+            float v00, v01, v10, v11;
+            if (pair) {
+              const f32x2 p0 = buf_load2(cs, okr ? (cbase + y0 * wc + xl) * 4 : kOOB, soff);
+              const f32x2 p1 = buf_load2(cs, okr ? (cbase + y1 * wc + xl) * 4 : kOOB, soff);
+              v00 = last ? p0[1] : p0[0];
+              v01 = p0[1];
+              v10 = last ? p1[1] : p1[0];
+              v11 = p1[1];
+            } else {
+              v00 = buf_load(cs, okr ? (cbase + y0 * wc + x0) * 4 : kOOB, soff);
+              v01 = buf_load(cs, okr ? (cbase + y0 * wc + x1) * 4 : kOOB, soff);
+              v10 = buf_load(cs, okr ? (cbase + y1 * wc + x0) * 4 : kOOB, soff);
+              v11 = buf_load(cs, okr ? (cbase + y1 * wc + x1) * 4 : kOOB, soff);
+            }
             float v = fmaf(av[r], sc[r % NCO], sh[r % NCO]);
             v = v > 0.0f ? v : v * slope;
             v += ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
@@ -904,7 +930,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       c.item += gridDim.x;
       c.valid = c.item < total;
       if (c.valid) {
-        c.tc = decode_tile<TZ, TY, TX>(c.item, tiles_x, tiles_y, tiles_z, B);
+        c.tc = decode_tile<TZ, TY, TX>(c.item, total, tiles_x, tiles_y, tiles_z, B);
         regs.template init_tile<S>(c.tc.tz0 - 1, c.tc.ty0 - 1, c.tc.tx0 - XLO, Hi, Wi);
       } else {
         regs.template kill_plan<S>();  // no more work: the (unconditional) loads of this set read nothing
@@ -920,7 +946,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   pf.item = blockIdx.x;
   pf.chunk = 0;
   pf.valid = true;
-  pf.tc = decode_tile<TZ, TY, TX>(pf.item, tiles_x, tiles_y, tiles_z, B);
+  pf.tc = decode_tile<TZ, TY, TX>(pf.item, total, tiles_x, tiles_y, tiles_z, B);
   regs.template init_tile<0>(pf.tc.tz0 - 1, pf.tc.ty0 - 1, pf.tc.tx0 - XLO, Hi, Wi);
   TileCoord cur = pf.tc;  // tile being computed
   int cur_chunk = 0, tiles_done = 0;
@@ -1053,7 +1079,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       if (!store_next) {
         more = false;  // no further work item: this was the last tile
       } else {
-        cur = decode_tile<TZ, TY, TX>(blockIdx.x + tiles_done * gridDim.x, tiles_x, tiles_y, tiles_z, B);
+        cur = decode_tile<TZ, TY, TX>(blockIdx.x + tiles_done * gridDim.x, total, tiles_x, tiles_y, tiles_z, B);
         load_coeffs(cur.slice);
       }
     }
@@ -1104,10 +1130,12 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jcol = lane & 15, kq = lane >> 4;
-  const int bid = blockIdx.x;
-  const int tx0 = (bid % tiles_x) * TX;
-  const int ty0 = ((bid / tiles_x) % tiles_y) * TY;
-  const int tz0 = (bid / (tiles_x * tiles_y)) * TZ;
+  // XCD-major tile order, z fastest (see decode_tile): the halos of neighbouring tiles share an L2
+  const int tiles_z = gridDim.x / (tiles_x * tiles_y);
+  const int bid = xcd_major(blockIdx.x, gridDim.x);
+  const int tz0 = (bid % tiles_z) * TZ;
+  const int tx0 = ((bid / tiles_z) % tiles_x) * TX;
+  const int ty0 = (bid / (tiles_z * tiles_x)) * TY;
   const int b = blockIdx.y, slice = blockIdx.z;
   const int slices = gridDim.z;
 
@@ -1292,10 +1320,11 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
   float *tile = smem;
   float *wts = smem + CK * SC;
   const int nstages = (cin + CK - 1) / CK;
-  const int bid = blockIdx.x;
-  const int tx0 = (bid % tiles_x) * TX;
-  const int ty0 = ((bid / tiles_x) % tiles_y) * TY;
-  const int tz0 = (bid / (tiles_x * tiles_y)) * TZ;
+  const int tiles_z = gridDim.x / (tiles_x * tiles_y);
+  const int bid = xcd_major(blockIdx.x, gridDim.x);  // XCD-major tile order, z fastest (see decode_tile)
+  const int tz0 = (bid % tiles_z) * TZ;
+  const int tx0 = ((bid / tiles_z) % tiles_x) * TX;
+  const int ty0 = (bid / (tiles_z * tiles_x)) * TY;
   const int b = blockIdx.y;
   const int xi = threadIdx.x & 7, yi = (threadIdx.x >> 3) & 7, zi = threadIdx.x >> 6;
   // (kz, ky, cil) = 0; VEC 1: the 6 inputs x-1 .. x+4 start at local 4 xi (16-byte aligned);
