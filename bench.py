@@ -70,6 +70,22 @@ def feature_flops(H, W):
     return full + half + quarter
 
 
+def pmc_traffic(kernel_prefix, batch):
+    """HBM-side bytes per launch of one kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in their own runs, tools/gpu_final.sh -> profiles/r01_final_pmc_traffic.json,
+    at batch 2): average over the kernel's launches, read bytes corrected x2 as MI355X_MICROARCH.md prescribes."""
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")
+    if batch != 2 or not os.path.isfile(path):
+        return None, "PMC passes were collected at --batch 2 on the default config only"
+    rows = [r for r in json.load(open(path)) if r["kernel"].startswith(kernel_prefix)]
+    if not rows:
+        return None, "kernel not in " + os.path.relpath(path, ROOT)
+    n = sum(r["launches"] for r in rows)
+    mb = sum((r["read_mb_corrected"] + r["write_mb"]) * r["launches"] for r in rows) / n
+    return mb * 1e6, ("bytes per launch (read + write, mean over the 3 cascade levels) from profiles/r01_final_pmc_traffic.json; "
+                      "algorithmic bytes of the same launches: 384e6")
+
+
 def cpu_baseline(cfg_name, repeats=3):
     """Oracle (CPU port of the reference forward) on the same synthetic workload, host cores."""
     from oracle import cpu_restatement as R
@@ -178,9 +194,10 @@ def main():
             conv0_ms = sum(summ[f"costreg_{l}/conv0"]["ms"] for l in range(3))
             conv0_flops = sum(work[l]["conv0_flops"] for l in range(3)) * K
             ach = conv0_flops / (conv0_ms * 1e-3) / 1e12
-            line["roofline"] = {"kernel": "conv3d_kernel<stride 1, Cout 8> (CostRegNet.conv0, 3 launches per depth map)",
+            traffic, traffic_note = pmc_traffic("conv16db_kernel<2,", B if args.config == "dtu_640x512_v3_var" else None)
+            line["roofline"] = {"kernel": "conv16db_kernel<PX> (CostRegNet.conv0: Cout 8, stride 1; 3 launches per step)",
                                 "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                                "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                                 "avg_launch_ms": conv0_ms / (3 * K)}
             cr_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("costreg_"))
             cr_flops = sum(work[l]["costreg_flops"] for l in range(3)) * K
