@@ -1771,7 +1771,7 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
     const long wide_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 4) * c.slices * B;
     static const int db_ci = getenv("CASMVS_DB_CI") ? atoi(getenv("CASMVS_DB_CI")) : 3;  // A/B switch (profiling); default: double-buffered
     const bool al = W % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
-    if (wide_blocks >= 512) {
+    if (wide_blocks >= 512 && D >= 3) {  // the wide tile is 4 deep: with D <= 2 half of every tile would be padding
       if ((db_ci & 1) && al) return launch_conv16db<FMT_CI, 4, 4, 4, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
       return launch_conv16<FMT_CI, 1, 8, 8, 4, 8, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
     }

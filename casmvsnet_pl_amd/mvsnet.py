@@ -220,6 +220,18 @@ class CascadeMVSNet(nn.Module):
         self.timer = None        # optional profiling.StageTimer: HIP events around every stage
         self.last_index = {}     # level -> (B,h,w) int32 depth index, filled when keep_index is set
         self.keep_index = False
+        self._const_cache = {}
+
+    def _const(self, value, B, device):
+        """(B,) device vector filled with a python float, cached: the per-level depth ranges of a scene are
+        the same call after call and a `torch.full` is a 5 us kernel launch."""
+        key = (float(value), B, str(device))
+        t = self._const_cache.get(key)
+        if t is None:
+            if len(self._const_cache) > 64:
+                self._const_cache.clear()
+            t = self._const_cache[key] = _per_sample(value, B, device)
+        return t
 
     def set_timer(self, timer):
         self.timer = timer
@@ -259,7 +271,7 @@ class CascadeMVSNet(nn.Module):
         dev = imgs.device
         results = {}
         imgs = imgs.reshape(B * V, 3, H, W).float()
-        proj_mats = proj_mats.float()
+        proj_mats = proj_mats.float().permute(2, 0, 1, 3, 4).contiguous()  # (levels, B, V-1, 3, 4): one copy, not one per level
         t = self.timer
         with torch.no_grad():
             with stage(t, "feature"):
@@ -269,7 +281,7 @@ class CascadeMVSNet(nn.Module):
                 feats_l = feats[f"level_{l}"]
                 C, h, w = feats_l.shape[1:]
                 feats_l = feats_l.reshape(B, V, C, h, w)
-                proj_mats_l = proj_mats[:, :, l].contiguous()
+                proj_mats_l = proj_mats[l]
                 D = self.n_depths[l]
                 ratio = self.interval_ratios[l]
                 if isinstance(depth_interval, torch.Tensor):
@@ -277,12 +289,13 @@ class CascadeMVSNet(nn.Module):
                     half_b = (D / 2) * interval_b                                          # modules.py:44
                 else:
                     depth_interval_l = depth_interval * ratio
-                    interval_b = _per_sample(depth_interval_l, B, dev)
-                    half_b = _per_sample(D / 2 * depth_interval_l, B, dev)
+                    interval_b = self._const(depth_interval_l, B, dev)
+                    half_b = self._const(D / 2 * depth_interval_l, B, dev)
                 with stage(t, f"hypotheses_{l}"):
                     if l == self.levels - 1:
-                        depth_values = ops.depth_hypotheses(None, _per_sample(init_depth_min, B, dev), interval_b,
-                                                            None, D, h, w)
+                        dmin_b = (_per_sample(init_depth_min, B, dev) if isinstance(init_depth_min, torch.Tensor)
+                                  else self._const(init_depth_min, B, dev))
+                        depth_values = ops.depth_hypotheses(None, dmin_b, interval_b, None, D, h, w)
                     else:
                         depth_values = ops.depth_hypotheses(depth_l, None, interval_b, half_b, D, h, w)
                 cl = self.feature.last_channels_last[f"level_{l}"].view(B, V, h, w, C)
