@@ -249,8 +249,8 @@ __device__ __forceinline__ float lane_bcast_f(int src_lane, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
 }
 
-template <int C, int MODE>
-__global__ __launch_bounds__(kThreads) void costvol_nhwc_kernel(
+template <int C, int MODE, int OCC = 1>  // OCC: minimum waves per SIMD the register allocation must allow
+__global__ __launch_bounds__(kThreads, OCC) void costvol_nhwc_kernel(
     const float *__restrict__ feats, const float *__restrict__ proj,
     const float *__restrict__ depth, float *__restrict__ out, int V, int G, int h, int w, int D,
     int tiles, int tiles_per_xcd) {
@@ -487,13 +487,13 @@ extern "C" int casmvs_costvol_var_nhwc_f32(const float *feats, const float *proj
   Grid g = make_grid(B, h * w, D, 1);
   dim3 blk(kThreads);
   hipStream_t st = (hipStream_t)stream;
-  if (C == 32)
-    hipLaunchKernelGGL((costvol_nhwc_kernel<32, 0>), g.grid, blk, 0, st, feats, proj, depth, out, V, 1, h, w, D, g.tiles, g.tiles_per_xcd);
-  else if (C == 16)
-    hipLaunchKernelGGL((costvol_nhwc_kernel<16, 0>), g.grid, blk, 0, st, feats, proj, depth, out, V, 1, h, w, D, g.tiles, g.tiles_per_xcd);
-  else if (C == 8)
-    hipLaunchKernelGGL((costvol_nhwc_kernel<8, 0>), g.grid, blk, 0, st, feats, proj, depth, out, V, 1, h, w, D, g.tiles, g.tiles_per_xcd);
+  // register budget (minimum waves per SIMD) A/B-tested per channel count: default / 6 / 8
+#define CASMVS_CV(CC, OO) hipLaunchKernelGGL((costvol_nhwc_kernel<CC, 0, OO>), g.grid, blk, 0, st, feats, proj, depth, out, V, 1, h, w, D, g.tiles, g.tiles_per_xcd)
+  if (C == 32) CASMVS_CV(32, 1);
+  else if (C == 16) CASMVS_CV(16, 6);
+  else if (C == 8) CASMVS_CV(8, 8);
   else
+#undef CASMVS_CV
     return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_var_nhwc: C=%d (need 8, 16 or 32)", C);
   return casmvs::check_launch("costvol_var_nhwc_kernel");
 }
