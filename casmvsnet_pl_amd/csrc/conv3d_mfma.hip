@@ -1420,6 +1420,87 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
   }
 }
 
+// ---- FPN top-down step: 1x1 lateral conv + bilinear x2 upsample-add (mvsnet.py:36-38, 49-50) -----------
+// out = (conv1x1(x) * scale + shift) + upsample2x(up), align_corners = True.  The MFMA form of this layer
+// (conv16_kernel<..., KS = 1, UPS = 1>) spends its time in the epilogue's per-element gathers: measured 172 us
+// for lat0 at batch 2 against ~75 us of HBM time.  Here a thread owns 4 consecutive x of one row and walks
+// the output channels: the 8 / 16 input channels of its 4 pixels stay in registers, the 4-column source
+// window of the coarser map comes as one 16-byte load per row, the horizontal interpolation is a 4 x 4
+// "tent" weight matrix computed once per thread (zeros for the columns a pixel does not use: adding exact
+// zeros keeps ATen's lambda0 * v0 + lambda1 * v1), and every store is 16 bytes, 1 KiB contiguous per wave.
+typedef float f32x4u4 __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int CIN>
+__global__ __launch_bounds__(kThreads) void fpn_lateral_kernel(
+    const float *__restrict__ x, const float *__restrict__ wpk, const float *__restrict__ up,
+    float *__restrict__ out, int cout, int H, int W, int units, int slices) {
+  extern __shared__ float smem[];
+  float *wl = smem;               // [cout][CIN]
+  float *sc = smem + cout * CIN;  // [cout] scale, then [cout] shift
+  for (int e = threadIdx.x; e < cout * CIN; e += kThreads) {
+    const int co = e / CIN, ci = e - co * CIN;  // CI-form image: lane = (ci % 4) * 16 + co % 16 of unit ci / 4, slice co / 16
+    wl[e] = wpk[((size_t)(co >> 4) * units + (ci >> 2)) * 64 + (ci & 3) * 16 + (co & 15)];
+  }
+  const float *tail = wpk + (size_t)slices * units * 64;
+  for (int e = threadIdx.x; e < cout; e += kThreads) {
+    sc[e] = tail[e];
+    sc[cout + e] = tail[slices * 16 + e];
+  }
+  __syncthreads();
+  const int n = blockIdx.y;
+  const int wq = W >> 2;
+  const int q = blockIdx.x * kThreads + threadIdx.x;
+  if (q >= H * wq) return;
+  const int y = q / wq, ox = (q - y * wq) * 4;
+  f32x4 c[CIN];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci)
+    c[ci] = *reinterpret_cast<const f32x4 *>(x + (((size_t)n * CIN + ci) * H + y) * W + ox);
+  // ATen upsample_bilinear2d, align_corners: src = dst * (in - 1) / (out - 1)
+  const int hc = H >> 1, wc = W >> 1;
+  const float sy = H > 1 ? (float)(hc - 1) / (float)(H - 1) : 0.0f;
+  const float sx = W > 1 ? (float)(wc - 1) / (float)(W - 1) : 0.0f;
+  const float fy = sy * (float)y;
+  const int y0 = (int)fy, y1 = y0 + (y0 < hc - 1 ? 1 : 0);
+  const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+  int xb = 0;
+  float T[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float fx = sx * (float)(ox + k);
+    const int x0 = (int)fx, x1 = x0 + (x0 < wc - 1 ? 1 : 0);
+    const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+    if (k == 0) xb = x0 < wc - 4 ? x0 : wc - 4;  // 4-column window [xb, xb + 4) holds every column the 4 pixels use
+#pragma unroll
+    for (int m = 0; m < 4; ++m) T[k][m] = (m == x0 - xb ? lx0 : 0.0f) + (m == x1 - xb ? lx1 : 0.0f);
+  }
+  const float *u0 = up + ((size_t)n * cout * hc + y0) * wc + xb;
+  const float *u1 = up + ((size_t)n * cout * hc + y1) * wc + xb;
+  float *op = out + ((size_t)n * cout * H + y) * W + ox;
+#pragma unroll 2
+  for (int co = 0; co < cout; ++co) {
+    const f32x4 r0 = *reinterpret_cast<const f32x4u4 *>(u0 + (size_t)co * hc * wc);
+    const f32x4 r1 = *reinterpret_cast<const f32x4u4 *>(u1 + (size_t)co * hc * wc);
+    const float *wr = wl + co * CIN;
+    f32x4 a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float wv = wr[ci];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = fmaf(c[ci][k], wv, a[k]);
+    }
+    const float scale = sc[co], shift = sc[cout + co];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float h0 = fmaf(T[k][3], r0[3], fmaf(T[k][2], r0[2], fmaf(T[k][1], r0[1], T[k][0] * r0[0])));
+      const float h1 = fmaf(T[k][3], r1[3], fmaf(T[k][2], r1[2], fmaf(T[k][1], r1[1], T[k][0] * r1[0])));
+      o[k] = fmaf(a[k], scale, shift) + (ly0 * h0 + ly1 * h1);
+    }
+    *reinterpret_cast<f32x4 *>(op + (size_t)co * H * W) = o;
+  }
+}
+
 // ---- MFMA probes ----------------------------------------------------------------------------------
 // Lane-mapping probe: D = A * B for A[i][k] = 1 + i + 16 k, B[k][j] = (1 + k) * (3 + j) on 16x16x4
 // (dump rows 0..3 = the 4 accumulator registers), then the 4x4x1 broadcast form with ABID 0/5/15.
@@ -1824,9 +1905,21 @@ int conv2d_forward(int kind, const float *packed, const float *in, const float *
     case CASMVS_CONV2D_K1:
       if (out2) return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 1, 0, 1>(c, packed, in, out2, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
       return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 1>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
-    default:
+    default: {
       CASMVS_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv2d_forward(K1_UP): odd dims %dx%d", H, W);
+      static const bool no_fpn = getenv("CASMVS_NO_FPN_KERNEL") != nullptr;  // A/B switch (profiling)
+      const bool al = ((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out)) & 15) == 0;
+      if (!no_fpn && slope == 1.0f && (cin == 8 || cin == 16) && cout <= 64 && W % 4 == 0 && W >= 8 && al && N <= 65535) {
+        const size_t lds = (size_t)cout * (cin + 2) * sizeof(float);
+        dim3 grid((unsigned)casmvs::ceil_div(H * (W / 4), kThreads), (unsigned)N);
+        if (cin == 8)
+          hipLaunchKernelGGL(fpn_lateral_kernel<8>, grid, dim3(kThreads), lds, st, in, packed, up, out, cout, H, W, c.units, c.slices);
+        else
+          hipLaunchKernelGGL(fpn_lateral_kernel<16>, grid, dim3(kThreads), lds, st, in, packed, up, out, cout, H, W, c.units, c.slices);
+        return casmvs::check_launch("fpn_lateral_kernel");
+      }
       return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 1, 1>(c, packed, in, up, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
+    }
   }
 }
 }  // namespace
