@@ -766,16 +766,18 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
 //   * the whole chunk loop is one flattened, fully unrolled sequence (all LDS offsets immediates,
 //     no loop-carried register copies), instantiated once per buffer parity.
 // VEC = 4 staging only (Wi % 4 == 0).
-template <int MODE, int CK, int NT, int TZ, int TY, int TX>
-struct Conv16DbCfg : Conv16Cfg<MODE, 1, CK, NT, TZ, TY, TX, 4> {
-  using Base = Conv16Cfg<MODE, 1, CK, NT, TZ, TY, TX, 4>;
+template <int MODE, int CK, int NT, int TZ, int TY, int TX, int STRIDE = 1>
+struct Conv16DbCfg : Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, 4> {
+  using Base = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, 4>;
   static constexpr int BUF = CK * Base::SC + Base::NW;  // floats per buffer
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(float);
 };
 
 // Staging registers of the double-buffered kernel: like Stager<4>, but every address is a
 // precomputed register so that a load / store operation is exactly one memory instruction.
-template <int CK, int IZ, int IY, int IXR, int SC, int NW>
+// DEINT (stride-2 layers): rows are stored [even columns | odd columns] (see Stager<5>): a staged 16-byte
+// group becomes two 8-byte LDS writes.
+template <int CK, int IZ, int IY, int IXR, int SC, int NW, bool DEINT = false>
 struct DbStager {
   static_assert(IXR % 4 == 0 && SC % 4 == 0 && NW % 4 == 0, "16-byte groups");
   static constexpr int ROWV = IXR / 4, PLV = IY * ROWV, TOTV = CK * IZ * PLV;
@@ -806,7 +808,7 @@ struct DbStager {
       const int c = pl / IZ, iz = pl - c * IZ, iy = r / ROWV, xv = r - iy * ROWV;
       cil[k] = c;
       t_ok[k] = e < TOTV;
-      lds_t[k] = tile0 + (e < TOTV ? c * SC + iz * (IY * IXR) + iy * IXR + 4 * xv : 0);
+      lds_t[k] = tile0 + (e < TOTV ? c * SC + iz * (IY * IXR) + iy * IXR + (DEINT ? 2 : 4) * xv : 0);
     }
 #pragma unroll
     for (int i = 0; i < NWR; ++i) {
@@ -857,22 +859,31 @@ struct DbStager {
       if (w_ok[J]) *reinterpret_cast<f32x4v *>(lds_w[J] + BUFOFF) = w[S][J];
     } else {
       constexpr int k = J - NWR;
-      if (t_ok[k]) *reinterpret_cast<f32x4v *>(lds_t[k] + BUFOFF) = v[S][k];
+      if constexpr (DEINT) {
+        if (t_ok[k]) {
+          *reinterpret_cast<f32x2 *>(lds_t[k] + BUFOFF) = f32x2{v[S][k][0], v[S][k][2]};            // columns 4 xv, + 2
+          *reinterpret_cast<f32x2 *>(lds_t[k] + BUFOFF + IXR / 2) = f32x2{v[S][k][1], v[S][k][3]};  // columns 4 xv + 1, + 3
+        }
+      } else {
+        if (t_ok[k]) *reinterpret_cast<f32x4v *>(lds_t[k] + BUFOFF) = v[S][k];
+      }
     }
   }
 };
 
-template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+template <int MODE, int CK, int NT, int TZ, int TY, int TX, int STRIDE = 1>
 __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int B, int cin, int cout, int Di, int Hi, int Wi, int per_slice, int slices,
     int tiles_x, int tiles_y, int tiles_z, float slope) {
-  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX>;
+  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX, STRIDE>;
+  static_assert(STRIDE == 1 || (STRIDE == 2 && MODE == FMT_CI), "stride 2: CI form only");
+  constexpr bool DEINT = Cfg::DEINT;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
   constexpr int NA = Cfg::NA, NITER = Cfg::NITER, ASTEP = Cfg::ASTEP, NW = Cfg::NW, NXG = Cfg::NXG;
   constexpr int XLO = Cfg::XLO, XOFF = Cfg::XOFF, BUF = Cfg::BUF;
   constexpr int COUTB = MODE == FMT_PX ? 8 : 16;
-  const int Do = Di, Ho = Hi, Wo = Wi;
+  const int Do = Di / STRIDE, Ho = Hi / STRIDE, Wo = Wi / STRIDE;
   const int nstages = (cin + CK - 1) / CK;
   extern __shared__ float smem[];
 
@@ -888,6 +899,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
     const int ct = wave * NT + t;
     const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
     if (MODE == FMT_PX) bptr[t] = smem + cz * SZ + cy * SY + cx * 32 + 2 * jcol + kq + XOFF;
+    else if (DEINT) bptr[t] = smem + kq * SC + (cz * 2) * SZ + (cy * 2) * SY + cx * 16 + jcol;  // parity halves: unit stride
     else bptr[t] = smem + kq * SC + cz * SZ + cy * SY + cx * 16 + jcol + XOFF;
   }
   const float *aptr = smem + CK * SC + lane;
@@ -895,24 +907,35 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int in_cs = Di * Hi * Wi, out_cs = in_cs;
+  const int in_cs = Di * Hi * Wi, out_cs = Do * Ho * Wo;
   const size_t in_ss = (size_t)cin * in_cs, out_ss = (size_t)cout * out_cs;
   const float *tail = wpk + (size_t)slices * per_slice;
   const rsrc_t wsrc = make_rsrc(wpk, ((size_t)slices * per_slice) * 4);
 
   constexpr int NS = NA * NT;
-  constexpr int P = NS % 8 == 0 ? 8 : (NS % 4 == 0 ? 4 : NS);
-  static_assert(NS % P == 0, "ring slots must line up across iterations");
   constexpr auto it_off = [](int it) constexpr -> int {
+    if (DEINT) {  // see conv16_kernel: tap kx of output j reads column 2 j + kx + 3 of the row
+      const int kx = it % 3;
+      return (it / 9) * SZ + ((it / 3) % 3) * SY + (kx == 1 ? 2 : IX / 2 + (kx == 0 ? 1 : 2));
+    }
     return MODE == FMT_PX ? (it / 3) * SZ + (it % 3) * SY : (it / 9) * SZ + ((it / 3) % 3) * SY + (it % 3);
   };
-  using St = DbStager<CK, IZ, IY, IX, SC, NW>;
+  using St = DbStager<CK, IZ, IY, IX, SC, NW, DEINT>;
   constexpr int NOPS = St::NOPS;
   // side-work schedule of work item w (register set / LDS buffer parity PAR = w & 1):
   //   steps 1 .. NOPS        : load op j of item w + 2  -> register set PAR (free since item w - 1)
   //   steps ST0 + j * SST     : store op j of item w + 1 (set 1 - PAR, loaded during item w - 1)
   //                             -> LDS buffer 1 - PAR
   constexpr int TOTAL_STEPS = NITER * NS;
+  // B-operand ring: the ds_read of step g + P is issued right before the MFMA of step g.  The loop is
+  // flattened, so the look-ahead may span iterations: the small tiles (NS = 1, 2) get 8 steps too.
+  // (NS = 4 keeps P = 4: 8 measured no faster and costs the wide CI tile a wave of occupancy.)
+  constexpr int P = NS % 8 == 0 ? 8 : (NS % 4 == 0 ? 4 : (TOTAL_STEPS >= 16 ? 8 : 2));
+  constexpr auto b_tile = [](int g) constexpr -> int { return ((g < TOTAL_STEPS ? g : TOTAL_STEPS - 1) % NS) % NT; };
+  constexpr auto b_off = [it_off](int g) constexpr -> int {
+    const int gg = g < TOTAL_STEPS ? g : TOTAL_STEPS - 1;  // beyond the chunk: harmless re-read of the last operand
+    return it_off(gg / NS) + ((gg % NS) / NT) * ASTEP;
+  };
   static_assert(2 * NOPS + 4 <= TOTAL_STEPS, "not enough MFMA steps to hide the staging operations");
   constexpr int ST0 = NOPS + 2, SST = (TOTAL_STEPS - ST0 - 1) / NOPS;
 
@@ -931,7 +954,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       c.valid = c.item < total;
       if (c.valid) {
         c.tc = decode_tile<TZ, TY, TX>(c.item, total, tiles_x, tiles_y, tiles_z, B);
-        regs.template init_tile<S>(c.tc.tz0 - 1, c.tc.ty0 - 1, c.tc.tx0 - XLO, Hi, Wi);
+        regs.template init_tile<S>(c.tc.tz0 * STRIDE - 1, c.tc.ty0 * STRIDE - 1, c.tc.tx0 * STRIDE - XLO, Hi, Wi);
       } else {
         regs.template kill_plan<S>();  // no more work: the (unconditional) loads of this set read nothing
       }
@@ -947,7 +970,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   pf.chunk = 0;
   pf.valid = true;
   pf.tc = decode_tile<TZ, TY, TX>(pf.item, total, tiles_x, tiles_y, tiles_z, B);
-  regs.template init_tile<0>(pf.tc.tz0 - 1, pf.tc.ty0 - 1, pf.tc.tx0 - XLO, Hi, Wi);
+  regs.template init_tile<0>(pf.tc.tz0 * STRIDE - 1, pf.tc.ty0 * STRIDE - 1, pf.tc.tx0 * STRIDE - XLO, Hi, Wi);
   TileCoord cur = pf.tc;  // tile being computed
   int cur_chunk = 0, tiles_done = 0;
   // prologue: work item 0 -> set 0 -> buffer 0; work item 1 -> set 1 (in flight)
@@ -999,8 +1022,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
 #pragma unroll
     for (int a = 0; a < NA; ++a) a_cur[a] = aptr[RD + (a * NITER) * 64];
     float ring[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) ring[i] = bptr[i % NT][RD + (i / NT) * ASTEP];
+    static_for<P>([&](auto i_) {
+      constexpr int i = decltype(i_)::value;
+      ring[i] = bptr[b_tile(i)][RD + b_off(i)];
+    });
     // one flattened, fully unrolled loop over the NITER * NS steps: every index and every LDS
     // offset below is a compile-time constant
     static_for<TOTAL_STEPS>([&](auto g_) {
@@ -1012,10 +1037,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
 #pragma unroll
         for (int aa = 0; aa < NA; ++aa) a_nxt[aa] = aptr[RD + (aa * NITER + itn) * 64];
       }
-      const float bcur = ring[i % P];
-      constexpr int ii = i + P;
-      if constexpr (ii < NS) ring[i % P] = bptr[ii % NT][RD + it_off(it) + (ii / NT) * ASTEP];
-      else ring[i % P] = bptr[(ii - NS) % NT][RD + it_off(itn) + ((ii - NS) / NT) * ASTEP];
+      const float bcur = ring[g % P];
+      ring[g % P] = bptr[b_tile(g + P)][RD + b_off(g + P)];
       acc[t] = mfma16(a_cur[a], bcur, acc[t]);
       // ---- side work in this step's spare issue slots ----
       // (issued unconditionally - a dead set loads with out-of-range offsets and its stores land in
@@ -1675,13 +1698,15 @@ int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, con
   return casmvs::check_launch("conv16_kernel");
 }
 
-template <int MODE, int CK, int NT, int TZ, int TY, int TX>
+template <int MODE, int CK, int NT, int TZ, int TY, int TX, int STRIDE = 1>
 int launch_conv16db(const LayerCfg &c, const float *packed, const float *in, const float *skip, float *out,
                     int B, int cin, int cout, int D, int H, int W, float slope, hipStream_t st) {
-  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX>;
-  auto kernel = conv16db_kernel<MODE, CK, NT, TZ, TY, TX>;
+  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX, STRIDE>;
+  auto kernel = conv16db_kernel<MODE, CK, NT, TZ, TY, TX, STRIDE>;
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv16db_kernel")) return rc;
-  const int tiles_x = casmvs::ceil_div(W, TX), tiles_y = casmvs::ceil_div(H, TY), tiles_z = casmvs::ceil_div(D, TZ);
+  // D, H, W are the INPUT dims; tiles cover the output
+  const int tiles_x = casmvs::ceil_div(W / STRIDE, TX), tiles_y = casmvs::ceil_div(H / STRIDE, TY),
+            tiles_z = casmvs::ceil_div(D / STRIDE, TZ);
   const long total = (long)tiles_x * tiles_y * tiles_z * B * c.slices;
   CASMVS_REQUIRE(total < (1L << 31), "conv3d_forward: too many tiles");
   const int resident = resident_blocks(kernel, Cfg::LDS_BYTES);
@@ -1864,6 +1889,10 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
     const long wide_blocks = (long)casmvs::ceil_div(W / 2, 16) * casmvs::ceil_div(H / 2, 8) * casmvs::ceil_div(D / 2, 2) * c.slices * B;
     // wide tile (2, 4, 16), 2 column tiles per wave: A/B-tested against (2, 8, 16) x 4, (1, 8, 16) with CK = 8 and
     // (1, 16, 16) x 4 - the small tile wins by 7 % (5 resident workgroups per CU instead of 3)
+    static const int db_s2 = getenv("CASMVS_DB_S2") ? atoi(getenv("CASMVS_DB_S2")) : 3;  // A/B switch (profiling); default: double-buffered form
+    const bool al2 = W % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
+    if (wide_blocks >= 512 && (db_s2 & 1) && al2) return launch_conv16db<FMT_CI, 4, 2, 2, 4, 16, 2>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+    if (wide_blocks < 512 && (db_s2 & 2) && al2) return launch_conv16db<FMT_CI, 4, 1, 1, 4, 16, 2>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
     if (wide_blocks >= 512) return launch_conv16<FMT_CI, 2, 4, 2, 2, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
     return launch_conv16<FMT_CI, 2, 8, 1, 1, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
   }
