@@ -766,9 +766,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv16_kernel(
 //   * the whole chunk loop is one flattened, fully unrolled sequence (all LDS offsets immediates,
 //     no loop-carried register copies), instantiated once per buffer parity.
 // VEC = 4 staging only (Wi % 4 == 0).
-template <int MODE, int CK, int NT, int TZ, int TY, int TX, int STRIDE = 1>
-struct Conv16DbCfg : Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, 4> {
-  using Base = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, 4>;
+template <int MODE, int CK, int NT, int TZ, int TY, int TX, int STRIDE = 1, int KZ = 3>
+struct Conv16DbCfg : Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, 4, KZ, 3> {
+  using Base = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, 4, KZ, 3>;
   static constexpr int BUF = CK * Base::SC + Base::NW;  // floats per buffer
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF * sizeof(float);
 };
@@ -871,12 +871,15 @@ struct DbStager {
   }
 };
 
-template <int MODE, int CK, int NT, int TZ, int TY, int TX, int STRIDE = 1>
+// KZ = 1 (TZ = 1, D = 1): the 3x3 2D layers of FeatureNet; OUT2 = 1: `skip` is a second, pixel-major output
+// (as in conv16_kernel).
+template <int MODE, int CK, int NT, int TZ, int TY, int TX, int STRIDE = 1, int KZ = 3, int OUT2 = 0>
 __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
     const float *__restrict__ in, const float *__restrict__ wpk, const float *__restrict__ skip,
     float *__restrict__ out, int B, int cin, int cout, int Di, int Hi, int Wi, int per_slice, int slices,
     int tiles_x, int tiles_y, int tiles_z, float slope) {
-  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX, STRIDE>;
+  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX, STRIDE, KZ>;
+  constexpr int PZ = Cfg::PZ;
   static_assert(STRIDE == 1 || (STRIDE == 2 && MODE == FMT_CI), "stride 2: CI form only");
   constexpr bool DEINT = Cfg::DEINT;
   constexpr int IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC;
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       c.valid = c.item < total;
       if (c.valid) {
         c.tc = decode_tile<TZ, TY, TX>(c.item, total, tiles_x, tiles_y, tiles_z, B);
-        regs.template init_tile<S>(c.tc.tz0 * STRIDE - 1, c.tc.ty0 * STRIDE - 1, c.tc.tx0 * STRIDE - XLO, Hi, Wi);
+        regs.template init_tile<S>(c.tc.tz0 * STRIDE - PZ, c.tc.ty0 * STRIDE - 1, c.tc.tx0 * STRIDE - XLO, Hi, Wi);
       } else {
         regs.template kill_plan<S>();  // no more work: the (unconditional) loads of this set read nothing
       }
@@ -970,7 +973,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   pf.chunk = 0;
   pf.valid = true;
   pf.tc = decode_tile<TZ, TY, TX>(pf.item, total, tiles_x, tiles_y, tiles_z, B);
-  regs.template init_tile<0>(pf.tc.tz0 * STRIDE - 1, pf.tc.ty0 * STRIDE - 1, pf.tc.tx0 * STRIDE - XLO, Hi, Wi);
+  regs.template init_tile<0>(pf.tc.tz0 * STRIDE - PZ, pf.tc.ty0 * STRIDE - 1, pf.tc.tx0 * STRIDE - XLO, Hi, Wi);
   TileCoord cur = pf.tc;  // tile being computed
   int cur_chunk = 0, tiles_done = 0;
   // prologue: work item 0 -> set 0 -> buffer 0; work item 1 -> set 1 (in flight)
@@ -1057,7 +1060,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
     bool more = true;
     if (++cur_chunk == nstages) {  // tile finished: epilogue, then switch to the next tile
       const rsrc_t dst = make_rsrc(out + cur.b * out_ss, out_ss * 4);
-      const rsrc_t skp = make_rsrc(skip ? skip + cur.b * out_ss : out, out_ss * 4);
+      const rsrc_t skp = make_rsrc((skip && !OUT2) ? skip + cur.b * out_ss : out, out_ss * 4);
+      [[maybe_unused]] const rsrc_t d2 = make_rsrc(OUT2 ? const_cast<float *>(skip) + cur.b * out_ss : out, out_ss * 4);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int ct = wave * NT + t;
@@ -1069,6 +1073,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
           const int ox = cur.tx0 + cx * 32 + 2 * jcol;
           const bool ok = oz < Do && oy < Ho && ox < Wo;  // Wo % 4 == 0 here: the pair is in range
           const int voff = ok ? (2 * kq * out_cs + (oz * Ho + oy) * Wo + ox) * 4 : kOOB;
+          [[maybe_unused]] float o2[2][2];  // [x phase][channel 2*kq + h]
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             float v0 = fmaf(av[2 * h], sc[h % NCO], sh[h % NCO]);
@@ -1076,25 +1081,38 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
             v0 = v0 > 0.0f ? v0 : v0 * slope;
             v1 = v1 > 0.0f ? v1 : v1 * slope;
             const int soff = h * out_cs * 4;
-            if (skip) {
+            if constexpr (OUT2) {
+              o2[0][h] = v0;
+              o2[1][h] = v1;
+            } else if (skip) {
               const f32x2 sk = buf_load2(skp, voff, soff);
               v0 += sk[0];
               v1 += sk[1];
             }
             buf_store2(f32x2{v0, v1}, dst, voff, soff);
           }
+          if constexpr (OUT2) {  // pixel-major copy: channels (2 kq, 2 kq + 1) of pixels ox, ox + 1
+            const int pbase = (((oz * Ho + oy) * Wo + ox) * cout + 2 * kq) * 4;
+            buf_store2(f32x2{o2[0][0], o2[0][1]}, d2, ok ? pbase : kOOB, 0);
+            buf_store2(f32x2{o2[1][0], o2[1][1]}, d2, ok ? pbase + cout * 4 : kOOB, 0);
+          }
         } else {
           const int ox = cur.tx0 + cx * 16 + jcol;
           const bool ok = oz < Do && oy < Ho && ox < Wo;
           const int vbase = ((cur.slice * 16 + 4 * kq) * out_cs + (oz * Ho + oy) * Wo + ox) * 4;
+          [[maybe_unused]] f32x4 o4;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int voff = (ok && cur.slice * 16 + 4 * kq + r < cout) ? vbase : kOOB;
             float v = fmaf(av[r], sc[r % NCO], sh[r % NCO]);
             v = v > 0.0f ? v : v * slope;
-            if (skip) v += buf_load(skp, voff, r * out_cs * 4);
+            if constexpr (OUT2) o4[r] = v;
+            else if (skip) v += buf_load(skp, voff, r * out_cs * 4);
             buf_store(v, dst, voff, r * out_cs * 4);
           }
+          if constexpr (OUT2)  // pixel-major copy: this lane's 4 consecutive channels in one store (cout % 16 == 0)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), d2,
+                ok ? (((oz * Ho + oy) * Wo + ox) * cout + cur.slice * 16 + 4 * kq) * 4 : kOOB, 0, 0);
         }
       }
       cur_chunk = 0;
@@ -1698,11 +1716,11 @@ int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, con
   return casmvs::check_launch("conv16_kernel");
 }
 
-template <int MODE, int CK, int NT, int TZ, int TY, int TX, int STRIDE = 1>
+template <int MODE, int CK, int NT, int TZ, int TY, int TX, int STRIDE = 1, int KZ = 3, int OUT2 = 0>
 int launch_conv16db(const LayerCfg &c, const float *packed, const float *in, const float *skip, float *out,
                     int B, int cin, int cout, int D, int H, int W, float slope, hipStream_t st) {
-  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX, STRIDE>;
-  auto kernel = conv16db_kernel<MODE, CK, NT, TZ, TY, TX, STRIDE>;
+  using Cfg = Conv16DbCfg<MODE, CK, NT, TZ, TY, TX, STRIDE, KZ>;
+  auto kernel = conv16db_kernel<MODE, CK, NT, TZ, TY, TX, STRIDE, KZ, OUT2>;
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv16db_kernel")) return rc;
   // D, H, W are the INPUT dims; tiles cover the output
   const int tiles_x = casmvs::ceil_div(W / STRIDE, TX), tiles_y = casmvs::ceil_div(H / STRIDE, TY),
@@ -1921,13 +1939,27 @@ int conv2d_forward(int kind, const float *packed, const float *in, const float *
   CASMVS_REQUIRE(!out2 || (reinterpret_cast<size_t>(out2) & 15) == 0, "conv2d_forward: out2 must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   switch (kind) {
-    case CASMVS_CONV2D_K3:
+    case CASMVS_CONV2D_K3: {
+      // double-buffered kernel (16-byte staging: W % 4 == 0, aligned); otherwise the single-buffer one below
+      // A/B-tested (3 repeats on one box): the Cout = 8 (PX) layers gain 11 % (smooth0 132 -> 117 us), the CI layers
+      // nothing -> default 1 (bit 0 = PX layers, bit 1 = CI layers)
+      static const int db2d = getenv("CASMVS_DB_2D") ? atoi(getenv("CASMVS_DB_2D")) : 1;
+      const bool al = W % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
+      if (al && (db2d & 1) && c.fmt == FMT_PX) {
+        if (out2) return launch_conv16db<FMT_PX, 4, 4, 1, 8, 64, 1, 1, 1>(c, packed, in, out2, out, N, cin, cout, 1, H, W, slope, st);
+        return launch_conv16db<FMT_PX, 4, 4, 1, 8, 64, 1, 1, 0>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, slope, st);
+      }
+      if (al && (db2d & 2) && c.fmt == FMT_CI) {
+        if (out2) return launch_conv16db<FMT_CI, 8, 4, 1, 8, 32, 1, 1, 1>(c, packed, in, out2, out, N, cin, cout, 1, H, W, slope, st);
+        return launch_conv16db<FMT_CI, 8, 4, 1, 8, 32, 1, 1, 0>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, slope, st);
+      }
       if (c.fmt == FMT_PX) {
         if (out2) return launch_conv16_v<FMT_PX, 1, 4, 4, 1, 8, 64, 1, 1, 3, 0, 1>(c, packed, in, out2, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
         return launch_conv16_v<FMT_PX, 1, 4, 4, 1, 8, 64, 1, 1, 3>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
       }
       if (out2) return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 3, 0, 1>(c, packed, in, out2, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
       return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 3>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
+    }
     case CASMVS_CONV2D_K5S2:
       CASMVS_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv2d_forward(K5S2): odd input dims %dx%d", H, W);
       return launch_conv16_v<FMT_CI, 2, 4, 4, 1, 8, 32, 1, 1, 5>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H / 2, W / 2, slope, st);
