@@ -194,7 +194,7 @@ def main():
             conv0_ms = sum(summ[f"costreg_{l}/conv0"]["ms"] for l in range(3))
             conv0_flops = sum(work[l]["conv0_flops"] for l in range(3)) * K
             ach = conv0_flops / (conv0_ms * 1e-3) / 1e12
-            traffic, traffic_note = pmc_traffic("conv16db_kernel<2,", B if args.config == "dtu_640x512_v3_var" else None)
+            traffic, traffic_note = pmc_traffic("conv16db_kernel<2, 4, 4, 4, 4, 32", B if args.config == "dtu_640x512_v3_var" else None)
             line["roofline"] = {"kernel": "conv16db_kernel<PX> (CostRegNet.conv0: Cout 8, stride 1; 3 launches per step)",
                                 "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,

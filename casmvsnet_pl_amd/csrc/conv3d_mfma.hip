@@ -33,7 +33,9 @@
 //   zero[64] (target of out-of-range staging loads).  Image order inside a chunk, and the
 //   lane -> (row, k) -> weight mapping, are documented at each format in pack_weight().
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -1663,32 +1665,46 @@ __global__ __launch_bounds__(kThreads) void mfma_lds_rate2_kernel(float *out, in
   if (s == 123.456f) out[0] = s;
 }
 
+// Per-kernel host-side caches, keyed by the kernel's ADDRESS (all instantiations of one kernel template have
+// the same function-pointer type, so a function-local static in a template <class K> helper would be shared
+// between them - it was: the first instantiation launched decided the grid of all the others).
+struct KernelCache {
+  std::mutex m;
+  std::unordered_map<const void *, int> lds_set, resident;
+};
+inline KernelCache &kernel_cache() {
+  static KernelCache c;
+  return c;
+}
+
 // Kernels that need more than the default 64 KiB of LDS must opt in once per process.
 template <class K>
 int ensure_lds(K kernel, size_t bytes, const char *what) {
-  static bool done = false;  // one instance per kernel instantiation (template)
-  if (!done && bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "%s: hipFuncSetAttribute(%zu B LDS): %s", what, bytes, hipGetErrorString(e));
-  }
-  done = true;
+  if (bytes <= 64 * 1024) return CASMVS_OK;
+  const void *key = reinterpret_cast<const void *>(kernel);
+  KernelCache &c = kernel_cache();
+  std::lock_guard<std::mutex> lock(c.m);
+  if (c.lds_set.count(key)) return CASMVS_OK;
+  hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "%s: hipFuncSetAttribute(%zu B LDS): %s", what, bytes, hipGetErrorString(e));
+  c.lds_set[key] = 1;
   return CASMVS_OK;
 }
 
-// Number of workgroups of `kernel` that are resident on the whole device at once (cached per
-// kernel instantiation): the persistent kernels launch exactly that many.
+// Number of workgroups of `kernel` that are resident on the whole device at once (cached per kernel):
+// the persistent kernels launch exactly that many.
 template <class K>
 int resident_blocks(K kernel, size_t lds_bytes) {
-  static int cached = 0;
-  if (cached == 0) {
-    int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    cached = per_cu * cus;
-  }
-  return cached;
+  const void *key = reinterpret_cast<const void *>(kernel);
+  KernelCache &c = kernel_cache();
+  std::lock_guard<std::mutex> lock(c.m);
+  auto it = c.resident.find(key);
+  if (it != c.resident.end()) return it->second;
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  return c.resident[key] = per_cu * cus;
 }
 
 template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int KZ = 3, int KS = 3, int UPS = 0, int OUT2 = 0>
