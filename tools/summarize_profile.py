@@ -55,7 +55,9 @@ with open(os.path.join(out, prefix + "_pmc_traffic.md"), "w") as f:
             "Command: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events` (batch 2, 640x512, 3 views).\n"
             "FETCH_SIZE is doubled (gfx950 rocprofv3 tallies the 128-byte requests of 16 B/lane reads at 64 B: "
             "MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.  Both count L2 misses, i.e. include "
-            "Infinity-Cache hits.  One row per (kernel, grid size) = per cascade level.\n\n"
+            "Infinity-Cache hits.  One row per (kernel, grid size) = per cascade level.\n"
+            "The bench line of the same gpurun call ran before these passes: its roofline.traffic field is the conv0 figure of the PREVIOUS summary "
+            "(bench.py reads profiles/r01_final_pmc_traffic.json); re-run bench.py after refreshing this file to make the two agree.\n\n"
             "| kernel | grid threads | launches | avg us (under PMC) | read MB | write MB |\n|---|---|---|---|---|---|\n")
     for r in table:
         f.write(f"| `{r['kernel']}` | {r['grid_threads']} | {r['launches']} | {r['avg_us_under_pmc']:.1f} | "
