@@ -1713,13 +1713,15 @@ int launch_conv16_v(const LayerCfg &c, const float *packed, const float *in, con
                     float slope, hipStream_t st) {
   using Cfg = Conv16Cfg<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, KZ, KS>;
   auto kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 0, KZ, KS, UPS, OUT2>;
-  if constexpr (MODE == FMT_PX && KZ == 3) {  // profiling-only ablations of the dominant kernel (results are wrong)
+#ifdef CASMVS_TRACE  // profiling build only (tools/build_trace_lib.sh): ablations of the PX kernel - their RESULTS ARE WRONG
+  if constexpr (MODE == FMT_PX && KZ == 3) {
     static const int abl = getenv("CASMVS_ABLATE") ? atoi(getenv("CASMVS_ABLATE")) : 0;
     if (abl == 1) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 1>;
     if (abl == 2) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 2>;
     if (abl == 16) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 16>;
     if (abl == 32) kernel = conv16_kernel<MODE, STRIDE, CK, NT, TZ, TY, TX, VEC, 32>;
   }
+#endif
   if (int rc = ensure_lds(kernel, Cfg::LDS_BYTES, "conv16_kernel")) return rc;
   const int tiles_x = casmvs::ceil_div(Wo, TX), tiles_y = casmvs::ceil_div(Ho, TY),
             tiles_z = casmvs::ceil_div(Do, TZ);

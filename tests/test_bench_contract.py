@@ -1,0 +1,48 @@
+"""CPU checks of bench.py's bookkeeping: the algorithmic bytes / FLOPs it divides by are the ones SURVEY 8(d)
+states, and it refuses to run without a GPU instead of falling back."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_algorithmic_work_matches_survey_8d(bench):
+    H, W, V, G, n_depths, _ = bench.CONFIGS["dtu_640x512_v3_var"]
+    work = bench.algorithmic_work(H, W, V, G, n_depths)
+    # fused cost-volume build 137.6 / 194.0 / 125.8 MB at levels 2 / 1 / 0 (work is keyed by level)
+    assert [round(work[l]["costvol_bytes"] / 1e6, 1) for l in (2, 1, 0)] == [137.6, 194.0, 125.8]
+    assert [round(work[l]["softmax_bytes"] / 1e6, 1) for l in (2, 1, 0)] == [8.0, 21.6, 23.6]
+    # CostRegNet 19.96 / 35.11 / 26.05 GFLOP, conv0 alone 13.59 / 18.12 / 9.06
+    assert [round(work[l]["costreg_flops"] / 1e9, 2) for l in (2, 1, 0)] == [19.96, 35.11, 26.05]
+    assert [round(work[l]["conv0_flops"] / 1e9, 2) for l in (2, 1, 0)] == [13.59, 18.12, 9.06]
+    gwc = bench.algorithmic_work(*bench.CONFIGS["dtu_640x512_v3_gwc8"][:5])
+    assert [round(gwc[l]["costvol_bytes"] / 1e6, 1) for l in (2, 1, 0)] == [43.3, 110.1, 125.8]
+    # FeatureNet: 16.9 GFLOP for the 3 views
+    assert round(3 * bench.feature_flops(H, W) / 1e9, 1) == 16.9
+
+
+def test_pmc_traffic_lookup(bench):
+    val, note = bench.pmc_traffic("conv16db_kernel<2, 4, 4, 4, 4, 32", 2)
+    assert val is None or 3.8e8 < val < 2e9, note   # >= the algorithmic 384 MB of the same launches
+    assert bench.pmc_traffic("conv16db_kernel<2, 4, 4, 4, 4, 32", 1)[0] is None
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
