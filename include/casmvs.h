@@ -11,13 +11,15 @@
  * Conventions (all entry points):
  *   - return 0 (CASMVS_OK) or a negative CASMVS_ERR_* code; never throw across the ABI.
  *     `casmvs_last_error()` returns a thread-local human readable message for the last failure.
- *   - every tensor is fp32, contiguous, row-major in the reference's own layout (NCHW / NCDHW).
+ *   - every tensor is fp32, contiguous, row-major in the reference's own layout (NCHW / NCDHW);
+ *     the *_nhwc entry points (pixel-major feature maps) say so explicitly.
  *   - the CALLER owns every buffer (inputs, outputs, workspace, packed weights).  The library
  *     allocates no device memory and keeps no pointer after return.
  *   - device pointers are raw `hipDeviceptr`-style `float*` on the calling thread's current
  *     device; `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).
- *   - fully asynchronous on `stream`: no internal synchronisation, re-entrant, no global mutable
- *     state.  Inputs are `const`; outputs must not alias inputs.
+ *   - fully asynchronous on `stream`: no internal synchronisation, re-entrant; the only global state
+ *     is a mutex-protected cache of per-kernel launch constants (occupancy, LDS opt-in).  Inputs
+ *     are `const`; outputs must not alias inputs.
  *   - built with `hipcc --offload-arch=gfx950` only.  No CPU fallback exists: on a machine
  *     without a gfx950 device the launch entry points fail with CASMVS_ERR_HIP.
  */
@@ -69,6 +71,8 @@ int casmvs_depth_hypotheses_f32(const float *prev_depth, const float *depth_min_
  * proj  : device (B, 3, 4)        (P_src @ inv(P_ref))[:3]
  * depth : device (B, D, H, W)     per-pixel depth hypotheses of the reference view
  * out   : device (B, C, D, H, W)  warped source volume (bilinear, zeros padding, align_corners)
+ * Coordinates follow the reference's fp32 operation order; its seven divisions per tap set are
+ * evaluated to <= 1 ulp (reciprocal + one Newton step), everything else is separately rounded.
  */
 int casmvs_homo_warp_f32(const float *src, const float *proj, const float *depth, float *out,
                          int B, int C, int H, int W, int D, void *stream);
