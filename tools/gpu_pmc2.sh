@@ -1,5 +1,7 @@
 #!/bin/bash
 # LDS / instruction-fetch counters of the MFMA loop (conv0 kernel), ABL=2 and normal.
+# (historic: the ablation modes now exist only in the -DCASMVS_TRACE build, tools/build_trace_lib.sh; point
+#  casmvsnet_pl_amd/_lib.LIB_PATH at libcasmvs_trace.so as tools/gpu_trace2.py does to reproduce)
 TAG=${1:-pmc3}
 ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTDIR/gpurun_out/$TAG
