@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libcasmvs_hip.so")
+# CASMVS_LIB_PATH: load another BUILD of the same library (profiling: -DCASMVS_TRACE, compiler-flag A/B runs)
+LIB_PATH = os.environ.get("CASMVS_LIB_PATH") or os.path.join(_PKG_DIR, "libcasmvs_hip.so")
 ABI_VERSION = 1
 
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
