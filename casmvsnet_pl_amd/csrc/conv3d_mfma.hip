@@ -1424,9 +1424,21 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
         float i0, i5;
         f32x4v m;
         if constexpr (VEC == 4) {
-          i0 = row[3];
+          // The two edge inputs x - 1 and x + 4 are the neighbouring lanes' m[3] / m[0]: fetched with DPP row
+          // shifts.  (As single-dword LDS reads at word 4 xi + 3 they hit 8 of the 32 banks from all 64 lanes:
+          // 8-way conflicts that made the kernel LDS-bound - halving its VALU count changed nothing.)  Only
+          // the first / last lane of an 8-lane row needs the tile's halo column: one broadcast read per row.
           m = *reinterpret_cast<const f32x4v *>(row + 4);
-          i5 = row[8];
+          const float *rb = row - 4 * xi;  // the row's first staged word (x0 - 4)
+          const float h0 = rb[3], h5 = rb[36];
+          // (the empty asm pins the two elements in their own registers: hipcc 7.2 otherwise folds BOTH DPP
+          //  sources to element 0 of the 16-byte load - reproduced in a 10-line kernel)
+          float m3 = m[3], m0 = m[0];
+          asm volatile("" : "+v"(m3), "+v"(m0));
+          const float l0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m3), 0x111, 0xf, 0xf, false));  // row_shr:1
+          const float l5 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m0), 0x101, 0xf, 0xf, false));  // row_shl:1
+          i0 = xi == 0 ? h0 : l0;
+          i5 = xi == 7 ? h5 : l5;
         } else {
           const f32x4v a = *reinterpret_cast<const f32x4v *>(row);
           const f32x2 e = *reinterpret_cast<const f32x2 *>(row + 4);
