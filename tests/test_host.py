@@ -68,6 +68,40 @@ def test_packed_layer_cache_tracks_parameter_changes():
     assert net.packed_layers(torch.device("cpu")) is not p2
 
 
+def test_featurenet_packing_folds_abn_and_tracks_parameter_changes():
+    from casmvsnet_pl_amd import FeatureNet
+    import torch.nn.functional as F
+    import kernel_model as KM
+    net = FeatureNet(ABN).eval()
+    with torch.no_grad():
+        for m in net.modules():  # non-trivial ABN statistics
+            if hasattr(m, "running_var"):
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.normal_(0, 0.1)
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.normal_(0, 0.1)
+    p1 = net.packed_layers(torch.device("cpu"))
+    assert len(p1) == 13 and net.packed_layers(torch.device("cpu")) is p1
+    # the packed image of conv1.0 (5x5 stride 2 + folded ABN) drives the kernel index model to the reference layer
+    x = torch.randn(1, 8, 12, 16)
+    blk = net.conv1[0]
+    want = blk(x)
+    got = KM.emulate2d(KM.K5S2, p1[2], x, 16, slope=0.01)
+    assert float((got - want).abs().max()) < 1e-4
+    # plain conv + bias (smooth0) and the FPN layer (lat0): bias travels as `shift`, no activation (slope 1)
+    f = torch.randn(1, 32, 8, 12)
+    assert float((KM.emulate2d(KM.K3, p1[12], f, 8, slope=1.0) - net.smooth0(f)).abs().max()) < 1e-4
+    c0, up = torch.randn(1, 8, 8, 12), torch.randn(1, 32, 4, 6)
+    want = F.interpolate(up, scale_factor=2, mode="bilinear", align_corners=True) + net.lat0(c0)
+    assert float((KM.emulate2d(KM.K1_UP, p1[10], c0, 32, up=up, slope=1.0) - want).abs().max()) < 1e-4
+    with torch.no_grad():
+        net.smooth0.bias.add_(1.0)
+    p2 = net.packed_layers(torch.device("cpu"))
+    assert p2 is not p1 and not torch.equal(p1[12], p2[12])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 3, 32, 32))
+
+
 def test_forward_fails_loudly_without_gpu():
     m = CascadeMVSNet(norm_act=ABN).eval()
     imgs, proj, dmin, dint = make_inputs(1, 3, 32, 32, seed=0)
