@@ -4,10 +4,9 @@
 // (ConvBnReLU3D): Conv3d / ConvTranspose3d (k3, p1) -> eval-mode ABN -> (+ skip).
 //
 // Instruction choice (measured on MI355X with casmvs_selftest_mfma_rate): the
-// fp32 MFMA that runs at the full 64 FLOP/clk/SIMD is v_mfma_f32_16x16x4_f32 (32 cycles);
-// the 16-block v_mfma_f32_4x4x1_16b_f32 form, attractive for tiny Cout, issues at HALF that
-// rate when its accumulators are reused back to back; it is not used by any kernel any more (the
-// 1-channel `prob` head is a VALU kernel) and survives only in the rate probes.
+// fp32 MFMA that runs at the full 64 FLOP/clk/SIMD is v_mfma_f32_16x16x4_f32 (32 cycles, 149-155
+// TFLOP/s chip-wide); the 16-block v_mfma_f32_4x4x1_16b_f32 form reaches 135 and is not used by any
+// kernel (the 1-channel `prob` head is a VALU kernel); it survives only in the rate probes.
 //
 // Formulation.  D[16 rows][16 cols] += A[16][4] * B[4][16] per instruction with
 //   cols = 16 output voxels that are consecutive along x (one "column tile"),
@@ -58,7 +57,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// 4x4x1 with A-block broadcast: acc[r] (lane) += a[4*ABID + r] * b[lane]   (prob head only)
+// 4x4x1 with A-block broadcast: acc[r] (lane) += a[4*ABID + r] * b[lane]   (lane-mapping probe only)
 template <int ABID>
 __device__ __forceinline__ f32x4 mfma_bcast(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, /*cbsz=*/4, /*abid=*/ABID, /*blgp=*/0);

@@ -2,12 +2,12 @@
 return shapes), with the arithmetic done by the HIP engine through the C ABI.
 
 reference                      here
-modules.py:8-18   ConvBnReLU    parameter container (FeatureNet, PyTorch-ROCm ops)
+modules.py:8-18   ConvBnReLU    parameter container (folded into the 2D MFMA conv epilogue, casmvs_conv2d_*)
 modules.py:21-31  ConvBnReLU3D  parameter container (folded into the MFMA conv epilogue)
 modules.py:34-49  get_depth_values  -> casmvs_depth_hypotheses_f32 (on an already-upsampled map)
 modules.py:52-92  homo_warp         -> casmvs_homo_warp_f32
-modules.py:95-104 depth_regression  -> torch reduction (not on the fused hot path: the engine
-                                       fuses softmax + regression in casmvs_softmax_regress_f32)
+modules.py:95-104 depth_regression  -> device-side torch reduction, API parity only (the engine fuses
+                                       softmax + regression + confidence in casmvs_softmax_regress_f32)
 """
 import torch
 import torch.nn as nn
@@ -17,13 +17,36 @@ from .inplace_abn import InPlaceABN
 
 
 class ConvBnReLU(nn.Module):
+    """modules.py:8-18.  Inside FeatureNet the layer runs as part of casmvs_featurenet_forward_f32; called on
+    its own it is one casmvs_conv2d_forward_f32 launch (eval-mode ABN folded).  No torch / CPU path."""
+
+    _KINDS = {(3, 1, 1): ops.CONV2D_K3, (5, 2, 2): ops.CONV2D_K5S2, (1, 1, 0): ops.CONV2D_K1}
+
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1, norm_act=InPlaceABN):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = norm_act(out_channels)
+        self._geometry = (kernel_size, stride, pad)
 
     def forward(self, x):
-        return self.bn(self.conv(x))
+        if not x.is_cuda:
+            raise RuntimeError("casmvsnet_pl_amd.ConvBnReLU runs on the MI355X only; there is no CPU fallback")
+        if self.training and torch.is_grad_enabled():
+            raise RuntimeError("casmvsnet_pl_amd.ConvBnReLU is an inference engine (eval-mode ABN folded into the "
+                               "MFMA conv epilogue); call model.eval() / torch.no_grad().")
+        kind = self._KINDS.get(self._geometry)
+        if kind is None:
+            raise RuntimeError(f"ConvBnReLU: (kernel, stride, pad) = {self._geometry} is not one of the layer shapes of "
+                               "FeatureNet (3,1,1), (5,2,2), (1,1,0)")
+        bn = self.bn
+        if hasattr(bn, "folded_scale_shift"):
+            scale, shift = bn.folded_scale_shift()
+        else:
+            s64 = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+            scale, shift = s64.float().cpu(), (bn.bias.detach().double() - bn.running_mean.detach().double() * s64).float().cpu()
+        slope = bn.leaky_slope() if hasattr(bn, "leaky_slope") else float(getattr(bn, "activation_param", 0.01))
+        packed = ops.conv2d_pack(kind, self.conv.weight, scale, shift).to(x.device)
+        return ops.conv2d_forward(kind, packed, x.float(), self.conv.out_channels, slope=slope)
 
 
 class ConvBnReLU3D(nn.Module):
@@ -64,7 +87,11 @@ def homo_warp(src_feat, proj_mat, depth_values):
 
 
 def depth_regression(p, depth_values):
-    """p (B,D,H,W); depth_values (B,D,H,W) or (D) -> (B,H,W)   (modules.py:95-104)."""
+    """p (B,D,H,W); depth_values (B,D,H,W) or (D) -> (B,H,W)   (modules.py:95-104).
+    Kept for API parity only: the engine never calls it (softmax, regression and confidence are one kernel,
+    casmvs_softmax_regress_f32).  A device-side torch reduction; like every op here it refuses CPU tensors."""
+    if not p.is_cuda:
+        raise RuntimeError("casmvsnet_pl_amd.depth_regression runs on the MI355X only; there is no CPU fallback")
     if depth_values.dim() == 1:
         depth_values = depth_values.view(1, -1, 1, 1)
-    return (p * depth_values).sum(1).to(depth_values.dtype)
+    return (p * depth_values.to(p.device)).sum(1).to(depth_values.dtype)

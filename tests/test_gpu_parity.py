@@ -233,6 +233,23 @@ def test_conv2d_layer_matches_torch_cpu(dev, report, kind, cin, cout, N, H, W):
     assert err < 2e-5
 
 
+def test_convbnrelu_module_runs_one_hip_layer(dev):
+    from casmvsnet_pl_amd import ABN, ConvBnReLU
+    g = torch.Generator().manual_seed(5)
+    m = ConvBnReLU(8, 16, 5, 2, 2, norm_act=ABN).eval()
+    with torch.no_grad():
+        m.bn.running_var.uniform_(0.5, 1.5, generator=g)
+        m.bn.running_mean.normal_(0, 0.1, generator=g)
+        m.bn.weight.uniform_(0.6, 1.4, generator=g)
+        m.bn.bias.normal_(0, 0.1, generator=g)
+    x = torch.randn(2, 8, 24, 40, generator=g)
+    want = F.leaky_relu(F.batch_norm(F.conv2d(x, m.conv.weight, None, stride=2, padding=2), m.bn.running_mean,
+                                     m.bn.running_var, m.bn.weight, m.bn.bias, False, 0.0, m.bn.eps), 0.01)
+    with torch.no_grad():
+        got = m.to(dev)(x.to(dev)).cpu()
+    assert got.shape == want.shape and scaled_err(got, want) < 2e-5
+
+
 @pytest.mark.parametrize("N,H,W", [(3, 64, 96), (2, 32, 64), (5, 160, 128), (1, 36, 44)])
 def test_featurenet_matches_oracle(dev, report, N, H, W):
     from casmvsnet_pl_amd import ABN, FeatureNet

@@ -85,7 +85,10 @@ def test_featurenet_packing_folds_abn_and_tracks_parameter_changes():
     # the packed image of conv1.0 (5x5 stride 2 + folded ABN) drives the kernel index model to the reference layer
     x = torch.randn(1, 8, 12, 16)
     blk = net.conv1[0]
-    want = blk(x)
+    want = F.leaky_relu(F.batch_norm(F.conv2d(x, blk.conv.weight, None, stride=2, padding=2), blk.bn.running_mean,
+                                     blk.bn.running_var, blk.bn.weight, blk.bn.bias, False, 0.0, blk.bn.eps), 0.01)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        blk(x)
     got = KM.emulate2d(KM.K5S2, p1[2], x, 16, slope=0.01)
     assert float((got - want).abs().max()) < 1e-4
     # plain conv + bias (smooth0) and the FPN layer (lat0): bias travels as `shift`, no activation (slope 1)
