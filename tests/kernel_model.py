@@ -180,3 +180,84 @@ def emulate2d(kind, packed, x, cout, up=None, slope=0.01):
     if up is not None:
         y = y + F.interpolate(up.double(), scale_factor=2, mode="bilinear", align_corners=True)
     return y.float()
+
+
+# ---- stride-2 layers on the x-de-interleaved LDS rows (Stager<5> / DbStager<DEINT>) ---------------
+def emulate_s2_deint(x, w, TZ=2, TY=4, TX=16):
+    """Index walk of the stride-2 CI kernels with 16-byte staging: the row of a tile starts at input column
+    2 x0 - 4 and is stored [even columns | odd columns]; tap kx of output column j reads column 2 j + kx + 3 of
+    the row = index j + 2 of the even half (kx = 1) or j + 1 / j + 2 of the odd half (kx = 0 / 2).
+    x (cin, D, H, W), w (cout, cin, 3, 3, 3) -> (cout, D/2, H/2, W/2)."""
+    import numpy as np
+    cin, D, H, W = x.shape
+    cout = w.shape[0]
+    IZ, IY = 2 * (TZ - 1) + 3, 2 * (TY - 1) + 3
+    IX = (4 + 2 * (TX - 1) + 2 + 3) // 4 * 4
+    Do, Ho, Wo = D // 2, H // 2, W // 2
+    out = np.zeros((cout, Do, Ho, Wo), dtype=np.float64)
+    for tz0 in range(0, Do, TZ):
+        for ty0 in range(0, Ho, TY):
+            for tx0 in range(0, Wo, TX):
+                tile = np.zeros((cin, IZ, IY, IX))
+                iz0, iy0, ix0 = tz0 * 2 - 1, ty0 * 2 - 1, tx0 * 2 - 4
+                for iz in range(IZ):
+                    for iy in range(IY):
+                        for xv in range(IX // 4):  # one staged 16-byte group
+                            gz, gy, gx = iz0 + iz, iy0 + iy, ix0 + 4 * xv
+                            v = np.zeros((cin, 4))
+                            if 0 <= gz < D and 0 <= gy < H and gx >= 0 and gx + 3 < W:
+                                v = x[:, gz, gy, gx:gx + 4]
+                            tile[:, iz, iy, 2 * xv:2 * xv + 2] = v[:, [0, 2]]
+                            tile[:, iz, iy, IX // 2 + 2 * xv:IX // 2 + 2 * xv + 2] = v[:, [1, 3]]
+                for cz in range(TZ):
+                    for cy in range(TY):
+                        for j in range(TX):
+                            oz, oy, ox = tz0 + cz, ty0 + cy, tx0 + j
+                            if oz >= Do or oy >= Ho or ox >= Wo:
+                                continue
+                            acc = np.zeros(cout)
+                            for it in range(27):
+                                kz, ky, kx = it // 9, (it // 3) % 3, it % 3
+                                xo = 2 if kx == 1 else IX // 2 + (1 if kx == 0 else 2)
+                                acc += w[:, :, kz, ky, kx] @ tile[:, cz * 2 + kz, cy * 2 + ky, j + xo]
+                            out[:, oz, oy, ox] = acc
+    return out
+
+
+# ---- FPN top-down step as fpn_lateral_kernel computes it (thread = 4 consecutive x) ---------------
+def emulate_fpn_lateral(x, w, b, up):
+    """x (cin, H, W), w (cout, cin), b (cout), up (cout, H/2, W/2) -> (cout, H, W): 4-column source window
+    [xb, xb + 4) per thread and a 4 x 4 tent matrix for the horizontal interpolation (fp32 like the kernel)."""
+    import numpy as np
+    f32 = np.float32
+    cin, H, W = x.shape
+    cout, hc, wc = up.shape
+    assert W % 4 == 0 and wc >= 4
+    sy = f32(hc - 1) / f32(H - 1) if H > 1 else f32(0)
+    sx = f32(wc - 1) / f32(W - 1) if W > 1 else f32(0)
+    out = np.zeros((cout, H, W), dtype=np.float32)
+    lat = np.einsum("oc,chw->ohw", w.astype(np.float64), x.astype(np.float64)) + b[:, None, None]
+    for y in range(H):
+        fy = f32(sy * f32(y))
+        y0 = int(fy)
+        y1 = y0 + (1 if y0 < hc - 1 else 0)
+        ly1 = f32(fy - f32(y0))
+        ly0 = f32(1) - ly1
+        for ox in range(0, W, 4):
+            T = np.zeros((4, 4), dtype=np.float32)
+            xb = None
+            for k in range(4):
+                fx = f32(sx * f32(ox + k))
+                x0 = int(fx)
+                x1 = x0 + (1 if x0 < wc - 1 else 0)
+                lx1 = f32(fx - f32(x0))
+                lx0 = f32(1) - lx1
+                if k == 0:
+                    xb = x0 if x0 < wc - 4 else wc - 4
+                assert 0 <= x0 - xb < 4 and 0 <= x1 - xb < 4, "a pixel's columns must lie inside the 4-column window"
+                T[k, x0 - xb] += lx0
+                T[k, x1 - xb] += lx1
+            r0, r1 = up[:, y0, xb:xb + 4], up[:, y1, xb:xb + 4]      # (cout, 4)
+            h0, h1 = r0 @ T.T, r1 @ T.T                               # (cout, 4 pixels)
+            out[:, y, ox:ox + 4] = lat[:, y, ox:ox + 4] + (ly0 * h0 + ly1 * h1)
+    return out

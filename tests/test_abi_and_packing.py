@@ -127,3 +127,27 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 def test_ops_reject_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.homo_warp(torch.zeros(1, 1, 4, 4), torch.zeros(1, 3, 4), torch.ones(1, 1, 4, 4))
+
+
+def test_stride2_deinterleaved_row_walk_is_a_stride2_convolution():
+    """Index model of the stride-2 kernels' [even | odd] LDS rows (wide and deep tile) == F.conv3d stride 2."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 6, 12, 40, generator=g)
+    w = torch.randn(5, 3, 3, 3, 3, generator=g)
+    ref = F.conv3d(x[None], w, None, stride=2, padding=1)[0].numpy()
+    for tile in ((2, 4, 16), (1, 4, 16)):
+        got = KM.emulate_s2_deint(x.numpy(), w.numpy(), *tile)
+        assert abs(got - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("H,W", [(4, 8), (6, 12), (10, 40), (8, 64)])
+def test_fpn_lateral_window_and_tent_weights_reproduce_interpolate(H, W):
+    """The 4-column window + tent matrix of fpn_lateral_kernel == F.interpolate(x2, bilinear, align_corners) + 1x1 conv."""
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(8, H, W, generator=g)
+    w = torch.randn(16, 8, generator=g) * 0.3
+    b = torch.randn(16, generator=g) * 0.1
+    up = torch.randn(16, H // 2, W // 2, generator=g)
+    want = F.interpolate(up[None], scale_factor=2, mode="bilinear", align_corners=True)[0] + F.conv2d(x[None], w[:, :, None, None], b)[0]
+    got = KM.emulate_fpn_lateral(x.numpy(), w.numpy(), b.numpy(), up.numpy())
+    assert abs(got - want.numpy()).max() < 1e-4
