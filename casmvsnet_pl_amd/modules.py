@@ -27,6 +27,7 @@ class ConvBnReLU(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = norm_act(out_channels)
         self._geometry = (kernel_size, stride, pad)
+        self._packed = None  # (key, device tensor, slope): re-packed when a parameter / buffer changes
 
     def forward(self, x):
         if not x.is_cuda:
@@ -38,14 +39,17 @@ class ConvBnReLU(nn.Module):
         if kind is None:
             raise RuntimeError(f"ConvBnReLU: (kernel, stride, pad) = {self._geometry} is not one of the layer shapes of "
                                "FeatureNet (3,1,1), (5,2,2), (1,1,0)")
-        bn = self.bn
-        if hasattr(bn, "folded_scale_shift"):
-            scale, shift = bn.folded_scale_shift()
-        else:
-            s64 = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
-            scale, shift = s64.float().cpu(), (bn.bias.detach().double() - bn.running_mean.detach().double() * s64).float().cpu()
-        slope = bn.leaky_slope() if hasattr(bn, "leaky_slope") else float(getattr(bn, "activation_param", 0.01))
-        packed = ops.conv2d_pack(kind, self.conv.weight, scale, shift).to(x.device)
+        key = (str(x.device),) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        if self._packed is None or self._packed[0] != key:
+            bn = self.bn
+            if hasattr(bn, "folded_scale_shift"):
+                scale, shift = bn.folded_scale_shift()
+            else:
+                s64 = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+                scale, shift = s64.float().cpu(), (bn.bias.detach().double() - bn.running_mean.detach().double() * s64).float().cpu()
+            slope = bn.leaky_slope() if hasattr(bn, "leaky_slope") else float(getattr(bn, "activation_param", 0.01))
+            self._packed = (key, ops.conv2d_pack(kind, self.conv.weight, scale, shift).to(x.device), slope)
+        _, packed, slope = self._packed
         return ops.conv2d_forward(kind, packed, x.float(), self.conv.out_channels, slope=slope)
 
 
