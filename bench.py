@@ -102,8 +102,8 @@ def cpu_baseline(cfg_name, repeats=3):
     times.sort()
     med = times[len(times) // 2]
     return {"value": 1.0 / med, "unit": "depth-maps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{repeats} timed forwards (median {med:.3f} s) of the same {cfg_name} workload after 1 warm-up, "
-                      f"torch CPU fp32, {torch.get_num_threads()} threads"}
+            "sample": f"{repeats} timed forwards of ONE depth map each (median {med:.3f} s) on the same {cfg_name} inputs / weights "
+                      f"after 1 warm-up, torch CPU fp32, {torch.get_num_threads()} threads"}
 
 
 def main():
