@@ -46,8 +46,10 @@ def dtu_like_cameras(V, H, W, depth_mid=680.0, baseline=60.0, levels=3):
             dx, dy = dirs[(v - 1) % len(dirs)]
             scale = baseline * (1.0 + 0.15 * ((v - 1) // len(dirs)) + 0.07 * (v - 1))
             c = torch.tensor([dx * scale, dy * scale, 0.0], dtype=torch.float64)
-            # world -> camera rotation that points the optical axis at (0, 0, depth_mid)
-            R = _rot_x(math.atan2(c[1].item(), depth_mid)) @ _rot_y(-math.atan2(c[0].item(), depth_mid))
+            # world -> camera rotation that points the optical axis at (0, 0, depth_mid): the direction
+            # (-cx, -cy, depth_mid) from the camera centre to that point must map onto +z.  (Round 1 had both
+            # signs flipped - a DIVERGENT rig whose source views saw only about half of the reference frustum.)
+            R = _rot_x(-math.atan2(c[1].item(), depth_mid)) @ _rot_y(math.atan2(c[0].item(), depth_mid))
         t = -R @ c
         mats = []
         for l in range(levels):  # fine -> coarse
