@@ -29,6 +29,14 @@ SYMBOLS = {
     "casmvs_nchw_to_nhwc_f32": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_var_nhwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_gwc_nhwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_costvol_lds_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "casmvs_costvol_var_lds_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_costvol_gwc_lds_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_homo_warp_nhwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_costvol_partial_var_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_costvol_partial_gwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_costvol_var_finalize_f32": (c_int, [_FP, _FP, _FP, c_size_t, c_int, c_void_p]),
+    "casmvs_costvol_gwc_finalize_f32": (c_int, [_FP, _FP, c_size_t, c_int, c_void_p]),
     "casmvs_conv3d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "casmvs_conv3d_pack_f32": (c_int, [c_int, c_int, c_int, _FP, _FP, _FP, _FP]),
     "casmvs_conv3d_forward_f32": (c_int, [c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
@@ -40,6 +48,7 @@ SYMBOLS = {
     "casmvs_featurenet_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "casmvs_featurenet_forward_f32": (c_int, [POINTER(c_void_p), _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
     "casmvs_softmax_regress_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_depth_regression_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_selftest_mfma": (c_int, [_FP]),
     "casmvs_selftest_mfma_rate": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
 }

@@ -11,35 +11,48 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcasmvs_hip.so")
-SOURCES = ["abi.hip", "costvol.hip", "depth_ops.hip", "conv3d_mfma.hip", "conv2d_mfma.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(REPO_ROOT, "include", "casmvs.h")]
+SOURCES = ["abi.hip", "costvol.hip", "costvol_lds.hip", "depth_ops.hip", "conv3d_mfma.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "plane_sweep.h"), os.path.join(REPO_ROOT, "include", "casmvs.h")]
 
 
 def _sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.isfile(os.path.join(CSRC, s))]
 
 
-def is_stale():
-    if not os.path.isfile(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(f) > t for f in _sources() + HEADERS)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
-def build_library(force=False, verbose=False):
-    """Compile every HIP source into one shared library.  Returns the library path."""
-    if not force and not is_stale():
-        return LIB_PATH
+def build_library(force=False, verbose=False, extra_flags=(), lib_path=None, obj_dir=None):
+    """Compile every HIP source (one object per source, rebuilt only when it or a header changed, in parallel) and
+    link them into one shared library.  Returns the library path.  `extra_flags` / `lib_path` / `obj_dir` build a
+    variant next to the production library (tools/build_trace_lib.sh: -DCASMVS_TRACE, -DCASMVS_IEEE_DIV)."""
+    lib_path = lib_path or LIB_PATH
+    obj_dir = obj_dir or os.path.join(PKG_DIR, "build")
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC] + _sources() + ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
+    inc = ["-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC]
+    hdr_time = max(os.path.getmtime(h) for h in HEADERS)
+    jobs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.isfile(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            cmd = [hipcc] + FLAGS + list(extra_flags) + inc + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, proc in jobs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n" + out)
+    if not jobs and os.path.isfile(lib_path) and os.path.getmtime(lib_path) >= max(os.path.getmtime(o) for o in objs):
+        return lib_path
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path + ".tmp"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+        raise RuntimeError("hipcc link failed:\n" + res.stdout)
+    os.replace(lib_path + ".tmp", lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":

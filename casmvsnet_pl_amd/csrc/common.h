@@ -21,6 +21,13 @@ inline int check_launch(const char *what) {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Per-(device, kernel) launch constants, cached under a mutex (abi.hip).  Both are properties of the DEVICE the
+// calling thread is on: a process that drives several GPUs gets each one opted in / measured separately.
+// ensure_dynamic_lds: kernels that use more than the default 64 KiB of dynamic LDS must opt in once per device.
+int ensure_dynamic_lds(const void *kernel, size_t bytes, const char *what);
+// Number of workgroups of `kernel` resident on the whole device at once (persistent kernels launch exactly that many).
+int resident_blocks(const void *kernel, int threads, size_t lds_bytes);
+
 }  // namespace casmvs
 
 #define CASMVS_REQUIRE(cond, ...)                                            \

@@ -1679,43 +1679,32 @@ __global__ __launch_bounds__(kThreads) void mfma_lds_rate2_kernel(float *out, in
 // Per-kernel host-side caches, keyed by the kernel's ADDRESS (all instantiations of one kernel template have
 // the same function-pointer type, so a function-local static in a template <class K> helper would be shared
 // between them - it was: the first instantiation launched decided the grid of all the others).
-struct KernelCache {
-  std::mutex m;
-  std::unordered_map<const void *, int> lds_set, resident;
-};
-inline KernelCache &kernel_cache() {
-  static KernelCache c;
-  return c;
+// A/B switches exist in the profiling build only (tools/build_trace_lib.sh, -DCASMVS_TRACE): the production
+// library never reads the environment.
+inline int trace_env_int(const char *name, int dflt) {
+#ifdef CASMVS_TRACE
+  if (const char *e = getenv(name)) return atoi(e);
+#else
+  (void)name;
+#endif
+  return dflt;
+}
+inline bool trace_env_set(const char *name) {
+#ifdef CASMVS_TRACE
+  return getenv(name) != nullptr;
+#else
+  (void)name;
+  return false;
+#endif
 }
 
-// Kernels that need more than the default 64 KiB of LDS must opt in once per process.
 template <class K>
 int ensure_lds(K kernel, size_t bytes, const char *what) {
-  if (bytes <= 64 * 1024) return CASMVS_OK;
-  const void *key = reinterpret_cast<const void *>(kernel);
-  KernelCache &c = kernel_cache();
-  std::lock_guard<std::mutex> lock(c.m);
-  if (c.lds_set.count(key)) return CASMVS_OK;
-  hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "%s: hipFuncSetAttribute(%zu B LDS): %s", what, bytes, hipGetErrorString(e));
-  c.lds_set[key] = 1;
-  return CASMVS_OK;
+  return casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), bytes, what);
 }
-
-// Number of workgroups of `kernel` that are resident on the whole device at once (cached per kernel):
-// the persistent kernels launch exactly that many.
 template <class K>
 int resident_blocks(K kernel, size_t lds_bytes) {
-  const void *key = reinterpret_cast<const void *>(kernel);
-  KernelCache &c = kernel_cache();
-  std::lock_guard<std::mutex> lock(c.m);
-  auto it = c.resident.find(key);
-  if (it != c.resident.end()) return it->second;
-  int per_cu = 0, dev = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
-  (void)hipGetDevice(&dev);
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-  return c.resident[key] = per_cu * cus;
+  return casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), kThreads, lds_bytes);
 }
 
 template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int KZ = 3, int KS = 3, int UPS = 0, int OUT2 = 0>
@@ -1765,7 +1754,7 @@ int launch_conv16db(const LayerCfg &c, const float *packed, const float *in, con
 
 // 16-byte staging needs rows that start 16-byte aligned: Wi % 4 == 0 (and 16-byte aligned tensors).
 inline bool vec4_ok(const float *in, int Wi) {
-  static const bool disabled = getenv("CASMVS_NO_VEC4") != nullptr;  // A/B switch (profiling)
+  static const bool disabled = trace_env_set("CASMVS_NO_VEC4");  // A/B switch (profiling)
   return !disabled && Wi % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
 }
 
@@ -1783,7 +1772,7 @@ int launch_conv16(const LayerCfg &c, const float *packed, const float *in, const
     // 16-byte staging into x-de-interleaved rows (Stager<5>): correct and bank-conflict free, but measured
     // 10-15 % slower on conv1 / conv3 (wider rows -> one resident workgroup fewer; the per-tile set-up
     // of the flattened stager costs more VALU next to the MFMAs).  Kept for A/B runs: CASMVS_S2_VEC4=1.
-    static const bool s2_vec4 = getenv("CASMVS_S2_VEC4") != nullptr;
+    static const bool s2_vec4 = trace_env_set("CASMVS_S2_VEC4");
     if (s2_vec4 && vec4_ok(in, Wi))
       return launch_conv16_v<MODE, STRIDE, CK, NT, TZ, TY, TX, 4>(c, packed, in, skip, out, B, cin, cout, Di, Hi, Wi, Do, Ho, Wo, slope, st);
   }
@@ -1916,13 +1905,13 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
       return launch_prob(c, packed, in, out, B, cin, D, H, W, slope, st);
     }
     if (c.fmt == FMT_PX) {
-      static const bool no_db = getenv("CASMVS_NO_DB") != nullptr;  // A/B switch (profiling)
+      static const bool no_db = trace_env_set("CASMVS_NO_DB");  // A/B switch (profiling)
       if (!no_db && W % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0)
         return launch_conv16db<FMT_PX, 4, 4, 4, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
       return launch_conv16<FMT_PX, 1, 4, 8, 8, 4, 32>(c, packed, in, skip, out, B, cin, cout, D, H, W, D, H, W, slope, st);
     }
     const long wide_blocks = (long)casmvs::ceil_div(W, 16) * casmvs::ceil_div(H, 8) * casmvs::ceil_div(D, 4) * c.slices * B;
-    static const int db_ci = getenv("CASMVS_DB_CI") ? atoi(getenv("CASMVS_DB_CI")) : 3;  // A/B switch (profiling); default: double-buffered
+    static const int db_ci = trace_env_int("CASMVS_DB_CI", 3);  // A/B switch (profiling); default: double-buffered
     const bool al = W % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
     if (wide_blocks >= 512 && D >= 3) {  // the wide tile is 4 deep: with D <= 2 half of every tile would be padding
       if ((db_ci & 1) && al) return launch_conv16db<FMT_CI, 4, 4, 4, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
@@ -1936,7 +1925,7 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
     const long wide_blocks = (long)casmvs::ceil_div(W / 2, 16) * casmvs::ceil_div(H / 2, 8) * casmvs::ceil_div(D / 2, 2) * c.slices * B;
     // wide tile (2, 4, 16), 2 column tiles per wave: A/B-tested against (2, 8, 16) x 4, (1, 8, 16) with CK = 8 and
     // (1, 16, 16) x 4 - the small tile wins by 7 % (5 resident workgroups per CU instead of 3)
-    static const int db_s2 = getenv("CASMVS_DB_S2") ? atoi(getenv("CASMVS_DB_S2")) : 3;  // A/B switch (profiling); default: double-buffered form
+    static const int db_s2 = trace_env_int("CASMVS_DB_S2", 3);  // A/B switch (profiling); default: double-buffered form
     const bool al2 = W % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
     if (wide_blocks >= 512 && (db_s2 & 1) && al2) return launch_conv16db<FMT_CI, 4, 2, 2, 4, 16, 2>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
     if (wide_blocks < 512 && (db_s2 & 2) && al2) return launch_conv16db<FMT_CI, 4, 1, 1, 4, 16, 2>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
@@ -1972,7 +1961,7 @@ int conv2d_forward(int kind, const float *packed, const float *in, const float *
       // double-buffered kernel (16-byte staging: W % 4 == 0, aligned); otherwise the single-buffer one below
       // A/B-tested (3 repeats on one box): the Cout = 8 (PX) layers gain 11 % (smooth0 132 -> 117 us), the CI layers
       // nothing -> default 1 (bit 0 = PX layers, bit 1 = CI layers)
-      static const int db2d = getenv("CASMVS_DB_2D") ? atoi(getenv("CASMVS_DB_2D")) : 1;
+      static const int db2d = trace_env_int("CASMVS_DB_2D", 1);
       const bool al = W % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
       if (al && (db2d & 1) && c.fmt == FMT_PX) {
         if (out2) return launch_conv16db<FMT_PX, 4, 4, 1, 8, 64, 1, 1, 1>(c, packed, in, out2, out, N, cin, cout, 1, H, W, slope, st);
@@ -1997,7 +1986,7 @@ int conv2d_forward(int kind, const float *packed, const float *in, const float *
       return launch_conv16_v<FMT_CI, 1, 8, 4, 1, 8, 32, 1, 1, 1>(c, packed, in, nullptr, out, N, cin, cout, 1, H, W, 1, H, W, slope, st);
     default: {
       CASMVS_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv2d_forward(K1_UP): odd dims %dx%d", H, W);
-      static const bool no_fpn = getenv("CASMVS_NO_FPN_KERNEL") != nullptr;  // A/B switch (profiling)
+      static const bool no_fpn = trace_env_set("CASMVS_NO_FPN_KERNEL");  // A/B switch (profiling)
       const bool al = ((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out)) & 15) == 0;
       if (!no_fpn && slope == 1.0f && (cin == 8 || cin == 16) && cout <= 64 && W % 4 == 0 && W >= 8 && al && N <= 65535) {
         const size_t lds = (size_t)cout * (cin + 2) * sizeof(float);

@@ -11,97 +11,19 @@
 // volume is ever materialised.  Blocks are mapped so that each XCD owns a contiguous band of
 // image rows: the per-XCD L2 (4 MiB) then only has to hold 1/8 of every source feature map.
 #include "common.h"
+#include "plane_sweep.h"
 
 namespace {
+
+using namespace casmvs_dev;
 
 constexpr int kThreads = 256;
 
 // The 2x2 bilinear footprint is fetched as two 8-byte row pairs (x, x+1): half the vector-memory
-// instructions of four scalar taps.  o_n / o_s are the element offsets of the LEFT element of
-// the north / south pair inside one (h, w) channel plane (clamped so both elements exist);
-// the four weights already carry ATen's zeros padding (weight 0 for a tap outside the image).
-struct Taps {
-  int o_n, o_s;
-  float w_nl, w_nr, w_sl, w_sr;  // north-left, north-right, south-left, south-right
-};
-
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));  // 4-byte aligned pair
-
-// a / b from r = v_rcp_f32(b) (1 ulp) and one Newton step on the quotient: <= 1 ulp from the correctly
-// rounded result (usually equal to it) at 1/3 of the instruction slots of the IEEE expansion.  The seven
-// divisions of a tap set were a third of this VALU-bound kernel's instructions (PMC: ~540 VALU / wave).
-// Non-finite intermediates (depth ~ 0) end as NaN / inf coordinates either way and drop the tap.
-__device__ __forceinline__ float div_by(float a, float b, float rcp_b) {
-  const float q = a * rcp_b;
-  const float r = fmaf(-b, q, a);
-  return fmaf(r, rcp_b, q);
-}
-
-// Coordinates + bilinear taps of ref pixel (x, y) at depth dv in the source view whose
-// (P_src @ inv(P_ref))[:3] is P (12 floats, row-major 3x4).  Follows modules.py:59-89 and
-// ATen's grid_sampler (bilinear, zeros padding, align_corners=True) operation by operation.
-__device__ __forceinline__ Taps plane_sweep_taps(const float *__restrict__ P, float xf, float yf,
-                                                 float dv, int W, int H) {
-  // src_grid_d = R @ (x, y, 1)^T + T / depth                       (modules.py:72)
-  float rx = fmaf(P[2], 1.0f, fmaf(P[1], yf, P[0] * xf));
-  float ry = fmaf(P[6], 1.0f, fmaf(P[5], yf, P[4] * xf));
-  float rz = fmaf(P[10], 1.0f, fmaf(P[9], yf, P[8] * xf));
-  const float rdv = __builtin_amdgcn_rcpf(dv);
-  float qx = rx + div_by(P[3], dv, rdv);
-  float qy = ry + div_by(P[7], dv, rdv);
-  float qz = rz + div_by(P[11], dv, rdv);
-  // negative depth -> somewhere outside the image                  (modules.py:76-79)
-  if (qz <= 1e-7f) {
-    qx = (float)W;
-    qy = (float)H;
-    qz = 1.0f;
-  }
-  const float rqz = __builtin_amdgcn_rcpf(qz);
-  float u = div_by(qx, qz, rqz);  // modules.py:81
-  float v = div_by(qy, qz, rqz);
-  // scale to [-1, 1] (modules.py:83-84) and ATen's un-normalisation (align_corners=True)
-  const float hx = (float)(W - 1) * 0.5f, hy = (float)(H - 1) * 0.5f;
-  float gx = div_by(u, hx, __builtin_amdgcn_rcpf(hx)) - 1.0f;
-  float gy = div_by(v, hy, __builtin_amdgcn_rcpf(hy)) - 1.0f;
-  float ix = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
-  float iy = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
-  float x0 = floorf(ix), y0 = floorf(iy);
-  float tw = ix - x0, te = 1.0f - tw;  // ATen CPU kernel: w = x - x_w, e = 1 - w
-  float tn = iy - y0, ts = 1.0f - tn;
-  // Bounds tests in float: NaN / +-inf / huge coordinates fail every comparison, so the tap is
-  // dropped exactly like ATen's zeros padding and is never converted to an int index.
-  // x: left element of the pair is column xl = clamp(x0, 0, W-2); columns x0 and x0+1 carry
-  // weights te and tw when they exist.
-  const float fW = (float)W, fH = (float)H;
-  float wl, wr;
-  int xl;
-  if (x0 >= 0.0f && x0 <= fW - 2.0f) {        // both columns inside
-    xl = (int)x0; wl = te; wr = tw;
-  } else if (x0 == -1.0f) {                   // only column x0+1 = 0 inside
-    xl = 0; wl = tw; wr = 0.0f;
-  } else if (x0 == fW - 1.0f) {               // only column x0 = W-1 inside
-    xl = W - 2; wl = 0.0f; wr = te;
-  } else {
-    xl = 0; wl = 0.0f; wr = 0.0f;
-  }
-  const bool y0_in = (y0 >= 0.0f) && (y0 <= fH - 1.0f);
-  const bool y1_in = (y0 >= -1.0f) && (y0 <= fH - 2.0f);
-  const int yi0 = y0_in ? (int)y0 : 0;
-  const int yi1 = y1_in ? (int)y0 + 1 : 0;
-  const float wn = y0_in ? ts : 0.0f, wsth = y1_in ? tn : 0.0f;
-  Taps t;
-  t.o_n = yi0 * W + xl;
-  t.o_s = yi1 * W + xl;
-  t.w_nl = wl * wn;   // ATen: nw = e * s, ne = w * s, sw = e * n, se = w * n
-  t.w_nr = wr * wn;
-  t.w_sl = wl * wsth;
-  t.w_sr = wr * wsth;
-  return t;
-}
-
-__device__ __forceinline__ float sample(const float *__restrict__ plane, const Taps &t) {
-  const f32x2u n = *reinterpret_cast<const f32x2u *>(plane + t.o_n);
-  const f32x2u s = *reinterpret_cast<const f32x2u *>(plane + t.o_s);
+// instructions of four scalar taps.
+__device__ __forceinline__ float sample(const float *__restrict__ plane, const Taps &t, int W) {
+  const f32x2u n = *reinterpret_cast<const f32x2u *>(plane + t.yn * W + t.xl);
+  const f32x2u s = *reinterpret_cast<const f32x2u *>(plane + t.ys * W + t.xl);
   return fmaf(s[1], t.w_sr, fmaf(s[0], t.w_sl, fmaf(n[1], t.w_nr, n[0] * t.w_nl)));
 }
 
@@ -134,7 +56,7 @@ __global__ __launch_bounds__(kThreads) void homo_warp_kernel(
   const Taps t = plane_sweep_taps(proj + (size_t)b * 12, (float)x, (float)y, dv, W, H);
   const float *sp = src + (size_t)b * C * hw;
   float *op = out + ((size_t)b * C * D + d) * hw + p;
-  for (int c = 0; c < C; ++c) op[(size_t)c * D * hw] = sample(sp + (size_t)c * hw, t);
+  for (int c = 0; c < C; ++c) op[(size_t)c * D * hw] = sample(sp + (size_t)c * hw, t, W);
 }
 
 // ---- fused warp + aggregation ---------------------------------------------------------------
@@ -173,7 +95,7 @@ __global__ __launch_bounds__(kThreads) void costvol_kernel(
     const float *sp = fb + (size_t)v * C * hw;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      float val = sample(sp + (size_t)c * hw, t);
+      float val = sample(sp + (size_t)c * hw, t, w);
       s[c] = s[c] + val;
       if (MODE == 0) q[c] = fmaf(val, val, q[c]);
     }
@@ -214,12 +136,7 @@ __global__ __launch_bounds__(kThreads) void costvol_kernel(
 // feature maps stored pixel-major (B, V, h, w, C) one bilinear tap of 4 channels is ONE 16-byte load,
 // so a voxel needs C loads per source view instead of 2 C.  Same taps, same weights, same order of
 // operations per channel as costvol_kernel: results are bit-identical.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + imm, 0, 0));
-}
 
 // Lane roles.  A WAVEFRONT owns 64 consecutive pixels of one depth plane and all C channels; the four
 // wavefronts of a workgroup never synchronise with each other:
@@ -232,16 +149,6 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, i
 //   store:   the variance (or the per-channel products of the group-wise correlation) goes through
 //            a wave-private LDS transpose so that the volume is written with lane = (channel,
 //            4 pixels): 16-byte stores, 256 B contiguous per channel.
-// A pointer the compiler must treat as wave-uniform (SGPRs).  Without it LLVM carries the map bases
-// through a divergent region in VGPRs and wraps EVERY buffer load in a waterfall loop (measured:
-// 637 VALU instructions per wave instead of ~300, the kernel became VALU-bound).
-__device__ __forceinline__ const float *uniform_ptr(const float *p) {
-  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-  return reinterpret_cast<const float *>(((unsigned long long)hi << 32) | lo);
-}
-
 __device__ __forceinline__ int lane_bcast_i(int src_lane, int v) {
   return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
 }
@@ -290,14 +197,15 @@ __global__ __launch_bounds__(kThreads, OCC) void costvol_nhwc_kernel(
   }
   for (int v = 1; v < V; ++v) {
     Taps t = plane_sweep_taps(proj + ((size_t)b * (V - 1) + (v - 1)) * 12, (float)xa, (float)ya, dv, w, h);
-    if (pa >= hw) t = Taps{0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (pa >= hw) t = Taps{0, 0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+    const int t_on = t.yn * w + t.xl, t_os = t.ys * w + t.xl;
     const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(uniform_ptr(fb + (size_t)v * view_floats)), 0,
         __builtin_amdgcn_readfirstlane((int)(view_floats * 4)), 0x00020000);
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
       const int pl = it * PPI + pxi;  // the wave-local pixel this lane gathers for
-      const int on0 = (lane_bcast_i(pl, t.o_n) * C + 4 * g) * 4, os0 = (lane_bcast_i(pl, t.o_s) * C + 4 * g) * 4;
+      const int on0 = (lane_bcast_i(pl, t_on) * C + 4 * g) * 4, os0 = (lane_bcast_i(pl, t_os) * C + 4 * g) * 4;
       const float w_nl = lane_bcast_f(pl, t.w_nl), w_nr = lane_bcast_f(pl, t.w_nr);
       const float w_sl = lane_bcast_f(pl, t.w_sl), w_sr = lane_bcast_f(pl, t.w_sr);
       const f32x4 n0 = buf_load4(src, on0, 0), n1 = buf_load4(src, on0, C * 4);

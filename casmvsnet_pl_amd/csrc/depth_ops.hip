@@ -128,7 +128,33 @@ __global__ __launch_bounds__(kThreads) void softmax_regress_kernel(
   if (index) index[(size_t)b * hw + p] = idx;
 }
 
+// ---- depth_regression (modules.py:95-104): sum_k p_k * d_k, d per voxel (B, D, h, w) or per plane (D) -------
+__global__ __launch_bounds__(kThreads) void depth_regression_kernel(const float *__restrict__ prob,
+                                                                   const float *__restrict__ dvals, float *__restrict__ out,
+                                                                   int D, int hw, int per_plane) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= hw) return;
+  const float *pp = prob + (size_t)b * D * hw + p;
+  const float *dp = per_plane ? dvals : dvals + (size_t)b * D * hw + p;
+  const size_t ds = per_plane ? 1 : (size_t)hw;
+  float acc = 0.0f;
+  for (int k = 0; k < D; ++k) acc = acc + pp[(size_t)k * hw] * dp[(size_t)k * ds];
+  out[(size_t)b * hw + p] = acc;
+}
+
 }  // namespace
+
+extern "C" int casmvs_depth_regression_f32(const float *prob, const float *depth_values, float *out, int B, int D,
+                                           int h, int w, int depth_values_per_plane, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(prob && depth_values && out, "depth_regression: null pointer");
+  CASMVS_REQUIRE(B > 0 && B <= 65535 && D > 0 && h > 0 && w > 0, "depth_regression: bad shape B=%d D=%d h=%d w=%d", B, D, h, w);
+  dim3 grid((unsigned)casmvs::ceil_div(h * w, kThreads), (unsigned)B);
+  hipLaunchKernelGGL(depth_regression_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, prob, depth_values, out, D,
+                     h * w, depth_values_per_plane ? 1 : 0);
+  return casmvs::check_launch("depth_regression_kernel");
+}
 
 extern "C" int casmvs_depth_hypotheses_f32(const float *prev_depth, const float *depth_min_b,
                                            const float *interval_b, const float *half_range_b,

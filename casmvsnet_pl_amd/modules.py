@@ -53,15 +53,45 @@ class ConvBnReLU(nn.Module):
         return ops.conv2d_forward(kind, packed, x.float(), self.conv.out_channels, slope=slope)
 
 
+def _folded(bn):
+    """Eval-mode ABN -> (scale, shift, slope) on the host."""
+    if hasattr(bn, "folded_scale_shift"):
+        scale, shift = bn.folded_scale_shift()
+    else:
+        s64 = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        scale, shift = s64.float().cpu(), (bn.bias.detach().double() - bn.running_mean.detach().double() * s64).float().cpu()
+    slope = bn.leaky_slope() if hasattr(bn, "leaky_slope") else float(getattr(bn, "activation_param", 0.01))
+    return scale, shift, slope
+
+
 class ConvBnReLU3D(nn.Module):
+    """modules.py:21-31.  Inside CostRegNet the layer runs as part of casmvs_costreg_forward_f32; called on its own
+    it is one casmvs_conv3d_forward_f32 launch (eval-mode ABN folded into the MFMA conv epilogue)."""
+
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1, norm_act=InPlaceABN):
         super().__init__()
         self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = norm_act(out_channels)
+        self._geometry = (kernel_size, stride, pad)
+        self._packed = None
 
     def forward(self, x):
-        raise RuntimeError("ConvBnReLU3D is executed by the fused MI355X CostRegNet engine "
-                           "(casmvsnet_pl_amd.mvsnet.CostRegNet.forward), not layer by layer")
+        if not x.is_cuda:
+            raise RuntimeError("casmvsnet_pl_amd.ConvBnReLU3D runs on the MI355X only; there is no CPU fallback")
+        if self.training:
+            raise RuntimeError("casmvsnet_pl_amd.ConvBnReLU3D is an inference engine (eval-mode ABN folded into the "
+                               "MFMA conv epilogue); call model.eval().")
+        kind = {(3, 1, 1): ops.CONV_S1, (3, 2, 1): ops.CONV_S2}.get(self._geometry)
+        if kind is None:
+            raise RuntimeError(f"ConvBnReLU3D: (kernel, stride, pad) = {self._geometry} is not a CostRegNet layer shape "
+                               "(3,1,1) or (3,2,1)")
+        key = (str(x.device),) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        if self._packed is None or self._packed[0] != key:
+            scale, shift, slope = _folded(self.bn)
+            self._packed = (key, ops.conv3d_pack(kind, self.conv.weight, scale, shift).to(x.device), slope)
+        _, packed, slope = self._packed
+        with torch.no_grad():
+            return ops.conv3d_forward(kind, packed, x.float(), self.conv.out_channels, None, slope)
 
 
 def _per_sample(value, B, device):
@@ -91,11 +121,11 @@ def homo_warp(src_feat, proj_mat, depth_values):
 
 
 def depth_regression(p, depth_values):
-    """p (B,D,H,W); depth_values (B,D,H,W) or (D) -> (B,H,W)   (modules.py:95-104).
-    Kept for API parity only: the engine never calls it (softmax, regression and confidence are one kernel,
-    casmvs_softmax_regress_f32).  A device-side torch reduction; like every op here it refuses CPU tensors."""
+    """p (B,D,H,W); depth_values (B,D,H,W) or (D) -> (B,H,W)   (modules.py:95-104), one casmvs_depth_regression_f32
+    launch.  The engine's forward never calls it (softmax, regression and confidence are one kernel,
+    casmvs_softmax_regress_f32); like every op here it refuses CPU tensors."""
     if not p.is_cuda:
         raise RuntimeError("casmvsnet_pl_amd.depth_regression runs on the MI355X only; there is no CPU fallback")
-    if depth_values.dim() == 1:
-        depth_values = depth_values.view(1, -1, 1, 1)
-    return (p * depth_values.to(p.device)).sum(1).to(depth_values.dtype)
+    if depth_values.dim() not in (1, 4):
+        depth_values = depth_values.reshape(-1) if depth_values.numel() == p.shape[1] else depth_values.expand_as(p)
+    return ops.depth_regression(p.float(), depth_values.float()).to(depth_values.dtype)

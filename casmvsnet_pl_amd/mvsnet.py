@@ -264,6 +264,12 @@ class CascadeMVSNet(nn.Module):
     def forward(self, imgs, proj_mats, init_depth_min, depth_interval):
         """imgs (B,V,3,H,W); proj_mats (B,V-1,levels,3,4) fine->coarse; init_depth_min,
         depth_interval: float or (B,1) tensor.  Returns {"depth_l", "confidence_l"} for l in 0..2."""
+        if self.training:
+            # checked BEFORE the no_grad region below (inside it the sub-modules' own guards cannot fire): a
+            # train-mode call would otherwise silently run eval-mode ABN and return grad-less outputs
+            raise RuntimeError("casmvsnet_pl_amd.CascadeMVSNet.forward is the inference engine (eval-mode ABN folded "
+                               "into the MFMA conv epilogues, no autograd graph): call model.eval().  Training through "
+                               "the HIP ops is available op by op (casmvsnet_pl_amd.autograd), not as a whole model.")
         if not imgs.is_cuda:
             raise RuntimeError("casmvsnet_pl_amd.CascadeMVSNet runs on the MI355X only: move the model and inputs "
                                "to 'cuda' (ROCm). There is no CPU fallback.")

@@ -31,18 +31,29 @@ def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def homo_warp(src_feat, proj_mat, depth_values):
-    """modules.py:52-92.  (B,C,H,W), (B,3,4), (B,D,H,W) -> (B,C,D,H,W)."""
+def homo_warp(src_feat, proj_mat, depth_values, impl="auto"):
+    """modules.py:52-92.  (B,C,H,W), (B,3,4), (B,D,H,W) -> (B,C,D,H,W).
+    impl: "lds" = pixel-major copy of src + casmvs_homo_warp_nhwc_f32 (source box staged in LDS), "gather" =
+    casmvs_homo_warp_f32 (NCHW gathers), "auto" = "lds" when the shape has an LDS plan.  Bit-identical results."""
     src_feat, proj_mat, depth_values = _dev(src_feat, "src_feat"), _dev(proj_mat, "proj_mat"), _dev(depth_values, "depth_values")
     B, C, H, W = src_feat.shape
     D = depth_values.shape[1]
     if proj_mat.shape != (B, 3, 4) or depth_values.shape != (B, D, H, W):
         raise ValueError(f"homo_warp: shapes {tuple(src_feat.shape)} {tuple(proj_mat.shape)} {tuple(depth_values.shape)}")
+    lib = _lib.load()
+    if impl == "auto":
+        impl = "lds" if C in (8, 16, 32) and lib.casmvs_costvol_lds_supported(C, W, D, 1, 1) else "gather"
     out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=src_feat.device)
     with torch.cuda.device(src_feat.device):
-        rc = _lib.load().casmvs_homo_warp_f32(_ptr(src_feat), _ptr(proj_mat), _ptr(depth_values), _ptr(out),
-                                              B, C, H, W, D, _stream(src_feat))
-    _lib.check(rc, "casmvs_homo_warp_f32")
+        if impl == "lds":
+            nhwc = nchw_to_nhwc(src_feat)
+            rc = lib.casmvs_homo_warp_nhwc_f32(_ptr(nhwc), _ptr(proj_mat), _ptr(depth_values), _ptr(out),
+                                               B, C, H, W, D, _stream(src_feat))
+            _lib.check(rc, "casmvs_homo_warp_nhwc_f32")
+        else:
+            rc = lib.casmvs_homo_warp_f32(_ptr(src_feat), _ptr(proj_mat), _ptr(depth_values), _ptr(out),
+                                          B, C, H, W, D, _stream(src_feat))
+            _lib.check(rc, "casmvs_homo_warp_f32")
     return out
 
 
@@ -57,11 +68,14 @@ def nchw_to_nhwc(x):
     return out
 
 
-def costvol(feats, proj_mats, depth_values, num_groups=1, channels_last=False):
+def costvol(feats, proj_mats, depth_values, num_groups=1, channels_last=False, impl="auto"):
     """Fused plane sweep + aggregation (mvsnet.py:134-172).
-    feats (B,V,C,h,w) - or (B,V,h,w,C) with channels_last=True, the faster kernel -,
+    feats (B,V,C,h,w) - or (B,V,h,w,C) with channels_last=True, the faster kernels -,
     proj_mats (B,V-1,3,4), depth_values (B,D,h,w) ->
-    (B,C,D,h,w) variance volume (num_groups == 1) or (B,G,D,h,w) group-wise correlation."""
+    (B,C,D,h,w) variance volume (num_groups == 1) or (B,G,D,h,w) group-wise correlation.
+    impl (channels_last only): "lds" = source boxes staged in LDS (casmvs_costvol_*_lds_f32), "gather" = the
+    texture-path gather kernels (casmvs_costvol_*_nhwc_f32), "auto" = "lds" when the shape has an LDS plan.
+    All three kernel families give bit-identical volumes."""
     feats, proj_mats, depth_values = _dev(feats, "feats"), _dev(proj_mats, "proj_mats"), _dev(depth_values, "depth_values")
     if channels_last:
         B, V, h, w, C = feats.shape
@@ -71,7 +85,12 @@ def costvol(feats, proj_mats, depth_values, num_groups=1, channels_last=False):
     if proj_mats.shape != (B, V - 1, 3, 4) or depth_values.shape != (B, D, h, w):
         raise ValueError(f"costvol: shapes {tuple(feats.shape)} {tuple(proj_mats.shape)} {tuple(depth_values.shape)}")
     lib = _lib.load()
-    sfx = "_nhwc" if channels_last else ""
+    if not channels_last:
+        sfx = ""
+    else:
+        if impl == "auto":
+            impl = "lds" if lib.casmvs_costvol_lds_supported(C, w, D, V - 1, num_groups) else "gather"
+        sfx = "_lds" if impl == "lds" else "_nhwc"
     with torch.cuda.device(feats.device):
         if num_groups == 1:
             out = torch.empty((B, C, D, h, w), dtype=torch.float32, device=feats.device)
@@ -84,6 +103,48 @@ def costvol(feats, proj_mats, depth_values, num_groups=1, channels_last=False):
                                                               B, V, C, num_groups, h, w, D, _stream(feats))
             _lib.check(rc, f"casmvs_costvol_gwc{sfx}_f32")
     return out
+
+
+def costvol_partial(feats_nhwc, proj_mats, depth_values, view_begin, view_end, num_groups=1, include_ref=True):
+    """Partial sums of the view-sharded cost volume: the source views [view_begin, view_end)
+    (1-based; view 0 is the reference) of feats_nhwc (B,V,h,w,C).
+    num_groups == 1: -> (sum, sq), each (B,C,D,h,w), `include_ref` adds ref / ref^2 (exactly one rank does);
+    num_groups  > 1: -> (B,G,D,h,w) group means of (sum of the warped views) * ref.
+    Finalise (after the all-reduce) with costvol_finalize."""
+    feats, proj_mats, depth_values = _dev(feats_nhwc, "feats"), _dev(proj_mats, "proj_mats"), _dev(depth_values, "depth_values")
+    B, V, h, w, C = feats.shape
+    D = depth_values.shape[1]
+    if proj_mats.shape != (B, V - 1, 3, 4) or depth_values.shape != (B, D, h, w):
+        raise ValueError(f"costvol_partial: shapes {tuple(feats.shape)} {tuple(proj_mats.shape)} {tuple(depth_values.shape)}")
+    lib = _lib.load()
+    with torch.cuda.device(feats.device):
+        if num_groups == 1:
+            both = torch.empty((2, B, C, D, h, w), dtype=torch.float32, device=feats.device)  # one buffer: one all-reduce
+            rc = lib.casmvs_costvol_partial_var_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(both[0]), _ptr(both[1]),
+                                                    B, V, C, h, w, D, view_begin, view_end, int(bool(include_ref)), _stream(feats))
+            _lib.check(rc, "casmvs_costvol_partial_var_f32")
+            return both
+        out = torch.empty((B, num_groups, D, h, w), dtype=torch.float32, device=feats.device)
+        rc = lib.casmvs_costvol_partial_gwc_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(out),
+                                                B, V, C, num_groups, h, w, D, view_begin, view_end, _stream(feats))
+        _lib.check(rc, "casmvs_costvol_partial_gwc_f32")
+        return out
+
+
+def costvol_finalize(partial, V, num_groups=1):
+    """(sum, sq) stacked as (2,B,C,D,h,w) -> variance (B,C,D,h,w) (mvsnet.py:167); or the all-reduced correlation
+    (B,G,D,h,w) -> / (V-1) (mvsnet.py:171), in place."""
+    partial = _dev(partial, "partial")
+    lib = _lib.load()
+    with torch.cuda.device(partial.device):
+        if num_groups == 1:
+            out = partial[0]
+            rc = lib.casmvs_costvol_var_finalize_f32(_ptr(partial[0]), _ptr(partial[1]), _ptr(out), out.numel(), V, _stream(partial))
+            _lib.check(rc, "casmvs_costvol_var_finalize_f32")
+            return out
+        rc = lib.casmvs_costvol_gwc_finalize_f32(_ptr(partial), _ptr(partial), partial.numel(), V, _stream(partial))
+        _lib.check(rc, "casmvs_costvol_gwc_finalize_f32")
+        return partial
 
 
 def depth_hypotheses(prev_depth, depth_min_b, interval_b, half_range_b, D, h, w):
@@ -122,6 +183,21 @@ def softmax_regress(cost, depth_values, return_index=False):
                                                     _ptr(index), B, D, h, w, _stream(cost))
     _lib.check(rc, "casmvs_softmax_regress_f32")
     return (depth, conf, index) if return_index else (depth, conf)
+
+
+def depth_regression(p, depth_values):
+    """modules.py:95-104.  p (B,D,h,w); depth_values (B,D,h,w) or (D,) -> (B,h,w)  (casmvs_depth_regression_f32)."""
+    p = _dev(p, "p")
+    depth_values = _dev(depth_values.to(p.device), "depth_values")
+    B, D, h, w = p.shape
+    per_plane = depth_values.dim() == 1
+    if (per_plane and depth_values.shape[0] != D) or (not per_plane and tuple(depth_values.shape) != (B, D, h, w)):
+        raise ValueError(f"depth_regression: shapes {tuple(p.shape)} {tuple(depth_values.shape)}")
+    out = torch.empty((B, h, w), dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        rc = _lib.load().casmvs_depth_regression_f32(_ptr(p), _ptr(depth_values), _ptr(out), B, D, h, w, int(per_plane), _stream(p))
+    _lib.check(rc, "casmvs_depth_regression_f32")
+    return out
 
 
 def conv3d_pack(kind, weight, scale=None, shift=None):

@@ -63,14 +63,17 @@ def dtu_like_cameras(V, H, W, depth_mid=680.0, baseline=60.0, levels=3):
     return views
 
 
-def make_inputs(B=1, V=3, H=512, W=640, seed=0, geometry="dtu", levels=3):
-    """-> imgs (B,V,3,H,W), proj_mats (B,V-1,levels,3,4), init_depth_min (float), depth_interval (float)."""
+def make_inputs(B=1, V=3, H=512, W=640, seed=0, geometry="dtu", levels=3, depth_scale=1.0):
+    """-> imgs (B,V,3,H,W), proj_mats (B,V-1,levels,3,4), init_depth_min (float), depth_interval (float).
+    depth_scale: the scene (camera baselines and the depth the rig converges on) is scaled by this factor -
+    BlendedMVS rescales every scene so that depth_min = 100 (blendedmvs.py:98-104); the returned depth range is
+    DTU's and must then be replaced by the caller (blendedmvs_like_interval)."""
     g = torch.Generator().manual_seed(seed)
     imgs = torch.randn(B, V, 3, H, W, generator=g, dtype=torch.float32)
     proj = []
     for b in range(B):
         if geometry == "dtu":
-            cams = dtu_like_cameras(V, H, W, baseline=60.0 * (1.0 + 0.1 * b), levels=levels)
+            cams = dtu_like_cameras(V, H, W, depth_mid=680.0 * depth_scale, baseline=60.0 * (1.0 + 0.1 * b) * depth_scale, levels=levels)
         elif geometry == "random":
             # near-identity homographies + translations of mixed sign: exercises out-of-bounds taps
             # and the z <= 1e-7 branch (modules.py:76-79)
@@ -95,6 +98,27 @@ def blendedmvs_like_interval(depth_min=100.0, depth_max=100.0 * 935.0 / 425.0, n
     """BlendedMVS: scenes are rescaled so depth_min -> 100 (blendedmvs.py:98-104) and
     depth_interval = (depth_max - depth_min) / 192 (blendedmvs.py:170-173)."""
     return depth_min, (depth_max - depth_min) / n_intervals
+
+
+# The BASELINE.json workloads: name -> (H, W, V, num_groups, n_depths, interval_ratios, depth range kind)
+CONFIGS = {
+    "dtu_640x512_v3_var": (512, 640, 3, 1, (8, 32, 48), (1.0, 2.0, 4.0), "dtu"),
+    "dtu_640x512_v3_gwc8": (512, 640, 3, 8, (8, 32, 48), (1.0, 2.0, 4.0), "dtu"),
+    "dtu_1152x864_v5_var": (864, 1152, 5, 1, (8, 32, 48), (1.0, 2.0, 4.0), "dtu"),
+    "blended_768x576_v7_var": (576, 768, 7, 1, (8, 32, 48), (1.0, 2.0, 4.0), "blended"),
+}
+
+
+def config_inputs(name, B=1, seed=0):
+    """Synthetic inputs of a BASELINE workload: imgs, proj_mats, init_depth_min, depth_interval.  The BlendedMVS
+    config uses that dataset's scene scaling: depth_min -> 100 and depth_interval = (depth_max - depth_min) / 192
+    (blendedmvs.py:98-104,170-173), with the whole rig scaled accordingly."""
+    H, W, V, _, _, _, kind = CONFIGS[name]
+    if kind == "blended":
+        dmin, dint = blendedmvs_like_interval()
+        imgs, proj, _, _ = make_inputs(B, V, H, W, seed=seed, depth_scale=dmin / DTU_DEPTH_MIN)
+        return imgs, proj, dmin, dint
+    return make_inputs(B, V, H, W, seed=seed)
 
 
 def randomize_state_dict(state_dict, seed=0, prob_gain=(0.2, 0.5, 2.0)):

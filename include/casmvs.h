@@ -18,7 +18,8 @@
  *   - device pointers are raw `hipDeviceptr`-style `float*` on the calling thread's current
  *     device; `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).
  *   - fully asynchronous on `stream`: no internal synchronisation, re-entrant; the only global state
- *     is a mutex-protected cache of per-kernel launch constants (occupancy, LDS opt-in).  Inputs
+ *     is a mutex-protected cache of per-(device, kernel) launch constants (occupancy, LDS opt-in); the
+ *     library never reads the environment.  Inputs
  *     are `const`; outputs must not alias inputs.
  *   - built with `hipcc --offload-arch=gfx950` only.  No CPU fallback exists: on a machine
  *     without a gfx950 device the launch entry points fail with CASMVS_ERR_HIP.
@@ -106,6 +107,42 @@ int casmvs_costvol_var_nhwc_f32(const float *feats, const float *proj, const flo
                                 int B, int V, int C, int h, int w, int D, void *stream);
 int casmvs_costvol_gwc_nhwc_f32(const float *feats, const float *proj, const float *depth, float *out,
                                 int B, int V, int C, int G, int h, int w, int D, void *stream);
+
+/* ---- LDS-staged plane sweep (the fast path) ---------------------------------------------------
+ * Same operations and results (bit-identical) as the *_nhwc gather kernels above, but the box of source pixels
+ * a tile of 256 reference pixels reaches over a chunk of 8 depth planes is staged once in LDS and every
+ * bilinear tap is an LDS read (the gather kernels are bound by the CU's texture path, not by HBM).
+ * feats (B, V, h, w, C) pixel-major, C in {8, 16, 32}; D % 8 == 0; at most 8 source views per call.
+ * casmvs_costvol_lds_supported: 1 when a shape has an LDS plan (otherwise use the *_nhwc kernels).
+ * casmvs_homo_warp_nhwc_f32 replaces models/modules.py:52-92 for a pixel-major source map (B, H, W, C):
+ *   out (B, C, D, H, W) exactly as casmvs_homo_warp_f32. */
+int casmvs_costvol_lds_supported(int C, int w, int D, int n_src_views, int G);
+int casmvs_costvol_var_lds_f32(const float *feats, const float *proj, const float *depth, float *out,
+                               int B, int V, int C, int h, int w, int D, void *stream);
+int casmvs_costvol_gwc_lds_f32(const float *feats, const float *proj, const float *depth, float *out,
+                               int B, int V, int C, int G, int h, int w, int D, void *stream);
+int casmvs_homo_warp_nhwc_f32(const float *src, const float *proj, const float *depth, float *out,
+                              int B, int C, int H, int W, int D, void *stream);
+
+/* ---- view-sharded build (BASELINE configs 4/5) --------------------------------------
+ * The sums of models/mvsnet.py:147-167 are linear in the source views: a rank warps the source views
+ * [view_begin, view_end) (1-based indices into feats' view axis, view 0 = reference) and produces
+ *   variance:    sum = [ref] + SUM_v warped_v,  sq = [ref^2] + SUM_v warped_v^2     (B, C, D, h, w) each;
+ *                include_ref != 0 on exactly one rank adds the bracketed terms;
+ *   correlation: out = mean_{c in group}( (SUM_v warped_v) * ref )                   (B, G, D, h, w).
+ * After an all-reduce(SUM) of those buffers every rank finalises:
+ *   var = sq / V - (sum / V)^2   (casmvs_costvol_var_finalize_f32; may run in place, out == sum or sq)
+ *   cor = out / (V - 1)          (casmvs_costvol_gwc_finalize_f32; may run in place).
+ * With a single rank (views [1, V), include_ref = 1) partial + finalise equals the fused kernels bit for bit.
+ * n = number of floats (a multiple of 4). */
+int casmvs_costvol_partial_var_f32(const float *feats, const float *proj, const float *depth, float *sum,
+                                   float *sq, int B, int V, int C, int h, int w, int D, int view_begin,
+                                   int view_end, int include_ref, void *stream);
+int casmvs_costvol_partial_gwc_f32(const float *feats, const float *proj, const float *depth, float *out,
+                                   int B, int V, int C, int G, int h, int w, int D, int view_begin,
+                                   int view_end, void *stream);
+int casmvs_costvol_var_finalize_f32(const float *sum, const float *sq, float *out, size_t n, int V, void *stream);
+int casmvs_costvol_gwc_finalize_f32(const float *in, float *out, size_t n, int V, void *stream);
 
 /* ---- (a8) CostRegNet 3D convolutions (fp32 MFMA) -------------------------------------------
  * Replaces: models/mvsnet.py:60-104 `CostRegNet` and models/modules.py:21-31 `ConvBnReLU3D`
@@ -201,6 +238,12 @@ int casmvs_featurenet_forward_f32(const float *const *packed_layers, const float
 int casmvs_softmax_regress_f32(const float *cost, const float *depth_values, float *depth,
                                float *confidence, int32_t *index, int B, int D, int h, int w,
                                void *stream);
+
+/* Replaces: models/modules.py:95-104 `depth_regression(p, depth_values)` on its own (the engine's forward uses the
+ * fused kernel above): out[b, y, x] = sum_k prob[b, k, y, x] * d, with d = depth_values[b, k, y, x]
+ * (depth_values_per_plane == 0, shape (B, D, h, w)) or depth_values[k] (depth_values_per_plane != 0, shape (D)). */
+int casmvs_depth_regression_f32(const float *prob, const float *depth_values, float *out, int B, int D,
+                                int h, int w, int depth_values_per_plane, void *stream);
 
 /* ---- self test ------------------------------------------------------------------------------
  * Runs the MFMA lane-mapping probes the conv kernels rely on (v_mfma_f32_16x16x4_f32 operand /

@@ -2,9 +2,17 @@
 against the oracle (oracle/cpu_restatement.py, pinned to the real reference by tests/test_oracle.py)
 on the same seeded inputs, plus end-to-end parity against the committed golden fixtures.
 
-Tolerances (written here, per north_star): depth within 1e-3 relative (measured ~1e-6..1e-5);
-depth index = clamp(trunc(sum_k p_k k)) identical except for pixels whose expected index sits
-within 1e-3 of an integer boundary (the oracle's own 1-thread vs 8-thread noise class).
+Tolerances.  north_star's bar: depth within 1e-3 relative, depth index = clamp(trunc(sum_k p_k k)) identical.
+What the tests assert is tighter - at most ~10x what was MEASURED on the MI355X (profiles/*parity_report.json),
+so that a regression of one order of magnitude fails although it would still meet the bar:
+  depth 1e-4 relative (measured 3e-6..8e-6); homo_warp 1.5e-4 abs (1.3e-5); cost volume 5e-5 of its range
+  (4.6e-6); conv layers 1.2e-5 of the range (1.1e-6); hypotheses 3e-6 rel (2.7e-7); confidence 5e-4 abs on
+  pixels with equal index (4.5e-5).
+Depth index: every pixel whose index differs from the oracle's must have an expected index e = sum_k p_k k
+within 1e-3 of an integer - trunc() is discontinuous there and the oracle's own 1-thread vs 8-thread runs
+already differ by 1e-5 in e - and each such pixel is listed in the parity report with its
+distance to the boundary.  Anywhere else a different index fails the test.
+The three cost-volume kernel families (NCHW gather, pixel-major gather, LDS-staged) must agree BIT FOR BIT.
 """
 import pytest
 import torch
@@ -41,7 +49,8 @@ def _proj_like(B, V, H, W, seed, geometry="dtu", level=0):
 
 
 @pytest.mark.parametrize("B,C,H,W,D,geometry", [(1, 8, 32, 40, 8, "dtu"), (2, 32, 24, 56, 5, "dtu"),
-                                                (1, 3, 17, 23, 4, "random"), (1, 16, 64, 80, 48, "dtu")])
+                                                (1, 3, 17, 23, 4, "random"), (1, 16, 64, 80, 48, "dtu"),
+                                                (2, 32, 40, 72, 16, "dtu"), (1, 8, 20, 30, 8, "random")])
 def test_homo_warp_matches_oracle(dev, report, B, C, H, W, D, geometry):
     g = torch.Generator().manual_seed(B * 1000 + C * 10 + D)
     src = torch.randn(B, C, H, W, generator=g)
@@ -52,19 +61,25 @@ def test_homo_warp_matches_oracle(dev, report, B, C, H, W, D, geometry):
         depth[:, 0] = 1e-9      # tiny positive depth: huge coordinates
         depth[:, 1] = -50.0     # negative depth
     want = R.homo_warp(src, proj, depth)
-    got = _ops().homo_warp(src.to(dev), proj.to(dev), depth.to(dev)).cpu()
+    got = _ops().homo_warp(src.to(dev), proj.to(dev), depth.to(dev), impl="gather").cpu()
     assert torch.isfinite(got).all()
     err = max_abs(got, want)
     report("homo_warp", shape=[B, C, H, W, D], geometry=geometry, max_abs=err, nonzero_frac=float((want != 0).float().mean()))
-    assert err < 2e-3  # bilinear is continuous: |d value| <= |grad| * coordinate noise (~1e-4 px)
+    assert err < 1.5e-4  # measured 1.3e-5: bilinear is continuous, |d value| <= |grad| * coordinate noise (~1e-5 px)
     assert float(((got != 0) != (want != 0)).float().mean()) < 1e-3  # same in/out-of-bounds pattern
+    if C in (8, 16, 32) and D % 8 == 0:  # the LDS-staged form of the un-fused op: same arithmetic, same bits
+        assert torch.equal(_ops().homo_warp(src.to(dev), proj.to(dev), depth.to(dev), impl="lds").cpu(), got)
 
 
 @pytest.mark.parametrize("B,V,C,G,h,w,D,geometry", [
     (1, 3, 8, 1, 32, 40, 8, "dtu"), (1, 3, 16, 1, 32, 48, 32, "dtu"), (2, 5, 32, 1, 16, 24, 48, "dtu"),
     (1, 2, 4, 1, 20, 28, 3, "dtu"), (1, 3, 6, 1, 20, 28, 3, "random"), (1, 7, 8, 1, 24, 32, 8, "dtu"),
     (1, 3, 32, 8, 16, 24, 48, "dtu"), (1, 3, 16, 8, 32, 48, 32, "dtu"), (1, 3, 8, 8, 32, 40, 8, "dtu"),
-    (2, 4, 16, 4, 16, 24, 8, "random"), (1, 3, 32, 2, 16, 24, 8, "dtu")])
+    (2, 4, 16, 4, 16, 24, 8, "random"), (1, 3, 32, 2, 16, 24, 8, "dtu"),
+    # LDS-staged kernel: partial tiles (w % 32 != 0, h % 8 != 0), w % 4 != 0 (scalar stores), 64-wide tiles, 7 views
+    (1, 3, 16, 1, 44, 72, 16, "dtu"), (1, 3, 8, 1, 21, 30, 8, "dtu"), (2, 3, 16, 1, 16, 128, 8, "dtu"),
+    (1, 7, 8, 1, 24, 64, 8, "dtu"), (1, 9, 8, 1, 16, 32, 8, "dtu"), (1, 3, 32, 1, 24, 40, 8, "random"),
+    (1, 5, 16, 8, 24, 64, 16, "dtu")])
 def test_costvol_matches_oracle(dev, report, B, V, C, G, h, w, D, geometry):
     g = torch.Generator().manual_seed(V * 100 + C + G)
     feats = torch.randn(B, V, C, h, w, generator=g)
@@ -75,12 +90,59 @@ def test_costvol_matches_oracle(dev, report, B, V, C, G, h, w, D, geometry):
     err = max_abs(got, want)
     report("costvol", shape=[B, V, C, G, h, w, D], geometry=geometry, max_abs=err, ref_absmax=float(want.abs().max()))
     assert got.shape == want.shape and torch.isfinite(got).all()
-    assert err < 5e-3 * max(1.0, float(want.abs().max()))
-    if C in (8, 16, 32):  # the channel-last kernel does the same arithmetic in the same order: bit-identical
+    assert err < 5e-5 * max(1.0, float(want.abs().max()))  # measured 4.6e-6
+    if C in (8, 16, 32):  # the channel-last kernels do the same arithmetic in the same order: bit-identical
         nhwc = _ops().nchw_to_nhwc(feats.reshape(B * V, C, h, w).to(dev))
         assert torch.equal(nhwc.cpu(), feats.reshape(B * V, C, h, w).permute(0, 2, 3, 1).contiguous())
-        got2 = _ops().costvol(nhwc.view(B, V, h, w, C), proj.to(dev), depth.to(dev), G, channels_last=True).cpu()
+        got2 = _ops().costvol(nhwc.view(B, V, h, w, C), proj.to(dev), depth.to(dev), G, channels_last=True, impl="gather").cpu()
         assert torch.equal(got2, got)
+        if D % 8 == 0:
+            got3 = _ops().costvol(nhwc.view(B, V, h, w, C), proj.to(dev), depth.to(dev), G, channels_last=True, impl="lds").cpu()
+            assert torch.equal(got3, got)
+
+
+@pytest.mark.parametrize("C,G,h,w,D", [(8, 1, 64, 128, 8), (16, 1, 48, 64, 32), (32, 1, 32, 64, 16), (16, 8, 48, 64, 8)])
+def test_costvol_lds_with_taps_outside_the_box(dev, report, C, G, h, w, D):
+    """Per-pixel depth noise of hundreds of units scatters the taps of a tile over far more source pixels than a
+    view's LDS box holds: the lanes whose taps fall outside gather from the global map.  Same bits either way."""
+    V, B = 3, 1
+    g = torch.Generator().manual_seed(C + D)
+    feats = torch.randn(B, V, C, h, w, generator=g)
+    proj, dmin, dint = _proj_like(B, V, h, w, seed=3, level=1)
+    depth = 430.0 + 500.0 * torch.rand(B, 1, h, w, generator=g) + torch.arange(D).view(1, D, 1, 1) * dint * 2
+    nhwc = _ops().nchw_to_nhwc(feats.reshape(B * V, C, h, w).to(dev)).view(B, V, h, w, C)
+    a = _ops().costvol(nhwc, proj.to(dev), depth.to(dev), G, channels_last=True, impl="gather")
+    b = _ops().costvol(nhwc, proj.to(dev), depth.to(dev), G, channels_last=True, impl="lds")
+    want = R.cost_volume(feats, proj, depth, G)
+    report("costvol_lds_noisy", shape=[C, G, h, w, D], max_abs=max_abs(b.cpu(), want))
+    assert torch.equal(a, b)
+    assert max_abs(b.cpu(), want) < 5e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("V,C,G,h,w,D", [(3, 16, 1, 32, 64, 16), (5, 8, 1, 24, 32, 8), (5, 32, 8, 16, 32, 8), (4, 16, 4, 24, 40, 8)])
+def test_view_sharded_partial_sums(dev, report, V, C, G, h, w, D):
+    """Sum x / Sum x^2 (and the correlation) are linear in the source views.  One rank (all views,
+    include_ref) + finalise == the fused kernel bit for bit; two ranks' partial sums added == fused to rounding."""
+    ops = _ops()
+    B = 2
+    g = torch.Generator().manual_seed(V * 7 + C)
+    feats = torch.randn(B, V, C, h, w, generator=g)
+    proj, dmin, dint = _proj_like(B, V, h, w, seed=V)
+    depth = dmin + torch.rand(B, 1, h, w, generator=g) * 300.0 + torch.arange(D).view(1, D, 1, 1) * dint * 2
+    nhwc = ops.nchw_to_nhwc(feats.reshape(B * V, C, h, w).to(dev)).view(B, V, h, w, C)
+    P, dv = proj.to(dev), depth.to(dev)
+    fused = ops.costvol(nhwc, P, dv, G, channels_last=True, impl="lds")
+    one = ops.costvol_finalize(ops.costvol_partial(nhwc, P, dv, 1, V, G, include_ref=True), V, G)
+    assert torch.equal(one, fused)
+    mid = 1 + (V - 1) // 2
+    p0 = ops.costvol_partial(nhwc, P, dv, 1, mid, G, include_ref=True)     # "rank 0": views [1, mid) + the reference terms
+    p1 = ops.costvol_partial(nhwc, P, dv, mid, V, G, include_ref=False)    # "rank 1": views [mid, V)
+    two = ops.costvol_finalize(p0 + p1, V, G)                               # the all-reduce(SUM), then every rank finalises
+    err = scaled_err(two, fused)
+    report("view_sharded_partial", shape=[V, C, G, h, w, D], scaled_err=err)
+    assert err < 2e-6  # a different summation order of the same terms
+    want = R.cost_volume(feats, proj, depth, G)
+    assert max_abs(two.cpu(), want) < 5e-5 * max(1.0, float(want.abs().max()))
 
 
 def test_costvol_identical_views_have_zero_variance(dev):
@@ -103,7 +165,7 @@ def test_depth_hypotheses_match_oracle(dev, report, B, D, hp, wp):
     got = _ops().depth_hypotheses(prev.to(dev), None, interval.view(B).to(dev), half.to(dev), D, 2 * hp, 2 * wp).cpu()
     err = rel_err(got, want)
     report("hypotheses", shape=[B, D, hp, wp], rel=err)
-    assert err < 5e-6  # bilinear x2 weights: ATen's separable order vs ours, a few ulp
+    assert err < 3e-6  # measured 2.7e-7: bilinear x2 weights, ATen's separable order vs ours, a few ulp
     # coarsest level
     want0 = R.initial_depth_values(425.0, 2.65 * 4.0, D, B, hp, wp)
     got0 = _ops().depth_hypotheses(None, torch.full((B,), 425.0, device=dev), torch.full((B,), 2.65 * 4.0, device=dev),
@@ -129,9 +191,9 @@ def test_softmax_regress_matches_oracle(dev, report, B, D, h, w):
     mism = (i_g != i_w)
     report("softmax_regress", shape=[B, D, h, w], depth_rel=rel_err(d_g, d_w), conf_abs=max_abs(c_g, c_w),
            index_mismatch=int(mism.sum()), index_mismatch_off_boundary=int((mism & ~near).sum()))
-    assert rel_err(d_g, d_w) < 1e-5
+    assert rel_err(d_g, d_w) < 5e-6  # measured 4.5e-7
     assert int((mism & ~near).sum()) == 0
-    assert max_abs(c_g[~mism], c_w[~mism]) < 1e-5
+    assert max_abs(c_g[~mism], c_w[~mism]) < 2e-6  # measured 1.2e-7
     assert float(d_g[0, 0, 0]) == pytest.approx(float(dv[0, D - 1, 0, 0]), rel=1e-6)
 
 
@@ -179,7 +241,7 @@ def test_conv3d_layer_matches_torch_cpu(dev, report, kind, cin, cout, B, D, H, W
     err = scaled_err(got, want)
     report("conv3d", kind=kind, cin=cin, cout=cout, shape=[B, D, H, W], scaled_err=err, max_abs=max_abs(got, want))
     assert got.shape == want.shape
-    assert err < 2e-5
+    assert err < 1.2e-5  # measured <= 1.1e-6
 
 
 @pytest.mark.parametrize("cin,B,D,h,w", [(8, 1, 8, 32, 40), (16, 1, 32, 16, 24), (32, 2, 16, 16, 16)])
@@ -197,7 +259,7 @@ def test_costreg_matches_oracle(dev, report, cin, B, D, h, w):
     err = scaled_err(got, want)
     report("costreg", cin=cin, shape=[B, D, h, w], scaled_err=err)
     assert got.shape == want.shape
-    assert err < 5e-5
+    assert err < 1.2e-5  # measured 1.1e-6
 
 
 CONV2D_CASES = [  # kind, cin, cout, N, H, W
@@ -230,7 +292,7 @@ def test_conv2d_layer_matches_torch_cpu(dev, report, kind, cin, cout, N, H, W):
     err = scaled_err(got, want)
     report("conv2d", kind=kind, cin=cin, cout=cout, shape=[N, H, W], scaled_err=err, max_abs=max_abs(got, want))
     assert got.shape == want.shape
-    assert err < 2e-5
+    assert err < 1e-5  # measured <= 7e-7
 
 
 def test_convbnrelu_module_runs_one_hip_layer(dev):
@@ -268,7 +330,87 @@ def test_featurenet_matches_oracle(dev, report, N, H, W):
         errs[l] = scaled_err(g_l, w_l)
         assert torch.equal(net.last_channels_last[f"level_{l}"].cpu(), g_l.permute(0, 2, 3, 1).contiguous())
     report("featurenet", shape=[N, H, W], scaled_err=errs)
-    assert max(errs.values()) < 5e-5
+    assert max(errs.values()) < 1.4e-5  # measured 1.4e-6
+
+
+def test_convbnrelu3d_module_runs_one_hip_layer(dev):
+    """modules.py:21-31 called on its own (it was a raise stub)."""
+    from casmvsnet_pl_amd import ABN
+    from casmvsnet_pl_amd.modules import ConvBnReLU3D
+    g = torch.Generator().manual_seed(9)
+    for stride in (1, 2):
+        m = ConvBnReLU3D(8, 16, stride=stride, norm_act=ABN).eval()
+        with torch.no_grad():
+            m.bn.running_var.uniform_(0.5, 1.5, generator=g)
+            m.bn.running_mean.normal_(0, 0.1, generator=g)
+            m.bn.weight.uniform_(0.6, 1.4, generator=g)
+            m.bn.bias.normal_(0, 0.1, generator=g)
+        x = torch.randn(1, 8, 8, 16, 24, generator=g)
+        want = F.leaky_relu(F.batch_norm(F.conv3d(x, m.conv.weight, None, stride=stride, padding=1), m.bn.running_mean,
+                                         m.bn.running_var, m.bn.weight, m.bn.bias, False, 0.0, m.bn.eps), 0.01)
+        got = m.to(dev)(x.to(dev)).cpu()
+        assert got.shape == want.shape and scaled_err(got, want) < 1.2e-5
+
+
+def test_public_module_functions_match_oracle(dev, report):
+    """The importable functions of models/modules.py (get_depth_values :34-49, depth_regression :95-104, homo_warp
+    :52-92) through the host mirror, float and (B,1)-tensor intervals, (B,D,H,W) and (D,) depth values."""
+    from casmvsnet_pl_amd import modules as M
+    g = torch.Generator().manual_seed(77)
+    B, D, H, W = 2, 32, 24, 40
+    cur = 500.0 + 300.0 * torch.rand(B, 1, H, W, generator=g)
+    cur[0, 0, 0, 0] = 2.0  # clamp_min(1e-7) branch
+    for interval in (5.3, torch.tensor([[5.3], [4.1]])):
+        want = R.get_depth_values(cur, D, interval)
+        got = M.get_depth_values(cur.to(dev), D, interval if isinstance(interval, float) else interval.to(dev)).cpu()
+        assert got.shape == want.shape and rel_err(got, want) < 3e-6
+    p = F.softmax(torch.randn(B, D, H, W, generator=g) * 2, 1)
+    dv = R.get_depth_values(cur, D, 5.3)
+    for d in (dv, torch.linspace(425.0, 935.0, D)):
+        want = R.depth_regression(p, d)
+        got = M.depth_regression(p.to(dev), d.to(dev)).cpu()
+        assert got.shape == want.shape
+        report("depth_regression", per_plane=d.dim() == 1, rel=rel_err(got, want))
+        assert rel_err(got, want) < 2e-6  # a D-term fp32 sum in a different order
+    src = torch.randn(B, 16, H, W, generator=g)
+    proj, _, _ = _proj_like(B, 2, H, W, seed=2)
+    want = R.homo_warp(src, proj[:, 0], dv)
+    got = M.homo_warp(src.to(dev), proj[:, 0].to(dev), dv.to(dev)).cpu()
+    assert max_abs(got, want) < 1.5e-4
+
+
+def _expected_index(cost):
+    """e = sum_k softmax(cost)_k * k in float64 from the ORACLE's cost: where trunc(e) is discontinuous."""
+    D = cost.shape[1]
+    return (F.softmax(cost.double(), 1) * torch.arange(D, dtype=torch.float64).view(1, D, 1, 1)).sum(1)
+
+
+def _check_levels(report, name, got, got_index, want, want_index, want_cost, extra=None):
+    """Asserts the per-level parity contract of the module docstring and reports every index flip."""
+    stats, flips = dict(extra or {}), []
+    for l in (2, 1, 0):
+        d, c = got[f"depth_{l}"].cpu(), got[f"confidence_{l}"].cpu()
+        gi, wi = got_index[l].cpu().long(), want_index[l]
+        mism = gi != wi
+        e = _expected_index(want_cost[l])
+        dist = (e - e.round()).abs()
+        stats[f"depth_rel_{l}"] = rel_err(d, want[f"depth_{l}"])
+        stats[f"index_match_{l}"] = float((~mism).float().mean())
+        stats[f"index_flips_{l}"] = int(mism.sum())
+        stats[f"conf_abs_{l}"] = max_abs(c[~mism], want[f"confidence_{l}"][~mism]) if (~mism).any() else 0.0
+        stats[f"flip_max_boundary_dist_{l}"] = float(dist[mism].max()) if mism.any() else 0.0
+        stats[f"pixels_within_1e-3_of_boundary_{l}"] = int((dist < 1e-3).sum())
+        for b, y, x in mism.nonzero()[:32].tolist():
+            flips.append(dict(level=l, b=b, y=y, x=x, got=int(gi[b, y, x]), want=int(wi[b, y, x]),
+                              expected_index=float(e[b, y, x]), boundary_dist=float(dist[b, y, x])))
+    stats["flips"] = flips
+    report(name, **stats)
+    for l in (2, 1, 0):
+        assert stats[f"depth_rel_{l}"] < 1e-4, (l, stats[f"depth_rel_{l}"])          # bar 1e-3, measured <= 8.4e-6
+        assert stats[f"flip_max_boundary_dist_{l}"] < 1e-3, (l, flips)                # every flip sits ON a trunc() boundary
+        assert stats[f"index_flips_{l}"] <= stats[f"pixels_within_1e-3_of_boundary_{l}"]
+        assert stats[f"conf_abs_{l}"] < 5e-4, (l, stats[f"conf_abs_{l}"])            # measured 4.5e-5
+    return stats
 
 
 def _index_report(g, model, inter_or_golden_index):
@@ -290,16 +432,9 @@ def test_end_to_end_matches_golden_fixture(dev, report, case):
     res = model(imgs.to(dev), proj.to(dev), g.init_depth_min, g.depth_interval)
     # reference index, recomputed from the fixture's cost volumes with the oracle
     want_idx = {l: R.softmax_regress(g.t(f"cost_{l}"), g.t(f"depth_values_{l}"))[2] for l in (2, 1, 0)}
-    stats = {}
-    for l in (2, 1, 0):
-        d, c = res[f"depth_{l}"].cpu(), res[f"confidence_{l}"].cpu()
-        stats[f"depth_rel_{l}"] = rel_err(d, g.t(f"depth_{l}"))
-        stats[f"conf_abs_{l}"] = max_abs(c, g.t(f"confidence_{l}"))
-        stats[f"index_match_{l}"] = float((model.last_index[l].cpu().long() == want_idx[l]).float().mean())
-    report("e2e_golden", case=case, **stats)
-    assert stats["depth_rel_0"] < 1e-3 and stats["depth_rel_1"] < 1e-3 and stats["depth_rel_2"] < 1e-3
-    assert stats["index_match_2"] > 0.999 and stats["index_match_1"] > 0.999 and stats["index_match_0"] > 0.999
-    assert stats["conf_abs_2"] < 5e-3 or stats["index_match_2"] < 1.0
+    want = {f"{k}_{l}": g.t(f"{k}_{l}") for k in ("depth", "confidence") for l in (2, 1, 0)}
+    _check_levels(report, "e2e_golden", res, model.last_index, want, want_idx, {l: g.t(f"cost_{l}") for l in (2, 1, 0)},
+                  extra=dict(case=case))
 
 
 @pytest.mark.parametrize("G", [1, 8])
@@ -317,25 +452,22 @@ def test_end_to_end_tensor_depth_range_batch2(dev, report, G):
     got = model(imgs.to(dev), proj.to(dev), dmin_t.to(dev), dint_t.to(dev))
     errs = {k: rel_err(got[k].cpu(), want[k]) for k in want if k.startswith("depth")}
     report("e2e_tensor_range", G=G, **errs)
-    assert max(errs.values()) < 1e-3
+    assert max(errs.values()) < 1e-4  # bar 1e-3, measured 5e-6
 
 
-def test_full_size_640x512_matches_oracle(dev, report):
-    """BASELINE config 1/2: 640x512, 3 views, n_depths [8,32,48], variance - the oracle needs ~2-5 s."""
+@pytest.mark.parametrize("config", ["dtu_640x512_v3_var", "dtu_640x512_v3_gwc8", "dtu_1152x864_v5_var", "blended_768x576_v7_var"])
+def test_full_size_config_matches_oracle(dev, report, config):
+    """Every BASELINE workload at its full size against the oracle (a few seconds to ~half a minute of CPU each):
+    depth at all three levels, confidence on equal-index pixels, and every index flip on a trunc() boundary."""
     from casmvsnet_pl_amd import ABN, CascadeMVSNet
-    from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
-    model = CascadeMVSNet(num_groups=1, norm_act=ABN)
+    from casmvsnet_pl_amd.synthetic import CONFIGS, config_inputs, randomize_state_dict
+    H, W, V, G, n_depths, ratios, _ = CONFIGS[config]
+    model = CascadeMVSNet(n_depths=list(n_depths), interval_ratios=list(ratios), num_groups=G, norm_act=ABN)
     randomize_state_dict(model.state_dict(), seed=0)
-    imgs, proj, dmin, dint = make_inputs(1, 3, 512, 640, seed=0)
-    want, inter = R.cascade_forward(model.state_dict(), imgs, proj, dmin, dint, return_intermediates=True)
+    imgs, proj, dmin, dint = config_inputs(config, 1, seed=0)  # the BlendedMVS config with its scaled depth interval
+    want, inter = R.cascade_forward(model.state_dict(), imgs, proj, dmin, dint, n_depths, ratios, G, return_intermediates=True)
     model = model.to(dev).eval()
     model.keep_index = True
     got = model(imgs.to(dev), proj.to(dev), dmin, dint)
-    stats = {}
-    for l in (2, 1, 0):
-        stats[f"depth_rel_{l}"] = rel_err(got[f"depth_{l}"].cpu(), want[f"depth_{l}"])
-        stats[f"index_match_{l}"] = float((model.last_index[l].cpu().long() == inter[f"index_{l}"]).float().mean())
-        stats[f"conf_abs_{l}"] = max_abs(got[f"confidence_{l}"].cpu(), want[f"confidence_{l}"])
-    report("e2e_640x512", **stats)
-    assert stats["depth_rel_0"] < 1e-3
-    assert min(stats[f"index_match_{l}"] for l in (2, 1, 0)) > 0.999
+    _check_levels(report, "e2e_full_size", got, model.last_index, want, {l: inter[f"index_{l}"] for l in (2, 1, 0)},
+                  {l: inter[f"cost_{l}"] for l in (2, 1, 0)}, extra=dict(config=config))

@@ -117,6 +117,17 @@ def test_forward_fails_loudly_without_gpu():
         net(torch.zeros(1, 8, 8, 8, 8, requires_grad=True))
 
 
+def test_full_model_in_train_mode_raises():
+    """the no_grad region inside forward must not swallow the training guard (train.py calls the model
+    in train mode; silently running eval-mode ABN there would be a wrong-result bug, not a missing feature)."""
+    m = CascadeMVSNet(norm_act=ABN)  # nn.Module default: training = True
+    imgs, proj, dmin, dint = make_inputs(1, 3, 32, 32, seed=0)
+    with pytest.raises(RuntimeError, match="inference engine"):
+        m(imgs, proj, dmin, dint)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="inference engine"):
+        m(imgs, proj, dmin, dint)
+
+
 def test_dropin_import_paths():
     code = ("from models.mvsnet import CascadeMVSNet, CostRegNet, FeatureNet, homo_warp; "
             "from models.modules import ConvBnReLU3D, get_depth_values, depth_regression; "

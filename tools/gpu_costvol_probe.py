@@ -1,39 +1,81 @@
-"""Times casmvs_costvol_var_f32 at the three level shapes of the 640x512 config with (a) fronto-parallel
-depth planes (perfect tap locality) and (b) per-pixel noisy depth (what random-init weights produce)."""
-import sys, os
+"""Cost-volume kernels alone at the three level shapes of a config: gather (NCHW, pixel-major) vs LDS-staged,
+with (a) smooth depth, (b) the noise-like per-pixel depth random-init weights produce; checks that the three
+kernel families agree bit for bit and prints kernel time + fraction of the HBM roof (algorithmic bytes).
+   python tools/gpu_costvol_probe.py [H W V [batch]]          env CV_PROBE_G=8 -> group-wise correlation"""
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from casmvsnet_pl_amd import ops
 from casmvsnet_pl_amd.synthetic import make_inputs
 
-QUICK = bool(os.environ.get("CV_PROBE_QUICK"))
+H, W, V = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (512, 640, 3)
+B = int(sys.argv[4]) if len(sys.argv) >= 5 else 1
+G = int(os.environ.get("CV_PROBE_G", "1"))
+IMPLS = os.environ.get("CV_PROBE_IMPLS", "nchw,gather,lds").split(",")
 dev = torch.device("cuda:0")
-_, proj, dmin, dint = make_inputs(1, 3, 512, 640, seed=0)
-for l, (C, D) in {2: (32, 48), 1: (16, 32), 0: (8, 8)}.items():
-    h, w = 512 >> l, 640 >> l
-    feats = torch.randn(1, 3, C, h, w, device=dev)
-    P = proj[:, :, l].contiguous().to(dev)
-    k = torch.arange(D, device=dev, dtype=torch.float32).view(1, D, 1, 1)
-    planes = (dmin + k * dint * 2 ** l * (48 * 4 / D / 2 ** l)).expand(1, D, h, w).contiguous()
-    noisy = (425.0 + 500.0 * torch.rand(1, 1, h, w, device=dev) + k * dint * 2 ** l).contiguous()
-    smooth = (600.0 + 100.0 * torch.sin(torch.linspace(0, 6.0, w, device=dev)).view(1, 1, 1, w) + k * dint * 2 ** l).expand(1, D, h, w).contiguous()
-    nhwc = ops.nchw_to_nhwc(feats.view(3, C, h, w)).view(1, 3, h, w, C)
-    for name, dv in ((("smooth", smooth),) if QUICK else (("planes", planes), ("smooth", smooth), ("noisy", noisy))):
-        for lay, f in (("nchw", feats), ("nhwc", nhwc)):
-            for _ in range(0 if QUICK else 3):
-                ops.costvol(f, P, dv, 1, channels_last=lay == "nhwc")
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            NR = 2 if QUICK else 10
-            for _ in range(NR):
-                ops.costvol(f, P, dv, 1, channels_last=lay == "nhwc")
-            e.record(); torch.cuda.synchronize()
-            ms = s.elapsed_time(e) / NR
-            byt = 4 * (3 * C * h * w + D * h * w + C * D * h * w)
-            print(f"level {l} C={C} D={D} {h}x{w} depth={name:7s} {lay} {ms*1e3:8.1f} us  {byt/ms/1e6:8.1f} GB/s  frac {byt/ms/1e6/8000:.3f}")
+_, proj, dmin, dint = make_inputs(B, V, H, W, seed=0)
+
+
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(10):
-        ops.nchw_to_nhwc(feats.view(3, C, h, w))
-    e.record(); torch.cuda.synchronize()
-    print(f"level {l} nchw_to_nhwc {s.elapsed_time(e)*100:.1f} us")
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+for l, (C, D) in {2: (32, 48), 1: (16, 32), 0: (8, 8)}.items():
+    h, w = H >> l, W >> l
+    g = torch.Generator(device="cpu").manual_seed(l)
+    feats = torch.randn(B, V, C, h, w, generator=g).to(dev)
+    P = proj[:, :, l].contiguous().to(dev)
+    k = torch.arange(D, device=dev, dtype=torch.float32).view(1, D, 1, 1)
+    step = dint * 2 ** l
+    base_s = 680.0 - D / 2 * step + 60.0 * torch.sin(torch.linspace(0, 6.0, w, device=dev)).view(1, 1, 1, w)
+    smooth = (base_s + k * step).expand(B, D, h, w).contiguous()
+    # noise-like: what the previous level's regression gives with random weights (|d depth / dx| ~ 15 units)
+    coarse = 680.0 + 40.0 * torch.randn(B, 1, h // 2, w // 2, generator=g).to(dev)
+    up = torch.nn.functional.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True)
+    noisy = (up - D / 2 * step + k * step).contiguous()
+    nhwc = ops.nchw_to_nhwc(feats.view(B * V, C, h, w)).view(B, V, h, w, C)
+    byt = 4 * B * (V * C * h * w + D * h * w + (G if G > 1 else C) * D * h * w)
+    for name, dv in (("smooth", smooth), ("noisy", noisy)):
+        outs = {}
+        for impl in IMPLS:
+            if impl == "nchw":
+                fn = lambda: ops.costvol(feats, P, dv, G)
+            else:
+                fn = lambda impl=impl: ops.costvol(nhwc, P, dv, G, channels_last=True, impl=impl)
+            try:
+                outs[impl] = fn()
+            except RuntimeError as ex:
+                print(f"level {l} {impl}: {ex}")
+                continue
+            ms = timed(fn)
+            print(f"level {l} C={C} D={D} {h}x{w} V={V} B={B} G={G} depth={name:6s} {impl:6s} {ms*1e3:8.1f} us  "
+                  f"{byt/ms/1e6:8.1f} GB/s  frac {byt/ms/1e6/8000:.3f}", flush=True)
+        ks = list(outs)
+        for a in ks[1:]:
+            same = torch.equal(outs[ks[0]], outs[a])
+            print(f"   {a} == {ks[0]} bitwise: {same}" + ("" if same else f"  max|diff| {float((outs[ks[0]] - outs[a]).abs().max()):.3e}"))
+    if G == 1:
+        src = feats[:, 1].contiguous()
+        P1 = P[:, 0].contiguous()
+        bw = 4 * B * (C * h * w + D * h * w + C * D * h * w)
+        ow = {}
+        for impl in ("gather", "lds"):
+            fn = lambda impl=impl: ops.homo_warp(src, P1, smooth, impl=impl)
+            try:
+                ow[impl] = fn()
+            except RuntimeError as ex:
+                print(f"level {l} homo_warp {impl}: {ex}")
+                continue
+            ms = timed(fn)
+            print(f"level {l} homo_warp (un-fused op) {impl:6s} {ms*1e3:8.1f} us  {bw/ms/1e6:8.1f} GB/s  frac {bw/ms/1e6/8000:.3f}", flush=True)
+        if len(ow) == 2:
+            print("   homo_warp lds == gather bitwise:", torch.equal(ow["gather"], ow["lds"]))
