@@ -30,6 +30,7 @@ SYMBOLS = {
     "casmvs_costvol_var_nhwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_gwc_nhwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_lds_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "casmvs_costvol_lds_preferred": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "casmvs_costvol_var_lds_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_gwc_lds_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_homo_warp_nhwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -31,11 +31,16 @@ namespace {
 
 using namespace casmvs_dev;
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kThreads = 256;
 constexpr int kMaxViews = 8;   // source views staged at once
 constexpr int RS = 65;         // row stride of the transpose buffer (odd: conflict-free)
-constexpr int kFixedLds = kMaxViews * 8 * 4 + 4 * kMaxViews * 4 * 4 + 4 * 4 * RS * 4;  // prm + red + tr = 4928 B
-static_assert(kFixedLds % 16 == 0, "the boxes must start 16-byte aligned");
+constexpr int kMaxPG = 2;      // plane groups: a tile's 256 pixels are worked on by PG x 4 waves, each group its own planes
+// prm + red + pmat + tr (one [4][RS] transpose buffer per wave)
+constexpr int fixed_lds(int pg) { return kMaxViews * 8 * 4 + 4 * kMaxViews * 4 * 4 + kMaxViews * 12 * 4 + pg * 4 * 4 * RS * 4; }
+static_assert(fixed_lds(1) % 16 == 0 && fixed_lds(2) % 16 == 0, "the boxes must start 16-byte aligned");
 
 enum { MODE_VAR = 0, MODE_GWC = 1, MODE_WARP = 2, MODE_VAR_PART = 3, MODE_GWC_PART = 4 };
 
@@ -53,6 +58,7 @@ struct SweepArgs {
   int G, h, w, D;
   int tiles_x, tiles, tiles_per_xcd;
   int cap_units;       // LDS capacity of one view's box in 16-byte units
+  int ablate;          // profiling build only (-DCASMVS_TRACE): bit 0 no volume stores, 1 no LDS tap reads, 2 taps of plane 0
 };
 
 __device__ __forceinline__ int wave_min(int v) {
@@ -74,14 +80,32 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // One plane of CS values per pixel (lane = pixel) -> global (.., c, d, y, x) with lane = (channel, 4 pixels):
 // 16-byte stores, TW * 4 bytes contiguous per channel and row.  `tr` = this wave's [4][RS] transpose rows.
-template <int CS, int TW>
-__device__ __forceinline__ void store_plane_transposed(const float (&vals)[CS], float *tr, float *plane_base,
-                                                       size_t chan_stride, int wave, int lane, int tx, int ty, int h, int w) {
+// Buffer stores: the per-lane offset `voff` ((channel lane>>4 of the split, pixel) - or beyond the buffer for a
+// pixel outside the image: the hardware drops the store) is computed ONCE per kernel; what changes per plane and
+// channel group is a scalar offset.  No per-store address arithmetic, no 64-bit pointers in VGPRs.
+struct PlaneStore {
+  __amdgpu_buffer_rsrc_t rsrc;   // the batch element's whole volume
+  int voff;                      // bytes; past the buffer for lanes that store nothing
+};
+
+template <int TW>
+__device__ __forceinline__ PlaneStore make_plane_store(float *batch_base, size_t batch_bytes, int c0, int D, int hw, int h, int w,
+                                                       int wave, int lane, int tx, int ty) {
   constexpr int TH = kThreads / TW;
   const int q4 = lane & 15, cw = lane >> 4;
   const int tw_ = wave * 64 + 4 * q4;          // workgroup-local pixel index of the first of the 4 pixels
+  PlaneStore ps;
   const int py = ty * TH + tw_ / TW, px = tx * TW + tw_ % TW;
-  float *op = plane_base + (size_t)py * w + px;
+  ps.rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(batch_base), 0, uniform_int((int)batch_bytes), 0x00020000);
+  const bool ok = py < h && px < w;   // w % 4 == 0: the 4 pixels of a lane are inside or outside together
+  ps.voff = ok ? ((c0 + cw) * D * hw + py * w + px) * 4 : -16;   // -16 = 0xfffffff0: past any buffer
+  return ps;
+}
+
+template <int CS>
+__device__ __forceinline__ void store_plane_transposed(const float (&vals)[CS], float *tr, const PlaneStore &ps, int lane,
+                                                       int D, int hw, int d, int w) {
+  const int q4 = lane & 15, cw = lane >> 4;
 #pragma unroll
   for (int j = 0; j < CS / 4; ++j) {
 #pragma unroll
@@ -89,33 +113,167 @@ __device__ __forceinline__ void store_plane_transposed(const float (&vals)[CS], 
     wave_lds_fence();
     const float *row = tr + cw * RS + 4 * q4;
     const f32x4 o{row[0], row[1], row[2], row[3]};
-    float *oc = op + (size_t)(4 * j + cw) * chan_stride;
-    if (py < h) {
-      if ((w & 3) == 0) {
-        if (px < w) *reinterpret_cast<f32x4 *>(oc) = o;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (px + i < w) oc[i] = o[i];
-      }
-    }
+    const int soff = uniform_int((4 * j * D + d) * hw * 4);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ps.rsrc, ps.voff, soff, 0);   // w % 4 == 0 (host)
     wave_lds_fence();  // the rows are rewritten by the next channel group
   }
 }
 
-template <int C, int CS, int MODE, int TW, int DC>
-__global__ __launch_bounds__(kThreads) void costvol_lds_kernel(const SweepArgs a) {
+// The plane's CS values per pixel -> global.  Default: through the wave-private transpose (16-byte stores).
+// -DCASMVS_CV_DIRECT (A/B build): lane = pixel stores one dword per channel, TW * 4 contiguous bytes per
+// instruction, no LDS round trip.
+template <int CS>
+__device__ __forceinline__ void store_plane(const float (&vals)[CS], float *tr, const PlaneStore &ps, int lane, int D, int hw,
+                                            int d, int w, int direct_voff) {
+#ifdef CASMVS_CV_DIRECT
+  (void)tr; (void)lane; (void)w;
+#pragma unroll
+  for (int c = 0; c < CS; ++c)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vals[c]), ps.rsrc, direct_voff,
+                                          uniform_int((c * D + d) * hw * 4), 0);
+#else
+  (void)direct_voff;
+  store_plane_transposed<CS>(vals, tr, ps, lane, D, hw, d, w);
+#endif
+}
+
+// LDS layout of a staged box row, in 16-byte units: pixel px (box-relative) starts at unit(px), its CS/4 channel
+// groups follow contiguously, a row takes row_units(bw).  Measured with tools/probes/lds_probe.hip (ds_read_b128,
+// lane i reads pixel p + i): a pixel stride of 2 or 4 units is 2- / 4-way bank conflicted, any ODD stride is
+// conflict free, and so is stride 2 with one extra unit every 8 pixels.
+//   CS = 8 : unit(px) = 2 px + (px >> 3)    (6 % padding: what lets four workgroups share a CU's LDS)
+//   CS = 16: unit(px) = 5 px,  CS = 32: unit(px) = 9 px    (odd stride: 25 % / 12.5 % padding)
+template <int CS>
+struct BoxLayout {
+  static constexpr int GL = CS / 4;
+  static __device__ __forceinline__ int unit(int px) { return CS == 8 ? 2 * px + (px >> 3) : px * (GL + 1); }
+  static __device__ __forceinline__ int row_units(int bw) { return CS == 8 ? 2 * bw + (bw >> 3) + 1 : bw * (GL + 1); }
+  // widest box of a given capacity (units) that still has one row; rows of a box of width bw
+  static __host__ __device__ constexpr int units_per_px_bound() { return CS == 8 ? 3 : GL + 1; }
+};
+
+// Box of one staged view, wave-uniform (SGPRs).
+struct Box {
+  int bx0, by0, bw, bh;
+};
+
+__device__ __forceinline__ Box read_box(const int *prm, int vi) {
+  const int *p = prm + vi * 8;
+  return Box{uniform_int(p[0]), uniform_int(p[1]), uniform_int(p[2]), uniform_int(p[3])};
+}
+
+// One source view's contribution to one plane of this thread's pixel: taps -> 4 * CS/4 LDS reads (or, for a lane
+// whose footprint is not inside the staged box, global gathers) -> s += val, q += val^2.
+//
+// gfx9 has ONE in-order counter (vmcnt) for vector-memory loads AND stores: a wait for a load that was issued
+// after the previous plane's volume stores also waits for those stores to reach HBM.  The first version of this
+// kernel paid that ~1-2 us once per plane and view (the compiler waits for the rarely taken gather branch's
+// registers at the merge point, unconditionally) and was slower than the gather kernels.  Hence: the gather
+// branch is wave-uniform (skipped by a scalar branch) and drains its own loads with an explicit s_waitcnt
+// INSIDE the branch, so the steady state carries no vector-memory wait at all.
+template <int C, int CS, bool SQ>
+__device__ __forceinline__ void accumulate_view(const float *P, float xf, float yf, float dvk, int w, int h, bool valid,
+                                                const Box &bx_, const f32x4 *bx, const float *view_map, int view_bytes,
+                                                int c0, f32x2 (&s)[CS / 2], f32x2 (&q)[CS / 2], int abl) {
+  constexpr int GL = CS / 4;
+  using L = BoxLayout<CS>;
+  const int rowu = L::row_units(bx_.bw);
+  Taps t = plane_sweep_taps(P, xf, yf, dvk, w, h);
+  if (!valid) t.w_nl = t.w_nr = t.w_sl = t.w_sr = 0.0f;
+  const bool live = taps_live(t);
+  const int rx = t.xl - bx_.bx0, ryn = t.yn - bx_.by0, rys = t.ys - bx_.by0;
+  const bool in = (rx >= 0) & (rx + 1 < bx_.bw) & (ryn >= 0) & (rys < bx_.bh);   // yn <= ys
+  const bool use_lds = live & in;
+  // a dead voxel (all weights 0) reads the box origin: staged, finite data
+  // left / right pixel of the pair in the north row, and the distance to the south row
+  const int uL = use_lds ? ryn * rowu + L::unit(rx) : 0, uR = use_lds ? ryn * rowu + L::unit(rx + 1) : L::unit(1);
+  const int dS = (use_lds & (rys != ryn)) ? rowu : 0;
+  const bool outside = live & !in;
+  const f32x2 w_nl{t.w_nl, t.w_nl}, w_nr{t.w_nr, t.w_nr}, w_sl{t.w_sl, t.w_sl}, w_sr{t.w_sr, t.w_sr};
+  // channel groups in batches of JB (8 channels): at most 8 ds_read_b128 = 32 registers of tap data live at a time -
+  // what keeps the 8-wave (PG = 2) form inside 128 VGPRs; the scheduling barriers stop the compiler from hoisting the
+  // next batch's reads above this batch's arithmetic
+  constexpr int JB = GL < 2 ? GL : 2;
+#pragma unroll
+  for (int jb = 0; jb < GL; jb += JB) {
+    f32x4 n0[JB], n1[JB], s0[JB], s1[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      if (abl & 2) {   // ablation: the timing without the LDS tap reads (wrong results)
+        n0[j] = f32x4{t.w_nl, xf, yf, dvk}; n1[j] = n0[j]; s0[j] = n0[j]; s1[j] = n0[j];
+        continue;
+      }
+      n0[j] = bx[uL + jb + j]; n1[j] = bx[uR + jb + j];
+      s0[j] = bx[uL + dS + jb + j]; s1[j] = bx[uR + dS + jb + j];
+    }
+    if (__builtin_amdgcn_ballot_w64(outside) != 0) {   // rare: noise-like depth, or a box clipped by the LDS capacity
+      const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(view_map), 0, view_bytes, 0x00020000);
+      // every lane loads (a valid image address either way), only the lanes outside their box keep the result;
+      // one tap at a time: the rare path must not raise the register count of the common one
+      const int on0 = ((t.yn * w + t.xl) * C + c0 + 4 * jb) * 4, os0 = ((t.ys * w + t.xl) * C + c0 + 4 * jb) * 4;
+#define CASMVS_GATHER_TAP(dst, voff, imm)                                        \
+      {                                                                          \
+        f32x4 g[JB];                                                             \
+        _Pragma("unroll") for (int j = 0; j < JB; ++j) g[j] = buf_load4(src, voff, (imm) + 16 * j); \
+        __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) only, INSIDE the branch */ \
+        _Pragma("unroll") for (int j = 0; j < JB; ++j)                           \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[j][i] = outside ? g[j][i] : dst[j][i]; \
+      }
+      CASMVS_GATHER_TAP(n0, on0, 0)
+      CASMVS_GATHER_TAP(n1, on0, C * 4)
+      CASMVS_GATHER_TAP(s0, os0, 0)
+      CASMVS_GATHER_TAP(s1, os0, C * 4)
+#undef CASMVS_GATHER_TAP
+    }
+    // Two channels per instruction (v_pk_mul / v_pk_fma / v_pk_add_f32): a wave issues one instruction every ~5
+    // cycles whatever it is, so the instruction COUNT is the wave's run time.  Per lane and channel the operations
+    // and their order are those of the scalar form: val = fma(s1, w_sr, fma(s0, w_sl, fma(n1, w_nr, n0 * w_nl))),
+    // s += val, q = fma(val, val, q).
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        const f32x2 a0 = hlf ? n0[j].zw : n0[j].xy, a1 = hlf ? n1[j].zw : n1[j].xy;
+        const f32x2 b0 = hlf ? s0[j].zw : s0[j].xy, b1 = hlf ? s1[j].zw : s1[j].xy;
+        f32x2 val = a0 * w_nl;
+        val = __builtin_elementwise_fma(a1, w_nr, val);
+        val = __builtin_elementwise_fma(b0, w_sl, val);
+        val = __builtin_elementwise_fma(b1, w_sr, val);
+        s[2 * (jb + j) + hlf] = s[2 * (jb + j) + hlf] + val;
+        if (SQ) q[2 * (jb + j) + hlf] = __builtin_elementwise_fma(val, val, q[2 * (jb + j) + hlf]);
+      }
+    }
+    if (GL > JB) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// NV: number of staged source views when known at compile time (their loop is unrolled and the boxes / matrices
+// live in SGPRs), 0 = run-time count (rolled loop, box re-read from LDS per view).
+// Register budget: the CS = 8 boxes are small enough for three workgroups per CU (168 VGPRs; at 128 - four per CU - the
+// compiler spills inside the plane loop, and a scratch reload is a vector-memory load that drains the store queue);
+// the larger splits are LDS-bound at two workgroups per CU anyway.
+//
+// PG (plane groups): the LDS boxes cap the workgroups per CU at 2 (CS = 16) - 8 waves per CU, 2 per SIMD - and a wave
+// issues one instruction every ~5-7 cycles whatever it is (tools/probes/valu_probe.hip, clock_probe.hip), so two
+// waves leave the SIMD's VALU (one instruction per ~1.7 cycles) mostly idle: measured, the kernel ran at the speed of
+// its longest wave, not of any unit.  With PG = 2 the SAME tile and boxes are worked on by 8 waves, waves 4-7 taking
+// the upper half of the chunk's planes: twice the waves per byte of LDS.
+template <int C, int CS, int MODE, int TW, int DC, int NV, int PG>
+__global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) void costvol_lds_kernel(const SweepArgs a) {
+  constexpr int NT = kThreads * PG;   // threads of the workgroup
+  constexpr int kFixedLds = fixed_lds(PG);
   constexpr int TH = kThreads / TW;
   constexpr int GL = CS / 4;                     // 16-byte units per staged pixel
-  constexpr int GLP = GL == 1 ? 1 : GL + 1;      // padded (odd) pixel stride in units
+  using L = BoxLayout<CS>;
   constexpr int NSPLIT = C / CS;
-  constexpr int NUB = 8;                         // staging loads in flight per thread
+  constexpr int NUB = CS == 8 ? 4 : 8;           // staging loads in flight per thread (the 128-VGPR budget of CS = 8)
   constexpr bool SQ = MODE == MODE_VAR || MODE == MODE_VAR_PART;
   constexpr bool NEED_REF = MODE != MODE_WARP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int *prm = reinterpret_cast<int *>(smem);                   // [kMaxViews][8]: bx0, by0, bw, bh, q256, r256
   int *red = prm + kMaxViews * 8;                             // [4 waves][kMaxViews][4]
-  float *tr_all = reinterpret_cast<float *>(red + 4 * kMaxViews * 4);
+  float *pmat = reinterpret_cast<float *>(red + 4 * kMaxViews * 4);   // [kMaxViews][12] the views' 3x4 matrices
+  float *tr_all = pmat + kMaxViews * 12;
   f32x4 *box = reinterpret_cast<f32x4 *>(smem + kFixedLds);   // [nv][cap_units]
 
   // ---- work item ----------------------------------------------------------------------------------------
@@ -130,9 +288,11 @@ __global__ __launch_bounds__(kThreads) void costvol_lds_kernel(const SweepArgs a
   const int d0 = (rem / NSPLIT) * DC, c0 = (rem % NSPLIT) * CS;
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int b = blockIdx.y;
-  const int h = a.h, w = a.w, hw = h * w, D = a.D, nv = a.nv;
+  const int h = a.h, w = a.w, hw = h * w, D = a.D;
+  const int nv = NV > 0 ? NV : a.nv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int px = tx * TW + tid % TW, py = ty * TH + tid / TW;
+  const int tp = tid % kThreads, pg = tid / kThreads;   // pixel of the tile, plane group
+  const int px = tx * TW + tp % TW, py = ty * TH + tp / TW;
   const bool valid = px < w && py < h;
   const int pcl = valid ? py * w + px : 0;
   const float xf = (float)px, yf = (float)py;
@@ -141,20 +301,27 @@ __global__ __launch_bounds__(kThreads) void costvol_lds_kernel(const SweepArgs a
   const float *fb = uniform_ptr(a.feats + (size_t)b * a.Vtot * view_floats);
   const float *pb = uniform_ptr(a.proj + ((size_t)b * a.pstride + a.pv0) * 12);
 
-  float dv[DC];
-  {
-    const float *dp = a.depth + ((size_t)b * D + d0) * hw + pcl;
-#pragma unroll
-    for (int k = 0; k < DC; ++k) dv[k] = dp[(size_t)k * hw];
-  }
+  // depth hypotheses of this pixel: the chunk's first and last plane now (boxes), the others one plane ahead
+  // inside the plane loop (a load issued BEFORE a plane's volume stores only waits for the stores of the plane
+  // before: gfx9's vmcnt is in order - and it costs one register instead of DC)
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(uniform_ptr(a.depth + (size_t)b * D * hw)), 0, uniform_int(D * hw * 4), 0x00020000);
+  const float dv_first = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int(d0 * hw * 4), 0));
+  const float dv_last = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + DC - 1) * hw * 4), 0));
 
-  // ---- 1. boxes ---------------------------------------------------------------------------------------------
-  for (int vi = 0; vi < nv; ++vi) {
+  // The matrices go through LDS: the compiler cannot prove that `proj` is not written by the volume stores, so
+  // inside the plane loop it re-loads them with VECTOR loads - and on gfx9 a wait for a vector load also waits
+  // for every older store (one in-order vmcnt): the plane loop must not contain a single vector-memory load.
+  if (tid < nv * 12) pmat[tid] = pb[tid];
+
+  // ---- 1. boxes (by the waves of plane group 0) ---------------------------------------------------------------
+#pragma unroll 1
+  for (int vi = 0; vi < (pg == 0 ? nv : 0); ++vi) {
     const float *P = pb + vi * 12;
     int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const Taps t = plane_sweep_taps(P, xf, yf, dv[e == 0 ? 0 : DC - 1], w, h);
+      const Taps t = plane_sweep_taps(P, xf, yf, e == 0 ? dv_first : dv_last, w, h);
       if (valid && taps_live(t)) {
         xmn = min(xmn, t.xl); xmx = max(xmx, t.xl + 1);
         ymn = min(ymn, t.yn); ymx = max(ymx, t.ys);
@@ -176,35 +343,37 @@ __global__ __launch_bounds__(kThreads) void costvol_lds_kernel(const SweepArgs a
     }
     if (xmn > xmx) { xmn = 0; xmx = 1; ymn = 0; ymx = 0; }   // nothing of this tile projects into the view
     int bw = xmx - xmn + 1, bh = ymx - ymn + 1;
-    const int maxbw = a.cap_units / GLP;                      // host guarantees >= 2
+    const int maxbw = a.cap_units / L::units_per_px_bound() - 1;   // host guarantees >= 2
     if (bw > maxbw) bw = maxbw;
-    const int maxbh = a.cap_units / (bw * GLP);
+    const int maxbh = a.cap_units / L::row_units(bw);
     if (bh > maxbh) bh = maxbh;
-    const int nsu = bw * GL, q256 = kThreads / nsu;
+    const int nsu = bw * GL, q256 = NT / nsu;
     int *p = prm + tid * 8;
-    p[0] = xmn; p[1] = ymn; p[2] = bw; p[3] = bh; p[4] = q256; p[5] = kThreads - q256 * nsu;
+    p[0] = xmn; p[1] = ymn; p[2] = bw; p[3] = bh; p[4] = q256; p[5] = NT - q256 * nsu;
   }
   __syncthreads();
 
   // ---- 2. staging -----------------------------------------------------------------------------------------------
+#pragma unroll 1
   for (int vi = 0; vi < nv; ++vi) {
     const int *p = prm + vi * 8;
     const int bx0 = uniform_int(p[0]), by0 = uniform_int(p[1]), bw = uniform_int(p[2]), bh = uniform_int(p[3]);
     const int q256 = uniform_int(p[4]), r256 = uniform_int(p[5]);
-    const int nsu = bw * GL, total = bh * nsu, rowu = bw * GLP;
+    const int nsu = bw * GL, total = bh * nsu, rowu = L::row_units(bw);
     const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(uniform_ptr(fb + (size_t)(a.v0 + vi) * view_floats)), 0, view_bytes, 0x00020000);
     f32x4 *bx = box + (size_t)vi * a.cap_units;
     int row = tid / nsu, ru = tid - row * nsu;
-    for (int base = 0; base < total; base += kThreads * NUB) {
+    for (int base = 0; base < total; base += NT * NUB) {
       f32x4 regs[NUB];
       int lo[NUB];
 #pragma unroll
       for (int i = 0; i < NUB; ++i) {
-        const bool ok = base + tid + kThreads * i < total;
+        const bool ok = base + tid + NT * i < total;
         const int pxx = ru / GL, ch = ru % GL;
-        lo[i] = ok ? row * rowu + pxx * GLP + ch : -1;
-        if (ok) regs[i] = buf_load4(src, (((by0 + row) * w + bx0 + pxx) * C + c0 + 4 * ch) * 4, 0);
+        lo[i] = ok ? row * rowu + L::unit(pxx) + ch : -1;
+        // a lane past the end of the box loads the map's first bytes (and drops them): no divergence, no branch
+        regs[i] = buf_load4(src, ok ? (((by0 + row) * w + bx0 + pxx) * C + c0 + 4 * ch) * 4 : 0, 0);
         ru += r256; row += q256;
         if (ru >= nsu) { ru -= nsu; ++row; }
       }
@@ -226,84 +395,114 @@ __global__ __launch_bounds__(kThreads) void costvol_lds_kernel(const SweepArgs a
   }
   __syncthreads();
 
-  // ---- 3. plane by plane ----------------------------------------------------------------------------------------
+  // wave-uniform per-view constants of the unrolled form
+  constexpr int NVS = NV > 0 ? NV : 1;
+  Box boxes[NVS];
+  float Pm[NVS][12];
+  if (NV > 0) {
+#pragma unroll
+    for (int vi = 0; vi < NVS; ++vi) {
+      boxes[vi] = read_box(prm, vi);
+#pragma unroll
+      for (int i = 0; i < 12; ++i)
+        Pm[vi][i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pmat[vi * 12 + i])));
+    }
+  }
+
+  const size_t vol_floats = (size_t)C * D * hw;   // one batch element of out (VAR / WARP / VAR_PART)
+  const PlaneStore ps = make_plane_store<TW>(a.out + (size_t)b * vol_floats, vol_floats * 4, c0, D, hw, h, w, wave & 3, lane, tx, ty);
+  PlaneStore ps2 = ps;
+  if (MODE == MODE_VAR_PART)
+    ps2.rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.out2 + (size_t)b * vol_floats), 0, uniform_int((int)(vol_floats * 4)), 0x00020000);
+  const int direct_voff = valid ? (c0 * D * hw + pcl) * 4 : -16;
+
+#ifdef CASMVS_TRACE
+  const int abl = a.ablate;
+#else
+  constexpr int abl = 0;
+#endif
+
+  // ---- 3. plane by plane (a rolled loop: the body is ~1.5 KB of code per view, the 8 planes unrolled were 40 KB)
   float *tr = tr_all + wave * (4 * RS);
   const float rV = 1.0f / (float)a.nviews_total;
+  // CS >= 16 runs at two waves per SIMD whatever it does (LDS): registers are free there and the planes' depths
+  // are all loaded up front, which keeps every vector-memory wait out of the plane loop.
+  constexpr bool DV_REGS = CS >= 16;
+  constexpr int KP = DC / PG;          // planes of a plane group
+  const int k0 = uniform_int(pg * KP);
+  float dvr[DV_REGS ? KP : 1];
+  if (DV_REGS) {
 #pragma unroll
-  for (int k = 0; k < DC; ++k) {
-    float s[CS], q[CS];
+    for (int i = 0; i < KP; ++i)
+      dvr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + k0 + i) * hw * 4), 0));
+  }
+  float dvk = DV_REGS ? dvr[0]
+                      : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + k0) * hw * 4), 0));
+#pragma unroll 1
+  for (int k = k0; k < k0 + KP; ++k) {
+    float dv_next = dv_last;
+    if (DV_REGS) {
 #pragma unroll
-    for (int c = 0; c < CS; ++c) {
+      for (int i = 1; i < KP; ++i) dv_next = (k + 1 - k0 == i) ? dvr[i] : dv_next;   // selects on a scalar condition
+    } else if (!(abl & 4)) {
+      const int kn = k + 1 < DC ? k + 1 : DC - 1;
+      dv_next = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + kn) * hw * 4), 0));
+    }
+    f32x2 s2[CS / 2], q2[CS / 2];
+#pragma unroll
+    for (int c = 0; c < CS / 2; ++c) {
       if (MODE == MODE_VAR || (MODE == MODE_VAR_PART && a.with_ref)) {
-        s[c] = ref[c];                 // volume_sum = ref_volume            (mvsnet.py:140)
-        q[c] = ref[c] * ref[c];        // volume_sq_sum = ref_volume ** 2    (mvsnet.py:141)
+        s2[c] = f32x2{ref[2 * c], ref[2 * c + 1]};   // volume_sum = ref_volume            (mvsnet.py:140)
+        q2[c] = s2[c] * s2[c];                       // volume_sq_sum = ref_volume ** 2    (mvsnet.py:141)
       } else {
-        s[c] = 0.0f;                   // volume_sum = 0                     (mvsnet.py:144)
-        q[c] = 0.0f;
+        s2[c] = f32x2{0.0f, 0.0f};                   // volume_sum = 0                     (mvsnet.py:144)
+        q2[c] = f32x2{0.0f, 0.0f};
       }
     }
-    for (int vi = 0; vi < nv; ++vi) {
-      const int *p = prm + vi * 8;
-      const int bx0 = uniform_int(p[0]), by0 = uniform_int(p[1]), bw = uniform_int(p[2]), bh = uniform_int(p[3]);
-      const int rowu = bw * GLP;
-      Taps t = plane_sweep_taps(pb + vi * 12, xf, yf, dv[k], w, h);
-      if (!valid) t.w_nl = t.w_nr = t.w_sl = t.w_sr = 0.0f;
-      const bool live = taps_live(t);
-      const int rx = t.xl - bx0, ryn = t.yn - by0, rys = t.ys - by0;
-      const bool in = (rx >= 0) & (rx + 1 < bw) & (ryn >= 0) & (rys < bh);   // yn <= ys
-      const bool use_lds = live & in;
-      // a dead voxel (all weights 0) reads the box origin: staged, finite data
-      const int aN = use_lds ? ryn * rowu + rx * GLP : 0, aS = use_lds ? rys * rowu + rx * GLP : 0;
-      const f32x4 *bx = box + (size_t)vi * a.cap_units;
-      f32x4 n0[GL], n1[GL], s0[GL], s1[GL];
+    if (NV > 0) {
 #pragma unroll
-      for (int j = 0; j < GL; ++j) {
-        n0[j] = bx[aN + j]; n1[j] = bx[aN + GLP + j];
-        s0[j] = bx[aS + j]; s1[j] = bx[aS + GLP + j];
-      }
-      if (live & !in) {   // a tap outside the staged box: this lane gathers from the global map
-        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(uniform_ptr(fb + (size_t)(a.v0 + vi) * view_floats)), 0, view_bytes, 0x00020000);
-        const int on0 = ((t.yn * w + t.xl) * C + c0) * 4, os0 = ((t.ys * w + t.xl) * C + c0) * 4;
+      for (int vi = 0; vi < NVS; ++vi)
+        accumulate_view<C, CS, SQ>(Pm[vi], xf, yf, dvk, w, h, valid, boxes[vi], box + (size_t)vi * a.cap_units,
+                                   fb + (size_t)(a.v0 + vi) * view_floats, view_bytes, c0, s2, q2, abl);
+    } else {
+#pragma unroll 1
+      for (int vi = 0; vi < nv; ++vi) {
+        const Box bxv = read_box(prm, vi);
+        float Pv[12];
 #pragma unroll
-        for (int j = 0; j < GL; ++j) {
-          n0[j] = buf_load4(src, on0, 16 * j); n1[j] = buf_load4(src, on0, C * 4 + 16 * j);
-          s0[j] = buf_load4(src, os0, 16 * j); s1[j] = buf_load4(src, os0, C * 4 + 16 * j);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < GL; ++j) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float val = fmaf(s1[j][i], t.w_sr, fmaf(s0[j][i], t.w_sl, fmaf(n1[j][i], t.w_nr, n0[j][i] * t.w_nl)));
-          s[4 * j + i] = s[4 * j + i] + val;
-          if (SQ) q[4 * j + i] = fmaf(val, val, q[4 * j + i]);
-        }
+        for (int i = 0; i < 12; ++i) Pv[i] = pmat[vi * 12 + i];
+        accumulate_view<C, CS, SQ>(Pv, xf, yf, dvk, w, h, valid, bxv, box + (size_t)vi * a.cap_units,
+                                   uniform_ptr(fb + (size_t)(a.v0 + vi) * view_floats), view_bytes, c0, s2, q2, abl);
       }
     }
     // ---- 4. the plane leaves -------------------------------------------------------------------------------------
     const int d = d0 + k;
-    if (MODE == MODE_VAR || MODE == MODE_WARP || MODE == MODE_VAR_PART) {
-      if (MODE == MODE_VAR) {
+    float s[CS], q[CS];
+    if (MODE == MODE_VAR) {
+      const f32x2 rV2{rV, rV};
 #pragma unroll
-        for (int c = 0; c < CS; ++c) {
-          const float m = s[c] * rV;   // sq/V - (sum/V)^2 (mvsnet.py:167), x/V as x * (1/V)
-          s[c] = q[c] * rV - m * m;
-        }
+      for (int c = 0; c < CS / 2; ++c) {
+        const f32x2 m = s2[c] * rV2;   // sq/V - (sum/V)^2 (mvsnet.py:167), x/V as x * (1/V)
+        s2[c] = q2[c] * rV2 - m * m;
       }
-      const size_t chan_stride = (size_t)D * hw;
-      float *base = a.out + (((size_t)b * C + c0) * D + d) * hw;
-      store_plane_transposed<CS, TW>(s, tr, base, chan_stride, wave, lane, tx, ty, h, w);
-      if (MODE == MODE_VAR_PART) {
-        float *base2 = a.out2 + (((size_t)b * C + c0) * D + d) * hw;
-        store_plane_transposed<CS, TW>(q, tr, base2, chan_stride, wave, lane, tx, ty, h, w);
-      }
+    }
+#pragma unroll
+    for (int c = 0; c < CS / 2; ++c) {
+      s[2 * c] = s2[c].x; s[2 * c + 1] = s2[c].y;
+      q[2 * c] = q2[c].x; q[2 * c + 1] = q2[c].y;
+    }
+    if (MODE == MODE_VAR || MODE == MODE_WARP || MODE == MODE_VAR_PART) {
+      if (!(abl & 1)) store_plane<CS>(s, tr, ps, lane, D, hw, d, w, direct_voff);
+      if (MODE == MODE_VAR_PART) store_plane<CS>(q, tr, ps2, lane, D, hw, d, w, direct_voff);
     } else {
       // group-wise correlation (mvsnet.py:170-171): mean over the C/G channels of a group of
       // volume_sum * ref_volume, then / (V - 1); lane = pixel stores TW consecutive x per group
       const int cpg = C / a.G;
       const float fn = (float)cpg, fv = (float)a.nviews_total;
-      float *op = a.out + (((size_t)b * a.G + c0 / cpg) * D + d) * hw + pcl;
+      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+          uniform_ptr(a.out + (size_t)b * a.G * D * hw), 0, uniform_int(a.G * D * hw * 4), 0x00020000);
+      const int gvoff = valid ? pcl * 4 : -16;
+      int gsoff = ((c0 / cpg) * D + d) * hw * 4;
       float acc = 0.0f;
       int cnt = 0;
 #pragma unroll
@@ -311,13 +510,15 @@ __global__ __launch_bounds__(kThreads) void costvol_lds_kernel(const SweepArgs a
         acc = acc + s[c] * ref[c];
         if (++cnt == cpg) {
           const float m = acc / fn;
-          if (valid) *op = MODE == MODE_GWC ? m / fv : m;
-          op += (size_t)D * hw;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, MODE == MODE_GWC ? m / fv : m), gr, gvoff,
+                                                uniform_int(gsoff), 0);
+          gsoff += D * hw * 4;
           acc = 0.0f;
           cnt = 0;
         }
       }
     }
+    dvk = dv_next;
   }
 }
 
@@ -345,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void gwc_finalize_kernel(const f32x4 *__r
 }
 
 struct Plan {
-  int cs, tw, dc, cap_units, lds_bytes;
+  int cs, tw, dc, pg, cap_units, lds_bytes;
 };
 
 // LDS plan: the highest occupancy (3, 2, 1 workgroups per CU) whose per-view capacity still holds the box a
@@ -354,44 +555,68 @@ bool make_plan(int C, int w, int D, int nv, int G, int mode, Plan &p) {
   if (nv < 1 || nv > kMaxViews) return false;
   p.dc = 8;
   if (D % p.dc != 0) return false;
-  p.tw = (w % 64 == 0) ? 64 : 32;
-  p.cs = C == 32 ? 16 : C;
+  if (w % 4 != 0) return false;                 // 16-byte volume stores
+  p.tw = (C == 8 && w % 64 == 0) ? 64 : 32;   // A/B (tools/gpu_cv_ab.sh): 32 x 8 tiles win at C = 16, no difference at C = 8
+  p.cs = C >= 16 ? 16 : 8;
   const bool gwc = mode == MODE_GWC || mode == MODE_GWC_PART;
-  if (gwc && (C / G) > p.cs) p.cs = C;     // a group must not straddle two channel splits
+  while (gwc && (C / G) > p.cs) p.cs *= 2;     // a group must not straddle two channel splits
+  p.pg = 1;   // two plane groups (8 waves on the same boxes) need <= 128 VGPRs: the compiler spills in the plane loop, 3x slower
 #ifdef CASMVS_TRACE   // profiling build only: A/B of the tile shape / channel split
+  if (const char *e = getenv("CASMVS_CV_PG")) p.pg = atoi(e);
   if (const char *e = getenv("CASMVS_CV_TW")) p.tw = atoi(e);
   if (const char *e = getenv("CASMVS_CV_CS")) p.cs = atoi(e);
 #endif
-  if (C % p.cs != 0 || (p.cs != 4 && p.cs != 8 && p.cs != 16 && p.cs != 32)) return false;
-  const int gl = p.cs / 4, glp = gl == 1 ? 1 : gl + 1, th = kThreads / p.tw;
-  const int need = (p.tw + p.dc + 4) * (th + 2) * glp;
+  if (C % p.cs != 0 || (p.cs != 8 && p.cs != 16 && p.cs != 32)) return false;
+  const int upp = p.cs == 8 ? 3 : p.cs / 4 + 1, th = kThreads / p.tw;   // upper bound of the units per staged pixel
+  const int need = ((p.tw + p.dc + 4) * (p.cs == 8 ? 17 : 8 * upp) / 8 + 1) * (th + 2);
   static const int budgets[3] = {52 * 1024, 79 * 1024, 158 * 1024};
   for (int i = 0; i < 3; ++i) {
-    const int cap = (budgets[i] - kFixedLds) / (nv * 16);
+    const int cap = (budgets[i] - fixed_lds(p.pg)) / (nv * 16);
     if (cap >= need) {
       p.cap_units = cap;
-      p.lds_bytes = kFixedLds + nv * cap * 16;
+      p.lds_bytes = fixed_lds(p.pg) + nv * cap * 16;
       return true;
     }
   }
   return false;
 }
 
-template <int C, int CS, int MODE, int TW>
-int launch_cfg(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
-  auto kernel = costvol_lds_kernel<C, CS, MODE, TW, 8>;
+template <int C, int CS, int MODE, int TW, int NV, int PG>
+int launch_pg(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
+  auto kernel = costvol_lds_kernel<C, CS, MODE, TW, 8, NV, PG>;
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), 158 * 1024, "costvol_lds_kernel")) return rc;
   const int inner = (a.D / 8) * (C / CS);
   dim3 grid((unsigned)(8 * a.tiles_per_xcd * inner), (unsigned)B);
-  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), (size_t)p.lds_bytes, st, a);
+  hipLaunchKernelGGL(kernel, grid, dim3(kThreads * PG), (size_t)p.lds_bytes, st, a);
   return casmvs::check_launch("costvol_lds_kernel");
+}
+
+template <int C, int CS, int MODE, int TW, int NV>
+int launch_nv(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
+#ifdef CASMVS_TRACE   // the two-plane-group form is kept for A/B runs only (see make_plan)
+  if constexpr (NV == 2 || NV == 1) {
+    if (p.pg == 2) return launch_pg<C, CS, MODE, TW, NV, 2>(a, p, B, st);
+  }
+#endif
+  return launch_pg<C, CS, MODE, TW, NV, 1>(a, p, B, st);
+}
+
+// Which view counts get an unrolled kernel: the un-fused warp has one view; the fused builders the headline
+// V = 3 (2 source views); everything else (other V, the partial sums of the view-sharded build) the rolled form.
+template <int C, int CS, int MODE, int TW>
+int launch_cfg(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
+  if constexpr (MODE == MODE_WARP) return launch_nv<C, CS, MODE, TW, 1>(a, p, B, st);
+  if constexpr (MODE == MODE_VAR || MODE == MODE_GWC) {
+    if (a.nv == 2) return launch_nv<C, CS, MODE, TW, 2>(a, p, B, st);
+  }
+  return launch_nv<C, CS, MODE, TW, 0>(a, p, B, st);
 }
 
 template <int C, int MODE>
 int launch_c(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
 #define CASMVS_TRY(CSV, TWV) \
   if (p.cs == CSV && p.tw == TWV) return launch_cfg<C, CSV, MODE, TWV>(a, p, B, st);
-  if constexpr (C >= 32) { CASMVS_TRY(32, 64) CASMVS_TRY(32, 32) }
+  if constexpr (C == 32) { CASMVS_TRY(32, 64) CASMVS_TRY(32, 32) }
   if constexpr (C >= 16) { CASMVS_TRY(16, 64) CASMVS_TRY(16, 32) }
   CASMVS_TRY(8, 64) CASMVS_TRY(8, 32)
 #undef CASMVS_TRY
@@ -408,6 +633,10 @@ int launch_mode(SweepArgs a, int C, int B, hipStream_t st, const char *what) {
   a.tiles = a.tiles_x * casmvs::ceil_div(a.h, th);
   a.tiles_per_xcd = casmvs::ceil_div(a.tiles, 8);
   a.cap_units = p.cap_units;
+  a.ablate = 0;
+#ifdef CASMVS_TRACE
+  if (const char *e = getenv("CASMVS_CV_ABLATE")) a.ablate = atoi(e);
+#endif
   if (C == 32) return launch_c<32, MODE>(a, p, B, st);
   if (C == 16) return launch_c<16, MODE>(a, p, B, st);
   if (C == 8) return launch_c<8, MODE>(a, p, B, st);
@@ -420,6 +649,7 @@ int check_common(const char *what, const void *feats, const void *proj, const vo
   CASMVS_REQUIRE(B > 0 && B <= 65535 && V >= 1 && h > 1 && w > 1 && D > 0, "%s: bad shape B=%d V=%d C=%d h=%d w=%d D=%d", what, B, V, C, h, w, D);
   CASMVS_REQUIRE(((reinterpret_cast<size_t>(feats) | reinterpret_cast<size_t>(out)) & 15) == 0, "%s: feats and out must be 16-byte aligned", what);
   CASMVS_REQUIRE((size_t)h * w * C < ((size_t)1 << 29), "%s: one view's map must hold < 2^29 floats", what);
+  CASMVS_REQUIRE((size_t)h * w * C * D < ((size_t)1 << 29), "%s: one batch element's volume must hold < 2^29 floats", what);
   return CASMVS_OK;
 }
 
@@ -432,12 +662,19 @@ extern "C" int casmvs_costvol_lds_supported(int C, int w, int D, int n_src_views
   return make_plan(C, w, D, n_src_views, G > 1 ? G : 1, G > 1 ? MODE_GWC : MODE_VAR, p) ? 1 : 0;
 }
 
+// Measured on the MI355X (tools/gpu_cv_ab.sh, profiles/r02_costvol_ab.txt): the LDS-staged variance build beats the
+// gather kernel at C = 16 and C = 8 (1.1-1.5x); at C = 32 the channel split repeats the tap arithmetic and the gather
+// kernel wins; the correlation (G > 1) writes 4-16x fewer bytes and the gather kernel wins at every level.
+extern "C" int casmvs_costvol_lds_preferred(int C, int w, int D, int n_src_views, int G) {
+  return (G <= 1 && C <= 16 && casmvs_costvol_lds_supported(C, w, D, n_src_views, G)) ? 1 : 0;
+}
+
 extern "C" int casmvs_costvol_var_lds_f32(const float *feats, const float *proj, const float *depth, float *out, int B,
                                           int V, int C, int h, int w, int D, void *stream) {
   casmvs::clear_error();
   if (int rc = check_common("costvol_var_lds", feats, proj, depth, out, B, V, C, h, w, D)) return rc;
   CASMVS_REQUIRE(V >= 2, "costvol_var_lds: V=%d", V);
-  SweepArgs a{feats, proj, depth, out, nullptr, V, 1, V - 1, 0, V - 1, 1, V, 1, h, w, D, 0, 0, 0, 0};
+  SweepArgs a{feats, proj, depth, out, nullptr, V, 1, V - 1, 0, V - 1, 1, V, 1, h, w, D, 0, 0, 0, 0, 0};
   return launch_mode<MODE_VAR>(a, C, B, (hipStream_t)stream, "costvol_var_lds");
 }
 
@@ -446,7 +683,7 @@ extern "C" int casmvs_costvol_gwc_lds_f32(const float *feats, const float *proj,
   casmvs::clear_error();
   if (int rc = check_common("costvol_gwc_lds", feats, proj, depth, out, B, V, C, h, w, D)) return rc;
   CASMVS_REQUIRE(V >= 2 && G >= 1 && C % G == 0, "costvol_gwc_lds: V=%d C=%d G=%d", V, C, G);
-  SweepArgs a{feats, proj, depth, out, nullptr, V, 1, V - 1, 0, V - 1, 0, V - 1, G, h, w, D, 0, 0, 0, 0};
+  SweepArgs a{feats, proj, depth, out, nullptr, V, 1, V - 1, 0, V - 1, 0, V - 1, G, h, w, D, 0, 0, 0, 0, 0};
   return launch_mode<MODE_GWC>(a, C, B, (hipStream_t)stream, "costvol_gwc_lds");
 }
 
@@ -454,7 +691,7 @@ extern "C" int casmvs_homo_warp_nhwc_f32(const float *src, const float *proj, co
                                          int C, int H, int W, int D, void *stream) {
   casmvs::clear_error();
   if (int rc = check_common("homo_warp_nhwc", src, proj, depth, out, B, 1, C, H, W, D)) return rc;
-  SweepArgs a{src, proj, depth, out, nullptr, 1, 0, 1, 0, 1, 0, 1, 1, H, W, D, 0, 0, 0, 0};
+  SweepArgs a{src, proj, depth, out, nullptr, 1, 0, 1, 0, 1, 0, 1, 1, H, W, D, 0, 0, 0, 0, 0};
   return launch_mode<MODE_WARP>(a, C, B, (hipStream_t)stream, "homo_warp_nhwc");
 }
 
@@ -465,7 +702,7 @@ extern "C" int casmvs_costvol_partial_var_f32(const float *feats, const float *p
   if (int rc = check_common("costvol_partial_var", feats, proj, depth, sum, B, V, C, h, w, D)) return rc;
   CASMVS_REQUIRE(sq && (reinterpret_cast<size_t>(sq) & 15) == 0, "costvol_partial_var: sq must be a 16-byte aligned pointer");
   CASMVS_REQUIRE(1 <= view_begin && view_begin < view_end && view_end <= V, "costvol_partial_var: source views [%d, %d) of V=%d", view_begin, view_end, V);
-  SweepArgs a{feats, proj, depth, sum, sq, V, view_begin, view_end - view_begin, view_begin - 1, V - 1, include_ref ? 1 : 0, V, 1, h, w, D, 0, 0, 0, 0};
+  SweepArgs a{feats, proj, depth, sum, sq, V, view_begin, view_end - view_begin, view_begin - 1, V - 1, include_ref ? 1 : 0, V, 1, h, w, D, 0, 0, 0, 0, 0};
   return launch_mode<MODE_VAR_PART>(a, C, B, (hipStream_t)stream, "costvol_partial_var");
 }
 
@@ -476,7 +713,7 @@ extern "C" int casmvs_costvol_partial_gwc_f32(const float *feats, const float *p
   if (int rc = check_common("costvol_partial_gwc", feats, proj, depth, out, B, V, C, h, w, D)) return rc;
   CASMVS_REQUIRE(G >= 1 && C % G == 0, "costvol_partial_gwc: C=%d G=%d", C, G);
   CASMVS_REQUIRE(1 <= view_begin && view_begin < view_end && view_end <= V, "costvol_partial_gwc: source views [%d, %d) of V=%d", view_begin, view_end, V);
-  SweepArgs a{feats, proj, depth, out, nullptr, V, view_begin, view_end - view_begin, view_begin - 1, V - 1, 0, V - 1, G, h, w, D, 0, 0, 0, 0};
+  SweepArgs a{feats, proj, depth, out, nullptr, V, view_begin, view_end - view_begin, view_begin - 1, V - 1, 0, V - 1, G, h, w, D, 0, 0, 0, 0, 0};
   return launch_mode<MODE_GWC_PART>(a, C, B, (hipStream_t)stream, "costvol_partial_gwc");
 }
 

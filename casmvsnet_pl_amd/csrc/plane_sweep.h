@@ -48,12 +48,12 @@ __device__ __forceinline__ Taps plane_sweep_taps(const float *__restrict__ P, fl
   float qx = rx + div_by(P[3], dv, rdv);
   float qy = ry + div_by(P[7], dv, rdv);
   float qz = rz + div_by(P[11], dv, rdv);
-  // negative depth -> somewhere outside the image                  (modules.py:76-79)
-  if (qz <= 1e-7f) {
-    qx = (float)W;
-    qy = (float)H;
-    qz = 1.0f;
-  }
+  // negative depth -> somewhere outside the image                  (modules.py:76-79).  Selects, not branches:
+  // the compiler turned the if / else-if chains of this function into ~10 exec-masked regions per call.
+  const bool behind = qz <= 1e-7f;
+  qx = behind ? (float)W : qx;
+  qy = behind ? (float)H : qy;
+  qz = behind ? 1.0f : qz;
   const float rqz = __builtin_amdgcn_rcpf(qz);
   float u = div_by(qx, qz, rqz);  // modules.py:81
   float v = div_by(qy, qz, rqz);
@@ -67,26 +67,23 @@ __device__ __forceinline__ Taps plane_sweep_taps(const float *__restrict__ P, fl
   float tw = ix - x0, te = 1.0f - tw;  // ATen CPU kernel: w = x - x_w, e = 1 - w
   float tn = iy - y0, ts = 1.0f - tn;
   // Bounds tests in float: NaN / +-inf / huge coordinates fail every comparison, so the tap is
-  // dropped exactly like ATen's zeros padding and is never converted to an int index.
+  // dropped exactly like ATen's zeros padding (its int index below is never used with a non-zero weight).
   // x: left element of the pair is column xl = clamp(x0, 0, W-2); columns x0 and x0+1 carry
   // weights te and tw when they exist.
   const float fW = (float)W, fH = (float)H;
-  float wl, wr;
-  int xl;
-  if (x0 >= 0.0f && x0 <= fW - 2.0f) {        // both columns inside
-    xl = (int)x0; wl = te; wr = tw;
-  } else if (x0 == -1.0f) {                   // only column x0+1 = 0 inside
-    xl = 0; wl = tw; wr = 0.0f;
-  } else if (x0 == fW - 1.0f) {               // only column x0 = W-1 inside
-    xl = W - 2; wl = 0.0f; wr = te;
-  } else {
-    xl = 0; wl = 0.0f; wr = 0.0f;
-  }
-  const bool y0_in = (y0 >= 0.0f) && (y0 <= fH - 1.0f);
-  const bool y1_in = (y0 >= -1.0f) && (y0 <= fH - 2.0f);
+  const bool x_both = (x0 >= 0.0f) & (x0 <= fW - 2.0f);   // both columns inside
+  const bool x_right = x0 == -1.0f;                        // only column x0+1 = 0 inside
+  const bool x_left = x0 == fW - 1.0f;                     // only column x0 = W-1 inside
+  const int xi = (int)fminf(fmaxf(x0, 0.0f), fW - 2.0f);   // NaN -> 0
+  const int xl = x_both ? xi : (x_left ? W - 2 : 0);
+  const float wl = x_both ? te : (x_right ? tw : 0.0f);
+  const float wr = x_both ? tw : (x_left ? te : 0.0f);
+  const bool y0_in = (y0 >= 0.0f) & (y0 <= fH - 1.0f);
+  const bool y1_in = (y0 >= -1.0f) & (y0 <= fH - 2.0f);
   // a row outside the image gets weight 0 and the address of the other row (of row 0 when both are outside)
-  const int yv0 = y0_in ? (int)y0 : 0;
-  const int yv1 = y1_in ? (int)y0 + 1 : yv0;
+  const int yi = (int)fminf(fmaxf(y0, -1.0f), fH - 1.0f);  // NaN -> -1
+  const int yv0 = y0_in ? yi : 0;
+  const int yv1 = y1_in ? yi + 1 : yv0;
   const float wn = y0_in ? ts : 0.0f, wsth = y1_in ? tn : 0.0f;
   Taps t;
   t.xl = xl;

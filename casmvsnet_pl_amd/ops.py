@@ -74,7 +74,7 @@ def costvol(feats, proj_mats, depth_values, num_groups=1, channels_last=False, i
     proj_mats (B,V-1,3,4), depth_values (B,D,h,w) ->
     (B,C,D,h,w) variance volume (num_groups == 1) or (B,G,D,h,w) group-wise correlation.
     impl (channels_last only): "lds" = source boxes staged in LDS (casmvs_costvol_*_lds_f32), "gather" = the
-    texture-path gather kernels (casmvs_costvol_*_nhwc_f32), "auto" = "lds" when the shape has an LDS plan.
+    texture-path gather kernels (casmvs_costvol_*_nhwc_f32), "auto" = whichever was measured faster for the shape (casmvs_costvol_lds_preferred).
     All three kernel families give bit-identical volumes."""
     feats, proj_mats, depth_values = _dev(feats, "feats"), _dev(proj_mats, "proj_mats"), _dev(depth_values, "depth_values")
     if channels_last:
@@ -89,7 +89,7 @@ def costvol(feats, proj_mats, depth_values, num_groups=1, channels_last=False, i
         sfx = ""
     else:
         if impl == "auto":
-            impl = "lds" if lib.casmvs_costvol_lds_supported(C, w, D, V - 1, num_groups) else "gather"
+            impl = "lds" if lib.casmvs_costvol_lds_preferred(C, w, D, V - 1, num_groups) else "gather"
         sfx = "_lds" if impl == "lds" else "_nhwc"
     with torch.cuda.device(feats.device):
         if num_groups == 1:

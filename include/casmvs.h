@@ -113,10 +113,12 @@ int casmvs_costvol_gwc_nhwc_f32(const float *feats, const float *proj, const flo
  * a tile of 256 reference pixels reaches over a chunk of 8 depth planes is staged once in LDS and every
  * bilinear tap is an LDS read (the gather kernels are bound by the CU's texture path, not by HBM).
  * feats (B, V, h, w, C) pixel-major, C in {8, 16, 32}; D % 8 == 0; at most 8 source views per call.
- * casmvs_costvol_lds_supported: 1 when a shape has an LDS plan (otherwise use the *_nhwc kernels).
+ * casmvs_costvol_lds_supported: 1 when a shape has an LDS plan (otherwise use the *_nhwc kernels);
+ * casmvs_costvol_lds_preferred: 1 when that plan is also the faster kernel on the MI355X (measured per channel count).
  * casmvs_homo_warp_nhwc_f32 replaces models/modules.py:52-92 for a pixel-major source map (B, H, W, C):
  *   out (B, C, D, H, W) exactly as casmvs_homo_warp_f32. */
 int casmvs_costvol_lds_supported(int C, int w, int D, int n_src_views, int G);
+int casmvs_costvol_lds_preferred(int C, int w, int D, int n_src_views, int G);
 int casmvs_costvol_var_lds_f32(const float *feats, const float *proj, const float *depth, float *out,
                                int B, int V, int C, int h, int w, int D, void *stream);
 int casmvs_costvol_gwc_lds_f32(const float *feats, const float *proj, const float *depth, float *out,

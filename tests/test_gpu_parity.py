@@ -67,7 +67,8 @@ def test_homo_warp_matches_oracle(dev, report, B, C, H, W, D, geometry):
     report("homo_warp", shape=[B, C, H, W, D], geometry=geometry, max_abs=err, nonzero_frac=float((want != 0).float().mean()))
     assert err < 1.5e-4  # measured 1.3e-5: bilinear is continuous, |d value| <= |grad| * coordinate noise (~1e-5 px)
     assert float(((got != 0) != (want != 0)).float().mean()) < 1e-3  # same in/out-of-bounds pattern
-    if C in (8, 16, 32) and D % 8 == 0:  # the LDS-staged form of the un-fused op: same arithmetic, same bits
+    from casmvsnet_pl_amd import _lib
+    if C in (8, 16, 32) and _lib.load().casmvs_costvol_lds_supported(C, W, D, 1, 1):  # the LDS-staged form: same bits
         assert torch.equal(_ops().homo_warp(src.to(dev), proj.to(dev), depth.to(dev), impl="lds").cpu(), got)
 
 
@@ -96,7 +97,8 @@ def test_costvol_matches_oracle(dev, report, B, V, C, G, h, w, D, geometry):
         assert torch.equal(nhwc.cpu(), feats.reshape(B * V, C, h, w).permute(0, 2, 3, 1).contiguous())
         got2 = _ops().costvol(nhwc.view(B, V, h, w, C), proj.to(dev), depth.to(dev), G, channels_last=True, impl="gather").cpu()
         assert torch.equal(got2, got)
-        if D % 8 == 0:
+        from casmvsnet_pl_amd import _lib
+        if _lib.load().casmvs_costvol_lds_supported(C, w, D, V - 1, G):
             got3 = _ops().costvol(nhwc.view(B, V, h, w, C), proj.to(dev), depth.to(dev), G, channels_last=True, impl="lds").cpu()
             assert torch.equal(got3, got)
 

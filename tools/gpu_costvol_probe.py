@@ -17,8 +17,11 @@ dev = torch.device("cuda:0")
 _, proj, dmin, dint = make_inputs(B, V, H, W, seed=0)
 
 
-def timed(fn, reps=10):
-    for _ in range(3):
+REPS = int(os.environ.get("CV_PROBE_REPS", "10"))
+
+
+def timed(fn, reps=REPS):
+    for _ in range(3 if reps > 1 else 0):
         fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()

@@ -12,13 +12,14 @@ echo "pytest exit: $?" >> $OUT/pytest_cv.log
 tail -15 $OUT/pytest_cv.log
 timeout 300 python tools/gpu_costvol_probe.py 512 640 3 1 > $OUT/probe_b1.txt 2>&1
 timeout 300 python tools/gpu_costvol_probe.py 512 640 3 2 > $OUT/probe_b2.txt 2>&1
-for cs in 8 32; do
+for cs in 16 32; do
   CV_PROBE_IMPLS=lds CASMVS_LIB_PATH=$ROOTDIR/casmvsnet_pl_amd/libcasmvs_trace.so CASMVS_CV_CS=$cs timeout 200 python tools/gpu_costvol_probe.py 512 640 3 1 > $OUT/probe_b1_cs$cs.txt 2>&1
 done
 CV_PROBE_IMPLS=lds CASMVS_LIB_PATH=$ROOTDIR/casmvsnet_pl_amd/libcasmvs_trace.so CASMVS_CV_TW=32 timeout 200 python tools/gpu_costvol_probe.py 512 640 3 1 > $OUT/probe_b1_tw32.txt 2>&1
+CV_PROBE_IMPLS=lds CASMVS_LIB_PATH=$ROOTDIR/casmvsnet_pl_amd/libcasmvs_cvdirect.so timeout 200 python tools/gpu_costvol_probe.py 512 640 3 1 > $OUT/probe_b1_direct.txt 2>&1
 CV_PROBE_G=8 timeout 200 python tools/gpu_costvol_probe.py 512 640 3 1 > $OUT/probe_b1_gwc8.txt 2>&1
 cat $OUT/probe_b1.txt
-grep -h "lds" $OUT/probe_b2.txt $OUT/probe_b1_cs8.txt $OUT/probe_b1_cs32.txt $OUT/probe_b1_tw32.txt | grep -v bitwise
+for f in probe_b2 probe_b1_cs16 probe_b1_cs32 probe_b1_tw32 probe_b1_direct; do echo "== $f"; grep -h "lds" $OUT/$f.txt | grep -v bitwise; done
 cat $OUT/probe_b1_gwc8.txt | grep -v homo
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
 python tools/show_bench.py $OUT/bench.json 2>/dev/null | head -40 || cut -c1-400 $OUT/bench.json
