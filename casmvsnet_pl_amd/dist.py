@@ -9,10 +9,11 @@ optional gather of the per-view results to rank 0.
 
 The view-sharded variant named by BASELINE configs 4/5 (each rank warps a subset of the source
 views, one all_reduce(SUM) of the sum / sum-of-squares accumulators per level) is implemented in
-`view_sharded_variance`: the accumulators are linear in the views, so the exchange is exact up to
+`view_sharded_cost_volume` on the HIP partial-sum kernels (`CascadeMVSNet.view_shard_group`,
+`bench.py --mode view_sharded`): the accumulators are linear in the views, so the exchange is exact up to
 fp32 summation order.  It moves 2*C*D*h*w*4 bytes per level through a ring that is bound by one
 xGMI link (~153 GB/s), i.e. ~10x-100x the time of building the same level locally from HBM - it is
-provided for completeness and measured honestly, not used by default.
+provided because the configs name it and measured honestly, not used by default.
 """
 import os
 
@@ -76,24 +77,56 @@ def max_over_ranks(seconds, device):
     return float(t.item())
 
 
-def view_shard(n_src_views, rank, world):
-    """Source views (1-based view ids 1..V-1) rank `rank` warps in the view-sharded variant."""
-    return [v for v in range(1, n_src_views + 1) if (v - 1) % world == rank]
+def view_range(n_src_views, rank, world):
+    """Source views [begin, end) (1-based view ids 1..V-1; view 0 is the reference) that rank `rank` warps in the
+    view-sharded build: contiguous, balanced (sizes differ by at most one); ranks beyond the number of source views
+    get an empty range."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    base, extra = divmod(n_src_views, world)
+    begin = 1 + rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
 
 
-def view_sharded_variance(partial_sums_fn, feats, proj_mats, depth_values, group=None):
-    """Variance cost volume with the source views split over the ranks of `group`.
+class HipSweepEngine:
+    """The per-rank engine of the view-sharded build: the HIP partial-sum / finalise kernels (include/casmvs.h:
+    casmvs_costvol_partial_{var,gwc}_f32, casmvs_costvol_{var,gwc}_finalize_f32)."""
 
-    partial_sums_fn(feats, proj_mats, depth_values, views, include_ref) -> (sum, sq) computes
-    sum_v warped_v and sum_v warped_v**2 over `views` (plus ref, ref**2 when include_ref) with the
-    local engine.  The two accumulators are all-reduced (SUM) and every rank finalises
-    var = sq/V - (sum/V)**2 (mvsnet.py:167)."""
+    @staticmethod
+    def partial(feats_nhwc, proj_mats, depth_values, begin, end, num_groups, include_ref):
+        from . import ops
+        return ops.costvol_partial(feats_nhwc, proj_mats, depth_values, begin, end, num_groups, include_ref)
+
+    @staticmethod
+    def zeros_like_partial(feats_nhwc, depth_values, num_groups):
+        B, V, h, w, C = feats_nhwc.shape
+        D = depth_values.shape[1]
+        shape = (2, B, C, D, h, w) if num_groups == 1 else (B, num_groups, D, h, w)
+        return torch.zeros(shape, dtype=torch.float32, device=feats_nhwc.device)
+
+    @staticmethod
+    def finalize(partial, V, num_groups):
+        from . import ops
+        return ops.costvol_finalize(partial, V, num_groups)
+
+
+def view_sharded_cost_volume(feats_nhwc, proj_mats, depth_values, num_groups=1, group=None, engine=HipSweepEngine):
+    """Cost volume of ONE set of reference views with the source views split over the ranks of `group`
+    (models/mvsnet.py:147-167 is the loop being sharded; BASELINE configs 4/5).
+
+    The sums are linear in the source views: rank r warps its views [begin, end) against the full reference
+    frustum - rank 0 also adds the reference terms ref / ref^2 - the partial buffers ((2,B,C,D,h,w) = sum and
+    sum of squares for the variance; (B,G,D,h,w) for the correlation) are combined with ONE all_reduce(SUM) per level,
+    and every rank finalises (var = sq/V - (sum/V)^2, or / (V-1)).  Exact up to fp32 summation order; with one rank it
+    equals the fused kernel bit for bit.  feats_nhwc (B,V,h,w,C) pixel-major, all views present on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    V = feats.shape[1]
-    s, q = partial_sums_fn(feats, proj_mats, depth_values, view_shard(V - 1, rank, world), rank == 0)
+    V = feats_nhwc.shape[1]
+    begin, end = view_range(V - 1, rank, world)
+    if begin < end:
+        part = engine.partial(feats_nhwc, proj_mats, depth_values, begin, end, num_groups, rank == 0)
+    else:   # more ranks than source views: this rank contributes nothing
+        part = engine.zeros_like_partial(feats_nhwc, depth_values, num_groups)
     if world > 1:
-        buf = torch.stack([s, q])  # one collective per level instead of two
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        s, q = buf[0], buf[1]
-    return q.div(V).sub(s.div(V).pow(2))
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return engine.finalize(part, V, num_groups)

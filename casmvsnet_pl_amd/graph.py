@@ -1,0 +1,61 @@
+"""Whole-forward hipGraph: `eval.py:213-222` calls `CascadeMVSNet.forward` once per reference view with the same
+shapes every time, and one forward is ~50 kernel launches of 5-300 us each.  Captured once into a hipGraph
+(torch.cuda.CUDAGraph drives hipStreamBeginCapture on ROCm) the launches cost the host one hipGraphLaunch, and the
+short kernels of the U-Net's bottom (conv3..conv9: ~20 us each) run back to back instead of at the host's launch rate.
+
+Everything the engine launches goes to torch's current stream with caller-owned buffers, no allocation, no
+synchronisation and no host read-back inside the library (include/casmvs.h), so a forward is capturable as is; the
+per-kernel one-time set-up (LDS opt-in, occupancy queries, weight packing, workspaces, cached per-level constants)
+happens in the warm-up calls before the capture.
+"""
+import torch
+
+
+class GraphedForward:
+    """model(imgs, proj_mats, init_depth_min, depth_interval) as one hipGraph replay.
+
+    The graph is captured for the shapes of the example inputs; `__call__` copies new inputs into the static input
+    buffers, replays, and returns the STATIC output tensors (overwritten by the next call: clone what must survive).
+    init_depth_min / depth_interval: python floats are baked into the graph (they select cached constant tensors);
+    (B,1) tensors are copied into static buffers like the images."""
+
+    def __init__(self, model, imgs, proj_mats, init_depth_min, depth_interval, warmup=2):
+        if model.training:
+            raise RuntimeError("GraphedForward captures the inference engine: call model.eval() first")
+        if not imgs.is_cuda:
+            raise RuntimeError("GraphedForward needs device-resident example inputs")
+        self.model = model
+        self.imgs = imgs.clone()
+        self.proj_mats = proj_mats.clone()
+        self.init_depth_min = init_depth_min.clone() if isinstance(init_depth_min, torch.Tensor) else init_depth_min
+        self.depth_interval = depth_interval.clone() if isinstance(depth_interval, torch.Tensor) else depth_interval
+        timer = model.timer
+        model.set_timer(None)  # events cannot be recorded into a capture
+        side = torch.cuda.Stream(device=imgs.device)
+        side.wait_stream(torch.cuda.current_stream(imgs.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                model(self.imgs, self.proj_mats, self.init_depth_min, self.depth_interval)
+        torch.cuda.current_stream(imgs.device).wait_stream(side)
+        torch.cuda.synchronize(imgs.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = model(self.imgs, self.proj_mats, self.init_depth_min, self.depth_interval)
+        model.set_timer(timer)
+
+    def __call__(self, imgs=None, proj_mats=None, init_depth_min=None, depth_interval=None):
+        if imgs is not None and imgs.data_ptr() != self.imgs.data_ptr():
+            self.imgs.copy_(imgs, non_blocking=True)
+        if proj_mats is not None and proj_mats.data_ptr() != self.proj_mats.data_ptr():
+            self.proj_mats.copy_(proj_mats, non_blocking=True)
+        for name, new in (("init_depth_min", init_depth_min), ("depth_interval", depth_interval)):
+            cur = getattr(self, name)
+            if new is None:
+                continue
+            if isinstance(cur, torch.Tensor):
+                cur.copy_(new.reshape(cur.shape), non_blocking=True)
+            elif float(new) != float(cur):
+                raise ValueError(f"GraphedForward: {name} = {new} differs from the captured constant {cur}; capture a new "
+                                 "graph (python floats are baked in) or pass (B,1) tensors when the range varies")
+        self.graph.replay()
+        return self.outputs

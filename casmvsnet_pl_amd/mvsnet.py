@@ -220,6 +220,9 @@ class CascadeMVSNet(nn.Module):
         self.timer = None        # optional profiling.StageTimer: HIP events around every stage
         self.last_index = {}     # level -> (B,h,w) int32 depth index, filled when keep_index is set
         self.keep_index = False
+        self.view_shard_group = None   # a torch.distributed group: split the source views over its ranks (dist.py)
+        self.keep_cost = False   # parity tests: keep the regularised cost (B,D,h,w) of every level in last_cost
+        self.last_cost = {}
         self._const_cache = {}
 
     def _const(self, value, B, device):
@@ -248,11 +251,16 @@ class CascadeMVSNet(nn.Module):
             B, V, C, h, w = feats.shape
             if feats_channels_last is None and C in (8, 16, 32):
                 feats_channels_last = ops.nchw_to_nhwc(feats.reshape(B * V, C, h, w)).view(B, V, h, w, C)
-            if feats_channels_last is not None:
+            if self.view_shard_group is not None:
+                from .dist import view_sharded_cost_volume
+                volume = view_sharded_cost_volume(feats_channels_last, proj_mats, depth_values, self.G, self.view_shard_group)
+            elif feats_channels_last is not None:
                 volume = ops.costvol(feats_channels_last, proj_mats, depth_values, self.G, channels_last=True)
             else:
                 volume = ops.costvol(feats, proj_mats, depth_values, self.G)
         cost = cost_reg(volume).squeeze(1)                                  # mvsnet.py:174
+        if self.keep_cost:
+            self.last_cost[level] = cost
         with stage(t, f"softmax_{level}"):
             if self.keep_index:
                 depth, confidence, index = ops.softmax_regress(cost, depth_values, return_index=True)

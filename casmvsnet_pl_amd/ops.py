@@ -57,6 +57,21 @@ def homo_warp(src_feat, proj_mat, depth_values, impl="auto"):
     return out
 
 
+def homo_warp_nhwc(src_nhwc, proj_mat, depth_values):
+    """modules.py:52-92 on a pixel-major source map (B,H,W,C) -> (B,C,D,H,W): casmvs_homo_warp_nhwc_f32
+    (LDS-staged).  Raises for shapes without an LDS plan (use homo_warp)."""
+    src, proj_mat, depth_values = _dev(src_nhwc, "src_nhwc"), _dev(proj_mat, "proj_mat"), _dev(depth_values, "depth_values")
+    B, H, W, C = src.shape
+    D = depth_values.shape[1]
+    if proj_mat.shape != (B, 3, 4) or depth_values.shape != (B, D, H, W):
+        raise ValueError(f"homo_warp_nhwc: shapes {tuple(src.shape)} {tuple(proj_mat.shape)} {tuple(depth_values.shape)}")
+    out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = _lib.load().casmvs_homo_warp_nhwc_f32(_ptr(src), _ptr(proj_mat), _ptr(depth_values), _ptr(out), B, C, H, W, D, _stream(src))
+    _lib.check(rc, "casmvs_homo_warp_nhwc_f32")
+    return out
+
+
 def nchw_to_nhwc(x):
     """(N, C, h, w) -> (N, h, w, C) device copy (casmvs_nchw_to_nhwc_f32), C in {8, 16, 32}."""
     x = _dev(x, "x")

@@ -19,7 +19,7 @@ def bench():
 
 
 def test_algorithmic_work_matches_survey_8d(bench):
-    H, W, V, G, n_depths, _ = bench.CONFIGS["dtu_640x512_v3_var"]
+    H, W, V, G, n_depths = bench.CONFIGS["dtu_640x512_v3_var"][:5]
     work = bench.algorithmic_work(H, W, V, G, n_depths)
     # fused cost-volume build 137.6 / 194.0 / 125.8 MB at levels 2 / 1 / 0 (work is keyed by level)
     assert [round(work[l]["costvol_bytes"] / 1e6, 1) for l in (2, 1, 0)] == [137.6, 194.0, 125.8]
@@ -29,6 +29,8 @@ def test_algorithmic_work_matches_survey_8d(bench):
     assert [round(work[l]["conv0_flops"] / 1e9, 2) for l in (2, 1, 0)] == [13.59, 18.12, 9.06]
     gwc = bench.algorithmic_work(*bench.CONFIGS["dtu_640x512_v3_gwc8"][:5])
     assert [round(gwc[l]["costvol_bytes"] / 1e6, 1) for l in (2, 1, 0)] == [43.3, 110.1, 125.8]
+    # the un-fused homo_warp op: 132.4 / 183.5 / 104.9 MB (one source view)
+    assert [round(work[l]["homo_warp_bytes"] / 1e6, 1) for l in (2, 1, 0)] == [132.4, 183.5, 104.9]
     # FeatureNet: 16.9 GFLOP for the 3 views
     assert round(3 * bench.feature_flops(H, W) / 1e9, 1) == 16.9
 

@@ -1,0 +1,114 @@
+"""GPU tests of the pieces around the kernels: the whole-forward hipGraph, the view-sharded build over RCCL
+(world size 1 - one GPU per gpurun box - so that `backend="nccl"` and the bench launcher are executed at all), and
+bench.py's output contract under torch.distributed.run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def _model(dev, G=1, seed=3):
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet
+    from casmvsnet_pl_amd.synthetic import randomize_state_dict
+    m = CascadeMVSNet(num_groups=G, norm_act=ABN)
+    randomize_state_dict(m.state_dict(), seed=seed)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("tensor_range", [False, True])
+def test_graph_replay_equals_eager(dev, tensor_range):
+    """One hipGraph replay == the kernel-by-kernel forward, bit for bit, also after the inputs changed."""
+    from casmvsnet_pl_amd.graph import GraphedForward
+    from casmvsnet_pl_amd.synthetic import make_inputs
+    model = _model(dev)
+    B = 2
+    imgs, proj, dmin, dint = make_inputs(B, 3, 64, 96, seed=1)
+    imgs2, proj2, _, _ = make_inputs(B, 3, 64, 96, seed=2)
+    if tensor_range:
+        dmin = torch.tensor([[dmin], [dmin + 20.0]], device=dev)
+        dint = torch.tensor([[dint], [dint * 0.9]], device=dev)
+    gf = GraphedForward(model, imgs.to(dev), proj.to(dev), dmin, dint)
+    for a, b in ((imgs, proj), (imgs2, proj2), (imgs, proj)):
+        want = {k: v.clone() for k, v in model(a.to(dev), b.to(dev), dmin, dint).items()}
+        got = gf(a.to(dev), b.to(dev))
+        torch.cuda.synchronize()
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+    if not tensor_range:
+        with pytest.raises(ValueError, match="captured constant"):
+            gf(imgs.to(dev), proj.to(dev), 400.0, dint)
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29613"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _bench_line(out):
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, out.stderr[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_under_torchrun_world1_replica():
+    """The driver's multi-GPU launch line at N = 1: torch.distributed.run + nccl (= RCCL) process group."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29611", "bench.py", "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-batch1"])
+    line = _bench_line(out)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["value"] > 50
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert 0.05 < line["roofline"]["frac"] < 1.0
+
+
+def test_bench_view_sharded_world1_runs_the_rccl_path():
+    """bench.py --mode view_sharded: partial-sum kernels + all_reduce over the nccl backend + finalise (world size 1)."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29612", "bench.py", "--gpus", "1", "--steps", "4", "--warmup", "2", "--mode", "view_sharded",
+                "--config", "dtu_1152x864_v5_var", "--batch", "1", "--no-cpu-baseline", "--no-events"])
+    line = _bench_line(out)
+    assert line["scaling"] == "strong" and "view-sharded" in line["config"]["parallelism"] and line["value"] > 5
+
+
+VIEW_SHARD_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from casmvsnet_pl_amd import ABN, CascadeMVSNet
+from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+ok = True
+for G, V in ((1, 5), (8, 3)):
+    m = CascadeMVSNet(num_groups=G, norm_act=ABN)
+    randomize_state_dict(m.state_dict(), seed=4)
+    m = m.to(dev).eval()
+    imgs, proj, dmin, dint = make_inputs(1, V, 64, 96, seed=6)
+    want = {k: v.clone() for k, v in m(imgs.to(dev), proj.to(dev), dmin, dint).items()}
+    m.view_shard_group = dist.group.WORLD
+    got = m(imgs.to(dev), proj.to(dev), dmin, dint)
+    ok = ok and all(torch.equal(got[k], want[k]) for k in want)
+dist.destroy_process_group()
+print("VIEW_SHARDED_EQUALS_FUSED", ok)
+"""
+
+
+def test_view_sharded_model_equals_fused_world1():
+    """CascadeMVSNet.view_shard_group at world size 1 over nccl: partial sums + all-reduce + finalise reproduce the
+    fused kernels' depth maps bit for bit (variance V = 5 and group-wise correlation)."""
+    out = _run([sys.executable, "-c", VIEW_SHARD_SCRIPT], timeout=600)
+    assert "VIEW_SHARDED_EQUALS_FUSED True" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
