@@ -93,7 +93,7 @@ def pmc_traffic(kernel_prefix, batch):
 
 def cpu_baseline(cfg_name):
     """Oracle (CPU port of the reference forward) on the same synthetic workload, at the best of a sweep over the
-    host's thread count (all 128 hardware threads of the GPU box are 2x slower than 16-32: oversubscription)."""
+    host's thread count (all 256 hardware threads of the GPU box are 25x slower than 8: oversubscription)."""
     from oracle import cpu_restatement as R
     H, W, V, G, n_depths, ratios, _ = CONFIGS[cfg_name]
     model = CascadeMVSNet(n_depths=list(n_depths), interval_ratios=list(ratios), num_groups=G, norm_act=ABN)
@@ -101,7 +101,7 @@ def cpu_baseline(cfg_name):
     imgs, proj, dmin, dint = config_inputs(cfg_name, 1, seed=0)
     ncpu = os.cpu_count() or 8
     old = torch.get_num_threads()
-    sweep = sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu})
+    sweep = sorted({t for t in (4, 8, 16, 32, 64) if t <= ncpu})   # beyond 64 threads torch's CPU ops only lose (256 threads: 54 s per forward)
     best, per_threads = None, {}
     t_start = time.perf_counter()
     for i, nt in enumerate(sweep):
