@@ -1,0 +1,188 @@
+// Depth filtering / fusion of one reference view against its source views.
+//
+// Reference semantics: eval.py:113-182 (xy_ref2src, xy_src2ref, check_geo_consistency: numba + cv2.remap) and
+// eval.py:273-326 (confidence mask via cv2.resize x4, geometric mask count, depth / colour averaging, world points).
+// The two OpenCV functions are restated (oracle/fusion_restatement.py states from what): remap = 5-bit fixed-point
+// coordinates + a 32 x 32 weight table (float weights for the depth map, 15-bit integer weights for the 8-bit image),
+// constant-0 border; resize = half-pixel-centre bilinear, horizontal then vertical.
+//
+// One thread per reference pixel, lanes along the row: the reference maps are read / written coalesced; each source
+// view costs 4 depth taps + 4 x 3 byte taps around one projected point - neighbouring pixels project to neighbouring
+// points, so the gathers of a wavefront fall into a few cache lines.  HBM-bound (algorithmic bytes per reference
+// view: H W (4 + 3 + S (4 + 3)) read, H W (4 + 24 + 4 + 1 + 12) written).  Built with -ffp-contract=off: every
+// float operation below is separately rounded, in the oracle's order; masks and counts are integer work and must
+// match the oracle bit for bit.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int INTER_BITS = 5, INTER_TAB = 32;
+
+struct FuseArgs {
+  const float *depth_ref;          // (H, W)
+  const unsigned char *image_ref;  // (H, W, 3)
+  const float *proba_quarter;      // (H/4, W/4) or nullptr (no confidence mask)
+  const float *depth_src;          // (S, H, W)
+  const unsigned char *image_src;  // (S, H, W, 3)
+  const float *m_ref2src;          // (S, 3, 4)  (P_src @ inv(P_ref))[:3]
+  const float *m_src2ref;          // (S, 3, 4)  (P_ref @ inv(P_src))[:3]
+  const float *m_ref2world;        // (3, 4) rows of inv(P_ref), or nullptr (no world points)
+  float *depth_refined;            // (H, W)
+  double *image_refined;           // (H, W, 3)
+  int *mask_geo_sum;               // (H, W)
+  unsigned char *mask_final;       // (H, W)
+  float *xyz_world;                // (H, W, 3) or nullptr
+  unsigned char *mask_geo;         // (S, H, W) or nullptr: the per-view masks of check_geo_consistency
+  float *depth_reproj;             // (S, H, W) or nullptr: the per-view masked reprojected depths
+  unsigned char *image_s2r;        // (S, H, W, 3) or nullptr: the per-view masked warped source images
+  int S, H, W;
+  float conf;
+  int min_geo_consistent;
+};
+
+// cvRound(v * 32): round half to even; NaN / beyond int32 -> INT_MIN like x86's cvtss2si
+__device__ __forceinline__ int fixed_coord(float v) {
+  const float r = rintf(v * (float)INTER_TAB);
+  return (fabsf(r) < 2147483648.0f) ? (int)r : (int)0x80000000;
+}
+
+__device__ __forceinline__ float project_row(const float *m, float X, float Y, float Z) {
+  return ((m[0] * X + m[1] * Y) + m[2] * Z) + m[3];
+}
+
+// cv2.resize(proba, fx = 4, fy = 4, INTER_LINEAR) at destination pixel (x, y): hresize of the two rows, then vresize
+__device__ __forceinline__ float resize_x4(const float *__restrict__ p, int hq, int wq, int x, int y) {
+  auto coef = [](int d, int n, int &s0, int &s1, float &a) {
+    const float f = (float)(((double)d + 0.5) * 0.25 - 0.5);
+    int s = (int)floorf(f);
+    a = f - (float)s;
+    if (s < 0) { s = 0; a = 0.0f; }
+    if (s >= n - 1) { s = n - 1; a = 0.0f; }
+    s0 = s;
+    s1 = min(s + 1, n - 1);
+  };
+  int x0, x1, y0, y1;
+  float ax, ay;
+  coef(x, wq, x0, x1, ax);
+  coef(y, hq, y0, y1, ay);
+  const float r0 = p[y0 * wq + x0] * (1.0f - ax) + p[y0 * wq + x1] * ax;
+  const float r1 = p[y1 * wq + x0] * (1.0f - ax) + p[y1 * wq + x1] * ax;
+  return r0 * (1.0f - ay) + r1 * ay;
+}
+
+__global__ __launch_bounds__(kThreads) void fuse_view_kernel(const FuseArgs a) {
+  const int x = blockIdx.x * kThreads + threadIdx.x, y = blockIdx.y;
+  if (x >= a.W) return;
+  const int H = a.H, W = a.W, hw = H * W, p = y * W + x;
+  const float d = a.depth_ref[p];
+  const float xf = (float)x, yf = (float)y;
+  const float X = xf * d, Y = yf * d;                       // eval.py:117: (x, y, 1) * depth_ref
+  float dsum = d;                                           // np.sum([depth_ref, reproj_1, ...], 0): sequential float32
+  unsigned isum[3] = {a.image_ref[3 * p], a.image_ref[3 * p + 1], a.image_ref[3 * p + 2]};
+  int nsum = 0;
+  for (int s = 0; s < a.S; ++s) {
+    const float *M = a.m_ref2src + s * 12;
+    const float q0 = project_row(M, X, Y, d), q1 = project_row(M + 4, X, Y, d), q2 = project_row(M + 8, X, Y, d);
+    const float u = q0 / q2, v = q1 / q2;                   // eval.py:123
+    // cv2.remap: fixed-point coordinates, 2x2 taps with constant-0 border
+    const int sx = fixed_coord(u), sy = fixed_coord(v);
+    const int ix = min(max(sx >> INTER_BITS, -32768), 32767), iy = min(max(sy >> INTER_BITS, -32768), 32767);
+    const int fx = sx & (INTER_TAB - 1), fy = sy & (INTER_TAB - 1);
+    const float ax = (float)fx / (float)INTER_TAB, ay = (float)fy / (float)INTER_TAB;
+    const float w0 = (1.0f - ay) * (1.0f - ax), w1 = (1.0f - ay) * ax, w2 = ay * (1.0f - ax), w3 = ay * ax;
+    const bool x0in = ix >= 0 && ix < W, x1in = ix + 1 >= 0 && ix + 1 < W;
+    const bool y0in = iy >= 0 && iy < H, y1in = iy + 1 >= 0 && iy + 1 < H;
+    const int cx0 = min(max(ix, 0), W - 1), cx1 = min(max(ix + 1, 0), W - 1);
+    const int cy0 = min(max(iy, 0), H - 1), cy1 = min(max(iy + 1, 0), H - 1);
+    const float *ds = a.depth_src + (size_t)s * hw;
+    const float t0 = (x0in && y0in) ? ds[cy0 * W + cx0] : 0.0f, t1 = (x1in && y0in) ? ds[cy0 * W + cx1] : 0.0f;
+    const float t2 = (x0in && y1in) ? ds[cy1 * W + cx0] : 0.0f, t3 = (x1in && y1in) ? ds[cy1 * W + cx1] : 0.0f;
+    const float d_s2r = ((t0 * w0 + t1 * w1) + t2 * w2) + t3 * w3;   // remapBilinear, CV_32F
+    // 8-bit image: integer weights that sum to 2^15, rounding shift
+    int wi[4];
+    {
+      const float wf[4] = {w0, w1, w2, w3};
+      int tot = 0, kmax = 0, kmin = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        wi[k] = (int)rint((double)wf[k] * 32768.0);
+        tot += wi[k];
+      }
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {   // first maximum / first minimum, like numpy's argmax / argmin
+        if (wi[k] > wi[kmax]) kmax = k;
+        if (wi[k] < wi[kmin]) kmin = k;
+      }
+      const int diff = tot - 32768;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k == (diff < 0 ? kmax : kmin)) wi[k] -= diff;
+    }
+    const unsigned char *is = a.image_src + (size_t)s * hw * 3;
+    int col[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int b0 = (x0in && y0in) ? is[(cy0 * W + cx0) * 3 + c] : 0, b1 = (x1in && y0in) ? is[(cy0 * W + cx1) * 3 + c] : 0;
+      const int b2 = (x0in && y1in) ? is[(cy1 * W + cx0) * 3 + c] : 0, b3 = (x1in && y1in) ? is[(cy1 * W + cx1) * 3 + c] : 0;
+      const int acc = b0 * wi[0] + b1 * wi[1] + b2 * wi[2] + b3 * wi[3];
+      col[c] = min(max((acc + (1 << 14)) >> 15, 0), 255);
+    }
+    // back to the reference view with the sampled depth            (eval.py:130-153)
+    const float X2 = u * d_s2r, Y2 = v * d_s2r;
+    const float *Q = a.m_src2ref + s * 12;
+    const float r0 = project_row(Q, X2, Y2, d_s2r), r1 = project_row(Q + 4, X2, Y2, d_s2r), r2 = project_row(Q + 8, X2, Y2, d_s2r);
+    const float ddx = r0 / r2 - xf, ddy = r1 / r2 - yf;
+    const bool m_pix = (ddx * ddx + ddy * ddy) < 1.0f;            // |p_reproj - p| < 1
+    const bool m_dep = fabsf((r2 - d) / d) < 0.01f;               // |d_reproj - d| / d < 0.01   (NaN -> false)
+    const bool m = m_pix && m_dep;
+    const float dr = m ? r2 : 0.0f;                               // depth_ref_reproj[~mask_geo] = 0
+    dsum = dsum + dr;
+    nsum += m ? 1 : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) isum[c] += m ? (unsigned)col[c] : 0u;
+    if (a.mask_geo) a.mask_geo[(size_t)s * hw + p] = m ? 1 : 0;
+    if (a.depth_reproj) a.depth_reproj[(size_t)s * hw + p] = dr;
+    if (a.image_s2r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.image_s2r[((size_t)s * hw + p) * 3 + c] = m ? (unsigned char)col[c] : 0;
+    }
+  }
+  // float32 sum / int count in float64, rounded to float32          (eval.py:312-313)
+  const float drf = (float)((double)dsum / (double)(nsum + 1));
+  a.depth_refined[p] = drf;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a.image_refined[(size_t)3 * p + c] = (double)isum[c] / (double)(nsum + 1);
+  a.mask_geo_sum[p] = nsum;
+  bool m_conf = true;
+  if (a.proba_quarter) m_conf = resize_x4(a.proba_quarter, H / 4, W / 4, x, y) > a.conf;   // eval.py:281-283
+  a.mask_final[p] = (m_conf && nsum >= a.min_geo_consistent) ? 1 : 0;
+  if (a.xyz_world) {   // inv(P_ref) @ (x d, y d, d, 1): int64 * float32 -> float64 products (eval.py:322-327)
+    const double Xw = (double)x * (double)drf, Yw = (double)y * (double)drf, Zw = (double)drf;
+    const float *Mi = a.m_ref2world;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      a.xyz_world[(size_t)3 * p + i] = (float)((((double)Mi[4 * i] * Xw + (double)Mi[4 * i + 1] * Yw) + (double)Mi[4 * i + 2] * Zw) + (double)Mi[4 * i + 3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int casmvs_fuse_reference_view(const float *depth_ref, const unsigned char *image_ref, const float *proba_quarter,
+                                          const float *depth_src, const unsigned char *image_src, const float *m_ref2src,
+                                          const float *m_src2ref, const float *m_ref2world, float *depth_refined,
+                                          double *image_refined, int32_t *mask_geo_sum, unsigned char *mask_final,
+                                          float *xyz_world, unsigned char *mask_geo, float *depth_reproj, unsigned char *image_s2r,
+                                          int S, int H, int W, float conf, int min_geo_consistent, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(depth_ref && image_ref && depth_refined && image_refined && mask_geo_sum && mask_final, "fuse_reference_view: null pointer");
+  CASMVS_REQUIRE(S >= 0 && H > 0 && W > 0 && H <= 65535, "fuse_reference_view: bad shape S=%d H=%d W=%d", S, H, W);
+  CASMVS_REQUIRE(S == 0 || (depth_src && image_src && m_ref2src && m_src2ref), "fuse_reference_view: null source-view pointer");
+  CASMVS_REQUIRE(!proba_quarter || (H % 4 == 0 && W % 4 == 0), "fuse_reference_view: the confidence map is (H/4, W/4): H, W must be multiples of 4");
+  CASMVS_REQUIRE(!xyz_world || m_ref2world, "fuse_reference_view: xyz_world needs m_ref2world");
+  FuseArgs a{depth_ref, image_ref, proba_quarter, depth_src, image_src, m_ref2src, m_src2ref, m_ref2world, depth_refined,
+             image_refined, mask_geo_sum, mask_final, xyz_world, mask_geo, depth_reproj, image_s2r, S, H, W, conf, min_geo_consistent};
+  dim3 grid((unsigned)casmvs::ceil_div(W, kThreads), (unsigned)H);
+  hipLaunchKernelGGL(fuse_view_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  return casmvs::check_launch("fuse_view_kernel");
+}

@@ -247,6 +247,23 @@ int casmvs_softmax_regress_f32(const float *cost, const float *depth_values, flo
 int casmvs_depth_regression_f32(const float *prob, const float *depth_values, float *out, int B, int D,
                                 int h, int w, int depth_values_per_plane, void *stream);
 
+/* ---- (f-3) depth filtering / fusion of one reference view --------------------------------------
+ * Replaces: eval.py:113-182 (xy_ref2src, xy_src2ref, check_geo_consistency) and eval.py:273-326 (confidence mask,
+ * geometric-consistency count, depth / colour averaging, back-projection) for ONE reference view against S source
+ * views; the surrounding scan loop / PFM / PLY I/O stays on the host.  All maps are full resolution (H, W).
+ * depth_ref (H,W) f32; image_ref (H,W,3) u8; proba_quarter (H/4,W/4) f32 = confidence_2, or NULL (no confidence mask);
+ * depth_src (S,H,W) f32; image_src (S,H,W,3) u8; m_ref2src / m_src2ref (S,3,4) f32 = (P_src inv(P_ref))[:3] /
+ * (P_ref inv(P_src))[:3]; m_ref2world (3,4) = rows of inv(P_ref) or NULL.
+ * Outputs: depth_refined (H,W) f32; image_refined (H,W,3) f64; mask_geo_sum (H,W) i32; mask_final (H,W) u8 =
+ * (proba > conf) & (mask_geo_sum >= min_geo_consistent); optional xyz_world (H,W,3) f32 for every pixel, mask_geo
+ * (S,H,W) u8, depth_reproj (S,H,W) f32 and image_s2r (S,H,W,3) u8 (the per-view results of check_geo_consistency). */
+int casmvs_fuse_reference_view(const float *depth_ref, const unsigned char *image_ref, const float *proba_quarter,
+                               const float *depth_src, const unsigned char *image_src, const float *m_ref2src,
+                               const float *m_src2ref, const float *m_ref2world, float *depth_refined,
+                               double *image_refined, int32_t *mask_geo_sum, unsigned char *mask_final,
+                               float *xyz_world, unsigned char *mask_geo, float *depth_reproj, unsigned char *image_s2r,
+                               int S, int H, int W, float conf, int min_geo_consistent, void *stream);
+
 /* ---- self test ------------------------------------------------------------------------------
  * Runs the MFMA lane-mapping probes the conv kernels rely on (v_mfma_f32_16x16x4_f32 operand /
  * result layout, and v_mfma_f32_4x4x1_16b_f32 with A-block broadcast).  Returns 0 when the hardware semantics match the kernels' assumptions.
