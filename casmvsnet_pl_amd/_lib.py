@@ -51,6 +51,8 @@ SYMBOLS = {
     "casmvs_softmax_regress_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_depth_regression_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_fuse_reference_view": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "casmvs_homo_warp_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_softmax_regress_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_selftest_mfma": (c_int, [_FP]),
     "casmvs_selftest_mfma_rate": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
 }

@@ -264,6 +264,17 @@ int casmvs_fuse_reference_view(const float *depth_ref, const unsigned char *imag
                                float *xyz_world, unsigned char *mask_geo, float *depth_reproj, unsigned char *image_s2r,
                                int S, int H, int W, float conf, int min_geo_consistent, void *stream);
 
+/* ---- (f-2) backward of the plane sweep and of the depth regression (training, op by op) -----------
+ * casmvs_homo_warp_backward_f32: the gradient of models/modules.py:52-92 with respect to src_feat (the grid depends on
+ *   the DETACHED depth hypotheses only, mvsnet.py:231): grad_src (B,C,H,W) = scatter-add of grad_out (B,C,D,H,W) with the
+ *   forward's bilinear weights (fp32 hardware atomics).  grad_src is zeroed by the call.
+ * casmvs_softmax_regress_backward_f32: depth = sum_k softmax(cost)_k d_k (mvsnet.py:175-177): grad_cost (B,D,h,w) =
+ *   grad_depth (B,h,w) * p_k (d_k - depth).  (The confidence is computed under no_grad in the reference.) */
+int casmvs_homo_warp_backward_f32(const float *grad_out, const float *proj, const float *depth, float *grad_src,
+                                  int B, int C, int H, int W, int D, void *stream);
+int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_values, const float *grad_depth,
+                                        float *grad_cost, int B, int D, int h, int w, void *stream);
+
 /* ---- self test ------------------------------------------------------------------------------
  * Runs the MFMA lane-mapping probes the conv kernels rely on (v_mfma_f32_16x16x4_f32 operand /
  * result layout, and v_mfma_f32_4x4x1_16b_f32 with A-block broadcast).  Returns 0 when the hardware semantics match the kernels' assumptions.
