@@ -62,7 +62,7 @@ def test_softmax_regression_backward_matches_autograd_of_the_oracle(dev, report,
     err = float((c_dev.grad.cpu().double() - c64.grad).abs().max() / c64.grad.abs().max())
     report("softmax_regress_backward", shape=[B, D, h, w], scaled_err=err)
     assert float((depth.detach().cpu().double() - depth64.detach()).abs().max()) < 1e-3
-    assert err < 1e-5
+    assert err < 1e-4   # measured 9e-6..2e-5: (d_k - depth) cancels ~3 digits of the fp32 depths (d ~ 500, spacing 2.65)
 
 
 def test_training_style_cost_volume_is_differentiable_end_to_end(dev):

@@ -422,8 +422,9 @@ def _check_levels(report, name, got, model, want, want_index, want_cost, extra=N
         assert stats[f"index_flips_{l}"] <= stats[f"pixels_within_tol_of_boundary_{l}"]
         assert stats[f"conf_abs_{l}"] < 5 * boundary_tol, (l, stats[f"conf_abs_{l}"])  # measured 1.4e-4 (1.6e-3 for gwc8)
         if f"cost_scaled_err_{l}" in stats:
-            # the cost of a finer level also carries the coarser levels' depth error (shifted hypotheses): measured 4.7e-5
-            assert stats[f"cost_scaled_err_{l}"] < 5e-4, (l, stats[f"cost_scaled_err_{l}"])
+            # level 2 is pure kernel error (measured 5e-6); a finer level's cost also carries the coarser levels' depth
+            # error - its hypotheses are shifted by it - (measured up to 6.5e-4 at 1152x864)
+            assert stats[f"cost_scaled_err_{l}"] < (5e-5 if l == 2 else 5e-3), (l, stats[f"cost_scaled_err_{l}"])
             assert stats[f"flip_max_boundary_dist_{l}"] <= stats[f"e_noise_{l}"] + 1e-5   # a flip needs e to cross the boundary
     return stats
 
