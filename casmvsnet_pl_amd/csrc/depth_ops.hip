@@ -143,7 +143,33 @@ __global__ __launch_bounds__(kThreads) void depth_regression_kernel(const float 
   out[(size_t)b * hw + p] = acc;
 }
 
+// ---- input images: uint8 HWC -> normalised float CHW ---------------------------------------------------------
+// datasets/dtu.py:134-137 (T.ToTensor + T.Normalize): x = u8 / 255, then (x - mean[c]) / std[c], all float32 - done on
+// the device so that the host uploads 1 byte per sample instead of 4.  Thread per pixel, three coalesced plane stores.
+__global__ __launch_bounds__(kThreads) void normalize_u8_kernel(const unsigned char *__restrict__ in, float *__restrict__ out,
+                                                               int hw, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= hw) return;
+  const unsigned char *ip = in + ((size_t)n * hw + p) * 3;
+  float *op = out + (size_t)n * 3 * hw + p;
+  op[0] = ((float)ip[0] / 255.0f - m0) / s0;
+  op[hw] = ((float)ip[1] / 255.0f - m1) / s1;
+  op[2 * (size_t)hw] = ((float)ip[2] / 255.0f - m2) / s2;
+}
+
 }  // namespace
+
+extern "C" int casmvs_normalize_images_u8(const unsigned char *images, float *out, int N, int H, int W, const float *mean3,
+                                          const float *std3, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(images && out && mean3 && std3, "normalize_images: null pointer");
+  CASMVS_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0, "normalize_images: bad shape N=%d H=%d W=%d", N, H, W);
+  dim3 grid((unsigned)casmvs::ceil_div(H * W, kThreads), (unsigned)N);
+  hipLaunchKernelGGL(normalize_u8_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, images, out, H * W, mean3[0], mean3[1],
+                     mean3[2], std3[0], std3[1], std3[2]);
+  return casmvs::check_launch("normalize_u8_kernel");
+}
 
 extern "C" int casmvs_depth_regression_f32(const float *prob, const float *depth_values, float *out, int B, int D,
                                            int h, int w, int depth_values_per_plane, void *stream) {

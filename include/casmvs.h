@@ -247,6 +247,12 @@ int casmvs_softmax_regress_f32(const float *cost, const float *depth_values, flo
 int casmvs_depth_regression_f32(const float *prob, const float *depth_values, float *out, int B, int D,
                                 int h, int w, int depth_values_per_plane, void *stream);
 
+/* ---- (f-4) input images ------------------------------------------------------------------------
+ * Replaces: datasets/dtu.py:134-137 (T.ToTensor + T.Normalize) on the device: images (N,H,W,3) uint8 RGB ->
+ * out (N,3,H,W) float32 = (u8 / 255 - mean[c]) / std[c]; mean3 / std3 are HOST arrays of 3 floats. */
+int casmvs_normalize_images_u8(const unsigned char *images, float *out, int N, int H, int W, const float *mean3,
+                               const float *std3, void *stream);
+
 /* ---- (f-3) depth filtering / fusion of one reference view --------------------------------------
  * Replaces: eval.py:113-182 (xy_ref2src, xy_src2ref, check_geo_consistency) and eval.py:273-326 (confidence mask,
  * geometric-consistency count, depth / colour averaging, back-projection) for ONE reference view against S source
