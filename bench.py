@@ -9,7 +9,9 @@ A "step" is one forward pass (FeatureNet + 3 cascade levels) over one batch of -
 reference's DTU training batch; `--batch 1` is its eval.py loop and is ALSO measured and printed as "batch1") with
 their source views: DTU 640x512, 3 views, n_depths [8,32,48], variance cost volume, fp32, synthetic inputs already
 resident in HBM, random-init weights.  The timed steps replay the forward as one hipGraph (casmvsnet_pl_amd/graph.py;
-`--no-graph` launches kernel by kernel).
+`--no-graph` launches kernel by kernel), and --streams (default 2) independent forwards are in flight per GPU, each on
+its own HIP stream: a step is then one round of all of them (reference views are independent, eval.py:213); the
+single-stream figure is measured and printed beside it ("single_stream").
 
 --mode replica (default): with N GPUs every rank processes its own depth maps (the path shards at depth-map
 granularity, SURVEY 8e: no data-path collective) -> weak scaling; value = depth maps all ranks produced / max-over-ranks
@@ -35,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from casmvsnet_pl_amd import ABN, CascadeMVSNet  # noqa: E402
-from casmvsnet_pl_amd.graph import GraphedForward  # noqa: E402
+from casmvsnet_pl_amd.graph import ConcurrentForwards, GraphedForward  # noqa: E402
 from casmvsnet_pl_amd.profiling import StageTimer  # noqa: E402
 from casmvsnet_pl_amd.synthetic import CONFIGS, config_inputs, randomize_state_dict  # noqa: E402
 
@@ -184,6 +186,9 @@ def main():
                          "--batch 1 = the reference's eval.py loop, always measured too)")
     ap.add_argument("--mode", default="replica", choices=["replica", "view_sharded"])
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying one hipGraph")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent forwards in flight per GPU, one HIP stream + hipGraph each (a step = one round of all of "
+                         "them; 1 = a single forward per step).  The single-stream figures are printed as well.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the instrumented pass (no roofline objects)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-1 measurement")
@@ -224,12 +229,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(B, steps, warmup):
+    def measure(B, steps, warmup, streams=1):
         model, imgs, proj, dmin, dint = build(B)
         for _ in range(warmup):
             model(imgs, proj, dmin, dint)
         use_graph = not args.no_graph and not view_sharded   # a collective inside a capture is not attempted
-        if use_graph:
+        if use_graph and streams > 1:
+            cf = ConcurrentForwards(model, imgs, proj, dmin, dint, n_streams=streams)
+            step = lambda: cf.run()[-1]
+        elif use_graph:
             gf = GraphedForward(model, imgs, proj, dmin, dint)
             step = lambda: gf(imgs, proj)
         else:
@@ -243,9 +251,10 @@ def main():
         return model, (imgs, proj, dmin, dint), elapsed, use_graph
 
     B = args.batch
-    model, inputs, elapsed, used_graph = measure(B, args.steps, args.warmup)
+    NS = 1 if (view_sharded or args.no_graph) else max(1, args.streams)
+    model, inputs, elapsed, used_graph = measure(B, args.steps, args.warmup, NS)
     K = args.steps
-    maps = (1 if view_sharded else world) * B * K
+    maps = (1 if view_sharded else world) * B * NS * K
     line = None
     if rank == 0:
         line = {
@@ -255,9 +264,11 @@ def main():
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if view_sharded else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config, "H": H, "W": W, "views": V, "n_depths": list(n_depths),
-                       "interval_ratios": list(ratios), "num_groups": G, "depth_maps_per_step_per_gpu": B,
+                       "interval_ratios": list(ratios), "num_groups": G, "depth_maps_per_step_per_gpu": B * NS,
+                       "batch_per_forward": B, "concurrent_forwards_per_gpu": NS,
                        "depth_interval": inputs[3], "init_depth_min": inputs[2],
-                       "launch": "one hipGraph replay per step" if used_graph else "kernel by kernel",
+                       "launch": (f"{NS} independent forwards per step, each one hipGraph replay on its own HIP stream" if NS > 1 else
+                                  "one hipGraph replay per step") if used_graph else "kernel by kernel",
                        "parallelism": (f"view-sharded x{world}: source views split over the ranks, one RCCL all-reduce of the sum / "
                                        "sum-of-squares volumes per level, every rank regularises") if view_sharded else
                                       f"replica x{world} (one depth map stream per GPU, no data-path collective)",
@@ -322,12 +333,22 @@ def main():
                                          "note": "kernel-by-kernel launches with ~90 HIP events per step, right after the timed steps"}
     del model
     # ---- the reference's eval.py loop: one reference view per step ---------------------------------------------------
+    if NS > 1:
+        _, _, els, gs = measure(B, K, max(2, args.warmup // 2), 1)
+        if rank == 0:
+            line["single_stream"] = {"value": world * B * K / els, "unit": "depth-maps/s", "ms_per_step": 1e3 * els / K, "steps": K,
+                                     "note": f"one forward of batch {B} per step (one stream, one hipGraph replay)"}
     if B != 1 and not args.no_batch1:
-        _, _, el1, g1 = measure(1, K, max(2, args.warmup // 2))
+        _, _, el1, g1 = measure(1, K, max(2, args.warmup // 2), 1)
         if rank == 0:
             line["batch1"] = {"value": (1 if view_sharded else world) * K / el1, "unit": "depth-maps/s", "ms_per_step": 1e3 * el1 / K,
                               "steps": K, "launch": "one hipGraph replay per step" if g1 else "kernel by kernel",
-                              "note": "eval.py:213-222 processes one reference view per forward"}
+                              "note": "eval.py:213-222 processes one reference view per forward (one stream)"}
+        if NS > 1:
+            _, _, el1s, _ = measure(1, K, max(2, args.warmup // 2), NS)
+            if rank == 0:
+                line["batch1"]["concurrent"] = {"value": world * NS * K / el1s, "unit": "depth-maps/s", "ms_per_step": 1e3 * el1s / K,
+                                                "note": f"{NS} single-view forwards in flight, one stream each"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)

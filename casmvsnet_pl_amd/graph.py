@@ -59,3 +59,45 @@ class GraphedForward:
                                  "graph (python floats are baked in) or pass (B,1) tensors when the range varies")
         self.graph.replay()
         return self.outputs
+
+
+class ConcurrentForwards:
+    """N captured forwards on N HIP streams, for throughput over INDEPENDENT reference views (eval.py:213 iterates them
+    with no cross-iteration state).
+
+    Why: one forward is a chain of ~50 dependent kernels; about a third of them (the bottom of the 3D U-Net, the
+    level-2 layers, the softmax / hypothesis kernels) launch fewer workgroups than the chip holds, and every kernel has a
+    drain tail.  A second, independent forward on another stream fills those holes: measured on the MI355X
+    (tools/gpu_streams_probe.py) 2 streams x batch 2 = 684 depth maps/s against 627 for one stream (batch 4 on one
+    stream: 663; 3 streams: no further gain).  Each stream owns a replica of the module (its workspaces and packed
+    weights, ~10 MB) so that the forwards share nothing but the read-only inputs they are given.
+
+    `run(batches)` takes one (imgs, proj_mats) pair per stream (None = reuse the captured inputs), replays the graphs
+    concurrently and returns the list of STATIC output dicts after making the caller's stream wait for all of them."""
+
+    def __init__(self, model, imgs, proj_mats, init_depth_min, depth_interval, n_streams=2, warmup=2):
+        import copy
+        self.device = imgs.device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        self.forwards = []
+        for st in self.streams:
+            replica = copy.deepcopy(model)
+            st.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(st):
+                self.forwards.append(GraphedForward(replica, imgs, proj_mats, init_depth_min, depth_interval, warmup))
+        torch.cuda.synchronize(self.device)
+
+    def __len__(self):
+        return len(self.forwards)
+
+    def run(self, batches=None):
+        cur = torch.cuda.current_stream(self.device)
+        outs = []
+        for i, (gf, st) in enumerate(zip(self.forwards, self.streams)):
+            st.wait_stream(cur)   # inputs produced on the caller's stream are complete before the copy / replay
+            with torch.cuda.stream(st):
+                b = batches[i] if batches is not None else None
+                outs.append(gf(*b) if b is not None else gf())
+        for st in self.streams:
+            cur.wait_stream(st)
+        return outs

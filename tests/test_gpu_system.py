@@ -112,3 +112,20 @@ def test_view_sharded_model_equals_fused_world1():
     fused kernels' depth maps bit for bit (variance V = 5 and group-wise correlation)."""
     out = _run([sys.executable, "-c", VIEW_SHARD_SCRIPT], timeout=600)
     assert "VIEW_SHARDED_EQUALS_FUSED True" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+
+
+def test_concurrent_forwards_equal_single_stream(dev):
+    """Two captured forwards on two streams give the same bits as the kernel-by-kernel forward, on different inputs."""
+    from casmvsnet_pl_amd.graph import ConcurrentForwards
+    from casmvsnet_pl_amd.synthetic import make_inputs
+    model = _model(dev)
+    ins = [make_inputs(1, 3, 64, 96, seed=s) for s in (1, 2)]
+    dmin, dint = ins[0][2], ins[0][3]
+    cf = ConcurrentForwards(model, ins[0][0].to(dev), ins[0][1].to(dev), dmin, dint, n_streams=2)
+    want = [{k: v.clone() for k, v in model(i[0].to(dev), i[1].to(dev), dmin, dint).items()} for i in ins]
+    for _ in range(2):
+        outs = cf.run([(i[0].to(dev), i[1].to(dev)) for i in ins])
+        torch.cuda.synchronize()
+        for o, w in zip(outs, want):
+            for k in w:
+                assert torch.equal(o[k], w[k]), k
