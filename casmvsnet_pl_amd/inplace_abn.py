@@ -69,7 +69,38 @@ class ABN(nn.Module):
 
 
 class InPlaceABN(ABN):
-    """Same arithmetic as ABN; the in-place memory trick of the CUDA extension is irrelevant here."""
+    """The in-place memory trick of mapillary's CUDA extension is irrelevant here, its ARITHMETIC is not: to keep the
+    activation invertible the extension normalises with gamma = |weight| + eps instead of `weight` (as recalled from
+    the upstream kernels and the In-Place ABN paper - the extension cannot be built or inspected offline).  A negative
+    or tiny BN weight therefore gives a different layer under `norm_act=InPlaceABN` (train.py:41, Lightning
+    validation) than under `norm_act=ABN` (eval.py:201, what the oracle and the golden fixtures run): both classes
+    reproduce their own upstream semantics here, in the module forward and in the folded conv epilogue."""
+
+    def _gamma(self):
+        return self.weight.abs() + self.eps
+
+    def folded_scale_shift(self):
+        if not self.affine:
+            return super().folded_scale_shift()
+        var = self.running_var.detach().double()
+        mean = self.running_mean.detach().double()
+        gamma = self.weight.detach().double().abs() + self.eps
+        scale = gamma / torch.sqrt(var + self.eps)
+        shift = self.bias.detach().double() - mean * scale
+        return scale.float().cpu(), shift.float().cpu()
+
+    def forward(self, x):
+        if not self.affine:
+            return super().forward(x)
+        x = F.batch_norm(x, self.running_mean, self.running_var, self._gamma(), self.bias,
+                         self.training, self.momentum, self.eps)
+        if self.activation == "leaky_relu":
+            return F.leaky_relu(x, negative_slope=self.activation_param)
+        if self.activation == "relu":
+            return F.relu(x)
+        if self.activation == "identity":
+            return x
+        raise RuntimeError(f"unsupported ABN activation {self.activation!r}")
 
 
 InPlaceABNSync = InPlaceABN

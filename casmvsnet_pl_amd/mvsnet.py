@@ -37,14 +37,36 @@ def _fold_norm(owner, norm):
     return scale, shift, slope
 
 
-def _state_key(module, device):
-    key = [str(device)]
-    for _, t in module.state_dict(keep_vars=True).items():
-        key.append((t.data_ptr(), t._version))
-    return tuple(key)
+class _PackedWeights:
+    """Mixin of the modules that keep folded + packed device images of their parameters.
+
+    The images are rebuilt when a parameter / buffer tensor was replaced or modified in place through autograd-visible
+    operations (its storage pointer or `_version` changed - optimiser steps, `copy_`, `load_state_dict`), when the
+    module is moved / cast (`_apply`) and when a state dict is loaded.  An edit THROUGH `.data` (`p.data.mul_(..)`,
+    common in EMA / weight-surgery code) bumps no version counter: call `invalidate_packed()` after it."""
+
+    def _init_packed(self):
+        self._packed = None
+        self._packed_key = None
+        self._key_tensors = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+
+    def invalidate_packed(self):
+        self._packed = None
+        self._packed_key = None
+        self._key_tensors = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _state_key(self, device):
+        if self._key_tensors is None:   # the tensor OBJECTS survive in-place updates; a replaced one changes data_ptr
+            self._key_tensors = list(self.state_dict(keep_vars=True).values())
+        return (str(device),) + tuple((t.data_ptr(), t._version) for t in self._key_tensors)
 
 
-class FeatureNet(nn.Module):
+class FeatureNet(_PackedWeights, nn.Module):
     """3-level FPN feature extractor (mvsnet.py:7-57): same layers / state-dict keys as the reference;
     `forward` runs the 13 layers as MFMA kernels (casmvs_featurenet_forward_f32) with eval-mode ABN
     folded into the conv epilogue and each FPN upsample-add fused into its lateral 1x1 conv."""
@@ -75,8 +97,7 @@ class FeatureNet(nn.Module):
         self.lat0 = nn.Conv2d(8, 32, 1)
         self.smooth1 = nn.Conv2d(32, 16, 3, padding=1)
         self.smooth0 = nn.Conv2d(32, 8, 3, padding=1)
-        self._packed = None
-        self._packed_key = None
+        self._init_packed()
         self._workspace = None
         self._slope = 0.01
         self.timer = None         # optional profiling.StageTimer (bench.py)
@@ -84,7 +105,7 @@ class FeatureNet(nn.Module):
 
     def packed_layers(self, device):
         """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
-        key = _state_key(self, device)
+        key = self._state_key(device)
         if self._packed is not None and key == self._packed_key:
             return self._packed
         packed, slopes = [], set()
@@ -123,7 +144,7 @@ class FeatureNet(nn.Module):
         return {"level_0": feat0, "level_1": feat1, "level_2": feat2}
 
 
-class CostRegNet(nn.Module):
+class CostRegNet(_PackedWeights, nn.Module):
     """3D U-Net regulariser (mvsnet.py:60-104).  Parameters live in torch modules with the
     reference's names; `forward` runs the fused MFMA engine on folded, pre-packed weights."""
 
@@ -152,8 +173,7 @@ class CostRegNet(nn.Module):
             nn.ConvTranspose3d(16, 8, 3, padding=1, output_padding=1, stride=2, bias=False),
             norm_act(8))
         self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
-        self._packed = None       # list of 11 device tensors
-        self._packed_key = None
+        self._init_packed()       # _packed: list of 11 device tensors
         self._workspace = None
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.timer_name = "costreg"
@@ -169,7 +189,7 @@ class CostRegNet(nn.Module):
 
     def packed_layers(self, device):
         """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
-        key = _state_key(self, device)
+        key = self._state_key(device)
         if self._packed is not None and key == self._packed_key:
             return self._packed
         packed, slopes = [], set()

@@ -101,6 +101,14 @@ def test_featurenet_packing_folds_abn_and_tracks_parameter_changes():
         net.smooth0.bias.add_(1.0)
     p2 = net.packed_layers(torch.device("cpu"))
     assert p2 is not p1 and not torch.equal(p1[12], p2[12])
+    # an edit through .data bumps no version counter: it needs the explicit invalidation; load_state_dict invalidates itself
+    net.smooth0.bias.data.add_(1.0)
+    assert net.packed_layers(torch.device("cpu")) is p2
+    net.invalidate_packed()
+    p3 = net.packed_layers(torch.device("cpu"))
+    assert p3 is not p2 and not torch.equal(p3[12], p2[12])
+    net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+    assert net.packed_layers(torch.device("cpu")) is not p3
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 3, 32, 32))
 
@@ -115,6 +123,25 @@ def test_forward_fails_loudly_without_gpu():
     net = CostRegNet(8, ABN)  # training mode + grad: the engine refuses instead of silently falling back
     with pytest.raises(RuntimeError, match="inference engine"):
         net(torch.zeros(1, 8, 8, 8, 8, requires_grad=True))
+
+
+def test_inplace_abn_uses_abs_gamma_plus_eps_like_upstream():
+    """ADVICE r1: InPlaceABN normalises with |weight| + eps (upstream's invertibility trick), ABN with the weight as is;
+    the folded conv epilogue must follow the class the caller chose."""
+    g = torch.Generator().manual_seed(0)
+    for cls in (ABN, InPlaceABN):
+        m = cls(6).eval()
+        with torch.no_grad():
+            m.weight.copy_(torch.tensor([1.2, -0.7, 1e-7, 0.5, -1e-3, 2.0]))
+            m.bias.normal_(0, 0.1, generator=g)
+            m.running_mean.normal_(0, 0.2, generator=g)
+            m.running_var.uniform_(0.5, 1.5, generator=g)
+        x = torch.randn(2, 6, 4, 5, generator=g)
+        scale, shift = m.folded_scale_shift()
+        y = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        y = torch.where(y > 0, y, y * m.leaky_slope())
+        assert float((y - m(x)).abs().max()) < 1e-5
+        assert (scale[1] < 0) == (cls is ABN)   # the negative weight keeps its sign only under plain ABN
 
 
 def test_full_model_in_train_mode_raises():
