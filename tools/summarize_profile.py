@@ -40,7 +40,7 @@ for r in csv.DictReader(open(os.path.join(src, "pmc_fetch", "pmc_kernel_trace.cs
     dur[k][1] += 1
 table = []
 for k in fetch:
-    if not any(s in k[0] for s in ("conv16", "deconv16", "prob_valu", "costvol", "softmax", "hypotheses", "nchw_to")):
+    if not any(s in k[0] for s in ("conv16", "deconv16", "prob_valu", "costvol", "softmax", "hypotheses", "nchw_to", "fpn_lateral")):
         continue
     f_kb, n = fetch[k]
     w_kb = write.get(k, (0.0, 0))[0]
@@ -52,12 +52,12 @@ table.sort(key=lambda r: -(r["read_mb_corrected"] + r["write_mb"]) * r["launches
 json.dump(table, open(os.path.join(out, prefix + "_pmc_traffic.json"), "w"), indent=1)
 with open(os.path.join(out, prefix + "_pmc_traffic.md"), "w") as f:
     f.write("# HBM-side traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two separate passes)\n\n"
-            "Command: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events` (batch 2, 640x512, 3 views).\n"
+            "Command: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --streams 1 --no-batch1` (batch 2, 640x512, 3 views).\n"
             "FETCH_SIZE is doubled (gfx950 rocprofv3 tallies the 128-byte requests of 16 B/lane reads at 64 B: "
             "MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.  Both count L2 misses, i.e. include "
             "Infinity-Cache hits.  One row per (kernel, grid size) = per cascade level.\n"
-            "The bench line of the same gpurun call ran before these passes: its roofline.traffic field is the conv0 figure of the PREVIOUS summary "
-            "(bench.py reads profiles/r01_final_pmc_traffic.json); re-run bench.py after refreshing this file to make the two agree.\n\n"
+            "tools/gpu_final.sh runs these passes BEFORE the bench line of the same gpurun call and bench.py reads the newest "
+            "profiles/r*_pmc_traffic.json, so the committed bench line's roofline.traffic is this table's conv0 figure.\n\n"
             "| kernel | grid threads | launches | avg us (under PMC) | read MB | write MB |\n|---|---|---|---|---|---|\n")
     for r in table:
         f.write(f"| `{r['kernel']}` | {r['grid_threads']} | {r['launches']} | {r['avg_us_under_pmc']:.1f} | "
