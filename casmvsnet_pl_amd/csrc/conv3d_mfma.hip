@@ -450,25 +450,20 @@ __device__ __forceinline__ int xcd_major(int v, int total) {  // bijection on [0
 struct TileCoord {
   int tx0, ty0, tz0, b, slice;
 };
-// Tile order inside an XCD's contiguous item range: z fastest, then NB consecutive tile rows in y, then x, then the
-// next band of NB rows.  The ~100 tiles an XCD works on at one time then form a block of NB tile rows x a few tile
-// columns instead of one full-width tile row: the y-halo every tile row re-reads from HBM (round 1: conv0 fetched
-// 1.71x its input, all of the excess being the rows above / below a 4-row slab) is shared inside the block.
-__device__ __forceinline__ int band_rows(int tiles_y) { return (tiles_y & 3) == 0 ? 4 : ((tiles_y & 1) == 0 ? 2 : 1); }
+// Tile order inside an XCD's contiguous item range: z fastest, then x, then y.  (Tried in round 2: NB = 4 consecutive
+// tile rows in y before x - a 16-row x 128-px block per XCD instead of a full-width 4-row slab.  PMC FETCH_SIZE of
+// conv0 went UP, 561 -> 753 MB per launch, no change in time: neither working set fits the 4 MiB L2 and the slab's
+// streaming order along x re-uses the z-halo planes better.  Reverted.)
 template <int TZ, int TY, int TX>
 __device__ __forceinline__ TileCoord decode_tile(int v, int total, int tiles_x, int tiles_y, int tiles_z, int B) {
   int item = xcd_major(v, total);
   TileCoord c;
-  const int nb = band_rows(tiles_y);
   c.tz0 = (item % tiles_z) * TZ;
   item /= tiles_z;
-  const int yy = item % nb;
-  item /= nb;
   c.tx0 = (item % tiles_x) * TX;
   item /= tiles_x;
-  const int bands = tiles_y / nb;
-  c.ty0 = ((item % bands) * nb + yy) * TY;
-  item /= bands;
+  c.ty0 = (item % tiles_y) * TY;
+  item /= tiles_y;
   c.b = item % B;
   c.slice = item / B;
   return c;

@@ -132,18 +132,27 @@ def costvol_partial(feats_nhwc, proj_mats, depth_values, view_begin, view_end, n
     if proj_mats.shape != (B, V - 1, 3, 4) or depth_values.shape != (B, D, h, w):
         raise ValueError(f"costvol_partial: shapes {tuple(feats.shape)} {tuple(proj_mats.shape)} {tuple(depth_values.shape)}")
     lib = _lib.load()
+    # The kernels stage every view of a call in LDS: a range that does not fit (many views x wide channel splits) is
+    # processed in chunks whose partial sums are added - they are sums, the order of the additions is the only difference.
+    nv = view_end - view_begin
+    while nv > 1 and not lib.casmvs_costvol_lds_supported(C, w, D, nv, num_groups):
+        nv -= 1
+    total = None
     with torch.cuda.device(feats.device):
-        if num_groups == 1:
-            both = torch.empty((2, B, C, D, h, w), dtype=torch.float32, device=feats.device)  # one buffer: one all-reduce
-            rc = lib.casmvs_costvol_partial_var_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(both[0]), _ptr(both[1]),
-                                                    B, V, C, h, w, D, view_begin, view_end, int(bool(include_ref)), _stream(feats))
-            _lib.check(rc, "casmvs_costvol_partial_var_f32")
-            return both
-        out = torch.empty((B, num_groups, D, h, w), dtype=torch.float32, device=feats.device)
-        rc = lib.casmvs_costvol_partial_gwc_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(out),
-                                                B, V, C, num_groups, h, w, D, view_begin, view_end, _stream(feats))
-        _lib.check(rc, "casmvs_costvol_partial_gwc_f32")
-        return out
+        for vb in range(view_begin, view_end, nv):
+            ve = min(vb + nv, view_end)
+            if num_groups == 1:
+                part = torch.empty((2, B, C, D, h, w), dtype=torch.float32, device=feats.device)  # one buffer: one all-reduce
+                rc = lib.casmvs_costvol_partial_var_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(part[0]), _ptr(part[1]),
+                                                        B, V, C, h, w, D, vb, ve, int(bool(include_ref) and vb == view_begin), _stream(feats))
+                _lib.check(rc, "casmvs_costvol_partial_var_f32")
+            else:
+                part = torch.empty((B, num_groups, D, h, w), dtype=torch.float32, device=feats.device)
+                rc = lib.casmvs_costvol_partial_gwc_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(part),
+                                                        B, V, C, num_groups, h, w, D, vb, ve, _stream(feats))
+                _lib.check(rc, "casmvs_costvol_partial_gwc_f32")
+            total = part if total is None else total.add_(part)
+    return total
 
 
 def costvol_finalize(partial, V, num_groups=1):
