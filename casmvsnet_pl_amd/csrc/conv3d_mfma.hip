@@ -1708,7 +1708,11 @@ int ensure_lds(K kernel, size_t bytes, const char *what) {
 }
 template <class K>
 int resident_blocks(K kernel, size_t lds_bytes) {
-  return casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), kThreads, lds_bytes);
+  const int r = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), kThreads, lds_bytes);
+  // profiling build: CASMVS_GRID_PCT = percentage of the resident capacity a persistent kernel launches (experiment:
+  // two concurrent forwards sharing the chip side by side instead of kernel after kernel)
+  static const int pct = trace_env_int("CASMVS_GRID_PCT", 100);
+  return pct >= 100 ? r : (r * pct / 100 < 8 ? 8 : r * pct / 100);
 }
 
 template <int MODE, int STRIDE, int CK, int NT, int TZ, int TY, int TX, int VEC, int KZ = 3, int KS = 3, int UPS = 0, int OUT2 = 0>
