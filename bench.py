@@ -84,13 +84,13 @@ def pmc_traffic(kernel_prefix, batch):
     if batch != 2 or not files:
         return None, "PMC passes are collected at --batch 2 on the default config only"
     path = files[-1]
-    rows = [r for r in json.load(open(path)) if r["kernel"].startswith(kernel_prefix)]
+    prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
+    rows = [r for r in json.load(open(path)) if r["kernel"].startswith(prefixes)]
     if not rows:
         return None, "kernel not in " + os.path.relpath(path, ROOT)
     n = sum(r["launches"] for r in rows)
     mb = sum((r["read_mb_corrected"] + r["write_mb"]) * r["launches"] for r in rows) / n
-    return mb * 1e6, (f"bytes per launch (read + write, mean over the 3 cascade levels) from {os.path.relpath(path, ROOT)}; "
-                      "algorithmic bytes of the same launches: 384e6")
+    return mb * 1e6, f"bytes per launch (read + write, mean over the 3 cascade levels) from {os.path.relpath(path, ROOT)}"
 
 
 def cpu_baseline(cfg_name):
@@ -303,7 +303,8 @@ def main():
             traffic, traffic_note = pmc_traffic("conv16db_kernel<2, 4, 4, 4, 4, 32", B if args.config == HEADLINE else None)
             line["roofline"] = {"kernel": "conv16db_kernel<PX> (CostRegNet.conv0: Cout 8, stride 1; 3 launches per step)",
                                 "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                                "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                                "traffic_note": traffic_note + "; algorithmic bytes of the same launches: 384e6",
                                 "avg_launch_ms": conv0_ms / (3 * n_ev)}
             cr_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("costreg_"))
             cr_flops = sum(work[l]["costreg_flops"] for l in range(3)) * n_ev
@@ -313,11 +314,13 @@ def main():
                                         "ms_per_depth_map": cr_ms / n_ev / B}
             cv_ms = sum(summ[f"costvol_{l}"]["ms"] for l in range(3))
             cv_bytes = sum(work[l]["costvol_bytes"] for l in range(3)) * n_ev
+            cv_traffic, cv_note = pmc_traffic(("costvol_lds_kernel", "costvol_nhwc_kernel"), B if args.config == HEADLINE else None)
             line["roofline_costvol"] = {"kernel": "fused homo_warp + aggregation (3 launches: costvol_lds_kernel at C = 8 / 16, "
                                                   "costvol_nhwc_kernel at C = 32 and for group-wise correlation)",
                                         "bound": "hbm", "achieved": cv_bytes / (cv_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": cv_bytes / (cv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "traffic": None, "ms_per_depth_map": cv_ms / n_ev / B,
+                                        "traffic": cv_traffic, "traffic_note": cv_note + f"; algorithmic: {cv_bytes / n_ev / 3:.4g}",
+                                        "ms_per_depth_map": cv_ms / n_ev / B,
                                         "per_level_frac": {str(l): work[l]["costvol_bytes"] * n_ev / (summ[f"costvol_{l}"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS for l in range(3)}}
             sm_ms = sum(summ[f"softmax_{l}"]["ms"] for l in range(3))
             sm_bytes = sum(work[l]["softmax_bytes"] for l in range(3)) * n_ev
