@@ -42,6 +42,19 @@ constexpr int kMaxPG = 2;      // plane groups: a tile's 256 pixels are worked o
 constexpr int fixed_lds(int pg) { return kMaxViews * 8 * 4 + 4 * kMaxViews * 4 * 4 + kMaxViews * 12 * 4 + pg * 4 * 4 * RS * 4; }
 static_assert(fixed_lds(1) % 16 == 0 && fixed_lds(2) % 16 == 0, "the boxes must start 16-byte aligned");
 
+#ifdef CASMVS_TRACE
+// Profiling build only (tools/gpu_cv_trace.py): thread 0 of every 32nd workgroup (batch element 0) stamps the shader
+// clock at the phase boundaries of costvol_lds_kernel; read back by casmvs_cv_trace_read.
+__device__ unsigned long long g_cv_trace[64 * 32];
+#define CV_STAMP()                                                                                      \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && blockIdx.y == 0 && (blockIdx.x >> 5) < 64 && tr_n < 32) \
+      g_cv_trace[(blockIdx.x >> 5) * 32 + tr_n++] = __builtin_readcyclecounter();                       \
+  } while (0)
+#else
+#define CV_STAMP() do {} while (0)
+#endif
+
 enum { MODE_VAR = 0, MODE_GWC = 1, MODE_WARP = 2, MODE_VAR_PART = 3, MODE_GWC_PART = 4 };
 
 struct SweepArgs {
@@ -61,15 +74,29 @@ struct SweepArgs {
   int ablate;          // profiling build only (-DCASMVS_TRACE): bit 0 no volume stores, 1 no LDS tap reads, 2 taps of plane 0
 };
 
+// Wave-wide min / max with a wave-uniform result.  DPP inside the rows of 16 lanes (lane ^ 1, lane ^ 2, mirror of 8,
+// mirror of 16: four VALU instructions with a lane-permuting operand), then the four rows through v_readlane / s_min.
+// (Round 2 used six __shfl_xor steps = six dependent ds_bpermute_b32 per value: 24 LDS-crossbar round trips per view in
+// the prologue of every workgroup.)
+template <int CTRL>
+__device__ __forceinline__ int dpp_perm(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
 __device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
-  return v;
+  v = min(v, dpp_perm<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = min(v, dpp_perm<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = min(v, dpp_perm<0x141>(v));   // row_half_mirror
+  v = min(v, dpp_perm<0x140>(v));   // row_mirror
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
-  return v;
+  v = max(v, dpp_perm<0xB1>(v));
+  v = max(v, dpp_perm<0x4E>(v));
+  v = max(v, dpp_perm<0x141>(v));
+  v = max(v, dpp_perm<0x140>(v));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -171,7 +198,7 @@ __device__ __forceinline__ Box read_box(const int *prm, int vi) {
 // registers at the merge point, unconditionally) and was slower than the gather kernels.  Hence: the gather
 // branch is wave-uniform (skipped by a scalar branch) and drains its own loads with an explicit s_waitcnt
 // INSIDE the branch, so the steady state carries no vector-memory wait at all.
-template <int C, int CS, bool SQ>
+template <int C, int CS, bool SQ, int JBM = 2>
 __device__ __forceinline__ void accumulate_view(const float *P, float xf, float yf, float dvk, int w, int h, bool valid,
                                                 const Box &bx_, const f32x4 *bx, const float *view_map, int view_bytes,
                                                 int c0, f32x2 (&s)[CS / 2], f32x2 (&q)[CS / 2], int abl) {
@@ -193,7 +220,7 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
   // channel groups in batches of JB (8 channels): at most 8 ds_read_b128 = 32 registers of tap data live at a time -
   // what keeps the 8-wave (PG = 2) form inside 128 VGPRs; the scheduling barriers stop the compiler from hoisting the
   // next batch's reads above this batch's arithmetic
-  constexpr int JB = GL < 2 ? GL : 2;
+  constexpr int JB = GL < JBM ? GL : JBM;
 #pragma unroll
   for (int jb = 0; jb < GL; jb += JB) {
     f32x4 n0[JB], n1[JB], s0[JB], s1[JB];
@@ -258,8 +285,15 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
 // waves leave the SIMD's VALU (one instruction per ~1.7 cycles) mostly idle: measured, the kernel ran at the speed of
 // its longest wave, not of any unit.  With PG = 2 the SAME tile and boxes are worked on by 8 waves, waves 4-7 taking
 // the upper half of the chunk's planes: twice the waves per byte of LDS.
+#ifndef CASMVS_WARP_OCC
+#define CASMVS_WARP_OCC 3   // waves per SIMD of the one-view (homo_warp) kernels at CS = 16: 136 VGPRs, one box per workgroup (A/B: 2, 4)
+#endif
+constexpr int waves_per_simd(int cs, int mode, int pg) {
+  return pg == 2 ? 4 : (cs == 8 ? 3 : (mode == MODE_WARP && cs == 16 ? CASMVS_WARP_OCC : 2));
+}
+
 template <int C, int CS, int MODE, int TW, int DC, int NV, int PG>
-__global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) void costvol_lds_kernel(const SweepArgs a) {
+__global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void costvol_lds_kernel(const SweepArgs a) {
   constexpr int NT = kThreads * PG;   // threads of the workgroup
   constexpr int kFixedLds = fixed_lds(PG);
   constexpr int TH = kThreads / TW;
@@ -268,6 +302,12 @@ __global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) voi
   constexpr int NSPLIT = C / CS;
   constexpr int NUB = CS == 8 ? 4 : 8;           // staging loads in flight per thread (the 128-VGPR budget of CS = 8)
   constexpr bool SQ = MODE == MODE_VAR || MODE == MODE_VAR_PART;
+#ifndef CASMVS_JB2
+#define CASMVS_JB2 4   // channel groups (of 4) whose tap data is in flight at once at 2 waves per SIMD: all 16 reads of a
+                       // view are issued, the next view's taps are computed under their latency (A/B: 2 = round 2)
+#endif
+  // tap data in flight: 16 registers per channel group
+  constexpr int kJB = waves_per_simd(CS, MODE, PG) >= 4 ? 1 : (waves_per_simd(CS, MODE, PG) == 2 ? CASMVS_JB2 : 2);
   constexpr bool NEED_REF = MODE != MODE_WARP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int *prm = reinterpret_cast<int *>(smem);                   // [kMaxViews][8]: bx0, by0, bw, bh, q256, r256
@@ -276,6 +316,10 @@ __global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) voi
   float *tr_all = pmat + kMaxViews * 12;
   f32x4 *box = reinterpret_cast<f32x4 *>(smem + kFixedLds);   // [nv][cap_units]
 
+#ifdef CASMVS_TRACE
+  int tr_n = 0;
+#endif
+  CV_STAMP();   // 0: kernel start
   // ---- work item ----------------------------------------------------------------------------------------
   // XCD-aware order (block b runs on XCD b % 8; speed only): XCD k owns the tiles [k, k + 1) * tiles_per_xcd,
   // and all depth chunks / channel splits of a tile - which read the same source region - are adjacent.
@@ -309,15 +353,60 @@ __global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) voi
   const float dv_first = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int(d0 * hw * 4), 0));
   const float dv_last = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + DC - 1) * hw * 4), 0));
 
-  // The matrices go through LDS: the compiler cannot prove that `proj` is not written by the volume stores, so
-  // inside the plane loop it re-loads them with VECTOR loads - and on gfx9 a wait for a vector load also waits
-  // for every older store (one in-order vmcnt): the plane loop must not contain a single vector-memory load.
-  if (tid < nv * 12) pmat[tid] = pb[tid];
+  // ---- every global load the prologue and the plane loop need is issued HERE, together: the matrices, the reference
+  // features, the chunk's depths.  (Round 2 issued them where they were used: three exposed memory latencies -
+  // matrices per view inside the extents loop, `ref` after the staging, the depths before the plane loop - a third
+  // of a workgroup's life, tools/gpu_cv_trace.py.)
+  constexpr int NVS = NV > 0 ? NV : 1;
+  // NV > 0: lane l of every wave loads element l of the staged views' matrices (<= 24 floats; out-of-range lanes read
+  // 0 from the buffer), v_readlane then puts them in SGPRs.  Run-time view count: through LDS (the compiler cannot
+  // prove that `proj` is not written by the volume stores and would re-load it with VECTOR loads inside the plane
+  // loop, where a wait for a vector load also waits for every older store: gfx9 has one in-order vmcnt).
+  float pm_lane = 0.0f;
+  if (NV > 0) {
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pb), 0, uniform_int(NVS * 12 * 4), 0x00020000);
+    pm_lane = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, lane * 4, 0, 0));
+  } else if (tid < nv * 12) {
+    pmat[tid] = pb[tid];
+  }
+  float ref[CS];
+  if (NEED_REF) {
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(fb), 0, view_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < GL; ++j) {
+      const f32x4 r = buf_load4(r0, (pcl * C + c0 + 4 * j) * 4, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ref[4 * j + i] = r[i];
+    }
+  }
+  // CS >= 16 runs at two waves per SIMD whatever it does (LDS): registers are free there and the planes' depths
+  // are all loaded up front, which keeps every vector-memory wait out of the plane loop.
+#ifdef CASMVS_DV_REGS_ALL
+  constexpr bool DV_REGS = true;
+#else
+  constexpr bool DV_REGS = CS >= 16;
+#endif
+  constexpr int KP = DC / PG;          // planes of a plane group
+  const int k0 = uniform_int(pg * KP);
+  float dvr[DV_REGS ? KP : 1];
+  if (DV_REGS) {
+#pragma unroll
+    for (int i = 0; i < KP; ++i)
+      dvr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + k0 + i) * hw * 4), 0));
+  } else {
+    dvr[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + k0) * hw * 4), 0));
+  }
+  float Pm[NVS][12];
+  if (NV > 0) {
+#pragma unroll
+    for (int vi = 0; vi < NVS; ++vi)
+#pragma unroll
+      for (int i = 0; i < 12; ++i)
+        Pm[vi][i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pm_lane), vi * 12 + i));
+  }
 
   // ---- 1. boxes (by the waves of plane group 0) ---------------------------------------------------------------
-#pragma unroll 1
-  for (int vi = 0; vi < (pg == 0 ? nv : 0); ++vi) {
-    const float *P = pb + vi * 12;
+  auto extents = [&](const float *P, int vi) {
     int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -332,8 +421,19 @@ __global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) voi
       int *r = red + (wave * kMaxViews + vi) * 4;
       r[0] = xmn; r[1] = xmx; r[2] = ymn; r[3] = ymx;
     }
+  };
+  if (pg == 0) {   // wave-uniform
+    if (NV > 0) {
+#pragma unroll
+      for (int vi = 0; vi < NVS; ++vi) extents(Pm[vi], vi);
+    } else {
+#pragma unroll 1
+      for (int vi = 0; vi < nv; ++vi) extents(pb + vi * 12, vi);
+    }
   }
+  CV_STAMP();   // 1: this wave's extents done (depth loads landed, taps at the chunk's first / last plane, wave reductions)
   __syncthreads();
+  CV_STAMP();   // 2: all waves there
   if (tid < nv) {
     int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
 #pragma unroll
@@ -353,60 +453,71 @@ __global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) voi
   }
   __syncthreads();
 
+  CV_STAMP();   // 3: boxes published
   // ---- 2. staging -----------------------------------------------------------------------------------------------
-#pragma unroll 1
-  for (int vi = 0; vi < nv; ++vi) {
+  // One pass = NUB 16-byte loads per thread and view.  NV > 0: the first pass of EVERY view is issued before anything
+  // is waited for (one memory latency for all the boxes; a box of the expected size is one pass).
+  struct ViewStage {
+    int bx0, by0, nsu, total, rowu, q256, r256, row, ru, base;
+    __amdgpu_buffer_rsrc_t src;
+    f32x4 *bx;
+    f32x4 regs[NUB];
+    int lo[NUB];
+  };
+  auto stage_init = [&](ViewStage &s, int vi) {
     const int *p = prm + vi * 8;
-    const int bx0 = uniform_int(p[0]), by0 = uniform_int(p[1]), bw = uniform_int(p[2]), bh = uniform_int(p[3]);
-    const int q256 = uniform_int(p[4]), r256 = uniform_int(p[5]);
-    const int nsu = bw * GL, total = bh * nsu, rowu = L::row_units(bw);
-    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(uniform_ptr(fb + (size_t)(a.v0 + vi) * view_floats)), 0, view_bytes, 0x00020000);
-    f32x4 *bx = box + (size_t)vi * a.cap_units;
-    int row = tid / nsu, ru = tid - row * nsu;
-    for (int base = 0; base < total; base += NT * NUB) {
-      f32x4 regs[NUB];
-      int lo[NUB];
+    s.bx0 = uniform_int(p[0]); s.by0 = uniform_int(p[1]);
+    const int bw = uniform_int(p[2]), bh = uniform_int(p[3]);
+    s.q256 = uniform_int(p[4]); s.r256 = uniform_int(p[5]);
+    s.nsu = bw * GL; s.total = bh * s.nsu; s.rowu = L::row_units(bw);
+    s.src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(uniform_ptr(fb + (size_t)(a.v0 + vi) * view_floats)), 0, view_bytes, 0x00020000);
+    s.bx = box + (size_t)vi * a.cap_units;
+    s.row = tid / s.nsu; s.ru = tid - s.row * s.nsu; s.base = 0;
+  };
+  auto stage_issue = [&](ViewStage &s) {
 #pragma unroll
-      for (int i = 0; i < NUB; ++i) {
-        const bool ok = base + tid + NT * i < total;
-        const int pxx = ru / GL, ch = ru % GL;
-        lo[i] = ok ? row * rowu + L::unit(pxx) + ch : -1;
-        // a lane past the end of the box loads the map's first bytes (and drops them): no divergence, no branch
-        regs[i] = buf_load4(src, ok ? (((by0 + row) * w + bx0 + pxx) * C + c0 + 4 * ch) * 4 : 0, 0);
-        ru += r256; row += q256;
-        if (ru >= nsu) { ru -= nsu; ++row; }
-      }
-#pragma unroll
-      for (int i = 0; i < NUB; ++i)
-        if (lo[i] >= 0) bx[lo[i]] = regs[i];
+    for (int i = 0; i < NUB; ++i) {
+      const bool ok = s.base + tid + NT * i < s.total;
+      const int pxx = s.ru / GL, ch = s.ru % GL;
+      s.lo[i] = ok ? s.row * s.rowu + L::unit(pxx) + ch : -1;
+      // a lane past the end of the box loads the map's first bytes (and drops them): no divergence, no branch
+      s.regs[i] = buf_load4(s.src, ok ? (((s.by0 + s.row) * w + s.bx0 + pxx) * C + c0 + 4 * ch) * 4 : 0, 0);
+      s.ru += s.r256; s.row += s.q256;
+      if (s.ru >= s.nsu) { s.ru -= s.nsu; ++s.row; }
     }
-  }
-
-  float ref[CS];
-  if (NEED_REF) {
-    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(fb), 0, view_bytes, 0x00020000);
+    s.base += NT * NUB;
+  };
+  auto stage_commit = [&](ViewStage &s) {
 #pragma unroll
-    for (int j = 0; j < GL; ++j) {
-      const f32x4 r = buf_load4(r0, (pcl * C + c0 + 4 * j) * 4, 0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ref[4 * j + i] = r[i];
-    }
-  }
-  __syncthreads();
-
-  // wave-uniform per-view constants of the unrolled form
-  constexpr int NVS = NV > 0 ? NV : 1;
-  Box boxes[NVS];
-  float Pm[NVS][12];
+    for (int i = 0; i < NUB; ++i)
+      if (s.lo[i] >= 0) s.bx[s.lo[i]] = s.regs[i];
+  };
   if (NV > 0) {
+    ViewStage st[NVS];
+#pragma unroll
+    for (int vi = 0; vi < NVS; ++vi) { stage_init(st[vi], vi); stage_issue(st[vi]); }
 #pragma unroll
     for (int vi = 0; vi < NVS; ++vi) {
-      boxes[vi] = read_box(prm, vi);
-#pragma unroll
-      for (int i = 0; i < 12; ++i)
-        Pm[vi][i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pmat[vi * 12 + i])));
+      stage_commit(st[vi]);
+      while (st[vi].base < st[vi].total) { stage_issue(st[vi]); stage_commit(st[vi]); }   // a box larger than one pass
     }
+  } else {
+#pragma unroll 1
+    for (int vi = 0; vi < nv; ++vi) {
+      ViewStage s1;
+      stage_init(s1, vi);
+      while (s1.base < s1.total) { stage_issue(s1); stage_commit(s1); }
+    }
+  }
+  CV_STAMP();   // 4: boxes staged (this wave's loads landed and were written to LDS)
+  __syncthreads();
+
+  CV_STAMP();   // 5: all waves staged
+  // wave-uniform boxes of the unrolled form
+  Box boxes[NVS];
+  if (NV > 0) {
+#pragma unroll
+    for (int vi = 0; vi < NVS; ++vi) boxes[vi] = read_box(prm, vi);
   }
 
   const size_t vol_floats = (size_t)C * D * hw;   // one batch element of out (VAR / WARP / VAR_PART)
@@ -425,19 +536,14 @@ __global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) voi
   // ---- 3. plane by plane (a rolled loop: the body is ~1.5 KB of code per view, the 8 planes unrolled were 40 KB)
   float *tr = tr_all + wave * (4 * RS);
   const float rV = 1.0f / (float)a.nviews_total;
-  // CS >= 16 runs at two waves per SIMD whatever it does (LDS): registers are free there and the planes' depths
-  // are all loaded up front, which keeps every vector-memory wait out of the plane loop.
-  constexpr bool DV_REGS = CS >= 16;
-  constexpr int KP = DC / PG;          // planes of a plane group
-  const int k0 = uniform_int(pg * KP);
-  float dvr[DV_REGS ? KP : 1];
-  if (DV_REGS) {
-#pragma unroll
-    for (int i = 0; i < KP; ++i)
-      dvr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + k0 + i) * hw * 4), 0));
-  }
-  float dvk = DV_REGS ? dvr[0]
-                      : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + k0) * hw * 4), 0));
+  float dvk = dvr[0];
+#ifndef CASMVS_NO_PRELOOP_WAIT
+  // Every load issued so far has landed after this: the compiler's wait-count pass then knows that nothing the plane
+  // loop reads is pending and places no vmcnt wait inside it.  Without it (ISA, round 2) it waited vmcnt(5) ... vmcnt(0)
+  // for the depth registers in EVERY iteration - and vmcnt(0) also waits for the previous plane's volume stores.
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+#endif
+  CV_STAMP();   // 6: plane loop begins
 #pragma unroll 1
   for (int k = k0; k < k0 + KP; ++k) {
     float dv_next = dv_last;
@@ -462,7 +568,7 @@ __global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) voi
     if (NV > 0) {
 #pragma unroll
       for (int vi = 0; vi < NVS; ++vi)
-        accumulate_view<C, CS, SQ>(Pm[vi], xf, yf, dvk, w, h, valid, boxes[vi], box + (size_t)vi * a.cap_units,
+        accumulate_view<C, CS, SQ, kJB>(Pm[vi], xf, yf, dvk, w, h, valid, boxes[vi], box + (size_t)vi * a.cap_units,
                                    fb + (size_t)(a.v0 + vi) * view_floats, view_bytes, c0, s2, q2, abl);
     } else {
 #pragma unroll 1
@@ -471,7 +577,7 @@ __global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) voi
         float Pv[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) Pv[i] = pmat[vi * 12 + i];
-        accumulate_view<C, CS, SQ>(Pv, xf, yf, dvk, w, h, valid, bxv, box + (size_t)vi * a.cap_units,
+        accumulate_view<C, CS, SQ, kJB>(Pv, xf, yf, dvk, w, h, valid, bxv, box + (size_t)vi * a.cap_units,
                                    uniform_ptr(fb + (size_t)(a.v0 + vi) * view_floats), view_bytes, c0, s2, q2, abl);
       }
     }
@@ -519,7 +625,12 @@ __global__ __launch_bounds__(kThreads * PG, PG == 2 ? 4 : (CS == 8 ? 3 : 2)) voi
       }
     }
     dvk = dv_next;
+    CV_STAMP();   // 7 + k: plane k issued (taps, LDS reads, accumulation, stores issued)
   }
+#ifdef CASMVS_TRACE
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  CV_STAMP();   // last: this wave's stores acknowledged
+#endif
 }
 
 // sum / sum-of-squares -> variance (mvsnet.py:167), and the scaling of the all-reduced correlation
@@ -569,8 +680,11 @@ bool make_plan(int C, int w, int D, int nv, int G, int mode, Plan &p) {
   if (C % p.cs != 0 || (p.cs != 8 && p.cs != 16 && p.cs != 32)) return false;
   const int upp = p.cs == 8 ? 3 : p.cs / 4 + 1, th = kThreads / p.tw;   // upper bound of the units per staged pixel
   const int need = ((p.tw + p.dc + 4) * (p.cs == 8 ? 17 : 8 * upp) / 8 + 1) * (th + 2);
-  static const int budgets[3] = {52 * 1024, 79 * 1024, 158 * 1024};
-  for (int i = 0; i < 3; ++i) {
+  // workgroups per CU the registers allow (waves_per_simd of the kernel that will run): a smaller LDS budget than
+  // that buys nothing and only clips boxes earlier
+  const int occ = waves_per_simd(p.cs, mode, p.pg) / p.pg;
+  static const int budgets[4] = {39 * 1024, 52 * 1024, 79 * 1024, 158 * 1024};
+  for (int i = occ >= 4 ? 0 : (occ == 3 ? 1 : 2); i < 4; ++i) {
     const int cap = (budgets[i] - fixed_lds(p.pg)) / (nv * 16);
     if (cap >= need) {
       p.cap_units = cap;
@@ -655,6 +769,18 @@ int check_common(const char *what, const void *feats, const void *proj, const vo
 
 }  // namespace
 
+#ifdef CASMVS_TRACE
+extern "C" int casmvs_cv_trace_read(unsigned long long *host, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return -3;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cv_trace), sizeof(unsigned long long) * 64 * 32) != hipSuccess) return -3;
+  if (clear) {
+    static unsigned long long z[64 * 32];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_cv_trace), z, sizeof(z)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#endif
+
 extern "C" int casmvs_costvol_lds_supported(int C, int w, int D, int n_src_views, int G) {
   Plan p;
   if (C != 8 && C != 16 && C != 32) return 0;
@@ -662,11 +788,13 @@ extern "C" int casmvs_costvol_lds_supported(int C, int w, int D, int n_src_views
   return make_plan(C, w, D, n_src_views, G > 1 ? G : 1, G > 1 ? MODE_GWC : MODE_VAR, p) ? 1 : 0;
 }
 
-// Measured on the MI355X (tools/gpu_cv_ab.sh, profiles/r02_costvol_ab.txt): the LDS-staged variance build beats the
-// gather kernel at C = 16 and C = 8 (1.1-1.5x); at C = 32 the channel split repeats the tap arithmetic and the gather
-// kernel wins; the correlation (G > 1) writes 4-16x fewer bytes and the gather kernel wins at every level.
+// Measured on the MI355X (tools/gpu_cv_variants.sh, profiles/r03_costvol_ab.txt): with two source views (V = 3) the
+// LDS-staged variance build beats the gather kernel at every level shape (C = 32 / 16 / 8: 91 / 135 / 84 us against
+// 108 / 227 / 95 at batch 2).  With more source views the boxes of all views no longer fit next to a second workgroup
+// (one workgroup per CU = one wave per SIMD) and the gather kernel wins (V = 5: 513 vs 651 us at level 1); the
+// correlation (G > 1) writes 4-16x fewer bytes and the gather kernel wins at every level.
 extern "C" int casmvs_costvol_lds_preferred(int C, int w, int D, int n_src_views, int G) {
-  return (G <= 1 && C <= 16 && casmvs_costvol_lds_supported(C, w, D, n_src_views, G)) ? 1 : 0;
+  return (G <= 1 && n_src_views <= 2 && casmvs_costvol_lds_supported(C, w, D, n_src_views, G)) ? 1 : 0;
 }
 
 extern "C" int casmvs_costvol_var_lds_f32(const float *feats, const float *proj, const float *depth, float *out, int B,
