@@ -788,7 +788,7 @@ extern "C" int casmvs_costvol_lds_supported(int C, int w, int D, int n_src_views
   return make_plan(C, w, D, n_src_views, G > 1 ? G : 1, G > 1 ? MODE_GWC : MODE_VAR, p) ? 1 : 0;
 }
 
-// Measured on the MI355X (tools/gpu_cv_variants.sh, profiles/r03_costvol_ab.txt): with two source views (V = 3) the
+// Measured on the MI355X (tools/gpu_cv_variants.sh, profiles/r02_s3_costvol_ab.txt): with two source views (V = 3) the
 // LDS-staged variance build beats the gather kernel at every level shape (C = 32 / 16 / 8: 91 / 135 / 84 us against
 // 108 / 227 / 95 at batch 2).  With more source views the boxes of all views no longer fit next to a second workgroup
 // (one workgroup per CU = one wave per SIMD) and the gather kernel wins (V = 5: 513 vs 651 us at level 1); the

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B builds of the LDS cost-volume kernels (round 3): only costvol_lds.hip is recompiled per variant, the other
+# A/B builds of the LDS cost-volume kernels (round 2, third session): only costvol_lds.hip is recompiled per variant, the other
 # objects are the production ones.  Select with CASMVS_LIB_PATH=casmvsnet_pl_amd/libcv_<name>.so.
 #   usage: tools/build_cv_variants.sh name1:"-DFLAG ..." name2:"..."
 cd "$(dirname "$0")/.." || exit 1
