@@ -53,6 +53,17 @@ SYMBOLS = {
     "casmvs_fuse_reference_view": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_homo_warp_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_softmax_regress_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 7),
+    "casmvs_conv_wgrad_f32": (c_int, [c_int, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_conv_dgrad_direct_f32": (c_int, [c_int, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_channel_sums_blocks": (c_int, [c_int, c_size_t]),
+    "casmvs_channel_sums_f64": (c_int, [_FP, _FP, c_int, c_int, c_size_t, c_void_p]),
+    "casmvs_abn_apply_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_size_t, c_float, c_void_p]),
+    "casmvs_abn_backward_sums_f64": (c_int, [_FP] * 6 + [c_int, c_int, c_size_t, c_float, c_void_p]),
+    "casmvs_abn_backward_apply_f32": (c_int, [_FP] * 9 + [c_int, c_int, c_size_t, c_float, c_void_p]),
+    "casmvs_upsample2x_add_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_upsample2x_backward_f32": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_costvol_var_backward_f32": (c_int, [_FP] * 5 + [c_int] * 6 + [c_void_p]),
     "casmvs_normalize_images_u8": (c_int, [_FP, _FP, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "casmvs_selftest_mfma": (c_int, [_FP]),
     "casmvs_selftest_mfma_rate": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),

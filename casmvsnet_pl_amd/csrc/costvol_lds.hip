@@ -71,7 +71,7 @@ struct SweepArgs {
   int G, h, w, D;
   int tiles_x, tiles, tiles_per_xcd;
   int cap_units;       // LDS capacity of one view's box in 16-byte units
-  int ablate;          // profiling build only (-DCASMVS_TRACE): bit 0 no volume stores, 1 no LDS tap reads, 2 taps of plane 0
+  int ablate;          // profiling build only (-DCASMVS_TRACE): bit 0 no volume stores, 1 no LDS tap reads, 2 taps of plane 0, 3 stores only
 };
 
 // Wave-wide min / max with a wave-uniform result.  DPP inside the rows of 16 lanes (lane ^ 1, lane ^ 2, mirror of 8,
@@ -129,6 +129,11 @@ __device__ __forceinline__ PlaneStore make_plane_store(float *batch_base, size_t
   return ps;
 }
 
+#ifndef CASMVS_CV_STORE_AUX
+#define CASMVS_CV_STORE_AUX 2   // cache-policy bits of the volume stores (gfx94x: 1 = sc0, 2 = nt, 16 = sc1).  nt = streaming: the
+                                // volume does not displace the boxes / depth maps the kernel re-reads from L2 (level 1, batch 2:
+                                // 133 -> 104 us, profiles/r02_s3_costvol_store_policy.txt)
+#endif
 template <int CS>
 __device__ __forceinline__ void store_plane_transposed(const float (&vals)[CS], float *tr, const PlaneStore &ps, int lane,
                                                        int D, int hw, int d, int w) {
@@ -141,7 +146,7 @@ __device__ __forceinline__ void store_plane_transposed(const float (&vals)[CS], 
     const float *row = tr + cw * RS + 4 * q4;
     const f32x4 o{row[0], row[1], row[2], row[3]};
     const int soff = uniform_int((4 * j * D + d) * hw * 4);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ps.rsrc, ps.voff, soff, 0);   // w % 4 == 0 (host)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ps.rsrc, ps.voff, soff, CASMVS_CV_STORE_AUX);   // w % 4 == 0 (host)
     wave_lds_fence();  // the rows are rewritten by the next channel group
   }
 }
@@ -458,7 +463,9 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
   // One pass = NUB 16-byte loads per thread and view.  NV > 0: the first pass of EVERY view is issued before anything
   // is waited for (one memory latency for all the boxes; a box of the expected size is one pass).
   struct ViewStage {
-    int bx0, by0, nsu, total, rowu, q256, r256, row, ru, base;
+    int nsu, total, rowu, base;
+    int ru, lofs, gofs;          // this thread's next unit: index inside its box row, LDS unit of the row, global byte offset of the row
+    int r256, dL, dG, gW;        // per step of NT units: ru += r256, the row advances by q256 (+ 1 when ru wraps)
     __amdgpu_buffer_rsrc_t src;
     f32x4 *bx;
     f32x4 regs[NUB];
@@ -466,24 +473,30 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
   };
   auto stage_init = [&](ViewStage &s, int vi) {
     const int *p = prm + vi * 8;
-    s.bx0 = uniform_int(p[0]); s.by0 = uniform_int(p[1]);
-    const int bw = uniform_int(p[2]), bh = uniform_int(p[3]);
-    s.q256 = uniform_int(p[4]); s.r256 = uniform_int(p[5]);
+    const int bx0 = uniform_int(p[0]), by0 = uniform_int(p[1]), bw = uniform_int(p[2]), bh = uniform_int(p[3]);
+    const int q256 = uniform_int(p[4]);
+    s.r256 = uniform_int(p[5]);
     s.nsu = bw * GL; s.total = bh * s.nsu; s.rowu = L::row_units(bw);
     s.src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(uniform_ptr(fb + (size_t)(a.v0 + vi) * view_floats)), 0, view_bytes, 0x00020000);
     s.bx = box + (size_t)vi * a.cap_units;
-    s.row = tid / s.nsu; s.ru = tid - s.row * s.nsu; s.base = 0;
+    const int row = tid / s.nsu;
+    s.ru = tid - row * s.nsu; s.base = 0;
+    s.gW = w * C * 4;
+    s.lofs = row * s.rowu; s.gofs = ((by0 + row) * w + bx0) * (C * 4) + c0 * 4;
+    s.dL = q256 * s.rowu; s.dG = q256 * s.gW;
   };
+  // (all running offsets: no multiplication, no division per load - the round-2 form spent 28 instructions per load)
   auto stage_issue = [&](ViewStage &s) {
 #pragma unroll
     for (int i = 0; i < NUB; ++i) {
       const bool ok = s.base + tid + NT * i < s.total;
-      const int pxx = s.ru / GL, ch = s.ru % GL;
-      s.lo[i] = ok ? s.row * s.rowu + L::unit(pxx) + ch : -1;
-      // a lane past the end of the box loads the map's first bytes (and drops them): no divergence, no branch
-      s.regs[i] = buf_load4(s.src, ok ? (((s.by0 + s.row) * w + s.bx0 + pxx) * C + c0 + 4 * ch) * 4 : 0, 0);
-      s.ru += s.r256; s.row += s.q256;
-      if (s.ru >= s.nsu) { s.ru -= s.nsu; ++s.row; }
+      const int pxx = (int)((unsigned)s.ru / (unsigned)GL), ch = (int)((unsigned)s.ru % (unsigned)GL);
+      s.lo[i] = ok ? s.lofs + L::unit(pxx) + ch : -1;
+      // a lane past the end of the box addresses beyond the buffer: the hardware returns 0 without a memory access
+      s.regs[i] = buf_load4(s.src, ok ? s.gofs + (pxx * C + 4 * ch) * 4 : -16, 0);
+      s.ru += s.r256; s.lofs += s.dL; s.gofs += s.dG;
+      const bool wrap = s.ru >= s.nsu;
+      s.ru -= wrap ? s.nsu : 0; s.lofs += wrap ? s.rowu : 0; s.gofs += wrap ? s.gW : 0;
     }
     s.base += NT * NUB;
   };
@@ -548,8 +561,11 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
   for (int k = k0; k < k0 + KP; ++k) {
     float dv_next = dv_last;
     if (DV_REGS) {
+      // the chunk's depths rotate through the register array (KP - 1 moves; a select chain on the scalar plane
+      // counter cost three instructions per plane of the chunk, dynamic register indexing is not available)
+      dv_next = KP > 1 ? dvr[1] : dvr[0];
 #pragma unroll
-      for (int i = 1; i < KP; ++i) dv_next = (k + 1 - k0 == i) ? dvr[i] : dv_next;   // selects on a scalar condition
+      for (int i = 1; i + 1 < KP; ++i) dvr[i] = dvr[i + 1];
     } else if (!(abl & 4)) {
       const int kn = k + 1 < DC ? k + 1 : DC - 1;
       dv_next = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + kn) * hw * 4), 0));
@@ -565,7 +581,8 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
         q2[c] = f32x2{0.0f, 0.0f};
       }
     }
-    if (NV > 0) {
+    if (abl & 8) {   // ablation: the plane loop without taps, LDS reads and accumulation - what the volume stores alone cost
+    } else if (NV > 0) {
 #pragma unroll
       for (int vi = 0; vi < NVS; ++vi)
         accumulate_view<C, CS, SQ, kJB>(Pm[vi], xf, yf, dvk, w, h, valid, boxes[vi], box + (size_t)vi * a.cap_units,

@@ -97,8 +97,10 @@ __device__ __forceinline__ Taps plane_sweep_taps(const float *__restrict__ P, fl
 }
 
 // true when at least one tap of the footprint carries weight (the voxel projects into the source image)
+// (the weights are products of selected values in [0, 1] - never negative, never NaN: a NaN coordinate fails every bounds
+// test above and selects the constants 0 - so "any weight != 0" is "the largest weight > 0": 4 instructions instead of 7)
 __device__ __forceinline__ bool taps_live(const Taps &t) {
-  return (t.w_nl != 0.0f) | (t.w_nr != 0.0f) | (t.w_sl != 0.0f) | (t.w_sr != 0.0f);
+  return fmaxf(fmaxf(t.w_nl, t.w_nr), fmaxf(t.w_sl, t.w_sr)) > 0.0f;
 }
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int imm) {

@@ -1,0 +1,547 @@
+// Training-side kernels: what `train.py` needs beyond the inference engine.
+//
+//   conv_wgrad_kernel            weight gradient of every convolution kind of the model (Conv2d k3 / k5s2 / k1, Conv3d k3
+//                                s1 / s2, ConvTranspose3d k3 s2) on the matrix cores: torch's conv backward w.r.t. `weight`
+//                                (models/modules.py:13,26, models/mvsnet.py:36-38,74-89)
+//   conv_dgrad_direct_kernel     input gradient of the layer shapes the forward MFMA kernels cannot express as another
+//                                forward layer (Conv2d k5s2, the 8-channel 1x1 lateral); every other input gradient IS a
+//                                forward launch with adjoint weights (casmvsnet_pl_amd/training.py)
+//   channel_sums / abn_*         train-mode ABN = BatchNorm with batch statistics + leaky ReLU (inplace_abn.ABN /
+//                                InPlaceABN as used by modules.py:14,27 and mvsnet.py:77,82,87), forward and backward
+//   upsample2x_add_*             the FPN top-down step F.interpolate(x2, bilinear, align_corners=True) + lateral
+//                                (mvsnet.py:36-38), forward and backward
+//   costvol_var_bwd_kernel       gradient of the variance cost volume (mvsnet.py:137-167) w.r.t. the feature maps
+//
+// Everything is fp32; reductions that decide parameters (weight gradients, batch statistics) are accumulated per
+// workgroup and summed in a fixed order (double for the statistics): results are run-to-run reproducible.
+#include "common.h"
+#include "plane_sweep.h"
+
+namespace {
+
+using namespace casmvs_dev;
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// ---- weight gradient -------------------------------------------------------------------------------------------------
+// Every kind is G[cs][cb][t] = sum over (b, o) of small[b][cs][o] * big[b][cb][S o - P + t]   (per axis; t = kernel tap):
+//   Conv (stride S, pad P):        small = grad_out (cs = cout), big = input (cb = cin)          -> (cout, cin, taps)
+//   ConvTranspose3d (k3 s2 p1 op1): small = input (cs = cin),   big = grad_out (cb = cout), S = 2 -> (cin, cout, taps)
+// i.e. a GEMM with the positions o as the contraction: D[16 cs x 16 cb] += A[16 cs x 4 o] B[4 o x 16 cb] per tap.
+// A workgroup owns one (16 cs, 16 cb) pair and walks tiles of 4 x 16 positions of the small grid; its four waves take four
+// consecutive k-steps (4 positions each) of a tile row and keep one accumulator per tap.  No atomics: every wave
+// writes its partial sums, wgrad_reduce_kernel adds them in a fixed order.
+template <int S, int KZ, int KS>
+struct WgradCfg {
+  static constexpr int T = KZ * KS * KS;
+  static constexpr int TY = 4, TX = 16;
+  static constexpr int PZ = KZ / 2, P = KS / 2;
+  static constexpr int IZ = KZ, IY = (TY - 1) * S + KS, IX = (TX - 1) * S + KS;
+  static constexpr int SY = IX, SZ = IY * IX;
+  static constexpr int SC = (IZ * SZ) | 1;   // odd channel stride: the 16 cb lanes of a B operand hit 16 different banks
+  static constexpr int SS = 65;              // row stride of the small tile (64 positions + 1)
+  static constexpr size_t LDS_BYTES = (size_t)(16 * SC + 16 * SS) * sizeof(float);
+};
+
+template <int S, int KZ, int KS>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__restrict__ small, const float *__restrict__ big,
+                                                             float *__restrict__ partial, int B, int Cs, int Cb, int Zs,
+                                                             int Ys, int Xs, int cb_groups, int tiles_y, int tiles_x) {
+  using Cfg = WgradCfg<S, KZ, KS>;
+  constexpr int T = Cfg::T, IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, SS = Cfg::SS;
+  extern __shared__ float smem[];
+  float *bigT = smem;               // [16 cb][IZ][IY][IX]
+  float *smallT = smem + 16 * SC;   // [16 cs][64 positions]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int rt = blockIdx.y / cb_groups, cg = blockIdx.y - rt * cb_groups;
+  const int Zb = KZ == 1 ? 1 : Zs * S, Yb = Ys * S, Xb = Xs * S;
+  const size_t small_cs = (size_t)Zs * Ys * Xs, big_cs = (size_t)Zb * Yb * Xb;
+  const int tiles = B * Zs * tiles_y * tiles_x;
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    int r = tile;
+    const int tx = r % tiles_x; r /= tiles_x;
+    const int ty = r % tiles_y; r /= tiles_y;
+    const int oz = r % Zs, b = r / Zs;
+    const int oy0 = ty * Cfg::TY, ox0 = tx * Cfg::TX;
+    __syncthreads();   // the previous tile's operands are no longer read
+    // small tile: 16 channels x (4 x 16) positions, zero outside the grid / beyond Cs
+    for (int e = threadIdx.x; e < 16 * 64; e += kThreads) {
+      const int c = e >> 6, q = e & 63, oy = oy0 + (q >> 4), ox = ox0 + (q & 15), ch = rt * 16 + c;
+      float v = 0.0f;
+      if (ch < Cs && oy < Ys && ox < Xs) v = small[((size_t)b * Cs + ch) * small_cs + ((size_t)oz * Ys + oy) * Xs + ox];
+      smallT[c * SS + q] = v;
+    }
+    // big tile: 16 channels x the footprint of the tile's taps, zero padding outside the grid / beyond Cb
+    const int bz0 = (KZ == 1 ? 0 : oz * S) - Cfg::PZ, by0 = oy0 * S - Cfg::P, bx0 = ox0 * S - Cfg::P;
+    for (int e = threadIdx.x; e < 16 * IZ * IY * IX; e += kThreads) {
+      const int c = e / (IZ * IY * IX), rem = e - c * (IZ * IY * IX);
+      const int iz = rem / (IY * IX), rem2 = rem - iz * (IY * IX), iy = rem2 / IX, ix = rem2 - iy * IX;
+      const int gz = bz0 + iz, gy = by0 + iy, gx = bx0 + ix, ch = cg * 16 + c;
+      float v = 0.0f;
+      if (ch < Cb && gz >= 0 && gz < Zb && gy >= 0 && gy < Yb && gx >= 0 && gx < Xb)
+        v = big[((size_t)b * Cb + ch) * big_cs + ((size_t)gz * Yb + gy) * Xb + gx];
+      bigT[c * SC + iz * SZ + iy * SY + ix] = v;
+    }
+    __syncthreads();
+    // this wave's four k-steps: row oy = wave of the tile, positions ox = 4 ks + kq
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int q = wave * 16 + ks * 4 + kq;
+      const float a = smallT[i16 * SS + q];
+      const float *bp = bigT + i16 * SC + (wave * S) * SY + (ks * 4 + kq) * S;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int tz = t / (KS * KS), ty_ = (t / KS) % KS, tx_ = t % KS;
+        acc[t] = mfma16(a, bp[tz * SZ + ty_ * SY + tx_], acc[t]);
+      }
+    }
+  }
+  // partial[((blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave)][t][cs 16][cb 16]; D row = 4 kq + r, column = i16
+  float *pp = partial + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (size_t)(T * 256);
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pp[t * 256 + (4 * kq + r) * 16 + i16] = acc[t][r];
+}
+
+// grad_weight[cs][cb][t] = sum of the partials (fixed order)
+__global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, int Cs, int Cb,
+                                                               int T, int cb_groups, int gy, int gx) {
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= Cs * Cb * T) return;
+  const int t = e % T, cb = (e / T) % Cb, cs = e / (T * Cb);
+  const int y = (cs >> 4) * cb_groups + (cb >> 4);
+  const size_t off = (size_t)t * 256 + (cs & 15) * 16 + (cb & 15);
+  float s = 0.0f;
+  for (int x = 0; x < gx; ++x)
+    for (int wv = 0; wv < 4; ++wv) s += partial[(((size_t)x * gy + y) * 4 + wv) * (size_t)(T * 256) + off];
+  gw[e] = s;
+}
+
+// ---- direct input gradient (layer shapes without an adjoint forward kernel) ------------------------------------------
+// grad_in[b][ci][p] = sum over (co, t) with S o - P + t = p of grad_out[b][co][o] * w[co][ci][t]   (Conv2d / Conv3d weights)
+__global__ __launch_bounds__(kThreads) void conv_dgrad_direct_kernel(const float *__restrict__ gout, const float *__restrict__ w,
+                                                                    float *__restrict__ gin, int cin, int cout, int Zi, int Yi,
+                                                                    int Xi, int S, int KZ, int KS) {
+  const int b = blockIdx.z, ci = blockIdx.y;
+  const size_t in_cs = (size_t)Zi * Yi * Xi;
+  const size_t p = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (p >= in_cs) return;
+  const int x = (int)(p % Xi), y = (int)((p / Xi) % Yi), z = (int)(p / ((size_t)Xi * Yi));
+  const int Sz = KZ == 1 ? 1 : S;   // 2D layers: one plane
+  const int Zo = Zi / Sz, Yo = Yi / S, Xo = Xi / S, PZ = KZ / 2, P = KS / 2, T = KZ * KS * KS;
+  const size_t out_cs = (size_t)Zo * Yo * Xo;
+  float acc = 0.0f;
+  for (int tz = 0; tz < KZ; ++tz) {
+    const int nz = z + PZ - tz;
+    if (nz < 0 || nz % Sz || nz / Sz >= Zo) continue;
+    for (int ty = 0; ty < KS; ++ty) {
+      const int ny = y + P - ty;
+      if (ny < 0 || ny % S || ny / S >= Yo) continue;
+      for (int tx = 0; tx < KS; ++tx) {
+        const int nx = x + P - tx;
+        if (nx < 0 || nx % S || nx / S >= Xo) continue;
+        const size_t o = ((size_t)(nz / Sz) * Yo + ny / S) * Xo + nx / S;
+        const int t = (tz * KS + ty) * KS + tx;
+        for (int co = 0; co < cout; ++co)
+          acc = fmaf(gout[((size_t)b * cout + co) * out_cs + o], w[((size_t)co * cin + ci) * T + t], acc);
+      }
+    }
+  }
+  gin[((size_t)b * cin + ci) * in_cs + p] = acc;
+}
+
+// ---- per-channel sums (batch statistics, bias gradients, ABN backward reductions) ------------------------------------
+// x, y: (N, C, n) ; out[c][blk][2] (double) = partial sums of channel c over this block's slice:
+//   MODE 0: sum x, sum x^2                     (ABN forward statistics; bias gradient = the first)
+//   MODE 1: g = x * (y > 0 ? 1 : slope), xhat = (y2 - mean[c]) * rstd[c]: sum g, sum g * xhat   (ABN backward)
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void channel_sums_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                               const float *__restrict__ y2, const float *__restrict__ mean,
+                                                               const float *__restrict__ rstd, double *__restrict__ out, int N,
+                                                               int C, size_t n, float slope) {
+  const int c = blockIdx.y, nblk = gridDim.x;
+  const size_t total = (size_t)N * n;
+  float s0 = 0.0f, s1 = 0.0f;
+  double d0 = 0.0, d1 = 0.0;
+  const float mu = MODE == 1 ? mean[c] : 0.0f, rs = MODE == 1 ? rstd[c] : 0.0f;
+  int cnt = 0;
+  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)nblk * kThreads) {
+    const size_t img = e / n, off = (img * C + c) * n + (e - img * n);
+    float a, bq;
+    if (MODE == 0) {
+      a = x[off];
+      bq = a * a;
+    } else {
+      const float g = x[off] * (y[off] > 0.0f ? 1.0f : slope);
+      a = g;
+      bq = g * ((y2[off] - mu) * rs);
+    }
+    s0 += a;
+    s1 += bq;
+    if (++cnt == 64) {   // fp32 runs of 64 values, then double
+      d0 += s0; d1 += s1; s0 = s1 = 0.0f; cnt = 0;
+    }
+  }
+  d0 += s0; d1 += s1;
+  __shared__ double red[2][kThreads];
+  red[0][threadIdx.x] = d0; red[1][threadIdx.x] = d1;
+  __syncthreads();
+  for (int st = kThreads / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + st];
+      red[1][threadIdx.x] += red[1][threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[((size_t)c * nblk + blockIdx.x) * 2] = red[0][0];
+    out[((size_t)c * nblk + blockIdx.x) * 2 + 1] = red[1][0];
+  }
+}
+
+// y = lrelu(x * a[c] + b[c])   (a = gamma * rstd, b = beta - mean * a)
+__global__ __launch_bounds__(kThreads) void abn_apply_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ bq,
+                                                            float *__restrict__ y, int C, size_t n, float slope) {
+  const int nc = blockIdx.y;
+  const size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (e >= n) return;
+  const int c = nc % C;
+  const float v = fmaf(x[(size_t)nc * n + e], a[c], bq[c]);
+  y[(size_t)nc * n + e] = v > 0.0f ? v : v * slope;
+}
+
+// gx = a[c] * (g - m1[c] - xhat * m2[c]),  g = gy * (y > 0 ? 1 : slope), xhat = (x - mean[c]) * rstd[c]
+// (m1 = sum g / M, m2 = sum g xhat / M, a = gamma * rstd)
+__global__ __launch_bounds__(kThreads) void abn_bwd_apply_kernel(const float *__restrict__ gy, const float *__restrict__ y, const float *__restrict__ x,
+                                                                const float *__restrict__ a, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                const float *__restrict__ m1, const float *__restrict__ m2, float *__restrict__ gx,
+                                                                int C, size_t n, float slope) {
+  const int nc = blockIdx.y;
+  const size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (e >= n) return;
+  const int c = nc % C;
+  const size_t off = (size_t)nc * n + e;
+  const float g = gy[off] * (y[off] > 0.0f ? 1.0f : slope);
+  const float xhat = (x[off] - mean[c]) * rstd[c];
+  gx[off] = a[c] * (g - m1[c] - xhat * m2[c]);
+}
+
+// ---- FPN top-down step ----------------------------------------------------------------------------------------------------
+// ATen upsample_bilinear2d, align_corners = True: src = o * (n_in - 1) / (n_out - 1), i0 = floor(src), i1 = i0 + (i0 < n_in - 1),
+// l1 = src - i0, l0 = 1 - l1; value = l0y * (l0x v00 + l1x v01) + l1y * (l0x v10 + l1x v11)
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_of(int o, int n_in, int n_out) {
+  const float scale = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.0f;
+  const float src = scale * (float)o;
+  Lerp r;
+  r.i0 = (int)src;
+  r.i1 = r.i0 + (r.i0 < n_in - 1 ? 1 : 0);
+  r.l1 = src - (float)r.i0;
+  r.l0 = 1.0f - r.l1;
+  return r;
+}
+
+__global__ __launch_bounds__(kThreads) void upsample2x_add_kernel(const float *__restrict__ lat, const float *__restrict__ up, float *__restrict__ out,
+                                                                 int H, int W) {
+  const int nc = blockIdx.y, h = H / 2, w = W / 2;
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  const Lerp ly = lerp_of(y, h, H), lx = lerp_of(x, w, W);
+  const float *u = up + (size_t)nc * h * w;
+  const float v = ly.l0 * (lx.l0 * u[ly.i0 * w + lx.i0] + lx.l1 * u[ly.i0 * w + lx.i1]) +
+                  ly.l1 * (lx.l0 * u[ly.i1 * w + lx.i0] + lx.l1 * u[ly.i1 * w + lx.i1]);
+  out[(size_t)nc * H * W + p] = v + lat[(size_t)nc * H * W + p];
+}
+
+// grad_up[iy][ix] = sum over the fine pixels whose stencil contains (iy, ix): a gather over the <= 6 x 6 candidates, no atomics
+__global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float *__restrict__ gout, float *__restrict__ gup, int H, int W) {
+  const int nc = blockIdx.y, h = H / 2, w = W / 2;
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= h * w) return;
+  const int iy = p / w, ix = p - iy * w;
+  const float *g = gout + (size_t)nc * H * W;
+  const int y_lo = max(0, 2 * iy - 3), y_hi = min(H - 1, 2 * iy + 4), x_lo = max(0, 2 * ix - 3), x_hi = min(W - 1, 2 * ix + 4);
+  float acc = 0.0f;
+  for (int y = y_lo; y <= y_hi; ++y) {
+    const Lerp ly = lerp_of(y, h, H);
+    const float wy = (ly.i0 == iy ? ly.l0 : 0.0f) + (ly.i1 == iy ? ly.l1 : 0.0f);
+    if (wy == 0.0f && ly.i0 != iy && ly.i1 != iy) continue;
+    for (int x = x_lo; x <= x_hi; ++x) {
+      const Lerp lx = lerp_of(x, w, W);
+      const float wx = (lx.i0 == ix ? lx.l0 : 0.0f) + (lx.i1 == ix ? lx.l1 : 0.0f);
+      acc += g[y * W + x] * (wy * wx);
+    }
+  }
+  gup[(size_t)nc * h * w + p] = acc;
+}
+
+// ---- variance cost volume backward ----------------------------------------------------------------------------------
+// var = Q / V - (S / V)^2 with S = sum of the V views' values, Q = sum of their squares (mvsnet.py:140-167), so
+// d var / d x_v = 2 x_v / V - 2 S / V^2 for the reference (x_0 = ref feature, every plane) and for each warped view.
+// One thread per reference pixel walks the planes: the warped values are re-gathered (same taps as the forward), the
+// reference gradient accumulates in registers, the source gradients are scattered with fp32 atomics like homo_warp's.
+template <int C>
+__global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *__restrict__ feats, const float *__restrict__ proj,
+                                                                  const float *__restrict__ depth, const float *__restrict__ gvol,
+                                                                  float *__restrict__ gfeats, int V, int H, int W, int D) {
+  const int b = blockIdx.y, hw = H * W;
+  const int p = blockIdx.x * kThreads + threadIdx.x;
+  if (p >= hw) return;
+  const int y = p / W, x = p - y * W;
+  const float *fb = feats + (size_t)b * V * C * hw;
+  float *gb = gfeats + (size_t)b * V * C * hw;
+  const float fV = (float)V;
+  float ref[C], gref[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    ref[c] = fb[(size_t)c * hw + p];
+    gref[c] = 0.0f;
+  }
+  for (int d = 0; d < D; ++d) {
+    const float dv = depth[((size_t)b * D + d) * hw + p];
+    float S[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) S[c] = ref[c];
+    for (int v = 1; v < V; ++v) {
+      const Taps t = plane_sweep_taps(proj + ((size_t)b * (V - 1) + (v - 1)) * 12, (float)x, (float)y, dv, W, H);
+      if (!taps_live(t)) continue;
+      const float *fv = fb + (size_t)v * C * hw;
+      const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float *fc = fv + (size_t)c * hw;
+        S[c] += fmaf(fc[os + 1], t.w_sr, fmaf(fc[os], t.w_sl, fmaf(fc[on + 1], t.w_nr, fc[on] * t.w_nl)));
+      }
+    }
+    const float *gv = gvol + ((size_t)b * C * D + d) * hw + p;
+    float g[C], common[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      g[c] = gv[(size_t)c * D * hw];
+      common[c] = 2.0f * S[c] / (fV * fV);
+      gref[c] += g[c] * (2.0f * ref[c] / fV - common[c]);
+    }
+    for (int v = 1; v < V; ++v) {
+      const Taps t = plane_sweep_taps(proj + ((size_t)b * (V - 1) + (v - 1)) * 12, (float)x, (float)y, dv, W, H);
+      if (!taps_live(t)) {   // the warped value is 0: its gradient has nowhere to go
+        continue;
+      }
+      const float *fv = fb + (size_t)v * C * hw;
+      float *gsv = gb + (size_t)v * C * hw;
+      const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float *fc = fv + (size_t)c * hw;
+        const float xv = fmaf(fc[os + 1], t.w_sr, fmaf(fc[os], t.w_sl, fmaf(fc[on + 1], t.w_nr, fc[on] * t.w_nl)));
+        const float gx = g[c] * (2.0f * xv / fV - common[c]);
+        float *gc = gsv + (size_t)c * hw;
+        if (t.w_nl != 0.0f) unsafeAtomicAdd(gc + on, gx * t.w_nl);
+        if (t.w_nr != 0.0f) unsafeAtomicAdd(gc + on + 1, gx * t.w_nr);
+        if (t.w_sl != 0.0f) unsafeAtomicAdd(gc + os, gx * t.w_sl);
+        if (t.w_sr != 0.0f) unsafeAtomicAdd(gc + os + 1, gx * t.w_sr);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) gb[(size_t)c * hw + p] = gref[c];   // view 0: written, not accumulated (one thread per pixel)
+}
+
+struct WgradGeom {
+  int S, KZ, KS, transposed;
+};
+bool wgrad_geom(int kind, WgradGeom &g) {
+  switch (kind) {
+    case CASMVS_CONV_S1: g = {1, 3, 3, 0}; return true;
+    case CASMVS_CONV_S2: g = {2, 3, 3, 0}; return true;
+    case CASMVS_CONV_T2: g = {2, 3, 3, 1}; return true;
+    case CASMVS_CONV2D_K3: g = {1, 1, 3, 0}; return true;
+    case CASMVS_CONV2D_K5S2: g = {2, 1, 5, 0}; return true;
+    case CASMVS_CONV2D_K1:
+    case CASMVS_CONV2D_K1_UP: g = {1, 1, 1, 0}; return true;
+    default: return false;
+  }
+}
+
+struct WgradLaunch {
+  int Cs, Cb, Zs, Ys, Xs, row_tiles, cb_groups, tiles_y, tiles_x, gx, gy, T;
+};
+// D, H, W: the layer's INPUT dims (as in the forward call)
+bool wgrad_launch(int kind, int B, int cin, int cout, int D, int H, int W, WgradLaunch &l) {
+  WgradGeom g;
+  if (!wgrad_geom(kind, g) || B < 1 || cin < 1 || cout < 1 || D < 1 || H < 1 || W < 1) return false;
+  if (g.KZ == 1 && D != 1) return false;
+  if (g.S == 2 && !g.transposed && ((g.KZ == 3 && D % 2) || H % 2 || W % 2)) return false;
+  if (g.transposed) {   // small = input grid
+    l.Cs = cin; l.Cb = cout; l.Zs = D; l.Ys = H; l.Xs = W;
+  } else {              // small = output grid
+    l.Cs = cout; l.Cb = cin;
+    l.Zs = g.KZ == 3 ? D / g.S : 1; l.Ys = H / g.S; l.Xs = W / g.S;
+  }
+  l.T = g.KZ * g.KS * g.KS;
+  l.row_tiles = casmvs::ceil_div(l.Cs, 16);
+  l.cb_groups = casmvs::ceil_div(l.Cb, 16);
+  l.tiles_y = casmvs::ceil_div(l.Ys, 4);
+  l.tiles_x = casmvs::ceil_div(l.Xs, 16);
+  l.gy = l.row_tiles * l.cb_groups;
+  const long tiles = (long)B * l.Zs * l.tiles_y * l.tiles_x;
+  long gx = 768 / l.gy;
+  if (gx < 1) gx = 1;
+  if (gx > tiles) gx = tiles;
+  l.gx = (int)gx;
+  return true;
+}
+
+template <int S, int KZ, int KS>
+int launch_wgrad(const WgradLaunch &l, const float *small, const float *big, float *partial, int B, hipStream_t st) {
+  auto kernel = conv_wgrad_kernel<S, KZ, KS>;
+  const size_t lds = WgradCfg<S, KZ, KS>::LDS_BYTES;
+  if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "conv_wgrad_kernel")) return rc;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)l.gx, (unsigned)l.gy), dim3(kThreads), lds, st, small, big, partial, B, l.Cs, l.Cb, l.Zs,
+                     l.Ys, l.Xs, l.cb_groups, l.tiles_y, l.tiles_x);
+  return casmvs::check_launch("conv_wgrad_kernel");
+}
+
+}  // namespace
+
+extern "C" size_t casmvs_conv_wgrad_workspace_bytes(int kind, int B, int cin, int cout, int D, int H, int W) {
+  WgradLaunch l;
+  if (!wgrad_launch(kind, B, cin, cout, D, H, W, l)) return 0;
+  return (size_t)l.gx * l.gy * 4 * l.T * 256 * sizeof(float);
+}
+
+extern "C" int casmvs_conv_wgrad_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
+                                     int cin, int cout, int D, int H, int W, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(in && grad_out && grad_weight && workspace, "conv_wgrad: null pointer");
+  WgradLaunch l;
+  if (!wgrad_launch(kind, B, cin, cout, D, H, W, l))
+    return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv_wgrad: kind=%d B=%d cin=%d cout=%d input %dx%dx%d", kind, B, cin, cout, D, H, W);
+  WgradGeom g;
+  wgrad_geom(kind, g);
+  const float *small = g.transposed ? in : grad_out, *big = g.transposed ? grad_out : in;
+  float *partial = static_cast<float *>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (g.KZ == 3 && g.S == 1) rc = launch_wgrad<1, 3, 3>(l, small, big, partial, B, st);
+  else if (g.KZ == 3) rc = launch_wgrad<2, 3, 3>(l, small, big, partial, B, st);
+  else if (g.KS == 3) rc = launch_wgrad<1, 1, 3>(l, small, big, partial, B, st);
+  else if (g.KS == 5) rc = launch_wgrad<2, 1, 5>(l, small, big, partial, B, st);
+  else rc = launch_wgrad<1, 1, 1>(l, small, big, partial, B, st);
+  if (rc) return rc;
+  const int n = l.Cs * l.Cb * l.T;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)casmvs::ceil_div(n, kThreads)), dim3(kThreads), 0, st, partial, grad_weight, l.Cs,
+                     l.Cb, l.T, l.cb_groups, l.gy, l.gx);
+  return casmvs::check_launch("wgrad_reduce_kernel");
+}
+
+extern "C" int casmvs_conv_dgrad_direct_f32(int kind, const float *weight, const float *grad_out, float *grad_in, int B, int cin,
+                                            int cout, int D, int H, int W, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(weight && grad_out && grad_in, "conv_dgrad_direct: null pointer");
+  WgradGeom g;
+  if (!wgrad_geom(kind, g) || g.transposed)
+    return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "conv_dgrad_direct: kind=%d (Conv2d / Conv3d kinds only)", kind);
+  CASMVS_REQUIRE(B > 0 && B <= 65535 && cin > 0 && cin <= 65535 && cout > 0 && D > 0 && H > 0 && W > 0 && (g.KZ == 3 || D == 1),
+                 "conv_dgrad_direct: bad shape B=%d cin=%d cout=%d %dx%dx%d", B, cin, cout, D, H, W);
+  const size_t in_cs = (size_t)D * H * W;
+  dim3 grid((unsigned)((in_cs + kThreads - 1) / kThreads), (unsigned)cin, (unsigned)B);
+  hipLaunchKernelGGL(conv_dgrad_direct_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, grad_out, weight, grad_in, cin, cout, D, H, W,
+                     g.S, g.KZ, g.KS);
+  return casmvs::check_launch("conv_dgrad_direct_kernel");
+}
+
+namespace {
+int sums_blocks(int N, size_t n) {
+  const size_t total = (size_t)N * n;
+  size_t b = (total + (size_t)kThreads * 64 - 1) / ((size_t)kThreads * 64);
+  if (b < 1) b = 1;
+  if (b > 256) b = 256;
+  return (int)b;
+}
+}  // namespace
+
+extern "C" int casmvs_channel_sums_blocks(int N, size_t n) { return sums_blocks(N, n); }
+
+// out: (C, blocks, 2) doubles with blocks = casmvs_channel_sums_blocks(N, n): sum x, sum x^2 over this block's slice
+extern "C" int casmvs_channel_sums_f64(const float *x, double *out, int N, int C, size_t n, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(x && out && N > 0 && C > 0 && C <= 65535 && n > 0, "channel_sums: bad arguments");
+  hipLaunchKernelGGL(channel_sums_kernel<0>, dim3((unsigned)sums_blocks(N, n), (unsigned)C), dim3(kThreads), 0, (hipStream_t)stream, x,
+                     nullptr, nullptr, nullptr, nullptr, out, N, C, n, 0.0f);
+  return casmvs::check_launch("channel_sums_kernel");
+}
+
+extern "C" int casmvs_abn_apply_f32(const float *x, const float *scale, const float *shift, float *y, int N, int C, size_t n, float slope,
+                                    void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(x && scale && shift && y && N > 0 && C > 0 && (size_t)N * C <= 65535 && n > 0, "abn_apply: bad arguments");
+  hipLaunchKernelGGL(abn_apply_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads), (unsigned)(N * C)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, scale, shift, y, C, n, slope);
+  return casmvs::check_launch("abn_apply_kernel");
+}
+
+// sums: (C, blocks, 2) doubles: sum g, sum g * xhat  (g = grad_y * lrelu'(y), xhat = (x - mean) * rstd)
+extern "C" int casmvs_abn_backward_sums_f64(const float *grad_y, const float *y, const float *x, const float *mean, const float *rstd,
+                                            double *sums, int N, int C, size_t n, float slope, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(grad_y && y && x && mean && rstd && sums && N > 0 && C > 0 && C <= 65535 && n > 0, "abn_backward_sums: bad arguments");
+  hipLaunchKernelGGL(channel_sums_kernel<1>, dim3((unsigned)sums_blocks(N, n), (unsigned)C), dim3(kThreads), 0, (hipStream_t)stream, grad_y, y,
+                     x, mean, rstd, sums, N, C, n, slope);
+  return casmvs::check_launch("channel_sums_kernel<1>");
+}
+
+extern "C" int casmvs_abn_backward_apply_f32(const float *grad_y, const float *y, const float *x, const float *scale, const float *mean,
+                                             const float *rstd, const float *m1, const float *m2, float *grad_x, int N, int C, size_t n,
+                                             float slope, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(grad_y && y && x && scale && mean && rstd && m1 && m2 && grad_x && N > 0 && C > 0 && (size_t)N * C <= 65535 && n > 0,
+                 "abn_backward_apply: bad arguments");
+  hipLaunchKernelGGL(abn_bwd_apply_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads), (unsigned)(N * C)), dim3(kThreads), 0,
+                     (hipStream_t)stream, grad_y, y, x, scale, mean, rstd, m1, m2, grad_x, C, n, slope);
+  return casmvs::check_launch("abn_bwd_apply_kernel");
+}
+
+extern "C" int casmvs_upsample2x_add_f32(const float *lat, const float *up, float *out, int N, int C, int H, int W, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(lat && up && out && N > 0 && C > 0 && (size_t)N * C <= 65535 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
+                 "upsample2x_add: bad arguments");
+  hipLaunchKernelGGL(upsample2x_add_kernel, dim3((unsigned)casmvs::ceil_div(H * W, kThreads), (unsigned)(N * C)), dim3(kThreads), 0,
+                     (hipStream_t)stream, lat, up, out, H, W);
+  return casmvs::check_launch("upsample2x_add_kernel");
+}
+
+extern "C" int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad_up, int N, int C, int H, int W, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(grad_out && grad_up && N > 0 && C > 0 && (size_t)N * C <= 65535 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
+                 "upsample2x_backward: bad arguments");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)casmvs::ceil_div((H / 2) * (W / 2), kThreads), (unsigned)(N * C)), dim3(kThreads), 0,
+                     (hipStream_t)stream, grad_out, grad_up, H, W);
+  return casmvs::check_launch("upsample2x_bwd_kernel");
+}
+
+extern "C" int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,
+                                               float *grad_feats, int B, int V, int C, int h, int w, int D, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(feats && proj && depth && grad_vol && grad_feats, "costvol_var_backward: null pointer");
+  CASMVS_REQUIRE(B > 0 && B <= 65535 && V >= 2 && h > 1 && w > 1 && D > 0, "costvol_var_backward: bad shape B=%d V=%d h=%d w=%d D=%d", B, V, h, w, D);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)B * V * C * h * w * sizeof(float), st);
+  if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "costvol_var_backward: hipMemsetAsync: %s", hipGetErrorString(e));
+  dim3 grid((unsigned)casmvs::ceil_div(h * w, kThreads), (unsigned)B);
+#define CASMVS_VB(CV) \
+  if (C == CV) { hipLaunchKernelGGL(costvol_var_bwd_kernel<CV>, grid, dim3(kThreads), 0, st, feats, proj, depth, grad_vol, grad_feats, V, h, w, D); return casmvs::check_launch("costvol_var_bwd_kernel"); }
+  CASMVS_VB(8) CASMVS_VB(16) CASMVS_VB(32) CASMVS_VB(4)
+#undef CASMVS_VB
+  return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_var_backward: C=%d (4, 8, 16 or 32)", C);
+}

@@ -32,9 +32,9 @@ class ConvBnReLU(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("casmvsnet_pl_amd.ConvBnReLU runs on the MI355X only; there is no CPU fallback")
-        if self.training and torch.is_grad_enabled():
-            raise RuntimeError("casmvsnet_pl_amd.ConvBnReLU is an inference engine (eval-mode ABN folded into the "
-                               "MFMA conv epilogue); call model.eval() / torch.no_grad().")
+        if self.training:   # batch statistics, autograd graph (training.py)
+            from .training import conv_bn_relu_2d
+            return conv_bn_relu_2d(self, x.float())
         kind = self._KINDS.get(self._geometry)
         if kind is None:
             raise RuntimeError(f"ConvBnReLU: (kernel, stride, pad) = {self._geometry} is not one of the layer shapes of "
@@ -78,9 +78,9 @@ class ConvBnReLU3D(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("casmvsnet_pl_amd.ConvBnReLU3D runs on the MI355X only; there is no CPU fallback")
-        if self.training:
-            raise RuntimeError("casmvsnet_pl_amd.ConvBnReLU3D is an inference engine (eval-mode ABN folded into the "
-                               "MFMA conv epilogue); call model.eval().")
+        if self.training:   # batch statistics, autograd graph (training.py)
+            from .training import conv_bn_relu_3d
+            return conv_bn_relu_3d(self, x.float())
         kind = {(3, 1, 1): ops.CONV_S1, (3, 2, 1): ops.CONV_S2}.get(self._geometry)
         if kind is None:
             raise RuntimeError(f"ConvBnReLU3D: (kernel, stride, pad) = {self._geometry} is not a CostRegNet layer shape "

@@ -10,8 +10,9 @@ mvsnet.py:125-195  CascadeMVSNet.predict_depth  casmvs_costvol_{var,gwc}_f32 -> 
                                              casmvs_softmax_regress_f32
 mvsnet.py:197-244  CascadeMVSNet.forward     same loop; hypotheses by casmvs_depth_hypotheses_f32
 
-The engine is inference-only (eval-mode ABN folded into the conv epilogue, no autograd); calling
-it in training mode or on CPU tensors raises instead of silently falling back.
+In eval mode this is the fused inference engine (eval-mode ABN folded into the conv epilogue, no autograd graph); in
+train mode (`model.train()`, train.py:99-103) every module runs its differentiable HIP form (training.py: batch-statistics
+ABN, convolution gradients on the matrix cores).  CPU tensors raise instead of silently falling back.
 """
 import torch
 import torch.nn as nn
@@ -125,11 +126,11 @@ class FeatureNet(_PackedWeights, nn.Module):
 
     def forward(self, x):
         """x (N, 3, H, W) -> {"level_0": (N,8,H,W), "level_1": (N,16,H/2,W/2), "level_2": (N,32,H/4,W/4)}."""
-        if self.training and torch.is_grad_enabled():
-            raise RuntimeError("casmvsnet_pl_amd.FeatureNet is an inference engine (eval-mode ABN folded into the "
-                               "MFMA conv epilogue); call model.eval() / torch.no_grad().")
         if not x.is_cuda:
             raise RuntimeError("casmvsnet_pl_amd.FeatureNet runs on the MI355X only; there is no CPU fallback")
+        if self.training:   # batch statistics + autograd graph (training.py); eval mode = the fused engine below
+            from .training import feature_net_train
+            return feature_net_train(self, x.float())
         N, _, H, W = x.shape
         packed = self.packed_layers(x.device)
         need = ops.featurenet_workspace_bytes(N, H, W)
@@ -209,10 +210,9 @@ class CostRegNet(_PackedWeights, nn.Module):
 
     def forward(self, x):
         """x (B, Cin, D, h, w) -> (B, 1, D, h, w)."""
-        if self.training and torch.is_grad_enabled():
-            raise RuntimeError("casmvsnet_pl_amd.CostRegNet is an inference engine (eval-mode ABN folded into the "
-                               "MFMA conv epilogue); call model.eval() / torch.no_grad(). Training support is the "
-                               "next scope row (SURVEY 8f-2).")
+        if self.training:   # batch statistics + autograd graph (training.py); eval mode = the fused engine below
+            from .training import cost_reg_net_train
+            return cost_reg_net_train(self, x)
         B, _, D, h, w = x.shape
         packed = self.packed_layers(x.device)
         need = ops.costreg_workspace_bytes(B, D, h, w)
@@ -293,11 +293,12 @@ class CascadeMVSNet(nn.Module):
         """imgs (B,V,3,H,W); proj_mats (B,V-1,levels,3,4) fine->coarse; init_depth_min,
         depth_interval: float or (B,1) tensor.  Returns {"depth_l", "confidence_l"} for l in 0..2."""
         if self.training:
-            # checked BEFORE the no_grad region below (inside it the sub-modules' own guards cannot fire): a
-            # train-mode call would otherwise silently run eval-mode ABN and return grad-less outputs
-            raise RuntimeError("casmvsnet_pl_amd.CascadeMVSNet.forward is the inference engine (eval-mode ABN folded "
-                               "into the MFMA conv epilogues, no autograd graph): call model.eval().  Training through "
-                               "the HIP ops is available op by op (casmvsnet_pl_amd.autograd), not as a whole model.")
+            # train mode (train.py:99-103): batch-statistics ABN and an autograd graph, every tensor-sized operation a HIP
+            # kernel (casmvsnet_pl_amd/training.py).  The fused inference engine below is the eval-mode path.
+            if not imgs.is_cuda:
+                raise RuntimeError("casmvsnet_pl_amd.CascadeMVSNet runs on the MI355X only; there is no CPU fallback")
+            from .training import cascade_forward_train
+            return cascade_forward_train(self, imgs, proj_mats, init_depth_min, depth_interval)
         if not imgs.is_cuda:
             raise RuntimeError("casmvsnet_pl_amd.CascadeMVSNet runs on the MI355X only: move the model and inputs "
                                "to 'cuda' (ROCm). There is no CPU fallback.")

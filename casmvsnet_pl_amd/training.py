@@ -1,0 +1,426 @@
+"""Training through the HIP engine: what `train.py:99-127` needs - a train-mode forward of
+`CascadeMVSNet` whose graph autograd can walk, with every tensor-sized operation executed by libcasmvs_hip.so.
+
+reference op (train mode)                              here
+nn.Conv2d / Conv3d / ConvTranspose3d forward           the inference MFMA kernels, un-folded (scale 1, slope 1): `conv`
+  ... gradient w.r.t. the input                        the SAME forward kernels with adjoint weights (a transposed / flipped
+                                                       weight tensor, or the strided <-> transposed kind); the three layer shapes
+                                                       without such a twin (Conv2d k5 s2, the 8-channel 1x1 lateral) use
+                                                       casmvs_conv_dgrad_direct_f32
+  ... gradient w.r.t. the weight / bias                casmvs_conv_wgrad_f32 (matrix cores) / casmvs_channel_sums_f64
+ABN / InPlaceABN in train mode (modules.py:14,27)      casmvs_channel_sums_f64 + casmvs_abn_apply_f32; backward
+                                                       casmvs_abn_backward_{sums_f64,apply_f32}; running statistics updated
+F.interpolate(x2, bilinear, align_corners) + lateral   casmvs_upsample2x_add_f32 / casmvs_upsample2x_backward_f32
+homo_warp + variance volume (mvsnet.py:137-167)        fused forward kernel; casmvs_costvol_var_backward_f32
+softmax + depth regression (mvsnet.py:175-177)         autograd.softmax_depth_regression
+
+torch is the autograd tape, the allocator and the per-channel (C floats) arithmetic around the kernels; skip additions
+of the U-Net are torch adds.  Nothing here runs on CPU tensors.  Not tuned for speed: the backward kernels are
+straightforward (see DESIGN.md 2.6 for measured step times).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from . import autograd as A
+from ._lib import CONV_S1, CONV_S2, CONV_T2, CONV2D_K3, CONV2D_K5S2, CONV2D_K1
+
+_3D = (CONV_S1, CONV_S2, CONV_T2)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# ---- device-side packing of a layer image --------------------------------------------------------------------------------
+# casmvs_conv{2,3}d_pack_f32 is host code (it runs once per checkpoint in the inference engine).  In training the weights
+# change every step: the packing is a fixed gather, so it is derived ONCE per layer shape by packing a weight tensor
+# whose values are their own indices, and applied on the device as one index_select per forward.
+_PACK_MAPS = {}
+
+
+def _pack_map(kind, cin, cout, has_bias, device):
+    key = (kind, cin, cout, has_bias, str(device))
+    m = _PACK_MAPS.get(key)
+    if m is not None:
+        return m
+    three_d = kind in _3D
+    k = {CONV2D_K3: 3, CONV2D_K5S2: 5, CONV2D_K1: 1}.get(kind, 3)
+    shape = ((cin, cout) if kind == CONV_T2 else (cout, cin)) + ((3, 3, 3) if three_d else (k, k))
+    n = 1
+    for s in shape:
+        n *= s
+    if n + 2 >= (1 << 24):
+        raise RuntimeError("training: layer too large for the index-valued packing probe")
+    probe_w = (torch.arange(n, dtype=torch.float32) + 2.0).reshape(shape)         # weight i -> value i + 2
+    probe_shift = -(torch.arange(cout, dtype=torch.float32) + 1.0) if has_bias else None   # bias c -> value -(c + 1)
+    packed = (ops.conv3d_pack if three_d else ops.conv2d_pack)(kind, probe_w, None, probe_shift)
+    # source vector on the device: [weights (n), bias (cout or 0), 0.0, 1.0]
+    nb = cout if has_bias else 0
+    idx = torch.empty(packed.numel(), dtype=torch.int64)
+    v = packed.round().to(torch.int64)
+    idx[v >= 2] = v[v >= 2] - 2
+    idx[v == 1] = n + nb + 1
+    idx[v == 0] = n + nb
+    idx[v < 0] = n + (-v[v < 0] - 1)
+    m = _PACK_MAPS[key] = idx.to(device)
+    return m
+
+
+def device_pack(kind, weight, bias=None):
+    """Packed layer image (the operand casmvs_conv{2,3}d_forward_f32 takes) of `weight` [+ `bias`] with scale 1, on the device."""
+    if kind == CONV_T2:
+        cin, cout = weight.shape[:2]
+    else:
+        cout, cin = weight.shape[:2]
+    idx = _pack_map(kind, cin, cout, bias is not None, weight.device)
+    parts = [weight.detach().reshape(-1).float()]
+    if bias is not None:
+        parts.append(bias.detach().reshape(-1).float())
+    parts.append(torch.tensor([0.0, 1.0], dtype=torch.float32, device=weight.device))
+    return torch.cat(parts).index_select(0, idx)
+
+
+def _forward_kernel_supports(kind, cin, cout):
+    lib = _lib.load()
+    fn = lib.casmvs_conv3d_packed_floats if kind in _3D else lib.casmvs_conv2d_packed_floats
+    return fn(kind, cin, cout) > 0
+
+
+def _conv_raw(kind, weight, bias, x):
+    """conv (no activation) through the inference MFMA kernels."""
+    cout = weight.shape[1] if kind == CONV_T2 else weight.shape[0]
+    packed = device_pack(kind, weight, bias)
+    if kind in _3D:
+        return ops.conv3d_forward(kind, packed, x, cout, None, slope=1.0)
+    return ops.conv2d_forward(kind, packed, x, cout, slope=1.0)
+
+
+def conv_wgrad(kind, x, grad_out, weight_shape):
+    """Gradient w.r.t. the weight (torch layout of `kind`), casmvs_conv_wgrad_f32."""
+    lib = _lib.load()
+    x, grad_out = x.contiguous(), grad_out.contiguous()
+    if kind in _3D:
+        B, cin, D, H, W = x.shape
+    else:
+        B, cin, H, W = x.shape
+        D = 1
+    cout = grad_out.shape[1]
+    nbytes = lib.casmvs_conv_wgrad_workspace_bytes(kind, B, cin, cout, D, H, W)
+    if nbytes == 0:
+        raise RuntimeError(f"conv_wgrad: unsupported kind={kind} input {tuple(x.shape)}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    gw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.casmvs_conv_wgrad_f32(kind, _ptr(x), _ptr(grad_out), _ptr(gw), ctypes.c_void_p(ws.data_ptr()), B, cin, cout, D, H, W,
+                                       _stream(x))
+    _lib.check(rc, "casmvs_conv_wgrad_f32")
+    return gw
+
+
+def conv_dgrad(kind, weight, grad_out, x_shape):
+    """Gradient w.r.t. the input: a forward launch of the adjoint layer, or the direct kernel."""
+    grad_out = grad_out.contiguous()
+    if kind == CONV_T2:                      # ConvTranspose3d (cin, cout, k): adjoint = strided conv cout -> cin, same tensor
+        cin, cout = weight.shape[:2]
+        adj_kind, adj_w, a_in, a_out = CONV_S2, weight, cout, cin
+    elif kind == CONV_S2:                    # strided conv (cout, cin, k): adjoint = ConvTranspose3d (cin_T = cout, cout_T = cin)
+        cout, cin = weight.shape[:2]
+        adj_kind, adj_w, a_in, a_out = CONV_T2, weight, cout, cin
+    elif kind in (CONV_S1, CONV2D_K3, CONV2D_K1):   # stride 1: swap the channel roles, mirror the taps
+        cout, cin = weight.shape[:2]
+        flip = (2, 3, 4) if kind == CONV_S1 else (2, 3)
+        adj_kind, a_in, a_out = kind, cout, cin
+        adj_w = weight.transpose(0, 1)
+        adj_w = adj_w.flip(flip) if kind != CONV2D_K1 else adj_w
+    else:
+        cout, cin = weight.shape[:2]
+        adj_kind = None
+    if adj_kind is not None and _forward_kernel_supports(adj_kind, a_in, a_out):
+        return _conv_raw(adj_kind, adj_w.contiguous(), None, grad_out)
+    # Conv2d k5 s2, 1x1 / 3x3 with a channel count the MFMA forms do not take as an output
+    if kind == CONV_T2:
+        raise RuntimeError("conv_dgrad: ConvTranspose3d shape without an adjoint kernel")
+    gin = torch.empty(x_shape, dtype=torch.float32, device=grad_out.device)
+    if kind in _3D:
+        B, _, D, H, W = x_shape
+    else:
+        B, _, H, W = x_shape
+        D = 1
+    w = weight.detach().contiguous().float()
+    with torch.cuda.device(grad_out.device):
+        rc = _lib.load().casmvs_conv_dgrad_direct_f32(kind, _ptr(w), _ptr(grad_out), _ptr(gin), B, cin, cout, D, H, W, _stream(grad_out))
+    _lib.check(rc, "casmvs_conv_dgrad_direct_f32")
+    return gin
+
+
+def channel_sums(x):
+    """x (N,C,...) -> (sum, sum of squares) per channel as float64 (C,) tensors (casmvs_channel_sums_f64)."""
+    x = x.contiguous()
+    N, C = x.shape[:2]
+    n = x.numel() // (N * C)
+    lib = _lib.load()
+    blocks = lib.casmvs_channel_sums_blocks(N, n)
+    part = torch.empty((C, blocks, 2), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.casmvs_channel_sums_f64(_ptr(x), _ptr(part), N, C, n, _stream(x))
+    _lib.check(rc, "casmvs_channel_sums_f64")
+    s = part.sum(1)
+    return s[:, 0], s[:, 1]
+
+
+class _Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, kind):
+        x = x.contiguous().float()
+        ctx.kind = kind
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        return _conv_raw(kind, weight, bias, x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        gx = conv_dgrad(ctx.kind, weight, gy, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        gw = conv_wgrad(ctx.kind, x, gy, tuple(weight.shape)) if ctx.needs_input_grad[1] else None
+        gb = channel_sums(gy)[0].float() if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None
+
+
+def conv(x, weight, bias, kind):
+    """Differentiable convolution of one of the model's layer kinds (forward, input, weight and bias gradients in HIP)."""
+    if not x.is_cuda:
+        raise RuntimeError("casmvsnet_pl_amd.training runs on the MI355X only; there is no CPU fallback")
+    return _Conv.apply(x, weight, bias, kind)
+
+
+class _ABNTrain(torch.autograd.Function):
+    """y = leaky_relu(batch_norm(x) with BATCH statistics); updates the running statistics in place like F.batch_norm."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope):
+        x = x.contiguous().float()
+        N, C = x.shape[:2]
+        n = x.numel() // (N * C)
+        M = N * n
+        s0, s1 = channel_sums(x)
+        mean = s0 / M
+        var = (s1 / M - mean * mean).clamp_min(0.0)            # biased, float64
+        rstd = (var + eps).rsqrt()
+        scale = (gamma.detach().double() * rstd).float()
+        shift = (beta.detach().double() - mean * gamma.detach().double() * rstd).float()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().casmvs_abn_apply_f32(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), N, C, n, float(slope), _stream(x))
+        _lib.check(rc, "casmvs_abn_apply_f32")
+        with torch.no_grad():                                    # F.batch_norm: running_var takes the UNBIASED variance
+            running_mean.mul_(1.0 - momentum).add_(mean.float(), alpha=momentum)
+            running_var.mul_(1.0 - momentum).add_((var * (M / max(M - 1, 1))).float(), alpha=momentum)
+        ctx.save_for_backward(x, y, scale, mean.float(), rstd.float())
+        ctx.slope, ctx.M = float(slope), M
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, scale, mean, rstd = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        N, C = x.shape[:2]
+        n = x.numel() // (N * C)
+        lib = _lib.load()
+        blocks = lib.casmvs_channel_sums_blocks(N, n)
+        part = torch.empty((C, blocks, 2), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.casmvs_abn_backward_sums_f64(_ptr(gy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(part), N, C, n, ctx.slope, _stream(x))
+            _lib.check(rc, "casmvs_abn_backward_sums_f64")
+            s = part.sum(1)
+            g_beta, g_gamma = s[:, 0].float(), s[:, 1].float()
+            m1, m2 = (s[:, 0] / ctx.M).float(), (s[:, 1] / ctx.M).float()
+            gx = torch.empty_like(x)
+            rc = lib.casmvs_abn_backward_apply_f32(_ptr(gy), _ptr(y), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(m1), _ptr(m2),
+                                                   _ptr(gx), N, C, n, ctx.slope, _stream(x))
+            _lib.check(rc, "casmvs_abn_backward_apply_f32")
+        return gx, g_gamma, g_beta, None, None, None, None, None
+
+
+def abn_train(norm, x):
+    """Train-mode forward of an ABN-like module (`weight`, `bias`, `running_mean`, `running_var`, `eps`, `momentum`,
+    leaky-relu slope): inplace_abn.ABN (gamma = weight) or InPlaceABN (gamma = |weight| + eps, see inplace_abn.py)."""
+    if not getattr(norm, "affine", True) or norm.weight is None:
+        raise RuntimeError("training: ABN without affine parameters is not supported")
+    gamma = norm._gamma() if hasattr(norm, "_gamma") else norm.weight
+    slope = norm.leaky_slope() if hasattr(norm, "leaky_slope") else float(getattr(norm, "activation_param", 0.01))
+    return _ABNTrain.apply(x, gamma, norm.bias, norm.running_mean, norm.running_var, float(norm.momentum), float(norm.eps), slope)
+
+
+class _UpsampleAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lat, up):
+        lat, up = lat.contiguous().float(), up.contiguous().float()
+        N, C, H, W = lat.shape
+        if tuple(up.shape) != (N, C, H // 2, W // 2):
+            raise ValueError(f"upsample_add: shapes {tuple(lat.shape)} {tuple(up.shape)}")
+        out = torch.empty_like(lat)
+        with torch.cuda.device(lat.device):
+            rc = _lib.load().casmvs_upsample2x_add_f32(_ptr(lat), _ptr(up), _ptr(out), N, C, H, W, _stream(lat))
+        _lib.check(rc, "casmvs_upsample2x_add_f32")
+        ctx.shape = (N, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.shape
+        g = g.contiguous().float()
+        gup = None
+        if ctx.needs_input_grad[1]:
+            gup = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device):
+                rc = _lib.load().casmvs_upsample2x_backward_f32(_ptr(g), _ptr(gup), N, C, H, W, _stream(g))
+            _lib.check(rc, "casmvs_upsample2x_backward_f32")
+        return (g if ctx.needs_input_grad[0] else None), gup
+
+
+def upsample_add(lat, up):
+    """mvsnet.py:36-38: F.interpolate(up, scale_factor=2, mode="bilinear", align_corners=True) + lat."""
+    return _UpsampleAdd.apply(lat, up)
+
+
+class _VarianceVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, proj_mats, depth_values):
+        feats = feats.contiguous().float()
+        proj_mats, depth_values = proj_mats.detach().contiguous().float(), depth_values.detach().contiguous().float()
+        ctx.save_for_backward(feats, proj_mats, depth_values)
+        B, V, C, h, w = feats.shape
+        if C in (8, 16, 32):
+            nhwc = ops.nchw_to_nhwc(feats.reshape(B * V, C, h, w)).view(B, V, h, w, C)
+            return ops.costvol(nhwc, proj_mats, depth_values, 1, channels_last=True)
+        return ops.costvol(feats, proj_mats, depth_values, 1)
+
+    @staticmethod
+    def backward(ctx, gvol):
+        feats, proj_mats, depth_values = ctx.saved_tensors
+        B, V, C, h, w = feats.shape
+        D = depth_values.shape[1]
+        gvol = gvol.contiguous().float()
+        gfeats = torch.empty_like(feats)
+        with torch.cuda.device(feats.device):
+            rc = _lib.load().casmvs_costvol_var_backward_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(gvol), _ptr(gfeats),
+                                                             B, V, C, h, w, D, _stream(feats))
+        _lib.check(rc, "casmvs_costvol_var_backward_f32")
+        return gfeats, None, None
+
+
+def variance_volume(feats, proj_mats, depth_values):
+    """Differentiable mvsnet.py:137-167 (G = 1): feats (B,V,C,h,w), proj_mats (B,V-1,3,4), depth_values (B,D,h,w) [no grad]
+    -> (B,C,D,h,w)."""
+    return _VarianceVolume.apply(feats, proj_mats, depth_values)
+
+
+def groupwise_volume(feats, proj_mats, depth_values, G):
+    """mvsnet.py:142-144,157-162,169-172 as the reference's own training code writes it: the differentiable HIP warp per
+    view, torch elementwise ops for the (small) correlation."""
+    B, V, C, h, w = feats.shape
+    D = depth_values.shape[1]
+    ref = feats[:, 0].unsqueeze(2).expand(-1, -1, D, -1, -1).reshape(B, G, C // G, D, h, w)
+    vsum = 0
+    for v in range(1, V):
+        warped = A.homo_warp(feats[:, v].contiguous(), proj_mats[:, v - 1].contiguous(), depth_values)
+        vsum = vsum + warped.reshape(B, G, C // G, D, h, w)
+    return (vsum * ref).mean(2).div(V - 1)
+
+
+# ---- train-mode forwards of the three modules (the eval-mode forwards stay the fused inference engine) -----------------
+_KIND2D = {(3, 1, 1): CONV2D_K3, (5, 2, 2): CONV2D_K5S2, (1, 1, 0): CONV2D_K1}
+_KIND3D = {(3, 1, 1): CONV_S1, (3, 2, 1): CONV_S2}
+
+
+def conv_bn_relu_2d(m, x):
+    """modules.py:8-18 in train mode."""
+    kind = _KIND2D.get(m._geometry)
+    if kind is None:
+        raise RuntimeError(f"training: ConvBnReLU geometry {m._geometry} is not a FeatureNet layer shape")
+    return abn_train(m.bn, conv(x, m.conv.weight, None, kind))
+
+
+def conv_bn_relu_3d(m, x):
+    """modules.py:21-31 in train mode."""
+    kind = _KIND3D.get(m._geometry)
+    if kind is None:
+        raise RuntimeError(f"training: ConvBnReLU3D geometry {m._geometry} is not a CostRegNet layer shape")
+    return abn_train(m.bn, conv(x, m.conv.weight, None, kind))
+
+
+def feature_net_train(net, x):
+    """mvsnet.py:40-57 in train mode: x (N,3,H,W) -> {"level_0", "level_1", "level_2"} with an autograd graph."""
+    c0 = x
+    for m in net.conv0:
+        c0 = conv_bn_relu_2d(m, c0)
+    c1 = c0
+    for m in net.conv1:
+        c1 = conv_bn_relu_2d(m, c1)
+    c2 = c1
+    for m in net.conv2:
+        c2 = conv_bn_relu_2d(m, c2)
+    feat2 = conv(c2, net.toplayer.weight, net.toplayer.bias, CONV2D_K1)
+    feat1 = upsample_add(conv(c1, net.lat1.weight, net.lat1.bias, CONV2D_K1), feat2)
+    feat0 = upsample_add(conv(c0, net.lat0.weight, net.lat0.bias, CONV2D_K1), feat1)
+    feat1 = conv(feat1, net.smooth1.weight, net.smooth1.bias, CONV2D_K3)
+    feat0 = conv(feat0, net.smooth0.weight, net.smooth0.bias, CONV2D_K3)
+    return {"level_0": feat0, "level_1": feat1, "level_2": feat2}
+
+
+def cost_reg_net_train(net, x):
+    """mvsnet.py:91-104 in train mode: x (B,Cin,D,h,w) -> (B,1,D,h,w)."""
+    conv0 = conv_bn_relu_3d(net.conv0, x)
+    conv2 = conv_bn_relu_3d(net.conv2, conv_bn_relu_3d(net.conv1, conv0))
+    conv4 = conv_bn_relu_3d(net.conv4, conv_bn_relu_3d(net.conv3, conv2))
+    y = conv_bn_relu_3d(net.conv6, conv_bn_relu_3d(net.conv5, conv4))
+    y = conv4 + abn_train(net.conv7[1], conv(y, net.conv7[0].weight, None, CONV_T2))
+    y = conv2 + abn_train(net.conv9[1], conv(y, net.conv9[0].weight, None, CONV_T2))
+    y = conv0 + abn_train(net.conv11[1], conv(y, net.conv11[0].weight, None, CONV_T2))
+    return conv(y, net.prob.weight, net.prob.bias, CONV_S1)
+
+
+def cascade_forward_train(model, imgs, proj_mats, init_depth_min, depth_interval):
+    """mvsnet.py:197-244 in train mode (what train.py:99-103 calls): the same loop as the inference forward, on the
+    differentiable ops.  Depth hypotheses come from the DETACHED previous depth (mvsnet.py:231)."""
+    from .modules import _per_sample
+    B, V, _, H, W = imgs.shape
+    dev = imgs.device
+    feats = feature_net_train(model.feature, imgs.reshape(B * V, 3, H, W).float())
+    proj = proj_mats.float()
+    results = {}
+    depth_l = None
+    for l in reversed(range(model.levels)):
+        feats_l = feats[f"level_{l}"]
+        C, h, w = feats_l.shape[1:]
+        feats_l = feats_l.reshape(B, V, C, h, w)
+        proj_l = proj[:, :, l].contiguous()
+        D = model.n_depths[l]
+        ratio = model.interval_ratios[l]
+        if isinstance(depth_interval, torch.Tensor):
+            interval_b = depth_interval.reshape(B).to(dev, torch.float32) * ratio
+            half_b = (D / 2) * interval_b
+        else:
+            interval_b = _per_sample(depth_interval * ratio, B, dev)
+            half_b = _per_sample(D / 2 * (depth_interval * ratio), B, dev)
+        with torch.no_grad():
+            if l == model.levels - 1:
+                depth_values = ops.depth_hypotheses(None, _per_sample(init_depth_min, B, dev), interval_b, None, D, h, w)
+            else:
+                depth_values = ops.depth_hypotheses(depth_l.detach(), None, interval_b, half_b, D, h, w)
+        if model.G == 1:
+            volume = variance_volume(feats_l, proj_l, depth_values)
+        else:
+            volume = groupwise_volume(feats_l, proj_l, depth_values, model.G)
+        cost = cost_reg_net_train(getattr(model, f"cost_reg_{l}"), volume).squeeze(1)
+        depth_l, confidence_l = A.softmax_depth_regression(cost, depth_values)
+        results[f"depth_{l}"] = depth_l
+        results[f"confidence_{l}"] = confidence_l
+    return results

@@ -281,6 +281,49 @@ int casmvs_homo_warp_backward_f32(const float *grad_out, const float *proj, cons
 int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_values, const float *grad_depth,
                                         float *grad_cost, int B, int D, int h, int w, void *stream);
 
+/* ---- (f-2) training kernels: weight / input gradients, train-mode ABN, FPN step, cost-volume gradient -----------
+ * What `train.py` (train.py:99-127: forward in train mode, loss.backward()) needs beyond the inference engine.  The host
+ * side (casmvsnet_pl_amd/training.py) wires them into torch.autograd.Function objects.
+ *
+ * casmvs_conv_wgrad_f32: gradient of any convolution kind of the model (CASMVS_CONV_S1 / S2 / T2, CASMVS_CONV2D_K3 / K5S2 /
+ *   K1) with respect to its weight, on the matrix cores.  `in` is the layer's input (B,cin,D,H,W) (2D kinds: D = 1),
+ *   `grad_out` the gradient of its output; grad_weight has the torch layout of the kind: Conv (cout,cin,taps),
+ *   ConvTranspose3d (cin,cout,27).  `workspace` (device, casmvs_conv_wgrad_workspace_bytes) holds per-workgroup partial
+ *   sums that are added in a fixed order: reproducible, no atomics.
+ * casmvs_conv_dgrad_direct_f32: gradient with respect to the INPUT for Conv kinds, straight from the definition (one thread per
+ *   input element).  Only for the layer shapes whose adjoint is not itself a forward layer of the MFMA engine (Conv2d
+ *   k5 s2, 1x1 with 8 input channels): every other input gradient is casmvs_conv{2,3}d_forward_f32 with adjoint weights.
+ *   `weight` (cout,cin,taps) on the device; (D,H,W) = the layer's input dims.
+ * casmvs_channel_sums_f64: out (C, blocks, 2) doubles = per-workgroup partial (sum x, sum x^2) of x (N,C,n) per channel,
+ *   blocks = casmvs_channel_sums_blocks(N, n): batch statistics of ABN / BatchNorm in train mode; bias gradients.
+ * casmvs_abn_apply_f32: y = leaky_relu(x * scale[c] + shift[c]) (scale = gamma * rstd, shift = beta - mean * scale).
+ * casmvs_abn_backward_sums_f64 / casmvs_abn_backward_apply_f32: with g = grad_y * leaky_relu'(y) and xhat = (x - mean) * rstd:
+ *   sums (C, blocks, 2) = partial (sum g, sum g xhat) [= grad_beta, grad_gamma]; grad_x = scale * (g - m1 - xhat * m2) with
+ *   m1 = sum g / M, m2 = sum g xhat / M (device vectors of C floats).
+ * casmvs_upsample2x_add_f32 / casmvs_upsample2x_backward_f32: out (N,C,H,W) = lat + bilinear x2 (align_corners = True) of
+ *   up (N,C,H/2,W/2) (mvsnet.py:36-38); grad_up = the transpose of the interpolation applied to grad_out (a gather).
+ * casmvs_costvol_var_backward_f32: gradient of the variance volume (mvsnet.py:137-167) w.r.t. feats (B,V,C,h,w) given
+ *   grad_vol (B,C,D,h,w): d var / d x_v = 2 x_v / V - 2 sum_v x_v / V^2 through the plane sweep's bilinear weights
+ *   (reference view: no warp).  grad_feats is zeroed by the call; the hypotheses get no gradient (mvsnet.py:231). */
+size_t casmvs_conv_wgrad_workspace_bytes(int kind, int B, int cin, int cout, int D, int H, int W);
+int casmvs_conv_wgrad_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
+                          int cin, int cout, int D, int H, int W, void *stream);
+int casmvs_conv_dgrad_direct_f32(int kind, const float *weight, const float *grad_out, float *grad_in, int B, int cin,
+                                 int cout, int D, int H, int W, void *stream);
+int casmvs_channel_sums_blocks(int N, size_t n);
+int casmvs_channel_sums_f64(const float *x, double *out, int N, int C, size_t n, void *stream);
+int casmvs_abn_apply_f32(const float *x, const float *scale, const float *shift, float *y, int N, int C, size_t n, float slope,
+                         void *stream);
+int casmvs_abn_backward_sums_f64(const float *grad_y, const float *y, const float *x, const float *mean, const float *rstd,
+                                 double *sums, int N, int C, size_t n, float slope, void *stream);
+int casmvs_abn_backward_apply_f32(const float *grad_y, const float *y, const float *x, const float *scale, const float *mean,
+                                  const float *rstd, const float *m1, const float *m2, float *grad_x, int N, int C, size_t n,
+                                  float slope, void *stream);
+int casmvs_upsample2x_add_f32(const float *lat, const float *up, float *out, int N, int C, int H, int W, void *stream);
+int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad_up, int N, int C, int H, int W, void *stream);
+int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,
+                                    float *grad_feats, int B, int V, int C, int h, int w, int D, void *stream);
+
 /* ---- self test ------------------------------------------------------------------------------
  * Runs the MFMA lane-mapping probes the conv kernels rely on (v_mfma_f32_16x16x4_f32 operand /
  * result layout, and v_mfma_f32_4x4x1_16b_f32 with A-block broadcast).  Returns 0 when the hardware semantics match the kernels' assumptions.

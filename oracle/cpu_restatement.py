@@ -72,37 +72,38 @@ def depth_regression(p, depth_values):
 
 # ---- building blocks over a state dict ------------------------------------------------------------
 
-def _abn(x, sd, prefix):
-    """inplace_abn.ABN in eval mode: batch_norm(running stats, eps 1e-5) + leaky_relu(0.01)."""
+def _abn(x, sd, prefix, training=False):
+    """inplace_abn.ABN: batch_norm(eps 1e-5, momentum 0.1) + leaky_relu(0.01); eval mode = running statistics, train mode
+    (train.py) = batch statistics + in-place update of the running ones."""
     x = F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
-                     sd[prefix + ".bias"], False, 0.1, ABN_EPS)
+                     sd[prefix + ".bias"], training, 0.1, ABN_EPS)
     return F.leaky_relu(x, negative_slope=ABN_SLOPE)
 
 
-def _cbr2d(x, sd, prefix, stride, pad):
+def _cbr2d(x, sd, prefix, stride, pad, training=False):
     """modules.py:8-18 ConvBnReLU."""
-    return _abn(F.conv2d(x, sd[prefix + ".conv.weight"], None, stride, pad), sd, prefix + ".bn")
+    return _abn(F.conv2d(x, sd[prefix + ".conv.weight"], None, stride, pad), sd, prefix + ".bn", training)
 
 
-def _cbr3d(x, sd, prefix, stride):
+def _cbr3d(x, sd, prefix, stride, training=False):
     """modules.py:21-31 ConvBnReLU3D (k3, p1, no conv bias)."""
-    return _abn(F.conv3d(x, sd[prefix + ".conv.weight"], None, stride, 1), sd, prefix + ".bn")
+    return _abn(F.conv3d(x, sd[prefix + ".conv.weight"], None, stride, 1), sd, prefix + ".bn", training)
 
 
-def _up3d(x, sd, prefix):
+def _up3d(x, sd, prefix, training=False):
     """mvsnet.py:74-87: ConvTranspose3d(k3, p1, output_padding 1, s2, no bias) + ABN."""
     y = F.conv_transpose3d(x, sd[prefix + ".0.weight"], None, stride=2, padding=1, output_padding=1)
-    return _abn(y, sd, prefix + ".1")
+    return _abn(y, sd, prefix + ".1", training)
 
 
-def feature_net(x, sd, prefix="feature"):
+def feature_net(x, sd, prefix="feature", training=False):
     """mvsnet.py:7-57 FeatureNet.forward.  x (N,3,H,W) -> dict level_0/1/2."""
-    p = prefix
-    c0 = _cbr2d(_cbr2d(x, sd, p + ".conv0.0", 1, 1), sd, p + ".conv0.1", 1, 1)            # :14-16
-    c1 = _cbr2d(c0, sd, p + ".conv1.0", 2, 2)                                              # :18-21
-    c1 = _cbr2d(_cbr2d(c1, sd, p + ".conv1.1", 1, 1), sd, p + ".conv1.2", 1, 1)
-    c2 = _cbr2d(c1, sd, p + ".conv2.0", 2, 2)                                              # :23-26
-    c2 = _cbr2d(_cbr2d(c2, sd, p + ".conv2.1", 1, 1), sd, p + ".conv2.2", 1, 1)
+    p, tr = prefix, training
+    c0 = _cbr2d(_cbr2d(x, sd, p + ".conv0.0", 1, 1, tr), sd, p + ".conv0.1", 1, 1, tr)    # :14-16
+    c1 = _cbr2d(c0, sd, p + ".conv1.0", 2, 2, tr)                                          # :18-21
+    c1 = _cbr2d(_cbr2d(c1, sd, p + ".conv1.1", 1, 1, tr), sd, p + ".conv1.2", 1, 1, tr)
+    c2 = _cbr2d(c1, sd, p + ".conv2.0", 2, 2, tr)                                          # :23-26
+    c2 = _cbr2d(_cbr2d(c2, sd, p + ".conv2.1", 1, 1, tr), sd, p + ".conv2.2", 1, 1, tr)
 
     def up_add(a, b):                                                                      # :36-38
         return F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True) + b
@@ -115,19 +116,19 @@ def feature_net(x, sd, prefix="feature"):
     return {"level_0": feat0, "level_1": feat1, "level_2": feat2}
 
 
-def cost_reg_net(x, sd, prefix, return_intermediates=False):
+def cost_reg_net(x, sd, prefix, return_intermediates=False, training=False):
     """mvsnet.py:91-104 CostRegNet.forward.  x (B,Cin,D,h,w) -> (B,1,D,h,w)."""
-    p = prefix
-    conv0 = _cbr3d(x, sd, p + ".conv0", 1)                                                 # :92
-    conv1 = _cbr3d(conv0, sd, p + ".conv1", 2)
-    conv2 = _cbr3d(conv1, sd, p + ".conv2", 1)                                             # :93
-    conv3 = _cbr3d(conv2, sd, p + ".conv3", 2)
-    conv4 = _cbr3d(conv3, sd, p + ".conv4", 1)                                             # :94
-    conv5 = _cbr3d(conv4, sd, p + ".conv5", 2)
-    conv6 = _cbr3d(conv5, sd, p + ".conv6", 1)                                             # :96
-    up7 = conv4 + _up3d(conv6, sd, p + ".conv7")                                           # :97
-    up9 = conv2 + _up3d(up7, sd, p + ".conv9")                                             # :99
-    up11 = conv0 + _up3d(up9, sd, p + ".conv11")                                           # :101
+    p, tr = prefix, training
+    conv0 = _cbr3d(x, sd, p + ".conv0", 1, tr)                                             # :92
+    conv1 = _cbr3d(conv0, sd, p + ".conv1", 2, tr)
+    conv2 = _cbr3d(conv1, sd, p + ".conv2", 1, tr)                                         # :93
+    conv3 = _cbr3d(conv2, sd, p + ".conv3", 2, tr)
+    conv4 = _cbr3d(conv3, sd, p + ".conv4", 1, tr)                                         # :94
+    conv5 = _cbr3d(conv4, sd, p + ".conv5", 2, tr)
+    conv6 = _cbr3d(conv5, sd, p + ".conv6", 1, tr)                                         # :96
+    up7 = conv4 + _up3d(conv6, sd, p + ".conv7", tr)                                       # :97
+    up9 = conv2 + _up3d(up7, sd, p + ".conv9", tr)                                         # :99
+    up11 = conv0 + _up3d(up9, sd, p + ".conv11", tr)                                       # :101
     out = F.conv3d(up11, sd[p + ".prob.weight"], sd[p + ".prob.bias"], 1, 1)               # :103
     if return_intermediates:
         return out, {"conv0": conv0, "conv1": conv1, "conv2": conv2, "conv3": conv3, "conv4": conv4,
@@ -216,3 +217,36 @@ def cascade_forward(sd, imgs, proj_mats, init_depth_min, depth_interval, n_depth
                 inter[f"cost_{l}"] = cost
                 inter[f"index_{l}"] = index_l
     return (results, inter) if return_intermediates else results
+
+
+def cascade_forward_train(sd, imgs, proj_mats, init_depth_min, depth_interval, n_depths=(8, 32, 48),
+                          interval_ratios=(1, 2, 4), num_groups=1):
+    """mvsnet.py:197-244 in TRAIN mode (train.py:99-103): batch-statistics ABN (the running statistics in `sd` are
+    updated in place, like the modules' buffers), an autograd graph from the six outputs back to every tensor of `sd`
+    that requires grad; the hypotheses of levels 1 and 0 come from the DETACHED previous depth (:231)."""
+    B, V, _, H, W = imgs.shape
+    results = {}
+    feats = feature_net(imgs.reshape(B * V, 3, H, W), sd, training=True)                   # :204-205
+    depth_l = None
+    for l in reversed(range(3)):                                                           # :207
+        feats_l = feats[f"level_{l}"]
+        feats_l = feats_l.view(B, V, *feats_l.shape[1:])                                   # :209
+        proj_mats_l = proj_mats[:, :, l]                                                   # :210
+        depth_interval_l = depth_interval * interval_ratios[l]                             # :211
+        D = n_depths[l]
+        h, w = feats_l.shape[-2:]
+        if l == 2:
+            depth_values = initial_depth_values(init_depth_min, depth_interval_l, D, B, h, w)
+        else:
+            depth_lm1 = F.interpolate(depth_l.detach().unsqueeze(1), scale_factor=2, mode="bilinear",
+                                      align_corners=True)                                  # :231-234
+            depth_values = get_depth_values(depth_lm1, D, depth_interval_l)                # :235
+        volume = cost_volume(feats_l, proj_mats_l, depth_values, num_groups)               # :150-153 / :159-160
+        cost = cost_reg_net(volume, sd, f"cost_reg_{l}", training=True).squeeze(1)         # :174
+        prob_volume = F.softmax(cost, 1)                                                   # :175
+        depth_l = depth_regression(prob_volume, depth_values)                              # :177
+        with torch.no_grad():                                                              # :179-193
+            _, confidence_l, _ = softmax_regress(cost, depth_values)
+        results[f"depth_{l}"] = depth_l
+        results[f"confidence_{l}"] = confidence_l
+    return results

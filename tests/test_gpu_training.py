@@ -1,0 +1,220 @@
+"""GPU tests of the training path (casmvsnet_pl_amd/training.py): every differentiable HIP op against
+torch autograd of the same op on CPU (the reference's own graph: F.conv2d / conv3d / conv_transpose3d, F.batch_norm +
+leaky_relu, F.interpolate, the oracle's cost volume), then the whole model in train mode - outputs, all 130 parameter
+gradients and the updated running statistics - against the TRAIN-mode oracle (oracle/cpu_restatement.py:
+cascade_forward_train, pinned to the live reference by tests/test_oracle.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_restatement as R
+from util import max_abs, rel_err, scaled_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def _ref_conv(kind, x, w, b):
+    from casmvsnet_pl_amd import ops
+    if kind == ops.CONV_S1:
+        return F.conv3d(x, w, b, 1, 1)
+    if kind == ops.CONV_S2:
+        return F.conv3d(x, w, b, 2, 1)
+    if kind == ops.CONV_T2:
+        return F.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1)
+    if kind == ops.CONV2D_K3:
+        return F.conv2d(x, w, b, 1, 1)
+    if kind == ops.CONV2D_K5S2:
+        return F.conv2d(x, w, b, 2, 2)
+    return F.conv2d(x, w, b, 1, 0)
+
+
+# (kind name, weight shape, input spatial shape, bias, input needs grad): every layer shape of the model
+_CONV_CASES = [
+    ("CONV_S1", (8, 16, 3, 3, 3), (8, 12, 20), False, True),      # CostRegNet.conv0 (level 1)
+    ("CONV_S1", (8, 8, 3, 3, 3), (8, 8, 16), False, True),        # conv0 at level 0 / group-wise volumes
+    ("CONV_S1", (8, 32, 3, 3, 3), (8, 8, 16), False, True),       # conv0 at level 2
+    ("CONV_S1", (16, 16, 3, 3, 3), (4, 6, 10), False, True),      # conv2
+    ("CONV_S1", (64, 64, 3, 3, 3), (2, 3, 5), False, True),       # conv6
+    ("CONV_S1", (1, 8, 3, 3, 3), (8, 12, 20), True, True),        # prob
+    ("CONV_S2", (16, 8, 3, 3, 3), (8, 12, 20), False, True),      # conv1
+    ("CONV_S2", (64, 32, 3, 3, 3), (4, 6, 12), False, True),      # conv5
+    ("CONV_T2", (64, 32, 3, 3, 3), (2, 3, 5), False, True),       # conv7
+    ("CONV_T2", (16, 8, 3, 3, 3), (4, 6, 10), False, True),       # conv11
+    ("CONV2D_K3", (8, 3, 3, 3), (24, 40), False, False),          # FeatureNet.conv0.0 (the image needs no gradient)
+    ("CONV2D_K3", (8, 8, 3, 3), (24, 40), False, True),           # conv0.1
+    ("CONV2D_K3", (32, 32, 3, 3), (12, 20), False, True),         # conv2.1
+    ("CONV2D_K3", (8, 32, 3, 3), (24, 40), True, True),           # smooth0
+    ("CONV2D_K3", (16, 32, 3, 3), (12, 20), True, True),          # smooth1
+    ("CONV2D_K5S2", (16, 8, 5, 5), (24, 40), False, True),        # conv1.0
+    ("CONV2D_K5S2", (32, 16, 5, 5), (12, 20), False, True),       # conv2.0
+    ("CONV2D_K1", (32, 32, 1, 1), (6, 10), True, True),           # toplayer
+    ("CONV2D_K1", (32, 16, 1, 1), (12, 20), True, True),          # lat1
+    ("CONV2D_K1", (32, 8, 1, 1), (24, 40), True, True),           # lat0 (direct input-gradient kernel)
+]
+
+
+@pytest.mark.parametrize("kname,wshape,spatial,has_bias,x_grad", _CONV_CASES)
+def test_conv_forward_and_gradients_match_torch(dev, report, kname, wshape, spatial, has_bias, x_grad):
+    from casmvsnet_pl_amd import ops, training as T
+    kind = getattr(ops, kname)
+    g = torch.Generator().manual_seed(sum(wshape) + len(spatial))
+    cin = wshape[0] if kind == ops.CONV_T2 else wshape[1]
+    cout = wshape[1] if kind == ops.CONV_T2 else wshape[0]
+    B = 2
+    x = torch.randn((B, cin) + spatial, generator=g)
+    w = torch.randn(wshape, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) if has_bias else None
+    xr, wr = x.clone().requires_grad_(x_grad), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    want = _ref_conv(kind, xr, wr, br)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy)
+    xd, wd = x.to(dev).requires_grad_(x_grad), w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if has_bias else None
+    got = T.conv(xd, wd, bd, kind)
+    got.backward(gy.to(dev))
+    errs = {"fwd": scaled_err(got.detach(), want.detach()), "gw": scaled_err(wd.grad, wr.grad)}
+    if x_grad:
+        errs["gx"] = scaled_err(xd.grad, xr.grad)
+    if has_bias:
+        errs["gb"] = scaled_err(bd.grad, br.grad)
+    report("train_conv", kind=kname, weight=list(wshape), **errs)
+    # fp32 sums of up to ~10^4 products in another order than torch's (measured <= 3e-6)
+    assert all(e < 3e-5 for e in errs.values()), errs
+
+
+@pytest.mark.parametrize("shape,inplace", [((2, 8, 6, 10, 12), False), ((3, 16, 20, 28), False), ((2, 32, 4, 6, 6), True)])
+def test_abn_train_forward_backward_and_running_stats(dev, report, shape, inplace):
+    from casmvsnet_pl_amd import ABN, InPlaceABN, training as T
+    g = torch.Generator().manual_seed(shape[1])
+    C = shape[1]
+    cls = InPlaceABN if inplace else ABN
+    ref, mod = cls(C), cls(C)
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(C, generator=g))   # negative weights included: |w| + eps under InPlaceABN
+        ref.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        ref.running_mean.normal_(0, 0.2, generator=g)
+        ref.running_var.uniform_(0.5, 1.5, generator=g)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(dev)
+    x = torch.randn(shape, generator=g) * 1.7 + 0.4
+    gy = torch.randn(shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref.train()(xr).backward(gy)
+    xd = x.to(dev).requires_grad_(True)
+    y = T.abn_train(mod.train(), xd)
+    y.backward(gy.to(dev))
+    errs = {"fwd": scaled_err(y.detach(), ref(xr).detach()), "gx": scaled_err(xd.grad, xr.grad),
+            "gw": scaled_err(mod.weight.grad, ref.weight.grad), "gb": scaled_err(mod.bias.grad, ref.bias.grad)}
+    report("train_abn", shape=list(shape), inplace=inplace, **errs)
+    assert all(e < 2e-5 for e in errs.values()), errs
+    # running statistics after ONE train-mode call, from the same starting buffers
+    a, b2 = cls(C), cls(C)
+    with torch.no_grad():
+        for m in (a, b2):
+            m.weight.copy_(ref.weight); m.bias.copy_(ref.bias)
+            m.running_mean.fill_(0.25); m.running_var.fill_(1.5)
+    b2 = b2.to(dev)
+    a.train()(x)
+    T.abn_train(b2.train(), x.to(dev))
+    assert max_abs(b2.running_mean, a.running_mean) < 1e-6 and max_abs(b2.running_var, a.running_var) < 1e-5
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 32, 12, 20), (3, 32, 24, 40), (1, 4, 6, 6)])
+def test_upsample_add_matches_interpolate(dev, report, N, C, H, W):
+    from casmvsnet_pl_amd import training as T
+    g = torch.Generator().manual_seed(H)
+    lat, up, gy = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H // 2, W // 2, generator=g), torch.randn(N, C, H, W, generator=g)
+    lr, ur = lat.clone().requires_grad_(True), up.clone().requires_grad_(True)
+    want = F.interpolate(ur, scale_factor=2, mode="bilinear", align_corners=True) + lr
+    want.backward(gy)
+    ld, ud = lat.to(dev).requires_grad_(True), up.to(dev).requires_grad_(True)
+    got = T.upsample_add(ld, ud)
+    got.backward(gy.to(dev))
+    errs = {"fwd": max_abs(got.detach(), want.detach()), "g_lat": max_abs(ld.grad, lr.grad), "g_up": scaled_err(ud.grad, ur.grad)}
+    report("train_upsample_add", shape=[N, C, H, W], **errs)
+    assert errs["fwd"] < 2e-6 and errs["g_lat"] == 0.0 and errs["g_up"] < 2e-6
+
+
+@pytest.mark.parametrize("B,V,C,h,w,D,geometry", [(1, 3, 8, 24, 32, 4, "dtu"), (2, 3, 16, 16, 24, 8, "dtu"), (1, 4, 32, 16, 16, 3, "random")])
+def test_variance_volume_backward_matches_autograd_of_the_oracle(dev, report, B, V, C, h, w, D, geometry):
+    from casmvsnet_pl_amd import training as T
+    from casmvsnet_pl_amd.synthetic import make_inputs
+    g = torch.Generator().manual_seed(C + D)
+    _, proj, dmin, dint = make_inputs(B, V, h, w, seed=C, geometry=geometry)
+    P = proj[:, :, 0].contiguous()
+    feats = torch.randn(B, V, C, h, w, generator=g)
+    depth = dmin + torch.rand(B, D, h, w, generator=g) * 400.0
+    fr = feats.clone().requires_grad_(True)
+    want = R.cost_volume(fr, P, depth, 1)                     # mvsnet.py:150-153,167 (train-mode arithmetic)
+    gv = torch.randn(want.shape, generator=g)
+    want.backward(gv)
+    fd = feats.to(dev).requires_grad_(True)
+    got = T.variance_volume(fd, P.to(dev), depth.to(dev))
+    got.backward(gv.to(dev))
+    errs = {"fwd": scaled_err(got.detach(), want.detach()), "g_feats": scaled_err(fd.grad, fr.grad)}
+    report("train_variance_volume", shape=[B, V, C, h, w, D], geometry=geometry, **errs)
+    assert errs["fwd"] < 1e-5 and errs["g_feats"] < 3e-5
+
+
+@pytest.mark.parametrize("G,inplace", [(1, False), (1, True), (8, False)])
+def test_model_in_train_mode_matches_the_train_mode_oracle(dev, report, G, inplace):
+    """train.py:99-127: forward in train mode, loss, backward - outputs, every parameter gradient and the running
+    statistics after the step against the CPU oracle (which is pinned to the live reference)."""
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet, InPlaceABN
+    from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
+    model = CascadeMVSNet(num_groups=G, norm_act=InPlaceABN if inplace else ABN)
+    sd0 = randomize_state_dict(model.state_dict(), seed=21 + G)
+    if inplace:   # the oracle's ABN uses the weight as is: give it |w| + eps, which is what InPlaceABN normalises with
+        sd_oracle = {k: ((v.abs() + 1e-5) if (k.endswith(".weight") and v.dim() == 1) else v.clone()) for k, v in sd0.items()}
+    else:
+        sd_oracle = {k: v.clone() for k, v in sd0.items()}
+    imgs, proj, dmin, dint = make_inputs(2, 3, 64, 96, seed=9)
+    for k, v in sd_oracle.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    want = R.cascade_forward_train(sd_oracle, imgs, proj, dmin, dint, (8, 32, 48), (1.0, 2.0, 4.0), G)
+    g = torch.Generator().manual_seed(1)
+    tgt = {l: torch.randn(want[f"depth_{l}"].shape, generator=g) for l in range(3)}
+    sum((want[f"depth_{l}"] * tgt[l]).mean() for l in range(3)).backward()
+    model.load_state_dict(sd0)
+    model = model.to(dev).train()
+    got = model(imgs.to(dev), proj.to(dev), dmin, dint)
+    sum((got[f"depth_{l}"] * tgt[l].to(dev)).mean() for l in range(3)).backward()
+    out_err = {f"depth_{l}": rel_err(got[f"depth_{l}"].detach(), want[f"depth_{l}"].detach()) for l in range(3)}
+    assert all(got[f"depth_{l}"].requires_grad and not got[f"confidence_{l}"].requires_grad for l in range(3))
+    worst, errs_all = ("", 0.0), []
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        ref_g = sd_oracle[k].grad
+        if inplace and k.endswith(".weight") and p.dim() == 1:
+            ref_g = ref_g * torch.sign(sd0[k])                 # d(|w| + eps) / dw
+        # error relative to the tensor's largest gradient entry - but `prob.bias` (softmax is shift invariant) and the
+        # biases in front of a batch norm have an EXACTLY zero gradient that both sides only approximate with rounding
+        # noise: those are compared on the scale of the layer's weight gradient
+        wk = k.rsplit(".", 1)[0] + ".weight"
+        floor = float(sd_oracle[wk].grad.abs().max()) * 1e-3 if (k.endswith(".bias") and wk in sd_oracle and sd_oracle[wk].grad is not None) else 0.0
+        e = float((p.grad.detach().cpu().double() - ref_g.double()).abs().max() / max(float(ref_g.abs().max()), floor, 1e-30))
+        errs_all.append(e)
+        if e > worst[1]:
+            worst = (k, e)
+    n = len(errs_all)
+    median = sorted(errs_all)[n // 2]
+    stats = max(max_abs(b, sd_oracle[k]) for k, b in model.named_buffers() if "running" in k)
+    report("train_model", G=G, inplace=inplace, outputs=out_err, worst_grad=worst[0], worst_grad_scaled_err=worst[1],
+           median_grad_scaled_err=median, params=n, running_stats_max_abs=stats)
+    assert n == 130
+    assert all(e < 1e-3 for e in out_err.values()), out_err      # north_star's bar on the depth maps
+    assert stats < 1e-4
+    # The end-to-end gradient is ill-conditioned on random weights: the ORACLE ITSELF moves by up to 3.7e-2 (scaled, worst
+    # tensor) when its weights are perturbed by 1e-7 relative, and by 2.9e-2 between 1 and 8 CPU threads (leaky-ReLU kinks
+    # and bilinear tap boundaries flip under 1e-6 forward differences).  The per-op tests above carry the accuracy claim
+    # (<= 3e-5 per op); here the typical tensor must agree closely and no tensor may be off by more than that noise class.
+    assert median < 5e-3, median
+    assert worst[1] < 0.25, worst

@@ -120,8 +120,8 @@ def test_forward_fails_loudly_without_gpu():
         m(imgs, proj, dmin, dint)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.costvol(torch.zeros(1, 3, 8, 8, 8), torch.zeros(1, 2, 3, 4), torch.ones(1, 4, 8, 8))
-    net = CostRegNet(8, ABN)  # training mode + grad: the engine refuses instead of silently falling back
-    with pytest.raises(RuntimeError, match="inference engine"):
+    net = CostRegNet(8, ABN)  # training mode: the differentiable HIP path, which has no CPU fallback either
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 8, 8, 8, 8, requires_grad=True))
 
 
@@ -144,15 +144,32 @@ def test_inplace_abn_uses_abs_gamma_plus_eps_like_upstream():
         assert (scale[1] < 0) == (cls is ABN)   # the negative weight keeps its sign only under plain ABN
 
 
-def test_full_model_in_train_mode_raises():
-    """the no_grad region inside forward must not swallow the training guard (train.py calls the model
-    in train mode; silently running eval-mode ABN there would be a wrong-result bug, not a missing feature)."""
+def test_full_model_in_train_mode_takes_the_training_path_and_refuses_cpu():
+    """a train-mode call must never run the eval-mode engine silently (train.py calls the model in train
+    mode).  Since round 2 train mode is the differentiable HIP path (casmvsnet_pl_amd/training.py): on CPU tensors it
+    refuses, with or without grad enabled - it does not fall back to eval-mode ABN."""
     m = CascadeMVSNet(norm_act=ABN)  # nn.Module default: training = True
     imgs, proj, dmin, dint = make_inputs(1, 3, 32, 32, seed=0)
-    with pytest.raises(RuntimeError, match="inference engine"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(imgs, proj, dmin, dint)
-    with torch.no_grad(), pytest.raises(RuntimeError, match="inference engine"):
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
         m(imgs, proj, dmin, dint)
+
+
+def test_device_pack_map_reproduces_the_host_packing():
+    """training.device_pack (one index_select) must give the image casmvs_conv{2,3}d_pack_f32 gives (scale 1, shift = bias)."""
+    from casmvsnet_pl_amd import training as T
+    g = torch.Generator().manual_seed(3)
+    cases = [(ops.CONV_S1, (8, 16, 3, 3, 3), False), (ops.CONV_S1, (1, 8, 3, 3, 3), True), (ops.CONV_S2, (32, 16, 3, 3, 3), False),
+             (ops.CONV_T2, (64, 32, 3, 3, 3), False), (ops.CONV_T2, (16, 8, 3, 3, 3), False), (ops.CONV2D_K3, (8, 3, 3, 3), False),
+             (ops.CONV2D_K3, (8, 32, 3, 3), True), (ops.CONV2D_K5S2, (16, 8, 5, 5), False), (ops.CONV2D_K1, (32, 8, 1, 1), True)]
+    for kind, shape, has_bias in cases:
+        w = torch.randn(shape, generator=g)
+        cout = shape[1] if kind == ops.CONV_T2 else shape[0]
+        b = torch.randn(cout, generator=g) if has_bias else None
+        want = (ops.conv3d_pack if len(shape) == 5 else ops.conv2d_pack)(kind, w, None, b)
+        got = T.device_pack(kind, w, b)   # CPU tensors: the map itself is device-agnostic
+        assert torch.equal(got, want), (kind, shape)
 
 
 def test_dropin_import_paths():

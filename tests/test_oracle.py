@@ -55,6 +55,40 @@ def test_restatement_matches_live_reference(G, V, geometry):
         assert rel_err(got[k], want[k]) < 1e-5 if k.startswith("depth") else max_abs(got[k], want[k]) < 1e-4, k
 
 
+@pytest.mark.skipif(not reference_available(), reason="/root/reference only exists in the build container")
+@pytest.mark.parametrize("G", [1, 8])
+def test_train_mode_restatement_matches_live_reference_gradients(G):
+    """The TRAIN-mode restatement (batch-statistics ABN, graph back to every parameter) against the unmodified reference
+    in train mode (train.py:99-103): outputs, every parameter gradient, and the updated running statistics."""
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet
+    from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
+    sd0 = randomize_state_dict(CascadeMVSNet(num_groups=G, norm_act=ABN).state_dict(), seed=11 + G)
+    imgs, proj, dmin, dint = make_inputs(2, 3, 32, 32, seed=5)
+    ref = build_reference_model([8, 32, 48], [1.0, 2.0, 4.0], G, sd0).train()
+    want = ref(imgs, proj, dmin, dint)
+    g = torch.Generator().manual_seed(0)
+    tgt = {l: torch.randn(want[f"depth_{l}"].shape, generator=g) for l in range(3)}
+    sum((want[f"depth_{l}"] * tgt[l]).mean() for l in range(3)).backward()
+    sd = {k: v.clone() for k, v in sd0.items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    got = R.cascade_forward_train(sd, imgs, proj, dmin, dint, (8, 32, 48), (1.0, 2.0, 4.0), G)
+    sum((got[f"depth_{l}"] * tgt[l]).mean() for l in range(3)).backward()
+    for l in range(3):
+        assert rel_err(got[f"depth_{l}"], want[f"depth_{l}"]) < 1e-5
+    ref_params = dict(ref.named_parameters())
+    ref_bufs = dict(ref.named_buffers())
+    n = 0
+    for k, v in sd.items():
+        if v.requires_grad:
+            assert scaled_err(v.grad, ref_params[k].grad) < 1e-4, k
+            n += 1
+        elif "running" in k:
+            assert max_abs(v, ref_bufs[k]) < 1e-5, k
+    assert n == 130
+
+
 def test_identity_homography_returns_input():
     torch.manual_seed(0)
     src = torch.randn(1, 4, 12, 20)

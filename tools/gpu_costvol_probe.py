@@ -20,16 +20,33 @@ _, proj, dmin, dint = make_inputs(B, V, H, W, seed=0)
 REPS = int(os.environ.get("CV_PROBE_REPS", "10"))
 
 
+# CV_PROBE_DIRTY=<MB>: before every timed launch a torch fill_ of that many MB runs (ordinary stores): the caches then
+# hold another kernel's dirty lines and none of the inputs, as inside the forward (each launch timed on its own)
+DIRTY_MB = int(os.environ.get("CV_PROBE_DIRTY", "0"))
+_dirty = torch.empty(DIRTY_MB * 262144, device=dev) if DIRTY_MB else None
+
+
 def timed(fn, reps=REPS):
     for _ in range(3 if reps > 1 else 0):
         fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
+    if _dirty is None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+    total = 0.0
     for _ in range(reps):
+        _dirty.fill_(1.0)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
         fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / reps
+        e.record()
+        torch.cuda.synchronize()
+        total += s.elapsed_time(e)
+    return total / reps
 
 
 for l, (C, D) in {2: (32, 48), 1: (16, 32), 0: (8, 8)}.items():
