@@ -42,7 +42,8 @@ struct WgradCfg {
   static constexpr int SY = IX, SZ = IY * IX;
   static constexpr int SC = (IZ * SZ) | 1;   // odd channel stride: the 16 cb lanes of a B operand hit 16 different banks
   static constexpr int SS = 65;              // row stride of the small tile (64 positions + 1)
-  static constexpr size_t LDS_BYTES = (size_t)(16 * SC + 16 * SS) * sizeof(float);
+  static constexpr int TILE_FLOATS = 16 * SC + 16 * SS, RED_FLOATS = T * 256;   // the end-of-kernel reduction reuses the buffer
+  static constexpr size_t LDS_BYTES = (size_t)(TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS) * sizeof(float);
 };
 
 template <int S, int KZ, int KS>
@@ -102,26 +103,39 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
       }
     }
   }
-  // partial[((blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave)][t][cs 16][cb 16]; D row = 4 kq + r, column = i16
-  float *pp = partial + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (size_t)(T * 256);
+  // The four waves' accumulators are added through LDS in wave order (deterministic), then the workgroup writes ONE partial:
+  // partial[blockIdx.x * gridDim.y + blockIdx.y][t][cs 16][cb 16]; D row = 4 kq + r, column = i16
+  __syncthreads();
+  float *red = smem;   // T * 256 floats (<= the tile buffers: 16 * SC >= 27 * 16 * 16 only for the 3D kinds; see LDS_BYTES)
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
 #pragma unroll
-  for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pp[t * 256 + (4 * kq + r) * 16 + i16] = acc[t][r];
+        for (int r = 0; r < 4; ++r) {
+          float *q = red + t * 256 + (4 * kq + r) * 16 + i16;
+          *q = wv == 0 ? acc[t][r] : *q + acc[t][r];
+        }
+    }
+    __syncthreads();
+  }
+  float *pp = partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (size_t)(T * 256);
+  for (int e = threadIdx.x; e < T * 256; e += kThreads) pp[e] = red[e];
 }
 
-// grad_weight[cs][cb][t] = sum of the partials (fixed order)
+// grad_weight[cs][cb][t] = sum over the workgroups' partials in a fixed order.  One thread per element of the partial layout
+// (coalesced reads), scattered write into the torch layout.
 __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, int Cs, int Cb,
                                                                int T, int cb_groups, int gy, int gx) {
-  const int e = blockIdx.x * kThreads + threadIdx.x;
-  if (e >= Cs * Cb * T) return;
-  const int t = e % T, cb = (e / T) % Cb, cs = e / (T * Cb);
-  const int y = (cs >> 4) * cb_groups + (cb >> 4);
-  const size_t off = (size_t)t * 256 + (cs & 15) * 16 + (cb & 15);
+  const int e = blockIdx.x * kThreads + threadIdx.x;   // (y, t, i, j)
+  if (e >= gy * T * 256) return;
+  const int j = e & 15, i = (e >> 4) & 15, t = (e >> 8) % T, y = (e >> 8) / T;
+  const int cs = (y / cb_groups) * 16 + i, cb = (y % cb_groups) * 16 + j;
+  if (cs >= Cs || cb >= Cb) return;
+  const float *p = partial + (size_t)y * (T * 256) + (size_t)t * 256 + i * 16 + j;
   float s = 0.0f;
-  for (int x = 0; x < gx; ++x)
-    for (int wv = 0; wv < 4; ++wv) s += partial[(((size_t)x * gy + y) * 4 + wv) * (size_t)(T * 256) + off];
-  gw[e] = s;
+  for (int x = 0; x < gx; ++x) s += p[(size_t)x * gy * (T * 256)];
+  gw[((size_t)cs * Cb + cb) * T + t] = s;
 }
 
 // ---- direct input gradient (layer shapes without an adjoint forward kernel) ------------------------------------------
@@ -289,13 +303,15 @@ __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float *_
 // ---- variance cost volume backward ----------------------------------------------------------------------------------
 // var = Q / V - (S / V)^2 with S = sum of the V views' values, Q = sum of their squares (mvsnet.py:140-167), so
 // d var / d x_v = 2 x_v / V - 2 S / V^2 for the reference (x_0 = ref feature, every plane) and for each warped view.
-// One thread per reference pixel walks the planes: the warped values are re-gathered (same taps as the forward), the
-// reference gradient accumulates in registers, the source gradients are scattered with fp32 atomics like homo_warp's.
+// One thread per (reference pixel, chunk of planes): the warped values are re-gathered (same taps as the forward), the
+// reference gradient accumulates in registers over the chunk, the source gradients are scattered with fp32 atomics like
+// homo_warp's (lanes = consecutive pixels of a channel plane: the atomics of a wave fall on a few cache lines; a
+// pixel-major variant whose lanes each add C consecutive floats was 2.5x slower - the lanes' footprints overlap).
 template <int C>
 __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *__restrict__ feats, const float *__restrict__ proj,
                                                                   const float *__restrict__ depth, const float *__restrict__ gvol,
-                                                                  float *__restrict__ gfeats, int V, int H, int W, int D) {
-  const int b = blockIdx.y, hw = H * W;
+                                                                  float *__restrict__ gfeats, int V, int H, int W, int D, int dch) {
+  const int b = blockIdx.z, d_begin = blockIdx.y * dch, d_end = min(d_begin + dch, D), hw = H * W;
   const int p = blockIdx.x * kThreads + threadIdx.x;
   if (p >= hw) return;
   const int y = p / W, x = p - y * W;
@@ -308,7 +324,7 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     ref[c] = fb[(size_t)c * hw + p];
     gref[c] = 0.0f;
   }
-  for (int d = 0; d < D; ++d) {
+  for (int d = d_begin; d < d_end; ++d) {
     const float dv = depth[((size_t)b * D + d) * hw + p];
     float S[C];
 #pragma unroll
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     }
   }
 #pragma unroll
-  for (int c = 0; c < C; ++c) gb[(size_t)c * hw + p] = gref[c];   // view 0: written, not accumulated (one thread per pixel)
+  for (int c = 0; c < C; ++c) unsafeAtomicAdd(gb + (size_t)c * hw + p, gref[c]);   // view 0: one add per plane chunk
 }
 
 struct WgradGeom {
@@ -395,7 +411,7 @@ bool wgrad_launch(int kind, int B, int cin, int cout, int D, int H, int W, Wgrad
   l.tiles_x = casmvs::ceil_div(l.Xs, 16);
   l.gy = l.row_tiles * l.cb_groups;
   const long tiles = (long)B * l.Zs * l.tiles_y * l.tiles_x;
-  long gx = 768 / l.gy;
+  long gx = 512 / l.gy;
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
   l.gx = (int)gx;
@@ -417,7 +433,7 @@ int launch_wgrad(const WgradLaunch &l, const float *small, const float *big, flo
 extern "C" size_t casmvs_conv_wgrad_workspace_bytes(int kind, int B, int cin, int cout, int D, int H, int W) {
   WgradLaunch l;
   if (!wgrad_launch(kind, B, cin, cout, D, H, W, l)) return 0;
-  return (size_t)l.gx * l.gy * 4 * l.T * 256 * sizeof(float);
+  return (size_t)l.gx * l.gy * l.T * 256 * sizeof(float);
 }
 
 extern "C" int casmvs_conv_wgrad_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
@@ -439,7 +455,7 @@ extern "C" int casmvs_conv_wgrad_f32(int kind, const float *in, const float *gra
   else if (g.KS == 5) rc = launch_wgrad<2, 1, 5>(l, small, big, partial, B, st);
   else rc = launch_wgrad<1, 1, 1>(l, small, big, partial, B, st);
   if (rc) return rc;
-  const int n = l.Cs * l.Cb * l.T;
+  const int n = l.gy * l.T * 256;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)casmvs::ceil_div(n, kThreads)), dim3(kThreads), 0, st, partial, grad_weight, l.Cs,
                      l.Cb, l.T, l.cb_groups, l.gy, l.gx);
   return casmvs::check_launch("wgrad_reduce_kernel");
@@ -538,10 +554,12 @@ extern "C" int casmvs_costvol_var_backward_f32(const float *feats, const float *
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)B * V * C * h * w * sizeof(float), st);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "costvol_var_backward: hipMemsetAsync: %s", hipGetErrorString(e));
-  dim3 grid((unsigned)casmvs::ceil_div(h * w, kThreads), (unsigned)B);
+  const int dch = D >= 16 ? 4 : (D >= 4 ? 2 : 1);   // planes per thread
+  dim3 grid((unsigned)casmvs::ceil_div(h * w, kThreads), (unsigned)casmvs::ceil_div(D, dch), (unsigned)B);
 #define CASMVS_VB(CV) \
-  if (C == CV) { hipLaunchKernelGGL(costvol_var_bwd_kernel<CV>, grid, dim3(kThreads), 0, st, feats, proj, depth, grad_vol, grad_feats, V, h, w, D); return casmvs::check_launch("costvol_var_bwd_kernel"); }
+  if (C == CV) { hipLaunchKernelGGL(costvol_var_bwd_kernel<CV>, grid, dim3(kThreads), 0, st, feats, proj, depth, grad_vol, grad_feats, V, h, w, D, dch); return casmvs::check_launch("costvol_var_bwd_kernel"); }
   CASMVS_VB(8) CASMVS_VB(16) CASMVS_VB(32) CASMVS_VB(4)
 #undef CASMVS_VB
   return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_var_backward: C=%d (4, 8, 16 or 32)", C);
 }
+

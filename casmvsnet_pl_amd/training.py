@@ -297,7 +297,7 @@ class _VarianceVolume(torch.autograd.Function):
         proj_mats, depth_values = proj_mats.detach().contiguous().float(), depth_values.detach().contiguous().float()
         ctx.save_for_backward(feats, proj_mats, depth_values)
         B, V, C, h, w = feats.shape
-        if C in (8, 16, 32):
+        if C in (8, 16, 32):   # pixel-major copy: what the fast forward kernels read
             nhwc = ops.nchw_to_nhwc(feats.reshape(B * V, C, h, w)).view(B, V, h, w, C)
             return ops.costvol(nhwc, proj_mats, depth_values, 1, channels_last=True)
         return ops.costvol(feats, proj_mats, depth_values, 1)
