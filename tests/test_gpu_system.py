@@ -129,3 +129,42 @@ def test_concurrent_forwards_equal_single_stream(dev):
         for o, w in zip(outs, want):
             for k in w:
                 assert torch.equal(o[k], w[k]), k
+
+
+DDP_TRAIN_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from torch.nn.parallel import DistributedDataParallel as DDP
+from casmvsnet_pl_amd import CascadeMVSNet, InPlaceABN
+from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+def grads(wrap):
+    m = CascadeMVSNet(norm_act=InPlaceABN)
+    randomize_state_dict(m.state_dict(), seed=8)
+    m = m.to(dev).train()
+    net = DDP(m, device_ids=[0]) if wrap else m
+    imgs, proj, dmin, dint = make_inputs(1, 3, 64, 96, seed=2)
+    out = net(imgs.to(dev), proj.to(dev), dmin, dint)
+    sum(torch.nn.functional.smooth_l1_loss(out[f"depth_{l}"], torch.full_like(out[f"depth_{l}"], 600.0)) for l in range(3)).backward()
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9)
+    opt.step()
+    return [p.grad.clone() for p in m.parameters()], [p.detach().clone() for p in m.parameters()]
+g0, p0 = grads(False)
+g1, p1 = grads(True)
+# the forward is deterministic; the feature-map gradients of the cost volume are fp32 atomics (order-dependent last bits)
+err = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(g0, g1))
+moved = all(float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-9 for a, b in zip(p0, p1))
+dist.destroy_process_group()
+print("DDP_TRAIN_STEP", len(g0), err < 1e-4 and moved, err)
+"""
+
+
+def test_ddp_training_step_world1_over_rccl():
+    """train.py:198-199 trains under (Lightning's) DistributedDataParallel: the train-mode model wrapped in DDP over the nccl
+    (= RCCL) backend at world size 1 takes a full step - the gradient hooks see every parameter of the custom autograd
+    Functions - and, with one rank, lands on the same gradients and weights as the bare model (up to the order of the
+    fp32 atomics of the cost-volume backward)."""
+    out = _run([sys.executable, "-c", DDP_TRAIN_SCRIPT], timeout=600)
+    assert "DDP_TRAIN_STEP 130 True" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])

@@ -34,12 +34,15 @@ for cfg in dtu_640x512_v3_gwc8 dtu_1152x864_v5_var blended_768x576_v7_var; do
 done
 for cfg in dtu_1152x864_v5_var blended_768x576_v7_var; do
   timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 bench.py --gpus 1 \
-     --mode view_sharded --config $cfg --batch 1 --steps 10 --warmup 3 --no-cpu-baseline --no-events > $OUT/bench_viewsharded_$cfg.json 2>> $OUT/bench.err
+     --mode view_sharded --config $cfg --batch 1 --steps 10 --warmup 3 --no-cpu-baseline --no-events 2>> $OUT/bench.err | grep "^{" > $OUT/bench_viewsharded_$cfg.json
 done
 timeout 300 python tools/gpu_costvol_probe.py 512 640 3 1 2>/dev/null > $OUT/costvol_probe_b1.txt
 timeout 300 python tools/gpu_costvol_probe.py 512 640 3 2 2>/dev/null > $OUT/costvol_probe_b2.txt
 for p in lds_probe valu_probe clock_probe store_probe; do timeout 120 tools/probes/bin/$p > $OUT/$p.txt 2>/dev/null; done
 timeout 200 python tools/gpu_streams_probe.py 2>/dev/null > $OUT/streams_probe.txt
+# cost-volume kernels as they run inside the forward (caches dirtied by another writer between launches), and a training step
+CV_PROBE_DIRTY=512 CV_PROBE_IMPLS=gather,lds timeout 300 python tools/gpu_costvol_probe.py 512 640 3 2 2>/dev/null > $OUT/costvol_probe_b2_dirty.txt
+timeout 300 python tools/gpu_train_step.py 2>/dev/null | grep -E "train step|eval forward" > $OUT/train_step.txt
 cat $OUT/mfma_rate.txt; tail -4 $OUT/pytest_gpu.log; python tools/show_bench.py $OUT/bench.json | head -8; tail -3 $OUT/bench.err; cat $OUT/summarize.log | tail -3
 for f in $OUT/bench_*.json; do python -c "
 import json,sys
