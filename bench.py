@@ -132,6 +132,38 @@ def cpu_baseline(cfg_name):
                       f"{ncpu} hardware threads"}
 
 
+def stock_pytorch_rocm(cfg_name, dev):
+    """SURVEY 8(d)'s second comparison row: the SAME restated reference forward, executed on the MI355X by stock
+    PyTorch-ROCm operators (MIOpen convolutions, ATen grid_sample / batch_norm / softmax) - what a plain `model.cuda()` of
+    the reference gives.  Part of the baseline leg like cpu_baseline (the only place bench.py touches oracle/).  The
+    first call spends about a minute in MIOpen's kernel search; it is not timed."""
+    from oracle import cpu_restatement as R
+    H, W, V, G, n_depths, ratios, _ = CONFIGS[cfg_name]
+    model = CascadeMVSNet(n_depths=list(n_depths), interval_ratios=list(ratios), num_groups=G, norm_act=ABN)
+    sd = {k: v.to(dev) for k, v in randomize_state_dict(model.state_dict(), seed=0).items()}
+    imgs, proj, dmin, dint = config_inputs(cfg_name, 1, seed=0)
+    imgs, proj = imgs.to(dev), proj.to(dev)
+    old = torch.get_default_device() if hasattr(torch, "get_default_device") else None
+    torch.set_default_device(dev)   # the restatement creates its grids / plane indices on the default device
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                R.cascade_forward(sd, imgs, proj, dmin, dint, n_depths, ratios, G)
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                R.cascade_forward(sd, imgs, proj, dmin, dint, n_depths, ratios, G)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_default_device(old if old is not None else "cpu")
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "depth-maps/s", "ms_per_forward": 1e3 * med, "kind": "port on stock PyTorch-ROCm operators",
+            "sample": f"median of 7 forwards of ONE depth map ({cfg_name}) after 3 warm-ups, torch {torch.__version__} on the same GPU"}
+
+
 def timed_steps(step, steps, barrier):
     barrier()
     t0 = time.perf_counter()
@@ -190,6 +222,8 @@ def main():
                     help="independent forwards in flight per GPU, one HIP stream + hipGraph each (a step = one round of all of "
                          "them; 1 = a single forward per step).  The single-stream figures are printed as well.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stock-pytorch", action="store_true",
+                    help="also time the restated reference forward on stock PyTorch-ROCm operators on this GPU (adds ~1 min of MIOpen search)")
     ap.add_argument("--no-events", action="store_true", help="skip the instrumented pass (no roofline objects)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="the instrumented pass records its ~90 HIP events on every n-th of its K kernel-by-kernel steps (an event "
@@ -359,6 +393,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
+        if world == 1 and args.stock_pytorch:
+            line["stock_pytorch_rocm"] = stock_pytorch_rocm(args.config, dev)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

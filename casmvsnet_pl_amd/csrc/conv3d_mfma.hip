@@ -84,8 +84,8 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 //   CI / TCI : unit = 4 input channels (one "ci quad"), kz*ks*ks tap images -> [quad][tap][64]
 //   PX       : unit = 1 input channel, kz*ks (kz,ky) images                 -> [ci][kz*3+ky][64]
 //   TPX      : unit = 4 input channels, 9 (kz,ky) x 2 (dx) images           -> [quad][kz*3+ky][dx][64]
-//   P1       : unit = 1 input channel, its 27 taps contiguous (+ 5 zeros): no lane images - the
-//              1-channel `prob` head is a VALU kernel that reads its weights as wave-uniform scalars
+//   P1       : unit = 2 input channels, [tap (27 + 5 zeros)][channel of the pair]: no lane images - the 1-channel
+//              `prob` head is a VALU kernel that reads its weights as wave-uniform scalars, a pair per packed FMA
 // The 2D layers of FeatureNet (kinds CASMVS_CONV2D_*) are the same formats with kz = 1.
 inline bool layer_cfg(int kind, int cin, int cout, LayerCfg &c) {
   if (cin < 1 || cout < 1) return false;
@@ -93,7 +93,7 @@ inline bool layer_cfg(int kind, int cin, int cout, LayerCfg &c) {
   c.ks = 3;
   const int quads = round_up((cin + 3) / 4, 4);
   if (kind == CASMVS_CONV_S1) {
-    if (cout == 1) { c.fmt = FMT_P1; c.coutb = 4; c.units = round_up(cin, 8); c.unit_floats = 32; }
+    if (cout == 1) { c.fmt = FMT_P1; c.coutb = 4; c.units = round_up(cin, 8) / 2; c.unit_floats = 64; }
     else if (cout == 8) { c.fmt = FMT_PX; c.coutb = 8; c.units = round_up(cin, 8); c.unit_floats = 9 * 64; }
     else if (cout % 16 == 0) { c.fmt = FMT_CI; c.coutb = 16; c.units = quads; c.unit_floats = 27 * 64; }
     else return false;
@@ -133,8 +133,8 @@ inline float pack_weight(const LayerCfg &c, int kind, int cin, int cout, const f
   };
   const int i = l & 15, k = l >> 4;
   switch (c.fmt) {
-    case FMT_P1:     // one 32-float row per input channel: l = tap
-      return l < 27 ? conv_w(0, unit, l) : 0.0f;
+    case FMT_P1:     // one 64-float row per PAIR of input channels: l = 2 * tap + (channel & 1)
+      return (l >> 1) < 27 ? conv_w(0, 2 * unit + (l & 1), l >> 1) : 0.0f;
     case FMT_CI:     // img = tap; row i = co, k = input channel of the quad
     case FMT_TCI:
       return conv_w(sl * 16 + i, unit * 4 + k, img);
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
   const int in_cs = Di * Hi * Wi;
   const size_t in_ss = (size_t)cin * in_cs;
   const rsrc_t src = make_rsrc(in + b * in_ss, in_ss * 4);
-  const int rows = (cin + 7) / 8 * 8;  // packed image: [input channel][32]: the channel's 27 taps, contiguous
+  const int rows = (cin + 7) / 8 * 8;  // packed image: [channel pair][tap (32)][2]
   const float *scale = wpk + (size_t)rows * 32;
   const float *shift = scale + 4;
   Stager<VEC, CK, IZ, IY, IX, SC, NW> regs;
@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
 #pragma unroll
     for (int c = 0; c < CK; ++c) {
       const int ci = s * CK + c;  // channels >= cin: staged zeros x zero weights
-      const float *wci = wpk + ci * 32;  // wave-uniform: s_load_dwordx8 / x16
+      const float *wci = wpk + (ci >> 1) * 64 + (ci & 1);  // wave-uniform scalar loads; tap t of this channel at [2 t]
 #pragma unroll
       for (int r9 = 0; r9 < 9; ++r9) {
         const float *row = row0 + c * SC + (r9 / 3) * SZ + (r9 % 3) * SY;
@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
           m = f32x4v{a[1], a[2], a[3], e[0]};
           i5 = e[1];
         }
-        const float w0 = wci[r9 * 3 + 0], w1 = wci[r9 * 3 + 1], w2 = wci[r9 * 3 + 2];
+        const float w0 = wci[(r9 * 3 + 0) * 2], w1 = wci[(r9 * 3 + 1) * 2], w2 = wci[(r9 * 3 + 2) * 2];
         acc[0] = fmaf(m[1], w2, fmaf(m[0], w1, fmaf(i0, w0, acc[0])));
         acc[1] = fmaf(m[2], w2, fmaf(m[1], w1, fmaf(m[0], w0, acc[1])));
         acc[2] = fmaf(m[3], w2, fmaf(m[2], w1, fmaf(m[1], w0, acc[2])));
@@ -1476,6 +1476,110 @@ __global__ __launch_bounds__(kThreads, 4) void prob_valu_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) buf_store(v[i], dst, (ok && ox + i < Wi) ? vbase + 4 * i : kOOB, 0);
   }
+}
+
+// ---- `prob` head, packed-math form (W % 4 == 0, aligned input) ---------------------------------------------------------
+// The kernel above issues 19 instructions per 12 FMAs (one b128 + two b32 LDS reads, two DPP moves, two selects per
+// input row and channel): it is instruction-bound at 3.6x its HBM time.  Here the LDS tile interleaves the two channels
+// of a PAIR ([x][2]), rows start at x0 - 1 so that the 6 x 2 inputs a thread needs per (pair, kz, ky) are three aligned
+// ds_read_b128, and every FMA is a v_pk_fma_f32 over the channel pair with the weight pair as a scalar operand: 15
+// instructions per 24 FMAs.  The two channel-parity partial sums of an output are added at the end.
+struct ProbPkCfg {
+  static constexpr int TZ = 4, TY = 8, TX = 32, IZ = TZ + 2, IY = TY + 2;
+  static constexpr int SY = 76;             // floats per row: 38 channel pairs (37 used: x0 - 1 .. x0 + 35), 16-byte multiple
+  static constexpr int SZ = IY * SY, SP = IZ * SZ;   // per plane, per channel pair
+  static constexpr int CKP = 2;             // channel pairs per stage
+  static constexpr int GROUPS = 2 * CKP * IZ * IY * 10;   // 16-byte global groups per stage (10 per row: x0 - 4 .. x0 + 35)
+  static constexpr int NK = (GROUPS + kThreads - 1) / kThreads;
+  static constexpr size_t LDS_BYTES = (size_t)CKP * SP * sizeof(float);
+};
+
+__global__ __launch_bounds__(kThreads, 4) void prob_pk_kernel(const float *__restrict__ in, const float *__restrict__ wpk,
+                                                             float *__restrict__ out, int cin, int Di, int Hi, int Wi,
+                                                             int tiles_x, int tiles_y, float slope) {
+  using Cfg = ProbPkCfg;
+  constexpr int IZ = Cfg::IZ, IY = Cfg::IY, SY = Cfg::SY, SZ = Cfg::SZ, SP = Cfg::SP, NK = Cfg::NK;
+  extern __shared__ float smem[];
+  float *tile = smem;
+  const int nstages = (cin + 2 * Cfg::CKP - 1) / (2 * Cfg::CKP);
+  const int tiles_z = gridDim.x / (tiles_x * tiles_y);
+  const int bid = xcd_major(blockIdx.x, gridDim.x);
+  const int tz0 = (bid % tiles_z) * Cfg::TZ;
+  const int tx0 = ((bid / tiles_z) % tiles_x) * Cfg::TX;
+  const int ty0 = (bid / (tiles_z * tiles_x)) * Cfg::TY;
+  const int b = blockIdx.y;
+  const int xi = threadIdx.x & 7, yi = (threadIdx.x >> 3) & 7, zi = threadIdx.x >> 6;
+  const int in_cs = Di * Hi * Wi;
+  const size_t in_ss = (size_t)cin * in_cs;
+  const rsrc_t src = make_rsrc(in + b * in_ss, in_ss * 4);
+  const int rows = (cin + 7) / 8 * 8;
+  const float *scale = wpk + (size_t)rows * 32;
+  const float *shift = scale + 4;
+
+  // staging plan (tile constants): group e = tid + 256 k -> (channel of the stage, plane, row, 16-byte group of the row)
+  int voff[NK], loff[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int e = threadIdx.x + k * kThreads;
+    const int cl = e / (IZ * IY * 10), r = e - cl * (IZ * IY * 10);
+    const int iz = r / (IY * 10), r2 = r - iz * (IY * 10), iy = r2 / 10, g = r2 - iy * 10;
+    const int gz = tz0 - 1 + iz, gy = ty0 - 1 + iy, gx = tx0 - 4 + 4 * g;
+    const bool ok = e < Cfg::GROUPS && gz >= 0 && gz < Di && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;   // Wi % 4 == 0
+    voff[k] = ok ? (cl * in_cs + (gz * Hi + gy) * Wi + gx) * 4 : kOOB;
+    // element j of the group is column L = 4 g + j of the row (L = 0 is x0 - 4); columns 3 .. 39 are kept at [L - 3][parity]
+    loff[k] = (cl >> 1) * SP + iz * SZ + iy * SY + 2 * (4 * g - 3) + (cl & 1);
+  }
+  f32x4v v[NK];
+  auto load_stage = [&](int s) {
+    const int soff = s * 2 * Cfg::CKP * in_cs * 4;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) v[k] = buf_load4(src, voff[k], soff);   // channels >= cin lie beyond the sample: zeros
+  };
+  load_stage(0);
+  f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+  for (int s = 0; s < nstages; ++s) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      // the row's first group (g == 0) holds columns 0 .. 3: only column 3 is staged
+      const int e = threadIdx.x + k * kThreads;
+      const bool g0 = (e % 10) == 0;
+      if (e < Cfg::GROUPS) {
+        float *q = tile + loff[k];
+        if (!g0) { q[0] = v[k][0]; q[2] = v[k][1]; q[4] = v[k][2]; }
+        q[6] = v[k][3];
+      }
+    }
+    __syncthreads();
+    if (s + 1 < nstages) load_stage(s + 1);
+#pragma unroll
+    for (int pp = 0; pp < Cfg::CKP; ++pp) {
+      const float *wq = wpk + (size_t)(s * Cfg::CKP + pp) * 64;   // wave-uniform: [tap][2]
+#pragma unroll
+      for (int r9 = 0; r9 < 9; ++r9) {
+        const float *row = tile + pp * SP + (zi + r9 / 3) * SZ + (yi + r9 % 3) * SY + 8 * xi;
+        const f32x4v A = *reinterpret_cast<const f32x4v *>(row), Bq = *reinterpret_cast<const f32x4v *>(row + 4),
+                     Cq = *reinterpret_cast<const f32x4v *>(row + 8);
+        const f32x2 P[6] = {f32x2{A[0], A[1]}, f32x2{A[2], A[3]}, f32x2{Bq[0], Bq[1]}, f32x2{Bq[2], Bq[3]}, f32x2{Cq[0], Cq[1]}, f32x2{Cq[2], Cq[3]}};
+        const f32x2 W0{wq[r9 * 6 + 0], wq[r9 * 6 + 1]}, W1{wq[r9 * 6 + 2], wq[r9 * 6 + 3]}, W2{wq[r9 * 6 + 4], wq[r9 * 6 + 5]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_elementwise_fma(P[j + 2], W2, __builtin_elementwise_fma(P[j + 1], W1, __builtin_elementwise_fma(P[j], W0, acc[j])));
+      }
+    }
+  }
+  const int oz = tz0 + zi, oy = ty0 + yi, ox = tx0 + 4 * xi;
+  const rsrc_t dst = make_rsrc(out + (size_t)b * in_cs, (size_t)in_cs * 4);
+  const float sc0 = scale[0], sh0 = shift[0];
+  float o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[i] = fmaf(acc[i][0] + acc[i][1], sc0, sh0);
+    o[i] = o[i] > 0.0f ? o[i] : o[i] * slope;
+  }
+  const bool ok = oz < Di && oy < Hi && ox < Wi;
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4v{o[0], o[1], o[2], o[3]}), dst,
+                                         ok ? ((oz * Hi + oy) * Wi + ox) * 4 : kOOB, 0, 0);
 }
 
 // ---- FPN top-down step: 1x1 lateral conv + bilinear x2 upsample-add (mvsnet.py:36-38, 49-50) -----------
@@ -1826,6 +1930,14 @@ int launch_prob_v(const float *packed, const float *in, float *out, int B, int c
 
 int launch_prob(const LayerCfg &, const float *packed, const float *in, float *out, int B, int cin,
                 int D, int H, int W, float slope, hipStream_t st) {
+  static const bool no_pk = trace_env_set("CASMVS_NO_PROB_PK");  // A/B switch (profiling build)
+  if (!no_pk && vec4_ok(in, W)) {
+    if (int rc = ensure_lds(prob_pk_kernel, ProbPkCfg::LDS_BYTES, "prob_pk_kernel")) return rc;
+    const int tiles_x = casmvs::ceil_div(W, 32), tiles_y = casmvs::ceil_div(H, 8), tiles_z = casmvs::ceil_div(D, 4);
+    hipLaunchKernelGGL(prob_pk_kernel, dim3((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, 1), dim3(kThreads), ProbPkCfg::LDS_BYTES, st,
+                       in, packed, out, cin, D, H, W, tiles_x, tiles_y, slope);
+    return casmvs::check_launch("prob_pk_kernel");
+  }
   if (vec4_ok(in, W)) return launch_prob_v<4>(packed, in, out, B, cin, D, H, W, slope, st);
   return launch_prob_v<1>(packed, in, out, B, cin, D, H, W, slope, st);
 }

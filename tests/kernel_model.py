@@ -23,7 +23,7 @@ def layer_cfg(kind, cin, cout):
     """-> fmt, coutb, slices, units, unit_floats (mirrors layer_cfg in conv3d_mfma.hip)."""
     q = _ru((cin + 3) // 4, 4)
     if kind == S1:
-        fmt, coutb, units, uf = (P1, 4, _ru(cin, 8), 32) if cout == 1 else (PX, 8, _ru(cin, 8), 9 * 64) if cout == 8 else (CI, 16, q, 27 * 64)
+        fmt, coutb, units, uf = (P1, 4, _ru(cin, 8) // 2, 64) if cout == 1 else (PX, 8, _ru(cin, 8), 9 * 64) if cout == 8 else (CI, 16, q, 27 * 64)
     elif kind == S2:
         fmt, coutb, units, uf = CI, 16, q, 27 * 64
     else:
@@ -54,14 +54,14 @@ def emulate(kind, packed, x, cout, skip=None, slope=0.01):
     def chan(xp, ci):  # staged tile: channels >= cin are zero-filled
         return xp[:, ci] if ci < cin else torch.zeros_like(xp[:, 0])
 
-    if fmt == P1:  # VALU kernel: row ci of the image = the channel's 27 taps (+ 5 zeros)
-        rows = packed[:body].reshape(units, 32).double()
+    if fmt == P1:  # VALU kernel: row p of the image = the 27 taps (+ 5 zeros) of the channel PAIR p, [tap][channel & 1]
+        rows = packed[:body].reshape(units, 32, 2).double()
         assert float(rows[:, 27:].abs().sum()) == 0.0
         xp = F.pad(xd, (1, 1, 1, 1, 1, 1))
-        for ci in range(units):
+        for ci in range(2 * units):
             for tap in range(27):
                 kz, ky, kx = tap // 9, (tap // 3) % 3, tap % 3
-                acc[:, 0] += rows[ci, tap] * chan(xp, ci)[:, kz:kz + D, ky:ky + H, kx:kx + W]
+                acc[:, 0] += rows[ci // 2, tap, ci % 2] * chan(xp, ci)[:, kz:kz + D, ky:ky + H, kx:kx + W]
     elif fmt == CI:
         st = 1 if kind == S1 else 2
         xp = F.pad(xd, (1, 1, 1, 1, 1, 1))
