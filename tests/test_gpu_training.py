@@ -218,3 +218,34 @@ def test_model_in_train_mode_matches_the_train_mode_oracle(dev, report, G, inpla
     # (<= 3e-5 per op); here the typical tensor must agree closely and no tensor may be off by more than that noise class.
     assert median < 5e-3, median
     assert worst[1] < 0.25, worst
+
+
+def test_sgd_steps_reduce_the_loss(dev, report):
+    """train.py's loop in miniature: the reference's default optimiser (SGD lr 1e-3, momentum 0.9, opt.py:40-47), SL1 loss over
+    the three levels (losses.py), InPlaceABN, 12 steps on one fixed batch - the loss must fall monotonically."""
+    from casmvsnet_pl_amd import CascadeMVSNet, InPlaceABN
+    from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
+    model = CascadeMVSNet(norm_act=InPlaceABN)
+    randomize_state_dict(model.state_dict(), seed=0)
+    model = model.to(dev).train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+    imgs, proj, dmin, dint = make_inputs(2, 3, 64, 96, seed=3)
+    imgs, proj = imgs.to(dev), proj.to(dev)
+    g = torch.Generator().manual_seed(0)
+    gt = {l: (560.0 + 30.0 * torch.randn(2, 64 >> l, 96 >> l, generator=g)).to(dev) for l in range(3)}
+    losses = []
+    for _ in range(12):
+        opt.zero_grad(set_to_none=True)
+        res = model(imgs, proj, dmin, dint)
+        loss = sum(F.smooth_l1_loss(res[f"depth_{l}"], gt[l]) * 2 ** (1 - l) for l in range(3))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    report("train_sgd_steps", losses=[round(x, 2) for x in losses])
+    assert all(b < a for a, b in zip(losses, losses[1:])), losses
+    assert losses[-1] < 0.5 * losses[0], losses
+    # and the trained weights serve the eval-mode engine (packed images are rebuilt from the updated parameters)
+    model.eval()
+    with torch.no_grad():
+        out = model(imgs, proj, dmin, dint)
+    assert all(torch.isfinite(out[f"depth_{l}"]).all() for l in range(3))
