@@ -95,36 +95,31 @@ __global__ __launch_bounds__(kThreads) void fuse_view_kernel(const FuseArgs a) {
     const bool y0in = iy >= 0 && iy < H, y1in = iy + 1 >= 0 && iy + 1 < H;
     const int cx0 = min(max(ix, 0), W - 1), cx1 = min(max(ix + 1, 0), W - 1);
     const int cy0 = min(max(iy, 0), H - 1), cy1 = min(max(iy + 1, 0), H - 1);
+    // Every tap is loaded from its CLAMPED (always valid) address and zeroed by a select afterwards: 4 + 12 independent loads
+    // in flight per source view.  (Written as `inside ? load : 0` the compiler made 16 exec-masked branches whose loads
+    // completed one after the other: 16 serial memory latencies per view, the kernel ran at 0.13 of the HBM roof.)
     const float *ds = a.depth_src + (size_t)s * hw;
-    const float t0 = (x0in && y0in) ? ds[cy0 * W + cx0] : 0.0f, t1 = (x1in && y0in) ? ds[cy0 * W + cx1] : 0.0f;
-    const float t2 = (x0in && y1in) ? ds[cy1 * W + cx0] : 0.0f, t3 = (x1in && y1in) ? ds[cy1 * W + cx1] : 0.0f;
-    const float d_s2r = ((t0 * w0 + t1 * w1) + t2 * w2) + t3 * w3;   // remapBilinear, CV_32F
-    // 8-bit image: integer weights that sum to 2^15, rounding shift
-    int wi[4];
-    {
-      const float wf[4] = {w0, w1, w2, w3};
-      int tot = 0, kmax = 0, kmin = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        wi[k] = (int)rint((double)wf[k] * 32768.0);
-        tot += wi[k];
-      }
-#pragma unroll
-      for (int k = 1; k < 4; ++k) {   // first maximum / first minimum, like numpy's argmax / argmin
-        if (wi[k] > wi[kmax]) kmax = k;
-        if (wi[k] < wi[kmin]) kmin = k;
-      }
-      const int diff = tot - 32768;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k == (diff < 0 ? kmax : kmin)) wi[k] -= diff;
-    }
+    const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
+    const bool in00 = x0in && y0in, in01 = x1in && y0in, in10 = x0in && y1in, in11 = x1in && y1in;
+    const float l0 = ds[o00], l1 = ds[o01], l2 = ds[o10], l3 = ds[o11];
     const unsigned char *is = a.image_src + (size_t)s * hw * 3;
+    int bt[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      bt[0][c] = is[o00 * 3 + c]; bt[1][c] = is[o01 * 3 + c]; bt[2][c] = is[o10 * 3 + c]; bt[3][c] = is[o11 * 3 + c];
+    }
+    const float t0 = in00 ? l0 : 0.0f, t1 = in01 ? l1 : 0.0f, t2 = in10 ? l2 : 0.0f, t3 = in11 ? l3 : 0.0f;
+    const float d_s2r = ((t0 * w0 + t1 * w1) + t2 * w2) + t3 * w3;   // remapBilinear, CV_32F
+    // 8-bit image: OpenCV's integer weight table, saturate_cast<short>(w * 2^15) with the rounding error of the four
+    // entries pushed onto the largest / smallest one.  With 5-bit fractions the weights are (32 - fy)(32 - fx) / 1024 ...
+    // fy fx / 1024: exact in float32, and w * 2^15 = 32 x an integer product - the rounding is the identity, the four
+    // entries sum to exactly 2^15 and the correction never fires.  (The float64 rint / argmax / argmin form of the
+    // oracle, oracle/fusion_restatement.py, gives the same integers; it cost 16 fp64 instructions per source view.)
+    const int wi[4] = {(INTER_TAB - fy) * (INTER_TAB - fx) * 32, (INTER_TAB - fy) * fx * 32, fy * (INTER_TAB - fx) * 32, fy * fx * 32};
     int col[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const int b0 = (x0in && y0in) ? is[(cy0 * W + cx0) * 3 + c] : 0, b1 = (x1in && y0in) ? is[(cy0 * W + cx1) * 3 + c] : 0;
-      const int b2 = (x0in && y1in) ? is[(cy1 * W + cx0) * 3 + c] : 0, b3 = (x1in && y1in) ? is[(cy1 * W + cx1) * 3 + c] : 0;
+      const int b0 = in00 ? bt[0][c] : 0, b1 = in01 ? bt[1][c] : 0, b2 = in10 ? bt[2][c] : 0, b3 = in11 ? bt[3][c] : 0;
       const int acc = b0 * wi[0] + b1 * wi[1] + b2 * wi[2] + b3 * wi[3];
       col[c] = min(max((acc + (1 << 14)) >> 15, 0), 255);
     }
