@@ -36,12 +36,15 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 template <int S, int KZ, int KS>
 struct WgradCfg {
   static constexpr int T = KZ * KS * KS;
-  static constexpr int TY = 4, TX = 16;
+  // tile of the small grid: TZ x 4 x 16 positions.  The stride-1 3D layers (the bulk of the FLOPs) take four planes per
+  // tile: the kz halo is then 6 planes per 4 instead of 3 per 1 (staging bytes per position: 2.5x instead of 5x)
+  static constexpr int TZ = (KZ == 3 && S == 1) ? 4 : 1, TY = 4, TX = 16;
+  static constexpr int ROWS = TZ * TY, NPOS = ROWS * TX;   // (z, y) rows of 16 positions; a wave owns ROWS / 4 of them
   static constexpr int PZ = KZ / 2, P = KS / 2;
-  static constexpr int IZ = KZ, IY = (TY - 1) * S + KS, IX = (TX - 1) * S + KS;
+  static constexpr int IZ = (TZ - 1) * S + KZ, IY = (TY - 1) * S + KS, IX = (TX - 1) * S + KS;
   static constexpr int SY = IX, SZ = IY * IX;
   static constexpr int SC = (IZ * SZ) | 1;   // odd channel stride: the 16 cb lanes of a B operand hit 16 different banks
-  static constexpr int SS = 65;              // row stride of the small tile (64 positions + 1)
+  static constexpr int SS = NPOS + 1;        // row stride of the small tile
   static constexpr int TILE_FLOATS = 16 * SC + 16 * SS, RED_FLOATS = T * 256;   // the end-of-kernel reduction reuses the buffer
   static constexpr size_t LDS_BYTES = (size_t)(TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS) * sizeof(float);
 };
@@ -49,18 +52,19 @@ struct WgradCfg {
 template <int S, int KZ, int KS>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__restrict__ small, const float *__restrict__ big,
                                                              float *__restrict__ partial, int B, int Cs, int Cb, int Zs,
-                                                             int Ys, int Xs, int cb_groups, int tiles_y, int tiles_x) {
+                                                             int Ys, int Xs, int cb_groups, int tiles_z, int tiles_y, int tiles_x) {
   using Cfg = WgradCfg<S, KZ, KS>;
   constexpr int T = Cfg::T, IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, SS = Cfg::SS;
+  constexpr int TZ = Cfg::TZ, TY = Cfg::TY, NPOS = Cfg::NPOS, RPW = Cfg::ROWS / 4;
   extern __shared__ float smem[];
   float *bigT = smem;               // [16 cb][IZ][IY][IX]
-  float *smallT = smem + 16 * SC;   // [16 cs][64 positions]
+  float *smallT = smem + 16 * SC;   // [16 cs][NPOS positions]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
   const int rt = blockIdx.y / cb_groups, cg = blockIdx.y - rt * cb_groups;
   const int Zb = KZ == 1 ? 1 : Zs * S, Yb = Ys * S, Xb = Xs * S;
   const size_t small_cs = (size_t)Zs * Ys * Xs, big_cs = (size_t)Zb * Yb * Xb;
-  const int tiles = B * Zs * tiles_y * tiles_x;
+  const int tiles = B * tiles_z * tiles_y * tiles_x;
   f32x4 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -68,45 +72,73 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     int r = tile;
     const int tx = r % tiles_x; r /= tiles_x;
     const int ty = r % tiles_y; r /= tiles_y;
-    const int oz = r % Zs, b = r / Zs;
-    const int oy0 = ty * Cfg::TY, ox0 = tx * Cfg::TX;
+    const int tz = r % tiles_z, b = r / tiles_z;
+    const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * Cfg::TX;
     __syncthreads();   // the previous tile's operands are no longer read
-    // small tile: 16 channels x (4 x 16) positions, zero outside the grid / beyond Cs
-    for (int e = threadIdx.x; e < 16 * 64; e += kThreads) {
-      const int c = e >> 6, q = e & 63, oy = oy0 + (q >> 4), ox = ox0 + (q & 15), ch = rt * 16 + c;
-      float v = 0.0f;
-      if (ch < Cs && oy < Ys && ox < Xs) v = small[((size_t)b * Cs + ch) * small_cs + ((size_t)oz * Ys + oy) * Xs + ox];
-      smallT[c * SS + q] = v;
+    // Staging in batches of 8 elements per thread: all 8 loads are issued (from clamped, always valid addresses; the value
+    // is zeroed by a select when the element lies outside the grid / beyond the channel count) before the first LDS
+    // write - written as `if (inside) v = load` per element the loads complete one after the other (a memory latency each).
+    constexpr int UB = 8;
+    // small tile: 16 channels x NPOS positions (q = (z * TY + y) * 16 + x)
+    for (int e0 = 0; e0 < 16 * NPOS; e0 += UB * kThreads) {
+      float v[UB];
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int e = min(e0 + threadIdx.x + i * kThreads, 16 * NPOS - 1);
+        const int c = e / NPOS, q = e - c * NPOS, oz = oz0 + q / (TY * 16), oy = oy0 + (q >> 4) % TY, ox = ox0 + (q & 15), ch = rt * 16 + c;
+        const bool ok = ch < Cs && oz < Zs && oy < Ys && ox < Xs;
+        const float l = small[((size_t)b * Cs + min(ch, Cs - 1)) * small_cs + ((size_t)min(oz, Zs - 1) * Ys + min(oy, Ys - 1)) * Xs + min(ox, Xs - 1)];
+        v[i] = ok ? l : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int e = e0 + threadIdx.x + i * kThreads;
+        if (e < 16 * NPOS) smallT[(e / NPOS) * SS + (e % NPOS)] = v[i];
+      }
     }
     // big tile: 16 channels x the footprint of the tile's taps, zero padding outside the grid / beyond Cb
-    const int bz0 = (KZ == 1 ? 0 : oz * S) - Cfg::PZ, by0 = oy0 * S - Cfg::P, bx0 = ox0 * S - Cfg::P;
-    for (int e = threadIdx.x; e < 16 * IZ * IY * IX; e += kThreads) {
-      const int c = e / (IZ * IY * IX), rem = e - c * (IZ * IY * IX);
-      const int iz = rem / (IY * IX), rem2 = rem - iz * (IY * IX), iy = rem2 / IX, ix = rem2 - iy * IX;
-      const int gz = bz0 + iz, gy = by0 + iy, gx = bx0 + ix, ch = cg * 16 + c;
-      float v = 0.0f;
-      if (ch < Cb && gz >= 0 && gz < Zb && gy >= 0 && gy < Yb && gx >= 0 && gx < Xb)
-        v = big[((size_t)b * Cb + ch) * big_cs + ((size_t)gz * Yb + gy) * Xb + gx];
-      bigT[c * SC + iz * SZ + iy * SY + ix] = v;
+    const int bz0 = (KZ == 1 ? 0 : oz0 * S) - Cfg::PZ, by0 = oy0 * S - Cfg::P, bx0 = ox0 * S - Cfg::P;
+    constexpr int NBIG = 16 * IZ * IY * IX;
+    for (int e0 = 0; e0 < NBIG; e0 += UB * kThreads) {
+      float v[UB];
+      int lo[UB];
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        const int e = e0 + threadIdx.x + i * kThreads;
+        const int ec = min(e, NBIG - 1);
+        const int c = ec / (IZ * IY * IX), rem = ec - c * (IZ * IY * IX);
+        const int iz = rem / (IY * IX), rem2 = rem - iz * (IY * IX), iy = rem2 / IX, ix = rem2 - iy * IX;
+        const int gz = bz0 + iz, gy = by0 + iy, gx = bx0 + ix, ch = cg * 16 + c;
+        const bool ok = ch < Cb && gz >= 0 && gz < Zb && gy >= 0 && gy < Yb && gx >= 0 && gx < Xb;
+        const float l = big[((size_t)b * Cb + min(ch, Cb - 1)) * big_cs + ((size_t)min(max(gz, 0), Zb - 1) * Yb + min(max(gy, 0), Yb - 1)) * Xb + min(max(gx, 0), Xb - 1)];
+        v[i] = ok ? l : 0.0f;
+        lo[i] = e < NBIG ? c * SC + iz * SZ + iy * SY + ix : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < UB; ++i)
+        if (lo[i] >= 0) bigT[lo[i]] = v[i];
     }
     __syncthreads();
-    // this wave's four k-steps: row oy = wave of the tile, positions ox = 4 ks + kq
+    // this wave's rows (z, y) of the tile, four k-steps (positions ox = 4 ks + kq) each
+#pragma unroll 1
+    for (int rr = 0; rr < RPW; ++rr) {   // rolled: unrolled, the 16 x T operand loads of a wave were all hoisted (368 registers)
+      const int row = wave * RPW + rr, rz = row / TY, ry = row % TY;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int q = wave * 16 + ks * 4 + kq;
-      const float a = smallT[i16 * SS + q];
-      const float *bp = bigT + i16 * SC + (wave * S) * SY + (ks * 4 + kq) * S;
+      for (int ks = 0; ks < 4; ++ks) {
+        const float a = smallT[i16 * SS + row * 16 + ks * 4 + kq];
+        const float *bp = bigT + i16 * SC + (rz * S) * SZ + (ry * S) * SY + (ks * 4 + kq) * S;
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int tz = t / (KS * KS), ty_ = (t / KS) % KS, tx_ = t % KS;
-        acc[t] = mfma16(a, bp[tz * SZ + ty_ * SY + tx_], acc[t]);
+        for (int t = 0; t < T; ++t) {
+          const int tz_ = t / (KS * KS), ty_ = (t / KS) % KS, tx_ = t % KS;
+          acc[t] = mfma16(a, bp[tz_ * SZ + ty_ * SY + tx_], acc[t]);
+        }
       }
     }
   }
   // The four waves' accumulators are added through LDS in wave order (deterministic), then the workgroup writes ONE partial:
   // partial[blockIdx.x * gridDim.y + blockIdx.y][t][cs 16][cb 16]; D row = 4 kq + r, column = i16
   __syncthreads();
-  float *red = smem;   // T * 256 floats (<= the tile buffers: 16 * SC >= 27 * 16 * 16 only for the 3D kinds; see LDS_BYTES)
+  float *red = smem;   // T * 256 floats (LDS_BYTES covers it)
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
 #pragma unroll
@@ -181,14 +213,14 @@ __global__ __launch_bounds__(kThreads) void channel_sums_kernel(const float *__r
                                                                const float *__restrict__ rstd, double *__restrict__ out, int N,
                                                                int C, size_t n, float slope) {
   const int c = blockIdx.y, nblk = gridDim.x;
-  const size_t total = (size_t)N * n;
   float s0 = 0.0f, s1 = 0.0f;
   double d0 = 0.0, d1 = 0.0;
   const float mu = MODE == 1 ? mean[c] : 0.0f, rs = MODE == 1 ? rstd[c] : 0.0f;
   int cnt = 0;
-  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (size_t)nblk * kThreads) {
-    const size_t img = e / n, off = (img * C + c) * n + (e - img * n);
-    float a, bq;
+  // block `blockIdx.x` owns the slice [lo, hi) of every image's plane of channel c: contiguous, coalesced, no division per
+  // element; four elements per thread and step are loaded before they are used
+  const size_t per = (n + nblk - 1) / nblk, lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  auto term = [&](size_t off, float &a, float &bq) {
     if (MODE == 0) {
       a = x[off];
       bq = a * a;
@@ -197,10 +229,24 @@ __global__ __launch_bounds__(kThreads) void channel_sums_kernel(const float *__r
       a = g;
       bq = g * ((y2[off] - mu) * rs);
     }
-    s0 += a;
-    s1 += bq;
-    if (++cnt == 64) {   // fp32 runs of 64 values, then double
-      d0 += s0; d1 += s1; s0 = s1 = 0.0f; cnt = 0;
+  };
+  for (int img = 0; img < N; ++img) {
+    const size_t base = ((size_t)img * C + c) * n;
+    for (size_t e = lo + threadIdx.x; e < hi; e += 4 * kThreads) {
+      float a[4], bq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t ee = e + (size_t)i * kThreads;
+        a[i] = 0.0f; bq[i] = 0.0f;
+        term(base + (ee < hi ? ee : e), a[i], bq[i]);
+        if (ee >= hi) { a[i] = 0.0f; bq[i] = 0.0f; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s0 += a[i]; s1 += bq[i]; }
+      cnt += 4;
+      if (cnt >= 64) {   // fp32 runs of 64 values, then double
+        d0 += s0; d1 += s1; s0 = s1 = 0.0f; cnt = 0;
+      }
     }
   }
   d0 += s0; d1 += s1;
@@ -390,7 +436,7 @@ bool wgrad_geom(int kind, WgradGeom &g) {
 }
 
 struct WgradLaunch {
-  int Cs, Cb, Zs, Ys, Xs, row_tiles, cb_groups, tiles_y, tiles_x, gx, gy, T;
+  int Cs, Cb, Zs, Ys, Xs, row_tiles, cb_groups, tiles_z, tiles_y, tiles_x, gx, gy, T;
 };
 // D, H, W: the layer's INPUT dims (as in the forward call)
 bool wgrad_launch(int kind, int B, int cin, int cout, int D, int H, int W, WgradLaunch &l) {
@@ -407,10 +453,11 @@ bool wgrad_launch(int kind, int B, int cin, int cout, int D, int H, int W, Wgrad
   l.T = g.KZ * g.KS * g.KS;
   l.row_tiles = casmvs::ceil_div(l.Cs, 16);
   l.cb_groups = casmvs::ceil_div(l.Cb, 16);
+  l.tiles_z = casmvs::ceil_div(l.Zs, (g.KZ == 3 && g.S == 1) ? 4 : 1);   // WgradCfg::TZ
   l.tiles_y = casmvs::ceil_div(l.Ys, 4);
   l.tiles_x = casmvs::ceil_div(l.Xs, 16);
   l.gy = l.row_tiles * l.cb_groups;
-  const long tiles = (long)B * l.Zs * l.tiles_y * l.tiles_x;
+  const long tiles = (long)B * l.tiles_z * l.tiles_y * l.tiles_x;
   long gx = 512 / l.gy;
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
@@ -424,7 +471,7 @@ int launch_wgrad(const WgradLaunch &l, const float *small, const float *big, flo
   const size_t lds = WgradCfg<S, KZ, KS>::LDS_BYTES;
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "conv_wgrad_kernel")) return rc;
   hipLaunchKernelGGL(kernel, dim3((unsigned)l.gx, (unsigned)l.gy), dim3(kThreads), lds, st, small, big, partial, B, l.Cs, l.Cb, l.Zs,
-                     l.Ys, l.Xs, l.cb_groups, l.tiles_y, l.tiles_x);
+                     l.Ys, l.Xs, l.cb_groups, l.tiles_z, l.tiles_y, l.tiles_x);
   return casmvs::check_launch("conv_wgrad_kernel");
 }
 
