@@ -27,7 +27,7 @@ run_pmc pmc_write WRITE_SIZE
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o stats -- python $ROOTDIR/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-events --streams 1 --no-batch1 > $OUT/prof_bench.json 2> $OUT/prof.err)
 find $OUT/prof -name "*.db" -delete 2>/dev/null; find $OUT/prof -type f -size +4M -delete 2>/dev/null
 python tools/summarize_profile.py $OUT ${PREFIX:-r02} > $OUT/summarize.log 2>&1
-timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+timeout 900 python bench.py --steps 20 --warmup 5 --stock-pytorch > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit: $?" >> $OUT/bench.err
 for cfg in dtu_640x512_v3_gwc8 dtu_1152x864_v5_var blended_768x576_v7_var; do
   timeout 400 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_$cfg.json 2>> $OUT/bench.err
