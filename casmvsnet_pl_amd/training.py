@@ -72,6 +72,17 @@ def _pack_map(kind, cin, cout, has_bias, device):
     return m
 
 
+_ZERO_ONE = {}
+
+
+def _zero_one(device):
+    """The constants [0, 1] on `device` (created once: a host tensor per call would be a pageable upload per layer)."""
+    t = _ZERO_ONE.get(str(device))
+    if t is None:
+        t = _ZERO_ONE[str(device)] = torch.tensor([0.0, 1.0], dtype=torch.float32, device=device)
+    return t
+
+
 def device_pack(kind, weight, bias=None):
     """Packed layer image (the operand casmvs_conv{2,3}d_forward_f32 takes) of `weight` [+ `bias`] with scale 1, on the device."""
     if kind == CONV_T2:
@@ -82,7 +93,7 @@ def device_pack(kind, weight, bias=None):
     parts = [weight.detach().reshape(-1).float()]
     if bias is not None:
         parts.append(bias.detach().reshape(-1).float())
-    parts.append(torch.tensor([0.0, 1.0], dtype=torch.float32, device=weight.device))
+    parts.append(_zero_one(weight.device))
     return torch.cat(parts).index_select(0, idx)
 
 
