@@ -50,8 +50,47 @@ for it in range(steps + 2):
         rows.append((e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3), wall, float(loss)))
 rows.sort(key=lambda r: r[3])
 f, b, o, wall, loss = rows[len(rows) // 2]
-print(f"train step {H}x{W} B={B} V=3: forward {f:.1f} ms  backward {b:.1f} ms  optimizer {o:.1f} ms  wall {wall:.1f} ms  "
-      f"({B / wall * 1e3:.2f} samples/s)  loss {loss:.3f}  peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
+print(f"train step {H}x{W} B={B} V=3 (losses.py SL1Loss: boolean-mask indexing, a host sync per level): forward {f:.1f} ms  backward {b:.1f} ms  optimizer {o:.1f} ms  wall {wall:.1f} ms  "
+      f"({B / wall * 1e3:.2f} samples/s)  loss {loss:.3f}  peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB", flush=True)
+del res, loss   # the first phase's autograd graph (its AccumulateGrad nodes live on the default stream) must be gone before the capture
+opt.zero_grad(set_to_none=True)
+# the same step with a sync-free masked loss, kernel by kernel and captured ONCE into a hipGraph (forward + loss + backward +
+# SGD update: every op of the training path is capture-safe - no host read-back, no allocation outside torch's pool)
+maskf = {l: mask[l].float() for l in range(3)}
+
+
+def step():
+    opt.zero_grad(set_to_none=False)
+    res = model(imgs, proj, dmin, dint)
+    loss = sum((F.smooth_l1_loss(res[f"depth_{l}"], gt[l], reduction="none") * maskf[l]).sum() / maskf[l].sum() * 2 ** (1 - l) for l in range(3))
+    loss.backward()
+    opt.step()
+    return loss
+
+
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3):
+        step()
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+eager = (time.perf_counter() - t0) / 5 * 1e3
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    step()
+for _ in range(2):
+    graph.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    graph.replay()
+torch.cuda.synchronize()
+print(f"same step, sync-free masked loss: {eager:.1f} ms kernel by kernel, {(time.perf_counter() - t0) / 10 * 1e3:.1f} ms as one hipGraph replay", flush=True)
 model.eval()
 with torch.no_grad():
     for _ in range(2):
