@@ -165,9 +165,19 @@ __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float *__r
   const int cs = (y / cb_groups) * 16 + i, cb = (y % cb_groups) * 16 + j;
   if (cs >= Cs || cb >= Cb) return;
   const float *p = partial + (size_t)y * (T * 256) + (size_t)t * 256 + i * 16 + j;
-  float s = 0.0f;
-  for (int x = 0; x < gx; ++x) s += p[(size_t)x * gy * (T * 256)];
-  gw[((size_t)cs * Cb + cb) * T + t] = s;
+  const size_t stride = (size_t)gy * (T * 256);
+  // eight independent running sums (eight loads in flight: one thread walks up to 512 partials), combined in a fixed order
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int x = 0;
+  for (; x + 8 <= gx; x += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(x + k) * stride];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+  for (; x < gx; ++x) acc[x & 7] += p[(size_t)x * stride];
+  gw[((size_t)cs * Cb + cb) * T + t] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
 // ---- direct input gradient (layer shapes without an adjoint forward kernel) ------------------------------------------

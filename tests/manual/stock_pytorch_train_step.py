@@ -1,7 +1,7 @@
 """Manual measurement (not collected by pytest; ~4 min, most of it MIOpen's kernel search in the first step): the
 reference's training step - restated train-mode forward (oracle/cpu_restatement.py: cascade_forward_train), SL1-style
 loss, backward, SGD - executed on the MI355X by STOCK PyTorch-ROCm operators, at the reference's default training
-configuration (batch 1, 3 views, 640x512).  The comparison row of DESIGN 2.6: 2224 ms per step (6.5 GiB) against 42 ms
+configuration (batch 1, 3 views, 640x512).  The comparison row of DESIGN 2.6: 2224 ms per step (6.5 GiB) against 35 ms
 (2.3 GiB) through casmvsnet_pl_amd.training (tools/gpu_train_step.py).   python tests/manual/stock_pytorch_train_step.py"""
 import sys, time, torch
 import torch.nn.functional as F
