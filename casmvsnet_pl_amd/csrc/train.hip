@@ -363,13 +363,19 @@ __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float *_
 // reference gradient accumulates in registers over the chunk, the source gradients are scattered with fp32 atomics like
 // homo_warp's (lanes = consecutive pixels of a channel plane: the atomics of a wave fall on a few cache lines; a
 // pixel-major variant whose lanes each add C consecutive floats was 2.5x slower - the lanes' footprints overlap).
+// wave shift by one lane (gfx9 DPP wave_shr:1 / wave_shl:1): lane i reads lane i - 1 / i + 1; the first / last lane reads 0
+__device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float lane_prev(float v) { return __builtin_bit_cast(float, lane_prev(__builtin_bit_cast(int, v))); }
+
 template <int C>
 __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *__restrict__ feats, const float *__restrict__ proj,
                                                                   const float *__restrict__ depth, const float *__restrict__ gvol,
                                                                   float *__restrict__ gfeats, int V, int H, int W, int D, int dch) {
   const int b = blockIdx.z, d_begin = blockIdx.y * dch, d_end = min(d_begin + dch, D), hw = H * W;
-  const int p = blockIdx.x * kThreads + threadIdx.x;
-  if (p >= hw) return;
+  const int pr = blockIdx.x * kThreads + threadIdx.x, lane = threadIdx.x & 63;
+  const bool valid = pr < hw;        // no early exit: the lanes exchange tap gradients with their neighbours (DPP) below
+  const int p = valid ? pr : hw - 1;
   const int y = p / W, x = p - y * W;
   const float *fb = feats + (size_t)b * V * C * hw;
   float *gb = gfeats + (size_t)b * V * C * hw;
@@ -385,9 +391,8 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     float S[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) S[c] = ref[c];
-    for (int v = 1; v < V; ++v) {
+    for (int v = 1; v < V; ++v) {   // dead voxels: all four weights are 0 and the (clamped) addresses are valid
       const Taps t = plane_sweep_taps(proj + ((size_t)b * (V - 1) + (v - 1)) * 12, (float)x, (float)y, dv, W, H);
-      if (!taps_live(t)) continue;
       const float *fv = fb + (size_t)v * C * hw;
       const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
 #pragma unroll
@@ -397,36 +402,45 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
       }
     }
     const float *gv = gvol + ((size_t)b * C * D + d) * hw + p;
-    float g[C], common[C];
+    float g[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      g[c] = gv[(size_t)c * D * hw];
-      common[c] = 2.0f * S[c] / (fV * fV);
-      gref[c] += g[c] * (2.0f * ref[c] / fV - common[c]);
+      g[c] = valid ? gv[(size_t)c * D * hw] : 0.0f;
+      S[c] = 2.0f * S[c] / (fV * fV);                      // now the common term
+      gref[c] += g[c] * (2.0f * ref[c] / fV - S[c]);
     }
     for (int v = 1; v < V; ++v) {
       const Taps t = plane_sweep_taps(proj + ((size_t)b * (V - 1) + (v - 1)) * 12, (float)x, (float)y, dv, W, H);
-      if (!taps_live(t)) {   // the warped value is 0: its gradient has nowhere to go
-        continue;
-      }
       const float *fv = fb + (size_t)v * C * hw;
       float *gsv = gb + (size_t)v * C * hw;
       const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
+      // Neighbouring lanes are neighbouring pixels: lane i's RIGHT tap column is usually lane i + 1's LEFT one.  The right
+      // contribution travels one lane up (DPP) and is added to the neighbour's left one: ~2 atomics per channel and row
+      // pair instead of 4.  A lane keeps its right tap only when the next lane does not continue the run.
+      const int pxl = lane_prev(t.xl), pyn = lane_prev(t.yn), pys = lane_prev(t.ys);
+      const int nxl = lane_next(t.xl), nyn = lane_next(t.yn), nys = lane_next(t.ys);
+      const bool mp_n = lane > 0 && pyn == t.yn && pxl + 1 == t.xl, mp_s = lane > 0 && pys == t.ys && pxl + 1 == t.xl;
+      const bool ab_n = lane < 63 && nyn == t.yn && nxl == t.xl + 1, ab_s = lane < 63 && nys == t.ys && nxl == t.xl + 1;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float *fc = fv + (size_t)c * hw;
         const float xv = fmaf(fc[os + 1], t.w_sr, fmaf(fc[os], t.w_sl, fmaf(fc[on + 1], t.w_nr, fc[on] * t.w_nl)));
-        const float gx = g[c] * (2.0f * xv / fV - common[c]);
+        const float gx = g[c] * (2.0f * xv / fV - S[c]);
+        const float rn = gx * t.w_nr, rs = gx * t.w_sr;
+        const float prn = lane_prev(rn), prs = lane_prev(rs);
+        const float an = gx * t.w_nl + (mp_n ? prn : 0.0f), as = gx * t.w_sl + (mp_s ? prs : 0.0f);
         float *gc = gsv + (size_t)c * hw;
-        if (t.w_nl != 0.0f) unsafeAtomicAdd(gc + on, gx * t.w_nl);
-        if (t.w_nr != 0.0f) unsafeAtomicAdd(gc + on + 1, gx * t.w_nr);
-        if (t.w_sl != 0.0f) unsafeAtomicAdd(gc + os, gx * t.w_sl);
-        if (t.w_sr != 0.0f) unsafeAtomicAdd(gc + os + 1, gx * t.w_sr);
+        if (an != 0.0f) unsafeAtomicAdd(gc + on, an);
+        if (!ab_n && rn != 0.0f) unsafeAtomicAdd(gc + on + 1, rn);
+        if (as != 0.0f) unsafeAtomicAdd(gc + os, as);
+        if (!ab_s && rs != 0.0f) unsafeAtomicAdd(gc + os + 1, rs);
       }
     }
   }
+  if (valid) {
 #pragma unroll
-  for (int c = 0; c < C; ++c) unsafeAtomicAdd(gb + (size_t)c * hw + p, gref[c]);   // view 0: one add per plane chunk
+    for (int c = 0; c < C; ++c) unsafeAtomicAdd(gb + (size_t)c * hw + p, gref[c]);   // view 0: one add per plane chunk
+  }
 }
 
 struct WgradGeom {
