@@ -5,8 +5,11 @@ depth ranges (train.py's DataLoader collate), PFM depth / confidence files (data
 what the MI355X adds: the images travel as uint8 (4x fewer PCIe bytes) and are normalised by a HIP kernel, and a
 double-buffered prefetcher overlaps the host->device copies of batch i+1 with the forward of batch i on a second stream.
 
-Image decoding (PIL / cv2 in the reference) is not part of this module: it takes decoded uint8 arrays.
+`DTUReader` reads a DTU-format tree the way datasets/dtu.py does (pair file, camera files, PIL-decoded images, PFM depth
+maps and visibility masks with cv2's nearest-neighbour down-sampling restated in numpy) and yields samples with uint8
+images, ready for `collate` + `DevicePrefetcher`.
 """
+import os
 import ctypes
 import re
 
@@ -48,6 +51,120 @@ def relative_proj_mats(proj_ref, proj_srcs):
     """datasets/dtu.py:181-186: (P_src,l @ inverse(P_ref,l))[:3] per source view and level -> (V-1, levels, 3, 4)."""
     ref_inv = torch.inverse(proj_ref)
     return torch.stack([p @ ref_inv for p in proj_srcs])[:, :, :3]
+
+
+# ---- files of a DTU-format scene (datasets/dtu.py) ------------------------------------------------------------------
+
+def read_image_u8(filename, img_wh=None):
+    """dtu.py:168-170: PIL decode (RGB), optionally PIL's bilinear resize to (W, H) -> (H, W, 3) uint8.  The normalisation
+    (dtu.py:134-137) happens on the device (normalize_images_u8)."""
+    from PIL import Image
+    img = Image.open(filename).convert("RGB")
+    if img_wh is not None:
+        img = img.resize(tuple(img_wh), Image.BILINEAR)
+    return np.array(img, dtype=np.uint8)   # a writable copy (torch.from_numpy)
+
+
+def resize_nearest(a, out_hw=None, fx=None, fy=None):
+    """cv2.resize(..., interpolation=cv2.INTER_NEAREST) as dtu.py:94-129 uses it: source index = min(floor(dst * scale),
+    n - 1) with scale = 1 / fx (or n_src / n_dst) in double, per axis."""
+    a = np.asarray(a)
+    H, W = a.shape[:2]
+    if out_hw is None:
+        out_hw = (int(round(H * fy)), int(round(W * fx)))
+        sy, sx = 1.0 / fy, 1.0 / fx
+    else:
+        sy, sx = H / out_hw[0], W / out_hw[1]
+    iy = np.minimum(np.floor(np.arange(out_hw[0]) * sy).astype(np.int64), H - 1)
+    ix = np.minimum(np.floor(np.arange(out_hw[1]) * sx).astype(np.int64), W - 1)
+    return a[iy][:, ix]
+
+
+def _pyramid(level0):
+    l1 = resize_nearest(level0, fx=0.5, fy=0.5)
+    return level0, l1, resize_nearest(l1, fx=0.5, fy=0.5)
+
+
+class DTUReader:
+    """datasets/dtu.py as a plain reader: `len()` samples, `reader[i]` -> the dict DTUDataset.__getitem__ returns, with the
+    images as uint8 (`imgs_u8` (V,H,W,3)) instead of normalised floats.  `scans`: the list dtu.py reads from
+    datasets/lists/dtu/<split>.txt.  img_wh=None: training layout (640x512 crops, all 7 light conditions, ground-truth
+    depths and masks); img_wh=(W,H): test layout (full images resized, light condition 3, intrinsics rescaled)."""
+
+    def __init__(self, root_dir, scans, n_views=3, levels=3, depth_interval=2.65, img_wh=None, n_cameras=49):
+        if img_wh is not None and (img_wh[0] % 32 or img_wh[1] % 32):
+            raise ValueError("img_wh must both be multiples of 32!")          # dtu.py:21-23
+        self.root_dir, self.scans, self.n_views, self.levels = root_dir, list(scans), n_views, levels
+        self.depth_interval, self.img_wh = depth_interval, img_wh
+        self.metas = []                                                       # dtu.py:30-49
+        light_idxs = [3] if img_wh else range(7)
+        with open(os.path.join(root_dir, "Cameras/pair.txt")) as f:
+            lines = [l.rstrip() for l in f.readlines()]
+        n = int(lines[0])
+        pairs = [(int(lines[1 + 2 * i]), [int(x) for x in lines[2 + 2 * i].split()[1::2]]) for i in range(n)]
+        for scan in self.scans:
+            for ref_view, src_views in pairs:
+                for light_idx in light_idxs:
+                    self.metas.append((scan, light_idx, ref_view, src_views))
+        self.proj_mats = []                                                   # dtu.py:51-77
+        for vid in range(n_cameras):
+            name = f"Cameras/train/{vid:08d}_cam.txt" if img_wh is None else f"Cameras/{vid:08d}_cam.txt"
+            path = os.path.join(root_dir, name)
+            if not os.path.isfile(path):
+                self.proj_mats.append(None)
+                continue
+            K, E, depth_min = read_cam_file(path)
+            if img_wh is not None:                                            # to the coarsest level of the resized image
+                K[0] *= img_wh[0] / 1600 / 4
+                K[1] *= img_wh[1] / 1200 / 4
+            self.proj_mats.append((build_proj_mats(K, E, levels), depth_min))
+
+    def __len__(self):
+        return len(self.metas)
+
+    def read_depth(self, filename):
+        """dtu.py:93-111: (1200,1600) PFM -> level_0 (512,640) crop of the half-size map (or the resized map), level_1, level_2."""
+        depth = np.array(read_pfm(filename)[0], dtype=np.float32)
+        if self.img_wh is None:
+            d0 = resize_nearest(depth, fx=0.5, fy=0.5)[44:556, 80:720]
+        else:
+            d0 = resize_nearest(depth, out_hw=(self.img_wh[1], self.img_wh[0]))
+        return {f"level_{l}": torch.from_numpy(np.ascontiguousarray(d)) for l, d in enumerate(_pyramid(d0))}
+
+    def read_mask(self, filename):
+        """dtu.py:113-131: 8-bit visibility image -> boolean masks at the three levels."""
+        from PIL import Image
+        mask = np.asarray(Image.open(filename).convert("L"))
+        if self.img_wh is None:
+            m0 = resize_nearest(mask, fx=0.5, fy=0.5)[44:556, 80:720]
+        else:
+            m0 = resize_nearest(mask, out_hw=(self.img_wh[1], self.img_wh[0]))
+        return {f"level_{l}": torch.from_numpy(np.ascontiguousarray(m)).bool() for l, m in enumerate(_pyramid(m0))}
+
+    def __getitem__(self, idx):                                               # dtu.py:147-192
+        scan, light_idx, ref_view, src_views = self.metas[idx]
+        view_ids = [ref_view] + src_views[:self.n_views - 1]
+        sample, imgs, proj_mats = {}, [], []
+        for i, vid in enumerate(view_ids):
+            if self.img_wh is None:
+                img_filename = os.path.join(self.root_dir, f"Rectified/{scan}_train/rect_{vid + 1:03d}_{light_idx}_r5000.png")
+            else:
+                img_filename = os.path.join(self.root_dir, f"Rectified/{scan}/rect_{vid + 1:03d}_{light_idx}_r5000.png")
+            imgs.append(torch.from_numpy(read_image_u8(img_filename, self.img_wh)))
+            proj_mat_ls, depth_min = self.proj_mats[vid]
+            if i == 0:
+                sample["init_depth_min"] = torch.tensor([depth_min], dtype=torch.float32)
+                if self.img_wh is None:
+                    sample["masks"] = self.read_mask(os.path.join(self.root_dir, f"Depths/{scan}/depth_visual_{vid:04d}.png"))
+                    sample["depths"] = self.read_depth(os.path.join(self.root_dir, f"Depths/{scan}/depth_map_{vid:04d}.pfm"))
+                ref_proj = proj_mat_ls
+            else:
+                proj_mats.append(proj_mat_ls)
+        sample["imgs_u8"] = torch.stack(imgs)                                  # (V, H, W, 3) uint8
+        sample["proj_mats"] = relative_proj_mats(ref_proj, proj_mats)          # (V-1, levels, 3, 4) fine -> coarse
+        sample["depth_interval"] = torch.tensor([self.depth_interval], dtype=torch.float32)
+        sample["scan_vid"] = (scan, ref_view)
+        return sample
 
 
 # ---- PFM -----------------------------------------------------------------------------------------------------------------

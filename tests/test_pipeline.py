@@ -84,3 +84,115 @@ def test_prefetcher_feeds_the_engine_in_order():
         assert torch.equal(out["depth_0"], direct[i])
         n += 1
     assert n == 5
+
+
+def _write_dtu_tree(root, test_layout, g):
+    """A two-camera-pair DTU-format tree with random images / depths (file names and text formats of the real dataset)."""
+    from PIL import Image
+    os = __import__("os")
+    cam_dir = root / ("Cameras" if test_layout else "Cameras/train")
+    cam_dir.mkdir(parents=True, exist_ok=True)
+    (root / "Cameras").mkdir(exist_ok=True)
+    (root / "Cameras" / "pair.txt").write_text("3\n0\n2 1 0.9 2 0.8\n1\n2 0 0.9 2 0.7\n2\n2 1 0.6 0 0.5\n")
+    for vid in range(3):
+        K = np.array([[2892.33 if test_layout else 361.54, 0, 823.2 if test_layout else 82.9], [0, 2883.18 if test_layout else 360.4, 619.07 if test_layout else 66.4], [0, 0, 1]])
+        E = np.eye(4)
+        E[:3, 3] = [10.0 * vid, -5.0 * vid, 2.0]
+        lines = ["extrinsic"] + [" ".join(f"{v:.6f}" for v in row) for row in E] + ["", "intrinsic"] + \
+                [" ".join(f"{v:.6f}" for v in row) for row in K] + ["", f"{425.0 + vid} 2.5"]
+        (cam_dir / f"{vid:08d}_cam.txt").write_text("\n".join(lines) + "\n")
+    scan = "scan9"
+    img_dir = root / "Rectified" / (scan if test_layout else scan + "_train")
+    img_dir.mkdir(parents=True)
+    hw = (1200, 1600) if test_layout else (512, 640)
+    imgs = {}
+    for vid in range(3):
+        for light in ([3] if test_layout else range(7)):
+            a = g.integers(0, 256, hw + (3,), dtype=np.uint8)
+            Image.fromarray(a).save(img_dir / f"rect_{vid + 1:03d}_{light}_r5000.png")
+            imgs[(vid, light)] = a
+    depths = {}
+    if not test_layout:
+        (root / "Depths" / scan).mkdir(parents=True)
+        for vid in range(3):
+            d = (500.0 + 100.0 * g.random((1200, 1600))).astype(np.float32)
+            P.save_pfm(str(root / "Depths" / scan / f"depth_map_{vid:04d}.pfm"), d)
+            m = (g.random((1200, 1600)) > 0.3).astype(np.uint8) * 255
+            Image.fromarray(m).save(root / "Depths" / scan / f"depth_visual_{vid:04d}.png")
+            depths[vid] = (d, m)
+    return scan, imgs, depths
+
+
+def test_dtu_reader_training_layout(tmp_path):
+    g = np.random.default_rng(0)
+    scan, imgs, depths = _write_dtu_tree(tmp_path, False, g)
+    r = P.DTUReader(str(tmp_path), [scan], n_views=3, n_cameras=3)
+    assert len(r) == 3 * 7                                     # 3 reference views x 7 light conditions (dtu.py:37-49)
+    s = r[8]                                                   # reference view 1, light 1
+    assert s["scan_vid"] == (scan, 1) and s["imgs_u8"].shape == (3, 512, 640, 3) and s["imgs_u8"].dtype == torch.uint8
+    assert np.array_equal(s["imgs_u8"][0].numpy(), imgs[(1, 1)]) and np.array_equal(s["imgs_u8"][1].numpy(), imgs[(0, 1)])
+    assert float(s["init_depth_min"]) == 426.0 and abs(float(s["depth_interval"]) - 2.65) < 1e-6
+    assert s["proj_mats"].shape == (2, 3, 3, 4)
+    want = P.relative_proj_mats(r.proj_mats[1][0], [r.proj_mats[0][0], r.proj_mats[2][0]])
+    assert torch.equal(s["proj_mats"], want)
+    # ground truth: half-size nearest-neighbour map, (44:556, 80:720) crop, then two more halvings (dtu.py:93-131)
+    d, m = depths[1]
+    d0 = d[::2, ::2][44:556, 80:720]
+    assert np.array_equal(s["depths"]["level_0"].numpy(), d0) and np.array_equal(s["depths"]["level_2"].numpy(), d0[::4, ::4])
+    assert np.array_equal(s["masks"]["level_1"].numpy(), (m[::2, ::2][44:556, 80:720] > 0)[::2, ::2])
+    b = P.collate([r[0], r[8]])
+    assert b["imgs_u8"].shape == (2, 3, 512, 640, 3) and b["init_depth_min"].shape == (2, 1)
+
+
+def test_dtu_reader_test_layout_resizes_images_and_intrinsics(tmp_path):
+    from PIL import Image
+    g = np.random.default_rng(1)
+    scan, imgs, _ = _write_dtu_tree(tmp_path, True, g)
+    r = P.DTUReader(str(tmp_path), [scan], n_views=2, img_wh=(160, 128), n_cameras=3)
+    assert len(r) == 3                                         # light condition 3 only
+    s = r[0]
+    assert s["imgs_u8"].shape == (2, 128, 160, 3) and "depths" not in s
+    want = np.asarray(Image.fromarray(imgs[(0, 3)]).resize((160, 128), Image.BILINEAR))
+    assert np.array_equal(s["imgs_u8"][0].numpy(), want)
+    # intrinsics scaled to the coarsest level of the resized image: fx * W / 1600 / 4 (dtu.py:61-63)
+    K, E, _ = P.read_cam_file(str(tmp_path / "Cameras" / "00000000_cam.txt"))
+    K[0] *= 160 / 1600 / 4
+    K[1] *= 128 / 1200 / 4
+    assert torch.allclose(r.proj_mats[0][0][2, :3], torch.tensor(K @ E[:3]), rtol=1e-5)
+    with pytest.raises(ValueError):
+        P.DTUReader(str(tmp_path), [scan], img_wh=(100, 128))
+
+
+def test_resize_nearest_matches_cv2_index_rule():
+    a = np.arange(7 * 10).reshape(7, 10)
+    assert np.array_equal(P.resize_nearest(a, fx=0.5, fy=0.5), a[[0, 2, 4, 6]][:, [0, 2, 4, 6, 8]])      # round(3.5) = 4 rows
+    assert np.array_equal(P.resize_nearest(a, out_hw=(3, 4)), a[[0, 2, 4]][:, [0, 2, 5, 7]])
+
+
+@pytest.mark.gpu
+def test_files_to_depth_maps_through_reader_prefetcher_and_engine(tmp_path):
+    """eval.py:213-222 end to end on files: DTU-format tree -> DTUReader (PIL decode, camera files) -> collate -> DevicePrefetcher
+    (uint8 upload, device normalisation, side stream) -> CascadeMVSNet.forward; equals the forward on hand-normalised inputs."""
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet
+    from casmvsnet_pl_amd.synthetic import randomize_state_dict
+    dev = torch.device("cuda:0")
+    g = np.random.default_rng(2)
+    scan, _, _ = _write_dtu_tree(tmp_path, True, g)
+    r = P.DTUReader(str(tmp_path), [scan], n_views=3, img_wh=(160, 128), n_cameras=3)
+    model = CascadeMVSNet(norm_act=ABN)
+    randomize_state_dict(model.state_dict(), seed=1)
+    model = model.to(dev).eval()
+    samples = [r[i] for i in range(len(r))]
+    batches = [P.collate([s]) for s in samples]
+    n = 0
+    for i, b in enumerate(P.DevicePrefetcher(batches, dev, depth=2)):
+        out = model(b["imgs"], b["proj_mats"], b["init_depth_min"], b["depth_interval"])
+        u8 = samples[i]["imgs_u8"].unsqueeze(0)
+        mean, std = torch.tensor(P.IMAGENET_MEAN).view(1, 1, 3, 1, 1), torch.tensor(P.IMAGENET_STD).view(1, 1, 3, 1, 1)
+        imgs = u8.permute(0, 1, 4, 2, 3).float().div(255).sub(mean).div(std).to(dev)
+        want = model(imgs, samples[i]["proj_mats"].unsqueeze(0).to(dev), samples[i]["init_depth_min"].view(1, 1).to(dev),
+                     samples[i]["depth_interval"].view(1, 1).to(dev))
+        assert b["scan_vid"] == [(scan, i)] and out["depth_0"].shape == (1, 128, 160)
+        assert torch.equal(out["depth_0"], want["depth_0"]) and torch.isfinite(out["depth_0"]).all()
+        n += 1
+    assert n == 3
