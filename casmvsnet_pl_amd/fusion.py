@@ -86,3 +86,59 @@ def check_geo_consistency(depth_ref, P_world2ref, depth_src, P_world2src, image_
     r = fuse_reference_view(depth_ref, image_ref, None, P_world2ref, [depth_src], [image_src], [P_world2src],
                             min_geo_consistent=0, return_points=False, return_per_view=True, device=device)
     return r["depth_ref_reproj"][0], r["mask_geo"][0], r["image_src2ref"][0]
+
+
+def fuse_scan(views, metas, conf=0.999, min_geo_consistent=5, skip=1, device="cuda"):
+    """The scan loop of eval.py:255-326 in memory: `views` maps a view id to a dict with `depth` (H,W) float32, `image`
+    (H,W,3) uint8, `proba` (H/4,W/4) float32 (= confidence_2, eval.py:226) and `P` (4,4) world -> pixel projection;
+    `metas` is the list of (ref_vid, src_vids) in processing order.  As in the reference, a view that was already refined
+    as a reference view is used with its refined depth and 8-bit refined image when it later serves as a source (or
+    reference) view; views without a prediction are skipped (the reference's FileNotFoundError branch).
+    -> points (N,3) float32, colors (N,3) uint8 (device tensors), and the dict of refined depth maps."""
+    depth_refined, image_refined = {}, {}
+    pts, cols = [], []
+
+    def current(vid):
+        if vid in image_refined:                                  # eval.py:263-265 / :284-286
+            return depth_refined[vid], image_refined[vid]
+        return views[vid]["depth"], views[vid]["image"]
+
+    for ref_vid, src_vids in metas:
+        if ref_vid not in views or any(s not in views for s in src_vids):
+            continue                                              # eval.py:323-326
+        depth_ref, image_ref = current(ref_vid)
+        srcs = [current(s) for s in src_vids]
+        for s, (d, _) in zip(src_vids, srcs):
+            depth_refined.setdefault(s, d)                        # eval.py:293
+        r = fuse_reference_view(depth_ref, image_ref, views[ref_vid]["proba"], views[ref_vid]["P"], [d for d, _ in srcs],
+                                [i for _, i in srcs], [views[s]["P"] for s in src_vids], conf=conf,
+                                min_geo_consistent=min_geo_consistent, return_points=True, device=device)
+        depth_refined[ref_vid] = r["depth_refined"]               # eval.py:304-305
+        # save_refined_image / read_refined_image (cv2.imwrite of the float64 means, cv2.imread): an 8-bit round trip,
+        # saturate_cast<uchar> = round half to even
+        image_refined[ref_vid] = torch.clamp(torch.round(r["image_refined"]), 0, 255).to(torch.uint8)
+        m = r["mask_final"]
+        pts.append(r["xyz_world"][m][::skip])                     # eval.py:313-320 (row-major pixel order)
+        cols.append(r["image_refined"][m][::skip].to(torch.uint8))    # eval.py:338: astype(uint8) of the float64 means
+    dev = torch.device(device)
+    points = torch.cat(pts) if pts else torch.empty((0, 3), dtype=torch.float32, device=dev)
+    colors = torch.cat(cols) if cols else torch.empty((0, 3), dtype=torch.uint8, device=dev)
+    return points, colors, depth_refined
+
+
+def write_ply(filename, points, colors):
+    """eval.py:336-350 without plyfile: binary little-endian PLY with vertex properties x y z (float) red green blue (uchar)."""
+    points = np.ascontiguousarray(points.detach().cpu().numpy() if isinstance(points, torch.Tensor) else points, dtype="<f4")
+    colors = np.ascontiguousarray(colors.detach().cpu().numpy() if isinstance(colors, torch.Tensor) else colors, dtype=np.uint8)
+    if points.ndim != 2 or points.shape[1] != 3 or colors.shape != points.shape:
+        raise ValueError("write_ply: points and colors must both be (N, 3)")
+    vertex = np.empty(len(points), dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    for i, k in enumerate(("x", "y", "z")):
+        vertex[k] = points[:, i]
+    for i, k in enumerate(("red", "green", "blue")):
+        vertex[k] = colors[:, i]
+    header = ("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+              "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % len(points))
+    with open(filename, "wb") as f:
+        f.write(header.encode("ascii"))
+        vertex.tofile(f)

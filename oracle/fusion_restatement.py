@@ -173,3 +173,34 @@ def fuse_reference_view(depth_ref, image_ref, proba_ref_quarter, P_world2ref, de
     xyz_world = np.stack([((Minv[i, 0] * X + Minv[i, 1] * Y) + Minv[i, 2] * Z) + Minv[i, 3] for i in range(3)], -1)
     return dict(depth_refined=depth_refined, image_refined=image_refined, mask_geo_sum=mask_geo_sum,
                 mask_final=mask_final, xyz_world=xyz_world.astype(f32))
+
+
+def fuse_scan(views, metas, conf=0.999, min_geo_consistent=5, skip=1):
+    """eval.py:255-326 (the scan loop) in memory, numpy: refined depth / 8-bit refined image of an already processed view
+    replace its prediction when it is used again (eval.py:263-265, :284-293; the refined image goes through cv2.imwrite /
+    cv2.imread = an 8-bit round trip with round-half-even), masked world points and truncated colours are collected
+    (:313-321, :338).  views: vid -> dict(depth, image, proba, P)."""
+    depth_refined, image_refined, vs, v_colors = {}, {}, [], []
+
+    def current(vid):
+        if vid in image_refined:
+            return depth_refined[vid], image_refined[vid]
+        return views[vid]["depth"], views[vid]["image"]
+
+    for ref_vid, src_vids in metas:
+        if ref_vid not in views or any(s not in views for s in src_vids):
+            continue
+        depth_ref, image_ref = current(ref_vid)
+        srcs = [current(s) for s in src_vids]
+        for s, (d, _) in zip(src_vids, srcs):
+            depth_refined.setdefault(s, d)
+        r = fuse_reference_view(depth_ref, image_ref, views[ref_vid]["proba"], views[ref_vid]["P"], [d for d, _ in srcs],
+                                [i for _, i in srcs], [views[s]["P"] for s in src_vids], conf=conf, min_geo_consistent=min_geo_consistent)
+        depth_refined[ref_vid] = r["depth_refined"]
+        image_refined[ref_vid] = np.clip(np.rint(r["image_refined"]), 0, 255).astype(np.uint8)
+        m = r["mask_final"]
+        vs.append(r["xyz_world"][m][::skip])
+        v_colors.append(r["image_refined"][m][::skip])
+    if not vs:
+        return np.zeros((0, 3), f32), np.zeros((0, 3), np.uint8), depth_refined
+    return np.vstack(vs).astype(f32), np.vstack(v_colors).astype(np.uint8), depth_refined

@@ -108,3 +108,32 @@ def test_fusion_kernel_matches_oracle(H, W, S, seed, report):
         assert np.array_equal(g["mask_geo"][s], m) and np.array_equal(g["depth_ref_reproj"][s], d) and np.array_equal(g["image_src2ref"][s], im)
     d1, m1, i1 = fusion.check_geo_consistency(depths[0], Ps[0], depths[1], Ps[1], images[0], images[1], (W, H))
     assert np.array_equal(m1.cpu().numpy(), g["mask_geo"][0]) and np.array_equal(d1.cpu().numpy(), g["depth_ref_reproj"][0])
+
+
+@pytest.mark.gpu
+def test_scan_loop_matches_oracle_and_writes_ply(tmp_path, report):
+    """eval.py:255-350: every view in turn as the reference view, later views re-using the refined depth / 8-bit refined
+    image of earlier ones; masked world points + truncated colours; PLY file.  Bit-exact against the numpy restatement."""
+    from casmvsnet_pl_amd import fusion
+    H, W, S = 48, 64, 4
+    Ps, depths, images, proba = _scene(H, W, S, seed=7)
+    g = np.random.default_rng(3)
+    views = {v: dict(depth=depths[v], image=images[v], proba=g.random((H // 4, W // 4)).astype(np.float32), P=Ps[v]) for v in range(S + 1)}
+    metas = [(r, [s for s in range(S + 1) if s != r][:3]) for r in range(S + 1)] + [(9, [0, 1, 2])]   # view 9 has no prediction: skipped
+    want_p, want_c, want_d = F.fuse_scan(views, metas, conf=0.3, min_geo_consistent=2, skip=2)
+    got_p, got_c, got_d = fusion.fuse_scan(views, metas, conf=0.3, min_geo_consistent=2, skip=2)
+    torch.cuda.synchronize()
+    report("fusion_scan", points=int(len(want_p)), views=S + 1)
+    assert len(want_p) > 200 and got_p.shape == want_p.shape and got_c.shape == want_c.shape
+    assert np.array_equal(got_c.cpu().numpy(), want_c)
+    assert float(np.abs(got_p.cpu().numpy() - want_p).max() / np.abs(want_p).max()) < 1e-6
+    for v in want_d:
+        d = got_d[v].cpu().numpy() if isinstance(got_d[v], torch.Tensor) else got_d[v]
+        assert np.array_equal(d, want_d[v]), v
+    f = tmp_path / "scan.ply"
+    fusion.write_ply(str(f), got_p, got_c)
+    raw = f.read_bytes()
+    head, body = raw.split(b"end_header\n", 1)
+    assert head.startswith(b"ply\nformat binary_little_endian 1.0\n") and (b"element vertex %d\n" % len(want_p)) in head
+    rec = np.frombuffer(body, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    assert len(rec) == len(want_p) and np.array_equal(rec["red"], want_c[:, 0]) and np.array_equal(rec["z"], got_p.cpu().numpy()[:, 2])
