@@ -196,3 +196,23 @@ def test_files_to_depth_maps_through_reader_prefetcher_and_engine(tmp_path):
         assert torch.equal(out["depth_0"], want["depth_0"]) and torch.isfinite(out["depth_0"]).all()
         n += 1
     assert n == 3
+
+
+@pytest.mark.gpu
+def test_files_to_point_cloud(tmp_path):
+    """eval.py end to end on a (tiny, synthetic) DTU-format tree: images + cameras -> depth maps -> fused point cloud -> PLY."""
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet
+    from casmvsnet_pl_amd.reconstruct import reconstruct_scan
+    from casmvsnet_pl_amd.synthetic import randomize_state_dict
+    g = np.random.default_rng(4)
+    scan, _, _ = _write_dtu_tree(tmp_path, True, g)
+    reader = P.DTUReader(str(tmp_path), [scan], n_views=3, img_wh=(160, 128), n_cameras=3)
+    model = CascadeMVSNet(norm_act=ABN)
+    randomize_state_dict(model.state_dict(), seed=2)
+    model = model.to("cuda").eval()
+    ply = tmp_path / "scan9.ply"
+    # random weights give no geometrically consistent depth: accept every pixel so that the path to the file is exercised
+    pts, cols = reconstruct_scan(model, reader, scan, out_ply=str(ply), conf=-1.0, min_geo_consistent=0, skip=4)
+    assert pts.shape[1] == 3 and pts.shape == cols.shape and len(pts) == 3 * (128 * 160 // 4) and torch.isfinite(pts).all()
+    head = ply.read_bytes().split(b"end_header\n")[0]
+    assert (b"element vertex %d\n" % len(pts)) in head
