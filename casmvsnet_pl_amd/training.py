@@ -435,3 +435,32 @@ def cascade_forward_train(model, imgs, proj_mats, init_depth_min, depth_interval
         results[f"depth_{l}"] = depth_l
         results[f"confidence_{l}"] = confidence_l
     return results
+
+
+def sl1_loss(results, depths, masks, levels=3):
+    """losses.py:4-19 (SL1Loss): sum over the levels of SmoothL1(depth_l[mask_l], gt_l[mask_l]) * 2^(1 - l).  torch ops on
+    (B,h,w) maps - the boolean indexing is a host sync per level, as in the reference."""
+    loss = 0
+    for l in range(levels):
+        m = masks[f"level_{l}"]
+        loss = loss + torch.nn.functional.smooth_l1_loss(results[f"depth_{l}"][m], depths[f"level_{l}"][m], reduction="mean") * 2 ** (1 - l)
+    return loss
+
+
+def train_steps(model, batches, optimizer, device="cuda"):
+    """train.py:99-103 + Lightning's optimisation step, without Lightning: for every batch (dicts from pipeline.collate
+    over pipeline.DTUReader samples in training layout: imgs_u8 / imgs, proj_mats, depths, masks, init_depth_min,
+    depth_interval) forward in train mode, SL1 loss, backward, optimizer step.  -> list of loss values."""
+    from .pipeline import DevicePrefetcher
+    model.train()
+    losses = []
+    for b in DevicePrefetcher(batches, device, depth=2):
+        depths = {k: torch.stack([d[k] for d in b["depths"]]).to(device) for k in b["depths"][0]}
+        masks = {k: torch.stack([m[k] for m in b["masks"]]).to(device) for k in b["masks"][0]}
+        optimizer.zero_grad(set_to_none=True)
+        results = model(b["imgs"], b["proj_mats"], b["init_depth_min"], b["depth_interval"])
+        loss = sl1_loss(results, depths, masks)
+        loss.backward()
+        optimizer.step()
+        losses.append(float(loss.detach()))
+    return losses

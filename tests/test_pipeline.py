@@ -86,7 +86,7 @@ def test_prefetcher_feeds_the_engine_in_order():
     assert n == 5
 
 
-def _write_dtu_tree(root, test_layout, g):
+def _write_dtu_tree(root, test_layout, g, lights=None):
     """A two-camera-pair DTU-format tree with random images / depths (file names and text formats of the real dataset)."""
     from PIL import Image
     os = __import__("os")
@@ -107,7 +107,7 @@ def _write_dtu_tree(root, test_layout, g):
     hw = (1200, 1600) if test_layout else (512, 640)
     imgs = {}
     for vid in range(3):
-        for light in ([3] if test_layout else range(7)):
+        for light in (lights if lights is not None else ([3] if test_layout else range(7))):
             a = g.integers(0, 256, hw + (3,), dtype=np.uint8)
             Image.fromarray(a).save(img_dir / f"rect_{vid + 1:03d}_{light}_r5000.png")
             imgs[(vid, light)] = a
@@ -216,3 +216,26 @@ def test_files_to_point_cloud(tmp_path):
     assert pts.shape[1] == 3 and pts.shape == cols.shape and len(pts) == 3 * (128 * 160 // 4) and torch.isfinite(pts).all()
     head = ply.read_bytes().split(b"end_header\n")[0]
     assert (b"element vertex %d\n" % len(pts)) in head
+
+
+@pytest.mark.gpu
+def test_training_loop_on_files(tmp_path):
+    """train.py's loop on a DTU-format tree (training layout): DTUReader -> collate -> prefetcher -> train-mode forward ->
+    SL1 loss on the ground-truth depth / mask pyramids -> backward -> SGD; the loss falls."""
+    from casmvsnet_pl_amd import CascadeMVSNet, InPlaceABN
+    from casmvsnet_pl_amd import training as T
+    from casmvsnet_pl_amd.synthetic import randomize_state_dict
+    g = np.random.default_rng(5)
+    scan, _, _ = _write_dtu_tree(tmp_path, False, g, lights=[0])
+    reader = P.DTUReader(str(tmp_path), [scan], n_views=3, n_cameras=3)
+    idx = [i for i, m in enumerate(reader.metas) if m[1] == 0]          # the light condition that was written
+    assert len(idx) == 3
+    model = CascadeMVSNet(norm_act=InPlaceABN)
+    randomize_state_dict(model.state_dict(), seed=3)
+    model = model.to("cuda")
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+    sample = reader[idx[0]]
+    assert sample["depths"]["level_0"].shape == (512, 640) and sample["masks"]["level_2"].shape == (128, 160)
+    batches = [P.collate([sample])] * 4                                 # the same batch four times
+    losses = T.train_steps(model, batches, opt)
+    assert len(losses) == 4 and all(np.isfinite(losses)) and losses[-1] < losses[0], losses
