@@ -167,6 +167,77 @@ class DTUReader:
         return sample
 
 
+class BlendedMVSReader:
+    """datasets/blendedmvs.py as a plain reader: per scan `cams/pair.txt` (reference views with fewer than `n_views` valid
+    views are skipped, :46-57), per-scan depth scale 100 / depth_min of the scan's first camera applied to the depth range,
+    the extrinsic translations and the rendered depth maps (:98-104,108), intrinsics rescaled to the coarsest level of
+    `img_wh` (:73-74), and the PER-SAMPLE depth interval (depth_max - depth_min) / n_depths of BASELINE config 5 (:171).
+    Samples carry uint8 images (`imgs_u8`) like DTUReader.  `n_coarse_intervals` is the reference's `depth_interval`
+    constructor argument (192: it is a COUNT there)."""
+
+    def __init__(self, root_dir, scans, n_views=3, levels=3, n_coarse_intervals=192.0, img_wh=(768, 576)):
+        if img_wh[0] % 32 or img_wh[1] % 32:
+            raise ValueError("img_wh must both be multiples of 32!")
+        self.root_dir, self.scans, self.n_views, self.levels = root_dir, list(scans), n_views, levels
+        self.n_depths, self.img_wh = n_coarse_intervals, img_wh
+        self.metas, ref_views = [], {}
+        for scan in self.scans:                                                # blendedmvs.py:32-57
+            with open(os.path.join(root_dir, scan, "cams/pair.txt")) as f:
+                lines = [l.rstrip() for l in f.readlines()]
+            ref_views[scan] = []
+            for i in range(int(lines[0])):
+                ref_view, line = int(lines[1 + 2 * i]), lines[2 + 2 * i].split()
+                ref_views[scan].append(ref_view)
+                if int(line[0]) < n_views:
+                    continue
+                self.metas.append((scan, -1, ref_view, [int(x) for x in line[1::2]]))
+        low = root_dir.rstrip("/").endswith("dataset_low_res")                 # :62-66
+        img_w, img_h = (768, 576) if low else (2048, 1536)
+        self.proj_mats, self.scale_factors = {}, {}
+        for scan in self.scans:                                                # :67-85
+            self.proj_mats[scan] = {}
+            for vid in ref_views[scan]:
+                K, E, depth_min = read_cam_file(os.path.join(root_dir, scan, f"cams/{vid:08d}_cam.txt"))
+                if scan not in self.scale_factors:
+                    self.scale_factors[scan] = 100 / depth_min                 # the scan's first camera fixes the scale
+                depth_min *= self.scale_factors[scan]
+                E[:3, 3] *= self.scale_factors[scan]
+                K[0] *= img_wh[0] / img_w / 4
+                K[1] *= img_wh[1] / img_h / 4
+                self.proj_mats[scan][vid] = (build_proj_mats(K, E, levels), depth_min)
+
+    def __len__(self):
+        return len(self.metas)
+
+    def read_depth_and_mask(self, scan, filename, depth_min):                  # :106-128
+        depth = np.array(read_pfm(filename)[0], dtype=np.float32)
+        depth *= self.scale_factors[scan]                                      # in place on the float32 array, like the reference
+        levels_ = _pyramid(resize_nearest(depth, out_hw=(self.img_wh[1], self.img_wh[0])))
+        depths = {f"level_{l}": torch.from_numpy(np.ascontiguousarray(d)) for l, d in enumerate(levels_)}
+        masks = {f"level_{l}": torch.from_numpy(np.ascontiguousarray(d > depth_min)) for l, d in enumerate(levels_)}
+        return depths, masks, float(levels_[0].max())
+
+    def __getitem__(self, idx):                                                # :149-187
+        scan, _, ref_view, src_views = self.metas[idx]
+        sample, imgs, proj_mats = {}, [], []
+        for i, vid in enumerate([ref_view] + src_views[:self.n_views - 1]):
+            imgs.append(torch.from_numpy(read_image_u8(os.path.join(self.root_dir, f"{scan}/blended_images/{vid:08d}.jpg"), self.img_wh)))
+            proj_mat_ls, depth_min = self.proj_mats[scan][vid]
+            if i == 0:
+                depths, masks, depth_max = self.read_depth_and_mask(
+                    scan, os.path.join(self.root_dir, f"{scan}/rendered_depth_maps/{vid:08d}.pfm"), depth_min)
+                sample["init_depth_min"] = torch.tensor([depth_min], dtype=torch.float32)
+                sample["depth_interval"] = torch.tensor([(depth_max - depth_min) / self.n_depths], dtype=torch.float32)
+                ref_proj = proj_mat_ls
+            else:
+                proj_mats.append(proj_mat_ls)
+        sample["imgs_u8"] = torch.stack(imgs)
+        sample["proj_mats"] = relative_proj_mats(ref_proj, proj_mats)
+        sample["depths"], sample["masks"] = depths, masks
+        sample["scan_vid"] = (scan, ref_view)
+        return sample
+
+
 # ---- PFM -----------------------------------------------------------------------------------------------------------------
 
 def read_pfm(filename):

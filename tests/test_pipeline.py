@@ -239,3 +239,45 @@ def test_training_loop_on_files(tmp_path):
     batches = [P.collate([sample])] * 4                                 # the same batch four times
     losses = T.train_steps(model, batches, opt)
     assert len(losses) == 4 and all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_blendedmvs_reader_scales_the_scene_and_derives_the_interval(tmp_path):
+    """blendedmvs.py: per-scan scale 100 / depth_min(first camera) on depth range, translations and depth maps; reference
+    views with too few valid views skipped; depth_interval = (depth_max - depth_min) / 192 per sample (BASELINE config 5)."""
+    from PIL import Image
+    g = np.random.default_rng(6)
+    root = tmp_path / "dataset_low_res"
+    scan = "5a3ca9cb270f0e3f14d0eddb"
+    (root / scan / "cams").mkdir(parents=True)
+    (root / scan / "blended_images").mkdir()
+    (root / scan / "rendered_depth_maps").mkdir()
+    (root / scan / "cams" / "pair.txt").write_text("4\n0\n3 1 0.9 2 0.8 3 0.7\n1\n3 0 0.9 2 0.7 3 0.6\n2\n1 0 0.5\n3\n3 0 0.9 1 0.8 2 0.7\n")   # view 2: one valid view only
+    dmins = [4.0, 5.0, 6.0, 7.0]
+    depth0 = None
+    for vid in range(4):
+        K = np.array([[570.0, 0, 384.0], [0, 570.0, 288.0], [0, 0, 1]])
+        E = np.eye(4)
+        E[:3, 3] = [0.1 * vid, 0.2, 0.3]
+        lines = ["extrinsic"] + [" ".join(f"{v:.6f}" for v in row) for row in E] + ["", "intrinsic"] + \
+                [" ".join(f"{v:.6f}" for v in row) for row in K] + ["", f"{dmins[vid]} 0.05 128 10.4"]
+        (root / scan / "cams" / f"{vid:08d}_cam.txt").write_text("\n".join(lines) + "\n")
+        Image.fromarray(g.integers(0, 256, (576, 768, 3), dtype=np.uint8)).save(root / scan / "blended_images" / f"{vid:08d}.jpg")
+        d = (3.0 + 6.0 * g.random((576, 768))).astype(np.float32)
+        P.save_pfm(str(root / scan / "rendered_depth_maps" / f"{vid:08d}.pfm"), d)
+        if vid == 0:
+            depth0 = d
+    r = P.BlendedMVSReader(str(root), [scan], n_views=3, img_wh=(384, 288))
+    assert len(r) == 3 and [m[2] for m in r.metas] == [0, 1, 3]               # view 2 skipped (1 < n_views valid views)
+    sf = 100 / 4.0
+    assert r.scale_factors[scan] == sf
+    s = r[0]
+    assert s["imgs_u8"].shape == (3, 288, 384, 3) and s["proj_mats"].shape == (2, 3, 3, 4)
+    assert abs(float(s["init_depth_min"]) - 100.0) < 1e-4
+    d0 = P.resize_nearest(depth0 * np.float32(sf), out_hw=(288, 384))
+    assert np.allclose(s["depths"]["level_0"].numpy(), d0, rtol=1e-6)
+    assert abs(float(s["depth_interval"]) - (float(d0.max()) - 100.0) / 192.0) < 1e-4
+    assert np.array_equal(s["masks"]["level_1"].numpy(), s["depths"]["level_1"].numpy() > 100.0)
+    assert abs(r.proj_mats[scan][1][1] - 5.0 * sf) < 1e-4                      # every camera's range uses the SCAN's factor
+    # translation scaled, intrinsics to the coarsest level of the resized image (768 -> 384: x 0.5 / 4)
+    Pm = r.proj_mats[scan][0][0][2]
+    assert abs(float(Pm[0, 0]) - 570.0 * 384 / 768 / 4) < 1e-3 and abs(float(Pm[2, 3]) - 0.3 * sf) < 1e-4
