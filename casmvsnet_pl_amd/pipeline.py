@@ -238,6 +238,59 @@ class BlendedMVSReader:
         return sample
 
 
+class TanksReader:
+    """datasets/tanks.py as a plain reader (test only, like the reference): `<root>/<split>/<scan>/{pair.txt, cams/, images/}`,
+    intrinsics rescaled from the scan's native image size to the coarsest level of `img_wh` (:77-79), and the hand-tuned
+    depth interval of every scan (:42-49, :59-64) as the sample's `depth_interval`."""
+
+    IMAGE_SIZES = {"intermediate": {"Family": (1920, 1080), "Francis": (1920, 1080), "Horse": (1920, 1080), "Lighthouse": (2048, 1080),
+                                    "M60": (2048, 1080), "Panther": (2048, 1080), "Playground": (1920, 1080), "Train": (1920, 1080)},
+                   "advanced": {s: (1920, 1080) for s in ("Auditorium", "Ballroom", "Courtroom", "Museum", "Palace", "Temple")}}
+    DEPTH_INTERVALS = {"intermediate": {"Family": 2.5e-3, "Francis": 1e-2, "Horse": 1.5e-3, "Lighthouse": 1.5e-2, "M60": 5e-3,
+                                        "Panther": 5e-3, "Playground": 7e-3, "Train": 5e-3},
+                       "advanced": {"Auditorium": 3e-2, "Ballroom": 2e-2, "Courtroom": 2e-2, "Museum": 2e-2, "Palace": 1e-2, "Temple": 1e-2}}
+
+    def __init__(self, root_dir, split="intermediate", scans=None, n_views=3, levels=3, img_wh=(1152, 864)):
+        if img_wh[0] % 32 or img_wh[1] % 32:
+            raise ValueError("img_wh must both be multiples of 32!")
+        self.root_dir, self.split, self.n_views, self.levels, self.img_wh = root_dir, split, n_views, levels, img_wh
+        self.image_sizes, self.depth_interval = self.IMAGE_SIZES[split], self.DEPTH_INTERVALS[split]
+        self.scans = list(scans) if scans is not None else list(self.image_sizes)
+        self.metas, self.proj_mats = [], {}
+        for scan in self.scans:
+            with open(os.path.join(root_dir, split, scan, "pair.txt")) as f:
+                lines = [l.rstrip() for l in f.readlines()]
+            img_w, img_h = self.image_sizes[scan]
+            self.proj_mats[scan] = {}
+            for i in range(int(lines[0])):
+                ref_view = int(lines[1 + 2 * i])
+                self.metas.append((scan, -1, ref_view, [int(x) for x in lines[2 + 2 * i].split()[1::2]]))
+                K, E, depth_min = read_cam_file(os.path.join(root_dir, split, scan, f"cams/{ref_view:08d}_cam.txt"))
+                K[0] *= img_wh[0] / img_w / 4
+                K[1] *= img_wh[1] / img_h / 4
+                self.proj_mats[scan][ref_view] = (build_proj_mats(K, E, levels), depth_min)
+
+    def __len__(self):
+        return len(self.metas)
+
+    def __getitem__(self, idx):                                                # tanks.py:131-163
+        scan, _, ref_view, src_views = self.metas[idx]
+        sample, imgs, proj_mats = {}, [], []
+        for i, vid in enumerate([ref_view] + src_views[:self.n_views - 1]):
+            imgs.append(torch.from_numpy(read_image_u8(os.path.join(self.root_dir, self.split, scan, f"images/{vid:08d}.jpg"), self.img_wh)))
+            proj_mat_ls, depth_min = self.proj_mats[scan][vid]
+            if i == 0:
+                ref_proj = proj_mat_ls
+                sample["init_depth_min"] = torch.tensor([depth_min], dtype=torch.float32)
+                sample["depth_interval"] = torch.tensor([self.depth_interval[scan]], dtype=torch.float32)
+            else:
+                proj_mats.append(proj_mat_ls)
+        sample["imgs_u8"] = torch.stack(imgs)
+        sample["proj_mats"] = relative_proj_mats(ref_proj, proj_mats)
+        sample["scan_vid"] = (scan, ref_view)
+        return sample
+
+
 # ---- PFM -----------------------------------------------------------------------------------------------------------------
 
 def read_pfm(filename):

@@ -281,3 +281,27 @@ def test_blendedmvs_reader_scales_the_scene_and_derives_the_interval(tmp_path):
     # translation scaled, intrinsics to the coarsest level of the resized image (768 -> 384: x 0.5 / 4)
     Pm = r.proj_mats[scan][0][0][2]
     assert abs(float(Pm[0, 0]) - 570.0 * 384 / 768 / 4) < 1e-3 and abs(float(Pm[2, 3]) - 0.3 * sf) < 1e-4
+
+
+def test_tanks_reader(tmp_path):
+    from PIL import Image
+    g = np.random.default_rng(8)
+    scan = "Lighthouse"
+    base = tmp_path / "intermediate" / scan
+    (base / "cams").mkdir(parents=True)
+    (base / "images").mkdir()
+    (base / "pair.txt").write_text("3\n0\n2 1 0.9 2 0.8\n1\n2 0 0.9 2 0.7\n2\n2 1 0.6 0 0.5\n")
+    for vid in range(3):
+        K = np.array([[1165.0, 0, 1024.0], [0, 1165.0, 540.0], [0, 0, 1]])
+        E = np.eye(4)
+        E[:3, 3] = [0.05 * vid, 0.0, 0.1]
+        lines = ["extrinsic"] + [" ".join(f"{v:.6f}" for v in row) for row in E] + ["", "intrinsic"] + \
+                [" ".join(f"{v:.6f}" for v in row) for row in K] + ["", f"{0.4 + 0.1 * vid} 0.002"]
+        (base / "cams" / f"{vid:08d}_cam.txt").write_text("\n".join(lines) + "\n")
+        Image.fromarray(g.integers(0, 256, (270, 512, 3), dtype=np.uint8)).save(base / "images" / f"{vid:08d}.jpg")
+    r = P.TanksReader(str(tmp_path), "intermediate", scans=[scan], n_views=3, img_wh=(256, 128))
+    assert len(r) == 3
+    s = r[1]
+    assert s["scan_vid"] == (scan, 1) and s["imgs_u8"].shape == (3, 128, 256, 3) and s["proj_mats"].shape == (2, 3, 3, 4)
+    assert abs(float(s["init_depth_min"]) - 0.5) < 1e-6 and abs(float(s["depth_interval"]) - 1.5e-2) < 1e-8   # the scan's hand-tuned interval
+    assert abs(float(r.proj_mats[scan][0][0][2][0, 0]) - 1165.0 * 256 / 2048 / 4) < 1e-3                     # native width 2048 for this scan
