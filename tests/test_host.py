@@ -192,3 +192,24 @@ def test_synthetic_inputs_follow_the_dataset_contract():
     assert torch.allclose(proj[0, 0, 1, :2, 3], proj[0, 0, 0, :2, 3] / 2, rtol=1e-4)
     assert torch.allclose(proj[0, 0, 2, 2, 2:], proj[0, 0, 0, 2, 2:], rtol=1e-5)
     assert torch.allclose(proj[0, 0, 1, 2, :2], proj[0, 0, 0, 2, :2] * 2, rtol=1e-4)
+
+
+def test_checkpoints_in_the_reference_layouts(tmp_path):
+    """utils/__init__.py:51-80: Lightning checkpoints (`model.` prefix, other entries ignored) and plain state dicts load,
+    `prefixes_to_ignore` keeps the model's own tensors for the ignored keys, trained weights round-trip."""
+    from casmvsnet_pl_amd import checkpoint as C
+    a = CascadeMVSNet(num_groups=1, norm_act=ABN)
+    randomize_state_dict(a.state_dict(), seed=4)
+    C.save_ckpt(a, str(tmp_path / "l.ckpt"), epoch=3)
+    raw = torch.load(str(tmp_path / "l.ckpt"), weights_only=False)
+    raw["state_dict"]["loss.weight"] = torch.zeros(1)            # what --prefixes_to_ignore loss is there for (train.py, opt.py:37)
+    torch.save(raw, str(tmp_path / "l.ckpt"))
+    b = C.load_ckpt(CascadeMVSNet(num_groups=1, norm_act=ABN), str(tmp_path / "l.ckpt"))
+    assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items()) and raw["epoch"] == 3
+    C.save_ckpt(a, str(tmp_path / "p.ckpt"), lightning_layout=False)
+    c = CascadeMVSNet(num_groups=1, norm_act=ABN)
+    keep = c.state_dict()["cost_reg_2.prob.bias"].clone()
+    C.load_ckpt(c, str(tmp_path / "p.ckpt"), prefixes_to_ignore=["cost_reg_2.prob"])
+    assert torch.equal(c.state_dict()["cost_reg_2.prob.bias"], keep)
+    assert torch.equal(c.state_dict()["feature.conv0.0.conv.weight"], a.state_dict()["feature.conv0.0.conv.weight"])
+    assert len(C.extract_model_state_dict(str(tmp_path / "l.ckpt"))) == 206
