@@ -36,7 +36,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int kMaxViews = 8;   // source views staged at once
-constexpr int RS = 65;         // row stride of the transpose buffer (odd: conflict-free)
+#ifndef CASMVS_CV_RS
+#define CASMVS_CV_RS 68
+#endif
+constexpr int RS = CASMVS_CV_RS;   // row stride of the transpose buffer.  68: rows stay 16-byte aligned, so a lane's four pixels are ONE
+                                   // ds_read_b128 at consecutive 16-byte units (conflict-free); the writes (lane = consecutive floats) are
+                                   // conflict-free for any stride.  (65, round 2: misaligned rows -> two ds_read2_b32 with a 16-byte lane
+                                   // stride = bank conflicts: SQ_LDS_BANK_CONFLICT was 44 % of the LDS-active cycles.)
 constexpr int kMaxPG = 2;      // plane groups: a tile's 256 pixels are worked on by PG x 4 waves, each group its own planes
 // prm + red + pmat + tr (one [4][RS] transpose buffer per wave)
 constexpr int fixed_lds(int pg) { return kMaxViews * 8 * 4 + 4 * kMaxViews * 4 * 4 + kMaxViews * 12 * 4 + pg * 4 * 4 * RS * 4; }
@@ -144,7 +150,7 @@ __device__ __forceinline__ void store_plane_transposed(const float (&vals)[CS], 
     for (int i = 0; i < 4; ++i) tr[i * RS + lane] = vals[4 * j + i];
     wave_lds_fence();
     const float *row = tr + cw * RS + 4 * q4;
-    const f32x4 o{row[0], row[1], row[2], row[3]};
+    const f32x4 o = RS % 4 == 0 ? *reinterpret_cast<const f32x4 *>(row) : f32x4{row[0], row[1], row[2], row[3]};
     const int soff = uniform_int((4 * j * D + d) * hw * 4);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ps.rsrc, ps.voff, soff, CASMVS_CV_STORE_AUX);   // w % 4 == 0 (host)
     wave_lds_fence();  // the rows are rewritten by the next channel group
