@@ -159,6 +159,9 @@ inline float pack_weight(const LayerCfg &c, int kind, int cin, int cout, const f
 // scalar add and one buffer_load - no per-lane 64-bit address arithmetic, no predicate - and a
 // lane whose position is outside the image carries the offset kOOB >= num_records, for which the
 // hardware returns 0 (loads) or drops the access (stores): the convolution's zero padding for free.
+#ifndef CASMVS_CONV_STORE_AUX
+#define CASMVS_CONV_STORE_AUX 0   // cache-policy bits of the activation stores (2 = nt; A/B builds)
+#endif
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int kOOB = (int)0x80000000u;  // needs num_records <= 2^31 bytes (checked on the host)
 
@@ -173,10 +176,10 @@ __device__ __forceinline__ f32x2 buf_load2(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 __device__ __forceinline__ void buf_store(float v, rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, CASMVS_CONV_STORE_AUX);
 }
 __device__ __forceinline__ void buf_store2(f32x2 v, rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, CASMVS_CONV_STORE_AUX);
 }
 
 // ---- staging: global -> registers -> LDS, software-pipelined one chunk ahead -------------------
