@@ -155,29 +155,39 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
   for (int e = threadIdx.x; e < T * 256; e += kThreads) pp[e] = red[e];
 }
 
-// grad_weight[cs][cb][t] = sum over the workgroups' partials in a fixed order.  One thread per element of the partial layout
-// (coalesced reads), scattered write into the torch layout.
+// grad_weight[cs][cb][t] = sum over the workgroups' partials in a fixed order.  A block owns 32 consecutive elements of the
+// partial layout (128-byte coalesced reads) and splits the up to 512 partials into 8 slices, one per 32 threads: a thread
+// walks its slice with eight loads in flight (eight running sums, combined in a fixed order), thread 0..31 then add the
+// slices in slice order - run-to-run reproducible.  (One thread per element walking all 512 partials took 72 us per layer,
+// 3.3 ms of a 35 ms training step, for 7 MB of reads.)
+constexpr int kRedElems = 32, kRedSlices = kThreads / kRedElems;
 __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, int Cs, int Cb,
                                                                int T, int cb_groups, int gy, int gx) {
-  const int e = blockIdx.x * kThreads + threadIdx.x;   // (y, t, i, j)
-  if (e >= gy * T * 256) return;
-  const int j = e & 15, i = (e >> 4) & 15, t = (e >> 8) % T, y = (e >> 8) / T;
-  const int cs = (y / cb_groups) * 16 + i, cb = (y % cb_groups) * 16 + j;
-  if (cs >= Cs || cb >= Cb) return;
-  const float *p = partial + (size_t)y * (T * 256) + (size_t)t * 256 + i * 16 + j;
+  __shared__ float red[kRedSlices][kRedElems];
+  const int le = threadIdx.x & (kRedElems - 1), sl = threadIdx.x / kRedElems;
+  const int e = blockIdx.x * kRedElems + le;   // (y, t, i, j); gy * T * 256 is a multiple of 32: no ragged block
   const size_t stride = (size_t)gy * (T * 256);
-  // eight independent running sums (eight loads in flight: one thread walks up to 512 partials), combined in a fixed order
+  const float *p = partial + e;
+  const int per = (gx + kRedSlices - 1) / kRedSlices, lo = sl * per, hi = min(lo + per, gx);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int x = 0;
-  for (; x + 8 <= gx; x += 8) {
+  int x = lo;
+  for (; x + 8 <= hi; x += 8) {
     float v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(x + k) * stride];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] += v[k];
   }
-  for (; x < gx; ++x) acc[x & 7] += p[(size_t)x * stride];
-  gw[((size_t)cs * Cb + cb) * T + t] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  for (; x < hi; ++x) acc[(x - lo) & 7] += p[(size_t)x * stride];
+  red[sl][le] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (sl != 0) return;
+  float total = red[0][le];
+#pragma unroll
+  for (int q = 1; q < kRedSlices; ++q) total += red[q][le];
+  const int j = e & 15, i = (e >> 4) & 15, t = (e >> 8) % T, y = (e >> 8) / T;
+  const int cs = (y / cb_groups) * 16 + i, cb = (y % cb_groups) * 16 + j;
+  if (cs < Cs && cb < Cb) gw[((size_t)cs * Cb + cb) * T + t] = total;
 }
 
 // ---- direct input gradient (layer shapes without an adjoint forward kernel) ------------------------------------------
@@ -359,87 +369,164 @@ __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float *_
 // ---- variance cost volume backward ----------------------------------------------------------------------------------
 // var = Q / V - (S / V)^2 with S = sum of the V views' values, Q = sum of their squares (mvsnet.py:140-167), so
 // d var / d x_v = 2 x_v / V - 2 S / V^2 for the reference (x_0 = ref feature, every plane) and for each warped view.
-// One thread per (reference pixel, chunk of planes): the warped values are re-gathered (same taps as the forward), the
-// reference gradient accumulates in registers over the chunk, the source gradients are scattered with fp32 atomics like
-// homo_warp's (lanes = consecutive pixels of a channel plane: the atomics of a wave fall on a few cache lines; a
-// pixel-major variant whose lanes each add C consecutive floats was 2.5x slower - the lanes' footprints overlap).
+// The source-view gradient is the transpose of the bilinear gather (modules.py:87-89): a scatter.  One workgroup owns
+// (a 32 x 32 tile of reference pixels, 8 planes, CG channels, ONE source view): everything it scatters falls into the
+// bounding box of its taps in that view (the epipolar band of the tile: ~40 x 40 pixels), so the contributions are
+// accumulated in an LDS image of that box (ds_add_f32: no memory traffic, no contention between workgroups) and the box is
+// added to the gradient map once, one fp32 atomic per touched element and channel - ~2 atomics per pixel and channel instead
+// of the ~16 of a per-tap scatter (the per-tap form was 6.7 ms at level 1, 28 % of the whole training step).
+// Phase 1: the tile's taps in the view -> box (wave-uniform after an LDS min / max).  Phase 2: per (pixel, plane) the warped
+// values of ALL views are re-gathered (S needs them), the own view's gradient goes into the box; the workgroups of the
+// first source view also accumulate the reference view's gradient in registers.  Phase 3: box -> global.
+// A box that does not fit (degenerate geometry) scatters straight to global memory instead.
 // wave shift by one lane (gfx9 DPP wave_shr:1 / wave_shl:1): lane i reads lane i - 1 / i + 1; the first / last lane reads 0
 __device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int lane_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ float lane_prev(float v) { return __builtin_bit_cast(float, lane_prev(__builtin_bit_cast(int, v))); }
 
-template <int C>
+template <int CG>
 __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *__restrict__ feats, const float *__restrict__ proj,
                                                                   const float *__restrict__ depth, const float *__restrict__ gvol,
-                                                                  float *__restrict__ gfeats, int V, int H, int W, int D, int dch) {
-  const int b = blockIdx.z, d_begin = blockIdx.y * dch, d_end = min(d_begin + dch, D), hw = H * W;
-  const int pr = blockIdx.x * kThreads + threadIdx.x, lane = threadIdx.x & 63;
-  const bool valid = pr < hw;        // no early exit: the lanes exchange tap gradients with their neighbours (DPP) below
-  const int p = valid ? pr : hw - 1;
-  const int y = p / W, x = p - y * W;
+                                                                  float *__restrict__ gfeats, int V, int C, int H, int W, int D,
+                                                                  int tiles_x, int DCH, int CAP) {
+  constexpr int TS = 32, RPT = TS * TS / kThreads, RSTEP = kThreads / TS;
+  extern __shared__ float smem[];
+  float *box = smem;   // [CG][bh][bw], CAP cells per channel
+  __shared__ int ext[4];
+  const int tid = threadIdx.x, b = blockIdx.z, hw = H * W;
+  int r = blockIdx.y;
+  const int v = 1 + r % (V - 1); r /= (V - 1);
+  const int groups = C / CG, c0 = (r % groups) * CG, d_begin = (r / groups) * DCH, d_end = min(d_begin + DCH, D);
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int x = txi * TS + (tid & (TS - 1)), yb = tyi * TS + tid / TS;
   const float *fb = feats + (size_t)b * V * C * hw;
   float *gb = gfeats + (size_t)b * V * C * hw;
+  const float *Pb = proj + (size_t)b * (V - 1) * 12;
+  const float *Pv = Pb + (v - 1) * 12;
+  const float *db = depth + (size_t)b * D * hw;
   const float fV = (float)V;
-  float ref[C], gref[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    ref[c] = fb[(size_t)c * hw + p];
-    gref[c] = 0.0f;
-  }
-  for (int d = d_begin; d < d_end; ++d) {
-    const float dv = depth[((size_t)b * D + d) * hw + p];
-    float S[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) S[c] = ref[c];
-    for (int v = 1; v < V; ++v) {   // dead voxels: all four weights are 0 and the (clamped) addresses are valid
-      const Taps t = plane_sweep_taps(proj + ((size_t)b * (V - 1) + (v - 1)) * 12, (float)x, (float)y, dv, W, H);
-      const float *fv = fb + (size_t)v * C * hw;
-      const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float *fc = fv + (size_t)c * hw;
-        S[c] += fmaf(fc[os + 1], t.w_sr, fmaf(fc[os], t.w_sl, fmaf(fc[on + 1], t.w_nr, fc[on] * t.w_nl)));
+
+  // ---- 1. bounding box of this view's live taps
+  if (tid < 4) ext[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+  int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
+  if (x < W) {
+    for (int j = 0; j < RPT; ++j) {
+      const int y = yb + j * RSTEP;
+      if (y >= H) break;
+      for (int d = d_begin; d < d_end; ++d) {
+        const Taps t = plane_sweep_taps(Pv, (float)x, (float)y, db[(size_t)d * hw + y * W + x], W, H);
+        if (taps_live(t)) {
+          xmn = min(xmn, t.xl); xmx = max(xmx, t.xl + 1);
+          ymn = min(ymn, t.yn); ymx = max(ymx, t.ys);
+        }
       }
     }
-    const float *gv = gvol + ((size_t)b * C * D + d) * hw + p;
-    float g[C];
+  }
+  __syncthreads();
+  if (xmn <= xmx) {
+    atomicMin(&ext[0], xmn); atomicMax(&ext[1], xmx);
+    atomicMin(&ext[2], ymn); atomicMax(&ext[3], ymx);
+  }
+  __syncthreads();
+  const int bx0 = ext[0], by0 = ext[2];
+  const bool any = ext[0] <= ext[1];
+  const int bw = any ? ext[1] - ext[0] + 1 : 0, bh = any ? ext[3] - ext[2] + 1 : 0;
+  const bool in_lds = bw * bh <= CAP;
+  const int cells = bw * bh;
+  if (in_lds)
+    for (int e = tid; e < CG * cells; e += kThreads) box[e] = 0.0f;
+  __syncthreads();
+
+  // ---- 2. per (pixel, plane): S over the views, own view's gradient into the box
+  float *gsv = gb + ((size_t)v * C + c0) * hw;
+  const int lane = tid & 63;
+  // every lane runs the loops (the lanes exchange tap gradients with their neighbours by DPP below); a lane outside the
+  // image works on a clamped pixel with a zero upstream gradient and never adds anything
+  for (int j = 0; j < RPT; ++j) {
+    const int yr = yb + j * RSTEP;
+    const bool valid = x < W && yr < H;
+    const int xc = min(x, W - 1), y = min(yr, H - 1), p = y * W + xc;
+    float ref[CG], gref[CG];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      g[c] = valid ? gv[(size_t)c * D * hw] : 0.0f;
-      S[c] = 2.0f * S[c] / (fV * fV);                      // now the common term
-      gref[c] += g[c] * (2.0f * ref[c] / fV - S[c]);
+    for (int c = 0; c < CG; ++c) {
+      ref[c] = fb[(size_t)(c0 + c) * hw + p];
+      gref[c] = 0.0f;
     }
-    for (int v = 1; v < V; ++v) {
-      const Taps t = plane_sweep_taps(proj + ((size_t)b * (V - 1) + (v - 1)) * 12, (float)x, (float)y, dv, W, H);
-      const float *fv = fb + (size_t)v * C * hw;
-      float *gsv = gb + (size_t)v * C * hw;
-      const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
+    for (int d = d_begin; d < d_end; ++d) {
+      const float dv = db[(size_t)d * hw + p];
+      float S[CG], xv[CG];
+      Taps tv;
+#pragma unroll
+      for (int c = 0; c < CG; ++c) S[c] = ref[c];
+      for (int u = 1; u < V; ++u) {   // dead voxels: all four weights are 0 and the (clamped) addresses are valid
+        const Taps t = plane_sweep_taps(Pb + (u - 1) * 12, (float)xc, (float)y, dv, W, H);
+        const float *fu = fb + ((size_t)u * C + c0) * hw;
+        const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
+        const bool own = u == v;
+        if (own) tv = t;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+          const float *fc = fu + (size_t)c * hw;
+          const float val = fmaf(fc[os + 1], t.w_sr, fmaf(fc[os], t.w_sl, fmaf(fc[on + 1], t.w_nr, fc[on] * t.w_nl)));
+          S[c] += val;
+          if (own) xv[c] = val;
+        }
+      }
+      const float *gv = gvol + (((size_t)b * C + c0) * D + d) * hw + p;
+      const bool live = valid && taps_live(tv);
       // Neighbouring lanes are neighbouring pixels: lane i's RIGHT tap column is usually lane i + 1's LEFT one.  The right
-      // contribution travels one lane up (DPP) and is added to the neighbour's left one: ~2 atomics per channel and row
-      // pair instead of 4.  A lane keeps its right tap only when the next lane does not continue the run.
-      const int pxl = lane_prev(t.xl), pyn = lane_prev(t.yn), pys = lane_prev(t.ys);
-      const int nxl = lane_next(t.xl), nyn = lane_next(t.yn), nys = lane_next(t.ys);
-      const bool mp_n = lane > 0 && pyn == t.yn && pxl + 1 == t.xl, mp_s = lane > 0 && pys == t.ys && pxl + 1 == t.xl;
-      const bool ab_n = lane < 63 && nyn == t.yn && nxl == t.xl + 1, ab_s = lane < 63 && nys == t.ys && nxl == t.xl + 1;
+      // contribution travels one lane up (DPP) and is added to the neighbour's left one: ~2 adds per channel and row pair
+      // instead of 4 (LDS fp32 atomics retire ~0.5 lanes per clock and CU: they, not the gathers, bound this kernel).
+      // A lane keeps its right tap only when the next lane does not continue the run; dead lanes (key -100) never match.
+      const int kxl = live ? tv.xl : -100;
+      const int pxl = lane_prev(kxl), pyn = lane_prev(tv.yn), pys = lane_prev(tv.ys);
+      const int nxl = lane_next(kxl), nyn = lane_next(tv.yn), nys = lane_next(tv.ys);
+      const bool mp_n = live && lane > 0 && pyn == tv.yn && pxl + 1 == tv.xl, mp_s = live && lane > 0 && pys == tv.ys && pxl + 1 == tv.xl;
+      const bool ab_n = lane < 63 && nyn == tv.yn && nxl == tv.xl + 1, ab_s = lane < 63 && nys == tv.ys && nxl == tv.xl + 1;
+      const int lo_n = (tv.yn - by0) * bw + (tv.xl - bx0), lo_s = (tv.ys - by0) * bw + (tv.xl - bx0);
+      const int go_n = tv.yn * W + tv.xl, go_s = tv.ys * W + tv.xl;
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float *fc = fv + (size_t)c * hw;
-        const float xv = fmaf(fc[os + 1], t.w_sr, fmaf(fc[os], t.w_sl, fmaf(fc[on + 1], t.w_nr, fc[on] * t.w_nl)));
-        const float gx = g[c] * (2.0f * xv / fV - S[c]);
-        const float rn = gx * t.w_nr, rs = gx * t.w_sr;
+      for (int c = 0; c < CG; ++c) {
+        const float g = valid ? gv[(size_t)c * D * hw] : 0.0f;
+        const float common = 2.0f * S[c] / (fV * fV);
+        gref[c] += g * (2.0f * ref[c] / fV - common);
+        const float gx = g * (2.0f * xv[c] / fV - common);
+        const float rn = gx * tv.w_nr, rs = gx * tv.w_sr;
         const float prn = lane_prev(rn), prs = lane_prev(rs);
-        const float an = gx * t.w_nl + (mp_n ? prn : 0.0f), as = gx * t.w_sl + (mp_s ? prs : 0.0f);
-        float *gc = gsv + (size_t)c * hw;
-        if (an != 0.0f) unsafeAtomicAdd(gc + on, an);
-        if (!ab_n && rn != 0.0f) unsafeAtomicAdd(gc + on + 1, rn);
-        if (as != 0.0f) unsafeAtomicAdd(gc + os, as);
-        if (!ab_s && rs != 0.0f) unsafeAtomicAdd(gc + os + 1, rs);
+        const float an = gx * tv.w_nl + (mp_n ? prn : 0.0f), as = gx * tv.w_sl + (mp_s ? prs : 0.0f);
+        if (live) {
+          if (in_lds) {
+            float *q = box + c * cells;
+            atomicAdd(q + lo_n, an);
+            if (!ab_n) atomicAdd(q + lo_n + 1, rn);
+            atomicAdd(q + lo_s, as);
+            if (!ab_s) atomicAdd(q + lo_s + 1, rs);
+          } else {
+            float *q = gsv + (size_t)c * hw;
+            unsafeAtomicAdd(q + go_n, an);
+            if (!ab_n) unsafeAtomicAdd(q + go_n + 1, rn);
+            unsafeAtomicAdd(q + go_s, as);
+            if (!ab_s) unsafeAtomicAdd(q + go_s + 1, rs);
+          }
+        }
       }
     }
-  }
-  if (valid) {
+    if (v == 1 && valid) {   // view 0 (the reference features): one add per plane chunk
 #pragma unroll
-    for (int c = 0; c < C; ++c) unsafeAtomicAdd(gb + (size_t)c * hw + p, gref[c]);   // view 0: one add per plane chunk
+      for (int c = 0; c < CG; ++c) unsafeAtomicAdd(gb + (size_t)(c0 + c) * hw + p, gref[c]);
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. box -> gradient map (lanes = consecutive columns of a box row of one channel plane)
+  if (in_lds) {
+    for (int e = tid; e < CG * cells; e += kThreads) {
+      const float val = box[e];
+      if (val != 0.0f) {
+        const int c = e / cells, cell = e - c * cells, row = cell / bw, col = cell - row * bw;
+        unsafeAtomicAdd(gsv + (size_t)c * hw + (by0 + row) * W + bx0 + col, val);
+      }
+    }
   }
 }
 
@@ -527,7 +614,7 @@ extern "C" int casmvs_conv_wgrad_f32(int kind, const float *in, const float *gra
   else rc = launch_wgrad<1, 1, 1>(l, small, big, partial, B, st);
   if (rc) return rc;
   const int n = l.gy * l.T * 256;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)casmvs::ceil_div(n, kThreads)), dim3(kThreads), 0, st, partial, grad_weight, l.Cs,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n / kRedElems)), dim3(kThreads), 0, st, partial, grad_weight, l.Cs,
                      l.Cb, l.T, l.cb_groups, l.gy, l.gx);
   return casmvs::check_launch("wgrad_reduce_kernel");
 }
@@ -625,12 +712,25 @@ extern "C" int casmvs_costvol_var_backward_f32(const float *feats, const float *
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)B * V * C * h * w * sizeof(float), st);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "costvol_var_backward: hipMemsetAsync: %s", hipGetErrorString(e));
-  const int dch = D >= 16 ? 4 : (D >= 4 ? 2 : 1);   // planes per thread
-  dim3 grid((unsigned)casmvs::ceil_div(h * w, kThreads), (unsigned)casmvs::ceil_div(D, dch), (unsigned)B);
-#define CASMVS_VB(CV) \
-  if (C == CV) { hipLaunchKernelGGL(costvol_var_bwd_kernel<CV>, grid, dim3(kThreads), 0, st, feats, proj, depth, grad_vol, grad_feats, V, h, w, D, dch); return casmvs::check_launch("costvol_var_bwd_kernel"); }
-  CASMVS_VB(8) CASMVS_VB(16) CASMVS_VB(32) CASMVS_VB(4)
+  // 8 planes per workgroup; the LDS image holds 2304 box pixels (a 32 x 32 tile whose taps spread over ~48 x 48) of 8 channels
+  // = 72 KiB: two workgroups per CU
+  constexpr int dch = 8, cap = 2304;
+  const int tiles_x = casmvs::ceil_div(w, 32), tiles_y = casmvs::ceil_div(h, 32), chunks = casmvs::ceil_div(D, dch);
+#define CASMVS_VB(CG)                                                                                                          \
+  {                                                                                                                            \
+    const long gy = (long)chunks * (C / CG) * (V - 1);                                                                         \
+    CASMVS_REQUIRE(gy <= 65535, "costvol_var_backward: D=%d C=%d V=%d: too many (plane chunk, channel group, view) items", D, C, V); \
+    auto kernel = costvol_var_bwd_kernel<CG>;                                                                                  \
+    const size_t lds = (size_t)CG * cap * sizeof(float);                                                                       \
+    if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "costvol_var_bwd_kernel")) return rc; \
+    dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)gy, (unsigned)B);                                                       \
+    hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, feats, proj, depth, grad_vol, grad_feats, V, C, h, w, D, tiles_x, \
+                       dch, cap);                                                                                              \
+    return casmvs::check_launch("costvol_var_bwd_kernel");                                                                     \
+  }
+  if (C % 8 == 0 && C <= 64) CASMVS_VB(8)
+  if (C == 4) CASMVS_VB(4)
 #undef CASMVS_VB
-  return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_var_backward: C=%d (4, 8, 16 or 32)", C);
+  return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_var_backward: C=%d (4 or a multiple of 8 up to 64)", C);
 }
 

@@ -142,7 +142,10 @@ def test_upsample_add_matches_interpolate(dev, report, N, C, H, W):
     assert errs["fwd"] < 2e-6 and errs["g_lat"] == 0.0 and errs["g_up"] < 2e-6
 
 
-@pytest.mark.parametrize("B,V,C,h,w,D,geometry", [(1, 3, 8, 24, 32, 4, "dtu"), (2, 3, 16, 16, 24, 8, "dtu"), (1, 4, 32, 16, 16, 3, "random")])
+@pytest.mark.parametrize("B,V,C,h,w,D,geometry", [(1, 3, 8, 24, 32, 4, "dtu"), (2, 3, 16, 16, 24, 8, "dtu"), (1, 4, 32, 16, 16, 3, "random"),
+                                                     # several 32 x 32 tiles, ragged edges, two plane chunks; boxes larger than the LDS image
+                                                     (1, 3, 8, 72, 88, 12, "dtu"), (1, 3, 8, 48, 64, 4, "random"), (1, 2, 4, 40, 36, 9, "dtu"),
+                                                     (1, 3, 8, 64, 96, 3, "random")])
 def test_variance_volume_backward_matches_autograd_of_the_oracle(dev, report, B, V, C, h, w, D, geometry):
     from casmvsnet_pl_amd import training as T
     from casmvsnet_pl_amd.synthetic import make_inputs
