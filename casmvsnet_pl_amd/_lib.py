@@ -7,7 +7,7 @@ launches return CASMVS_ERR_HIP which is raised as RuntimeError.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # CASMVS_LIB_PATH: load another BUILD of the same library (profiling: -DCASMVS_TRACE, compiler-flag A/B runs)
@@ -61,6 +61,9 @@ SYMBOLS = {
     "casmvs_abn_apply_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_size_t, c_float, c_void_p]),
     "casmvs_abn_backward_sums_f64": (c_int, [_FP] * 6 + [c_int, c_int, c_size_t, c_float, c_void_p]),
     "casmvs_abn_backward_apply_f32": (c_int, [_FP] * 9 + [c_int, c_int, c_size_t, c_float, c_void_p]),
+    "casmvs_pack_gather_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "casmvs_abn_train_finish_f32": (c_int, [_FP, c_int, c_int, c_double, _FP, _FP, c_float, c_float, c_float] + [_FP] * 6 + [c_void_p]),
+    "casmvs_abn_backward_finish_f32": (c_int, [_FP, c_int, c_int, c_double, _FP, c_float] + [_FP] * 4 + [c_void_p]),
     "casmvs_upsample2x_add_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_upsample2x_backward_f32": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_var_backward_f32": (c_int, [_FP] * 5 + [c_int] * 6 + [c_void_p]),

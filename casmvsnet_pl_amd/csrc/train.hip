@@ -313,6 +313,71 @@ __global__ __launch_bounds__(kThreads) void abn_bwd_apply_kernel(const float *__
   gx[off] = a[c] * (g - m1[c] - xhat * m2[c]);
 }
 
+// ---- device-side packing of a layer image (training: the weights change every step) ---------------------------------------
+// out[i] = source[index[i]] over the virtual source vector [weight (n_w), bias (n_b), 0.0, 1.0]: the host packer's layout as
+// a fixed gather (training.py derives `index` once per layer shape), one launch instead of a cat + index_select (+ the
+// transpose / flip copies of an adjoint layer, which are folded into the index).
+__global__ __launch_bounds__(kThreads) void pack_gather_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                                              const int *__restrict__ index, float *__restrict__ out, int n_w, int n_b,
+                                                              int n_out) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_out) return;
+  const int k = index[i];
+  out[i] = k < n_w ? w[k] : (k < n_w + n_b ? bias[k - n_w] : (k == n_w + n_b ? 0.0f : 1.0f));
+}
+
+// ---- per-channel epilogues of the batch statistics ---------------------------------------------------------------------
+// One thread per channel turns the workgroups' partial sums (C, blocks, 2) into everything the layer needs, in double like
+// F.batch_norm's accumulation: forward -> mean, biased variance, rstd, scale = gamma * rstd, shift = beta - mean * scale and
+// the running statistics (momentum update with the UNBIASED variance); backward -> grad_gamma, grad_beta, m1, m2.
+// abs_eps >= 0: InPlaceABN's gamma = |weight| + abs_eps (inplace_abn.py), its gradient goes back through the abs.
+// (As ~40 tensor-sized-1 torch operations per layer these epilogues were 1500 of the 1900 kernels of a training step.)
+__global__ __launch_bounds__(64) void abn_train_finish_kernel(const double *__restrict__ sums, int blocks, int C, double M,
+                                                             const float *__restrict__ weight, const float *__restrict__ bias, float abs_eps,
+                                                             float eps, float momentum, float *__restrict__ rmean, float *__restrict__ rvar,
+                                                             float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean,
+                                                             float *__restrict__ rstd) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    s0 += sums[((size_t)c * blocks + b) * 2];
+    s1 += sums[((size_t)c * blocks + b) * 2 + 1];
+  }
+  const double mu = s0 / M;
+  double var = s1 / M - mu * mu;   // biased
+  var = var > 0.0 ? var : 0.0;
+  const double rs = 1.0 / sqrt(var + (double)eps);
+  const double g = abs_eps >= 0.0f ? (double)(fabsf(weight[c]) + abs_eps) : (double)weight[c];
+  scale[c] = (float)(g * rs);
+  shift[c] = (float)((double)bias[c] - mu * g * rs);
+  mean[c] = (float)mu;
+  rstd[c] = (float)rs;
+  if (rmean) {   // F.batch_norm: running = (1 - momentum) * running + momentum * batch (running_var: unbiased)
+    const float keep = (float)(1.0 - (double)momentum);
+    rmean[c] = rmean[c] * keep + momentum * (float)mu;
+    rvar[c] = rvar[c] * keep + momentum * (float)(var * (M / (M > 1.0 ? M - 1.0 : 1.0)));
+  }
+}
+
+__global__ __launch_bounds__(64) void abn_bwd_finish_kernel(const double *__restrict__ sums, int blocks, int C, double M,
+                                                           const float *__restrict__ weight, float abs_eps, float *__restrict__ gweight,
+                                                           float *__restrict__ gbias, float *__restrict__ m1, float *__restrict__ m2) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    s0 += sums[((size_t)c * blocks + b) * 2];
+    s1 += sums[((size_t)c * blocks + b) * 2 + 1];
+  }
+  const float w = weight[c];
+  const float sgn = abs_eps >= 0.0f ? (w > 0.0f ? 1.0f : (w < 0.0f ? -1.0f : 0.0f)) : 1.0f;   // d|w| / dw
+  gweight[c] = (float)s1 * sgn;
+  gbias[c] = (float)s0;
+  m1[c] = (float)(s0 / M);
+  m2[c] = (float)(s1 / M);
+}
+
 // ---- FPN top-down step ----------------------------------------------------------------------------------------------------
 // ATen upsample_bilinear2d, align_corners = True: src = o * (n_in - 1) / (n_out - 1), i0 = floor(src), i1 = i0 + (i0 < n_in - 1),
 // l1 = src - i0, l0 = 1 - l1; value = l0y * (l0x v00 + l1x v01) + l1y * (l0x v10 + l1x v11)
@@ -684,6 +749,40 @@ extern "C" int casmvs_abn_backward_apply_f32(const float *grad_y, const float *y
   hipLaunchKernelGGL(abn_bwd_apply_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads), (unsigned)(N * C)), dim3(kThreads), 0,
                      (hipStream_t)stream, grad_y, y, x, scale, mean, rstd, m1, m2, grad_x, C, n, slope);
   return casmvs::check_launch("abn_bwd_apply_kernel");
+}
+
+extern "C" int casmvs_pack_gather_f32(const float *weight, const float *bias, const int *index, float *out, int n_weight, int n_bias,
+                                      int n_out, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(weight && index && out && n_weight > 0 && n_bias >= 0 && (n_bias == 0 || bias) && n_out > 0,
+                 "pack_gather: bad arguments");
+  hipLaunchKernelGGL(pack_gather_kernel, dim3((unsigned)casmvs::ceil_div(n_out, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, weight,
+                     bias, index, out, n_weight, n_bias, n_out);
+  return casmvs::check_launch("pack_gather_kernel");
+}
+
+// sums: (C, blocks, 2) doubles from casmvs_channel_sums_f64; every output a device vector of C floats
+extern "C" int casmvs_abn_train_finish_f32(const double *sums, int blocks, int C, double count, const float *weight, const float *bias,
+                                           float abs_eps, float eps, float momentum, float *running_mean, float *running_var,
+                                           float *scale, float *shift, float *mean, float *rstd, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(sums && weight && bias && scale && shift && mean && rstd && blocks > 0 && C > 0 && count > 0.0 &&
+                     (running_mean != nullptr) == (running_var != nullptr),
+                 "abn_train_finish: bad arguments");
+  hipLaunchKernelGGL(abn_train_finish_kernel, dim3((unsigned)casmvs::ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, blocks, C, count,
+                     weight, bias, abs_eps, eps, momentum, running_mean, running_var, scale, shift, mean, rstd);
+  return casmvs::check_launch("abn_train_finish_kernel");
+}
+
+// sums: (C, blocks, 2) doubles from casmvs_abn_backward_sums_f64
+extern "C" int casmvs_abn_backward_finish_f32(const double *sums, int blocks, int C, double count, const float *weight, float abs_eps,
+                                              float *grad_weight, float *grad_bias, float *m1, float *m2, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(sums && weight && grad_weight && grad_bias && m1 && m2 && blocks > 0 && C > 0 && count > 0.0,
+                 "abn_backward_finish: bad arguments");
+  hipLaunchKernelGGL(abn_bwd_finish_kernel, dim3((unsigned)casmvs::ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, blocks, C, count,
+                     weight, abs_eps, grad_weight, grad_bias, m1, m2);
+  return casmvs::check_launch("abn_bwd_finish_kernel");
 }
 
 extern "C" int casmvs_upsample2x_add_f32(const float *lat, const float *up, float *out, int N, int C, int H, int W, void *stream) {

@@ -44,8 +44,11 @@ def _stream(t):
 _PACK_MAPS = {}
 
 
-def _pack_map(kind, cin, cout, has_bias, device):
-    key = (kind, cin, cout, has_bias, str(device))
+def _pack_map(kind, cin, cout, has_bias, device, adjoint=False):
+    """int32 gather index of the packed image of layer (kind, cin -> cout) over the source [weight, bias, 0, 1].
+    adjoint: the layer's weight is `w.transpose(0, 1).flip(spatial dims)` of the tensor handed to device_pack (shape
+    (cin, cout, k...): the input-gradient layer of a stride-1 convolution) - the permutation is folded into the index."""
+    key = (kind, cin, cout, has_bias, str(device), adjoint)
     m = _PACK_MAPS.get(key)
     if m is not None:
         return m
@@ -60,41 +63,43 @@ def _pack_map(kind, cin, cout, has_bias, device):
     probe_w = (torch.arange(n, dtype=torch.float32) + 2.0).reshape(shape)         # weight i -> value i + 2
     probe_shift = -(torch.arange(cout, dtype=torch.float32) + 1.0) if has_bias else None   # bias c -> value -(c + 1)
     packed = (ops.conv3d_pack if three_d else ops.conv2d_pack)(kind, probe_w, None, probe_shift)
-    # source vector on the device: [weights (n), bias (cout or 0), 0.0, 1.0]
+    # source vector: [weights (n), bias (cout or 0), 0.0, 1.0]
     nb = cout if has_bias else 0
     idx = torch.empty(packed.numel(), dtype=torch.int64)
     v = packed.round().to(torch.int64)
-    idx[v >= 2] = v[v >= 2] - 2
+    widx = v[v >= 2] - 2
+    if adjoint:   # flat index in the logical (transposed, mirrored) weight -> flat index in the tensor as stored
+        if kind == CONV_T2:
+            raise RuntimeError("training: no adjoint packing for ConvTranspose3d")
+        stored = (cin, cout) + tuple(shape[2:])
+        perm = torch.arange(n, dtype=torch.int64).reshape(stored).transpose(0, 1)
+        if shape[2] > 1:
+            perm = perm.flip(tuple(range(2, len(shape))))
+        widx = perm.reshape(-1)[widx]
+    idx[v >= 2] = widx
     idx[v == 1] = n + nb + 1
     idx[v == 0] = n + nb
     idx[v < 0] = n + (-v[v < 0] - 1)
-    m = _PACK_MAPS[key] = idx.to(device)
+    m = _PACK_MAPS[key] = idx.to(torch.int32).to(device)
     return m
 
 
-_ZERO_ONE = {}
-
-
-def _zero_one(device):
-    """The constants [0, 1] on `device` (created once: a host tensor per call would be a pageable upload per layer)."""
-    t = _ZERO_ONE.get(str(device))
-    if t is None:
-        t = _ZERO_ONE[str(device)] = torch.tensor([0.0, 1.0], dtype=torch.float32, device=device)
-    return t
-
-
-def device_pack(kind, weight, bias=None):
-    """Packed layer image (the operand casmvs_conv{2,3}d_forward_f32 takes) of `weight` [+ `bias`] with scale 1, on the device."""
-    if kind == CONV_T2:
+def device_pack(kind, weight, bias=None, adjoint=False):
+    """Packed layer image (the operand casmvs_conv{2,3}d_forward_f32 takes) of `weight` [+ `bias`] with scale 1, on the
+    device: one gather launch (casmvs_pack_gather_f32).  adjoint: pack `weight.transpose(0, 1).flip(spatial)` instead."""
+    if (kind == CONV_T2) != adjoint:
         cin, cout = weight.shape[:2]
     else:
         cout, cin = weight.shape[:2]
-    idx = _pack_map(kind, cin, cout, bias is not None, weight.device)
-    parts = [weight.detach().reshape(-1).float()]
-    if bias is not None:
-        parts.append(bias.detach().reshape(-1).float())
-    parts.append(_zero_one(weight.device))
-    return torch.cat(parts).index_select(0, idx)
+    idx = _pack_map(kind, cin, cout, bias is not None, weight.device, adjoint)
+    w = weight.detach().contiguous().float()
+    bz = None if bias is None else bias.detach().contiguous().float()
+    out = torch.empty(idx.numel(), dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = _lib.load().casmvs_pack_gather_f32(_ptr(w), _ptr(bz), _ptr(idx), _ptr(out), w.numel(), 0 if bz is None else bz.numel(),
+                                                idx.numel(), _stream(w))
+    _lib.check(rc, "casmvs_pack_gather_f32")
+    return out
 
 
 def _forward_kernel_supports(kind, cin, cout):
@@ -103,10 +108,11 @@ def _forward_kernel_supports(kind, cin, cout):
     return fn(kind, cin, cout) > 0
 
 
-def _conv_raw(kind, weight, bias, x):
-    """conv (no activation) through the inference MFMA kernels."""
-    cout = weight.shape[1] if kind == CONV_T2 else weight.shape[0]
-    packed = device_pack(kind, weight, bias)
+def _conv_raw(kind, weight, bias, x, adjoint=False):
+    """conv (no activation) through the inference MFMA kernels.  adjoint: the layer whose weight is
+    `weight.transpose(0, 1).flip(spatial)` (the input gradient of a stride-1 convolution)."""
+    cout = weight.shape[1] if (kind == CONV_T2) != adjoint else weight.shape[0]
+    packed = device_pack(kind, weight, bias, adjoint)
     if kind in _3D:
         return ops.conv3d_forward(kind, packed, x, cout, None, slope=1.0)
     return ops.conv2d_forward(kind, packed, x, cout, slope=1.0)
@@ -145,14 +151,13 @@ def conv_dgrad(kind, weight, grad_out, x_shape):
         adj_kind, adj_w, a_in, a_out = CONV_T2, weight, cout, cin
     elif kind in (CONV_S1, CONV2D_K3, CONV2D_K1):   # stride 1: swap the channel roles, mirror the taps
         cout, cin = weight.shape[:2]
-        flip = (2, 3, 4) if kind == CONV_S1 else (2, 3)
-        adj_kind, a_in, a_out = kind, cout, cin
-        adj_w = weight.transpose(0, 1)
-        adj_w = adj_w.flip(flip) if kind != CONV2D_K1 else adj_w
+        adj_kind, adj_w, a_in, a_out = kind, None, cout, cin     # the permutation is part of the packing index
     else:
         cout, cin = weight.shape[:2]
         adj_kind = None
     if adj_kind is not None and _forward_kernel_supports(adj_kind, a_in, a_out):
+        if adj_w is None:
+            return _conv_raw(adj_kind, weight, None, grad_out, adjoint=True)
         return _conv_raw(adj_kind, adj_w.contiguous(), None, grad_out)
     # Conv2d k5 s2, 1x1 / 3x3 with a channel count the MFMA forms do not take as an output
     if kind == CONV_T2:
@@ -212,61 +217,80 @@ def conv(x, weight, bias, kind):
 
 
 class _ABNTrain(torch.autograd.Function):
-    """y = leaky_relu(batch_norm(x) with BATCH statistics); updates the running statistics in place like F.batch_norm."""
+    """y = leaky_relu(batch_norm(x) with BATCH statistics); updates the running statistics in place like F.batch_norm.
+    `weight` is the module's parameter; abs_eps >= 0 selects InPlaceABN's gamma = |weight| + abs_eps (inplace_abn.py).
+    Per layer: channel sums -> ONE per-channel epilogue kernel (statistics, folded scale / shift, running statistics) ->
+    the elementwise apply; nothing of it is a torch operation."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope):
+    def forward(ctx, x, weight, beta, running_mean, running_var, momentum, eps, slope, abs_eps):
         x = x.contiguous().float()
         N, C = x.shape[:2]
         n = x.numel() // (N * C)
         M = N * n
-        s0, s1 = channel_sums(x)
-        mean = s0 / M
-        var = (s1 / M - mean * mean).clamp_min(0.0)            # biased, float64
-        rstd = (var + eps).rsqrt()
-        scale = (gamma.detach().double() * rstd).float()
-        shift = (beta.detach().double() - mean * gamma.detach().double() * rstd).float()
+        lib = _lib.load()
+        blocks = lib.casmvs_channel_sums_blocks(N, n)
+        part = torch.empty((C, blocks, 2), dtype=torch.float64, device=x.device)
+        vec = torch.empty((4, C), dtype=torch.float32, device=x.device)   # scale, shift, mean, rstd
         y = torch.empty_like(x)
+        w, bta = weight.detach().contiguous().float(), beta.detach().contiguous().float()
+        track = running_mean is not None and running_var is not None
         with torch.cuda.device(x.device):
-            rc = _lib.load().casmvs_abn_apply_f32(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), N, C, n, float(slope), _stream(x))
-        _lib.check(rc, "casmvs_abn_apply_f32")
-        with torch.no_grad():                                    # F.batch_norm: running_var takes the UNBIASED variance
-            running_mean.mul_(1.0 - momentum).add_(mean.float(), alpha=momentum)
-            running_var.mul_(1.0 - momentum).add_((var * (M / max(M - 1, 1))).float(), alpha=momentum)
-        ctx.save_for_backward(x, y, scale, mean.float(), rstd.float())
-        ctx.slope, ctx.M = float(slope), M
+            st = _stream(x)
+            rc = lib.casmvs_channel_sums_f64(_ptr(x), _ptr(part), N, C, n, st)
+            _lib.check(rc, "casmvs_channel_sums_f64")
+            rc = lib.casmvs_abn_train_finish_f32(_ptr(part), blocks, C, float(M), _ptr(w), _ptr(bta), float(abs_eps), float(eps),
+                                                 float(momentum), _ptr(running_mean) if track else None,
+                                                 _ptr(running_var) if track else None, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+                                                 _ptr(vec[3]), st)
+            _lib.check(rc, "casmvs_abn_train_finish_f32")
+            rc = lib.casmvs_abn_apply_f32(_ptr(x), _ptr(vec[0]), _ptr(vec[1]), _ptr(y), N, C, n, float(slope), st)
+            _lib.check(rc, "casmvs_abn_apply_f32")
+        if track:   # the kernel wrote the buffers behind torch's back: bump their version counters (packed-weight caches key on them)
+            torch.autograd.graph.increment_version(running_mean)
+            torch.autograd.graph.increment_version(running_var)
+        ctx.save_for_backward(x, y, w, vec)
+        ctx.slope, ctx.M, ctx.abs_eps = float(slope), M, float(abs_eps)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, scale, mean, rstd = ctx.saved_tensors
+        x, y, w, vec = ctx.saved_tensors
         gy = gy.contiguous().float()
         N, C = x.shape[:2]
         n = x.numel() // (N * C)
         lib = _lib.load()
         blocks = lib.casmvs_channel_sums_blocks(N, n)
         part = torch.empty((C, blocks, 2), dtype=torch.float64, device=x.device)
+        out = torch.empty((4, C), dtype=torch.float32, device=x.device)   # grad_weight, grad_bias, m1, m2
+        gx = torch.empty_like(x)
+        scale, mean, rstd = vec[0], vec[2], vec[3]
         with torch.cuda.device(x.device):
-            rc = lib.casmvs_abn_backward_sums_f64(_ptr(gy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(part), N, C, n, ctx.slope, _stream(x))
+            st = _stream(x)
+            rc = lib.casmvs_abn_backward_sums_f64(_ptr(gy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(part), N, C, n, ctx.slope, st)
             _lib.check(rc, "casmvs_abn_backward_sums_f64")
-            s = part.sum(1)
-            g_beta, g_gamma = s[:, 0].float(), s[:, 1].float()
-            m1, m2 = (s[:, 0] / ctx.M).float(), (s[:, 1] / ctx.M).float()
-            gx = torch.empty_like(x)
-            rc = lib.casmvs_abn_backward_apply_f32(_ptr(gy), _ptr(y), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(m1), _ptr(m2),
-                                                   _ptr(gx), N, C, n, ctx.slope, _stream(x))
+            rc = lib.casmvs_abn_backward_finish_f32(_ptr(part), blocks, C, float(ctx.M), _ptr(w), ctx.abs_eps, _ptr(out[0]), _ptr(out[1]),
+                                                    _ptr(out[2]), _ptr(out[3]), st)
+            _lib.check(rc, "casmvs_abn_backward_finish_f32")
+            rc = lib.casmvs_abn_backward_apply_f32(_ptr(gy), _ptr(y), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(out[2]), _ptr(out[3]),
+                                                   _ptr(gx), N, C, n, ctx.slope, st)
             _lib.check(rc, "casmvs_abn_backward_apply_f32")
-        return gx, g_gamma, g_beta, None, None, None, None, None
+        return gx, out[0], out[1], None, None, None, None, None, None
 
 
 def abn_train(norm, x):
     """Train-mode forward of an ABN-like module (`weight`, `bias`, `running_mean`, `running_var`, `eps`, `momentum`,
     leaky-relu slope): inplace_abn.ABN (gamma = weight) or InPlaceABN (gamma = |weight| + eps, see inplace_abn.py)."""
+    from .inplace_abn import InPlaceABN
     if not getattr(norm, "affine", True) or norm.weight is None:
         raise RuntimeError("training: ABN without affine parameters is not supported")
-    gamma = norm._gamma() if hasattr(norm, "_gamma") else norm.weight
+    if isinstance(norm, InPlaceABN):
+        weight, abs_eps = norm.weight, float(norm.eps)       # |weight| + eps inside the epilogue kernel (and its gradient)
+    else:                                                    # any other module: its own gamma expression stays an autograd graph
+        weight, abs_eps = (norm._gamma() if hasattr(norm, "_gamma") else norm.weight), -1.0
     slope = norm.leaky_slope() if hasattr(norm, "leaky_slope") else float(getattr(norm, "activation_param", 0.01))
-    return _ABNTrain.apply(x, gamma, norm.bias, norm.running_mean, norm.running_var, float(norm.momentum), float(norm.eps), slope)
+    return _ABNTrain.apply(x, weight, norm.bias, norm.running_mean, norm.running_var, float(norm.momentum), float(norm.eps), slope,
+                           abs_eps)
 
 
 class _UpsampleAdd(torch.autograd.Function):

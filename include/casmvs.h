@@ -300,6 +300,14 @@ int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_va
  * casmvs_abn_backward_sums_f64 / casmvs_abn_backward_apply_f32: with g = grad_y * leaky_relu'(y) and xhat = (x - mean) * rstd:
  *   sums (C, blocks, 2) = partial (sum g, sum g xhat) [= grad_beta, grad_gamma]; grad_x = scale * (g - m1 - xhat * m2) with
  *   m1 = sum g / M, m2 = sum g xhat / M (device vectors of C floats).
+ * casmvs_pack_gather_f32: out[i] = [weight (n_weight), bias (n_bias), 0, 1][index[i]]: the packed layer image of
+ *   casmvs_conv{2,3}d_pack_f32 as a gather on the device (index: n_out int32, derived once per layer shape by the caller).
+ * casmvs_abn_train_finish_f32: one launch from the partial sums of casmvs_channel_sums_f64 to the layer's per-channel vectors (C
+ *   floats each, device): mean, rstd = 1 / sqrt(biased var + eps), scale = gamma * rstd, shift = bias - mean * scale, and the
+ *   in-place momentum update of running_mean / running_var (unbiased variance, like F.batch_norm; both NULL = skip).
+ *   count = N * n elements per channel.  abs_eps >= 0: gamma = |weight| + abs_eps (InPlaceABN), otherwise gamma = weight.
+ * casmvs_abn_backward_finish_f32: from the partial sums of casmvs_abn_backward_sums_f64 to grad_bias = sum g,
+ *   grad_weight = sum g xhat (times sign(weight) when abs_eps >= 0), m1 = sum g / count, m2 = sum g xhat / count.
  * casmvs_upsample2x_add_f32 / casmvs_upsample2x_backward_f32: out (N,C,H,W) = lat + bilinear x2 (align_corners = True) of
  *   up (N,C,H/2,W/2) (mvsnet.py:36-38); grad_up = the transpose of the interpolation applied to grad_out (a gather).
  * casmvs_costvol_var_backward_f32: gradient of the variance volume (mvsnet.py:137-167) w.r.t. feats (B,V,C,h,w) given
@@ -319,6 +327,13 @@ int casmvs_abn_backward_sums_f64(const float *grad_y, const float *y, const floa
 int casmvs_abn_backward_apply_f32(const float *grad_y, const float *y, const float *x, const float *scale, const float *mean,
                                   const float *rstd, const float *m1, const float *m2, float *grad_x, int N, int C, size_t n,
                                   float slope, void *stream);
+int casmvs_pack_gather_f32(const float *weight, const float *bias, const int *index, float *out, int n_weight, int n_bias,
+                           int n_out, void *stream);
+int casmvs_abn_train_finish_f32(const double *sums, int blocks, int C, double count, const float *weight, const float *bias,
+                                float abs_eps, float eps, float momentum, float *running_mean, float *running_var, float *scale,
+                                float *shift, float *mean, float *rstd, void *stream);
+int casmvs_abn_backward_finish_f32(const double *sums, int blocks, int C, double count, const float *weight, float abs_eps,
+                                   float *grad_weight, float *grad_bias, float *m1, float *m2, void *stream);
 int casmvs_upsample2x_add_f32(const float *lat, const float *up, float *out, int N, int C, int H, int W, void *stream);
 int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad_up, int N, int C, int H, int W, void *stream);
 int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,

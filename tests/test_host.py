@@ -157,19 +157,34 @@ def test_full_model_in_train_mode_takes_the_training_path_and_refuses_cpu():
 
 
 def test_device_pack_map_reproduces_the_host_packing():
-    """training.device_pack (one index_select) must give the image casmvs_conv{2,3}d_pack_f32 gives (scale 1, shift = bias)."""
+    """training._pack_map (the index casmvs_pack_gather_f32 applies on the device) must give the image
+    casmvs_conv{2,3}d_pack_f32 gives (scale 1, shift = bias) - also for the adjoint layer of a stride-1 convolution, whose
+    transpose + tap mirror is folded into the index."""
     from casmvsnet_pl_amd import training as T
     g = torch.Generator().manual_seed(3)
     cases = [(ops.CONV_S1, (8, 16, 3, 3, 3), False), (ops.CONV_S1, (1, 8, 3, 3, 3), True), (ops.CONV_S2, (32, 16, 3, 3, 3), False),
              (ops.CONV_T2, (64, 32, 3, 3, 3), False), (ops.CONV_T2, (16, 8, 3, 3, 3), False), (ops.CONV2D_K3, (8, 3, 3, 3), False),
              (ops.CONV2D_K3, (8, 32, 3, 3), True), (ops.CONV2D_K5S2, (16, 8, 5, 5), False), (ops.CONV2D_K1, (32, 8, 1, 1), True)]
+
+    def gather(kind, w, b, adjoint):
+        cin, cout = (w.shape[:2] if (kind == ops.CONV_T2) != adjoint else w.shape[:2][::-1])
+        idx = T._pack_map(kind, cin, cout, b is not None, "cpu", adjoint).long()
+        assert idx.dtype == torch.int64 and T._pack_map(kind, cin, cout, b is not None, "cpu", adjoint).dtype == torch.int32
+        src = torch.cat([w.reshape(-1)] + ([b] if b is not None else []) + [torch.tensor([0.0, 1.0])])
+        return src[idx]
+
     for kind, shape, has_bias in cases:
         w = torch.randn(shape, generator=g)
         cout = shape[1] if kind == ops.CONV_T2 else shape[0]
         b = torch.randn(cout, generator=g) if has_bias else None
-        want = (ops.conv3d_pack if len(shape) == 5 else ops.conv2d_pack)(kind, w, None, b)
-        got = T.device_pack(kind, w, b)   # CPU tensors: the map itself is device-agnostic
-        assert torch.equal(got, want), (kind, shape)
+        pack = ops.conv3d_pack if len(shape) == 5 else ops.conv2d_pack
+        assert torch.equal(gather(kind, w, b, False), pack(kind, w, None, b)), (kind, shape)
+    for kind, shape in [(ops.CONV_S1, (8, 16, 3, 3, 3)), (ops.CONV_S1, (16, 16, 3, 3, 3)), (ops.CONV2D_K3, (16, 32, 3, 3)), (ops.CONV2D_K1, (32, 32, 1, 1))]:
+        w = torch.randn(shape, generator=g)      # stored (cout, cin, k...): the input-gradient layer maps cout -> cin channels
+        adj = w.transpose(0, 1)
+        adj = adj.flip(tuple(range(2, len(shape)))) if shape[2] > 1 else adj
+        pack = ops.conv3d_pack if len(shape) == 5 else ops.conv2d_pack
+        assert torch.equal(gather(kind, w, None, True), pack(kind, adj.contiguous(), None, None)), (kind, shape)
 
 
 def test_dropin_import_paths():
