@@ -49,8 +49,8 @@ struct WgradCfg {
   static constexpr size_t LDS_BYTES = (size_t)(TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS) * sizeof(float);
 };
 
-template <int S, int KZ, int KS>
-__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__restrict__ small, const float *__restrict__ big,
+template <int S, int KZ, int KS, bool VEC>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const float *__restrict__ small, const float *__restrict__ big,
                                                              float *__restrict__ partial, int B, int Cs, int Cb, int Zs,
                                                              int Ys, int Xs, int cb_groups, int tiles_z, int tiles_y, int tiles_x) {
   using Cfg = WgradCfg<S, KZ, KS>;
@@ -75,48 +75,124 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(const float *__res
     const int tz = r % tiles_z, b = r / tiles_z;
     const int oz0 = tz * TZ, oy0 = ty * TY, ox0 = tx * Cfg::TX;
     __syncthreads();   // the previous tile's operands are no longer read
-    // Staging in batches of 8 elements per thread: all 8 loads are issued (from clamped, always valid addresses; the value
-    // is zeroed by a select when the element lies outside the grid / beyond the channel count) before the first LDS
-    // write - written as `if (inside) v = load` per element the loads complete one after the other (a memory latency each).
-    constexpr int UB = 8;
-    // small tile: 16 channels x NPOS positions (q = (z * TY + y) * 16 + x)
-    for (int e0 = 0; e0 < 16 * NPOS; e0 += UB * kThreads) {
-      float v[UB];
-#pragma unroll
-      for (int i = 0; i < UB; ++i) {
-        const int e = min(e0 + threadIdx.x + i * kThreads, 16 * NPOS - 1);
-        const int c = e / NPOS, q = e - c * NPOS, oz = oz0 + q / (TY * 16), oy = oy0 + (q >> 4) % TY, ox = ox0 + (q & 15), ch = rt * 16 + c;
-        const bool ok = ch < Cs && oz < Zs && oy < Ys && ox < Xs;
-        const float l = small[((size_t)b * Cs + min(ch, Cs - 1)) * small_cs + ((size_t)min(oz, Zs - 1) * Ys + min(oy, Ys - 1)) * Xs + min(ox, Xs - 1)];
-        v[i] = ok ? l : 0.0f;
-      }
-#pragma unroll
-      for (int i = 0; i < UB; ++i) {
-        const int e = e0 + threadIdx.x + i * kThreads;
-        if (e < 16 * NPOS) smallT[(e / NPOS) * SS + (e % NPOS)] = v[i];
-      }
-    }
-    // big tile: 16 channels x the footprint of the tile's taps, zero padding outside the grid / beyond Cb
     const int bz0 = (KZ == 1 ? 0 : oz0 * S) - Cfg::PZ, by0 = oy0 * S - Cfg::P, bx0 = ox0 * S - Cfg::P;
-    constexpr int NBIG = 16 * IZ * IY * IX;
-    for (int e0 = 0; e0 < NBIG; e0 += UB * kThreads) {
-      float v[UB];
-      int lo[UB];
+    if constexpr (VEC) {
+      // Staging in 16-byte units (grid widths % 4 == 0, 16-byte aligned tensors of at most 2^31 bytes): a tile row of the
+      // small grid is 4 aligned vectors; a row of the big tile is P halo floats, 4 S aligned vectors, KS - P - S halo floats.
+      // Buffer loads: a unit outside the grid / beyond the channel count carries the offset kOOB and the hardware returns
+      // zeros (the padding).  All loads of a tile are in flight before the first LDS write: one memory round trip, and ~6x
+      // fewer index computations than element-wise staging (which cost as many issue cycles as the tile's MFMAs).
+      constexpr int kOOB = (int)0x80000000u;
+      constexpr int ROWS = Cfg::ROWS, P = Cfg::P;
+      constexpr int SU = 16 * ROWS * 4, NSU = (SU + kThreads - 1) / kThreads;
+      constexpr int RB = 16 * IZ * IY, VPR = 4 * S, BU = RB * VPR, NBU = (BU + kThreads - 1) / kThreads;
+      constexpr int NH = KS - S, HU = RB * NH, NHU = (HU + kThreads - 1) / kThreads;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(small), 0, (int)((size_t)B * Cs * small_cs * 4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(big), 0, (int)((size_t)B * Cb * big_cs * 4), 0x00020000);
+      f32x4 sv[NSU], bv[NBU];
+      float hv[NHU > 0 ? NHU : 1];
 #pragma unroll
-      for (int i = 0; i < UB; ++i) {
-        const int e = e0 + threadIdx.x + i * kThreads;
-        const int ec = min(e, NBIG - 1);
-        const int c = ec / (IZ * IY * IX), rem = ec - c * (IZ * IY * IX);
-        const int iz = rem / (IY * IX), rem2 = rem - iz * (IY * IX), iy = rem2 / IX, ix = rem2 - iy * IX;
-        const int gz = bz0 + iz, gy = by0 + iy, gx = bx0 + ix, ch = cg * 16 + c;
-        const bool ok = ch < Cb && gz >= 0 && gz < Zb && gy >= 0 && gy < Yb && gx >= 0 && gx < Xb;
-        const float l = big[((size_t)b * Cb + min(ch, Cb - 1)) * big_cs + ((size_t)min(max(gz, 0), Zb - 1) * Yb + min(max(gy, 0), Yb - 1)) * Xb + min(max(gx, 0), Xb - 1)];
-        v[i] = ok ? l : 0.0f;
-        lo[i] = e < NBIG ? c * SC + iz * SZ + iy * SY + ix : -1;
+      for (int i = 0; i < NSU; ++i) {
+        const int u = (int)threadIdx.x + i * kThreads;
+        const int c = u / (ROWS * 4), r = (u >> 2) % ROWS, k = u & 3;
+        const int oz = oz0 + r / TY, oy = oy0 + r % TY, ox = ox0 + 4 * k, ch = rt * 16 + c;
+        const bool ok = u < SU && ch < Cs && oz < Zs && oy < Ys && ox < Xs;
+        sv[i] = buf_load4(rs, ok ? ((((b * Cs + ch) * Zs + oz) * Ys + oy) * Xs + ox) * 4 : kOOB, 0);
+      }
+      if constexpr (NH > 0) {
+#pragma unroll
+        for (int i = 0; i < NHU; ++i) {
+          const int u = (int)threadIdx.x + i * kThreads;
+          const int row = u / NH, h = u - row * NH, c = row / (IZ * IY), rem = row - c * (IZ * IY), iz = rem / IY, iy = rem - iz * IY;
+          const int ix = h < P ? h : 16 * S + h;   // left halo 0 .. P-1, right halo P + 16 S ...
+          const int gz = bz0 + iz, gy = by0 + iy, gx = bx0 + ix, ch = cg * 16 + c;
+          const bool ok = u < HU && ch < Cb && gz >= 0 && gz < Zb && gy >= 0 && gy < Yb && gx >= 0 && gx < Xb;
+          hv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, ok ? ((((b * Cb + ch) * Zb + gz) * Yb + gy) * Xb + gx) * 4 : kOOB, 0, 0));
+        }
       }
 #pragma unroll
-      for (int i = 0; i < UB; ++i)
-        if (lo[i] >= 0) bigT[lo[i]] = v[i];
+      for (int i = 0; i < NSU; ++i) {
+        const int u = (int)threadIdx.x + i * kThreads;
+        if (u < SU) {
+          float *dst = smallT + (u / (ROWS * 4)) * SS + ((u >> 2) % ROWS) * 16 + 4 * (u & 3);
+          dst[0] = sv[i][0]; dst[1] = sv[i][1]; dst[2] = sv[i][2]; dst[3] = sv[i][3];
+        }
+      }
+      // the big tile's vectors in batches of at most 10 units per thread (40 registers in flight; 2 x 7 for the 14 of the stride-2 3D form)
+      constexpr int UBV = NBU <= 10 ? 10 : 7;
+#pragma unroll
+      for (int i0 = 0; i0 < NBU; i0 += UBV) {
+#pragma unroll
+        for (int i = i0; i < (i0 + UBV < NBU ? i0 + UBV : NBU); ++i) {
+          const int u = (int)threadIdx.x + i * kThreads;
+          const int row = u / VPR, k = u - row * VPR, c = row / (IZ * IY), rem = row - c * (IZ * IY), iz = rem / IY, iy = rem - iz * IY;
+          const int gz = bz0 + iz, gy = by0 + iy, gx = bx0 + P + 4 * k, ch = cg * 16 + c;
+          const bool ok = u < BU && ch < Cb && gz >= 0 && gz < Zb && gy >= 0 && gy < Yb && gx < Xb;
+          bv[i] = buf_load4(rb, ok ? ((((b * Cb + ch) * Zb + gz) * Yb + gy) * Xb + gx) * 4 : kOOB, 0);
+        }
+#pragma unroll
+        for (int i = i0; i < (i0 + UBV < NBU ? i0 + UBV : NBU); ++i) {
+          const int u = (int)threadIdx.x + i * kThreads;
+          if (u < BU) {
+            const int row = u / VPR, k = u - row * VPR, c = row / (IZ * IY), rem = row - c * (IZ * IY), iz = rem / IY, iy = rem - iz * IY;
+            float *dst = bigT + c * SC + iz * SZ + iy * SY + P + 4 * k;
+            dst[0] = bv[i][0]; dst[1] = bv[i][1]; dst[2] = bv[i][2]; dst[3] = bv[i][3];
+          }
+        }
+      }
+      if constexpr (NH > 0) {
+#pragma unroll
+        for (int i = 0; i < NHU; ++i) {
+          const int u = (int)threadIdx.x + i * kThreads;
+          if (u < HU) {
+            const int row = u / NH, h = u - row * NH, c = row / (IZ * IY), rem = row - c * (IZ * IY), iz = rem / IY, iy = rem - iz * IY;
+            bigT[c * SC + iz * SZ + iy * SY + (h < P ? h : 16 * S + h)] = hv[i];
+          }
+        }
+      }
+    } else {
+      // Scalar staging (any width / alignment) in batches of 8 elements per thread: all 8 loads are issued (from clamped, always
+      // valid addresses; the value is zeroed by a select when the element lies outside the grid / beyond the channel count)
+      // before the first LDS write.
+      constexpr int UB = 8;
+      // small tile: 16 channels x NPOS positions (q = (z * TY + y) * 16 + x)
+      for (int e0 = 0; e0 < 16 * NPOS; e0 += UB * kThreads) {
+        float v[UB];
+  #pragma unroll
+        for (int i = 0; i < UB; ++i) {
+          const int e = min(e0 + threadIdx.x + i * kThreads, 16 * NPOS - 1);
+          const int c = e / NPOS, q = e - c * NPOS, oz = oz0 + q / (TY * 16), oy = oy0 + (q >> 4) % TY, ox = ox0 + (q & 15), ch = rt * 16 + c;
+          const bool ok = ch < Cs && oz < Zs && oy < Ys && ox < Xs;
+          const float l = small[((size_t)b * Cs + min(ch, Cs - 1)) * small_cs + ((size_t)min(oz, Zs - 1) * Ys + min(oy, Ys - 1)) * Xs + min(ox, Xs - 1)];
+          v[i] = ok ? l : 0.0f;
+        }
+  #pragma unroll
+        for (int i = 0; i < UB; ++i) {
+          const int e = e0 + threadIdx.x + i * kThreads;
+          if (e < 16 * NPOS) smallT[(e / NPOS) * SS + (e % NPOS)] = v[i];
+        }
+      }
+      // big tile: 16 channels x the footprint of the tile's taps, zero padding outside the grid / beyond Cb
+      constexpr int NBIG = 16 * IZ * IY * IX;
+      for (int e0 = 0; e0 < NBIG; e0 += UB * kThreads) {
+        float v[UB];
+        int lo[UB];
+  #pragma unroll
+        for (int i = 0; i < UB; ++i) {
+          const int e = e0 + threadIdx.x + i * kThreads;
+          const int ec = min(e, NBIG - 1);
+          const int c = ec / (IZ * IY * IX), rem = ec - c * (IZ * IY * IX);
+          const int iz = rem / (IY * IX), rem2 = rem - iz * (IY * IX), iy = rem2 / IX, ix = rem2 - iy * IX;
+          const int gz = bz0 + iz, gy = by0 + iy, gx = bx0 + ix, ch = cg * 16 + c;
+          const bool ok = ch < Cb && gz >= 0 && gz < Zb && gy >= 0 && gy < Yb && gx >= 0 && gx < Xb;
+          const float l = big[((size_t)b * Cb + min(ch, Cb - 1)) * big_cs + ((size_t)min(max(gz, 0), Zb - 1) * Yb + min(max(gy, 0), Yb - 1)) * Xb + min(max(gx, 0), Xb - 1)];
+          v[i] = ok ? l : 0.0f;
+          lo[i] = e < NBIG ? c * SC + iz * SZ + iy * SY + ix : -1;
+        }
+  #pragma unroll
+        for (int i = 0; i < UB; ++i)
+          if (lo[i] >= 0) bigT[lo[i]] = v[i];
+      }
     }
     __syncthreads();
     // this wave's rows (z, y) of the tile, four k-steps (positions ox = 4 ks + kq) each
@@ -221,6 +297,49 @@ __global__ __launch_bounds__(kThreads) void conv_dgrad_direct_kernel(const float
     }
   }
   gin[((size_t)b * cin + ci) * in_cs + p] = acc;
+}
+
+// The same sum for ALL CIN input channels of a position in one thread: a grad_out value is loaded once and used CIN times (the
+// per-channel form above re-read it per channel and spent its time in the tap loop's divergent `continue`s: 370 us per layer).
+// The taps that reach an input position are enumerated directly (t = t0, t0 + S, ...: t = (p + P) mod S is the first with
+// S o = p + P - t), in the same ascending (tz, ty, tx, co) order: bit-identical results.
+template <int CIN>
+__global__ __launch_bounds__(kThreads) void conv_dgrad_direct_all_kernel(const float *__restrict__ gout, const float *__restrict__ w,
+                                                                        float *__restrict__ gin, int cout, int Zi, int Yi, int Xi, int S,
+                                                                        int KZ, int KS) {
+  const int b = blockIdx.z;
+  const size_t in_cs = (size_t)Zi * Yi * Xi;
+  const size_t p = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (p >= in_cs) return;
+  const int x = (int)(p % Xi), y = (int)((p / Xi) % Yi), z = (int)(p / ((size_t)Xi * Yi));
+  const int Sz = KZ == 1 ? 1 : S;   // 2D layers: one plane
+  const int Zo = Zi / Sz, Yo = Yi / S, Xo = Xi / S, PZ = KZ / 2, P = KS / 2, T = KZ * KS * KS;
+  const size_t out_cs = (size_t)Zo * Yo * Xo;
+  float acc[CIN];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.0f;
+  for (int tz = (z + PZ) % Sz; tz < KZ; tz += Sz) {
+    const int oz = (z + PZ - tz) / Sz;
+    if (z + PZ - tz < 0 || oz >= Zo) continue;
+    for (int ty = (y + P) % S; ty < KS; ty += S) {
+      const int oy = (y + P - ty) / S;
+      if (y + P - ty < 0 || oy >= Yo) continue;
+      for (int tx = (x + P) % S; tx < KS; tx += S) {
+        const int ox = (x + P - tx) / S;
+        if (x + P - tx < 0 || ox >= Xo) continue;
+        const size_t o = ((size_t)oz * Yo + oy) * Xo + ox;
+        const int t = (tz * KS + ty) * KS + tx;
+        for (int co = 0; co < cout; ++co) {
+          const float g = gout[((size_t)b * cout + co) * out_cs + o];
+          const float *wr = w + (size_t)co * CIN * T + t;
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(g, wr[ci * T], acc[ci]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci) gin[((size_t)b * CIN + ci) * in_cs + p] = acc[ci];
 }
 
 // ---- per-channel sums (batch statistics, bias gradients, ABN backward reductions) ------------------------------------
@@ -641,14 +760,24 @@ bool wgrad_launch(int kind, int B, int cin, int cout, int D, int H, int W, Wgrad
   return true;
 }
 
-template <int S, int KZ, int KS>
-int launch_wgrad(const WgradLaunch &l, const float *small, const float *big, float *partial, int B, hipStream_t st) {
-  auto kernel = conv_wgrad_kernel<S, KZ, KS>;
+template <int S, int KZ, int KS, bool VEC>
+int launch_wgrad_v(const WgradLaunch &l, const float *small, const float *big, float *partial, int B, hipStream_t st) {
+  auto kernel = conv_wgrad_kernel<S, KZ, KS, VEC>;
   const size_t lds = WgradCfg<S, KZ, KS>::LDS_BYTES;
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "conv_wgrad_kernel")) return rc;
   hipLaunchKernelGGL(kernel, dim3((unsigned)l.gx, (unsigned)l.gy), dim3(kThreads), lds, st, small, big, partial, B, l.Cs, l.Cb, l.Zs,
                      l.Ys, l.Xs, l.cb_groups, l.tiles_z, l.tiles_y, l.tiles_x);
   return casmvs::check_launch("conv_wgrad_kernel");
+}
+
+template <int S, int KZ, int KS>
+int launch_wgrad(const WgradLaunch &l, const float *small, const float *big, float *partial, int B, hipStream_t st) {
+  // 16-byte staging: grid rows that start 16-byte aligned and tensors a 32-bit buffer offset can address
+  const size_t small_bytes = (size_t)B * l.Cs * l.Zs * l.Ys * l.Xs * 4;
+  const size_t big_bytes = (size_t)B * l.Cb * (KZ == 1 ? 1 : l.Zs * S) * (l.Ys * S) * (l.Xs * S) * 4;
+  const bool vec = l.Xs % 4 == 0 && small_bytes <= (1ull << 31) && big_bytes <= (1ull << 31) &&
+                   (reinterpret_cast<size_t>(small) & 15) == 0 && (reinterpret_cast<size_t>(big) & 15) == 0;
+  return vec ? launch_wgrad_v<S, KZ, KS, true>(l, small, big, partial, B, st) : launch_wgrad_v<S, KZ, KS, false>(l, small, big, partial, B, st);
 }
 
 }  // namespace
@@ -694,6 +823,16 @@ extern "C" int casmvs_conv_dgrad_direct_f32(int kind, const float *weight, const
   CASMVS_REQUIRE(B > 0 && B <= 65535 && cin > 0 && cin <= 65535 && cout > 0 && D > 0 && H > 0 && W > 0 && (g.KZ == 3 || D == 1),
                  "conv_dgrad_direct: bad shape B=%d cin=%d cout=%d %dx%dx%d", B, cin, cout, D, H, W);
   const size_t in_cs = (size_t)D * H * W;
+  if (cin == 8 || cin == 16) {
+    dim3 grid_all((unsigned)((in_cs + kThreads - 1) / kThreads), 1u, (unsigned)B);
+    if (cin == 8)
+      hipLaunchKernelGGL(conv_dgrad_direct_all_kernel<8>, grid_all, dim3(kThreads), 0, (hipStream_t)stream, grad_out, weight, grad_in, cout, D,
+                         H, W, g.S, g.KZ, g.KS);
+    else
+      hipLaunchKernelGGL(conv_dgrad_direct_all_kernel<16>, grid_all, dim3(kThreads), 0, (hipStream_t)stream, grad_out, weight, grad_in, cout, D,
+                         H, W, g.S, g.KZ, g.KS);
+    return casmvs::check_launch("conv_dgrad_direct_all_kernel");
+  }
   dim3 grid((unsigned)((in_cs + kThreads - 1) / kThreads), (unsigned)cin, (unsigned)B);
   hipLaunchKernelGGL(conv_dgrad_direct_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, grad_out, weight, grad_in, cin, cout, D, H, W,
                      g.S, g.KZ, g.KS);

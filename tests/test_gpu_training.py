@@ -56,6 +56,11 @@ _CONV_CASES = [
     ("CONV2D_K1", (32, 32, 1, 1), (6, 10), True, True),           # toplayer
     ("CONV2D_K1", (32, 16, 1, 1), (12, 20), True, True),          # lat1
     ("CONV2D_K1", (32, 8, 1, 1), (24, 40), True, True),           # lat0 (direct input-gradient kernel)
+    # widths % 4 == 0: the 16-byte staging of the weight-gradient kernel in its strided / transposed / ragged-tile forms
+    ("CONV_S2", (16, 8, 3, 3, 3), (8, 16, 24), False, True),
+    ("CONV_T2", (16, 8, 3, 3, 3), (4, 8, 12), False, True),
+    ("CONV_S1", (8, 16, 3, 3, 3), (5, 10, 36), False, True),
+    ("CONV2D_K5S2", (32, 16, 5, 5), (20, 72), False, True),
 ]
 
 
