@@ -3,20 +3,19 @@
 
 reference op (train mode)                              here
 nn.Conv2d / Conv3d / ConvTranspose3d forward           the inference MFMA kernels, un-folded (scale 1, slope 1): `conv`
-  ... gradient w.r.t. the input                        the SAME forward kernels with adjoint weights (a transposed / flipped
-                                                       weight tensor, or the strided <-> transposed kind); the three layer shapes
+  ... gradient w.r.t. the input                        the SAME forward kernels with adjoint weights (transposed / mirrored through
+                                                       the packing index, or the strided <-> transposed kind); the three layer shapes
                                                        without such a twin (Conv2d k5 s2, the 8-channel 1x1 lateral) use
                                                        casmvs_conv_dgrad_direct_f32
   ... gradient w.r.t. the weight / bias                casmvs_conv_wgrad_f32 (matrix cores) / casmvs_channel_sums_f64
-ABN / InPlaceABN in train mode (modules.py:14,27)      casmvs_channel_sums_f64 + casmvs_abn_apply_f32; backward
-                                                       casmvs_abn_backward_{sums_f64,apply_f32}; running statistics updated
+ABN / InPlaceABN in train mode (modules.py:14,27)      casmvs_channel_sums_f64 -> casmvs_abn_train_finish_f32 -> casmvs_abn_apply_f32;
+                                                       backward casmvs_abn_backward_{sums_f64,finish_f32,apply_f32}; running statistics updated
 F.interpolate(x2, bilinear, align_corners) + lateral   casmvs_upsample2x_add_f32 / casmvs_upsample2x_backward_f32
 homo_warp + variance volume (mvsnet.py:137-167)        fused forward kernel; casmvs_costvol_var_backward_f32
 softmax + depth regression (mvsnet.py:175-177)         autograd.softmax_depth_regression
 
-torch is the autograd tape, the allocator and the per-channel (C floats) arithmetic around the kernels; skip additions
-of the U-Net are torch adds.  Nothing here runs on CPU tensors.  Not tuned for speed: the backward kernels are
-straightforward (see DESIGN.md 2.6 for measured step times).
+torch is the autograd tape and the allocator; the skip additions of the U-Net and the gradient accumulation are torch adds.  Nothing here runs on CPU tensors.  DESIGN.md 2.6 has the kernels and the measured step
+times (18 ms per step at the reference's default training configuration, 15 ms captured as one hipGraph).
 """
 import ctypes
 
