@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   constexpr int TS = 32, RPT = TS * TS / kThreads, RSTEP = kThreads / TS;
   extern __shared__ float smem[];
   float *box = smem;   // [CG][bh][bw], CAP cells per channel
-  __shared__ int ext[4];
+  __shared__ int ext[(TS * TS / kThreads + 1) * 4];   // tap boxes of the tile's RPT bands of 8 rows, then their union
   const int tid = threadIdx.x, b = blockIdx.z, hw = H * W;
   int r = blockIdx.y;
   const int v = 1 + r % (V - 1); r /= (V - 1);
@@ -590,31 +590,53 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   const float *db = depth + (size_t)b * D * hw;
   const float fV = (float)V;
 
-  // ---- 1. bounding box of this view's live taps
-  if (tid < 4) ext[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+  // ---- 1. bounding boxes of this view's live taps: the tile's, and (published only when the tile's does not fit the LDS
+  // image) one per band of RSTEP rows (a thread's j-th pixel)
+  if (tid < (RPT + 1) * 4) ext[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+  __syncthreads();
+  int bxmn[RPT], bxmx[RPT], bymn[RPT], bymx[RPT];
   int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
-  if (x < W) {
-    for (int j = 0; j < RPT; ++j) {
-      const int y = yb + j * RSTEP;
-      if (y >= H) break;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    bxmn[j] = INT_MAX; bxmx[j] = INT_MIN; bymn[j] = INT_MAX; bymx[j] = INT_MIN;
+    const int y = yb + j * RSTEP;
+    if (x < W && y < H) {
       for (int d = d_begin; d < d_end; ++d) {
         const Taps t = plane_sweep_taps(Pv, (float)x, (float)y, db[(size_t)d * hw + y * W + x], W, H);
         if (taps_live(t)) {
-          xmn = min(xmn, t.xl); xmx = max(xmx, t.xl + 1);
-          ymn = min(ymn, t.yn); ymx = max(ymx, t.ys);
+          bxmn[j] = min(bxmn[j], t.xl); bxmx[j] = max(bxmx[j], t.xl + 1);
+          bymn[j] = min(bymn[j], t.yn); bymx[j] = max(bymx[j], t.ys);
         }
       }
     }
+    xmn = min(xmn, bxmn[j]); xmx = max(xmx, bxmx[j]);
+    ymn = min(ymn, bymn[j]); ymx = max(ymx, bymx[j]);
   }
-  __syncthreads();
   if (xmn <= xmx) {
-    atomicMin(&ext[0], xmn); atomicMax(&ext[1], xmx);
-    atomicMin(&ext[2], ymn); atomicMax(&ext[3], ymx);
+    atomicMin(&ext[RPT * 4 + 0], xmn); atomicMax(&ext[RPT * 4 + 1], xmx);
+    atomicMin(&ext[RPT * 4 + 2], ymn); atomicMax(&ext[RPT * 4 + 3], ymx);
   }
   __syncthreads();
-  const int bx0 = ext[0], by0 = ext[2];
-  const bool any = ext[0] <= ext[1];
-  const int bw = any ? ext[1] - ext[0] + 1 : 0, bh = any ? ext[3] - ext[2] + 1 : 0;
+  // The whole tile's box in one LDS image when it fits; otherwise band by band (noisy depth maps spread a tile's taps over
+  // far more than its own extent), and a band whose box still does not fit scatters straight to global memory.
+  const bool whole = ext[RPT * 4] > ext[RPT * 4 + 1] ||
+                     (ext[RPT * 4 + 1] - ext[RPT * 4] + 1) * (ext[RPT * 4 + 3] - ext[RPT * 4 + 2] + 1) <= CAP;
+  if (!whole) {
+#pragma unroll
+    for (int j = 0; j < RPT; ++j)
+      if (bxmn[j] <= bxmx[j]) {
+        atomicMin(&ext[j * 4 + 0], bxmn[j]); atomicMax(&ext[j * 4 + 1], bxmx[j]);
+        atomicMin(&ext[j * 4 + 2], bymn[j]); atomicMax(&ext[j * 4 + 3], bymx[j]);
+      }
+    __syncthreads();
+  }
+  float *gsv = gb + ((size_t)v * C + c0) * hw;
+  const int lane = tid & 63;
+  for (int seg = 0; seg < (whole ? 1 : RPT); ++seg) {
+  const int *eb = ext + (whole ? RPT : seg) * 4;
+  const int bx0 = eb[0], by0 = eb[2];
+  const bool any = eb[0] <= eb[1];
+  const int bw = any ? eb[1] - eb[0] + 1 : 0, bh = any ? eb[3] - eb[2] + 1 : 0;
   const bool in_lds = bw * bh <= CAP;
   const int cells = bw * bh;
   if (in_lds)
@@ -622,11 +644,9 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   __syncthreads();
 
   // ---- 2. per (pixel, plane): S over the views, own view's gradient into the box
-  float *gsv = gb + ((size_t)v * C + c0) * hw;
-  const int lane = tid & 63;
   // every lane runs the loops (the lanes exchange tap gradients with their neighbours by DPP below); a lane outside the
   // image works on a clamped pixel with a zero upstream gradient and never adds anything
-  for (int j = 0; j < RPT; ++j) {
+  for (int j = whole ? 0 : seg; j < (whole ? RPT : seg + 1); ++j) {
     const int yr = yb + j * RSTEP;
     const bool valid = x < W && yr < H;
     const int xc = min(x, W - 1), y = min(yr, H - 1), p = y * W + xc;
@@ -711,6 +731,8 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
         unsafeAtomicAdd(gsv + (size_t)c * hw + (by0 + row) * W + bx0 + col, val);
       }
     }
+  }
+  __syncthreads();   // the image is zeroed again for the next band
   }
 }
 

@@ -1,5 +1,5 @@
 """Variance cost-volume backward (casmvs_costvol_var_backward_f32) at the three cascade levels of the reference's training
-configuration (batch 1, 3 views, 640x512): µs per call.   python tools/gpu_varbwd_probe.py [H W [V [B]]]"""
+configuration (batch 1, 3 views, 640x512): µs per call.   [VB_PROBE_NOISE_MM=30] python tools/gpu_varbwd_probe.py [H W [V [B]]]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,6 +23,9 @@ for level, (C, D, ratio) in {2: (32, 48, 4.0), 1: (16, 32, 2.0), 0: (8, 8, 1.0)}
         yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
         centre = 600.0 + 40.0 * torch.sin(xx / w * 6.0) * torch.cos(yy / h * 5.0)
         depth = (centre.view(1, 1, h, w) + dint * ratio * (torch.arange(D).float() - D / 2).view(1, D, 1, 1)).expand(B, D, h, w).contiguous()
+    noise = float(os.environ.get("VB_PROBE_NOISE_MM", "0"))   # per-pixel noise of the surface (an untrained model's depth maps)
+    if noise > 0 and level != 2:
+        depth = depth + noise * torch.randn(B, 1, h, w, generator=g)
     depth = depth.to(dev)
     vol = T.variance_volume(feats, P, depth)
     gv = torch.randn(vol.shape, generator=g).to(dev)
