@@ -261,3 +261,40 @@ def emulate_fpn_lateral(x, w, b, up):
             h0, h1 = r0 @ T.T, r1 @ T.T                               # (cout, 4 pixels)
             out[:, y, ox:ox + 4] = lat[:, y, ox:ox + 4] + (ly0 * h0 + ly1 * h1)
     return out
+
+
+# ---- weight-gradient kernel: 16-byte staging of a tile (csrc/train.hip, conv_wgrad_kernel<S, KZ, KS, VEC = true>) ----------
+def wgrad_cfg(S, KZ, KS):
+    """WgradCfg<S, KZ, KS> of train.hip."""
+    TZ = 4 if (KZ == 3 and S == 1) else 1
+    TY, TX = 4, 16
+    IZ, IY, IX = (TZ - 1) * S + KZ, (TY - 1) * S + KS, (TX - 1) * S + KS
+    return dict(TZ=TZ, TY=TY, TX=TX, ROWS=TZ * TY, P=KS // 2, PZ=KZ // 2, IZ=IZ, IY=IY, IX=IX)
+
+
+def wgrad_vector_staging_units(S, KZ, KS, threads=256):
+    """The (kind, LDS cell(s), element offsets relative to the tile origin) every thread writes in the vector staging, in
+    the kernel's own index arithmetic: 'small' units (c, row, 4 x), 'big' vector units (c, iz, iy, ix .. ix + 3), halo
+    scalars (c, iz, iy, ix)."""
+    g = wgrad_cfg(S, KZ, KS)
+    ROWS, P, IZ, IY, IX = g["ROWS"], g["P"], g["IZ"], g["IY"], g["IX"]
+    small, big = [], []
+    SU = 16 * ROWS * 4
+    for u in range(_ru(SU, threads)):
+        if u < SU:
+            c, r, k = u // (ROWS * 4), (u >> 2) % ROWS, u & 3
+            small += [(c, r, 4 * k + j) for j in range(4)]
+    RB, VPR, NH = 16 * IZ * IY, 4 * S, KS - S
+    for u in range(_ru(RB * VPR, threads)):
+        if u < RB * VPR:
+            row, k = divmod(u, VPR)
+            c, rem = divmod(row, IZ * IY)
+            iz, iy = divmod(rem, IY)
+            big += [(c, iz, iy, P + 4 * k + j) for j in range(4)]
+    for u in range(_ru(RB * NH, threads) if NH > 0 else 0):
+        if u < RB * NH:
+            row, h = divmod(u, NH)
+            c, rem = divmod(row, IZ * IY)
+            iz, iy = divmod(rem, IY)
+            big.append((c, iz, iy, h if h < P else 16 * S + h))
+    return g, small, big

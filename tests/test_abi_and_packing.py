@@ -151,3 +151,17 @@ def test_fpn_lateral_window_and_tent_weights_reproduce_interpolate(H, W):
     want = F.interpolate(up[None], scale_factor=2, mode="bilinear", align_corners=True)[0] + F.conv2d(x[None], w[:, :, None, None], b)[0]
     got = KM.emulate_fpn_lateral(x.numpy(), w.numpy(), b.numpy(), up.numpy())
     assert abs(got - want.numpy()).max() < 1e-4
+
+
+@pytest.mark.parametrize("S,KZ,KS", [(1, 3, 3), (2, 3, 3), (1, 1, 3), (2, 1, 5), (1, 1, 1)])
+def test_wgrad_vector_staging_writes_every_tile_cell_exactly_once(S, KZ, KS):
+    """The 16-byte staging of the weight-gradient kernel (train.hip): a big-tile row = P halo floats + 4 S aligned vectors +
+    (KS - P - S) halo floats.  Its units must cover the [16][IZ][IY][IX] operand tile and the [16][ROWS][16] small tile
+    exactly once (a missed cell would be stale data of the previous tile, a doubled one a wasted load), and the vector
+    units must start 16-byte aligned relative to the tile origin (x0 * S - P + ix with x0 % 16 == 0)."""
+    g, small, big = KM.wgrad_vector_staging_units(S, KZ, KS)
+    assert sorted(small) == [(c, r, x) for c in range(16) for r in range(g["ROWS"]) for x in range(16)]
+    assert sorted(big) == [(c, iz, iy, ix) for c in range(16) for iz in range(g["IZ"]) for iy in range(g["IY"]) for ix in range(g["IX"])]
+    # a vector unit's first element: global x = x0 * S - P + (P + 4 k) = x0 * S + 4 k: a multiple of 4 floats
+    vec_starts = {ix for (_, _, _, ix) in big[: 16 * g["IZ"] * g["IY"] * 4 * S * 4 : 4]}
+    assert all((ix - g["P"]) % 4 == 0 for ix in vec_starts)
