@@ -94,6 +94,30 @@ def test_conv_forward_and_gradients_match_torch(dev, report, kname, wshape, spat
     assert all(e < 3e-5 for e in errs.values()), errs
 
 
+@pytest.mark.parametrize("kname,wshape,spatial", [("CONV2D_K5S2", (6, 4, 5, 5), (12, 20)), ("CONV2D_K3", (5, 3, 3, 3), (9, 14)),
+                                                  ("CONV_S1", (3, 5, 3, 3, 3), (4, 5, 6)), ("CONV_S2", (4, 6, 3, 3, 3), (4, 6, 8))])
+def test_direct_input_gradient_any_channel_count(dev, report, kname, wshape, spatial):
+    """casmvs_conv_dgrad_direct_f32 straight from the definition, for channel counts outside the model's (its 8- / 16-channel
+    shapes take the all-channels-per-thread kernel, everything else the per-channel one)."""
+    from casmvsnet_pl_amd import _lib, ops
+    kind = getattr(ops, kname)
+    g = torch.Generator().manual_seed(sum(wshape))
+    cout, cin = wshape[:2]
+    x = torch.randn((2, cin) + spatial, generator=g).requires_grad_(True)
+    w = torch.randn(wshape, generator=g) * 0.3
+    want = _ref_conv(kind, x, w, None)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy)
+    gyd, wd = gy.to(dev).contiguous(), w.to(dev).contiguous()
+    gin = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    D, H, W = ((1,) + spatial) if len(spatial) == 2 else spatial
+    rc = _lib.load().casmvs_conv_dgrad_direct_f32(kind, ops._ptr(wd), ops._ptr(gyd), ops._ptr(gin), 2, cin, cout, D, H, W, ops._stream(gyd))
+    _lib.check(rc, "casmvs_conv_dgrad_direct_f32")
+    err = scaled_err(gin, x.grad)
+    report("train_dgrad_direct", kind=kname, weight=list(wshape), err=err)
+    assert err < 3e-5
+
+
 @pytest.mark.parametrize("shape,inplace", [((2, 8, 6, 10, 12), False), ((3, 16, 20, 28), False), ((2, 32, 4, 6, 6), True)])
 def test_abn_train_forward_backward_and_running_stats(dev, report, shape, inplace):
     from casmvsnet_pl_amd import ABN, InPlaceABN, training as T
