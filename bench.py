@@ -6,26 +6,33 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one forward pass (FeatureNet + 3 cascade levels) over one batch of --batch reference views (default 2, the
-reference's DTU training batch; `--batch 1` is its eval.py loop and is ALSO measured and printed as "batch1") with
-their source views: DTU 640x512, 3 views, n_depths [8,32,48], variance cost volume, fp32, synthetic inputs already
-resident in HBM, random-init weights.  The timed steps replay the forward as one hipGraph (casmvsnet_pl_amd/graph.py;
-`--no-graph` launches kernel by kernel), and --streams (default 2) independent forwards are in flight per GPU, each on
-its own HIP stream: a step is then one round of all of them (reference views are independent, eval.py:213); the
-single-stream figure is measured and printed beside it ("single_stream").
+reference's DTU training batch; `--batch 1` is its eval.py loop and is ALSO measured and printed as "batch1", with its own
+roofline objects) with their source views: DTU 640x512, 3 views, n_depths [8,32,48], variance cost volume, fp32,
+synthetic inputs already resident in HBM, random-init weights.  The timed steps replay the forward as one hipGraph
+(casmvsnet_pl_amd/graph.py; `--no-graph` launches kernel by kernel), and --streams (default 2) independent forwards are
+in flight per GPU, each on its own HIP stream: a step is then one round of all of them (reference views are independent,
+eval.py:213); the single-stream figure is measured and printed beside it ("single_stream").
+
+`value` = depth maps of all ranks / the max-over-ranks wall time of EXACTLY K steps (barrier + synchronize on both
+sides); `median_ms_per_step` (the median of the timed iterations) comes from one HIP event per step recorded
+inside the same timed region.
 
 --mode replica (default): with N GPUs every rank processes its own depth maps (the path shards at depth-map
-granularity, SURVEY 8e: no data-path collective) -> weak scaling; value = depth maps all ranks produced / max-over-ranks
-wall time.  --mode view_sharded (BASELINE configs 4/5): ALL ranks work on the same depth maps, each warps its share of
-the source views and the sum / sum-of-squares volumes are all-reduced over RCCL once per level -> strong scaling;
-value = depth maps / max-over-ranks wall time.
+granularity, SURVEY 8e: no data-path collective) -> weak scaling.  --mode view_sharded (BASELINE configs 4/5): ALL ranks
+work on the same depth maps, each warps its share of the source views and the sum / sum-of-squares volumes are
+all-reduced over RCCL once per level -> strong scaling.  --mode train: the reference's training step (train.py:99-127:
+train-mode forward, SL1 loss, backward, SGD) through the HIP training path; prints `train_step_ms` (metric:
+samples/s), no roofline objects.
 
 Prints ONE JSON line (rank 0).  The `roofline*` objects come from HIP events recorded on the launch stream around
 every kernel in an instrumented eager pass over the same inputs right after the timed steps (events cannot be recorded
-into a graph replay; same kernels, same shapes); `cpu_baseline` is the oracle (a CPU port of the reference's forward,
-oracle/cpu_restatement.py) timed on this host's cores at its best thread count.
+into a graph replay; same kernels, same shapes); `cpu_baseline` is the reference's own forward (/root/reference +
+import shims, kind "reference") when that tree exists, else the oracle (a CPU port of it, oracle/cpu_restatement.py,
+kind "port" - the GPU box has no /root/reference), timed on this host's cores at its best thread count.
 """
 import argparse
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -60,6 +67,8 @@ def algorithmic_work(H, W, V, G, n_depths, B=1):
             "costvol_bytes": 4 * B * (V * C * h * w + D * h * w + cout_vol * n),
             "homo_warp_bytes": 4 * B * (C * h * w + D * h * w + C * n) + 48 * B,   # the un-fused op, one source view
             "softmax_bytes": 4 * B * (2 * n + 2 * h * w),
+            # the `prob` head fused with the regression: 8 input channels + hypotheses read, cost + 2 maps written
+            "prob_regress_bytes": 4 * B * (8 * n + n + n + 2 * h * w),
             "conv0_flops": 2 * 27 * cin * 8 * n * B,
             "costreg_flops": (2 * 27 * cin * 8 + 6480) * n * B,
         }
@@ -75,32 +84,88 @@ def feature_flops(H, W):
     return full + half + quarter
 
 
+def library_sha16():
+    """First 16 hex digits of the sha256 of the HIP library this process runs (stamps the PMC files and the bench line)."""
+    from casmvsnet_pl_amd import _lib
+    try:
+        with open(_lib.LIB_PATH, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_traffic(kernel_prefix, batch):
     """HBM-side bytes per launch of one kernel from the newest committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     need a pass each and cannot be collected inside a timed run; tools/gpu_final.sh collects them in the same gpurun
     call as the bench line it commits, at batch 2): mean over the kernel's launches, read bytes corrected x2 as
-    MI355X_MICROARCH.md prescribes."""
+    MI355X_MICROARCH.md prescribes.  -> (bytes | None, note, source) - `source` says which file, when it was collected
+    and whether the library that produced it is the one running now (`same_library`)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if batch != 2 or not files:
-        return None, "PMC passes are collected at --batch 2 on the default config only"
+        return None, "PMC passes are collected at --batch 2 on the default config only", None
     path = files[-1]
+    doc = json.load(open(path))
+    meta = {}
+    if isinstance(doc, dict):   # round 3 layout: {"meta": {...}, "kernels": [...]}
+        meta, doc = doc.get("meta", {}), doc.get("kernels", [])
     prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
-    rows = [r for r in json.load(open(path)) if r["kernel"].startswith(prefixes)]
+    rows = [r for r in doc if r["kernel"].startswith(prefixes)]
+    source = {"file": os.path.relpath(path, ROOT), "collected": meta.get("collected"), "library_sha16": meta.get("library_sha16"),
+              "same_library": (meta.get("library_sha16") == library_sha16()) if meta.get("library_sha16") else None}
     if not rows:
-        return None, "kernel not in " + os.path.relpath(path, ROOT)
+        return None, "kernel not in " + os.path.relpath(path, ROOT), source
     n = sum(r["launches"] for r in rows)
     mb = sum((r["read_mb_corrected"] + r["write_mb"]) * r["launches"] for r in rows) / n
-    return mb * 1e6, f"bytes per launch (read + write, mean over the 3 cascade levels) from {os.path.relpath(path, ROOT)}"
+    return mb * 1e6, f"bytes per launch (read + write, mean over the 3 cascade levels) from {os.path.relpath(path, ROOT)}", source
+
+
+def aggregate(elapsed_local, maps_local, dist=None, device=None, sum_maps=True):
+    """The contract's cross-rank reduction: wall time = MAX over ranks, depth maps = SUM over ranks (replica mode: every
+    rank produced its own) or the local count (view-sharded: all ranks worked on the same maps).  `dist`: an initialised
+    torch.distributed module or None.  -> (elapsed, maps)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(elapsed_local), int(maps_local)
+    te = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    tm = torch.tensor([maps_local], dtype=torch.int64, device=device)
+    if sum_maps:
+        dist.all_reduce(tm, op=dist.ReduceOp.SUM)
+    return float(te.item()), int(tm.item())
+
+
+def base_line(metric, unit, value, world, steps, warmup, elapsed, scaling, config, median_ms=None):
+    """The driver's JSON contract (one line, rank 0)."""
+    line = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "config": config}
+    if median_ms is not None:
+        line["median_ms_per_step"] = median_ms
+    return line
 
 
 def cpu_baseline(cfg_name):
-    """Oracle (CPU port of the reference forward) on the same synthetic workload, at the best of a sweep over the
-    host's thread count (all 256 hardware threads of the GPU box are 25x slower than 8: oversubscription)."""
+    """The reference's forward on the same synthetic workload on this host's cores, at the best of a sweep over the thread
+    count (all 256 hardware threads of the GPU box are 25x slower than 8: oversubscription).  With /root/reference
+    present (the build container) it is the UNMODIFIED reference module behind the two import shims (kind "reference");
+    on the GPU box, where that tree does not exist, the oracle's restatement of it (kind "port")."""
     from oracle import cpu_restatement as R
+    from oracle import reference_loader as RL
     H, W, V, G, n_depths, ratios, _ = CONFIGS[cfg_name]
     model = CascadeMVSNet(n_depths=list(n_depths), interval_ratios=list(ratios), num_groups=G, norm_act=ABN)
     sd = randomize_state_dict(model.state_dict(), seed=0)
     imgs, proj, dmin, dint = config_inputs(cfg_name, 1, seed=0)
+    if RL.reference_available():
+        kind = "reference"
+        ref = RL.build_reference_model(n_depths, ratios, G, sd)
+
+        def forward():
+            with torch.no_grad():
+                return ref(imgs, proj, dmin, dint)
+    else:
+        kind = "port"
+
+        def forward():
+            return R.cascade_forward(sd, imgs, proj, dmin, dint, n_depths, ratios, G)
     ncpu = os.cpu_count() or 8
     old = torch.get_num_threads()
     sweep = sorted({t for t in (4, 8, 16, 32, 64) if t <= ncpu})   # beyond 64 threads torch's CPU ops only lose (256 threads: 54 s per forward)
@@ -109,9 +174,9 @@ def cpu_baseline(cfg_name):
     for i, nt in enumerate(sweep):
         torch.set_num_threads(nt)
         if i == 0:
-            R.cascade_forward(sd, imgs, proj, dmin, dint, n_depths, ratios, G)  # warm-up (allocator, op dispatch)
+            forward()  # warm-up (allocator, op dispatch)
         t0 = time.perf_counter()
-        R.cascade_forward(sd, imgs, proj, dmin, dint, n_depths, ratios, G)
+        forward()
         per_threads[nt] = time.perf_counter() - t0
         if best is None or per_threads[nt] < per_threads[best]:
             best = nt
@@ -121,14 +186,16 @@ def cpu_baseline(cfg_name):
     times = [per_threads[best]]
     for _ in range(2):
         t0 = time.perf_counter()
-        R.cascade_forward(sd, imgs, proj, dmin, dint, n_depths, ratios, G)
+        forward()
         times.append(time.perf_counter() - t0)
     torch.set_num_threads(old)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": 1.0 / med, "unit": "depth-maps/s", "cores": best, "kind": "port",
-            "sample": f"3 timed forwards of ONE depth map each (median {med:.3f} s) on the same {cfg_name} inputs / weights, torch CPU "
-                      f"fp32 at {best} threads = the best of a sweep {({k: round(v, 2) for k, v in per_threads.items()})} s over "
+    what = "the unmodified /root/reference models/mvsnet.py (import shims: inplace_abn, kornia)" if kind == "reference" else \
+           "oracle/cpu_restatement.py (the reference tree is not on this machine)"
+    return {"value": 1.0 / med, "unit": "depth-maps/s", "cores": best, "kind": kind,
+            "sample": f"3 timed forwards of ONE depth map each (median {med:.3f} s) of {what} on the same {cfg_name} inputs / weights, "
+                      f"torch CPU fp32 at {best} threads = the best of a sweep {({k: round(v, 2) for k, v in per_threads.items()})} s over "
                       f"{ncpu} hardware threads"}
 
 
@@ -165,46 +232,237 @@ def stock_pytorch_rocm(cfg_name, dev):
 
 
 def timed_steps(step, steps, barrier):
+    """EXACTLY `steps` steps between two barrier + synchronize pairs; one HIP event per step (recorded on the launch
+    stream, no synchronisation) gives the per-step durations for the median."""
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    for e in events:
+        e.record()   # creates the hipEvent_t outside the timed region
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    events[0].record()
+    for i in range(steps):
         out = step()
+        events[i + 1].record()
     barrier()
-    return time.perf_counter() - t0, out
+    elapsed = time.perf_counter() - t0
+    per_step = sorted(events[i].elapsed_time(events[i + 1]) for i in range(steps))
+    median = per_step[len(per_step) // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
+    return elapsed, out, median
+
+
+_DIRTY = {}
+
+
+def _timed_op(fn, reps, dirty_mb, dev):
+    """Mean ms of one call of fn: `reps` back-to-back calls between two events (hot: inputs stay in L2 / Infinity Cache),
+    or - dirty_mb > 0 - each call timed on its own after a torch fill_ of that many MB (ordinary stores): the caches then
+    hold another kernel's dirty lines and none of the inputs, the state every kernel starts from inside the forward."""
+    for _ in range(3):
+        fn()
+    if not dirty_mb:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+    buf = _DIRTY.get(dirty_mb)
+    if buf is None:
+        buf = _DIRTY[dirty_mb] = torch.empty(dirty_mb * 262144, device=dev)
+    total = 0.0
+    for _ in range(reps):
+        buf.fill_(1.0)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        total += s.elapsed_time(e)
+    return total / reps
 
 
 def homo_warp_roofline(dev, H, W, n_depths, B):
-    """The un-fused op models/modules.py:52-92 (north_star names its HBM-roofline fraction) at the three level
-    shapes: HIP events around 10 calls each, algorithmic bytes 4 B (C h w + D h w + C D h w)."""
+    """The un-fused op models/modules.py:52-92 (north_star names its HBM-roofline fraction) at the three level shapes,
+    algorithmic bytes 4 B (C h w + D h w + C D h w), measured four ways:
+      reference signature (NCHW source in, the pixel-major layout pass INCLUDED: ops.homo_warp) and the kernel alone on
+      a pixel-major source (what FeatureNet hands the engine), each hot (10 back-to-back calls) and with dirtied caches
+      (a 512 MB fill_ between calls = the state inside the forward).  `frac` is the most conservative of the four:
+      reference signature, dirtied caches."""
     from casmvsnet_pl_amd import ops
     from casmvsnet_pl_amd.synthetic import make_inputs
     _, proj, dmin, dint = make_inputs(B, 2, H, W, seed=0)
     work = algorithmic_work(H, W, 2, 1, n_depths, B)
-    per_level, tot_b, tot_ms = {}, 0.0, 0.0
+    variants = {"reference_signature_dirty": (True, 512), "reference_signature_hot": (True, 0),
+                "pixel_major_kernel_dirty": (False, 512), "pixel_major_kernel_hot": (False, 0)}
+    tot_b = sum(work[l]["homo_warp_bytes"] for l in range(3))
+    ms = {k: {} for k in variants}
     for l in range(3):
         C, D, h, w = 8 * 2 ** l, n_depths[l], H >> l, W >> l
-        src = torch.randn(B, h, w, C, device=dev)   # pixel-major, as FeatureNet hands it to the engine
+        nchw = torch.randn(B, C, h, w, device=dev)
+        nhwc = nchw.permute(0, 2, 3, 1).contiguous()   # pixel-major, as FeatureNet hands it to the engine
         P = proj[:, 0, l].contiguous().to(dev)
         step = dint * 2 ** l
         k = torch.arange(D, device=dev, dtype=torch.float32).view(1, D, 1, 1)
         depth = (680.0 - D / 2 * step + 40.0 * torch.sin(torch.linspace(0, 6.0, w, device=dev)).view(1, 1, 1, w) + k * step).expand(B, D, h, w).contiguous()
-        fn = lambda: ops.homo_warp_nhwc(src, P, depth)
-        for _ in range(3):
-            fn()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(10):
-            fn()
-        e.record()
+        for name, (ref_sig, dirty) in variants.items():
+            fn = (lambda: ops.homo_warp(nchw, P, depth)) if ref_sig else (lambda: ops.homo_warp_nhwc(nhwc, P, depth))
+            ms[name][l] = _timed_op(fn, 10, dirty, dev)
+    fr = {name: tot_b / (sum(v.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS for name, v in ms.items()}
+    per_level = {name: {str(l): work[l]["homo_warp_bytes"] / (v[l] * 1e-3) / 1e9 / HBM_PEAK_GBS for l in range(3)} for name, v in ms.items()}
+    head = "reference_signature_dirty"
+    return {"kernel": "homo_warp (un-fused op modules.py:52-92): nchw_to_nhwc_kernel + costvol_lds_kernel<MODE_WARP> through the "
+                      "reference signature (ops.homo_warp, NCHW source), one call per level shape, caches dirtied between calls",
+            "bound": "hbm", "achieved": fr[head] * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr[head], "traffic": None,
+            "frac_by_measurement": fr, "per_level_frac": per_level, "avg_launch_ms": sum(ms[head].values()) / 3}
+
+
+def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_homo_warp=True):
+    """K kernel-by-kernel steps with HIP events around every kernel on every `every`-th one -> roofline objects + stage times."""
+    H, W, V, G, n_depths, ratios, _ = CONFIGS[cfg_name]
+    n_ev = (K + every - 1) // every
+    timer = StageTimer()
+    timer.reserve((2 * 13 + 14 + 36) * n_ev)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):   # events on every `every`-th step: the GPU stays busy in between
+        model.set_timer(timer if i % every == 0 else None)
+        model(*inputs)
+    barrier()
+    eager_ms = 1e3 * (time.perf_counter() - t0) / K
+    model.set_timer(None)
+    summ = timer.summary(LAYER_NAMES)
+    work = algorithmic_work(H, W, V, G, n_depths, B)
+    per_step = {k: v["ms"] / n_ev for k, v in summ.items()}
+    out = {}
+    # dominant kernel: conv16db_kernel<PX> = CostRegNet.conv0 (3 launches per step)
+    conv0_ms = sum(summ[f"costreg_{l}/conv0"]["ms"] for l in range(3))
+    conv0_flops = sum(work[l]["conv0_flops"] for l in range(3)) * n_ev
+    ach = conv0_flops / (conv0_ms * 1e-3) / 1e12
+    traffic, traffic_note, src = pmc_traffic("conv16db_kernel<2, 4, 4, 4, 4, 32", B if cfg_name == HEADLINE else None)
+    conv0_alg = sum(4 * B * ((G if G > 1 else 8 * 2 ** l) + 8) * n_depths[l] * (H >> l) * (W >> l) for l in range(3)) / 3
+    out["roofline"] = {"kernel": "conv16db_kernel<PX> (CostRegNet.conv0: Cout 8, stride 1; 3 launches per step)",
+                       "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                       "traffic_note": traffic_note + f"; algorithmic bytes per launch (mean of the 3 levels): {conv0_alg:.4g}",
+                       "traffic_source": src, "avg_launch_ms": conv0_ms / (3 * n_ev), "batch": B}
+    cr_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("costreg_"))
+    cr_flops = sum(work[l]["costreg_flops"] for l in range(3)) * n_ev
+    fused = getattr(model, "fuse_regress", False)
+    out["roofline_costreg"] = {"kernel": "all 33 CostRegNet launches" + (" (the `prob` interval includes the fused softmax regression)" if fused else ""),
+                               "bound": "mfma", "achieved": cr_flops / (cr_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": cr_flops / (cr_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                               "ms_per_depth_map": cr_ms / n_ev / B, "batch": B}
+    rest_ms = cr_ms - conv0_ms
+    out["roofline_costreg"]["without_conv0"] = {"ms_per_step": rest_ms / n_ev, "frac": (cr_flops - conv0_flops) / (rest_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    out["roofline_costreg"]["conv3_to_conv9_ms_per_step"] = sum(per_step[f"costreg_{l}/{n}"] for l in range(3) for n in ("conv3", "conv4", "conv5", "conv6", "conv7", "conv9"))
+    cv_ms = sum(summ[f"costvol_{l}"]["ms"] for l in range(3))
+    cv_bytes = sum(work[l]["costvol_bytes"] for l in range(3)) * n_ev
+    cv_traffic, cv_note, cv_src = pmc_traffic(("costvol_lds_kernel", "costvol_nhwc_kernel"), B if cfg_name == HEADLINE else None)
+    from casmvsnet_pl_amd import _lib
+    lds = [bool(_lib.load().casmvs_costvol_lds_preferred(8 * 2 ** l, W >> l, n_depths[l], V - 1, G)) for l in range(3)]
+    out["roofline_costvol"] = {"kernel": "fused homo_warp + aggregation, one launch per level: " +
+                                         ", ".join(f"level {l}: {'costvol_lds_kernel' if lds[l] else 'costvol_nhwc_kernel'}<C={8 * 2 ** l}>" for l in (2, 1, 0)),
+                               "bound": "hbm", "achieved": cv_bytes / (cv_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": cv_bytes / (cv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "traffic": cv_traffic, "traffic_note": cv_note + f"; algorithmic: {cv_bytes / n_ev / 3:.4g}", "traffic_source": cv_src,
+                               "ms_per_depth_map": cv_ms / n_ev / B, "batch": B,
+                               "per_level_frac": {str(l): work[l]["costvol_bytes"] * n_ev / (summ[f"costvol_{l}"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS for l in range(3)}}
+    if fused:
+        pr_ms = sum(summ[f"costreg_{l}/prob"]["ms"] for l in range(3))
+        pr_bytes = sum(work[l]["prob_regress_bytes"] for l in range(3)) * n_ev
+        out["roofline_prob_regress"] = {"kernel": "prob_zwalk_kernel (+ softmax_regress_kernel where the depth range is chunked): the `prob` head "
+                                                  "and mvsnet.py:174-193, 3 library calls per step", "bound": "hbm",
+                                        "achieved": pr_bytes / (pr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": pr_bytes / (pr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": pr_ms / n_ev, "batch": B}
+    else:
+        sm_ms = sum(summ[f"softmax_{l}"]["ms"] for l in range(3))
+        sm_bytes = sum(work[l]["softmax_bytes"] for l in range(3)) * n_ev
+        out["roofline_softmax"] = {"kernel": "softmax_regress_kernel (3 launches)", "bound": "hbm",
+                                   "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "batch": B}
+    ft_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("feature/"))
+    if ft_ms > 0:
+        ft_flops = feature_flops(H, W) * V * B * n_ev
+        out["roofline_feature"] = {"kernel": "all FeatureNet launches", "bound": "mfma",
+                                   "achieved": ft_flops / (ft_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": ft_flops / (ft_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                   "ms_per_depth_map": ft_ms / n_ev / B, "ms_per_step": ft_ms / n_ev, "batch": B}
+    if with_homo_warp:
+        out["roofline_homo_warp"] = homo_warp_roofline(dev, H, W, n_depths, B)
+        out["roofline_homo_warp"]["batch"] = B
+    out["stage_ms_per_step"] = {k: round(v, 4) for k, v in per_step.items()}
+    out["instrumented_pass"] = {"steps": K, "event_sampled_steps": n_ev, "ms_per_step": eager_ms,
+                                "note": f"kernel-by-kernel launches right after the timed steps, ~90 HIP events on every {every}-th step"}
+    return out
+
+
+def train_mode(args, dev, world, rank, dist, barrier):
+    """--mode train: the reference's training step (train.py:99-127) through the HIP training path - train-mode forward
+    (batch-statistics InPlaceABN), SL1 loss over the three levels (losses.py, masked), backward, SGD update -, captured as
+    ONE hipGraph like the inference forward (--no-graph: eager).  metric: training samples/s."""
+    from casmvsnet_pl_amd import InPlaceABN
+    from casmvsnet_pl_amd.training import sl1_loss, sl1_loss_masked
+    H, W, V, G, n_depths, ratios, _ = CONFIGS[args.config]
+    B = args.batch if args.batch_given else 1   # the reference's default: --batch_size 1
+    model = CascadeMVSNet(n_depths=list(n_depths), interval_ratios=list(ratios), num_groups=G, norm_act=InPlaceABN)
+    randomize_state_dict(model.state_dict(), seed=0)
+    model = model.to(dev).train()
+    net = model
+    if dist is not None and world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
+    imgs, proj, dmin, dint = config_inputs(args.config, B, seed=rank)
+    imgs, proj = imgs.to(dev), proj.to(dev)
+    g = torch.Generator().manual_seed(100 + rank)
+    depths = {f"level_{l}": (dmin + dint * 96 * torch.rand(B, H >> l, W >> l, generator=g)).to(dev) for l in range(3)}
+    masks = {f"level_{l}": (torch.rand(B, H >> l, W >> l, generator=g) > 0.2).to(dev) for l in range(3)}
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9)
+    use_graph = not args.no_graph and world == 1
+    # losses.py indexes with the boolean mask (a host sync per level): kept kernel by kernel; the captured step uses the
+    # same loss in its sync-free form (mean over the masked elements through a float mask)
+    loss_fn = sl1_loss_masked if use_graph else sl1_loss
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        loss = loss_fn(net(imgs, proj, dmin, dint), depths, masks)
+        loss.backward()
+        opt.step()
+        return loss
+
+    run = step
+    if use_graph:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(3, args.warmup)):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
-        ms = s.elapsed_time(e) / 10
-        per_level[str(l)] = work[l]["homo_warp_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        tot_b += work[l]["homo_warp_bytes"]
-        tot_ms += ms
-    ach = tot_b / (tot_ms * 1e-3) / 1e9
-    return {"kernel": "homo_warp (un-fused op, casmvs_homo_warp_nhwc_f32; one launch per level shape)", "bound": "hbm",
-            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-            "per_level_frac": per_level, "avg_launch_ms": tot_ms / 3}
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def run():
+            graph.replay()
+            return static_loss
+        for _ in range(2):
+            run()
+    else:
+        for _ in range(max(3, args.warmup)):
+            step()
+    elapsed, loss, median = timed_steps(run, args.steps, barrier)
+    assert torch.isfinite(loss).all()
+    elapsed, samples = aggregate(elapsed, B * args.steps, dist if world > 1 else None, dev)
+    if rank != 0:
+        return None
+    line = base_line(f"training samples/sec ({args.config}: train-mode forward + SL1 loss + backward + SGD, train.py:99-127)", "samples/s",
+                     samples / elapsed, world, args.steps, args.warmup, elapsed, "weak",
+                     {"workload": args.config + "_train", "H": H, "W": W, "views": V, "n_depths": list(n_depths), "num_groups": G,
+                      "batch_per_gpu": B, "launch": "one hipGraph replay per step" if use_graph else "kernel by kernel",
+                      "parallelism": f"DistributedDataParallel x{world} over RCCL" if world > 1 else "single GPU"}, median)
+    line["train_step_ms"] = 1e3 * elapsed / args.steps
+    line["peak_memory_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    return line
 
 
 def main():
@@ -213,10 +471,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=2,
-                    help="depth maps per step per GPU (reference views batched like the reference's train.py --batch_size 2; "
-                         "--batch 1 = the reference's eval.py loop, always measured too)")
-    ap.add_argument("--mode", default="replica", choices=["replica", "view_sharded"])
+    ap.add_argument("--batch", type=int, default=None,
+                    help="depth maps per step per GPU (default 2: reference views batched like the reference's train.py --batch_size 2; "
+                         "--batch 1 = the reference's eval.py loop, always measured too).  --mode train: default 1")
+    ap.add_argument("--mode", default="replica", choices=["replica", "view_sharded", "train"])
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying one hipGraph")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent forwards in flight per GPU, one HIP stream + hipGraph each (a step = one round of all of "
@@ -229,7 +487,11 @@ def main():
                     help="the instrumented pass records its ~90 HIP events on every n-th of its K kernel-by-kernel steps (an event "
                          "costs ~3 us of GPU time; on every step they would inflate the step by ~10 %% and starve the launch queue)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-1 measurement")
+    ap.add_argument("--no-fuse-regress", action="store_true", help="A/B: `prob` and the softmax regression as separate library calls")
     args = ap.parse_args()
+    args.batch_given = args.batch is not None
+    if args.batch is None:
+        args.batch = 2
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -247,6 +509,20 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.mode == "train":
+        line = train_mode(args, dev, world, rank, dist, barrier)
+        if rank == 0:
+            line["library_sha16"] = library_sha16()
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     H, W, V, G, n_depths, ratios, _ = CONFIGS[args.config]
     view_sharded = args.mode == "view_sharded"
 
@@ -254,17 +530,13 @@ def main():
         model = CascadeMVSNet(n_depths=list(n_depths), interval_ratios=list(ratios), num_groups=G, norm_act=ABN)
         randomize_state_dict(model.state_dict(), seed=0)
         model = model.to(dev).eval()
+        model.fuse_regress = not args.no_fuse_regress
         # replica: every rank works on its own depth maps (different seeds -> different images / cameras);
         # view_sharded: all ranks share the depth maps and split their source views
         imgs, proj, dmin, dint = config_inputs(args.config, B, seed=0 if view_sharded else rank)
         if view_sharded:
             model.view_shard_group = dist.group.WORLD
         return model, imgs.to(dev), proj.to(dev), dmin, dint
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def measure(B, steps, warmup, streams=1):
         model, imgs, proj, dmin, dint = build(B)
@@ -279,116 +551,64 @@ def main():
             step = lambda: gf(imgs, proj)
         else:
             step = lambda: model(imgs, proj, dmin, dint)
-        elapsed, out = timed_steps(step, steps, barrier)
-        if dist is not None:
-            te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            elapsed = float(te.item())
+        elapsed, out, median = timed_steps(step, steps, barrier)
+        maps_local = B * (streams if use_graph else 1) * steps
+        elapsed, maps = aggregate(elapsed, maps_local, dist, dev, sum_maps=not view_sharded)
         assert torch.isfinite(out["depth_0"]).all()
-        return model, (imgs, proj, dmin, dint), elapsed, use_graph
+        return model, (imgs, proj, dmin, dint), elapsed, maps, median, use_graph
 
     B = args.batch
     NS = 1 if (view_sharded or args.no_graph) else max(1, args.streams)
-    model, inputs, elapsed, used_graph = measure(B, args.steps, args.warmup, NS)
+    model, inputs, elapsed, maps, median, used_graph = measure(B, args.steps, args.warmup, NS)
     K = args.steps
-    maps = (1 if view_sharded else world) * B * NS * K
     line = None
     if rank == 0:
-        line = {
-            "metric": "depth-maps/sec at 640x512, 3 views, n_depths=[8,32,48]" if args.config == HEADLINE
-                      else f"depth-maps/sec ({args.config})",
-            "value": maps / elapsed, "unit": "depth-maps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong" if view_sharded else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.config, "H": H, "W": W, "views": V, "n_depths": list(n_depths),
-                       "interval_ratios": list(ratios), "num_groups": G, "depth_maps_per_step_per_gpu": B * NS,
-                       "batch_per_forward": B, "concurrent_forwards_per_gpu": NS,
-                       "depth_interval": inputs[3], "init_depth_min": inputs[2],
-                       "launch": (f"{NS} independent forwards per step, each one hipGraph replay on its own HIP stream" if NS > 1 else
-                                  "one hipGraph replay per step") if used_graph else "kernel by kernel",
-                       "parallelism": (f"view-sharded x{world}: source views split over the ranks, one RCCL all-reduce of the sum / "
-                                       "sum-of-squares volumes per level, every rank regularises") if view_sharded else
-                                      f"replica x{world} (one depth map stream per GPU, no data-path collective)",
-                       "feature_net": "HIP MFMA kernels (casmvs_featurenet_forward_f32)"},
-        }
+        line = base_line("depth-maps/sec at 640x512, 3 views, n_depths=[8,32,48]" if args.config == HEADLINE else f"depth-maps/sec ({args.config})",
+                         "depth-maps/s", maps / elapsed, world, K, args.warmup, elapsed, "strong" if view_sharded else "weak",
+                         {"workload": args.config, "H": H, "W": W, "views": V, "n_depths": list(n_depths),
+                          "interval_ratios": list(ratios), "num_groups": G, "depth_maps_per_step_per_gpu": B * NS,
+                          "batch_per_forward": B, "concurrent_forwards_per_gpu": NS,
+                          "depth_interval": inputs[3], "init_depth_min": inputs[2],
+                          "launch": (f"{NS} independent forwards per step, each one hipGraph replay on its own HIP stream" if NS > 1 else
+                                     "one hipGraph replay per step") if used_graph else "kernel by kernel",
+                          "parallelism": (f"view-sharded x{world}: source views split over the ranks, one RCCL all-reduce of the sum / "
+                                          "sum-of-squares volumes per level, every rank regularises") if view_sharded else
+                                         f"replica x{world} (one depth map stream per GPU, no data-path collective)",
+                          "feature_net": "HIP MFMA kernels (casmvs_featurenet_forward_f32)",
+                          "regression": "fused into the `prob` head's library call (casmvs_costreg_regress_f32)" if model.fuse_regress else "separate launch"},
+                         median)
+        line["library_sha16"] = library_sha16()
 
     # ---- instrumented eager pass: HIP events around every kernel (same model, same inputs) ------------------------
     if not args.no_events:
-        every = max(1, args.event_every)
-        n_ev = (K + every - 1) // every
-        timer = StageTimer()
-        timer.reserve((2 * 13 + 14 + 36) * n_ev)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(K):   # K kernel-by-kernel steps, events on every `every`-th one: the GPU stays busy in between
-            model.set_timer(timer if i % every == 0 else None)
-            model(*inputs)
-        barrier()
-        eager_ms = 1e3 * (time.perf_counter() - t0) / K
-        model.set_timer(None)
+        res = instrumented_pass(model, inputs, args.config, B, K, max(1, args.event_every), barrier, dev)
         if rank == 0:
-            summ = timer.summary(LAYER_NAMES)
-            work = algorithmic_work(H, W, V, G, n_depths, B)
-            per_step = {k: v["ms"] / n_ev for k, v in summ.items()}
-            # dominant kernel: conv16db_kernel<PX> = CostRegNet.conv0 (3 launches per step)
-            conv0_ms = sum(summ[f"costreg_{l}/conv0"]["ms"] for l in range(3))
-            conv0_flops = sum(work[l]["conv0_flops"] for l in range(3)) * n_ev
-            ach = conv0_flops / (conv0_ms * 1e-3) / 1e12
-            traffic, traffic_note = pmc_traffic("conv16db_kernel<2, 4, 4, 4, 4, 32", B if args.config == HEADLINE else None)
-            line["roofline"] = {"kernel": "conv16db_kernel<PX> (CostRegNet.conv0: Cout 8, stride 1; 3 launches per step)",
-                                "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                                "traffic_note": traffic_note + "; algorithmic bytes of the same launches: 384e6",
-                                "avg_launch_ms": conv0_ms / (3 * n_ev)}
-            cr_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("costreg_"))
-            cr_flops = sum(work[l]["costreg_flops"] for l in range(3)) * n_ev
-            line["roofline_costreg"] = {"kernel": "all 33 CostRegNet launches", "bound": "mfma",
-                                        "achieved": cr_flops / (cr_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                                        "unit": "TFLOP/s", "frac": cr_flops / (cr_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                        "ms_per_depth_map": cr_ms / n_ev / B}
-            cv_ms = sum(summ[f"costvol_{l}"]["ms"] for l in range(3))
-            cv_bytes = sum(work[l]["costvol_bytes"] for l in range(3)) * n_ev
-            cv_traffic, cv_note = pmc_traffic(("costvol_lds_kernel", "costvol_nhwc_kernel"), B if args.config == HEADLINE else None)
-            line["roofline_costvol"] = {"kernel": "fused homo_warp + aggregation (3 launches: costvol_lds_kernel at C = 8 / 16, "
-                                                  "costvol_nhwc_kernel at C = 32 and for group-wise correlation)",
-                                        "bound": "hbm", "achieved": cv_bytes / (cv_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": cv_bytes / (cv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "traffic": cv_traffic, "traffic_note": cv_note + f"; algorithmic: {cv_bytes / n_ev / 3:.4g}",
-                                        "ms_per_depth_map": cv_ms / n_ev / B,
-                                        "per_level_frac": {str(l): work[l]["costvol_bytes"] * n_ev / (summ[f"costvol_{l}"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS for l in range(3)}}
-            sm_ms = sum(summ[f"softmax_{l}"]["ms"] for l in range(3))
-            sm_bytes = sum(work[l]["softmax_bytes"] for l in range(3)) * n_ev
-            line["roofline_softmax"] = {"kernel": "softmax_regress_kernel (3 launches)", "bound": "hbm",
-                                        "achieved": sm_bytes / (sm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": sm_bytes / (sm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            ft_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("feature/"))
-            if ft_ms > 0:
-                ft_flops = feature_flops(H, W) * V * B * n_ev
-                line["roofline_feature"] = {"kernel": "all 13 FeatureNet launches", "bound": "mfma",
-                                            "achieved": ft_flops / (ft_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                                            "unit": "TFLOP/s", "frac": ft_flops / (ft_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                            "ms_per_depth_map": ft_ms / n_ev / B}
-            line["roofline_homo_warp"] = homo_warp_roofline(dev, H, W, n_depths, B)
-            line["stage_ms_per_step"] = {k: round(v, 4) for k, v in per_step.items()}
-            line["instrumented_pass"] = {"steps": K, "event_sampled_steps": n_ev, "ms_per_step": eager_ms,
-                                         "note": f"kernel-by-kernel launches right after the timed steps, ~90 HIP events on every {every}-th step"}
+            line.update(res)
     del model
-    # ---- the reference's eval.py loop: one reference view per step ---------------------------------------------------
+    # ---- one forward per step (no concurrency), and the reference's eval.py loop: one reference view per step --------
     if NS > 1:
-        _, _, els, gs = measure(B, K, max(2, args.warmup // 2), 1)
+        _, _, els, ms1, med1, _ = measure(B, K, max(2, args.warmup // 2), 1)
         if rank == 0:
-            line["single_stream"] = {"value": world * B * K / els, "unit": "depth-maps/s", "ms_per_step": 1e3 * els / K, "steps": K,
+            line["single_stream"] = {"value": ms1 / els, "unit": "depth-maps/s", "ms_per_step": 1e3 * els / K, "median_ms_per_step": med1, "steps": K,
                                      "note": f"one forward of batch {B} per step (one stream, one hipGraph replay)"}
     if B != 1 and not args.no_batch1:
-        _, _, el1, g1 = measure(1, K, max(2, args.warmup // 2), 1)
+        m1, in1, el1, mp1, medb1, g1 = measure(1, K, max(2, args.warmup // 2), 1)
         if rank == 0:
-            line["batch1"] = {"value": (1 if view_sharded else world) * K / el1, "unit": "depth-maps/s", "ms_per_step": 1e3 * el1 / K,
+            line["batch1"] = {"value": mp1 / el1, "unit": "depth-maps/s", "ms_per_step": 1e3 * el1 / K, "median_ms_per_step": medb1,
                               "steps": K, "launch": "one hipGraph replay per step" if g1 else "kernel by kernel",
                               "note": "eval.py:213-222 processes one reference view per forward (one stream)"}
-        if NS > 1:
-            _, _, el1s, _ = measure(1, K, max(2, args.warmup // 2), NS)
+        if not args.no_events:
+            r1 = instrumented_pass(m1, in1, args.config, 1, K, max(1, args.event_every), barrier, dev)
             if rank == 0:
-                line["batch1"]["concurrent"] = {"value": world * NS * K / el1s, "unit": "depth-maps/s", "ms_per_step": 1e3 * el1s / K,
+                for k in ("roofline", "roofline_costreg", "roofline_costvol", "roofline_feature", "roofline_homo_warp", "roofline_prob_regress",
+                          "roofline_softmax", "stage_ms_per_step"):
+                    if k in r1:
+                        line["batch1"][k] = r1[k]
+        del m1
+        if NS > 1:
+            _, _, el1s, mp1s, _, _ = measure(1, K, max(2, args.warmup // 2), NS)
+            if rank == 0:
+                line["batch1"]["concurrent"] = {"value": mp1s / el1s, "unit": "depth-maps/s", "ms_per_step": 1e3 * el1s / K,
                                                 "note": f"{NS} single-view forwards in flight, one stream each"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

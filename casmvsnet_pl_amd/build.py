@@ -11,8 +11,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcasmvs_hip.so")
-SOURCES = ["abi.hip", "costvol.hip", "costvol_lds.hip", "depth_ops.hip", "fusion.hip", "backward.hip", "train.hip", "conv3d_mfma.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "plane_sweep.h"), os.path.join(REPO_ROOT, "include", "casmvs.h")]
+SOURCES = ["abi.hip", "costvol.hip", "costvol_lds.hip", "depth_ops.hip", "fusion.hip", "backward.hip", "train.hip", "prob_regress.hip", "conv3d_mfma.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "plane_sweep.h", "buffer_ops.h", "softmax_regress.h")] + [os.path.join(REPO_ROOT, "include", "casmvs.h")]
 
 
 def _sources():

@@ -4,10 +4,12 @@ prefix.  The 206 state-dict keys are the reference's, so the released checkpoint
 import torch
 
 
-def extract_model_state_dict(ckpt_path, prefixes_to_ignore=()):
+def extract_model_state_dict(ckpt_path, prefixes_to_ignore=(), trust_checkpoint=False):
     """utils/__init__.py:51-74: -> {key: tensor} of the network (Lightning's `model.` prefix stripped, keys that start
-    with one of `prefixes_to_ignore` dropped)."""
-    checkpoint = torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=False)
+    with one of `prefixes_to_ignore` dropped).  The file is read with `weights_only=True` (tensors and primitive
+    containers only - what the released checkpoints hold); `trust_checkpoint=True` allows arbitrary pickled objects
+    (a Lightning checkpoint with custom hyper-parameter objects) and must only be used on files you produced."""
+    checkpoint = torch.load(ckpt_path, map_location=torch.device("cpu"), weights_only=not trust_checkpoint)
     source = checkpoint["state_dict"] if "state_dict" in checkpoint else checkpoint
     lightning = "state_dict" in checkpoint
     out = {}
@@ -22,10 +24,10 @@ def extract_model_state_dict(ckpt_path, prefixes_to_ignore=()):
     return out
 
 
-def load_ckpt(model, ckpt_path, prefixes_to_ignore=()):
+def load_ckpt(model, ckpt_path, prefixes_to_ignore=(), trust_checkpoint=False):
     """utils/__init__.py:76-80: update the model's own state dict with the checkpoint's entries, then load it (strict)."""
     state = model.state_dict()
-    state.update(extract_model_state_dict(ckpt_path, prefixes_to_ignore))
+    state.update(extract_model_state_dict(ckpt_path, prefixes_to_ignore, trust_checkpoint))
     model.load_state_dict(state)
     return model
 

@@ -36,12 +36,13 @@
 #include <type_traits>
 #include <unordered_map>
 
+#include "buffer_ops.h"
 #include "common.h"
 
 namespace {
 
+using namespace casmvs::buf;  // rsrc_t, kOOB, make_rsrc, buf_load*, buf_store*, xcd_major, f32x2, f32x4v, u32x2, u32x4
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 
@@ -153,35 +154,6 @@ inline float pack_weight(const LayerCfg &c, int kind, int cin, int cout, const f
   return 0.0f;
 }
 
-// ---- buffer addressing ---------------------------------------------------------------------------
-// Tiles are staged with raw buffer loads/stores: address = descriptor base (SGPRs) + per-lane byte
-// offset (VGPR, invariant for a whole tile) + per-plane byte offset (SGPR).  A load then costs one
-// scalar add and one buffer_load - no per-lane 64-bit address arithmetic, no predicate - and a
-// lane whose position is outside the image carries the offset kOOB >= num_records, for which the
-// hardware returns 0 (loads) or drops the access (stores): the convolution's zero padding for free.
-#ifndef CASMVS_CONV_STORE_AUX
-#define CASMVS_CONV_STORE_AUX 0   // cache-policy bits of the activation stores (2 = nt; A/B builds)
-#endif
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr int kOOB = (int)0x80000000u;  // needs num_records <= 2^31 bytes (checked on the host)
-
-__device__ __forceinline__ rsrc_t make_rsrc(const float *base, size_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float buf_load(rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 buf_load2(rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-}
-__device__ __forceinline__ void buf_store(float v, rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, CASMVS_CONV_STORE_AUX);
-}
-__device__ __forceinline__ void buf_store2(f32x2 v, rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, CASMVS_CONV_STORE_AUX);
-}
-
 // ---- staging: global -> registers -> LDS, software-pipelined one chunk ahead -------------------
 // A chunk = CK input channels of the zero-padded halo tile (CK*IZ planes of IY*IX floats) plus
 // the chunk's NW weight floats.  A thread copies the same NPASS in-plane positions of every
@@ -191,11 +163,6 @@ __device__ __forceinline__ void buf_store2(f32x2 v, rsrc_t r, int voff, int soff
 // while the MFMA loop of chunk s runs; they are written to LDS after the next barrier.  Weights
 // go through LDS too, so that the MFMA loop contains no vector-memory instruction (an in-loop
 // global load would make the compiler's in-order vmcnt wait drain the whole prefetch).
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4v buf_load4(rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
 
 // Stager<VEC = 1>: one float per load.  A thread copies the same NPASS in-plane positions of
 // every plane; per-lane byte offsets are tile constants, the plane offset is scalar.
@@ -445,11 +412,6 @@ __device__ unsigned long long g_trace[64 * 128];
 // ~80-100 concurrent tiles = one z-x slab, whose halos are then shared inside that L2).  With the
 // plain v -> tile map neighbouring tiles ran on 8 different XCDs and every L2 fetched every halo:
 // PMC FETCH_SIZE of conv0 was 5x the algorithmic input bytes (profiles/r01_pmc_traffic.md).
-__device__ __forceinline__ int xcd_major(int v, int total) {  // bijection on [0, total)
-  const int xcd = v & 7, idx = v >> 3;
-  const int q = total >> 3, r = total & 7;
-  return xcd * q + (xcd < r ? xcd : r) + idx;
-}
 struct TileCoord {
   int tx0, ty0, tz0, b, slice;
 };
@@ -1148,6 +1110,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
 // (m + d) of a cell is read ONCE from LDS (8 B operands per channel quad) and feeds the 27 (TCI)
 // / 18 (TPX) MFMAs of the four (pz, py) passes.  TCI keeps two accumulators per pass (x parity),
 // TPX folds the x parity into the rows (co, px).
+#ifndef CASMVS_DECONV_PREFETCH
+#define CASMVS_DECONV_PREFETCH 1   // 0: A/B builds without the skip prefetch under the last chunk
+#endif
 template <int MODE, int CK, int NT, int TZ, int TY, int TX, int VEC>
 struct Deconv16Cfg {
   static_assert(MODE == FMT_TCI || MODE == FMT_TPX, "deconv16: TCI or TPX");
@@ -1226,14 +1191,50 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
   // (Tried: warming the skip tensor's cache lines with fire-and-forget loads issued here - the
   // in-order vmcnt made the first stage wait for them and the epilogue did not get faster.)
 
+  // Epilogue operands fetched BEFORE the last chunk's MFMA loop (round 3): the per-lane coefficients at kernel start, and
+  // - where the registers allow: TPX (32 registers) and the one-tile TCI form - every skip value of the tile right after
+  // the last staging barrier, so that the epilogue's global round trip runs under the MFMAs instead of after them
+  // (conv11 was at MFMA time + HBM time: the two did not overlap inside a workgroup).  No staging load is younger than
+  // them, so the in-order vmcnt wait of the epilogue waits for nothing else.
+  constexpr bool PREFETCH_SKIP = CASMVS_DECONV_PREFETCH && (MODE == FMT_TPX || NT == 1);
+  const rsrc_t dst = make_rsrc(out + b * out_ss, out_ss * 4);
+  const rsrc_t skp = make_rsrc(skip ? skip + b * out_ss : out, out_ss * 4);
+  float sc[NCO], sh[NCO];
+#pragma unroll
+  for (int h = 0; h < NCO; ++h) {
+    sc[h] = scale[NCO * kq + h];
+    sh[h] = shift[NCO * kq + h];
+  }
+  int vcell[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ct = wave * NT + t;
+    const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
+    const int mz = tz0 + cz, my = ty0 + cy, mx = tx0 + cx * 16 + jcol;
+    const bool ok = mz < Di && my < Hi && mx < Wi;
+    // per-lane part: first channel of the lane (slice*COUTB + NCO*kq) and the cell's even-corner voxel
+    vcell[t] = ok ? ((slice * COUTB + NCO * kq) * out_cs + (2 * mz * Ho + 2 * my) * Wo + 2 * mx) * 4 : kOOB;
+  }
+  [[maybe_unused]] f32x2 skall[PREFETCH_SKIP ? NT * 4 : 1][NCO];
+
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();
     TRACE_STAMP();  // after barrier 1
     regs.store(tile, wts);
     __syncthreads();
     TRACE_STAMP();  // after store + barrier 2
-    if (s + 1 < nstages)
+    if (s + 1 < nstages) {
       regs.load(src, cin, (s + 1) * CK, wslice + (size_t)(s + 1) * NW);
+    } else if (PREFETCH_SKIP && skip) {
+#pragma unroll
+      for (int bi = 0; bi < NT * 4; ++bi)
+#pragma unroll
+        for (int h = 0; h < NCO; ++h) {
+          const int t = bi / 4, ps = bi % 4;
+          const int voff = (slice * COUTB + NCO * kq + h < cout) ? vcell[t] : kOOB;
+          skall[PREFETCH_SKIP ? bi : 0][h] = buf_load2(skp, voff, (h * out_cs + ((ps >> 1) * Ho + (ps & 1)) * Wo) * 4);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       float aw[UI];  // this quad's images
@@ -1271,43 +1272,26 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
   }
 
   TRACE_STAMP();  // MFMA loops done
-  const rsrc_t dst = make_rsrc(out + b * out_ss, out_ss * 4);
-  const rsrc_t skp = make_rsrc(skip ? skip + b * out_ss : out, out_ss * 4);
-  float sc[NCO], sh[NCO];
-  int vcell[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int ct = wave * NT + t;
-    const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
-    const int mz = tz0 + cz, my = ty0 + cy, mx = tx0 + cx * 16 + jcol;
-    const bool ok = mz < Di && my < Hi && mx < Wi;
-    // per-lane part: first channel of the lane (slice*COUTB + NCO*kq) and the cell's even-corner voxel
-    vcell[t] = ok ? ((slice * COUTB + NCO * kq) * out_cs + (2 * mz * Ho + 2 * my) * Wo + 2 * mx) * 4 : kOOB;
-  }
-#pragma unroll
-  for (int h = 0; h < NCO; ++h) {
-    sc[h] = scale[NCO * kq + h];
-    sh[h] = shift[NCO * kq + h];
-  }
-  // Skip loads are issued in batches ahead of the stores.  Interleaved (load, wait, add, store per
-  // element) the in-order vmcnt wait of load i also waits for store i-1: 32 serial memory round trips
-  // per wave - measured 38k of the 61k cycles of a conv11 workgroup (tools/gpu_trace2.py).
-  // (tile, pass) pairs per batch of skip loads: TPX 16 x 8 bytes in flight per lane, TCI 8 (its two x-parity
-  // accumulators leave fewer registers: a 16-load batch would cost a resident workgroup per CU)
-  constexpr int BP = MODE == FMT_TCI ? 2 : 8;
+  // Without the prefetch (wide TCI tile: its two x-parity accumulators leave no room for 64 more registers) the skip
+  // loads are issued in batches ahead of the stores.  Interleaved (load, wait, add, store per element) the in-order vmcnt
+  // wait of load i also waits for store i-1: 32 serial memory round trips per wave - measured 38k of the 61k cycles of a
+  // conv11 workgroup (tools/gpu_trace2.py).
+  constexpr int BP = PREFETCH_SKIP ? NT * 4 : 2;  // (tile, pass) pairs per batch
   static_assert((NT * 4) % BP == 0, "batches cover the tile x pass pairs");
 #pragma unroll
   for (int b0 = 0; b0 < NT * 4; b0 += BP) {
-    f32x2 sk[BP][NCO];
-    if (skip) {
+    [[maybe_unused]] f32x2 sk[PREFETCH_SKIP ? 1 : BP][NCO];
+    if constexpr (!PREFETCH_SKIP) {
+      if (skip) {
 #pragma unroll
-      for (int bi = 0; bi < BP; ++bi)
+        for (int bi = 0; bi < BP; ++bi)
 #pragma unroll
-        for (int h = 0; h < NCO; ++h) {
-          const int t = (b0 + bi) / 4, ps = (b0 + bi) % 4;
-          const int voff = (slice * COUTB + NCO * kq + h < cout) ? vcell[t] : kOOB;
-          sk[bi][h] = buf_load2(skp, voff, (h * out_cs + ((ps >> 1) * Ho + (ps & 1)) * Wo) * 4);
-        }
+          for (int h = 0; h < NCO; ++h) {
+            const int t = (b0 + bi) / 4, ps = (b0 + bi) % 4;
+            const int voff = (slice * COUTB + NCO * kq + h < cout) ? vcell[t] : kOOB;
+            sk[bi][h] = buf_load2(skp, voff, (h * out_cs + ((ps >> 1) * Ho + (ps & 1)) * Wo) * 4);
+          }
+      }
     }
 #pragma unroll
     for (int bi = 0; bi < BP; ++bi) {
@@ -1326,8 +1310,9 @@ __global__ __launch_bounds__(kThreads) void deconv16_kernel(
         v0 = v0 > 0.0f ? v0 : v0 * slope;
         v1 = v1 > 0.0f ? v1 : v1 * slope;
         if (skip) {
-          v0 += sk[bi][h][0];
-          v1 += sk[bi][h][1];
+          const f32x2 sv = PREFETCH_SKIP ? skall[PREFETCH_SKIP ? b0 + bi : 0][h] : sk[PREFETCH_SKIP ? 0 : bi][h];
+          v0 += sv[0];
+          v1 += sv[1];
         }
         buf_store2(f32x2{v0, v1}, dst, voff, soff);
       }
@@ -1933,6 +1918,11 @@ int launch_prob_v(const float *packed, const float *in, float *out, int B, int c
 
 int launch_prob(const LayerCfg &, const float *packed, const float *in, float *out, int B, int cin,
                 int D, int H, int W, float slope, hipStream_t st) {
+  // depth-walking kernel (prob_regress.hip): cin == 8, 16-byte aligned rows; the tile kernels below serve the rest
+  static const bool no_zwalk = trace_env_set("CASMVS_NO_PROB_ZWALK");  // A/B switch (profiling build)
+  if (!no_zwalk && casmvs_prob_regress_supported(cin, W) && vec4_ok(in, W) && (reinterpret_cast<size_t>(out) & 15) == 0)
+    return casmvs_prob_regress_f32(packed, in, nullptr, out, nullptr, nullptr, nullptr, B, cin, D, H, W, slope,
+                                   trace_env_int("CASMVS_PROB_ZCHUNK", 0), st);
   static const bool no_pk = trace_env_set("CASMVS_NO_PROB_PK");  // A/B switch (profiling build)
   if (!no_pk && vec4_ok(in, W)) {
     if (int rc = ensure_lds(prob_pk_kernel, ProbPkCfg::LDS_BYTES, "prob_pk_kernel")) return rc;
@@ -2197,15 +2187,16 @@ extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
   return (size_t)B * floats * sizeof(float);
 }
 
-extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, const float *vol,
-                                          float *cost, void *workspace, int B, int cin, int D,
-                                          int h, int w, float slope, void *const *layer_events,
-                                          void *stream) {
-  casmvs::clear_error();
-  CASMVS_REQUIRE(packed_layers && vol && cost && workspace, "costreg_forward: null pointer");
+namespace {
+// conv0 .. conv11 (+ skips) into the workspace, then the `prob` head: on its own (depth == nullptr), or fused with the
+// softmax / regression / confidence that consumes it (casmvs_prob_regress_f32).
+int costreg_run(const char *who, const float *const *packed_layers, const float *vol, const float *depth_values,
+                float *cost, float *depth, float *confidence, int32_t *index, void *workspace, int B, int cin, int D,
+                int h, int w, float slope, void *const *layer_events, void *stream) {
+  CASMVS_REQUIRE(packed_layers && vol && cost && workspace, "%s: null pointer", who);
   CASMVS_REQUIRE(B > 0 && cin > 0 && D > 0 && h > 0 && w > 0 && D % 8 == 0 && h % 8 == 0 && w % 8 == 0,
-                 "costreg_forward: B=%d cin=%d D=%d h=%d w=%d (D, h, w must be multiples of 8)", B, cin, D, h, w);
-  for (int i = 0; i < 11; ++i) CASMVS_REQUIRE(packed_layers[i], "costreg_forward: packed_layers[%d] is null", i);
+                 "%s: B=%d cin=%d D=%d h=%d w=%d (D, h, w must be multiples of 8)", who, B, cin, D, h, w);
+  for (int i = 0; i < 11; ++i) CASMVS_REQUIRE(packed_layers[i], "%s: packed_layers[%d] is null", who, i);
   const size_t n = (size_t)B * D * h * w;
   float *ws = (float *)workspace;
   float *c0 = ws;            ws += 8 * n;
@@ -2237,10 +2228,37 @@ extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, con
   CASMVS_L(CASMVS_CONV_T2, P[7], c6, c4, u7, B, 64, 32, D / 8, h / 8, w / 8, sl, stream);           // conv4 + conv7
   CASMVS_L(CASMVS_CONV_T2, P[8], u7, c2, u9, B, 32, 16, D / 4, h / 4, w / 4, sl, stream);           // conv2 + conv9
   CASMVS_L(CASMVS_CONV_T2, P[9], u9, c0, u11, B, 16, 8, D / 2, h / 2, w / 2, sl, stream);           // conv0 + conv11
-  CASMVS_L(CASMVS_CONV_S1, P[10], u11, nullptr, cost, B, 8, 1, D, h, w, 1.0f, stream);              // prob
+  if (depth == nullptr) {
+    CASMVS_L(CASMVS_CONV_S1, P[10], u11, nullptr, cost, B, 8, 1, D, h, w, 1.0f, stream);            // prob
+  } else {
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    rc = casmvs_prob_regress_f32(P[10], u11, depth_values, cost, depth, confidence, index, B, 8, D, h, w, 1.0f,
+                                 trace_env_int("CASMVS_PROB_ZCHUNK", 0), stream);                   // prob + softmax regression
+    if (rc != CASMVS_OK) return rc;
+  }
 #undef CASMVS_L
   if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[11], (hipStream_t)stream);
   return CASMVS_OK;
+}
+}  // namespace
+
+extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, const float *vol,
+                                          float *cost, void *workspace, int B, int cin, int D,
+                                          int h, int w, float slope, void *const *layer_events,
+                                          void *stream) {
+  casmvs::clear_error();
+  return costreg_run("costreg_forward", packed_layers, vol, nullptr, cost, nullptr, nullptr, nullptr, workspace, B, cin, D, h, w,
+                     slope, layer_events, stream);
+}
+
+extern "C" int casmvs_costreg_regress_f32(const float *const *packed_layers, const float *vol, const float *depth_values,
+                                          float *cost, float *depth, float *confidence, int32_t *index, void *workspace,
+                                          int B, int cin, int D, int h, int w, float slope, void *const *layer_events,
+                                          void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(depth_values && depth && confidence, "costreg_regress: null pointer");
+  return costreg_run("costreg_regress", packed_layers, vol, depth_values, cost, depth, confidence, index, workspace, B, cin, D, h,
+                     w, slope, layer_events, stream);
 }
 
 extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float *tflops) {

@@ -8,6 +8,7 @@
 // Built with -ffp-contract=off: every * and + below is a separately rounded fp32 operation, in
 // the reference's (torch's) order.
 #include "common.h"
+#include "softmax_regress.h"
 
 namespace {
 
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kThreads) void hypotheses_kernel(
 }
 
 // ---- softmax + regression + confidence ---------------------------------------------------------
-template <int DT>  // DT > 0: D == DT, values cached in registers; DT == 0: generic 3-pass
+template <int DT>  // DT > 0: D == DT, values cached in registers; DT == 0: generic 3-pass (softmax_regress.h)
 __global__ __launch_bounds__(kThreads) void softmax_regress_kernel(
     const float *__restrict__ cost, const float *__restrict__ dvals, float *__restrict__ depth,
     float *__restrict__ conf, int32_t *__restrict__ index, int Drt, int hw) {
@@ -63,66 +64,9 @@ __global__ __launch_bounds__(kThreads) void softmax_regress_kernel(
   const int p = blockIdx.x * kThreads + threadIdx.x;
   if (p >= hw) return;
   const int D = DT > 0 ? DT : Drt;
-  const float *cp = cost + (size_t)b * D * hw + p;
-  const float *dp = dvals + (size_t)b * D * hw + p;
-  constexpr int NR = DT > 0 ? DT : 1;
-  float e[NR];
-  float mx = -INFINITY;
-  if (DT > 0) {
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      e[k] = cp[(size_t)k * hw];
-      mx = fmaxf(mx, e[k]);
-    }
-  } else {
-    for (int k = 0; k < D; ++k) mx = fmaxf(mx, cp[(size_t)k * hw]);
-  }
-  // p_k = exp(x_k - max) / sum                                   (F.softmax, mvsnet.py:175)
-  float sum = 0.0f;
-  if (DT > 0) {
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      e[k] = expf(e[k] - mx);
-      sum = sum + e[k];
-    }
-  } else {
-    for (int k = 0; k < D; ++k) sum = sum + expf(cp[(size_t)k * hw] - mx);
-  }
-  // depth = sum_k p_k d_k (modules.py:103); expected index = sum_k p_k k  (mvsnet.py:185-189)
-  float dsum = 0.0f, isum = 0.0f;
-  if (DT > 0) {
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      e[k] = e[k] / sum;
-      dsum = dsum + e[k] * dp[(size_t)k * hw];
-      isum = isum + e[k] * (float)k;
-    }
-  } else {
-    for (int k = 0; k < D; ++k) {
-      const float pk = expf(cp[(size_t)k * hw] - mx) / sum;
-      dsum = dsum + pk * dp[(size_t)k * hw];
-      isum = isum + pk * (float)k;
-    }
-  }
-  // .long() truncates toward zero; isum >= 0 so this is floor; clamp to [0, D-1] (mvsnet.py:189-190)
+  float dsum, c4;
   int idx;
-  if (!(isum == isum)) {
-    idx = 0;  // NaN: torch's float->int64 cast of NaN is INT64_MIN, clamped to 0
-  } else {
-    float cl = fminf(fmaxf(isum, 0.0f), (float)(D - 1));
-    idx = (int)cl;
-  }
-  // confidence = p[idx-1] + p[idx] + p[idx+1] + p[idx+2], zeros outside [0, D) (mvsnet.py:181-193:
-  // 4 * avg_pool3d of the (1, 2)-padded volume, window 4, then gather at idx)
-  float c4 = 0.0f;
-  if (DT > 0) {
-#pragma unroll
-    for (int k = 0; k < NR; ++k)
-      if (k >= idx - 1 && k <= idx + 2) c4 = c4 + e[k];
-  } else {
-    for (int k = max(idx - 1, 0); k <= min(idx + 2, D - 1); ++k)
-      c4 = c4 + expf(cp[(size_t)k * hw] - mx) / sum;
-  }
+  casmvs::softmax_regress_pixel<DT>(cost + (size_t)b * D * hw + p, dvals + (size_t)b * D * hw + p, (size_t)hw, D, dsum, c4, idx);
   depth[(size_t)b * hw + p] = dsum;
   conf[(size_t)b * hw + p] = c4;
   if (index) index[(size_t)b * hw + p] = idx;

@@ -126,6 +126,10 @@ def depth_regression(p, depth_values):
     casmvs_softmax_regress_f32); like every op here it refuses CPU tensors."""
     if not p.is_cuda:
         raise RuntimeError("casmvsnet_pl_amd.depth_regression runs on the MI355X only; there is no CPU fallback")
-    if depth_values.dim() not in (1, 4):
-        depth_values = depth_values.reshape(-1) if depth_values.numel() == p.shape[1] else depth_values.expand_as(p)
+    if depth_values.dim() == 1 and depth_values.shape[0] == p.shape[1]:
+        pass                                                   # (D): one depth per plane
+    elif depth_values.numel() == p.shape[1] and depth_values.dim() != 4:
+        depth_values = depth_values.reshape(-1)
+    elif tuple(depth_values.shape) != tuple(p.shape):          # anything `p * depth_values` broadcasts: (1,D,1,1), (B,D,1,1), ...
+        depth_values = depth_values.expand_as(p).contiguous()
     return ops.depth_regression(p.float(), depth_values.float()).to(depth_values.dtype)

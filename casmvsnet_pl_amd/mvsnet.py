@@ -41,30 +41,31 @@ def _fold_norm(owner, norm):
 class _PackedWeights:
     """Mixin of the modules that keep folded + packed device images of their parameters.
 
-    The images are rebuilt when a parameter / buffer tensor was replaced or modified in place through autograd-visible
-    operations (its storage pointer or `_version` changed - optimiser steps, `copy_`, `load_state_dict`), when the
-    module is moved / cast (`_apply`) and when a state dict is loaded.  An edit THROUGH `.data` (`p.data.mul_(..)`,
-    common in EMA / weight-surgery code) bumps no version counter: call `invalidate_packed()` after it."""
+    The images are rebuilt when a parameter / buffer was REPLACED (`m.weight = nn.Parameter(..)`, pruning,
+    parametrisation, a swapped sub-module: the key holds the identity of every current tensor), modified in place through
+    autograd-visible operations (its storage pointer or `_version` changed - optimiser steps, `copy_`,
+    `load_state_dict`), when the module is moved / cast (`_apply`) and when a state dict is loaded.  An edit THROUGH
+    `.data` (`p.data.mul_(..)`, common in EMA / weight-surgery code) bumps no version counter: call
+    `invalidate_packed()` after it."""
 
     def _init_packed(self):
         self._packed = None
         self._packed_key = None
-        self._key_tensors = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
     def invalidate_packed(self):
         self._packed = None
         self._packed_key = None
-        self._key_tensors = None
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_packed()
         return super()._apply(fn, *args, **kwargs)
 
     def _state_key(self, device):
-        if self._key_tensors is None:   # the tensor OBJECTS survive in-place updates; a replaced one changes data_ptr
-            self._key_tensors = list(self.state_dict(keep_vars=True).values())
-        return (str(device),) + tuple((t.data_ptr(), t._version) for t in self._key_tensors)
+        # walks the CURRENT module tree on every call (~40 us): a cached tensor list would keep answering for tensor
+        # objects that are no longer the module's (round-2 advisor finding)
+        return (str(device),) + tuple((id(t), t.data_ptr(), t._version) for m in self.modules()
+                                      for t in (*m._parameters.values(), *m._buffers.values()) if t is not None)
 
 
 class FeatureNet(_PackedWeights, nn.Module):
@@ -223,6 +224,18 @@ class CostRegNet(_PackedWeights, nn.Module):
         cost = ops.costreg_forward(packed, x, ws, slope=self._slope, layer_events=events)
         return cost.unsqueeze(1)
 
+    def regress(self, x, depth_values, return_index=False):
+        """CostRegNet + softmax / depth regression / confidence (mvsnet.py:174-193) in one library call: x (B,Cin,D,h,w),
+        depth_values (B,D,h,w) -> cost (B,D,h,w), depth (B,h,w), confidence (B,h,w) [, index].  Eval mode only."""
+        B, _, D, h, w = x.shape
+        packed = self.packed_layers(x.device)
+        need = ops.costreg_workspace_bytes(B, D, h, w)
+        ws = self._workspace
+        if ws is None or ws.device != x.device or ws.numel() < need:
+            ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        events = self.timer.layer_events(self.timer_name) if self.timer is not None else None
+        return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index)
+
 
 class CascadeMVSNet(nn.Module):
     """Cascade MVSNet with the reference's constructor / forward signature (mvsnet.py:107-244)."""
@@ -242,6 +255,7 @@ class CascadeMVSNet(nn.Module):
         self.keep_index = False
         self.view_shard_group = None   # a torch.distributed group: split the source views over its ranks (dist.py)
         self.keep_cost = False   # parity tests: keep the regularised cost (B,D,h,w) of every level in last_cost
+        self.fuse_regress = True  # eval mode: `prob` + softmax regression in one library call (CostRegNet.regress)
         self.last_cost = {}
         self._const_cache = {}
 
@@ -278,6 +292,15 @@ class CascadeMVSNet(nn.Module):
                 volume = ops.costvol(feats_channels_last, proj_mats, depth_values, self.G, channels_last=True)
             else:
                 volume = ops.costvol(feats, proj_mats, depth_values, self.G)
+        if self.fuse_regress and isinstance(cost_reg, CostRegNet) and not cost_reg.training:
+            # mvsnet.py:174-193 inside the CostRegNet call: the `prob` head hands its cost values to the regression
+            out = cost_reg.regress(volume, depth_values, return_index=self.keep_index)
+            cost, depth, confidence = out[:3]
+            if self.keep_index:
+                self.last_index[level] = out[3]
+            if self.keep_cost:
+                self.last_cost[level] = cost
+            return depth, confidence
         cost = cost_reg(volume).squeeze(1)                                  # mvsnet.py:174
         if self.keep_cost:
             self.last_cost[level] = cost

@@ -299,6 +299,61 @@ def costreg_forward(packed_layers, vol, workspace, slope=0.01, layer_events=None
     return cost
 
 
+def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, layer_events=None, return_index=False):
+    """CostRegNet + softmax / depth regression / confidence in one library call (mvsnet.py:91-104 + :174-193): the `prob`
+    head walks the depth axis and, when the whole depth range is one chunk, runs the regression on the cost values it has
+    just produced (casmvs_costreg_regress_f32).  -> cost (B,D,h,w), depth (B,h,w), confidence (B,h,w) [, index int32]."""
+    vol, depth_values = _dev(vol, "vol"), _dev(depth_values, "depth_values")
+    B, cin, D, h, w = vol.shape
+    if tuple(depth_values.shape) != (B, D, h, w):
+        raise ValueError(f"costreg_regress: shapes {tuple(vol.shape)} {tuple(depth_values.shape)}")
+    if len(packed_layers) != 11:
+        raise ValueError("costreg_regress: need 11 packed layers")
+    arr = (ctypes.c_void_p * 11)(*[p.data_ptr() for p in packed_layers])
+    dev = vol.device
+    cost = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+    depth = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+    conf = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+    index = torch.empty((B, h, w), dtype=torch.int32, device=dev) if return_index else None
+    if workspace.numel() * workspace.element_size() < costreg_workspace_bytes(B, D, h, w):
+        raise ValueError("costreg_regress: workspace too small")
+    ev = None
+    if layer_events is not None:
+        if len(layer_events) != 12:
+            raise ValueError("costreg_regress: need 12 events")
+        ev = (ctypes.c_void_p * 12)(*[e.cuda_event for e in layer_events])
+    with torch.cuda.device(dev):
+        rc = _lib.load().casmvs_costreg_regress_f32(arr, _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
+                                                    _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
+                                                    float(slope), ev, _stream(vol))
+    _lib.check(rc, "casmvs_costreg_regress_f32")
+    return (cost, depth, conf, index) if return_index else (cost, depth, conf)
+
+
+def prob_regress(packed, x, depth_values=None, slope=1.0, zchunk=0, return_index=False):
+    """The `prob` head on its own (casmvs_prob_regress_f32): x (B,8,D,h,w) -> cost (B,D,h,w); with depth_values (B,D,h,w)
+    also depth, confidence (B,h,w) [, index].  zchunk: output planes per workgroup along D (0 = library's choice)."""
+    x, packed = _dev(x, "x"), _dev(packed, "packed")
+    B, cin, D, h, w = x.shape
+    dev = x.device
+    cost = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+    depth = conf = index = None
+    if depth_values is not None:
+        depth_values = _dev(depth_values, "depth_values")
+        if tuple(depth_values.shape) != (B, D, h, w):
+            raise ValueError(f"prob_regress: shapes {tuple(x.shape)} {tuple(depth_values.shape)}")
+        depth = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+        conf = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+        index = torch.empty((B, h, w), dtype=torch.int32, device=dev) if return_index else None
+    with torch.cuda.device(dev):
+        rc = _lib.load().casmvs_prob_regress_f32(_ptr(packed), _ptr(x), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
+                                                 _ptr(index), B, cin, D, h, w, float(slope), int(zchunk), _stream(x))
+    _lib.check(rc, "casmvs_prob_regress_f32")
+    if depth_values is None:
+        return cost
+    return (cost, depth, conf, index) if return_index else (cost, depth, conf)
+
+
 _CONV2D_KSIZE = {CONV2D_K3: 3, CONV2D_K5S2: 5, CONV2D_K1: 1, CONV2D_K1_UP: 1}
 
 

@@ -470,6 +470,17 @@ def sl1_loss(results, depths, masks, levels=3):
     return loss
 
 
+def sl1_loss_masked(results, depths, masks, levels=3):
+    """The same loss without the boolean-mask indexing (no host sync, capturable into a hipGraph): the element-wise
+    SmoothL1 times the float mask, summed and divided by the mask's count - the mean over the masked elements."""
+    loss = 0
+    for l in range(levels):
+        m = masks[f"level_{l}"].to(results[f"depth_{l}"].dtype)
+        e = torch.nn.functional.smooth_l1_loss(results[f"depth_{l}"], depths[f"level_{l}"], reduction="none")
+        loss = loss + (e * m).sum() / m.sum() * 2 ** (1 - l)
+    return loss
+
+
 def train_steps(model, batches, optimizer, device="cuda"):
     """train.py:99-103 + Lightning's optimisation step, without Lightning: for every batch (dicts from pipeline.collate
     over pipeline.DTUReader samples in training layout: imgs_u8 / imgs, proj_mats, depths, masks, init_depth_min,

@@ -241,6 +241,31 @@ int casmvs_softmax_regress_f32(const float *cost, const float *depth_values, flo
                                float *confidence, int32_t *index, int B, int D, int h, int w,
                                void *stream);
 
+/* ---- (a8 tail + a9) the `prob` head walking the depth axis, fused with the regression ---------------
+ * Replaces: models/mvsnet.py:89,104 (`prob`: Conv3d 8 -> 1, k3 p1, bias) followed by models/mvsnet.py:174-193
+ *           (softmax, depth_regression, confidence) - one launch when the whole depth range is one chunk.
+ * packed : device image of the head's parameters (casmvs_conv3d_pack_f32, kind S1, cout 1)
+ * in     : device (B, 8, D, h, w), 16-byte aligned, w % 4 == 0 (casmvs_prob_regress_supported)
+ * cost   : device (B, D, h, w), always written (the regularised cost, mvsnet.py:174), 16-byte aligned
+ * depth_values (B, D, h, w), depth / confidence (B, h, w), index (B, h, w) int32 or NULL: as
+ *          casmvs_softmax_regress_f32; depth == NULL: only `cost` is produced (all four may then be NULL)
+ * slope  : leaky-relu slope of the head (1.0 = none, the reference)
+ * zchunk : output planes per workgroup along D; 0 = chosen by the library (the whole range when the pixel
+ *          tiles fill the chip: then the regression runs inside the same kernel, else as a second launch).
+ */
+int casmvs_prob_regress_supported(int cin, int w);
+int casmvs_prob_regress_f32(const float *packed, const float *in, const float *depth_values, float *cost,
+                            float *depth, float *confidence, int32_t *index, int B, int cin, int D, int h,
+                            int w, float slope, int zchunk, void *stream);
+
+/* Whole CostRegNet + regression: casmvs_costreg_forward_f32 with the head replaced by casmvs_prob_regress_f32.
+ * `cost` (B, D, h, w) is still produced.  layer_events: as casmvs_costreg_forward_f32 (event 10 before the head,
+ * event 11 after the head INCLUDING the regression). */
+int casmvs_costreg_regress_f32(const float *const *packed_layers, const float *vol, const float *depth_values,
+                               float *cost, float *depth, float *confidence, int32_t *index, void *workspace,
+                               int B, int cin, int D, int h, int w, float slope, void *const *layer_events,
+                               void *stream);
+
 /* Replaces: models/modules.py:95-104 `depth_regression(p, depth_values)` on its own (the engine's forward uses the
  * fused kernel above): out[b, y, x] = sum_k prob[b, k, y, x] * d, with d = depth_values[b, k, y, x]
  * (depth_values_per_plane == 0, shape (B, D, h, w)) or depth_values[k] (depth_values_per_plane != 0, shape (D)). */

@@ -165,3 +165,25 @@ def test_wgrad_vector_staging_writes_every_tile_cell_exactly_once(S, KZ, KS):
     # a vector unit's first element: global x = x0 * S - P + (P + 4 k) = x0 * S + 4 k: a multiple of 4 floats
     vec_starts = {ix for (_, _, _, ix) in big[: 16 * g["IZ"] * g["IY"] * 4 * S * 4 : 4]}
     assert all((ix - g["P"]) % 4 == 0 for ix in vec_starts)
+
+
+@pytest.mark.parametrize("D,H,W,zc", [(8, 8, 68, 8), (8, 12, 64, 4), (16, 4, 8, 8), (4, 9, 132, 3)])
+def test_prob_zwalk_model_staging_and_rotating_accumulators_are_the_prob_convolution(D, H, W, zc):
+    """csrc/prob_regress.hip: the staging plan writes every LDS cell of a plane slot exactly once, every output voxel is
+    produced exactly once, and the depth walk (three rotating accumulators, chunks of zc planes with one halo plane on
+    either side, ragged last tiles / chunks) equals Conv3d(8 -> 1, k3 p1) + bias on the C packer's image."""
+    g = torch.Generator().manual_seed(D * 1000 + W)
+    x = torch.randn(2, 8, D, H, W, generator=g)
+    w = torch.randn(1, 8, 3, 3, 3, generator=g) * 0.2
+    bias = torch.randn(1, generator=g)
+    packed = ops.conv3d_pack(ops.CONV_S1, w, None, bias)
+    ref = F.conv3d(x.double(), w.double(), bias.double(), padding=1)[:, 0]
+    got = KM.emulate_prob_zwalk(packed, x, zc)
+    assert float((got - ref).abs().max()) < 1e-10
+
+
+def test_prob_zwalk_tap_reads_are_bank_conflict_free():
+    """The two ds_read_b128 of a (channel pair, ky) step take 4 LDS cycles each (the minimum) with the kernel's row stride;
+    the 16-lanes-per-row alternative (32 x 16 tile) would take 8 whatever the stride."""
+    assert KM.prob_zwalk_bank_cycles(KM.PZ_RS, 0) == 4 and KM.prob_zwalk_bank_cycles(KM.PZ_RS, 4) == 4
+    assert KM.PZ_RS % 4 == 0 and KM.PZ_RS >= 2 * (KM.PZ_TX + 2)

@@ -36,9 +36,60 @@ def test_algorithmic_work_matches_survey_8d(bench):
 
 
 def test_pmc_traffic_lookup(bench):
-    val, note = bench.pmc_traffic("conv16db_kernel<2, 4, 4, 4, 4, 32", 2)
+    val, note, src = bench.pmc_traffic("conv16db_kernel<2, 4, 4, 4, 4, 32", 2)
     assert val is None or 3.8e8 < val < 2e9, note   # >= the algorithmic 384 MB of the same launches
+    assert val is None or src["file"].startswith("profiles/")
     assert bench.pmc_traffic("conv16db_kernel<2, 4, 4, 4, 4, 32", 1)[0] is None
+
+
+def _rank_aggregate(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    # rank r took (1 + r) seconds for 40 * (r + 1) depth maps
+    rep = mod.aggregate(1.0 + rank, 40 * (rank + 1), dist)                      # replica: MAX time, SUM maps
+    shard = mod.aggregate(1.0 + rank, 40, dist, sum_maps=False)                 # view-sharded: the same maps on every rank
+    line = None
+    if rank == 0:
+        line = mod.base_line("depth-maps/sec at 640x512, 3 views, n_depths=[8,32,48]", "depth-maps/s", rep[1] / rep[0], world, 20, 5,
+                             rep[0], "weak", {"workload": "dtu_640x512_v3_var"}, 1.23)
+    q.put((rank, rep, shard, line))
+    dist.destroy_process_group()
+
+
+def test_rank_aggregation_and_json_contract_at_world_size_2():
+    """bench.py's cross-rank bookkeeping on the gloo backend (the driver's N > 1 runs use nccl = RCCL): wall time = MAX over
+    ranks, depth maps = SUM over ranks (replica) or the local count (view-sharded); rank 0's line carries the driver's keys."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_rank_aggregate, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, rep, shard, line in got:
+        assert rep == (2.0, 120) and shard == (2.0, 40)
+    line = got[0][3]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config"):
+        assert key in line
+    assert line["value"] == 60.0 and line["n_gpus"] == 2 and line["ms_per_step"] == 100.0 and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and line["dtype"] == "f32" and line["config"]["workload"] == "dtu_640x512_v3_var"
+    assert bench_single_rank_aggregate()
+
+
+def bench_single_rank_aggregate():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.aggregate(0.5, 7) == (0.5, 7)
 
 
 def test_bench_refuses_to_run_without_a_gpu():

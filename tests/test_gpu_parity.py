@@ -251,6 +251,55 @@ def test_conv3d_layer_matches_torch_cpu(dev, report, kind, cin, cout, B, D, H, W
     assert err < 1.2e-5  # measured <= 1.1e-6
 
 
+PROB_CASES = [(1, 8, 8, 64), (2, 8, 32, 40), (1, 32, 16, 72), (2, 48, 24, 132), (1, 12, 9, 36), (1, 4, 5, 8), (1, 16, 70, 196)]
+
+
+@pytest.mark.parametrize("B,D,h,w", PROB_CASES)
+def test_prob_head_depth_walk_matches_conv3d(dev, report, B, D, h, w):
+    """csrc/prob_regress.hip (mvsnet.py:89,104): Conv3d(8 -> 1, k3 p1) + bias with the depth axis walked by one workgroup
+    per pixel tile - whole range, library-chosen chunks and explicit chunk sizes (ragged last chunk, one-plane halos,
+    ragged tiles in x / y) - vs torch CPU float64; the chunked forms are BIT-equal to the unchunked one (same FMA order)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + D * 10 + w)
+    x = torch.randn(B, 8, D, h, w, generator=g)
+    wt = torch.randn(1, 8, 3, 3, 3, generator=g) * 0.2
+    bias = torch.randn(1, generator=g)
+    want = F.conv3d(x.double(), wt.double(), bias.double(), padding=1)[:, 0]
+    packed = ops.conv3d_pack(ops.CONV_S1, wt, None, bias).to(dev)
+    xd = x.to(dev)
+    whole = ops.prob_regress(packed, xd, zchunk=D).cpu()
+    err = scaled_err(whole, want)
+    report("prob_zwalk", shape=[B, D, h, w], scaled_err=err)
+    assert err < 1.2e-5
+    for zc in (0, 4, 8, 5, 1):
+        assert torch.equal(ops.prob_regress(packed, xd, zchunk=zc).cpu(), whole), f"zchunk={zc}"
+    # the layer entry point of the C ABI (casmvs_conv3d_forward_f32, cout == 1) runs the same kernel
+    assert torch.equal(ops.conv3d_forward(ops.CONV_S1, packed, xd, 1, slope=1.0).cpu()[:, 0], whole)
+
+
+@pytest.mark.parametrize("B,D,h,w", [(1, 8, 32, 64), (2, 32, 16, 40), (1, 48, 16, 72), (1, 12, 9, 36), (1, 16, 12, 20)])
+def test_prob_head_fused_regression_equals_the_two_kernel_form(dev, report, B, D, h, w):
+    """mvsnet.py:174-193 inside the head's kernel (one chunk: every thread regresses the cost values it produced) ==
+    casmvs_softmax_regress_f32 on the same cost, bit for bit - depth, confidence, index - and the chunked call (which
+    launches the regression separately) as well; the regression itself vs the oracle."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 100 + D + w)
+    x = torch.randn(B, 8, D, h, w, generator=g)
+    wt = torch.randn(1, 8, 3, 3, 3, generator=g) * 0.6   # a peaked softmax
+    bias = torch.randn(1, generator=g)
+    dv = 425.0 + torch.rand(B, 1, h, w, generator=g) * 100.0 + 2.5 * torch.arange(D).view(1, D, 1, 1)
+    packed = ops.conv3d_pack(ops.CONV_S1, wt, None, bias).to(dev)
+    xd, dvd = x.to(dev), dv.contiguous().to(dev)
+    cost, depth, conf, idx = ops.prob_regress(packed, xd, dvd, zchunk=D, return_index=True)       # fused
+    d2, c2, i2 = ops.softmax_regress(cost, dvd, return_index=True)
+    assert torch.equal(depth, d2) and torch.equal(conf, c2) and torch.equal(idx, i2)
+    cost3, d3, c3, i3 = ops.prob_regress(packed, xd, dvd, zchunk=4, return_index=True)            # chunked + regression launch
+    assert torch.equal(cost3, cost) and torch.equal(d3, depth) and torch.equal(c3, conf) and torch.equal(i3, idx)
+    want_d, _, _ = R.softmax_regress(cost.cpu(), dv.contiguous())
+    report("prob_regress_fused", shape=[B, D, h, w], depth_rel=rel_err(depth, want_d))
+    assert rel_err(depth, want_d) < 1e-5
+
+
 @pytest.mark.parametrize("cin,B,D,h,w", [(8, 1, 8, 32, 40), (16, 1, 32, 16, 24), (32, 2, 16, 16, 16)])
 def test_costreg_matches_oracle(dev, report, cin, B, D, h, w):
     from casmvsnet_pl_amd import ABN, CostRegNet

@@ -68,6 +68,47 @@ def test_packed_layer_cache_tracks_parameter_changes():
     assert net.packed_layers(torch.device("cpu")) is not p2
 
 
+def test_packed_layer_cache_sees_a_replaced_parameter_or_module():
+    """Weight surgery that swaps the tensor OBJECT (`m.weight = nn.Parameter(..)`, a swapped sub-module): the old object
+    keeps its data_ptr / _version, so the key must hold the identity of the module's CURRENT tensors (advisor, round 2)."""
+    import torch.nn as nn
+    net = CostRegNet(8, ABN).eval()
+    cpu = torch.device("cpu")
+    p1 = net.packed_layers(cpu)
+    net.prob.weight = nn.Parameter(net.prob.weight.detach() * 3.0)
+    p2 = net.packed_layers(cpu)
+    assert p2 is not p1 and not torch.equal(p1[10], p2[10])
+    net.conv2.bn = ABN(16).eval()
+    with torch.no_grad():
+        net.conv2.bn.weight.fill_(0.5)
+    p3 = net.packed_layers(cpu)
+    assert p3 is not p2 and not torch.equal(p2[2], p3[2])
+    assert net.packed_layers(cpu) is p3                                             # and still a cache hit when nothing changed
+
+
+def test_depth_regression_accepts_every_shape_the_reference_broadcasts():
+    """modules.py:95-104 multiplies p (B,D,H,W) by depth_values: (D,), (B,D,H,W) and anything broadcastable."""
+    import casmvsnet_pl_amd.modules as M
+    seen = {}
+
+    def fake(p, dv):
+        seen["shape"] = tuple(dv.shape)
+        return torch.zeros(p.shape[0], *p.shape[2:])
+
+    class FakeP(torch.Tensor):
+        is_cuda = True
+    p = torch.rand(2, 4, 3, 5).as_subclass(FakeP)
+    orig = M.ops.depth_regression
+    M.ops.depth_regression = fake
+    try:
+        for shape, want in (((4,), (4,)), ((2, 4, 3, 5), (2, 4, 3, 5)), ((1, 4, 1, 1), (2, 4, 3, 5)), ((2, 4, 1, 1), (2, 4, 3, 5)),
+                            ((4, 1, 1), (4,))):
+            M.depth_regression(p, torch.rand(shape))
+            assert seen["shape"] == want, (shape, seen["shape"])
+    finally:
+        M.ops.depth_regression = orig
+
+
 def test_featurenet_packing_folds_abn_and_tracks_parameter_changes():
     from casmvsnet_pl_amd import FeatureNet
     import torch.nn.functional as F
