@@ -22,6 +22,8 @@
 // regression launch and its read of the cost volume from memory disappear.
 //
 // Bound: VALU issue (108 v_pk_fma_f32 per output voxel); nominal roof: HBM (8 input channels + 1 output per voxel).
+#include <type_traits>
+
 #include "buffer_ops.h"
 #include "common.h"
 #include "softmax_regress.h"
@@ -54,29 +56,54 @@ struct ProbZCfg {
 template <int KZM>
 __device__ __forceinline__ void zwalk_plane(const float *rows, const float *__restrict__ wpk, f32x2 (&A)[3][2]) {
   using Cfg = ProbZCfg;
-  // the rows of step i + 1 = (pair, ky) are read from LDS before the FMAs of step i are issued
-  f32x4v lo = *reinterpret_cast<const f32x4v *>(rows), hi = *reinterpret_cast<const f32x4v *>(rows + 4);
+  constexpr int NSTEP = Cfg::NPAIR * 3;  // step i = (pair i / 3, ky = i % 3)
+  // Software pipeline, pinned with sched_barrier: the two LDS rows AND the scalar weight loads of step i + 1 are issued
+  // before the FMAs of step i, so that the one wait a step needs (lgkmcnt(0): scalar loads return out of order, any wait
+  // on them is a full drain) finds everything landed.  (First version: the compiler issued each step's s_load / ds_read
+  // right in front of its own wait - 12 exposed scalar-cache + LDS latencies per plane with 72 FMA cycles between them:
+  // the kernel ran at a third of its VALU time whatever the chunking or the prefetch depth.)
+  f32x4v lo[2], hi[2];
+  f32x2 W[2][3][3];  // [buffer][kz][kx]: (even, odd channel) weights of the step
+  auto fetch = [&](auto buf_, int i) {
+    constexpr int BUF = decltype(buf_)::value;
+    const float *row = rows + (i / 3) * Cfg::SP + (i % 3) * Cfg::RS;
+    lo[BUF] = *reinterpret_cast<const f32x4v *>(row);
+    hi[BUF] = *reinterpret_cast<const f32x4v *>(row + 4);
+    const float *wq = wpk + (i / 3) * 64 + (i % 3) * 6;  // taps (kz, ky, kx = 0..2) x (even, odd channel) at [kz * 18 + 2 kx + c]
 #pragma unroll
-  for (int i = 0; i < Cfg::NPAIR * 3; ++i) {
-    const int p = i / 3, ky = i % 3;
-    const f32x2 P[4] = {f32x2{lo[0], lo[1]}, f32x2{lo[2], lo[3]}, f32x2{hi[0], hi[1]}, f32x2{hi[2], hi[3]}};
-    if (i + 1 < Cfg::NPAIR * 3) {
-      const float *row = rows + ((i + 1) / 3) * Cfg::SP + ((i + 1) % 3) * Cfg::RS;
-      lo = *reinterpret_cast<const f32x4v *>(row);
-      hi = *reinterpret_cast<const f32x4v *>(row + 4);
+    for (int kz = 0; kz < 3; ++kz) {
+      if (!((KZM >> kz) & 1)) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) W[BUF][kz][kx] = f32x2{wq[kz * 18 + 2 * kx], wq[kz * 18 + 2 * kx + 1]};
     }
-    const float *wq = wpk + p * 64 + ky * 6;  // taps (kz, ky, kx = 0..2) x (even, odd channel) at [kz * 18 + 2 kx + c]
+  };
+  auto fmas = [&](auto buf_) {
+    constexpr int BUF = decltype(buf_)::value;
+    const f32x2 P[4] = {f32x2{lo[BUF][0], lo[BUF][1]}, f32x2{lo[BUF][2], lo[BUF][3]}, f32x2{hi[BUF][0], hi[BUF][1]}, f32x2{hi[BUF][2], hi[BUF][3]}};
     // tap by tap over the (up to) six independent accumulators (kz, pixel): no two consecutive FMAs depend on each other
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
       for (int kz = 0; kz < 3; ++kz) {
         if (!((KZM >> kz) & 1)) continue;
-        const f32x2 W{wq[kz * 18 + 2 * kx], wq[kz * 18 + 2 * kx + 1]};
-        A[2 - kz][0] = __builtin_elementwise_fma(P[kx], W, A[2 - kz][0]);
-        A[2 - kz][1] = __builtin_elementwise_fma(P[kx + 1], W, A[2 - kz][1]);
+        A[2 - kz][0] = __builtin_elementwise_fma(P[kx], W[BUF][kz][kx], A[2 - kz][0]);
+        A[2 - kz][1] = __builtin_elementwise_fma(P[kx + 1], W[BUF][kz][kx], A[2 - kz][1]);
       }
     }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  fetch(B0{}, 0);
+#pragma unroll
+  for (int i = 0; i < NSTEP; i += 2) {
+    fetch(B1{}, i + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fmas(B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 2 < NSTEP) fetch(B0{}, i + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    fmas(B1{});
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -124,21 +151,39 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
       loff[k][j] = (e < Cfg::ITEMS && q >= 0 && q <= Cfg::TX + 1) ? p * SP + iy * RS + 2 * q : SLOT;
     }
   }
-  f32x4v v0[NK], v1[NK];
-  auto load_plane = [&](int z) {  // z in [0, Di)
-    const int soff = z * HiWi * 4;
+  // two register sets: the plane after next is in flight from memory while the next one waits in registers for its LDS
+  // slot - every load has a whole plane step plus its own to land (with one set the load of plane z + 1 had to land within
+  // the FMAs of plane z: ~1.3 us, about the memory latency once HBM is busy)
+#ifndef CASMVS_PROB_PREFETCH
+#define CASMVS_PROB_PREFETCH 2   // planes in flight ahead of the one being multiplied (1: A/B builds)
+#endif
+  constexpr int NSET = CASMVS_PROB_PREFETCH;
+  static_assert(NSET == 1 || NSET == 2, "one or two staging register sets");
+  f32x4v v0[NSET][NK], v1[NSET][NK];
+  // Loads, LDS stores and the cost store of a step are issued UNCONDITIONALLY (a plane that does not exist is read through
+  // an empty buffer descriptor = zeros; a cost plane outside the chunk is stored to an out-of-range offset = dropped): with
+  // a vector-memory operation inside a branch the compiler's wait-count pass must assume it did not execute and waits
+  // vmcnt(0) for the OLDER set - i.e. also for the loads it has just issued (seen in the ISA of the first version).
+  const rsrc_t none = make_rsrc(in, 0);
+  auto load_plane = [&](auto set_, int z, bool exists) {
+    constexpr int S = decltype(set_)::value;
+    const rsrc_t r = exists ? src : none;
+    const int soff = exists ? z * HiWi * 4 : 0;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-      v0[k] = buf_load4(src, voff0[k], soff);
-      v1[k] = buf_load4(src, voff1[k], soff);
+      v0[S][k] = buf_load4(r, voff0[k], soff);
+      v1[S][k] = buf_load4(r, voff1[k], soff);
     }
   };
-  auto store_plane = [&](float *slot) {
+  auto store_plane = [&](auto set_, float *slot) {
+    constexpr int S = decltype(set_)::value;
 #pragma unroll
     for (int k = 0; k < NK; ++k)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2 *>(slot + loff[k][j]) = f32x2{v0[k][j], v1[k][j]};
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2 *>(slot + loff[k][j]) = f32x2{v0[S][k][j], v1[S][k][j]};
   };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, NSET - 1>;
 
   const int oy = ty0 + yi, ox = tx0 + 2 * xi;
   const int out_voff = (oy < Hi && ox < Wi) ? (oy * Wi + ox) * 4 : kOOB;  // Wi even: the pixel pair is inside or outside
@@ -146,36 +191,46 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
 #pragma unroll
   for (int i = 0; i < 3; ++i) A[i][0] = A[i][1] = f32x2{0.f, 0.f};
 
-  const int nplanes = z_hi - z_lo + 2;  // input planes z_lo - 1 .. z_hi
-  int zin = z_lo - 1;
-  if (zin >= 0) {
-    load_plane(zin);
-    store_plane(smem);
-  }
-  __syncthreads();
-  for (int it = 0; it < nplanes; ++it, ++zin) {
+  const int nplanes = z_hi - z_lo + 2;  // input planes z_lo - 1 .. z_hi (step `it` multiplies plane z_lo - 1 + it)
+  const int z0 = z_lo - 1;
+  // step `it`, staging set PAR = it & 1 (NSET == 2): LDS slot PAR holds plane z0 + it; set 1 - PAR holds plane z0 + it + 1
+  // (in flight since step it - 1 or the prologue); set PAR is free -> plane z0 + it + 2 is put in flight into it
+  auto step = [&](int it, auto par_) {
+    constexpr int PAR = decltype(par_)::value;
+    using Mine = std::integral_constant<int, NSET == 2 ? PAR : 0>;
+    using Other = std::integral_constant<int, NSET == 2 ? 1 - PAR : 0>;
+    const int zin = z0 + it;
     const float *cur = smem + (it & 1) * SLOTS;
-    const bool nxt = it + 1 < nplanes && zin + 1 < Di;  // the next plane exists (zin + 1 >= 0 always)
-    if (nxt) load_plane(zin + 1);
+    if (NSET == 2) load_plane(Mine{}, zin + 2, it + 2 < nplanes && zin + 2 < Di);
+    else load_plane(Mine{}, zin + 1, it + 1 < nplanes && zin + 1 < Di);
     if (zin >= 0 && zin < Di) {
       const float *rows = cur + yi * RS + 4 * xi;
       if (it == 0) zwalk_plane<1>(rows, wpk, A);                 // only output plane z_lo takes from plane z_lo - 1
       else if (it == nplanes - 1) zwalk_plane<4>(rows, wpk, A);  // only output plane z_hi - 1 takes from plane z_hi
       else zwalk_plane<7>(rows, wpk, A);
     }
-    if (it >= 2) {  // output plane zin - 1 in [z_lo, z_hi) is complete
+    {  // output plane zin - 1 is complete; it lies in [z_lo, z_hi) from step 2 on
       float o0 = fmaf(A[0][0][0] + A[0][0][1], sc0, sh0), o1 = fmaf(A[0][1][0] + A[0][1][1], sc0, sh0);
       o0 = o0 > 0.0f ? o0 : o0 * slope;
       o1 = o1 > 0.0f ? o1 : o1 * slope;
-      buf_store2(f32x2{o0, o1}, dst, out_voff, (zin - 1) * HiWi * 4);
+      buf_store2(f32x2{o0, o1}, dst, it >= 2 ? out_voff : kOOB, it >= 2 ? (zin - 1) * HiWi * 4 : 0);
     }
     A[0][0] = A[1][0];
     A[0][1] = A[1][1];
     A[1][0] = A[2][0];
     A[1][1] = A[2][1];
     A[2][0] = A[2][1] = f32x2{0.f, 0.f};
-    if (nxt) store_plane(smem + ((it + 1) & 1) * SLOTS);
+    store_plane(Other{}, smem + ((it + 1) & 1) * SLOTS);   // (zeros when plane zin + 1 does not exist: never multiplied)
     __syncthreads();  // the other slot is published, this one is free
+  };
+  // prologue: plane z0 -> set 0 -> slot 0; plane z0 + 1 -> set 1 (in flight)
+  load_plane(Set0{}, z0, z0 >= 0);
+  if (NSET == 2) load_plane(Set1{}, z0 + 1, nplanes > 1 && z0 + 1 < Di);
+  store_plane(Set0{}, smem);
+  __syncthreads();
+  for (int it = 0; it < nplanes; it += 2) {
+    step(it, Set0{});
+    if (it + 1 < nplanes) step(it + 1, std::integral_constant<int, 1>{});
   }
 
   if constexpr (FUSE) {

@@ -43,8 +43,8 @@ def homo_warp(src_feat, proj_mat, depth_values):
     R = proj_mat[:, :, :3]                                                          # :62
     T = proj_mat[:, :, 3:]                                                          # :63
     # kornia.utils.create_meshgrid(H, W, normalized_coordinates=False): [...,0]=x, [...,1]=y  :66-67
-    xs = torch.linspace(0, W - 1, W, dtype=torch.float32)
-    ys = torch.linspace(0, H - 1, H, dtype=torch.float32)
+    xs = torch.linspace(0, W - 1, W, dtype=src_feat.dtype)   # float32 in the reference; float64 when the whole oracle
+    ys = torch.linspace(0, H - 1, H, dtype=src_feat.dtype)   # is run in double (the "truth" of the gradient tests)
     gy, gx = torch.meshgrid(ys, xs, indexing="ij")
     ref_grid = torch.stack([gx, gy], 0).reshape(1, 2, H * W).expand(B, -1, -1)     # :68-69
     ref_grid = torch.cat((ref_grid, torch.ones_like(ref_grid[:, :1])), 1)           # :70
@@ -174,9 +174,9 @@ def softmax_regress(cost, depth_values):
     return depth, confidence, depth_index
 
 
-def initial_depth_values(init_depth_min, depth_interval_l, D, B, h, w):
+def initial_depth_values(init_depth_min, depth_interval_l, D, B, h, w, dtype=torch.float32):
     """mvsnet.py:213-229."""
-    steps = torch.arange(0, D, dtype=torch.float32)
+    steps = torch.arange(0, D, dtype=dtype)
     if isinstance(init_depth_min, float):
         dv = init_depth_min + depth_interval_l * steps                                     # :216-219
         return dv.reshape(1, D, 1, 1).expand(B, D, h, w).contiguous()                      # :220-221
@@ -236,7 +236,7 @@ def cascade_forward_train(sd, imgs, proj_mats, init_depth_min, depth_interval, n
         D = n_depths[l]
         h, w = feats_l.shape[-2:]
         if l == 2:
-            depth_values = initial_depth_values(init_depth_min, depth_interval_l, D, B, h, w)
+            depth_values = initial_depth_values(init_depth_min, depth_interval_l, D, B, h, w, dtype=imgs.dtype)
         else:
             depth_lm1 = F.interpolate(depth_l.detach().unsqueeze(1), scale_factor=2, mode="bilinear",
                                       align_corners=True)                                  # :231-234

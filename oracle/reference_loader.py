@@ -67,3 +67,53 @@ def build_reference_model(n_depths, interval_ratios, num_groups, state_dict=None
     if num_groups == 1:
         model.training = True
     return model
+
+
+_GENERIC = ("models", "datasets", "utils", "inplace_abn", "kornia", "cv2", "numba", "plyfile", "torchvision")
+
+
+def _import_from_reference(names, extra_files=()):
+    """Import top-level modules `names` (and single files) of the reference with /root/reference and the shims in front of
+    sys.path, keep them under private names, then restore sys.path / sys.modules so that same-named packages of the
+    environment (HuggingFace `datasets`, the product's drop-in `models`) stay importable afterwards."""
+    import importlib.util
+    if not reference_available():
+        raise RuntimeError(f"reference not found under {REFERENCE_ROOT}")
+    saved_path = list(sys.path)
+    saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in _GENERIC}
+    for k in saved:
+        del sys.modules[k]
+    out = {}
+    try:
+        sys.path.insert(0, REFERENCE_ROOT)
+        sys.path.insert(0, _SHIMS)
+        for n in names:
+            out[n] = importlib.import_module(n)
+        for alias, rel in extra_files:
+            spec = importlib.util.spec_from_file_location(alias, os.path.join(REFERENCE_ROOT, rel))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            out[alias] = mod
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in _GENERIC]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+        sys.path[:] = saved_path
+    return out
+
+
+def load_reference_eval():
+    """The unmodified /root/reference/eval.py as a module (its __main__ block does not run): `xy_ref2src`, `xy_src2ref`,
+    `check_geo_consistency` (eval.py:113-182) are the reference's own numpy code; behind them `numba.jit` is the identity and
+    `cv2.remap` / `cv2.resize` are oracle/fusion_restatement.py (see oracle/shims/cv2)."""
+    if "_casmvs_ref_eval" not in sys.modules:
+        sys.modules["_casmvs_ref_eval"] = _import_from_reference((), [("_casmvs_ref_eval", "eval.py")])["_casmvs_ref_eval"]
+    return sys.modules["_casmvs_ref_eval"]
+
+
+def load_reference_datasets():
+    """The unmodified /root/reference/datasets package (DTUDataset, BlendedMVSDataset, TanksDataset) behind the cv2 /
+    torchvision shims (PIL is installed and does the decoding / bilinear resize, as in the reference)."""
+    if "_casmvs_ref_datasets" not in sys.modules:
+        sys.modules["_casmvs_ref_datasets"] = _import_from_reference(("datasets",))["datasets"]
+    return sys.modules["_casmvs_ref_datasets"]

@@ -9,7 +9,7 @@ from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict, tensor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("e2e_") and f.endswith(".npz"))
 
 
 class Golden:

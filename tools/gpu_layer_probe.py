@@ -71,7 +71,7 @@ for l, D in ((2, 48), (1, 32), (0, 8)):
         row = [f"    prob head (HBM {byt / 8e3 / 1e3:.1f} us at 8 TB/s):"]
         us = timed(lambda: ops.conv3d_forward(ops.CONV_S1, pk, x, 1, slope=1.0))
         row.append(f"layer entry {us:.1f}")
-        for zc in sorted({0, 4, 8, 16, D}):
+        for zc in ([int(z) for z in os.environ['LAYER_PROBE_ZCHUNKS'].split(',')] if os.environ.get('LAYER_PROBE_ZCHUNKS') else sorted({0, 4, 8, 16, D})):
             if zc > D:
                 continue
             us = timed(lambda: ops.prob_regress(pk, x, zchunk=zc))

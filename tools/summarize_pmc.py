@@ -15,7 +15,11 @@ for ps in sys.argv[2:]:
             k = r["Kernel_Name"]
             if "costvol" not in k and "homo_warp" not in k and os.environ.get("PMC_ALL") is None:
                 continue
+            if os.environ.get("PMC_FILTER") and not re.search(os.environ["PMC_FILTER"], k):
+                continue
             k = re.sub(r"\(anonymous namespace\)::|void |\(.*", "", k)
+            if os.environ.get("PMC_BY_GRID"):   # the same kernel at several launch shapes (cascade levels): one row per grid
+                k += " grid " + r.get("Grid_Size", "?")
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("==", ps)
     for k in sorted(acc):
