@@ -36,17 +36,21 @@ constexpr int kThreads = 256;
 struct ProbZCfg {
   static constexpr int TX = 64, TY = 8;          // output pixels per workgroup; a thread = 2 consecutive x of one row
   static constexpr int IY = TY + 2;              // staged rows y0 - 1 .. y0 + TY
-  static constexpr int NG = TX / 4 + 2;          // 16-byte global groups per staged row: x0 - 4 .. x0 + TX + 3
-  static constexpr int RS = 2 * (TX + 2);        // floats per LDS row: positions x0 - 1 .. x0 + TX, [position][channel of the pair]
+  static constexpr int NPP = TX / 2 + 1;         // position pairs per staged row: positions x0 - 1 .. x0 + TX as (x0 - 1 + 2 m, x0 + 2 m)
+  static constexpr int RS = 4 * NPP;             // floats per LDS row: [position][channel of the pair]; rows are contiguous
   static constexpr int SP = IY * RS;             // floats per channel pair of one plane
   static constexpr int NPAIR = 4;                // 8 input channels
-  static constexpr int SLOT = NPAIR * SP;        // floats per plane slot (+ 4: a dump pair for the unused staged columns)
-  static constexpr int ITEMS = NPAIR * IY * NG;  // (pair, row, group) staging items per plane
+  static constexpr int SLOT = NPAIR * SP;        // floats per plane slot
+  static constexpr int ITEMS = NPAIR * IY * NPP; // (channel pair, row, position pair) staging items per plane; item e -> floats [4 e, 4 e + 4)
   static constexpr int NK = (ITEMS + kThreads - 1) / kThreads;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)(SLOT + 4) * sizeof(float);
-  // lane (xi = tid & 31, yi = tid >> 5) reads floats [4 xi, 4 xi + 8) of row yi + ky: 32 lanes x 16 B = 512 B per row
-  // of lanes, two rows per wave RS floats apart - conflict-free for the 4 x 16-lane groups of ds_read_b128
-  // (checked for RS = 132 by enumeration, tests/kernel_model.py: prob_zwalk_bank_cycles)
+  static constexpr size_t LDS_BYTES = 2 * (size_t)SLOT * sizeof(float);
+  // Reads: lane (xi = tid & 31, yi = tid >> 5) reads floats [4 xi, 4 xi + 8) of row yi + ky: 32 lanes x 16 B = 512 B per row
+  // of lanes, two rows per wave RS floats apart - conflict-free for the 4 x 16-lane groups of ds_read_b128 (RS = 132,
+  // enumerated in tests/kernel_model.py: prob_zwalk_bank_cycles).
+  // Writes: item e (= thread + 256 k) owns the 16 bytes at float 4 e: one ds_write_b128 per item, consecutive lanes write
+  // consecutive 16-byte units - conflict-free.  (First version: a thread staged 4 x of a channel pair as four
+  // ds_write_b64 32 bytes apart from its neighbour's = 4-way bank conflicts; PMC: SQ_LDS_BANK_CONFLICT 47 % of
+  // SQ_LDS_IDX_ACTIVE, LDS-active time = the kernel's run time, VALU busy 29 % - profiles/r03_pmc_prob_zwalk.txt.)
   static_assert(RS % 4 == 0, "rows start 16-byte aligned");
 };
 
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
     float *__restrict__ depth, float *__restrict__ conf, int32_t *__restrict__ index, int Di, int Hi, int Wi,
     int tiles_x, int tiles_y, int zc, float slope) {
   using Cfg = ProbZCfg;
-  constexpr int NK = Cfg::NK, RS = Cfg::RS, SP = Cfg::SP, SLOT = Cfg::SLOT, SLOTS = Cfg::SLOT + 4, NG = Cfg::NG, IY = Cfg::IY;
+  constexpr int NK = Cfg::NK, RS = Cfg::RS, SLOTS = Cfg::SLOT, NPP = Cfg::NPP, IY = Cfg::IY;
   extern __shared__ float smem[];
   const int ntile = tiles_x * tiles_y;
   const int nchunk = gridDim.x / ntile;
@@ -132,24 +136,25 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
   const float *tail = wpk + 8 * 32;  // scale[4] | shift[4] after the [pair][64] weight rows (cin = 8)
   const float sc0 = tail[0], sh0 = tail[4];
 
-  // staging plan (tile constants): item e = tid + 256 k -> (pair, staged row, 16-byte group of the row)
-  int voff0[NK], voff1[NK], loff[NK][4];
+  // staging plan (tile constants): item e = tid + 256 k -> (channel pair, staged row, position pair m): the two positions
+  // x = x0 - 1 + 2 m, x + 1 of BOTH channels of the pair = two 8-byte loads -> (c0[x], c1[x], c0[x+1], c1[x+1]).
+  // x is odd: a pair straddles the image's left edge (x = -1: m = 0 of the first tile column) or its right edge
+  // (x + 1 = Wi); there the pair one position further inside is loaded and shifted (edge tiles only: wave-uniform branch).
+  int voff0[NK], voff1[NK];
+  bool edge_l[NK], edge_r[NK];
+  const bool edge_tile = tx0 == 0 || tx0 + Cfg::TX >= Wi;
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int e = threadIdx.x + k * kThreads;
-    const int p = e / (IY * NG), r = e - p * (IY * NG);
-    const int iy = r / NG, g = r - iy * NG;
-    const int gy = ty0 - 1 + iy, gx = tx0 - 4 + 4 * g;
-    const bool ok = e < Cfg::ITEMS && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;  // Wi % 4 == 0: a group is inside or outside
-    voff0[k] = ok ? ((2 * p) * in_cs + gy * Wi + gx) * 4 : kOOB;
-    voff1[k] = ok ? ((2 * p + 1) * in_cs + gy * Wi + gx) * 4 : kOOB;
-    // column j of the group is position q = 4 g + j - 3 of the LDS row (position 0 = x0 - 1); positions 0 .. TX + 1 are
-    // kept, the others (3 columns of the first group, 3 of the last, items beyond the plane) go to a dump word pair
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = 4 * g + j - 3;
-      loff[k][j] = (e < Cfg::ITEMS && q >= 0 && q <= Cfg::TX + 1) ? p * SP + iy * RS + 2 * q : SLOT;
-    }
+    const int p = e / (IY * NPP), r = e - p * (IY * NPP);
+    const int iy = r / NPP, m = r - iy * NPP;
+    const int gy = ty0 - 1 + iy, x = tx0 - 1 + 2 * m;
+    edge_l[k] = x < 0;
+    edge_r[k] = x + 1 == Wi;
+    const int xl = edge_l[k] ? 0 : (edge_r[k] ? x - 1 : x);   // first element of the loaded pair: inside the row
+    const bool ok = e < Cfg::ITEMS && gy >= 0 && gy < Hi && x < Wi;
+    voff0[k] = ok ? ((2 * p) * in_cs + gy * Wi + xl) * 4 : kOOB;
+    voff1[k] = ok ? ((2 * p + 1) * in_cs + gy * Wi + xl) * 4 : kOOB;
   }
   // two register sets: the plane after next is in flight from memory while the next one waits in registers for its LDS
   // slot - every load has a whole plane step plus its own to land (with one set the load of plane z + 1 had to land within
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
 #endif
   constexpr int NSET = CASMVS_PROB_PREFETCH;
   static_assert(NSET == 1 || NSET == 2, "one or two staging register sets");
-  f32x4v v0[NSET][NK], v1[NSET][NK];
+  f32x2 v0[NSET][NK], v1[NSET][NK];
   // Loads, LDS stores and the cost store of a step are issued UNCONDITIONALLY (a plane that does not exist is read through
   // an empty buffer descriptor = zeros; a cost plane outside the chunk is stored to an out-of-range offset = dropped): with
   // a vector-memory operation inside a branch the compiler's wait-count pass must assume it did not execute and waits
@@ -171,16 +176,26 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
     const int soff = exists ? z * HiWi * 4 : 0;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-      v0[S][k] = buf_load4(r, voff0[k], soff);
-      v1[S][k] = buf_load4(r, voff1[k], soff);
+      v0[S][k] = buf_load2(r, voff0[k], soff);
+      v1[S][k] = buf_load2(r, voff1[k], soff);
     }
   };
   auto store_plane = [&](auto set_, float *slot) {
     constexpr int S = decltype(set_)::value;
+    if (edge_tile) {   // (x = -1, x = 0) was loaded as (0, 1): keep (zero, [0]); (Wi - 1, Wi) as (Wi - 2, Wi - 1): keep ([1], zero)
 #pragma unroll
-    for (int k = 0; k < NK; ++k)
+      for (int k = 0; k < NK; ++k) {
+        const f32x2 a = v0[S][k], c = v1[S][k];
+        v0[S][k] = edge_l[k] ? f32x2{0.f, a[0]} : (edge_r[k] ? f32x2{a[1], 0.f} : a);
+        v1[S][k] = edge_l[k] ? f32x2{0.f, c[0]} : (edge_r[k] ? f32x2{c[1], 0.f} : c);
+      }
+    }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2 *>(slot + loff[k][j]) = f32x2{v0[S][k][j], v1[S][k][j]};
+    for (int k = 0; k < NK; ++k) {
+      const int e = threadIdx.x + k * kThreads;
+      if (k < NK - 1 || e < Cfg::ITEMS)
+        *reinterpret_cast<f32x4v *>(slot + 4 * e) = f32x4v{v0[S][k][0], v1[S][k][0], v0[S][k][1], v1[S][k][1]};
+    }
   };
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, NSET - 1>;

@@ -302,49 +302,72 @@ def wgrad_vector_staging_units(S, KZ, KS, threads=256):
 
 # ---- csrc/prob_regress.hip: the `prob` head walking the depth axis ---------------------------------------------------
 PZ_TX, PZ_TY, PZ_THREADS = 64, 8, 256
-PZ_IY, PZ_NG, PZ_RS = PZ_TY + 2, PZ_TX // 4 + 2, 2 * (PZ_TX + 2)
+PZ_IY, PZ_NPP = PZ_TY + 2, PZ_TX // 2 + 1
+PZ_RS = 4 * PZ_NPP
 PZ_SP = PZ_IY * PZ_RS
 PZ_SLOT = 4 * PZ_SP
-PZ_ITEMS = 4 * PZ_IY * PZ_NG
+PZ_ITEMS = 4 * PZ_IY * PZ_NPP
 
 # lane groups of one ds_read_b128 wave-instruction (MI355X_MICROARCH.md, LDS table): 4 x 16 lanes, one LDS cycle each
 _B128_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
 _B128_GROUPS += [[l + 32 for l in g] for g in _B128_GROUPS]
 
 
-def prob_zwalk_bank_cycles(row_stride=PZ_RS, first_float=0):
-    """LDS-array cycles of one ds_read_b128 of the z-walk kernel's tap reads (lane = (xi = l & 31, yi = l >> 5) reads the
-    4 floats at yi * RS + 4 xi + first_float): 4 = conflict-free (64 banks of 4 bytes; same address broadcasts)."""
+def _b128_cycles(addr_of_lane, groups):
     total = 0
-    for g in _B128_GROUPS:
+    for g in groups:
         banks = {}
         for l in g:
-            a = (l >> 5) * row_stride + 4 * (l & 31) + first_float
+            a = addr_of_lane(l)
             for w in range(4):
                 banks.setdefault((a + w) % 64, set()).add(a + w)
         total += max(len(v) for v in banks.values())
     return total
 
 
-def prob_zwalk_staging_plan():
-    """-> list over staging items e < ITEMS of (pair, staged row, group, [LDS float offset of column j or None] * 4)."""
+def prob_zwalk_bank_cycles(row_stride=PZ_RS, first_float=0):
+    """LDS-array cycles of one ds_read_b128 of the z-walk kernel's tap reads (lane = (xi = l & 31, yi = l >> 5) reads the
+    4 floats at yi * RS + 4 xi + first_float): 4 = conflict-free (64 banks of 4 bytes; same address broadcasts)."""
+    return _b128_cycles(lambda l: (l >> 5) * row_stride + 4 * (l & 31) + first_float, _B128_GROUPS)
+
+
+def prob_zwalk_write_cycles():
+    """LDS-array cycles of one ds_write_b128 of the staging (8 x 8 contiguous lanes, 32 banks): lane l writes floats
+    [4 l, 4 l + 4) - 8 = conflict-free.  The first version's ds_write_b64 (lane l writes 2 floats at 8 l) took 4 x its
+    minimum."""
+    def cyc(addr, width, groups):
+        total = 0
+        for g in groups:
+            banks = {}
+            for l in g:
+                for w in range(width):
+                    banks.setdefault((addr(l) + w) % 32, set()).add(addr(l) + w)
+            total += max(len(v) for v in banks.values())
+        return total
+    g8 = [list(range(8 * i, 8 * i + 8)) for i in range(8)]
+    g16 = [list(range(16 * i, 16 * i + 16)) for i in range(4)]
+    return cyc(lambda l: 4 * l, 4, g8), cyc(lambda l: 8 * l, 2, g16)
+
+
+def prob_zwalk_staging_plan(tx0, W):
+    """-> list over staging items e < ITEMS of (pair, staged row, x of the pair's first position, x loaded, shift) with
+    shift = 0 (as loaded), +1 (left edge: keep (0, loaded[0])), -1 (right edge: keep (loaded[1], 0))."""
     plan = []
     for e in range(PZ_ITEMS):
-        p, r = divmod(e, PZ_IY * PZ_NG)
-        iy, g = divmod(r, PZ_NG)
-        offs = []
-        for j in range(4):
-            q = 4 * g + j - 3
-            offs.append(p * PZ_SP + iy * PZ_RS + 2 * q if 0 <= q <= PZ_TX + 1 else None)
-        plan.append((p, iy, g, offs))
+        p, r = divmod(e, PZ_IY * PZ_NPP)
+        iy, m = divmod(r, PZ_NPP)
+        x = tx0 - 1 + 2 * m
+        edge_l, edge_r = x < 0, x + 1 == W
+        plan.append((p, iy, x, 0 if edge_l else (x - 1 if edge_r else x), 1 if edge_l else (-1 if edge_r else 0)))
     return plan
 
 
 def emulate_prob_zwalk(packed, x, zc, slope=1.0):
     """The kernel's data flow in float64: per (tile, chunk) the input planes z_lo - 1 .. z_hi are staged one at a time into a
-    pair-interleaved halo tile, every thread (xi, yi) reads rows yi + ky at floats [4 xi, 4 xi + 8) and accumulates the
-    plane into the three rotating accumulators (output planes z_in + 1, z_in, z_in - 1 for kz = 0, 1, 2).
-    packed: the P1 image of casmvs_conv3d_pack_f32 (cin = 8, cout = 1).  x (B, 8, D, H, W), W % 4 == 0 -> (B, D, H, W)."""
+    pair-interleaved halo tile (item e = 16 bytes at float 4 e), every thread (xi, yi) reads rows yi + ky at floats
+    [4 xi, 4 xi + 8) and accumulates the plane into the three rotating accumulators (output planes z_in + 1, z_in, z_in - 1
+    for kz = 0, 1, 2).  packed: the P1 image of casmvs_conv3d_pack_f32 (cin = 8, cout = 1).
+    x (B, 8, D, H, W), W % 4 == 0 -> (B, D, H, W)."""
     import numpy as np
     B, cin, D, H, W = x.shape
     assert cin == 8 and W % 4 == 0
@@ -354,7 +377,6 @@ def emulate_prob_zwalk(packed, x, zc, slope=1.0):
     sc0, sh0 = pk[256], pk[260]
     out = np.full((B, D, H, W), np.nan)
     written = np.zeros((B, D, H, W), dtype=np.int32)
-    plan = prob_zwalk_staging_plan()
     tiles_x, tiles_y = -(-W // PZ_TX), -(-H // PZ_TY)
     nchunk = -(-D // zc)
     tid = np.arange(PZ_THREADS)
@@ -363,6 +385,7 @@ def emulate_prob_zwalk(packed, x, zc, slope=1.0):
         for ty in range(tiles_y):
             for tx in range(tiles_x):
                 tx0, ty0 = tx * PZ_TX, ty * PZ_TY
+                plan = prob_zwalk_staging_plan(tx0, W)
                 for ch in range(nchunk):
                     z_lo, z_hi = ch * zc, min(ch * zc + zc, D)
                     A = np.zeros((3, 2, 2, PZ_THREADS))   # [acc][pixel][channel parity][thread]
@@ -371,17 +394,17 @@ def emulate_prob_zwalk(packed, x, zc, slope=1.0):
                         zin = z_lo - 1 + it
                         if 0 <= zin < D:
                             slot = np.full(PZ_SLOT, np.nan)
-                            count = np.zeros(PZ_SLOT, dtype=np.int32)
-                            for (p, iy, g, offs) in plan:
-                                gy, gx = ty0 - 1 + iy, tx0 - 4 + 4 * g
-                                ok = 0 <= gy < H and 0 <= gx < W
-                                for j in range(4):
-                                    if offs[j] is None:
-                                        continue
-                                    for c in range(2):
-                                        slot[offs[j] + c] = xn[b, 2 * p + c, zin, gy, gx + j] if ok else 0.0
-                                        count[offs[j] + c] += 1
-                            assert (count == 1).all(), "every LDS cell of the slot is written exactly once"
+                            for e, (p, iy, xp, xl, shift) in enumerate(plan):
+                                gy = ty0 - 1 + iy
+                                if 0 <= gy < H and xp < W:
+                                    assert 0 <= xl and xl + 1 < W, "the loaded pair lies inside the row"
+                                    ld = xn[b, 2 * p:2 * p + 2, zin, gy, xl:xl + 2]       # [channel][2 positions]
+                                    pos = ld if shift == 0 else (np.stack([np.zeros(2), ld[:, 0]], 1) if shift == 1 else np.stack([ld[:, 1], np.zeros(2)], 1))
+                                else:
+                                    pos = np.zeros((2, 2))                                # out-of-range offset: the hardware returns 0
+                                assert np.isnan(slot[4 * e:4 * e + 4]).all()
+                                slot[4 * e:4 * e + 4] = [pos[0, 0], pos[1, 0], pos[0, 1], pos[1, 1]]
+                            assert not np.isnan(slot).any(), "every LDS cell of the slot is written exactly once"
                             kzs = [0] if it == 0 else [2] if it == nplanes - 1 else [0, 1, 2]
                             for p in range(4):
                                 for ky in range(3):

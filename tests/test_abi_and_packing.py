@@ -182,8 +182,11 @@ def test_prob_zwalk_model_staging_and_rotating_accumulators_are_the_prob_convolu
     assert float((got - ref).abs().max()) < 1e-10
 
 
-def test_prob_zwalk_tap_reads_are_bank_conflict_free():
-    """The two ds_read_b128 of a (channel pair, ky) step take 4 LDS cycles each (the minimum) with the kernel's row stride;
-    the 16-lanes-per-row alternative (32 x 16 tile) would take 8 whatever the stride."""
+def test_prob_zwalk_lds_accesses_are_bank_conflict_free():
+    """The two ds_read_b128 of a (channel pair, ky) step take 4 LDS cycles each (the minimum) with the kernel's row stride,
+    and the staging's ds_write_b128 (item e = 16 bytes at float 4 e) 8 (the minimum); the first version's four ds_write_b64
+    32 bytes apart took 4x theirs (PMC: bank conflicts = 47 % of the LDS-active cycles)."""
     assert KM.prob_zwalk_bank_cycles(KM.PZ_RS, 0) == 4 and KM.prob_zwalk_bank_cycles(KM.PZ_RS, 4) == 4
-    assert KM.PZ_RS % 4 == 0 and KM.PZ_RS >= 2 * (KM.PZ_TX + 2)
+    assert KM.PZ_RS % 4 == 0 and KM.PZ_RS == 2 * (KM.PZ_TX + 2)
+    new, old = KM.prob_zwalk_write_cycles()
+    assert new == 8 and old == 16      # b64: 4 groups x 1 cycle minimum -> 4 x 4 = 16
