@@ -2130,21 +2130,21 @@ extern "C" size_t casmvs_featurenet_workspace_bytes(int N, int H, int W) {
   return (size_t)N * (48 * hw + 80 * (hw / 4) + 96 * (hw / 16)) * sizeof(float);
 }
 
-extern "C" int casmvs_featurenet_forward_f32(const float *const *packed_layers, const float *imgs,
-                                             float *feat0, float *feat1, float *feat2, float *feat0_nhwc,
-                                             float *feat1_nhwc, float *feat2_nhwc, void *workspace, int N,
-                                             int H, int W, float slope, void *const *layer_events,
-                                             void *stream) {
-  casmvs::clear_error();
+namespace {
+int featurenet_run(const float *const *packed_layers, const float *fused0_packed, const float *fused0_bias9, const float *imgs,
+                   float *feat0, float *feat1, float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
+                   void *workspace, int N, int H, int W, float slope, void *const *layer_events, void *stream) {
   CASMVS_REQUIRE(packed_layers && imgs && feat0 && feat1 && feat2 && workspace, "featurenet_forward: null pointer");
   CASMVS_REQUIRE(N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0,
                  "featurenet_forward: N=%d H=%d W=%d (H, W must be multiples of 4)", N, H, W);
   for (int i = 0; i < 13; ++i) CASMVS_REQUIRE(packed_layers[i], "featurenet_forward: packed_layers[%d] is null", i);
+  CASMVS_REQUIRE((fused0_packed == nullptr) == (fused0_bias9 == nullptr), "featurenet_forward: fused0_packed and fused0_bias9 go together");
+  const bool fuse0 = fused0_packed && casmvs_fpn_tail0_supported(H, W) && N <= 65535;
   const size_t hw = (size_t)N * H * W;
   float *ws = (float *)workspace;
   float *a0 = ws;  ws += 8 * hw;          // conv0.0
   float *c0 = ws;  ws += 8 * hw;          // conv0
-  float *f0 = ws;  ws += 32 * hw;         // up(feat1') + lat0(conv0)
+  float *f0 = ws;  ws += 32 * hw;         // up(feat1') + lat0(conv0)   (unused by the fused tail)
   float *a1 = ws;  ws += 16 * (hw / 4);   // conv1.0
   float *b1 = ws;  ws += 16 * (hw / 4);   // conv1.1
   float *c1 = ws;  ws += 16 * (hw / 4);   // conv1
@@ -2155,9 +2155,11 @@ extern "C" int casmvs_featurenet_forward_f32(const float *const *packed_layers, 
   const float *const *P = packed_layers;
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
   int rc, li = 0;
-#define CASMVS_L(...)                                                                          \
+#define CASMVS_EV()                                                                            \
   if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);   \
-  ++li;                                                                                        \
+  ++li
+#define CASMVS_L(...)                                                                          \
+  CASMVS_EV();                                                                                 \
   rc = conv2d_forward(__VA_ARGS__);                                                            \
   if (rc != CASMVS_OK) return rc
   CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, nullptr, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
@@ -2170,12 +2172,45 @@ extern "C" int casmvs_featurenet_forward_f32(const float *const *packed_layers, 
   CASMVS_L(CASMVS_CONV2D_K3, P[7], b2, nullptr, c2, nullptr, N, 32, 32, H4, W4, slope, stream);        // conv2.2  :25
   CASMVS_L(CASMVS_CONV2D_K1, P[8], c2, nullptr, feat2, feat2_nhwc, N, 32, 32, H4, W4, 1.0f, stream);      // toplayer :48
   CASMVS_L(CASMVS_CONV2D_K1_UP, P[9], c1, feat2, f1, nullptr, N, 16, 32, H2, W2, 1.0f, stream);        // lat1 + up :49
-  CASMVS_L(CASMVS_CONV2D_K1_UP, P[10], c0, f1, f0, nullptr, N, 8, 32, H, W, 1.0f, stream);             // lat0 + up :50
+  if (fuse0) {   // lat0 + up + smooth0 in one kernel (fpn_fused.hip); the `lat0` interval of layer_events times it, `smooth0` is empty
+    CASMVS_EV();
+    rc = casmvs_fpn_tail0_f32(fused0_packed, fused0_bias9, c0, f1, feat0, feat0_nhwc, N, H, W, stream);   // :50-51,54
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K1_UP, P[10], c0, f1, f0, nullptr, N, 8, 32, H, W, 1.0f, stream);           // lat0 + up :50
+  }
   CASMVS_L(CASMVS_CONV2D_K3, P[11], f1, nullptr, feat1, feat1_nhwc, N, 32, 16, H2, W2, 1.0f, stream);     // smooth1  :53
-  CASMVS_L(CASMVS_CONV2D_K3, P[12], f0, nullptr, feat0, feat0_nhwc, N, 32, 8, H, W, 1.0f, stream);        // smooth0  :54
+  if (fuse0) {
+    CASMVS_EV();
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K3, P[12], f0, nullptr, feat0, feat0_nhwc, N, 32, 8, H, W, 1.0f, stream);      // smooth0  :54
+  }
 #undef CASMVS_L
+#undef CASMVS_EV
   if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[13], (hipStream_t)stream);
   return CASMVS_OK;
+}
+}  // namespace
+
+extern "C" int casmvs_featurenet_forward_f32(const float *const *packed_layers, const float *imgs,
+                                             float *feat0, float *feat1, float *feat2, float *feat0_nhwc,
+                                             float *feat1_nhwc, float *feat2_nhwc, void *workspace, int N,
+                                             int H, int W, float slope, void *const *layer_events,
+                                             void *stream) {
+  casmvs::clear_error();
+  return featurenet_run(packed_layers, nullptr, nullptr, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace, N, H, W,
+                        slope, layer_events, stream);
+}
+
+extern "C" int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const float *fused0_packed,
+                                                   const float *fused0_bias9, const float *imgs, float *feat0, float *feat1,
+                                                   float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
+                                                   void *workspace, int N, int H, int W, float slope,
+                                                   void *const *layer_events, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(fused0_packed && fused0_bias9, "featurenet_forward_fused: null pointer");
+  return featurenet_run(packed_layers, fused0_packed, fused0_bias9, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace,
+                        N, H, W, slope, layer_events, stream);
 }
 
 extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {

@@ -28,6 +28,10 @@
 #include "common.h"
 #include "softmax_regress.h"
 
+#ifndef CASMVS_PZ_ABL
+#define CASMVS_PZ_ABL 0   // profiling builds only (WRONG results): 1 no FMAs, 2 no LDS tap reads, 4 no global loads, 8 no LDS staging
+#endif                    // writes, 16 no barriers, 32 no scalar weight loads (constants)
+
 namespace {
 
 using namespace casmvs::buf;
@@ -71,19 +75,31 @@ __device__ __forceinline__ void zwalk_plane(const float *rows, const float *__re
   auto fetch = [&](auto buf_, int i) {
     constexpr int BUF = decltype(buf_)::value;
     const float *row = rows + (i / 3) * Cfg::SP + (i % 3) * Cfg::RS;
-    lo[BUF] = *reinterpret_cast<const f32x4v *>(row);
-    hi[BUF] = *reinterpret_cast<const f32x4v *>(row + 4);
+    if (CASMVS_PZ_ABL & 2) {
+      lo[BUF] = f32x4v{1.f, 2.f, 3.f, (float)i};
+      hi[BUF] = lo[BUF];
+    } else {
+      lo[BUF] = *reinterpret_cast<const f32x4v *>(row);
+      hi[BUF] = *reinterpret_cast<const f32x4v *>(row + 4);
+    }
     const float *wq = wpk + (i / 3) * 64 + (i % 3) * 6;  // taps (kz, ky, kx = 0..2) x (even, odd channel) at [kz * 18 + 2 kx + c]
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz) {
       if (!((KZM >> kz) & 1)) continue;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) W[BUF][kz][kx] = f32x2{wq[kz * 18 + 2 * kx], wq[kz * 18 + 2 * kx + 1]};
+      for (int kx = 0; kx < 3; ++kx)
+        W[BUF][kz][kx] = (CASMVS_PZ_ABL & 32) ? f32x2{0.5f + kz, 0.25f * kx} : f32x2{wq[kz * 18 + 2 * kx], wq[kz * 18 + 2 * kx + 1]};
     }
   };
   auto fmas = [&](auto buf_) {
     constexpr int BUF = decltype(buf_)::value;
     const f32x2 P[4] = {f32x2{lo[BUF][0], lo[BUF][1]}, f32x2{lo[BUF][2], lo[BUF][3]}, f32x2{hi[BUF][0], hi[BUF][1]}, f32x2{hi[BUF][2], hi[BUF][3]}};
+    if (CASMVS_PZ_ABL & 1) {   // keep the operands live without the 18 FMAs
+      A[1][0] = A[1][0] + P[0] + P[3];
+      if (KZM & 1) A[2][0] = A[2][0] + W[BUF][0][0];
+      if (KZM & 4) A[0][0] = A[0][0] + W[BUF][2][2];
+      return;
+    }
     // tap by tap over the (up to) six independent accumulators (kz, pixel): no two consecutive FMAs depend on each other
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
@@ -176,6 +192,11 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
     const int soff = exists ? z * HiWi * 4 : 0;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
+      if (CASMVS_PZ_ABL & 4) {
+        v0[S][k] = f32x2{(float)z, 1.f};
+        v1[S][k] = v0[S][k];
+        continue;
+      }
       v0[S][k] = buf_load2(r, voff0[k], soff);
       v1[S][k] = buf_load2(r, voff1[k], soff);
     }
@@ -193,7 +214,7 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       const int e = threadIdx.x + k * kThreads;
-      if (k < NK - 1 || e < Cfg::ITEMS)
+      if ((k < NK - 1 || e < Cfg::ITEMS) && !((CASMVS_PZ_ABL & 8) && v0[S][k][0] != 12345.f))
         *reinterpret_cast<f32x4v *>(slot + 4 * e) = f32x4v{v0[S][k][0], v1[S][k][0], v0[S][k][1], v1[S][k][1]};
     }
   };
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
     A[1][1] = A[2][1];
     A[2][0] = A[2][1] = f32x2{0.f, 0.f};
     store_plane(Other{}, smem + ((it + 1) & 1) * SLOTS);   // (zeros when plane zin + 1 does not exist: never multiplied)
-    __syncthreads();  // the other slot is published, this one is free
+    if (!(CASMVS_PZ_ABL & 16)) __syncthreads();  // the other slot is published, this one is free
   };
   // prologue: plane z0 -> set 0 -> slot 0; plane z0 + 1 -> set 1 (in flight)
   load_plane(Set0{}, z0, z0 >= 0);

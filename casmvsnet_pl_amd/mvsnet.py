@@ -38,6 +38,25 @@ def _fold_norm(owner, norm):
     return scale, shift, slope
 
 
+def compose_fpn_tail(lat_weight, lat_bias, smooth_weight, smooth_bias):
+    """The FPN tail smooth(lat(x) + up(y)) (mvsnet.py:36-38,50-51,54) as ONE 3x3 convolution over [x | up(y)]: nothing
+    non-linear sits between the 1x1 lateral conv, the sum and the 3x3 smoothing conv.  Returns
+      weight (cout, cin + cmid, 3, 3) = [ smooth_weight o lat_weight | smooth_weight ]   (composed in float64),
+      bias9  (3, 3, cout): smooth_bias + the sum over the smoothing taps INSIDE the image of smooth_weight[.., ky, kx] . lat_bias
+             for the row classes (first / inner / last row) x column classes - zero padding applies to the SUM, so the
+             lateral bias only arrives through taps that exist.
+    lat_weight (cmid, cin, 1, 1), lat_bias (cmid), smooth_weight (cout, cmid, 3, 3), smooth_bias (cout)."""
+    Ws, Wl = smooth_weight.detach().double().cpu(), lat_weight.detach().double().cpu()[:, :, 0, 0]
+    bl, bs = lat_bias.detach().double().cpu(), smooth_bias.detach().double().cpu()
+    composed = torch.einsum("omyx,mi->oiyx", Ws, Wl)
+    weight = torch.cat([composed, Ws], dim=1).float()
+    tap_bias = torch.einsum("omyx,m->oyx", Ws, bl)                       # (cout, ky, kx)
+    valid = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}                         # taps inside the image for the first / inner / last row (column)
+    bias9 = torch.stack([torch.stack([bs + sum(tap_bias[:, ky, kx] for ky in valid[r] for kx in valid[c]) for c in range(3)])
+                         for r in range(3)]).float()
+    return weight.contiguous(), bias9.contiguous()
+
+
 class _PackedWeights:
     """Mixin of the modules that keep folded + packed device images of their parameters.
 
@@ -102,6 +121,8 @@ class FeatureNet(_PackedWeights, nn.Module):
         self._init_packed()
         self._workspace = None
         self._slope = 0.01
+        self._fused0 = None       # (packed 40-channel 3x3 layer, bias classes) of the fused full-resolution tail
+        self.fuse_tail = True     # lat0 + upsample-add + smooth0 as one kernel (False: the reference's three steps, A/B and tests)
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.last_channels_last = None
 
@@ -122,6 +143,9 @@ class FeatureNet(_PackedWeights, nn.Module):
         if len(slopes) > 1:
             raise RuntimeError("FeatureNet: all ABN layers must share one activation slope")
         self._slope = slopes.pop() if slopes else 0.01
+        # the full-resolution tail lat0 + upsample-add + smooth0 as one 40-channel 3x3 layer (csrc/fpn_fused.hip)
+        w40, bias9 = compose_fpn_tail(self.lat0.weight, self.lat0.bias, self.smooth0.weight, self.smooth0.bias)
+        self._fused0 = (ops.conv2d_pack(ops.CONV2D_K3, w40, None, None).to(device), bias9.to(device))
         self._packed, self._packed_key = packed, key
         return packed
 
@@ -140,7 +164,7 @@ class FeatureNet(_PackedWeights, nn.Module):
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         events = self.timer.layer_events("feature", 14, self.LAYER_NAMES) if self.timer is not None else None
         feat0, feat1, feat2, cl = ops.featurenet_forward(packed, x.float(), ws, slope=self._slope, layer_events=events,
-                                                         channels_last_copies=True)
+                                                         channels_last_copies=True, fused0=self._fused0 if self.fuse_tail else None)
         # pixel-major copies of the three maps (same kernels, second store): what the cost-volume gather reads
         self.last_channels_last = {"level_0": cl[0], "level_1": cl[1], "level_2": cl[2]}
         return {"level_0": feat0, "level_1": feat1, "level_2": feat2}

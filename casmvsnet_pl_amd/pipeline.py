@@ -360,6 +360,42 @@ def collate(samples):
     return out
 
 
+class ParallelLoader:
+    """train.py:85-97 / eval.py:213 (`DataLoader(dataset, num_workers=4, pin_memory=True)`): an iterable of collated
+    batches of `reader` whose samples are read by `num_workers` THREADS - a sample's cost is PNG / JPEG decoding and the
+    resize in PIL and the PFM parsing in numpy, all of which release the GIL - with `prefetch_batches` batches in flight
+    ahead of the consumer and delivery in index order (same batches as a sequential loop).  Feed it to DevicePrefetcher:
+    decode (threads) -> pinned staging + H2D copy (side stream) -> engine, three stages overlapped.
+
+    indices: the sample order (default: all samples in order; pass a permutation for training); a last partial batch is
+    kept (drop_last=False like the reference's validation / test loaders)."""
+
+    def __init__(self, reader, batch_size=1, num_workers=4, indices=None, prefetch_batches=4, drop_last=False):
+        self.reader, self.batch_size, self.num_workers = reader, int(batch_size), max(1, int(num_workers))
+        self.indices = list(range(len(reader))) if indices is None else list(indices)
+        self.prefetch = max(1, int(prefetch_batches))
+        if drop_last:
+            self.indices = self.indices[:len(self.indices) // self.batch_size * self.batch_size]
+
+    def __len__(self):
+        return (len(self.indices) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        batches = [self.indices[i:i + self.batch_size] for i in range(0, len(self.indices), self.batch_size)]
+        pool = ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="casmvs-loader")
+        try:
+            pending = []   # per batch: the futures of its samples, submitted in order
+            nxt = 0
+            while nxt < len(batches) or pending:
+                while nxt < len(batches) and len(pending) < self.prefetch:
+                    pending.append([pool.submit(self.reader.__getitem__, i) for i in batches[nxt]])
+                    nxt += 1
+                yield collate([f.result() for f in pending.pop(0)])
+        finally:
+            pool.shutdown(wait=False, cancel_futures=True)
+
+
 class DevicePrefetcher:
     """Iterates batches (dicts from `collate`) and hands them over device-resident, with the host->device copies of the
     NEXT batch in flight on a side stream while the caller computes on the current one (`depth` batches ahead).

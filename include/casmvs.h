@@ -230,6 +230,29 @@ int casmvs_featurenet_forward_f32(const float *const *packed_layers, const float
                                   float *feat2_nhwc, void *workspace, int N, int H, int W, float slope,
                                   void *const *layer_events, void *stream);
 
+/* FeatureNet's full-resolution FPN tail as one kernel: feat0 = smooth0(lat0(conv0) + upsample2x(feat1_sum))
+ * (mvsnet.py:36-38,50-51,54) without materialising the 32-channel sum.  The three operators are linear:
+ *   packed40 : device image of casmvs_conv2d_pack_f32(CASMVS_CONV2D_K3, cin = 40, cout = 8) of the weight
+ *              [ (smooth0.weight o lat0.weight) (8, 8, 3, 3) | smooth0.weight (8, 32, 3, 3) ] along the input channels
+ *              (scale = 1, shift = 0), 16-byte aligned;
+ *   bias9    : device (3, 3, 8): smooth0.bias + the sum over smooth0's taps that lie INSIDE the image of
+ *              smooth0.weight[:, :, ky, kx] . lat0.bias, for the row classes (first / inner / last row) x column classes;
+ *   conv0 (N, 8, H, W); feat1_sum (N, 32, H/2, W/2) = lat1(conv1) + up(feat2); feat0 (N, 8, H, W); feat0_nhwc NULL or
+ *   (N, H, W, 8).  H even, W % 4 == 0, W >= 8 (casmvs_fpn_tail0_supported).
+ */
+int casmvs_fpn_tail0_supported(int H, int W);
+int casmvs_fpn_tail0_f32(const float *packed40, const float *bias9, const float *conv0, const float *feat1_sum,
+                         float *feat0, float *feat0_nhwc, int N, int H, int W, void *stream);
+
+/* casmvs_featurenet_forward_f32 with the full-resolution tail (lat0, upsample-add, smooth0) run by casmvs_fpn_tail0_f32
+ * (packed_layers[10] / [12] are then unused but must still be non-NULL).  layer_events: the `lat0` interval times the fused
+ * kernel, the `smooth0` interval is empty. */
+int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const float *fused0_packed,
+                                        const float *fused0_bias9, const float *imgs, float *feat0, float *feat1,
+                                        float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
+                                        void *workspace, int N, int H, int W, float slope,
+                                        void *const *layer_events, void *stream);
+
 /* ---- (a9) softmax over depth + soft-argmin regression + confidence --------------------------
  * Replaces: models/mvsnet.py:174-193 and models/modules.py:95-104:
  *   p = softmax_D(cost); depth = sum_k p_k d_k; idx = clamp(trunc(sum_k p_k k), 0, D-1);

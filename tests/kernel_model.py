@@ -429,3 +429,76 @@ def emulate_prob_zwalk(packed, x, zc, slope=1.0):
                         A[2] = 0.0
     assert (written == 1).all(), "every output voxel is produced exactly once"
     return torch.from_numpy(out)
+
+
+# ---- csrc/fpn_fused.hip: lat0 + upsample-add + smooth0 as one 40-channel PX-form 3x3 layer -----------------------------
+def emulate_fpn_tail0(packed40, bias9, c0, f1):
+    """The kernel's data flow (float32 staging like the kernel, float64 accumulation): per 8 x 64 output tile and chunk of 4
+    input channels the halo tile [4][10][72] is staged - channels 0..7 straight from c0, channels 8..39 interpolated from the
+    half-resolution f1 through the 4-column window / 4 x 4 tent matrix and ATen's vertical weights - and multiplied in the PX
+    form (row i = (co = i >> 1, x phase i & 1), k = input x offset) with the lane images of the C packer.
+    c0 (8, H, W), f1 (32, H/2, W/2) numpy float32 -> (8, H, W)."""
+    import numpy as np
+    f32 = np.float32
+    _, H, W = c0.shape
+    hc, wc = H // 2, W // 2
+    img = np.asarray(packed40[:40 * 192], dtype=np.float64).reshape(40, 3, 4, 16)     # [ci][ky][k][i]
+    sy = f32(hc - 1) / f32(H - 1) if H > 1 else f32(0)
+    sx = f32(wc - 1) / f32(W - 1) if W > 1 else f32(0)
+    out = np.full((8, H, W), np.nan)
+    for ty0 in range(0, H, 8):
+        for tx0 in range(0, W, 64):
+            acc = np.zeros((8, 8, 64))                                                  # [co][cy][x - tx0]
+            for s in range(10):
+                tile = np.zeros((4, 10, 72), dtype=np.float64)
+                for c in range(4):
+                    for iy in range(10):
+                        for g in range(18):
+                            gy, gx = ty0 - 1 + iy, tx0 - 4 + 4 * g
+                            if not (0 <= gy < H and 0 <= gx < W):
+                                continue                                                 # out-of-range offset: zeros
+                            if s < 2:
+                                tile[c, iy, 4 * g:4 * g + 4] = c0[4 * s + c, gy, gx:gx + 4]
+                                continue
+                            fy = f32(sy * f32(gy))
+                            y0 = int(fy)
+                            y1 = y0 + (1 if y0 < hc - 1 else 0)
+                            ly1 = f32(fy - f32(y0))
+                            ly0 = f32(1) - ly1
+                            T = np.zeros((4, 4), dtype=np.float32)
+                            xb = None
+                            for j in range(4):
+                                fx = f32(sx * f32(gx + j))
+                                x0 = int(fx)
+                                x1 = x0 + (1 if x0 < wc - 1 else 0)
+                                lx1 = f32(fx - f32(x0))
+                                if j == 0:
+                                    xb = x0 if x0 < wc - 4 else wc - 4
+                                assert 0 <= x0 - xb < 4 and 0 <= x1 - xb < 4, "a pixel's columns must lie inside the 4-column window"
+                                T[j, x0 - xb] += f32(1) - lx1
+                                T[j, x1 - xb] += lx1
+                            ch = 4 * (s - 2) + c
+                            top, bot = T @ f1[ch, y0, xb:xb + 4], T @ f1[ch, y1, xb:xb + 4]
+                            tile[c, iy, 4 * g:4 * g + 4] = ly0 * top + ly1 * bot
+                for c in range(4):
+                    for ky in range(3):
+                        A = img[4 * s + c, ky]                                           # [k][i]
+                        for cy in range(8):
+                            for cx in range(2):
+                                for k in range(4):
+                                    bvals = tile[c, cy + ky, cx * 32 + 3 + k + 2 * np.arange(16)]    # B[k][j]
+                                    for i in range(16):
+                                        acc[i >> 1, cy, cx * 32 + (i & 1) + 2 * np.arange(16)] += A[k, i] * bvals
+            for cy in range(8):
+                oy = ty0 + cy
+                if oy >= H:
+                    continue
+                r = 0 if oy == 0 else (2 if oy == H - 1 else 1)
+                for x in range(64):
+                    ox = tx0 + x
+                    if ox >= W:
+                        continue
+                    cc = 0 if ox == 0 else (2 if ox == W - 1 else 1)
+                    out[:, oy, ox] = acc[:, cy, x] + np.asarray(bias9[r, cc], dtype=np.float64)
+    assert not np.isnan(out).any()
+    return out

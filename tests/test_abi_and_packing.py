@@ -190,3 +190,22 @@ def test_prob_zwalk_lds_accesses_are_bank_conflict_free():
     assert KM.PZ_RS % 4 == 0 and KM.PZ_RS == 2 * (KM.PZ_TX + 2)
     new, old = KM.prob_zwalk_write_cycles()
     assert new == 8 and old == 16      # b64: 4 groups x 1 cycle minimum -> 4 x 4 = 16
+
+
+@pytest.mark.parametrize("H,W", [(8, 64), (12, 72), (20, 132)])
+def test_fpn_fused_tail_model_equals_lat_upsample_smooth(H, W):
+    """csrc/fpn_fused.hip: the composed 40-channel layer (mvsnet.compose_fpn_tail -> casmvs_conv2d_pack_f32), the upsampled
+    channels staged through the 4-column window / tent matrix, the PX lane images and the nine border bias classes reproduce
+    smooth0(lat0(x) + interpolate(y)) of mvsnet.py:50-51,54 (ragged tiles in x and y)."""
+    import numpy as np
+    from casmvsnet_pl_amd.mvsnet import compose_fpn_tail
+    g = torch.Generator().manual_seed(H + W)
+    lw, lb = torch.randn(32, 8, 1, 1, generator=g) * 0.3, torch.randn(32, generator=g)
+    sw, sb = torch.randn(8, 32, 3, 3, generator=g) * 0.2, torch.randn(8, generator=g)
+    x, y = torch.randn(1, 8, H, W, generator=g), torch.randn(1, 32, H // 2, W // 2, generator=g)
+    ref = F.conv2d(F.conv2d(x.double(), lw.double(), lb.double()) + F.interpolate(y.double(), scale_factor=2, mode="bilinear", align_corners=True),
+                   sw.double(), sb.double(), padding=1)[0]
+    w40, bias9 = compose_fpn_tail(lw, lb, sw, sb)
+    packed = ops.conv2d_pack(ops.CONV2D_K3, w40, None, None)
+    got = KM.emulate_fpn_tail0(packed.numpy(), bias9.numpy(), x[0].numpy(), y[0].numpy())
+    assert float(np.abs(got - ref.numpy()).max()) < 2e-5 * float(ref.abs().max())

@@ -389,6 +389,27 @@ def test_featurenet_matches_oracle(dev, report, N, H, W):
     assert max(errs.values()) < 1.4e-5  # measured 1.4e-6
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 8, 64), (2, 36, 72), (1, 64, 196), (3, 128, 160)])
+def test_fpn_fused_tail_matches_lat_upsample_smooth(dev, report, N, H, W):
+    """csrc/fpn_fused.hip (mvsnet.py:36-38,50-51,54): feat0 = smooth0(lat0(conv0) + interpolate(feat1')) as one kernel over
+    the composed 40-channel layer, vs torch CPU float64 - ragged tiles, image borders (the nine bias classes), both outputs."""
+    from casmvsnet_pl_amd.mvsnet import compose_fpn_tail
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    lw, lb = torch.randn(32, 8, 1, 1, generator=g) * 0.3, torch.randn(32, generator=g)
+    sw, sb = torch.randn(8, 32, 3, 3, generator=g) * 0.2, torch.randn(8, generator=g)
+    x, y = torch.randn(N, 8, H, W, generator=g), torch.randn(N, 32, H // 2, W // 2, generator=g)
+    want = F.conv2d(F.conv2d(x.double(), lw.double(), lb.double()) + F.interpolate(y.double(), scale_factor=2, mode="bilinear", align_corners=True),
+                    sw.double(), sb.double(), padding=1)
+    w40, bias9 = compose_fpn_tail(lw, lb, sw, sb)
+    packed = ops.conv2d_pack(ops.CONV2D_K3, w40, None, None).to(dev)
+    got, got_cl = ops.fpn_tail0(packed, bias9.to(dev), x.to(dev), y.to(dev), channels_last_copy=True)
+    err = scaled_err(got, want)
+    report("fpn_tail0", shape=[N, H, W], scaled_err=err)
+    assert err < 1.2e-5
+    assert torch.equal(got_cl, got.permute(0, 2, 3, 1).contiguous())
+
+
 def test_convbnrelu3d_module_runs_one_hip_layer(dev):
     """modules.py:21-31 called on its own (it was a raise stub)."""
     from casmvsnet_pl_amd import ABN

@@ -86,6 +86,29 @@ def test_prefetcher_feeds_the_engine_in_order():
     assert n == 5
 
 
+def test_parallel_loader_delivers_the_sequential_batches_in_order():
+    """pipeline.ParallelLoader (train.py:85-97 `DataLoader(num_workers=..)`): samples read by worker threads finishing
+    out of order, batches delivered in index order, last partial batch kept / dropped, a permutation honoured."""
+    import random
+    import time
+
+    class Reader:
+        def __len__(self):
+            return 23
+
+        def __getitem__(self, i):
+            time.sleep(random.random() * 0.004)
+            return {"imgs_u8": torch.full((3, 2, 2, 3), i, dtype=torch.uint8), "proj_mats": torch.zeros(2, 3, 3, 4),
+                    "init_depth_min": torch.tensor([float(i)]), "depth_interval": torch.tensor([2.5]), "scan_vid": ("s", i)}
+    got = list(P.ParallelLoader(Reader(), batch_size=4, num_workers=8))
+    assert len(got) == 6 and [b["imgs_u8"].shape[0] for b in got] == [4, 4, 4, 4, 4, 3]
+    assert [v for b in got for _, v in b["scan_vid"]] == list(range(23))
+    assert got[2]["init_depth_min"].shape == (4, 1) and got[2]["init_depth_min"][:, 0].tolist() == [8.0, 9.0, 10.0, 11.0]
+    perm = [5, 1, 22, 7, 0]
+    got = list(P.ParallelLoader(Reader(), batch_size=2, num_workers=3, indices=perm, drop_last=True))
+    assert [v for b in got for _, v in b["scan_vid"]] == perm[:4] and len(P.ParallelLoader(Reader(), 2, 3, perm, drop_last=True)) == 2
+
+
 def _write_dtu_tree(root, test_layout, g, lights=None):
     """A two-camera-pair DTU-format tree with random images / depths (file names and text formats of the real dataset)."""
     from PIL import Image
