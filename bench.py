@@ -488,6 +488,7 @@ def main():
                          "costs ~3 us of GPU time; on every step they would inflate the step by ~10 %% and starve the launch queue)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-1 measurement")
     ap.add_argument("--no-fuse-regress", action="store_true", help="A/B: `prob` and the softmax regression as separate library calls")
+    ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: FeatureNet's full-resolution FPN tail as one kernel (1) or as the reference's three steps (0); default: the model's")
     args = ap.parse_args()
     args.batch_given = args.batch is not None
     if args.batch is None:
@@ -531,6 +532,8 @@ def main():
         randomize_state_dict(model.state_dict(), seed=0)
         model = model.to(dev).eval()
         model.fuse_regress = not args.no_fuse_regress
+        if args.fuse_tail is not None:
+            model.feature.fuse_tail = bool(args.fuse_tail)
         # replica: every rank works on its own depth maps (different seeds -> different images / cameras);
         # view_sharded: all ranks share the depth maps and split their source views
         imgs, proj, dmin, dint = config_inputs(args.config, B, seed=0 if view_sharded else rank)

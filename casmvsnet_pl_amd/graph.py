@@ -43,6 +43,15 @@ class GraphedForward:
             self.outputs = model(self.imgs, self.proj_mats, self.init_depth_min, self.depth_interval)
         model.set_timer(timer)
 
+    def refresh_weights(self):
+        """After the model's parameters changed (an optimiser step, load_state_dict): re-pack the folded weight images IN
+        PLACE, so that the next replay - which reads them through the pointers captured in the graph - sees the new
+        weights.  No re-capture."""
+        dev = self.imgs.device
+        self.model.feature.packed_layers(dev)
+        for l in range(self.model.levels):
+            getattr(self.model, f"cost_reg_{l}").packed_layers(dev)
+
     def __call__(self, imgs=None, proj_mats=None, init_depth_min=None, depth_interval=None):
         if imgs is not None and imgs.data_ptr() != self.imgs.data_ptr():
             self.imgs.copy_(imgs, non_blocking=True)
@@ -61,6 +70,14 @@ class GraphedForward:
         return self.outputs
 
 
+def shared_parameter_replica(model):
+    """A copy of the module tree - own workspaces, own packed-weight images, own timers - whose Parameters and buffers ARE
+    the source model's tensor objects (deepcopy with those objects pre-seeded in the memo)."""
+    import copy
+    memo = {id(t): t for t in list(model.parameters()) + list(model.buffers())}
+    return copy.deepcopy(model, memo)
+
+
 class ConcurrentForwards:
     """N captured forwards on N HIP streams, for throughput over INDEPENDENT reference views (eval.py:213 iterates them
     with no cross-iteration state).
@@ -69,19 +86,20 @@ class ConcurrentForwards:
     level-2 layers, the softmax / hypothesis kernels) launch fewer workgroups than the chip holds, and every kernel has a
     drain tail.  A second, independent forward on another stream fills those holes: measured on the MI355X
     (tools/gpu_streams_probe.py) 2 streams x batch 2 = 684 depth maps/s against 627 for one stream (batch 4 on one
-    stream: 663; 3 streams: no further gain).  Each stream owns a replica of the module (its workspaces and packed
-    weights, ~10 MB) so that the forwards share nothing but the read-only inputs they are given.
+    stream: 663; 3 streams: no further gain).  Each stream owns a replica of the module TREE (its workspaces and packed
+    weight images, ~10 MB) whose Parameters and buffers are the source model's own tensor objects
+    (`shared_parameter_replica`): a weight update of the model is a weight update of every replica, and
+    `refresh_weights()` re-packs the images in place for the captured graphs.
 
     `run(batches)` takes one (imgs, proj_mats) pair per stream (None = reuse the captured inputs), replays the graphs
     concurrently and returns the list of STATIC output dicts after making the caller's stream wait for all of them."""
 
     def __init__(self, model, imgs, proj_mats, init_depth_min, depth_interval, n_streams=2, warmup=2):
-        import copy
         self.device = imgs.device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.forwards = []
         for st in self.streams:
-            replica = copy.deepcopy(model)
+            replica = shared_parameter_replica(model)
             st.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(st):
                 self.forwards.append(GraphedForward(replica, imgs, proj_mats, init_depth_min, depth_interval, warmup))
@@ -89,6 +107,11 @@ class ConcurrentForwards:
 
     def __len__(self):
         return len(self.forwards)
+
+    def refresh_weights(self):
+        """Re-pack every replica's weight images in place after the (shared) parameters changed."""
+        for gf in self.forwards:
+            gf.refresh_weights()
 
     def run(self, batches=None):
         cur = torch.cuda.current_stream(self.device)

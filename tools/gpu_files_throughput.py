@@ -49,9 +49,9 @@ randomize_state_dict(model.state_dict(), seed=0)
 model = model.to(dev).eval()
 
 
-def run_from_files(workers, epochs=3):
+def run_from_files(workers, epochs=3, processes=False):
     idx = list(range(len(reader))) * epochs
-    loader = P.ParallelLoader(reader, batch_size=B, num_workers=workers, indices=idx, prefetch_batches=max(4, workers // B), drop_last=True)
+    loader = P.ParallelLoader(reader, batch_size=B, num_workers=workers, indices=idx, prefetch_batches=max(4, workers // B), drop_last=True, processes=processes)
     n = 0
     t0 = None
     for i, b in enumerate(P.DevicePrefetcher(loader, dev, depth=3)):
@@ -65,9 +65,9 @@ def run_from_files(workers, epochs=3):
     return (n - B) / (time.perf_counter() - t0), out
 
 
-def run_decode_only(workers):
-    idx = list(range(len(reader))) * 2
-    loader = P.ParallelLoader(reader, batch_size=B, num_workers=workers, indices=idx, prefetch_batches=max(4, workers // B), drop_last=True)
+def run_decode_only(workers, processes=False):
+    idx = list(range(len(reader))) * (6 if processes else 2)
+    loader = P.ParallelLoader(reader, batch_size=B, num_workers=workers, indices=idx, prefetch_batches=max(4, workers // B), drop_last=True, processes=processes)
     t0 = time.perf_counter()
     n = sum(b["imgs_u8"].shape[0] for b in loader)
     return n / (time.perf_counter() - t0)
@@ -86,7 +86,11 @@ for _ in range(30):
 torch.cuda.synchronize()
 resident = 30 * B / (time.perf_counter() - t0)
 print(f"device-resident inputs, kernel by kernel, batch {B}: {resident:.1f} depth maps/s")
-for wk in WORKERS:
-    dec = run_decode_only(wk)
-    rate, _ = run_from_files(wk)
-    print(f"workers {wk:3d}: decode + collate alone {dec:7.1f} depth maps/s ({3 * dec:.0f} images/s); files -> depth maps {rate:7.1f} /s = {rate / resident:.2f} of resident", flush=True)
+for procs in (False, True):
+    for wk in WORKERS:
+        if procs and wk < 4:
+            continue
+        dec = run_decode_only(wk, procs)
+        rate, _ = run_from_files(wk, epochs=8 if procs else 3, processes=procs)
+        print(f"{'processes' if procs else 'threads  '} {wk:3d}: decode + collate alone {dec:7.1f} depth maps/s ({3 * dec:.0f} images/s); files -> depth maps {rate:7.1f} /s = "
+              f"{rate / resident:.2f} of resident", flush=True)
