@@ -181,6 +181,19 @@ int casmvs_conv3d_forward_f32(int kind, const float *packed, const float *in, co
                               float *out, int B, int cin, int cout, int D, int H, int W,
                               float slope, void *stream);
 
+/* CostRegNet.conv0 (Conv3d cin -> 8, k3 s1 p1, folded ABN, leaky-relu; mvsnet.py:63,91) on the bf16 matrix cores with
+ * float32-grade arithmetic: every float32 operand = the exact sum of three bf16 slices, a product = six (terms = 0 / 6) or
+ * all nine (terms = 9) exact bf16 x bf16 partial products accumulated in float32 (csrc/conv0_splitbf16.hip).
+ * cin in {8, 16, 32}, W % 4 == 0, 16-byte aligned tensors.  `packed`: HOST image from casmvs_conv0_splitbf16_pack
+ * (weight (8, cin, 3, 3, 3), scale / shift (8) or NULL), copied to the device by the caller.
+ * casmvs_selftest_mfma_bf16: lane-semantics probe of v_mfma_f32_16x16x32_bf16 (dump: NULL or 256 floats). */
+size_t casmvs_conv0_splitbf16_packed_bytes(int cin);
+int casmvs_conv0_splitbf16_pack(int cin, const float *weight, const float *scale, const float *shift, void *packed);
+int casmvs_conv0_splitbf16_supported(int cin, int W);
+int casmvs_conv0_splitbf16_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
+                                       float slope, int terms, void *stream);
+int casmvs_selftest_mfma_bf16(float *dump);
+
 /* Whole CostRegNet (mvsnet.py:91-104).  `packed_layers[11]` are the device images of
  * conv0..conv6, conv7, conv9, conv11, prob (in that order).  `workspace` holds the intermediate
  * activations; its size comes from casmvs_costreg_workspace_bytes.

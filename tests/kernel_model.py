@@ -502,3 +502,54 @@ def emulate_fpn_tail0(packed40, bias9, c0, f1):
                     out[:, oy, ox] = acc[:, cy, x] + np.asarray(bias9[r, cc], dtype=np.float64)
     assert not np.isnan(out).any()
     return out
+
+
+# ---- csrc/conv0_splitbf16.hip: conv0 on the bf16 matrix cores, float32 operands as three exact bf16 slices ---------------
+def bf16_split3(x):
+    """x float32 ndarray -> three float32 arrays (each exactly a bf16 value) with hi + mid + lo == x exactly (truncation:
+    the three 8-bit slices of the 24-bit significand, as the kernel's mask-and-subtract)."""
+    import numpy as np
+    x = np.asarray(x, dtype=np.float32)
+    hi = (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    r = (x - hi).astype(np.float32)
+    mid = (r.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    lo = (r - mid).astype(np.float32)
+    return hi, mid, lo
+
+
+SB_TERMS = [(0, 0), (0, 1), (1, 0), (0, 2), (2, 0), (1, 1), (1, 2), (2, 1), (2, 2)]   # (weight slice, activation slice), by magnitude class
+
+
+def emulate_conv0_splitbf16(packed, x, cin, terms=6, slope=0.01):
+    """Data flow of conv0_sb_kernel in float64: the packed lane images [chunk][kz*3+ky][slice][lane][8 bf16] are decoded, the
+    activations split like the kernel does, and every output = sum over (chunk, kz, ky, x offset u, ci) of the first `terms`
+    partial products A_slice[i][k] * B_slice[k][j] with rows i = (co, x phase), k = (u, ci), then scale / shift / leaky-relu.
+    x (B, cin, D, H, W) float32 numpy, W even -> (B, 8, D, H, W)."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    nch = cin // 8
+    body = nch * 9 * 3 * 64 * 8 * 2
+    img = (raw[:body].view(np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(nch, 9, 3, 64, 8).astype(np.float64)
+    tail = raw[body:body + 64].view(np.float32).astype(np.float64)
+    scale, shift = tail[:8], tail[8:16]
+    B, _, D, H, W = x.shape
+    xs = [np.pad(s.astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1), (1, 3))) for s in bf16_split3(x)]   # zero halo (x: -1 .. W + 2)
+    assert float(np.abs(xs[0] + xs[1] + xs[2] - np.pad(x.astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1), (1, 3)))).max()) == 0.0
+    acc = np.zeros((B, 8, D, H, W))
+    for ch in range(nch):
+        for r9 in range(9):
+            kz, ky = divmod(r9, 3)
+            for (sa, sb) in SB_TERMS[:terms]:
+                A = img[ch, r9, sa].reshape(4, 16, 8)                                   # [u][i][ci]
+                for u in range(4):
+                    for s in range(2):                                                   # row i = 2 co + s
+                        kx = u - s                                                       # A is zero where kx is not a tap
+                        wrow = A[u, s::2, :]                                             # (co, ci)
+                        if not wrow.any():
+                            continue
+                        assert 0 <= kx <= 2
+                        # outputs x = 2 j + s read input x + kx - 1 = 2 j + u - 1 -> padded index 2 j + u
+                        src = xs[sb][:, ch * 8:ch * 8 + 8, kz:kz + D, ky:ky + H, u:u + W:2][..., :(W - s + 1) // 2]
+                        acc[:, :, :, :, s::2] += np.einsum("oc,bcdhw->bodhw", wrow, src)
+    y = acc * scale[None, :, None, None, None] + shift[None, :, None, None, None]
+    return np.where(y > 0, y, y * slope)

@@ -251,6 +251,38 @@ def test_conv3d_layer_matches_torch_cpu(dev, report, kind, cin, cout, B, D, H, W
     assert err < 1.2e-5  # measured <= 1.1e-6
 
 
+def test_mfma_bf16_lane_semantics_selftest(report):
+    rc, dump, msg = _ops().selftest_mfma_bf16()
+    report("mfma_bf16_selftest", rc=rc, msg=msg, reg0=dump[0, :8].tolist())
+    assert rc == 0, msg
+
+
+SB_CASES = [(8, 1, 8, 16, 32), (16, 2, 4, 8, 64), (32, 1, 12, 24, 40), (8, 1, 5, 9, 36), (16, 1, 6, 20, 100), (32, 1, 3, 5, 8)]
+
+
+@pytest.mark.parametrize("cin,B,D,H,W", SB_CASES)
+def test_conv0_splitbf16_matches_torch_cpu(dev, report, cin, B, D, H, W):
+    """csrc/conv0_splitbf16.hip: conv0 (Conv3d cin -> 8 + folded ABN + leaky-relu, mvsnet.py:63) with every float32 operand
+    as three exact bf16 slices on the bf16 matrix cores: vs torch CPU float64 at the SAME bound as the float32-MFMA layer
+    kernels (1.2e-5 of the range; measured ~3e-7: at or below the float32 kernel's own error), six and nine partial
+    products, ragged tiles in x / y / z; and against the float32-MFMA kernel of the same layer."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(cin * 100 + D + W)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2
+    scale, shift = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    want = _conv_ref(ops.CONV_S1, x.double(), w.double(), scale.double(), shift.double(), None, 0.01)
+    packed = ops.conv0_splitbf16_pack(w, scale, shift).to(dev)
+    xd = x.to(dev)
+    got6 = ops.conv0_splitbf16_forward(packed, xd, slope=0.01, terms=6).cpu()
+    got9 = ops.conv0_splitbf16_forward(packed, xd, slope=0.01, terms=9).cpu()
+    f32 = ops.conv3d_forward(ops.CONV_S1, ops.conv3d_pack(ops.CONV_S1, w, scale, shift).to(dev), xd, 8, slope=0.01).cpu()
+    e6, e9, ef = scaled_err(got6, want), scaled_err(got9, want), scaled_err(f32, want)
+    report("conv0_splitbf16", shape=[cin, B, D, H, W], err_6_terms=e6, err_9_terms=e9, err_f32_mfma=ef, vs_f32_kernel=scaled_err(got6, f32))
+    assert e6 < 1.2e-5 and e9 < 1.2e-5
+    assert e6 < 4 * max(ef, 2e-7)     # float32-grade: no worse than a few times the float32 kernel's own distance to float64
+
+
 PROB_CASES = [(1, 8, 8, 64), (2, 8, 32, 40), (1, 32, 16, 72), (2, 48, 24, 132), (1, 12, 9, 36), (1, 4, 5, 8), (1, 16, 70, 196)]
 
 
