@@ -35,6 +35,10 @@
 #include "buffer_ops.h"
 #include "common.h"
 
+#ifndef CASMVS_SB_ABL
+#define CASMVS_SB_ABL 0   // profiling builds only (WRONG results): 1 no MFMAs, 2 no split / LDS staging writes, 4 no global loads, 8 no tap reads
+#endif
+
 namespace {
 
 using namespace casmvs::buf;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(SbCfg::THREADS, 2) void conv0_sb_kernel(const float
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) R[r][c] = buf_load4(src, voff[r], (chunk * 8 + c) * cs * 4);
+      for (int c = 0; c < 8; ++c) R[r][c] = (CASMVS_SB_ABL & 4) ? f32x4v{1.f, (float)c, 2.f, 3.f} : buf_load4(src, voff[r], (chunk * 8 + c) * cs * 4);
   };
   auto commit = [&]() {   // registers -> LDS: the three bf16 slices of every staged voxel, the chunk's lane images
 #pragma unroll
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(SbCfg::THREADS, 2) void conv0_sb_kernel(const float
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      if (vox[r] < 0) continue;   // (second round: 88 of the 512 threads)
+      if (vox[r] < 0 || ((CASMVS_SB_ABL & 2) && R[r][0][0] != 12345.f)) continue;   // (second round: 88 of the 512 threads)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x[8];
@@ -231,13 +235,17 @@ __global__ __launch_bounds__(SbCfg::THREADS, 2) void conv0_sb_kernel(const float
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int s = 0; s < 3; ++s) bv[t][s] = act[s * NV + vb[t] + (kz * IY + ky) * Cfg::ROW];
+          for (int s = 0; s < 3; ++s)
+            bv[t][s] = (CASMVS_SB_ABL & 8) ? u32x4{(unsigned)r9, 1u, 2u, (unsigned)t} : act[s * NV + vb[t] + (kz * IY + ky) * Cfg::ROW];
         // partial products by decreasing magnitude class; consecutive MFMAs use different accumulators
         constexpr int PA[9] = {0, 0, 1, 0, 2, 1, 1, 2, 2}, PB[9] = {0, 1, 0, 2, 0, 1, 2, 1, 2};
 #pragma unroll
         for (int p = 0; p < TERMS; ++p)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = mfma_bf16(a[PA[p]], bv[t][PB[p]], acc[t]);
+          for (int t = 0; t < NT; ++t) {
+            if (CASMVS_SB_ABL & 1) acc[t][0] += __builtin_bit_cast(float, a[PA[p]][0] ^ bv[t][PB[p]][1]);   // keeps the operands live
+            else acc[t] = mfma_bf16(a[PA[p]], bv[t][PB[p]], acc[t]);
+          }
       }
     }
     // ---- epilogue: y = lrelu(acc * scale + shift); lane holds rows 4 u + r = (co = 2 u + (r >> 1), x phase r & 1), column j ----

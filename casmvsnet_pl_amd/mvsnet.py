@@ -213,6 +213,11 @@ class CostRegNet(_PackedWeights, nn.Module):
             norm_act(8))
         self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
         self._init_packed()       # _packed: list of 11 device tensors
+        self._conv0_sb = None     # conv0's split-bf16 image (uint8 device tensor)
+        # "splitbf16": conv0 on the bf16 matrix cores, every float32 operand as three exact bf16 slices, six partial products
+        # per product, float32 accumulation (float32-grade: its distance to float64 is at or below the float32 MFMA kernel's);
+        # "f32": conv0 on the float32 MFMA kernel like every other layer.  Used by `regress` (the engine's eval path).
+        self.conv0_mode = "splitbf16"
         self._workspace = None
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.timer_name = "costreg"
@@ -243,6 +248,13 @@ class CostRegNet(_PackedWeights, nn.Module):
         if len(slopes) > 1:
             raise RuntimeError("CostRegNet: all ABN layers must share one activation slope")
         self._slope = slopes.pop() if slopes else 0.01
+        # conv0 once more as the split-bf16 image (csrc/conv0_splitbf16.hip): three exact bf16 slices of every weight
+        cin = self.conv0.conv.weight.shape[1]
+        if cin in (8, 16, 32):
+            scale0, shift0, _ = _fold_norm("CostRegNet.conv0", self.conv0.bn)
+            self._store_packed("_conv0_sb", ops.conv0_splitbf16_pack(self.conv0.conv.weight, scale0, shift0).to(device))
+        else:
+            self._conv0_sb = None
         self._packed_key = key
         return self._store_packed("_packed", packed)
 
@@ -271,7 +283,8 @@ class CostRegNet(_PackedWeights, nn.Module):
         if ws is None or ws.device != x.device or ws.numel() < need:
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         events = self.timer.layer_events(self.timer_name) if self.timer is not None else None
-        return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index)
+        sb = self._conv0_sb if self.conv0_mode == "splitbf16" else None
+        return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index, conv0_sb=sb)
 
 
 class CascadeMVSNet(nn.Module):
