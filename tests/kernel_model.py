@@ -553,3 +553,43 @@ def emulate_conv0_splitbf16(packed, x, cin, terms=6, slope=0.01):
                         acc[:, :, :, :, s::2] += np.einsum("oc,bcdhw->bodhw", wrow, src)
     y = acc * scale[None, :, None, None, None] + shift[None, :, None, None, None]
     return np.where(y > 0, y, y * slope)
+
+
+def conv0_sb_tile_runs(total, grid):
+    """The work distribution of conv0_sb_kernel: workgroup b -> [first, end) of linear tile indices (XCD b % 8 owns a contiguous
+    range, each of its workgroups a contiguous run of it)."""
+    nx = min(8, grid)
+    runs = []
+    for b in range(grid):
+        xcd, lidx = b % nx, b // nx
+        wgs = (grid - xcd + nx - 1) // nx
+        q8, r8 = divmod(total, nx)
+        xs, ntile = xcd * q8 + min(xcd, r8), q8 + (1 if xcd < r8 else 0)
+        run, extra = divmod(ntile, wgs)
+        first = xs + lidx * run + min(lidx, extra)
+        runs.append((first, first + run + (1 if lidx < extra else 0)))
+    return runs
+
+
+def conv0_sb_slot(x):
+    """16-byte slot of column x inside a staged row (SbCfg::slot)."""
+    return x ^ (((x >> 3) & 1) << 1)
+
+
+def conv0_sb_lds_cycles():
+    """(tap-read cycles of one ds_read_b128 [4 = minimum], staging-write cycles summed over the four ds_write_b128 of an item
+    [32 = minimum; 100 without the swizzle at this row stride]) for the kernel's layout: slot(x) within a row, 41 slots per row."""
+    read = _b128_cycles(lambda l: 4 * conv0_sb_slot(2 * (l & 15) + (l >> 4) + 3), _B128_GROUPS)
+
+    def write(slot_fn):
+        tot = 0
+        for j in range(4):
+            for g0 in range(0, 64, 8):
+                banks = {}
+                for i in range(g0, g0 + 8):
+                    row, gi = divmod(i, 10)
+                    s = row * 41 + slot_fn(4 * gi + j)
+                    banks.setdefault(s % 8, set()).add(s)
+                tot += max(len(v) for v in banks.values())
+        return tot
+    return read, write(conv0_sb_slot), write(lambda x: x)

@@ -233,3 +233,20 @@ def test_conv0_splitbf16_packing_and_partial_products(cin, terms):
     assert np.array_equal((hi.astype(np.float64) + mid + lo), x.numpy().astype(np.float64))
     for part in (hi, mid, lo):
         assert not (part.view(np.uint32) & 0xFFFF).any()          # each slice is exactly a bf16 number
+
+
+def test_conv0_splitbf16_tile_runs_and_lds_layout():
+    """conv0_sb_kernel's work distribution covers every tile exactly once for any (tiles, workgroups <= tiles) - also fewer
+    than 8 workgroups - and its swizzled LDS rows keep the tap reads conflict-free while the staging writes cost 1.75x their
+    minimum (3.1x without the swizzle)."""
+    import itertools
+    for total, grid in itertools.product([1, 5, 8, 9, 100, 255, 256, 257, 1920, 2560, 5120], [1, 3, 8, 9, 64, 255, 256]):
+        if grid > total:
+            continue
+        runs = KM.conv0_sb_tile_runs(total, grid)
+        assert sorted(t for a, b in runs for t in range(a, b)) == list(range(total)), (total, grid)
+        if grid % 8 == 0 or grid == total:   # what the host launches (resident workgroups: a multiple of 8, or one per tile): balanced runs
+            assert max(b - a for a, b in runs) - min(b - a for a, b in runs) <= 2, (total, grid)
+    assert len({KM.conv0_sb_slot(x) for x in range(40)}) == 40 and max(KM.conv0_sb_slot(x) for x in range(40)) < 41
+    read, write, write_linear = KM.conv0_sb_lds_cycles()
+    assert read == 4 and write == 56 and write_linear == 100      # (32 would be conflict-free; with 40-slot rows and no swizzle: 128)
