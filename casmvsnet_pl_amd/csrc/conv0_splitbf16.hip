@@ -106,8 +106,8 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 struct SbTile {
   int tx0, ty0, tz0, b;
 };
-// linear tile index -> tile: z fastest, then x, then y, then batch element
-__device__ __forceinline__ SbTile sb_decode(int item, int tiles_x, int tiles_y, int tiles_z) {
+__device__ __forceinline__ SbTile sb_decode(int v, int total, int tiles_x, int tiles_y, int tiles_z) {
+  int item = xcd_major(v, total);   // z fastest, then x, then y (the halos of neighbouring tiles share an XCD's L2)
   SbTile t;
   t.tz0 = (item % tiles_z) * SbCfg::TZ;
   item /= tiles_z;
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(SbCfg::THREADS, 2) void conv0_sb_kernel(const float
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int jcol = lane & 15, u = lane >> 4;
   const int total = tiles_x * tiles_y * tiles_z * B;
+  if ((int)blockIdx.x >= total) return;
   const int HW = H * W, cs = D * HW;
   const size_t in_ss = (size_t)CIN * cs, out_ss = (size_t)8 * cs;
   const float *tail = reinterpret_cast<const float *>(wpk + (size_t)NCH * Cfg::W_BYTES);
@@ -204,26 +205,14 @@ __global__ __launch_bounds__(SbCfg::THREADS, 2) void conv0_sb_kernel(const float
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Work distribution.  Workgroup b runs on XCD b % 8 (speed only): XCD x owns the contiguous tile range [xs, xe), and each of
-  // its workgroups a contiguous RUN of it - consecutive tiles along z, whose 2-of-6 shared input planes the same CU has just
-  // read (L2 / L1 hits), next to the runs of its XCD neighbours (shared x / y halos in the same L2).  (First version: tiles
-  // dealt round-robin, 32 apart per workgroup: the ablations showed the global loads as the largest exposed cost.)
-  const int nx = min(8, (int)gridDim.x);                             // (a launch of fewer than 8 workgroups: that many ranges)
-  const int xcd = blockIdx.x % nx, lidx = blockIdx.x / nx;
-  const int wgs = ((int)gridDim.x - xcd + nx - 1) / nx;              // workgroups of this launch on this XCD
-  const int q8 = total / nx, r8 = total - q8 * nx;
-  const int xs = xcd * q8 + min(xcd, r8), ntile = q8 + (xcd < r8 ? 1 : 0);
-  const int run = ntile / wgs, extra = ntile - run * wgs;
-  int item = xs + lidx * run + min(lidx, extra);
-  const int item_end = item + run + (lidx < extra ? 1 : 0);
-  if (item >= item_end) return;
-  SbTile cur = sb_decode(item, tiles_x, tiles_y, tiles_z);
+  int item = blockIdx.x;
+  SbTile cur = sb_decode(item, total, tiles_x, tiles_y, tiles_z);
   plan(cur);
   prefetch(cur, 0, true);
   for (;;) {
-    const int next_item = item + 1;
-    const bool have_next = next_item < item_end;
-    const SbTile nxt = have_next ? sb_decode(next_item, tiles_x, tiles_y, tiles_z) : cur;
+    const int next_item = item + gridDim.x;
+    const bool have_next = next_item < total;
+    const SbTile nxt = have_next ? sb_decode(next_item, total, tiles_x, tiles_y, tiles_z) : cur;
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       __syncthreads();   // every wave is done with the previous chunk's LDS

@@ -306,6 +306,45 @@ def selftest_mfma_bf16():
     return rc, dump.view(4, 64), _lib.load().casmvs_last_error().decode()
 
 
+def conv0_splitf16_pack(weight, scale=None, shift=None):
+    """Host-side packing of CostRegNet.conv0 for the split-f16 kernel (casmvs_conv0_splitf16_pack): weight (8, cin, 3,3,3),
+    cin in {8, 16, 32} -> uint8 CPU tensor (2^kw w as two float16 slices per weight, MFMA lane images + scale 2^-kw / shift)."""
+    weight = weight.detach().to("cpu", torch.float32).contiguous()
+    cout, cin = weight.shape[:2]
+    lib = _lib.load()
+    n = lib.casmvs_conv0_splitf16_packed_bytes(cin)
+    if cout != 8 or tuple(weight.shape[2:]) != (3, 3, 3) or n == 0:
+        raise ValueError(f"conv0_splitf16_pack: weight {tuple(weight.shape)} (need (8, 8|16|32, 3, 3, 3))")
+    packed = torch.empty(n, dtype=torch.uint8)
+    sc = None if scale is None else scale.detach().to("cpu", torch.float32).contiguous()
+    sh = None if shift is None else shift.detach().to("cpu", torch.float32).contiguous()
+    rc = lib.casmvs_conv0_splitf16_pack(cin, _ptr(weight), _ptr(sc), _ptr(sh), ctypes.c_void_p(packed.data_ptr()))
+    _lib.check(rc, "casmvs_conv0_splitf16_pack")
+    return packed
+
+
+def conv0_splitf16_forward(packed, x, slope=0.01, terms=0):
+    """conv0 on the f16 matrix cores with float32-grade arithmetic (casmvs_conv0_splitf16_forward_f32): x (B,cin,D,H,W) ->
+    (B,8,D,H,W).  terms: 0 / 3 = three partial products per product, 4 = all four."""
+    x = _dev(x, "x")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("conv0_splitf16_forward: `packed` must be the uint8 image on the MI355X")
+    B, cin, D, H, W = x.shape
+    out = torch.empty((B, 8, D, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_conv0_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W,
+                                                           float(slope), int(terms), _stream(x))
+    _lib.check(rc, "casmvs_conv0_splitf16_forward_f32")
+    return out
+
+
+def selftest_mfma_f16():
+    """Lane-semantics probe of v_mfma_f32_16x16x32_f16 -> (rc, dump (4 regs, 64 lanes), message)."""
+    dump = torch.zeros(4 * 64, dtype=torch.float32)
+    rc = _lib.load().casmvs_selftest_mfma_f16(_ptr(dump))
+    return rc, dump.view(4, 64), _lib.load().casmvs_last_error().decode()
+
+
 def costreg_workspace_bytes(B, D, h, w):
     n = _lib.load().casmvs_costreg_workspace_bytes(B, D, h, w)
     if n == 0:

@@ -194,6 +194,19 @@ int casmvs_conv0_splitbf16_forward_f32(const void *packed, const float *in, floa
                                        float slope, int terms, void *stream);
 int casmvs_selftest_mfma_bf16(float *dump);
 
+/* The same layer on the f16 matrix cores (csrc/conv0_splitf16.hip): every float32 operand = the sum of two float16 numbers
+ * (22 of its 24 significand bits) after an exact power-of-two scaling into float16's range - one per weight tensor (host),
+ * one per staged (tile, 8-channel chunk) of the input (device, from the tile's largest magnitude) - three (terms = 0 / 3)
+ * or four (terms = 4) exact f16 x f16 partial products accumulated in float32.  Half the matrix instructions and 2/3 of the
+ * LDS bytes of the bf16 variant: two workgroups share a CU.  Same argument rules as casmvs_conv0_splitbf16_*; weights must be
+ * finite.  casmvs_selftest_mfma_f16: lane-semantics probe of v_mfma_f32_16x16x32_f16 (dump: NULL or 256 floats). */
+size_t casmvs_conv0_splitf16_packed_bytes(int cin);
+int casmvs_conv0_splitf16_pack(int cin, const float *weight, const float *scale, const float *shift, void *packed);
+int casmvs_conv0_splitf16_supported(int cin, int W);
+int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
+                                      float slope, int terms, void *stream);
+int casmvs_selftest_mfma_f16(float *dump);
+
 /* Whole CostRegNet (mvsnet.py:91-104).  `packed_layers[11]` are the device images of
  * conv0..conv6, conv7, conv9, conv11, prob (in that order).  `workspace` holds the intermediate
  * activations; its size comes from casmvs_costreg_workspace_bytes.

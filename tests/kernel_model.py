@@ -555,20 +555,59 @@ def emulate_conv0_splitbf16(packed, x, cin, terms=6, slope=0.01):
     return np.where(y > 0, y, y * slope)
 
 
-def conv0_sb_tile_runs(total, grid):
-    """The work distribution of conv0_sb_kernel: workgroup b -> [first, end) of linear tile indices (XCD b % 8 owns a contiguous
-    range, each of its workgroups a contiguous run of it)."""
-    nx = min(8, grid)
-    runs = []
-    for b in range(grid):
-        xcd, lidx = b % nx, b // nx
-        wgs = (grid - xcd + nx - 1) // nx
-        q8, r8 = divmod(total, nx)
-        xs, ntile = xcd * q8 + min(xcd, r8), q8 + (1 if xcd < r8 else 0)
-        run, extra = divmod(ntile, wgs)
-        first = xs + lidx * run + min(lidx, extra)
-        runs.append((first, first + run + (1 if lidx < extra else 0)))
-    return runs
+SF_TERMS = [(0, 0), (0, 1), (1, 0), (1, 1)]
+
+
+def emulate_conv0_splitf16(packed, x, cin, terms=3, slope=0.01, tile=(4, 4, 32), halo_x=(4, 4)):
+    """Data flow of conv0_sf_kernel in float64: per output tile and chunk of 8 input channels the staged halo tile
+    (z0-1..z0+TZ, y0-1..y0+TY, x0-4..x0+TX+3; zero outside the volume) is scaled by the power of two that puts its largest
+    magnitude into [2^14, 2^15), split into f16(x') and f16(x' - f16(x')) (round to nearest even), multiplied with the packed
+    lane images' two float16 weight slices (first `terms` of aa, ab, ba, bb), unscaled by 2^-kx and summed over the chunks;
+    then scale (which carries 2^-kw) / shift / leaky-relu.  x (B, cin, D, H, W) float32 numpy -> (B, 8, D, H, W)."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    nch = cin // 8
+    body = nch * 9 * 2 * 64 * 8 * 2
+    img = raw[:body].view(np.float16).reshape(nch, 9, 2, 64, 8).astype(np.float64)
+    tail = raw[body:body + 64].view(np.float32).astype(np.float64)
+    scale, shift = tail[:8], tail[8:16]
+    B, _, D, H, W = x.shape
+    TZ, TY, TX = tile
+    hl, hr = halo_x
+    px = ((W + TX - 1) // TX) * TX - W
+    xp = np.pad(x.astype(np.float32), ((0, 0), (0, 0), (1, TZ + 1), (1, TY + 1), (hl, hr + px)))
+    acc = np.zeros((B, 8, D, H, W))
+    for b in range(B):
+        for z0 in range(0, D, TZ):
+            for y0 in range(0, H, TY):
+                for x0 in range(0, W, TX):
+                    out = np.zeros((8, TZ, TY, TX))
+                    for ch in range(nch):
+                        halo = xp[b, ch * 8:ch * 8 + 8, z0:z0 + TZ + 2, y0:y0 + TY + 2, x0:x0 + TX + hl + hr]
+                        e = max(int(np.abs(halo).max().view(np.uint32)) >> 23, 15)
+                        mult, inv = np.float32(2.0) ** (141 - e), 2.0 ** (e - 141)
+                        xs = halo * mult
+                        xa = xs.astype(np.float16)
+                        xb = (xs - xa.astype(np.float32)).astype(np.float16)
+                        sl = [xa.astype(np.float64), xb.astype(np.float64)]
+                        part = np.zeros((8, TZ, TY, TX))
+                        for r9 in range(9):
+                            kz, ky = divmod(r9, 3)
+                            for (sa, sb) in SF_TERMS[:terms]:
+                                A = img[ch, r9, sa].reshape(4, 16, 8)                       # [u][i][ci]
+                                for u in range(4):
+                                    for s in range(2):
+                                        wrow = A[u, s::2, :]                                # (co, ci); zero where u - s is not a tap
+                                        if not wrow.any():
+                                            continue
+                                        # outputs x = x0 + 2 j + s read input x0 + 2 j + u - 1 = halo column 2 j + u - 1 + hl
+                                        src = sl[sb][:, kz:kz + TZ, ky:ky + TY, u - 1 + hl:u - 1 + hl + TX:2]
+                                        part[:, :, :, s::2] += np.einsum("oc,cdhw->odhw", wrow, src)
+                        out += part * inv
+                    dz, dy, dx = min(TZ, D - z0), min(TY, H - y0), min(TX, W - x0)
+                    acc[b, :, z0:z0 + dz, y0:y0 + dy, x0:x0 + dx] = out[:, :dz, :dy, :dx]
+    y = acc * scale[None, :, None, None, None] + shift[None, :, None, None, None]
+    return np.where(y > 0, y, y * slope)
 
 
 def conv0_sb_slot(x):

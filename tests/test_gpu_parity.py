@@ -283,6 +283,40 @@ def test_conv0_splitbf16_matches_torch_cpu(dev, report, cin, B, D, H, W):
     assert e6 < 4 * max(ef, 2e-7)     # float32-grade: no worse than a few times the float32 kernel's own distance to float64
 
 
+def test_mfma_f16_lane_semantics_selftest(report):
+    rc, dump, msg = _ops().selftest_mfma_f16()
+    report("mfma_f16_selftest", rc=rc, msg=msg, reg0=dump[0, :8].tolist())
+    assert rc == 0, msg
+
+
+SF_CASES = [c + (1.0,) for c in SB_CASES] + [(8, 1, 5, 9, 36, 3e4), (16, 1, 6, 10, 68, 1e-30), (32, 2, 9, 7, 32, 1e-3)]
+
+
+@pytest.mark.parametrize("cin,B,D,H,W,amp", SF_CASES)
+def test_conv0_splitf16_matches_torch_cpu(dev, report, cin, B, D, H, W, amp):
+    """csrc/conv0_splitf16.hip: conv0 with every float32 operand as two float16 slices behind exact power-of-two scalings (one
+    per weight tensor, one per staged tile and chunk) on the f16 matrix cores: vs torch CPU float64 at the SAME bound as the
+    float32-MFMA layer kernels and no worse than a few times that kernel's own error; three and four partial products;
+    ragged tiles; inputs far outside float16's range (3e4, 1e-30) and a corner 10^6 times smaller than the rest."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(cin * 100 + D + W)
+    x = torch.randn(B, cin, D, H, W, generator=g) * amp
+    x[..., -2:, -3:] *= 1e-6
+    w = torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2
+    scale, shift = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1 * amp
+    want = _conv_ref(ops.CONV_S1, x.double(), w.double(), scale.double(), shift.double(), None, 0.01)
+    packed = ops.conv0_splitf16_pack(w, scale, shift).to(dev)
+    xd = x.to(dev)
+    got3 = ops.conv0_splitf16_forward(packed, xd, slope=0.01, terms=3).cpu()
+    got4 = ops.conv0_splitf16_forward(packed, xd, slope=0.01, terms=4).cpu()
+    f32 = ops.conv3d_forward(ops.CONV_S1, ops.conv3d_pack(ops.CONV_S1, w, scale, shift).to(dev), xd, 8, slope=0.01).cpu()
+    e3, e4, ef = scaled_err(got3, want), scaled_err(got4, want), scaled_err(f32, want)
+    report("conv0_splitf16", shape=[cin, B, D, H, W], amp=amp, err_3_terms=e3, err_4_terms=e4, err_f32_mfma=ef, vs_f32_kernel=scaled_err(got3, f32))
+    assert torch.isfinite(got3).all()
+    assert e3 < 1.2e-5 and e4 < 1.2e-5
+    assert e3 < 4 * max(ef, 2e-7)     # float32-grade: no worse than a few times the float32 kernel's own distance to float64
+
+
 PROB_CASES = [(1, 8, 8, 64), (2, 8, 32, 40), (1, 32, 16, 72), (2, 48, 24, 132), (1, 12, 9, 36), (1, 4, 5, 8), (1, 16, 70, 196)]
 
 

@@ -1,5 +1,6 @@
 """CostRegNet.conv0 alone at the three cascade-level shapes: the float32-MFMA kernel (conv16db_kernel<PX>) against the
-split-bf16 kernel (conv0_sb_kernel, 6 and 9 partial products), each launch timed on its own with dirtied caches.
+split-bf16 kernel (conv0_sb_kernel, 6 and 9 partial products) and the split-f16 kernel (conv0_sf_kernel, 3 and 4), each launch
+timed on its own with dirtied caches; errors against a float64 convolution of a sub-volume.
    python tools/gpu_conv0_probe.py [H W [batch]]"""
 import os
 import sys
@@ -41,7 +42,16 @@ for l, (cin, D) in ((2, (32, 48)), (1, (16, 32)), (0, (8, 8))):
     t32 = timed(lambda: ops.conv3d_forward(ops.CONV_S1, p32, x, 8))
     t6 = timed(lambda: ops.conv0_splitbf16_forward(psb, x, terms=6))
     t9 = timed(lambda: ops.conv0_splitbf16_forward(psb, x, terms=9))
-    a, b6 = ops.conv3d_forward(ops.CONV_S1, p32, x, 8), ops.conv0_splitbf16_forward(psb, x, terms=6)
-    diff = float((a - b6).abs().max() / a.abs().max())
-    print(f"level {l} (cin {cin}, D {D}, {h}x{w}): f32 MFMA {t32:.1f} ({gf / t32 * 1e3:.0f} TF/s)  split-bf16 x6 {t6:.1f} ({gf / t6 * 1e3:.0f} TF/s)  x9 {t9:.1f} ({gf / t9 * 1e3:.0f})  "
-          f"max |f32 - x6| / max|f32| = {diff:.2e}", flush=True)
+    psf = ops.conv0_splitf16_pack(wt, sc, sh).to(dev)
+    t3 = timed(lambda: ops.conv0_splitf16_forward(psf, x, terms=3))
+    t4 = timed(lambda: ops.conv0_splitf16_forward(psf, x, terms=4))
+    # float64 truth on a sub-volume (all of D, 24 x 40 pixels; its border outputs are excluded: they see the crop's zero padding)
+    xs = x[:1, :, :, :24, :40]
+    ref = torch.nn.functional.conv3d(xs.double(), wt.to(dev).double(), None, padding=1) * sc.to(dev).double().view(1, -1, 1, 1, 1) + sh.to(dev).double().view(1, -1, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01)[..., :, 1:-1, 1:-1]
+    errs = []
+    for fn in (lambda v: ops.conv3d_forward(ops.CONV_S1, p32, v, 8), lambda v: ops.conv0_splitbf16_forward(psb, v, terms=6), lambda v: ops.conv0_splitf16_forward(psf, v, terms=3)):
+        got = fn(x)[:1, :, :, :24, :40][..., :, 1:-1, 1:-1].double()
+        errs.append(float((got - ref).abs().max() / ref.abs().max()))
+    print(f"level {l} (cin {cin}, D {D}, {h}x{w}): f32 MFMA {t32:.1f} ({gf / t32 * 1e3:.0f} TF/s)  split-bf16 x6 {t6:.1f} ({gf / t6 * 1e3:.0f} TF/s)  x9 {t9:.1f}  "
+          f"split-f16 x3 {t3:.1f} ({gf / t3 * 1e3:.0f} TF/s)  x4 {t4:.1f}   max err / range vs float64: f32 {errs[0]:.1e}  bf16x6 {errs[1]:.1e}  f16x3 {errs[2]:.1e}", flush=True)
