@@ -340,20 +340,27 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
     conv0_ms = sum(summ[f"costreg_{l}/conv0"]["ms"] for l in range(3))
     conv0_flops = sum(work[l]["conv0_flops"] for l in range(3)) * n_ev
     ach = conv0_flops / (conv0_ms * 1e-3) / 1e12
-    split = getattr(model.cost_reg_0, "conv0_mode", "f32") == "splitbf16" and getattr(model, "fuse_regress", False) and G in (1, 8)
-    traffic, traffic_note, src = pmc_traffic("conv0_sb_kernel" if split else "conv16db_kernel<2, 4, 4, 4, 4, 32", B if cfg_name == HEADLINE else None)
+    mode = getattr(model.cost_reg_0, "conv0_mode", "f32")
+    split = mode if mode in ("splitbf16", "splitf16") and getattr(model, "fuse_regress", False) and G in (1, 8) else None
+    kname = {"splitbf16": "conv0_sb_kernel", "splitf16": "conv0_sf_kernel", None: "conv16db_kernel<2, 4, 4, 4, 4, 32"}[split]
+    traffic, traffic_note, src = pmc_traffic(kname, B if cfg_name == HEADLINE else None)
     conv0_alg = sum(4 * B * ((G if G > 1 else 8 * 2 ** l) + 8) * n_depths[l] * (H >> l) * (W >> l) for l in range(3)) / 3
-    out["roofline"] = {"kernel": ("conv0_sb_kernel<CIN, 6> (CostRegNet.conv0 on the bf16 matrix cores, float32 operands as three exact bf16 slices; "
-                                  "3 launches per step)") if split else "conv16db_kernel<PX> (CostRegNet.conv0: Cout 8, stride 1; 3 launches per step)",
+    out["roofline"] = {"kernel": {"splitbf16": "conv0_sb_kernel<CIN, 6> (CostRegNet.conv0 on the bf16 matrix cores, float32 operands as three exact "
+                                               "bf16 slices; 3 launches per step)",
+                                  "splitf16": "conv0_sf_kernel<CIN, 3> (CostRegNet.conv0 on the f16 matrix cores, float32 operands as two float16 slices "
+                                              "behind exact power-of-two scalings; 3 launches per step)",
+                                  None: "conv16db_kernel<PX> (CostRegNet.conv0: Cout 8, stride 1; 3 launches per step)"}[split],
                        "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                        "traffic_note": traffic_note + f"; algorithmic bytes per launch (mean of the 3 levels): {conv0_alg:.4g}",
                        "traffic_source": src, "avg_launch_ms": conv0_ms / (3 * n_ev), "batch": B,
                        "peak_note": "achieved = the layer's ALGORITHMIC float32 FLOPs (2 * 27 * cin * 8 per voxel) / its HIP-event time; peak = the "
                                     "float32 MFMA dense peak (the arithmetic the path computes in)"}
-    if split:   # what the matrix cores actually execute: 6 bf16 products per float32 product, 4 K-slots per 3 taps
-        out["roofline"]["executed"] = {"dtype": "bf16", "flops_per_algorithmic_flop": 8.0, "achieved": 8.0 * ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                                       "unit": "TFLOP/s", "frac": 8.0 * ach / MFMA_BF16_PEAK_TFLOPS}
+    if split:   # what the matrix cores actually execute: 6 bf16 (3 f16) products per float32 product, 4 K-slots per 3 taps
+        mult = {"splitbf16": 8.0, "splitf16": 4.0}[split]
+        out["roofline"]["executed"] = {"dtype": {"splitbf16": "bf16", "splitf16": "f16"}[split], "flops_per_algorithmic_flop": mult, "achieved": mult * ach,
+                                       "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mult * ach / MFMA_BF16_PEAK_TFLOPS,
+                                       "note": "the dense bf16 and f16 matrix peaks are equal (2.5 PFLOP/s)"}
     cr_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("costreg_"))
     cr_flops = sum(work[l]["costreg_flops"] for l in range(3)) * n_ev
     fused = getattr(model, "fuse_regress", False)
@@ -496,9 +503,10 @@ def main():
                          "costs ~3 us of GPU time; on every step they would inflate the step by ~10 %% and starve the launch queue)")
     ap.add_argument("--no-batch1", action="store_true", help="skip the extra batch-1 measurement")
     ap.add_argument("--no-fuse-regress", action="store_true", help="A/B: `prob` and the softmax regression as separate library calls")
-    ap.add_argument("--conv0-mode", default=None, choices=["splitbf16", "f32"],
-                    help="CostRegNet.conv0: 'splitbf16' = float32 operands as three exact bf16 slices on the bf16 matrix cores (the model's default), "
-                         "'f32' = the float32 MFMA kernel like every other layer; the other mode's throughput is measured and printed beside the headline")
+    ap.add_argument("--conv0-mode", default=None, choices=["splitf16", "splitbf16", "f32"],
+                    help="CostRegNet.conv0: 'splitf16' = float32 operands as two scaled float16 slices on the f16 matrix cores (the model's default), "
+                         "'splitbf16' = three exact bf16 slices on the bf16 matrix cores, 'f32' = the float32 MFMA kernel like every other layer; the "
+                         "other modes' throughputs are measured and printed beside the headline")
     ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: FeatureNet's full-resolution FPN tail as one kernel (1) or as the reference's three steps (0); default: the model's")
     args = ap.parse_args()
     args.batch_given = args.batch is not None
@@ -596,9 +604,13 @@ def main():
                                          f"replica x{world} (one depth map stream per GPU, no data-path collective)",
                           "feature_net": "HIP MFMA kernels (casmvs_featurenet_forward_f32)",
                           "regression": "fused into the `prob` head's library call (casmvs_costreg_regress_f32)" if model.fuse_regress else "separate launch",
-                          "conv0_arithmetic": ("float32 operands as three exact bf16 slices, six bf16 x bf16 partial products per product on the bf16 "
-                                               "matrix cores, float32 accumulation (conv0_splitbf16.hip)") if model.cost_reg_0.conv0_mode == "splitbf16"
-                                              else "float32 MFMA (v_mfma_f32_16x16x4_f32)"},
+                          "conv0_arithmetic": {"splitbf16": "float32 operands as three exact bf16 slices, six bf16 x bf16 partial products per product on the "
+                                                            "bf16 matrix cores, float32 accumulation (conv0_splitbf16.hip)",
+                                               "splitf16": "float32 operands as two float16 slices (22 significand bits) behind exact power-of-two scalings, "
+                                                           "three f16 x f16 partial products per product on the f16 matrix cores, float32 accumulation "
+                                                           "(conv0_splitf16.hip); float32-grade: distance to a float64 convolution at or below the "
+                                                           "float32 MFMA kernel's",
+                                               "f32": "float32 MFMA (v_mfma_f32_16x16x4_f32)"}[model.cost_reg_0.conv0_mode]},
                          median)
         line["library_sha16"] = library_sha16()
 
@@ -614,13 +626,17 @@ def main():
         if rank == 0:
             line["single_stream"] = {"value": ms1 / els, "unit": "depth-maps/s", "ms_per_step": 1e3 * els / K, "median_ms_per_step": med1, "steps": K,
                                      "note": f"one forward of batch {B} per step (one stream, one hipGraph replay)"}
-    if not args.no_batch1:   # the same configuration with conv0 in the OTHER arithmetic, beside the headline (not instead of it)
-        this_mode = args.conv0_mode or "splitbf16"
-        conv0_mode[0] = "f32" if this_mode == "splitbf16" else "splitbf16"
-        _, _, elo, mso, medo, _ = measure(B, K, max(2, args.warmup // 2), NS)
+    if not args.no_batch1:   # the same configuration with conv0 in the OTHER arithmetics, beside the headline (not instead of it)
+        this_mode = args.conv0_mode or "splitf16"
+        others = []
+        for other in ("f32", "splitbf16", "splitf16"):
+            if other == this_mode:
+                continue
+            conv0_mode[0] = other
+            _, _, elo, mso, medo, _ = measure(B, K, max(2, args.warmup // 2), NS)
+            others.append({"conv0_mode": other, "value": mso / elo, "unit": "depth-maps/s", "ms_per_step": 1e3 * elo / K, "median_ms_per_step": medo})
         if rank == 0:
-            line["conv0_other_mode"] = {"conv0_mode": conv0_mode[0], "value": mso / elo, "unit": "depth-maps/s", "ms_per_step": 1e3 * elo / K,
-                                        "median_ms_per_step": medo, "note": "same launch configuration as the headline, only conv0's kernel differs"}
+            line["conv0_other_modes"] = {"modes": others, "note": "same launch configuration as the headline, only conv0's kernel differs"}
         conv0_mode[0] = None
     if B != 1 and not args.no_batch1:
         m1, in1, el1, mp1, medb1, g1 = measure(1, K, max(2, args.warmup // 2), 1)

@@ -2225,7 +2225,7 @@ extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
 namespace {
 // conv0 .. conv11 (+ skips) into the workspace, then the `prob` head: on its own (depth == nullptr), or fused with the
 // softmax / regression / confidence that consumes it (casmvs_prob_regress_f32).
-int costreg_run(const char *who, const float *const *packed_layers, const void *conv0_sb, const float *vol, const float *depth_values,
+int costreg_run(const char *who, const float *const *packed_layers, const void *conv0_split, int conv0_arith, const float *vol, const float *depth_values,
                 float *cost, float *depth, float *confidence, int32_t *index, void *workspace, int B, int cin, int D,
                 int h, int w, float slope, void *const *layer_events, void *stream) {
   CASMVS_REQUIRE(packed_layers && vol && cost && workspace, "%s: null pointer", who);
@@ -2253,11 +2253,21 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
   ++li;                                                                                        \
   rc = casmvs_conv3d_forward_f32(__VA_ARGS__);                                                 \
   if (rc != CASMVS_OK) return rc
-  if (conv0_sb && casmvs_conv0_splitbf16_supported(cin, w) && (reinterpret_cast<size_t>(vol) & 15) == 0) {
+  CASMVS_REQUIRE(conv0_arith == CASMVS_CONV0_F32 || conv0_arith == CASMVS_CONV0_SPLIT_BF16 || conv0_arith == CASMVS_CONV0_SPLIT_F16,
+                 "%s: conv0_arith=%d", who, conv0_arith);
+  CASMVS_REQUIRE(conv0_arith == CASMVS_CONV0_F32 || conv0_split, "%s: conv0_arith=%d needs the split image of conv0", who, conv0_arith);
+  const bool split_ok = (reinterpret_cast<size_t>(vol) & 15) == 0;
+  if (conv0_arith == CASMVS_CONV0_SPLIT_BF16 && split_ok && casmvs_conv0_splitbf16_supported(cin, w)) {
     // conv0 on the bf16 matrix cores, float32 operands as three exact bf16 slices (conv0_splitbf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_conv0_splitbf16_forward_f32(conv0_sb, vol, c0, B, cin, D, h, w, sl, 0, stream);
+    rc = casmvs_conv0_splitbf16_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 0, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else if (conv0_arith == CASMVS_CONV0_SPLIT_F16 && split_ok && casmvs_conv0_splitf16_supported(cin, w)) {
+    // conv0 on the f16 matrix cores, float32 operands as two scaled float16 slices (conv0_splitf16.hip)
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv0_splitf16_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 0, stream);
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV_S1, P[0], vol, nullptr, c0, B, cin, 8, D, h, w, sl, stream);               // conv0
@@ -2290,17 +2300,17 @@ extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, con
                                           int h, int w, float slope, void *const *layer_events,
                                           void *stream) {
   casmvs::clear_error();
-  return costreg_run("costreg_forward", packed_layers, nullptr, vol, nullptr, cost, nullptr, nullptr, nullptr, workspace, B, cin, D, h, w,
+  return costreg_run("costreg_forward", packed_layers, nullptr, CASMVS_CONV0_F32, vol, nullptr, cost, nullptr, nullptr, nullptr, workspace, B, cin, D, h, w,
                      slope, layer_events, stream);
 }
 
-extern "C" int casmvs_costreg_regress_f32(const float *const *packed_layers, const void *conv0_splitbf16, const float *vol,
+extern "C" int casmvs_costreg_regress_f32(const float *const *packed_layers, const void *conv0_split, int conv0_arith, const float *vol,
                                           const float *depth_values, float *cost, float *depth, float *confidence, int32_t *index,
                                           void *workspace, int B, int cin, int D, int h, int w, float slope,
                                           void *const *layer_events, void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(depth_values && depth && confidence, "costreg_regress: null pointer");
-  return costreg_run("costreg_regress", packed_layers, conv0_splitbf16, vol, depth_values, cost, depth, confidence, index, workspace, B,
+  return costreg_run("costreg_regress", packed_layers, conv0_split, conv0_arith, vol, depth_values, cost, depth, confidence, index, workspace, B,
                      cin, D, h, w, slope, layer_events, stream);
 }
 

@@ -214,10 +214,14 @@ class CostRegNet(_PackedWeights, nn.Module):
         self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
         self._init_packed()       # _packed: list of 11 device tensors
         self._conv0_sb = None     # conv0's split-bf16 image (uint8 device tensor)
-        # "splitbf16": conv0 on the bf16 matrix cores, every float32 operand as three exact bf16 slices, six partial products
-        # per product, float32 accumulation (float32-grade: its distance to float64 is at or below the float32 MFMA kernel's);
-        # "f32": conv0 on the float32 MFMA kernel like every other layer.  Used by `regress` (the engine's eval path).
-        self.conv0_mode = "splitbf16"
+        self._conv0_sf = None     # conv0's split-f16 image
+        # conv0's arithmetic in `regress` (the engine's eval path), all float32-grade (distance to a float64 convolution at or
+        # below the float32 MFMA kernel's):
+        #   "splitf16":  f16 matrix cores, every float32 operand as two float16 slices behind exact power-of-two scalings (per
+        #                weight tensor / per staged tile), three partial products per product, float32 accumulation
+        #   "splitbf16": bf16 matrix cores, three exact bf16 slices per operand, six partial products
+        #   "f32":       the float32 MFMA kernel like every other layer
+        self.conv0_mode = "splitf16"
         self._workspace = None
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.timer_name = "costreg"
@@ -253,8 +257,9 @@ class CostRegNet(_PackedWeights, nn.Module):
         if cin in (8, 16, 32):
             scale0, shift0, _ = _fold_norm("CostRegNet.conv0", self.conv0.bn)
             self._store_packed("_conv0_sb", ops.conv0_splitbf16_pack(self.conv0.conv.weight, scale0, shift0).to(device))
+            self._store_packed("_conv0_sf", ops.conv0_splitf16_pack(self.conv0.conv.weight, scale0, shift0).to(device))
         else:
-            self._conv0_sb = None
+            self._conv0_sb = self._conv0_sf = None
         self._packed_key = key
         return self._store_packed("_packed", packed)
 
@@ -283,8 +288,15 @@ class CostRegNet(_PackedWeights, nn.Module):
         if ws is None or ws.device != x.device or ws.numel() < need:
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         events = self.timer.layer_events(self.timer_name) if self.timer is not None else None
-        sb = self._conv0_sb if self.conv0_mode == "splitbf16" else None
-        return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index, conv0_sb=sb)
+        if self.conv0_mode not in ("splitf16", "splitbf16", "f32"):
+            raise ValueError(f"CostRegNet.conv0_mode={self.conv0_mode!r} (splitf16, splitbf16 or f32)")
+        split, arith = None, ops.CONV0_F32
+        if self.conv0_mode == "splitf16" and self._conv0_sf is not None:
+            split, arith = self._conv0_sf, ops.CONV0_SPLIT_F16
+        elif self.conv0_mode == "splitbf16" and self._conv0_sb is not None:
+            split, arith = self._conv0_sb, ops.CONV0_SPLIT_BF16
+        return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index,
+                                   conv0_split=split, conv0_arith=arith)
 
 
 class CascadeMVSNet(nn.Module):

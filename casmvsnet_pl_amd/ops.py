@@ -377,12 +377,16 @@ def costreg_forward(packed_layers, vol, workspace, slope=0.01, layer_events=None
     return cost
 
 
-def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, layer_events=None, return_index=False, conv0_sb=None):
+CONV0_F32, CONV0_SPLIT_BF16, CONV0_SPLIT_F16 = 0, 1, 2   # casmvs.h: CASMVS_CONV0_*
+
+
+def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, layer_events=None, return_index=False, conv0_split=None,
+                    conv0_arith=CONV0_F32):
     """CostRegNet + softmax / depth regression / confidence in one library call (mvsnet.py:91-104 + :174-193): the `prob`
     head walks the depth axis and, when the whole depth range is one chunk, runs the regression on the cost values it has
     just produced (casmvs_costreg_regress_f32).  -> cost (B,D,h,w), depth (B,h,w), confidence (B,h,w) [, index int32].
-    conv0_sb: device image of conv0_splitbf16_pack (conv0 on the bf16 matrix cores, float32 operands as three exact bf16
-    slices) or None (conv0 on the float32 MFMA kernel)."""
+    conv0_arith: CONV0_F32 (conv0 on the float32 MFMA kernel), CONV0_SPLIT_BF16 / CONV0_SPLIT_F16 with conv0_split = the device
+    image of conv0_splitbf16_pack / conv0_splitf16_pack (conv0 on the bf16 / f16 matrix cores with float32-grade arithmetic)."""
     vol, depth_values = _dev(vol, "vol"), _dev(depth_values, "depth_values")
     B, cin, D, h, w = vol.shape
     if tuple(depth_values.shape) != (B, D, h, w):
@@ -403,8 +407,8 @@ def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, lay
             raise ValueError("costreg_regress: need 12 events")
         ev = (ctypes.c_void_p * 12)(*[e.cuda_event for e in layer_events])
     with torch.cuda.device(dev):
-        rc = _lib.load().casmvs_costreg_regress_f32(arr, None if conv0_sb is None else ctypes.c_void_p(conv0_sb.data_ptr()),
-                                                    _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
+        rc = _lib.load().casmvs_costreg_regress_f32(arr, None if conv0_split is None else ctypes.c_void_p(conv0_split.data_ptr()),
+                                                    int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
                                                     _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
                                                     float(slope), ev, _stream(vol))
     _lib.check(rc, "casmvs_costreg_regress_f32")

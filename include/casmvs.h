@@ -309,10 +309,14 @@ int casmvs_prob_regress_f32(const float *packed, const float *in, const float *d
 
 /* Whole CostRegNet + regression: casmvs_costreg_forward_f32 with the head replaced by casmvs_prob_regress_f32.
  * `cost` (B, D, h, w) is still produced.  layer_events: as casmvs_costreg_forward_f32 (event 10 before the head,
- * event 11 after the head INCLUDING the regression).  conv0_splitbf16: NULL (conv0 on the float32 MFMA kernel, packed_layers[0])
- * or the DEVICE copy of casmvs_conv0_splitbf16_pack's image of conv0 (cin 8 / 16 / 32): conv0 on the bf16 matrix cores with
- * float32 operands as three exact bf16 slices (casmvs_conv0_splitbf16_forward_f32). */
-int casmvs_costreg_regress_f32(const float *const *packed_layers, const void *conv0_splitbf16, const float *vol,
+ * event 11 after the head INCLUDING the regression).  conv0_arith selects conv0's arithmetic: CASMVS_CONV0_F32 (the float32
+ * MFMA kernel on packed_layers[0]; conv0_split may be NULL), CASMVS_CONV0_SPLIT_BF16 / CASMVS_CONV0_SPLIT_F16 with conv0_split =
+ * the DEVICE copy of casmvs_conv0_splitbf16_pack's / casmvs_conv0_splitf16_pack's image of conv0 (cin 8 / 16 / 32; any other
+ * shape falls back to the float32 kernel). */
+#define CASMVS_CONV0_F32 0
+#define CASMVS_CONV0_SPLIT_BF16 1
+#define CASMVS_CONV0_SPLIT_F16 2
+int casmvs_costreg_regress_f32(const float *const *packed_layers, const void *conv0_split, int conv0_arith, const float *vol,
                                const float *depth_values, float *cost, float *depth, float *confidence, int32_t *index,
                                void *workspace, int B, int cin, int D, int h, int w, float slope,
                                void *const *layer_events, void *stream);
