@@ -51,6 +51,10 @@ SYMBOLS = {
     "casmvs_conv0_splitf16_supported": (c_int, [c_int, c_int]),
     "casmvs_conv0_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_selftest_mfma_f16": (c_int, [_FP]),
+    "casmvs_conv_ci_splitf16_packed_bytes": (c_size_t, [c_int, c_int]),
+    "casmvs_conv_ci_splitf16_pack": (c_int, [c_int, c_int, _FP, _FP, _FP, c_void_p]),
+    "casmvs_conv_ci_splitf16_supported": (c_int, [c_int, c_int, c_int]),
+    "casmvs_conv_ci_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_costreg_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "casmvs_costreg_forward_f32": (c_int, [POINTER(c_void_p), _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
     "casmvs_conv2d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
@@ -64,7 +68,7 @@ SYMBOLS = {
     "casmvs_softmax_regress_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_prob_regress_supported": (c_int, [c_int, c_int]),
     "casmvs_prob_regress_f32": (c_int, [_FP] * 7 + [c_int] * 5 + [c_float, c_int, c_void_p]),
-    "casmvs_costreg_regress_f32": (c_int, [POINTER(c_void_p), c_void_p, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
+    "casmvs_costreg_regress_f32": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
     "casmvs_depth_regression_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_fuse_reference_view": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_homo_warp_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -2225,7 +2225,7 @@ extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
 namespace {
 // conv0 .. conv11 (+ skips) into the workspace, then the `prob` head: on its own (depth == nullptr), or fused with the
 // softmax / regression / confidence that consumes it (casmvs_prob_regress_f32).
-int costreg_run(const char *who, const float *const *packed_layers, const void *conv0_split, int conv0_arith, const float *vol, const float *depth_values,
+int costreg_run(const char *who, const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol, const float *depth_values,
                 float *cost, float *depth, float *confidence, int32_t *index, void *workspace, int B, int cin, int D,
                 int h, int w, float slope, void *const *layer_events, void *stream) {
   CASMVS_REQUIRE(packed_layers && vol && cost && workspace, "%s: null pointer", who);
@@ -2255,6 +2255,8 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
   if (rc != CASMVS_OK) return rc
   CASMVS_REQUIRE(conv0_arith == CASMVS_CONV0_F32 || conv0_arith == CASMVS_CONV0_SPLIT_BF16 || conv0_arith == CASMVS_CONV0_SPLIT_F16,
                  "%s: conv0_arith=%d", who, conv0_arith);
+  const void *conv0_split = split_layers ? split_layers[0] : nullptr;
+  const void *conv2_split = split_layers ? split_layers[1] : nullptr, *conv4_split = split_layers ? split_layers[2] : nullptr;
   CASMVS_REQUIRE(conv0_arith == CASMVS_CONV0_F32 || conv0_split, "%s: conv0_arith=%d needs the split image of conv0", who, conv0_arith);
   const bool split_ok = (reinterpret_cast<size_t>(vol) & 15) == 0;
   if (conv0_arith == CASMVS_CONV0_SPLIT_BF16 && split_ok && casmvs_conv0_splitbf16_supported(cin, w)) {
@@ -2273,9 +2275,23 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     CASMVS_L(CASMVS_CONV_S1, P[0], vol, nullptr, c0, B, cin, 8, D, h, w, sl, stream);               // conv0
   }
   CASMVS_L(CASMVS_CONV_S2, P[1], c0, nullptr, c1, B, 8, 16, D, h, w, sl, stream);                   // conv1
-  CASMVS_L(CASMVS_CONV_S1, P[2], c1, nullptr, c2, B, 16, 16, D / 2, h / 2, w / 2, sl, stream);      // conv2
+  if (conv2_split && casmvs_conv_ci_splitf16_supported(16, 16, w / 2)) {                            // conv2 on the f16 matrix cores
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv_ci_splitf16_forward_f32(conv2_split, c1, c2, B, 16, 16, D / 2, h / 2, w / 2, sl, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV_S1, P[2], c1, nullptr, c2, B, 16, 16, D / 2, h / 2, w / 2, sl, stream);    // conv2
+  }
   CASMVS_L(CASMVS_CONV_S2, P[3], c2, nullptr, c3, B, 16, 32, D / 2, h / 2, w / 2, sl, stream);      // conv3
-  CASMVS_L(CASMVS_CONV_S1, P[4], c3, nullptr, c4, B, 32, 32, D / 4, h / 4, w / 4, sl, stream);      // conv4
+  if (conv4_split && casmvs_conv_ci_splitf16_supported(32, 32, w / 4)) {                            // conv4 on the f16 matrix cores
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv_ci_splitf16_forward_f32(conv4_split, c3, c4, B, 32, 32, D / 4, h / 4, w / 4, sl, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV_S1, P[4], c3, nullptr, c4, B, 32, 32, D / 4, h / 4, w / 4, sl, stream);    // conv4
+  }
   CASMVS_L(CASMVS_CONV_S2, P[5], c4, nullptr, c5, B, 32, 64, D / 4, h / 4, w / 4, sl, stream);      // conv5
   CASMVS_L(CASMVS_CONV_S1, P[6], c5, nullptr, c6, B, 64, 64, D / 8, h / 8, w / 8, sl, stream);      // conv6
   CASMVS_L(CASMVS_CONV_T2, P[7], c6, c4, u7, B, 64, 32, D / 8, h / 8, w / 8, sl, stream);           // conv4 + conv7
@@ -2304,13 +2320,13 @@ extern "C" int casmvs_costreg_forward_f32(const float *const *packed_layers, con
                      slope, layer_events, stream);
 }
 
-extern "C" int casmvs_costreg_regress_f32(const float *const *packed_layers, const void *conv0_split, int conv0_arith, const float *vol,
+extern "C" int casmvs_costreg_regress_f32(const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol,
                                           const float *depth_values, float *cost, float *depth, float *confidence, int32_t *index,
                                           void *workspace, int B, int cin, int D, int h, int w, float slope,
                                           void *const *layer_events, void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(depth_values && depth && confidence, "costreg_regress: null pointer");
-  return costreg_run("costreg_regress", packed_layers, conv0_split, conv0_arith, vol, depth_values, cost, depth, confidence, index, workspace, B,
+  return costreg_run("costreg_regress", packed_layers, split_layers, conv0_arith, vol, depth_values, cost, depth, confidence, index, workspace, B,
                      cin, D, h, w, slope, layer_events, stream);
 }
 

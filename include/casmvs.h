@@ -207,6 +207,16 @@ int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float
                                       float slope, int terms, void *stream);
 int casmvs_selftest_mfma_f16(float *dump);
 
+/* CostRegNet's stride-1 layers with equal channel counts (conv2: 16 -> 16, conv4: 32 -> 32; Conv3d k3 s1 p1 + folded ABN + leaky-relu,
+ * mvsnet.py:66,69) in the arithmetic of casmvs_conv0_splitf16_forward_f32, channel-inner matrix form (csrc/conv_ci_splitf16.hip).
+ * (cin, cout) in {(16, 16), (32, 32)}, W % 2 == 0, tensors 8-byte aligned.  `packed`: HOST image from casmvs_conv_ci_splitf16_pack
+ * (weight (cout, cin, 3, 3, 3) finite, scale / shift (cout) or NULL), copied to the device (16-byte aligned) by the caller. */
+size_t casmvs_conv_ci_splitf16_packed_bytes(int cin, int cout);
+int casmvs_conv_ci_splitf16_pack(int cin, int cout, const float *weight, const float *scale, const float *shift, void *packed);
+int casmvs_conv_ci_splitf16_supported(int cin, int cout, int W);
+int casmvs_conv_ci_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int cout, int D, int H, int W,
+                                        float slope, void *stream);
+
 /* Whole CostRegNet (mvsnet.py:91-104).  `packed_layers[11]` are the device images of
  * conv0..conv6, conv7, conv9, conv11, prob (in that order).  `workspace` holds the intermediate
  * activations; its size comes from casmvs_costreg_workspace_bytes.
@@ -310,13 +320,14 @@ int casmvs_prob_regress_f32(const float *packed, const float *in, const float *d
 /* Whole CostRegNet + regression: casmvs_costreg_forward_f32 with the head replaced by casmvs_prob_regress_f32.
  * `cost` (B, D, h, w) is still produced.  layer_events: as casmvs_costreg_forward_f32 (event 10 before the head,
  * event 11 after the head INCLUDING the regression).  conv0_arith selects conv0's arithmetic: CASMVS_CONV0_F32 (the float32
- * MFMA kernel on packed_layers[0]; conv0_split may be NULL), CASMVS_CONV0_SPLIT_BF16 / CASMVS_CONV0_SPLIT_F16 with conv0_split =
- * the DEVICE copy of casmvs_conv0_splitbf16_pack's / casmvs_conv0_splitf16_pack's image of conv0 (cin 8 / 16 / 32; any other
- * shape falls back to the float32 kernel). */
+ * MFMA kernel on packed_layers[0]), CASMVS_CONV0_SPLIT_BF16 / CASMVS_CONV0_SPLIT_F16 with split_layers[0] = the DEVICE copy of
+ * casmvs_conv0_splitbf16_pack's / casmvs_conv0_splitf16_pack's image of conv0 (cin 8 / 16 / 32; any other shape falls back to the
+ * float32 kernel).  split_layers: NULL, or 3 pointers { conv0 image or NULL, conv2 image or NULL, conv4 image or NULL }; a non-NULL
+ * conv2 / conv4 entry (DEVICE copy of casmvs_conv_ci_splitf16_pack's image) runs that layer on the f16 matrix cores too. */
 #define CASMVS_CONV0_F32 0
 #define CASMVS_CONV0_SPLIT_BF16 1
 #define CASMVS_CONV0_SPLIT_F16 2
-int casmvs_costreg_regress_f32(const float *const *packed_layers, const void *conv0_split, int conv0_arith, const float *vol,
+int casmvs_costreg_regress_f32(const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol,
                                const float *depth_values, float *cost, float *depth, float *confidence, int32_t *index,
                                void *workspace, int B, int cin, int D, int h, int w, float slope,
                                void *const *layer_events, void *stream);

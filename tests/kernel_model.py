@@ -610,6 +610,85 @@ def emulate_conv0_splitf16(packed, x, cin, terms=3, slope=0.01, tile=(4, 4, 32),
     return np.where(y > 0, y, y * slope)
 
 
+def emulate_conv_ci_splitf16(packed, x, cin, cout, slope=0.01, tile=(4, 4, 16), halo_x=(2, 2)):
+    """Data flow of conv_ci_sf_kernel in float64.  The lane images [chunk][step][row block][slice][lane][8 f16] are decoded into the
+    two weight slices W_s[co][ci][tap] exactly as the kernel's lanes meet them (lane (i, kb) of step m: co = 16 rb + i,
+    ci = 16 chunk + 8 (kb & 1) + e, tap 2 m + (kb >> 1); tap 27 must be zero); per output tile and chunk of 16 input channels the
+    staged halo tile (z0-1..z0+TZ, y0-1..y0+TY, x0-2..x0+TX+1; zero outside) is scaled, split and multiplied (aa, ab, ba), unscaled
+    and summed over the chunks; then scale / shift / leaky-relu.  x (B, cin, D, H, W) float32 numpy -> (B, cout, D, H, W)."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    nch, nrb = cin // 16, cout // 16
+    body = nch * 14 * nrb * 2 * 64 * 8 * 2
+    img = raw[:body].view(np.float16).reshape(nch, 14, nrb, 2, 64, 8).astype(np.float64)
+    tail = raw[body:body + 8 * cout].view(np.float32).astype(np.float64)
+    scale, shift = tail[:cout], tail[cout:]
+    Ws = np.zeros((2, cout, cin, 28))
+    for ch in range(nch):
+        for st in range(14):
+            for rb in range(nrb):
+                for lane in range(64):
+                    i, kb = lane & 15, lane >> 4
+                    Ws[:, 16 * rb + i, 16 * ch + 8 * (kb & 1):16 * ch + 8 * (kb & 1) + 8, 2 * st + (kb >> 1)] = img[ch, st, rb, :, lane, :]
+    assert not Ws[:, :, :, 27].any()
+    Ws = Ws[:, :, :, :27].reshape(2, cout, cin, 3, 3, 3)
+    B, _, D, H, W = x.shape
+    TZ, TY, TX = tile
+    hl, hr = halo_x
+    px = ((W + TX - 1) // TX) * TX - W
+    xp = np.pad(x.astype(np.float32), ((0, 0), (0, 0), (1, TZ + 1), (1, TY + 1), (hl, hr + px)))
+    acc = np.zeros((B, cout, D, H, W))
+    for b in range(B):
+        for z0 in range(0, D, TZ):
+            for y0 in range(0, H, TY):
+                for x0 in range(0, W, TX):
+                    out = np.zeros((cout, TZ, TY, TX))
+                    for ch in range(nch):
+                        halo = xp[b, ch * 16:ch * 16 + 16, z0:z0 + TZ + 2, y0:y0 + TY + 2, x0:x0 + TX + hl + hr]
+                        e = max(int(np.abs(halo).max().view(np.uint32)) >> 23, 15)
+                        mult, inv = np.float32(2.0) ** (141 - e), 2.0 ** (e - 141)
+                        xs = halo * mult
+                        xa = xs.astype(np.float16)
+                        xb = (xs - xa.astype(np.float32)).astype(np.float16)
+                        sl = [xa.astype(np.float64), xb.astype(np.float64)]
+                        part = np.zeros((cout, TZ, TY, TX))
+                        for (sa, sb) in ((0, 0), (0, 1), (1, 0)):
+                            wv = Ws[sa][:, ch * 16:ch * 16 + 16]
+                            for kz in range(3):
+                                for ky in range(3):
+                                    for kx in range(3):
+                                        src = sl[sb][:, kz:kz + TZ, ky:ky + TY, kx + hl - 1:kx + hl - 1 + TX]
+                                        part += np.einsum("oc,cdhw->odhw", wv[:, :, kz, ky, kx], src)
+                        out += part * inv
+                    dz, dy, dx = min(TZ, D - z0), min(TY, H - y0), min(TX, W - x0)
+                    acc[b, :, z0:z0 + dz, y0:y0 + dy, x0:x0 + dx] = out[:, :dz, :dy, :dx]
+    y = acc * scale[None, :, None, None, None] + shift[None, :, None, None, None]
+    return np.where(y > 0, y, y * slope)
+
+
+def conv_ci_sf_lds_cycles():
+    """(tap-read cycles of one ds_read_b128 of conv_ci_sf_kernel for every step's lane-half distance [4 = conflict-free],
+    staging-write cycles of one ds_write_b128 pair in the kernel's order and in the plain order [8 = conflict-free per write])."""
+    RS, IY, NVOX = 20, 6, 720
+    reads = []
+    for dist in (1, RS - 2, (IY - 2) * RS - 2):
+        reads.append(_b128_cycles(lambda l, d=dist: 4 * (((l >> 4) & 1) * NVOX + (l & 15) + 1 + (l >> 5) * d), _B128_GROUPS))
+
+    def write_cycles(order):
+        tot = 0
+        for which in range(2):
+            for g0 in range(0, 64, 8):
+                banks = {}
+                for i in range(g0, g0 + 8):
+                    swp = ((i >> 2) & 1) if order else 0
+                    row, g = divmod(i, 10)
+                    unit = row * RS + 2 * g + (swp if which == 0 else 1 - swp)
+                    banks.setdefault(unit % 8, set()).add(unit)
+                tot += max(len(v) for v in banks.values())
+        return tot
+    return reads, write_cycles(True), write_cycles(False)
+
+
 def conv0_sb_slot(x):
     """16-byte slot of column x inside a staged row (SbCfg::slot)."""
     return x ^ (((x >> 3) & 1) << 1)

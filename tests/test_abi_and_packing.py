@@ -259,6 +259,37 @@ def test_conv0_splitf16_packing_and_partial_products(cin, terms, shape, amp):
         ops.conv0_splitf16_pack(w * float("inf"), scale, shift)
 
 
+@pytest.mark.parametrize("c,shape,amp", [(16, (3, 4, 6), 1.0), (16, (5, 6, 18), 1e-3), (32, (2, 3, 8), 1.0), (16, (4, 5, 34), 3e4), (32, (5, 2, 20), 1e-30)])
+def test_conv_ci_splitf16_packing_and_partial_products(c, shape, amp):
+    """csrc/conv_ci_splitf16.hip: the C packer's lane images (tap pairs x 16 channels per step, 2^kw w as two float16 slices, the
+    28th tap zero) decoded lane by lane, with the kernel's per-(tile, chunk) scaling and two-slice split of the activations,
+    reproduce Conv3d + folded ABN to float32 grade (<= 4e-7 of the output range against float64) at any input magnitude."""
+    import numpy as np
+    g = torch.Generator().manual_seed(c + shape[2])
+    x = torch.randn(1, c, *shape, generator=g) * amp
+    x[..., -2:, -3:] *= 1e-6
+    w = torch.randn(c, c, 3, 3, 3, generator=g) * 0.1
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1 * amp
+    packed = ops.conv_ci_splitf16_pack(w, scale, shift)
+    assert packed.numel() == c // 16 * 14 * (c // 16) * 2 * 64 * 16 + 8 * c
+    ref = F.conv3d(x.double(), w.double(), None, padding=1) * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01).numpy()
+    got = KM.emulate_conv_ci_splitf16(packed.numpy(), x.numpy(), c, c)
+    err = float(np.abs(got - ref).max() / np.abs(ref).max())
+    assert err < 4e-7, err
+    with pytest.raises(ValueError):
+        ops.conv_ci_splitf16_pack(torch.randn(16, 32, 3, 3, 3))
+
+
+def test_conv_ci_splitf16_lds_layout():
+    """conv_ci_sf_kernel's planes [slice][channel half][voxel] keep every tap read conflict-free for all three lane-half distances
+    (next x, next row, next plane), and writing the two voxels of an item in lane-dependent order (lanes 0-3 of every 8 the even
+    voxel first, lanes 4-7 the odd one) makes the staging writes conflict-free (plain order: 2-way)."""
+    reads, w_kernel, w_plain = KM.conv_ci_sf_lds_cycles()
+    assert reads == [4, 4, 4], reads
+    assert w_kernel == 16 and w_plain == 32, (w_kernel, w_plain)
+
+
 def test_conv0_splitbf16_lds_layout():
     """conv0_sb_kernel's swizzled LDS rows keep the tap reads conflict-free while the staging writes cost 1.75x their minimum
     (3.1x without the swizzle).  (Tiles are dealt round-robin in XCD-major order like every other layer - contiguous runs per

@@ -317,6 +317,33 @@ def test_conv0_splitf16_matches_torch_cpu(dev, report, cin, B, D, H, W, amp):
     assert e3 < 4 * max(ef, 2e-7)     # float32-grade: no worse than a few times the float32 kernel's own distance to float64
 
 
+CI_CASES = [(16, 1, 4, 8, 16, 1.0), (16, 2, 5, 9, 36, 1.0), (32, 1, 6, 10, 20, 1.0), (32, 2, 3, 5, 50, 1e-3), (16, 1, 9, 6, 34, 3e4), (32, 1, 4, 4, 16, 1e-30),
+            (16, 1, 2, 3, 2, 1.0)]
+
+
+@pytest.mark.parametrize("c,B,D,H,W,amp", CI_CASES)
+def test_conv_ci_splitf16_matches_torch_cpu(dev, report, c, B, D, H, W, amp):
+    """csrc/conv_ci_splitf16.hip: conv2 (16 -> 16) / conv4 (32 -> 32) of CostRegNet (mvsnet.py:66,69) on the f16 matrix cores, every
+    float32 operand as two scaled float16 slices: vs torch CPU float64 at the SAME bound as the float32-MFMA layer kernels and no
+    worse than a few times that kernel's own error; ragged tiles in all three directions, inputs far outside float16's range."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(c * 100 + D + W)
+    x = torch.randn(B, c, D, H, W, generator=g) * amp
+    x[..., -1:, -1:] *= 1e-6
+    w = torch.randn(c, c, 3, 3, 3, generator=g) * 0.1
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1 * amp
+    want = _conv_ref(ops.CONV_S1, x.double(), w.double(), scale.double(), shift.double(), None, 0.01)
+    packed = ops.conv_ci_splitf16_pack(w, scale, shift).to(dev)
+    xd = x.to(dev)
+    got = ops.conv_ci_splitf16_forward(packed, xd, c, slope=0.01).cpu()
+    f32 = ops.conv3d_forward(ops.CONV_S1, ops.conv3d_pack(ops.CONV_S1, w, scale, shift).to(dev), xd, c, slope=0.01).cpu()
+    e3, ef = scaled_err(got, want), scaled_err(f32, want)
+    report("conv_ci_splitf16", shape=[c, B, D, H, W], amp=amp, err_splitf16=e3, err_f32_mfma=ef, vs_f32_kernel=scaled_err(got, f32))
+    assert torch.isfinite(got).all()
+    assert e3 < 1.2e-5
+    assert e3 < 4 * max(ef, 2e-7)
+
+
 PROB_CASES = [(1, 8, 8, 64), (2, 8, 32, 40), (1, 32, 16, 72), (2, 48, 24, 132), (1, 12, 9, 36), (1, 4, 5, 8), (1, 16, 70, 196)]
 
 

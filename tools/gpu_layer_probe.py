@@ -60,6 +60,14 @@ for l, D in ((2, 48), (1, 32), (0, 8)):
             us = timed(lambda: ops.conv3d_forward(kind, pk, x, cout))
             nout = x[:, 0].numel() / (8 if kind == ops.CONV_S2 else 1)
             row.append(f"{name} {us:.1f} ({2 * 27 * cin * cout * nout / 1e9 / us * 1e3:.0f} TF/s)")
+            if kind == ops.CONV_S1 and cin == cout and cin in (16, 32):   # the same layer on the f16 matrix cores (conv_ci_splitf16.hip)
+                g = torch.Generator().manual_seed(2)
+                wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1
+                sc_, sh_ = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+                psf = ops.conv_ci_splitf16_pack(wt, sc_, sh_).to(dev)
+                us2 = timed(lambda: ops.conv_ci_splitf16_forward(psf, x, cout))
+                a, b = ops.conv3d_forward(kind, pk, x, cout), ops.conv_ci_splitf16_forward(psf, x, cout)
+                row.append(f"[split-f16 {us2:.1f} ({2 * 27 * cin * cout * nout / 1e9 / us2 * 1e3:.0f} TF/s), max diff / range {float((a - b).abs().max() / a.abs().max()):.1e}]")
     print("  ".join(row), flush=True)
     if "prob" in ITEMS:
         x = torch.randn(B, 8, D, h, w, device=dev)
