@@ -505,8 +505,9 @@ def main():
     ap.add_argument("--no-fuse-regress", action="store_true", help="A/B: `prob` and the softmax regression as separate library calls")
     ap.add_argument("--conv0-mode", default=None, choices=["splitf16", "splitbf16", "f32"],
                     help="CostRegNet.conv0: 'splitf16' = float32 operands as two scaled float16 slices on the f16 matrix cores (the model's default), "
-                         "'splitbf16' = three exact bf16 slices on the bf16 matrix cores, 'f32' = the float32 MFMA kernel like every other layer; the "
-                         "other modes' throughputs are measured and printed beside the headline")
+                         "'splitbf16' = three exact bf16 slices on the bf16 matrix cores, 'f32' = the float32 MFMA kernel like every other layer; "
+                         "'splitf16' also runs conv2 / conv4 in that arithmetic, the other two keep them in float32; the other modes' throughputs "
+                         "are measured and printed beside the headline")
     ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: FeatureNet's full-resolution FPN tail as one kernel (1) or as the reference's three steps (0); default: the model's")
     args = ap.parse_args()
     args.batch_given = args.batch is not None
@@ -557,8 +558,9 @@ def main():
             model.feature.fuse_tail = bool(args.fuse_tail)
         mode = conv0_mode[0] or args.conv0_mode
         if mode is not None:
-            for l in range(3):
+            for l in range(3):   # "splitf16" = every layer that has an f16 form (conv0, conv2, conv4); the other two keep conv2 / conv4 in float32
                 getattr(model, f"cost_reg_{l}").conv0_mode = mode
+                getattr(model, f"cost_reg_{l}").ci_mode = "splitf16" if mode == "splitf16" else "f32"
         # replica: every rank works on its own depth maps (different seeds -> different images / cameras);
         # view_sharded: all ranks share the depth maps and split their source views
         imgs, proj, dmin, dint = config_inputs(args.config, B, seed=0 if view_sharded else rank)
@@ -610,7 +612,9 @@ def main():
                                                            "three f16 x f16 partial products per product on the f16 matrix cores, float32 accumulation "
                                                            "(conv0_splitf16.hip); float32-grade: distance to a float64 convolution at or below the "
                                                            "float32 MFMA kernel's",
-                                               "f32": "float32 MFMA (v_mfma_f32_16x16x4_f32)"}[model.cost_reg_0.conv0_mode]},
+                                               "f32": "float32 MFMA (v_mfma_f32_16x16x4_f32)"}[model.cost_reg_0.conv0_mode],
+                          "conv2_conv4_arithmetic": "as conv0's split-f16 (conv_ci_splitf16.hip); conv4 only where its tiles are full (levels 1, 2)"
+                                                    if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA"},
                          median)
         line["library_sha16"] = library_sha16()
 
@@ -636,7 +640,9 @@ def main():
             _, _, elo, mso, medo, _ = measure(B, K, max(2, args.warmup // 2), NS)
             others.append({"conv0_mode": other, "value": mso / elo, "unit": "depth-maps/s", "ms_per_step": 1e3 * elo / K, "median_ms_per_step": medo})
         if rank == 0:
-            line["conv0_other_modes"] = {"modes": others, "note": "same launch configuration as the headline, only conv0's kernel differs"}
+            line["conv0_other_modes"] = {"modes": others, "note": "same launch configuration as the headline; 'f32' = every CostRegNet layer on the "
+                                                                  "float32 MFMA kernels, 'splitbf16' = only conv0 on the bf16 matrix cores, 'splitf16' = "
+                                                                  "conv0, conv2, conv4 on the f16 matrix cores"}
         conv0_mode[0] = None
     if B != 1 and not args.no_batch1:
         m1, in1, el1, mp1, medb1, g1 = measure(1, K, max(2, args.warmup // 2), 1)

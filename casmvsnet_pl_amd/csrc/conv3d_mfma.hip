@@ -2284,7 +2284,10 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     CASMVS_L(CASMVS_CONV_S1, P[2], c1, nullptr, c2, B, 16, 16, D / 2, h / 2, w / 2, sl, stream);    // conv2
   }
   CASMVS_L(CASMVS_CONV_S2, P[3], c2, nullptr, c3, B, 16, 32, D / 2, h / 2, w / 2, sl, stream);      // conv3
-  if (conv4_split && casmvs_conv_ci_splitf16_supported(32, 32, w / 4)) {                            // conv4 on the f16 matrix cores
+  // conv4 on the f16 matrix cores where its 4 x 4 x 16 tiles are full and there are enough of them (measured: 60 tiles or a
+  // 2-plane volume are faster on the float32 kernel's deep variant; 120 tiles and more on the f16 one)
+  const long conv4_tiles = (long)B * casmvs::ceil_div(D / 4, 4) * casmvs::ceil_div(h / 4, 4) * casmvs::ceil_div(w / 4, 16);
+  if (conv4_split && casmvs_conv_ci_splitf16_supported(32, 32, w / 4) && D / 4 >= 3 && conv4_tiles >= 100) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
     rc = casmvs_conv_ci_splitf16_forward_f32(conv4_split, c3, c4, B, 32, 32, D / 4, h / 4, w / 4, sl, stream);
