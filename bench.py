@@ -487,13 +487,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None,
-                    help="depth maps per step per GPU (default 2: reference views batched like the reference's train.py --batch_size 2; "
-                         "--batch 1 = the reference's eval.py loop, always measured too).  --mode train: default 1")
+                    help="depth maps per forward per GPU (default 4: independent reference views batched like the reference's train.py "
+                         "--batch_size; --batch 1 = the reference's eval.py loop, always measured too).  --mode train: default 1")
     ap.add_argument("--mode", default="replica", choices=["replica", "view_sharded", "train"])
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying one hipGraph")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="independent forwards in flight per GPU, one HIP stream + hipGraph each (a step = one round of all of "
-                         "them; 1 = a single forward per step).  The single-stream figures are printed as well.")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent forwards in flight per GPU, one HIP stream + hipGraph each (a step = one round of all of them).  Default 1: "
+                         "with more than one stream every layer runs on the float32 MFMA kernels (graph.ConcurrentForwards: f16 / bf16 matrix "
+                         "instructions beside another stream's float32 matrix instructions corrupt the latter on the MI355X); that configuration "
+                         "(2 streams x batch 2, float32) is measured and printed beside the headline as `two_streams_float32`.")
+    ap.add_argument("--unsafe-mixed-streams", action="store_true",
+                    help="experiments only: with --streams > 1 keep the split-f16 / split-bf16 layers in the replicas (results are NOT reliable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stock-pytorch", action="store_true",
                     help="also time the restated reference forward on stock PyTorch-ROCm operators on this GPU (adds ~1 min of MIOpen search)")
@@ -512,7 +516,7 @@ def main():
     args = ap.parse_args()
     args.batch_given = args.batch is not None
     if args.batch is None:
-        args.batch = 2
+        args.batch = 4
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -574,7 +578,10 @@ def main():
             model(imgs, proj, dmin, dint)
         use_graph = not args.no_graph and not view_sharded   # a collective inside a capture is not attempted
         if use_graph and streams > 1:
-            cf = ConcurrentForwards(model, imgs, proj, dmin, dint, n_streams=streams)
+            cf = ConcurrentForwards(model, imgs, proj, dmin, dint, n_streams=streams, mixed_matrix_types=args.unsafe_mixed_streams)
+            if not args.unsafe_mixed_streams:   # what the replicas run (and what the instrumented pass below should time)
+                for l in range(3):
+                    getattr(model, f"cost_reg_{l}").conv0_mode = getattr(model, f"cost_reg_{l}").ci_mode = "f32"
             step = lambda: cf.run()[-1]
         elif use_graph:
             gf = GraphedForward(model, imgs, proj, dmin, dint)
@@ -630,6 +637,15 @@ def main():
         if rank == 0:
             line["single_stream"] = {"value": ms1 / els, "unit": "depth-maps/s", "ms_per_step": 1e3 * els / K, "median_ms_per_step": med1, "steps": K,
                                      "note": f"one forward of batch {B} per step (one stream, one hipGraph replay)"}
+    if NS == 1 and used_graph and not args.no_batch1 and (args.conv0_mode or "splitf16") != "f32":
+        # round 2's launch configuration: two concurrent forwards of batch 2, which must run all-float32 (graph.ConcurrentForwards)
+        _, _, el2, ms2, med2, _ = measure(2, K, max(2, args.warmup // 2), 2)
+        if rank == 0:
+            line["two_streams_float32"] = {"value": ms2 / el2, "unit": "depth-maps/s", "ms_per_step": 1e3 * el2 / K, "median_ms_per_step": med2, "steps": K,
+                                           "note": "2 independent forwards of batch 2 per step, one hipGraph + HIP stream each, every layer on the float32 MFMA "
+                                                   "kernels: f16 / bf16 matrix instructions of one stream's kernels corrupt the float32 matrix instructions "
+                                                   "of the other's when they share a SIMD (profiles/r03_mfma_coresidency.txt), so the split-f16 layers "
+                                                   "are used in single-stream launches only"}
     if not args.no_batch1:   # the same configuration with conv0 in the OTHER arithmetics, beside the headline (not instead of it)
         this_mode = args.conv0_mode or "splitf16"
         others = []

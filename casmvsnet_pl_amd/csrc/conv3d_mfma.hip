@@ -41,6 +41,9 @@
 
 namespace {
 
+#ifndef CASMVS_MFMA_DRAIN_NOPS
+#define CASMVS_MFMA_DRAIN_NOPS 0
+#endif
 using namespace casmvs::buf;  // rsrc_t, kOOB, make_rsrc, buf_load*, buf_store*, xcd_major, f32x2, f32x4v, u32x2, u32x4
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1029,6 +1032,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
 
     bool more = true;
     if (++cur_chunk == nstages) {  // tile finished: epilogue, then switch to the next tile
+#pragma unroll
+      for (int dn = 0; dn < CASMVS_MFMA_DRAIN_NOPS; ++dn) asm volatile("s_nop 15");   // debug builds (co-residency experiment)
       const rsrc_t dst = make_rsrc(out + cur.b * out_ss, out_ss * 4);
       const rsrc_t skp = make_rsrc((skip && !OUT2) ? skip + cur.b * out_ss : out, out_ss * 4);
       [[maybe_unused]] const rsrc_t d2 = make_rsrc(OUT2 ? const_cast<float *>(skip) + cur.b * out_ss : out, out_ss * 4);

@@ -30,6 +30,13 @@
 #include "buffer_ops.h"
 #include "common.h"
 
+#ifndef CASMVS_CI_LOAD_AUX
+#define CASMVS_CI_LOAD_AUX 0    // cache-policy bits of the activation loads (debug builds: 17 = sc0 | sc1, system-coherent)
+#endif
+#ifndef CASMVS_CI_STORE_AUX
+#define CASMVS_CI_STORE_AUX 0
+#endif
+
 namespace {
 
 using namespace casmvs::buf;
@@ -170,7 +177,8 @@ __global__ __launch_bounds__(256, (CiCfg<CIN, COUT>::WG_PER_CU)) void conv_ci_sf
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
-      for (int c = 0; c < 16; ++c) R[r][c] = buf_load2(src, voff[r], (chunk * 16 + c) * cs * 4);
+      for (int c = 0; c < 16; ++c)
+        R[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(src, voff[r], (chunk * 16 + c) * cs * 4, CASMVS_CI_LOAD_AUX));
   };
 
   f32x4 acc[NT][RB];
@@ -296,14 +304,14 @@ __global__ __launch_bounds__(256, (CiCfg<CIN, COUT>::WG_PER_CU)) void conv_ci_sf
     for (int t = 0; t < NT; ++t) {
       const int oz = cur.tz0 + wave, oy = cur.ty0 + t, ox = cur.tx0 + jcol;
       const bool ok = oz < D && oy < H && ox < W;
-      const int o0 = ok ? ((oz * H + oy) * W + ox) * 4 : kOOB;
+      const int o0 = ok ? (4 * kb * cs + (oz * H + oy) * W + ox) * 4 : kOOB;   // the lane's first channel row (4 kb) is part of the lane offset
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = fmaf(acc[t][rb][r], sc[rb][r], sh[rb][r]);
           v = v > 0.0f ? v : v * slope;
-          buf_store(v, dst, o0, (rb * 16 + 4 * kb + r) * cs * 4);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), dst, o0, (rb * 16 + r) * cs * 4, CASMVS_CI_STORE_AUX);
         }
         acc[t][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }

@@ -92,14 +92,28 @@ class ConcurrentForwards:
     `refresh_weights()` re-packs the images in place for the captured graphs.
 
     `run(batches)` takes one (imgs, proj_mats) pair per stream (None = reuse the captured inputs), replays the graphs
-    concurrently and returns the list of STATIC output dicts after making the caller's stream wait for all of them."""
+    concurrently and returns the list of STATIC output dicts after making the caller's stream wait for all of them.
 
-    def __init__(self, model, imgs, proj_mats, init_depth_min, depth_interval, n_streams=2, warmup=2):
+    MATRIX-INSTRUCTION TYPES MUST NOT MIX ACROSS THE STREAMS.  Measured on the MI355X (tools/debug/disturber.py,
+    profiles/r03_mfma_coresidency.txt): while waves of another kernel issue v_mfma_f32_16x16x32_f16 / _bf16 on a SIMD, a
+    float32 layer kernel (v_mfma_f32_16x16x4_f32) co-resident on that SIMD returns a few wrong accumulator values (row 14 of
+    the 16 x 16 tile) - 800 of 800 replays with a pure f16-MFMA loop as the neighbour, none with a float32-MFMA, LDS or VALU
+    neighbour.  Inside ONE stream kernels never overlap, so the split-f16 / split-bf16 layers (CostRegNet.conv0_mode, ci_mode) are
+    safe there; across streams they would run beside the other forward's float32 layers.  The replicas therefore run every layer
+    on the float32 MFMA kernels unless `mixed_matrix_types=True` (experiments only: results are NOT reliable)."""
+
+    def __init__(self, model, imgs, proj_mats, init_depth_min, depth_interval, n_streams=2, warmup=2, mixed_matrix_types=False):
         self.device = imgs.device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.forwards = []
         for st in self.streams:
             replica = shared_parameter_replica(model)
+            if not mixed_matrix_types:
+                for m in replica.modules():
+                    if hasattr(m, "conv0_mode"):
+                        m.conv0_mode = "f32"
+                    if hasattr(m, "ci_mode"):
+                        m.ci_mode = "f32"
             st.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(st):
                 self.forwards.append(GraphedForward(replica, imgs, proj_mats, init_depth_min, depth_interval, warmup))

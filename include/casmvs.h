@@ -317,6 +317,10 @@ int casmvs_prob_regress_f32(const float *packed, const float *in, const float *d
                             float *depth, float *confidence, int32_t *index, int B, int cin, int D, int h,
                             int w, float slope, int zchunk, void *stream);
 
+/* Debug tooling (tools/debug/disturber.py, DESIGN.md "co-residency"): a neighbour kernel of a chosen kind - 0 f32 MFMA, 1 f16 MFMA,
+ * 2 bf16 MFMA, 3 LDS traffic over its whole allocation, 4 VALU - with `lds_bytes` (16 .. 163840) of dynamic LDS per 256-thread workgroup. */
+int casmvs_debug_disturb(int kind, int blocks, int iters, int lds_bytes, float *sink, void *stream);
+
 /* Whole CostRegNet + regression: casmvs_costreg_forward_f32 with the head replaced by casmvs_prob_regress_f32.
  * `cost` (B, D, h, w) is still produced.  layer_events: as casmvs_costreg_forward_f32 (event 10 before the head,
  * event 11 after the head INCLUDING the regression).  conv0_arith selects conv0's arithmetic: CASMVS_CONV0_F32 (the float32

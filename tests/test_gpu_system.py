@@ -24,6 +24,11 @@ def _model(dev, G=1, seed=3):
     from casmvsnet_pl_amd.synthetic import randomize_state_dict
     m = CascadeMVSNet(num_groups=G, norm_act=ABN)
     randomize_state_dict(m.state_dict(), seed=seed)
+    for l in range(3):   # A/B hooks for debugging runs (default: the model's own modes)
+        if os.environ.get("CASMVS_TEST_CI_MODE"):
+            getattr(m, f"cost_reg_{l}").ci_mode = os.environ["CASMVS_TEST_CI_MODE"]
+        if os.environ.get("CASMVS_TEST_CONV0_MODE"):
+            getattr(m, f"cost_reg_{l}").conv0_mode = os.environ["CASMVS_TEST_CONV0_MODE"]
     return m.to(dev).eval()
 
 
@@ -115,15 +120,22 @@ def test_view_sharded_model_equals_fused_world1():
 
 
 def test_concurrent_forwards_equal_single_stream(dev):
-    """Two captured forwards on two streams give the same bits as the kernel-by-kernel forward, on different inputs."""
+    """Two captured forwards on two streams give the same bits as the kernel-by-kernel forward, on different inputs.  The replicas run
+    every layer on the float32 MFMA kernels (matrix-instruction types must not mix across streams: graph.py), so the reference is
+    the model in its all-float32 modes."""
     from casmvsnet_pl_amd.graph import ConcurrentForwards
     from casmvsnet_pl_amd.synthetic import make_inputs
     model = _model(dev)
     ins = [make_inputs(1, 3, 64, 96, seed=s) for s in (1, 2)]
     dmin, dint = ins[0][2], ins[0][3]
     cf = ConcurrentForwards(model, ins[0][0].to(dev), ins[0][1].to(dev), dmin, dint, n_streams=2)
+    for gf in cf.forwards:
+        assert all(getattr(gf.model, f"cost_reg_{l}").conv0_mode == "f32" and getattr(gf.model, f"cost_reg_{l}").ci_mode == "f32" for l in range(3))
+    assert model.cost_reg_0.conv0_mode != "f32"   # the source model keeps its own (single-stream) arithmetic
+    for l in range(3):
+        getattr(model, f"cost_reg_{l}").conv0_mode = getattr(model, f"cost_reg_{l}").ci_mode = "f32"
     want = [{k: v.clone() for k, v in model(i[0].to(dev), i[1].to(dev), dmin, dint).items()} for i in ins]
-    for _ in range(2):
+    for _ in range(20):
         outs = cf.run([(i[0].to(dev), i[1].to(dev)) for i in ins])
         torch.cuda.synchronize()
         for o, w in zip(outs, want):
