@@ -102,13 +102,15 @@ def pmc_traffic(kernel_prefix, batch):
     MI355X_MICROARCH.md prescribes.  -> (bytes | None, note, source) - `source` says which file, when it was collected
     and whether the library that produced it is the one running now (`same_library`)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if batch != 2 or not files:
-        return None, "PMC passes are collected at --batch 2 on the default config only", None
+    if batch is None or not files:
+        return None, "PMC passes are collected on the default config only", None
     path = files[-1]
     doc = json.load(open(path))
     meta = {}
     if isinstance(doc, dict):   # round 3 layout: {"meta": {...}, "kernels": [...]}
         meta, doc = doc.get("meta", {}), doc.get("kernels", [])
+    if (meta.get("batch") or 2) != batch:
+        return None, f"the PMC passes of {os.path.relpath(path, ROOT)} were collected at batch {meta.get('batch') or 2}, this run uses batch {batch}", None
     prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
     rows = [r for r in doc if r["kernel"].startswith(prefixes)]
     source = {"file": os.path.relpath(path, ROOT), "collected": meta.get("collected"), "library_sha16": meta.get("library_sha16"),
@@ -487,7 +489,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default=HEADLINE, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None,
-                    help="depth maps per forward per GPU (default 4: independent reference views batched like the reference's train.py "
+                    help="depth maps per forward per GPU (default 8: independent reference views batched like the reference's train.py "
                          "--batch_size; --batch 1 = the reference's eval.py loop, always measured too).  --mode train: default 1")
     ap.add_argument("--mode", default="replica", choices=["replica", "view_sharded", "train"])
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying one hipGraph")
@@ -516,7 +518,7 @@ def main():
     args = ap.parse_args()
     args.batch_given = args.batch is not None
     if args.batch is None:
-        args.batch = 4
+        args.batch = 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

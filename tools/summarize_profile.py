@@ -40,7 +40,8 @@ for r in csv.DictReader(open(os.path.join(src, "pmc_fetch", "pmc_kernel_trace.cs
     dur[k][1] += 1
 table = []
 for k in fetch:
-    if not any(s in k[0] for s in ("conv16", "deconv16", "prob_valu", "costvol", "softmax", "hypotheses", "nchw_to", "fpn_lateral")):
+    if not any(s in k[0] for s in ("conv16", "deconv16", "prob_valu", "prob_zwalk", "costvol", "softmax", "hypotheses", "nchw_to", "fpn_lateral", "fpn_tail0",
+                                   "conv0_sf", "conv0_sb", "conv_ci_sf")):
         continue
     f_kb, n = fetch[k]
     w_kb = write.get(k, (0.0, 0))[0]
@@ -49,14 +50,18 @@ for k in fetch:
     table.append({"kernel": k[0], "grid_threads": k[1], "launches": n, "avg_us_under_pmc": dur[k][0] / max(dur[k][1], 1),
                   "fetch_kb_raw": f_kb, "read_mb_corrected": 2 * f_kb / 1e3, "write_mb": w_kb / 1e3})
 table.sort(key=lambda r: -(r["read_mb_corrected"] + r["write_mb"]) * r["launches"])
-json.dump(table, open(os.path.join(out, prefix + "_pmc_traffic.json"), "w"), indent=1)
+import hashlib
+lib = os.path.join(root, "casmvsnet_pl_amd", "libcasmvs_hip.so")
+meta = {"collected": os.environ.get("PMC_DATE", "unknown"), "batch": int(os.environ.get("PMC_BATCH", "0")) or None,
+        "command": os.environ.get("PMC_CMD_NOTE", ""), "library_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.isfile(lib) else None}
+json.dump({"meta": meta, "kernels": table}, open(os.path.join(out, prefix + "_pmc_traffic.json"), "w"), indent=1)
 with open(os.path.join(out, prefix + "_pmc_traffic.md"), "w") as f:
     f.write("# HBM-side traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two separate passes)\n\n"
-            "Command: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --streams 1 --no-batch1` (batch 2, 640x512, 3 views).\n"
+            f"Command: `{meta['command']}` (batch {meta['batch']}, 640x512, 3 views), collected {meta['collected']}, library sha256[:16] {meta['library_sha16']}.\n"
             "FETCH_SIZE is doubled (gfx950 rocprofv3 tallies the 128-byte requests of 16 B/lane reads at 64 B: "
             "MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.  Both count L2 misses, i.e. include "
             "Infinity-Cache hits.  One row per (kernel, grid size) = per cascade level.\n"
-            "tools/gpu_final.sh runs these passes BEFORE the bench line of the same gpurun call and bench.py reads the newest "
+            "tools/gpu_final3.sh runs these passes BEFORE the bench line of the same gpurun call and bench.py reads the newest "
             "profiles/r*_pmc_traffic.json, so the committed bench line's roofline.traffic is this table's conv0 figure.\n\n"
             "| kernel | grid threads | launches | avg us (under PMC) | read MB | write MB |\n|---|---|---|---|---|---|\n")
     for r in table:
