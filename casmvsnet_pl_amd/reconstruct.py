@@ -2,6 +2,12 @@
 reference view of a scan (eval.py:209-241) - files -> DTUReader -> collate -> DevicePrefetcher -> CascadeMVSNet.forward -,
 then depth filtering / fusion into a coloured point cloud (eval.py:255-350, fusion.fuse_scan) and a PLY file.  Nothing
 is written between the steps: depth_0 / confidence_2 stay on the device (the reference round-trips them through PFM files).
+
+One deliberate deviation when `img_wh` differs from the files' native size: the fusion step colours its points from the image
+the depth step saw - the reader's PIL `Image.BILINEAR` resize (datasets/dtu.py:162; PIL anti-aliases on downscale) - while
+eval.py:266-268 re-reads the file with cv2 and resizes it with `cv2.resize(INTER_LINEAR)` (no anti-aliasing): point colours and
+the 8-bit `image_refined` of processed views can differ in the last bits there.  At the native size (the reference's DTU
+evaluation: 1152 x 864 files read at 1152 x 864) the two paths are identical.
 """
 import torch
 
