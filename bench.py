@@ -567,6 +567,7 @@ def main():
             for l in range(3):   # "splitf16" = every layer that has an f16 form (conv0, conv2, conv4); the other two keep conv2 / conv4 in float32
                 getattr(model, f"cost_reg_{l}").conv0_mode = mode
                 getattr(model, f"cost_reg_{l}").ci_mode = "splitf16" if mode == "splitf16" else "f32"
+            model.feature.tail_mode = "splitf16" if mode == "splitf16" else "f32"
         # replica: every rank works on its own depth maps (different seeds -> different images / cameras);
         # view_sharded: all ranks share the depth maps and split their source views
         imgs, proj, dmin, dint = config_inputs(args.config, B, seed=0 if view_sharded else rank)
@@ -584,6 +585,7 @@ def main():
             if not args.unsafe_mixed_streams:   # what the replicas run (and what the instrumented pass below should time)
                 for l in range(3):
                     getattr(model, f"cost_reg_{l}").conv0_mode = getattr(model, f"cost_reg_{l}").ci_mode = "f32"
+                model.feature.tail_mode = "f32"
             step = lambda: cf.run()[-1]
         elif use_graph:
             gf = GraphedForward(model, imgs, proj, dmin, dint)
@@ -623,7 +625,9 @@ def main():
                                                            "float32 MFMA kernel's",
                                                "f32": "float32 MFMA (v_mfma_f32_16x16x4_f32)"}[model.cost_reg_0.conv0_mode],
                           "conv2_conv4_arithmetic": "as conv0's split-f16 (conv_ci_splitf16.hip); conv4 only where its tiles are full (levels 1, 2)"
-                                                    if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA"},
+                                                    if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA",
+                          "fpn_tail_arithmetic": ("as conv0's split-f16 (fpn_fused_sf.hip)" if model.feature.tail_mode == "splitf16" else "float32 MFMA (fpn_fused.hip)")
+                                                 if model.feature.fuse_tail else "three float32 steps (lat0, upsample-add, smooth0)"},
                          median)
         line["library_sha16"] = library_sha16()
 

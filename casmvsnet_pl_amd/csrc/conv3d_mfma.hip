@@ -2136,7 +2136,7 @@ extern "C" size_t casmvs_featurenet_workspace_bytes(int N, int H, int W) {
 }
 
 namespace {
-int featurenet_run(const float *const *packed_layers, const float *fused0_packed, const float *fused0_bias9, const float *imgs,
+int featurenet_run(const float *const *packed_layers, const void *fused0_packed, int fused0_arith, const float *fused0_bias9, const float *imgs,
                    float *feat0, float *feat1, float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
                    void *workspace, int N, int H, int W, float slope, void *const *layer_events, void *stream) {
   CASMVS_REQUIRE(packed_layers && imgs && feat0 && feat1 && feat2 && workspace, "featurenet_forward: null pointer");
@@ -2144,6 +2144,7 @@ int featurenet_run(const float *const *packed_layers, const float *fused0_packed
                  "featurenet_forward: N=%d H=%d W=%d (H, W must be multiples of 4)", N, H, W);
   for (int i = 0; i < 13; ++i) CASMVS_REQUIRE(packed_layers[i], "featurenet_forward: packed_layers[%d] is null", i);
   CASMVS_REQUIRE((fused0_packed == nullptr) == (fused0_bias9 == nullptr), "featurenet_forward: fused0_packed and fused0_bias9 go together");
+  CASMVS_REQUIRE(fused0_arith == 0 || fused0_arith == 1, "featurenet_forward: fused0_arith=%d (0 float32 image, 1 split-f16 image)", fused0_arith);
   const bool fuse0 = fused0_packed && casmvs_fpn_tail0_supported(H, W) && N <= 65535;
   const size_t hw = (size_t)N * H * W;
   float *ws = (float *)workspace;
@@ -2179,7 +2180,8 @@ int featurenet_run(const float *const *packed_layers, const float *fused0_packed
   CASMVS_L(CASMVS_CONV2D_K1_UP, P[9], c1, feat2, f1, nullptr, N, 16, 32, H2, W2, 1.0f, stream);        // lat1 + up :49
   if (fuse0) {   // lat0 + up + smooth0 in one kernel (fpn_fused.hip); the `lat0` interval of layer_events times it, `smooth0` is empty
     CASMVS_EV();
-    rc = casmvs_fpn_tail0_f32(fused0_packed, fused0_bias9, c0, f1, feat0, feat0_nhwc, N, H, W, stream);   // :50-51,54
+    rc = fused0_arith == 1 ? casmvs_fpn_tail0_splitf16_f32(fused0_packed, fused0_bias9, c0, f1, feat0, feat0_nhwc, N, H, W, stream)
+                           : casmvs_fpn_tail0_f32(reinterpret_cast<const float *>(fused0_packed), fused0_bias9, c0, f1, feat0, feat0_nhwc, N, H, W, stream);   // :50-51,54
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV2D_K1_UP, P[10], c0, f1, f0, nullptr, N, 8, 32, H, W, 1.0f, stream);           // lat0 + up :50
@@ -2203,18 +2205,18 @@ extern "C" int casmvs_featurenet_forward_f32(const float *const *packed_layers, 
                                              int H, int W, float slope, void *const *layer_events,
                                              void *stream) {
   casmvs::clear_error();
-  return featurenet_run(packed_layers, nullptr, nullptr, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace, N, H, W,
+  return featurenet_run(packed_layers, nullptr, 0, nullptr, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace, N, H, W,
                         slope, layer_events, stream);
 }
 
-extern "C" int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const float *fused0_packed,
+extern "C" int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const void *fused0_packed, int fused0_arith,
                                                    const float *fused0_bias9, const float *imgs, float *feat0, float *feat1,
                                                    float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
                                                    void *workspace, int N, int H, int W, float slope,
                                                    void *const *layer_events, void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(fused0_packed && fused0_bias9, "featurenet_forward_fused: null pointer");
-  return featurenet_run(packed_layers, fused0_packed, fused0_bias9, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace,
+  return featurenet_run(packed_layers, fused0_packed, fused0_arith, fused0_bias9, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace,
                         N, H, W, slope, layer_events, stream);
 }
 

@@ -114,6 +114,8 @@ class ConcurrentForwards:
                         m.conv0_mode = "f32"
                     if hasattr(m, "ci_mode"):
                         m.ci_mode = "f32"
+                    if hasattr(m, "tail_mode"):
+                        m.tail_mode = "f32"
             st.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(st):
                 self.forwards.append(GraphedForward(replica, imgs, proj_mats, init_depth_min, depth_interval, warmup))

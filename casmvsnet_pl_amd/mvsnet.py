@@ -136,6 +136,8 @@ class FeatureNet(_PackedWeights, nn.Module):
         self._slope = 0.01
         self._fused0 = None       # (packed 40-channel 3x3 layer, bias classes) of the fused full-resolution tail
         self.fuse_tail = True     # lat0 + upsample-add + smooth0 as one kernel (False: the reference's three steps, A/B and tests)
+        self._fused0_sf = None    # the same tail as the split-f16 image
+        self.tail_mode = "splitf16"   # arithmetic of the fused tail: "splitf16" (f16 matrix cores, fpn_fused_sf.hip) or "f32"
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.last_channels_last = None
 
@@ -159,6 +161,7 @@ class FeatureNet(_PackedWeights, nn.Module):
         # the full-resolution tail lat0 + upsample-add + smooth0 as one 40-channel 3x3 layer (csrc/fpn_fused.hip)
         w40, bias9 = compose_fpn_tail(self.lat0.weight, self.lat0.bias, self.smooth0.weight, self.smooth0.bias)
         self._store_packed("_fused0", (ops.conv2d_pack(ops.CONV2D_K3, w40, None, None).to(device), bias9.to(device)))
+        self._store_packed("_fused0_sf", (ops.fpn_tail0_splitf16_pack(w40).to(device), bias9.to(device)))
         self._packed_key = key
         return self._store_packed("_packed", packed)
 
@@ -176,8 +179,12 @@ class FeatureNet(_PackedWeights, nn.Module):
         if ws is None or ws.device != x.device or ws.numel() < need:
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         events = self.timer.layer_events("feature", 14, self.LAYER_NAMES) if self.timer is not None else None
+        if self.tail_mode not in ("splitf16", "f32"):
+            raise ValueError(f"FeatureNet.tail_mode={self.tail_mode!r} (splitf16 or f32)")
+        sf = self.fuse_tail and self.tail_mode == "splitf16"
+        fused0 = (self._fused0_sf if sf else self._fused0) if self.fuse_tail else None
         feat0, feat1, feat2, cl = ops.featurenet_forward(packed, x.float(), ws, slope=self._slope, layer_events=events,
-                                                         channels_last_copies=True, fused0=self._fused0 if self.fuse_tail else None)
+                                                         channels_last_copies=True, fused0=fused0, fused0_splitf16=sf)
         # pixel-major copies of the three maps (same kernels, second store): what the cost-volume gather reads
         self.last_channels_last = {"level_0": cl[0], "level_1": cl[1], "level_2": cl[2]}
         return {"level_0": feat0, "level_1": feat1, "level_2": feat2}

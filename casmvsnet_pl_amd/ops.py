@@ -536,13 +536,45 @@ def fpn_tail0(packed40, bias9, conv0, feat1_sum, channels_last_copy=False):
     return (out, out2) if channels_last_copy else out
 
 
-def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None, channels_last_copies=False, fused0=None):
+def fpn_tail0_splitf16_pack(weight40):
+    """Host-side packing of the composed 40-channel 3x3 tail (mvsnet.compose_fpn_tail) for the split-f16 kernel
+    (casmvs_fpn_tail0_splitf16_pack): weight40 (8, 40, 3, 3) -> uint8 CPU tensor."""
+    weight40 = weight40.detach().to("cpu", torch.float32).contiguous()
+    if tuple(weight40.shape) != (8, 40, 3, 3):
+        raise ValueError(f"fpn_tail0_splitf16_pack: weight {tuple(weight40.shape)} (need (8, 40, 3, 3))")
+    lib = _lib.load()
+    packed = torch.empty(lib.casmvs_fpn_tail0_splitf16_packed_bytes(), dtype=torch.uint8)
+    rc = lib.casmvs_fpn_tail0_splitf16_pack(_ptr(weight40), ctypes.c_void_p(packed.data_ptr()))
+    _lib.check(rc, "casmvs_fpn_tail0_splitf16_pack")
+    return packed
+
+
+def fpn_tail0_splitf16(packed, bias9, conv0, feat1_sum, channels_last_copy=False):
+    """fpn_tail0 on the f16 matrix cores with float32-grade arithmetic (casmvs_fpn_tail0_splitf16_f32); packed: device uint8 image of
+    fpn_tail0_splitf16_pack."""
+    conv0, feat1_sum, bias9 = _dev(conv0, "conv0"), _dev(feat1_sum, "feat1_sum"), _dev(bias9, "bias9")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("fpn_tail0_splitf16: `packed` must be the uint8 image on the MI355X")
+    N, c, H, W = conv0.shape
+    if c != 8 or tuple(feat1_sum.shape) != (N, 32, H // 2, W // 2) or tuple(bias9.shape) != (3, 3, 8):
+        raise ValueError(f"fpn_tail0_splitf16: shapes {tuple(conv0.shape)} {tuple(feat1_sum.shape)} {tuple(bias9.shape)}")
+    out = torch.empty((N, 8, H, W), dtype=torch.float32, device=conv0.device)
+    out2 = torch.empty((N, H, W, 8), dtype=torch.float32, device=conv0.device) if channels_last_copy else None
+    with torch.cuda.device(conv0.device):
+        rc = _lib.load().casmvs_fpn_tail0_splitf16_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(bias9), _ptr(conv0), _ptr(feat1_sum), _ptr(out), _ptr(out2),
+                                                       N, H, W, _stream(conv0))
+    _lib.check(rc, "casmvs_fpn_tail0_splitf16_f32")
+    return (out, out2) if channels_last_copy else out
+
+
+def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None, channels_last_copies=False, fused0=None, fused0_splitf16=False):
     """Whole FeatureNet (mvsnet.py:40-57).  packed_layers: 13 device tensors (conv0.0 .. conv2.2,
     toplayer, lat1, lat0, smooth1, smooth0); imgs (N,3,H,W) -> feat0 (N,8,H,W), feat1 (N,16,H/2,W/2),
     feat2 (N,32,H/4,W/4).  layer_events: optional 14 recorded torch.cuda.Event.
     channels_last_copies: also return the three maps pixel-major (N,h,w,C) (written by the same
     kernels) -> (feat0, feat1, feat2, (nhwc0, nhwc1, nhwc2)).  fused0: (packed40, bias9) device tensors - the
-    full-resolution tail as one kernel (casmvs_featurenet_forward_fused_f32)."""
+    full-resolution tail as one kernel (casmvs_featurenet_forward_fused_f32); fused0_splitf16: packed40 is the uint8 image of
+    fpn_tail0_splitf16_pack (the tail on the f16 matrix cores) instead of the float32 conv2d_pack image."""
     imgs = _dev(imgs, "imgs")
     N, c, H, W = imgs.shape
     if c != 3 or len(packed_layers) != 13:
@@ -567,7 +599,8 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
         ev = (ctypes.c_void_p * 14)(*[e.cuda_event for e in layer_events])
     with torch.cuda.device(dev):
         if fused0 is not None:   # (packed 40-channel tail, bias classes): lat0 + upsample-add + smooth0 in one kernel
-            rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, _ptr(fused0[0]), _ptr(fused0[1]), _ptr(imgs), _ptr(feat0), _ptr(feat1),
+            rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
+                                                                 _ptr(imgs), _ptr(feat0), _ptr(feat1),
                                                                  _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
                                                                  ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev, _stream(imgs))
         else:

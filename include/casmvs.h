@@ -282,8 +282,15 @@ int casmvs_fpn_tail0_f32(const float *packed40, const float *bias9, const float 
 
 /* casmvs_featurenet_forward_f32 with the full-resolution tail (lat0, upsample-add, smooth0) run by casmvs_fpn_tail0_f32
  * (packed_layers[10] / [12] are then unused but must still be non-NULL).  layer_events: the `lat0` interval times the fused
- * kernel, the `smooth0` interval is empty. */
-int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const float *fused0_packed,
+ * kernel, the `smooth0` interval is empty.  fused0_arith: 0 = fused0_packed is the float32 image (casmvs_conv2d_pack_f32 of the
+ * composed 40-channel layer, casmvs_fpn_tail0_f32), 1 = the split-f16 image (casmvs_fpn_tail0_splitf16_pack,
+ * casmvs_fpn_tail0_splitf16_f32: the same kernel on the f16 matrix cores in the arithmetic of casmvs_conv0_splitf16_forward_f32).
+ * casmvs_fpn_tail0_splitf16_pack: HOST, weight40 (8, 40, 3, 3) float32 finite -> casmvs_fpn_tail0_splitf16_packed_bytes() bytes. */
+size_t casmvs_fpn_tail0_splitf16_packed_bytes(void);
+int casmvs_fpn_tail0_splitf16_pack(const float *weight40, void *packed);
+int casmvs_fpn_tail0_splitf16_f32(const void *packed, const float *bias9, const float *conv0, const float *feat1_sum,
+                                  float *feat0, float *feat0_nhwc, int N, int H, int W, void *stream);
+int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const void *fused0_packed, int fused0_arith,
                                         const float *fused0_bias9, const float *imgs, float *feat0, float *feat1,
                                         float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
                                         void *workspace, int N, int H, int W, float slope,

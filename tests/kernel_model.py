@@ -504,6 +504,56 @@ def emulate_fpn_tail0(packed40, bias9, c0, f1):
     return out
 
 
+def emulate_fpn_tail0_splitf16(packed, bias9, c0, f1, tile=(16, 32)):
+    """Data flow of fpn_tail0_sf_kernel in float64: the 40-channel input [c0 | up(f1)] (float32: the upsample by torch's ATen kernel,
+    whose rule the kernel restates) is staged per 16 x 32 output tile and chunk of 8 channels as the halo tile (y0-1..y0+16,
+    x0-4..x0+35; zero outside), scaled to [2^14, 2^15), split into two float16 slices and multiplied (aa, ab, ba) with the packer's
+    lane images [chunk][ky][slice][lane][8 f16]; chunks unscaled and summed; then 2^-kw and the nine border bias classes.
+    c0 (8, H, W), f1 (32, H/2, W/2) numpy float32 -> (8, H, W)."""
+    import numpy as np
+    import torch
+    raw = np.asarray(packed, dtype=np.uint8)
+    body = 5 * 3 * 2 * 64 * 8 * 2
+    img = raw[:body].view(np.float16).reshape(5, 3, 2, 64, 8).astype(np.float64)
+    unscale = float(raw[body:body + 4].view(np.float32)[0])
+    _, H, W = c0.shape
+    up = torch.nn.functional.interpolate(torch.from_numpy(np.ascontiguousarray(f1))[None], scale_factor=2, mode="bilinear", align_corners=True)[0].numpy()
+    x40 = np.concatenate([c0.astype(np.float32), up.astype(np.float32)], 0)
+    TY, TX = tile
+    py, px = ((H + TY - 1) // TY) * TY - H, ((W + TX - 1) // TX) * TX - W
+    xp = np.pad(x40, ((0, 0), (1, 1 + py), (4, 4 + px)))
+    out = np.zeros((8, H, W))
+    for y0 in range(0, H, TY):
+        for x0 in range(0, W, TX):
+            acc = np.zeros((8, TY, TX))
+            for ch in range(5):
+                halo = xp[ch * 8:ch * 8 + 8, y0:y0 + TY + 2, x0:x0 + TX + 8]
+                e = max(int(np.abs(halo).max().view(np.uint32)) >> 23, 15)
+                mult, inv = np.float32(2.0) ** (141 - e), 2.0 ** (e - 141)
+                xs = halo * mult
+                xa = xs.astype(np.float16)
+                xb = (xs - xa.astype(np.float32)).astype(np.float16)
+                sl = [xa.astype(np.float64), xb.astype(np.float64)]
+                part = np.zeros((8, TY, TX))
+                for ky in range(3):
+                    for (sa, sb) in ((0, 0), (0, 1), (1, 0)):
+                        A = img[ch, ky, sa].reshape(4, 16, 8)                               # [u][i][ci]
+                        for u in range(4):
+                            for s in range(2):
+                                wrow = A[u, s::2, :]                                        # (co, ci); zero where u - s is not a tap
+                                if not wrow.any():
+                                    continue
+                                src = sl[sb][:, ky:ky + TY, u + 3:u + 3 + TX:2]             # outputs x0 + 2 j + s read halo column 2 j + u + 3
+                                part[:, :, s::2] += np.einsum("oc,chw->ohw", wrow, src)
+                acc += part * inv
+            dy, dx = min(TY, H - y0), min(TX, W - x0)
+            out[:, y0:y0 + dy, x0:x0 + dx] = acc[:, :dy, :dx] * unscale
+    b9 = np.asarray(bias9, dtype=np.float64)
+    rows = np.array([0 if y == 0 else (2 if y == H - 1 else 1) for y in range(H)])
+    cols = np.array([0 if x == 0 else (2 if x == W - 1 else 1) for x in range(W)])
+    return out + b9[rows][:, cols].transpose(2, 0, 1)
+
+
 # ---- csrc/conv0_splitbf16.hip: conv0 on the bf16 matrix cores, float32 operands as three exact bf16 slices ---------------
 def bf16_split3(x):
     """x float32 ndarray -> three float32 arrays (each exactly a bf16 value) with hi + mid + lo == x exactly (truncation:

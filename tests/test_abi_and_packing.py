@@ -211,6 +211,26 @@ def test_fpn_fused_tail_model_equals_lat_upsample_smooth(H, W):
     assert float(np.abs(got - ref.numpy()).max()) < 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("H,W,amp", [(8, 64, 1.0), (20, 36, 1.0), (34, 72, 1e-4), (16, 32, 3e4)])
+def test_fpn_fused_tail_splitf16_model(H, W, amp):
+    """csrc/fpn_fused_sf.hip: the composed 40-channel tail as split-f16 lane images (casmvs_fpn_tail0_splitf16_pack), the per-(tile,
+    chunk) scaling + two-slice split of the staged [conv0 | up(feat1')] tile and the nine bias classes reproduce
+    smooth0(lat0(x) + interpolate(y)) to float32 grade (<= 4e-6 of the range against float64), ragged tiles, any magnitude."""
+    import numpy as np
+    from casmvsnet_pl_amd.mvsnet import compose_fpn_tail
+    g = torch.Generator().manual_seed(H + W)
+    lw, lb = torch.randn(32, 8, 1, 1, generator=g) * 0.3, torch.randn(32, generator=g) * amp
+    sw, sb = torch.randn(8, 32, 3, 3, generator=g) * 0.2, torch.randn(8, generator=g) * amp
+    x, y = torch.randn(1, 8, H, W, generator=g) * amp, torch.randn(1, 32, H // 2, W // 2, generator=g) * amp
+    ref = F.conv2d(F.conv2d(x.double(), lw.double(), lb.double()) + F.interpolate(y.double(), scale_factor=2, mode="bilinear", align_corners=True),
+                   sw.double(), sb.double(), padding=1)[0]
+    w40, bias9 = compose_fpn_tail(lw, lb, sw, sb)
+    packed = ops.fpn_tail0_splitf16_pack(w40)
+    assert packed.numel() == 5 * 3 * 2 * 64 * 16 + 16
+    got = KM.emulate_fpn_tail0_splitf16(packed.numpy(), bias9.numpy(), x[0].numpy(), y[0].numpy())
+    assert float(np.abs(got - ref.numpy()).max()) < 4e-6 * float(ref.abs().max())   # measured <= 1.7e-6 (the float32 model of the float32 kernel: bound 2e-5)
+
+
 @pytest.mark.parametrize("cin,terms", [(8, 6), (16, 6), (32, 6), (8, 9), (8, 3)])
 def test_conv0_splitbf16_packing_and_partial_products(cin, terms):
     """csrc/conv0_splitbf16.hip: the C packer's lane images (three exact bf16 slices of every weight, rows = (co, x phase),

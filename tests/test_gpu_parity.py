@@ -503,6 +503,29 @@ def test_fpn_fused_tail_matches_lat_upsample_smooth(dev, report, N, H, W):
     assert torch.equal(got_cl, got.permute(0, 2, 3, 1).contiguous())
 
 
+@pytest.mark.parametrize("N,H,W,amp", [(1, 8, 64, 1.0), (2, 36, 72, 1.0), (1, 64, 196, 1e-4), (3, 128, 160, 1.0), (1, 18, 32, 3e4)])
+def test_fpn_fused_tail_splitf16_matches_lat_upsample_smooth(dev, report, N, H, W, amp):
+    """csrc/fpn_fused_sf.hip: the fused tail on the f16 matrix cores (two scaled float16 slices per operand, float32 accumulation) vs
+    torch CPU float64 at the float32 kernel's bound and no worse than a few times that kernel's own error; both outputs."""
+    from casmvsnet_pl_amd.mvsnet import compose_fpn_tail
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    lw, lb = torch.randn(32, 8, 1, 1, generator=g) * 0.3, torch.randn(32, generator=g) * amp
+    sw, sb = torch.randn(8, 32, 3, 3, generator=g) * 0.2, torch.randn(8, generator=g) * amp
+    x, y = torch.randn(N, 8, H, W, generator=g) * amp, torch.randn(N, 32, H // 2, W // 2, generator=g) * amp
+    want = F.conv2d(F.conv2d(x.double(), lw.double(), lb.double()) + F.interpolate(y.double(), scale_factor=2, mode="bilinear", align_corners=True),
+                    sw.double(), sb.double(), padding=1)
+    w40, bias9 = compose_fpn_tail(lw, lb, sw, sb)
+    psf = ops.fpn_tail0_splitf16_pack(w40).to(dev)
+    got, got_cl = ops.fpn_tail0_splitf16(psf, bias9.to(dev), x.to(dev), y.to(dev), channels_last_copy=True)
+    f32 = ops.fpn_tail0(ops.conv2d_pack(ops.CONV2D_K3, w40, None, None).to(dev), bias9.to(dev), x.to(dev), y.to(dev))
+    err, ef = scaled_err(got, want), scaled_err(f32, want)
+    report("fpn_tail0_splitf16", shape=[N, H, W], amp=amp, scaled_err=err, err_f32_kernel=ef)
+    assert torch.isfinite(got).all()
+    assert err < 1.2e-5 and err < 4 * max(ef, 2e-7)
+    assert torch.equal(got_cl, got.permute(0, 2, 3, 1).contiguous())
+
+
 def test_convbnrelu3d_module_runs_one_hip_layer(dev):
     """modules.py:21-31 called on its own (it was a raise stub)."""
     from casmvsnet_pl_amd import ABN

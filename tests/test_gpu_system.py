@@ -131,9 +131,11 @@ def test_concurrent_forwards_equal_single_stream(dev):
     cf = ConcurrentForwards(model, ins[0][0].to(dev), ins[0][1].to(dev), dmin, dint, n_streams=2)
     for gf in cf.forwards:
         assert all(getattr(gf.model, f"cost_reg_{l}").conv0_mode == "f32" and getattr(gf.model, f"cost_reg_{l}").ci_mode == "f32" for l in range(3))
+        assert gf.model.feature.tail_mode == "f32"
     assert model.cost_reg_0.conv0_mode != "f32"   # the source model keeps its own (single-stream) arithmetic
     for l in range(3):
         getattr(model, f"cost_reg_{l}").conv0_mode = getattr(model, f"cost_reg_{l}").ci_mode = "f32"
+    model.feature.tail_mode = "f32"
     want = [{k: v.clone() for k, v in model(i[0].to(dev), i[1].to(dev), dmin, dint).items()} for i in ins]
     for _ in range(20):
         outs = cf.run([(i[0].to(dev), i[1].to(dev)) for i in ins])
