@@ -29,6 +29,7 @@
 
 #include "buffer_ops.h"
 #include "common.h"
+#include "split_f16.h"
 
 #ifndef CASMVS_CI_LOAD_AUX
 #define CASMVS_CI_LOAD_AUX 0    // cache-policy bits of the activation loads (debug builds: 17 = sc0 | sc1, system-coherent)
@@ -65,18 +66,7 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// 8 channels of one voxel, scaled by the tile's power of two -> the two 16-byte float16 vectors (as conv0_splitf16.hip)
-__device__ __forceinline__ void split8_f16(const float (&x)[8], float mult, u32x4 (&o)[2]) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const float s0 = x[2 * p] * mult, s1 = x[2 * p + 1] * mult;         // exact
-    const f16x2 a = {(_Float16)s0, (_Float16)s1};                        // round to nearest even
-    const float r0 = s0 - (float)a[0], r1 = s1 - (float)a[1];           // exact
-    const f16x2 b = {(_Float16)r0, (_Float16)r1};
-    o[0][p] = __builtin_bit_cast(unsigned, a);
-    o[1][p] = __builtin_bit_cast(unsigned, b);
-  }
-}
+__device__ __forceinline__ void split8_f16(const float (&x)[8], float mult, u32x4 (&o)[2]) { casmvs::split8_f16(x, mult, o); }   // split_f16.h
 
 __device__ __forceinline__ unsigned wave_max_bits_ci(unsigned v) {
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]

@@ -21,6 +21,7 @@
 
 #include "buffer_ops.h"
 #include "common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -47,17 +48,7 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ void split8(const float (&x)[8], float mult, u32x4 (&o)[2]) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const float s0 = x[2 * p] * mult, s1 = x[2 * p + 1] * mult;         // exact
-    const f16x2 a = {(_Float16)s0, (_Float16)s1};                        // round to nearest even
-    const float r0 = s0 - (float)a[0], r1 = s1 - (float)a[1];           // exact
-    const f16x2 b = {(_Float16)r0, (_Float16)r1};
-    o[0][p] = __builtin_bit_cast(unsigned, a);
-    o[1][p] = __builtin_bit_cast(unsigned, b);
-  }
-}
+__device__ __forceinline__ void split8(const float (&x)[8], float mult, u32x4 (&o)[2]) { casmvs::split8_f16(x, mult, o); }   // split_f16.h
 
 __device__ __forceinline__ unsigned wave_max_bits_fs(unsigned v) {
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
@@ -171,15 +162,24 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
     for (int ch = 0; ch < NCH; ++ch) {
       // ---- interpolate (chunks 1..4), find the staged tile's largest magnitude ----
       float V[8][4];
+      if (ch == 0) {   // conv0's channels as they are
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          // ATen: h0lambda * (w0lambda * v00 + w1lambda * v01) + h1lambda * (w0lambda * v10 + w1lambda * v11)
-          const float top = fmaf(T[j][3], ra[c][3], fmaf(T[j][2], ra[c][2], fmaf(T[j][1], ra[c][1], T[j][0] * ra[c][0])));
-          const float bot = fmaf(T[j][3], rb[c][3], fmaf(T[j][2], rb[c][2], fmaf(T[j][1], rb[c][1], T[j][0] * rb[c][0])));
-          V[c][j] = ch == 0 ? ra[c][j] : ly0 * top + ly1 * bot;
+          for (int j = 0; j < 4; ++j) V[c][j] = ra[c][j];
+      } else {
+        // bilinear 2x, align_corners: the vertical blend of the two source rows first (4 window columns), then the horizontal tent
+        // (two non-zero weights per pixel; the exact zeros of T add nothing).  ATen blends horizontally first: the two orders differ
+        // by float32 roundings of the interpolated value - below this kernel's own 2^-22 slice error.
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float w[4];
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm) w[mm] = fmaf(ly1, rb[c][mm], ly0 * ra[c][mm]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) V[c][j] = fmaf(T[j][3], w[3], fmaf(T[j][2], w[2], fmaf(T[j][1], w[1], T[j][0] * w[0])));
         }
+      }
       float m = 0.0f;
 #pragma unroll
       for (int c = 0; c < 8; ++c)

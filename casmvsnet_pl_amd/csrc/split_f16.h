@@ -1,0 +1,37 @@
+// The two-slice float16 split shared by the split-f16 kernels (conv0_splitf16.hip, conv_ci_splitf16.hip, fpn_fused_sf.hip):
+// x' = x * mult (mult an exact power of two), a = f16(x') (round to nearest even), b = f16(x' - a) with x' - a exact.
+// Six VALU operations per PAIR of values: two multiplies, v_cvt_pk_f16_f32 for (a0, a1), two v_fma_mix_f32 that read a's halves as
+// float16 sources (r = x * mult - a, exact: x * mult is exact and the difference is representable), v_cvt_pk_f16_f32 for (b0, b1).
+// (The compiler's own code for the C++ form re-derived each a as a second, scalar conversion and converted it back: 10 per pair.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace casmvs {
+
+typedef _Float16 split_f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned split_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, float mult, unsigned &a_bits, unsigned &b_bits) {
+  const float s0 = x0 * mult, s1 = x1 * mult;                     // exact
+  const split_f16x2 a = {(_Float16)s0, (_Float16)s1};             // round to nearest even
+  const unsigned ab = __builtin_bit_cast(unsigned, a);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(mult), "v"(ab));                 // x0 * mult - a.lo
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(mult), "v"(ab));   // x1 * mult - a.hi
+  const split_f16x2 b = {(_Float16)r0, (_Float16)r1};
+  a_bits = ab;
+  b_bits = __builtin_bit_cast(unsigned, b);
+}
+
+// 8 channels of one voxel -> the two 16-byte float16 vectors (slice a, slice b)
+__device__ __forceinline__ void split8_f16(const float (&x)[8], float mult, split_u32x4 (&o)[2]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned a, b;
+    split_pair_f16(x[2 * p], x[2 * p + 1], mult, a, b);
+    o[0][p] = a;
+    o[1][p] = b;
+  }
+}
+
+}  // namespace casmvs
