@@ -41,7 +41,10 @@ struct FsCfg {
   static constexpr int WUNITS = NCH * 3 * 2 * 64;                   // [chunk][ky][slice][lane]: 1920 16-byte units
   static constexpr int NWL = (WUNITS + THREADS - 1) / THREADS;      // 8
   static constexpr size_t ACT_BYTES = (size_t)2 * NV * 16, W_BYTES = (size_t)WUNITS * 16;
-  static constexpr size_t LDS_BYTES = ACT_BYTES + W_BYTES + 16;     // 54 352
+#ifndef CASMVS_FS_LDS_PAD
+#define CASMVS_FS_LDS_PAD 0   // debug builds: extra dynamic LDS per workgroup (e.g. 50000: one workgroup per CU)
+#endif
+  static constexpr size_t LDS_BYTES = ACT_BYTES + W_BYTES + 16 + CASMVS_FS_LDS_PAD;     // 54 352
 };
 
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
@@ -95,10 +98,14 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
   // lane's B slot of staged row 0 of this wave's first output row (ky = 0): (4 wave) * ROW + slot(2 j + u + 3)
   const int vbase = 4 * wave * Cfg::ROW + Cfg::slot(2 * jcol + u + 3);
 
-  // staging plan of a tile: item e = tid -> (staged row, 4-x group)
+  // staging plan of a tile: item e = tid -> (staged row, 4-x group).  Two parts: the integer part (what the chunk-0 prefetch of the
+  // next tile needs) runs in the last chunk of the current tile; the floating-point part (the interpolation constants of chunks
+  // 1..4) runs at the top of the tile, when this wave has no matrix instruction in flight.  (With the conversions and compares of
+  // the tent matrix issued between the wave's own f16 MFMAs, staged values of lanes 48-63 came out wrong in ~1 of 500 tiles,
+  // only with two workgroups per CU - tools/debug/fpn_sf_check.py)
   int voff_d, voff_u0, voff_u1, vox, vxor;
   float ly0, ly1, T[4][4];
-  auto plan = [&](int ty0, int tx0) {
+  auto plan_int = [&](int ty0, int tx0) {
     const int e = tid;
     const int iy = e / (IX / 4), g = e - iy * (IX / 4);
     const int gy = ty0 - 1 + iy, gx = tx0 - 4 + 4 * g;
@@ -106,6 +113,12 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
     vox = e < Cfg::ITEMS ? iy * Cfg::ROW + 4 * g : -1;
     vxor = ((g >> 1) & 1) << 1;
     voff_d = ok ? (gy * W + gx) * 4 : kOOB;
+  };
+  auto plan_fp = [&](int ty0, int tx0) {
+    const int e = tid;
+    const int iy = e / (IX / 4), g = e - iy * (IX / 4);
+    const int gy = ty0 - 1 + iy, gx = tx0 - 4 + 4 * g;
+    const bool ok = e < Cfg::ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
     // ATen upsample_bilinear2d, align_corners: src = dst * scale; i0 = (int)src; i1 = i0 + (i0 < in - 1); l1 = src - i0
     const float fy = sy * (float)(ok ? gy : 0);
     const int y0 = (int)fy, y1 = y0 + (y0 < hc - 1 ? 1 : 0);
@@ -151,18 +164,23 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
   };
   int item = blockIdx.x, n, ty0, tx0;
   decode(item, n, ty0, tx0);
-  plan(ty0, tx0);
+  plan_int(ty0, tx0);
   prefetch(n, 0, true);
   for (;;) {
     const int next_item = item + gridDim.x;
     const bool have_next = next_item < total;
     int nn = n, nty0 = ty0, ntx0 = tx0;
     if (have_next) decode(next_item, nn, nty0, ntx0);
+    plan_fp(ty0, tx0);
+    asm volatile("" ::: "memory");
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       // ---- interpolate (chunks 1..4), find the staged tile's largest magnitude ----
       float V[8][4];
-      if (ch == 0) {   // conv0's channels as they are
+#ifndef CASMVS_FS_DEBUG
+#define CASMVS_FS_DEBUG 0   // debug builds (WRONG results): 1 = no interpolation (every chunk staged like chunk 0), 2 = the next tile's plan from the
+#endif                      // first tile's (no per-tile plan arithmetic), 4 = no DPP reduction (every tile scaled by 2^0)
+      if (ch == 0 || (CASMVS_FS_DEBUG & 1)) {   // conv0's channels as they are
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
       for (int c = 0; c < 8; ++c)
 #pragma unroll
         for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(V[c][j]));
-      const unsigned wm = wave_max_bits_fs(__builtin_bit_cast(unsigned, m));
+      const unsigned wm = (CASMVS_FS_DEBUG & 4) ? 0x47000000u : wave_max_bits_fs(__builtin_bit_cast(unsigned, m));
       if (lane == 0) wmax[wave] = wm;
       __syncthreads();   // every wave is done with the previous chunk's LDS; the four maxima (and, first time, the lane images) are visible
       const u32x4 w4 = *reinterpret_cast<const u32x4 *>(wmax);
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
       if (ch + 1 < NCH) {
         prefetch(n, ch + 1, true);
       } else {
-        plan(nty0, ntx0);
+        if (!(CASMVS_FS_DEBUG & 2)) plan_int(nty0, ntx0);
         prefetch(nn, 0, have_next);
       }
       // ---- matrix phase: the wave's six staged rows read once, 3 ky x 4 output rows x 3 partial products ----

@@ -16,8 +16,13 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, float mult, u
   const split_f16x2 a = {(_Float16)s0, (_Float16)s1};             // round to nearest even
   const unsigned ab = __builtin_bit_cast(unsigned, a);
   float r0, r1;
+#ifdef CASMVS_SPLIT_NOASM   // debug builds: the plain C++ form (10 operations per pair)
+  r0 = s0 - (float)a[0];
+  r1 = s1 - (float)a[1];
+#else
   asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "v"(mult), "v"(ab));                 // x0 * mult - a.lo
   asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "v"(mult), "v"(ab));   // x1 * mult - a.hi
+#endif
   const split_f16x2 b = {(_Float16)r0, (_Float16)r1};
   a_bits = ab;
   b_bits = __builtin_bit_cast(unsigned, b);

@@ -526,6 +526,38 @@ def test_fpn_fused_tail_splitf16_matches_lat_upsample_smooth(dev, report, N, H, 
     assert torch.equal(got_cl, got.permute(0, 2, 3, 1).contiguous())
 
 
+def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
+    """Every launch of the f16-matrix-core kernels reproduces the first launch's bits at sizes that keep two workgroups per CU busy
+    (thousands of tiles).  Guards a hazard found in round 3: floating-point VALU work issued between a wave's own f16 MFMAs
+    (the FPN tail's per-tile interpolation constants) came out wrong in lanes 48-63 in ~1 of 500 tiles - only under full occupancy,
+    so the small parity cases above could not see it."""
+    from casmvsnet_pl_amd.mvsnet import compose_fpn_tail
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    cases = []
+    x0 = torch.randn(2, 16, 32, 128, 160, generator=g).to(dev)
+    w0 = torch.randn(8, 16, 3, 3, 3, generator=g) * 0.1
+    p0 = ops.conv0_splitf16_pack(w0).to(dev)
+    pb = ops.conv0_splitbf16_pack(w0).to(dev)
+    cases.append(("conv0_sf", lambda: ops.conv0_splitf16_forward(p0, x0)))
+    cases.append(("conv0_sb", lambda: ops.conv0_splitbf16_forward(pb, x0)))
+    xc = torch.randn(2, 16, 16, 128, 160, generator=g).to(dev)
+    pc = ops.conv_ci_splitf16_pack(torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1).to(dev)
+    cases.append(("conv_ci_sf", lambda: ops.conv_ci_splitf16_forward(pc, xc, 16)))
+    lw, lb = torch.randn(32, 8, 1, 1, generator=g) * 0.3, torch.randn(32, generator=g)
+    sw, sb = torch.randn(8, 32, 3, 3, generator=g) * 0.2, torch.randn(8, generator=g)
+    w40, bias9 = compose_fpn_tail(lw, lb, sw, sb)
+    pf, b9 = ops.fpn_tail0_splitf16_pack(w40).to(dev), bias9.to(dev)
+    xf, yf = torch.randn(6, 8, 512, 640, generator=g).to(dev), torch.randn(6, 32, 256, 320, generator=g).to(dev)
+    cases.append(("fpn_tail0_sf", lambda: ops.fpn_tail0_splitf16(pf, b9, xf, yf)))
+    bad = {}
+    for name, fn in cases:
+        ref = fn()
+        bad[name] = sum(0 if torch.equal(fn(), ref) else 1 for _ in range(15))
+    report("split_f16_bit_stability", launches=15, differing=bad)
+    assert not any(bad.values()), bad
+
+
 def test_convbnrelu3d_module_runs_one_hip_layer(dev):
     """modules.py:21-31 called on its own (it was a raise stub)."""
     from casmvsnet_pl_amd import ABN
