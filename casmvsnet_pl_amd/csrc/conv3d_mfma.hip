@@ -2136,7 +2136,8 @@ extern "C" size_t casmvs_featurenet_workspace_bytes(int N, int H, int W) {
 }
 
 namespace {
-int featurenet_run(const float *const *packed_layers, const void *fused0_packed, int fused0_arith, const float *fused0_bias9, const float *imgs,
+int featurenet_run(const float *const *packed_layers, const void *fused0_packed, int fused0_arith, const float *fused0_bias9, const void *const *ci_layers,
+                   const float *imgs,
                    float *feat0, float *feat1, float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
                    void *workspace, int N, int H, int W, float slope, void *const *layer_events, void *stream) {
   CASMVS_REQUIRE(packed_layers && imgs && feat0 && feat1 && feat2 && workspace, "featurenet_forward: null pointer");
@@ -2171,11 +2172,39 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
   CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, nullptr, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
   CASMVS_L(CASMVS_CONV2D_K3, P[1], a0, nullptr, c0, nullptr, N, 8, 8, H, W, slope, stream);            // conv0.1  :15
   CASMVS_L(CASMVS_CONV2D_K5S2, P[2], c0, nullptr, a1, nullptr, N, 8, 16, H, W, slope, stream);         // conv1.0  :18
-  CASMVS_L(CASMVS_CONV2D_K3, P[3], a1, nullptr, b1, nullptr, N, 16, 16, H2, W2, slope, stream);        // conv1.1  :19
-  CASMVS_L(CASMVS_CONV2D_K3, P[4], b1, nullptr, c1, nullptr, N, 16, 16, H2, W2, slope, stream);        // conv1.2  :20
+  if (ci_layers && ci_layers[0] && casmvs_conv2d_ci_splitf16_supported(16, W2)) {   // conv1.1 on the f16 matrix cores (conv2d_ci_splitf16.hip)
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[0], a1, b1, N, 16, H2, W2, slope, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K3, P[3], a1, nullptr, b1, nullptr, N, 16, 16, H2, W2, slope, stream);        // conv1.1  :19
+  }
+  if (ci_layers && ci_layers[1] && casmvs_conv2d_ci_splitf16_supported(16, W2)) {   // conv1.2 on the f16 matrix cores (conv2d_ci_splitf16.hip)
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[1], b1, c1, N, 16, H2, W2, slope, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K3, P[4], b1, nullptr, c1, nullptr, N, 16, 16, H2, W2, slope, stream);        // conv1.2  :20
+  }
   CASMVS_L(CASMVS_CONV2D_K5S2, P[5], c1, nullptr, a2, nullptr, N, 16, 32, H2, W2, slope, stream);      // conv2.0  :23
-  CASMVS_L(CASMVS_CONV2D_K3, P[6], a2, nullptr, b2, nullptr, N, 32, 32, H4, W4, slope, stream);        // conv2.1  :24
-  CASMVS_L(CASMVS_CONV2D_K3, P[7], b2, nullptr, c2, nullptr, N, 32, 32, H4, W4, slope, stream);        // conv2.2  :25
+  if (ci_layers && ci_layers[2] && casmvs_conv2d_ci_splitf16_supported(32, W4)) {   // conv2.1 on the f16 matrix cores (conv2d_ci_splitf16.hip)
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[2], a2, b2, N, 32, H4, W4, slope, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K3, P[6], a2, nullptr, b2, nullptr, N, 32, 32, H4, W4, slope, stream);        // conv2.1  :24
+  }
+  if (ci_layers && ci_layers[3] && casmvs_conv2d_ci_splitf16_supported(32, W4)) {   // conv2.2 on the f16 matrix cores (conv2d_ci_splitf16.hip)
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[3], b2, c2, N, 32, H4, W4, slope, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K3, P[7], b2, nullptr, c2, nullptr, N, 32, 32, H4, W4, slope, stream);        // conv2.2  :25
+  }
   CASMVS_L(CASMVS_CONV2D_K1, P[8], c2, nullptr, feat2, feat2_nhwc, N, 32, 32, H4, W4, 1.0f, stream);      // toplayer :48
   CASMVS_L(CASMVS_CONV2D_K1_UP, P[9], c1, feat2, f1, nullptr, N, 16, 32, H2, W2, 1.0f, stream);        // lat1 + up :49
   if (fuse0) {   // lat0 + up + smooth0 in one kernel (fpn_fused.hip); the `lat0` interval of layer_events times it, `smooth0` is empty
@@ -2205,18 +2234,18 @@ extern "C" int casmvs_featurenet_forward_f32(const float *const *packed_layers, 
                                              int H, int W, float slope, void *const *layer_events,
                                              void *stream) {
   casmvs::clear_error();
-  return featurenet_run(packed_layers, nullptr, 0, nullptr, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace, N, H, W,
+  return featurenet_run(packed_layers, nullptr, 0, nullptr, nullptr, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace, N, H, W,
                         slope, layer_events, stream);
 }
 
 extern "C" int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const void *fused0_packed, int fused0_arith,
-                                                   const float *fused0_bias9, const float *imgs, float *feat0, float *feat1,
+                                                   const float *fused0_bias9, const void *const *ci_layers, const float *imgs, float *feat0, float *feat1,
                                                    float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
                                                    void *workspace, int N, int H, int W, float slope,
                                                    void *const *layer_events, void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(fused0_packed && fused0_bias9, "featurenet_forward_fused: null pointer");
-  return featurenet_run(packed_layers, fused0_packed, fused0_arith, fused0_bias9, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace,
+  return featurenet_run(packed_layers, fused0_packed, fused0_arith, fused0_bias9, ci_layers, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace,
                         N, H, W, slope, layer_events, stream);
 }
 

@@ -138,6 +138,7 @@ class FeatureNet(_PackedWeights, nn.Module):
         self.fuse_tail = True     # lat0 + upsample-add + smooth0 as one kernel (False: the reference's three steps, A/B and tests)
         self._fused0_sf = None    # the same tail as the split-f16 image
         self.tail_mode = "splitf16"   # arithmetic of the fused tail: "splitf16" (f16 matrix cores, fpn_fused_sf.hip) or "f32"
+        self._ci2d = None         # split-f16 images of conv1.1, conv1.2, conv2.1, conv2.2 (conv2d_ci_splitf16.hip; follow tail_mode)
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.last_channels_last = None
 
@@ -162,6 +163,12 @@ class FeatureNet(_PackedWeights, nn.Module):
         w40, bias9 = compose_fpn_tail(self.lat0.weight, self.lat0.bias, self.smooth0.weight, self.smooth0.bias)
         self._store_packed("_fused0", (ops.conv2d_pack(ops.CONV2D_K3, w40, None, None).to(device), bias9.to(device)))
         self._store_packed("_fused0_sf", (ops.fpn_tail0_splitf16_pack(w40).to(device), bias9.to(device)))
+        ci = []
+        for name in ("conv1.1", "conv1.2", "conv2.1", "conv2.2"):
+            m = self.get_submodule(name)
+            sc, sh, _ = _fold_norm(f"FeatureNet.{name}", m.bn)
+            ci.append(ops.conv2d_ci_splitf16_pack(m.conv.weight, sc, sh).to(device))
+        self._store_packed("_ci2d", ci)
         self._packed_key = key
         return self._store_packed("_packed", packed)
 
@@ -184,7 +191,7 @@ class FeatureNet(_PackedWeights, nn.Module):
         sf = self.fuse_tail and self.tail_mode == "splitf16"
         fused0 = (self._fused0_sf if sf else self._fused0) if self.fuse_tail else None
         feat0, feat1, feat2, cl = ops.featurenet_forward(packed, x.float(), ws, slope=self._slope, layer_events=events,
-                                                         channels_last_copies=True, fused0=fused0, fused0_splitf16=sf)
+                                                         channels_last_copies=True, fused0=fused0, fused0_splitf16=sf, ci_layers=self._ci2d if sf else None)
         # pixel-major copies of the three maps (same kernels, second store): what the cost-volume gather reads
         self.last_channels_last = {"level_0": cl[0], "level_1": cl[1], "level_2": cl[2]}
         return {"level_0": feat0, "level_1": feat1, "level_2": feat2}

@@ -536,6 +536,36 @@ def fpn_tail0(packed40, bias9, conv0, feat1_sum, channels_last_copy=False):
     return (out, out2) if channels_last_copy else out
 
 
+def conv2d_ci_splitf16_pack(weight, scale=None, shift=None):
+    """Host-side packing of a 3x3 stride-1 equal-channel FeatureNet layer (16 -> 16 or 32 -> 32) for the split-f16 kernel
+    (casmvs_conv2d_ci_splitf16_pack): weight (c, c, 3, 3) -> uint8 CPU tensor."""
+    weight = weight.detach().to("cpu", torch.float32).contiguous()
+    c = weight.shape[0]
+    lib = _lib.load()
+    n = lib.casmvs_conv2d_ci_splitf16_packed_bytes(c)
+    if tuple(weight.shape) != (c, c, 3, 3) or n == 0:
+        raise ValueError(f"conv2d_ci_splitf16_pack: weight {tuple(weight.shape)} (need (16, 16, 3, 3) or (32, 32, 3, 3))")
+    packed = torch.empty(n, dtype=torch.uint8)
+    sc = None if scale is None else scale.detach().to("cpu", torch.float32).contiguous()
+    sh = None if shift is None else shift.detach().to("cpu", torch.float32).contiguous()
+    rc = lib.casmvs_conv2d_ci_splitf16_pack(c, _ptr(weight), _ptr(sc), _ptr(sh), ctypes.c_void_p(packed.data_ptr()))
+    _lib.check(rc, "casmvs_conv2d_ci_splitf16_pack")
+    return packed
+
+
+def conv2d_ci_splitf16_forward(packed, x, slope=0.01):
+    """conv1.1 / conv1.2 / conv2.1 / conv2.2 of FeatureNet on the f16 matrix cores (casmvs_conv2d_ci_splitf16_forward_f32): x (N,c,H,W) -> same."""
+    x = _dev(x, "x")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("conv2d_ci_splitf16_forward: `packed` must be the uint8 image on the MI355X")
+    N, c, H, W = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_conv2d_ci_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), N, c, H, W, float(slope), _stream(x))
+    _lib.check(rc, "casmvs_conv2d_ci_splitf16_forward_f32")
+    return out
+
+
 def fpn_tail0_splitf16_pack(weight40):
     """Host-side packing of the composed 40-channel 3x3 tail (mvsnet.compose_fpn_tail) for the split-f16 kernel
     (casmvs_fpn_tail0_splitf16_pack): weight40 (8, 40, 3, 3) -> uint8 CPU tensor."""
@@ -567,14 +597,16 @@ def fpn_tail0_splitf16(packed, bias9, conv0, feat1_sum, channels_last_copy=False
     return (out, out2) if channels_last_copy else out
 
 
-def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None, channels_last_copies=False, fused0=None, fused0_splitf16=False):
+def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None, channels_last_copies=False, fused0=None, fused0_splitf16=False,
+                       ci_layers=None):
     """Whole FeatureNet (mvsnet.py:40-57).  packed_layers: 13 device tensors (conv0.0 .. conv2.2,
     toplayer, lat1, lat0, smooth1, smooth0); imgs (N,3,H,W) -> feat0 (N,8,H,W), feat1 (N,16,H/2,W/2),
     feat2 (N,32,H/4,W/4).  layer_events: optional 14 recorded torch.cuda.Event.
     channels_last_copies: also return the three maps pixel-major (N,h,w,C) (written by the same
     kernels) -> (feat0, feat1, feat2, (nhwc0, nhwc1, nhwc2)).  fused0: (packed40, bias9) device tensors - the
     full-resolution tail as one kernel (casmvs_featurenet_forward_fused_f32); fused0_splitf16: packed40 is the uint8 image of
-    fpn_tail0_splitf16_pack (the tail on the f16 matrix cores) instead of the float32 conv2d_pack image."""
+    fpn_tail0_splitf16_pack (the tail on the f16 matrix cores) instead of the float32 conv2d_pack image.  ci_layers (with fused0 only):
+    4 device images of conv2d_ci_splitf16_pack for conv1.1, conv1.2, conv2.1, conv2.2 (entries may be None) - those layers on the f16 cores."""
     imgs = _dev(imgs, "imgs")
     N, c, H, W = imgs.shape
     if c != 3 or len(packed_layers) != 13:
@@ -599,8 +631,11 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
         ev = (ctypes.c_void_p * 14)(*[e.cuda_event for e in layer_events])
     with torch.cuda.device(dev):
         if fused0 is not None:   # (packed 40-channel tail, bias classes): lat0 + upsample-add + smooth0 in one kernel
+            ci = None
+            if ci_layers is not None:
+                ci = (ctypes.c_void_p * 4)(*[None if t is None else t.data_ptr() for t in ci_layers])
             rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
-                                                                 _ptr(imgs), _ptr(feat0), _ptr(feat1),
+                                                                 ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
                                                                  _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
                                                                  ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev, _stream(imgs))
         else:

@@ -285,13 +285,22 @@ int casmvs_fpn_tail0_f32(const float *packed40, const float *bias9, const float 
  * kernel, the `smooth0` interval is empty.  fused0_arith: 0 = fused0_packed is the float32 image (casmvs_conv2d_pack_f32 of the
  * composed 40-channel layer, casmvs_fpn_tail0_f32), 1 = the split-f16 image (casmvs_fpn_tail0_splitf16_pack,
  * casmvs_fpn_tail0_splitf16_f32: the same kernel on the f16 matrix cores in the arithmetic of casmvs_conv0_splitf16_forward_f32).
- * casmvs_fpn_tail0_splitf16_pack: HOST, weight40 (8, 40, 3, 3) float32 finite -> casmvs_fpn_tail0_splitf16_packed_bytes() bytes. */
+ * casmvs_fpn_tail0_splitf16_pack: HOST, weight40 (8, 40, 3, 3) float32 finite -> casmvs_fpn_tail0_splitf16_packed_bytes() bytes.
+ * ci_layers: NULL, or 4 pointers { conv1.1, conv1.2, conv2.1, conv2.2 } to DEVICE copies of casmvs_conv2d_ci_splitf16_pack's images (an
+ * entry may be NULL): those layers then run on the f16 matrix cores (casmvs_conv2d_ci_splitf16_forward_f32). */
+/* FeatureNet's 3x3 stride-1 equal-channel layers (conv1.1, conv1.2: 16 -> 16; conv2.1, conv2.2: 32 -> 32; ConvBnReLU, mvsnet.py:19-20,24-25) in
+ * the split-f16 arithmetic (csrc/conv2d_ci_splitf16.hip).  c in {16, 32}, W % 2 == 0, tensors 8-byte aligned.  `packed`: HOST image from
+ * casmvs_conv2d_ci_splitf16_pack (weight (c, c, 3, 3) finite, scale / shift (c) or NULL), copied to the device (16-byte aligned). */
+size_t casmvs_conv2d_ci_splitf16_packed_bytes(int c);
+int casmvs_conv2d_ci_splitf16_pack(int c, const float *weight, const float *scale, const float *shift, void *packed);
+int casmvs_conv2d_ci_splitf16_supported(int c, int W);
+int casmvs_conv2d_ci_splitf16_forward_f32(const void *packed, const float *in, float *out, int N, int c, int H, int W, float slope, void *stream);
 size_t casmvs_fpn_tail0_splitf16_packed_bytes(void);
 int casmvs_fpn_tail0_splitf16_pack(const float *weight40, void *packed);
 int casmvs_fpn_tail0_splitf16_f32(const void *packed, const float *bias9, const float *conv0, const float *feat1_sum,
                                   float *feat0, float *feat0_nhwc, int N, int H, int W, void *stream);
 int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const void *fused0_packed, int fused0_arith,
-                                        const float *fused0_bias9, const float *imgs, float *feat0, float *feat1,
+                                        const float *fused0_bias9, const void *const *ci_layers, const float *imgs, float *feat0, float *feat1,
                                         float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
                                         void *workspace, int N, int H, int W, float slope,
                                         void *const *layer_events, void *stream);

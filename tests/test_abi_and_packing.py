@@ -301,6 +301,27 @@ def test_conv_ci_splitf16_packing_and_partial_products(c, shape, amp):
         ops.conv_ci_splitf16_pack(torch.randn(16, 32, 3, 3, 3))
 
 
+@pytest.mark.parametrize("c,N,H,W,amp", [(16, 1, 8, 16, 1.0), (16, 2, 18, 36, 1e-3), (32, 1, 20, 18, 1.0), (32, 1, 5, 50, 3e4), (16, 1, 3, 2, 1e-30)])
+def test_conv2d_ci_splitf16_packing_and_partial_products(c, N, H, W, amp):
+    """csrc/conv2d_ci_splitf16.hip: lane images (tap pairs of the 9 taps x 16 channels per step, the 10th tap zero) decoded lane by lane,
+    per-(tile, chunk) scaling + two-slice split reproduce Conv2d 3x3 + folded ABN + leaky-relu to float32 grade at any magnitude."""
+    import numpy as np
+    g = torch.Generator().manual_seed(c + H + W)
+    x = torch.randn(N, c, H, W, generator=g) * amp
+    w = torch.randn(c, c, 3, 3, generator=g) * 0.1
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1 * amp
+    packed = ops.conv2d_ci_splitf16_pack(w, scale, shift)
+    assert packed.numel() == (c // 16) ** 2 * 5 * 2 * 64 * 16 + 8 * c
+    ref = F.conv2d(x.double(), w.double(), None, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01).numpy()
+    got = KM.emulate_conv2d_ci_splitf16(packed.numpy(), x.numpy(), c)
+    assert float(np.abs(got - ref).max() / np.abs(ref).max()) < 4e-7
+    with pytest.raises(ValueError):
+        ops.conv2d_ci_splitf16_pack(torch.randn(16, 32, 3, 3))
+    padded, unpadded = KM.conv2d_ci_sf_lds_cycles()
+    assert padded == [4, 4] and max(unpadded) > 4
+
+
 def test_conv_ci_splitf16_lds_layout():
     """conv_ci_sf_kernel's planes [slice][channel half][voxel] keep every tap read conflict-free for all three lane-half distances
     (next x, next row, next plane), and writing the two voxels of an item in lane-dependent order (lanes 0-3 of every 8 the even

@@ -526,6 +526,28 @@ def test_fpn_fused_tail_splitf16_matches_lat_upsample_smooth(dev, report, N, H, 
     assert torch.equal(got_cl, got.permute(0, 2, 3, 1).contiguous())
 
 
+@pytest.mark.parametrize("c,N,H,W,amp", [(16, 1, 16, 16, 1.0), (16, 2, 36, 72, 1.0), (32, 1, 40, 50, 1.0), (32, 3, 128, 160, 1e-3), (16, 1, 9, 34, 3e4),
+                                         (32, 1, 4, 2, 1e-30), (16, 6, 256, 320, 1.0)])
+def test_conv2d_ci_splitf16_matches_torch_cpu(dev, report, c, N, H, W, amp):
+    """csrc/conv2d_ci_splitf16.hip: FeatureNet's conv1.1 / conv1.2 (16 -> 16) and conv2.1 / conv2.2 (32 -> 32) on the f16 matrix cores vs
+    torch CPU float64 at the float32 kernel's bound and no worse than a few times that kernel's own error; ragged tiles, persistent loop
+    (the last case: 1920 tiles), inputs far outside float16's range."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(c * 100 + H + W)
+    x = torch.randn(N, c, H, W, generator=g) * amp
+    w = torch.randn(c, c, 3, 3, generator=g) * 0.1
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1 * amp
+    want = F.conv2d(x.double(), w.double(), None, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    want = torch.where(want > 0, want, want * 0.01)
+    xd = x.to(dev)
+    got = ops.conv2d_ci_splitf16_forward(ops.conv2d_ci_splitf16_pack(w, scale, shift).to(dev), xd, slope=0.01).cpu()
+    f32 = ops.conv2d_forward(ops.CONV2D_K3, ops.conv2d_pack(ops.CONV2D_K3, w, scale, shift).to(dev), xd, c, slope=0.01).cpu()
+    e3, ef = scaled_err(got, want), scaled_err(f32, want)
+    report("conv2d_ci_splitf16", shape=[c, N, H, W], amp=amp, err_splitf16=e3, err_f32_mfma=ef)
+    assert torch.isfinite(got).all()
+    assert e3 < 1.2e-5 and e3 < 4 * max(ef, 2e-7)
+
+
 def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
     """Every launch of the f16-matrix-core kernels reproduces the first launch's bits at sizes that keep two workgroups per CU busy
     (thousands of tiles).  Guards a hazard found in round 3: floating-point VALU work issued between a wave's own f16 MFMAs
@@ -550,6 +572,9 @@ def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
     pf, b9 = ops.fpn_tail0_splitf16_pack(w40).to(dev), bias9.to(dev)
     xf, yf = torch.randn(6, 8, 512, 640, generator=g).to(dev), torch.randn(6, 32, 256, 320, generator=g).to(dev)
     cases.append(("fpn_tail0_sf", lambda: ops.fpn_tail0_splitf16(pf, b9, xf, yf)))
+    x2 = torch.randn(6, 16, 256, 320, generator=g).to(dev)
+    p2 = ops.conv2d_ci_splitf16_pack(torch.randn(16, 16, 3, 3, generator=g) * 0.1).to(dev)
+    cases.append(("conv2d_ci_sf", lambda: ops.conv2d_ci_splitf16_forward(p2, x2)))
     bad = {}
     for name, fn in cases:
         ref = fn()
