@@ -49,14 +49,14 @@ randomize_state_dict(model.state_dict(), seed=0)
 model = model.to(dev).eval()
 
 
-def run_from_files(workers, epochs=3, processes=False):
+def run_from_files(workers, epochs=3, processes=False, skip=3):
     idx = list(range(len(reader))) * epochs
     loader = P.ParallelLoader(reader, batch_size=B, num_workers=workers, indices=idx, prefetch_batches=max(4, workers // B), drop_last=True, processes=processes)
     n = 0
     t0 = None
     for i, b in enumerate(P.DevicePrefetcher(loader, dev, depth=3)):
         out = model(b["imgs"], b["proj_mats"], b["init_depth_min"].to(dev), b["depth_interval"].to(dev))
-        if i == 3:                     # warm-up: first batches fill the pipeline
+        if i == skip:                  # warm-up: first batches fill the pipeline (worker processes: also their start-up)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             n = 0
@@ -66,7 +66,7 @@ def run_from_files(workers, epochs=3, processes=False):
 
 
 def run_decode_only(workers, processes=False):
-    idx = list(range(len(reader))) * (6 if processes else 2)
+    idx = list(range(len(reader))) * (20 if processes else 2)
     loader = P.ParallelLoader(reader, batch_size=B, num_workers=workers, indices=idx, prefetch_batches=max(4, workers // B), drop_last=True, processes=processes)
     t0 = time.perf_counter()
     n = sum(b["imgs_u8"].shape[0] for b in loader)
@@ -87,10 +87,8 @@ torch.cuda.synchronize()
 resident = 30 * B / (time.perf_counter() - t0)
 print(f"device-resident inputs, kernel by kernel, batch {B}: {resident:.1f} depth maps/s")
 for procs in (False, True):
-    for wk in WORKERS:
-        if procs and wk < 4:
-            continue
+    for wk in (WORKERS if not procs else [w for w in WORKERS if 16 <= w <= 64] or [32]):
         dec = run_decode_only(wk, procs)
-        rate, _ = run_from_files(wk, epochs=8 if procs else 3, processes=procs)
+        rate, _ = run_from_files(wk, epochs=60 if procs else 6, processes=procs, skip=40 if procs else 3)   # processes: ~3000 samples, timed after their start-up
         print(f"{'processes' if procs else 'threads  '} {wk:3d}: decode + collate alone {dec:7.1f} depth maps/s ({3 * dec:.0f} images/s); files -> depth maps {rate:7.1f} /s = "
               f"{rate / resident:.2f} of resident", flush=True)
