@@ -68,10 +68,10 @@ SYMBOLS = {
     "casmvs_fpn_tail0_splitf16_packed_bytes": (c_size_t, []),
     "casmvs_fpn_tail0_splitf16_pack": (c_int, [_FP, c_void_p]),
     "casmvs_fpn_tail0_splitf16_f32": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
-    "casmvs_conv2d_ci_splitf16_packed_bytes": (c_size_t, [c_int]),
-    "casmvs_conv2d_ci_splitf16_pack": (c_int, [c_int, _FP, _FP, _FP, c_void_p]),
-    "casmvs_conv2d_ci_splitf16_supported": (c_int, [c_int, c_int]),
-    "casmvs_conv2d_ci_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "casmvs_conv2d_ci_splitf16_packed_bytes": (c_size_t, [c_int, c_int]),
+    "casmvs_conv2d_ci_splitf16_pack": (c_int, [c_int, c_int, _FP, _FP, _FP, c_void_p]),
+    "casmvs_conv2d_ci_splitf16_supported": (c_int, [c_int, c_int, c_int]),
+    "casmvs_conv2d_ci_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_featurenet_forward_fused_f32": (c_int, [POINTER(c_void_p), c_void_p, c_int, _FP, POINTER(c_void_p), _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
     "casmvs_softmax_regress_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_prob_regress_supported": (c_int, [c_int, c_int]),

@@ -1,5 +1,6 @@
-// FeatureNet's 3x3 stride-1 layers with equal channel counts (conv1.1 / conv1.2: 16 -> 16, conv2.1 / conv2.2: 32 -> 32;
-// ConvBnReLU, models/modules.py:8-18, models/mvsnet.py:19-20,24-25) on the f16 matrix cores in the float32-grade split arithmetic
+// FeatureNet's 3x3 stride-1 layers with 16 / 32 channels (conv1.1 / conv1.2: 16 -> 16, conv2.1 / conv2.2: 32 -> 32: ConvBnReLU,
+// models/modules.py:8-18, models/mvsnet.py:19-20,24-25; smooth1: Conv2d 32 -> 16 with bias, mvsnet.py:32,53, which also writes the
+// pixel-major copy of its output) on the f16 matrix cores in the float32-grade split arithmetic
 // of conv0_splitf16.hip: the 2D sibling of conv_ci_splitf16.hip.
 //
 // Formulation: D[16 x 16] += A[16 x 32] B[32 x 16]; rows = 16 output channels (C / 16 row blocks share every B operand), columns = 16
@@ -27,14 +28,14 @@ using namespace casmvs::buf;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int C>
+template <int CIN, int COUT>
 struct C2Cfg {
   static constexpr int THREADS = 256, NT = 4;
   static constexpr int TY = 16, TX = 16;
   static constexpr int IY = TY + 2, IX = TX + 4;                     // rows y0 - 1 .. y0 + 16, columns x0 - 2 .. x0 + 17
   static constexpr int RS = IX;                                      // 16-byte units per staged row of one plane
   static constexpr int NVOX = ((IY * RS + 15) / 16) * 16;            // units per plane, padded to 256 B: 368
-  static constexpr int RB = C / 16, NCH = C / 16, STEPS = 5;
+  static constexpr int RB = COUT / 16, NCH = CIN / 16, STEPS = 5;
   static constexpr int ITEMS = IY * (IX / 2);                        // 180
   static constexpr int WUNITS = NCH * STEPS * RB * 2 * 64;           // [chunk][step][row block][slice][lane]: 640 / 2560 16-byte units
   static constexpr int NWL = (WUNITS + THREADS - 1) / THREADS;       // 3 / 10
@@ -56,12 +57,13 @@ __device__ __forceinline__ unsigned wave_max_bits_c2(unsigned v) {
   return max(max(a, b), max(c, d));
 }
 
-// in (N, C, H, W) float32, W % 2 == 0, 8-byte aligned; wpk: [chunk][step][row block][slice][lane] 16-byte lane images, then scale[C]
-// (ABN scale x 2^-kw), shift[C]; out (N, C, H, W).
-template <int C>
+// in (N, CIN, H, W) float32, W % 2 == 0, 8-byte aligned; wpk: [chunk][step][row block][slice][lane] 16-byte lane images, then scale[COUT]
+// (ABN scale x 2^-kw), shift[COUT]; out (N, COUT, H, W); out2: NULL or (N, H, W, COUT) pixel-major (16-byte aligned).
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
-                                                             float *__restrict__ out, int N, int H, int W, int tiles_x, int tiles_y, float slope) {
-  using Cfg = C2Cfg<C>;
+                                                             float *__restrict__ out, float *__restrict__ out2, int N, int H, int W, int tiles_x,
+                                                             int tiles_y, float slope) {
+  using Cfg = C2Cfg<CIN, COUT>;
   constexpr int NCH = Cfg::NCH, RB = Cfg::RB, NT = Cfg::NT, NWL = Cfg::NWL, IX = Cfg::IX, NVOX = Cfg::NVOX, RS = Cfg::RS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4 *act = reinterpret_cast<u32x4 *>(smem_raw);                                          // [slice][half][NVOX]
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__res
   const int total = tiles_x * tiles_y * N;
   if ((int)blockIdx.x >= total) return;
   const int hw = H * W;
-  const size_t ss = (size_t)C * hw;
+  const size_t ss = (size_t)CIN * hw, oss = (size_t)COUT * hw;
   {   // the lane images of all chunks: once per workgroup
     const rsrc_t wsrc = make_rsrc(reinterpret_cast<const float *>(wpk), Cfg::W_BYTES);
 #pragma unroll
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__res
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       sc[rb][r] = tail[rb * 16 + 4 * kb + r];
-      sh[rb][r] = tail[C + rb * 16 + 4 * kb + r];
+      sh[rb][r] = tail[COUT + rb * 16 + 4 * kb + r];
     }
   const rsrc_t none = make_rsrc(in, 0);
 
@@ -224,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__res
           for (int q = 0; q < 4; ++q) acc[t][rb][q] = NCH > 1 ? fmaf(part[t][rb][q], inv, acc[t][rb][q]) : part[t][rb][q] * inv;
     }
     // ---- epilogue: y = lrelu(acc * scale + shift); lane holds rows 4 kb + r (output channel 16 rb + 4 kb + r), column j ----
-    const rsrc_t dst = make_rsrc(out + (size_t)n * ss, ss * 4);
+    const rsrc_t dst = make_rsrc(out + (size_t)n * oss, oss * 4);
+    const rsrc_t dst2 = make_rsrc(out2 ? out2 + (size_t)n * oss : out, oss * 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int oy = ty0 + 4 * wave + t, ox = tx0 + jcol;
@@ -232,12 +235,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__res
       const int o0 = ok ? (4 * kb * hw + oy * W + ox) * 4 : kOOB;   // the lane's first channel row is part of the lane offset
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
+        f32x4v o4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = fmaf(acc[t][rb][r], sc[rb][r], sh[rb][r]);
           v = v > 0.0f ? v : v * slope;
+          o4[r] = v;
           buf_store(v, dst, o0, (rb * 16 + r) * hw * 4);
         }
+        if (out2)   // pixel-major copy: this lane's 4 consecutive channels of pixel (oy, ox) in one store
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), dst2, ok ? ((oy * W + ox) * COUT + 4 * kb) * 4 : kOOB, rb * 64, 0);
         acc[t][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -256,37 +263,41 @@ inline uint16_t f16_bits_c2(float x) {
   return b;
 }
 
-template <int C>
-int launch_c2(const void *packed, const float *in, float *out, int N, int H, int W, float slope, hipStream_t st) {
-  using Cfg = C2Cfg<C>;
+template <int CIN, int COUT>
+int launch_c2(const void *packed, const float *in, float *out, float *out2, int N, int H, int W, float slope, hipStream_t st) {
+  using Cfg = C2Cfg<CIN, COUT>;
   const int tiles_x = casmvs::ceil_div(W, Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY);
   const long total = (long)tiles_x * tiles_y * N;
   CASMVS_REQUIRE(total < (1L << 31), "conv2d_ci_splitf16_forward: too many tiles");
-  auto kernel = conv2d_ci_sf_kernel<C>;
+  auto kernel = conv2d_ci_sf_kernel<CIN, COUT>;
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), Cfg::LDS_BYTES, "conv2d_ci_sf_kernel")) return rc;
   const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), Cfg::THREADS, Cfg::LDS_BYTES);
   hipLaunchKernelGGL(kernel, dim3((unsigned)(total < resident ? total : resident)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, in,
-                     reinterpret_cast<const unsigned char *>(packed), out, N, H, W, tiles_x, tiles_y, slope);
+                     reinterpret_cast<const unsigned char *>(packed), out, out2, N, H, W, tiles_x, tiles_y, slope);
   return casmvs::check_launch("conv2d_ci_sf_kernel");
 }
 
 }  // namespace
 
-extern "C" size_t casmvs_conv2d_ci_splitf16_packed_bytes(int c) {
-  if (c != 16 && c != 32) return 0;
-  return (size_t)(c / 16) * 5 * (c / 16) * 2 * 64 * 16 + (size_t)2 * c * sizeof(float);
+namespace {
+inline bool c2_shape_ok(int cin, int cout) { return (cin == 16 && cout == 16) || (cin == 32 && cout == 32) || (cin == 32 && cout == 16); }
+}  // namespace
+
+extern "C" size_t casmvs_conv2d_ci_splitf16_packed_bytes(int cin, int cout) {
+  if (!c2_shape_ok(cin, cout)) return 0;
+  return (size_t)(cin / 16) * 5 * (cout / 16) * 2 * 64 * 16 + (size_t)2 * cout * sizeof(float);
 }
 
-// HOST-side packing: weight (c, c, 3, 3) float32 -> w' = 2^kw w (max |w'| in [2^13, 2^14)); per chunk of 16 input channels, per step m
+// HOST-side packing: weight (cout, cin, 3, 3) float32 -> w' = 2^kw w (max |w'| in [2^13, 2^14)); per chunk of 16 input channels, per step m
 // (taps 2 m, 2 m + 1), per row block, per slice, per lane the 8 float16 values
 // A[i = lane & 15][k = 8 (lane >> 4) + e] = slice(w'[co = 16 rb + i][ci = 16 chunk + 8 ((lane >> 4) & 1) + e][tap 2 m + (lane >> 5)]), zero for tap 9;
-// then scale[c] * 2^-kw, shift[c].
-extern "C" int casmvs_conv2d_ci_splitf16_pack(int c, const float *weight, const float *scale, const float *shift, void *packed) {
+// then scale[cout] * 2^-kw, shift[cout].
+extern "C" int casmvs_conv2d_ci_splitf16_pack(int cin, int cout, const float *weight, const float *scale, const float *shift, void *packed) {
   casmvs::clear_error();
   CASMVS_REQUIRE(weight && packed, "conv2d_ci_splitf16_pack: null pointer");
-  CASMVS_REQUIRE(c == 16 || c == 32, "conv2d_ci_splitf16_pack: c=%d (16 or 32)", c);
+  CASMVS_REQUIRE(c2_shape_ok(cin, cout), "conv2d_ci_splitf16_pack: cin=%d cout=%d (16 -> 16, 32 -> 32 or 32 -> 16)", cin, cout);
   float wmax = 0.0f;
-  for (size_t i = 0; i < (size_t)c * c * 9; ++i) {
+  for (size_t i = 0; i < (size_t)cout * cin * 9; ++i) {
     CASMVS_REQUIRE(std::isfinite(weight[i]), "conv2d_ci_splitf16_pack: weight %zu is not finite", i);
     wmax = std::fmax(wmax, std::fabs(weight[i]));
   }
@@ -294,15 +305,15 @@ extern "C" int casmvs_conv2d_ci_splitf16_pack(int c, const float *weight, const 
   if (wmax > 0.0f) (void)std::frexp(wmax, &ex);
   const int kw = 14 - ex;
   uint16_t *p = reinterpret_cast<uint16_t *>(packed);
-  for (int ch = 0; ch < c / 16; ++ch)
+  for (int ch = 0; ch < cin / 16; ++ch)
     for (int st = 0; st < 5; ++st)
-      for (int rb = 0; rb < c / 16; ++rb) {
+      for (int rb = 0; rb < cout / 16; ++rb) {
         uint16_t img[2][64][8];
         for (int l = 0; l < 64; ++l) {
           const int i = l & 15, kb = l >> 4, tap = 2 * st + (kb >> 1), co = 16 * rb + i;
           for (int e = 0; e < 8; ++e) {
             const int ci = 16 * ch + 8 * (kb & 1) + e;
-            const float w = tap < 9 ? std::ldexp(weight[((size_t)co * c + ci) * 9 + tap], kw) : 0.0f;
+            const float w = tap < 9 ? std::ldexp(weight[((size_t)co * cin + ci) * 9 + tap], kw) : 0.0f;
             const float a = (float)(_Float16)w;
             img[0][l][e] = f16_bits_c2(w);
             img[1][l][e] = f16_bits_c2(w - a);
@@ -312,21 +323,24 @@ extern "C" int casmvs_conv2d_ci_splitf16_pack(int c, const float *weight, const 
         p += 2 * 64 * 8;
       }
   float *tail = reinterpret_cast<float *>(p);
-  for (int k = 0; k < c; ++k) tail[k] = std::ldexp(scale ? scale[k] : 1.0f, -kw);
-  for (int k = 0; k < c; ++k) tail[c + k] = shift ? shift[k] : 0.0f;
+  for (int k = 0; k < cout; ++k) tail[k] = std::ldexp(scale ? scale[k] : 1.0f, -kw);
+  for (int k = 0; k < cout; ++k) tail[cout + k] = shift ? shift[k] : 0.0f;
   return CASMVS_OK;
 }
 
-extern "C" int casmvs_conv2d_ci_splitf16_supported(int c, int W) { return (c == 16 || c == 32) && W % 2 == 0 && W >= 2; }
+extern "C" int casmvs_conv2d_ci_splitf16_supported(int cin, int cout, int W) { return c2_shape_ok(cin, cout) && W % 2 == 0 && W >= 2; }
 
-extern "C" int casmvs_conv2d_ci_splitf16_forward_f32(const void *packed, const float *in, float *out, int N, int c, int H, int W, float slope,
-                                                     void *stream) {
+extern "C" int casmvs_conv2d_ci_splitf16_forward_f32(const void *packed, const float *in, float *out, float *out_nhwc, int N, int cin, int cout, int H,
+                                                     int W, float slope, void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(packed && in && out, "conv2d_ci_splitf16_forward: null pointer");
-  CASMVS_REQUIRE(N > 0 && H > 0 && W > 0 && casmvs_conv2d_ci_splitf16_supported(c, W), "conv2d_ci_splitf16_forward: N=%d c=%d H=%d W=%d", N, c, H, W);
-  CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out)) & 7) == 0 && (reinterpret_cast<size_t>(packed) & 15) == 0,
-                 "conv2d_ci_splitf16_forward: 8-byte aligned tensors, 16-byte aligned image");
-  CASMVS_REQUIRE((size_t)c * H * W < ((size_t)1 << 29), "conv2d_ci_splitf16_forward: one image's tensor must hold < 2^29 floats");
+  CASMVS_REQUIRE(N > 0 && H > 0 && W > 0 && casmvs_conv2d_ci_splitf16_supported(cin, cout, W), "conv2d_ci_splitf16_forward: N=%d cin=%d cout=%d H=%d W=%d", N, cin, cout, H, W);
+  CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out)) & 7) == 0 &&
+                 ((reinterpret_cast<size_t>(packed) | reinterpret_cast<size_t>(out_nhwc)) & 15) == 0,
+                 "conv2d_ci_splitf16_forward: 8-byte aligned tensors, 16-byte aligned image / pixel-major output");
+  CASMVS_REQUIRE((size_t)cin * H * W < ((size_t)1 << 29) && (size_t)cout * H * W < ((size_t)1 << 29), "conv2d_ci_splitf16_forward: one image's tensor must hold < 2^29 floats");
   hipStream_t st = (hipStream_t)stream;
-  return c == 16 ? launch_c2<16>(packed, in, out, N, H, W, slope, st) : launch_c2<32>(packed, in, out, N, H, W, slope, st);
+  if (cin == 16) return launch_c2<16, 16>(packed, in, out, out_nhwc, N, H, W, slope, st);
+  if (cout == 32) return launch_c2<32, 32>(packed, in, out, out_nhwc, N, H, W, slope, st);
+  return launch_c2<32, 16>(packed, in, out, out_nhwc, N, H, W, slope, st);
 }

@@ -2172,35 +2172,35 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
   CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, nullptr, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
   CASMVS_L(CASMVS_CONV2D_K3, P[1], a0, nullptr, c0, nullptr, N, 8, 8, H, W, slope, stream);            // conv0.1  :15
   CASMVS_L(CASMVS_CONV2D_K5S2, P[2], c0, nullptr, a1, nullptr, N, 8, 16, H, W, slope, stream);         // conv1.0  :18
-  if (ci_layers && ci_layers[0] && casmvs_conv2d_ci_splitf16_supported(16, W2)) {   // conv1.1 on the f16 matrix cores (conv2d_ci_splitf16.hip)
+  if (ci_layers && ci_layers[0] && casmvs_conv2d_ci_splitf16_supported(16, 16, W2)) {   // conv1.1 on the f16 matrix cores (conv2d_ci_splitf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[0], a1, b1, N, 16, H2, W2, slope, stream);
+    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[0], a1, b1, nullptr, N, 16, 16, H2, W2, slope, stream);
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV2D_K3, P[3], a1, nullptr, b1, nullptr, N, 16, 16, H2, W2, slope, stream);        // conv1.1  :19
   }
-  if (ci_layers && ci_layers[1] && casmvs_conv2d_ci_splitf16_supported(16, W2)) {   // conv1.2 on the f16 matrix cores (conv2d_ci_splitf16.hip)
+  if (ci_layers && ci_layers[1] && casmvs_conv2d_ci_splitf16_supported(16, 16, W2)) {   // conv1.2 on the f16 matrix cores (conv2d_ci_splitf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[1], b1, c1, N, 16, H2, W2, slope, stream);
+    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[1], b1, c1, nullptr, N, 16, 16, H2, W2, slope, stream);
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV2D_K3, P[4], b1, nullptr, c1, nullptr, N, 16, 16, H2, W2, slope, stream);        // conv1.2  :20
   }
   CASMVS_L(CASMVS_CONV2D_K5S2, P[5], c1, nullptr, a2, nullptr, N, 16, 32, H2, W2, slope, stream);      // conv2.0  :23
-  if (ci_layers && ci_layers[2] && casmvs_conv2d_ci_splitf16_supported(32, W4)) {   // conv2.1 on the f16 matrix cores (conv2d_ci_splitf16.hip)
+  if (ci_layers && ci_layers[2] && casmvs_conv2d_ci_splitf16_supported(32, 32, W4)) {   // conv2.1 on the f16 matrix cores (conv2d_ci_splitf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[2], a2, b2, N, 32, H4, W4, slope, stream);
+    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[2], a2, b2, nullptr, N, 32, 32, H4, W4, slope, stream);
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV2D_K3, P[6], a2, nullptr, b2, nullptr, N, 32, 32, H4, W4, slope, stream);        // conv2.1  :24
   }
-  if (ci_layers && ci_layers[3] && casmvs_conv2d_ci_splitf16_supported(32, W4)) {   // conv2.2 on the f16 matrix cores (conv2d_ci_splitf16.hip)
+  if (ci_layers && ci_layers[3] && casmvs_conv2d_ci_splitf16_supported(32, 32, W4)) {   // conv2.2 on the f16 matrix cores (conv2d_ci_splitf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[3], b2, c2, N, 32, H4, W4, slope, stream);
+    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[3], b2, c2, nullptr, N, 32, 32, H4, W4, slope, stream);
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV2D_K3, P[7], b2, nullptr, c2, nullptr, N, 32, 32, H4, W4, slope, stream);        // conv2.2  :25
@@ -2215,7 +2215,14 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
   } else {
     CASMVS_L(CASMVS_CONV2D_K1_UP, P[10], c0, f1, f0, nullptr, N, 8, 32, H, W, 1.0f, stream);           // lat0 + up :50
   }
-  CASMVS_L(CASMVS_CONV2D_K3, P[11], f1, nullptr, feat1, feat1_nhwc, N, 32, 16, H2, W2, 1.0f, stream);     // smooth1  :53
+  if (ci_layers && ci_layers[4] && casmvs_conv2d_ci_splitf16_supported(32, 16, W2) && (reinterpret_cast<size_t>(feat1_nhwc) & 15) == 0) {   // smooth1 on the f16 matrix cores
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[4], f1, feat1, feat1_nhwc, N, 32, 16, H2, W2, 1.0f, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K3, P[11], f1, nullptr, feat1, feat1_nhwc, N, 32, 16, H2, W2, 1.0f, stream);     // smooth1  :53
+  }
   if (fuse0) {
     CASMVS_EV();
   } else {
@@ -2320,10 +2327,11 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     CASMVS_L(CASMVS_CONV_S1, P[2], c1, nullptr, c2, B, 16, 16, D / 2, h / 2, w / 2, sl, stream);    // conv2
   }
   CASMVS_L(CASMVS_CONV_S2, P[3], c2, nullptr, c3, B, 16, 32, D / 2, h / 2, w / 2, sl, stream);      // conv3
-  // conv4 on the f16 matrix cores where its 4 x 4 x 16 tiles are full and there are enough of them (measured: 60 tiles or a
-  // 2-plane volume are faster on the float32 kernel's deep variant; 120 tiles and more on the f16 one)
-  const long conv4_tiles = (long)B * casmvs::ceil_div(D / 4, 4) * casmvs::ceil_div(h / 4, 4) * casmvs::ceil_div(w / 4, 16);
-  if (conv4_split && casmvs_conv_ci_splitf16_supported(32, 32, w / 4) && D / 4 >= 3 && conv4_tiles >= 100) {
+  // conv4 on the f16 matrix cores where there are enough of its 256-voxel tiles (4 x 4 x 16, or 2 x 8 x 16 for a 2-plane volume) to
+  // fill the chip (measured: 60 tiles are faster on the float32 kernel's deep variant, 120 and more on the f16 one)
+  const int tz4 = D / 4 <= 2 ? 2 : 4;
+  const long conv4_tiles = (long)B * casmvs::ceil_div(D / 4, tz4) * casmvs::ceil_div(h / 4, 16 / tz4) * casmvs::ceil_div(w / 4, 16);
+  if (conv4_split && casmvs_conv_ci_splitf16_supported(32, 32, w / 4) && (D / 4 == 2 || D / 4 >= 3) && conv4_tiles >= 100) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
     rc = casmvs_conv_ci_splitf16_forward_f32(conv4_split, c3, c4, B, 32, 32, D / 4, h / 4, w / 4, sl, stream);

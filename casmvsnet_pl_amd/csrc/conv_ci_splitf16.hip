@@ -21,7 +21,8 @@
 //
 // Workgroup = 256 threads (4 waves), output tile 4 x 4 x 16 voxels, wave w = z plane w, 4 (y) column tiles; per chunk of
 // 16 input channels the halo tile 6 x 6 x 20 voxels (x0 - 2 .. x0 + 17: 8-byte aligned pairs) x 2 slices x 32 B = 45 KiB and the
-// chunk's lane images 14 steps x 2 slices x COUT / 16 KiB.  conv2: 73 KiB, two workgroups per CU, weights loaded once.
+// chunk's lane images 14 steps x 2 slices x COUT / 16 KiB.  conv2: 73 KiB, two workgroups per CU, weights loaded once.  Volumes of
+// 2 planes (conv4 at cascade level 0) use a 2 x 8 x 16 tile (halo 4 x 10 x 20).
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -45,10 +46,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int TZ_ = 4>
 struct CiCfg {
   static constexpr int THREADS = 256, WAVES = 4, NT = 4;
-  static constexpr int TZ = 4, TY = 4, TX = 16;
+  static constexpr int TZ = TZ_, TY = 16 / TZ_, TX = 16;           // 16 (z, y) rows of 16 x: 4 x 4 (default) or 2 x 8 (volumes of 2 planes)
   static constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 4;       // x0 - 2 .. x0 + 17
   static constexpr int RS = IX;                                      // 16-byte units per staged row of one plane (no padding: see the write order)
   static constexpr int NVOX = IZ * IY * RS;                          // units per plane: 720 (x 16 B = 45 x 256 B: planes start on the same bank)
@@ -100,12 +101,13 @@ __host__ __device__ constexpr int ci_tap_off(int t) { return ((t / 9) * Cfg::IY 
 
 // in (B, CIN, D, H, W) float32, W % 2 == 0, 8-byte aligned; wpk: [chunk][step][row block][slice][lane] 16-byte lane images, then
 // scale[COUT] (ABN scale x 2^-kw), shift[COUT]; out (B, COUT, D, H, W).
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256, (CiCfg<CIN, COUT>::WG_PER_CU)) void conv_ci_sf_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
+template <int CIN, int COUT, int TZ>
+__global__ __launch_bounds__(256, (CiCfg<CIN, COUT, TZ>::WG_PER_CU)) void conv_ci_sf_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
                                                                                        float *__restrict__ out, int B, int D, int H, int W, int tiles_x,
                                                                                        int tiles_y, int tiles_z, float slope) {
-  using Cfg = CiCfg<CIN, COUT>;
+  using Cfg = CiCfg<CIN, COUT, TZ>;
   constexpr int NCH = Cfg::NCH, RB = Cfg::RB, NT = Cfg::NT, NR = Cfg::NR, NWL = Cfg::NWL, IX = Cfg::IX, IY = Cfg::IY, NVOX = Cfg::NVOX, RS = Cfg::RS;
+  static_assert(TZ == 4 || TZ == 2, "tile 4 x 4 x 16 or 2 x 8 x 16");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4 *act = reinterpret_cast<u32x4 *>(smem_raw);                                          // [slice][half][NVOX]
   u32x4 *wl = reinterpret_cast<u32x4 *>(smem_raw + Cfg::ACT_BYTES);                          // [step][rb][slice][64]
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(256, (CiCfg<CIN, COUT>::WG_PER_CU)) void conv_ci_sf
   int vbx[NT], vby[NT], vbz[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int v = half * NVOX + (wave * IY + t) * RS + jcol + 1;
+    const int r16 = wave * NT + t;   // this wave's t-th (z, y) row of the tile
+    const int v = half * NVOX + ((r16 / Cfg::TY) * IY + r16 % Cfg::TY) * RS + jcol + 1;
     vbx[t] = v + hi_tap * 1;
     vby[t] = v + hi_tap * (RS - 2);
     vbz[t] = v + hi_tap * ((IY - 2) * RS - 2);
@@ -292,7 +295,8 @@ __global__ __launch_bounds__(256, (CiCfg<CIN, COUT>::WG_PER_CU)) void conv_ci_sf
     const rsrc_t dst = make_rsrc(out + (size_t)cur.b * out_ss, out_ss * 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int oz = cur.tz0 + wave, oy = cur.ty0 + t, ox = cur.tx0 + jcol;
+      const int r16 = wave * NT + t;
+      const int oz = cur.tz0 + r16 / Cfg::TY, oy = cur.ty0 + r16 % Cfg::TY, ox = cur.tx0 + jcol;
       const bool ok = oz < D && oy < H && ox < W;
       const int o0 = ok ? (4 * kb * cs + (oz * H + oy) * W + ox) * 4 : kOOB;   // the lane's first channel row (4 kb) is part of the lane offset
 #pragma unroll
@@ -319,13 +323,13 @@ inline uint16_t f16_bits_ci(float x) {   // round to nearest even (host)
   return b;
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int TZ>
 int launch_ci(const void *packed, const float *in, float *out, int B, int D, int H, int W, float slope, hipStream_t st) {
-  using Cfg = CiCfg<CIN, COUT>;
+  using Cfg = CiCfg<CIN, COUT, TZ>;
   const int tiles_x = casmvs::ceil_div(W, Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY), tiles_z = casmvs::ceil_div(D, Cfg::TZ);
   const long total = (long)tiles_x * tiles_y * tiles_z * B;
   CASMVS_REQUIRE(total < (1L << 31), "conv_ci_splitf16_forward: too many tiles");
-  auto kernel = conv_ci_sf_kernel<CIN, COUT>;
+  auto kernel = conv_ci_sf_kernel<CIN, COUT, TZ>;
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), Cfg::LDS_BYTES, "conv_ci_sf_kernel")) return rc;
   const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), Cfg::THREADS, Cfg::LDS_BYTES);
   hipLaunchKernelGGL(kernel, dim3((unsigned)(total < resident ? total : resident)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, in,
@@ -395,6 +399,7 @@ extern "C" int casmvs_conv_ci_splitf16_forward_f32(const void *packed, const flo
   CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 29) && (size_t)cout * D * H * W < ((size_t)1 << 29),
                  "conv_ci_splitf16_forward: one sample's tensors must hold < 2^29 floats");
   hipStream_t st = (hipStream_t)stream;
-  if (cin == 16) return launch_ci<16, 16>(packed, in, out, B, D, H, W, slope, st);
-  return launch_ci<32, 32>(packed, in, out, B, D, H, W, slope, st);
+  // volumes of at most 2 planes (conv4 at cascade level 0: D / 4 = 2): the 2 x 8 x 16 tile - a 4-deep tile would be half padding
+  if (cin == 16) return D <= 2 ? launch_ci<16, 16, 2>(packed, in, out, B, D, H, W, slope, st) : launch_ci<16, 16, 4>(packed, in, out, B, D, H, W, slope, st);
+  return D <= 2 ? launch_ci<32, 32, 2>(packed, in, out, B, D, H, W, slope, st) : launch_ci<32, 32, 4>(packed, in, out, B, D, H, W, slope, st);
 }

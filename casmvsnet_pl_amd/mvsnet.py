@@ -138,7 +138,7 @@ class FeatureNet(_PackedWeights, nn.Module):
         self.fuse_tail = True     # lat0 + upsample-add + smooth0 as one kernel (False: the reference's three steps, A/B and tests)
         self._fused0_sf = None    # the same tail as the split-f16 image
         self.tail_mode = "splitf16"   # arithmetic of the fused tail: "splitf16" (f16 matrix cores, fpn_fused_sf.hip) or "f32"
-        self._ci2d = None         # split-f16 images of conv1.1, conv1.2, conv2.1, conv2.2 (conv2d_ci_splitf16.hip; follow tail_mode)
+        self._ci2d = None         # split-f16 images of conv1.1, conv1.2, conv2.1, conv2.2, smooth1 (conv2d_ci_splitf16.hip; follow tail_mode)
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.last_channels_last = None
 
@@ -168,6 +168,7 @@ class FeatureNet(_PackedWeights, nn.Module):
             m = self.get_submodule(name)
             sc, sh, _ = _fold_norm(f"FeatureNet.{name}", m.bn)
             ci.append(ops.conv2d_ci_splitf16_pack(m.conv.weight, sc, sh).to(device))
+        ci.append(ops.conv2d_ci_splitf16_pack(self.smooth1.weight, None, self.smooth1.bias).to(device))   # smooth1: Conv2d 32 -> 16 with bias
         self._store_packed("_ci2d", ci)
         self._packed_key = key
         return self._store_packed("_packed", packed)

@@ -286,15 +286,18 @@ int casmvs_fpn_tail0_f32(const float *packed40, const float *bias9, const float 
  * composed 40-channel layer, casmvs_fpn_tail0_f32), 1 = the split-f16 image (casmvs_fpn_tail0_splitf16_pack,
  * casmvs_fpn_tail0_splitf16_f32: the same kernel on the f16 matrix cores in the arithmetic of casmvs_conv0_splitf16_forward_f32).
  * casmvs_fpn_tail0_splitf16_pack: HOST, weight40 (8, 40, 3, 3) float32 finite -> casmvs_fpn_tail0_splitf16_packed_bytes() bytes.
- * ci_layers: NULL, or 4 pointers { conv1.1, conv1.2, conv2.1, conv2.2 } to DEVICE copies of casmvs_conv2d_ci_splitf16_pack's images (an
- * entry may be NULL): those layers then run on the f16 matrix cores (casmvs_conv2d_ci_splitf16_forward_f32). */
-/* FeatureNet's 3x3 stride-1 equal-channel layers (conv1.1, conv1.2: 16 -> 16; conv2.1, conv2.2: 32 -> 32; ConvBnReLU, mvsnet.py:19-20,24-25) in
- * the split-f16 arithmetic (csrc/conv2d_ci_splitf16.hip).  c in {16, 32}, W % 2 == 0, tensors 8-byte aligned.  `packed`: HOST image from
- * casmvs_conv2d_ci_splitf16_pack (weight (c, c, 3, 3) finite, scale / shift (c) or NULL), copied to the device (16-byte aligned). */
-size_t casmvs_conv2d_ci_splitf16_packed_bytes(int c);
-int casmvs_conv2d_ci_splitf16_pack(int c, const float *weight, const float *scale, const float *shift, void *packed);
-int casmvs_conv2d_ci_splitf16_supported(int c, int W);
-int casmvs_conv2d_ci_splitf16_forward_f32(const void *packed, const float *in, float *out, int N, int c, int H, int W, float slope, void *stream);
+ * ci_layers: NULL, or 5 pointers { conv1.1, conv1.2, conv2.1, conv2.2, smooth1 } to DEVICE copies of casmvs_conv2d_ci_splitf16_pack's images
+ * (an entry may be NULL): those layers then run on the f16 matrix cores (casmvs_conv2d_ci_splitf16_forward_f32). */
+/* FeatureNet's 3x3 stride-1 layers with 16 / 32 channels (conv1.1, conv1.2: 16 -> 16; conv2.1, conv2.2: 32 -> 32: ConvBnReLU, mvsnet.py:19-20,24-25;
+ * smooth1: Conv2d 32 -> 16 with bias, mvsnet.py:32,53) in the split-f16 arithmetic (csrc/conv2d_ci_splitf16.hip).  (cin, cout) in {(16, 16),
+ * (32, 32), (32, 16)}, W % 2 == 0, tensors 8-byte aligned.  `packed`: HOST image from casmvs_conv2d_ci_splitf16_pack (weight (cout, cin, 3, 3)
+ * finite, scale / shift (cout) or NULL), copied to the device (16-byte aligned).  out_nhwc: NULL or the pixel-major copy (N, H, W, cout),
+ * 16-byte aligned.  slope: 0.01 for the ABN layers, 1.0 for smooth1. */
+size_t casmvs_conv2d_ci_splitf16_packed_bytes(int cin, int cout);
+int casmvs_conv2d_ci_splitf16_pack(int cin, int cout, const float *weight, const float *scale, const float *shift, void *packed);
+int casmvs_conv2d_ci_splitf16_supported(int cin, int cout, int W);
+int casmvs_conv2d_ci_splitf16_forward_f32(const void *packed, const float *in, float *out, float *out_nhwc, int N, int cin, int cout, int H, int W,
+                                          float slope, void *stream);
 size_t casmvs_fpn_tail0_splitf16_packed_bytes(void);
 int casmvs_fpn_tail0_splitf16_pack(const float *weight40, void *packed);
 int casmvs_fpn_tail0_splitf16_f32(const void *packed, const float *bias9, const float *conv0, const float *feat1_sum,

@@ -716,19 +716,20 @@ def emulate_conv_ci_splitf16(packed, x, cin, cout, slope=0.01, tile=(4, 4, 16), 
     return np.where(y > 0, y, y * slope)
 
 
-def emulate_conv2d_ci_splitf16(packed, x, c, slope=0.01, tile=(16, 16), halo_x=(2, 2)):
+def emulate_conv2d_ci_splitf16(packed, x, c, slope=0.01, tile=(16, 16), halo_x=(2, 2), cout=None):
     """Data flow of conv2d_ci_sf_kernel in float64 (the 2D sibling of emulate_conv_ci_splitf16): lane images
     [chunk][step][row block][slice][lane][8 f16] decoded lane by lane (tap 2 m + (kb >> 1) of the 9, tap 9 zero), per 16 x 16 output tile
     and chunk of 16 input channels the halo tile (y0-1..y0+16, x0-2..x0+17) scaled, split, multiplied (aa, ab, ba), unscaled, summed.
     x (N, c, H, W) float32 numpy -> (N, c, H, W)."""
     import numpy as np
     raw = np.asarray(packed, dtype=np.uint8)
-    nch = nrb = c // 16
+    cout = c if cout is None else cout
+    nch, nrb = c // 16, cout // 16
     body = nch * 5 * nrb * 2 * 64 * 8 * 2
     img = raw[:body].view(np.float16).reshape(nch, 5, nrb, 2, 64, 8).astype(np.float64)
-    tail = raw[body:body + 8 * c].view(np.float32).astype(np.float64)
-    scale, shift = tail[:c], tail[c:]
-    Ws = np.zeros((2, c, c, 10))
+    tail = raw[body:body + 8 * cout].view(np.float32).astype(np.float64)
+    scale, shift = tail[:cout], tail[cout:]
+    Ws = np.zeros((2, cout, c, 10))
     for ch in range(nch):
         for st in range(5):
             for rb in range(nrb):
@@ -736,17 +737,17 @@ def emulate_conv2d_ci_splitf16(packed, x, c, slope=0.01, tile=(16, 16), halo_x=(
                     i, kb = lane & 15, lane >> 4
                     Ws[:, 16 * rb + i, 16 * ch + 8 * (kb & 1):16 * ch + 8 * (kb & 1) + 8, 2 * st + (kb >> 1)] = img[ch, st, rb, :, lane, :]
     assert not Ws[:, :, :, 9].any()
-    Ws = Ws[:, :, :, :9].reshape(2, c, c, 3, 3)
+    Ws = Ws[:, :, :, :9].reshape(2, cout, c, 3, 3)
     N, _, H, W = x.shape
     TY, TX = tile
     hl, hr = halo_x
     py, px = ((H + TY - 1) // TY) * TY - H, ((W + TX - 1) // TX) * TX - W
     xp = np.pad(x.astype(np.float32), ((0, 0), (0, 0), (1, 1 + py), (hl, hr + px)))
-    acc = np.zeros((N, c, H, W))
+    acc = np.zeros((N, cout, H, W))
     for n in range(N):
         for y0 in range(0, H, TY):
             for x0 in range(0, W, TX):
-                out = np.zeros((c, TY, TX))
+                out = np.zeros((cout, TY, TX))
                 for ch in range(nch):
                     halo = xp[n, ch * 16:ch * 16 + 16, y0:y0 + TY + 2, x0:x0 + TX + hl + hr]
                     e = max(int(np.abs(halo).max().view(np.uint32)) >> 23, 15)
@@ -755,7 +756,7 @@ def emulate_conv2d_ci_splitf16(packed, x, c, slope=0.01, tile=(16, 16), halo_x=(
                     xa = xs.astype(np.float16)
                     xb = (xs - xa.astype(np.float32)).astype(np.float16)
                     sl = [xa.astype(np.float64), xb.astype(np.float64)]
-                    part = np.zeros((c, TY, TX))
+                    part = np.zeros((cout, TY, TX))
                     for (sa, sb) in ((0, 0), (0, 1), (1, 0)):
                         wv = Ws[sa][:, ch * 16:ch * 16 + 16]
                         for ky in range(3):

@@ -318,7 +318,7 @@ def test_conv0_splitf16_matches_torch_cpu(dev, report, cin, B, D, H, W, amp):
 
 
 CI_CASES = [(16, 1, 4, 8, 16, 1.0), (16, 2, 5, 9, 36, 1.0), (32, 1, 6, 10, 20, 1.0), (32, 2, 3, 5, 50, 1e-3), (16, 1, 9, 6, 34, 3e4), (32, 1, 4, 4, 16, 1e-30),
-            (16, 1, 2, 3, 2, 1.0)]
+            (16, 1, 2, 3, 2, 1.0), (32, 2, 2, 20, 36, 1.0), (16, 1, 1, 9, 16, 1.0), (32, 8, 2, 128, 160, 1.0)]
 
 
 @pytest.mark.parametrize("c,B,D,H,W,amp", CI_CASES)
@@ -526,24 +526,26 @@ def test_fpn_fused_tail_splitf16_matches_lat_upsample_smooth(dev, report, N, H, 
     assert torch.equal(got_cl, got.permute(0, 2, 3, 1).contiguous())
 
 
-@pytest.mark.parametrize("c,N,H,W,amp", [(16, 1, 16, 16, 1.0), (16, 2, 36, 72, 1.0), (32, 1, 40, 50, 1.0), (32, 3, 128, 160, 1e-3), (16, 1, 9, 34, 3e4),
-                                         (32, 1, 4, 2, 1e-30), (16, 6, 256, 320, 1.0)])
-def test_conv2d_ci_splitf16_matches_torch_cpu(dev, report, c, N, H, W, amp):
+@pytest.mark.parametrize("c,N,H,W,amp,cout", [(16, 1, 16, 16, 1.0, 16), (16, 2, 36, 72, 1.0, 16), (32, 1, 40, 50, 1.0, 32), (32, 3, 128, 160, 1e-3, 32), (16, 1, 9, 34, 3e4, 16),
+                                              (32, 1, 4, 2, 1e-30, 32), (16, 6, 256, 320, 1.0, 16), (32, 2, 36, 72, 1.0, 16), (32, 6, 256, 320, 1.0, 16)])
+def test_conv2d_ci_splitf16_matches_torch_cpu(dev, report, c, N, H, W, amp, cout):
     """csrc/conv2d_ci_splitf16.hip: FeatureNet's conv1.1 / conv1.2 (16 -> 16) and conv2.1 / conv2.2 (32 -> 32) on the f16 matrix cores vs
     torch CPU float64 at the float32 kernel's bound and no worse than a few times that kernel's own error; ragged tiles, persistent loop
     (the last case: 1920 tiles), inputs far outside float16's range."""
     ops = _ops()
     g = torch.Generator().manual_seed(c * 100 + H + W)
     x = torch.randn(N, c, H, W, generator=g) * amp
-    w = torch.randn(c, c, 3, 3, generator=g) * 0.1
-    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1 * amp
+    w = torch.randn(cout, c, 3, 3, generator=g) * 0.1
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1 * amp
     want = F.conv2d(x.double(), w.double(), None, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
     want = torch.where(want > 0, want, want * 0.01)
     xd = x.to(dev)
-    got = ops.conv2d_ci_splitf16_forward(ops.conv2d_ci_splitf16_pack(w, scale, shift).to(dev), xd, slope=0.01).cpu()
-    f32 = ops.conv2d_forward(ops.CONV2D_K3, ops.conv2d_pack(ops.CONV2D_K3, w, scale, shift).to(dev), xd, c, slope=0.01).cpu()
+    got, got_cl = ops.conv2d_ci_splitf16_forward(ops.conv2d_ci_splitf16_pack(w, scale, shift).to(dev), xd, cout=cout, slope=0.01, channels_last_copy=True)
+    assert torch.equal(got_cl, got.permute(0, 2, 3, 1).contiguous())
+    got = got.cpu()
+    f32 = ops.conv2d_forward(ops.CONV2D_K3, ops.conv2d_pack(ops.CONV2D_K3, w, scale, shift).to(dev), xd, cout, slope=0.01).cpu()
     e3, ef = scaled_err(got, want), scaled_err(f32, want)
-    report("conv2d_ci_splitf16", shape=[c, N, H, W], amp=amp, err_splitf16=e3, err_f32_mfma=ef)
+    report("conv2d_ci_splitf16", shape=[c, cout, N, H, W], amp=amp, err_splitf16=e3, err_f32_mfma=ef)
     assert torch.isfinite(got).all()
     assert e3 < 1.2e-5 and e3 < 4 * max(ef, 2e-7)
 
