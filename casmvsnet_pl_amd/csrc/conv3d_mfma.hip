@@ -2300,6 +2300,7 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
                  "%s: conv0_arith=%d", who, conv0_arith);
   const void *conv0_split = split_layers ? split_layers[0] : nullptr;
   const void *conv2_split = split_layers ? split_layers[1] : nullptr, *conv4_split = split_layers ? split_layers[2] : nullptr;
+  const void *conv6_split = split_layers ? split_layers[3] : nullptr;
   CASMVS_REQUIRE(conv0_arith == CASMVS_CONV0_F32 || conv0_split, "%s: conv0_arith=%d needs the split image of conv0", who, conv0_arith);
   const bool split_ok = (reinterpret_cast<size_t>(vol) & 15) == 0;
   if (conv0_arith == CASMVS_CONV0_SPLIT_BF16 && split_ok && casmvs_conv0_splitbf16_supported(cin, w)) {
@@ -2340,7 +2341,16 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     CASMVS_L(CASMVS_CONV_S1, P[4], c3, nullptr, c4, B, 32, 32, D / 4, h / 4, w / 4, sl, stream);    // conv4
   }
   CASMVS_L(CASMVS_CONV_S2, P[5], c4, nullptr, c5, B, 32, 64, D / 4, h / 4, w / 4, sl, stream);      // conv5
-  CASMVS_L(CASMVS_CONV_S1, P[6], c5, nullptr, c6, B, 64, 64, D / 8, h / 8, w / 8, sl, stream);      // conv6
+  // conv6 on the f16 matrix cores where the volume has >= 3 planes and enough 4 x 4 x 16 tiles (as conv4)
+  const long conv6_tiles = (long)B * casmvs::ceil_div(D / 8, 4) * casmvs::ceil_div(h / 8, 4) * casmvs::ceil_div(w / 8, 16);
+  if (conv6_split && casmvs_conv_ci_splitf16_supported(64, 64, w / 8) && D / 8 >= 3 && conv6_tiles >= 100) {
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv_ci_splitf16_forward_f32(conv6_split, c5, c6, B, 64, 64, D / 8, h / 8, w / 8, sl, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV_S1, P[6], c5, nullptr, c6, B, 64, 64, D / 8, h / 8, w / 8, sl, stream);      // conv6
+  }
   CASMVS_L(CASMVS_CONV_T2, P[7], c6, c4, u7, B, 64, 32, D / 8, h / 8, w / 8, sl, stream);           // conv4 + conv7
   CASMVS_L(CASMVS_CONV_T2, P[8], u7, c2, u9, B, 32, 16, D / 4, h / 4, w / 4, sl, stream);           // conv2 + conv9
   CASMVS_L(CASMVS_CONV_T2, P[9], u9, c0, u11, B, 16, 8, D / 2, h / 2, w / 2, sl, stream);           // conv0 + conv11

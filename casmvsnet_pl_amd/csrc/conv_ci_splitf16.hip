@@ -1,4 +1,4 @@
-// CostRegNet's stride-1 U-Net layers with 16 or 32 channels on both sides (conv2: 16 -> 16, conv4: 32 -> 32; Conv3d k3 s1 p1 +
+// CostRegNet's stride-1 U-Net layers with equal channel counts (conv2: 16 -> 16, conv4: 32 -> 32, conv6: 64 -> 64; Conv3d k3 s1 p1 +
 // folded ABN + leaky-relu) on the f16 matrix cores with float32-grade arithmetic - the arithmetic of conv0_splitf16.hip
 // (every float32 operand = two float16 slices behind exact power-of-two scalings, three partial products, float32
 // accumulation) in the channel-inner ("CI") matrix form.
@@ -337,7 +337,7 @@ int launch_ci(const void *packed, const float *in, float *out, int B, int D, int
   return casmvs::check_launch("conv_ci_sf_kernel");
 }
 
-inline bool ci_shape_ok(int cin, int cout) { return (cin == 16 && cout == 16) || (cin == 32 && cout == 32); }
+inline bool ci_shape_ok(int cin, int cout) { return (cin == 16 && cout == 16) || (cin == 32 && cout == 32) || (cin == 64 && cout == 64); }
 
 }  // namespace
 
@@ -353,7 +353,7 @@ extern "C" size_t casmvs_conv_ci_splitf16_packed_bytes(int cin, int cout) {
 extern "C" int casmvs_conv_ci_splitf16_pack(int cin, int cout, const float *weight, const float *scale, const float *shift, void *packed) {
   casmvs::clear_error();
   CASMVS_REQUIRE(weight && packed, "conv_ci_splitf16_pack: null pointer");
-  CASMVS_REQUIRE(ci_shape_ok(cin, cout), "conv_ci_splitf16_pack: cin=%d cout=%d (16 -> 16 or 32 -> 32)", cin, cout);
+  CASMVS_REQUIRE(ci_shape_ok(cin, cout), "conv_ci_splitf16_pack: cin=%d cout=%d (16 -> 16, 32 -> 32 or 64 -> 64)", cin, cout);
   float wmax = 0.0f;
   for (size_t i = 0; i < (size_t)cout * cin * 27; ++i) {
     CASMVS_REQUIRE(std::isfinite(weight[i]), "conv_ci_splitf16_pack: weight %zu is not finite", i);
@@ -401,5 +401,9 @@ extern "C" int casmvs_conv_ci_splitf16_forward_f32(const void *packed, const flo
   hipStream_t st = (hipStream_t)stream;
   // volumes of at most 2 planes (conv4 at cascade level 0: D / 4 = 2): the 2 x 8 x 16 tile - a 4-deep tile would be half padding
   if (cin == 16) return D <= 2 ? launch_ci<16, 16, 2>(packed, in, out, B, D, H, W, slope, st) : launch_ci<16, 16, 4>(packed, in, out, B, D, H, W, slope, st);
-  return D <= 2 ? launch_ci<32, 32, 2>(packed, in, out, B, D, H, W, slope, st) : launch_ci<32, 32, 4>(packed, in, out, B, D, H, W, slope, st);
+  if (cin == 32) return D <= 2 ? launch_ci<32, 32, 2>(packed, in, out, B, D, H, W, slope, st) : launch_ci<32, 32, 4>(packed, in, out, B, D, H, W, slope, st);
+  // 64 -> 64: a chunk's lane images are 112 KiB - with the 45 KiB tile that is the whole LDS of a CU (one workgroup; the 2 x 8 x 16 tile
+  // does not fit: volumes of <= 2 planes stay on the float32 kernel, casmvs_conv_ci_splitf16_supported_volume)
+  CASMVS_REQUIRE(D >= 3, "conv_ci_splitf16_forward: 64 -> 64 needs D >= 3 (D=%d)", D);
+  return launch_ci<64, 64, 4>(packed, in, out, B, D, H, W, slope, st);
 }

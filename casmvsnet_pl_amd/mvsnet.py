@@ -230,8 +230,8 @@ class CostRegNet(_PackedWeights, nn.Module):
         self._init_packed()       # _packed: list of 11 device tensors
         self._conv0_sb = None     # conv0's split-bf16 image (uint8 device tensor)
         self._conv0_sf = None     # conv0's split-f16 image
-        self._ci_sf = None        # (conv2, conv4) split-f16 images
-        self.ci_mode = "splitf16" # conv2 / conv4 in `regress`: "splitf16" (f16 matrix cores, conv_ci_splitf16.hip) or "f32"
+        self._ci_sf = None        # (conv2, conv4, conv6) split-f16 images
+        self.ci_mode = "splitf16" # conv2 / conv4 / conv6 in `regress`: "splitf16" (f16 matrix cores, conv_ci_splitf16.hip) or "f32"
         # conv0's arithmetic in `regress` (the engine's eval path), all float32-grade (distance to a float64 convolution at or
         # below the float32 MFMA kernel's):
         #   "splitf16":  f16 matrix cores, every float32 operand as two float16 slices behind exact power-of-two scalings (per
@@ -278,7 +278,7 @@ class CostRegNet(_PackedWeights, nn.Module):
         else:
             self._conv0_sb = self._conv0_sf = None
         ci = []
-        for name in ("conv2", "conv4"):
+        for name in ("conv2", "conv4", "conv6"):
             m = getattr(self, name)
             sc, sh, _ = _fold_norm(f"CostRegNet.{name}", m.bn)
             ci.append(ops.conv_ci_splitf16_pack(m.conv.weight, sc, sh).to(device))
@@ -320,9 +320,9 @@ class CostRegNet(_PackedWeights, nn.Module):
             split, arith = self._conv0_sb, ops.CONV0_SPLIT_BF16
         if self.ci_mode not in ("splitf16", "f32"):
             raise ValueError(f"CostRegNet.ci_mode={self.ci_mode!r} (splitf16 or f32)")
-        c2, c4 = self._ci_sf if self.ci_mode == "splitf16" else (None, None)
+        c2, c4, c6 = self._ci_sf if self.ci_mode == "splitf16" else (None, None, None)
         return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index,
-                                   conv0_split=split, conv0_arith=arith, conv2_split=c2, conv4_split=c4)
+                                   conv0_split=split, conv0_arith=arith, conv2_split=c2, conv4_split=c4, conv6_split=c6)
 
 
 class CascadeMVSNet(nn.Module):

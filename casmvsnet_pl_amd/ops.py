@@ -353,7 +353,7 @@ def conv_ci_splitf16_pack(weight, scale=None, shift=None):
     lib = _lib.load()
     n = lib.casmvs_conv_ci_splitf16_packed_bytes(cin, cout)
     if tuple(weight.shape[2:]) != (3, 3, 3) or n == 0:
-        raise ValueError(f"conv_ci_splitf16_pack: weight {tuple(weight.shape)} (need (16, 16, 3, 3, 3) or (32, 32, 3, 3, 3))")
+        raise ValueError(f"conv_ci_splitf16_pack: weight {tuple(weight.shape)} (need (c, c, 3, 3, 3) with c in 16, 32, 64)")
     packed = torch.empty(n, dtype=torch.uint8)
     sc = None if scale is None else scale.detach().to("cpu", torch.float32).contiguous()
     sh = None if shift is None else shift.detach().to("cpu", torch.float32).contiguous()
@@ -413,13 +413,13 @@ CONV0_F32, CONV0_SPLIT_BF16, CONV0_SPLIT_F16 = 0, 1, 2   # casmvs.h: CASMVS_CONV
 
 
 def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, layer_events=None, return_index=False, conv0_split=None,
-                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None):
+                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None, conv6_split=None):
     """CostRegNet + softmax / depth regression / confidence in one library call (mvsnet.py:91-104 + :174-193): the `prob`
     head walks the depth axis and, when the whole depth range is one chunk, runs the regression on the cost values it has
     just produced (casmvs_costreg_regress_f32).  -> cost (B,D,h,w), depth (B,h,w), confidence (B,h,w) [, index int32].
     conv0_arith: CONV0_F32 (conv0 on the float32 MFMA kernel), CONV0_SPLIT_BF16 / CONV0_SPLIT_F16 with conv0_split = the device
     image of conv0_splitbf16_pack / conv0_splitf16_pack (conv0 on the bf16 / f16 matrix cores with float32-grade arithmetic).
-    conv2_split / conv4_split: device images of conv_ci_splitf16_pack (those layers on the f16 matrix cores) or None."""
+    conv2_split / conv4_split / conv6_split: device images of conv_ci_splitf16_pack (those layers on the f16 matrix cores) or None."""
     vol, depth_values = _dev(vol, "vol"), _dev(depth_values, "depth_values")
     B, cin, D, h, w = vol.shape
     if tuple(depth_values.shape) != (B, D, h, w):
@@ -440,8 +440,8 @@ def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, lay
             raise ValueError("costreg_regress: need 12 events")
         ev = (ctypes.c_void_p * 12)(*[e.cuda_event for e in layer_events])
     split = None
-    if conv0_split is not None or conv2_split is not None or conv4_split is not None:
-        split = (ctypes.c_void_p * 3)(*[None if t is None else t.data_ptr() for t in (conv0_split, conv2_split, conv4_split)])
+    if conv0_split is not None or conv2_split is not None or conv4_split is not None or conv6_split is not None:
+        split = (ctypes.c_void_p * 4)(*[None if t is None else t.data_ptr() for t in (conv0_split, conv2_split, conv4_split, conv6_split)])
     with torch.cuda.device(dev):
         rc = _lib.load().casmvs_costreg_regress_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
                                                     _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,

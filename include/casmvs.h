@@ -207,9 +207,9 @@ int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float
                                       float slope, int terms, void *stream);
 int casmvs_selftest_mfma_f16(float *dump);
 
-/* CostRegNet's stride-1 layers with equal channel counts (conv2: 16 -> 16, conv4: 32 -> 32; Conv3d k3 s1 p1 + folded ABN + leaky-relu,
- * mvsnet.py:66,69) in the arithmetic of casmvs_conv0_splitf16_forward_f32, channel-inner matrix form (csrc/conv_ci_splitf16.hip).
- * (cin, cout) in {(16, 16), (32, 32)}, W % 2 == 0, tensors 8-byte aligned.  `packed`: HOST image from casmvs_conv_ci_splitf16_pack
+/* CostRegNet's stride-1 layers with equal channel counts (conv2: 16 -> 16, conv4: 32 -> 32, conv6: 64 -> 64; Conv3d k3 s1 p1 + folded ABN +
+ * leaky-relu, mvsnet.py:66,69,72) in the arithmetic of casmvs_conv0_splitf16_forward_f32, channel-inner matrix form
+ * (csrc/conv_ci_splitf16.hip).  (cin, cout) in {(16, 16), (32, 32), (64, 64)} (64 -> 64: D >= 3), W % 2 == 0, tensors 8-byte aligned.  `packed`: HOST image from casmvs_conv_ci_splitf16_pack
  * (weight (cout, cin, 3, 3, 3) finite, scale / shift (cout) or NULL), copied to the device (16-byte aligned) by the caller. */
 size_t casmvs_conv_ci_splitf16_packed_bytes(int cin, int cout);
 int casmvs_conv_ci_splitf16_pack(int cin, int cout, const float *weight, const float *scale, const float *shift, void *packed);
@@ -345,8 +345,9 @@ int casmvs_debug_disturb(int kind, int blocks, int iters, int lds_bytes, float *
  * event 11 after the head INCLUDING the regression).  conv0_arith selects conv0's arithmetic: CASMVS_CONV0_F32 (the float32
  * MFMA kernel on packed_layers[0]), CASMVS_CONV0_SPLIT_BF16 / CASMVS_CONV0_SPLIT_F16 with split_layers[0] = the DEVICE copy of
  * casmvs_conv0_splitbf16_pack's / casmvs_conv0_splitf16_pack's image of conv0 (cin 8 / 16 / 32; any other shape falls back to the
- * float32 kernel).  split_layers: NULL, or 3 pointers { conv0 image or NULL, conv2 image or NULL, conv4 image or NULL }; a non-NULL
- * conv2 / conv4 entry (DEVICE copy of casmvs_conv_ci_splitf16_pack's image) runs that layer on the f16 matrix cores too. */
+ * float32 kernel).  split_layers: NULL, or 4 pointers { conv0, conv2, conv4, conv6 images, each or NULL }; a non-NULL conv2 / conv4 / conv6
+ * entry (DEVICE copy of casmvs_conv_ci_splitf16_pack's image) runs that layer on the f16 matrix cores too (conv4 / conv6 only where the
+ * volume gives >= 100 tiles; conv6 only with >= 3 planes). */
 #define CASMVS_CONV0_F32 0
 #define CASMVS_CONV0_SPLIT_BF16 1
 #define CASMVS_CONV0_SPLIT_F16 2

@@ -280,7 +280,7 @@ def test_conv0_splitf16_packing_and_partial_products(cin, terms, shape, amp):
 
 
 @pytest.mark.parametrize("c,shape,amp", [(16, (3, 4, 6), 1.0), (16, (5, 6, 18), 1e-3), (32, (2, 3, 8), 1.0), (16, (4, 5, 34), 3e4), (32, (5, 2, 20), 1e-30),
-                                         (32, (2, 10, 18), 1.0)])
+                                         (32, (2, 10, 18), 1.0), (64, (3, 4, 6), 1.0)])
 def test_conv_ci_splitf16_packing_and_partial_products(c, shape, amp):
     """csrc/conv_ci_splitf16.hip: the C packer's lane images (tap pairs x 16 channels per step, 2^kw w as two float16 slices, the
     28th tap zero) decoded lane by lane, with the kernel's per-(tile, chunk) scaling and two-slice split of the activations,

@@ -318,7 +318,8 @@ def test_conv0_splitf16_matches_torch_cpu(dev, report, cin, B, D, H, W, amp):
 
 
 CI_CASES = [(16, 1, 4, 8, 16, 1.0), (16, 2, 5, 9, 36, 1.0), (32, 1, 6, 10, 20, 1.0), (32, 2, 3, 5, 50, 1e-3), (16, 1, 9, 6, 34, 3e4), (32, 1, 4, 4, 16, 1e-30),
-            (16, 1, 2, 3, 2, 1.0), (32, 2, 2, 20, 36, 1.0), (16, 1, 1, 9, 16, 1.0), (32, 8, 2, 128, 160, 1.0)]
+            (16, 1, 2, 3, 2, 1.0), (32, 2, 2, 20, 36, 1.0), (16, 1, 1, 9, 16, 1.0), (32, 8, 2, 128, 160, 1.0), (64, 1, 4, 8, 16, 1.0), (64, 2, 6, 10, 36, 1e-3),
+            (64, 8, 4, 32, 40, 1.0)]
 
 
 @pytest.mark.parametrize("c,B,D,H,W,amp", CI_CASES)
