@@ -624,10 +624,13 @@ def main():
                                                            "(conv0_splitf16.hip); float32-grade: distance to a float64 convolution at or below the "
                                                            "float32 MFMA kernel's",
                                                "f32": "float32 MFMA (v_mfma_f32_16x16x4_f32)"}[model.cost_reg_0.conv0_mode],
-                          "conv2_conv4_arithmetic": "as conv0's split-f16 (conv_ci_splitf16.hip); conv4 only where its tiles are full (levels 1, 2)"
-                                                    if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA",
-                          "fpn_tail_arithmetic": ("as conv0's split-f16 (fpn_fused_sf.hip)" if model.feature.tail_mode == "splitf16" else "float32 MFMA (fpn_fused.hip)")
-                                                 if model.feature.fuse_tail else "three float32 steps (lat0, upsample-add, smooth0)"},
+                          "conv2_conv4_conv6_arithmetic": "as conv0's split-f16 (conv_ci_splitf16.hip); conv4 / conv6 only where the volume gives >= 100 tiles "
+                                                          "(conv6: >= 3 planes)" if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA",
+                          "featurenet_arithmetic": ("fused FPN tail, conv1.1 / conv1.2 / conv2.1 / conv2.2 / smooth1 as conv0's split-f16 (fpn_fused_sf.hip, "
+                                                    "conv2d_ci_splitf16.hip); the other layers float32 MFMA" if model.feature.tail_mode == "splitf16"
+                                                    else "float32 MFMA (fused FPN tail: fpn_fused.hip)")
+                                                   if model.feature.fuse_tail else "float32 MFMA, the FPN tail as three steps (lat0, upsample-add, smooth0)",
+                          "every_layer_float32_value": "conv0_other_modes.modes[conv0_mode == 'f32'] of this line"},
                          median)
         line["library_sha16"] = library_sha16()
 
