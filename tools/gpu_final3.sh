@@ -17,6 +17,7 @@ print('mfma 16x16x4 blocks 2048 TFLOP/s %.1f' % ops.selftest_mfma_rate(1, 2048, 
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit: $?" >> $OUT/pytest_gpu.log
 cp gpurun_out/parity_report.json $OUT/ 2>/dev/null
+timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke exit: $?" >> $OUT/smoke.log
 # PMC passes FIRST, so that the bench line below reads the traffic figures of THIS build (bench.py: pmc_traffic)
 export PMC_BATCH=${BENCH_BATCH:-8}
 export PMC_CMD_NOTE="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-events --no-batch1 --batch $PMC_BATCH"
@@ -42,11 +43,12 @@ for cfg in dtu_1152x864_v5_var blended_768x576_v7_var; do
      --mode view_sharded --config $cfg --batch 1 --steps 10 --warmup 3 --no-cpu-baseline --no-events 2>> $OUT/bench.err | grep "^{" > $OUT/bench_viewsharded_$cfg.json
 done
 timeout 400 python bench.py --mode train --steps 10 --warmup 3 > $OUT/bench_train.json 2>> $OUT/bench.err
-timeout 300 python tools/gpu_files_throughput.py 49 16 64 128 2>/dev/null > $OUT/files_throughput.txt
+timeout 300 python tools/gpu_files_throughput.py 49 64 128 2>/dev/null > $OUT/files_throughput.txt
+timeout 100 python tools/gpu_fpn_probe.py 2>/dev/null | grep "^N" > $OUT/fpn_probe.txt
 timeout 200 python tools/gpu_conv0_probe.py 2>/dev/null | grep -v amdgpu > $OUT/conv0_probe.txt
 LAYER_PROBE_ITEMS=bottom,deconv timeout 200 python tools/gpu_layer_probe.py 2>/dev/null | grep -v amdgpu > $OUT/layer_probe.txt
 for d in k0:1024 k1:1024 none; do DISTURB=$d timeout 100 python tools/debug/disturber.py 2>&1 | grep "^disturber" >> $OUT/mfma_coresidency_recheck.txt; done
-cat $OUT/mfma_rate.txt; tail -4 $OUT/pytest_gpu.log; python tools/show_bench.py $OUT/bench.json | head -8; tail -3 $OUT/bench.err; cat $OUT/summarize.log | tail -3
+cat $OUT/mfma_rate.txt; tail -4 $OUT/pytest_gpu.log; tail -3 $OUT/smoke.log; python tools/show_bench.py $OUT/bench.json | head -8; tail -3 $OUT/bench.err; cat $OUT/summarize.log | tail -3
 for f in $OUT/bench_*.json; do python -c "
 import json,sys
 j=json.load(open('$f')); print('$(basename $f)', round(j['value'],1), j['unit'], str(j['config'].get('launch'))[:40], j.get('two_streams_float32',{}).get('value'), j.get('batch1',{}).get('value'))" 2>/dev/null; done
