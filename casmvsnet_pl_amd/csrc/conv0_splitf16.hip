@@ -66,17 +66,6 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
 // 8 channels of one voxel, scaled by the tile's power of two -> the two 16-byte float16 vectors: split_f16.h
 __device__ __forceinline__ void split_voxel_f16(const float (&x)[8], float mult, u32x4 (&o)[2]) { casmvs::split8_f16(x, mult, o); }
 
-// maximum over the wave of a non-negative float's bit pattern (DPP inside rows of 16, scalar across the four rows)
-__device__ __forceinline__ unsigned wave_max_bits(unsigned v) {
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
-  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-  const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-  return max(max(a, b), max(c, d));
-}
-
 struct SfTile {
   int tx0, ty0, tz0, b;
 };
@@ -178,14 +167,11 @@ __global__ __launch_bounds__(SfCfg::THREADS, 2) void conv0_sf_kernel(const float
         for (int c = 0; c < 8; ++c)
 #pragma unroll
           for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(R[r][c][j]));
-      const unsigned wm = wave_max_bits(__builtin_bit_cast(unsigned, m));
+      const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
       if (lane == 0) wmax[wave] = wm;
       __syncthreads();   // every wave is done with the previous chunk's LDS; the four maxima are visible
-      const u32x4 w4 = *reinterpret_cast<const u32x4 *>(wmax);
-      int e = (int)(max(max(w4[0], w4[1]), max(w4[2], w4[3])) >> 23);
-      e = e < 15 ? 15 : e;                                                    // (an all-zero or denormal tile: 2^126)
-      const float mult = __builtin_bit_cast(float, (unsigned)(268 - e) << 23);   // max |x| 2^kx in [2^14, 2^15)
-      const float inv = __builtin_bit_cast(float, (unsigned)(e - 14) << 23);     // 2^-kx
+      float mult, inv;   // max |x| 2^kx in [2^14, 2^15); 2^-kx
+      casmvs::tile_scale(wmax, mult, inv);
       // ---- registers -> LDS: the two float16 slices of every staged voxel, the chunk's lane images ----
       if (NCH > 1 || first) {
 #pragma unroll

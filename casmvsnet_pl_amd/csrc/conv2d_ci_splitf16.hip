@@ -47,16 +47,6 @@ __device__ __forceinline__ f32x4 mfma_f16_c2(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ unsigned wave_max_bits_c2(unsigned v) {
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
-  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-  const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-  return max(max(a, b), max(c, d));
-}
-
 // in (N, CIN, H, W) float32, W % 2 == 0, 8-byte aligned; wpk: [chunk][step][row block][slice][lane] 16-byte lane images, then scale[COUT]
 // (ABN scale x 2^-kw), shift[COUT]; out (N, COUT, H, W); out2: NULL or (N, H, W, COUT) pixel-major (16-byte aligned).
 template <int CIN, int COUT>
@@ -149,14 +139,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__res
       float m = 0.0f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) m = fmaxf(m, fmaxf(fabsf(R[c][0]), fabsf(R[c][1])));
-      const unsigned wm = wave_max_bits_c2(__builtin_bit_cast(unsigned, m));
+      const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
       if (lane == 0) wmax[wave] = wm;
       __syncthreads();   // every wave is done with the previous chunk's LDS; the four maxima (first time: the lane images) are visible
-      const u32x4 w4 = *reinterpret_cast<const u32x4 *>(wmax);
-      int e = (int)(max(max(w4[0], w4[1]), max(w4[2], w4[3])) >> 23);
-      e = e < 15 ? 15 : e;
-      const float mult = __builtin_bit_cast(float, (unsigned)(268 - e) << 23);   // max |x| 2^kx in [2^14, 2^15)
-      const float inv = __builtin_bit_cast(float, (unsigned)(e - 14) << 23);     // 2^-kx
+      float mult, inv;   // max |x| 2^kx in [2^14, 2^15); 2^-kx
+      casmvs::tile_scale(wmax, mult, inv);
       if (vox >= 0) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {

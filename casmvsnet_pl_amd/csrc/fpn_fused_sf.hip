@@ -11,7 +11,8 @@
 //
 // Formulation: PX form of conv0_splitf16.hip in 2D - rows = (8 output channels x 2 x-phases), K = 32 = 4 input x-offsets x 8
 // channels of a chunk, 5 chunks (chunk 0: conv0's 8 channels, chunks 1-4: 8 upsampled channels each), 3 row taps.  Workgroup =
-// 256 threads, output tile 16 x 32 pixels, wave w = rows 4 w .. 4 w + 3; halo tile 18 x 40 pixels x 2 slices x 16 B = 23 KiB;
+// 256 threads, output tile 20 x 32 pixels, wave w = rows 5 w .. 5 w + 4; halo tile 22 x 40 pixels x 2 slices x 16 B = 28 KiB
+// (220 staging items on the 256 threads: one round at 86 % lane use; a 16-row tile used 70 %);
 // the lane images of all 5 chunks (30 KiB) stay in LDS: persistent workgroups, tiles XCD-major.  One staging item = (row, 4 x)
 // x 8 channels: 8 (direct) or 16 (two source rows) 16-byte loads, in flight during the previous chunk's matrix phase.
 #include <cmath>
@@ -31,12 +32,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct FsCfg {
-  static constexpr int THREADS = 256, NT = 4;
-  static constexpr int TY = 16, TX = 32;
-  static constexpr int IY = TY + 2, IX = TX + 8;                    // rows y0 - 1 .. y0 + 16, columns x0 - 4 .. x0 + 35
-  static constexpr int ROW = IX + 1, NV = IY * ROW;                 // 16-byte slots per staged row / per slice: 738
+  static constexpr int THREADS = 256, NT = 5;
+  static constexpr int TY = 4 * NT, TX = 32;
+  static constexpr int IY = TY + 2, IX = TX + 8;                    // rows y0 - 1 .. y0 + 20, columns x0 - 4 .. x0 + 35
+  static constexpr int ROW = IX + 1, NV = IY * ROW;                 // 16-byte slots per staged row / per slice: 902
   static __host__ __device__ constexpr int slot(int x) { return x ^ (((x >> 3) & 1) << 1); }   // as SfCfg::slot
-  static constexpr int ITEMS = IY * (IX / 4);                       // 180: one round
+  static constexpr int ITEMS = IY * (IX / 4);                       // 220: one round
+  static_assert(ITEMS <= THREADS, "one staging round");
   static constexpr int CD = 8, CU = 32, NCH = (CD + CU) / 8;        // 5 chunks
   static constexpr int WUNITS = NCH * 3 * 2 * 64;                   // [chunk][ky][slice][lane]: 1920 16-byte units
   static constexpr int NWL = (WUNITS + THREADS - 1) / THREADS;      // 8
@@ -44,7 +46,7 @@ struct FsCfg {
 #ifndef CASMVS_FS_LDS_PAD
 #define CASMVS_FS_LDS_PAD 0   // debug builds: extra dynamic LDS per workgroup (e.g. 50000: one workgroup per CU)
 #endif
-  static constexpr size_t LDS_BYTES = ACT_BYTES + W_BYTES + 16 + CASMVS_FS_LDS_PAD;     // 54 352
+  static constexpr size_t LDS_BYTES = ACT_BYTES + W_BYTES + 16 + CASMVS_FS_LDS_PAD;     // 59 600
 };
 
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
@@ -52,16 +54,6 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
 }
 
 __device__ __forceinline__ void split8(const float (&x)[8], float mult, u32x4 (&o)[2]) { casmvs::split8_f16(x, mult, o); }   // split_f16.h
-
-__device__ __forceinline__ unsigned wave_max_bits_fs(unsigned v) {
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
-  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-  const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-  return max(max(a, b), max(c, d));
-}
 
 // c0 (N, 8, H, W), f1 (N, 32, H/2, W/2); wpk: [chunk][ky][slice][lane] 16-byte lane images, then unscale = 2^-kw (one float);
 // bias9 (3, 3, 8): [row class][column class][co].  out (N, 8, H, W); out2: NULL or (N, H, W, 8) pixel-major.
@@ -95,8 +87,8 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
   const float sx = W > 1 ? (float)(wc - 1) / (float)(W - 1) : 0.0f;
   const rsrc_t none = make_rsrc(c0, 0);
 
-  // lane's B slot of staged row 0 of this wave's first output row (ky = 0): (4 wave) * ROW + slot(2 j + u + 3)
-  const int vbase = 4 * wave * Cfg::ROW + Cfg::slot(2 * jcol + u + 3);
+  // lane's B slot of staged row 0 of this wave's first output row (ky = 0): (NT wave) * ROW + slot(2 j + u + 3)
+  const int vbase = NT * wave * Cfg::ROW + Cfg::slot(2 * jcol + u + 3);
 
   // staging plan of a tile: item e = tid -> (staged row, 4-x group).  Two parts: the integer part (what the chunk-0 prefetch of the
   // next tile needs) runs in the last chunk of the current tile; the floating-point part (the interpolation constants of chunks
@@ -203,14 +195,11 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
       for (int c = 0; c < 8; ++c)
 #pragma unroll
         for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(V[c][j]));
-      const unsigned wm = (CASMVS_FS_DEBUG & 4) ? 0x47000000u : wave_max_bits_fs(__builtin_bit_cast(unsigned, m));
+      const unsigned wm = (CASMVS_FS_DEBUG & 4) ? 0x47000000u : casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
       if (lane == 0) wmax[wave] = wm;
       __syncthreads();   // every wave is done with the previous chunk's LDS; the four maxima (and, first time, the lane images) are visible
-      const u32x4 w4 = *reinterpret_cast<const u32x4 *>(wmax);
-      int e = (int)(max(max(w4[0], w4[1]), max(w4[2], w4[3])) >> 23);
-      e = e < 15 ? 15 : e;
-      const float mult = __builtin_bit_cast(float, (unsigned)(268 - e) << 23);   // max |x| 2^kx in [2^14, 2^15)
-      const float inv = __builtin_bit_cast(float, (unsigned)(e - 14) << 23);     // 2^-kx
+      float mult, inv;   // max |x| 2^kx in [2^14, 2^15); 2^-kx
+      casmvs::tile_scale(wmax, mult, inv);
       if (vox >= 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -260,7 +249,7 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
     const rsrc_t dst2 = make_rsrc(out2 ? out2 + (size_t)n * 8 * hw : out, (size_t)8 * hw * 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int oy = ty0 + 4 * wave + t, ox = tx0 + 2 * jcol;
+      const int oy = ty0 + NT * wave + t, ox = tx0 + 2 * jcol;
       const bool ok = oy < H && ox < W;   // W even: the pixel pair is inside or outside
       const int rcls = oy == 0 ? 0 : (oy == H - 1 ? 2 : 1);
       const int c0cls = ox == 0 ? 0 : 1, c1cls = ox + 1 == W - 1 ? 2 : 1;   // ox even: never the last column; ox + 1 odd: never the first

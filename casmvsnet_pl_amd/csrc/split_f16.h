@@ -39,4 +39,25 @@ __device__ __forceinline__ void split8_f16(const float (&x)[8], float mult, spli
   }
 }
 
+// maximum over the wave of a non-negative float's bit pattern (DPP inside rows of 16, scalar across the four rows)
+__device__ __forceinline__ unsigned wave_max_bits(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
+  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return max(max(a, b), max(c, d));
+}
+
+// The staged tile's power-of-two scaling from the four waves' maxima (bit patterns of non-negative floats, 16-byte aligned in LDS):
+// mult = 2^kx puts the largest magnitude into [2^14, 2^15), inv = 2^-kx; an all-zero or denormal tile is scaled by 2^126.
+__device__ __forceinline__ void tile_scale(const unsigned *wave_maxima, float &mult, float &inv) {
+  const split_u32x4 w4 = *reinterpret_cast<const split_u32x4 *>(wave_maxima);
+  int e = (int)(max(max(w4[0], w4[1]), max(w4[2], w4[3])) >> 23);
+  e = e < 15 ? 15 : e;
+  mult = __builtin_bit_cast(float, (unsigned)(268 - e) << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(e - 14) << 23);
+}
+
 }  // namespace casmvs

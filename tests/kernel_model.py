@@ -504,9 +504,9 @@ def emulate_fpn_tail0(packed40, bias9, c0, f1):
     return out
 
 
-def emulate_fpn_tail0_splitf16(packed, bias9, c0, f1, tile=(16, 32)):
+def emulate_fpn_tail0_splitf16(packed, bias9, c0, f1, tile=(20, 32)):
     """Data flow of fpn_tail0_sf_kernel in float64: the 40-channel input [c0 | up(f1)] (float32: the upsample by torch's ATen kernel,
-    whose rule the kernel restates) is staged per 16 x 32 output tile and chunk of 8 channels as the halo tile (y0-1..y0+16,
+    whose rule the kernel restates) is staged per 20 x 32 output tile and chunk of 8 channels as the halo tile (y0-1..y0+20,
     x0-4..x0+35; zero outside), scaled to [2^14, 2^15), split into two float16 slices and multiplied (aa, ab, ba) with the packer's
     lane images [chunk][ky][slice][lane][8 f16]; chunks unscaled and summed; then 2^-kw and the nine border bias classes.
     c0 (8, H, W), f1 (32, H/2, W/2) numpy float32 -> (8, H, W)."""
