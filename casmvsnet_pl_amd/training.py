@@ -356,9 +356,57 @@ def variance_volume(feats, proj_mats, depth_values):
     return _VarianceVolume.apply(feats, proj_mats, depth_values)
 
 
+class _GroupwiseVolume(torch.autograd.Function):
+    """mvsnet.py:142-144,157-162,169-172.  Forward: the fused inference kernel (no warped volume is materialised or kept for the
+    backward).  Backward, from the saved features: the gradient of every warped volume is the SAME tensor
+    gw[b,c,d] = g[b,c // (C/G),d] * ref[b,c] / (C/G * (V-1)) (built once), scattered to each source view by the warp's HIP backward
+    kernel; the reference view's gradient needs the sum of the warped volumes, recomputed one view at a time."""
+
+    @staticmethod
+    def forward(ctx, feats, proj_mats, depth_values, G):
+        feats = feats.contiguous().float()
+        proj_mats, depth_values = proj_mats.detach().contiguous().float(), depth_values.detach().contiguous().float()
+        ctx.save_for_backward(feats, proj_mats, depth_values)
+        ctx.G = int(G)
+        B, V, C, h, w = feats.shape
+        if C in (8, 16, 32):   # pixel-major copy: what the fast forward kernels read
+            nhwc = ops.nchw_to_nhwc(feats.reshape(B * V, C, h, w)).view(B, V, h, w, C)
+            return ops.costvol(nhwc, proj_mats, depth_values, ctx.G, channels_last=True)
+        return ops.costvol(feats, proj_mats, depth_values, ctx.G)
+
+    @staticmethod
+    def backward(ctx, gvol):
+        feats, proj_mats, depth_values = ctx.saved_tensors
+        B, V, C, h, w = feats.shape
+        G, D = ctx.G, depth_values.shape[1]
+        cg = C // G
+        gch = gvol.contiguous().float().repeat_interleave(cg, dim=1).mul_(1.0 / (cg * (V - 1)))   # (B,C,D,h,w): g of the channel's group, scaled
+        gfeats = torch.empty_like(feats)
+        gw = gch * feats[:, 0].unsqueeze(2)                                                      # d loss / d warped_v, the same for every view
+        vsum = None
+        lib = _lib.load()
+        with torch.cuda.device(feats.device):
+            for v in range(1, V):
+                gsrc = torch.empty((B, C, h, w), dtype=torch.float32, device=feats.device)
+                rc = lib.casmvs_homo_warp_backward_f32(_ptr(gw), _ptr(proj_mats[:, v - 1].contiguous()), _ptr(depth_values), _ptr(gsrc),
+                                                       B, C, h, w, D, _stream(feats))
+                _lib.check(rc, "casmvs_homo_warp_backward_f32")
+                gfeats[:, v] = gsrc
+                warped = ops.homo_warp(feats[:, v].contiguous(), proj_mats[:, v - 1].contiguous(), depth_values)
+                vsum = warped if vsum is None else vsum.add_(warped)
+        gfeats[:, 0] = (gch * vsum).sum(2)
+        return gfeats, None, None, None
+
+
 def groupwise_volume(feats, proj_mats, depth_values, G):
-    """mvsnet.py:142-144,157-162,169-172 as the reference's own training code writes it: the differentiable HIP warp per
-    view, torch elementwise ops for the (small) correlation."""
+    """Differentiable mvsnet.py:142-144,157-162,169-172 (G > 1): feats (B,V,C,h,w), proj_mats (B,V-1,3,4), depth_values (B,D,h,w)
+    [no grad] -> (B,G,D,h,w)."""
+    return _GroupwiseVolume.apply(feats, proj_mats, depth_values, G)
+
+
+def groupwise_volume_composed(feats, proj_mats, depth_values, G):
+    """The same volume as the reference's training code composes it (one differentiable HIP warp per view + torch elementwise ops):
+    kept as the test's second opinion on _GroupwiseVolume."""
     B, V, C, h, w = feats.shape
     D = depth_values.shape[1]
     ref = feats[:, 0].unsqueeze(2).expand(-1, -1, D, -1, -1).reshape(B, G, C // G, D, h, w)

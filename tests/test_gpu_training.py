@@ -195,6 +195,36 @@ def test_variance_volume_backward_matches_autograd_of_the_oracle(dev, report, B,
     assert errs["fwd"] < 1e-5 and errs["g_feats"] < 3e-5
 
 
+@pytest.mark.parametrize("B,V,C,h,w,D,G,geometry", [(1, 3, 8, 24, 32, 4, 8, "dtu"), (2, 3, 16, 16, 24, 8, 4, "dtu"), (1, 4, 32, 16, 16, 3, 8, "random"),
+                                                       (1, 3, 8, 48, 64, 6, 2, "dtu"), (1, 5, 32, 20, 28, 4, 8, "dtu")])
+def test_groupwise_volume_backward_matches_autograd_of_the_oracle(dev, report, B, V, C, h, w, D, G, geometry):
+    """training._GroupwiseVolume (mvsnet.py:142-144,157-162,169-172 for G > 1): forward = the fused inference kernel, backward = one
+    shared gradient volume scattered per view by the warp's HIP backward + the reference view's sum - vs autograd of the oracle, and
+    vs the composition of per-view differentiable warps it replaces."""
+    from casmvsnet_pl_amd import training as T
+    from casmvsnet_pl_amd.synthetic import make_inputs
+    g = torch.Generator().manual_seed(C + D + G)
+    _, proj, dmin, dint = make_inputs(B, V, h, w, seed=C, geometry=geometry)
+    P = proj[:, :, 0].contiguous()
+    feats = torch.randn(B, V, C, h, w, generator=g)
+    depth = dmin + torch.rand(B, D, h, w, generator=g) * 400.0
+    fr = feats.clone().requires_grad_(True)
+    want = R.cost_volume(fr, P, depth, G)
+    gv = torch.randn(want.shape, generator=g)
+    want.backward(gv)
+    fd = feats.to(dev).requires_grad_(True)
+    got = T.groupwise_volume(fd, P.to(dev), depth.to(dev), G)
+    got.backward(gv.to(dev))
+    fc = feats.to(dev).requires_grad_(True)
+    comp = T.groupwise_volume_composed(fc, P.to(dev), depth.to(dev), G)
+    comp.backward(gv.to(dev))
+    errs = {"fwd": scaled_err(got.detach(), want.detach()), "g_feats": scaled_err(fd.grad, fr.grad), "g_ref_view": scaled_err(fd.grad[:, 0], fr.grad[:, 0]),
+            "fwd_vs_composed": scaled_err(got.detach(), comp.detach()), "g_vs_composed": scaled_err(fd.grad, fc.grad)}
+    report("train_groupwise_volume", shape=[B, V, C, h, w, D, G], geometry=geometry, **errs)
+    assert got.shape == (B, G, D, h, w)
+    assert errs["fwd"] < 1e-5 and errs["g_feats"] < 3e-5 and errs["g_ref_view"] < 3e-5 and errs["g_vs_composed"] < 3e-5
+
+
 def _oracle_train_step(sd0, dtype, imgs, proj, dmin, dint, G):
     """One train-mode forward + backward of the oracle (pinned to the live reference by tests/test_oracle.py) in `dtype`:
     -> outputs, state dict (leaf tensors with .grad, running statistics updated)."""
