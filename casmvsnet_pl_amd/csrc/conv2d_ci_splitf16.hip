@@ -40,7 +40,12 @@ struct C2Cfg {
   static constexpr int WUNITS = NCH * STEPS * RB * 2 * 64;           // [chunk][step][row block][slice][lane]: 640 / 2560 16-byte units
   static constexpr int NWL = (WUNITS + THREADS - 1) / THREADS;       // 3 / 10
   static constexpr size_t ACT_BYTES = (size_t)4 * NVOX * 16, W_BYTES = (size_t)WUNITS * 16;
-  static constexpr size_t LDS_BYTES = ACT_BYTES + W_BYTES + 16;      // 33 808 / 64 528
+  // At most TWO workgroups per CU (= two waves per SIMD): the requested LDS is padded to 56 KiB.  A SIMD that holds one staging wave
+  // (packed float32 arithmetic) and TWO waves with f16 matrix instructions in flight is the configuration in which float32 results
+  // came out wrong on this GPU; with two waves per SIMD, and no floating-point work between a wave's own matrix
+  // instructions, a staging wave never meets more than one stream of them.
+  static constexpr size_t LDS_USED = ACT_BYTES + W_BYTES + 16;       // 33 808 / 43 936 / 64 528
+  static constexpr size_t LDS_BYTES = LDS_USED < 56 * 1024 ? 56 * 1024 : LDS_USED;
 };
 
 __device__ __forceinline__ f32x4 mfma_f16_c2(u32x4 a, u32x4 b, f32x4 c) {

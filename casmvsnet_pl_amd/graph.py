@@ -94,11 +94,11 @@ class ConcurrentForwards:
     `run(batches)` takes one (imgs, proj_mats) pair per stream (None = reuse the captured inputs), replays the graphs
     concurrently and returns the list of STATIC output dicts after making the caller's stream wait for all of them.
 
-    MATRIX-INSTRUCTION TYPES MUST NOT MIX ACROSS THE STREAMS.  Measured on the MI355X (tools/debug/disturber.py,
-    profiles/r03_mfma_coresidency.txt): while waves of another kernel issue v_mfma_f32_16x16x32_f16 / _bf16 on a SIMD, a
+    MATRIX-INSTRUCTION TYPES MUST NOT MIX ACROSS THE STREAMS.  Measured on the MI355X (tools/debug/disturber.py, disturber_valu.py,
+    profiles/r03_mfma_coresidency*.txt): while waves of another kernel issue v_mfma_f32_16x16x32_f16 / _bf16 on a SIMD, a
     float32 layer kernel (v_mfma_f32_16x16x4_f32) co-resident on that SIMD returns a few wrong accumulator values (row 14 of
     the 16 x 16 tile) - 800 of 800 replays with a pure f16-MFMA loop as the neighbour, none with a float32-MFMA, LDS or VALU
-    neighbour.  Inside ONE stream kernels never overlap, so the split-f16 / split-bf16 layers (CostRegNet.conv0_mode, ci_mode) are
+    neighbour - and so does the packed-float32 arithmetic of the cost-volume kernel (91 of 400).  Inside ONE stream kernels never overlap, so the split-f16 / split-bf16 layers (CostRegNet.conv0_mode, ci_mode) are
     safe there; across streams they would run beside the other forward's float32 layers.  The replicas therefore run every layer
     on the float32 MFMA kernels unless `mixed_matrix_types=True` (experiments only: results are NOT reliable)."""
 
