@@ -1,4 +1,5 @@
-"""Builds libcasmvs_hip.so (the C-ABI HIP library, include/casmvs.h) in-tree with hipcc for gfx950.
+"""Builds libcasmvs_hip.so (the C-ABI HIP library, include/casmvs.h) in-tree with hipcc for gfx950, and libcasmvs_io.so
+(include/casmvs_io.h: host-side file decoding, plain C++) with g++.
 
 `python -m casmvsnet_pl_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a
 GPU; the .so is git-ignored but travels with the repo snapshot to the GPU box.
@@ -18,6 +19,12 @@ HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "plane_sweep.h", "buffer_
 def _sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.isfile(os.path.join(CSRC, s))]
 
+
+IO_LIB_PATH = os.path.join(PKG_DIR, "libcasmvs_io.so")
+IO_SOURCES = [os.path.join(PKG_DIR, "csrc_host", "png_decode.cpp")]
+IO_HEADERS = [os.path.join(REPO_ROOT, "include", "casmvs_io.h")]
+# no -march: the library travels to hosts with other CPUs (the SIMD it uses is SSE2, part of x86-64)
+IO_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra"]
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
@@ -55,5 +62,22 @@ def build_library(force=False, verbose=False, extra_flags=(), lib_path=None, obj
     return lib_path
 
 
+def build_io_library(force=False, verbose=False, lib_path=None):
+    """g++ build of libcasmvs_io.so (include/casmvs_io.h: host-side PNG decoding of the input pipeline; no HIP, no torch)."""
+    lib_path = lib_path or IO_LIB_PATH
+    newest = max(os.path.getmtime(f) for f in IO_SOURCES + IO_HEADERS)
+    if not force and os.path.isfile(lib_path) and os.path.getmtime(lib_path) >= newest:
+        return lib_path
+    cmd = [os.environ.get("CXX", "g++")] + IO_FLAGS + ["-I" + os.path.join(REPO_ROOT, "include")] + IO_SOURCES + ["-o", lib_path + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed on libcasmvs_io.so:\n" + res.stdout)
+    os.replace(lib_path + ".tmp", lib_path)
+    return lib_path
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_io_library(force="--force" in sys.argv, verbose=True))

@@ -16,7 +16,7 @@ import re
 import numpy as np
 import torch
 
-from . import _lib
+from . import _io, _lib
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)   # dtu.py:135-136
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -55,14 +55,50 @@ def relative_proj_mats(proj_ref, proj_srcs):
 
 # ---- files of a DTU-format scene (datasets/dtu.py) ------------------------------------------------------------------
 
-def read_image_u8(filename, img_wh=None):
-    """dtu.py:168-170: PIL decode (RGB), optionally PIL's bilinear resize to (W, H) -> (H, W, 3) uint8.  The normalisation
-    (dtu.py:134-137) happens on the device (normalize_images_u8)."""
+def _decode_file(filename, channels):
+    """(H, W, 3) / (H, W) uint8 of an image file: PNGs go through libcasmvs_io.so (include/casmvs_io.h: byte-identical to
+    PIL's `Image.open(f).convert("RGB" / "L")`, 2-3x faster and outside the GIL); other formats - and the PNG variants that
+    library declines (interlaced, 1/2/4/16-bit samples) - are decoded by PIL as in the reference."""
+    if str(filename).lower().endswith(".png"):
+        with open(filename, "rb") as f:
+            data = f.read()
+        arr = _io.decode_png(data, channels)
+        if arr is not None:
+            return arr
     from PIL import Image
-    img = Image.open(filename).convert("RGB")
-    if img_wh is not None:
-        img = img.resize(tuple(img_wh), Image.BILINEAR)
-    return np.array(img, dtype=np.uint8)   # a writable copy (torch.from_numpy)
+    return np.array(Image.open(filename).convert("RGB" if channels == 3 else "L"), dtype=np.uint8)   # a writable copy (torch.from_numpy)
+
+
+def read_image_u8(filename, img_wh=None):
+    """dtu.py:168-170: decode (RGB), optionally PIL's bilinear resize to (W, H) -> (H, W, 3) uint8.  The normalisation
+    (dtu.py:134-137) happens on the device (normalize_images_u8)."""
+    arr = _decode_file(filename, 3)
+    if img_wh is not None and (arr.shape[1], arr.shape[0]) != tuple(img_wh):   # PIL's resize to the same size is a copy
+        from PIL import Image
+        arr = np.array(Image.fromarray(arr).resize(tuple(img_wh), Image.BILINEAR), dtype=np.uint8)
+    return arr
+
+
+def read_images_u8(filenames, img_wh=None):
+    """The views of one sample -> (V, H, W, 3) uint8 tensor.  PNG views are decoded straight into their slice of the sample's
+    array (no per-view copy, no stack); anything else - other formats, PNG variants libcasmvs_io.so declines, views that
+    need the resize - goes through read_image_u8."""
+    out = None
+    for i, filename in enumerate(filenames):
+        if str(filename).lower().endswith(".png"):
+            with open(filename, "rb") as f:
+                data = f.read()
+            info = _io.png_info(data)
+            if info is not None and (img_wh is None or tuple(info[:2]) == tuple(img_wh)):
+                if out is None:
+                    out = np.empty((len(filenames), info[1], info[0], 3), np.uint8)
+                if out.shape[1:3] == (info[1], info[0]) and _io.decode_png(data, 3, out=out[i]) is not None:
+                    continue
+        arr = read_image_u8(filename, img_wh)
+        if out is None:
+            out = np.empty((len(filenames),) + arr.shape, np.uint8)
+        out[i] = arr      # a view of another size raises here, as torch.stack did
+    return torch.from_numpy(out)
 
 
 def resize_nearest(a, out_hw=None, fx=None, fy=None):
@@ -133,8 +169,7 @@ class DTUReader:
 
     def read_mask(self, filename):
         """dtu.py:113-131: 8-bit visibility image -> boolean masks at the three levels."""
-        from PIL import Image
-        mask = np.asarray(Image.open(filename).convert("L"))
+        mask = _decode_file(filename, 1)
         if self.img_wh is None:
             m0 = resize_nearest(mask, fx=0.5, fy=0.5)[44:556, 80:720]
         else:
@@ -144,13 +179,12 @@ class DTUReader:
     def __getitem__(self, idx):                                               # dtu.py:147-192
         scan, light_idx, ref_view, src_views = self.metas[idx]
         view_ids = [ref_view] + src_views[:self.n_views - 1]
-        sample, imgs, proj_mats = {}, [], []
+        sample, img_files, proj_mats = {}, [], []
         for i, vid in enumerate(view_ids):
             if self.img_wh is None:
-                img_filename = os.path.join(self.root_dir, f"Rectified/{scan}_train/rect_{vid + 1:03d}_{light_idx}_r5000.png")
+                img_files.append(os.path.join(self.root_dir, f"Rectified/{scan}_train/rect_{vid + 1:03d}_{light_idx}_r5000.png"))
             else:
-                img_filename = os.path.join(self.root_dir, f"Rectified/{scan}/rect_{vid + 1:03d}_{light_idx}_r5000.png")
-            imgs.append(torch.from_numpy(read_image_u8(img_filename, self.img_wh)))
+                img_files.append(os.path.join(self.root_dir, f"Rectified/{scan}/rect_{vid + 1:03d}_{light_idx}_r5000.png"))
             proj_mat_ls, depth_min = self.proj_mats[vid]
             if i == 0:
                 sample["init_depth_min"] = torch.tensor([depth_min], dtype=torch.float32)
@@ -160,7 +194,7 @@ class DTUReader:
                 ref_proj = proj_mat_ls
             else:
                 proj_mats.append(proj_mat_ls)
-        sample["imgs_u8"] = torch.stack(imgs)                                  # (V, H, W, 3) uint8
+        sample["imgs_u8"] = read_images_u8(img_files, self.img_wh)              # (V, H, W, 3) uint8
         sample["proj_mats"] = relative_proj_mats(ref_proj, proj_mats)          # (V-1, levels, 3, 4) fine -> coarse
         sample["depth_interval"] = torch.tensor([self.depth_interval], dtype=torch.float32)
         sample["scan_vid"] = (scan, ref_view)
@@ -360,6 +394,19 @@ def collate(samples):
     return out
 
 
+def configure_host_threads(intra_op_threads=1):
+    """Call once in a process that feeds the engine from files.  torch's CPU operators (the `torch.stack` of `collate`, the pinned
+    staging copy of DevicePrefetcher) run on an OpenMP pool with one thread per visible hardware thread, and after every parallel
+    region those threads SPIN (libiomp's 200 ms block time) on the cores the decode threads need: measured on 8 cores
+    (tools/cpu_loader_rate.py), ParallelLoader with 8 threads delivers 130 depth maps/s with torch's default pool and 435 with one
+    intra-op thread - the sample function alone, without collate, reaches 460.  A GPU pod that sees 256 hardware threads
+    but is granted 16 cores suffers most.  The host-side torch work of this pipeline is a few memcpy-sized copies; one thread
+    is the right number.  Returns the previous setting."""
+    prev = torch.get_num_threads()
+    torch.set_num_threads(int(intra_op_threads))
+    return prev
+
+
 class ParallelLoader:
     """train.py:85-97 / eval.py:213 (`DataLoader(dataset, num_workers=4, pin_memory=True)`): an iterable of collated
     batches of `reader` whose samples are read by `num_workers` THREADS - a sample's cost is PNG / JPEG decoding and the
@@ -369,7 +416,8 @@ class ParallelLoader:
 
     indices: the sample order (default: all samples in order; pass a permutation for training); a last partial batch is
     kept (drop_last=False like the reference's validation / test loaders).  processes=True: worker processes (see
-    _iter_processes) - what sustains the engine's rate on a many-core host."""
+    _iter_processes).  Call configure_host_threads() first: torch's spinning intra-op pool otherwise takes the decode threads'
+    cores (3x fewer samples per second, measured)."""
 
     def __init__(self, reader, batch_size=1, num_workers=4, indices=None, prefetch_batches=4, drop_last=False, processes=False):
         self.reader, self.batch_size, self.num_workers = reader, int(batch_size), max(1, int(num_workers))

@@ -44,6 +44,7 @@ png_kb = np.mean([os.path.getsize(os.path.join(root, "Rectified", "scan1", f)) f
 reader = P.DTUReader(root, ["scan1"], n_views=3, img_wh=(W, H), n_cameras=NV)
 print(f"tree: {NV} views of {W}x{H} PNG ({png_kb:.0f} KB each) under {root}; {len(reader)} reference views, 3 views per depth map, batch {B}; host threads {os.cpu_count()}")
 
+P.configure_host_threads(1)   # torch's spinning intra-op pool would take the decode threads' cores (pipeline.configure_host_threads)
 model = CascadeMVSNet(norm_act=ABN)
 randomize_state_dict(model.state_dict(), seed=0)
 model = model.to(dev).eval()
