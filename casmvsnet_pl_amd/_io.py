@@ -29,6 +29,12 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
+        if not os.path.isfile(LIB_PATH) and "CASMVS_IO_LIB_PATH" not in os.environ:
+            try:   # a two-second g++ build of one C++ file (no GPU, no dependencies); every host of this package has the compiler
+                from .build import build_io_library
+                build_io_library()
+            except Exception as e:
+                raise RuntimeError(f"{LIB_PATH} is missing and could not be built ({e}): run `python -m casmvsnet_pl_amd.build`") from e
         if not os.path.isfile(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m casmvsnet_pl_amd.build` (g++, no GPU needed)")
         lib = ctypes.CDLL(LIB_PATH)
