@@ -79,6 +79,7 @@ SYMBOLS = {
     "casmvs_costreg_regress_f32": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
     "casmvs_depth_regression_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_fuse_reference_view": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "casmvs_fuse_reference_view_paired": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_homo_warp_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_softmax_regress_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 7),

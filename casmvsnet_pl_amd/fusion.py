@@ -29,13 +29,15 @@ def _ptr(t):
 
 
 def fuse_reference_view(depth_ref, image_ref, proba_ref_quarter, P_world2ref, depth_srcs, image_srcs, P_world2srcs,
-                        conf=0.999, min_geo_consistent=5, return_points=True, return_per_view=False, device="cuda"):
+                        conf=0.999, min_geo_consistent=5, return_points=True, return_per_view=False, device="cuda", paired_taps=False):
     """eval.py:273-326 for one reference view.
     depth_ref (H,W) float32; image_ref (H,W,3) uint8 RGB; proba_ref_quarter (H/4,W/4) float32 (= confidence_2, what
     eval.py:226 saves) or None; P_world2ref (4,4); depth_srcs (S,H,W); image_srcs (S,H,W,3) uint8; P_world2srcs (S,4,4).
     -> dict: depth_refined (H,W) f32, image_refined (H,W,3) f64, mask_geo_sum (H,W) i32, mask_final (H,W) bool,
        xyz_world (H,W,3) f32 [return_points], mask_geo (S,H,W) bool / depth_ref_reproj (S,H,W) / image_src2ref
-       (S,H,W,3) u8 [return_per_view: what check_geo_consistency returns for every source view]."""
+       (S,H,W,3) u8 [return_per_view: what check_geo_consistency returns for every source view].
+    paired_taps=True launches casmvs_fuse_reference_view_paired (one load per tap row; bit-identical by construction, not yet
+    measured on the GPU - tools/gpu_fusion_probe.py)."""
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("casmvsnet_pl_amd.fusion runs on the MI355X only; there is no CPU fallback")
@@ -66,7 +68,8 @@ def fuse_reference_view(depth_ref, image_ref, proba_ref_quarter, P_world2ref, de
         out["depth_ref_reproj"] = torch.empty((S, H, W), dtype=torch.float32, device=dev)
         out["image_src2ref"] = torch.empty((S, H, W, 3), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.load().casmvs_fuse_reference_view(
+        entry = _lib.load().casmvs_fuse_reference_view_paired if paired_taps else _lib.load().casmvs_fuse_reference_view
+        rc = entry(
             _ptr(depth_ref), _ptr(image_ref), _ptr(proba), _ptr(depth_src), _ptr(image_src), _ptr(m_r2s), _ptr(m_s2r), _ptr(m_r2w),
             _ptr(out["depth_refined"]), _ptr(out["image_refined"]), _ptr(out["mask_geo_sum"]), _ptr(out["mask_final"]),
             _ptr(out.get("xyz_world")), _ptr(out.get("mask_geo")), _ptr(out.get("depth_ref_reproj")), _ptr(out.get("image_src2ref")),

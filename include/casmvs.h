@@ -385,6 +385,17 @@ int casmvs_fuse_reference_view(const float *depth_ref, const unsigned char *imag
                                float *xyz_world, unsigned char *mask_geo, float *depth_reproj, unsigned char *image_s2r,
                                int S, int H, int W, float conf, int min_geo_consistent, void *stream);
 
+/* The same function with a quarter of the vector-memory instructions: the two taps of a row come from one 8-byte load (depth
+ * pair; six colour bytes), the view matrices from LDS.  Same expressions in the same order - results are bit-identical to
+ * casmvs_fuse_reference_view.  Needs W, H >= 2 and S <= 64.  Added at the end of round 3 WITHOUT a GPU measurement
+ * (tools/gpu_fusion_probe.py compares the two): not yet what casmvsnet_pl_amd.fusion calls by default. */
+int casmvs_fuse_reference_view_paired(const float *depth_ref, const unsigned char *image_ref, const float *proba_quarter,
+                                      const float *depth_src, const unsigned char *image_src, const float *m_ref2src,
+                                      const float *m_src2ref, const float *m_ref2world, float *depth_refined,
+                                      double *image_refined, int32_t *mask_geo_sum, unsigned char *mask_final,
+                                      float *xyz_world, unsigned char *mask_geo, float *depth_reproj, unsigned char *image_s2r,
+                                      int S, int H, int W, float conf, int min_geo_consistent, void *stream);
+
 /* ---- (f-2) backward of the plane sweep and of the depth regression (training, op by op) -----------
  * casmvs_homo_warp_backward_f32: the gradient of models/modules.py:52-92 with respect to src_feat (the grid depends on
  *   the DETACHED depth hypotheses only, mvsnet.py:231): grad_src (B,C,H,W) = scatter-add of grad_out (B,C,D,H,W) with the

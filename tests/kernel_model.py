@@ -824,3 +824,33 @@ def conv0_sb_lds_cycles():
                 tot += max(len(v) for v in banks.values())
         return tot
     return read, write(conv0_sb_slot), write(lambda x: x)
+
+
+# ---- fuse_view_paired_kernel (csrc/fusion.hip): the two taps of a row from one 8-byte load -------------------------------------
+def fusion_paired_taps(depth, image, ix, iy):
+    """Host model of the tap fetch of fuse_view_paired_kernel for one source view: depth (H, W) float32, image (H, W, 3) uint8,
+    integer tap origins ix, iy (any int32: the kernel clamps).  Returns (4 depth taps, 4 x 3 colour taps) in the kernel's tap order
+    (y0x0, y0x1, y1x0, y1x1) fetched the way the kernel does - pair base bx = min(cx0, W - 2), one little-endian 8-byte word holding
+    six colour bytes, read 2 bytes early where it would run past the view - from the CLAMPED addresses (zeroing of outside taps comes
+    after, as in fuse_view_kernel)."""
+    H, W = depth.shape
+    hw = H * W
+    dflat = depth.reshape(-1)
+    bflat = image.reshape(-1)
+    cx0, cx1 = min(max(ix, 0), W - 1), min(max(ix + 1, 0), W - 1)
+    cy0, cy1 = min(max(iy, 0), H - 1), min(max(iy + 1, 0), H - 1)
+    bx = min(cx0, W - 2)
+    hi0, hi1 = cx0 != bx, cx1 != bx
+    dtaps, ctaps = [], []
+    for cy in (cy0, cy1):
+        r = cy * W + bx
+        pair = (dflat[r], dflat[r + 1])                      # 8 bytes at a 4-byte aligned address: never past the view (r + 1 <= hw - 1)
+        back = 2 if r >= hw - 2 else 0
+        start = 3 * r - back
+        assert 0 <= start and start + 8 <= 3 * hw, "the 8-byte colour load leaves the view"
+        word = int.from_bytes(bflat[start:start + 8].tobytes(), "little") >> (8 * back)
+        for hi in (hi0, hi1):
+            dtaps.append(pair[1] if hi else pair[0])
+            w32 = (word >> 24 if hi else word) & 0xFFFFFFFF
+            ctaps.append([(w32 >> (8 * c)) & 255 for c in range(3)])
+    return dtaps, ctaps

@@ -340,3 +340,22 @@ def test_conv0_splitbf16_lds_layout():
     assert len({KM.conv0_sb_slot(x) for x in range(40)}) == 40 and max(KM.conv0_sb_slot(x) for x in range(40)) < 41
     read, write, write_linear = KM.conv0_sb_lds_cycles()
     assert read == 4 and write == 56 and write_linear == 100      # (32 would be conflict-free; with 40-slot rows and no swizzle: 128)
+
+
+def test_fusion_paired_tap_fetch_equals_direct_indexing():
+    """fuse_view_paired_kernel's one-load-per-row tap fetch (host model) returns the taps fuse_view_kernel loads one by one, for
+    every tap origin incl. far outside, the clamped border columns and the last pixel pair of the view (the 2-bytes-early load)."""
+    import numpy as np
+    from kernel_model import fusion_paired_taps
+    g = np.random.default_rng(0)
+    for H, W in ((2, 2), (3, 2), (5, 7), (4, 16)):
+        depth = g.standard_normal((H, W)).astype(np.float32)
+        image = g.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        for iy in range(-3, H + 3):
+            for ix in range(-3, W + 3):
+                cx0, cx1 = min(max(ix, 0), W - 1), min(max(ix + 1, 0), W - 1)
+                cy0, cy1 = min(max(iy, 0), H - 1), min(max(iy + 1, 0), H - 1)
+                want = [(cy0, cx0), (cy0, cx1), (cy1, cx0), (cy1, cx1)]
+                dt, ct = fusion_paired_taps(depth, image, ix, iy)
+                assert [float(v) for v in dt] == [float(depth[y, x]) for y, x in want], (H, W, ix, iy)
+                assert ct == [[int(v) for v in image[y, x]] for y, x in want], (H, W, ix, iy)
