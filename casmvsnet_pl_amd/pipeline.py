@@ -475,7 +475,7 @@ class DevicePrefetcher:
     Tensors are staged through pinned buffers (a pageable source would make the copy synchronous); `imgs_u8` batches are
     normalised on the device, still on the side stream, and delivered as `imgs`.  Non-tensor entries pass through."""
 
-    def __init__(self, batches, device="cuda", depth=2):
+    def __init__(self, batches, device="cuda", depth=2, threaded=False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DevicePrefetcher feeds the MI355X engine; there is no CPU path")
@@ -483,6 +483,26 @@ class DevicePrefetcher:
         self.depth = max(1, depth)
         self.stream = torch.cuda.Stream(device=self.device)
         self.queue = []
+        # threaded=True: a background thread pulls batches and stages them (pinned copy, H2D enqueue, normalisation launch) so
+        # that the consumer's thread only launches the engine - at ~450 batches/s the 0.6 ms staging copy of a 6 MB batch is
+        # a quarter of the consumer's time per batch.  (Added at the end of round 3 without a GPU run: opt-in.)
+        self.threaded = bool(threaded)
+        self._thread = None
+        if self.threaded:
+            import queue
+            import threading
+            self._q = queue.Queue(maxsize=self.depth)
+            self._thread = threading.Thread(target=self._worker, name="casmvs-stager", daemon=True)
+            self._thread.start()
+
+    def _worker(self):
+        try:
+            torch.cuda.set_device(self.device)
+            for batch in self.it:
+                self._q.put(self._stage(batch))
+            self._q.put(None)
+        except BaseException as e:   # delivered to the consumer by __next__
+            self._q.put(e)
 
     def _stage(self, batch):
         out, keep = {}, []
@@ -504,6 +524,20 @@ class DevicePrefetcher:
         return self
 
     def __next__(self):
+        if self.threaded:
+            item = self._q.get()
+            if item is None:
+                self._q.put(None)   # stay exhausted
+                raise StopIteration
+            if isinstance(item, BaseException):
+                self._q.put(item)
+                raise item
+            out, ev, _keep = item
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for v in out.values():
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(torch.cuda.current_stream(self.device))
+            return out
         while len(self.queue) < self.depth:
             try:
                 self.queue.append(self._stage(next(self.it)))

@@ -17,7 +17,10 @@ from casmvsnet_pl_amd.synthetic import randomize_state_dict
 
 NV = int(sys.argv[1]) if len(sys.argv) > 1 else 49
 WORKERS = [int(a) for a in sys.argv[2:]] or [1, 4, 16, 32, 64]
-H, W, B = 512, 640, 2
+H, W = 512, 640
+B = int(os.environ.get("FT_BATCH", "2"))                   # FT_BATCH=8 FT_GRAPH=1: the bench's launch (one hipGraph replay of 8 reference views)
+GRAPH = os.environ.get("FT_GRAPH", "0") == "1"
+THREADED = os.environ.get("FT_THREADED", "0") == "1"       # DevicePrefetcher(threaded=True): staging on its own thread
 dev = torch.device("cuda:0")
 root = tempfile.mkdtemp(prefix="casmvs_dtu_")
 g = np.random.default_rng(0)
@@ -55,8 +58,8 @@ def run_from_files(workers, epochs=3, processes=False, skip=3):
     loader = P.ParallelLoader(reader, batch_size=B, num_workers=workers, indices=idx, prefetch_batches=max(4, workers // B), drop_last=True, processes=processes)
     n = 0
     t0 = None
-    for i, b in enumerate(P.DevicePrefetcher(loader, dev, depth=3)):
-        out = model(b["imgs"], b["proj_mats"], b["init_depth_min"].to(dev), b["depth_interval"].to(dev))
+    for i, b in enumerate(P.DevicePrefetcher(loader, dev, depth=3, threaded=THREADED)):
+        out = forward(b["imgs"], b["proj_mats"], b["init_depth_min"].to(dev), b["depth_interval"].to(dev))
         if i == skip:                  # warm-up: first batches fill the pipeline (worker processes: also their start-up)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -75,18 +78,22 @@ def run_decode_only(workers, processes=False):
 
 
 # device-resident reference: the same batch shape, inputs already in HBM, kernel by kernel (what the files path also runs)
-b0 = P.collate([reader[0], reader[1]])
+b0 = P.collate([reader[i] for i in range(B)])
 imgs = P.normalize_images_u8(b0["imgs_u8"].to(dev))
 proj, dmin, dint = b0["proj_mats"].to(dev), b0["init_depth_min"].to(dev), b0["depth_interval"].to(dev)
+forward = model
+if GRAPH:
+    from casmvsnet_pl_amd.graph import GraphedForward
+    forward = GraphedForward(model, imgs, proj, dmin, dint)   # (B,1) range tensors: copied into the captured buffers per call
 for _ in range(3):
-    model(imgs, proj, dmin, dint)
+    forward(imgs, proj, dmin, dint)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(30):
-    model(imgs, proj, dmin, dint)
+    forward(imgs, proj, dmin, dint)
 torch.cuda.synchronize()
 resident = 30 * B / (time.perf_counter() - t0)
-print(f"device-resident inputs, kernel by kernel, batch {B}: {resident:.1f} depth maps/s")
+print(f"device-resident inputs, {'one hipGraph replay per batch' if GRAPH else 'kernel by kernel'}, batch {B}, stager thread {THREADED}: {resident:.1f} depth maps/s")
 for procs in (False, True):
     for wk in (WORKERS if not procs else [w for w in WORKERS if 16 <= w <= 64] or [32]):
         dec = run_decode_only(wk, procs)
