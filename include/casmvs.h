@@ -442,6 +442,16 @@ int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_va
 size_t casmvs_conv_wgrad_workspace_bytes(int kind, int B, int cin, int cout, int D, int H, int W);
 int casmvs_conv_wgrad_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
                           int cin, int cout, int D, int H, int W, void *stream);
+
+/* Weight gradient of the `prob` layer (Conv3d 8 -> 1, k3 s1 p1; models/mvsnet.py:89) on its own kernel: grad_weight (1, 8, 3, 3, 3)
+ * = sum over (b, z, y, x) of grad_out (B, 1, D, H, W) * in (B, 8, D, H, W) shifted by the tap, zero padded.  The generic
+ * casmvs_conv_wgrad_f32 pads the single output channel to a 16-row matrix tile; this one keeps 108 accumulators per thread on the
+ * vector ALU (csrc/prob_wgrad.hip), deterministic (fixed-order reduction through `workspace`, casmvs_prob_wgrad_workspace_bytes).
+ * Needs W % 4 == 0, 16-byte aligned tensors, 8 D H W < 2^29; casmvs_conv_wgrad_f32 routes the layer here when that holds. */
+int casmvs_prob_wgrad_supported(int B, int D, int H, int W);
+size_t casmvs_prob_wgrad_workspace_bytes(int B, int D, int H, int W);
+int casmvs_prob_wgrad_f32(const float *in, const float *grad_out, float *grad_weight, void *workspace, int B, int D, int H, int W,
+                          void *stream);
 int casmvs_conv_dgrad_direct_f32(int kind, const float *weight, const float *grad_out, float *grad_in, int B, int cin,
                                  int cout, int D, int H, int W, void *stream);
 int casmvs_channel_sums_blocks(int N, size_t n);
