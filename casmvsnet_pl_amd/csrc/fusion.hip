@@ -161,12 +161,15 @@ __global__ __launch_bounds__(kThreads) void fuse_view_kernel(const FuseArgs a) {
   }
 }
 
-// ---- the same arithmetic with a quarter of the memory instructions (round 3, unmeasured: opt-in entry point) ----------
+// ---- the same arithmetic with a quarter of the memory instructions (round 3; measured: bit-identical, 95 -> 83 us) ----------
 // fuse_view_kernel issues per source view 4 dword + 8 byte / short tap loads and 6 x 16-byte loads of the two 3 x 4 matrices (the
 // per-view outputs it may store forbid scalar loads): ~18 vector-memory instructions per (pixel, view), each a 64-address
 // gather for the CU's address unit - 105 us at 0.14 of the HBM roof.  Here the two taps of a row come from ONE load -
 // 8 bytes of depth (bx, bx + 1) and 8 bytes holding the six colour bytes, bx = min(x0, W - 2) and selects for the clamped
 // border columns - and the matrices are staged in LDS once per workgroup: 4 vector-memory instructions per (pixel, view).
+// What bounds both kernels is the vector ALU: 255 instructions per (pixel, view) here - five correctly rounded divisions (55), six
+// 3 x 4 projections (36), the fixed-point coordinates and weights (~30), the colour interpolation (~60), the border selects (31) -
+// at 4 cycles per wave64 instruction: 67 us for 995 k pixels x 10 views on 256 CUs, 83 measured; the HBM floor is 15 us.
 // Every float operation is the same expression in the same order as above; results must be bit-identical.
 constexpr int kMaxViewsLds = 64;
 

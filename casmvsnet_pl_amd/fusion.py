@@ -29,15 +29,17 @@ def _ptr(t):
 
 
 def fuse_reference_view(depth_ref, image_ref, proba_ref_quarter, P_world2ref, depth_srcs, image_srcs, P_world2srcs,
-                        conf=0.999, min_geo_consistent=5, return_points=True, return_per_view=False, device="cuda", paired_taps=False):
+                        conf=0.999, min_geo_consistent=5, return_points=True, return_per_view=False, device="cuda", paired_taps=True):
     """eval.py:273-326 for one reference view.
     depth_ref (H,W) float32; image_ref (H,W,3) uint8 RGB; proba_ref_quarter (H/4,W/4) float32 (= confidence_2, what
     eval.py:226 saves) or None; P_world2ref (4,4); depth_srcs (S,H,W); image_srcs (S,H,W,3) uint8; P_world2srcs (S,4,4).
     -> dict: depth_refined (H,W) f32, image_refined (H,W,3) f64, mask_geo_sum (H,W) i32, mask_final (H,W) bool,
        xyz_world (H,W,3) f32 [return_points], mask_geo (S,H,W) bool / depth_ref_reproj (S,H,W) / image_src2ref
        (S,H,W,3) u8 [return_per_view: what check_geo_consistency returns for every source view].
-    paired_taps=True launches casmvs_fuse_reference_view_paired (one load per tap row; bit-identical by construction, not yet
-    measured on the GPU - tools/gpu_fusion_probe.py)."""
+    paired_taps=True (default) launches casmvs_fuse_reference_view_paired - one load per tap row, matrices from LDS: bit-identical
+    to casmvs_fuse_reference_view on every output (tools/native/fusion_check.cpp on the MI355X: profiles/r03_fusion_paired_check.txt),
+    95 -> 83 us per 1152 x 864 reference view with 10 source views; shapes it does not take (W < 2, > 64 source views) use the
+    other entry."""
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("casmvsnet_pl_amd.fusion runs on the MI355X only; there is no CPU fallback")
@@ -68,7 +70,7 @@ def fuse_reference_view(depth_ref, image_ref, proba_ref_quarter, P_world2ref, de
         out["depth_ref_reproj"] = torch.empty((S, H, W), dtype=torch.float32, device=dev)
         out["image_src2ref"] = torch.empty((S, H, W, 3), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        entry = _lib.load().casmvs_fuse_reference_view_paired if paired_taps else _lib.load().casmvs_fuse_reference_view
+        entry = _lib.load().casmvs_fuse_reference_view_paired if (paired_taps and W >= 2 and H >= 2 and S <= 64) else _lib.load().casmvs_fuse_reference_view
         rc = entry(
             _ptr(depth_ref), _ptr(image_ref), _ptr(proba), _ptr(depth_src), _ptr(image_src), _ptr(m_r2s), _ptr(m_s2r), _ptr(m_r2w),
             _ptr(out["depth_refined"]), _ptr(out["image_refined"]), _ptr(out["mask_geo_sum"]), _ptr(out["mask_final"]),

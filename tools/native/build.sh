@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds the torch-free check binaries against the in-tree library (run after `python -m casmvsnet_pl_amd.build`).
+# tools/probes/bin/ is git-ignored but travels with the gpurun snapshot:
+#   /usr/local/graft/bin/gpurun --timeout 60 -- 'tools/probes/bin/prob_wgrad_check; tools/probes/bin/fusion_check'
+set -e
+cd "$(dirname "$0")/../.."
+mkdir -p tools/probes/bin
+for name in fusion_check prob_wgrad_check; do
+  /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/native/$name.cpp -Iinclude -Lcasmvsnet_pl_amd -lcasmvs_hip \
+    -Wl,-rpath,'$ORIGIN/../../../casmvsnet_pl_amd' -o tools/probes/bin/$name 2>&1 | grep -E "error" || true
+  ls -la tools/probes/bin/$name
+done
