@@ -33,6 +33,12 @@
 #include "common.h"
 #include "split_f16.h"
 
+#ifndef CASMVS_SF_PRIO
+#define CASMVS_SF_PRIO 0   // A/B builds: 1 = raised wave priority during the matrix phase (tools/native/conv0_ab.cpp)
+#endif
+#ifndef CASMVS_SF_ORDER
+#define CASMVS_SF_ORDER (-1)  // A/B builds force one tile order for every shape (0 .. 3, see sf_decode); -1: the measured choice per CIN
+#endif
 #ifndef CASMVS_SF_ABL
 #define CASMVS_SF_ABL 0   // profiling builds only (WRONG results): 1 no MFMAs, 2 no split / LDS staging writes, 4 no global loads, 8 no tap reads
 #endif
@@ -69,13 +75,41 @@ __device__ __forceinline__ void split_voxel_f16(const float (&x)[8], float mult,
 struct SfTile {
   int tx0, ty0, tz0, b;
 };
+// Work order of the persistent workgroups (results do not depend on it).  Items are dealt XCD-major (buffer_ops.h), so the
+// workgroups resident on an XCD at one time walk neighbouring tiles and meet each other's halo lines in that XCD's L2.
+//   ORDER 0: z fastest, then x, then y (round 3's first form)      1: x fastest, then z, then y
+//   ORDER 2: as 1, and the two workgroups a CU holds (dispatch slots idx and idx + 32 of an XCD) take NEIGHBOURING items
+//   ORDER 3: x, then y, then z
+// Measured with tools/native/conv0_ab.cpp (batch 2, dirtied caches, bit-identical outputs; profiles/r03_conv0_tile_order_ab.txt):
+// against order 0, order 1 is +2.6 % at every level, order 2 +4.7 % / 0 / +6.4 % at cin = 32 / 16 / 8, order 3 +2 / -2.6 / 0.
+template <int ORDER>
 __device__ __forceinline__ SfTile sf_decode(int v, int total, int tiles_x, int tiles_y, int tiles_z) {
-  int item = xcd_major(v, total);   // z fastest, then x, then y (the halos of neighbouring tiles share an XCD's L2)
+  if (ORDER == 2) {
+    const int xcd = v & 7, idx = v >> 3;
+    if ((idx | 63) < (total >> 3)) v = ((((idx & ~63) | ((idx & 31) << 1) | ((idx >> 5) & 1))) << 3) | xcd;   // a bijection inside full groups of 64 slots
+  }
+  int item = xcd_major(v, total);
   SfTile t;
-  t.tz0 = (item % tiles_z) * SfCfg::TZ;
-  item /= tiles_z;
-  t.tx0 = (item % tiles_x) * SfCfg::TX;
-  item /= tiles_x;
+  if (ORDER == 3) {
+    t.tx0 = (item % tiles_x) * SfCfg::TX;
+    item /= tiles_x;
+    t.ty0 = (item % tiles_y) * SfCfg::TY;
+    item /= tiles_y;
+    t.tz0 = (item % tiles_z) * SfCfg::TZ;
+    t.b = item / tiles_z;
+    return t;
+  }
+  if (ORDER == 1 || ORDER == 2) {
+    t.tx0 = (item % tiles_x) * SfCfg::TX;
+    item /= tiles_x;
+    t.tz0 = (item % tiles_z) * SfCfg::TZ;
+    item /= tiles_z;
+  } else {
+    t.tz0 = (item % tiles_z) * SfCfg::TZ;
+    item /= tiles_z;
+    t.tx0 = (item % tiles_x) * SfCfg::TX;
+    item /= tiles_x;
+  }
   t.ty0 = (item % tiles_y) * SfCfg::TY;
   t.b = item / tiles_y;
   return t;
@@ -88,6 +122,7 @@ __global__ __launch_bounds__(SfCfg::THREADS, 2) void conv0_sf_kernel(const float
                                                                     float *__restrict__ out, int B, int D, int H, int W, int tiles_x,
                                                                     int tiles_y, int tiles_z, float slope) {
   using Cfg = SfCfg;
+  constexpr int ORDER = CASMVS_SF_ORDER >= 0 ? CASMVS_SF_ORDER : (CIN == 16 ? 1 : 2);
   constexpr int NCH = CIN / 8, NT = Cfg::NT, NR = Cfg::NR, NWL = Cfg::NWL, IX = Cfg::IX, IY = Cfg::IY, NV = Cfg::NV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4 *act = reinterpret_cast<u32x4 *>(smem_raw);                                      // [2][NV]
@@ -149,14 +184,14 @@ __global__ __launch_bounds__(SfCfg::THREADS, 2) void conv0_sf_kernel(const float
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int item = blockIdx.x;
-  SfTile cur = sf_decode(item, total, tiles_x, tiles_y, tiles_z);
+  SfTile cur = sf_decode<ORDER>(item, total, tiles_x, tiles_y, tiles_z);
   plan(cur);
   prefetch(cur, 0, true, true);
   bool first = true;
   for (;;) {
     const int next_item = item + gridDim.x;
     const bool have_next = next_item < total;
-    const SfTile nxt = have_next ? sf_decode(next_item, total, tiles_x, tiles_y, tiles_z) : cur;
+    const SfTile nxt = have_next ? sf_decode<ORDER>(next_item, total, tiles_x, tiles_y, tiles_z) : cur;
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       // ---- the staged tile's largest magnitude (this thread's loads -> wave -> workgroup) ----
@@ -206,6 +241,9 @@ __global__ __launch_bounds__(SfCfg::THREADS, 2) void conv0_sf_kernel(const float
       f32x4 part[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) part[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if CASMVS_SF_PRIO
+      __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
       for (int kz = 0; kz < 3; ++kz) {
         u32x4 row[NT + 2][2];
@@ -230,6 +268,9 @@ __global__ __launch_bounds__(SfCfg::THREADS, 2) void conv0_sf_kernel(const float
             }
         }
       }
+#if CASMVS_SF_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
