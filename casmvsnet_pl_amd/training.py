@@ -130,7 +130,8 @@ def conv_wgrad(kind, x, grad_out, weight_shape):
         B, cin, H, W = x.shape
         D = 1
     cout = grad_out.shape[1]
-    if PROB_WGRAD_KERNEL and kind == CONV_S1 and cin == 8 and cout == 1 and lib.casmvs_prob_wgrad_supported(B, D, H, W):
+    if (PROB_WGRAD_KERNEL and kind == CONV_S1 and cin == 8 and cout == 1 and lib.casmvs_prob_wgrad_supported(B, D, H, W)
+            and x.data_ptr() % 16 == 0 and grad_out.data_ptr() % 16 == 0):
         # the `prob` layer: one output channel would be padded to a 16-row matrix tile; its own vector-ALU kernel is 3.3x faster
         ws = torch.empty(lib.casmvs_prob_wgrad_workspace_bytes(B, D, H, W), dtype=torch.uint8, device=x.device)
         gw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
