@@ -49,5 +49,15 @@ __device__ __forceinline__ int xcd_major(int v, int total) {
   return xcd * q + (xcd < r ? xcd : r) + idx;
 }
 
+// A/B builds (work-order experiments, tools/notorch/ab_step.py): of a persistent kernel with TWO resident workgroups per CU the
+// hardware places dispatch slots idx and idx + 32 of an XCD on the same CU; this remap gives that pair NEIGHBOURING items (and
+// with them shared halo lines in the CU's L1 / the XCD's L2).  A bijection inside full groups of 64 slots; v = blockIdx.x + n gridDim.x
+// with gridDim.x a multiple of 8.  conv0_splitf16.hip measured +5 % with it at cin = 8 / 32 (profiles/r03_conv0_tile_order_ab.txt).
+__device__ __forceinline__ int cu_pair_remap(int v, int total) {
+  const int xcd = v & 7, idx = v >> 3;
+  if ((idx | 63) < (total >> 3)) v = ((((idx & ~63) | ((idx & 31) << 1) | ((idx >> 5) & 1))) << 3) | xcd;
+  return v;
+}
+
 }  // namespace buf
 }  // namespace casmvs

@@ -22,6 +22,10 @@
 #include "common.h"
 #include "split_f16.h"
 
+#ifndef CASMVS_C2_PAIR
+#define CASMVS_C2_PAIR 0
+#endif
+
 namespace {
 
 using namespace casmvs::buf;
@@ -116,6 +120,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__res
     for (int c = 0; c < 16; ++c) R[c] = buf_load2(src, voff, (chunk * 16 + c) * hw * 4);
   };
   auto decode = [&](int v, int &n, int &ty0, int &tx0) {
+#if CASMVS_C2_PAIR   // A/B builds: the two workgroups of a CU on neighbouring tiles (buffer_ops.h: cu_pair_remap)
+    v = cu_pair_remap(v, total);
+#endif
     int item = xcd_major(v, total);   // x fastest, then y, then image
     tx0 = (item % tiles_x) * Cfg::TX;
     item /= tiles_x;

@@ -415,6 +415,9 @@ __device__ unsigned long long g_trace[64 * 128];
 // ~80-100 concurrent tiles = one z-x slab, whose halos are then shared inside that L2).  With the
 // plain v -> tile map neighbouring tiles ran on 8 different XCDs and every L2 fetched every halo:
 // PMC FETCH_SIZE of conv0 was 5x the algorithmic input bytes (profiles/r01_pmc_traffic.md).
+#ifndef CASMVS_DB_ORDER
+#define CASMVS_DB_ORDER 0   // A/B builds: 1 = x-fastest tile order, 2 = x fastest + CU pairing (buffer_ops.h: cu_pair_remap)
+#endif
 struct TileCoord {
   int tx0, ty0, tz0, b, slice;
 };
@@ -424,12 +427,22 @@ struct TileCoord {
 // streaming order along x re-uses the z-halo planes better.  Reverted.)
 template <int TZ, int TY, int TX>
 __device__ __forceinline__ TileCoord decode_tile(int v, int total, int tiles_x, int tiles_y, int tiles_z, int B) {
+#if CASMVS_DB_ORDER == 2
+  v = cu_pair_remap(v, total);
+#endif
   int item = xcd_major(v, total);
   TileCoord c;
+#if CASMVS_DB_ORDER >= 1   // A/B builds: x fastest, then z, then y (conv0_splitf16.hip: +2.6 %)
+  c.tx0 = (item % tiles_x) * TX;
+  item /= tiles_x;
+  c.tz0 = (item % tiles_z) * TZ;
+  item /= tiles_z;
+#else
   c.tz0 = (item % tiles_z) * TZ;
   item /= tiles_z;
   c.tx0 = (item % tiles_x) * TX;
   item /= tiles_x;
+#endif
   c.ty0 = (item % tiles_y) * TY;
   item /= tiles_y;
   c.b = item % B;

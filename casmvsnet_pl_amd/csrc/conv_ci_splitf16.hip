@@ -35,6 +35,9 @@
 #ifndef CASMVS_CI_LOAD_AUX
 #define CASMVS_CI_LOAD_AUX 0    // cache-policy bits of the activation loads (debug builds: 17 = sc0 | sc1, system-coherent)
 #endif
+#ifndef CASMVS_CI_ORDER
+#define CASMVS_CI_ORDER 0       // A/B builds: 1 = x-fastest tile order, 2 = x fastest + CU pairing (buffer_ops.h: cu_pair_remap)
+#endif
 #ifndef CASMVS_CI_STORE_AUX
 #define CASMVS_CI_STORE_AUX 0
 #endif
@@ -74,12 +77,22 @@ struct CiTile {
 };
 template <typename Cfg>
 __device__ __forceinline__ CiTile ci_decode(int v, int total, int tiles_x, int tiles_y, int tiles_z) {
+#if CASMVS_CI_ORDER == 2
+  if (Cfg::WG_PER_CU == 2) v = cu_pair_remap(v, total);
+#endif
   int item = xcd_major(v, total);   // z fastest, then x, then y (the halos of neighbouring tiles share an XCD's L2)
   CiTile t;
+#if CASMVS_CI_ORDER >= 1   // A/B builds: x fastest, then z, then y
+  t.tx0 = (item % tiles_x) * Cfg::TX;
+  item /= tiles_x;
+  t.tz0 = (item % tiles_z) * Cfg::TZ;
+  item /= tiles_z;
+#else
   t.tz0 = (item % tiles_z) * Cfg::TZ;
   item /= tiles_z;
   t.tx0 = (item % tiles_x) * Cfg::TX;
   item /= tiles_x;
+#endif
   t.ty0 = (item % tiles_y) * Cfg::TY;
   t.b = item / tiles_y;
   return t;

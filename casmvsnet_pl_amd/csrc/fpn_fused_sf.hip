@@ -24,6 +24,10 @@
 #include "common.h"
 #include "split_f16.h"
 
+#ifndef CASMVS_FS_PAIR
+#define CASMVS_FS_PAIR 0
+#endif
+
 namespace {
 
 using namespace casmvs::buf;
@@ -148,6 +152,9 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto decode = [&](int v, int &n, int &ty0, int &tx0) {
+#if CASMVS_FS_PAIR   // A/B builds: the two workgroups of a CU on neighbouring tiles (buffer_ops.h: cu_pair_remap)
+    v = cu_pair_remap(v, total);
+#endif
     int item = xcd_major(v, total);   // x fastest, then y, then image
     tx0 = (item % tiles_x) * Cfg::TX;
     item /= tiles_x;
