@@ -1,0 +1,282 @@
+// CostRegNet.conv0 (Conv3d Cin -> 8, k3 s1 p1 + folded ABN + leaky-relu) in split-f16 arithmetic, INPUT-stationary along z.
+//
+// *** Written at the end of round 3 WITHOUT a GPU run (the round's GPU minutes were spent): an opt-in entry point, not what the engine
+// *** calls.  tools/native/conv0_zm_check.cpp is its first test (against conv0_sf_kernel and a float64 convolution).
+//
+// Why.  conv0_sf_kernel (conv0_splitf16.hip) is bound by its L1 -> L2 request stream: a 4 x 4 x 32 output tile stages a 6 x 6 x 40 halo
+// box per chunk of 8 input channels - 2.8 staged voxels per output voxel, each row of 40 floats touching three cache lines - and without
+// its global loads the kernel runs in half the time (profiles/r03_conv0_splitf16_ablations.txt).  Here a workgroup owns a 16 (y) x 32 (x)
+// patch and MARCHES along z: every input plane of the patch (18 x 40 with the halo) is staged ONCE per chunk and feeds the three
+// output planes it touches, whose accumulators rotate through registers.  1.41 staged voxels per output voxel (the y / x halo only),
+// half the split work, a third of the row reads from LDS; the matrix instructions per output are the same.
+//
+// Arithmetic: that of conv0_splitf16.hip (w' = 2^kw w on the host; x' = 2^kx x with kx chosen per STAGED UNIT - here one plane patch of one
+// chunk - so that max |x'| is in [2^14, 2^15); a = f16(x'), b = f16(x' - a); products aa, ab, ba on v_mfma_f32_16x16x32_f16 with float32
+// accumulation; the unit's matrix result times 2^-kx added to the output plane's float32 accumulator).  The packed weight image is the one
+// casmvs_conv0_splitf16_pack writes.  Results differ from conv0_sf_kernel's in the last bits (other staging units, other summation
+// grouping); both sit ~3e-7 of the range from a float64 convolution (host model: tests/kernel_model.py: emulate_conv0_zmarch).
+//
+// Shape of the work: item = (sample, y tile, x tile, z segment); segments only where the (y, x) patches alone would not fill the chip
+// (a segment re-stages one halo plane at each end).  All chunks' lane images stay in LDS (18 KiB per chunk) next to ONE plane patch
+// (23 KiB): cin = 8 / 16 -> 41 / 59 KiB, two workgroups per CU (the request is padded to 56 KiB so that never three share one: the
+// rule for f16 matrix kernels).  cin = 32 (90 KiB: one workgroup per CU) stays on conv0_sf_kernel.
+// Matrix phase of a unit: the wave's six staged rows are read once (12 x 16 B per lane), then 3 (kz) x 3 (ky) x 4 (rows) x 3 partial
+// products = 108 MFMAs between which only LDS reads of the lane images are issued (no floating-point vector work: DESIGN.md 2.0).
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "buffer_ops.h"
+#include "common.h"
+#include "split_f16.h"
+
+namespace {
+
+using namespace casmvs::buf;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ZmCfg {
+  static constexpr int THREADS = 256, NT = 4;
+  static constexpr int TY = 16, TX = 32;
+  static constexpr int IY = TY + 2, IX = TX + 8, ROW = IX + 1;    // x0 - 4 .. x0 + 35 (16-byte aligned global groups); odd row stride
+  static constexpr int NV = IY * ROW;                               // 16-byte slots per slice: 738
+  static __host__ __device__ constexpr int slot(int x) { return x ^ (((x >> 3) & 1) << 1); }   // as SfCfg::slot
+  static constexpr int ITEMS = IY * (IX / 4);                       // (y, group of 4 x) staging items: 180 of the 256 threads
+  static constexpr int WUNITS = 9 * 2 * 64;                         // 16-byte units of a chunk's lane images
+  static constexpr size_t ACT_BYTES = (size_t)2 * NV * 16;          // 23 616
+  static __host__ __device__ constexpr size_t w_bytes(int nch) { return (size_t)nch * WUNITS * 16; }
+  static __host__ __device__ constexpr size_t lds_bytes(int nch) {
+    return ACT_BYTES + w_bytes(nch) + 16 < 56 * 1024 ? (size_t)56 * 1024 : ACT_BYTES + w_bytes(nch) + 16;
+  }
+};
+
+__device__ __forceinline__ f32x4 zm_mfma(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+struct ZmItem {
+  int tx0, ty0, zs, ze, b;
+};
+
+// in (B, CIN, D, H, W) float32, W % 4 == 0, 16-byte aligned; wpk: the image of casmvs_conv0_splitf16_pack; out (B, 8, D, H, W).
+template <int CIN>
+__global__ __launch_bounds__(ZmCfg::THREADS, 2) void conv0_zm_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
+                                                                    float *__restrict__ out, int B, int D, int H, int W, int tiles_x,
+                                                                    int tiles_y, int nseg, int zlen, float slope) {
+  using Cfg = ZmCfg;
+  constexpr int NCH = CIN / 8, NT = Cfg::NT, IX = Cfg::IX, ROW = Cfg::ROW, NV = Cfg::NV;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4 *act = reinterpret_cast<u32x4 *>(smem_raw);                                              // [2][NV]
+  u32x4 *wl = reinterpret_cast<u32x4 *>(smem_raw + Cfg::ACT_BYTES);                              // [chunk][9][2][64]
+  unsigned *wmax = reinterpret_cast<unsigned *>(smem_raw + Cfg::ACT_BYTES + Cfg::w_bytes(NCH));   // [4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jcol = lane & 15, u = lane >> 4;
+  const int total = tiles_x * tiles_y * nseg * B;
+  if ((int)blockIdx.x >= total) return;
+  const int HW = H * W, cs = D * HW;
+  const size_t in_ss = (size_t)CIN * cs, out_ss = (size_t)8 * cs;
+  const float *tail = reinterpret_cast<const float *>(wpk + Cfg::w_bytes(NCH));
+  float sc[2], sh[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    sc[h] = tail[2 * u + h];
+    sh[h] = tail[8 + 2 * u + h];
+  }
+  const rsrc_t none = make_rsrc(in, 0);
+  // every chunk's lane images, once per workgroup (visible after the first unit's first barrier)
+  for (int unit = tid; unit < NCH * Cfg::WUNITS; unit += Cfg::THREADS) wl[unit] = reinterpret_cast<const u32x4 *>(wpk)[unit];
+
+  // lane's B voxel of the wave's first staged row: the wave owns output rows 4 wave .. 4 wave + 3 = staged rows 4 wave .. 4 wave + 5
+  const int vbase = (4 * wave) * ROW + Cfg::slot(2 * jcol + u + 3);
+
+  auto decode = [&](int v) {
+    int item = xcd_major(v, total);   // x fastest, then the z segment, then y
+    ZmItem t;
+    t.tx0 = (item % tiles_x) * Cfg::TX;
+    item /= tiles_x;
+    const int seg = item % nseg;
+    item /= nseg;
+    t.ty0 = (item % tiles_y) * Cfg::TY;
+    t.b = item / tiles_y;
+    t.zs = seg * zlen;
+    t.ze = min(t.zs + zlen, D);
+    return t;
+  };
+  // staging plan of the current prefetch target: item e = tid -> (iy, 4-x group); the plane and the channel come as a scalar offset
+  int voff, vox, vxor;
+  auto plan = [&](const ZmItem &tc) {
+    const int e = tid, iy = e / (IX / 4), g = e - iy * (IX / 4);
+    const int gy = tc.ty0 - 1 + iy, gx = tc.tx0 - 4 + 4 * g;
+    const bool ok = e < Cfg::ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;   // W % 4 == 0
+    voff = ok ? (gy * W + gx) * 4 : kOOB;
+    vox = e < Cfg::ITEMS ? iy * ROW + 4 * g : -1;
+    vxor = ((g >> 1) & 1) << 1;
+  };
+  f32x4v R[8];
+  auto prefetch = [&](const ZmItem &tc, int zi, int chunk, bool exists) {   // every load of one unit; nothing here waits
+    const rsrc_t src = exists ? make_rsrc(in + (size_t)tc.b * in_ss, in_ss * 4) : none;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) R[c] = buf_load4(src, voff, ((chunk * 8 + c) * cs + zi * HW) * 4);
+  };
+
+  // acc[0] / [1] / [2]: output planes zi - 1 / zi / zi + 1 while input plane zi is being processed
+  f32x4 acc[3][NT];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int item = blockIdx.x;
+  ZmItem cur = decode(item);
+  plan(cur);
+  prefetch(cur, max(cur.zs - 1, 0), 0, true);
+  for (;;) {
+    const int next_item = item + gridDim.x;
+    const bool have_next = next_item < total;
+    const ZmItem nxt = have_next ? decode(next_item) : cur;
+    const int zhi = min(cur.ze, D - 1);   // the last plane of this item that exists
+    const rsrc_t dst = make_rsrc(out + (size_t)cur.b * out_ss, out_ss * 4);
+#pragma unroll 1
+    for (int zi = cur.zs - 1; zi <= cur.ze; ++zi) {
+      if (zi >= 0 && zi < D) {
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ++ch) {
+          // ---- the staged unit's largest magnitude (this thread's loads -> wave -> workgroup) ----
+          float m = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(R[c][j]));
+          const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
+          if (lane == 0) wmax[wave] = wm;
+          __syncthreads();   // every wave is done with the previous unit's LDS; the four maxima are visible
+          float mult, inv;
+          casmvs::tile_scale(wmax, mult, inv);
+          // ---- registers -> LDS: the two float16 slices of every staged voxel ----
+          if (vox >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float x[8];
+#pragma unroll
+              for (int c = 0; c < 8; ++c) x[c] = R[c][j];
+              u32x4 o[2];
+              casmvs::split8_f16(x, mult, o);
+#pragma unroll
+              for (int s = 0; s < 2; ++s) act[s * NV + vox + (j ^ vxor)] = o[s];
+            }
+          }
+          __syncthreads();
+          // ---- the next unit's loads: next chunk of this plane, next plane, or the first plane of the next item ----
+          if (ch + 1 < NCH) {
+            prefetch(cur, zi, ch + 1, true);
+          } else if (zi < zhi) {
+            prefetch(cur, zi + 1, 0, true);
+          } else {
+            plan(nxt);
+            prefetch(nxt, max(nxt.zs - 1, 0), 0, have_next);
+          }
+          // ---- matrix phase: six staged rows read once; 3 kz x 3 ky x 4 rows x 3 partial products ----
+          __builtin_amdgcn_sched_barrier(0);   // the prefetch's address arithmetic is integer work, but keep the phase boundary explicit
+          u32x4 row[NT + 2][2];
+#pragma unroll
+          for (int yr = 0; yr < NT + 2; ++yr)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) row[yr][s] = act[s * NV + vbase + yr * ROW];
+          f32x4 part[3][NT];
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) part[kz][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              u32x4 a[2];
+#pragma unroll
+              for (int s = 0; s < 2; ++s) a[s] = wl[((ch * 9 + kz * 3 + ky) * 2 + s) * 64 + lane];
+              constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+#pragma unroll
+              for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) part[kz][t] = zm_mfma(a[PA[p]], row[t + ky][PB[p]], part[kz][t]);
+            }
+          // input plane zi is tap kz of output plane zi + 1 - kz.  The fold is floating-point vector work: it must not be scheduled
+          // between the matrix instructions above (the compiler did move the kz = 0 folds up) - pinned.
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[2 - kz][t][q] = fmaf(part[kz][t][q], inv, acc[2 - kz][t][q]);
+        }
+      }
+      // ---- output plane zi - 1 has seen its three input planes: y = lrelu(acc * scale + shift); then the accumulators move up ----
+      const int zo = zi - 1;
+      const bool plane_ok = zo >= cur.zs && zo < cur.ze;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int oy = cur.ty0 + 4 * wave + t, ox = cur.tx0 + 2 * jcol;
+        const bool ok = plane_ok && oy < H && ox < W;   // W even: the pixel pair is inside or outside
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v0 = fmaf(acc[0][t][2 * h], sc[h], sh[h]), v1 = fmaf(acc[0][t][2 * h + 1], sc[h], sh[h]);
+          v0 = v0 > 0.0f ? v0 : v0 * slope;
+          v1 = v1 > 0.0f ? v1 : v1 * slope;
+          buf_store2(f32x2{v0, v1}, dst, ok ? ((2 * u + h) * cs + (zo * H + oy) * W + ox) * 4 : kOOB, 0);
+        }
+        acc[0][t] = acc[1][t];
+        acc[1][t] = acc[2][t];
+        acc[2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    // what the segment's last halo plane left behind belongs to planes of the next segment: drop it
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!have_next) break;
+    item = next_item;
+    cur = nxt;
+  }
+}
+
+template <int CIN>
+int launch_zm(const void *packed, const float *in, float *out, int B, int D, int H, int W, float slope, hipStream_t st) {
+  using Cfg = ZmCfg;
+  constexpr int NCH = CIN / 8;
+  const int tiles_x = casmvs::ceil_div(W, Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY);
+  auto kernel = conv0_zm_kernel<CIN>;
+  const size_t lds = Cfg::lds_bytes(NCH);
+  if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "conv0_zm_kernel")) return rc;
+  const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), Cfg::THREADS, lds);
+  // z segments only where the (y, x) patches alone leave workgroups idle or unevenly loaded: aim at >= 4 items per resident workgroup,
+  // segments of at least 4 planes (each one re-stages a halo plane at both ends)
+  const long patches = (long)B * tiles_x * tiles_y;
+  int nseg = 1;
+  while (patches * nseg < 4L * resident && D / (nseg + 1) >= 4) ++nseg;
+  const int zlen = casmvs::ceil_div(D, nseg);
+  nseg = casmvs::ceil_div(D, zlen);
+  const long total = patches * nseg;
+  CASMVS_REQUIRE(total < (1L << 31), "conv0_zmarch_forward: too many items");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(total < resident ? total : resident)), dim3(Cfg::THREADS), lds, st, in,
+                     reinterpret_cast<const unsigned char *>(packed), out, B, D, H, W, tiles_x, tiles_y, nseg, zlen, slope);
+  return casmvs::check_launch("conv0_zm_kernel");
+}
+
+}  // namespace
+
+extern "C" int casmvs_conv0_zmarch_supported(int cin, int W) { return (cin == 8 || cin == 16) && W % 4 == 0 && W >= 4; }
+
+extern "C" int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
+                                               float slope, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(packed && in && out, "conv0_zmarch_forward: null pointer");
+  CASMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && casmvs_conv0_zmarch_supported(cin, W), "conv0_zmarch_forward: B=%d cin=%d D=%d H=%d W=%d", B, cin, D, H, W);
+  CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(packed)) & 15) == 0, "conv0_zmarch_forward: 16-byte aligned pointers");
+  CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 29), "conv0_zmarch_forward: one sample's input tensor must hold < 2^29 floats");
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 8) return launch_zm<8>(packed, in, out, B, D, H, W, slope, st);
+  return launch_zm<16>(packed, in, out, B, D, H, W, slope, st);
+}

@@ -338,6 +338,20 @@ def conv0_splitf16_forward(packed, x, slope=0.01, terms=0):
     return out
 
 
+def conv0_zmarch_forward(packed, x, slope=0.01):
+    """conv0 in split-f16 arithmetic, input-stationary along z (casmvs_conv0_zmarch_forward_f32, csrc/conv0_zmarch.hip): `packed` is the
+    image of conv0_splitf16_pack, x (B,cin,D,H,W) with cin 8 / 16 -> (B,8,D,H,W).  Opt-in (added without a GPU run at the end of round 3)."""
+    x = _dev(x, "x")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("conv0_zmarch_forward: `packed` must be the uint8 image on the MI355X")
+    B, cin, D, H, W = x.shape
+    out = torch.empty((B, 8, D, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_conv0_zmarch_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W, float(slope), _stream(x))
+    _lib.check(rc, "casmvs_conv0_zmarch_forward_f32")
+    return out
+
+
 def selftest_mfma_f16():
     """Lane-semantics probe of v_mfma_f32_16x16x32_f16 -> (rc, dump (4 regs, 64 lanes), message)."""
     dump = torch.zeros(4 * 64, dtype=torch.float32)

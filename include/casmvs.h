@@ -205,6 +205,17 @@ int casmvs_conv0_splitf16_pack(int cin, const float *weight, const float *scale,
 int casmvs_conv0_splitf16_supported(int cin, int W);
 int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
                                       float slope, int terms, void *stream);
+
+/* conv0 in the same split-f16 arithmetic, input-stationary along z (csrc/conv0_zmarch.hip): a workgroup owns a 16 x 32 (y, x) patch and
+ * marches along z, staging every input plane once per chunk of 8 channels (per-plane power-of-two scaling) and feeding the three
+ * output planes it touches - half the staged voxels per output voxel of casmvs_conv0_splitf16_forward_f32, whose L1 -> L2 request
+ * stream bounds it.  `packed`: the image of casmvs_conv0_splitf16_pack.  cin = 8 or 16, W % 4 == 0.  Results agree with the other
+ * entry to ~1e-6 of the range (both ~3e-7 from a float64 convolution), not bit for bit.
+ * WRITTEN WITHOUT A GPU RUN at the end of round 3 (tools/native/conv0_zm_check.cpp is its first test): opt-in, nothing in the
+ * package calls it. */
+int casmvs_conv0_zmarch_supported(int cin, int W);
+int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope,
+                                    void *stream);
 int casmvs_selftest_mfma_f16(float *dump);
 
 /* CostRegNet's stride-1 layers with equal channel counts (conv2: 16 -> 16, conv4: 32 -> 32, conv6: 64 -> 64; Conv3d k3 s1 p1 + folded ABN +

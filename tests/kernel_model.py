@@ -854,3 +854,61 @@ def fusion_paired_taps(depth, image, ix, iy):
             w32 = (word >> 24 if hi else word) & 0xFFFFFFFF
             ctaps.append([(w32 >> (8 * c)) & 255 for c in range(3)])
     return dtaps, ctaps
+
+
+def emulate_conv0_zmarch(packed, x, cin, slope=0.01, patch=(16, 32), halo_x=(4, 4), zlen=None):
+    """Data flow of conv0_zm_kernel (csrc/conv0_zmarch.hip) in float64: a staged UNIT is one input plane of a 16 x 32 (y, x) patch with its
+    halo (y0-1..y0+16, x0-4..x0+35; zero outside the volume) and one chunk of 8 channels; it is scaled by the power of two that puts its
+    largest magnitude into [2^14, 2^15), split into f16(x') and f16(x' - f16(x')), multiplied (aa, ab, ba) with the packed lane images'
+    weight slices of ALL three kz - input plane zi is tap kz of output plane zi + 1 - kz - unscaled by 2^-kx and added to that output
+    plane.  zlen: z segment length (None: the whole depth); a segment's first / last halo plane contributes only inside the segment, so
+    the segmentation does not change a single number.  x (B, cin, D, H, W) float32 numpy -> (B, 8, D, H, W)."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    nch = cin // 8
+    body = nch * 9 * 2 * 64 * 8 * 2
+    img = raw[:body].view(np.float16).reshape(nch, 9, 2, 64, 8).astype(np.float64)
+    tail = raw[body:body + 64].view(np.float32).astype(np.float64)
+    scale, shift = tail[:8], tail[8:16]
+    B, _, D, H, W = x.shape
+    TY, TX = patch
+    hl, hr = halo_x
+    px = ((W + TX - 1) // TX) * TX - W
+    xp = np.pad(x.astype(np.float32), ((0, 0), (0, 0), (0, 0), (1, TY + 1), (hl, hr + px)))
+    zlen = D if zlen is None else zlen
+    acc = np.zeros((B, 8, D, H, W))
+    for b in range(B):
+        for zs in range(0, D, zlen):
+            ze = min(zs + zlen, D)
+            for y0 in range(0, H, TY):
+                for x0 in range(0, W, TX):
+                    out = np.zeros((8, D + 2, TY, TX))                     # output planes -1 .. D (the out-of-range ones are dropped)
+                    for zi in range(max(zs - 1, 0), min(ze, D - 1) + 1):
+                        for ch in range(nch):
+                            halo = xp[b, ch * 8:ch * 8 + 8, zi, y0:y0 + TY + 2, x0:x0 + TX + hl + hr]
+                            e = max(int(np.abs(halo).max().view(np.uint32)) >> 23, 15)
+                            mult, inv = np.float32(2.0) ** (141 - e), 2.0 ** (e - 141)
+                            xs = halo * mult
+                            xa = xs.astype(np.float16)
+                            xb = (xs - xa.astype(np.float32)).astype(np.float16)
+                            sl = [xa.astype(np.float64), xb.astype(np.float64)]
+                            for r9 in range(9):
+                                kz, ky = divmod(r9, 3)
+                                zo = zi + 1 - kz
+                                if not (zs <= zo < ze):
+                                    continue
+                                part = np.zeros((8, TY, TX))
+                                for (sa, sb) in SF_TERMS[:3]:
+                                    A = img[ch, r9, sa].reshape(4, 16, 8)                       # [u][i][ci]
+                                    for u in range(4):
+                                        for s in range(2):
+                                            wrow = A[u, s::2, :]                                # (co, ci); zero where u - s is not a tap
+                                            if not wrow.any():
+                                                continue
+                                            src = sl[sb][:, ky:ky + TY, u - 1 + hl:u - 1 + hl + TX:2]
+                                            part[:, :, s::2] += np.einsum("oc,chw->ohw", wrow, src)
+                                out[:, zo + 1] += part * inv
+                    dy, dx = min(TY, H - y0), min(TX, W - x0)
+                    acc[b, :, zs:ze, y0:y0 + dy, x0:x0 + dx] = out[:, zs + 1:ze + 1, :dy, :dx]
+    y = acc * scale[None, :, None, None, None] + shift[None, :, None, None, None]
+    return np.where(y > 0, y, y * slope)

@@ -359,3 +359,30 @@ def test_fusion_paired_tap_fetch_equals_direct_indexing():
                 dt, ct = fusion_paired_taps(depth, image, ix, iy)
                 assert [float(v) for v in dt] == [float(depth[y, x]) for y, x in want], (H, W, ix, iy)
                 assert ct == [[int(v) for v in image[y, x]] for y, x in want], (H, W, ix, iy)
+
+
+@pytest.mark.parametrize("cin,shape,zlen", [(8, (1, 5, 20, 36), None), (16, (2, 9, 17, 44), 4), (8, (1, 3, 33, 32), 2)])
+def test_conv0_zmarch_host_model_is_a_float32_grade_convolution(cin, shape, zlen):
+    """The arithmetic of csrc/conv0_zmarch.hip (per-plane-patch power-of-two scaling, two float16 slices, three partial products, the
+    packed image of casmvs_conv0_splitf16_pack) restated on the host: within 1e-6 of the range from a float64 convolution, equal - to
+    float64 rounding - with and without z segments, and as close as the tiled kernel's model."""
+    import numpy as np
+    import torch
+    from casmvsnet_pl_amd import ops
+    from kernel_model import emulate_conv0_splitf16, emulate_conv0_zmarch
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(cin + D)
+    x = torch.randn(B, cin, D, H, W, generator=g) * 3.0
+    x[:, :, :, :3, :5] *= 1e-4                                   # a corner far below the rest: its planes get their own scale
+    w = torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2
+    scale, shift = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    packed = ops.conv0_splitf16_pack(w, scale, shift).numpy()
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1) * scale.double().view(1, 8, 1, 1, 1) + shift.double().view(1, 8, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01).numpy()
+    rng = np.abs(ref).max()
+    got = emulate_conv0_zmarch(packed, x.numpy(), cin, zlen=zlen)
+    whole = emulate_conv0_zmarch(packed, x.numpy(), cin, zlen=None)
+    tiled = emulate_conv0_splitf16(packed, x.numpy(), cin)
+    assert np.abs(got - ref).max() / rng < 1e-6
+    assert np.abs(got - whole).max() / rng < 1e-12
+    assert np.abs(got - ref).max() <= 3.0 * np.abs(tiled - ref).max() + 1e-7 * rng

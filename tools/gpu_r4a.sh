@@ -9,6 +9,8 @@ OUT=$ROOTDIR/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOTDIR
 export TMPDIR=/tmp
+# torch-free first (seconds): the kernel written blind at the end of round 3, then the checks of the kernels that are already defaults
+(timeout 60 tools/probes/bin/conv0_zm_check 2; timeout 30 tools/probes/bin/prob_wgrad_check; timeout 30 tools/probes/bin/fusion_check; timeout 60 python tools/notorch/step_runner.py --batch 8) > $OUT/native.txt 2>&1
 nproc > $OUT/host.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host.txt 2>/dev/null; lscpu | grep -E "Model name|^CPU\(s\)|Flags" | cut -c1-600 >> $OUT/host.txt
 timeout 120 python tools/cpu_png_decode_bench.py 48 1 8 16 32 > $OUT/cpu_png_decode.txt 2>&1
 timeout 200 python tools/cpu_loader_rate.py 49 8 16 32 64 > $OUT/cpu_loader_rate.txt 2>&1
@@ -19,4 +21,4 @@ FT_BATCH=8 FT_GRAPH=1 FT_THREADED=1 timeout 300 python tools/gpu_files_throughpu
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit: $?" >> $OUT/pytest_gpu.log
-tail -3 $OUT/pytest_gpu.log; cat $OUT/fusion_probe.txt; tail -4 $OUT/files_b8_graph*.txt; cut -c1-300 $OUT/bench.json
+cat $OUT/native.txt; tail -3 $OUT/pytest_gpu.log; cat $OUT/fusion_probe.txt; tail -4 $OUT/files_b8_graph*.txt; cut -c1-300 $OUT/bench.json
