@@ -51,6 +51,10 @@ SYMBOLS = {
     "casmvs_conv0_splitf16_supported": (c_int, [c_int, c_int]),
     "casmvs_conv0_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_selftest_mfma_f16": (c_int, [_FP]),
+    "casmvs_fnet_conv0_fused_packed_bytes": (c_size_t, []),
+    "casmvs_fnet_conv0_fused_pack": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "casmvs_fnet_conv0_fused_supported": (c_int, [c_int]),
+    "casmvs_fnet_conv0_fused_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_conv0_zmarch_supported": (c_int, [c_int, c_int]),
     "casmvs_conv0_zmarch_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_debug_disturb": (c_int, [c_int, c_int, c_int, c_int, _FP, c_void_p]),

@@ -615,6 +615,32 @@ def fpn_tail0_splitf16(packed, bias9, conv0, feat1_sum, channels_last_copy=False
     return (out, out2) if channels_last_copy else out
 
 
+def fnet_conv0_fused_pack(w0, scale0, shift0, w1, scale1, shift1):
+    """Host-side packing for casmvs_fnet_conv0_fused_f32: conv0.0 (8,3,3,3) and conv0.1 (8,8,3,3) with their folded ABN -> uint8 CPU tensor."""
+    lib = _lib.load()
+    t = [None if a is None else a.detach().to("cpu", torch.float32).contiguous() for a in (w0, scale0, shift0, w1, scale1, shift1)]
+    if tuple(t[0].shape) != (8, 3, 3, 3) or tuple(t[3].shape) != (8, 8, 3, 3):
+        raise ValueError(f"fnet_conv0_fused_pack: weights {tuple(t[0].shape)} {tuple(t[3].shape)} (need (8,3,3,3) and (8,8,3,3))")
+    packed = torch.empty(lib.casmvs_fnet_conv0_fused_packed_bytes(), dtype=torch.uint8)
+    rc = lib.casmvs_fnet_conv0_fused_pack(*[_ptr(a) for a in t], ctypes.c_void_p(packed.data_ptr()))
+    _lib.check(rc, "casmvs_fnet_conv0_fused_pack")
+    return packed
+
+
+def fnet_conv0_fused(packed, imgs, slope=0.01):
+    """FeatureNet.conv0 (two ConvBnReLU layers) as one kernel (casmvs_fnet_conv0_fused_f32): imgs (N,3,H,W) -> (N,8,H,W).  Opt-in (added
+    without a GPU run at the end of round 3)."""
+    imgs = _dev(imgs, "imgs")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("fnet_conv0_fused: `packed` must be the uint8 image on the MI355X")
+    N, c, H, W = imgs.shape
+    out = torch.empty((N, 8, H, W), dtype=torch.float32, device=imgs.device)
+    with torch.cuda.device(imgs.device):
+        rc = _lib.load().casmvs_fnet_conv0_fused_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(imgs), _ptr(out), N, H, W, float(slope), _stream(imgs))
+    _lib.check(rc, "casmvs_fnet_conv0_fused_f32")
+    return out
+
+
 def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None, channels_last_copies=False, fused0=None, fused0_splitf16=False,
                        ci_layers=None):
     """Whole FeatureNet (mvsnet.py:40-57).  packed_layers: 13 device tensors (conv0.0 .. conv2.2,

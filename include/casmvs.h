@@ -319,6 +319,18 @@ int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const
                                         void *workspace, int N, int H, int W, float slope,
                                         void *const *layer_events, void *stream);
 
+/* FeatureNet.conv0 = ConvBnReLU(3, 8, 3) -> ConvBnReLU(8, 8, 3) (models/mvsnet.py:14-16) as ONE kernel (csrc/fnet_conv0_fused.hip): the image tile
+ * in LDS, the first layer on the vector ALU (its 8-channel output never leaves the CU), the second in conv0_splitf16.hip's matrix form with
+ * one z tap (float32-grade split-f16 arithmetic).  imgs (N, 3, H, W) -> out (N, 8, H, W); W % 4 == 0.  `packed` (host,
+ * casmvs_fnet_conv0_fused_packed_bytes): w0 (8,3,3,3) / w1 (8,8,3,3) = the torch weights, scale / shift = the folded eval-mode ABN of each layer.
+ * WRITTEN WITHOUT A GPU RUN at the end of round 3 (tools/native/fnet_conv0_check.cpp is its first test): opt-in, nothing in the package
+ * calls it; casmvs_featurenet_forward*_f32 run the two layers as separate launches. */
+size_t casmvs_fnet_conv0_fused_packed_bytes(void);
+int casmvs_fnet_conv0_fused_pack(const float *w0, const float *scale0, const float *shift0, const float *w1, const float *scale1,
+                                 const float *shift1, void *packed);
+int casmvs_fnet_conv0_fused_supported(int W);
+int casmvs_fnet_conv0_fused_f32(const void *packed, const float *imgs, float *out, int N, int H, int W, float slope, void *stream);
+
 /* ---- (a9) softmax over depth + soft-argmin regression + confidence --------------------------
  * Replaces: models/mvsnet.py:174-193 and models/modules.py:95-104:
  *   p = softmax_D(cost); depth = sum_k p_k d_k; idx = clamp(trunc(sum_k p_k k), 0, D-1);

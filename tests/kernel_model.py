@@ -912,3 +912,57 @@ def emulate_conv0_zmarch(packed, x, cin, slope=0.01, patch=(16, 32), halo_x=(4, 
                     acc[b, :, zs:ze, y0:y0 + dy, x0:x0 + dx] = out[:, zs + 1:ze + 1, :dy, :dx]
     y = acc * scale[None, :, None, None, None] + shift[None, :, None, None, None]
     return np.where(y > 0, y, y * slope)
+
+
+def emulate_fnet_conv0_fused(packed, imgs, slope=0.01, tile=(16, 32), halo_x=(4, 4)):
+    """Data flow of fnet_conv0_fused_kernel (csrc/fnet_conv0_fused.hip): conv0.0 (3 -> 8, 3 x 3, zero padding) + its folded ABN + leaky-relu
+    in float32 from the packed image's [ci][ky][kx][co] weights, ZERO outside the image; per 16 x 32 output tile that map's halo box
+    (y0-1..y0+16, x0-4..x0+35) is scaled by the power of two that puts its largest magnitude into [2^14, 2^15), split into two float16
+    slices and multiplied (aa, ab, ba) with conv0.1's lane images (the packing of a (kz, ky) pair of conv0_splitf16.hip, one per ky),
+    unscaled; conv0.1's scale (which carries 2^-kw) / shift / leaky-relu.  imgs (N, 3, H, W) float32 numpy -> (N, 8, H, W) float64."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    img1 = raw[:6144].view(np.float16).reshape(3, 2, 64, 8).astype(np.float64)
+    tail = raw[6144:6144 + 248 * 4].view(np.float32)
+    scale1, shift1 = tail[:8].astype(np.float64), tail[8:16].astype(np.float64)
+    w0 = tail[16:16 + 216].reshape(3, 3, 3, 8)                          # [ci][ky][kx][co]
+    scale0, shift0 = tail[232:240], tail[240:248]
+    N, _, H, W = imgs.shape
+    xp = np.pad(imgs.astype(np.float32), ((0, 0), (0, 0), (1, 1), (1, 1)))
+    mid = np.zeros((N, 8, H, W), np.float32)
+    for ci in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                mid += xp[:, ci, None, ky:ky + H, kx:kx + W] * w0[ci, ky, kx][None, :, None, None]
+    mid = mid * scale0[None, :, None, None] + shift0[None, :, None, None]
+    mid = np.where(mid > 0, mid, mid * np.float32(slope)).astype(np.float32)
+    TY, TX = tile
+    hl, hr = halo_x
+    px = ((W + TX - 1) // TX) * TX - W
+    mp = np.pad(mid, ((0, 0), (0, 0), (1, TY + 1), (hl, hr + px)))
+    acc = np.zeros((N, 8, H, W))
+    for n in range(N):
+        for y0 in range(0, H, TY):
+            for x0 in range(0, W, TX):
+                halo = mp[n, :, y0:y0 + TY + 2, x0:x0 + TX + hl + hr]
+                e = max(int(np.abs(halo).max().view(np.uint32)) >> 23, 15)
+                mult, inv = np.float32(2.0) ** (141 - e), 2.0 ** (e - 141)
+                xs = halo * mult
+                xa = xs.astype(np.float16)
+                xb = (xs - xa.astype(np.float32)).astype(np.float16)
+                sl = [xa.astype(np.float64), xb.astype(np.float64)]
+                part = np.zeros((8, TY, TX))
+                for ky in range(3):
+                    for (sa, sb) in SF_TERMS[:3]:
+                        A = img1[ky, sa].reshape(4, 16, 8)                   # [u][i][ci]
+                        for u in range(4):
+                            for s in range(2):
+                                wrow = A[u, s::2, :]
+                                if not wrow.any():
+                                    continue
+                                src = sl[sb][:, ky:ky + TY, u - 1 + hl:u - 1 + hl + TX:2]
+                                part[:, :, s::2] += np.einsum("oc,chw->ohw", wrow, src)
+                dy, dx = min(TY, H - y0), min(TX, W - x0)
+                acc[n, :, y0:y0 + dy, x0:x0 + dx] = (part * inv)[:, :dy, :dx]
+    y = acc * scale1[None, :, None, None] + shift1[None, :, None, None]
+    return np.where(y > 0, y, y * slope)

@@ -386,3 +386,27 @@ def test_conv0_zmarch_host_model_is_a_float32_grade_convolution(cin, shape, zlen
     assert np.abs(got - ref).max() / rng < 1e-6
     assert np.abs(got - whole).max() / rng < 1e-12
     assert np.abs(got - ref).max() <= 3.0 * np.abs(tiled - ref).max() + 1e-7 * rng
+
+
+@pytest.mark.parametrize("shape", [(1, 20, 36), (2, 33, 44), (1, 16, 4)])
+def test_fnet_conv0_fused_host_model_is_the_two_layers(shape):
+    """The arithmetic of csrc/fnet_conv0_fused.hip restated on the host (float32 first layer zeroed outside the image, split-f16 second layer
+    from casmvs_fnet_conv0_fused_pack's image): within 2e-6 of the range from the two ConvBnReLU layers in float64."""
+    import numpy as np
+    import torch
+    from casmvsnet_pl_amd import ops
+    from kernel_model import emulate_fnet_conv0_fused
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w0, w1 = torch.randn(8, 3, 3, 3, generator=g) * 0.3, torch.randn(8, 8, 3, 3, generator=g) * 0.2
+    s0, b0 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    s1, b1 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    packed = ops.fnet_conv0_fused_pack(w0, s0, b0, w1, s1, b1).numpy()
+
+    def layer(t, w, s, b):
+        y = torch.nn.functional.conv2d(t, w.double(), padding=1) * s.double().view(1, 8, 1, 1) + b.double().view(1, 8, 1, 1)
+        return torch.where(y > 0, y, y * 0.01)
+    ref = layer(layer(x.double(), w0, s0, b0), w1, s1, b1).numpy()
+    got = emulate_fnet_conv0_fused(packed, x.numpy())
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
