@@ -338,6 +338,38 @@ def conv0_splitf16_forward(packed, x, slope=0.01, terms=0):
     return out
 
 
+def deconv11_splitf16_pack(weight, scale=None, shift=None):
+    """Host-side packing of conv11 (ConvTranspose3d 16 -> 8, weight (16, 8, 3, 3, 3)) for casmvs_deconv11_splitf16_forward_f32 -> uint8 CPU tensor."""
+    weight = weight.detach().to("cpu", torch.float32).contiguous()
+    if tuple(weight.shape) != (16, 8, 3, 3, 3):
+        raise ValueError(f"deconv11_splitf16_pack: weight {tuple(weight.shape)} (need (16, 8, 3, 3, 3))")
+    lib = _lib.load()
+    packed = torch.empty(lib.casmvs_deconv11_splitf16_packed_bytes(), dtype=torch.uint8)
+    sc = None if scale is None else scale.detach().to("cpu", torch.float32).contiguous()
+    sh = None if shift is None else shift.detach().to("cpu", torch.float32).contiguous()
+    rc = lib.casmvs_deconv11_splitf16_pack(_ptr(weight), _ptr(sc), _ptr(sh), ctypes.c_void_p(packed.data_ptr()))
+    _lib.check(rc, "casmvs_deconv11_splitf16_pack")
+    return packed
+
+
+def deconv11_splitf16_forward(packed, x, skip=None, slope=0.01):
+    """conv11 (+ ABN + leaky-relu + skip) on the f16 matrix cores (casmvs_deconv11_splitf16_forward_f32): x (B,16,Di,Hi,Wi), skip (B,8,2Di,2Hi,2Wi) or
+    None -> (B,8,2Di,2Hi,2Wi).  Opt-in (added without a GPU run at the end of round 3)."""
+    x = _dev(x, "x")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("deconv11_splitf16_forward: `packed` must be the uint8 image on the MI355X")
+    B, cin, Di, Hi, Wi = x.shape
+    if cin != 16:
+        raise ValueError("deconv11_splitf16_forward: 16 input channels")
+    if skip is not None:
+        skip = _dev(skip, "skip")
+    out = torch.empty((B, 8, 2 * Di, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_deconv11_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(skip), _ptr(out), B, Di, Hi, Wi, float(slope), _stream(x))
+    _lib.check(rc, "casmvs_deconv11_splitf16_forward_f32")
+    return out
+
+
 def conv0_zmarch_forward(packed, x, slope=0.01):
     """conv0 in split-f16 arithmetic, input-stationary along z (casmvs_conv0_zmarch_forward_f32, csrc/conv0_zmarch.hip): `packed` is the
     image of conv0_splitf16_pack, x (B,cin,D,H,W) with cin 8 / 16 -> (B,8,D,H,W).  Opt-in (added without a GPU run at the end of round 3)."""

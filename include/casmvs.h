@@ -216,6 +216,18 @@ int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float
 int casmvs_conv0_zmarch_supported(int cin, int W);
 int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope,
                                     void *stream);
+
+/* CostRegNet.conv11 = ConvTranspose3d(16 -> 8, k3 s2 p1 op1) + ABN + leaky-relu, plus the `conv0 + ...` skip (models/mvsnet.py:84-86, 101), on the
+ * f16 matrix cores in the same split arithmetic (csrc/deconv11_splitf16.hip): the x parities of the output are the two halves of the MFMA rows,
+ * K = 2 input x positions x 16 input channels, one MFMA set per (kz, ky) pair and 32 output x; output tile 4 x 8 x 32 from a 3 x 5 x 18 input box.
+ * in (B, 16, Di, Hi, Wi); skip (B, 8, 2 Di, 2 Hi, 2 Wi) or NULL; out like skip.  weight (16, 8, 3, 3, 3) = the torch ConvTranspose3d layout.
+ * casmvs_conv3d_forward_f32(CASMVS_CONV_T2, ...) is the float32-MFMA form of the same layer (0.9 ms of the 8.5 ms step).
+ * WRITTEN WITHOUT A GPU RUN at the end of round 3 (tools/native/deconv11_check.cpp is its first test): opt-in, nothing in the package calls it. */
+size_t casmvs_deconv11_splitf16_packed_bytes(void);
+int casmvs_deconv11_splitf16_pack(const float *weight, const float *scale, const float *shift, void *packed);
+int casmvs_deconv11_splitf16_supported(int Wi);
+int casmvs_deconv11_splitf16_forward_f32(const void *packed, const float *in, const float *skip, float *out, int B, int Di, int Hi, int Wi,
+                                         float slope, void *stream);
 int casmvs_selftest_mfma_f16(float *dump);
 
 /* CostRegNet's stride-1 layers with equal channel counts (conv2: 16 -> 16, conv4: 32 -> 32, conv6: 64 -> 64; Conv3d k3 s1 p1 + folded ABN +

@@ -966,3 +966,70 @@ def emulate_fnet_conv0_fused(packed, imgs, slope=0.01, tile=(16, 32), halo_x=(4,
                 acc[n, :, y0:y0 + dy, x0:x0 + dx] = (part * inv)[:, :dy, :dx]
     y = acc * scale1[None, :, None, None] + shift1[None, :, None, None]
     return np.where(y > 0, y, y * slope)
+
+
+def emulate_deconv11_splitf16(packed, x, skip=None, slope=0.01, tile=(4, 8, 32)):
+    """Data flow of deconv11_sf_kernel (csrc/deconv11_splitf16.hip) in float64.  The lane images [kz * 3 + ky][slice][lane][8 f16] are decoded into the two
+    weight slices W_s[ci][co][kz][ky][kx] exactly as the kernel's lanes meet them (lane (i, kb): co = i >> 1, px = i & 1, dx = kb >> 1,
+    ci = 8 (kb & 1) + e; kx = 1 / 2 / 0 for (px, dx) = (0, 0) / (1, 0) / (1, 1), and (0, 1) must be zero); per output tile the input box
+    (tz0/2 .. +2, ty0/2 .. +4, tx0/2 .. +17; zero beyond the volume) is scaled by the power of two that puts its largest magnitude into
+    [2^14, 2^15), split into two float16 slices and multiplied (aa, ab, ba) tap by tap - out[o] += in[i] w[k] with o = 2 i - 1 + k per axis -,
+    unscaled; scale (which carries 2^-kw) / shift / leaky-relu, then + skip.  x (B, 16, Di, Hi, Wi) float32 numpy -> (B, 8, 2 Di, 2 Hi, 2 Wi)."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    body = 9 * 2 * 64 * 8 * 2
+    img = raw[:body].view(np.float16).reshape(9, 2, 64, 8).astype(np.float64)
+    tail = raw[body:body + 64].view(np.float32).astype(np.float64)
+    scale, shift = tail[:8], tail[8:16]
+    Ws = np.zeros((2, 16, 8, 3, 3, 3))
+    for r9 in range(9):
+        for lane in range(64):
+            i, kb = lane & 15, lane >> 4
+            co, px, dx = i >> 1, i & 1, kb >> 1
+            kx = {(0, 0): 1, (1, 0): 2, (1, 1): 0}.get((px, dx))
+            vals = img[r9, :, lane, :]
+            if kx is None:
+                assert not vals.any(), "the (even x, next input) quarter of a lane image must be zero"
+                continue
+            Ws[:, 8 * (kb & 1):8 * (kb & 1) + 8, co, r9 // 3, r9 % 3, kx] = vals
+    B, _, Di, Hi, Wi = x.shape
+    TZ, TY, TX = tile
+    Do, Ho, Wo = 2 * Di, 2 * Hi, 2 * Wi
+    bz, by, bx = TZ // 2 + 1, TY // 2 + 1, TX // 2 + 1
+    xp = np.pad(x.astype(np.float32), ((0, 0), (0, 0), (0, bz + TZ), (0, by + TY), (0, bx + TX)))
+    acc = np.zeros((B, 8, Do, Ho, Wo))
+    for b in range(B):
+        for z0 in range(0, Do, TZ):
+            for y0 in range(0, Ho, TY):
+                for x0 in range(0, Wo, TX):
+                    box = xp[b, :, z0 // 2:z0 // 2 + bz, y0 // 2:y0 // 2 + by, x0 // 2:x0 // 2 + bx + 1]   # 3 x 5 x 18: what the kernel stages
+                    e = max(int(np.abs(box).max().view(np.uint32)) >> 23, 15)
+                    mult, inv = np.float32(2.0) ** (141 - e), 2.0 ** (e - 141)
+                    xs = box * mult
+                    xa = xs.astype(np.float16)
+                    xb = (xs - xa.astype(np.float32)).astype(np.float16)
+                    sl = [xa.astype(np.float64), xb.astype(np.float64)]
+                    out = np.zeros((8, TZ, TY, TX))
+                    for (sa, sb) in SF_TERMS[:3]:
+                        for kz in range(3):
+                            for ky in range(3):
+                                for kx in range(3):
+                                    w = Ws[sa, :, :, kz, ky, kx]                          # (ci, co)
+                                    # outputs o = 2 i - 1 + k inside the tile, i relative to the box origin (= tile origin / 2)
+                                    for iz in range(bz):
+                                        oz = 2 * iz - 1 + kz
+                                        if not (0 <= oz < TZ):
+                                            continue
+                                        for iy in range(by):
+                                            oy = 2 * iy - 1 + ky
+                                            if not (0 <= oy < TY):
+                                                continue
+                                            ix = np.arange(bx + 1)
+                                            ox = 2 * ix - 1 + kx
+                                            ok = (ox >= 0) & (ox < TX)
+                                            out[:, oz, oy, ox[ok]] += np.einsum("io,iw->ow", w, sl[sb][:, iz, iy, ix[ok]])
+                    dz, dy, dx_ = min(TZ, Do - z0), min(TY, Ho - y0), min(TX, Wo - x0)
+                    acc[b, :, z0:z0 + dz, y0:y0 + dy, x0:x0 + dx_] = (out * inv)[:, :dz, :dy, :dx_]
+    y = acc * scale[None, :, None, None, None] + shift[None, :, None, None, None]
+    y = np.where(y > 0, y, y * slope)
+    return y + (0 if skip is None else skip.astype(np.float64))

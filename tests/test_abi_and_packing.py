@@ -410,3 +410,25 @@ def test_fnet_conv0_fused_host_model_is_the_two_layers(shape):
     ref = layer(layer(x.double(), w0, s0, b0), w1, s1, b1).numpy()
     got = emulate_fnet_conv0_fused(packed, x.numpy())
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 4, 16), (2, 3, 5, 10), (1, 1, 9, 22)])
+def test_deconv11_splitf16_host_model_is_the_transposed_convolution(shape):
+    """The arithmetic and the tap / parity bookkeeping of csrc/deconv11_splitf16.hip restated on the host from casmvs_deconv11_splitf16_pack's
+    image: within 1e-6 of the range from ConvTranspose3d(16, 8, 3, stride 2, padding 1, output_padding 1) + ABN + leaky-relu + skip in float64."""
+    import numpy as np
+    import torch
+    from casmvsnet_pl_amd import ops
+    from kernel_model import emulate_deconv11_splitf16
+    B, Di, Hi, Wi = shape
+    g = torch.Generator().manual_seed(Di * 10 + Wi)
+    x = torch.randn(B, 16, Di, Hi, Wi, generator=g) * 2.0
+    w = torch.randn(16, 8, 3, 3, 3, generator=g) * 0.2
+    scale, shift = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    skip = torch.randn(B, 8, 2 * Di, 2 * Hi, 2 * Wi, generator=g)
+    packed = ops.deconv11_splitf16_pack(w, scale, shift).numpy()
+    ref = torch.nn.functional.conv_transpose3d(x.double(), w.double(), stride=2, padding=1, output_padding=1)
+    ref = ref * scale.double().view(1, 8, 1, 1, 1) + shift.double().view(1, 8, 1, 1, 1)
+    ref = (torch.where(ref > 0, ref, ref * 0.01) + skip.double()).numpy()
+    got = emulate_deconv11_splitf16(packed, x.numpy(), skip.numpy())
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-6
