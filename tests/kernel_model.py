@@ -1033,3 +1033,249 @@ def emulate_deconv11_splitf16(packed, x, skip=None, slope=0.01, tile=(4, 8, 32))
     y = acc * scale[None, :, None, None, None] + shift[None, :, None, None, None]
     y = np.where(y > 0, y, y * slope)
     return y + (0 if skip is None else skip.astype(np.float64))
+
+
+# ---- lane-level transcriptions of the kernels written without a GPU run (round 3): the index arithmetic of every thread, the LDS
+# ---- images and the operand / result lanes of v_mfma_f32_16x16x32_f16, so that a wrong offset shows on the CPU
+def mfma_16x16x32(a_lanes, b_lanes):
+    """D (16 x 16) = A B for one wave: a_lanes / b_lanes (64 lanes, 8 values).  Lane l of A holds row i = l & 15, k = 8 (l >> 4) .. + 8; lane l of
+    B holds column j = l & 15, the same k.  (The result lanes: lane l holds column j = l & 15, rows 4 (l >> 4) + r; casmvs_selftest_mfma_f16.)"""
+    import numpy as np
+    A = np.zeros((16, 32))
+    Bm = np.zeros((32, 16))
+    for l in range(64):
+        A[l & 15, 8 * (l >> 4):8 * (l >> 4) + 8] = a_lanes[l]
+        Bm[8 * (l >> 4):8 * (l >> 4) + 8, l & 15] = b_lanes[l]
+    return A @ Bm
+
+
+def split_f16_np(x32, mult):
+    import numpy as np
+    xs = (x32.astype(np.float32) * np.float32(mult)).astype(np.float32)
+    a = xs.astype(np.float16)
+    b = (xs - a.astype(np.float32)).astype(np.float16)
+    return a.astype(np.float64), b.astype(np.float64)
+
+
+def tile_scale_np(values):
+    """casmvs::tile_scale: mult = 2^kx that puts the largest magnitude into [2^14, 2^15), inv = 2^-kx (exponent field >= 15)."""
+    import numpy as np
+    e = max(int(np.abs(np.asarray(values, np.float32)).max().view(np.uint32)) >> 23, 15)
+    return np.float32(2.0) ** (141 - e), 2.0 ** (e - 141)
+
+
+def emulate_deconv11_lanes(packed, x, skip, slope=0.01):
+    """deconv11_sf_kernel thread by thread (csrc/deconv11_splitf16.hip): staging items -> LDS planes [slice][half][272], the lanes' B units vb[izl][iyr],
+    the (kz, ky) -> (output plane, input plane, row) tables, the result lanes' (channel, x parity, column) -> output addresses."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    wl = raw[:9 * 2 * 64 * 16].view(np.float16).reshape(9 * 2 * 64, 8).astype(np.float64)   # [(r9 * 2 + s) * 64 + lane]
+    tail = raw[9 * 2 * 64 * 16:][:64].view(np.float32).astype(np.float64)
+    B, _, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = 2 * Di, 2 * Hi, 2 * Wi
+    out = np.full((B, 8, Do, Ho, Wo), np.nan)
+    JY, JX, NVOX = 5, 18, 272
+    PA, PB = (0, 0, 1), (0, 1, 0)
+    for b in range(B):
+        for tz0 in range(0, Do, 4):
+            for ty0 in range(0, Ho, 8):
+                for tx0 in range(0, Wo, 32):
+                    # staging: thread e -> (box plane, row, pair of x), 16 channels, 2 voxels
+                    R = np.zeros((256, 16, 2), np.float32)
+                    vox = np.full(256, -1)
+                    for tid in range(135):
+                        e_iz, rem = divmod(tid, JY * (JX // 2))
+                        e_iy, e_g = divmod(rem, JX // 2)
+                        vox[tid] = (e_iz * JY + e_iy) * JX + 2 * e_g
+                        gz, gy, gx = tz0 // 2 + e_iz, ty0 // 2 + e_iy, tx0 // 2 + 2 * e_g
+                        if gz < Di and gy < Hi and gx < Wi:
+                            R[tid] = x[b, :, gz, gy, gx:gx + 2]
+                    mult, inv = tile_scale_np(R)
+                    act = np.zeros((4 * NVOX, 8))
+                    for tid in range(135):
+                        for hf in range(2):
+                            for p in range(2):
+                                sa, sb = split_f16_np(R[tid, hf * 8:hf * 8 + 8, p], mult)
+                                act[(0 * 2 + hf) * NVOX + vox[tid] + p] = sa
+                                act[(1 * 2 + hf) * NVOX + vox[tid] + p] = sb
+                    for wave in range(4):
+                        lanes = np.arange(64)
+                        jcol, kb = lanes & 15, lanes >> 4
+                        half, dx = kb & 1, kb >> 1
+                        vb = lambda izl, iyr: half * NVOX + (izl * JY + wave + iyr) * JX + jcol + dx
+                        rowv = {(izl, iyr, s): act[s * 2 * NVOX + vb(izl, iyr)] for izl in range(3) for iyr in range(2) for s in range(2)}
+                        acc = np.zeros((4, 2, 16, 16))
+                        for kz in range(3):
+                            for ky in range(3):
+                                a = [wl[((kz * 3 + ky) * 2 + s) * 64 + lanes] for s in range(2)]
+                                yo, iyr = (0 if ky == 1 else 1), (1 if ky == 0 else 0)
+                                for q in range(2):
+                                    zl = 2 * q if kz == 1 else 2 * q + 1
+                                    izl = q if kz == 1 else (q + 1 if kz == 0 else q)
+                                    for p in range(3):
+                                        acc[zl, yo] += mfma_16x16x32(a[PA[p]], rowv[(izl, iyr, PB[p])])
+                        for zl in range(4):
+                            for yo in range(2):
+                                oz, oy = tz0 + zl, ty0 + 2 * wave + yo
+                                for l in range(64):
+                                    u, j = l >> 4, l & 15
+                                    ox = tx0 + 2 * j
+                                    if not (oz < Do and oy < Ho and ox < Wo):
+                                        continue
+                                    for h in range(2):
+                                        co = 2 * u + h
+                                        for ph in range(2):
+                                            v = acc[zl, yo, 4 * u + 2 * h + ph, j] * inv * tail[co] + tail[8 + co]
+                                            v = v if v > 0 else v * slope
+                                            out[b, co, oz, oy, ox + ph] = v + (0.0 if skip is None else skip[b, co, oz, oy, ox + ph])
+    assert not np.isnan(out).any(), "an output voxel was never written"
+    return out
+
+
+def _px_slot(x):
+    return x ^ (((x >> 3) & 1) << 1)
+
+
+def emulate_conv0_zmarch_lanes(packed, x, cin, zlen, slope=0.01):
+    """conv0_zm_kernel thread by thread (csrc/conv0_zmarch.hip): staging items -> LDS slots (row stride 41, slot swizzle), the lanes' B units, the three
+    rotating accumulator sets, the segment bookkeeping, the result lanes -> output addresses."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    nch = cin // 8
+    wl = raw[:nch * 9 * 2 * 64 * 16].view(np.float16).reshape(nch * 9 * 2 * 64, 8).astype(np.float64)
+    tail = raw[nch * 9 * 2 * 64 * 16:][:64].view(np.float32).astype(np.float64)
+    B, _, D, H, W = x.shape
+    ROW, NV = 41, 18 * 41
+    PA, PB = (0, 0, 1), (0, 1, 0)
+    out = np.full((B, 8, D, H, W), np.nan)
+    lanes = np.arange(64)
+    jcol, u = lanes & 15, lanes >> 4
+    for b in range(B):
+        for zs in range(0, D, zlen):
+            ze = min(zs + zlen, D)
+            for ty0 in range(0, H, 16):
+                for tx0 in range(0, W, 32):
+                    acc = np.zeros((4, 3, 4, 16, 16))                       # [wave][slot][t]
+                    for zi in range(zs - 1, ze + 1):
+                        if 0 <= zi < D:
+                            for ch in range(nch):
+                                R = np.zeros((256, 8, 4), np.float32)
+                                vox, vxor = np.full(256, -1), np.zeros(256, int)
+                                for tid in range(180):
+                                    iy, g = divmod(tid, 10)
+                                    gy, gx = ty0 - 1 + iy, tx0 - 4 + 4 * g
+                                    vox[tid], vxor[tid] = iy * ROW + 4 * g, ((g >> 1) & 1) << 1
+                                    if 0 <= gy < H and 0 <= gx < W:
+                                        R[tid] = x[b, ch * 8:ch * 8 + 8, zi, gy, gx:gx + 4]
+                                mult, inv = tile_scale_np(R)
+                                act = np.zeros((2 * NV, 8))
+                                for tid in range(180):
+                                    for j in range(4):
+                                        sa, sb = split_f16_np(R[tid, :, j], mult)
+                                        act[0 * NV + vox[tid] + (j ^ vxor[tid])] = sa
+                                        act[1 * NV + vox[tid] + (j ^ vxor[tid])] = sb
+                                for wave in range(4):
+                                    vbase = (4 * wave) * ROW + _px_slot(2 * jcol + u + 3)
+                                    row = {(yr, s): act[s * NV + vbase + yr * ROW] for yr in range(6) for s in range(2)}
+                                    for kz in range(3):
+                                        for ky in range(3):
+                                            a = [wl[((ch * 9 + kz * 3 + ky) * 2 + s) * 64 + lanes] for s in range(2)]
+                                            for p in range(3):
+                                                for t in range(4):
+                                                    acc[wave, 2 - kz, t] += mfma_16x16x32(a[PA[p]], row[(t + ky, PB[p])]) * inv
+                        zo = zi - 1
+                        for wave in range(4):
+                            if zs <= zo < ze:
+                                for t in range(4):
+                                    oy = ty0 + 4 * wave + t
+                                    for l in range(64):
+                                        uu, j = l >> 4, l & 15
+                                        ox = tx0 + 2 * j
+                                        if not (oy < H and ox < W):
+                                            continue
+                                        for h in range(2):
+                                            co = 2 * uu + h
+                                            for ph in range(2):
+                                                v = acc[wave, 0, t, 4 * uu + 2 * h + ph, j] * tail[co] + tail[8 + co]
+                                                out[b, co, zo, oy, ox + ph] = v if v > 0 else v * slope
+                            acc[wave, 0], acc[wave, 1] = acc[wave, 1].copy(), acc[wave, 2].copy()
+                            acc[wave, 2] = 0.0
+    assert not np.isnan(out).any(), "an output voxel was never written"
+    return out
+
+
+def emulate_fnet_conv0_lanes(packed, imgs, slope=0.01):
+    """fnet_conv0_fused_kernel thread by thread (csrc/fnet_conv0_fused.hip): the image tile's LDS indices (float 0 = x0 - 5, loaded groups at 4 g - 3),
+    a thread's conv0.0 window (six floats from 4 g of rows iy .. iy + 2), the zeroing outside the image, then conv0.1 as in conv0_zm_kernel."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    wl = raw[:6144].view(np.float16).reshape(3 * 2 * 64, 8).astype(np.float64)
+    tail = raw[6144:6144 + 248 * 4].view(np.float32)
+    N, _, H, W = imgs.shape
+    JY, JX, JG, ROW, NV = 20, 48, 12, 41, 18 * 41
+    PA, PB = (0, 0, 1), (0, 1, 0)
+    out = np.full((N, 8, H, W), np.nan)
+    lanes = np.arange(64)
+    jcol, u = lanes & 15, lanes >> 4
+    for n in range(N):
+        for ty0 in range(0, H, 16):
+            for tx0 in range(0, W, 32):
+                img = np.zeros(3 * JY * JX, np.float32)
+                for e in range(3 * JY * JG):
+                    c, rem = divmod(e, JY * JG)
+                    iy, g = divmod(rem, JG)
+                    gy, gx = ty0 - 2 + iy, tx0 - 8 + 4 * g
+                    J = imgs[n, c, gy, gx:gx + 4] if (0 <= gy < H and 0 <= gx < W) else np.zeros(4, np.float32)
+                    for j in range(4):
+                        if 4 * g - 3 + j >= 0:
+                            img[(c * JY + iy) * JX + 4 * g - 3 + j] = J[j]
+                R = np.zeros((256, 8, 4), np.float32)
+                vox, vxor = np.full(256, -1), np.zeros(256, int)
+                for tid in range(180):
+                    it_iy, it_g = divmod(tid, 10)
+                    vox[tid], vxor[tid] = it_iy * ROW + 4 * it_g, ((it_g >> 1) & 1) << 1
+                    accv = np.zeros((8, 4), np.float32)
+                    for ci in range(3):
+                        for ky in range(3):
+                            rowp = (ci * JY + it_iy + ky) * JX + 4 * it_g
+                            in6 = img[rowp:rowp + 6]
+                            for kx in range(3):
+                                w8 = tail[16 + ((ci * 3 + ky) * 3 + kx) * 8:][:8]
+                                for j in range(4):
+                                    accv[:, j] = (in6[j + kx] * w8 + accv[:, j]).astype(np.float32)
+                    gy, gx = ty0 - 1 + it_iy, tx0 - 4 + 4 * it_g
+                    for c in range(8):
+                        for j in range(4):
+                            v = np.float32(accv[c, j] * tail[232 + c] + tail[240 + c])
+                            v = v if v > 0 else np.float32(v * np.float32(slope))
+                            R[tid, c, j] = v if (0 <= gy < H and 0 <= gx + j < W) else 0.0
+                mult, inv = tile_scale_np(R)
+                act = np.zeros((2 * NV, 8))
+                for tid in range(180):
+                    for j in range(4):
+                        sa, sb = split_f16_np(R[tid, :, j], mult)
+                        act[0 * NV + vox[tid] + (j ^ vxor[tid])] = sa
+                        act[1 * NV + vox[tid] + (j ^ vxor[tid])] = sb
+                for wave in range(4):
+                    vbase = (4 * wave) * ROW + _px_slot(2 * jcol + u + 3)
+                    row = {(yr, s): act[s * NV + vbase + yr * ROW] for yr in range(6) for s in range(2)}
+                    part = np.zeros((4, 16, 16))
+                    for ky in range(3):
+                        a = [wl[(ky * 2 + s) * 64 + lanes] for s in range(2)]
+                        for p in range(3):
+                            for t in range(4):
+                                part[t] += mfma_16x16x32(a[PA[p]], row[(t + ky, PB[p])])
+                    for t in range(4):
+                        oy = ty0 + 4 * wave + t
+                        for l in range(64):
+                            uu, j = l >> 4, l & 15
+                            ox = tx0 + 2 * j
+                            if not (oy < H and ox < W):
+                                continue
+                            for h in range(2):
+                                co = 2 * uu + h
+                                for ph in range(2):
+                                    v = part[t, 4 * uu + 2 * h + ph, j] * inv * float(tail[co]) + float(tail[8 + co])
+                                    out[n, co, oy, ox + ph] = v if v > 0 else v * slope
+    assert not np.isnan(out).any(), "an output pixel was never written"
+    return out

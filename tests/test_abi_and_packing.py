@@ -432,3 +432,55 @@ def test_deconv11_splitf16_host_model_is_the_transposed_convolution(shape):
     ref = (torch.where(ref > 0, ref, ref * 0.01) + skip.double()).numpy()
     got = emulate_deconv11_splitf16(packed, x.numpy(), skip.numpy())
     assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-6
+
+
+def test_deconv11_splitf16_lane_level_transcription():
+    """Every thread's index arithmetic of deconv11_sf_kernel transcribed (staging items, LDS planes, B units, tap tables, result lanes) on ragged
+    shapes: each output voxel written exactly by the tile that owns it, within 1e-6 of ConvTranspose3d + ABN + leaky-relu + skip in float64."""
+    import numpy as np
+    import torch
+    from casmvsnet_pl_amd import ops
+    from kernel_model import emulate_deconv11_lanes
+    for (B, Di, Hi, Wi) in ((1, 2, 4, 16), (1, 3, 5, 18)):
+        g = torch.Generator().manual_seed(Di + Wi)
+        x = torch.randn(B, 16, Di, Hi, Wi, generator=g) * 2.0
+        w = torch.randn(16, 8, 3, 3, 3, generator=g) * 0.2
+        scale, shift = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+        skip = torch.randn(B, 8, 2 * Di, 2 * Hi, 2 * Wi, generator=g)
+        packed = ops.deconv11_splitf16_pack(w, scale, shift).numpy()
+        ref = torch.nn.functional.conv_transpose3d(x.double(), w.double(), stride=2, padding=1, output_padding=1)
+        ref = ref * scale.double().view(1, 8, 1, 1, 1) + shift.double().view(1, 8, 1, 1, 1)
+        ref = (torch.where(ref > 0, ref, ref * 0.01) + skip.double()).numpy()
+        got = emulate_deconv11_lanes(packed, x.numpy(), skip.numpy())
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-6, (B, Di, Hi, Wi)
+
+
+def test_conv0_zmarch_and_fnet_conv0_lane_level_transcriptions():
+    """The index arithmetic of conv0_zm_kernel and fnet_conv0_fused_kernel transcribed thread by thread (tests/kernel_model.py) on ragged shapes, with
+    z segments: every output written by the item that owns it, within 2e-6 of the layers in float64."""
+    import numpy as np
+    import torch
+    from casmvsnet_pl_amd import ops
+    from kernel_model import emulate_conv0_zmarch_lanes, emulate_fnet_conv0_lanes
+    g = torch.Generator().manual_seed(11)
+    for cin, (B, D, H, W), zlen in ((8, (1, 3, 18, 36), 2), (16, (1, 5, 17, 32), 5)):
+        x = torch.randn(B, cin, D, H, W, generator=g) * 3.0
+        w = torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2
+        scale, shift = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+        packed = ops.conv0_splitf16_pack(w, scale, shift).numpy()
+        ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1) * scale.double().view(1, 8, 1, 1, 1) + shift.double().view(1, 8, 1, 1, 1)
+        ref = torch.where(ref > 0, ref, ref * 0.01).numpy()
+        got = emulate_conv0_zmarch_lanes(packed, x.numpy(), cin, zlen)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-6, (cin, zlen)
+    x = torch.randn(1, 3, 19, 36, generator=g)
+    w0, w1 = torch.randn(8, 3, 3, 3, generator=g) * 0.3, torch.randn(8, 8, 3, 3, generator=g) * 0.2
+    s0, b0 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    s1, b1 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    packed = ops.fnet_conv0_fused_pack(w0, s0, b0, w1, s1, b1).numpy()
+
+    def layer(t, w, s, b):
+        y = torch.nn.functional.conv2d(t, w.double(), padding=1) * s.double().view(1, 8, 1, 1) + b.double().view(1, 8, 1, 1)
+        return torch.where(y > 0, y, y * 0.01)
+    ref = layer(layer(x.double(), w0, s0, b0), w1, s1, b1).numpy()
+    got = emulate_fnet_conv0_lanes(packed, x.numpy())
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
