@@ -55,6 +55,10 @@ SYMBOLS = {
     "casmvs_fnet_conv0_fused_pack": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "casmvs_fnet_conv0_fused_supported": (c_int, [c_int]),
     "casmvs_fnet_conv0_fused_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_float, c_void_p]),
+    "casmvs_deconv9_splitf16_packed_bytes": (c_size_t, []),
+    "casmvs_deconv9_splitf16_pack": (c_int, [_FP, _FP, _FP, c_void_p]),
+    "casmvs_deconv9_splitf16_supported": (c_int, [c_int]),
+    "casmvs_deconv9_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_deconv11_splitf16_packed_bytes": (c_size_t, []),
     "casmvs_deconv11_splitf16_pack": (c_int, [_FP, _FP, _FP, c_void_p]),
     "casmvs_deconv11_splitf16_supported": (c_int, [c_int]),

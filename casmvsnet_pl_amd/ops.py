@@ -338,6 +338,38 @@ def conv0_splitf16_forward(packed, x, slope=0.01, terms=0):
     return out
 
 
+def deconv9_splitf16_pack(weight, scale=None, shift=None):
+    """Host-side packing of conv9 (ConvTranspose3d 32 -> 16, weight (32, 16, 3, 3, 3)) for casmvs_deconv9_splitf16_forward_f32 -> uint8 CPU tensor."""
+    weight = weight.detach().to("cpu", torch.float32).contiguous()
+    if tuple(weight.shape) != (32, 16, 3, 3, 3):
+        raise ValueError(f"deconv9_splitf16_pack: weight {tuple(weight.shape)} (need (32, 16, 3, 3, 3))")
+    lib = _lib.load()
+    packed = torch.empty(lib.casmvs_deconv9_splitf16_packed_bytes(), dtype=torch.uint8)
+    sc = None if scale is None else scale.detach().to("cpu", torch.float32).contiguous()
+    sh = None if shift is None else shift.detach().to("cpu", torch.float32).contiguous()
+    rc = lib.casmvs_deconv9_splitf16_pack(_ptr(weight), _ptr(sc), _ptr(sh), ctypes.c_void_p(packed.data_ptr()))
+    _lib.check(rc, "casmvs_deconv9_splitf16_pack")
+    return packed
+
+
+def deconv9_splitf16_forward(packed, x, skip=None, slope=0.01):
+    """conv9 (+ ABN + leaky-relu + skip) on the f16 matrix cores (casmvs_deconv9_splitf16_forward_f32): x (B,32,Di,Hi,Wi), skip (B,16,2Di,2Hi,2Wi) or
+    None -> (B,16,2Di,2Hi,2Wi).  Opt-in (added without a GPU run at the end of round 3)."""
+    x = _dev(x, "x")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("deconv9_splitf16_forward: `packed` must be the uint8 image on the MI355X")
+    B, cin, Di, Hi, Wi = x.shape
+    if cin != 32:
+        raise ValueError("deconv9_splitf16_forward: 32 input channels")
+    if skip is not None:
+        skip = _dev(skip, "skip")
+    out = torch.empty((B, 16, 2 * Di, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_deconv9_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(skip), _ptr(out), B, Di, Hi, Wi, float(slope), _stream(x))
+    _lib.check(rc, "casmvs_deconv9_splitf16_forward_f32")
+    return out
+
+
 def deconv11_splitf16_pack(weight, scale=None, shift=None):
     """Host-side packing of conv11 (ConvTranspose3d 16 -> 8, weight (16, 8, 3, 3, 3)) for casmvs_deconv11_splitf16_forward_f32 -> uint8 CPU tensor."""
     weight = weight.detach().to("cpu", torch.float32).contiguous()

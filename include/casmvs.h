@@ -228,6 +228,16 @@ int casmvs_deconv11_splitf16_pack(const float *weight, const float *scale, const
 int casmvs_deconv11_splitf16_supported(int Wi);
 int casmvs_deconv11_splitf16_forward_f32(const void *packed, const float *in, const float *skip, float *out, int B, int Di, int Hi, int Wi,
                                          float slope, void *stream);
+
+/* CostRegNet.conv9 = ConvTranspose3d(32 -> 16, k3 s2 p1 op1) + ABN + leaky-relu, plus the `conv2 + ...` skip (models/mvsnet.py:80-82, 99) the same
+ * way (csrc/deconv9_splitf16.hip): MFMA rows = the 16 output channels, K = the 32 input channels of one input voxel, three sets per (kz, ky) pair
+ * (kx = 1 -> even outputs; kx = 2 and kx = 0 from the next input -> odd outputs).  in (B, 32, Di, Hi, Wi); skip / out (B, 16, 2 Di, 2 Hi, 2 Wi).
+ * WRITTEN WITHOUT A GPU RUN at the end of round 3 (tools/native/deconv9_check.cpp is its first test): opt-in, nothing in the package calls it. */
+size_t casmvs_deconv9_splitf16_packed_bytes(void);
+int casmvs_deconv9_splitf16_pack(const float *weight, const float *scale, const float *shift, void *packed);
+int casmvs_deconv9_splitf16_supported(int Wi);
+int casmvs_deconv9_splitf16_forward_f32(const void *packed, const float *in, const float *skip, float *out, int B, int Di, int Hi, int Wi,
+                                        float slope, void *stream);
 int casmvs_selftest_mfma_f16(float *dump);
 
 /* CostRegNet's stride-1 layers with equal channel counts (conv2: 16 -> 16, conv4: 32 -> 32, conv6: 64 -> 64; Conv3d k3 s1 p1 + folded ABN +

@@ -1279,3 +1279,70 @@ def emulate_fnet_conv0_lanes(packed, imgs, slope=0.01):
                                     out[n, co, oy, ox + ph] = v if v > 0 else v * slope
     assert not np.isnan(out).any(), "an output pixel was never written"
     return out
+
+
+def emulate_deconv9_lanes(packed, x, skip, slope=0.01):
+    """deconv9_sf_kernel thread by thread (csrc/deconv9_splitf16.hip): staging items (16-channel half, box voxel pair) -> LDS planes [slice][quarter][192],
+    the lanes' B units (and the next voxel for the kx = 0 tap), the (kz, ky, kx) -> (output plane, row, x parity, input plane, row) tables, the result lanes."""
+    import numpy as np
+    raw = np.asarray(packed, dtype=np.uint8)
+    nw = 9 * 3 * 2 * 64
+    wl = raw[:nw * 16].view(np.float16).reshape(nw, 8).astype(np.float64)   # [((r9 * 3 + kx) * 2 + s) * 64 + lane]
+    tail = raw[nw * 16:][:128].view(np.float32).astype(np.float64)
+    B, _, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = 2 * Di, 2 * Hi, 2 * Wi
+    out = np.full((B, 16, Do, Ho, Wo), np.nan)
+    JY, JX, NVOX = 5, 18, 192
+    PA, PB = (0, 0, 1), (0, 1, 0)
+    lanes = np.arange(64)
+    jcol, kb = lanes & 15, lanes >> 4
+    for b in range(B):
+        for tz0 in range(0, Do, 2):
+            for ty0 in range(0, Ho, 8):
+                for tx0 in range(0, Wo, 32):
+                    R = np.zeros((256, 16, 2), np.float32)
+                    vox, ehf = np.full(256, -1), np.zeros(256, int)
+                    for tid in range(180):
+                        e_hf, e_pr = divmod(tid, 90)
+                        e_iz, rem = divmod(e_pr, JY * (JX // 2))
+                        e_iy, e_g = divmod(rem, JX // 2)
+                        vox[tid], ehf[tid] = (e_iz * JY + e_iy) * JX + 2 * e_g, e_hf
+                        gz, gy, gx = tz0 // 2 + e_iz, ty0 // 2 + e_iy, tx0 // 2 + 2 * e_g
+                        if gz < Di and gy < Hi and gx < Wi:
+                            R[tid] = x[b, e_hf * 16:e_hf * 16 + 16, gz, gy, gx:gx + 2]
+                    mult, inv = tile_scale_np(R)
+                    act = np.zeros((8 * NVOX, 8))
+                    for tid in range(180):
+                        for hh in range(2):
+                            for p in range(2):
+                                sa, sb = split_f16_np(R[tid, hh * 8:hh * 8 + 8, p], mult)
+                                act[(0 * 4 + ehf[tid] * 2 + hh) * NVOX + vox[tid] + p] = sa
+                                act[(1 * 4 + ehf[tid] * 2 + hh) * NVOX + vox[tid] + p] = sb
+                    for wave in range(4):
+                        vb = lambda izl, iyr: kb * NVOX + (izl * JY + wave + iyr) * JX + jcol
+                        acc = np.zeros((2, 2, 2, 16, 16))
+                        for kz in range(3):
+                            for ky in range(3):
+                                zl, izl = (0 if kz == 1 else 1), (1 if kz == 0 else 0)
+                                yo, iyr = (0 if ky == 1 else 1), (1 if ky == 0 else 0)
+                                for kx in range(3):
+                                    a = [wl[(((kz * 3 + ky) * 3 + kx) * 2 + s) * 64 + lanes] for s in range(2)]
+                                    px, nx = (0 if kx == 1 else 1), (1 if kx == 0 else 0)
+                                    for p in range(3):
+                                        acc[zl, yo, px] += mfma_16x16x32(a[PA[p]], act[PB[p] * 4 * NVOX + vb(izl, iyr) + nx])
+                        for zl in range(2):
+                            for yo in range(2):
+                                oz, oy = tz0 + zl, ty0 + 2 * wave + yo
+                                for l in range(64):
+                                    u, j = l >> 4, l & 15
+                                    ox = tx0 + 2 * j
+                                    if not (oz < Do and oy < Ho and ox < Wo):
+                                        continue
+                                    for r in range(4):
+                                        co = 4 * u + r
+                                        for px in range(2):
+                                            v = acc[zl, yo, px, 4 * u + r, j] * inv * tail[co] + tail[16 + co]
+                                            v = v if v > 0 else v * slope
+                                            out[b, co, oz, oy, ox + px] = v + (0.0 if skip is None else skip[b, co, oz, oy, ox + px])
+    assert not np.isnan(out).any(), "an output voxel was never written"
+    return out

@@ -484,3 +484,24 @@ def test_conv0_zmarch_and_fnet_conv0_lane_level_transcriptions():
     ref = layer(layer(x.double(), w0, s0, b0), w1, s1, b1).numpy()
     got = emulate_fnet_conv0_lanes(packed, x.numpy())
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+
+
+def test_deconv9_splitf16_lane_level_transcription():
+    """deconv9_sf_kernel's index arithmetic transcribed thread by thread on ragged shapes: within 1e-6 of ConvTranspose3d(32, 16, 3, stride 2, padding 1,
+    output_padding 1) + ABN + leaky-relu + skip in float64."""
+    import numpy as np
+    import torch
+    from casmvsnet_pl_amd import ops
+    from kernel_model import emulate_deconv9_lanes
+    for (B, Di, Hi, Wi) in ((1, 1, 4, 16), (1, 2, 5, 18)):
+        g = torch.Generator().manual_seed(Di + Wi + 3)
+        x = torch.randn(B, 32, Di, Hi, Wi, generator=g) * 2.0
+        w = torch.randn(32, 16, 3, 3, 3, generator=g) * 0.15
+        scale, shift = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
+        skip = torch.randn(B, 16, 2 * Di, 2 * Hi, 2 * Wi, generator=g)
+        packed = ops.deconv9_splitf16_pack(w, scale, shift).numpy()
+        ref = torch.nn.functional.conv_transpose3d(x.double(), w.double(), stride=2, padding=1, output_padding=1)
+        ref = ref * scale.double().view(1, 16, 1, 1, 1) + shift.double().view(1, 16, 1, 1, 1)
+        ref = (torch.where(ref > 0, ref, ref * 0.01) + skip.double()).numpy()
+        got = emulate_deconv9_lanes(packed, x.numpy(), skip.numpy())
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-6, (B, Di, Hi, Wi)
