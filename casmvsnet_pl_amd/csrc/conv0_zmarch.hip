@@ -19,7 +19,8 @@
 // Shape of the work: item = (sample, y tile, x tile, z segment); segments only where the (y, x) patches alone would not fill the chip
 // (a segment re-stages one halo plane at each end).  All chunks' lane images stay in LDS (18 KiB per chunk) next to ONE plane patch
 // (23 KiB): cin = 8 / 16 -> 41 / 59 KiB, two workgroups per CU (the request is padded to 56 KiB so that never three share one: the
-// rule for f16 matrix kernels).  cin = 32 (90 KiB: one workgroup per CU) stays on conv0_sf_kernel.
+// rule for f16 matrix kernels).  cin = 32 is 95 KiB: one workgroup per CU (instantiated so that the first test can time it
+// against conv0_sf_kernel; expected to stay on the tiled kernel).
 // Matrix phase of a unit: the wave's six staged rows are read once (12 x 16 B per lane), then 3 (kz) x 3 (ky) x 4 (rows) x 3 partial
 // products = 108 MFMAs between which only LDS reads of the lane images are issued (no floating-point vector work: DESIGN.md 2.0).
 #include <cmath>
@@ -267,7 +268,7 @@ int launch_zm(const void *packed, const float *in, float *out, int B, int D, int
 
 }  // namespace
 
-extern "C" int casmvs_conv0_zmarch_supported(int cin, int W) { return (cin == 8 || cin == 16) && W % 4 == 0 && W >= 4; }
+extern "C" int casmvs_conv0_zmarch_supported(int cin, int W) { return (cin == 8 || cin == 16 || cin == 32) && W % 4 == 0 && W >= 4; }
 
 extern "C" int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
                                                float slope, void *stream) {
@@ -278,5 +279,6 @@ extern "C" int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *
   CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 29), "conv0_zmarch_forward: one sample's input tensor must hold < 2^29 floats");
   hipStream_t st = (hipStream_t)stream;
   if (cin == 8) return launch_zm<8>(packed, in, out, B, D, H, W, slope, st);
-  return launch_zm<16>(packed, in, out, B, D, H, W, slope, st);
+  if (cin == 16) return launch_zm<16>(packed, in, out, B, D, H, W, slope, st);
+  return launch_zm<32>(packed, in, out, B, D, H, W, slope, st);   // 95 KiB of LDS: ONE workgroup per CU - measured against the tiled kernel before it is used
 }

@@ -209,7 +209,7 @@ int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float
 /* conv0 in the same split-f16 arithmetic, input-stationary along z (csrc/conv0_zmarch.hip): a workgroup owns a 16 x 32 (y, x) patch and
  * marches along z, staging every input plane once per chunk of 8 channels (per-plane power-of-two scaling) and feeding the three
  * output planes it touches - half the staged voxels per output voxel of casmvs_conv0_splitf16_forward_f32, whose L1 -> L2 request
- * stream bounds it.  `packed`: the image of casmvs_conv0_splitf16_pack.  cin = 8 or 16, W % 4 == 0.  Results agree with the other
+ * stream bounds it.  `packed`: the image of casmvs_conv0_splitf16_pack.  cin = 8, 16 (two workgroups per CU) or 32 (one), W % 4 == 0.  Results agree with the other
  * entry to ~1e-6 of the range (both ~3e-7 from a float64 convolution), not bit for bit.
  * WRITTEN WITHOUT A GPU RUN at the end of round 3 (tools/native/conv0_zm_check.cpp is its first test): opt-in, nothing in the
  * package calls it. */

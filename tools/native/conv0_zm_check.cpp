@@ -31,7 +31,7 @@ int main(int argc, char **argv) {
   hipMalloc(&dirty, dirty_bytes);
   struct Shape { int B, cin, D, H, W; bool host; };
   const Shape shapes[] = {{1, 8, 5, 20, 36, true},  {2, 16, 9, 17, 44, true}, {1, 8, 3, 33, 32, true}, {1, 16, 1, 16, 4, true}, {1, 8, 13, 50, 68, true},
-                          {batch, 16, 32, 256, 320, false}, {batch, 8, 8, 512, 640, false}, {1, 16, 32, 256, 320, false}, {1, 8, 8, 512, 640, false}};
+                          {1, 32, 6, 20, 36, true}, {batch, 32, 48, 128, 160, false}, {batch, 16, 32, 256, 320, false}, {batch, 8, 8, 512, 640, false}, {1, 16, 32, 256, 320, false}, {1, 8, 8, 512, 640, false}};
   bool all_ok = true;
   for (const Shape &s : shapes) {
     const size_t n = (size_t)s.D * s.H * s.W, nin = (size_t)s.B * s.cin * n, nout = (size_t)s.B * 8 * n;
