@@ -141,6 +141,10 @@ class FeatureNet(_PackedWeights, nn.Module):
         self._ci2d = None         # split-f16 images of conv1.1, conv1.2, conv2.1, conv2.2, smooth1 (conv2d_ci_splitf16.hip; follow tail_mode)
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.last_channels_last = None
+        # Kernels written without a GPU run at the end of round 3 (opt-in until their first tests have passed on the MI355X): {"conv0_fused"} runs
+        # conv0.0 + conv0.1 as one kernel (csrc/fnet_conv0_fused.hip) inside the split-f16 forward
+        self.experimental = set()
+        self._conv0_fused = None
 
     def packed_layers(self, device):
         """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
@@ -191,8 +195,16 @@ class FeatureNet(_PackedWeights, nn.Module):
             raise ValueError(f"FeatureNet.tail_mode={self.tail_mode!r} (splitf16 or f32)")
         sf = self.fuse_tail and self.tail_mode == "splitf16"
         fused0 = (self._fused0_sf if sf else self._fused0) if self.fuse_tail else None
+        conv0_fused = None
+        if sf and "conv0_fused" in self.experimental:
+            if self._conv0_fused is None or self._conv0_fused[0] != self._packed_key:
+                s0, b0, _ = _fold_norm("FeatureNet.conv0.0", self.conv0[0].bn)
+                s1, b1, _ = _fold_norm("FeatureNet.conv0.1", self.conv0[1].bn)
+                self._conv0_fused = (self._packed_key, ops.fnet_conv0_fused_pack(self.conv0[0].conv.weight, s0, b0, self.conv0[1].conv.weight, s1, b1).to(x.device))
+            conv0_fused = self._conv0_fused[1]
         feat0, feat1, feat2, cl = ops.featurenet_forward(packed, x.float(), ws, slope=self._slope, layer_events=events,
-                                                         channels_last_copies=True, fused0=fused0, fused0_splitf16=sf, ci_layers=self._ci2d if sf else None)
+                                                         channels_last_copies=True, fused0=fused0, fused0_splitf16=sf, ci_layers=self._ci2d if sf else None,
+                                                         conv0_fused=conv0_fused)
         # pixel-major copies of the three maps (same kernels, second store): what the cost-volume gather reads
         self.last_channels_last = {"level_0": cl[0], "level_1": cl[1], "level_2": cl[2]}
         return {"level_0": feat0, "level_1": feat1, "level_2": feat2}
@@ -242,6 +254,11 @@ class CostRegNet(_PackedWeights, nn.Module):
         self._workspace = None
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.timer_name = "costreg"
+        # Kernels written without a GPU run at the end of round 3 (opt-in until their first tests have passed on the MI355X), used by `regress` with
+        # conv0_mode "splitf16": "zmarch" (conv0 input-stationary along z for cin 8 / 16; "zmarch32": also cin 32), "deconv9", "deconv11" (conv9 / conv11
+        # on the f16 matrix cores)
+        self.experimental = set()
+        self._deconv_sf = None
 
     # -- weight folding / packing -------------------------------------------------------------
     def _layer_tensors(self, name):
@@ -321,8 +338,22 @@ class CostRegNet(_PackedWeights, nn.Module):
         if self.ci_mode not in ("splitf16", "f32"):
             raise ValueError(f"CostRegNet.ci_mode={self.ci_mode!r} (splitf16 or f32)")
         c2, c4, c6 = self._ci_sf if self.ci_mode == "splitf16" else (None, None, None)
+        zm, d9, d11 = 0, None, None
+        if self.experimental and self.ci_mode == "splitf16" and self.conv0_mode == "splitf16":   # never in the all-float32 replicas (graph.py)
+            unknown = set(self.experimental) - {"zmarch", "zmarch32", "deconv9", "deconv11"}
+            if unknown:
+                raise ValueError(f"CostRegNet.experimental: unknown entries {sorted(unknown)}")
+            zm = 2 if "zmarch32" in self.experimental else (1 if "zmarch" in self.experimental else 0)
+            if self._deconv_sf is None or self._deconv_sf[0] != self._packed_key:
+                s9, b9, _ = _fold_norm("CostRegNet.conv9", self.conv9[1])
+                s11, b11, _ = _fold_norm("CostRegNet.conv11", self.conv11[1])
+                self._deconv_sf = (self._packed_key, ops.deconv9_splitf16_pack(self.conv9[0].weight, s9, b9).to(x.device),
+                                   ops.deconv11_splitf16_pack(self.conv11[0].weight, s11, b11).to(x.device))
+            d9 = self._deconv_sf[1] if "deconv9" in self.experimental else None
+            d11 = self._deconv_sf[2] if "deconv11" in self.experimental else None
         return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index,
-                                   conv0_split=split, conv0_arith=arith, conv2_split=c2, conv4_split=c4, conv6_split=c6)
+                                   conv0_split=split, conv0_arith=arith, conv2_split=c2, conv4_split=c4, conv6_split=c6,
+                                   conv0_zmarch=zm, deconv9_split=d9, deconv11_split=d11)
 
 
 class CascadeMVSNet(nn.Module):

@@ -491,7 +491,7 @@ CONV0_F32, CONV0_SPLIT_BF16, CONV0_SPLIT_F16 = 0, 1, 2   # casmvs.h: CASMVS_CONV
 
 
 def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, layer_events=None, return_index=False, conv0_split=None,
-                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None, conv6_split=None):
+                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None, conv6_split=None, conv0_zmarch=0, deconv9_split=None, deconv11_split=None):
     """CostRegNet + softmax / depth regression / confidence in one library call (mvsnet.py:91-104 + :174-193): the `prob`
     head walks the depth axis and, when the whole depth range is one chunk, runs the regression on the cost values it has
     just produced (casmvs_costreg_regress_f32).  -> cost (B,D,h,w), depth (B,h,w), confidence (B,h,w) [, index int32].
@@ -520,10 +520,18 @@ def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, lay
     split = None
     if conv0_split is not None or conv2_split is not None or conv4_split is not None or conv6_split is not None:
         split = (ctypes.c_void_p * 4)(*[None if t is None else t.data_ptr() for t in (conv0_split, conv2_split, conv4_split, conv6_split)])
+    experimental = conv0_zmarch or deconv9_split is not None or deconv11_split is not None
     with torch.cuda.device(dev):
-        rc = _lib.load().casmvs_costreg_regress_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
-                                                    _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
-                                                    float(slope), ev, _stream(vol))
+        if experimental:   # the layer set written without a GPU run (casmvs_costreg_regress_x_f32): opt-in only
+            rc = _lib.load().casmvs_costreg_regress_x_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
+                                                          _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
+                                                          float(slope), ev, _stream(vol), int(conv0_zmarch),
+                                                          None if deconv9_split is None else ctypes.c_void_p(deconv9_split.data_ptr()),
+                                                          None if deconv11_split is None else ctypes.c_void_p(deconv11_split.data_ptr()))
+        else:
+            rc = _lib.load().casmvs_costreg_regress_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
+                                                        _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
+                                                        float(slope), ev, _stream(vol))
     _lib.check(rc, "casmvs_costreg_regress_f32")
     return (cost, depth, conf, index) if return_index else (cost, depth, conf)
 
@@ -706,7 +714,7 @@ def fnet_conv0_fused(packed, imgs, slope=0.01):
 
 
 def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None, channels_last_copies=False, fused0=None, fused0_splitf16=False,
-                       ci_layers=None):
+                       ci_layers=None, conv0_fused=None):
     """Whole FeatureNet (mvsnet.py:40-57).  packed_layers: 13 device tensors (conv0.0 .. conv2.2,
     toplayer, lat1, lat0, smooth1, smooth0); imgs (N,3,H,W) -> feat0 (N,8,H,W), feat1 (N,16,H/2,W/2),
     feat2 (N,32,H/4,W/4).  layer_events: optional 14 recorded torch.cuda.Event.
@@ -744,10 +752,17 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
                 if len(ci_layers) != 5:
                     raise ValueError("featurenet_forward: ci_layers needs 5 entries (conv1.1, conv1.2, conv2.1, conv2.2, smooth1)")
                 ci = (ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in ci_layers])
-            rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
-                                                                 ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
-                                                                 _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
-                                                                 ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev, _stream(imgs))
+            if conv0_fused is not None:   # experimental: conv0.0 + conv0.1 as one kernel (casmvs_featurenet_forward_fused_x_f32), opt-in only
+                rc = _lib.load().casmvs_featurenet_forward_fused_x_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
+                                                                       ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
+                                                                       _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
+                                                                       ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev, _stream(imgs),
+                                                                       ctypes.c_void_p(conv0_fused.data_ptr()))
+            else:
+                rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
+                                                                     ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
+                                                                     _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
+                                                                     ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev, _stream(imgs))
         else:
             rc = _lib.load().casmvs_featurenet_forward_f32(arr, _ptr(imgs), _ptr(feat0), _ptr(feat1), _ptr(feat2),
                                                            _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),

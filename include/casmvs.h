@@ -238,6 +238,20 @@ int casmvs_deconv9_splitf16_pack(const float *weight, const float *scale, const 
 int casmvs_deconv9_splitf16_supported(int Wi);
 int casmvs_deconv9_splitf16_forward_f32(const void *packed, const float *in, const float *skip, float *out, int B, int Di, int Hi, int Wi,
                                         float slope, void *stream);
+
+/* The engine's two whole-network calls with the EXPERIMENTAL layer set (the kernels above that were written without a GPU run: until their first
+ * tests have passed on the MI355X nothing in the package passes non-default values here).  As casmvs_costreg_regress_f32 plus: conv0_zmarch 1 = conv0
+ * through casmvs_conv0_zmarch_forward_f32 for cin 8 / 16 (2: also cin 32; needs conv0_arith = CASMVS_CONV0_SPLIT_F16 and its image),
+ * deconv9_image / deconv11_image = device images of casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack or NULL.  As
+ * casmvs_featurenet_forward_fused_f32 plus: conv0_fused_image = device image of casmvs_fnet_conv0_fused_pack or NULL. */
+int casmvs_costreg_regress_x_f32(const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol,
+                                 const float *depth_values, float *cost, float *depth, float *confidence, int32_t *index, void *workspace,
+                                 int B, int cin, int D, int h, int w, float slope, void *const *layer_events, void *stream, int conv0_zmarch,
+                                 const void *deconv9_image, const void *deconv11_image);
+int casmvs_featurenet_forward_fused_x_f32(const float *const *packed_layers, const void *fused0_packed, int fused0_arith, const float *fused0_bias9,
+                                          const void *const *ci_layers, const float *imgs, float *feat0, float *feat1, float *feat2,
+                                          float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc, void *workspace, int N, int H, int W, float slope,
+                                          void *const *layer_events, void *stream, const void *conv0_fused_image);
 int casmvs_selftest_mfma_f16(float *dump);
 
 /* CostRegNet's stride-1 layers with equal channel counts (conv2: 16 -> 16, conv4: 32 -> 32, conv6: 64 -> 64; Conv3d k3 s1 p1 + folded ABN +

@@ -24,6 +24,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=(512, 640))
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--all-f32", action="store_true", help="every layer on the float32 MFMA kernels (conv0_mode / ci_mode / tail_mode = f32)")
+ap.add_argument("--experimental", default="", help="comma list of the kernels written without a GPU run: zmarch | zmarch32, deconv9, deconv11, fnet_conv0")
 args = ap.parse_args()
 if args.lib:
     os.environ["CASMVS_LIB_PATH"] = os.path.abspath(args.lib)
@@ -111,21 +112,43 @@ for name in ("conv1.1", "conv1.2", "conv2.1", "conv2.2", "smooth1"):
 COSTREG = (("conv0", CONV_S1, None, 8), ("conv1", CONV_S2, 8, 16), ("conv2", CONV_S1, 16, 16), ("conv3", CONV_S2, 16, 32), ("conv4", CONV_S1, 32, 32),
            ("conv5", CONV_S2, 32, 64), ("conv6", CONV_S1, 64, 64), ("conv7", CONV_T2, 64, 32), ("conv9", CONV_T2, 32, 16), ("conv11", CONV_T2, 16, 8),
            ("prob", CONV_S1, 8, 1))
-costreg = []
+costreg, costreg_w = [], []
 for l in range(3):
     c_in0 = 8 * 2 ** l
     packed, split = [], [None] * 4
+    costreg_w.append({})
     for name, kind, cin, cout in COSTREG:
         cin = c_in0 if cin is None else cin
         w = rand_w((cin, cout, 3, 3, 3) if kind == CONV_T2 else (cout, cin, 3, 3, 3), cin * 27 / (8 if kind == CONV_T2 else 1))
         sc, sh = rand_abn(cout) if name != "prob" else (None, np.zeros(1, np.float32))
         packed.append(pack_f32(kind, cin, cout, w, sc, sh, True))
+        costreg_w[l][name] = (w, sc, sh)
         if name == "conv0":
             split[0] = pack_bytes(lib.casmvs_conv0_splitf16_packed_bytes(cin), lib.casmvs_conv0_splitf16_pack, cin, hp(w), hp(sc), hp(sh))
         if name in ("conv2", "conv4", "conv6"):
             split[1 + ("conv2", "conv4", "conv6").index(name)] = pack_bytes(lib.casmvs_conv_ci_splitf16_packed_bytes(cin, cout), lib.casmvs_conv_ci_splitf16_pack,
                                                                              cin, cout, hp(w), hp(sc), hp(sh))
     costreg.append((packed, split))
+
+# ---- the experimental layer set (casmvs_*_x_f32): images of the kernels written without a GPU run ----------------------------------
+EXP = set(filter(None, args.experimental.split(",")))
+assert EXP <= {"zmarch", "zmarch32", "deconv9", "deconv11", "fnet_conv0"}, EXP
+assert not (EXP and args.all_f32), "the experimental kernels belong to the split-f16 layer set"
+ZM = 2 if "zmarch32" in EXP else (1 if "zmarch" in EXP else 0)
+fnet_conv0_img = None
+if "fnet_conv0" in EXP:
+    (w00, s00, b00), (w01, s01, b01) = fw["conv0.0"], fw["conv0.1"]
+    fnet_conv0_img = pack_bytes(lib.casmvs_fnet_conv0_fused_packed_bytes(), lib.casmvs_fnet_conv0_fused_pack, hp(w00), hp(s00), hp(b00), hp(w01), hp(s01), hp(b01))
+deconv_imgs = []
+for l in range(3):
+    d9 = d11 = None
+    if "deconv9" in EXP:
+        w, sc, sh = costreg_w[l]["conv9"]
+        d9 = pack_bytes(lib.casmvs_deconv9_splitf16_packed_bytes(), lib.casmvs_deconv9_splitf16_pack, hp(w), hp(sc), hp(sh))
+    if "deconv11" in EXP:
+        w, sc, sh = costreg_w[l]["conv11"]
+        d11 = pack_bytes(lib.casmvs_deconv11_splitf16_packed_bytes(), lib.casmvs_deconv11_splitf16_pack, hp(w), hp(sc), hp(sh))
+    deconv_imgs.append((d9, d11))
 
 # ---- inputs: images, the DTU-like rig of synthetic.dtu_like_cameras / make_inputs --------------------------------------------
 imgs = DeviceArray.from_numpy(g.standard_normal((B * V, 3, H, W)).astype(np.float32))
@@ -194,9 +217,14 @@ def run_stage(name, fn, timed):
 
 
 def step(timed=False):
-    run_stage("feature", lambda: check(lib.casmvs_featurenet_forward_fused_f32(
-        arr13, (tail_f32 if args.all_f32 else tail_sf).p, 0 if args.all_f32 else 1, bias9_d.p, ci5, imgs.p, feat[0].p, feat[1].p, feat[2].p,
-        feat_cl[0].p, feat_cl[1].p, feat_cl[2].p, feat_ws.p, N, H, W, ctypes.c_float(0.01), None, st), "featurenet"), timed)
+    if fnet_conv0_img is not None:
+        run_stage("feature", lambda: check(lib.casmvs_featurenet_forward_fused_x_f32(
+            arr13, tail_sf.p, 1, bias9_d.p, ci5, imgs.p, feat[0].p, feat[1].p, feat[2].p,
+            feat_cl[0].p, feat_cl[1].p, feat_cl[2].p, feat_ws.p, N, H, W, ctypes.c_float(0.01), None, st, fnet_conv0_img.p), "featurenet_x"), timed)
+    else:
+        run_stage("feature", lambda: check(lib.casmvs_featurenet_forward_fused_f32(
+            arr13, (tail_f32 if args.all_f32 else tail_sf).p, 0 if args.all_f32 else 1, bias9_d.p, ci5, imgs.p, feat[0].p, feat[1].p, feat[2].p,
+            feat_cl[0].p, feat_cl[1].p, feat_cl[2].p, feat_ws.p, N, H, W, ctypes.c_float(0.01), None, st), "featurenet"), timed)
     prev = None
     for l in (2, 1, 0):
         L = levels[l]
@@ -211,9 +239,15 @@ def step(timed=False):
         packed, split = costreg[l]
         arr11 = (ctypes.c_void_p * 11)(*[p.ptr for p in packed])
         sp = None if args.all_f32 else (ctypes.c_void_p * 4)(*[None if s is None else s.ptr for s in split])
-        run_stage(f"costreg_{l}", lambda: check(lib.casmvs_costreg_regress_f32(
-            arr11, sp, 0 if args.all_f32 else 2, L["vol"].p, L["dv"].p, L["cost"].p, L["depth"].p, L["conf"].p, None, L["ws"].p, B, C, D, h, w,
-            ctypes.c_float(0.01), None, st), "costreg_regress"), timed)
+        d9, d11 = deconv_imgs[l]
+        if ZM or d9 is not None or d11 is not None:
+            run_stage(f"costreg_{l}", lambda: check(lib.casmvs_costreg_regress_x_f32(
+                arr11, sp, 2, L["vol"].p, L["dv"].p, L["cost"].p, L["depth"].p, L["conf"].p, None, L["ws"].p, B, C, D, h, w,
+                ctypes.c_float(0.01), None, st, ZM, None if d9 is None else d9.p, None if d11 is None else d11.p), "costreg_regress_x"), timed)
+        else:
+            run_stage(f"costreg_{l}", lambda: check(lib.casmvs_costreg_regress_f32(
+                arr11, sp, 0 if args.all_f32 else 2, L["vol"].p, L["dv"].p, L["cost"].p, L["depth"].p, L["conf"].p, None, L["ws"].p, B, C, D, h, w,
+                ctypes.c_float(0.01), None, st), "costreg_regress"), timed)
         prev = L
 
 
@@ -233,7 +267,10 @@ stage_ms = {s: events[s][1].ms_since(events[s][0]) for s in STAGES}
 d0 = levels[0]["depth"].numpy()
 lo, hi = DEPTH_MIN - 200.0, DEPTH_MIN + 192 * DEPTH_INTERVAL + 200.0
 ok = bool(np.isfinite(d0).all() and d0.min() > lo and d0.max() < hi)
-print(f"{hip.device_name()}  lib {os.path.basename(_lib.LIB_PATH)}  batch {B} x {V} views {W}x{H}  {'all-f32' if args.all_f32 else 'split-f16 layer set'}")
+print(f"{hip.device_name()}  lib {os.path.basename(_lib.LIB_PATH)}  batch {B} x {V} views {W}x{H}  {'all-f32' if args.all_f32 else 'split-f16 layer set'}"
+      + (f"  + experimental {sorted(EXP)}" if EXP else ""))
+d0_sum = float(np.float64(d0).sum())
+print(f"depth_0 checksum {d0_sum:.6f} (compare runs with and without --experimental: the same weights and inputs, results equal to ~1e-5 relative)")
 print(f"step {ms:.3f} ms  = {B / ms * 1e3:.1f} depth maps/s (kernel by kernel on one stream, {args.steps} steps after {args.warmup})")
 print("stages (one instrumented step, ms): " + "  ".join(f"{s} {stage_ms[s]:.3f}" for s in STAGES))
 print(f"sum of stages {sum(stage_ms.values()):.3f} ms; depth_0 range [{d0.min():.1f}, {d0.max():.1f}] mean {d0.mean():.1f}  {'ok' if ok else 'OUT OF RANGE'}")
