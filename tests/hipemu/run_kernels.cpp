@@ -1,0 +1,202 @@
+// Runs kernels of casmvsnet_pl_amd/csrc on the CPU through tests/hipemu/hip/hip_runtime.h - their own source - against float64 references:
+//   conv0_sf    the established tiled conv0 kernel (validated on the MI355X): checks the EMULATOR
+//   conv0_zm / fnet_conv0 / deconv11 / deconv9    the kernels written without a GPU run at the end of round 3
+// Build (tests/test_hip_emulation.py does it):
+//   /opt/rocm/lib/llvm/bin/clang++ -std=c++20 -O1 -pthread -DCASMVS_SPLIT_NOASM -Itests/hipemu -Iinclude -Icasmvsnet_pl_amd/csrc tests/hipemu/run_kernels.cpp -o <exe>
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+// what abi.hip provides to the launch wrappers
+namespace casmvs {
+static thread_local char g_err[512];
+char *error_buffer() { return g_err; }
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+void clear_error() { g_err[0] = 0; }
+int ensure_dynamic_lds(const void *, size_t bytes, const char *what) { return bytes <= 160 * 1024 ? 0 : fail(CASMVS_ERR_HIP, "%s: %zu bytes of LDS", what, bytes); }
+int resident_blocks(const void *, int, size_t) { return 3; }   // three persistent workgroups: every one walks several items
+}  // namespace casmvs
+extern "C" const char *casmvs_last_error(void) { return casmvs::g_err; }
+
+namespace {
+alignas(64) unsigned char smem_raw[HIPEMU_LDS_BYTES];   // the kernels' `extern __shared__ smem_raw[]`
+}
+
+#include "conv0_splitf16.hip"
+#include "conv0_zmarch.hip"
+#include "fnet_conv0_fused.hip"
+#include "deconv11_splitf16.hip"
+#include "deconv9_splitf16.hip"
+
+static uint32_t g_rng = 2463534242u;
+static float rnd() {
+  g_rng ^= g_rng << 13; g_rng ^= g_rng >> 17; g_rng ^= g_rng << 5;
+  return (float)(int32_t)g_rng * (1.0f / 2147483648.0f);
+}
+static double lrelu(double v) { return v > 0 ? v : v * 0.01f; }
+
+static double conv3d_check(const char *name, int cin, int B, int D, int H, int W, bool zmarch) {
+  const size_t n = (size_t)D * H * W;
+  std::vector<float> x((size_t)B * cin * n), w((size_t)8 * cin * 27), sc(8), sh(8), y((size_t)B * 8 * n, NAN);
+  for (auto &v : x) v = rnd() * 3.0f + 0.4f;
+  for (auto &v : w) v = rnd() * 0.2f;
+  for (int c = 0; c < 8; ++c) { sc[c] = 0.5f + 0.1f * c; sh[c] = 0.05f * (c - 4); }
+  std::vector<unsigned char> packed(casmvs_conv0_splitf16_packed_bytes(cin) + 16);
+  unsigned char *pk = packed.data() + ((16 - (reinterpret_cast<size_t>(packed.data()) & 15)) & 15);
+  if (casmvs_conv0_splitf16_pack(cin, w.data(), sc.data(), sh.data(), pk)) { printf("%s: pack: %s\n", name, casmvs_last_error()); return 1e9; }
+  float *xa = (float *)std::aligned_alloc(64, (x.size() * 4 + 63) & ~(size_t)63), *ya = (float *)std::aligned_alloc(64, (y.size() * 4 + 63) & ~(size_t)63);
+  std::memcpy(xa, x.data(), x.size() * 4);
+  std::memcpy(ya, y.data(), y.size() * 4);
+  const int rc = zmarch ? casmvs_conv0_zmarch_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, nullptr)
+                        : casmvs_conv0_splitf16_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, 0, nullptr);
+  if (rc) { printf("%s: %s\n", name, casmvs_last_error()); return 1e9; }
+  double err = 0, range = 0;
+  for (int b = 0; b < B; ++b)
+    for (int co = 0; co < 8; ++co)
+      for (int z = 0; z < D; ++z)
+        for (int yy = 0; yy < H; ++yy)
+          for (int xx = 0; xx < W; ++xx) {
+            double acc = 0;
+            for (int ci = 0; ci < cin; ++ci)
+              for (int kz = 0; kz < 3; ++kz)
+                for (int ky = 0; ky < 3; ++ky)
+                  for (int kx = 0; kx < 3; ++kx) {
+                    const int iz = z + kz - 1, iy = yy + ky - 1, ix = xx + kx - 1;
+                    if (iz < 0 || iz >= D || iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                    acc += (double)w[((size_t)co * cin + ci) * 27 + kz * 9 + ky * 3 + kx] * x[((size_t)b * cin + ci) * n + ((size_t)iz * H + iy) * W + ix];
+                  }
+            const double v = lrelu(acc * sc[co] + sh[co]);
+            const float got = ya[((size_t)b * 8 + co) * n + ((size_t)z * H + yy) * W + xx];
+            range = std::fmax(range, std::fabs(v));
+            err = std::fmax(err, std::isfinite(got) ? std::fabs(v - got) : 1e30);
+          }
+  std::free(xa); std::free(ya);
+  printf("%-10s cin=%d B=%d %dx%dx%d: max error / range = %.2e\n", name, cin, B, D, H, W, err / range);
+  return err / range;
+}
+
+static double fnet_check(int N, int H, int W) {
+  const size_t hw = (size_t)H * W;
+  std::vector<float> x((size_t)N * 3 * hw), w0(8 * 3 * 9), w1(8 * 8 * 9), s0(8), b0(8), s1(8), b1(8);
+  for (auto &v : x) v = rnd() * 2.0f;
+  for (auto &v : w0) v = rnd() * 0.3f;
+  for (auto &v : w1) v = rnd() * 0.2f;
+  for (int c = 0; c < 8; ++c) { s0[c] = 0.6f + 0.1f * c; b0[c] = 0.05f * (c - 3); s1[c] = 1.2f - 0.07f * c; b1[c] = 0.03f * (4 - c); }
+  unsigned char *pk = (unsigned char *)std::aligned_alloc(64, (casmvs_fnet_conv0_fused_packed_bytes() + 63) & ~(size_t)63);
+  casmvs_fnet_conv0_fused_pack(w0.data(), s0.data(), b0.data(), w1.data(), s1.data(), b1.data(), pk);
+  float *xa = (float *)std::aligned_alloc(64, (x.size() * 4 + 63) & ~(size_t)63), *ya = (float *)std::aligned_alloc(64, ((size_t)N * 8 * hw * 4 + 63) & ~(size_t)63);
+  std::memcpy(xa, x.data(), x.size() * 4);
+  for (size_t i = 0; i < (size_t)N * 8 * hw; ++i) ya[i] = NAN;
+  if (casmvs_fnet_conv0_fused_f32(pk, xa, ya, N, H, W, 0.01f, nullptr)) { printf("fnet_conv0: %s\n", casmvs_last_error()); return 1e9; }
+  std::vector<double> mid((size_t)N * 8 * hw);
+  auto conv = [&](auto in_at, int cin, const std::vector<float> &w, const std::vector<float> &sc, const std::vector<float> &sh, auto out_set) {
+    for (int n = 0; n < N; ++n)
+      for (int co = 0; co < 8; ++co)
+        for (int yy = 0; yy < H; ++yy)
+          for (int xx = 0; xx < W; ++xx) {
+            double acc = 0;
+            for (int ci = 0; ci < cin; ++ci)
+              for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                  const int iy = yy + ky - 1, ix = xx + kx - 1;
+                  if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                  acc += (double)w[((size_t)co * cin + ci) * 9 + ky * 3 + kx] * in_at(n, ci, iy, ix);
+                }
+            out_set(n, co, yy, xx, lrelu(acc * sc[co] + sh[co]));
+          }
+  };
+  conv([&](int n, int c, int yy, int xx) { return (double)x[((size_t)n * 3 + c) * hw + (size_t)yy * W + xx]; }, 3, w0, s0, b0,
+       [&](int n, int c, int yy, int xx, double v) { mid[((size_t)n * 8 + c) * hw + (size_t)yy * W + xx] = v; });
+  double err = 0, range = 0;
+  conv([&](int n, int c, int yy, int xx) { return mid[((size_t)n * 8 + c) * hw + (size_t)yy * W + xx]; }, 8, w1, s1, b1,
+       [&](int n, int c, int yy, int xx, double v) {
+         const float got = ya[((size_t)n * 8 + c) * hw + (size_t)yy * W + xx];
+         range = std::fmax(range, std::fabs(v));
+         err = std::fmax(err, std::isfinite(got) ? std::fabs(v - got) : 1e30);
+       });
+  std::free(pk); std::free(xa); std::free(ya);
+  printf("fnet_conv0 N=%d %dx%d: max error / range = %.2e\n", N, H, W, err / range);
+  return err / range;
+}
+
+static double deconv_check(int cin, int cout, int B, int Di, int Hi, int Wi) {
+  const size_t ni = (size_t)Di * Hi * Wi, no = ni * 8;
+  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
+  std::vector<float> x((size_t)B * cin * ni), w((size_t)cin * cout * 27), sc(cout), sh(cout), sk((size_t)B * cout * no);
+  for (auto &v : x) v = rnd() * 2.0f + 0.2f;
+  for (auto &v : w) v = rnd() * 0.2f;
+  for (auto &v : sk) v = rnd();
+  for (int c = 0; c < cout; ++c) { sc[c] = 0.5f + 0.05f * c; sh[c] = 0.03f * (c - 4); }
+  const size_t pb = cout == 8 ? casmvs_deconv11_splitf16_packed_bytes() : casmvs_deconv9_splitf16_packed_bytes();
+  unsigned char *pk = (unsigned char *)std::aligned_alloc(64, (pb + 63) & ~(size_t)63);
+  if (cout == 8 ? casmvs_deconv11_splitf16_pack(w.data(), sc.data(), sh.data(), pk) : casmvs_deconv9_splitf16_pack(w.data(), sc.data(), sh.data(), pk)) {
+    printf("deconv pack: %s\n", casmvs_last_error());
+    return 1e9;
+  }
+  float *xa = (float *)std::aligned_alloc(64, (x.size() * 4 + 63) & ~(size_t)63), *ska = (float *)std::aligned_alloc(64, (sk.size() * 4 + 63) & ~(size_t)63),
+        *ya = (float *)std::aligned_alloc(64, (sk.size() * 4 + 63) & ~(size_t)63);
+  std::memcpy(xa, x.data(), x.size() * 4);
+  std::memcpy(ska, sk.data(), sk.size() * 4);
+  for (size_t i = 0; i < sk.size(); ++i) ya[i] = NAN;
+  const int rc = cout == 8 ? casmvs_deconv11_splitf16_forward_f32(pk, xa, ska, ya, B, Di, Hi, Wi, 0.01f, nullptr)
+                           : casmvs_deconv9_splitf16_forward_f32(pk, xa, ska, ya, B, Di, Hi, Wi, 0.01f, nullptr);
+  if (rc) { printf("deconv: %s\n", casmvs_last_error()); return 1e9; }
+  std::vector<double> ref(sk.size(), 0.0);
+  for (int b = 0; b < B; ++b)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int iz = 0; iz < Di; ++iz)
+        for (int iy = 0; iy < Hi; ++iy)
+          for (int ix = 0; ix < Wi; ++ix) {
+            const double v = x[((size_t)b * cin + ci) * ni + ((size_t)iz * Hi + iy) * Wi + ix];
+            for (int co = 0; co < cout; ++co)
+              for (int kz = 0; kz < 3; ++kz)
+                for (int ky = 0; ky < 3; ++ky)
+                  for (int kx = 0; kx < 3; ++kx) {
+                    const int oz = 2 * iz - 1 + kz, oy = 2 * iy - 1 + ky, ox = 2 * ix - 1 + kx;
+                    if (oz < 0 || oz >= Do || oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+                    ref[((size_t)b * cout + co) * no + ((size_t)oz * Ho + oy) * Wo + ox] += v * w[((size_t)ci * cout + co) * 27 + kz * 9 + ky * 3 + kx];
+                  }
+          }
+  double err = 0, range = 0;
+  for (int b = 0; b < B; ++b)
+    for (int co = 0; co < cout; ++co)
+      for (size_t i = 0; i < no; ++i) {
+        const size_t o = ((size_t)b * cout + co) * no + i;
+        const double v = lrelu(ref[o] * sc[co] + sh[co]) + sk[o];
+        range = std::fmax(range, std::fabs(v));
+        err = std::fmax(err, std::isfinite(ya[o]) ? std::fabs(v - ya[o]) : 1e30);
+      }
+  std::free(pk); std::free(xa); std::free(ska); std::free(ya);
+  printf("deconv%-2d    B=%d in %dx%dx%d: max error / range = %.2e\n", cout == 8 ? 11 : 9, B, Di, Hi, Wi, err / range);
+  return err / range;
+}
+
+int main(int argc, char **argv) {
+  hipemu::g_lds = smem_raw;
+  const std::string which = argc > 1 ? argv[1] : "all";
+  double worst = 0;
+  auto take = [&](double e) { worst = std::fmax(worst, e); };
+  const bool all = which == "all", quick = which == "quick";   // quick: one small ragged case per kernel (the CPU test suite)
+  if (all || quick || which == "conv0_sf") take(conv3d_check("conv0_sf", 8, 1, 5, 9, 36, false));
+  if (all || which == "conv0_sf") take(conv3d_check("conv0_sf", 16, 1, 3, 6, 32, false));
+  if (all || quick || which == "conv0_zm") take(conv3d_check("conv0_zm", 16, 1, 5, 17, 36, true));
+  if (all || which == "conv0_zm") {
+    take(conv3d_check("conv0_zm", 8, 1, 5, 20, 36, true));
+    take(conv3d_check("conv0_zm", 16, 2, 9, 17, 44, true));
+    take(conv3d_check("conv0_zm", 32, 1, 3, 16, 32, true));
+  }
+  if (all || quick || which == "fnet_conv0") take(fnet_check(1, 20, 36));
+  if (all || which == "fnet_conv0") take(fnet_check(2, 33, 44));
+  if (all || quick || which == "deconv11") take(deconv_check(16, 8, 1, 2, 5, 18));
+  if (all || which == "deconv11") { take(deconv_check(16, 8, 2, 3, 5, 10)); take(deconv_check(16, 8, 1, 1, 9, 22)); }
+  if (all || quick || which == "deconv9") take(deconv_check(32, 16, 1, 1, 5, 18));
+  if (all || which == "deconv9") take(deconv_check(32, 16, 1, 2, 5, 18));
+  printf(worst < 2e-6 ? "ALL OK (worst %.2e)\n" : "FAILED (worst %.2e)\n", worst);
+  return worst < 2e-6 ? 0 : 1;
+}
