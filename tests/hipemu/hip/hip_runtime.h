@@ -144,6 +144,7 @@ inline void hipemu_buf_store(T v, hipemu_rsrc r, int voff, int soff) {
 #define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, aux) hipemu_buf_load<hipemu_u32x4>(r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b32(val, r, v, s, aux) hipemu_buf_store<unsigned>(val, r, v, s)
 #define __builtin_amdgcn_raw_buffer_store_b64(val, r, v, s, aux) hipemu_buf_store<hipemu_u32x2>(val, r, v, s)
+#define __builtin_amdgcn_raw_buffer_store_b128(val, r, v, s, aux) hipemu_buf_store<hipemu_u32x4>(val, r, v, s)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 

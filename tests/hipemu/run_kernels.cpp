@@ -3,43 +3,13 @@
 //   conv0_zm / fnet_conv0 / deconv11 / deconv9    the kernels written without a GPU run at the end of round 3
 // Build (tests/test_hip_emulation.py does it):
 //   /opt/rocm/lib/llvm/bin/clang++ -std=c++20 -O1 -pthread -DCASMVS_SPLIT_NOASM -Itests/hipemu -Iinclude -Icasmvsnet_pl_amd/csrc tests/hipemu/run_kernels.cpp -o <exe>
-#include <hip/hip_runtime.h>
-
-#include "common.h"
-
-// what abi.hip provides to the launch wrappers
-namespace casmvs {
-static thread_local char g_err[512];
-char *error_buffer() { return g_err; }
-int fail(int code, const char *fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
-void clear_error() { g_err[0] = 0; }
-int ensure_dynamic_lds(const void *, size_t bytes, const char *what) { return bytes <= 160 * 1024 ? 0 : fail(CASMVS_ERR_HIP, "%s: %zu bytes of LDS", what, bytes); }
-int resident_blocks(const void *, int, size_t) { return 3; }   // three persistent workgroups: every one walks several items
-}  // namespace casmvs
-extern "C" const char *casmvs_last_error(void) { return casmvs::g_err; }
-
-namespace {
-alignas(64) unsigned char smem_raw[HIPEMU_LDS_BYTES];   // the kernels' `extern __shared__ smem_raw[]`
-}
+#include "support.h"
 
 #include "conv0_splitf16.hip"
 #include "conv0_zmarch.hip"
 #include "fnet_conv0_fused.hip"
 #include "deconv11_splitf16.hip"
 #include "deconv9_splitf16.hip"
-
-static uint32_t g_rng = 2463534242u;
-static float rnd() {
-  g_rng ^= g_rng << 13; g_rng ^= g_rng >> 17; g_rng ^= g_rng << 5;
-  return (float)(int32_t)g_rng * (1.0f / 2147483648.0f);
-}
-static double lrelu(double v) { return v > 0 ? v : v * 0.01f; }
 
 static double conv3d_check(const char *name, int cin, int B, int D, int H, int W, bool zmarch) {
   const size_t n = (size_t)D * H * W;

@@ -15,14 +15,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = os.environ.get("HIPEMU_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
 
 
-@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-def test_kernels_run_on_the_cpu_against_float64(tmp_path):
-    exe = str(tmp_path / "run_kernels")
+def _build_and_run(tmp_path, source, names):
+    exe = str(tmp_path / source)
     build = subprocess.run([CLANG, "-std=c++20", "-O1", "-pthread", "-DCASMVS_SPLIT_NOASM", "-I" + os.path.join(ROOT, "tests", "hipemu"),
                             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "casmvsnet_pl_amd", "csrc"), "-x", "c++",
-                            os.path.join(ROOT, "tests", "hipemu", "run_kernels.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+                            os.path.join(ROOT, "tests", "hipemu", source + ".cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
     assert build.returncode == 0, build.stderr[-3000:]
     out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
-    for name in ("conv0_sf", "conv0_zm", "fnet_conv0", "deconv11", "deconv9"):
+    for name in names:
         assert name in out.stdout
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_kernels_run_on_the_cpu_against_float64(tmp_path):
+    _build_and_run(tmp_path, "run_kernels", ("conv0_sf", "conv0_zm", "fnet_conv0", "deconv11", "deconv9"))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_production_channel_inner_kernels_run_on_the_cpu(tmp_path):
+    """conv_ci_sf_kernel (CostRegNet conv2 / conv4 / conv6) and conv2d_ci_sf_kernel (FeatureNet, with its pixel-major second output): the device code of
+    two GPU-validated production kernels as a regression test that needs no GPU."""
+    _build_and_run(tmp_path, "run_kernels2", ("conv_ci", "conv2d_ci"))
