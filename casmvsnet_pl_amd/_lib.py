@@ -92,7 +92,9 @@ SYMBOLS = {
     "casmvs_prob_regress_supported": (c_int, [c_int, c_int]),
     "casmvs_prob_regress_f32": (c_int, [_FP] * 7 + [c_int] * 5 + [c_float, c_int, c_void_p]),
     "casmvs_costreg_regress_f32": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
-    "casmvs_costreg_regress_x_f32": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p]),
+    "casmvs_costreg_regress_x_f32": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_int]),
+    "casmvs_conv11_prob_regress_supported": (c_int, [c_int, c_int, c_int]),
+    "casmvs_conv11_prob_regress_f32": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_depth_regression_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_fuse_reference_view": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_fuse_reference_view_paired": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),

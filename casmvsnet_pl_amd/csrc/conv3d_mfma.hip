@@ -2300,10 +2300,12 @@ namespace {
 // conv0 .. conv11 (+ skips) into the workspace, then the `prob` head: on its own (depth == nullptr), or fused with the
 // softmax / regression / confidence that consumes it (casmvs_prob_regress_f32).
 // x_* (experimental layer set, casmvs_costreg_regress_x_f32): x_zmarch 1 = conv0 on conv0_zmarch.hip for cin 8 / 16, 2 = also cin 32; x_d9 / x_d11 = the
-// images of casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack (conv9 / conv11 on the f16 matrix cores)
+// images of casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack (conv9 / conv11 on the f16 matrix cores); x_tail 1 (with x_d11) = conv11 + skip +
+// `prob` + regression as ONE kernel (conv11_prob_fused.hip)
 int costreg_run(const char *who, const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol, const float *depth_values,
                 float *cost, float *depth, float *confidence, int32_t *index, void *workspace, int B, int cin, int D,
-                int h, int w, float slope, void *const *layer_events, void *stream, int x_zmarch = 0, const void *x_d9 = nullptr, const void *x_d11 = nullptr) {
+                int h, int w, float slope, void *const *layer_events, void *stream, int x_zmarch = 0, const void *x_d9 = nullptr, const void *x_d11 = nullptr,
+                int x_tail = 0) {
   CASMVS_REQUIRE(packed_layers && vol && cost && workspace, "%s: null pointer", who);
   CASMVS_REQUIRE(B > 0 && cin > 0 && D > 0 && h > 0 && w > 0 && D % 8 == 0 && h % 8 == 0 && w % 8 == 0,
                  "%s: B=%d cin=%d D=%d h=%d w=%d (D, h, w must be multiples of 8)", who, B, cin, D, h, w);
@@ -2398,6 +2400,18 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
   } else {
   CASMVS_L(CASMVS_CONV_T2, P[8], u7, c2, u9, B, 32, 16, D / 4, h / 4, w / 4, sl, stream);           // conv2 + conv9
   }
+  if (x_tail && x_d11 && depth != nullptr && casmvs_conv11_prob_regress_supported(D, h, w) && (reinterpret_cast<size_t>(x_d11) & 15) == 0) {
+    // conv11 + skip + prob + softmax regression in one depth-walking kernel: the `conv11` interval of layer_events times it, `prob` is empty
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv11_prob_regress_f32(x_d11, P[10], u9, c0, depth_values, cost, depth, confidence, index, B, D, h, w, sl, 0, stream);
+    if (rc != CASMVS_OK) return rc;
+    if (layer_events) {
+      (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+      (void)hipEventRecord((hipEvent_t)layer_events[11], (hipStream_t)stream);
+    }
+    return CASMVS_OK;
+  }
   if (x_d11 && casmvs_deconv11_splitf16_supported(w / 2) && (reinterpret_cast<size_t>(x_d11) & 15) == 0) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
@@ -2442,12 +2456,14 @@ extern "C" int casmvs_costreg_regress_f32(const float *const *packed_layers, con
 extern "C" int casmvs_costreg_regress_x_f32(const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol,
                                             const float *depth_values, float *cost, float *depth, float *confidence, int32_t *index,
                                             void *workspace, int B, int cin, int D, int h, int w, float slope,
-                                            void *const *layer_events, void *stream, int conv0_zmarch, const void *deconv9_image, const void *deconv11_image) {
+                                            void *const *layer_events, void *stream, int conv0_zmarch, const void *deconv9_image, const void *deconv11_image,
+                                            int fuse_tail) {
   casmvs::clear_error();
   CASMVS_REQUIRE(depth_values && depth && confidence, "costreg_regress_x: null pointer");
+  CASMVS_REQUIRE(!fuse_tail || deconv11_image, "costreg_regress_x: fuse_tail needs the conv11 image");
   CASMVS_REQUIRE(conv0_zmarch >= 0 && conv0_zmarch <= 2, "costreg_regress_x: conv0_zmarch=%d (0 off, 1 cin 8 / 16, 2 also cin 32)", conv0_zmarch);
   return costreg_run("costreg_regress_x", packed_layers, split_layers, conv0_arith, vol, depth_values, cost, depth, confidence, index, workspace, B,
-                     cin, D, h, w, slope, layer_events, stream, conv0_zmarch, deconv9_image, deconv11_image);
+                     cin, D, h, w, slope, layer_events, stream, conv0_zmarch, deconv9_image, deconv11_image, fuse_tail);
 }
 
 extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float *tflops) {

@@ -256,7 +256,7 @@ class CostRegNet(_PackedWeights, nn.Module):
         self.timer_name = "costreg"
         # Kernels written without a GPU run at the end of round 3 (opt-in until their first tests have passed on the MI355X), used by `regress` with
         # conv0_mode "splitf16": "zmarch" (conv0 input-stationary along z for cin 8 / 16; "zmarch32": also cin 32), "deconv9", "deconv11" (conv9 / conv11
-        # on the f16 matrix cores)
+        # on the f16 matrix cores), "tail" (conv11 + skip + prob + regression as one kernel, conv11_prob_fused.hip)
         self.experimental = set()
         self._deconv_sf = None
 
@@ -340,7 +340,7 @@ class CostRegNet(_PackedWeights, nn.Module):
         c2, c4, c6 = self._ci_sf if self.ci_mode == "splitf16" else (None, None, None)
         zm, d9, d11 = 0, None, None
         if self.experimental and self.ci_mode == "splitf16" and self.conv0_mode == "splitf16":   # never in the all-float32 replicas (graph.py)
-            unknown = set(self.experimental) - {"zmarch", "zmarch32", "deconv9", "deconv11"}
+            unknown = set(self.experimental) - {"zmarch", "zmarch32", "deconv9", "deconv11", "tail"}
             if unknown:
                 raise ValueError(f"CostRegNet.experimental: unknown entries {sorted(unknown)}")
             zm = 2 if "zmarch32" in self.experimental else (1 if "zmarch" in self.experimental else 0)
@@ -350,10 +350,10 @@ class CostRegNet(_PackedWeights, nn.Module):
                 self._deconv_sf = (self._packed_key, ops.deconv9_splitf16_pack(self.conv9[0].weight, s9, b9).to(x.device),
                                    ops.deconv11_splitf16_pack(self.conv11[0].weight, s11, b11).to(x.device))
             d9 = self._deconv_sf[1] if "deconv9" in self.experimental else None
-            d11 = self._deconv_sf[2] if "deconv11" in self.experimental else None
+            d11 = self._deconv_sf[2] if ("deconv11" in self.experimental or "tail" in self.experimental) else None
         return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index,
                                    conv0_split=split, conv0_arith=arith, conv2_split=c2, conv4_split=c4, conv6_split=c6,
-                                   conv0_zmarch=zm, deconv9_split=d9, deconv11_split=d11)
+                                   conv0_zmarch=zm, deconv9_split=d9, deconv11_split=d11, fuse_tail="tail" in self.experimental and d11 is not None)
 
 
 class CascadeMVSNet(nn.Module):

@@ -491,7 +491,7 @@ CONV0_F32, CONV0_SPLIT_BF16, CONV0_SPLIT_F16 = 0, 1, 2   # casmvs.h: CASMVS_CONV
 
 
 def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, layer_events=None, return_index=False, conv0_split=None,
-                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None, conv6_split=None, conv0_zmarch=0, deconv9_split=None, deconv11_split=None):
+                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None, conv6_split=None, conv0_zmarch=0, deconv9_split=None, deconv11_split=None, fuse_tail=False):
     """CostRegNet + softmax / depth regression / confidence in one library call (mvsnet.py:91-104 + :174-193): the `prob`
     head walks the depth axis and, when the whole depth range is one chunk, runs the regression on the cost values it has
     just produced (casmvs_costreg_regress_f32).  -> cost (B,D,h,w), depth (B,h,w), confidence (B,h,w) [, index int32].
@@ -527,7 +527,7 @@ def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, lay
                                                           _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
                                                           float(slope), ev, _stream(vol), int(conv0_zmarch),
                                                           None if deconv9_split is None else ctypes.c_void_p(deconv9_split.data_ptr()),
-                                                          None if deconv11_split is None else ctypes.c_void_p(deconv11_split.data_ptr()))
+                                                          None if deconv11_split is None else ctypes.c_void_p(deconv11_split.data_ptr()), 1 if fuse_tail else 0)
         else:
             rc = _lib.load().casmvs_costreg_regress_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
                                                         _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,

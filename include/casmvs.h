@@ -239,15 +239,27 @@ int casmvs_deconv9_splitf16_supported(int Wi);
 int casmvs_deconv9_splitf16_forward_f32(const void *packed, const float *in, const float *skip, float *out, int B, int Di, int Hi, int Wi,
                                         float slope, void *stream);
 
+/* CostRegNet's tail as ONE kernel (csrc/conv11_prob_fused.hip): conv11 (+ ABN + leaky-relu) + the conv0 skip, the `prob` head walking the depth axis and - when
+ * the depth range is one chunk - softmax / depth regression / confidence: the 8-channel full-resolution tensor between conv11 and `prob` (16 n of the 28 n
+ * floats the pair moves) exists only as LDS plane patches.  deconv11_image: casmvs_deconv11_splitf16_pack; prob_packed: casmvs_conv3d_pack_f32(CASMVS_CONV_S1, 8, 1);
+ * u9 (B, 16, D/2, h/2, w/2) = conv9's output; skip (B, 8, D, h, w) = conv0's output; cost (B, D, h, w) always written; depth / confidence (B, h, w)
+ * [, index] with depth_values (B, D, h, w), or depth = NULL (cost only).  D, h even, w % 4 == 0.  zchunk 0 = automatic.
+ * WRITTEN WITHOUT A GPU RUN at the end of round 3 (runs correctly on the CPU under tests/hipemu; tools/native/conv11_prob_check.cpp is its first GPU test). */
+int casmvs_conv11_prob_regress_supported(int D, int h, int w);
+int casmvs_conv11_prob_regress_f32(const void *deconv11_image, const float *prob_packed, const float *u9, const float *skip, const float *depth_values,
+                                   float *cost, float *depth, float *confidence, int32_t *index, int B, int D, int h, int w, float slope, int zchunk,
+                                   void *stream);
+
 /* The engine's two whole-network calls with the EXPERIMENTAL layer set (the kernels above that were written without a GPU run: until their first
  * tests have passed on the MI355X nothing in the package passes non-default values here).  As casmvs_costreg_regress_f32 plus: conv0_zmarch 1 = conv0
  * through casmvs_conv0_zmarch_forward_f32 for cin 8 / 16 (2: also cin 32; needs conv0_arith = CASMVS_CONV0_SPLIT_F16 and its image),
- * deconv9_image / deconv11_image = device images of casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack or NULL.  As
+ * deconv9_image / deconv11_image = device images of casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack or NULL; fuse_tail 1 (with
+ * deconv11_image) = conv11 + skip + `prob` + regression through casmvs_conv11_prob_regress_f32.  As
  * casmvs_featurenet_forward_fused_f32 plus: conv0_fused_image = device image of casmvs_fnet_conv0_fused_pack or NULL. */
 int casmvs_costreg_regress_x_f32(const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol,
                                  const float *depth_values, float *cost, float *depth, float *confidence, int32_t *index, void *workspace,
                                  int B, int cin, int D, int h, int w, float slope, void *const *layer_events, void *stream, int conv0_zmarch,
-                                 const void *deconv9_image, const void *deconv11_image);
+                                 const void *deconv9_image, const void *deconv11_image, int fuse_tail);
 int casmvs_featurenet_forward_fused_x_f32(const float *const *packed_layers, const void *fused0_packed, int fused0_arith, const float *fused0_bias9,
                                           const void *const *ci_layers, const float *imgs, float *feat0, float *feat1, float *feat2,
                                           float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc, void *workspace, int N, int H, int W, float slope,

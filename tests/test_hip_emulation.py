@@ -37,3 +37,10 @@ def test_production_channel_inner_kernels_run_on_the_cpu(tmp_path):
     """conv_ci_sf_kernel (CostRegNet conv2 / conv4 / conv6) and conv2d_ci_sf_kernel (FeatureNet, with its pixel-major second output): the device code of
     two GPU-validated production kernels as a regression test that needs no GPU."""
     _build_and_run(tmp_path, "run_kernels2", ("conv_ci", "conv2d_ci"))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_fused_costreg_tail_runs_on_the_cpu(tmp_path):
+    """conv11 + skip + `prob` + softmax regression as one depth-walking kernel (csrc/conv11_prob_fused.hip, written without a GPU run): cost volume, depth and
+    confidence against the layers in float64, two x tiles (stride 62, the first one starting at x = -1) and two y tiles."""
+    _build_and_run(tmp_path, "run_kernels3", ("conv11_prob",))

@@ -10,8 +10,8 @@ mkdir -p $OUT
 cd $ROOTDIR
 export TMPDIR=/tmp
 # torch-free first (seconds): the kernel written blind at the end of round 3, then the checks of the kernels that are already defaults
-(timeout 60 tools/probes/bin/conv0_zm_check 2; timeout 60 tools/probes/bin/fnet_conv0_check; timeout 60 tools/probes/bin/deconv11_check 2; timeout 60 tools/probes/bin/deconv9_check 2; timeout 30 tools/probes/bin/prob_wgrad_check; timeout 30 tools/probes/bin/fusion_check; timeout 60 python tools/notorch/step_runner.py --batch 8;
- for x in zmarch zmarch32 deconv11 deconv9 fnet_conv0 zmarch,deconv9,deconv11,fnet_conv0; do echo "== --experimental $x"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $x | tail -4; done) > $OUT/native.txt 2>&1
+(timeout 60 tools/probes/bin/conv0_zm_check 2; timeout 60 tools/probes/bin/fnet_conv0_check; timeout 60 tools/probes/bin/deconv11_check 2; timeout 60 tools/probes/bin/deconv9_check 2; timeout 90 tools/probes/bin/conv11_prob_check 2; timeout 30 tools/probes/bin/prob_wgrad_check; timeout 30 tools/probes/bin/fusion_check; timeout 60 python tools/notorch/step_runner.py --batch 8;
+ for x in zmarch zmarch32 deconv11 deconv9 fnet_conv0 tail zmarch,deconv9,deconv11,fnet_conv0 zmarch,deconv9,tail,fnet_conv0; do echo "== --experimental $x"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $x | tail -4; done) > $OUT/native.txt 2>&1
 nproc > $OUT/host.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host.txt 2>/dev/null; lscpu | grep -E "Model name|^CPU\(s\)|Flags" | cut -c1-600 >> $OUT/host.txt
 timeout 120 python tools/cpu_png_decode_bench.py 48 1 8 16 32 > $OUT/cpu_png_decode.txt 2>&1
 timeout 200 python tools/cpu_loader_rate.py 49 8 16 32 64 > $OUT/cpu_loader_rate.txt 2>&1

@@ -24,7 +24,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=(512, 640))
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--all-f32", action="store_true", help="every layer on the float32 MFMA kernels (conv0_mode / ci_mode / tail_mode = f32)")
-ap.add_argument("--experimental", default="", help="comma list of the kernels written without a GPU run: zmarch | zmarch32, deconv9, deconv11, fnet_conv0")
+ap.add_argument("--experimental", default="", help="comma list of the kernels written without a GPU run: zmarch | zmarch32, deconv9, deconv11, fnet_conv0, tail")
 args = ap.parse_args()
 if args.lib:
     os.environ["CASMVS_LIB_PATH"] = os.path.abspath(args.lib)
@@ -132,7 +132,7 @@ for l in range(3):
 
 # ---- the experimental layer set (casmvs_*_x_f32): images of the kernels written without a GPU run ----------------------------------
 EXP = set(filter(None, args.experimental.split(",")))
-assert EXP <= {"zmarch", "zmarch32", "deconv9", "deconv11", "fnet_conv0"}, EXP
+assert EXP <= {"zmarch", "zmarch32", "deconv9", "deconv11", "fnet_conv0", "tail"}, EXP
 assert not (EXP and args.all_f32), "the experimental kernels belong to the split-f16 layer set"
 ZM = 2 if "zmarch32" in EXP else (1 if "zmarch" in EXP else 0)
 fnet_conv0_img = None
@@ -145,7 +145,7 @@ for l in range(3):
     if "deconv9" in EXP:
         w, sc, sh = costreg_w[l]["conv9"]
         d9 = pack_bytes(lib.casmvs_deconv9_splitf16_packed_bytes(), lib.casmvs_deconv9_splitf16_pack, hp(w), hp(sc), hp(sh))
-    if "deconv11" in EXP:
+    if "deconv11" in EXP or "tail" in EXP:
         w, sc, sh = costreg_w[l]["conv11"]
         d11 = pack_bytes(lib.casmvs_deconv11_splitf16_packed_bytes(), lib.casmvs_deconv11_splitf16_pack, hp(w), hp(sc), hp(sh))
     deconv_imgs.append((d9, d11))
@@ -243,7 +243,7 @@ def step(timed=False):
         if ZM or d9 is not None or d11 is not None:
             run_stage(f"costreg_{l}", lambda: check(lib.casmvs_costreg_regress_x_f32(
                 arr11, sp, 2, L["vol"].p, L["dv"].p, L["cost"].p, L["depth"].p, L["conf"].p, None, L["ws"].p, B, C, D, h, w,
-                ctypes.c_float(0.01), None, st, ZM, None if d9 is None else d9.p, None if d11 is None else d11.p), "costreg_regress_x"), timed)
+                ctypes.c_float(0.01), None, st, ZM, None if d9 is None else d9.p, None if d11 is None else d11.p, 1 if "tail" in EXP else 0), "costreg_regress_x"), timed)
         else:
             run_stage(f"costreg_{l}", lambda: check(lib.casmvs_costreg_regress_f32(
                 arr11, sp, 0 if args.all_f32 else 2, L["vol"].p, L["dv"].p, L["cost"].p, L["depth"].p, L["conf"].p, None, L["ws"].p, B, C, D, h, w,
