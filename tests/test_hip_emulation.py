@@ -15,16 +15,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = os.environ.get("HIPEMU_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
 
 
-def _build_and_run(tmp_path, source, names):
+def _build_and_run(tmp_path, source, names, extra=()):
     exe = str(tmp_path / source)
-    build = subprocess.run([CLANG, "-std=c++20", "-O1", "-pthread", "-DCASMVS_SPLIT_NOASM", "-I" + os.path.join(ROOT, "tests", "hipemu"),
+    build = subprocess.run([CLANG, "-std=c++20", "-O1", "-pthread", *extra, "-DCASMVS_SPLIT_NOASM", "-I" + os.path.join(ROOT, "tests", "hipemu"),
                             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "casmvsnet_pl_amd", "csrc"), "-x", "c++",
                             os.path.join(ROOT, "tests", "hipemu", source + ".cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
     assert build.returncode == 0, build.stderr[-3000:]
-    out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
     for name in names:
         assert name in out.stdout
+    return out
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
@@ -44,3 +45,24 @@ def test_fused_costreg_tail_runs_on_the_cpu(tmp_path):
     """conv11 + skip + `prob` + softmax regression as one depth-walking kernel (csrc/conv11_prob_fused.hip, written without a GPU run): cost volume, depth and
     confidence against the layers in float64, two x tiles (stride 62, the first one starting at x = -1) and two y tiles."""
     _build_and_run(tmp_path, "run_kernels3", ("conv11_prob",))
+
+
+def _has_tsan(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text("int main() { return 0; }\n")
+    return subprocess.run([CLANG, "-fsanitize=thread", str(src), "-o", str(tmp_path / "t")], capture_output=True).returncode == 0
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+@pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "fnet_conv0", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")),
+                                          ("run_kernels3", ("conv11_prob",))])
+def test_no_lds_race_under_thread_sanitizer(tmp_path, source, names):
+    """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
+    LDS is plain memory shared by the workgroup's std::threads and the barrier is the only synchronisation between waves (the wave collectives synchronise
+    one wave's 64 threads, as the hardware's lock step does), so a write and a read of the same LDS word by different waves without a barrier between them is
+    reported as a data race - as are two workgroups storing to the same output element.  Checked to work: the fused tail with its slot-release barrier
+    removed passes the value check and produces 64 reports."""
+    if not _has_tsan(tmp_path):
+        pytest.skip("this clang++ has no ThreadSanitizer runtime")
+    out = _build_and_run(tmp_path, source, names, extra=("-g", "-fsanitize=thread"))
+    assert "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
