@@ -9,6 +9,8 @@ OUT=$ROOTDIR/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOTDIR
 export TMPDIR=/tmp
+# the check binaries are git-ignored: a fresh clone that skipped `bash tools/native/build.sh` builds them here (about a minute of box time)
+[ -x tools/probes/bin/conv11_prob_check ] || bash tools/native/build.sh > $OUT/native_build.txt 2>&1
 # torch-free first (seconds): the kernel written blind at the end of round 3, then the checks of the kernels that are already defaults
 (timeout 60 tools/probes/bin/conv0_zm_check 2; timeout 60 tools/probes/bin/fnet_conv0_check; timeout 60 tools/probes/bin/deconv11_check 2; timeout 60 tools/probes/bin/deconv9_check 2; timeout 90 tools/probes/bin/conv11_prob_check 2; timeout 30 tools/probes/bin/prob_wgrad_check; timeout 30 tools/probes/bin/fusion_check; timeout 60 python tools/notorch/step_runner.py --batch 8;
  for x in zmarch zmarch32 deconv11 deconv9 fnet_conv0 tail zmarch,deconv9,deconv11,fnet_conv0 zmarch,deconv9,tail,fnet_conv0; do echo "== --experimental $x"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $x | tail -4; done) > $OUT/native.txt 2>&1
