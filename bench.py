@@ -386,7 +386,7 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
                                "ms_per_depth_map": cv_ms / n_ev / B, "batch": B,
                                "per_level_frac": {str(l): work[l]["costvol_bytes"] * n_ev / (summ[f"costvol_{l}"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS for l in range(3)}}
     if fused:
-        pr_ms = sum(summ[f"costreg_{l}/prob"]["ms"] for l in range(3))
+        pr_ms = max(1e-6, sum(summ[f"costreg_{l}/prob"]["ms"] for l in range(3)))   # --experimental tail: the interval is empty (the walk is inside conv11's kernel)
         pr_bytes = sum(work[l]["prob_regress_bytes"] for l in range(3)) * n_ev
         out["roofline_prob_regress"] = {"kernel": "prob_zwalk_kernel (+ softmax_regress_kernel where the depth range is chunked): the `prob` head "
                                                   "and mvsnet.py:174-193, 3 library calls per step", "bound": "hbm",
@@ -515,7 +515,14 @@ def main():
                          "'splitf16' also runs conv2 / conv4 in that arithmetic, the other two keep them in float32; the other modes' throughputs "
                          "are measured and printed beside the headline")
     ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: FeatureNet's full-resolution FPN tail as one kernel (1) or as the reference's three steps (0); default: the model's")
+    ap.add_argument("--experimental", default=os.environ.get("CASMVS_EXPERIMENTAL", ""),
+                    help="comma-separated opt-in kernels (written at the end of round 3, DESIGN.md section 6): CostRegNet zmarch / zmarch32 / deconv9 / "
+                         "deconv11 / tail, FeatureNet fnet_conv0; named in the line's config.experimental - a line with this set is an A/B, not the headline")
     args = ap.parse_args()
+    args.experimental = sorted(x for x in args.experimental.split(",") if x)
+    unknown = set(args.experimental) - {"zmarch", "zmarch32", "deconv9", "deconv11", "tail", "fnet_conv0"}
+    if unknown:
+        raise SystemExit(f"--experimental: unknown {sorted(unknown)}")
     args.batch_given = args.batch is not None
     if args.batch is None:
         args.batch = 8
@@ -568,6 +575,10 @@ def main():
                 getattr(model, f"cost_reg_{l}").conv0_mode = mode
                 getattr(model, f"cost_reg_{l}").ci_mode = "splitf16" if mode == "splitf16" else "f32"
             model.feature.tail_mode = "splitf16" if mode == "splitf16" else "f32"
+        if args.experimental:
+            for l in range(3):
+                getattr(model, f"cost_reg_{l}").experimental = set(args.experimental) - {"fnet_conv0"}
+            model.feature.experimental = {"conv0_fused"} if "fnet_conv0" in args.experimental else set()
         # replica: every rank works on its own depth maps (different seeds -> different images / cameras);
         # view_sharded: all ranks share the depth maps and split their source views
         imgs, proj, dmin, dint = config_inputs(args.config, B, seed=0 if view_sharded else rank)
@@ -616,6 +627,7 @@ def main():
                                           "sum-of-squares volumes per level, every rank regularises") if view_sharded else
                                          f"replica x{world} (one depth map stream per GPU, no data-path collective)",
                           "feature_net": "HIP MFMA kernels (casmvs_featurenet_forward_f32)",
+                          **({"experimental": args.experimental} if args.experimental else {}),
                           "regression": "fused into the `prob` head's library call (casmvs_costreg_regress_f32)" if model.fuse_regress else "separate launch",
                           "conv0_arithmetic": {"splitbf16": "float32 operands as three exact bf16 slices, six bf16 x bf16 partial products per product on the "
                                                             "bf16 matrix cores, float32 accumulation (conv0_splitbf16.hip)",
