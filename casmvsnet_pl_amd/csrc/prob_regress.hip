@@ -272,7 +272,9 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
   if constexpr (FUSE) {
     // every cost value of this thread's two pixels was stored by this thread: wait for the stores, then read them
     // back (the "memory" clobber also keeps the compiler from moving the loads above the buffer stores)
+#ifndef HIPEMU_LDS_BYTES   // (tests/hipemu: the host has no such instruction, and needs none)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     if (oy < Hi && ox < Wi) {
       const size_t pix = (size_t)oy * Wi + ox;
       const float *cp = cost + (size_t)b * in_cs + pix, *dp = dvals + (size_t)b * in_cs + pix;

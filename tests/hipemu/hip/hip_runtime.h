@@ -32,7 +32,9 @@
 #define __global__
 #define __device__
 #define __host__
+#ifndef __shared__   // a translation unit whose kernels hold function-scope static LDS arrays defines it as `static` before this header
 #define __shared__
+#endif
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 
@@ -60,6 +62,9 @@ inline thread_local int t_lane = 0, t_wave = 0;
 #define gridDim hipemu::g_gridDim
 #define blockDim hipemu::g_blockDim
 typedef hipemu::Dim3 dim3;
+struct float2 {
+  float x, y;
+};
 
 // The workgroup's dynamic LDS: the kernels declare `extern __shared__ ... smem_raw[]` inside their anonymous namespace, so the translation unit that
 // includes them defines `namespace { alignas(64) unsigned char smem_raw[HIPEMU_LDS_BYTES]; }` and registers it with hipemu::g_lds.

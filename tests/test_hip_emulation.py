@@ -21,7 +21,8 @@ def _build_and_run(tmp_path, source, names, extra=()):
                             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "casmvsnet_pl_amd", "csrc"), "-x", "c++",
                             os.path.join(ROOT, "tests", "hipemu", source + ".cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
     assert build.returncode == 0, build.stderr[-3000:]
-    out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=1800)
+    env = dict(os.environ, TSAN_OPTIONS="exitcode=0")   # the sanitizer test judges the reports itself
+    out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=1800, env=env)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
     for name in names:
         assert name in out.stdout
@@ -41,6 +42,19 @@ def test_production_channel_inner_kernels_run_on_the_cpu(tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_production_prob_head_runs_on_the_cpu(tmp_path):
+    """prob_zwalk_kernel (Conv3d 8 -> 1 walking the depth axis, regression fused or chunked; the production head): cost, depth, confidence and index against
+    float64 - a GPU-free regression test of the kernel the fused tail was derived from."""
+    _build_and_run(tmp_path, "run_kernels4", ("prob_zwalk",))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_prob_weight_gradient_and_fusion_kernels_run_on_the_cpu(tmp_path):
+    """prob_wgrad_kernel + its reduction against a float64 loop; fuse_view_paired_kernel against fuse_view_kernel, all eight outputs bit-equal."""
+    _build_and_run(tmp_path, "run_kernels5", ("prob_wgrad", "fusion"))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_fused_costreg_tail_runs_on_the_cpu(tmp_path):
     """conv11 + skip + `prob` + softmax regression as one depth-walking kernel (csrc/conv11_prob_fused.hip, written without a GPU run): cost volume, depth and
     confidence against the layers in float64, two x tiles (stride 62, the first one starting at x = -1) and two y tiles."""
@@ -55,7 +69,7 @@ def _has_tsan(tmp_path):
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 @pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "fnet_conv0", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")),
-                                          ("run_kernels3", ("conv11_prob",))])
+                                          ("run_kernels3", ("conv11_prob",)), ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion"))])
 def test_no_lds_race_under_thread_sanitizer(tmp_path, source, names):
     """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
     LDS is plain memory shared by the workgroup's std::threads and the barrier is the only synchronisation between waves (the wave collectives synchronise
@@ -65,4 +79,8 @@ def test_no_lds_race_under_thread_sanitizer(tmp_path, source, names):
     if not _has_tsan(tmp_path):
         pytest.skip("this clang++ has no ThreadSanitizer runtime")
     out = _build_and_run(tmp_path, source, names, extra=("-g", "-fsanitize=thread"))
-    assert "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
+    reports = out.stderr.split("WARNING: ThreadSanitizer")[1:]
+    # the one intended same-address access: prob_wgrad_kernel's staging rounds past the last item all WRITE the dummy word box[DUMMY], which nobody reads
+    benign = [r for r in reports if "Write of size 4" in r and "Previous write of size 4" in r and
+              [ln.split("prob_wgrad.hip:")[1].split(":")[0] for ln in r.splitlines() if ln.lstrip().startswith("#0 ") and "prob_wgrad.hip:" in ln] == ["99", "99"]]
+    assert len(reports) == len(benign), reports[0][:3000]
