@@ -71,7 +71,22 @@ struct float2 {
 #define HIPEMU_LDS_BYTES (160 * 1024 + 64)
 namespace hipemu { inline unsigned char *g_lds = nullptr; }
 
-inline void __syncthreads() { hipemu::g_block->bar->arrive_and_wait(); }
+// LDS bank profile (tests/hipemu/lds_profile.cpp; built with -DHIPEMU_LDS_PROFILE -fsanitize=thread but linked against that file instead of the sanitizer's
+// runtime): the compiler's memory-access hooks record every access that falls into the workgroup's LDS array, these calls tell the recorder who is running
+#ifdef HIPEMU_LDS_PROFILE
+extern "C" void hipemu_prof_block_begin(const void *lds, size_t bytes, int nthreads);
+extern "C" void hipemu_prof_thread(int tid);
+extern "C" void hipemu_prof_barrier(void);
+extern "C" void hipemu_prof_block_end(void);
+#define HIPEMU_PROF(call) call
+#else
+#define HIPEMU_PROF(call) ((void)0)
+#endif
+
+inline void __syncthreads() {
+  hipemu::g_block->bar->arrive_and_wait();
+  HIPEMU_PROF(hipemu_prof_barrier());
+}
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
 inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
@@ -106,6 +121,7 @@ void hipemu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
         for (int w = 0; w < nwaves; ++w) blk.wave.push_back(std::make_unique<std::barrier<>>(std::min(64, nthreads - 64 * w)));
         g_block = &blk;
         if (g_lds) std::memset(g_lds, 0xCD, HIPEMU_LDS_BYTES);   // uninitialised LDS is garbage on the GPU too
+        HIPEMU_PROF(hipemu_prof_block_begin(g_lds, HIPEMU_LDS_BYTES, nthreads));
         std::vector<std::thread> threads;
         std::atomic<int> early{0};
         for (int t = 0; t < nthreads; ++t)
@@ -114,9 +130,11 @@ void hipemu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
             t_blockIdx = Dim3(bx, by, bz);
             t_lane = t & 63;
             t_wave = t >> 6;
+            HIPEMU_PROF(hipemu_prof_thread(t));
             kernel(args...);
           });
         for (auto &th : threads) th.join();
+        HIPEMU_PROF(hipemu_prof_block_end());
       }
   g_block = nullptr;
 }
