@@ -77,6 +77,7 @@ namespace hipemu { inline unsigned char *g_lds = nullptr; }
 extern "C" void hipemu_prof_block_begin(const void *lds, size_t bytes, int nthreads);
 extern "C" void hipemu_prof_thread(int tid);
 extern "C" void hipemu_prof_barrier(void);
+extern "C" void hipemu_prof_bufop(int on);
 extern "C" void hipemu_prof_block_end(void);
 #define HIPEMU_PROF(call) call
 #else
@@ -154,13 +155,17 @@ template <class T>
 inline T hipemu_buf_load(hipemu_rsrc r, int voff, int soff) {
   T v{};
   const uint64_t off = (uint64_t)(uint32_t)voff + (uint64_t)(uint32_t)soff;
+  HIPEMU_PROF(hipemu_prof_bufop(1));
   if ((uint32_t)voff < r.bytes && off + sizeof(T) <= r.bytes) std::memcpy(&v, r.base + off, sizeof(T));   // out of range: zeros
+  HIPEMU_PROF(hipemu_prof_bufop(0));
   return v;
 }
 template <class T>
 inline void hipemu_buf_store(T v, hipemu_rsrc r, int voff, int soff) {
   const uint64_t off = (uint64_t)(uint32_t)voff + (uint64_t)(uint32_t)soff;
+  HIPEMU_PROF(hipemu_prof_bufop(1));
   if ((uint32_t)voff < r.bytes && off + sizeof(T) <= r.bytes) std::memcpy(r.base + off, &v, sizeof(T));   // out of range: dropped
+  HIPEMU_PROF(hipemu_prof_bufop(0));
 }
 #define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, aux) hipemu_buf_load<unsigned>(r, v, s)
 #define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, aux) hipemu_buf_load<hipemu_u32x2>(r, v, s)

@@ -18,6 +18,9 @@
 // as the SOURCE makes them (the kernels use explicit 8- / 16-byte vector types for their LDS traffic).  Lanes that execute a site a different number of
 // times between two barriers (divergent loops) can be matched with the wrong partners; the kernels' LDS loops are wave-uniform.
 //
+// Global memory: the raw buffer loads / stores (hipemu_prof_bufop brackets them in hip_runtime.h) are recorded the same way; a wave-instruction's request is the
+// set of distinct 64- and 128-byte lines its active lanes touch - the L1 -> L2 request stream that bounds conv0.
+//
 // Report (at exit, to $HIPEMU_LDS_REPORT or stdout), one line per (site, kind): address, R/W, bytes, wave-instructions, LDS cycles, conflict-free cycles,
 // worst single instruction, and both cycle counts with a store's register transfer (4 / 6 / 13 cycles for 4 / 8 / 16 bytes) as the floor ("eff").  tools/lds_bank_profile.py turns the addresses into source lines.
 #include <algorithm>
@@ -35,9 +38,13 @@ namespace {
 
 struct Rec {
   uintptr_t site;
-  uint32_t epoch, occ, off;
+  uint64_t addr;   // LDS: offset into the array; global: the address
+  uint32_t epoch, occ;
   uint16_t bytes;
-  uint8_t write;
+  uint8_t write, global;
+};
+struct GlobalStat {
+  uint64_t n = 0, lanes = 0, bytes = 0, lines64 = 0, lines128 = 0;
 };
 struct SiteStat {
   uint64_t n = 0, cycles = 0, ideal = 0, worst = 0, lanes = 0, eff = 0, eff_ideal = 0;
@@ -47,15 +54,18 @@ const unsigned char *g_lo = nullptr, *g_hi = nullptr;
 int g_nthreads = 0;
 std::vector<std::vector<Rec>> g_recs;
 std::map<std::tuple<uintptr_t, int, int>, SiteStat> g_stats;   // (site, write, bytes)
-thread_local int t_tid = -1;
+std::map<std::tuple<uintptr_t, int, int>, GlobalStat> g_global;
+thread_local int t_tid = -1, t_bufop = 0;
 thread_local uint32_t t_epoch = 0;
 thread_local std::unordered_map<uintptr_t, uint32_t> *t_occ = nullptr;
 
 inline void record(const void *addr, int bytes, int write, void *site) {
   const unsigned char *a = static_cast<const unsigned char *>(addr);
-  if (t_tid < 0 || a < g_lo || a >= g_hi) return;
+  if (t_tid < 0) return;
+  const bool lds = a >= g_lo && a < g_hi;
+  if (!lds && !t_bufop) return;   // global memory: the raw buffer loads / stores only (hipemu_prof_bufop brackets them)
   uint32_t &occ = (*t_occ)[(uintptr_t)site];
-  g_recs[t_tid].push_back(Rec{(uintptr_t)site, t_epoch, occ++, (uint32_t)(a - g_lo), (uint16_t)bytes, (uint8_t)write});
+  g_recs[t_tid].push_back(Rec{(uintptr_t)site, lds ? (uint64_t)(a - g_lo) : (uint64_t)(uintptr_t)a, t_epoch, occ++, (uint16_t)bytes, (uint8_t)write, (uint8_t)!lds});
 }
 
 // lane groups of one wave-instruction
@@ -131,6 +141,10 @@ struct Reporter {
                    std::get<2>(kv.first), (unsigned long long)kv.second.n, (unsigned long long)kv.second.cycles, (unsigned long long)kv.second.ideal,
                    (unsigned long long)kv.second.worst, (unsigned long long)kv.second.lanes, (unsigned long long)kv.second.eff,
                    (unsigned long long)kv.second.eff_ideal);
+    for (const auto &kv : g_global)
+      std::fprintf(f, "GLB 0x%zx %c %d n=%llu lanes=%llu bytes=%llu lines64=%llu lines128=%llu\n", (size_t)std::get<0>(kv.first), std::get<1>(kv.first) ? 'W' : 'R',
+                   std::get<2>(kv.first), (unsigned long long)kv.second.n, (unsigned long long)kv.second.lanes, (unsigned long long)kv.second.bytes,
+                   (unsigned long long)kv.second.lines64, (unsigned long long)kv.second.lines128);
     if (path) std::fclose(f);
   }
 } g_reporter;
@@ -154,6 +168,8 @@ void hipemu_prof_thread(int tid) {
   t_occ = &occ;
 }
 
+void hipemu_prof_bufop(int on) { t_bufop = on; }
+
 void hipemu_prof_barrier(void) {
   if (t_tid < 0) return;
   ++t_epoch;
@@ -166,23 +182,42 @@ void hipemu_prof_block_end(void) {
     uint32_t wave, epoch, occ;
     uintptr_t site;
     uint16_t bytes;
-    uint8_t write, lane;
-    uint32_t off;
+    uint8_t write, lane, global;
+    uint64_t off;
   };
   std::vector<Item> all;
   for (int t = 0; t < g_nthreads; ++t)
-    for (const Rec &r : g_recs[t]) all.push_back(Item{(uint32_t)t >> 6, r.epoch, r.occ, r.site, r.bytes, r.write, (uint8_t)(t & 63), r.off});
-  auto key = [](const Item &i) { return std::make_tuple(i.wave, i.epoch, i.site, i.occ, i.write, i.bytes); };
+    for (const Rec &r : g_recs[t]) all.push_back(Item{(uint32_t)t >> 6, r.epoch, r.occ, r.site, r.bytes, r.write, (uint8_t)(t & 63), r.global, r.addr});
+  auto key = [](const Item &i) { return std::make_tuple(i.wave, i.epoch, i.site, i.occ, i.write, i.bytes, i.global); };
   std::sort(all.begin(), all.end(), [&](const Item &a, const Item &b) { return key(a) < key(b); });
   for (size_t i = 0; i < all.size();) {
     size_t j = i;
     int off[64];
     std::fill(off, off + 64, -1);
+    std::vector<uint64_t> l64, l128;
     while (j < all.size() && key(all[j]) == key(all[i])) {
       off[all[j].lane] = (int)all[j].off;
+      if (all[i].global)
+        for (uint64_t b = all[j].off; b < all[j].off + all[j].bytes; b += 4) {   // dword granularity: an access may straddle a line
+          l64.push_back(b >> 6);
+          l128.push_back(b >> 7);
+        }
       ++j;
     }
-    price(all[i].write, all[i].bytes, off, g_stats[std::make_tuple(all[i].site, (int)all[i].write, (int)all[i].bytes)]);
+    if (all[i].global) {   // one wave-instruction's memory request: the distinct 64- / 128-byte lines it touches
+      auto distinct = [](std::vector<uint64_t> &v) {
+        std::sort(v.begin(), v.end());
+        return (uint64_t)(std::unique(v.begin(), v.end()) - v.begin());
+      };
+      GlobalStat &g = g_global[std::make_tuple(all[i].site, (int)all[i].write, (int)all[i].bytes)];
+      g.n += 1;
+      g.lanes += j - i;
+      g.bytes += (j - i) * all[i].bytes;
+      g.lines64 += distinct(l64);
+      g.lines128 += distinct(l128);
+    } else {
+      price(all[i].write, all[i].bytes, off, g_stats[std::make_tuple(all[i].site, (int)all[i].write, (int)all[i].bytes)]);
+    }
     i = j;
   }
   g_recs.clear();

@@ -161,6 +161,10 @@ int main(int argc, char **argv) {
     take(conv3d_check("conv0_zm", 16, 2, 9, 17, 44, true));
     take(conv3d_check("conv0_zm", 32, 1, 3, 16, 32, true));
   }
+  if (which == "conv0_compare") {   // both conv0 kernels on ONE interior-dominated problem (tools/lds_bank_profile.py: their global request streams)
+    take(conv3d_check("conv0_sf", 16, 1, 8, 32, 128, false));
+    take(conv3d_check("conv0_zm", 16, 1, 8, 32, 128, true));
+  }
   if (all || quick || which == "fnet_conv0") take(fnet_check(1, 20, 36));
   if (all || which == "fnet_conv0") take(fnet_check(2, 33, 44));
   if (all || quick || which == "deconv11") take(deconv_check(16, 8, 1, 2, 5, 18));

@@ -38,7 +38,9 @@ def symbolize(exe, addresses):
     for a, block in zip(addresses, out.strip().split("\n\n")):
         lines = block.strip().splitlines()
         frames = [(lines[i], lines[i + 1]) for i in range(0, len(lines) - 1, 2)]
-        inner = frames[0][1] if frames else "?"
+        # the innermost frame inside a kernel source (the buffer helpers of buffer_ops.h / the emulator's header are inlined into it)
+        inner = next((loc for _, loc in frames if ".hip:" in loc), next((loc for _, loc in frames if "hip_runtime.h" not in loc and "buffer_ops.h" not in loc),
+                                                                        frames[0][1] if frames else "?"))
         kernel = next((fn for fn, _ in frames if fn.endswith("_kernel") or "_kernel<" in fn), frames[-1][0] if frames else "?")
         m = re.match(r"(.*?):(\d+):\d+$", inner)
         result[a] = (kernel, os.path.basename(m.group(1)) + ":" + m.group(2) if m else inner)
@@ -59,7 +61,19 @@ def profile(driver, mode="quick", workdir=None):
             m = re.match(r"LDS 0x([0-9a-f]+) ([RW]) (\d+) n=(\d+) cycles=(\d+) ideal=(\d+) worst=(\d+) lanes=\d+ eff=(\d+) eff_ideal=(\d+)", line)
             if m:
                 rows.append((int(m.group(1), 16), m.group(2), *(int(m.group(i)) for i in range(3, 10))))
-        sym = symbolize(exe, sorted({r[0] for r in rows}))
+        glb = []
+        for line in open(report):
+            m = re.match(r"GLB 0x([0-9a-f]+) ([RW]) (\d+) n=(\d+) lanes=(\d+) bytes=(\d+) lines64=(\d+) lines128=(\d+)", line)
+            if m:
+                glb.append((int(m.group(1), 16), m.group(2), *(int(m.group(i)) for i in range(3, 9))))
+        sym = symbolize(exe, sorted({r[0] for r in rows} | {r[0] for r in glb}))
+    global GLOBAL_TABLE
+    GLOBAL_TABLE = collections.OrderedDict()
+    for addr, rw, nbytes, n, lanes, nb, l64, l128 in glb:
+        kernel, where = sym[addr]
+        t = GLOBAL_TABLE.setdefault((kernel, where, rw, nbytes), [0, 0, 0, 0, 0])
+        for i, v in enumerate((n, lanes, nb, l64, l128)):
+            t[i] += v
     table = collections.OrderedDict()
     for addr, rw, nbytes, n, cyc, ideal, worst, eff, eff_ideal in rows:
         kernel, where = sym[addr]
@@ -71,6 +85,18 @@ def profile(driver, mode="quick", workdir=None):
         t[4] += eff
         t[5] += eff_ideal
     return table
+
+
+GLOBAL_TABLE = collections.OrderedDict()   # of the last profile(): {(kernel, 'file:line', 'R'|'W', bytes): [wave-instructions, lanes, bytes, 64-byte lines, 128-byte lines]}
+
+
+def global_per_kernel(table=None):
+    tot = collections.OrderedDict()
+    for (kernel, _, rw, _), vals in (GLOBAL_TABLE if table is None else table).items():
+        t = tot.setdefault(kernel, {"R": [0] * 5, "W": [0] * 5})[rw]
+        for i, v in enumerate(vals):
+            t[i] += v
+    return tot
 
 
 def per_kernel(table):
@@ -88,8 +114,20 @@ def main():
     mode = args[1] if len(args) > 1 else "quick"
     table = profile(driver, mode)
     print(f"LDS bank profile of tests/hipemu/{driver}.cpp ({mode}): wave-instructions, LDS-array cycles vs conflict-free cycles (1.00 = no bank conflict)")
-    for kernel, t in per_kernel(table).items():
+    gtot = global_per_kernel()
+    ltot = per_kernel(table)
+    for kernel in list(ltot) + [k for k in gtot if k not in ltot]:
+        t = ltot.get(kernel, {"R": [0] * 5, "W": [0] * 5})
         print(f"{kernel}")
+        for rw, name in (("R", "buffer loads "), ("W", "buffer stores")):
+            n, lanes, nb, l64, l128 = gtot.get(kernel, {"R": [0] * 5, "W": [0] * 5})[rw]
+            if n:
+                print(f"    {name} {n:8d} wave-instructions  {nb:10d} bytes in {l64:8d} 64-byte lines ({nb / (64 * l64):.2f} of the lines' bytes used) / "
+                      f"{l128:8d} 128-byte lines ({nb / (128 * l128):.2f}); {l64 / n:.1f} lines per instruction")
+                if "--lines" in sys.argv:
+                    for (k, where, r, nbytes), (n2, lanes2, nb2, a64, a128) in GLOBAL_TABLE.items():
+                        if k == kernel and r == rw:
+                            print(f"        {where:32s} {r}{nbytes:<3d} n={n2:7d}  {lanes2 / n2:5.1f} lanes, {a64 / n2:5.2f} 64-byte lines per instruction, {nb2 / (64 * a64):.2f} used")
         for rw, name in (("R", "reads "), ("W", "writes")):
             n, cyc, ideal, eff, eff_ideal = t[rw]
             if n:
