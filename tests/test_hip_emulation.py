@@ -4,7 +4,9 @@ checking), tests/hipemu/run_kernels.cpp includes the .hip files as C++ and runs 
 
 `conv0_sf` is the established kernel (validated on the GPU): it checks the emulator.  conv0_zm / fnet_conv0 / deconv11 / deconv9 were written at the end of
 round 3 without access to a GPU: this is the first time their code RUNS - ragged shapes, persistent workgroups that walk several items, z segments.
-What the emulation cannot show: timing, LDS bank conflicts, the co-residency hazard of DESIGN.md 2.0.  CPU only; needs ROCm's clang++ (host target)."""
+The same sources under ThreadSanitizer (a missing barrier is a reported race) and under an LDS bank-conflict / cache-line profile built from the compiler's
+memory-access hooks (tools/lds_bank_profile.py).  What the emulation cannot show: timing, the co-residency hazard of DESIGN.md 2.0, the device compiler's
+code.  CPU only; needs ROCm's clang++ (host target)."""
 import os
 import shutil
 import subprocess
@@ -15,12 +17,54 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = os.environ.get("HIPEMU_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
 
 
-def _build_and_run(tmp_path, source, names, extra=()):
-    exe = str(tmp_path / source)
+DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5")
+PROFILED = ("run_kernels", "run_kernels3")
+
+
+def _profile_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lds_bank_profile", os.path.join(ROOT, "tools", "lds_bank_profile.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    return tool
+
+
+def _compile(workdir, source, extra=(), suffix=""):
+    exe = os.path.join(workdir, source + suffix)
     build = subprocess.run([CLANG, "-std=c++20", "-O1", "-pthread", *extra, "-DCASMVS_SPLIT_NOASM", "-I" + os.path.join(ROOT, "tests", "hipemu"),
                             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "casmvsnet_pl_amd", "csrc"), "-x", "c++",
-                            os.path.join(ROOT, "tests", "hipemu", source + ".cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+                            os.path.join(ROOT, "tests", "hipemu", source + ".cpp"), "-o", exe], capture_output=True, text=True, timeout=900)
     assert build.returncode == 0, build.stderr[-3000:]
+    return exe
+
+
+def _has_tsan(workdir):
+    src = os.path.join(workdir, "t.cpp")
+    with open(src, "w") as f:
+        f.write("int main() { return 0; }\n")
+    return subprocess.run([CLANG, "-fsanitize=thread", src, "-o", os.path.join(workdir, "t")], capture_output=True).returncode == 0
+
+
+@pytest.fixture(scope="module")
+def built(tmp_path_factory):
+    """Every executable of this module - plain, ThreadSanitizer and LDS-profile builds of the five drivers - compiled concurrently, once."""
+    from concurrent.futures import ThreadPoolExecutor
+    workdir = str(tmp_path_factory.mktemp("hipemu"))
+    tsan = _has_tsan(workdir)
+    tool = _profile_tool()
+    jobs = {}
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
+        for source in DRIVERS:
+            jobs[(source, "plain")] = pool.submit(_compile, workdir, source)
+            if tsan:
+                jobs[(source, "tsan")] = pool.submit(_compile, workdir, source, ("-g", "-fsanitize=thread"), "_tsan")
+        if tsan:
+            for source in PROFILED:
+                jobs[(source, "profile")] = pool.submit(tool.build, source, workdir)
+    return {"workdir": workdir, "tsan": tsan, **{k: f.result() for k, f in jobs.items()}}
+
+
+def _run(exe, names):
     env = dict(os.environ, TSAN_OPTIONS="exitcode=0")   # the sanitizer test judges the reports itself
     out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=1800, env=env)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
@@ -30,55 +74,49 @@ def _build_and_run(tmp_path, source, names, extra=()):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-def test_kernels_run_on_the_cpu_against_float64(tmp_path):
-    _build_and_run(tmp_path, "run_kernels", ("conv0_sf", "conv0_zm", "fnet_conv0", "deconv11", "deconv9"))
+def test_kernels_run_on_the_cpu_against_float64(built):
+    _run(built[("run_kernels", "plain")], ("conv0_sf", "conv0_zm", "fnet_conv0", "deconv11", "deconv9"))
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-def test_production_channel_inner_kernels_run_on_the_cpu(tmp_path):
+def test_production_channel_inner_kernels_run_on_the_cpu(built):
     """conv_ci_sf_kernel (CostRegNet conv2 / conv4 / conv6) and conv2d_ci_sf_kernel (FeatureNet, with its pixel-major second output): the device code of
     two GPU-validated production kernels as a regression test that needs no GPU."""
-    _build_and_run(tmp_path, "run_kernels2", ("conv_ci", "conv2d_ci"))
+    _run(built[("run_kernels2", "plain")], ("conv_ci", "conv2d_ci"))
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-def test_production_prob_head_runs_on_the_cpu(tmp_path):
+def test_production_prob_head_runs_on_the_cpu(built):
     """prob_zwalk_kernel (Conv3d 8 -> 1 walking the depth axis, regression fused or chunked; the production head): cost, depth, confidence and index against
     float64 - a GPU-free regression test of the kernel the fused tail was derived from."""
-    _build_and_run(tmp_path, "run_kernels4", ("prob_zwalk",))
+    _run(built[("run_kernels4", "plain")], ("prob_zwalk",))
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-def test_prob_weight_gradient_and_fusion_kernels_run_on_the_cpu(tmp_path):
+def test_prob_weight_gradient_and_fusion_kernels_run_on_the_cpu(built):
     """prob_wgrad_kernel + its reduction against a float64 loop; fuse_view_paired_kernel against fuse_view_kernel, all eight outputs bit-equal."""
-    _build_and_run(tmp_path, "run_kernels5", ("prob_wgrad", "fusion"))
+    _run(built[("run_kernels5", "plain")], ("prob_wgrad", "fusion"))
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-def test_fused_costreg_tail_runs_on_the_cpu(tmp_path):
+def test_fused_costreg_tail_runs_on_the_cpu(built):
     """conv11 + skip + `prob` + softmax regression as one depth-walking kernel (csrc/conv11_prob_fused.hip, written without a GPU run): cost volume, depth and
     confidence against the layers in float64, two x tiles (stride 62, the first one starting at x = -1) and two y tiles."""
-    _build_and_run(tmp_path, "run_kernels3", ("conv11_prob",))
-
-
-def _has_tsan(tmp_path):
-    src = tmp_path / "t.cpp"
-    src.write_text("int main() { return 0; }\n")
-    return subprocess.run([CLANG, "-fsanitize=thread", str(src), "-o", str(tmp_path / "t")], capture_output=True).returncode == 0
+    _run(built[("run_kernels3", "plain")], ("conv11_prob",))
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 @pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "fnet_conv0", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")),
                                           ("run_kernels3", ("conv11_prob",)), ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion"))])
-def test_no_lds_race_under_thread_sanitizer(tmp_path, source, names):
+def test_no_lds_race_under_thread_sanitizer(built, source, names):
     """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
     LDS is plain memory shared by the workgroup's std::threads and the barrier is the only synchronisation between waves (the wave collectives synchronise
     one wave's 64 threads, as the hardware's lock step does), so a write and a read of the same LDS word by different waves without a barrier between them is
     reported as a data race - as are two workgroups storing to the same output element.  Checked to work: the fused tail with its slot-release barrier
     removed passes the value check and produces 64 reports."""
-    if not _has_tsan(tmp_path):
+    if not built["tsan"]:
         pytest.skip("this clang++ has no ThreadSanitizer runtime")
-    out = _build_and_run(tmp_path, source, names, extra=("-g", "-fsanitize=thread"))
+    out = _run(built[(source, "tsan")], names)
     reports = out.stderr.split("WARNING: ThreadSanitizer")[1:]
     # the one intended same-address access: prob_wgrad_kernel's staging rounds past the last item all WRITE the dummy word box[DUMMY], which nobody reads
     benign = [r for r in reports if "Write of size 4" in r and "Previous write of size 4" in r and
@@ -88,19 +126,16 @@ def test_no_lds_race_under_thread_sanitizer(tmp_path, source, names):
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 @pytest.mark.parametrize("source", ["run_kernels", "run_kernels3"])
-def test_lds_bank_profile_of_the_unmeasured_kernels(tmp_path, source):
+def test_lds_bank_profile_of_the_unmeasured_kernels(built, source):
     """tools/lds_bank_profile.py: the compiler's memory-access hooks (-fsanitize=thread, linked against tests/hipemu/lds_profile.cpp instead of the sanitizer)
     record every LDS access of the emulated run; the accesses of a wave are regrouped into wave-instructions and priced with the bank rules of
     MI355X_MICROARCH.md.  The model reproduces what the GPU's counters said about the tuned production kernels (prob_zwalk_kernel, conv_ci_sf_kernel,
     conv2d_ci_sf_kernel: conflict-free, profiles/r03_lds_bank_model.txt).  Asserted for the kernels no GPU has timed yet: the operand reads of their matrix
     phases are conflict-free, and the staging stores stay within 1.4x of their floor (a 16-byte store costs 13 cycles of register transfer anyway)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("lds_bank_profile", os.path.join(ROOT, "tools", "lds_bank_profile.py"))
-    tool = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(tool)
-    if not _has_tsan(tmp_path):   # the instrumentation pass comes with the same option
+    if not built["tsan"]:   # the instrumentation pass comes with the same option
         pytest.skip("this clang++ has no -fsanitize=thread")
-    totals = tool.per_kernel(tool.profile(source, "quick", workdir=str(tmp_path)))
+    tool = _profile_tool()
+    totals = tool.per_kernel(tool.profile(source, "quick", workdir=built["workdir"], exe=built[(source, "profile")]))
     want = {"run_kernels": ("conv0_sf_kernel", "conv0_zm_kernel", "fnet_conv0_fused_kernel", "deconv11_sf_kernel", "deconv9_sf_kernel"),
             "run_kernels3": ("conv11_prob_kernel",)}[source]
     for name in want:

@@ -47,11 +47,11 @@ def symbolize(exe, addresses):
     return result
 
 
-def profile(driver, mode="quick", workdir=None):
+def profile(driver, mode="quick", workdir=None, exe=None):
     """-> {(kernel, 'file:line', 'R'|'W', bytes): [wave-instructions, cycles, ideal, worst, cycles and ideal with the store transfer as the floor]}"""
     with tempfile.TemporaryDirectory() as tmp:
         workdir = workdir or tmp
-        exe = build(driver, workdir)
+        exe = exe or build(driver, workdir)
         report = os.path.join(workdir, driver + ".lds")
         run = subprocess.run([exe, mode], env=dict(os.environ, HIPEMU_LDS_REPORT=report), capture_output=True, text=True)
         if run.returncode != 0 or "ALL OK" not in run.stdout:
