@@ -516,11 +516,11 @@ def main():
                          "are measured and printed beside the headline")
     ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: FeatureNet's full-resolution FPN tail as one kernel (1) or as the reference's three steps (0); default: the model's")
     ap.add_argument("--experimental", default=os.environ.get("CASMVS_EXPERIMENTAL", ""),
-                    help="comma-separated opt-in kernels (written at the end of round 3, DESIGN.md section 6): CostRegNet zmarch / zmarch32 / deconv9 / "
+                    help="comma-separated opt-in kernels (written at the end of round 3, DESIGN.md section 6): CostRegNet zmarch / zmarch32 / xshift / deconv9 / "
                          "deconv11 / tail, FeatureNet fnet_conv0; named in the line's config.experimental - a line with this set is an A/B, not the headline")
     args = ap.parse_args()
     args.experimental = sorted(x for x in args.experimental.split(",") if x)
-    unknown = set(args.experimental) - {"zmarch", "zmarch32", "deconv9", "deconv11", "tail", "fnet_conv0"}
+    unknown = set(args.experimental) - {"zmarch", "zmarch32", "xshift", "deconv9", "deconv11", "tail", "fnet_conv0"}
     if unknown:
         raise SystemExit(f"--experimental: unknown {sorted(unknown)}")
     args.batch_given = args.batch is not None

@@ -65,6 +65,8 @@ SYMBOLS = {
     "casmvs_deconv11_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_conv0_zmarch_supported": (c_int, [c_int, c_int]),
     "casmvs_conv0_zmarch_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "casmvs_conv0_zmarch_forward_x_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "casmvs_conv0_splitf16_forward_x_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_debug_disturb": (c_int, [c_int, c_int, c_int, c_int, _FP, c_void_p]),
     "casmvs_conv_ci_splitf16_packed_bytes": (c_size_t, [c_int, c_int]),
     "casmvs_conv_ci_splitf16_pack": (c_int, [c_int, c_int, _FP, _FP, _FP, c_void_p]),

@@ -2299,7 +2299,7 @@ extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
 namespace {
 // conv0 .. conv11 (+ skips) into the workspace, then the `prob` head: on its own (depth == nullptr), or fused with the
 // softmax / regression / confidence that consumes it (casmvs_prob_regress_f32).
-// x_* (experimental layer set, casmvs_costreg_regress_x_f32): x_zmarch 1 = conv0 on conv0_zmarch.hip for cin 8 / 16, 2 = also cin 32; x_d9 / x_d11 = the
+// x_* (experimental layer set, casmvs_costreg_regress_x_f32): x_zmarch & 3: 1 = conv0 on conv0_zmarch.hip for cin 8 / 16, 2 = also cin 32; x_zmarch & 4: conv0's tile grid shifted by 4 voxels in x; x_d9 / x_d11 = the
 // images of casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack (conv9 / conv11 on the f16 matrix cores); x_tail 1 (with x_d11) = conv11 + skip +
 // `prob` + regression as ONE kernel (conv11_prob_fused.hip)
 int costreg_run(const char *who, const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol, const float *depth_values,
@@ -2344,16 +2344,17 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     ++li;
     rc = casmvs_conv0_splitbf16_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 0, stream);
     if (rc != CASMVS_OK) return rc;
-  } else if (conv0_arith == CASMVS_CONV0_SPLIT_F16 && x_zmarch > 0 && split_ok && casmvs_conv0_zmarch_supported(cin, w) && (cin != 32 || x_zmarch >= 2)) {
+  } else if (conv0_arith == CASMVS_CONV0_SPLIT_F16 && (x_zmarch & 3) > 0 && split_ok && casmvs_conv0_zmarch_supported(cin, w) && (cin != 32 || (x_zmarch & 3) >= 2)) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_conv0_zmarch_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, stream);   // the same arithmetic, input-stationary along z
+    rc = casmvs_conv0_zmarch_forward_x_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, (x_zmarch & 4) ? 4 : 0, stream);   // the same arithmetic, input-stationary along z
     if (rc != CASMVS_OK) return rc;
   } else if (conv0_arith == CASMVS_CONV0_SPLIT_F16 && split_ok && casmvs_conv0_splitf16_supported(cin, w)) {
     // conv0 on the f16 matrix cores, float32 operands as two scaled float16 slices (conv0_splitf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_conv0_splitf16_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 0, stream);
+    rc = (x_zmarch & 4) ? casmvs_conv0_splitf16_forward_x_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 4, stream)   // experimental: the tile grid shifted by 4 voxels
+                        : casmvs_conv0_splitf16_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 0, stream);
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV_S1, P[0], vol, nullptr, c0, B, cin, 8, D, h, w, sl, stream);               // conv0
@@ -2461,7 +2462,7 @@ extern "C" int casmvs_costreg_regress_x_f32(const float *const *packed_layers, c
   casmvs::clear_error();
   CASMVS_REQUIRE(depth_values && depth && confidence, "costreg_regress_x: null pointer");
   CASMVS_REQUIRE(!fuse_tail || deconv11_image, "costreg_regress_x: fuse_tail needs the conv11 image");
-  CASMVS_REQUIRE(conv0_zmarch >= 0 && conv0_zmarch <= 2, "costreg_regress_x: conv0_zmarch=%d (0 off, 1 cin 8 / 16, 2 also cin 32)", conv0_zmarch);
+  CASMVS_REQUIRE(conv0_zmarch >= 0 && conv0_zmarch <= 6 && (conv0_zmarch & 3) != 3, "costreg_regress_x: conv0_zmarch=%d (0 off, 1 cin 8 / 16, 2 also cin 32; + 4: shifted tile grid)", conv0_zmarch);
   return costreg_run("costreg_regress_x", packed_layers, split_layers, conv0_arith, vol, depth_values, cost, depth, confidence, index, workspace, B,
                      cin, D, h, w, slope, layer_events, stream, conv0_zmarch, deconv9_image, deconv11_image, fuse_tail);
 }

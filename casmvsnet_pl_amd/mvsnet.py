@@ -255,7 +255,8 @@ class CostRegNet(_PackedWeights, nn.Module):
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.timer_name = "costreg"
         # Kernels written without a GPU run at the end of round 3 (opt-in until their first tests have passed on the MI355X), used by `regress` with
-        # conv0_mode "splitf16": "zmarch" (conv0 input-stationary along z for cin 8 / 16; "zmarch32": also cin 32), "deconv9", "deconv11" (conv9 / conv11
+        # conv0_mode "splitf16": "zmarch" (conv0 input-stationary along z for cin 8 / 16; "zmarch32": also cin 32), "xshift" (conv0's tile grid - either kernel -
+        # shifted by 4 voxels in x: two cache lines per staged row instead of three), "deconv9", "deconv11" (conv9 / conv11
         # on the f16 matrix cores), "tail" (conv11 + skip + prob + regression as one kernel, conv11_prob_fused.hip)
         self.experimental = set()
         self._deconv_sf = None
@@ -340,10 +341,10 @@ class CostRegNet(_PackedWeights, nn.Module):
         c2, c4, c6 = self._ci_sf if self.ci_mode == "splitf16" else (None, None, None)
         zm, d9, d11 = 0, None, None
         if self.experimental and self.ci_mode == "splitf16" and self.conv0_mode == "splitf16":   # never in the all-float32 replicas (graph.py)
-            unknown = set(self.experimental) - {"zmarch", "zmarch32", "deconv9", "deconv11", "tail"}
+            unknown = set(self.experimental) - {"zmarch", "zmarch32", "xshift", "deconv9", "deconv11", "tail"}
             if unknown:
                 raise ValueError(f"CostRegNet.experimental: unknown entries {sorted(unknown)}")
-            zm = 2 if "zmarch32" in self.experimental else (1 if "zmarch" in self.experimental else 0)
+            zm = (2 if "zmarch32" in self.experimental else (1 if "zmarch" in self.experimental else 0)) + (4 if "xshift" in self.experimental else 0)
             if self._deconv_sf is None or self._deconv_sf[0] != self._packed_key:
                 s9, b9, _ = _fold_norm("CostRegNet.conv9", self.conv9[1])
                 s11, b11, _ = _fold_norm("CostRegNet.conv11", self.conv11[1])

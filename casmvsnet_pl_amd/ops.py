@@ -323,17 +323,22 @@ def conv0_splitf16_pack(weight, scale=None, shift=None):
     return packed
 
 
-def conv0_splitf16_forward(packed, x, slope=0.01, terms=0):
+def conv0_splitf16_forward(packed, x, slope=0.01, terms=0, x_offset=0):
     """conv0 on the f16 matrix cores with float32-grade arithmetic (casmvs_conv0_splitf16_forward_f32): x (B,cin,D,H,W) ->
-    (B,8,D,H,W).  terms: 0 / 3 = three partial products per product, 4 = all four."""
+    (B,8,D,H,W).  terms: 0 / 3 = three partial products per product, 4 = all four.  x_offset = 4 (opt-in, added without a GPU run): the tile
+    grid shifted by 4 voxels, two cache lines per staged row instead of three (casmvs_conv0_splitf16_forward_x_f32)."""
     x = _dev(x, "x")
     if not packed.is_cuda or packed.dtype != torch.uint8:
         raise RuntimeError("conv0_splitf16_forward: `packed` must be the uint8 image on the MI355X")
     B, cin, D, H, W = x.shape
     out = torch.empty((B, 8, D, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().casmvs_conv0_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W,
-                                                           float(slope), int(terms), _stream(x))
+        if x_offset:
+            rc = _lib.load().casmvs_conv0_splitf16_forward_x_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W,
+                                                                 float(slope), int(x_offset), _stream(x))
+        else:
+            rc = _lib.load().casmvs_conv0_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W,
+                                                               float(slope), int(terms), _stream(x))
     _lib.check(rc, "casmvs_conv0_splitf16_forward_f32")
     return out
 
@@ -402,17 +407,19 @@ def deconv11_splitf16_forward(packed, x, skip=None, slope=0.01):
     return out
 
 
-def conv0_zmarch_forward(packed, x, slope=0.01):
-    """conv0 in split-f16 arithmetic, input-stationary along z (casmvs_conv0_zmarch_forward_f32, csrc/conv0_zmarch.hip): `packed` is the
-    image of conv0_splitf16_pack, x (B,cin,D,H,W) with cin 8 / 16 -> (B,8,D,H,W).  Opt-in (added without a GPU run at the end of round 3)."""
+def conv0_zmarch_forward(packed, x, slope=0.01, x_offset=0):
+    """conv0 in split-f16 arithmetic, input-stationary along z (casmvs_conv0_zmarch_forward_x_f32, csrc/conv0_zmarch.hip): `packed` is the
+    image of conv0_splitf16_pack, x (B,cin,D,H,W) with cin 8 / 16 / 32 -> (B,8,D,H,W); x_offset 0 or 4 (patch grid shifted by 4 voxels).
+    Opt-in (added without a GPU run at the end of round 3)."""
     x = _dev(x, "x")
     if not packed.is_cuda or packed.dtype != torch.uint8:
         raise RuntimeError("conv0_zmarch_forward: `packed` must be the uint8 image on the MI355X")
     B, cin, D, H, W = x.shape
     out = torch.empty((B, 8, D, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().casmvs_conv0_zmarch_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W, float(slope), _stream(x))
-    _lib.check(rc, "casmvs_conv0_zmarch_forward_f32")
+        rc = _lib.load().casmvs_conv0_zmarch_forward_x_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W, float(slope), int(x_offset),
+                                                           _stream(x))
+    _lib.check(rc, "casmvs_conv0_zmarch_forward_x_f32")
     return out
 
 

@@ -205,6 +205,12 @@ int casmvs_conv0_splitf16_pack(int cin, const float *weight, const float *scale,
 int casmvs_conv0_splitf16_supported(int cin, int W);
 int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
                                       float slope, int terms, void *stream);
+/* EXPERIMENTAL (written without a GPU run, opt-in): the same kernel with its x tile grid starting at x_offset - 32 (x_offset = 4; 0 = the entry above).
+ * A staged row - 40 floats from x0 - 4 - then starts on a 128-byte line of the volume (W % 32 == 0) and touches two lines instead of three: on the CPU
+ * model of the request stream (tools/lds_bank_profile.py) 0.8 of the 128-byte line requests at W = 128, ~0.7 at W = 640, for one more tile column.
+ * Three-term products; results agree with the entry above to float32 rounding (the per-tile scalings cover other voxels). */
+int casmvs_conv0_splitf16_forward_x_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
+                                        float slope, int x_offset, void *stream);
 
 /* conv0 in the same split-f16 arithmetic, input-stationary along z (csrc/conv0_zmarch.hip): a workgroup owns a 16 x 32 (y, x) patch and
  * marches along z, staging every input plane once per chunk of 8 channels (per-plane power-of-two scaling) and feeding the three
@@ -216,6 +222,9 @@ int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float
 int casmvs_conv0_zmarch_supported(int cin, int W);
 int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope,
                                     void *stream);
+/* ... on the patch grid shifted by x_offset = 4 voxels (see casmvs_conv0_splitf16_forward_x_f32); x_offset = 0: the entry above. */
+int casmvs_conv0_zmarch_forward_x_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope,
+                                      int x_offset, void *stream);
 
 /* CostRegNet.conv11 = ConvTranspose3d(16 -> 8, k3 s2 p1 op1) + ABN + leaky-relu, plus the `conv0 + ...` skip (models/mvsnet.py:84-86, 101), on the
  * f16 matrix cores in the same split arithmetic (csrc/deconv11_splitf16.hip): the x parities of the output are the two halves of the MFMA rows,
@@ -252,7 +261,8 @@ int casmvs_conv11_prob_regress_f32(const void *deconv11_image, const float *prob
 
 /* The engine's two whole-network calls with the EXPERIMENTAL layer set (the kernels above that were written without a GPU run: until their first
  * tests have passed on the MI355X nothing in the package passes non-default values here).  As casmvs_costreg_regress_f32 plus: conv0_zmarch 1 = conv0
- * through casmvs_conv0_zmarch_forward_f32 for cin 8 / 16 (2: also cin 32; needs conv0_arith = CASMVS_CONV0_SPLIT_F16 and its image),
+ * through casmvs_conv0_zmarch_forward_f32 for cin 8 / 16 (2: also cin 32; needs conv0_arith = CASMVS_CONV0_SPLIT_F16 and its image; + 4: conv0's
+ * tile grid - of either kernel - shifted by 4 voxels in x, casmvs_conv0_splitf16_forward_x_f32),
  * deconv9_image / deconv11_image = device images of casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack or NULL; fuse_tail 1 (with
  * deconv11_image) = conv11 + skip + `prob` + regression through casmvs_conv11_prob_regress_f32.  As
  * casmvs_featurenet_forward_fused_f32 plus: conv0_fused_image = device image of casmvs_fnet_conv0_fused_pack or NULL. */

@@ -11,7 +11,7 @@
 #include "deconv11_splitf16.hip"
 #include "deconv9_splitf16.hip"
 
-static double conv3d_check(const char *name, int cin, int B, int D, int H, int W, bool zmarch) {
+static double conv3d_check(const char *name, int cin, int B, int D, int H, int W, bool zmarch, int xoff = 0) {
   const size_t n = (size_t)D * H * W;
   std::vector<float> x((size_t)B * cin * n), w((size_t)8 * cin * 27), sc(8), sh(8), y((size_t)B * 8 * n, NAN);
   for (auto &v : x) v = rnd() * 3.0f + 0.4f;
@@ -20,11 +20,13 @@ static double conv3d_check(const char *name, int cin, int B, int D, int H, int W
   std::vector<unsigned char> packed(casmvs_conv0_splitf16_packed_bytes(cin) + 16);
   unsigned char *pk = packed.data() + ((16 - (reinterpret_cast<size_t>(packed.data()) & 15)) & 15);
   if (casmvs_conv0_splitf16_pack(cin, w.data(), sc.data(), sh.data(), pk)) { printf("%s: pack: %s\n", name, casmvs_last_error()); return 1e9; }
-  float *xa = (float *)std::aligned_alloc(64, (x.size() * 4 + 63) & ~(size_t)63), *ya = (float *)std::aligned_alloc(64, (y.size() * 4 + 63) & ~(size_t)63);
+  float *xa = (float *)std::aligned_alloc(256, (x.size() * 4 + 255) & ~(size_t)255), *ya = (float *)std::aligned_alloc(256, (y.size() * 4 + 255) & ~(size_t)255);   // as device allocations: whole cache lines
   std::memcpy(xa, x.data(), x.size() * 4);
   std::memcpy(ya, y.data(), y.size() * 4);
-  const int rc = zmarch ? casmvs_conv0_zmarch_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, nullptr)
-                        : casmvs_conv0_splitf16_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, 0, nullptr);
+  const int rc = xoff ? (zmarch ? casmvs_conv0_zmarch_forward_x_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, xoff, nullptr)
+                                : casmvs_conv0_splitf16_forward_x_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, xoff, nullptr))
+                      : (zmarch ? casmvs_conv0_zmarch_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, nullptr)
+                                : casmvs_conv0_splitf16_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, 0, nullptr));
   if (rc) { printf("%s: %s\n", name, casmvs_last_error()); return 1e9; }
   double err = 0, range = 0;
   for (int b = 0; b < B; ++b)
@@ -164,6 +166,19 @@ int main(int argc, char **argv) {
   if (which == "conv0_compare") {   // both conv0 kernels on ONE interior-dominated problem (tools/lds_bank_profile.py: their global request streams)
     take(conv3d_check("conv0_sf", 16, 1, 8, 32, 128, false));
     take(conv3d_check("conv0_zm", 16, 1, 8, 32, 128, true));
+  }
+  if (which == "conv0_compare_x") {   // the same problem on the tile grid shifted by 4 voxels
+    take(conv3d_check("conv0_sf_x4", 16, 1, 8, 32, 128, false, 4));
+    take(conv3d_check("conv0_zm_x4", 16, 1, 8, 32, 128, true, 4));
+  }
+  // the shifted tile grids (x origin 4 - 32): a mostly empty first column, a ragged last one
+  if (all || quick || which == "conv0_x4") {
+    take(conv3d_check("conv0_sf_x4", 8, 1, 5, 9, 36, false, 4));
+    take(conv3d_check("conv0_zm_x4", 16, 1, 5, 17, 36, true, 4));
+  }
+  if (all || which == "conv0_x4") {
+    take(conv3d_check("conv0_sf_x4", 32, 1, 3, 6, 64, false, 4));
+    take(conv3d_check("conv0_zm_x4", 8, 2, 6, 20, 28, true, 4));
   }
   if (all || quick || which == "fnet_conv0") take(fnet_check(1, 20, 36));
   if (all || which == "fnet_conv0") take(fnet_check(2, 33, 44));

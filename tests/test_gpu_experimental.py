@@ -32,6 +32,9 @@ def test_conv0_zmarch_equals_the_tiled_kernel(dev, cin, shape):
     want = ops.conv0_splitf16_forward(packed, x)
     got = ops.conv0_zmarch_forward(packed, x)
     assert torch.equal(got, ops.conv0_zmarch_forward(packed, x)) and _rel(got, want) < 2e-6
+    # both kernels on the tile grid shifted by 4 voxels in x (a mostly empty first tile column, other per-tile scalings)
+    for shifted in (ops.conv0_splitf16_forward(packed, x, x_offset=4), ops.conv0_zmarch_forward(packed, x, x_offset=4)):
+        assert bool(torch.isfinite(shifted).all()) and _rel(shifted, want) < 2e-6
 
 
 @pytest.mark.parametrize("which,shape", [("deconv11", (2, 4, 12, 20)), ("deconv11", (1, 3, 5, 34)), ("deconv9", (2, 3, 6, 10)), ("deconv9", (1, 2, 5, 18))])
@@ -65,7 +68,7 @@ def test_fnet_conv0_fused_equals_the_two_layers(dev, shape):
 
 
 @pytest.mark.parametrize("exp_cost,exp_feat", [({"zmarch"}, set()), ({"deconv9", "deconv11"}, set()), ({"tail"}, set()), (set(), {"conv0_fused"}),
-                                               ({"zmarch32", "deconv9", "tail"}, {"conv0_fused"})])
+                                               ({"xshift"}, set()), ({"zmarch32", "xshift", "deconv9", "tail"}, {"conv0_fused"})])
 def test_whole_forward_with_experimental_layers_equals_the_default(dev, exp_cost, exp_feat):
     from casmvsnet_pl_amd import ABN, CascadeMVSNet
     from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict

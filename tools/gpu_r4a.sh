@@ -23,7 +23,7 @@ PASSED=""
   ALL=""
   for x in $PASSED; do
     echo "== --experimental $x"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $x | tail -4
-    [ $x = zmarch ] && { echo "== --experimental zmarch32"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental zmarch32 | tail -4; }
+    [ $x = zmarch ] && for y in zmarch32 xshift zmarch,xshift; do echo "== --experimental $y"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $y | tail -4; done   # conv0_zm_check covers the shifted grids too
     ALL="$ALL,$x"
   done
   ALL=${ALL#,}

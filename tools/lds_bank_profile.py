@@ -127,7 +127,7 @@ def main():
                 if "--lines" in sys.argv:
                     for (k, where, r, nbytes), (n2, lanes2, nb2, a64, a128) in GLOBAL_TABLE.items():
                         if k == kernel and r == rw:
-                            print(f"        {where:32s} {r}{nbytes:<3d} n={n2:7d}  {lanes2 / n2:5.1f} lanes, {a64 / n2:5.2f} 64-byte lines per instruction, {nb2 / (64 * a64):.2f} used")
+                            print(f"        {where:32s} {r}{nbytes:<3d} n={n2:7d}  {lanes2 / n2:5.1f} lanes, {a64 / n2:5.2f} 64-byte / {a128 / n2:5.2f} 128-byte lines per instruction, {nb2 / (64 * a64):.2f} / {nb2 / (128 * a128):.2f} used")
         for rw, name in (("R", "reads "), ("W", "writes")):
             n, cyc, ideal, eff, eff_ideal = t[rw]
             if n:

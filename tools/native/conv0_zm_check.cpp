@@ -1,7 +1,8 @@
 // First test of casmvs_conv0_zmarch_forward_f32 (csrc/conv0_zmarch.hip, written without a GPU run at the end of round 3), torch-free:
 // against casmvs_conv0_splitf16_forward_f32 (same packed image) on ragged small shapes with a float64 convolution on the host beside both,
 // twice for run-to-run bit stability, and on the cascade levels' shapes (cin 16: 32 x 256 x 320, cin 8: 8 x 512 x 640) with the time of
-// each kernel under dirtied caches.   conv0_zm_check [batch]
+// each kernel under dirtied caches; and the same for both kernels on the tile grid shifted by 4 voxels in x (casmvs_conv0_splitf16_forward_x_f32 /
+// casmvs_conv0_zmarch_forward_x_f32: two cache lines per staged row instead of three).   conv0_zm_check [batch]
 //   hipcc -O2 tools/native/conv0_zm_check.cpp -Iinclude -Lcasmvsnet_pl_amd -lcasmvs_hip -Wl,-rpath,'$ORIGIN/../../../casmvsnet_pl_amd' -o tools/probes/bin/conv0_zm_check
 #include <hip/hip_runtime.h>
 
@@ -42,18 +43,23 @@ int main(int argc, char **argv) {
     const size_t pb = casmvs_conv0_splitf16_packed_bytes(s.cin);
     std::vector<unsigned char> packed(pb);
     if (casmvs_conv0_splitf16_pack(s.cin, w.data(), scale.data(), shift.data(), packed.data())) { printf("pack: %s\n", casmvs_last_error()); return 3; }
-    float *dx, *dy[2];
+    constexpr int K = 4;   // 0 tiled, 1 z-march, 2 tiled on the shifted grid, 3 z-march on the shifted grid
+    const char *names[K] = {"tiled", "z-march", "tiled x+4", "z-march x+4"};
+    float *dx, *dy[K];
     void *dp;
-    hipMalloc(&dx, nin * 4); hipMalloc(&dp, pb); hipMalloc(&dy[0], nout * 4); hipMalloc(&dy[1], nout * 4);
+    hipMalloc(&dx, nin * 4); hipMalloc(&dp, pb);
+    for (int k = 0; k < K; ++k) hipMalloc(&dy[k], nout * 4);
     hipMemcpy(dx, x.data(), nin * 4, hipMemcpyHostToDevice);
     hipMemcpy(dp, packed.data(), pb, hipMemcpyHostToDevice);
     auto run = [&](int k) {
-      return k ? casmvs_conv0_zmarch_forward_f32(dp, dx, dy[1], s.B, s.cin, s.D, s.H, s.W, 0.01f, st)
-               : casmvs_conv0_splitf16_forward_f32(dp, dx, dy[0], s.B, s.cin, s.D, s.H, s.W, 0.01f, 0, st);
+      if (k == 0) return casmvs_conv0_splitf16_forward_f32(dp, dx, dy[0], s.B, s.cin, s.D, s.H, s.W, 0.01f, 0, st);
+      if (k == 1) return casmvs_conv0_zmarch_forward_f32(dp, dx, dy[1], s.B, s.cin, s.D, s.H, s.W, 0.01f, st);
+      if (k == 2) return casmvs_conv0_splitf16_forward_x_f32(dp, dx, dy[2], s.B, s.cin, s.D, s.H, s.W, 0.01f, 4, st);
+      return casmvs_conv0_zmarch_forward_x_f32(dp, dx, dy[3], s.B, s.cin, s.D, s.H, s.W, 0.01f, 4, st);
     };
-    std::vector<float> y[2], again(nout);
-    double us[2] = {0, 0};
-    for (int k = 0; k < 2; ++k) {
+    std::vector<float> y[K], again(nout);
+    double us[K] = {0, 0, 0, 0};
+    for (int k = 0; k < K; ++k) {
       hipMemset(dy[k], 0xff, nout * 4);
       if (run(k)) { printf("forward %d: %s\n", k, casmvs_last_error()); return 3; }
       if (hipStreamSynchronize(st) != hipSuccess) { printf("kernel %d failed: %s\n", k, hipGetErrorString(hipGetLastError())); return 4; }
@@ -73,20 +79,26 @@ int main(int argc, char **argv) {
       }
       us[k] = total * 1e3 / reps;
     }
-    hipMemcpy(again.data(), dy[1], nout * 4, hipMemcpyDeviceToHost);
-    const bool stable = memcmp(again.data(), y[1].data(), nout * 4) == 0;
+    bool stable = true;   // the timed repetitions wrote the same bits as the first run
+    for (int k = 1; k < K; ++k) {
+      hipMemcpy(again.data(), dy[k], nout * 4, hipMemcpyDeviceToHost);
+      stable = stable && memcmp(again.data(), y[k].data(), nout * 4) == 0;
+    }
     double range = 0, diff = 0;
     size_t nan = 0;
-    for (size_t i = 0; i < nout; ++i) {
-      range = std::fmax(range, std::fabs((double)y[0][i]));
-      if (!std::isfinite(y[1][i])) ++nan;
-      diff = std::fmax(diff, std::fabs((double)y[0][i] - y[1][i]));
-    }
-    printf("B=%d cin=%d %dx%dx%d: tiled %.1f us, z-march %.1f us (x%.3f); max |diff| / range = %.2e, non-finite %zu, repeat run %s", s.B, s.cin, s.D, s.H, s.W,
-           us[0], us[1], us[0] / us[1], diff / range, nan, stable ? "equal" : "DIFFERENT");
+    for (size_t i = 0; i < nout; ++i) range = std::fmax(range, std::fabs((double)y[0][i]));
+    for (int k = 1; k < K; ++k)
+      for (size_t i = 0; i < nout; ++i) {
+        if (!std::isfinite(y[k][i])) ++nan;
+        diff = std::fmax(diff, std::fabs((double)y[0][i] - y[k][i]));
+      }
+    printf("B=%d cin=%d %dx%dx%d:", s.B, s.cin, s.D, s.H, s.W);
+    for (int k = 0; k < K; ++k) printf(" %s %.1f us%s", names[k], us[k], k + 1 < K ? "," : "");
+    printf(" (x%.3f / x%.3f / x%.3f); max |diff| / range = %.2e, non-finite %zu, repeat runs %s", us[0] / us[1], us[0] / us[2], us[0] / us[3], diff / range, nan,
+           stable ? "equal" : "DIFFERENT");
     bool ok = nan == 0 && stable && diff / range < 2e-6;
     if (s.host) {
-      double err[2] = {0, 0};
+      double err[K] = {0, 0, 0, 0};
       for (int b = 0; b < s.B; ++b)
         for (int co = 0; co < 8; ++co)
           for (int z = 0; z < s.D; ++z)
@@ -104,14 +116,15 @@ int main(int argc, char **argv) {
                 double v = acc * scale[co] + shift[co];
                 v = v > 0 ? v : v * 0.01f;
                 const size_t o = ((size_t)b * 8 + co) * n + ((size_t)z * s.H + yy) * s.W + xx;
-                for (int k = 0; k < 2; ++k) err[k] = std::fmax(err[k], std::fabs(v - y[k][o]));
+                for (int k = 0; k < K; ++k) err[k] = std::fmax(err[k], std::fabs(v - y[k][o]));
               }
-      printf("; vs float64: tiled %.2e  z-march %.2e of the range", err[0] / range, err[1] / range);
-      ok = ok && err[1] / range < 2e-6;
+      printf("; vs float64: %.2e / %.2e / %.2e / %.2e of the range", err[0] / range, err[1] / range, err[2] / range, err[3] / range);
+      for (int k = 1; k < K; ++k) ok = ok && err[k] / range < 2e-6;
     }
     printf("  %s\n", ok ? "ok" : "FAILED");
     all_ok &= ok;
-    hipFree(dx); hipFree(dp); hipFree(dy[0]); hipFree(dy[1]);
+    hipFree(dx); hipFree(dp);
+    for (int k = 0; k < K; ++k) hipFree(dy[k]);
   }
   printf(all_ok ? "ALL OK\n" : "FAILURES\n");
   return all_ok ? 0 : 1;

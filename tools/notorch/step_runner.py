@@ -24,7 +24,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=(512, 640))
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--all-f32", action="store_true", help="every layer on the float32 MFMA kernels (conv0_mode / ci_mode / tail_mode = f32)")
-ap.add_argument("--experimental", default="", help="comma list of the kernels written without a GPU run: zmarch | zmarch32, deconv9, deconv11, fnet_conv0, tail")
+ap.add_argument("--experimental", default="", help="comma list of the kernels written without a GPU run: zmarch | zmarch32, xshift, deconv9, deconv11, fnet_conv0, tail")
 args = ap.parse_args()
 if args.lib:
     os.environ["CASMVS_LIB_PATH"] = os.path.abspath(args.lib)
@@ -132,9 +132,9 @@ for l in range(3):
 
 # ---- the experimental layer set (casmvs_*_x_f32): images of the kernels written without a GPU run ----------------------------------
 EXP = set(filter(None, args.experimental.split(",")))
-assert EXP <= {"zmarch", "zmarch32", "deconv9", "deconv11", "fnet_conv0", "tail"}, EXP
+assert EXP <= {"zmarch", "zmarch32", "xshift", "deconv9", "deconv11", "fnet_conv0", "tail"}, EXP
 assert not (EXP and args.all_f32), "the experimental kernels belong to the split-f16 layer set"
-ZM = 2 if "zmarch32" in EXP else (1 if "zmarch" in EXP else 0)
+ZM = (2 if "zmarch32" in EXP else (1 if "zmarch" in EXP else 0)) + (4 if "xshift" in EXP else 0)   # + 4: conv0's tile grid shifted by 4 voxels
 fnet_conv0_img = None
 if "fnet_conv0" in EXP:
     (w00, s00, b00), (w01, s01, b01) = fw["conv0.0"], fw["conv0.1"]
