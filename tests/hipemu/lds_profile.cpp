@@ -55,6 +55,7 @@ int g_nthreads = 0;
 std::vector<std::vector<Rec>> g_recs;
 std::map<std::tuple<uintptr_t, int, int>, SiteStat> g_stats;   // (site, write, bytes)
 std::map<std::tuple<uintptr_t, int, int>, GlobalStat> g_global;
+uint64_t g_epoch_lines[2][2] = {{0, 0}, {0, 0}};   // [write][64- / 128-byte]: distinct lines per (workgroup, barrier epoch), summed: reuse inside an epoch as L1 hits
 thread_local int t_tid = -1, t_bufop = 0;
 thread_local uint32_t t_epoch = 0;
 thread_local std::unordered_map<uintptr_t, uint32_t> *t_occ = nullptr;
@@ -141,6 +142,8 @@ struct Reporter {
                    std::get<2>(kv.first), (unsigned long long)kv.second.n, (unsigned long long)kv.second.cycles, (unsigned long long)kv.second.ideal,
                    (unsigned long long)kv.second.worst, (unsigned long long)kv.second.lanes, (unsigned long long)kv.second.eff,
                    (unsigned long long)kv.second.eff_ideal);
+    std::fprintf(f, "GLBSUM R epoch_lines64=%llu epoch_lines128=%llu\nGLBSUM W epoch_lines64=%llu epoch_lines128=%llu\n", (unsigned long long)g_epoch_lines[0][0],
+                 (unsigned long long)g_epoch_lines[0][1], (unsigned long long)g_epoch_lines[1][0], (unsigned long long)g_epoch_lines[1][1]);
     for (const auto &kv : g_global)
       std::fprintf(f, "GLB 0x%zx %c %d n=%llu lanes=%llu bytes=%llu lines64=%llu lines128=%llu\n", (size_t)std::get<0>(kv.first), std::get<1>(kv.first) ? 'W' : 'R',
                    std::get<2>(kv.first), (unsigned long long)kv.second.n, (unsigned long long)kv.second.lanes, (unsigned long long)kv.second.bytes,
@@ -186,8 +189,22 @@ void hipemu_prof_block_end(void) {
     uint64_t off;
   };
   std::vector<Item> all;
+  std::vector<std::tuple<uint32_t, uint64_t>> epoch_lines[2][2];
   for (int t = 0; t < g_nthreads; ++t)
-    for (const Rec &r : g_recs[t]) all.push_back(Item{(uint32_t)t >> 6, r.epoch, r.occ, r.site, r.bytes, r.write, (uint8_t)(t & 63), r.global, r.addr});
+    for (const Rec &r : g_recs[t]) {
+      all.push_back(Item{(uint32_t)t >> 6, r.epoch, r.occ, r.site, r.bytes, r.write, (uint8_t)(t & 63), r.global, r.addr});
+      if (r.global)
+        for (uint64_t b = r.addr; b < r.addr + r.bytes; b += 4) {
+          epoch_lines[r.write][0].emplace_back(r.epoch, b >> 6);
+          epoch_lines[r.write][1].emplace_back(r.epoch, b >> 7);
+        }
+    }
+  for (int w = 0; w < 2; ++w)
+    for (int k = 0; k < 2; ++k) {
+      auto &v = epoch_lines[w][k];
+      std::sort(v.begin(), v.end());
+      g_epoch_lines[w][k] += (uint64_t)(std::unique(v.begin(), v.end()) - v.begin());
+    }
   auto key = [](const Item &i) { return std::make_tuple(i.wave, i.epoch, i.site, i.occ, i.write, i.bytes, i.global); };
   std::sort(all.begin(), all.end(), [&](const Item &a, const Item &b) { return key(a) < key(b); });
   for (size_t i = 0; i < all.size();) {

@@ -60,9 +60,9 @@ static double fnet_check(int N, int H, int W) {
   for (auto &v : w0) v = rnd() * 0.3f;
   for (auto &v : w1) v = rnd() * 0.2f;
   for (int c = 0; c < 8; ++c) { s0[c] = 0.6f + 0.1f * c; b0[c] = 0.05f * (c - 3); s1[c] = 1.2f - 0.07f * c; b1[c] = 0.03f * (4 - c); }
-  unsigned char *pk = (unsigned char *)std::aligned_alloc(64, (casmvs_fnet_conv0_fused_packed_bytes() + 63) & ~(size_t)63);
+  unsigned char *pk = (unsigned char *)std::aligned_alloc(256, (casmvs_fnet_conv0_fused_packed_bytes() + 255) & ~(size_t)255);
   casmvs_fnet_conv0_fused_pack(w0.data(), s0.data(), b0.data(), w1.data(), s1.data(), b1.data(), pk);
-  float *xa = (float *)std::aligned_alloc(64, (x.size() * 4 + 63) & ~(size_t)63), *ya = (float *)std::aligned_alloc(64, ((size_t)N * 8 * hw * 4 + 63) & ~(size_t)63);
+  float *xa = (float *)std::aligned_alloc(256, (x.size() * 4 + 255) & ~(size_t)255), *ya = (float *)std::aligned_alloc(256, ((size_t)N * 8 * hw * 4 + 255) & ~(size_t)255);
   std::memcpy(xa, x.data(), x.size() * 4);
   for (size_t i = 0; i < (size_t)N * 8 * hw; ++i) ya[i] = NAN;
   if (casmvs_fnet_conv0_fused_f32(pk, xa, ya, N, H, W, 0.01f, nullptr)) { printf("fnet_conv0: %s\n", casmvs_last_error()); return 1e9; }
@@ -106,13 +106,13 @@ static double deconv_check(int cin, int cout, int B, int Di, int Hi, int Wi) {
   for (auto &v : sk) v = rnd();
   for (int c = 0; c < cout; ++c) { sc[c] = 0.5f + 0.05f * c; sh[c] = 0.03f * (c - 4); }
   const size_t pb = cout == 8 ? casmvs_deconv11_splitf16_packed_bytes() : casmvs_deconv9_splitf16_packed_bytes();
-  unsigned char *pk = (unsigned char *)std::aligned_alloc(64, (pb + 63) & ~(size_t)63);
+  unsigned char *pk = (unsigned char *)std::aligned_alloc(256, (pb + 255) & ~(size_t)255);
   if (cout == 8 ? casmvs_deconv11_splitf16_pack(w.data(), sc.data(), sh.data(), pk) : casmvs_deconv9_splitf16_pack(w.data(), sc.data(), sh.data(), pk)) {
     printf("deconv pack: %s\n", casmvs_last_error());
     return 1e9;
   }
-  float *xa = (float *)std::aligned_alloc(64, (x.size() * 4 + 63) & ~(size_t)63), *ska = (float *)std::aligned_alloc(64, (sk.size() * 4 + 63) & ~(size_t)63),
-        *ya = (float *)std::aligned_alloc(64, (sk.size() * 4 + 63) & ~(size_t)63);
+  float *xa = (float *)std::aligned_alloc(256, (x.size() * 4 + 255) & ~(size_t)255), *ska = (float *)std::aligned_alloc(256, (sk.size() * 4 + 255) & ~(size_t)255),
+        *ya = (float *)std::aligned_alloc(256, (sk.size() * 4 + 255) & ~(size_t)255);
   std::memcpy(xa, x.data(), x.size() * 4);
   std::memcpy(ska, sk.data(), sk.size() * 4);
   for (size_t i = 0; i < sk.size(); ++i) ya[i] = NAN;
@@ -170,6 +170,11 @@ int main(int argc, char **argv) {
   if (which == "conv0_compare_x") {   // the same problem on the tile grid shifted by 4 voxels
     take(conv3d_check("conv0_sf_x4", 16, 1, 8, 32, 128, false, 4));
     take(conv3d_check("conv0_zm_x4", 16, 1, 8, 32, 128, true, 4));
+  }
+  if (which == "streams") {   // interior-dominated problems with cache-line-aligned rows: the request streams of the other unmeasured kernels (tools/lds_bank_profile.py)
+    take(fnet_check(1, 32, 128));
+    take(deconv_check(16, 8, 1, 4, 8, 64));
+    take(deconv_check(32, 16, 1, 2, 8, 64));
   }
   // the shifted tile grids (x origin 4 - 32): a mostly empty first column, a ragged last one
   if (all || quick || which == "conv0_x4") {

@@ -35,7 +35,7 @@ static double fused_check(int B, int D, int H, int W, int zchunk) {
   for (int b = 0; b < B; ++b)
     for (int z = 0; z < D; ++z)
       for (size_t p = 0; p < (size_t)H * W; ++p) dv[((size_t)b * D + z) * H * W + p] = 425.0f + 2.5f * z + 0.01f * (float)(p % 7);
-  unsigned char *dpk = (unsigned char *)std::aligned_alloc(64, (casmvs_deconv11_splitf16_packed_bytes() + 63) & ~(size_t)63);
+  unsigned char *dpk = (unsigned char *)std::aligned_alloc(256, (casmvs_deconv11_splitf16_packed_bytes() + 255) & ~(size_t)255);
   casmvs_deconv11_splitf16_pack(w11.data(), sc.data(), sh.data(), dpk);
   // `prob` image as casmvs_conv3d_pack_f32(CASMVS_CONV_S1, 8, 1) writes it (conv3d_mfma.hip: P1 format): [pair][2 tap + channel & 1] (64 floats), scale[4] | shift[4], 64 zeros
   std::vector<float> ppk(4 * 64 + 8 + 64, 0.0f);
@@ -44,7 +44,7 @@ static double fused_check(int B, int D, int H, int W, int zchunk) {
   ppk[256] = 1.0f;
   ppk[260] = bias;
   auto dup = [](const std::vector<float> &v) {
-    float *p = (float *)std::aligned_alloc(64, (v.size() * 4 + 63) & ~(size_t)63);
+    float *p = (float *)std::aligned_alloc(256, (v.size() * 4 + 255) & ~(size_t)255);
     std::memcpy(p, v.data(), v.size() * 4);
     return p;
   };
@@ -127,6 +127,7 @@ int main(int argc, char **argv) {
   auto take = [&](double e) { worst = std::fmax(worst, e); };
   const bool all = which == "all", quick = which == "quick";
   if (all || quick) take(fused_check(1, 8, 10, 68, 8));      // one chunk: regression fused; two tiles in x (62 + 6), two in y
+  if (which == "streams") take(fused_check(1, 8, 16, 124, 8));   // two full x tiles (62 + 62): the request stream of an interior-dominated problem
   if (all) {
     take(fused_check(1, 8, 10, 68, 4));                      // chunks of 4 planes: halo planes at the chunk ends, separate regression
     take(fused_check(2, 6, 18, 124, 6));                     // generic-depth fused path, exact multiple of the x tile stride

@@ -62,6 +62,9 @@ def profile(driver, mode="quick", workdir=None, exe=None):
             if m:
                 rows.append((int(m.group(1), 16), m.group(2), *(int(m.group(i)) for i in range(3, 10))))
         glb = []
+        global EPOCH_LINES
+        EPOCH_LINES = {m.group(1): (int(m.group(2)), int(m.group(3))) for m in (re.match(r"GLBSUM ([RW]) epoch_lines64=(\d+) epoch_lines128=(\d+)", ln)
+                                                                                 for ln in open(report)) if m}
         for line in open(report):
             m = re.match(r"GLB 0x([0-9a-f]+) ([RW]) (\d+) n=(\d+) lanes=(\d+) bytes=(\d+) lines64=(\d+) lines128=(\d+)", line)
             if m:
@@ -87,6 +90,7 @@ def profile(driver, mode="quick", workdir=None, exe=None):
     return table
 
 
+EPOCH_LINES = {}   # of the last profile(): {'R'|'W': (distinct 64-byte lines, distinct 128-byte lines) per (workgroup, barrier epoch), summed over the run}
 GLOBAL_TABLE = collections.OrderedDict()   # of the last profile(): {(kernel, 'file:line', 'R'|'W', bytes): [wave-instructions, lanes, bytes, 64-byte lines, 128-byte lines]}
 
 
@@ -115,6 +119,9 @@ def main():
     table = profile(driver, mode)
     print(f"LDS bank profile of tests/hipemu/{driver}.cpp ({mode}): wave-instructions, LDS-array cycles vs conflict-free cycles (1.00 = no bank conflict)")
     gtot = global_per_kernel()
+    if EPOCH_LINES:
+        print("whole run, distinct lines per (workgroup, barrier epoch) - re-use inside an epoch counted once, as an L1 would: loads %d x 64 B / %d x 128 B, stores %d / %d"
+              % (*EPOCH_LINES.get("R", (0, 0)), *EPOCH_LINES.get("W", (0, 0))))
     ltot = per_kernel(table)
     for kernel in list(ltot) + [k for k in gtot if k not in ltot]:
         t = ltot.get(kernel, {"R": [0] * 5, "W": [0] * 5})
