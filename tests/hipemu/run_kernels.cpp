@@ -177,7 +177,7 @@ int main(int argc, char **argv) {
     take(deconv_check(32, 16, 1, 2, 8, 64));
   }
   // the shifted tile grids (x origin 4 - 32): a mostly empty first column, a ragged last one
-  if (all || quick || which == "conv0_x4") {
+  if (all || which == "conv0_x4_quick" || which == "conv0_x4") {
     take(conv3d_check("conv0_sf_x4", 8, 1, 5, 9, 36, false, 4));
     take(conv3d_check("conv0_zm_x4", 16, 1, 5, 17, 36, true, 4));
   }

@@ -64,9 +64,9 @@ def built(tmp_path_factory):
     return {"workdir": workdir, "tsan": tsan, **{k: f.result() for k, f in jobs.items()}}
 
 
-def _run(exe, names):
+def _run(exe, names, mode="quick"):
     env = dict(os.environ, TSAN_OPTIONS="exitcode=0")   # the sanitizer test judges the reports itself
-    out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=1800, env=env)
+    out = subprocess.run([exe, mode], capture_output=True, text=True, timeout=1800, env=env)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
     for name in names:
         assert name in out.stdout
@@ -76,6 +76,13 @@ def _run(exe, names):
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_kernels_run_on_the_cpu_against_float64(built):
     _run(built[("run_kernels", "plain")], ("conv0_sf", "conv0_zm", "fnet_conv0", "deconv11", "deconv9"))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_conv0_kernels_on_the_shifted_tile_grid(built):
+    """casmvs_conv0_splitf16_forward_x_f32 / casmvs_conv0_zmarch_forward_x_f32 (x_offset = 4: the tile grid starts at x = -28, a mostly empty first column and
+    a ragged last one) against float64."""
+    _run(built[("run_kernels", "plain")], ("conv0_sf_x4", "conv0_zm_x4"), mode="conv0_x4_quick")
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
