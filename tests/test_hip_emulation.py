@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = os.environ.get("HIPEMU_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
 
 
-DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5")
+DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6")
 PROFILED = ("run_kernels", "run_kernels3")
 
 
@@ -106,6 +106,13 @@ def test_prob_weight_gradient_and_fusion_kernels_run_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_production_fpn_tail_runs_on_the_cpu(built):
+    """fpn_tail0_sf_kernel (FeatureNet's full-resolution tail on the f16 matrix cores, the bilinear interpolation inside its staging; 0.45 ms of the step)
+    against lat0 / upsample-add / smooth0 in float64 at the GPU test's bound, both output layouts."""
+    _run(built[("run_kernels6", "plain")], ("fpn_tail0",))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_fused_costreg_tail_runs_on_the_cpu(built):
     """conv11 + skip + `prob` + softmax regression as one depth-walking kernel (csrc/conv11_prob_fused.hip, written without a GPU run): cost volume, depth and
     confidence against the layers in float64, two x tiles (stride 62, the first one starting at x = -1) and two y tiles."""
@@ -114,7 +121,7 @@ def test_fused_costreg_tail_runs_on_the_cpu(built):
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 @pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "fnet_conv0", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")),
-                                          ("run_kernels3", ("conv11_prob",)), ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion"))])
+                                          ("run_kernels3", ("conv11_prob",)), ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion")), ("run_kernels6", ("fpn_tail0",))])
 def test_no_lds_race_under_thread_sanitizer(built, source, names):
     """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
     LDS is plain memory shared by the workgroup's std::threads and the barrier is the only synchronisation between waves (the wave collectives synchronise
