@@ -160,3 +160,7 @@ def test_lds_bank_profile_of_the_unmeasured_kernels(built, source):
             assert n > 0 and cyc <= (1.2 if name == "fnet_conv0_fused_kernel" else 1.0) * ideal, (k, "reads", cyc, ideal)   # fnet: the vector-ALU phase's 6-float rows
             n, _, _, eff, eff_ideal = totals[k]["W"]
             assert n > 0 and eff <= 1.4 * eff_ideal, (k, "writes", eff, eff_ideal)
+    if source == "run_kernels":   # the model against the hardware: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of conv0_sf_kernel<8, 3> on the MI355X = 0.184
+        t = totals[next(k for k in totals if k.startswith("conv0_sf_kernel<8"))]   # (profiles/r03_pmc_conv0_split_kernels.txt)
+        cycles, ideal = t["R"][1] + t["W"][1], t["R"][2] + t["W"][2]
+        assert 0.17 < (cycles - ideal) / cycles < 0.20, (cycles, ideal)
