@@ -13,9 +13,9 @@ static double conv_ci_check(int c, int B, int D, int H, int W) {
   for (auto &v : w) v = rnd() * 0.15f;
   for (int i = 0; i < c; ++i) { sc[i] = 0.5f + 0.02f * i; sh[i] = 0.01f * (i - 4); }
   const size_t pb = casmvs_conv_ci_splitf16_packed_bytes(c, c);
-  unsigned char *pk = (unsigned char *)std::aligned_alloc(64, (pb + 63) & ~(size_t)63);
+  unsigned char *pk = (unsigned char *)std::aligned_alloc(256, (pb + 255) & ~(size_t)255);
   if (casmvs_conv_ci_splitf16_pack(c, c, w.data(), sc.data(), sh.data(), pk)) { printf("conv_ci pack: %s\n", casmvs_last_error()); return 1e9; }
-  float *xa = (float *)std::aligned_alloc(64, (x.size() * 4 + 63) & ~(size_t)63), *ya = (float *)std::aligned_alloc(64, (x.size() * 4 + 63) & ~(size_t)63);
+  float *xa = (float *)std::aligned_alloc(256, (x.size() * 4 + 63) & ~(size_t)63), *ya = (float *)std::aligned_alloc(256, (x.size() * 4 + 255) & ~(size_t)255);
   std::memcpy(xa, x.data(), x.size() * 4);
   for (size_t i = 0; i < x.size(); ++i) ya[i] = NAN;
   if (casmvs_conv_ci_splitf16_forward_f32(pk, xa, ya, B, c, c, D, H, W, 0.01f, nullptr)) { printf("conv_ci: %s\n", casmvs_last_error()); return 1e9; }
@@ -51,11 +51,11 @@ static double conv2d_ci_check(int cin, int cout, int N, int H, int W) {
   for (auto &v : w) v = rnd() * 0.15f;
   for (int i = 0; i < cout; ++i) { sc[i] = 0.5f + 0.02f * i; sh[i] = 0.01f * (i - 4); }
   const size_t pb = casmvs_conv2d_ci_splitf16_packed_bytes(cin, cout);
-  unsigned char *pk = (unsigned char *)std::aligned_alloc(64, (pb + 63) & ~(size_t)63);
+  unsigned char *pk = (unsigned char *)std::aligned_alloc(256, (pb + 255) & ~(size_t)255);
   if (casmvs_conv2d_ci_splitf16_pack(cin, cout, w.data(), sc.data(), sh.data(), pk)) { printf("conv2d_ci pack: %s\n", casmvs_last_error()); return 1e9; }
   const size_t no = (size_t)N * cout * hw;
-  float *xa = (float *)std::aligned_alloc(64, (x.size() * 4 + 63) & ~(size_t)63), *ya = (float *)std::aligned_alloc(64, (no * 4 + 63) & ~(size_t)63),
-        *yb = (float *)std::aligned_alloc(64, (no * 4 + 63) & ~(size_t)63);
+  float *xa = (float *)std::aligned_alloc(256, (x.size() * 4 + 63) & ~(size_t)63), *ya = (float *)std::aligned_alloc(256, (no * 4 + 255) & ~(size_t)255),
+        *yb = (float *)std::aligned_alloc(256, (no * 4 + 255) & ~(size_t)255);
   std::memcpy(xa, x.data(), x.size() * 4);
   for (size_t i = 0; i < no; ++i) ya[i] = yb[i] = NAN;
   if (casmvs_conv2d_ci_splitf16_forward_f32(pk, xa, ya, yb, N, cin, cout, H, W, 0.01f, nullptr)) { printf("conv2d_ci: %s\n", casmvs_last_error()); return 1e9; }
@@ -90,6 +90,10 @@ int main(int argc, char **argv) {
   const bool all = which == "all", quick = which == "quick";
   if (all || quick || which == "conv_ci") take(conv_ci_check(16, 1, 5, 6, 18));
   if (all || which == "conv_ci") { take(conv_ci_check(32, 1, 2, 9, 16)); take(conv_ci_check(16, 2, 4, 4, 34)); }
+  if (which == "streams") {   // interior-dominated problems with cache-line-aligned rows (tools/lds_bank_profile.py: request streams)
+    take(conv_ci_check(16, 1, 8, 16, 64));
+    take(conv2d_ci_check(16, 16, 1, 32, 128));
+  }
   if (all || quick || which == "conv2d_ci") take(conv2d_ci_check(32, 16, 1, 18, 20));
   if (all || which == "conv2d_ci") { take(conv2d_ci_check(16, 16, 2, 17, 34)); take(conv2d_ci_check(32, 32, 1, 16, 18)); }
   printf(worst < 2e-6 ? "ALL OK (worst %.2e)\n" : "FAILED (worst %.2e)\n", worst);

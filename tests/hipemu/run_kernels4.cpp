@@ -41,7 +41,7 @@ static double prob_check(int B, int D, int H, int W, int zchunk) {
   ppk[256] = 1.0f;
   ppk[260] = bias;
   auto dup = [](const std::vector<float> &v) {
-    float *p = (float *)std::aligned_alloc(64, (v.size() * 4 + 63) & ~(size_t)63);
+    float *p = (float *)std::aligned_alloc(256, (v.size() * 4 + 255) & ~(size_t)255);
     std::memcpy(p, v.data(), v.size() * 4);
     return p;
   };
@@ -108,6 +108,7 @@ int main(int argc, char **argv) {
   const bool all = which == "all", quick = which == "quick";
   if (all || quick) take(prob_check(1, 8, 10, 68, 8));       // one chunk: regression fused (DT = 8); two tiles in x (64 + 4), two in y
   if (all || quick) take(prob_check(1, 8, 10, 68, 4));       // chunks of 4 planes: halo planes at the chunk ends, separate regression
+  if (which == "streams") take(prob_check(1, 8, 16, 128, 8));
   if (all) {
     take(prob_check(2, 6, 9, 132, 0));                       // generic-depth fused path, three x tiles, automatic chunking
     take(prob_check(1, 16, 8, 64, 0));
