@@ -2,7 +2,7 @@
 # First gpurun call of round 4: everything added at the end of round 3 WITHOUT a GPU (the budget was spent) gets its
 # measurement here - the parity suite on the re-linked library, the paired-tap fusion kernel against the one-tap-per-load
 # kernel (bit equality + time), files -> depth maps with the native PNG decoder / one intra-op thread / stager thread, the
-# headline bench line.     /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_r4a.sh'
+# headline bench line.     /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/gpu_r4a.sh'
 TAG=${1:-r4a}
 ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTDIR/gpurun_out/$TAG
@@ -29,15 +29,14 @@ PASSED=""
   ALL=${ALL#,}
   echo "$PASSED" | grep -qw tail && ALL=$(echo "$ALL" | sed 's/deconv11,//; s/,deconv11$//; s/^deconv11$//')
   [ -n "$ALL" ] && { echo "== --experimental $ALL"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $ALL | tail -4; }; } > $OUT/native.txt 2>&1
-nproc > $OUT/host.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host.txt 2>/dev/null; lscpu | grep -E "Model name|^CPU\(s\)|Flags" | cut -c1-600 >> $OUT/host.txt
-timeout 120 python tools/cpu_png_decode_bench.py 48 1 8 16 32 > $OUT/cpu_png_decode.txt 2>&1
-timeout 200 python tools/cpu_loader_rate.py 49 8 16 32 64 > $OUT/cpu_loader_rate.txt 2>&1
-timeout 200 python tools/gpu_fusion_probe.py > $OUT/fusion_probe.txt 2>&1
-timeout 300 python tools/gpu_files_throughput.py 49 16 32 64 > $OUT/files_b2.txt 2>&1
-FT_BATCH=8 FT_GRAPH=1 timeout 300 python tools/gpu_files_throughput.py 49 16 32 64 > $OUT/files_b8_graph.txt 2>&1
-FT_BATCH=8 FT_GRAPH=1 FT_THREADED=1 timeout 300 python tools/gpu_files_throughput.py 49 16 32 64 > $OUT/files_b8_graph_stager.txt 2>&1
+nproc > $OUT/host.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host.txt 2>/dev/null; lscpu | grep -E "Model name|^CPU\(s\)" | cut -c1-200 >> $OUT/host.txt
+# the order is by value per GPU-minute (the whole script is ~30 of the round's 90): the headline line, the experimental set beside it, files -> maps, then the suite
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 [ -n "$ALL" ] && timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-batch1 --experimental $ALL > $OUT/bench_experimental.json 2> $OUT/bench_experimental.err
+FT_BATCH=8 FT_GRAPH=1 timeout 300 python tools/gpu_files_throughput.py 49 16 32 > $OUT/files_b8_graph.txt 2>&1
+FT_BATCH=8 FT_GRAPH=1 FT_THREADED=1 timeout 300 python tools/gpu_files_throughput.py 49 16 32 > $OUT/files_b8_graph_stager.txt 2>&1
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit: $?" >> $OUT/pytest_gpu.log
-cat $OUT/native.txt; tail -3 $OUT/pytest_gpu.log; cat $OUT/fusion_probe.txt; tail -4 $OUT/files_b8_graph*.txt; cut -c1-300 $OUT/bench.json
+# the gated parity cases of the experimental kernels, only when every one of them passed its native check
+[ "$(echo $PASSED | wc -w)" -eq 5 ] && { CASMVS_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_gpu_experimental.py -m gpu -q --timeout 300 -p no:cacheprovider > $OUT/pytest_experimental.log 2>&1; echo "pytest exit: $?" >> $OUT/pytest_experimental.log; }
+cat $OUT/native.txt; tail -3 $OUT/pytest_gpu.log; tail -3 $OUT/pytest_experimental.log 2>/dev/null; tail -4 $OUT/files_b8_graph*.txt; cut -c1-300 $OUT/bench.json; cut -c1-300 $OUT/bench_experimental.json 2>/dev/null
