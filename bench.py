@@ -439,8 +439,12 @@ def train_mode(args, dev, world, rank, dist, barrier):
     # same loss in its sync-free form (mean over the masked elements through a float mask)
     loss_fn = sl1_loss_masked if use_graph else sl1_loss
 
-    def step():
-        opt.zero_grad(set_to_none=False)
+    def step(zero=True):
+        # gradients dropped, not zero-filled (torch's default since 2.0): a zero-filled gradient makes autograd ADD into it - one more launch per
+        # parameter and step (115 `add` launches = 0.7 ms of the kernel-by-kernel step in profiles/r02_s3_train_step_kernel_stats.csv).
+        # --zero-fill-grads: the behaviour before round 3's last session (A/B).
+        if zero:
+            opt.zero_grad(set_to_none=not args.zero_fill_grads)
         loss = loss_fn(net(imgs, proj, dmin, dint), depths, masks)
         loss.backward()
         opt.step()
@@ -455,9 +459,25 @@ def train_mode(args, dev, world, rank, dist, barrier):
                 step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
+        def capture(zero_fill):
+            graph = torch.cuda.CUDAGraph()
+            if not zero_fill:
+                # torch's whole-network capture pattern: no gradients exist when the capture starts, so the captured backward allocates them from the
+                # graph's pool and WRITES them (no accumulate-add); every replay refills the same tensors, zero_grad is not part of the step
+                opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                loss = step(zero=zero_fill)
+            return graph, loss
+        try:
+            graph, static_loss = capture(args.zero_fill_grads)
+        except RuntimeError as e:   # (the dropped-gradient capture was written without a GPU run: keep the measured form as the fallback)
+            if args.zero_fill_grads:
+                raise
+            print(f"warning: capture with dropped gradients failed ({str(e).splitlines()[0][:200]}); falling back to zero-filled gradients", file=sys.stderr)
+            torch.cuda.synchronize()
+            args.zero_fill_grads = True
+            step()
+            graph, static_loss = capture(True)
 
         def run():
             graph.replay()
@@ -476,6 +496,7 @@ def train_mode(args, dev, world, rank, dist, barrier):
                      samples / elapsed, world, args.steps, args.warmup, elapsed, "weak",
                      {"workload": args.config + "_train", "H": H, "W": W, "views": V, "n_depths": list(n_depths), "num_groups": G,
                       "batch_per_gpu": B, "launch": "one hipGraph replay per step" if use_graph else "kernel by kernel",
+                      "zero_grad": "zero-filled gradients + accumulate-adds" if args.zero_fill_grads else "set_to_none",
                       "parallelism": f"DistributedDataParallel x{world} over RCCL" if world > 1 else "single GPU"}, median)
     line["train_step_ms"] = 1e3 * elapsed / args.steps
     line["peak_memory_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
@@ -515,6 +536,7 @@ def main():
                          "'splitf16' also runs conv2 / conv4 in that arithmetic, the other two keep them in float32; the other modes' throughputs "
                          "are measured and printed beside the headline")
     ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: FeatureNet's full-resolution FPN tail as one kernel (1) or as the reference's three steps (0); default: the model's")
+    ap.add_argument("--zero-fill-grads", action="store_true", help="--mode train A/B: optimizer.zero_grad(set_to_none=False) as before round 3's last session")
     ap.add_argument("--experimental", default=os.environ.get("CASMVS_EXPERIMENTAL", ""),
                     help="comma-separated opt-in kernels (written at the end of round 3, DESIGN.md section 6): CostRegNet zmarch / zmarch32 / xshift / deconv9 / "
                          "deconv11 / tail, FeatureNet fnet_conv0; named in the line's config.experimental - a line with this set is an A/B, not the headline")
