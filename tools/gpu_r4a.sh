@@ -39,4 +39,8 @@ timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider 
 echo "pytest exit: $?" >> $OUT/pytest_gpu.log
 # the gated parity cases of the experimental kernels, only when every one of them passed its native check
 [ "$(echo $PASSED | wc -w)" -eq 5 ] && { CASMVS_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_gpu_experimental.py -m gpu -q --timeout 300 -p no:cacheprovider > $OUT/pytest_experimental.log 2>&1; echo "pytest exit: $?" >> $OUT/pytest_experimental.log; }
+# the training step with dropped vs zero-filled gradients (bench.py --mode train; the first form was written without a GPU run)
+timeout 400 python bench.py --mode train --steps 20 --warmup 5 > $OUT/bench_train.json 2> $OUT/bench_train.err
+timeout 400 python bench.py --mode train --steps 20 --warmup 5 --zero-fill-grads > $OUT/bench_train_zero_fill.json 2> $OUT/bench_train_zero_fill.err
+grep -ho '"train_step_ms": [0-9.]*' $OUT/bench_train.json $OUT/bench_train_zero_fill.json
 cat $OUT/native.txt; tail -3 $OUT/pytest_gpu.log; tail -3 $OUT/pytest_experimental.log 2>/dev/null; tail -4 $OUT/files_b8_graph*.txt; cut -c1-300 $OUT/bench.json; cut -c1-300 $OUT/bench_experimental.json 2>/dev/null
