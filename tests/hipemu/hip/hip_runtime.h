@@ -226,3 +226,22 @@ inline int hipemu_update_dpp(int /*old*/, int src, int ctrl, int, int, bool) {
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
 inline unsigned hipemu_readlane(unsigned v, int lane) { return (unsigned)hipemu_lane_exchange((int)v, lane); }
 #define __builtin_amdgcn_readlane hipemu_readlane
+// v_readfirstlane under wave-uniform control flow: lane 0's value (a value that is NOT uniform shows, as on the hardware)
+inline unsigned hipemu_readfirstlane(unsigned v) { return (unsigned)hipemu_lane_exchange((int)v, 0); }
+#define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
+inline uint64_t hipemu_ballot(bool p) {
+  using namespace hipemu;
+  Block &blk = *g_block;
+  blk.lane_u32[t_wave][t_lane] = p ? 1u : 0u;
+  blk.wave[t_wave]->arrive_and_wait();
+  uint64_t m = 0;
+  for (int l = 0; l < 64; ++l) m |= (uint64_t)(blk.lane_u32[t_wave][l] & 1u) << l;
+  blk.wave[t_wave]->arrive_and_wait();
+  return m;
+}
+#define __builtin_amdgcn_ballot_w64 hipemu_ballot
+inline void hipemu_wave_barrier() { hipemu::g_block->wave[hipemu::t_wave]->arrive_and_wait(); }   // the wave's 64 threads are not in lock step here: a real rendezvous
+#define __builtin_amdgcn_wave_barrier hipemu_wave_barrier
+#define __builtin_amdgcn_fence(order, scope) std::atomic_thread_fence(std::memory_order_seq_cst)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))   // v_rcp_f32 is within 1 ulp of this
