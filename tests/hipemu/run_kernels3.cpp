@@ -131,6 +131,10 @@ int main(int argc, char **argv) {
   if (all) {
     take(fused_check(1, 8, 10, 68, 4));                      // chunks of 4 planes: halo planes at the chunk ends, separate regression
     take(fused_check(2, 6, 18, 124, 6));                     // generic-depth fused path, exact multiple of the x tile stride
+    take(fused_check(1, 16, 8, 64, 16));                     // the fused instantiations of the cascade's plane counts: DT = 16, 32, 48
+    take(fused_check(1, 32, 8, 64, 32));
+    take(fused_check(1, 48, 8, 64, 48));
+    take(fused_check(1, 48, 8, 64, 16));                     // 48 planes in three chunks
   }
   printf(worst < 2e-6 ? "ALL OK (worst %.2e)\n" : "FAILED (worst %.2e)\n", worst);
   return worst < 2e-6 ? 0 : 1;
