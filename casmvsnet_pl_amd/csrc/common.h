@@ -7,6 +7,14 @@
 
 #include "casmvs.h"
 
+// A kernel's dynamic LDS array.  (tests/hipemu compiles the kernels for the host, where a translation unit can hold function-scope static LDS arrays
+// - `__shared__` = `static` there - or `extern __shared__` declarations, not both: kernels that use both declare the dynamic one through this.)
+#ifdef HIPEMU_LDS_BYTES
+#define CASMVS_DYNAMIC_LDS(T, name) T *name = reinterpret_cast<T *>(hipemu::g_lds)
+#else
+#define CASMVS_DYNAMIC_LDS(T, name) extern __shared__ T name[]
+#endif
+
 namespace casmvs {
 
 char *error_buffer();  // thread-local, 512 bytes

@@ -49,6 +49,7 @@ struct Block {
   std::vector<std::unique_ptr<std::barrier<>>> wave;   // one rendezvous per wave of 64
   // exchange buffers of the wave collectives
   std::vector<std::array<_Float16, 64 * 8>> mfma_a, mfma_b;
+  std::vector<std::array<float, 64>> mfma_fa, mfma_fb;
   std::vector<std::array<uint32_t, 64>> lane_u32;
 };
 inline thread_local Dim3 t_threadIdx, t_blockIdx;
@@ -88,6 +89,21 @@ inline void __syncthreads() {
   hipemu::g_block->bar->arrive_and_wait();
   HIPEMU_PROF(hipemu_prof_barrier());
 }
+inline float unsafeAtomicAdd(float *p, float v) { return std::atomic_ref<float>(*p).fetch_add(v, std::memory_order_relaxed); }
+inline float atomicAdd(float *p, float v) { return std::atomic_ref<float>(*p).fetch_add(v, std::memory_order_relaxed); }
+inline int atomicAdd(int *p, int v) { return std::atomic_ref<int>(*p).fetch_add(v, std::memory_order_relaxed); }
+inline int atomicMin(int *p, int v) {
+  std::atomic_ref<int> a(*p);
+  int cur = a.load(std::memory_order_relaxed);
+  while (v < cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+  return cur;
+}
+inline int atomicMax(int *p, int v) {
+  std::atomic_ref<int> a(*p);
+  int cur = a.load(std::memory_order_relaxed);
+  while (v > cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+  return cur;
+}
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
 inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
@@ -102,6 +118,7 @@ enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
 template <class T>
 inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)std::malloc(n); return *p ? hipSuccess : 2; }
 inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int c, size_t n, void *) { std::memset(d, c, n); return 0; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 
@@ -119,6 +136,8 @@ void hipemu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
         blk.mfma_a.resize(nwaves);
         blk.mfma_b.resize(nwaves);
         blk.lane_u32.resize(nwaves);
+        blk.mfma_fa.resize(nwaves);
+        blk.mfma_fb.resize(nwaves);
         for (int w = 0; w < nwaves; ++w) blk.wave.push_back(std::make_unique<std::barrier<>>(std::min(64, nthreads - 64 * w)));
         g_block = &blk;
         if (g_lds) std::memset(g_lds, 0xCD, HIPEMU_LDS_BYTES);   // uninitialised LDS is garbage on the GPU too
@@ -203,6 +222,27 @@ inline hipemu_f32x4 hipemu_mfma_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, hip
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16 hipemu_mfma_16x16x32_f16
 
+// v_mfma_f32_16x16x4_f32: A lane l holds A[i = l & 15][k = l >> 4], B lane l holds B[k = l >> 4][j = l & 15]; D as above (column j = l & 15, rows 4 (l >> 4) + r)
+inline hipemu_f32x4 hipemu_mfma_16x16x4_f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+  using namespace hipemu;
+  Block &blk = *g_block;
+  auto &A = blk.mfma_fa[t_wave], &Bm = blk.mfma_fb[t_wave];
+  A[t_lane] = a;
+  Bm[t_lane] = b;
+  blk.wave[t_wave]->arrive_and_wait();
+  const int j = t_lane & 15;
+  hipemu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * (t_lane >> 4) + r;
+    double sum = 0.0;
+    for (int k = 0; k < 4; ++k) sum += (double)A[i + 16 * k] * (double)Bm[j + 16 * k];
+    d[r] = (float)((double)c[r] + sum);
+  }
+  blk.wave[t_wave]->arrive_and_wait();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4_f32
+
 inline int hipemu_lane_exchange(int v, int src_lane) {
   using namespace hipemu;
   Block &blk = *g_block;
@@ -213,9 +253,14 @@ inline int hipemu_lane_exchange(int v, int src_lane) {
   return out;
 }
 // the DPP controls casmvs::wave_max_bits uses (bound_ctrl / masks irrelevant for them: every lane has a source inside its row)
-inline int hipemu_update_dpp(int /*old*/, int src, int ctrl, int, int, bool) {
+inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) {
   const int l = hipemu::t_lane, row = l & ~15, q = l & ~3;
   int from;
+  if (ctrl == 0x138 || ctrl == 0x130) {   // wave_shr:1 / wave_shl:1 (bound_ctrl off): the lane without a source keeps `old`
+    const int f = ctrl == 0x138 ? l - 1 : l + 1;
+    const int got = hipemu_lane_exchange(src, f < 0 || f > 63 ? l : f);
+    return f < 0 || f > 63 ? old : got;
+  }
   if (ctrl == 0xB1) from = q + ((l & 3) ^ 1);            // quad_perm [1,0,3,2]
   else if (ctrl == 0x4E) from = q + ((l & 3) ^ 2);       // quad_perm [2,3,0,1]
   else if (ctrl == 0x141) from = (l & ~7) + (7 - (l & 7));   // row_half_mirror

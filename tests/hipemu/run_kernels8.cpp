@@ -1,0 +1,132 @@
+// As run_kernels.cpp, for the training path's matrix-core kernel (csrc/train.hip: conv_wgrad_kernel - the weight gradient of every convolution kind of the
+// model as a GEMM over the positions on v_mfma_f32_16x16x4_f32, 2 ms of the 14.5 ms training step - and its fixed-order reduction) and the per-channel
+// statistics kernel (channel_sums_kernel): GPU-validated device code as a regression test that needs no GPU, for the round that will work on the training
+// step.  Weight gradients against the definition in float64 for all six kinds; (sum x, sum x^2) against float64 sums.
+#define __shared__ static   // train.hip keeps its LDS in function-scope arrays (workgroups run one after the other here)
+#include "support.h"
+
+#include "train.hip"
+
+// kind -> stride, kernel depth, kernel size, pad, transposed (train.hip: wgrad_geom)
+struct Geo { int S, KZ, KS, transposed; };
+static Geo geo_of(int kind) {
+  switch (kind) {
+    case CASMVS_CONV_S1: return {1, 3, 3, 0};
+    case CASMVS_CONV_S2: return {2, 3, 3, 0};
+    case CASMVS_CONV_T2: return {2, 3, 3, 1};
+    case CASMVS_CONV2D_K3: return {1, 1, 3, 0};
+    case CASMVS_CONV2D_K5S2: return {2, 1, 5, 0};
+    default: return {1, 1, 1, 0};
+  }
+}
+
+static double wgrad_check(const char *name, int kind, int B, int cin, int cout, int D, int H, int W) {
+  const Geo g = geo_of(kind);
+  const int P = g.KS / 2, PZ = g.KZ / 2, T = g.KZ * g.KS * g.KS;
+  // output dims of the layer
+  const int Do = g.transposed ? 2 * D : (g.KZ == 3 ? (g.S == 2 ? D / 2 : D) : 1), Ho = g.transposed ? 2 * H : H / g.S, Wo = g.transposed ? 2 * W : W / g.S;
+  const size_t ni = (size_t)D * H * W, no = (size_t)Do * Ho * Wo;
+  std::vector<float> x((size_t)B * cin * ni), gy((size_t)B * cout * no);
+  for (auto &v : x) v = rnd();
+  for (auto &v : gy) v = rnd();
+  auto dup = [](const std::vector<float> &v) {
+    float *p = (float *)std::aligned_alloc(256, (v.size() * 4 + 255) & ~(size_t)255);
+    std::memcpy(p, v.data(), v.size() * 4);
+    return p;
+  };
+  float *xa = dup(x), *ga = dup(gy);
+  const size_t wsb = casmvs_conv_wgrad_workspace_bytes(kind, B, cin, cout, D, H, W);
+  if (!wsb) { printf("%s: shape not supported\n", name); return 1e9; }
+  void *ws = std::aligned_alloc(256, (wsb + 255) & ~(size_t)255);
+  std::vector<float> got((size_t)cin * cout * T, NAN), got2((size_t)cin * cout * T, NAN);
+  if (casmvs_conv_wgrad_f32(kind, xa, ga, got.data(), ws, B, cin, cout, D, H, W, nullptr)) { printf("%s: %s\n", name, casmvs_last_error()); return 1e9; }
+  // the experimental LDS layout (channel strides = 2 mod 32): the same sums in the same order
+  if (casmvs_conv_wgrad_x_f32(kind, xa, ga, got2.data(), ws, B, cin, cout, D, H, W, 1, nullptr)) { printf("%s (layout 1): %s\n", name, casmvs_last_error()); return 1e9; }
+  const bool same = std::memcmp(got.data(), got2.data(), got.size() * 4) == 0;
+  double err = 0, range = 0;
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int kz = 0; kz < g.KZ; ++kz)
+        for (int ky = 0; ky < g.KS; ++ky)
+          for (int kx = 0; kx < g.KS; ++kx) {
+            double acc = 0;
+            for (int b = 0; b < B; ++b) {
+              if (!g.transposed) {   // out[o] += w[co][ci][k] in[S o - P + k]
+                for (int oz = 0; oz < Do; ++oz)
+                  for (int oy = 0; oy < Ho; ++oy)
+                    for (int ox = 0; ox < Wo; ++ox) {
+                      const int iz = g.S * oz - PZ + kz, iy = g.S * oy - P + ky, ix = g.S * ox - P + kx;
+                      if (iz < 0 || iz >= D || iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                      acc += (double)gy[((size_t)b * cout + co) * no + ((size_t)oz * Ho + oy) * Wo + ox] * x[((size_t)b * cin + ci) * ni + ((size_t)iz * H + iy) * W + ix];
+                    }
+              } else {               // out[2 i - 1 + k] += in[i] w[ci][co][k]
+                for (int iz = 0; iz < D; ++iz)
+                  for (int iy = 0; iy < H; ++iy)
+                    for (int ix = 0; ix < W; ++ix) {
+                      const int oz = 2 * iz - 1 + kz, oy = 2 * iy - 1 + ky, ox = 2 * ix - 1 + kx;
+                      if (oz < 0 || oz >= Do || oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+                      acc += (double)x[((size_t)b * cin + ci) * ni + ((size_t)iz * H + iy) * W + ix] * gy[((size_t)b * cout + co) * no + ((size_t)oz * Ho + oy) * Wo + ox];
+                    }
+              }
+            }
+            const int t = (kz * g.KS + ky) * g.KS + kx;
+            const float v = g.transposed ? got[((size_t)ci * cout + co) * T + t] : got[((size_t)co * cin + ci) * T + t];
+            range = std::fmax(range, std::fabs(acc));
+            err = std::fmax(err, std::isfinite(v) ? std::fabs(acc - v) : 1e30);
+          }
+  std::free(xa); std::free(ga); std::free(ws);
+  printf("wgrad %-8s B=%d %d -> %d input %dx%dx%d: max error / largest gradient = %.2e; LDS layout 1 %s\n", name, B, cin, cout, D, H, W, err / range,
+         same ? "bit-identical" : "DIFFERENT");
+  return same ? err / range : 1.0;
+}
+
+static double sums_check(int N, int C, int n) {
+  std::vector<float> x((size_t)N * C * n);
+  for (auto &v : x) v = rnd() * 3.0f + 0.5f;
+  const int blocks = casmvs_channel_sums_blocks(N, (size_t)n);
+  std::vector<double> out((size_t)C * blocks * 2, NAN);
+  float *xa = (float *)std::aligned_alloc(256, (x.size() * 4 + 255) & ~(size_t)255);
+  std::memcpy(xa, x.data(), x.size() * 4);
+  if (casmvs_channel_sums_f64(xa, out.data(), N, C, (size_t)n, nullptr)) { printf("channel_sums: %s\n", casmvs_last_error()); return 1e9; }
+  double err = 0;
+  for (int c = 0; c < C; ++c) {
+    double s0 = 0, s1 = 0, g0 = 0, g1 = 0;
+    for (int i = 0; i < N; ++i)
+      for (int e = 0; e < n; ++e) {
+        const double v = x[((size_t)i * C + c) * n + e];
+        s0 += v;
+        s1 += v * v;
+      }
+    for (int b = 0; b < blocks; ++b) { g0 += out[((size_t)c * blocks + b) * 2]; g1 += out[((size_t)c * blocks + b) * 2 + 1]; }
+    err = std::fmax(err, std::fmax(std::fabs(g0 - s0) / std::fabs(s0), std::fabs(g1 - s1) / s1));
+  }
+  std::free(xa);
+  printf("channel_sums N=%d C=%d n=%d (%d blocks): max relative error = %.2e\n", N, C, n, blocks, err);
+  return err;
+}
+
+int main(int argc, char **argv) {
+  hipemu::g_lds = smem_raw;   // CASMVS_DYNAMIC_LDS (common.h)
+  const std::string which = argc > 1 ? argv[1] : "all";
+  double worst = 0;
+  auto take = [&](double e) { worst = std::fmax(worst, e); };
+  const bool all = which == "all", quick = which == "quick";
+  if (all || quick) {
+    take(wgrad_check("S1", CASMVS_CONV_S1, 1, 8, 8, 2, 3, 20));          // two tiles, ragged in z (2 of 4 planes), y (3 of 4 rows) and x (20 of 32)
+    take(wgrad_check("K5S2", CASMVS_CONV2D_K5S2, 1, 8, 16, 1, 8, 16));
+    take(sums_check(2, 8, 1000));
+  }
+  if (all) {
+    take(wgrad_check("S1", CASMVS_CONV_S1, 1, 8, 8, 5, 6, 20));          // ragged in z (tile 4), y and x
+    take(wgrad_check("S2", CASMVS_CONV_S2, 1, 8, 16, 4, 6, 12));
+    take(wgrad_check("T2", CASMVS_CONV_T2, 1, 16, 8, 2, 3, 10));
+    take(wgrad_check("S1", CASMVS_CONV_S1, 2, 16, 16, 3, 5, 9));
+    take(wgrad_check("S1", CASMVS_CONV_S1, 1, 8, 1, 4, 6, 12));          // `prob` on the generic kernel: one output channel in a 16-row tile
+    take(wgrad_check("K3", CASMVS_CONV2D_K3, 2, 8, 8, 1, 9, 20));
+    take(wgrad_check("K1", CASMVS_CONV2D_K1, 1, 32, 16, 1, 6, 10));
+    take(wgrad_check("T2", CASMVS_CONV_T2, 1, 32, 16, 1, 4, 6));
+    take(sums_check(1, 16, 70000));
+  }
+  printf(worst < 3e-6 ? "ALL OK (worst %.2e)\n" : "FAILED (worst %.2e)\n", worst);
+  return worst < 3e-6 ? 0 : 1;
+}

@@ -17,10 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = os.environ.get("HIPEMU_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
 
 
-DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7")
+DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7", "run_kernels8")
 PROFILED = ("run_kernels", "run_kernels3")
 # costvol_lds.hip instantiates 30 kernels: its ThreadSanitizer build alone takes 80 s - part of the suite only with HIPEMU_FULL=1 (clean when it was added)
-TSAN_DRIVERS = DRIVERS if os.environ.get("HIPEMU_FULL") == "1" else tuple(d for d in DRIVERS if d != "run_kernels7")
+# (run_kernels8: the weight-gradient cases take a minute under the sanitizer)
+TSAN_DRIVERS = DRIVERS if os.environ.get("HIPEMU_FULL") == "1" else tuple(d for d in DRIVERS if d not in ("run_kernels7", "run_kernels8"))
 
 
 def _profile_tool():
@@ -122,6 +123,15 @@ def test_production_plane_sweep_runs_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_training_weight_gradient_kernel_runs_on_the_cpu(built):
+    """conv_wgrad_kernel (csrc/train.hip: the weight gradient of every convolution kind as a GEMM over the positions on v_mfma_f32_16x16x4_f32 + the
+    fixed-order reduction) for Conv3d s1 and Conv2d k5 s2 (every kind in the driver's `all` mode) against the definition in float64 - with the production LDS layout and with
+    the experimental conflict-free one (casmvs_conv_wgrad_x_f32), which must give the same bits; channel_sums_kernel against float64 sums."""
+    out = _run(built[("run_kernels8", "plain")], ("wgrad S1", "wgrad K5S2", "channel_sums"))   # (`all`: every kind, profiles/r03_hip_emulation_all.txt)
+    assert "DIFFERENT" not in out.stdout and out.stdout.count("bit-identical") >= 2
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_fused_costreg_tail_runs_on_the_cpu(built):
     """conv11 + skip + `prob` + softmax regression as one depth-walking kernel (csrc/conv11_prob_fused.hip, written without a GPU run): cost volume, depth and
     confidence against the layers in float64, two x tiles (stride 62, the first one starting at x = -1) and two y tiles."""
@@ -130,7 +140,7 @@ def test_fused_costreg_tail_runs_on_the_cpu(built):
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 @pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "fnet_conv0", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")),
-                                          ("run_kernels3", ("conv11_prob",)), ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion")), ("run_kernels6", ("fpn_tail0",)), ("run_kernels7", ("costvol_lds",))])
+                                          ("run_kernels3", ("conv11_prob",)), ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion")), ("run_kernels6", ("fpn_tail0",)), ("run_kernels7", ("costvol_lds",)), ("run_kernels8", ("wgrad",))])
 def test_no_lds_race_under_thread_sanitizer(built, source, names):
     """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
     LDS is plain memory shared by the workgroup's std::threads and the barrier is the only synchronisation between waves (the wave collectives synchronise
@@ -140,7 +150,7 @@ def test_no_lds_race_under_thread_sanitizer(built, source, names):
     if not built["tsan"]:
         pytest.skip("this clang++ has no ThreadSanitizer runtime")
     if source not in TSAN_DRIVERS:
-        pytest.skip("80 s of compile time: HIPEMU_FULL=1")
+        pytest.skip("over a minute of compile / run time: HIPEMU_FULL=1")
     out = _run(built[(source, "tsan")], names)
     reports = out.stderr.split("WARNING: ThreadSanitizer")[1:]
     # the one intended same-address access: prob_wgrad_kernel's staging rounds past the last item all WRITE the dummy word box[DUMMY], which nobody reads

@@ -42,5 +42,6 @@ echo "pytest exit: $?" >> $OUT/pytest_gpu.log
 # the training step with dropped vs zero-filled gradients (bench.py --mode train; the first form was written without a GPU run)
 timeout 400 python bench.py --mode train --steps 20 --warmup 5 > $OUT/bench_train.json 2> $OUT/bench_train.err
 timeout 400 python bench.py --mode train --steps 20 --warmup 5 --zero-fill-grads > $OUT/bench_train_zero_fill.json 2> $OUT/bench_train_zero_fill.err
-grep -ho '"train_step_ms": [0-9.]*' $OUT/bench_train.json $OUT/bench_train_zero_fill.json
+timeout 400 python bench.py --mode train --steps 20 --warmup 5 --wgrad-layout 1 > $OUT/bench_train_wgrad_layout1.json 2> $OUT/bench_train_wgrad_layout1.err
+grep -ho '"train_step_ms": [0-9.]*' $OUT/bench_train.json $OUT/bench_train_zero_fill.json $OUT/bench_train_wgrad_layout1.json
 cat $OUT/native.txt; tail -3 $OUT/pytest_gpu.log; tail -3 $OUT/pytest_experimental.log 2>/dev/null; tail -4 $OUT/files_b8_graph*.txt; cut -c1-300 $OUT/bench.json; cut -c1-300 $OUT/bench_experimental.json 2>/dev/null

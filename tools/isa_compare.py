@@ -57,6 +57,11 @@ def demangle(names):
     return out
 
 
+def same_but_defaults(old, new):
+    """`new` is `old` with defaulted trailing template arguments (0 / false) appended"""
+    return old.endswith(">") and new.startswith(old[:-1]) and re.fullmatch(r"(, (0|false))+>", new[len(old) - 1:]) is not None
+
+
 def main():
     path = sys.argv[1]
     rev = sys.argv[2] if len(sys.argv) > 2 else "HEAD"
@@ -70,7 +75,7 @@ def main():
     old_names, new_names = dict(zip(demangle(list(old)), old)), dict(zip(demangle(list(new)), new))
     bad = 0
     for name, key in old_names.items():
-        cand = [n for n in new_names if n == name or re.sub(r"(, 0)+>$", ">", n) == name]
+        cand = [n for n in new_names if n == name or same_but_defaults(name, n)]
         if not cand:
             print(f"  {name}: gone")
             bad += 1
@@ -79,7 +84,7 @@ def main():
         bad += not same
         print(f"  {name}: {'identical' if same else 'DIFFERENT'} ({len(old[key])} -> {len(new[new_names[cand[0]]])} instructions)" + ("" if cand[0] == name else f"   [now {cand[0]}]"))
     for n in new_names:
-        if n not in old_names and re.sub(r"(, 0)+>$", ">", n) not in old_names:
+        if n not in old_names and not any(same_but_defaults(o, n) for o in old_names):
             print(f"  {n}: new ({len(new[new_names[n]])} instructions)")
     print("unchanged" if not bad else f"{bad} kernels differ")
     return 1 if bad else 0
