@@ -5,7 +5,7 @@
 #define __shared__ static   // train.hip keeps its LDS in function-scope arrays (workgroups run one after the other here)
 #include "support.h"
 
-#include "train.hip"
+#include "train.hip"   // (includes plane_sweep.h)
 
 // kind -> stride, kernel depth, kernel size, pad, transposed (train.hip: wgrad_geom)
 struct Geo { int S, KZ, KS, transposed; };
@@ -105,6 +105,79 @@ static double sums_check(int N, int C, int n) {
   return err;
 }
 
+// casmvs_costvol_var_backward_f32 (costvol_var_bwd_kernel: the scatter transpose of the plane sweep through an LDS box image with ds_add_f32, the largest kernel of
+// the training step) against d var / d x_v = 2 x_v / V - 2 sum x / V^2 through the bilinear weights, taps from the shared float32 routine, sums in float64
+static double varbwd_check(int B, int V, int C, int D, int h, int w) {
+  const size_t hw = (size_t)h * w;
+  std::vector<float> feats((size_t)B * V * C * hw), proj((size_t)B * (V - 1) * 12, 0.0f), depth((size_t)B * D * hw), gvol((size_t)B * C * D * hw);
+  for (auto &v : feats) v = rnd();
+  for (auto &v : gvol) v = rnd();
+  for (int b = 0; b < B; ++b) {
+    for (int v = 0; v < V - 1; ++v) {
+      float *P = proj.data() + ((size_t)b * (V - 1) + v) * 12;
+      P[0] = 1.0f; P[5] = 1.0f; P[10] = 1.0f;
+      P[1] = 0.002f * (v + 1); P[4] = -0.002f * (v + 1);
+      P[3] = (v % 2 ? -1.0f : 1.0f) * 0.6f / 1.376e-5f;   // 0.6 pixels of epipolar slide per plane (run_kernels7.cpp)
+      P[2] = -P[3] / 425.0f - 2.0f;
+      P[7] = 0.3f * 425.0f * (v + 1);
+    }
+    for (int d = 0; d < D; ++d)
+      for (size_t p = 0; p < hw; ++p) depth[((size_t)b * D + d) * hw + p] = 425.0f + 2.5f * d + 0.02f * (float)(p % 5);
+  }
+  auto dup = [](const std::vector<float> &v) {
+    float *p = (float *)std::aligned_alloc(256, (v.size() * 4 + 255) & ~(size_t)255);
+    std::memcpy(p, v.data(), v.size() * 4);
+    return p;
+  };
+  float *fa = dup(feats), *pa = dup(proj), *da = dup(depth), *ga = dup(gvol);
+  std::vector<float> nanv(feats.size(), NAN);
+  float *out = dup(nanv);
+  if (casmvs_costvol_var_backward_f32(fa, pa, da, ga, out, B, V, C, h, w, D, nullptr)) { printf("var_backward: %s\n", casmvs_last_error()); return 1e9; }
+  std::vector<double> want(feats.size(), 0.0);
+  for (int b = 0; b < B; ++b)
+    for (int d = 0; d < D; ++d)
+      for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+          const float dv = depth[((size_t)b * D + d) * hw + (size_t)y * w + x];
+          std::vector<casmvs_dev::Taps> taps(V - 1);
+          std::vector<std::vector<double>> xv(V - 1, std::vector<double>(C));
+          std::vector<double> S(C);
+          for (int c = 0; c < C; ++c) S[c] = feats[(((size_t)b * V) * C + c) * hw + (size_t)y * w + x];
+          for (int v = 0; v < V - 1; ++v) {
+            taps[v] = casmvs_dev::plane_sweep_taps(proj.data() + ((size_t)b * (V - 1) + v) * 12, (float)x, (float)y, dv, w, h);
+            const casmvs_dev::Taps &t = taps[v];
+            for (int c = 0; c < C; ++c) {
+              const float *f = feats.data() + (((size_t)b * V + 1 + v) * C + c) * hw;
+              xv[v][c] = (double)t.w_nl * f[(size_t)t.yn * w + t.xl] + (double)t.w_nr * f[(size_t)t.yn * w + t.xl + 1] + (double)t.w_sl * f[(size_t)t.ys * w + t.xl] +
+                         (double)t.w_sr * f[(size_t)t.ys * w + t.xl + 1];
+              S[c] += xv[v][c];
+            }
+          }
+          for (int c = 0; c < C; ++c) {
+            const double g = gvol[(((size_t)b * C + c) * D + d) * hw + (size_t)y * w + x];
+            const double xr = feats[(((size_t)b * V) * C + c) * hw + (size_t)y * w + x];
+            want[(((size_t)b * V) * C + c) * hw + (size_t)y * w + x] += g * (2.0 * xr / V - 2.0 * S[c] / ((double)V * V));
+            for (int v = 0; v < V - 1; ++v) {
+              const casmvs_dev::Taps &t = taps[v];
+              const double k = g * (2.0 * xv[v][c] / V - 2.0 * S[c] / ((double)V * V));
+              double *q = want.data() + (((size_t)b * V + 1 + v) * C + c) * hw;
+              q[(size_t)t.yn * w + t.xl] += k * t.w_nl;
+              q[(size_t)t.yn * w + t.xl + 1] += k * t.w_nr;
+              q[(size_t)t.ys * w + t.xl] += k * t.w_sl;
+              q[(size_t)t.ys * w + t.xl + 1] += k * t.w_sr;
+            }
+          }
+        }
+  double err = 0, range = 0;
+  for (size_t i = 0; i < want.size(); ++i) {
+    range = std::fmax(range, std::fabs(want[i]));
+    err = std::fmax(err, std::isfinite(out[i]) ? std::fabs(want[i] - out[i]) : 1e30);
+  }
+  std::free(fa); std::free(pa); std::free(da); std::free(ga); std::free(out);
+  printf("var_backward B=%d V=%d C=%d %dx%dx%d: max error / largest gradient = %.2e\n", B, V, C, D, h, w, err / range);
+  return err / range;
+}
+
 int main(int argc, char **argv) {
   hipemu::g_lds = smem_raw;   // CASMVS_DYNAMIC_LDS (common.h)
   const std::string which = argc > 1 ? argv[1] : "all";
@@ -115,6 +188,7 @@ int main(int argc, char **argv) {
     take(wgrad_check("S1", CASMVS_CONV_S1, 1, 8, 8, 2, 3, 20));          // two tiles, ragged in z (2 of 4 planes), y (3 of 4 rows) and x (20 of 32)
     take(wgrad_check("K5S2", CASMVS_CONV2D_K5S2, 1, 8, 16, 1, 8, 16));
     take(sums_check(2, 8, 1000));
+    take(varbwd_check(1, 3, 8, 8, 12, 36));                               // two 32 x 32 tiles (the second ragged), one chunk of 8 planes, two source views
   }
   if (all) {
     take(wgrad_check("S1", CASMVS_CONV_S1, 1, 8, 8, 5, 6, 20));          // ragged in z (tile 4), y and x
@@ -126,6 +200,7 @@ int main(int argc, char **argv) {
     take(wgrad_check("K1", CASMVS_CONV2D_K1, 1, 32, 16, 1, 6, 10));
     take(wgrad_check("T2", CASMVS_CONV_T2, 1, 32, 16, 1, 4, 6));
     take(sums_check(1, 16, 70000));
+    take(varbwd_check(2, 2, 16, 16, 34, 40));                             // two channel groups, two plane chunks, four tiles
   }
   printf(worst < 3e-6 ? "ALL OK (worst %.2e)\n" : "FAILED (worst %.2e)\n", worst);
   return worst < 3e-6 ? 0 : 1;
