@@ -17,11 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = os.environ.get("HIPEMU_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
 
 
-DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7", "run_kernels8")
+DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7", "run_kernels8", "run_kernels9")
 PROFILED = ("run_kernels", "run_kernels3")
 # costvol_lds.hip instantiates 30 kernels: its ThreadSanitizer build alone takes 80 s - part of the suite only with HIPEMU_FULL=1 (clean when it was added)
-# (run_kernels8: the weight-gradient cases take a minute under the sanitizer)
-TSAN_DRIVERS = DRIVERS if os.environ.get("HIPEMU_FULL") == "1" else tuple(d for d in DRIVERS if d not in ("run_kernels7", "run_kernels8"))
+# (run_kernels8: the weight-gradient cases take a minute under the sanitizer; run_kernels9: conv3d_mfma.hip is 2500 lines of templates - clean when added)
+TSAN_DRIVERS = DRIVERS if os.environ.get("HIPEMU_FULL") == "1" else tuple(d for d in DRIVERS if d not in ("run_kernels7", "run_kernels8", "run_kernels9"))
 
 
 def _profile_tool():
@@ -33,11 +33,14 @@ def _profile_tool():
 
 
 def _compile(workdir, source, extra=(), suffix=""):
-    exe = os.path.join(workdir, source + suffix)
+    exe, obj = os.path.join(workdir, source + suffix), os.path.join(workdir, source + suffix + ".o")
     build = subprocess.run([CLANG, "-std=c++20", "-O1", "-pthread", *extra, "-DCASMVS_SPLIT_NOASM", "-I" + os.path.join(ROOT, "tests", "hipemu"),
-                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "casmvsnet_pl_amd", "csrc"), "-x", "c++",
-                            os.path.join(ROOT, "tests", "hipemu", source + ".cpp"), "-o", exe], capture_output=True, text=True, timeout=900)
+                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "casmvsnet_pl_amd", "csrc"), "-x", "c++", "-c",
+                            os.path.join(ROOT, "tests", "hipemu", source + ".cpp"), "-o", obj], capture_output=True, text=True, timeout=900)
     assert build.returncode == 0, build.stderr[-3000:]
+    stubs = _profile_tool().link_stubs(obj, workdir, source + suffix)   # (run_kernels9: the kernel families conv3d_mfma.hip's engine functions call)
+    link = subprocess.run([CLANG, "-pthread", *[e for e in extra if e.startswith("-fsanitize")], obj, *stubs, "-o", exe], capture_output=True, text=True, timeout=300)
+    assert link.returncode == 0, link.stderr[-3000:]
     return exe
 
 
@@ -133,6 +136,13 @@ def test_training_weight_gradient_kernel_runs_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_float32_matrix_core_layers_run_on_the_cpu(built):
+    """csrc/conv3d_mfma.hip through casmvs_conv3d_forward_f32: Conv3d k3 s2 (conv1) and ConvTranspose3d k3 s2 + skip (conv11) on v_mfma_f32_16x16x4_f32
+    against the layers in float64 (the driver's `all` mode: also the stride-1 PX / CI forms, conv3, conv9 and the one-channel tile kernel)."""
+    _run(built[("run_kernels9", "plain")], ("conv3d_f32 S2", "conv3d_f32 T2"))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_fused_costreg_tail_runs_on_the_cpu(built):
     """conv11 + skip + `prob` + softmax regression as one depth-walking kernel (csrc/conv11_prob_fused.hip, written without a GPU run): cost volume, depth and
     confidence against the layers in float64, two x tiles (stride 62, the first one starting at x = -1) and two y tiles."""
@@ -141,7 +151,7 @@ def test_fused_costreg_tail_runs_on_the_cpu(built):
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 @pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "fnet_conv0", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")),
-                                          ("run_kernels3", ("conv11_prob",)), ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion")), ("run_kernels6", ("fpn_tail0",)), ("run_kernels7", ("costvol_lds",)), ("run_kernels8", ("wgrad",))])
+                                          ("run_kernels3", ("conv11_prob",)), ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion")), ("run_kernels6", ("fpn_tail0",)), ("run_kernels7", ("costvol_lds",)), ("run_kernels8", ("wgrad",)), ("run_kernels9", ("conv3d_f32",))])
 def test_no_lds_race_under_thread_sanitizer(built, source, names):
     """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
     LDS is plain memory shared by the workgroup's std::threads and the barrier is the only synchronisation between waves (the wave collectives synchronise
