@@ -84,6 +84,46 @@ static double conv3d_f32_check(const char *name, int kind, int B, int cin, int c
   return err / range;
 }
 
+// FeatureNet's float32 layers through casmvs_conv2d_forward_f32: Conv2d k3 s1 p1 / k5 s2 p2 (+ folded ABN + leaky-relu)
+static double conv2d_f32_check(const char *name, int kind, int N, int cin, int cout, int H, int W) {
+  const int KS = kind == CASMVS_CONV2D_K5S2 ? 5 : 3, S = kind == CASMVS_CONV2D_K5S2 ? 2 : 1, P = KS / 2, Ho = H / S, Wo = W / S;
+  std::vector<float> x((size_t)N * cin * H * W), w((size_t)cout * cin * KS * KS), sc(cout), sh(cout);
+  for (auto &v : x) v = rnd();
+  for (auto &v : w) v = rnd() * 0.2f;
+  for (int c = 0; c < cout; ++c) { sc[c] = 0.5f + 0.05f * c; sh[c] = 0.03f * (c - 4); }
+  const size_t pf = casmvs_conv2d_packed_floats(kind, cin, cout);
+  if (!pf) { printf("%s: layer not supported\n", name); return 1e9; }
+  float *pk = (float *)std::aligned_alloc(256, (pf * 4 + 255) & ~(size_t)255);
+  if (casmvs_conv2d_pack_f32(kind, cin, cout, w.data(), sc.data(), sh.data(), pk)) { printf("%s: pack: %s\n", name, casmvs_last_error()); return 1e9; }
+  float *xa = (float *)std::aligned_alloc(256, (x.size() * 4 + 255) & ~(size_t)255);
+  std::memcpy(xa, x.data(), x.size() * 4);
+  std::vector<float> out((size_t)N * cout * Ho * Wo, NAN);
+  float *oa = (float *)std::aligned_alloc(256, (out.size() * 4 + 255) & ~(size_t)255);
+  std::memcpy(oa, out.data(), out.size() * 4);
+  if (casmvs_conv2d_forward_f32(kind, pk, xa, nullptr, oa, N, cin, cout, H, W, 0.01f, nullptr)) { printf("%s: %s\n", name, casmvs_last_error()); return 1e9; }
+  double err = 0, range = 0;
+  for (int n = 0; n < N; ++n)
+    for (int co = 0; co < cout; ++co)
+      for (int oy = 0; oy < Ho; ++oy)
+        for (int ox = 0; ox < Wo; ++ox) {
+          double acc = 0;
+          for (int ci = 0; ci < cin; ++ci)
+            for (int ky = 0; ky < KS; ++ky)
+              for (int kx = 0; kx < KS; ++kx) {
+                const int iy = S * oy - P + ky, ix = S * ox - P + kx;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                acc += (double)w[(((size_t)co * cin + ci) * KS + ky) * KS + kx] * x[(((size_t)n * cin + ci) * H + iy) * W + ix];
+              }
+          const double v = lrelu(acc * sc[co] + sh[co]);
+          const float got = oa[(((size_t)n * cout + co) * Ho + oy) * Wo + ox];
+          range = std::fmax(range, std::fabs(v));
+          err = std::fmax(err, std::isfinite(got) ? std::fabs(v - got) : 1e30);
+        }
+  std::free(pk); std::free(xa); std::free(oa);
+  printf("conv2d_f32 %-4s N=%d %d -> %d input %dx%d: max error / range = %.2e\n", name, N, cin, cout, H, W, err / range);
+  return err / range;
+}
+
 int main(int argc, char **argv) {
   hipemu::g_lds = reinterpret_cast<unsigned char *>(smem);
   const std::string which = argc > 1 ? argv[1] : "all";
@@ -100,6 +140,10 @@ int main(int argc, char **argv) {
     take(conv3d_f32_check("S2", CASMVS_CONV_S2, 2, 16, 32, 2, 4, 12, false));     // conv3
     take(conv3d_f32_check("T2", CASMVS_CONV_T2, 1, 32, 16, 1, 3, 6, true));       // conv9 + skip
     take(conv3d_f32_check("S1", CASMVS_CONV_S1, 1, 8, 1, 3, 5, 20, false));       // prob (tile kernels)
+    take(conv2d_f32_check("K3", CASMVS_CONV2D_K3, 2, 3, 8, 10, 36));               // FeatureNet conv0.0
+    take(conv2d_f32_check("K3", CASMVS_CONV2D_K3, 1, 16, 16, 9, 20));              // conv1.1 on the float32 kernel
+    take(conv2d_f32_check("K5S2", CASMVS_CONV2D_K5S2, 1, 8, 16, 12, 40));          // conv1.0
+    take(conv2d_f32_check("K5S2", CASMVS_CONV2D_K5S2, 2, 16, 32, 8, 20));          // conv2.0
   }
   printf(worst < 2e-6 ? "ALL OK (worst %.2e)\n" : "FAILED (worst %.2e)\n", worst);
   return worst < 2e-6 ? 0 : 1;
