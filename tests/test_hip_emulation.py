@@ -1,12 +1,19 @@
 """The kernels' own source on the CPU: tests/hipemu/hip/hip_runtime.h stands in for the HIP runtime (one std::thread per GPU thread, wave collectives -
-the f16 MFMA with the lane layout casmvs_selftest_mfma_f16 verified on the MI355X, the DPP exchanges - as rendezvous, raw buffer addressing with range
-checking), tests/hipemu/run_kernels.cpp includes the .hip files as C++ and runs them against float64 references.
+the f16 and float32 MFMAs with the lane layouts the MI355X self-tests verified, DPP exchanges and wave shifts, ballots, readlane - as rendezvous of a wave's
+64 threads, raw buffer addressing with range checking, LDS / global atomics), the drivers include the .hip files as C++ and run them against float64:
 
-`conv0_sf` is the established kernel (validated on the GPU): it checks the emulator.  conv0_zm / fnet_conv0 / deconv11 / deconv9 were written at the end of
-round 3 without access to a GPU: this is the first time their code RUNS - ragged shapes, persistent workgroups that walk several items, z segments.
-The same sources under ThreadSanitizer (a missing barrier is a reported race) and under an LDS bank-conflict / cache-line profile built from the compiler's
-memory-access hooks (tools/lds_bank_profile.py).  What the emulation cannot show: timing, the co-residency hazard of DESIGN.md 2.0, the device compiler's
-code.  CPU only; needs ROCm's clang++ (host target)."""
+  run_kernels   conv0 split-f16 (tiled: validates the emulator; z-march, shifted grids), FeatureNet.conv0 fused, deconv9 / deconv11 split-f16
+  run_kernels2  conv_ci_sf / conv2d_ci_sf (production)                 run_kernels3  conv11 + prob + regression as one kernel
+  run_kernels4  prob z-walk head (production)                         run_kernels5  prob weight gradient, both fusion kernels (production)
+  run_kernels6  FPN tail split-f16 (production)                       run_kernels7  LDS-staged plane sweep / variance volume (production)
+  run_kernels8  training: conv_wgrad (all kinds, both LDS layouts), channel sums, variance-volume backward
+  run_kernels9  the float32 matrix-core layers of conv3d_mfma.hip (3D stride 1 / 2 / transposed + skip, 2D k3 / k5 s2)
+
+The kernels written at the end of round 3 without access to a GPU RUN here for the first time - ragged shapes, persistent workgroups that walk several
+items, z segments.  The same sources under ThreadSanitizer (a missing barrier is a reported race) and under an LDS bank-conflict / cache-line profile built
+from the compiler's memory-access hooks (tools/lds_bank_profile.py), whose conflict ratios match the MI355X's counters.  What the emulation cannot show:
+timing, the co-residency hazard of DESIGN.md 2.0 (tools/mfma_hazard_lint.py reads the schedules for it), the device compiler's code.  CPU only; needs
+ROCm's clang++ (host target)."""
 import os
 import shutil
 import subprocess
