@@ -134,6 +134,10 @@ int main(int argc, char **argv) {
     take(conv3d_f32_check("S2", CASMVS_CONV_S2, 1, 8, 16, 4, 6, 20, false));      // conv1
     take(conv3d_f32_check("T2", CASMVS_CONV_T2, 1, 16, 8, 2, 3, 10, true));       // conv11 + skip
   }
+  if (which == "streams") {   // interior-dominated, cache-line-aligned rows (tools/lds_bank_profile.py: request streams)
+    take(conv3d_f32_check("S2", CASMVS_CONV_S2, 1, 8, 16, 8, 16, 128, false));    // conv1
+    take(conv3d_f32_check("T2", CASMVS_CONV_T2, 1, 16, 8, 4, 8, 64, true));       // conv11 + skip
+  }
   if (all) {
     take(conv3d_f32_check("S1", CASMVS_CONV_S1, 1, 8, 8, 3, 5, 20, false));       // conv0 on the float32 kernel (PX form)
     take(conv3d_f32_check("S1", CASMVS_CONV_S1, 1, 16, 16, 3, 5, 18, false));     // conv2 (CI form)
