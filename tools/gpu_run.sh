@@ -1,0 +1,133 @@
+#!/bin/bash
+# ONE parameterised GPU-box runner (replaces the per-call gpu_r3*.sh / gpu_r4a.sh scripts of earlier rounds):
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_run.sh <tag> <stage> [<stage> ...]'
+# Every stage writes under gpurun_out/<tag>/ (the only directory that travels back) and prints a short tail.  Stages are ordered by the
+# caller; each is bounded by its own `timeout` so that a hung kernel cannot become a gpurun strike.
+#   native       torch-free C-ABI check binaries (tools/native/*.cpp -> tools/probes/bin/) + the step runner: seconds of GPU time
+#   experimental the step runner with each experimental layer set whose native check passed (needs `native` earlier in the same call)
+#   step         tools/notorch/step_runner.py --batch 8 (ms per step, per-stage HIP-event times; no torch)
+#   probes       tools/probes/*.hip stand-alone programs that exist as binaries (mfma co-residency reproducer, ...)
+#   bench        python bench.py --steps 20 --warmup 5 (the driver's line)               BENCH_ARGS="..." adds flags
+#   configs      bench lines of the other BASELINE configs (gwc8, 1152x864 V5, 768x576 V7), no CPU baseline
+#   suite        python -m pytest tests -m gpu
+#   smoke        __graft_entry__.smoke()
+#   train        bench.py --mode train (+ --zero-fill-grads, --wgrad-layout 1)
+#   files        tools/gpu_files_throughput.py (files -> depth maps, native decoder, batch-8 graph)
+#   pmc          FETCH_SIZE / WRITE_SIZE passes + kernel stats over the step runner (layout of tools/summarize_profile.py)
+#   prof         rocprofv3 --kernel-trace --stats over bench.py --steps 10 --no-cpu-baseline
+#   costvol      tools/gpu_costvol_probe.py at batch 1 and 8 with dirtied caches (all BASELINE configs)
+#   cmd          runs "$GPU_RUN_CMD" (one-off experiments without a new script)
+TAG=${1:-run}; shift
+ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOTDIR/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOTDIR
+export TMPDIR=/tmp
+PASSED=""
+ALL=""
+
+stage_native () {
+  [ -x tools/probes/bin/conv11_prob_check ] || bash tools/native/build.sh > $OUT/native_build.txt 2>&1
+  { for pair in ${NATIVE_CHECKS:-"zmarch:conv0_zm_check:2" "fnet_conv0:fnet_conv0_check:" "deconv11:deconv11_check:2" "deconv9:deconv9_check:2" "tail:conv11_prob_check:2"}; do
+      name=${pair%%:*}; rest=${pair#*:}; c=${rest%%:*}; arg=${rest#*:}
+      [ -x tools/probes/bin/$c ] || continue
+      timeout 90 tools/probes/bin/$c $arg; rc=$?; echo "-- $c: exit $rc"; [ $rc -eq 0 ] && PASSED="$PASSED $name"
+    done
+    for c in prob_wgrad_check fusion_check; do [ -x tools/probes/bin/$c ] && timeout 30 tools/probes/bin/$c; done
+    echo "== passed their native checks:$PASSED"; } > $OUT/native.txt 2>&1
+  echo "$PASSED" > $OUT/native_passed.txt
+  tail -40 $OUT/native.txt
+}
+
+stage_step () { timeout 90 python tools/notorch/step_runner.py --batch ${STEP_BATCH:-8} $STEP_ARGS > $OUT/step.txt 2>&1; tail -30 $OUT/step.txt; }
+
+stage_experimental () {
+  PASSED=$(cat $OUT/native_passed.txt 2>/dev/null)
+  { for x in $PASSED; do
+      echo "== --experimental $x"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $x | tail -4
+      [ $x = zmarch ] && for y in zmarch32 xshift zmarch,xshift; do echo "== --experimental $y"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $y | tail -4; done
+      ALL="$ALL,$x"
+    done
+    ALL=${ALL#,}
+    echo "$PASSED" | grep -qw tail && ALL=$(echo "$ALL" | sed 's/deconv11,//; s/,deconv11$//; s/^deconv11$//')
+    [ -n "$ALL" ] && { echo "== --experimental $ALL"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $ALL | tail -4; }; } > $OUT/experimental.txt 2>&1
+  echo "$ALL" > $OUT/experimental_set.txt
+  cat $OUT/experimental.txt
+}
+
+stage_probes () {
+  for b in ${PROBE_BINS:-mfma_coresidency_repro}; do
+    [ -x tools/probes/bin/$b ] && { timeout 120 tools/probes/bin/$b $PROBE_ARGS > $OUT/probe_$b.txt 2>&1; echo "-- $b: exit $?" >> $OUT/probe_$b.txt; tail -25 $OUT/probe_$b.txt; }
+  done
+}
+
+stage_bench () {
+  nproc > $OUT/host.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host.txt 2>/dev/null; lscpu | grep -E "Model name|^CPU\(s\)" | cut -c1-200 >> $OUT/host.txt
+  timeout 600 python bench.py --steps 20 --warmup 5 $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err
+  echo "bench exit: $?"; tail -3 $OUT/bench.err; cut -c1-1500 $OUT/bench.json
+}
+
+stage_configs () {
+  for cfg in dtu_640x512_v3_gwc8 dtu_1152x864_v5_var blended_768x576_v7_var; do
+    timeout 400 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline $CONFIG_ARGS > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
+    cut -c1-400 $OUT/bench_$cfg.json
+  done
+}
+
+stage_suite () {
+  timeout ${SUITE_TIMEOUT:-1500} python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider $SUITE_ARGS > $OUT/pytest_gpu.log 2>&1
+  echo "pytest exit: $?" >> $OUT/pytest_gpu.log; tail -15 $OUT/pytest_gpu.log
+}
+
+stage_smoke () { timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke exit: $?" >> $OUT/smoke.txt; tail -4 $OUT/smoke.txt; }
+
+stage_train () {
+  timeout 400 python bench.py --mode train --steps 20 --warmup 5 > $OUT/bench_train.json 2> $OUT/bench_train.err
+  for v in ${TRAIN_VARIANTS:-"--zero-fill-grads" "--wgrad-layout 1"}; do
+    n=$(echo $v | tr -d ' -'); timeout 400 python bench.py --mode train --steps 20 --warmup 5 $v > $OUT/bench_train_$n.json 2> $OUT/bench_train_$n.err
+  done
+  grep -ho '"train_step_ms": [0-9.]*' $OUT/bench_train*.json
+}
+
+stage_files () {
+  FT_BATCH=8 FT_GRAPH=1 timeout 300 python tools/gpu_files_throughput.py 49 16 32 > $OUT/files_b8_graph.txt 2>&1
+  FT_BATCH=8 FT_GRAPH=1 FT_THREADED=1 timeout 300 python tools/gpu_files_throughput.py 49 16 32 > $OUT/files_b8_graph_stager.txt 2>&1
+  tail -4 $OUT/files_b8_graph*.txt
+}
+
+stage_pmc () {
+  BATCH=${PMC_BATCH:-8}
+  RUN="python $ROOTDIR/tools/notorch/step_runner.py --batch $BATCH --steps 3 --warmup 1 $STEP_ARGS"
+  run_pmc () { name=$1; shift
+    (cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o pmc -- $RUN > $OUT/$name.log 2>&1)
+    find $OUT/$name -type f -size +8M -delete 2>/dev/null; }
+  run_pmc pmc_fetch FETCH_SIZE
+  run_pmc pmc_write WRITE_SIZE
+  (cd /tmp && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o stats -- $RUN > $OUT/prof.log 2>&1)
+  find $OUT/prof -name "*.db" -delete 2>/dev/null; find $OUT/prof -type f -size +4M -delete 2>/dev/null
+  date -u +%Y-%m-%dT%H:%MZ > $OUT/collected.txt
+  sha256sum casmvsnet_pl_amd/libcasmvs_hip.so | cut -c1-64 > $OUT/library_sha256.txt
+  echo "PMC_CMD_NOTE=\"$RUN\" PMC_BATCH=$BATCH PMC_DATE=$(cat $OUT/collected.txt)" > $OUT/summarize_env.txt
+  ls $OUT/pmc_fetch $OUT/pmc_write $OUT/prof | head -12; tail -2 $OUT/pmc_fetch.log
+}
+
+stage_prof () {
+  (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o stats -- python $ROOTDIR/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch1 > $OUT/bench_under_rocprof.json 2> $OUT/prof_bench.log)
+  find $OUT/prof_bench -name "*.db" -delete 2>/dev/null; find $OUT/prof_bench -type f -size +4M -delete 2>/dev/null
+  cut -c1-300 $OUT/bench_under_rocprof.json
+}
+
+stage_costvol () {
+  for b in 1 8; do CV_PROBE_DIRTY=512 timeout 300 python tools/gpu_costvol_probe.py $b > $OUT/costvol_probe_b$b.txt 2>&1; tail -30 $OUT/costvol_probe_b$b.txt; done
+}
+
+stage_cmd () { bash -c "$GPU_RUN_CMD" > $OUT/cmd.txt 2>&1; echo "cmd exit: $?" >> $OUT/cmd.txt; tail -${CMD_TAIL:-60} $OUT/cmd.txt; }
+
+for s in "$@"; do
+  echo "===== stage $s ($(date -u +%H:%M:%S))"
+  case $s in
+    native|step|experimental|probes|bench|configs|suite|smoke|train|files|pmc|prof|costvol|cmd) stage_$s ;;
+    *) echo "unknown stage $s" ;;
+  esac
+done
+echo "===== done ($(date -u +%H:%M:%S))"
