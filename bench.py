@@ -5,13 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one forward pass (FeatureNet + 3 cascade levels) over one batch of --batch reference views (default 2, the
-reference's DTU training batch; `--batch 1` is its eval.py loop and is ALSO measured and printed as "batch1", with its own
-roofline objects) with their source views: DTU 640x512, 3 views, n_depths [8,32,48], variance cost volume, fp32,
-synthetic inputs already resident in HBM, random-init weights.  The timed steps replay the forward as one hipGraph
-(casmvsnet_pl_amd/graph.py; `--no-graph` launches kernel by kernel), and --streams (default 2) independent forwards are
-in flight per GPU, each on its own HIP stream: a step is then one round of all of them (reference views are independent,
-eval.py:213); the single-stream figure is measured and printed beside it ("single_stream").
+A "step" is one forward pass (FeatureNet + 3 cascade levels) over one batch of --batch reference views (default 8: independent
+reference views batched like the reference's train.py --batch_size; `--batch 1` is its eval.py loop and is ALSO measured and
+printed as "batch1", with its own roofline objects) with their source views: DTU 640x512, 3 views, n_depths [8,32,48], variance
+cost volume, float32 tensors, synthetic inputs already resident in HBM, random-init weights.  The timed steps replay the forward as
+ONE hipGraph on ONE stream (casmvsnet_pl_amd/graph.py; `--no-graph` launches kernel by kernel).  `--streams N` > 1 puts N independent
+forwards in flight, each on its own HIP stream - those replicas run every layer on the float32 MFMA kernels (graph.ConcurrentForwards);
+that configuration (2 streams x batch 2) is measured and printed beside the headline as `two_streams_float32`.
 
 `value` = depth maps of all ranks / the max-over-ranks wall time of EXACTLY K steps (barrier + synchronize on both
 sides); `median_ms_per_step` (the median of the timed iterations) comes from one HIP event per step recorded
@@ -22,9 +22,15 @@ granularity, SURVEY 8e: no data-path collective) -> weak scaling.  --mode view_s
 work on the same depth maps, each warps its share of the source views and the sum / sum-of-squares volumes are
 all-reduced over RCCL once per level -> strong scaling.  --mode train: the reference's training step (train.py:99-127:
 train-mode forward, SL1 loss, backward, SGD) through the HIP training path; prints `train_step_ms` (metric:
-samples/s), no roofline objects.
+samples/s), no roofline objects.  The default line carries the same measurement as `train_step` (20 hipGraph replays of
+the batch-1 training step, ~0.3 s; --no-train-step skips it).
 
-Prints ONE JSON line (rank 0).  The `roofline*` objects come from HIP events recorded on the launch stream around
+Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (CostRegNet.conv0, three launches per step) against the roof that
+binds it: HBM - `achieved` = its ALGORITHMIC bytes (input + output volume of each launch) / its HIP-event time, `frac` against 8 TB/s;
+`traffic` = the kernel's PMC bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) when the committed PMC passes were collected on THIS build
+of the library (sha256 checked), else null; `roofline.mfma` holds the matrix-core view of the same launches (the f16 FLOPs they
+execute against the dense f16 peak, and `fp32_equivalent`: the layer's float32 FLOPs against the float32 MFMA peak, the figure earlier
+rounds led with - it is NOT a roofline fraction for a kernel that multiplies on the f16 cores).  The `roofline*` objects come from HIP events recorded on the launch stream around
 every kernel in an instrumented eager pass over the same inputs right after the timed steps (events cannot be recorded
 into a graph replay; same kernels, same shapes); `cpu_baseline` is the reference's own forward (/root/reference +
 import shims, kind "reference") when that tree exists, else the oracle (a CPU port of it, oracle/cpu_restatement.py,
@@ -50,7 +56,7 @@ from casmvsnet_pl_amd.synthetic import CONFIGS, config_inputs, randomize_state_d
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA dense peak (MI355X_MICROARCH.md)
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # bf16 MFMA dense peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # f16 / bf16 MFMA dense peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 LAYER_NAMES = ["conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "conv9", "conv11", "prob"]
 HEADLINE = "dtu_640x512_v3_var"
 
@@ -95,10 +101,16 @@ def library_sha16():
         return None
 
 
+def source_sha16():
+    """sha256[:16] of the sources + flags the running library was compiled from (casmvsnet_pl_amd/build.py)."""
+    from casmvsnet_pl_amd.build import source_sha16 as f
+    return f()
+
+
 def pmc_traffic(kernel_prefix, batch):
     """HBM-side bytes per launch of one kernel from the newest committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    need a pass each and cannot be collected inside a timed run; tools/gpu_final.sh collects them in the same gpurun
-    call as the bench line it commits, at batch 2): mean over the kernel's launches, read bytes corrected x2 as
+    need a pass each and cannot be collected inside a timed run; `tools/gpu_run.sh <tag> pmc` collects them over the torch-free step runner
+    on the same build of the library): mean over the kernel's launches, read bytes corrected x2 as
     MI355X_MICROARCH.md prescribes.  -> (bytes | None, note, source) - `source` says which file, when it was collected
     and whether the library that produced it is the one running now (`same_library`)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
@@ -113,10 +125,15 @@ def pmc_traffic(kernel_prefix, batch):
         return None, f"the PMC passes of {os.path.relpath(path, ROOT)} were collected at batch {meta.get('batch') or 2}, this run uses batch {batch}", None
     prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
     rows = [r for r in doc if r["kernel"].startswith(prefixes)]
+    # the same kernels = the same sources and flags (hipcc's binaries are not bit-reproducible: the .so hash only says "the same file")
+    same = (meta.get("source_sha16") == source_sha16()) if meta.get("source_sha16") else ((meta.get("library_sha16") == library_sha16()) if meta.get("library_sha16") else None)
     source = {"file": os.path.relpath(path, ROOT), "collected": meta.get("collected"), "library_sha16": meta.get("library_sha16"),
-              "same_library": (meta.get("library_sha16") == library_sha16()) if meta.get("library_sha16") else None}
+              "source_sha16": meta.get("source_sha16"), "same_library": same}
     if not rows:
         return None, "kernel not in " + os.path.relpath(path, ROOT), source
+    if not source["same_library"]:
+        return None, (f"{os.path.relpath(path, ROOT)} was collected on other kernel sources (source sha256 {meta.get('source_sha16')}, this run "
+                      f"{source_sha16()}): not reported"), source
     n = sum(r["launches"] for r in rows)
     mb = sum((r["read_mb_corrected"] + r["write_mb"]) * r["launches"] for r in rows) / n
     return mb * 1e6, f"bytes per launch (read + write, mean over the 3 cascade levels) from {os.path.relpath(path, ROOT)}", source
@@ -136,11 +153,11 @@ def aggregate(elapsed_local, maps_local, dist=None, device=None, sum_maps=True):
     return float(te.item()), int(tm.item())
 
 
-def base_line(metric, unit, value, world, steps, warmup, elapsed, scaling, config, median_ms=None):
+def base_line(metric, unit, value, world, steps, warmup, elapsed, scaling, config, median_ms=None, dtype="f32"):
     """The driver's JSON contract (one line, rank 0)."""
     line = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "config": config}
+            "dtype": dtype, "data": "synthetic", "config": config}
     if median_ms is not None:
         line["median_ms_per_step"] = median_ms
     return line
@@ -338,31 +355,47 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
     work = algorithmic_work(H, W, V, G, n_depths, B)
     per_step = {k: v["ms"] / n_ev for k, v in summ.items()}
     out = {}
-    # dominant kernel: conv16db_kernel<PX> = CostRegNet.conv0 (3 launches per step)
+    # dominant kernel: CostRegNet.conv0 (3 launches per step).  What binds it: with its products on the f16 matrix cores the layer's
+    # HBM time (input + output volume once, 8 TB/s) and its matrix time (3 partial products x 4/3 K padding at 2.5 PFLOP/s) are about equal
+    # (0.25 / 0.23 ms at level 1, batch 8) - the larger one, HBM, is the roof the fraction is quoted against; the matrix view sits beside it.
     conv0_ms = sum(summ[f"costreg_{l}/conv0"]["ms"] for l in range(3))
     conv0_flops = sum(work[l]["conv0_flops"] for l in range(3)) * n_ev
     ach = conv0_flops / (conv0_ms * 1e-3) / 1e12
-    mode = getattr(model.cost_reg_0, "conv0_mode", "f32")
+    mode = getattr(model.cost_reg_0, "_conv0_active", None) or "f32"
     split = mode if mode in ("splitbf16", "splitf16") and getattr(model, "fuse_regress", False) and G in (1, 8) else None
-    kname = {"splitbf16": "conv0_sb_kernel", "splitf16": "conv0_sf_kernel", None: "conv16db_kernel<2, 4, 4, 4, 4, 32"}[split]
-    traffic, traffic_note, src = pmc_traffic(kname, B if cfg_name == HEADLINE else None)
-    conv0_alg = sum(4 * B * ((G if G > 1 else 8 * 2 ** l) + 8) * n_depths[l] * (H >> l) * (W >> l) for l in range(3)) / 3
+    knames = {"splitbf16": ("conv0_sb_kernel",), "splitf16": ("conv0_sf_kernel", "conv0_zm_kernel"), None: ("conv16db_kernel<2, 4, 4, 4, 4, 32",)}[split]
+    traffic, traffic_note, src = pmc_traffic(knames, B if cfg_name == HEADLINE else None)
+    conv0_alg = sum(4 * B * ((G if G > 1 else 8 * 2 ** l) + 8) * n_depths[l] * (H >> l) * (W >> l) for l in range(3))   # bytes per step: input + output volumes
+    gbs = conv0_alg * n_ev / (conv0_ms * 1e-3) / 1e9
+    avg_launch_s = conv0_ms * 1e-3 / (3 * n_ev)
     out["roofline"] = {"kernel": {"splitbf16": "conv0_sb_kernel<CIN, 6> (CostRegNet.conv0 on the bf16 matrix cores, float32 operands as three exact "
                                                "bf16 slices; 3 launches per step)",
-                                  "splitf16": "conv0_sf_kernel<CIN, 3> (CostRegNet.conv0 on the f16 matrix cores, float32 operands as two float16 slices "
-                                              "behind exact power-of-two scalings; 3 launches per step)",
-                                  None: "conv16db_kernel<PX> (CostRegNet.conv0: Cout 8, stride 1; 3 launches per step)"}[split],
-                       "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                       "traffic_note": traffic_note + f"; algorithmic bytes per launch (mean of the 3 levels): {conv0_alg:.4g}",
-                       "traffic_source": src, "avg_launch_ms": conv0_ms / (3 * n_ev), "batch": B,
-                       "peak_note": "achieved = the layer's ALGORITHMIC float32 FLOPs (2 * 27 * cin * 8 per voxel) / its HIP-event time; peak = the "
-                                    "float32 MFMA dense peak (the arithmetic the path computes in)"}
+                                  "splitf16": "CostRegNet.conv0 on the f16 matrix cores (float32 operands as two float16 slices behind exact power-of-two "
+                                              "scalings), 3 launches per step: conv0_sf_kernel<8, 3> (level 0), conv0_zm_kernel<16> (level 1, "
+                                              "input-stationary along z), conv0_sf_kernel<32, 3> (level 2)",
+                                  None: "conv16db_kernel<PX> (CostRegNet.conv0 on the float32 MFMA: Cout 8, stride 1; 3 launches per step)"}[split],
+                       "bound": "hbm" if split else "mfma", "batch": B, "avg_launch_ms": conv0_ms / (3 * n_ev)}
+    hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": conv0_alg / 3,
+           "note": "achieved = ALGORITHMIC bytes (each launch reads its input volume and writes its 8-channel output once; mean of the 3 levels) / HIP-event time"}
+    mfma_view = {"fp32_equivalent": {"achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "ratio": ach / MFMA_F32_PEAK_TFLOPS,
+                                     "note": "the layer's ALGORITHMIC float32 FLOPs (2 * 27 * cin * 8 per voxel) / time over the float32 MFMA peak: comparable "
+                                             "across rounds; a roofline fraction only when conv0 runs on the float32 MFMA (conv0_other_modes)"}}
     if split:   # what the matrix cores actually execute: 6 bf16 (3 f16) products per float32 product, 4 K-slots per 3 taps
         mult = {"splitbf16": 8.0, "splitf16": 4.0}[split]
-        out["roofline"]["executed"] = {"dtype": {"splitbf16": "bf16", "splitf16": "f16"}[split], "flops_per_algorithmic_flop": mult, "achieved": mult * ach,
-                                       "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mult * ach / MFMA_BF16_PEAK_TFLOPS,
-                                       "note": "the dense bf16 and f16 matrix peaks are equal (2.5 PFLOP/s)"}
+        mfma_view["executed"] = {"dtype": {"splitbf16": "bf16", "splitf16": "f16"}[split], "flops_per_algorithmic_flop": mult, "achieved": mult * ach,
+                                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mult * ach / MFMA_F16_PEAK_TFLOPS,
+                                 "note": "the dense bf16 and f16 matrix peaks are equal (2.5 PFLOP/s)"}
+        out["roofline"].update(hbm)
+    else:
+        out["roofline"].update({"achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "hbm": hbm})
+    out["roofline"]["mfma"] = mfma_view
+    out["roofline"]["traffic"] = traffic
+    out["roofline"]["traffic_note"] = traffic_note
+    out["roofline"]["traffic_source"] = src
+    if traffic is not None:
+        out["roofline"]["traffic_frac"] = traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS     # counter bytes / time over the HBM peak
+        out["roofline"]["traffic_over_algorithmic"] = traffic / (conv0_alg / 3)
     cr_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("costreg_"))
     cr_flops = sum(work[l]["costreg_flops"] for l in range(3)) * n_ev
     fused = getattr(model, "fuse_regress", False)
@@ -386,7 +419,7 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
                                "ms_per_depth_map": cv_ms / n_ev / B, "batch": B,
                                "per_level_frac": {str(l): work[l]["costvol_bytes"] * n_ev / (summ[f"costvol_{l}"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS for l in range(3)}}
     if fused:
-        pr_ms = max(1e-6, sum(summ[f"costreg_{l}/prob"]["ms"] for l in range(3)))   # --experimental tail: the interval is empty (the walk is inside conv11's kernel)
+        pr_ms = max(1e-6, sum(summ[f"costreg_{l}/prob"]["ms"] for l in range(3)))
         pr_bytes = sum(work[l]["prob_regress_bytes"] for l in range(3)) * n_ev
         out["roofline_prob_regress"] = {"kernel": "prob_zwalk_kernel (+ softmax_regress_kernel where the depth range is chunked): the `prob` head "
                                                   "and mvsnet.py:174-193, 3 library calls per step", "bound": "hbm",
@@ -506,6 +539,21 @@ def train_mode(args, dev, world, rank, dist, barrier):
     return line
 
 
+def torchrun_command(n, argv, port=None):
+    """The contract's launch line for N ranks on one node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or os.environ.get("MASTER_PORT", 29531)), os.path.abspath(__file__)] + list(argv)
+
+
+def relaunch_under_torchrun(n, argv):
+    import subprocess
+    avail = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if avail < n:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {avail} GPU(s)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(torchrun_command(n, argv), env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -542,18 +590,15 @@ def main():
     ap.add_argument("--wgrad-layout", type=int, default=0, choices=[0, 1],
                     help="--mode train A/B: 1 = the weight-gradient kernel's conflict-free LDS layout (casmvs_conv_wgrad_x_f32, written without a GPU run)")
     ap.add_argument("--zero-fill-grads", action="store_true", help="--mode train A/B: optimizer.zero_grad(set_to_none=False) as before round 3's last session")
-    ap.add_argument("--experimental", default=os.environ.get("CASMVS_EXPERIMENTAL", ""),
-                    help="comma-separated opt-in kernels (written at the end of round 3, DESIGN.md section 6): CostRegNet zmarch / zmarch32 / xshift / deconv9 / "
-                         "deconv11 / tail, FeatureNet fnet_conv0; named in the line's config.experimental - a line with this set is an A/B, not the headline")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` object of the default line (20 hipGraph replays of the batch-1 training step)")
     args = ap.parse_args()
-    args.experimental = sorted(x for x in args.experimental.split(",") if x)
-    unknown = set(args.experimental) - {"zmarch", "zmarch32", "xshift", "deconv9", "deconv11", "tail", "fnet_conv0"}
-    if unknown:
-        raise SystemExit(f"--experimental: unknown {sorted(unknown)}")
     args.batch_given = args.batch is not None
     if args.batch is None:
         args.batch = 8
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU over RCCL, the contract's launch line)
+        sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -602,10 +647,6 @@ def main():
                 getattr(model, f"cost_reg_{l}").conv0_mode = mode
                 getattr(model, f"cost_reg_{l}").ci_mode = "splitf16" if mode == "splitf16" else "f32"
             model.feature.tail_mode = "splitf16" if mode == "splitf16" else "f32"
-        if args.experimental:
-            for l in range(3):
-                getattr(model, f"cost_reg_{l}").experimental = set(args.experimental) - {"fnet_conv0"}
-            model.feature.experimental = {"conv0_fused"} if "fnet_conv0" in args.experimental else set()
         # replica: every rank works on its own depth maps (different seeds -> different images / cameras);
         # view_sharded: all ranks share the depth maps and split their source views
         imgs, proj, dmin, dint = config_inputs(args.config, B, seed=0 if view_sharded else rank)
@@ -654,24 +695,29 @@ def main():
                                           "sum-of-squares volumes per level, every rank regularises") if view_sharded else
                                          f"replica x{world} (one depth map stream per GPU, no data-path collective)",
                           "feature_net": "HIP MFMA kernels (casmvs_featurenet_forward_f32)",
-                          **({"experimental": args.experimental} if args.experimental else {}),
                           "regression": "fused into the `prob` head's library call (casmvs_costreg_regress_f32)" if model.fuse_regress else "separate launch",
                           "conv0_arithmetic": {"splitbf16": "float32 operands as three exact bf16 slices, six bf16 x bf16 partial products per product on the "
                                                             "bf16 matrix cores, float32 accumulation (conv0_splitbf16.hip)",
                                                "splitf16": "float32 operands as two float16 slices (22 significand bits) behind exact power-of-two scalings, "
                                                            "three f16 x f16 partial products per product on the f16 matrix cores, float32 accumulation "
-                                                           "(conv0_splitf16.hip); float32-grade: distance to a float64 convolution at or below the "
-                                                           "float32 MFMA kernel's",
+                                                           "(conv0_splitf16.hip; cin = 16 = cascade level 1 on the z-marching kernel conv0_zmarch.hip); "
+                                                           "float32-grade: distance to a float64 convolution at or below the float32 MFMA kernel's",
                                                "f32": "float32 MFMA (v_mfma_f32_16x16x4_f32)"}[model.cost_reg_0.conv0_mode],
-                          "conv2_conv4_conv6_arithmetic": "as conv0's split-f16 (conv_ci_splitf16.hip); conv4 / conv6 only where the volume gives >= 100 tiles "
-                                                          "(conv6: >= 3 planes)" if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA",
+                          "conv2_conv4_conv6_conv9_conv11_arithmetic": "as conv0's split-f16 (conv_ci_splitf16.hip, deconv9_splitf16.hip, deconv11_splitf16.hip); "
+                                                                       "conv4 / conv6 only where the volume gives >= 100 tiles (conv6: >= 3 planes); conv1 / conv3 / "
+                                                                       "conv5 / conv7 and `prob` float32" if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA",
+                          "per_gpu_engine": f"one stream, batch {B}, one hipGraph replay per step, split-f16 layer set (what every rank of a replica run executes)"
+                                            if used_graph and NS == 1 and model.cost_reg_0.conv0_mode == "splitf16" else "see launch / *_arithmetic",
                           "featurenet_arithmetic": ("fused FPN tail, conv1.1 / conv1.2 / conv2.1 / conv2.2 / smooth1 as conv0's split-f16 (fpn_fused_sf.hip, "
                                                     "conv2d_ci_splitf16.hip); the other layers float32 MFMA" if model.feature.tail_mode == "splitf16"
                                                     else "float32 MFMA (fused FPN tail: fpn_fused.hip)")
                                                    if model.feature.fuse_tail else "float32 MFMA, the FPN tail as three steps (lat0, upsample-add, smooth0)",
                           "every_layer_float32_value": "conv0_other_modes.modes[conv0_mode == 'f32'] of this line"},
-                         median)
+                         median,
+                         dtype="f32" if model.cost_reg_0.conv0_mode == "f32" and model.cost_reg_0.ci_mode == "f32" and model.feature.tail_mode == "f32" else
+                               "f32 (tensors and accumulation float32; products of CostRegNet's conv0 / 2 / 4 / 6 / 9 / 11 and six FeatureNet layers formed on the f16 matrix cores from two float16 slices per operand)")
         line["library_sha16"] = library_sha16()
+        line["source_sha16"] = source_sha16()
 
     # ---- instrumented eager pass: HIP events around every kernel (same model, same inputs) ------------------------
     if not args.no_events:
@@ -727,6 +773,20 @@ def main():
             if rank == 0:
                 line["batch1"]["concurrent"] = {"value": mp1s / el1s, "unit": "depth-maps/s", "ms_per_step": 1e3 * el1s / K,
                                                 "note": f"{NS} single-view forwards in flight, one stream each"}
+    if world == 1 and args.mode == "replica" and args.config == HEADLINE and not args.no_train_step:
+        # f-2 (train.py:99-127) in the driver's line: the batch-1 training step as one hipGraph replay, 20 timed replays (~0.3 s)
+        torch.cuda.empty_cache()
+        targs = argparse.Namespace(**vars(args))
+        targs.batch, targs.batch_given, targs.steps, targs.warmup, targs.no_graph = 1, False, 20, 3, False
+        try:
+            tl = train_mode(targs, dev, 1, 0, None, barrier)
+            line["train_step"] = {"train_step_ms": tl["train_step_ms"], "samples_per_s": tl["value"], "median_ms_per_step": tl.get("median_ms_per_step"),
+                                  "steps": 20, "peak_memory_gib": tl["peak_memory_gib"], "config": tl["config"],
+                                  "note": "the reference's training step (train.py:99-127: train-mode forward with batch-statistics InPlaceABN, SL1 loss, "
+                                          "backward, SGD) on the same 640x512 x 3-view workload, batch 1, one hipGraph replay per step; "
+                                          "`python bench.py --mode train` prints it as its own line"}
+        except Exception as e:   # the inference line must not be lost to the extra measurement
+            line["train_step"] = {"error": f"{type(e).__name__}: {str(e).splitlines()[0][:300]}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)

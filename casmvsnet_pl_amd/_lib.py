@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # CASMVS_LIB_PATH: load another BUILD of the same library (profiling: -DCASMVS_TRACE, compiler-flag A/B runs)
 LIB_PATH = os.environ.get("CASMVS_LIB_PATH") or os.path.join(_PKG_DIR, "libcasmvs_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
 CONV2D_K3, CONV2D_K5S2, CONV2D_K1, CONV2D_K1_UP = 3, 4, 5, 6
@@ -51,10 +51,6 @@ SYMBOLS = {
     "casmvs_conv0_splitf16_supported": (c_int, [c_int, c_int]),
     "casmvs_conv0_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_selftest_mfma_f16": (c_int, [_FP]),
-    "casmvs_fnet_conv0_fused_packed_bytes": (c_size_t, []),
-    "casmvs_fnet_conv0_fused_pack": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
-    "casmvs_fnet_conv0_fused_supported": (c_int, [c_int]),
-    "casmvs_fnet_conv0_fused_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_deconv9_splitf16_packed_bytes": (c_size_t, []),
     "casmvs_deconv9_splitf16_pack": (c_int, [_FP, _FP, _FP, c_void_p]),
     "casmvs_deconv9_splitf16_supported": (c_int, [c_int]),
@@ -65,9 +61,6 @@ SYMBOLS = {
     "casmvs_deconv11_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_conv0_zmarch_supported": (c_int, [c_int, c_int]),
     "casmvs_conv0_zmarch_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "casmvs_conv0_zmarch_forward_x_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
-    "casmvs_conv0_splitf16_forward_x_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
-    "casmvs_debug_disturb": (c_int, [c_int, c_int, c_int, c_int, _FP, c_void_p]),
     "casmvs_conv_ci_splitf16_packed_bytes": (c_size_t, [c_int, c_int]),
     "casmvs_conv_ci_splitf16_pack": (c_int, [c_int, c_int, _FP, _FP, _FP, c_void_p]),
     "casmvs_conv_ci_splitf16_supported": (c_int, [c_int, c_int, c_int]),
@@ -89,14 +82,10 @@ SYMBOLS = {
     "casmvs_conv2d_ci_splitf16_supported": (c_int, [c_int, c_int, c_int]),
     "casmvs_conv2d_ci_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_featurenet_forward_fused_f32": (c_int, [POINTER(c_void_p), c_void_p, c_int, _FP, POINTER(c_void_p), _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
-    "casmvs_featurenet_forward_fused_x_f32": (c_int, [POINTER(c_void_p), c_void_p, c_int, _FP, POINTER(c_void_p), _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p, c_void_p]),
     "casmvs_softmax_regress_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_prob_regress_supported": (c_int, [c_int, c_int]),
     "casmvs_prob_regress_f32": (c_int, [_FP] * 7 + [c_int] * 5 + [c_float, c_int, c_void_p]),
     "casmvs_costreg_regress_f32": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
-    "casmvs_costreg_regress_x_f32": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_int]),
-    "casmvs_conv11_prob_regress_supported": (c_int, [c_int, c_int, c_int]),
-    "casmvs_conv11_prob_regress_f32": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_depth_regression_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_fuse_reference_view": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_fuse_reference_view_paired": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
@@ -125,6 +114,11 @@ SYMBOLS = {
     "casmvs_selftest_mfma_rate": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),
 }
 
+# exported by -DCASMVS_TRACE builds only (tools/build_trace_lib.sh; select the build with CASMVS_LIB_PATH): bound when present
+TRACE_SYMBOLS = {
+    "casmvs_debug_disturb": (c_int, [c_int, c_int, c_int, c_int, _FP, c_void_p]),
+}
+
 _lib = None
 
 
@@ -146,6 +140,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
+    for name, (restype, argtypes) in TRACE_SYMBOLS.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = restype, argtypes
     got = lib.casmvs_abi_version()
     if got != ABI_VERSION:
         raise CasMVSLibraryError(f"libcasmvs_hip.so ABI version {got}, binding expects {ABI_VERSION}")

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcasmvs_hip.so")
-SOURCES = ["abi.hip", "costvol.hip", "costvol_lds.hip", "depth_ops.hip", "fusion.hip", "backward.hip", "train.hip", "prob_wgrad.hip", "prob_regress.hip", "fpn_fused.hip", "fpn_fused_sf.hip", "fnet_conv0_fused.hip", "conv0_splitbf16.hip", "conv0_splitf16.hip", "conv0_zmarch.hip", "deconv11_splitf16.hip", "deconv9_splitf16.hip", "conv11_prob_fused.hip", "conv_ci_splitf16.hip", "conv2d_ci_splitf16.hip", "debug_disturb.hip", "conv3d_mfma.hip"]
+SOURCES = ["abi.hip", "costvol.hip", "costvol_lds.hip", "depth_ops.hip", "fusion.hip", "backward.hip", "train.hip", "prob_wgrad.hip", "prob_regress.hip", "fpn_fused.hip", "fpn_fused_sf.hip", "conv0_splitbf16.hip", "conv0_splitf16.hip", "conv0_zmarch.hip", "deconv11_splitf16.hip", "deconv9_splitf16.hip", "conv_ci_splitf16.hip", "conv2d_ci_splitf16.hip", "debug_disturb.hip", "conv3d_mfma.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "plane_sweep.h", "buffer_ops.h", "softmax_regress.h", "split_f16.h")] + [os.path.join(REPO_ROOT, "include", "casmvs.h")]
 
 
@@ -27,6 +27,19 @@ IO_HEADERS = [os.path.join(REPO_ROOT, "include", "casmvs_io.h")]
 IO_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra"]
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+
+
+def source_sha16():
+    """First 16 hex digits of a sha256 over everything the device code is compiled from (the .hip sources, their headers, the C header, the
+    compiler flags): equal hashes = the same kernels, whichever machine linked the .so (hipcc's output is not bit-reproducible across
+    builds, so the binary's own hash cannot say that).  Stamps the PMC files and the bench line (bench.py: traffic_source.same_library)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in sorted(_sources() + HEADERS):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def build_library(force=False, verbose=False, extra_flags=(), lib_path=None, obj_dir=None):
@@ -54,11 +67,12 @@ def build_library(force=False, verbose=False, extra_flags=(), lib_path=None, obj
             raise RuntimeError(f"hipcc failed on {src}:\n" + out)
     if not jobs and os.path.isfile(lib_path) and os.path.getmtime(lib_path) >= max(os.path.getmtime(o) for o in objs):
         return lib_path
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path + ".tmp"]
+    tmp = f"{lib_path}.{os.getpid()}.tmp"   # per-process name: two ranks building at once never write the same file; os.replace is atomic
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + res.stdout)
-    os.replace(lib_path + ".tmp", lib_path)
+    os.replace(tmp, lib_path)
     return lib_path
 
 
@@ -68,13 +82,18 @@ def build_io_library(force=False, verbose=False, lib_path=None):
     newest = max(os.path.getmtime(f) for f in IO_SOURCES + IO_HEADERS)
     if not force and os.path.isfile(lib_path) and os.path.getmtime(lib_path) >= newest:
         return lib_path
-    cmd = [os.environ.get("CXX", "g++")] + IO_FLAGS + ["-I" + os.path.join(REPO_ROOT, "include")] + IO_SOURCES + ["-o", lib_path + ".tmp"]
+    # _io.load() builds on first use: several ranks / DataLoader workers of a fresh checkout may get here together.  Each compiles into its OWN
+    # temporary file and installs it with an atomic rename - a reader sees the old complete library or a new complete one, never a partial file.
+    tmp = f"{lib_path}.{os.getpid()}.tmp"
+    cmd = [os.environ.get("CXX", "g++")] + IO_FLAGS + ["-I" + os.path.join(REPO_ROOT, "include")] + IO_SOURCES + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
         raise RuntimeError("g++ failed on libcasmvs_io.so:\n" + res.stdout)
-    os.replace(lib_path + ".tmp", lib_path)
+    os.replace(tmp, lib_path)
     return lib_path
 
 

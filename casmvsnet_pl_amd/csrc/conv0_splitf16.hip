@@ -82,12 +82,10 @@ struct SfTile {
 //   ORDER 3: x, then y, then z
 // Measured with tools/native/conv0_ab.cpp (batch 2, dirtied caches, bit-identical outputs; profiles/r03_conv0_tile_order_ab.txt):
 // against order 0, order 1 is +2.6 % at every level, order 2 +4.7 % / 0 / +6.4 % at cin = 32 / 16 / 8, order 3 +2 / -2.6 / 0.
-//   XOFF (0 or a multiple of 4 below TX): the x tile grid starts at XOFF - TX instead of 0 (one more, mostly empty, tile column).  With XOFF = 4 a staged row
-//   - 40 floats from x0 - 4 - starts on a 128-byte line of the volume (W % 32 == 0) and touches TWO lines instead of three: 2/3 of the L1 -> L2
-//   requests that bound this kernel, for ceil((W + 28) / 32) instead of W / 32 tile columns.  Opt-in (casmvs_conv0_splitf16_forward_x_f32).
-template <int ORDER, int XOFF = 0>
+// (round 4: a tile grid shifted by 4 voxels in x - two 128-byte lines per staged row instead of three - was measured on the MI355X and removed:
+// equal at cin 8 / 16, 10 % slower at cin 32, the output rows then straddle two lines; profiles/r04_native_checks_first_run.txt)
+template <int ORDER>
 __device__ __forceinline__ SfTile sf_decode(int v, int total, int tiles_x, int tiles_y, int tiles_z) {
-  constexpr int X0 = XOFF ? XOFF - SfCfg::TX : 0;
   if (ORDER == 2) {
     const int xcd = v & 7, idx = v >> 3;
     if ((idx | 63) < (total >> 3)) v = ((((idx & ~63) | ((idx & 31) << 1) | ((idx >> 5) & 1))) << 3) | xcd;   // a bijection inside full groups of 64 slots
@@ -95,7 +93,7 @@ __device__ __forceinline__ SfTile sf_decode(int v, int total, int tiles_x, int t
   int item = xcd_major(v, total);
   SfTile t;
   if (ORDER == 3) {
-    t.tx0 = (item % tiles_x) * SfCfg::TX + X0;
+    t.tx0 = (item % tiles_x) * SfCfg::TX;
     item /= tiles_x;
     t.ty0 = (item % tiles_y) * SfCfg::TY;
     item /= tiles_y;
@@ -104,14 +102,14 @@ __device__ __forceinline__ SfTile sf_decode(int v, int total, int tiles_x, int t
     return t;
   }
   if (ORDER == 1 || ORDER == 2) {
-    t.tx0 = (item % tiles_x) * SfCfg::TX + X0;
+    t.tx0 = (item % tiles_x) * SfCfg::TX;
     item /= tiles_x;
     t.tz0 = (item % tiles_z) * SfCfg::TZ;
     item /= tiles_z;
   } else {
     t.tz0 = (item % tiles_z) * SfCfg::TZ;
     item /= tiles_z;
-    t.tx0 = (item % tiles_x) * SfCfg::TX + X0;
+    t.tx0 = (item % tiles_x) * SfCfg::TX;
     item /= tiles_x;
   }
   t.ty0 = (item % tiles_y) * SfCfg::TY;
@@ -121,7 +119,7 @@ __device__ __forceinline__ SfTile sf_decode(int v, int total, int tiles_x, int t
 
 // in (B, CIN, D, H, W) float32, W % 4 == 0, 16-byte aligned; wpk: [chunk][kz * 3 + ky][slice][lane] 16-byte lane images, then
 // scale[8] (ABN scale x 2^-kw), shift[8] (float32); out (B, 8, D, H, W).  TERMS: 3 (default) or 4 (+ x_b w_b: A/B of the accuracy).
-template <int CIN, int TERMS, int XOFF = 0>
+template <int CIN, int TERMS>
 __global__ __launch_bounds__(SfCfg::THREADS, 2) void conv0_sf_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
                                                                     float *__restrict__ out, int B, int D, int H, int W, int tiles_x,
                                                                     int tiles_y, int tiles_z, float slope) {
@@ -188,14 +186,14 @@ __global__ __launch_bounds__(SfCfg::THREADS, 2) void conv0_sf_kernel(const float
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int item = blockIdx.x;
-  SfTile cur = sf_decode<ORDER, XOFF>(item, total, tiles_x, tiles_y, tiles_z);
+  SfTile cur = sf_decode<ORDER>(item, total, tiles_x, tiles_y, tiles_z);
   plan(cur);
   prefetch(cur, 0, true, true);
   bool first = true;
   for (;;) {
     const int next_item = item + gridDim.x;
     const bool have_next = next_item < total;
-    const SfTile nxt = have_next ? sf_decode<ORDER, XOFF>(next_item, total, tiles_x, tiles_y, tiles_z) : cur;
+    const SfTile nxt = have_next ? sf_decode<ORDER>(next_item, total, tiles_x, tiles_y, tiles_z) : cur;
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       // ---- the staged tile's largest magnitude (this thread's loads -> wave -> workgroup) ----
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(SfCfg::THREADS, 2) void conv0_sf_kernel(const float
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int oz = cur.tz0 + wave, oy = cur.ty0 + t, ox = cur.tx0 + 2 * jcol;
-      const bool ok = oz < D && oy < H && ox < W && (XOFF == 0 || ox >= 0);   // W even: the pixel pair is inside or outside
+      const bool ok = oz < D && oy < H && ox < W;   // W even: the pixel pair is inside or outside
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float v0 = fmaf(acc[t][2 * h], sc[h], sh[h]), v1 = fmaf(acc[t][2 * h + 1], sc[h], sh[h]);
@@ -370,34 +368,31 @@ extern "C" int casmvs_conv0_splitf16_pack(int cin, const float *weight, const fl
 extern "C" int casmvs_conv0_splitf16_supported(int cin, int W) { return (cin == 8 || cin == 16 || cin == 32) && W % 4 == 0 && W >= 4; }
 
 namespace {
-int conv0_sf_launch(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope, int terms, int x_offset, void *stream) {
+int conv0_sf_launch(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope, int terms, void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(packed && in && out, "conv0_splitf16_forward: null pointer");
   CASMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && casmvs_conv0_splitf16_supported(cin, W), "conv0_splitf16_forward: B=%d cin=%d D=%d H=%d W=%d", B, cin, D, H, W);
   CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(packed)) & 15) == 0, "conv0_splitf16_forward: 16-byte aligned pointers");
   CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 29), "conv0_splitf16_forward: one sample's input tensor must hold < 2^29 floats");
   CASMVS_REQUIRE(terms == 0 || terms == 3 || terms == 4, "conv0_splitf16_forward: terms=%d (0 = 3, 3 or 4)", terms);
-  CASMVS_REQUIRE(x_offset == 0 || (x_offset == 4 && terms != 4), "conv0_splitf16_forward: x_offset=%d (0, or 4 with three terms)", x_offset);
   using Cfg = SfCfg;
-  const int tiles_x = casmvs::ceil_div(W + (x_offset ? Cfg::TX - x_offset : 0), Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY), tiles_z = casmvs::ceil_div(D, Cfg::TZ);
+  const int tiles_x = casmvs::ceil_div(W, Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY), tiles_z = casmvs::ceil_div(D, Cfg::TZ);
   const long total = (long)tiles_x * tiles_y * tiles_z * B;
   CASMVS_REQUIRE(total < (1L << 31), "conv0_splitf16_forward: too many tiles");
   const unsigned char *wp = reinterpret_cast<const unsigned char *>(packed);
   hipStream_t st = (hipStream_t)stream;
-#define CASMVS_SF(CIN, T, XO)                                                                                                   \
+#define CASMVS_SF(CIN, T)                                                                                                       \
   {                                                                                                                             \
-    auto kernel = conv0_sf_kernel<CIN, T, XO>;                                                                                  \
+    auto kernel = conv0_sf_kernel<CIN, T>;                                                                                      \
     if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), Cfg::LDS_BYTES, "conv0_sf_kernel")) return rc; \
     const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), Cfg::THREADS, Cfg::LDS_BYTES);         \
     hipLaunchKernelGGL(kernel, dim3((unsigned)(total < resident ? total : resident)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, in, wp, \
                        out, B, D, H, W, tiles_x, tiles_y, tiles_z, slope);                                                      \
   }
   const bool four = terms == 4;
-  if (x_offset) {
-    if (cin == 8) CASMVS_SF(8, 3, 4) else if (cin == 16) CASMVS_SF(16, 3, 4) else CASMVS_SF(32, 3, 4)
-  } else if (cin == 8) { if (four) CASMVS_SF(8, 4, 0) else CASMVS_SF(8, 3, 0) }
-  else if (cin == 16) { if (four) CASMVS_SF(16, 4, 0) else CASMVS_SF(16, 3, 0) }
-  else { if (four) CASMVS_SF(32, 4, 0) else CASMVS_SF(32, 3, 0) }
+  if (cin == 8) { if (four) CASMVS_SF(8, 4) else CASMVS_SF(8, 3) }
+  else if (cin == 16) { if (four) CASMVS_SF(16, 4) else CASMVS_SF(16, 3) }
+  else { if (four) CASMVS_SF(32, 4) else CASMVS_SF(32, 3) }
 #undef CASMVS_SF
   return casmvs::check_launch("conv0_sf_kernel");
 }
@@ -405,14 +400,7 @@ int conv0_sf_launch(const void *packed, const float *in, float *out, int B, int 
 
 extern "C" int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
                                                  float slope, int terms, void *stream) {
-  return conv0_sf_launch(packed, in, out, B, cin, D, H, W, slope, terms, 0, stream);
-}
-
-// Experimental (no GPU has timed it): the same kernel on a tile grid shifted by x_offset = 4 voxels, see sf_decode.  Results are those of
-// casmvs_conv0_splitf16_forward_f32 except for the per-tile scaling (the tiles cover other voxels): float32-grade either way.
-extern "C" int casmvs_conv0_splitf16_forward_x_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
-                                                   float slope, int x_offset, void *stream) {
-  return conv0_sf_launch(packed, in, out, B, cin, D, H, W, slope, 3, x_offset, stream);
+  return conv0_sf_launch(packed, in, out, B, cin, D, H, W, slope, terms, stream);
 }
 
 // As casmvs_selftest_mfma_bf16, for v_mfma_f32_16x16x32_f16.

@@ -61,7 +61,7 @@ struct ZmItem {
 };
 
 // in (B, CIN, D, H, W) float32, W % 4 == 0, 16-byte aligned; wpk: the image of casmvs_conv0_splitf16_pack; out (B, 8, D, H, W).
-template <int CIN, int XOFF = 0>   // XOFF = 4: the x patch grid starts at 4 - TX, a staged row of 40 floats touches two 128-byte lines instead of three (conv0_splitf16.hip: sf_decode)
+template <int CIN>
 __global__ __launch_bounds__(ZmCfg::THREADS, 2) void conv0_zm_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
                                                                     float *__restrict__ out, int B, int D, int H, int W, int tiles_x,
                                                                     int tiles_y, int nseg, int zlen, float slope) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(ZmCfg::THREADS, 2) void conv0_zm_kernel(const float
   auto decode = [&](int v) {
     int item = xcd_major(v, total);   // x fastest, then the z segment, then y
     ZmItem t;
-    t.tx0 = (item % tiles_x) * Cfg::TX + (XOFF ? XOFF - Cfg::TX : 0);
+    t.tx0 = (item % tiles_x) * Cfg::TX;
     item /= tiles_x;
     const int seg = item % nseg;
     item /= nseg;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(ZmCfg::THREADS, 2) void conv0_zm_kernel(const float
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int oy = cur.ty0 + 4 * wave + t, ox = cur.tx0 + 2 * jcol;
-        const bool ok = plane_ok && oy < H && ox < W && (XOFF == 0 || ox >= 0);   // W even: the pixel pair is inside or outside
+        const bool ok = plane_ok && oy < H && ox < W;   // W even: the pixel pair is inside or outside
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           float v0 = fmaf(acc[0][t][2 * h], sc[h], sh[h]), v1 = fmaf(acc[0][t][2 * h + 1], sc[h], sh[h]);
@@ -243,12 +243,12 @@ __global__ __launch_bounds__(ZmCfg::THREADS, 2) void conv0_zm_kernel(const float
   }
 }
 
-template <int CIN, int XOFF = 0>
+template <int CIN>
 int launch_zm(const void *packed, const float *in, float *out, int B, int D, int H, int W, float slope, hipStream_t st) {
   using Cfg = ZmCfg;
   constexpr int NCH = CIN / 8;
-  const int tiles_x = casmvs::ceil_div(W + (XOFF ? Cfg::TX - XOFF : 0), Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY);
-  auto kernel = conv0_zm_kernel<CIN, XOFF>;
+  const int tiles_x = casmvs::ceil_div(W, Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY);
+  auto kernel = conv0_zm_kernel<CIN>;
   const size_t lds = Cfg::lds_bytes(NCH);
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "conv0_zm_kernel")) return rc;
   const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), Cfg::THREADS, lds);
@@ -270,33 +270,15 @@ int launch_zm(const void *packed, const float *in, float *out, int B, int D, int
 
 extern "C" int casmvs_conv0_zmarch_supported(int cin, int W) { return (cin == 8 || cin == 16 || cin == 32) && W % 4 == 0 && W >= 4; }
 
-namespace {
-int conv0_zm_launch(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope, int x_offset, void *stream) {
+extern "C" int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
+                                               float slope, void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(packed && in && out, "conv0_zmarch_forward: null pointer");
   CASMVS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && casmvs_conv0_zmarch_supported(cin, W), "conv0_zmarch_forward: B=%d cin=%d D=%d H=%d W=%d", B, cin, D, H, W);
   CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(packed)) & 15) == 0, "conv0_zmarch_forward: 16-byte aligned pointers");
   CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 29), "conv0_zmarch_forward: one sample's input tensor must hold < 2^29 floats");
-  CASMVS_REQUIRE(x_offset == 0 || x_offset == 4, "conv0_zmarch_forward: x_offset=%d (0 or 4)", x_offset);
   hipStream_t st = (hipStream_t)stream;
-  if (x_offset) {
-    if (cin == 8) return launch_zm<8, 4>(packed, in, out, B, D, H, W, slope, st);
-    if (cin == 16) return launch_zm<16, 4>(packed, in, out, B, D, H, W, slope, st);
-    return launch_zm<32, 4>(packed, in, out, B, D, H, W, slope, st);
-  }
   if (cin == 8) return launch_zm<8>(packed, in, out, B, D, H, W, slope, st);
   if (cin == 16) return launch_zm<16>(packed, in, out, B, D, H, W, slope, st);
-  return launch_zm<32>(packed, in, out, B, D, H, W, slope, st);   // 95 KiB of LDS: ONE workgroup per CU - measured against the tiled kernel before it is used
-}
-}  // namespace
-
-extern "C" int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
-                                               float slope, void *stream) {
-  return conv0_zm_launch(packed, in, out, B, cin, D, H, W, slope, 0, stream);
-}
-
-// As above on the patch grid shifted by x_offset = 4 voxels (two cache lines per staged row instead of three).
-extern "C" int casmvs_conv0_zmarch_forward_x_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
-                                                 float slope, int x_offset, void *stream) {
-  return conv0_zm_launch(packed, in, out, B, cin, D, H, W, slope, x_offset, stream);
+  return launch_zm<32>(packed, in, out, B, D, H, W, slope, st);   // 95 KiB of LDS: ONE workgroup per CU (measured: 0.74-0.9x the tiled kernel; the engine keeps cin = 32 tiled)
 }

@@ -2149,11 +2149,10 @@ extern "C" size_t casmvs_featurenet_workspace_bytes(int N, int H, int W) {
 }
 
 namespace {
-// x_conv0 (experimental layer set, casmvs_featurenet_forward_fused_x_f32): the image of casmvs_fnet_conv0_fused_pack - conv0.0 + conv0.1 as one kernel
 int featurenet_run(const float *const *packed_layers, const void *fused0_packed, int fused0_arith, const float *fused0_bias9, const void *const *ci_layers,
                    const float *imgs,
                    float *feat0, float *feat1, float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
-                   void *workspace, int N, int H, int W, float slope, void *const *layer_events, void *stream, const void *x_conv0 = nullptr) {
+                   void *workspace, int N, int H, int W, float slope, void *const *layer_events, void *stream) {
   CASMVS_REQUIRE(packed_layers && imgs && feat0 && feat1 && feat2 && workspace, "featurenet_forward: null pointer");
   CASMVS_REQUIRE(N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0,
                  "featurenet_forward: N=%d H=%d W=%d (H, W must be multiples of 4)", N, H, W);
@@ -2183,15 +2182,8 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
   CASMVS_EV();                                                                                 \
   rc = conv2d_forward(__VA_ARGS__);                                                            \
   if (rc != CASMVS_OK) return rc
-  if (x_conv0 && casmvs_fnet_conv0_fused_supported(W) && ((reinterpret_cast<size_t>(imgs) | reinterpret_cast<size_t>(x_conv0)) & 15) == 0) {
-    CASMVS_EV();   // conv0.0 + conv0.1 as one kernel (fnet_conv0_fused.hip); the `conv0.0` interval times it, `conv0.1` is empty
-    rc = casmvs_fnet_conv0_fused_f32(x_conv0, imgs, c0, N, H, W, slope, stream);
-    if (rc != CASMVS_OK) return rc;
-    CASMVS_EV();
-  } else {
   CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, nullptr, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
   CASMVS_L(CASMVS_CONV2D_K3, P[1], a0, nullptr, c0, nullptr, N, 8, 8, H, W, slope, stream);            // conv0.1  :15
-  }
   CASMVS_L(CASMVS_CONV2D_K5S2, P[2], c0, nullptr, a1, nullptr, N, 8, 16, H, W, slope, stream);         // conv1.0  :18
   if (ci_layers && ci_layers[0] && casmvs_conv2d_ci_splitf16_supported(16, 16, W2)) {   // conv1.1 on the f16 matrix cores (conv2d_ci_splitf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
@@ -2277,16 +2269,6 @@ extern "C" int casmvs_featurenet_forward_fused_f32(const float *const *packed_la
                         N, H, W, slope, layer_events, stream);
 }
 
-extern "C" int casmvs_featurenet_forward_fused_x_f32(const float *const *packed_layers, const void *fused0_packed, int fused0_arith,
-                                                     const float *fused0_bias9, const void *const *ci_layers, const float *imgs, float *feat0, float *feat1,
-                                                     float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc, void *workspace, int N, int H,
-                                                     int W, float slope, void *const *layer_events, void *stream, const void *conv0_fused_image) {
-  casmvs::clear_error();
-  CASMVS_REQUIRE(fused0_packed && fused0_bias9, "featurenet_forward_fused_x: null pointer");
-  return featurenet_run(packed_layers, fused0_packed, fused0_arith, fused0_bias9, ci_layers, imgs, feat0, feat1, feat2, feat0_nhwc, feat1_nhwc, feat2_nhwc, workspace,
-                        N, H, W, slope, layer_events, stream, conv0_fused_image);
-}
-
 extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
   if (B <= 0 || D <= 0 || h <= 0 || w <= 0 || D % 8 || h % 8 || w % 8) return 0;
   const size_t n = (size_t)D * h * w;  // full-resolution voxels
@@ -2299,13 +2281,12 @@ extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
 namespace {
 // conv0 .. conv11 (+ skips) into the workspace, then the `prob` head: on its own (depth == nullptr), or fused with the
 // softmax / regression / confidence that consumes it (casmvs_prob_regress_f32).
-// x_* (experimental layer set, casmvs_costreg_regress_x_f32): x_zmarch & 3: 1 = conv0 on conv0_zmarch.hip for cin 8 / 16, 2 = also cin 32; x_zmarch & 4: conv0's tile grid shifted by 4 voxels in x; x_d9 / x_d11 = the
-// images of casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack (conv9 / conv11 on the f16 matrix cores); x_tail 1 (with x_d11) = conv11 + skip +
-// `prob` + regression as ONE kernel (conv11_prob_fused.hip)
+// split_layers (casmvs_costreg_regress_f32): the images of the layers that have a form on the f16 matrix cores - conv0, conv2, conv4, conv6 (stride 1),
+// conv9, conv11 (transposed) - each or nullptr (the float32 MFMA kernel).  With conv0's split-f16 image, cin = 16 runs the z-marching kernel
+// (conv0_zmarch.hip: 1.10-1.15x the tiled one at level 1 on the MI355X, equal at cin = 8, 0.74-0.9x at cin = 32: profiles/r04_native_checks_first_run.txt).
 int costreg_run(const char *who, const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol, const float *depth_values,
                 float *cost, float *depth, float *confidence, int32_t *index, void *workspace, int B, int cin, int D,
-                int h, int w, float slope, void *const *layer_events, void *stream, int x_zmarch = 0, const void *x_d9 = nullptr, const void *x_d11 = nullptr,
-                int x_tail = 0) {
+                int h, int w, float slope, void *const *layer_events, void *stream) {
   CASMVS_REQUIRE(packed_layers && vol && cost && workspace, "%s: null pointer", who);
   CASMVS_REQUIRE(B > 0 && cin > 0 && D > 0 && h > 0 && w > 0 && D % 8 == 0 && h % 8 == 0 && w % 8 == 0,
                  "%s: B=%d cin=%d D=%d h=%d w=%d (D, h, w must be multiples of 8)", who, B, cin, D, h, w);
@@ -2336,6 +2317,7 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
   const void *conv0_split = split_layers ? split_layers[0] : nullptr;
   const void *conv2_split = split_layers ? split_layers[1] : nullptr, *conv4_split = split_layers ? split_layers[2] : nullptr;
   const void *conv6_split = split_layers ? split_layers[3] : nullptr;
+  const void *conv9_split = split_layers ? split_layers[4] : nullptr, *conv11_split = split_layers ? split_layers[5] : nullptr;
   CASMVS_REQUIRE(conv0_arith == CASMVS_CONV0_F32 || conv0_split, "%s: conv0_arith=%d needs the split image of conv0", who, conv0_arith);
   const bool split_ok = (reinterpret_cast<size_t>(vol) & 15) == 0;
   if (conv0_arith == CASMVS_CONV0_SPLIT_BF16 && split_ok && casmvs_conv0_splitbf16_supported(cin, w)) {
@@ -2344,17 +2326,16 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     ++li;
     rc = casmvs_conv0_splitbf16_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 0, stream);
     if (rc != CASMVS_OK) return rc;
-  } else if (conv0_arith == CASMVS_CONV0_SPLIT_F16 && (x_zmarch & 3) > 0 && split_ok && casmvs_conv0_zmarch_supported(cin, w) && (cin != 32 || (x_zmarch & 3) >= 2)) {
+  } else if (conv0_arith == CASMVS_CONV0_SPLIT_F16 && cin == 16 && split_ok && casmvs_conv0_zmarch_supported(cin, w)) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_conv0_zmarch_forward_x_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, (x_zmarch & 4) ? 4 : 0, stream);   // the same arithmetic, input-stationary along z
+    rc = casmvs_conv0_zmarch_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, stream);   // the same arithmetic, input-stationary along z
     if (rc != CASMVS_OK) return rc;
   } else if (conv0_arith == CASMVS_CONV0_SPLIT_F16 && split_ok && casmvs_conv0_splitf16_supported(cin, w)) {
     // conv0 on the f16 matrix cores, float32 operands as two scaled float16 slices (conv0_splitf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = (x_zmarch & 4) ? casmvs_conv0_splitf16_forward_x_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 4, stream)   // experimental: the tile grid shifted by 4 voxels
-                        : casmvs_conv0_splitf16_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 0, stream);
+    rc = casmvs_conv0_splitf16_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 0, stream);
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV_S1, P[0], vol, nullptr, c0, B, cin, 8, D, h, w, sl, stream);               // conv0
@@ -2393,33 +2374,21 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     CASMVS_L(CASMVS_CONV_S1, P[6], c5, nullptr, c6, B, 64, 64, D / 8, h / 8, w / 8, sl, stream);      // conv6
   }
   CASMVS_L(CASMVS_CONV_T2, P[7], c6, c4, u7, B, 64, 32, D / 8, h / 8, w / 8, sl, stream);           // conv4 + conv7
-  if (x_d9 && casmvs_deconv9_splitf16_supported(w / 4) && (reinterpret_cast<size_t>(x_d9) & 15) == 0) {
+  if (conv9_split && casmvs_deconv9_splitf16_supported(w / 4) && (reinterpret_cast<size_t>(conv9_split) & 15) == 0) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_deconv9_splitf16_forward_f32(x_d9, u7, c2, u9, B, D / 4, h / 4, w / 4, sl, stream);   // conv2 + conv9 on the f16 matrix cores
+    rc = casmvs_deconv9_splitf16_forward_f32(conv9_split, u7, c2, u9, B, D / 4, h / 4, w / 4, sl, stream);   // conv2 + conv9 on the f16 matrix cores
     if (rc != CASMVS_OK) return rc;
   } else {
-  CASMVS_L(CASMVS_CONV_T2, P[8], u7, c2, u9, B, 32, 16, D / 4, h / 4, w / 4, sl, stream);           // conv2 + conv9
+    CASMVS_L(CASMVS_CONV_T2, P[8], u7, c2, u9, B, 32, 16, D / 4, h / 4, w / 4, sl, stream);         // conv2 + conv9
   }
-  if (x_tail && x_d11 && depth != nullptr && casmvs_conv11_prob_regress_supported(D, h, w) && (reinterpret_cast<size_t>(x_d11) & 15) == 0) {
-    // conv11 + skip + prob + softmax regression in one depth-walking kernel: the `conv11` interval of layer_events times it, `prob` is empty
+  if (conv11_split && casmvs_deconv11_splitf16_supported(w / 2) && (reinterpret_cast<size_t>(conv11_split) & 15) == 0) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
-    rc = casmvs_conv11_prob_regress_f32(x_d11, P[10], u9, c0, depth_values, cost, depth, confidence, index, B, D, h, w, sl, 0, stream);
-    if (rc != CASMVS_OK) return rc;
-    if (layer_events) {
-      (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
-      (void)hipEventRecord((hipEvent_t)layer_events[11], (hipStream_t)stream);
-    }
-    return CASMVS_OK;
-  }
-  if (x_d11 && casmvs_deconv11_splitf16_supported(w / 2) && (reinterpret_cast<size_t>(x_d11) & 15) == 0) {
-    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
-    ++li;
-    rc = casmvs_deconv11_splitf16_forward_f32(x_d11, u9, c0, u11, B, D / 2, h / 2, w / 2, sl, stream);   // conv0 + conv11 on the f16 matrix cores
+    rc = casmvs_deconv11_splitf16_forward_f32(conv11_split, u9, c0, u11, B, D / 2, h / 2, w / 2, sl, stream);   // conv0 + conv11 on the f16 matrix cores
     if (rc != CASMVS_OK) return rc;
   } else {
-  CASMVS_L(CASMVS_CONV_T2, P[9], u9, c0, u11, B, 16, 8, D / 2, h / 2, w / 2, sl, stream);           // conv0 + conv11
+    CASMVS_L(CASMVS_CONV_T2, P[9], u9, c0, u11, B, 16, 8, D / 2, h / 2, w / 2, sl, stream);         // conv0 + conv11
   }
   if (depth == nullptr) {
     CASMVS_L(CASMVS_CONV_S1, P[10], u11, nullptr, cost, B, 8, 1, D, h, w, 1.0f, stream);            // prob
@@ -2452,19 +2421,6 @@ extern "C" int casmvs_costreg_regress_f32(const float *const *packed_layers, con
   CASMVS_REQUIRE(depth_values && depth && confidence, "costreg_regress: null pointer");
   return costreg_run("costreg_regress", packed_layers, split_layers, conv0_arith, vol, depth_values, cost, depth, confidence, index, workspace, B,
                      cin, D, h, w, slope, layer_events, stream);
-}
-
-extern "C" int casmvs_costreg_regress_x_f32(const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol,
-                                            const float *depth_values, float *cost, float *depth, float *confidence, int32_t *index,
-                                            void *workspace, int B, int cin, int D, int h, int w, float slope,
-                                            void *const *layer_events, void *stream, int conv0_zmarch, const void *deconv9_image, const void *deconv11_image,
-                                            int fuse_tail) {
-  casmvs::clear_error();
-  CASMVS_REQUIRE(depth_values && depth && confidence, "costreg_regress_x: null pointer");
-  CASMVS_REQUIRE(!fuse_tail || deconv11_image, "costreg_regress_x: fuse_tail needs the conv11 image");
-  CASMVS_REQUIRE(conv0_zmarch >= 0 && conv0_zmarch <= 6 && (conv0_zmarch & 3) != 3, "costreg_regress_x: conv0_zmarch=%d (0 off, 1 cin 8 / 16, 2 also cin 32; + 4: shifted tile grid)", conv0_zmarch);
-  return costreg_run("costreg_regress_x", packed_layers, split_layers, conv0_arith, vol, depth_values, cost, depth, confidence, index, workspace, B,
-                     cin, D, h, w, slope, layer_events, stream, conv0_zmarch, deconv9_image, deconv11_image, fuse_tail);
 }
 
 extern "C" int casmvs_selftest_mfma_rate(int shape, int blocks, int iters, float *tflops) {

@@ -1,6 +1,8 @@
 // Debug tooling (tools/debug/disturber.py): small "disturber" kernels for the co-residency experiments of round 3 - a float32 layer kernel
 // produced a few wrong values when workgroups of the split-f16 kernels ran beside it on another stream; these kernels isolate
-// which property of the neighbour matters (matrix-instruction type, LDS footprint above 64 KiB, LDS traffic).  Not used by the engine.
+// which property of the neighbour matters (matrix-instruction type, LDS footprint above 64 KiB, LDS traffic).  Not used by the engine and NOT part of
+// the production library: compiled only into -DCASMVS_TRACE builds (tools/build_trace_lib.sh -> libcasmvs_trace.so, CASMVS_LIB_PATH).
+#ifdef CASMVS_TRACE
 #include <cstdint>
 
 #include "buffer_ops.h"
@@ -63,3 +65,4 @@ extern "C" int casmvs_debug_disturb(int kind, int blocks, int iters, int lds_byt
 #undef CASMVS_DD
   return casmvs::check_launch("disturb_kernel");
 }
+#endif  // CASMVS_TRACE

@@ -52,11 +52,16 @@ __device__ __forceinline__ unsigned wave_max_bits(unsigned v) {
 
 // The staged tile's power-of-two scaling from the four waves' maxima (bit patterns of non-negative floats, 16-byte aligned in LDS):
 // mult = 2^kx puts the largest magnitude into [2^14, 2^15), inv = 2^-kx; an all-zero or denormal tile is scaled by 2^126.
+// Non-finite inputs: the per-thread maxima are fmaxf chains, which skip NaNs - a NaN voxel splits into NaN slices and reaches exactly the outputs whose
+// taps touch it, as in the float32 kernels.  An INFINITE voxel makes the tile's maximum infinite (e = 255): no finite scaling exists for its neighbours,
+// so the whole staged unit is poisoned (mult = NaN -> every slice NaN -> every output fed by this unit NaN): a superset of the outputs the float32 kernel
+// makes non-finite, never a finite wrong value (with mult = 2^-113 the finite voxels of the tile would silently flush to zero).
 __device__ __forceinline__ void tile_scale(const unsigned *wave_maxima, float &mult, float &inv) {
   const split_u32x4 w4 = *reinterpret_cast<const split_u32x4 *>(wave_maxima);
   int e = (int)(max(max(w4[0], w4[1]), max(w4[2], w4[3])) >> 23);
-  e = e < 15 ? 15 : e;
-  mult = __builtin_bit_cast(float, (unsigned)(268 - e) << 23);
+  const bool infinite = e >= 255;
+  e = e < 15 ? 15 : (e > 254 ? 254 : e);
+  mult = __builtin_bit_cast(float, infinite ? 0x7fc00000u : (unsigned)(268 - e) << 23);
   inv = __builtin_bit_cast(float, (unsigned)(e - 14) << 23);
 }
 

@@ -93,6 +93,23 @@ class _PackedWeights:
         setattr(self, attr, new)
         return new
 
+    def _split_image(self, attr, pack, wanted):
+        """The split-f16 / split-bf16 image(s) `attr` of a layer set: packed only when the selected modes use them (`wanted`), kept at their
+        addresses like every packed image (_store_packed).  The f16 / bf16 packers reject non-finite weights: such a model runs the layer on the
+        float32 MFMA kernel, which propagates Inf / NaN through the taps that touch it as the reference does - unless an image already
+        exists (a captured hipGraph may hold its address and cannot change kernels: that is an error)."""
+        if not wanted:
+            return None
+        try:
+            return self._store_packed(attr, pack())
+        except RuntimeError as e:
+            if "finite" not in str(e):
+                raise
+            if getattr(self, attr, None) is not None:
+                raise RuntimeError(f"{type(self).__name__}: non-finite weights cannot be re-packed for the f16 matrix cores and a packed image "
+                                   f"(possibly captured in a hipGraph) exists; select the float32 modes and re-capture") from e
+            return None
+
     def _state_key(self, device):
         # walks the CURRENT module tree on every call (~40 us): a cached tensor list would keep answering for tensor
         # objects that are no longer the module's (round-2 advisor finding)
@@ -139,16 +156,14 @@ class FeatureNet(_PackedWeights, nn.Module):
         self._fused0_sf = None    # the same tail as the split-f16 image
         self.tail_mode = "splitf16"   # arithmetic of the fused tail: "splitf16" (f16 matrix cores, fpn_fused_sf.hip) or "f32"
         self._ci2d = None         # split-f16 images of conv1.1, conv1.2, conv2.1, conv2.2, smooth1 (conv2d_ci_splitf16.hip; follow tail_mode)
+        self._split_active = False   # set by packed_layers: the split-f16 images are packed and current
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.last_channels_last = None
-        # Kernels written without a GPU run at the end of round 3 (opt-in until their first tests have passed on the MI355X): {"conv0_fused"} runs
-        # conv0.0 + conv0.1 as one kernel (csrc/fnet_conv0_fused.hip) inside the split-f16 forward
-        self.experimental = set()
-        self._conv0_fused = None
 
     def packed_layers(self, device):
         """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
-        key = self._state_key(device)
+        sf = self.fuse_tail and self.tail_mode == "splitf16"
+        key = self._state_key(device) + (bool(self.fuse_tail), sf)
         if self._packed is not None and key == self._packed_key:
             return self._packed
         packed, slopes = [], set()
@@ -163,17 +178,24 @@ class FeatureNet(_PackedWeights, nn.Module):
         if len(slopes) > 1:
             raise RuntimeError("FeatureNet: all ABN layers must share one activation slope")
         self._slope = slopes.pop() if slopes else 0.01
-        # the full-resolution tail lat0 + upsample-add + smooth0 as one 40-channel 3x3 layer (csrc/fpn_fused.hip)
-        w40, bias9 = compose_fpn_tail(self.lat0.weight, self.lat0.bias, self.smooth0.weight, self.smooth0.bias)
-        self._store_packed("_fused0", (ops.conv2d_pack(ops.CONV2D_K3, w40, None, None).to(device), bias9.to(device)))
-        self._store_packed("_fused0_sf", (ops.fpn_tail0_splitf16_pack(w40).to(device), bias9.to(device)))
-        ci = []
-        for name in ("conv1.1", "conv1.2", "conv2.1", "conv2.2"):
-            m = self.get_submodule(name)
-            sc, sh, _ = _fold_norm(f"FeatureNet.{name}", m.bn)
-            ci.append(ops.conv2d_ci_splitf16_pack(m.conv.weight, sc, sh).to(device))
-        ci.append(ops.conv2d_ci_splitf16_pack(self.smooth1.weight, None, self.smooth1.bias).to(device))   # smooth1: Conv2d 32 -> 16 with bias
-        self._store_packed("_ci2d", ci)
+        # the full-resolution tail lat0 + upsample-add + smooth0 as one 40-channel 3x3 layer (csrc/fpn_fused.hip); only the images of the
+        # selected arithmetic are packed (an all-float32 replica of graph.ConcurrentForwards never pays for - or trips over - the f16 packers)
+        if self.fuse_tail:
+            w40, bias9 = compose_fpn_tail(self.lat0.weight, self.lat0.bias, self.smooth0.weight, self.smooth0.bias)
+            self._store_packed("_fused0", (ops.conv2d_pack(ops.CONV2D_K3, w40, None, None).to(device), bias9.to(device)))
+            if self._split_image("_fused0_sf", lambda: (ops.fpn_tail0_splitf16_pack(w40).to(device), bias9.to(device)), sf) is None:
+                sf = False
+
+        def pack_ci():
+            ci = []
+            for name in ("conv1.1", "conv1.2", "conv2.1", "conv2.2"):
+                m = self.get_submodule(name)
+                sc, sh, _ = _fold_norm(f"FeatureNet.{name}", m.bn)
+                ci.append(ops.conv2d_ci_splitf16_pack(m.conv.weight, sc, sh).to(device))
+            ci.append(ops.conv2d_ci_splitf16_pack(self.smooth1.weight, None, self.smooth1.bias).to(device))   # smooth1: Conv2d 32 -> 16 with bias
+            return ci
+        self._split_image("_ci2d", pack_ci, sf)
+        self._split_active = sf   # the split-f16 images exist and are current: forward may select them
         self._packed_key = key
         return self._store_packed("_packed", packed)
 
@@ -185,26 +207,18 @@ class FeatureNet(_PackedWeights, nn.Module):
             from .training import feature_net_train
             return feature_net_train(self, x.float())
         N, _, H, W = x.shape
+        if self.tail_mode not in ("splitf16", "f32"):
+            raise ValueError(f"FeatureNet.tail_mode={self.tail_mode!r} (splitf16 or f32)")
         packed = self.packed_layers(x.device)
         need = ops.featurenet_workspace_bytes(N, H, W)
         ws = self._workspace
         if ws is None or ws.device != x.device or ws.numel() < need:
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         events = self.timer.layer_events("feature", 14, self.LAYER_NAMES) if self.timer is not None else None
-        if self.tail_mode not in ("splitf16", "f32"):
-            raise ValueError(f"FeatureNet.tail_mode={self.tail_mode!r} (splitf16 or f32)")
-        sf = self.fuse_tail and self.tail_mode == "splitf16"
+        sf = self._split_active   # fuse_tail and tail_mode == "splitf16" and finite weights (packed_layers)
         fused0 = (self._fused0_sf if sf else self._fused0) if self.fuse_tail else None
-        conv0_fused = None
-        if sf and "conv0_fused" in self.experimental:
-            if self._conv0_fused is None or self._conv0_fused[0] != self._packed_key:
-                s0, b0, _ = _fold_norm("FeatureNet.conv0.0", self.conv0[0].bn)
-                s1, b1, _ = _fold_norm("FeatureNet.conv0.1", self.conv0[1].bn)
-                self._conv0_fused = (self._packed_key, ops.fnet_conv0_fused_pack(self.conv0[0].conv.weight, s0, b0, self.conv0[1].conv.weight, s1, b1).to(x.device))
-            conv0_fused = self._conv0_fused[1]
         feat0, feat1, feat2, cl = ops.featurenet_forward(packed, x.float(), ws, slope=self._slope, layer_events=events,
-                                                         channels_last_copies=True, fused0=fused0, fused0_splitf16=sf, ci_layers=self._ci2d if sf else None,
-                                                         conv0_fused=conv0_fused)
+                                                         channels_last_copies=True, fused0=fused0, fused0_splitf16=sf, ci_layers=self._ci2d if sf else None)
         # pixel-major copies of the three maps (same kernels, second store): what the cost-volume gather reads
         self.last_channels_last = {"level_0": cl[0], "level_1": cl[1], "level_2": cl[2]}
         return {"level_0": feat0, "level_1": feat1, "level_2": feat2}
@@ -242,24 +256,23 @@ class CostRegNet(_PackedWeights, nn.Module):
         self._init_packed()       # _packed: list of 11 device tensors
         self._conv0_sb = None     # conv0's split-bf16 image (uint8 device tensor)
         self._conv0_sf = None     # conv0's split-f16 image
-        self._ci_sf = None        # (conv2, conv4, conv6) split-f16 images
-        self.ci_mode = "splitf16" # conv2 / conv4 / conv6 in `regress`: "splitf16" (f16 matrix cores, conv_ci_splitf16.hip) or "f32"
+        self._ci_sf = None        # (conv2, conv4, conv6, conv9, conv11) split-f16 images
+        # conv2 / conv4 / conv6 (conv_ci_splitf16.hip) and the transposed conv9 / conv11 (deconv9_splitf16.hip, deconv11_splitf16.hip) in `regress`:
+        # "splitf16" (f16 matrix cores) or "f32"
+        self.ci_mode = "splitf16"
         # conv0's arithmetic in `regress` (the engine's eval path), all float32-grade (distance to a float64 convolution at or
         # below the float32 MFMA kernel's):
         #   "splitf16":  f16 matrix cores, every float32 operand as two float16 slices behind exact power-of-two scalings (per
-        #                weight tensor / per staged tile), three partial products per product, float32 accumulation
+        #                weight tensor / per staged tile), three partial products per product, float32 accumulation; cin = 16 (cascade
+        #                level 1) on the z-marching kernel (conv0_zmarch.hip), cin = 8 / 32 on the tiled one (conv0_splitf16.hip)
         #   "splitbf16": bf16 matrix cores, three exact bf16 slices per operand, six partial products
         #   "f32":       the float32 MFMA kernel like every other layer
         self.conv0_mode = "splitf16"
         self._workspace = None
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.timer_name = "costreg"
-        # Kernels written without a GPU run at the end of round 3 (opt-in until their first tests have passed on the MI355X), used by `regress` with
-        # conv0_mode "splitf16": "zmarch" (conv0 input-stationary along z for cin 8 / 16; "zmarch32": also cin 32), "xshift" (conv0's tile grid - either kernel -
-        # shifted by 4 voxels in x: two cache lines per staged row instead of three), "deconv9", "deconv11" (conv9 / conv11
-        # on the f16 matrix cores), "tail" (conv11 + skip + prob + regression as one kernel, conv11_prob_fused.hip)
-        self.experimental = set()
-        self._deconv_sf = None
+        self._conv0_active = None   # set by packed_layers: which split image of conv0 is packed and current ("splitf16" / "splitbf16" / None)
+        self._ci_active = False     # ... and whether the five images of _ci_sf are
 
     # -- weight folding / packing -------------------------------------------------------------
     def _layer_tensors(self, name):
@@ -272,7 +285,11 @@ class CostRegNet(_PackedWeights, nn.Module):
 
     def packed_layers(self, device):
         """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
-        key = self._state_key(device)
+        if self.conv0_mode not in ("splitf16", "splitbf16", "f32"):
+            raise ValueError(f"CostRegNet.conv0_mode={self.conv0_mode!r} (splitf16, splitbf16 or f32)")
+        if self.ci_mode not in ("splitf16", "f32"):
+            raise ValueError(f"CostRegNet.ci_mode={self.ci_mode!r} (splitf16 or f32)")
+        key = self._state_key(device) + (self.conv0_mode, self.ci_mode)
         if self._packed is not None and key == self._packed_key:
             return self._packed
         packed, slopes = [], set()
@@ -287,20 +304,30 @@ class CostRegNet(_PackedWeights, nn.Module):
         if len(slopes) > 1:
             raise RuntimeError("CostRegNet: all ABN layers must share one activation slope")
         self._slope = slopes.pop() if slopes else 0.01
-        # conv0 once more as the split-bf16 image (csrc/conv0_splitbf16.hip): three exact bf16 slices of every weight
+        # the images of the layers' f16 / bf16 matrix-core forms: only those the selected modes use (an all-float32 replica of
+        # graph.ConcurrentForwards packs none), float32 fallback for non-finite weights (_split_image)
         cin = self.conv0.conv.weight.shape[1]
-        if cin in (8, 16, 32):
-            scale0, shift0, _ = _fold_norm("CostRegNet.conv0", self.conv0.bn)
-            self._store_packed("_conv0_sb", ops.conv0_splitbf16_pack(self.conv0.conv.weight, scale0, shift0).to(device))
-            self._store_packed("_conv0_sf", ops.conv0_splitf16_pack(self.conv0.conv.weight, scale0, shift0).to(device))
-        else:
-            self._conv0_sb = self._conv0_sf = None
-        ci = []
-        for name in ("conv2", "conv4", "conv6"):
-            m = getattr(self, name)
-            sc, sh, _ = _fold_norm(f"CostRegNet.{name}", m.bn)
-            ci.append(ops.conv_ci_splitf16_pack(m.conv.weight, sc, sh).to(device))
-        self._store_packed("_ci_sf", ci)
+        fold0 = lambda: _fold_norm("CostRegNet.conv0", self.conv0.bn)[:2]
+        self._conv0_active = None
+        if cin in (8, 16, 32) and self.conv0_mode == "splitbf16":
+            if self._split_image("_conv0_sb", lambda: ops.conv0_splitbf16_pack(self.conv0.conv.weight, *fold0()).to(device), True) is not None:
+                self._conv0_active = "splitbf16"
+        elif cin in (8, 16, 32) and self.conv0_mode == "splitf16":
+            if self._split_image("_conv0_sf", lambda: ops.conv0_splitf16_pack(self.conv0.conv.weight, *fold0()).to(device), True) is not None:
+                self._conv0_active = "splitf16"
+
+        def pack_ci():
+            ci = []
+            for name in ("conv2", "conv4", "conv6"):
+                m = getattr(self, name)
+                sc, sh, _ = _fold_norm(f"CostRegNet.{name}", m.bn)
+                ci.append(ops.conv_ci_splitf16_pack(m.conv.weight, sc, sh).to(device))
+            s9, b9, _ = _fold_norm("CostRegNet.conv9", self.conv9[1])
+            ci.append(ops.deconv9_splitf16_pack(self.conv9[0].weight, s9, b9).to(device))
+            s11, b11, _ = _fold_norm("CostRegNet.conv11", self.conv11[1])
+            ci.append(ops.deconv11_splitf16_pack(self.conv11[0].weight, s11, b11).to(device))
+            return ci
+        self._ci_active = self._split_image("_ci_sf", pack_ci, self.ci_mode == "splitf16") is not None
         self._packed_key = key
         return self._store_packed("_packed", packed)
 
@@ -329,32 +356,14 @@ class CostRegNet(_PackedWeights, nn.Module):
         if ws is None or ws.device != x.device or ws.numel() < need:
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
         events = self.timer.layer_events(self.timer_name) if self.timer is not None else None
-        if self.conv0_mode not in ("splitf16", "splitbf16", "f32"):
-            raise ValueError(f"CostRegNet.conv0_mode={self.conv0_mode!r} (splitf16, splitbf16 or f32)")
         split, arith = None, ops.CONV0_F32
-        if self.conv0_mode == "splitf16" and self._conv0_sf is not None:
+        if self._conv0_active == "splitf16":
             split, arith = self._conv0_sf, ops.CONV0_SPLIT_F16
-        elif self.conv0_mode == "splitbf16" and self._conv0_sb is not None:
+        elif self._conv0_active == "splitbf16":
             split, arith = self._conv0_sb, ops.CONV0_SPLIT_BF16
-        if self.ci_mode not in ("splitf16", "f32"):
-            raise ValueError(f"CostRegNet.ci_mode={self.ci_mode!r} (splitf16 or f32)")
-        c2, c4, c6 = self._ci_sf if self.ci_mode == "splitf16" else (None, None, None)
-        zm, d9, d11 = 0, None, None
-        if self.experimental and self.ci_mode == "splitf16" and self.conv0_mode == "splitf16":   # never in the all-float32 replicas (graph.py)
-            unknown = set(self.experimental) - {"zmarch", "zmarch32", "xshift", "deconv9", "deconv11", "tail"}
-            if unknown:
-                raise ValueError(f"CostRegNet.experimental: unknown entries {sorted(unknown)}")
-            zm = (2 if "zmarch32" in self.experimental else (1 if "zmarch" in self.experimental else 0)) + (4 if "xshift" in self.experimental else 0)
-            if self._deconv_sf is None or self._deconv_sf[0] != self._packed_key:
-                s9, b9, _ = _fold_norm("CostRegNet.conv9", self.conv9[1])
-                s11, b11, _ = _fold_norm("CostRegNet.conv11", self.conv11[1])
-                self._deconv_sf = (self._packed_key, ops.deconv9_splitf16_pack(self.conv9[0].weight, s9, b9).to(x.device),
-                                   ops.deconv11_splitf16_pack(self.conv11[0].weight, s11, b11).to(x.device))
-            d9 = self._deconv_sf[1] if "deconv9" in self.experimental else None
-            d11 = self._deconv_sf[2] if ("deconv11" in self.experimental or "tail" in self.experimental) else None
+        c2, c4, c6, c9, c11 = self._ci_sf if self._ci_active else (None,) * 5
         return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index,
-                                   conv0_split=split, conv0_arith=arith, conv2_split=c2, conv4_split=c4, conv6_split=c6,
-                                   conv0_zmarch=zm, deconv9_split=d9, deconv11_split=d11, fuse_tail="tail" in self.experimental and d11 is not None)
+                                   conv0_split=split, conv0_arith=arith, conv2_split=c2, conv4_split=c4, conv6_split=c6, conv9_split=c9, conv11_split=c11)
 
 
 class CascadeMVSNet(nn.Module):

@@ -323,22 +323,17 @@ def conv0_splitf16_pack(weight, scale=None, shift=None):
     return packed
 
 
-def conv0_splitf16_forward(packed, x, slope=0.01, terms=0, x_offset=0):
+def conv0_splitf16_forward(packed, x, slope=0.01, terms=0):
     """conv0 on the f16 matrix cores with float32-grade arithmetic (casmvs_conv0_splitf16_forward_f32): x (B,cin,D,H,W) ->
-    (B,8,D,H,W).  terms: 0 / 3 = three partial products per product, 4 = all four.  x_offset = 4 (opt-in, added without a GPU run): the tile
-    grid shifted by 4 voxels, two cache lines per staged row instead of three (casmvs_conv0_splitf16_forward_x_f32)."""
+    (B,8,D,H,W).  terms: 0 / 3 = three partial products per product, 4 = all four."""
     x = _dev(x, "x")
     if not packed.is_cuda or packed.dtype != torch.uint8:
         raise RuntimeError("conv0_splitf16_forward: `packed` must be the uint8 image on the MI355X")
     B, cin, D, H, W = x.shape
     out = torch.empty((B, 8, D, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        if x_offset:
-            rc = _lib.load().casmvs_conv0_splitf16_forward_x_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W,
-                                                                 float(slope), int(x_offset), _stream(x))
-        else:
-            rc = _lib.load().casmvs_conv0_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W,
-                                                               float(slope), int(terms), _stream(x))
+        rc = _lib.load().casmvs_conv0_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W,
+                                                           float(slope), int(terms), _stream(x))
     _lib.check(rc, "casmvs_conv0_splitf16_forward_f32")
     return out
 
@@ -407,19 +402,17 @@ def deconv11_splitf16_forward(packed, x, skip=None, slope=0.01):
     return out
 
 
-def conv0_zmarch_forward(packed, x, slope=0.01, x_offset=0):
-    """conv0 in split-f16 arithmetic, input-stationary along z (casmvs_conv0_zmarch_forward_x_f32, csrc/conv0_zmarch.hip): `packed` is the
-    image of conv0_splitf16_pack, x (B,cin,D,H,W) with cin 8 / 16 / 32 -> (B,8,D,H,W); x_offset 0 or 4 (patch grid shifted by 4 voxels).
-    Opt-in (added without a GPU run at the end of round 3)."""
+def conv0_zmarch_forward(packed, x, slope=0.01):
+    """conv0 in split-f16 arithmetic, input-stationary along z (casmvs_conv0_zmarch_forward_f32, csrc/conv0_zmarch.hip): `packed` is the
+    image of conv0_splitf16_pack, x (B,cin,D,H,W) with cin 8 / 16 / 32 -> (B,8,D,H,W).  The regulariser uses it at cin = 16."""
     x = _dev(x, "x")
     if not packed.is_cuda or packed.dtype != torch.uint8:
         raise RuntimeError("conv0_zmarch_forward: `packed` must be the uint8 image on the MI355X")
     B, cin, D, H, W = x.shape
     out = torch.empty((B, 8, D, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().casmvs_conv0_zmarch_forward_x_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W, float(slope), int(x_offset),
-                                                           _stream(x))
-    _lib.check(rc, "casmvs_conv0_zmarch_forward_x_f32")
+        rc = _lib.load().casmvs_conv0_zmarch_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W, float(slope), _stream(x))
+    _lib.check(rc, "casmvs_conv0_zmarch_forward_f32")
     return out
 
 
@@ -498,13 +491,14 @@ CONV0_F32, CONV0_SPLIT_BF16, CONV0_SPLIT_F16 = 0, 1, 2   # casmvs.h: CASMVS_CONV
 
 
 def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, layer_events=None, return_index=False, conv0_split=None,
-                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None, conv6_split=None, conv0_zmarch=0, deconv9_split=None, deconv11_split=None, fuse_tail=False):
+                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None, conv6_split=None, conv9_split=None, conv11_split=None):
     """CostRegNet + softmax / depth regression / confidence in one library call (mvsnet.py:91-104 + :174-193): the `prob`
     head walks the depth axis and, when the whole depth range is one chunk, runs the regression on the cost values it has
     just produced (casmvs_costreg_regress_f32).  -> cost (B,D,h,w), depth (B,h,w), confidence (B,h,w) [, index int32].
     conv0_arith: CONV0_F32 (conv0 on the float32 MFMA kernel), CONV0_SPLIT_BF16 / CONV0_SPLIT_F16 with conv0_split = the device
     image of conv0_splitbf16_pack / conv0_splitf16_pack (conv0 on the bf16 / f16 matrix cores with float32-grade arithmetic).
-    conv2_split / conv4_split / conv6_split: device images of conv_ci_splitf16_pack (those layers on the f16 matrix cores) or None."""
+    conv2_split / conv4_split / conv6_split: device images of conv_ci_splitf16_pack (those layers on the f16 matrix cores) or None;
+    conv9_split / conv11_split: device images of deconv9_splitf16_pack / deconv11_splitf16_pack (the transposed layers there) or None."""
     vol, depth_values = _dev(vol, "vol"), _dev(depth_values, "depth_values")
     B, cin, D, h, w = vol.shape
     if tuple(depth_values.shape) != (B, D, h, w):
@@ -525,20 +519,13 @@ def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, lay
             raise ValueError("costreg_regress: need 12 events")
         ev = (ctypes.c_void_p * 12)(*[e.cuda_event for e in layer_events])
     split = None
-    if conv0_split is not None or conv2_split is not None or conv4_split is not None or conv6_split is not None:
-        split = (ctypes.c_void_p * 4)(*[None if t is None else t.data_ptr() for t in (conv0_split, conv2_split, conv4_split, conv6_split)])
-    experimental = conv0_zmarch or deconv9_split is not None or deconv11_split is not None
+    images = (conv0_split, conv2_split, conv4_split, conv6_split, conv9_split, conv11_split)
+    if any(t is not None for t in images):
+        split = (ctypes.c_void_p * 6)(*[None if t is None else t.data_ptr() for t in images])
     with torch.cuda.device(dev):
-        if experimental:   # the layer set written without a GPU run (casmvs_costreg_regress_x_f32): opt-in only
-            rc = _lib.load().casmvs_costreg_regress_x_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
-                                                          _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
-                                                          float(slope), ev, _stream(vol), int(conv0_zmarch),
-                                                          None if deconv9_split is None else ctypes.c_void_p(deconv9_split.data_ptr()),
-                                                          None if deconv11_split is None else ctypes.c_void_p(deconv11_split.data_ptr()), 1 if fuse_tail else 0)
-        else:
-            rc = _lib.load().casmvs_costreg_regress_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
-                                                        _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
-                                                        float(slope), ev, _stream(vol))
+        rc = _lib.load().casmvs_costreg_regress_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
+                                                    _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
+                                                    float(slope), ev, _stream(vol))
     _lib.check(rc, "casmvs_costreg_regress_f32")
     return (cost, depth, conf, index) if return_index else (cost, depth, conf)
 
@@ -694,34 +681,8 @@ def fpn_tail0_splitf16(packed, bias9, conv0, feat1_sum, channels_last_copy=False
     return (out, out2) if channels_last_copy else out
 
 
-def fnet_conv0_fused_pack(w0, scale0, shift0, w1, scale1, shift1):
-    """Host-side packing for casmvs_fnet_conv0_fused_f32: conv0.0 (8,3,3,3) and conv0.1 (8,8,3,3) with their folded ABN -> uint8 CPU tensor."""
-    lib = _lib.load()
-    t = [None if a is None else a.detach().to("cpu", torch.float32).contiguous() for a in (w0, scale0, shift0, w1, scale1, shift1)]
-    if tuple(t[0].shape) != (8, 3, 3, 3) or tuple(t[3].shape) != (8, 8, 3, 3):
-        raise ValueError(f"fnet_conv0_fused_pack: weights {tuple(t[0].shape)} {tuple(t[3].shape)} (need (8,3,3,3) and (8,8,3,3))")
-    packed = torch.empty(lib.casmvs_fnet_conv0_fused_packed_bytes(), dtype=torch.uint8)
-    rc = lib.casmvs_fnet_conv0_fused_pack(*[_ptr(a) for a in t], ctypes.c_void_p(packed.data_ptr()))
-    _lib.check(rc, "casmvs_fnet_conv0_fused_pack")
-    return packed
-
-
-def fnet_conv0_fused(packed, imgs, slope=0.01):
-    """FeatureNet.conv0 (two ConvBnReLU layers) as one kernel (casmvs_fnet_conv0_fused_f32): imgs (N,3,H,W) -> (N,8,H,W).  Opt-in (added
-    without a GPU run at the end of round 3)."""
-    imgs = _dev(imgs, "imgs")
-    if not packed.is_cuda or packed.dtype != torch.uint8:
-        raise RuntimeError("fnet_conv0_fused: `packed` must be the uint8 image on the MI355X")
-    N, c, H, W = imgs.shape
-    out = torch.empty((N, 8, H, W), dtype=torch.float32, device=imgs.device)
-    with torch.cuda.device(imgs.device):
-        rc = _lib.load().casmvs_fnet_conv0_fused_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(imgs), _ptr(out), N, H, W, float(slope), _stream(imgs))
-    _lib.check(rc, "casmvs_fnet_conv0_fused_f32")
-    return out
-
-
 def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None, channels_last_copies=False, fused0=None, fused0_splitf16=False,
-                       ci_layers=None, conv0_fused=None):
+                       ci_layers=None):
     """Whole FeatureNet (mvsnet.py:40-57).  packed_layers: 13 device tensors (conv0.0 .. conv2.2,
     toplayer, lat1, lat0, smooth1, smooth0); imgs (N,3,H,W) -> feat0 (N,8,H,W), feat1 (N,16,H/2,W/2),
     feat2 (N,32,H/4,W/4).  layer_events: optional 14 recorded torch.cuda.Event.
@@ -759,17 +720,10 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
                 if len(ci_layers) != 5:
                     raise ValueError("featurenet_forward: ci_layers needs 5 entries (conv1.1, conv1.2, conv2.1, conv2.2, smooth1)")
                 ci = (ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in ci_layers])
-            if conv0_fused is not None:   # experimental: conv0.0 + conv0.1 as one kernel (casmvs_featurenet_forward_fused_x_f32), opt-in only
-                rc = _lib.load().casmvs_featurenet_forward_fused_x_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
-                                                                       ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
-                                                                       _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
-                                                                       ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev, _stream(imgs),
-                                                                       ctypes.c_void_p(conv0_fused.data_ptr()))
-            else:
-                rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
-                                                                     ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
-                                                                     _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
-                                                                     ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev, _stream(imgs))
+            rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
+                                                                 ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
+                                                                 _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
+                                                                 ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev, _stream(imgs))
         else:
             rc = _lib.load().casmvs_featurenet_forward_f32(arr, _ptr(imgs), _ptr(feat0), _ptr(feat1), _ptr(feat2),
                                                            _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CASMVS_ABI_VERSION 1
+#define CASMVS_ABI_VERSION 2
 
 #define CASMVS_OK 0
 #define CASMVS_ERR_INVALID_ARG (-1) /* null pointer / non-positive size / unsupported combination */
@@ -205,33 +205,22 @@ int casmvs_conv0_splitf16_pack(int cin, const float *weight, const float *scale,
 int casmvs_conv0_splitf16_supported(int cin, int W);
 int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
                                       float slope, int terms, void *stream);
-/* EXPERIMENTAL (written without a GPU run, opt-in): the same kernel with its x tile grid starting at x_offset - 32 (x_offset = 4; 0 = the entry above).
- * A staged row - 40 floats from x0 - 4 - then starts on a 128-byte line of the volume (W % 32 == 0) and touches two lines instead of three: on the CPU
- * model of the request stream (tools/lds_bank_profile.py) 0.8 of the 128-byte line requests at W = 128, ~0.7 at W = 640, for one more tile column.
- * Three-term products; results agree with the entry above to float32 rounding (the per-tile scalings cover other voxels). */
-int casmvs_conv0_splitf16_forward_x_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W,
-                                        float slope, int x_offset, void *stream);
-
 /* conv0 in the same split-f16 arithmetic, input-stationary along z (csrc/conv0_zmarch.hip): a workgroup owns a 16 x 32 (y, x) patch and
  * marches along z, staging every input plane once per chunk of 8 channels (per-plane power-of-two scaling) and feeding the three
  * output planes it touches - half the staged voxels per output voxel of casmvs_conv0_splitf16_forward_f32, whose L1 -> L2 request
  * stream bounds it.  `packed`: the image of casmvs_conv0_splitf16_pack.  cin = 8, 16 (two workgroups per CU) or 32 (one), W % 4 == 0.  Results agree with the other
  * entry to ~1e-6 of the range (both ~3e-7 from a float64 convolution), not bit for bit.
- * WRITTEN WITHOUT A GPU RUN at the end of round 3 (tools/native/conv0_zm_check.cpp is its first test): opt-in, nothing in the
- * package calls it. */
+ * Measured on the MI355X (tools/native/conv0_zm_check.cpp, profiles/r04_native_checks_first_run.txt): 1.10-1.15x the tiled kernel at cin = 16
+ * (cascade level 1), equal at cin = 8, 0.74-0.9x at cin = 32 - casmvs_costreg_regress_f32 uses it for cin = 16. */
 int casmvs_conv0_zmarch_supported(int cin, int W);
 int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope,
                                     void *stream);
-/* ... on the patch grid shifted by x_offset = 4 voxels (see casmvs_conv0_splitf16_forward_x_f32); x_offset = 0: the entry above. */
-int casmvs_conv0_zmarch_forward_x_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope,
-                                      int x_offset, void *stream);
-
 /* CostRegNet.conv11 = ConvTranspose3d(16 -> 8, k3 s2 p1 op1) + ABN + leaky-relu, plus the `conv0 + ...` skip (models/mvsnet.py:84-86, 101), on the
  * f16 matrix cores in the same split arithmetic (csrc/deconv11_splitf16.hip): the x parities of the output are the two halves of the MFMA rows,
  * K = 2 input x positions x 16 input channels, one MFMA set per (kz, ky) pair and 32 output x; output tile 4 x 8 x 32 from a 3 x 5 x 18 input box.
  * in (B, 16, Di, Hi, Wi); skip (B, 8, 2 Di, 2 Hi, 2 Wi) or NULL; out like skip.  weight (16, 8, 3, 3, 3) = the torch ConvTranspose3d layout.
  * casmvs_conv3d_forward_f32(CASMVS_CONV_T2, ...) is the float32-MFMA form of the same layer (0.9 ms of the 8.5 ms step).
- * WRITTEN WITHOUT A GPU RUN at the end of round 3 (tools/native/deconv11_check.cpp is its first test): opt-in, nothing in the package calls it. */
+ * Measured on the MI355X (tools/native/deconv11_check.cpp): 1.0-1.03x the float32 kernel, equal bits run to run; casmvs_costreg_regress_f32 takes its image as split_layers[5]. */
 size_t casmvs_deconv11_splitf16_packed_bytes(void);
 int casmvs_deconv11_splitf16_pack(const float *weight, const float *scale, const float *shift, void *packed);
 int casmvs_deconv11_splitf16_supported(int Wi);
@@ -241,39 +230,13 @@ int casmvs_deconv11_splitf16_forward_f32(const void *packed, const float *in, co
 /* CostRegNet.conv9 = ConvTranspose3d(32 -> 16, k3 s2 p1 op1) + ABN + leaky-relu, plus the `conv2 + ...` skip (models/mvsnet.py:80-82, 99) the same
  * way (csrc/deconv9_splitf16.hip): MFMA rows = the 16 output channels, K = the 32 input channels of one input voxel, three sets per (kz, ky) pair
  * (kx = 1 -> even outputs; kx = 2 and kx = 0 from the next input -> odd outputs).  in (B, 32, Di, Hi, Wi); skip / out (B, 16, 2 Di, 2 Hi, 2 Wi).
- * WRITTEN WITHOUT A GPU RUN at the end of round 3 (tools/native/deconv9_check.cpp is its first test): opt-in, nothing in the package calls it. */
+ * Measured on the MI355X (tools/native/deconv9_check.cpp): 1.2x the float32 kernel at the engine's shapes; casmvs_costreg_regress_f32 takes its image as split_layers[4]. */
 size_t casmvs_deconv9_splitf16_packed_bytes(void);
 int casmvs_deconv9_splitf16_pack(const float *weight, const float *scale, const float *shift, void *packed);
 int casmvs_deconv9_splitf16_supported(int Wi);
 int casmvs_deconv9_splitf16_forward_f32(const void *packed, const float *in, const float *skip, float *out, int B, int Di, int Hi, int Wi,
                                         float slope, void *stream);
 
-/* CostRegNet's tail as ONE kernel (csrc/conv11_prob_fused.hip): conv11 (+ ABN + leaky-relu) + the conv0 skip, the `prob` head walking the depth axis and - when
- * the depth range is one chunk - softmax / depth regression / confidence: the 8-channel full-resolution tensor between conv11 and `prob` (16 n of the 28 n
- * floats the pair moves) exists only as LDS plane patches.  deconv11_image: casmvs_deconv11_splitf16_pack; prob_packed: casmvs_conv3d_pack_f32(CASMVS_CONV_S1, 8, 1);
- * u9 (B, 16, D/2, h/2, w/2) = conv9's output; skip (B, 8, D, h, w) = conv0's output; cost (B, D, h, w) always written; depth / confidence (B, h, w)
- * [, index] with depth_values (B, D, h, w), or depth = NULL (cost only).  D, h even, w % 4 == 0.  zchunk 0 = automatic.
- * WRITTEN WITHOUT A GPU RUN at the end of round 3 (runs correctly on the CPU under tests/hipemu; tools/native/conv11_prob_check.cpp is its first GPU test). */
-int casmvs_conv11_prob_regress_supported(int D, int h, int w);
-int casmvs_conv11_prob_regress_f32(const void *deconv11_image, const float *prob_packed, const float *u9, const float *skip, const float *depth_values,
-                                   float *cost, float *depth, float *confidence, int32_t *index, int B, int D, int h, int w, float slope, int zchunk,
-                                   void *stream);
-
-/* The engine's two whole-network calls with the EXPERIMENTAL layer set (the kernels above that were written without a GPU run: until their first
- * tests have passed on the MI355X nothing in the package passes non-default values here).  As casmvs_costreg_regress_f32 plus: conv0_zmarch 1 = conv0
- * through casmvs_conv0_zmarch_forward_f32 for cin 8 / 16 (2: also cin 32; needs conv0_arith = CASMVS_CONV0_SPLIT_F16 and its image; + 4: conv0's
- * tile grid - of either kernel - shifted by 4 voxels in x, casmvs_conv0_splitf16_forward_x_f32),
- * deconv9_image / deconv11_image = device images of casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack or NULL; fuse_tail 1 (with
- * deconv11_image) = conv11 + skip + `prob` + regression through casmvs_conv11_prob_regress_f32.  As
- * casmvs_featurenet_forward_fused_f32 plus: conv0_fused_image = device image of casmvs_fnet_conv0_fused_pack or NULL. */
-int casmvs_costreg_regress_x_f32(const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol,
-                                 const float *depth_values, float *cost, float *depth, float *confidence, int32_t *index, void *workspace,
-                                 int B, int cin, int D, int h, int w, float slope, void *const *layer_events, void *stream, int conv0_zmarch,
-                                 const void *deconv9_image, const void *deconv11_image, int fuse_tail);
-int casmvs_featurenet_forward_fused_x_f32(const float *const *packed_layers, const void *fused0_packed, int fused0_arith, const float *fused0_bias9,
-                                          const void *const *ci_layers, const float *imgs, float *feat0, float *feat1, float *feat2,
-                                          float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc, void *workspace, int N, int H, int W, float slope,
-                                          void *const *layer_events, void *stream, const void *conv0_fused_image);
 int casmvs_selftest_mfma_f16(float *dump);
 
 /* CostRegNet's stride-1 layers with equal channel counts (conv2: 16 -> 16, conv4: 32 -> 32, conv6: 64 -> 64; Conv3d k3 s1 p1 + folded ABN +
@@ -377,18 +340,6 @@ int casmvs_featurenet_forward_fused_f32(const float *const *packed_layers, const
                                         void *workspace, int N, int H, int W, float slope,
                                         void *const *layer_events, void *stream);
 
-/* FeatureNet.conv0 = ConvBnReLU(3, 8, 3) -> ConvBnReLU(8, 8, 3) (models/mvsnet.py:14-16) as ONE kernel (csrc/fnet_conv0_fused.hip): the image tile
- * in LDS, the first layer on the vector ALU (its 8-channel output never leaves the CU), the second in conv0_splitf16.hip's matrix form with
- * one z tap (float32-grade split-f16 arithmetic).  imgs (N, 3, H, W) -> out (N, 8, H, W); W % 4 == 0.  `packed` (host,
- * casmvs_fnet_conv0_fused_packed_bytes): w0 (8,3,3,3) / w1 (8,8,3,3) = the torch weights, scale / shift = the folded eval-mode ABN of each layer.
- * WRITTEN WITHOUT A GPU RUN at the end of round 3 (tools/native/fnet_conv0_check.cpp is its first test): opt-in, nothing in the package
- * calls it; casmvs_featurenet_forward*_f32 run the two layers as separate launches. */
-size_t casmvs_fnet_conv0_fused_packed_bytes(void);
-int casmvs_fnet_conv0_fused_pack(const float *w0, const float *scale0, const float *shift0, const float *w1, const float *scale1,
-                                 const float *shift1, void *packed);
-int casmvs_fnet_conv0_fused_supported(int W);
-int casmvs_fnet_conv0_fused_f32(const void *packed, const float *imgs, float *out, int N, int H, int W, float slope, void *stream);
-
 /* ---- (a9) softmax over depth + soft-argmin regression + confidence --------------------------
  * Replaces: models/mvsnet.py:174-193 and models/modules.py:95-104:
  *   p = softmax_D(cost); depth = sum_k p_k d_k; idx = clamp(trunc(sum_k p_k k), 0, D-1);
@@ -417,18 +368,22 @@ int casmvs_prob_regress_f32(const float *packed, const float *in, const float *d
                             float *depth, float *confidence, int32_t *index, int B, int cin, int D, int h,
                             int w, float slope, int zchunk, void *stream);
 
-/* Debug tooling (tools/debug/disturber.py, DESIGN.md "co-residency"): a neighbour kernel of a chosen kind - 0 f32 MFMA, 1 f16 MFMA,
- * 2 bf16 MFMA, 3 LDS traffic over its whole allocation, 4 VALU - with `lds_bytes` (16 .. 163840) of dynamic LDS per 256-thread workgroup. */
+#ifdef CASMVS_TRACE
+/* Debug tooling, -DCASMVS_TRACE builds only (tools/build_trace_lib.sh; tools/debug/disturber.py, DESIGN.md "co-residency"): a neighbour kernel of a
+ * chosen kind - 0 f32 MFMA, 1 f16 MFMA, 2 bf16 MFMA, 3 LDS traffic over its whole allocation, 4 VALU - with `lds_bytes` (16 .. 163840) of dynamic LDS
+ * per 256-thread workgroup.  The production library does not contain it. */
 int casmvs_debug_disturb(int kind, int blocks, int iters, int lds_bytes, float *sink, void *stream);
+#endif
 
 /* Whole CostRegNet + regression: casmvs_costreg_forward_f32 with the head replaced by casmvs_prob_regress_f32.
  * `cost` (B, D, h, w) is still produced.  layer_events: as casmvs_costreg_forward_f32 (event 10 before the head,
  * event 11 after the head INCLUDING the regression).  conv0_arith selects conv0's arithmetic: CASMVS_CONV0_F32 (the float32
  * MFMA kernel on packed_layers[0]), CASMVS_CONV0_SPLIT_BF16 / CASMVS_CONV0_SPLIT_F16 with split_layers[0] = the DEVICE copy of
  * casmvs_conv0_splitbf16_pack's / casmvs_conv0_splitf16_pack's image of conv0 (cin 8 / 16 / 32; any other shape falls back to the
- * float32 kernel).  split_layers: NULL, or 4 pointers { conv0, conv2, conv4, conv6 images, each or NULL }; a non-NULL conv2 / conv4 / conv6
- * entry (DEVICE copy of casmvs_conv_ci_splitf16_pack's image) runs that layer on the f16 matrix cores too (conv4 / conv6 only where the
- * volume gives >= 100 tiles; conv6 only with >= 3 planes). */
+ * float32 kernel; with the split-f16 image cin = 16 runs casmvs_conv0_zmarch_forward_f32).  split_layers: NULL, or SIX pointers { conv0, conv2, conv4,
+ * conv6, conv9, conv11 images, each or NULL } (ABI version 2; version 1 read four); a non-NULL conv2 / conv4 / conv6 entry (DEVICE copy of
+ * casmvs_conv_ci_splitf16_pack's image) runs that layer on the f16 matrix cores too (conv4 / conv6 only where the volume gives >= 100 tiles; conv6
+ * only with >= 3 planes), a non-NULL conv9 / conv11 entry (casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack) the transposed layers. */
 #define CASMVS_CONV0_F32 0
 #define CASMVS_CONV0_SPLIT_BF16 1
 #define CASMVS_CONV0_SPLIT_F16 2

@@ -1,17 +1,17 @@
 // Runs kernels of casmvsnet_pl_amd/csrc on the CPU through tests/hipemu/hip/hip_runtime.h - their own source - against float64 references:
 //   conv0_sf    the established tiled conv0 kernel (validated on the MI355X): checks the EMULATOR
-//   conv0_zm / fnet_conv0 / deconv11 / deconv9    the kernels written without a GPU run at the end of round 3
+//   conv0_zm / deconv11 / deconv9    written without a GPU run at the end of round 3 with this emulation as their only test; all three passed
+//                                    their first run on the MI355X unchanged (profiles/r04_native_checks_first_run.txt) and are defaults now
 // Build (tests/test_hip_emulation.py does it):
 //   /opt/rocm/lib/llvm/bin/clang++ -std=c++20 -O1 -pthread -DCASMVS_SPLIT_NOASM -Itests/hipemu -Iinclude -Icasmvsnet_pl_amd/csrc tests/hipemu/run_kernels.cpp -o <exe>
 #include "support.h"
 
 #include "conv0_splitf16.hip"
 #include "conv0_zmarch.hip"
-#include "fnet_conv0_fused.hip"
 #include "deconv11_splitf16.hip"
 #include "deconv9_splitf16.hip"
 
-static double conv3d_check(const char *name, int cin, int B, int D, int H, int W, bool zmarch, int xoff = 0) {
+static double conv3d_check(const char *name, int cin, int B, int D, int H, int W, bool zmarch) {
   const size_t n = (size_t)D * H * W;
   std::vector<float> x((size_t)B * cin * n), w((size_t)8 * cin * 27), sc(8), sh(8), y((size_t)B * 8 * n, NAN);
   for (auto &v : x) v = rnd() * 3.0f + 0.4f;
@@ -23,10 +23,8 @@ static double conv3d_check(const char *name, int cin, int B, int D, int H, int W
   float *xa = (float *)std::aligned_alloc(256, (x.size() * 4 + 255) & ~(size_t)255), *ya = (float *)std::aligned_alloc(256, (y.size() * 4 + 255) & ~(size_t)255);   // as device allocations: whole cache lines
   std::memcpy(xa, x.data(), x.size() * 4);
   std::memcpy(ya, y.data(), y.size() * 4);
-  const int rc = xoff ? (zmarch ? casmvs_conv0_zmarch_forward_x_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, xoff, nullptr)
-                                : casmvs_conv0_splitf16_forward_x_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, xoff, nullptr))
-                      : (zmarch ? casmvs_conv0_zmarch_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, nullptr)
-                                : casmvs_conv0_splitf16_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, 0, nullptr));
+  const int rc = zmarch ? casmvs_conv0_zmarch_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, nullptr)
+                        : casmvs_conv0_splitf16_forward_f32(pk, xa, ya, B, cin, D, H, W, 0.01f, 0, nullptr);
   if (rc) { printf("%s: %s\n", name, casmvs_last_error()); return 1e9; }
   double err = 0, range = 0;
   for (int b = 0; b < B; ++b)
@@ -50,50 +48,6 @@ static double conv3d_check(const char *name, int cin, int B, int D, int H, int W
           }
   std::free(xa); std::free(ya);
   printf("%-10s cin=%d B=%d %dx%dx%d: max error / range = %.2e\n", name, cin, B, D, H, W, err / range);
-  return err / range;
-}
-
-static double fnet_check(int N, int H, int W) {
-  const size_t hw = (size_t)H * W;
-  std::vector<float> x((size_t)N * 3 * hw), w0(8 * 3 * 9), w1(8 * 8 * 9), s0(8), b0(8), s1(8), b1(8);
-  for (auto &v : x) v = rnd() * 2.0f;
-  for (auto &v : w0) v = rnd() * 0.3f;
-  for (auto &v : w1) v = rnd() * 0.2f;
-  for (int c = 0; c < 8; ++c) { s0[c] = 0.6f + 0.1f * c; b0[c] = 0.05f * (c - 3); s1[c] = 1.2f - 0.07f * c; b1[c] = 0.03f * (4 - c); }
-  unsigned char *pk = (unsigned char *)std::aligned_alloc(256, (casmvs_fnet_conv0_fused_packed_bytes() + 255) & ~(size_t)255);
-  casmvs_fnet_conv0_fused_pack(w0.data(), s0.data(), b0.data(), w1.data(), s1.data(), b1.data(), pk);
-  float *xa = (float *)std::aligned_alloc(256, (x.size() * 4 + 255) & ~(size_t)255), *ya = (float *)std::aligned_alloc(256, ((size_t)N * 8 * hw * 4 + 255) & ~(size_t)255);
-  std::memcpy(xa, x.data(), x.size() * 4);
-  for (size_t i = 0; i < (size_t)N * 8 * hw; ++i) ya[i] = NAN;
-  if (casmvs_fnet_conv0_fused_f32(pk, xa, ya, N, H, W, 0.01f, nullptr)) { printf("fnet_conv0: %s\n", casmvs_last_error()); return 1e9; }
-  std::vector<double> mid((size_t)N * 8 * hw);
-  auto conv = [&](auto in_at, int cin, const std::vector<float> &w, const std::vector<float> &sc, const std::vector<float> &sh, auto out_set) {
-    for (int n = 0; n < N; ++n)
-      for (int co = 0; co < 8; ++co)
-        for (int yy = 0; yy < H; ++yy)
-          for (int xx = 0; xx < W; ++xx) {
-            double acc = 0;
-            for (int ci = 0; ci < cin; ++ci)
-              for (int ky = 0; ky < 3; ++ky)
-                for (int kx = 0; kx < 3; ++kx) {
-                  const int iy = yy + ky - 1, ix = xx + kx - 1;
-                  if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-                  acc += (double)w[((size_t)co * cin + ci) * 9 + ky * 3 + kx] * in_at(n, ci, iy, ix);
-                }
-            out_set(n, co, yy, xx, lrelu(acc * sc[co] + sh[co]));
-          }
-  };
-  conv([&](int n, int c, int yy, int xx) { return (double)x[((size_t)n * 3 + c) * hw + (size_t)yy * W + xx]; }, 3, w0, s0, b0,
-       [&](int n, int c, int yy, int xx, double v) { mid[((size_t)n * 8 + c) * hw + (size_t)yy * W + xx] = v; });
-  double err = 0, range = 0;
-  conv([&](int n, int c, int yy, int xx) { return mid[((size_t)n * 8 + c) * hw + (size_t)yy * W + xx]; }, 8, w1, s1, b1,
-       [&](int n, int c, int yy, int xx, double v) {
-         const float got = ya[((size_t)n * 8 + c) * hw + (size_t)yy * W + xx];
-         range = std::fmax(range, std::fabs(v));
-         err = std::fmax(err, std::isfinite(got) ? std::fabs(v - got) : 1e30);
-       });
-  std::free(pk); std::free(xa); std::free(ya);
-  printf("fnet_conv0 N=%d %dx%d: max error / range = %.2e\n", N, H, W, err / range);
   return err / range;
 }
 
@@ -167,26 +121,10 @@ int main(int argc, char **argv) {
     take(conv3d_check("conv0_sf", 16, 1, 8, 32, 128, false));
     take(conv3d_check("conv0_zm", 16, 1, 8, 32, 128, true));
   }
-  if (which == "conv0_compare_x") {   // the same problem on the tile grid shifted by 4 voxels
-    take(conv3d_check("conv0_sf_x4", 16, 1, 8, 32, 128, false, 4));
-    take(conv3d_check("conv0_zm_x4", 16, 1, 8, 32, 128, true, 4));
-  }
   if (which == "streams") {   // interior-dominated problems with cache-line-aligned rows: the request streams of the other unmeasured kernels (tools/lds_bank_profile.py)
-    take(fnet_check(1, 32, 128));
     take(deconv_check(16, 8, 1, 4, 8, 64));
     take(deconv_check(32, 16, 1, 2, 8, 64));
   }
-  // the shifted tile grids (x origin 4 - 32): a mostly empty first column, a ragged last one
-  if (all || which == "conv0_x4_quick" || which == "conv0_x4") {
-    take(conv3d_check("conv0_sf_x4", 8, 1, 5, 9, 36, false, 4));
-    take(conv3d_check("conv0_zm_x4", 16, 1, 5, 17, 36, true, 4));
-  }
-  if (all || which == "conv0_x4") {
-    take(conv3d_check("conv0_sf_x4", 32, 1, 3, 6, 64, false, 4));
-    take(conv3d_check("conv0_zm_x4", 8, 2, 6, 20, 28, true, 4));
-  }
-  if (all || quick || which == "fnet_conv0") take(fnet_check(1, 20, 36));
-  if (all || which == "fnet_conv0") take(fnet_check(2, 33, 44));
   if (all || quick || which == "deconv11") take(deconv_check(16, 8, 1, 2, 5, 18));
   if (all || which == "deconv11") { take(deconv_check(16, 8, 2, 3, 5, 10)); take(deconv_check(16, 8, 1, 1, 9, 22)); }
   if (all || quick || which == "deconv9") take(deconv_check(32, 16, 1, 1, 5, 18));

@@ -914,60 +914,6 @@ def emulate_conv0_zmarch(packed, x, cin, slope=0.01, patch=(16, 32), halo_x=(4, 
     return np.where(y > 0, y, y * slope)
 
 
-def emulate_fnet_conv0_fused(packed, imgs, slope=0.01, tile=(16, 32), halo_x=(4, 4)):
-    """Data flow of fnet_conv0_fused_kernel (csrc/fnet_conv0_fused.hip): conv0.0 (3 -> 8, 3 x 3, zero padding) + its folded ABN + leaky-relu
-    in float32 from the packed image's [ci][ky][kx][co] weights, ZERO outside the image; per 16 x 32 output tile that map's halo box
-    (y0-1..y0+16, x0-4..x0+35) is scaled by the power of two that puts its largest magnitude into [2^14, 2^15), split into two float16
-    slices and multiplied (aa, ab, ba) with conv0.1's lane images (the packing of a (kz, ky) pair of conv0_splitf16.hip, one per ky),
-    unscaled; conv0.1's scale (which carries 2^-kw) / shift / leaky-relu.  imgs (N, 3, H, W) float32 numpy -> (N, 8, H, W) float64."""
-    import numpy as np
-    raw = np.asarray(packed, dtype=np.uint8)
-    img1 = raw[:6144].view(np.float16).reshape(3, 2, 64, 8).astype(np.float64)
-    tail = raw[6144:6144 + 248 * 4].view(np.float32)
-    scale1, shift1 = tail[:8].astype(np.float64), tail[8:16].astype(np.float64)
-    w0 = tail[16:16 + 216].reshape(3, 3, 3, 8)                          # [ci][ky][kx][co]
-    scale0, shift0 = tail[232:240], tail[240:248]
-    N, _, H, W = imgs.shape
-    xp = np.pad(imgs.astype(np.float32), ((0, 0), (0, 0), (1, 1), (1, 1)))
-    mid = np.zeros((N, 8, H, W), np.float32)
-    for ci in range(3):
-        for ky in range(3):
-            for kx in range(3):
-                mid += xp[:, ci, None, ky:ky + H, kx:kx + W] * w0[ci, ky, kx][None, :, None, None]
-    mid = mid * scale0[None, :, None, None] + shift0[None, :, None, None]
-    mid = np.where(mid > 0, mid, mid * np.float32(slope)).astype(np.float32)
-    TY, TX = tile
-    hl, hr = halo_x
-    px = ((W + TX - 1) // TX) * TX - W
-    mp = np.pad(mid, ((0, 0), (0, 0), (1, TY + 1), (hl, hr + px)))
-    acc = np.zeros((N, 8, H, W))
-    for n in range(N):
-        for y0 in range(0, H, TY):
-            for x0 in range(0, W, TX):
-                halo = mp[n, :, y0:y0 + TY + 2, x0:x0 + TX + hl + hr]
-                e = max(int(np.abs(halo).max().view(np.uint32)) >> 23, 15)
-                mult, inv = np.float32(2.0) ** (141 - e), 2.0 ** (e - 141)
-                xs = halo * mult
-                xa = xs.astype(np.float16)
-                xb = (xs - xa.astype(np.float32)).astype(np.float16)
-                sl = [xa.astype(np.float64), xb.astype(np.float64)]
-                part = np.zeros((8, TY, TX))
-                for ky in range(3):
-                    for (sa, sb) in SF_TERMS[:3]:
-                        A = img1[ky, sa].reshape(4, 16, 8)                   # [u][i][ci]
-                        for u in range(4):
-                            for s in range(2):
-                                wrow = A[u, s::2, :]
-                                if not wrow.any():
-                                    continue
-                                src = sl[sb][:, ky:ky + TY, u - 1 + hl:u - 1 + hl + TX:2]
-                                part[:, :, s::2] += np.einsum("oc,chw->ohw", wrow, src)
-                dy, dx = min(TY, H - y0), min(TX, W - x0)
-                acc[n, :, y0:y0 + dy, x0:x0 + dx] = (part * inv)[:, :dy, :dx]
-    y = acc * scale1[None, :, None, None] + shift1[None, :, None, None]
-    return np.where(y > 0, y, y * slope)
-
-
 def emulate_deconv11_splitf16(packed, x, skip=None, slope=0.01, tile=(4, 8, 32)):
     """Data flow of deconv11_sf_kernel (csrc/deconv11_splitf16.hip) in float64.  The lane images [kz * 3 + ky][slice][lane][8 f16] are decoded into the two
     weight slices W_s[ci][co][kz][ky][kx] exactly as the kernel's lanes meet them (lane (i, kb): co = i >> 1, px = i & 1, dx = kb >> 1,
@@ -1201,83 +1147,6 @@ def emulate_conv0_zmarch_lanes(packed, x, cin, zlen, slope=0.01):
                             acc[wave, 0], acc[wave, 1] = acc[wave, 1].copy(), acc[wave, 2].copy()
                             acc[wave, 2] = 0.0
     assert not np.isnan(out).any(), "an output voxel was never written"
-    return out
-
-
-def emulate_fnet_conv0_lanes(packed, imgs, slope=0.01):
-    """fnet_conv0_fused_kernel thread by thread (csrc/fnet_conv0_fused.hip): the image tile's LDS indices (float 0 = x0 - 5, loaded groups at 4 g - 3),
-    a thread's conv0.0 window (six floats from 4 g of rows iy .. iy + 2), the zeroing outside the image, then conv0.1 as in conv0_zm_kernel."""
-    import numpy as np
-    raw = np.asarray(packed, dtype=np.uint8)
-    wl = raw[:6144].view(np.float16).reshape(3 * 2 * 64, 8).astype(np.float64)
-    tail = raw[6144:6144 + 248 * 4].view(np.float32)
-    N, _, H, W = imgs.shape
-    JY, JX, JG, ROW, NV = 20, 48, 12, 41, 18 * 41
-    PA, PB = (0, 0, 1), (0, 1, 0)
-    out = np.full((N, 8, H, W), np.nan)
-    lanes = np.arange(64)
-    jcol, u = lanes & 15, lanes >> 4
-    for n in range(N):
-        for ty0 in range(0, H, 16):
-            for tx0 in range(0, W, 32):
-                img = np.zeros(3 * JY * JX, np.float32)
-                for e in range(3 * JY * JG):
-                    c, rem = divmod(e, JY * JG)
-                    iy, g = divmod(rem, JG)
-                    gy, gx = ty0 - 2 + iy, tx0 - 8 + 4 * g
-                    J = imgs[n, c, gy, gx:gx + 4] if (0 <= gy < H and 0 <= gx < W) else np.zeros(4, np.float32)
-                    for j in range(4):
-                        if 4 * g - 3 + j >= 0:
-                            img[(c * JY + iy) * JX + 4 * g - 3 + j] = J[j]
-                R = np.zeros((256, 8, 4), np.float32)
-                vox, vxor = np.full(256, -1), np.zeros(256, int)
-                for tid in range(180):
-                    it_iy, it_g = divmod(tid, 10)
-                    vox[tid], vxor[tid] = it_iy * ROW + 4 * it_g, ((it_g >> 1) & 1) << 1
-                    accv = np.zeros((8, 4), np.float32)
-                    for ci in range(3):
-                        for ky in range(3):
-                            rowp = (ci * JY + it_iy + ky) * JX + 4 * it_g
-                            in6 = img[rowp:rowp + 6]
-                            for kx in range(3):
-                                w8 = tail[16 + ((ci * 3 + ky) * 3 + kx) * 8:][:8]
-                                for j in range(4):
-                                    accv[:, j] = (in6[j + kx] * w8 + accv[:, j]).astype(np.float32)
-                    gy, gx = ty0 - 1 + it_iy, tx0 - 4 + 4 * it_g
-                    for c in range(8):
-                        for j in range(4):
-                            v = np.float32(accv[c, j] * tail[232 + c] + tail[240 + c])
-                            v = v if v > 0 else np.float32(v * np.float32(slope))
-                            R[tid, c, j] = v if (0 <= gy < H and 0 <= gx + j < W) else 0.0
-                mult, inv = tile_scale_np(R)
-                act = np.zeros((2 * NV, 8))
-                for tid in range(180):
-                    for j in range(4):
-                        sa, sb = split_f16_np(R[tid, :, j], mult)
-                        act[0 * NV + vox[tid] + (j ^ vxor[tid])] = sa
-                        act[1 * NV + vox[tid] + (j ^ vxor[tid])] = sb
-                for wave in range(4):
-                    vbase = (4 * wave) * ROW + _px_slot(2 * jcol + u + 3)
-                    row = {(yr, s): act[s * NV + vbase + yr * ROW] for yr in range(6) for s in range(2)}
-                    part = np.zeros((4, 16, 16))
-                    for ky in range(3):
-                        a = [wl[(ky * 2 + s) * 64 + lanes] for s in range(2)]
-                        for p in range(3):
-                            for t in range(4):
-                                part[t] += mfma_16x16x32(a[PA[p]], row[(t + ky, PB[p])])
-                    for t in range(4):
-                        oy = ty0 + 4 * wave + t
-                        for l in range(64):
-                            uu, j = l >> 4, l & 15
-                            ox = tx0 + 2 * j
-                            if not (oy < H and ox < W):
-                                continue
-                            for h in range(2):
-                                co = 2 * uu + h
-                                for ph in range(2):
-                                    v = part[t, 4 * uu + 2 * h + ph, j] * inv * float(tail[co]) + float(tail[8 + co])
-                                    out[n, co, oy, ox + ph] = v if v > 0 else v * slope
-    assert not np.isnan(out).any(), "an output pixel was never written"
     return out
 
 

@@ -99,3 +99,35 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+def test_gpus_flag_builds_the_contract_launch_line_and_refuses_missing_gpus(bench):
+    """`python bench.py --gpus N` without WORLD_SIZE starts the N ranks itself under torch.distributed.run (one process per GPU, 127.0.0.1
+    rendezvous) - the driver's own launch line; on a node with fewer GPUs it says so instead of silently running world size 1."""
+    cmd = bench.torchrun_command(4, ["--gpus", "4", "--steps", "3"], port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "this node shows 0 GPU(s)" in (r.stderr + r.stdout)
+
+
+def test_dominant_kernel_roofline_never_exceeds_its_roof(bench):
+    """The arithmetic behind `roofline` for the split-f16 conv0: algorithmic bytes / time against 8 TB/s, the f16 FLOPs the matrix cores execute
+    against the dense f16 peak.  With round 3's driver-timed launch times (profiles/r03_kernel_stats.csv: 1002.6 / 646.2 / 486.3 us at levels 1 / 2 / 0,
+    batch 8) both fractions are ~0.25 - the float32-peak ratio that read 0.99 is reported as `fp32_equivalent`, not as a fraction."""
+    H, W, V, G, n_depths = bench.CONFIGS["dtu_640x512_v3_var"][:5]
+    B = 8
+    work = bench.algorithmic_work(H, W, V, G, n_depths, B)
+    t = {1: 1002.6e-6, 2: 646.2e-6, 0: 486.3e-6}
+    alg_bytes = sum(4 * B * (8 * 2 ** l + 8) * n_depths[l] * (H >> l) * (W >> l) for l in range(3))
+    flops = sum(work[l]["conv0_flops"] for l in range(3))
+    hbm_frac = alg_bytes / sum(t.values()) / 1e9 / bench.HBM_PEAK_GBS
+    f16_frac = 4.0 * flops / sum(t.values()) / 1e12 / bench.MFMA_F16_PEAK_TFLOPS
+    assert 0.2 < hbm_frac < 0.3 and 0.2 < f16_frac < 0.3
+    assert flops / sum(t.values()) / 1e12 / bench.MFMA_F32_PEAK_TFLOPS > 0.9   # the old headline ratio: why it is no longer called `frac`

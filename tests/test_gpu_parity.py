@@ -552,38 +552,175 @@ def test_conv2d_ci_splitf16_matches_torch_cpu(dev, report, c, N, H, W, amp, cout
 
 
 def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
-    """Every launch of the f16-matrix-core kernels reproduces the first launch's bits at sizes that keep two workgroups per CU busy
-    (thousands of tiles).  Guards a hazard found in round 3: floating-point VALU work issued between a wave's own f16 MFMAs
-    (the FPN tail's per-tile interpolation constants) came out wrong in lanes 48-63 in ~1 of 500 tiles - only under full occupancy,
-    so the small parity cases above could not see it."""
+    """Every launch of EVERY f16-matrix-core kernel instantiation the forward can select reproduces the first launch's bits, 30 launches each, at sizes
+    that keep two workgroups per CU busy (thousands of tiles), and so does the batch-8 hipGraph bench.py times (30 replays).  Guards a hazard found in
+    round 3: floating-point VALU work issued between a wave's own f16 MFMAs (the FPN tail's per-tile interpolation constants) came out wrong in lanes
+    48-63 in ~1 of 500 tiles - only under full occupancy, so the small parity cases above could not see it.  The compiled schedules these
+    launches validate are pinned by tests/golden/mfma_phase_fp_instructions.json (tests/test_device_code_lints.py, CPU)."""
     from casmvsnet_pl_amd.mvsnet import compose_fpn_tail
     ops = _ops()
     g = torch.Generator().manual_seed(0)
     cases = []
-    x0 = torch.randn(2, 16, 32, 128, 160, generator=g).to(dev)
-    w0 = torch.randn(8, 16, 3, 3, 3, generator=g) * 0.1
-    p0 = ops.conv0_splitf16_pack(w0).to(dev)
-    pb = ops.conv0_splitbf16_pack(w0).to(dev)
-    cases.append(("conv0_sf", lambda: ops.conv0_splitf16_forward(p0, x0)))
-    cases.append(("conv0_sb", lambda: ops.conv0_splitbf16_forward(pb, x0)))
-    xc = torch.randn(2, 16, 16, 128, 160, generator=g).to(dev)
-    pc = ops.conv_ci_splitf16_pack(torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1).to(dev)
-    cases.append(("conv_ci_sf", lambda: ops.conv_ci_splitf16_forward(pc, xc, 16)))
-    lw, lb = torch.randn(32, 8, 1, 1, generator=g) * 0.3, torch.randn(32, generator=g)
-    sw, sb = torch.randn(8, 32, 3, 3, generator=g) * 0.2, torch.randn(8, generator=g)
+    rnd = lambda *shape, amp=1.0: (torch.randn(*shape, generator=g) * amp)
+    # conv0: the tiled kernel at cin 8 / 16 / 32, the z-marching kernel at cin 16 (what the regulariser runs at level 1) and cin 8, bf16 form (opt-in mode)
+    for cin, (B, D, H, W) in ((8, (2, 8, 512, 640)), (16, (2, 32, 128, 160)), (32, (2, 48, 128, 160))):
+        x0 = rnd(B, cin, D, H, W).to(dev)
+        w0 = rnd(8, cin, 3, 3, 3, amp=0.1)
+        p0 = ops.conv0_splitf16_pack(w0).to(dev)
+        cases.append((f"conv0_sf<{cin}>", lambda p0=p0, x0=x0: ops.conv0_splitf16_forward(p0, x0)))
+        if cin != 32:
+            cases.append((f"conv0_zm<{cin}>", lambda p0=p0, x0=x0: ops.conv0_zmarch_forward(p0, x0)))
+        if cin == 16:
+            pb = ops.conv0_splitbf16_pack(w0).to(dev)
+            cases.append(("conv0_sb<16>", lambda pb=pb, x0=x0: ops.conv0_splitbf16_forward(pb, x0)))
+    # conv2 / conv4 / conv6: every (channels, planes-per-tile) form - TZ 4, and TZ 2 for 2-plane volumes (conv4 at level 0)
+    for c, (B, D, H, W) in ((16, (2, 16, 128, 160)), (16, (8, 2, 256, 320)), (32, (4, 8, 64, 80)), (32, (8, 2, 128, 160)), (64, (8, 6, 32, 40))):
+        xc = rnd(B, c, D, H, W).to(dev)
+        pc = ops.conv_ci_splitf16_pack(rnd(c, c, 3, 3, 3, amp=0.1)).to(dev)
+        cases.append((f"conv_ci_sf<{c},{c},{2 if D <= 2 else 4}>", lambda pc=pc, xc=xc, c=c: ops.conv_ci_splitf16_forward(pc, xc, c)))
+    # conv9 / conv11 (transposed, with their skip tensors)
+    x9, s9 = rnd(4, 32, 8, 64, 80).to(dev), rnd(4, 16, 16, 128, 160).to(dev)
+    p9 = ops.deconv9_splitf16_pack(rnd(32, 16, 3, 3, 3, amp=0.1), torch.ones(16), torch.zeros(16)).to(dev)
+    cases.append(("deconv9_sf", lambda: ops.deconv9_splitf16_forward(p9, x9, s9)))
+    x11, s11 = rnd(2, 16, 16, 128, 160).to(dev), rnd(2, 8, 32, 256, 320).to(dev)
+    p11 = ops.deconv11_splitf16_pack(rnd(16, 8, 3, 3, 3, amp=0.1), torch.ones(8), torch.zeros(8)).to(dev)
+    cases.append(("deconv11_sf", lambda: ops.deconv11_splitf16_forward(p11, x11, s11)))
+    # FeatureNet: the fused tail and the three 2D channel-inner forms
+    lw, lb = rnd(32, 8, 1, 1, amp=0.3), rnd(32)
+    sw, sb = rnd(8, 32, 3, 3, amp=0.2), rnd(8)
     w40, bias9 = compose_fpn_tail(lw, lb, sw, sb)
     pf, b9 = ops.fpn_tail0_splitf16_pack(w40).to(dev), bias9.to(dev)
-    xf, yf = torch.randn(6, 8, 512, 640, generator=g).to(dev), torch.randn(6, 32, 256, 320, generator=g).to(dev)
+    xf, yf = rnd(6, 8, 512, 640).to(dev), rnd(6, 32, 256, 320).to(dev)
     cases.append(("fpn_tail0_sf", lambda: ops.fpn_tail0_splitf16(pf, b9, xf, yf)))
-    x2 = torch.randn(6, 16, 256, 320, generator=g).to(dev)
-    p2 = ops.conv2d_ci_splitf16_pack(torch.randn(16, 16, 3, 3, generator=g) * 0.1).to(dev)
-    cases.append(("conv2d_ci_sf", lambda: ops.conv2d_ci_splitf16_forward(p2, x2)))
+    for (cin, cout), (N, H, W) in (((16, 16), (6, 256, 320)), ((32, 32), (12, 128, 160)), ((32, 16), (6, 256, 320))):
+        x2 = rnd(N, cin, H, W).to(dev)
+        p2 = ops.conv2d_ci_splitf16_pack(rnd(cout, cin, 3, 3, amp=0.1)).to(dev)
+        cases.append((f"conv2d_ci_sf<{cin},{cout}>", lambda p2=p2, x2=x2, cout=cout: ops.conv2d_ci_splitf16_forward(p2, x2, cout=cout)))
+    launches = 30
     bad = {}
     for name, fn in cases:
         ref = fn()
-        bad[name] = sum(0 if torch.equal(fn(), ref) else 1 for _ in range(15))
-    report("split_f16_bit_stability", launches=15, differing=bad)
-    assert not any(bad.values()), bad
+        bad[name] = sum(0 if torch.equal(fn(), ref) else 1 for _ in range(launches))
+    del cases, ref
+    torch.cuda.empty_cache()
+    # the launch bench.py times: batch 8, one hipGraph replay per step
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet
+    from casmvsnet_pl_amd.graph import GraphedForward
+    from casmvsnet_pl_amd.synthetic import config_inputs, randomize_state_dict
+    model = CascadeMVSNet(norm_act=ABN)
+    randomize_state_dict(model.state_dict(), seed=0)
+    model = model.to(dev).eval()
+    imgs, proj, dmin, dint = config_inputs("dtu_640x512_v3_var", 8, seed=0)
+    gf = GraphedForward(model, imgs.to(dev), proj.to(dev), dmin, dint)
+    ref = {k: v.clone() for k, v in gf().items()}
+    bad["graph_batch8"] = 0
+    for _ in range(launches):
+        out = gf()
+        bad["graph_batch8"] += 0 if all(torch.equal(out[k], ref[k]) for k in ref) else 1
+    report("split_f16_bit_stability", launches=launches, differing=bad)
+    assert len(bad) == 18 and not any(bad.values()), bad
+
+
+@pytest.mark.parametrize("cin,shape", [(8, (2, 8, 48, 64)), (16, (1, 9, 17, 44)), (32, (1, 12, 32, 40))])
+def test_conv0_zmarch_equals_the_tiled_kernel(dev, report, cin, shape):
+    """conv0_zmarch.hip (input-stationary along z; the regulariser's conv0 at cin = 16) against the tiled split-f16 kernel on the same packed image, and
+    both against the layer in float64: other staging units and summation grouping, the same float32-grade arithmetic."""
+    ops = _ops()
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn(B, cin, D, H, W, generator=g) * 3
+    w = torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2
+    scale, shift = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    ref = F.conv3d(x.double(), w.double(), padding=1) * scale.double().view(1, 8, 1, 1, 1) + shift.double().view(1, 8, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01)
+    packed = ops.conv0_splitf16_pack(w, scale, shift).to(dev)
+    xd = x.to(dev)
+    tiled = ops.conv0_splitf16_forward(packed, xd)
+    got = ops.conv0_zmarch_forward(packed, xd)
+    assert torch.equal(got, ops.conv0_zmarch_forward(packed, xd))
+    e_zm, e_tiled = scaled_err(got.cpu(), ref), scaled_err(tiled.cpu(), ref)
+    report("conv0_zmarch", cin=cin, shape=list(shape), err_zmarch=e_zm, err_tiled=e_tiled)
+    assert e_zm < 2e-6 and e_zm < 3 * max(e_tiled, 2e-7)
+
+
+@pytest.mark.parametrize("which,shape", [("deconv11", (2, 4, 12, 20)), ("deconv11", (1, 3, 5, 34)), ("deconv9", (2, 3, 6, 10)), ("deconv9", (1, 2, 5, 18))])
+def test_deconv_splitf16_equals_the_layer(dev, report, which, shape):
+    """conv9 / conv11 (ConvTranspose3d k3 s2 p1 op1 + folded ABN + leaky-relu + skip, mvsnet.py:80-86,99-101) on the f16 matrix cores against the layer in
+    float64, beside the float32 MFMA kernel's own error."""
+    ops = _ops()
+    cin, cout = (16, 8) if which == "deconv11" else (32, 16)
+    B, Di, Hi, Wi = shape
+    g = torch.Generator().manual_seed(Di + Wi)
+    x = torch.randn(B, cin, Di, Hi, Wi, generator=g) * 2
+    w = torch.randn(cin, cout, 3, 3, 3, generator=g) * 0.2
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    skip = torch.randn(B, cout, 2 * Di, 2 * Hi, 2 * Wi, generator=g)
+    ref = F.conv_transpose3d(x.double(), w.double(), None, stride=2, padding=1, output_padding=1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1)
+    ref = torch.where(ref > 0, ref, ref * 0.01) + skip.double()
+    f32 = ops.conv3d_forward(ops.CONV_T2, ops.conv3d_pack(ops.CONV_T2, w, sc, sh).to(dev), x.to(dev), cout, skip.to(dev)).cpu()
+    pack, fwd = (ops.deconv11_splitf16_pack, ops.deconv11_splitf16_forward) if which == "deconv11" else (ops.deconv9_splitf16_pack, ops.deconv9_splitf16_forward)
+    got = fwd(pack(w, sc, sh).to(dev), x.to(dev), skip.to(dev)).cpu()
+    e_sf, e_f32 = scaled_err(got, ref), scaled_err(f32, ref)
+    report("deconv_splitf16", which=which, shape=list(shape), err_splitf16=e_sf, err_f32_mfma=e_f32)
+    assert torch.isfinite(got).all() and e_sf < 3e-6 and e_sf < 4 * max(e_f32, 2e-7)
+
+
+@pytest.mark.parametrize("kernel", ["conv0_sf", "conv0_zm", "conv_ci_sf"])
+def test_split_f16_kernels_never_turn_non_finite_inputs_into_finite_wrong_values(dev, kernel):
+    """Round-3 advisor finding (csrc/split_f16.h: tile_scale): a NaN voxel reaches exactly the outputs whose taps touch it (the per-tile maximum skips NaNs);
+    an INFINITE voxel leaves its staged unit without a finite scaling, so the whole unit is poisoned: every output is either non-finite or bit-equal to the
+    clean run's, and every output within the 3 x 3 x 3 reach of the bad voxel is non-finite - never a silently flushed finite value."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(17)
+    cin = {"conv0_sf": 8, "conv0_zm": 16, "conv_ci_sf": 16}[kernel]
+    x = torch.randn(1, cin, 8, 32, 64, generator=g)
+    if kernel == "conv_ci_sf":
+        packed = ops.conv_ci_splitf16_pack(torch.randn(cin, cin, 3, 3, 3, generator=g) * 0.2).to(dev)
+        run = lambda t: ops.conv_ci_splitf16_forward(packed, t.to(dev), cin).cpu()
+    else:
+        packed = ops.conv0_splitf16_pack(torch.randn(8, cin, 3, 3, 3, generator=g) * 0.2).to(dev)
+        fwd = ops.conv0_splitf16_forward if kernel == "conv0_sf" else ops.conv0_zmarch_forward
+        run = lambda t: fwd(packed, t.to(dev)).cpu()
+    clean = run(x)
+    assert torch.isfinite(clean).all()
+    z, y, xx = 4, 13, 37
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        xb = x.clone()
+        xb[0, 3, z, y, xx] = bad
+        got = run(xb)
+        finite = torch.isfinite(got)
+        assert torch.equal(got[finite], clean[finite]), (kernel, bad)
+        assert not finite[0, :, z - 1:z + 2, y - 1:y + 2, xx - 1:xx + 2].any(), (kernel, bad)
+        if bad != bad:   # NaN: nothing beyond the taps' reach is lost
+            touched = torch.zeros_like(finite)
+            touched[0, :, z - 1:z + 2, y - 1:y + 2, xx - 1:xx + 2] = True
+            assert bool(finite[~touched].all()), kernel
+        assert float(finite.float().mean()) > 0.5, (kernel, bad)   # the poisoned unit is local
+
+
+def test_whole_forward_float32_layers_equal_the_split_f16_layers(dev, report):
+    """The engine with every layer on the float32 MFMA kernels against the default layer set (conv0 / 2 / 4 / 6 / 9 / 11 and six FeatureNet layers on the
+    f16 matrix cores) on one problem: depths agree to float32 rounding in the median and within the oracle bound everywhere."""
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet
+    from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
+    model = CascadeMVSNet(norm_act=ABN)
+    randomize_state_dict(model.state_dict(), seed=3)
+    model = model.to(dev).eval()
+    imgs, proj, dmin, dint = make_inputs(2, 3, 128, 160, seed=4)
+    imgs, proj = imgs.to(dev), proj.to(dev)
+    want = {k: v.clone() for k, v in model(imgs, proj, dmin, dint).items()}
+    for l in range(3):
+        getattr(model, f"cost_reg_{l}").conv0_mode = getattr(model, f"cost_reg_{l}").ci_mode = "f32"
+    model.feature.tail_mode = "f32"
+    got = model(imgs, proj, dmin, dint)
+    assert model.cost_reg_0._conv0_active is None and not model.cost_reg_0._ci_active and not model.feature._split_active
+    stats = {}
+    for k in want:
+        if k.startswith("depth"):
+            rel = (got[k] - want[k]).abs() / want[k].abs()
+            stats[k] = [float(rel.max()), float(rel.median())]
+            assert float(rel.max()) < 1e-3 and float(rel.median()) < 2e-6, (k, stats[k])
+    report("f32_vs_splitf16_layers", **stats)
 
 
 def test_convbnrelu3d_module_runs_one_hip_layer(dev):

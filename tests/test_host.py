@@ -305,3 +305,43 @@ def test_replicas_share_parameters_and_repack_in_place():
     with torch.no_grad():
         model.feature.smooth0.weight.add_(0.5)
     assert rep.feature.packed_layers(cpu) is f1 and rep.feature._fused0[0].data_ptr() == fused_ptr
+
+
+def test_split_images_are_packed_only_for_the_selected_modes_and_non_finite_weights_fall_back_to_float32():
+    """Round-3 advisor findings: an all-float32 model (the replicas of graph.ConcurrentForwards) must not pay for - or raise from - the f16 / bf16 packers,
+    which reject non-finite weights; a split-f16 model with a NaN weight runs that layer set on the float32 kernels (Inf / NaN then propagate as in the
+    reference) instead of raising at pack time; every image a captured hipGraph may point to - the conv9 / conv11 images included - is re-packed IN PLACE."""
+    from casmvsnet_pl_amd import ABN
+    from casmvsnet_pl_amd.mvsnet import CostRegNet, FeatureNet
+    cpu = torch.device("cpu")
+    net = CostRegNet(16, ABN).eval()
+    net.conv0_mode = net.ci_mode = "f32"
+    net.packed_layers(cpu)
+    assert net._conv0_sf is None and net._conv0_sb is None and net._ci_sf is None and net._conv0_active is None and not net._ci_active
+    with torch.no_grad():
+        net.conv2.conv.weight[0, 0, 0, 0, 0] = float("nan")
+    net.packed_layers(cpu)                                   # float32 modes: a NaN weight is the float32 kernels' business
+    net.conv0_mode = net.ci_mode = "splitf16"
+    net.packed_layers(cpu)                                   # split modes: conv0's image is packed, the five channel-inner images fall back
+    assert net._conv0_active == "splitf16" and net._conv0_sf is not None and not net._ci_active
+    with torch.no_grad():
+        net.conv2.conv.weight[0, 0, 0, 0, 0] = 0.5
+    net.packed_layers(cpu)
+    assert net._ci_active and len(net._ci_sf) == 5           # conv2, conv4, conv6, conv9, conv11
+    ptrs = [t.data_ptr() for t in net._ci_sf] + [net._conv0_sf.data_ptr()]
+    before = net._ci_sf[4].clone()
+    with torch.no_grad():
+        net.conv11[0].weight.mul_(1.5)
+    net.packed_layers(cpu)
+    assert [t.data_ptr() for t in net._ci_sf] + [net._conv0_sf.data_ptr()] == ptrs and not torch.equal(net._ci_sf[4], before)
+    with torch.no_grad():
+        net.conv9[0].weight[0, 0, 0, 0, 0] = float("inf")   # an existing image (possibly captured) cannot silently change kernels
+    with pytest.raises(RuntimeError, match="non-finite"):
+        net.packed_layers(cpu)
+    feat = FeatureNet(ABN).eval()
+    feat.tail_mode = "f32"
+    feat.packed_layers(cpu)
+    assert feat._fused0 is not None and feat._fused0_sf is None and feat._ci2d is None and not feat._split_active
+    feat.tail_mode = "splitf16"
+    feat.packed_layers(cpu)
+    assert feat._split_active and len(feat._ci2d) == 5

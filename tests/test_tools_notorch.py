@@ -20,10 +20,10 @@ def test_step_runner_dry_run_reaches_the_first_launch():
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "featurenet" in out.stderr and "no ROCm-capable device" in out.stderr, out.stderr[-1500:]
-    # the experimental layer set: its packers and the _x entry points
+    # the float32 A/B switch of the layers that have an f16 form
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "notorch", "step_runner.py"), "--batch", "1", "--hw", "64", "96",
-                          "--experimental", "zmarch32,xshift,deconv9,tail,fnet_conv0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode != 0 and "featurenet_x" in out.stderr and "no ROCm-capable device" in out.stderr, out.stderr[-1500:]
+                          "--f32-layers", "conv9,conv11"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "featurenet" in out.stderr and "no ROCm-capable device" in out.stderr, out.stderr[-1500:]
 
 
 def test_step_runner_does_not_import_torch():

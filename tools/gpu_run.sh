@@ -4,7 +4,6 @@
 # Every stage writes under gpurun_out/<tag>/ (the only directory that travels back) and prints a short tail.  Stages are ordered by the
 # caller; each is bounded by its own `timeout` so that a hung kernel cannot become a gpurun strike.
 #   native       torch-free C-ABI check binaries (tools/native/*.cpp -> tools/probes/bin/) + the step runner: seconds of GPU time
-#   experimental the step runner with each experimental layer set whose native check passed (needs `native` earlier in the same call)
 #   step         tools/notorch/step_runner.py --batch 8 (ms per step, per-stage HIP-event times; no torch)
 #   probes       tools/probes/*.hip stand-alone programs that exist as binaries (mfma co-residency reproducer, ...)
 #   bench        python bench.py --steps 20 --warmup 5 (the driver's line)               BENCH_ARGS="..." adds flags
@@ -27,8 +26,8 @@ PASSED=""
 ALL=""
 
 stage_native () {
-  [ -x tools/probes/bin/conv11_prob_check ] || bash tools/native/build.sh > $OUT/native_build.txt 2>&1
-  { for pair in ${NATIVE_CHECKS:-"zmarch:conv0_zm_check:2" "fnet_conv0:fnet_conv0_check:" "deconv11:deconv11_check:2" "deconv9:deconv9_check:2" "tail:conv11_prob_check:2"}; do
+  [ -x tools/probes/bin/deconv9_check ] || bash tools/native/build.sh > $OUT/native_build.txt 2>&1
+  { for pair in ${NATIVE_CHECKS:-"zmarch:conv0_zm_check:2" "deconv11:deconv11_check:2" "deconv9:deconv9_check:2"}; do
       name=${pair%%:*}; rest=${pair#*:}; c=${rest%%:*}; arg=${rest#*:}
       [ -x tools/probes/bin/$c ] || continue
       timeout 90 tools/probes/bin/$c $arg; rc=$?; echo "-- $c: exit $rc"; [ $rc -eq 0 ] && PASSED="$PASSED $name"
@@ -40,20 +39,6 @@ stage_native () {
 }
 
 stage_step () { timeout 90 python tools/notorch/step_runner.py --batch ${STEP_BATCH:-8} $STEP_ARGS > $OUT/step.txt 2>&1; tail -30 $OUT/step.txt; }
-
-stage_experimental () {
-  PASSED=$(cat $OUT/native_passed.txt 2>/dev/null)
-  { for x in $PASSED; do
-      echo "== --experimental $x"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $x | tail -4
-      [ $x = zmarch ] && for y in zmarch32 xshift zmarch,xshift; do echo "== --experimental $y"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $y | tail -4; done
-      ALL="$ALL,$x"
-    done
-    ALL=${ALL#,}
-    echo "$PASSED" | grep -qw tail && ALL=$(echo "$ALL" | sed 's/deconv11,//; s/,deconv11$//; s/^deconv11$//')
-    [ -n "$ALL" ] && { echo "== --experimental $ALL"; timeout 60 python tools/notorch/step_runner.py --batch 8 --experimental $ALL | tail -4; }; } > $OUT/experimental.txt 2>&1
-  echo "$ALL" > $OUT/experimental_set.txt
-  cat $OUT/experimental.txt
-}
 
 stage_probes () {
   for b in ${PROBE_BINS:-mfma_coresidency_repro}; do
@@ -107,6 +92,7 @@ stage_pmc () {
   find $OUT/prof -name "*.db" -delete 2>/dev/null; find $OUT/prof -type f -size +4M -delete 2>/dev/null
   date -u +%Y-%m-%dT%H:%MZ > $OUT/collected.txt
   sha256sum casmvsnet_pl_amd/libcasmvs_hip.so | cut -c1-64 > $OUT/library_sha256.txt
+  python -c "import importlib.util as u; s = u.spec_from_file_location('b', 'casmvsnet_pl_amd/build.py'); m = u.module_from_spec(s); s.loader.exec_module(m); print(m.source_sha16())" > $OUT/source_sha16.txt
   echo "PMC_CMD_NOTE=\"$RUN\" PMC_BATCH=$BATCH PMC_DATE=$(cat $OUT/collected.txt)" > $OUT/summarize_env.txt
   ls $OUT/pmc_fetch $OUT/pmc_write $OUT/prof | head -12; tail -2 $OUT/pmc_fetch.log
 }
@@ -126,7 +112,7 @@ stage_cmd () { bash -c "$GPU_RUN_CMD" > $OUT/cmd.txt 2>&1; echo "cmd exit: $?" >
 for s in "$@"; do
   echo "===== stage $s ($(date -u +%H:%M:%S))"
   case $s in
-    native|step|experimental|probes|bench|configs|suite|smoke|train|files|pmc|prof|costvol|cmd) stage_$s ;;
+    native|step|probes|bench|configs|suite|smoke|train|files|pmc|prof|costvol|cmd) stage_$s ;;
     *) echo "unknown stage $s" ;;
   esac
 done

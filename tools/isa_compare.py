@@ -75,7 +75,7 @@ def main():
     old_names, new_names = dict(zip(demangle(list(old)), old)), dict(zip(demangle(list(new)), new))
     bad = 0
     for name, key in old_names.items():
-        cand = [n for n in new_names if n == name or same_but_defaults(name, n)]
+        cand = [n for n in new_names if n == name or same_but_defaults(name, n) or same_but_defaults(n, name)]   # trailing default arguments added OR removed
         if not cand:
             print(f"  {name}: gone")
             bad += 1
@@ -84,7 +84,7 @@ def main():
         bad += not same
         print(f"  {name}: {'identical' if same else 'DIFFERENT'} ({len(old[key])} -> {len(new[new_names[cand[0]]])} instructions)" + ("" if cand[0] == name else f"   [now {cand[0]}]"))
     for n in new_names:
-        if n not in old_names and not any(same_but_defaults(o, n) for o in old_names):
+        if n not in old_names and not any(same_but_defaults(o, n) or same_but_defaults(n, o) for o in old_names):
             print(f"  {n}: new ({len(new[new_names[n]])} instructions)")
     print("unchanged" if not bad else f"{bad} kernels differ")
     return 1 if bad else 0

@@ -9,8 +9,13 @@ schedule itself is read: per kernel, the MATRIX PHASES (runs of matrix instructi
 vector-ALU instruction inside them that is not integer / move / matrix work.  The kernels that were validated bit-stable at full occupancy on the MI355X
 (conv0_sf, conv_ci_sf, conv2d_ci_sf, fpn_tail0_sf) are the reference: their phases DO contain floating-point work - the folds / epilogues of accumulator
 chains that finished early, i.e. work that consumes matrix results, with up to ~40 matrix instructions of the wave still to issue - and are bit-stable at
-two workgroups per CU; the case that failed had floating-point work INDEPENDENT of the matrix results inside the phase.  The kernels written without a GPU
-run keep every floating-point instruction outside their phases (sched_barrier), the stricter form.  Exit status 1 only if a kernel listed in STRICT has any."""
+two workgroups per CU; the case that failed had floating-point work INDEPENDENT of the matrix results inside the phase.  The kernels of STRICT (written at
+the end of round 3, validated on the MI355X in round 4) keep every floating-point instruction outside their phases (sched_barrier), the stricter form.
+Exit status 1 if a kernel listed in STRICT has any.
+
+    python tools/mfma_hazard_lint.py --json [files]      prints {kernel: {opcode: count}} of the flagged instructions of EVERY kernel: the golden file
+    tests/golden/mfma_phase_fp_instructions.json pins that table for the production build (tests/test_device_code_lints.py): a compiler or source change that
+    puts one more floating-point instruction into a matrix phase fails the CPU suite and sends the kernel back to the full-occupancy bit-stability test."""
 import glob
 import os
 import re
@@ -24,7 +29,7 @@ from casmvsnet_pl_amd.build import FLAGS  # noqa: E402
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 GAP = int(os.environ.get("MFMA_LINT_GAP", "24"))
-STRICT = ("conv0_zm_kernel", "fnet_conv0_fused_kernel", "deconv11_sf_kernel", "deconv9_sf_kernel", "conv11_prob_kernel")   # no GPU has run these yet
+STRICT = ("conv0_zm_kernel", "deconv11_sf_kernel", "deconv9_sf_kernel")   # written with every floating-point instruction outside the matrix phases: must stay so
 # vector-ALU work that is NOT floating point: integer arithmetic, logic, shifts, moves, lane exchanges, accumulator moves
 INT_OK = re.compile(r"^v_(mov|accvgpr|add_lshl|bfrev|add_u|add_i|add_co|addc|sub_u|sub_i|sub_co|subrev_u|subrev_co|subb|mul_lo|mul_hi|mul_u|mul_i|mad_u|mad_i|mad_u64|lshl|lshr|ashr|and|or|xor|"
                     r"not|bfe|bfi|perm|alignbit|alignbyte|readlane|readfirstlane|writelane|swap|nop|lshlrev|lshrrev|ashrrev|add3|lshl_add|lshl_or|and_or|or3|xad|"
@@ -97,7 +102,32 @@ def demangle(names):
     return out
 
 
+def table(files=None):
+    """{kernel: {opcode: count}} of the floating-point vector instructions inside f16 / bf16 matrix phases, for every kernel that has matrix instructions."""
+    from concurrent.futures import ThreadPoolExecutor
+    files = files or sorted(f for f in glob.glob(os.path.join(ROOT, "casmvsnet_pl_amd", "csrc", "*.hip")) if "mfma_f32_16x16x32" in open(f).read())
+
+    def one(path):
+        with tempfile.TemporaryDirectory() as tmp:
+            ks = kernels(device_asm(path, tmp))
+        out = {}
+        for name, key in zip(demangle(list(ks)), ks):
+            n, _, flagged, _, _ = lint(ks[key])
+            if n and "probe" not in name:
+                out[name] = dict(sorted(flagged.items()))
+        return out
+    res = {}
+    with ThreadPoolExecutor(max_workers=min(8, len(files))) as pool:
+        for part in pool.map(one, files):
+            res.update(part)
+    return dict(sorted(res.items()))
+
+
 def main():
+    if "--json" in sys.argv[1:]:
+        import json
+        print(json.dumps(table([a for a in sys.argv[1:] if a != "--json"] or None), indent=1))
+        return 0
     files = sys.argv[1:] or sorted(f for f in glob.glob(os.path.join(ROOT, "casmvsnet_pl_amd", "csrc", "*.hip")) if "mfma_f32_16x16x32" in open(f).read())
     bad = 0
     print(f"matrix phases = runs of f16 / bf16 matrix instructions with <= {GAP} other instructions between neighbours; flagged = vector-ALU instructions inside a phase "
@@ -115,8 +145,8 @@ def main():
             bad += total > 0 and name.startswith(STRICT)
             detail = (f"  FLAGGED (the earliest with {earliest} matrix instructions still to issue) " + ", ".join(f"{k} x{v}" for k, v in sorted(flagged.items()))) if total else "  clean"
             print(f"  {name:44s} {n:4d} matrix instructions in {phases:2d} phases, {selects} selects inside{detail}")
-    print("the kernels no GPU has run yet keep all floating-point vector work outside their matrix phases" if not bad else
-          f"{bad} of the kernels no GPU has run yet have floating-point vector work inside a matrix phase")
+    print("the STRICT kernels keep all floating-point vector work outside their matrix phases" if not bad else
+          f"{bad} of the STRICT kernels have floating-point vector work inside a matrix phase")
     return 1 if bad else 0
 
 

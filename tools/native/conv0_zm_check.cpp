@@ -1,8 +1,8 @@
-// First test of casmvs_conv0_zmarch_forward_f32 (csrc/conv0_zmarch.hip, written without a GPU run at the end of round 3), torch-free:
+// Native check of casmvs_conv0_zmarch_forward_f32 (csrc/conv0_zmarch.hip), torch-free:
 // against casmvs_conv0_splitf16_forward_f32 (same packed image) on ragged small shapes with a float64 convolution on the host beside both,
 // twice for run-to-run bit stability, and on the cascade levels' shapes (cin 16: 32 x 256 x 320, cin 8: 8 x 512 x 640) with the time of
-// each kernel under dirtied caches; and the same for both kernels on the tile grid shifted by 4 voxels in x (casmvs_conv0_splitf16_forward_x_f32 /
-// casmvs_conv0_zmarch_forward_x_f32: two cache lines per staged row instead of three).   conv0_zm_check [batch]
+// each kernel under dirtied caches.   conv0_zm_check [batch]      (round 4's first run also timed both kernels on a tile grid shifted by 4 voxels
+// in x - equal or slower, removed: profiles/r04_native_checks_first_run.txt)
 //   hipcc -O2 tools/native/conv0_zm_check.cpp -Iinclude -Lcasmvsnet_pl_amd -lcasmvs_hip -Wl,-rpath,'$ORIGIN/../../../casmvsnet_pl_amd' -o tools/probes/bin/conv0_zm_check
 #include <hip/hip_runtime.h>
 
@@ -43,8 +43,8 @@ int main(int argc, char **argv) {
     const size_t pb = casmvs_conv0_splitf16_packed_bytes(s.cin);
     std::vector<unsigned char> packed(pb);
     if (casmvs_conv0_splitf16_pack(s.cin, w.data(), scale.data(), shift.data(), packed.data())) { printf("pack: %s\n", casmvs_last_error()); return 3; }
-    constexpr int K = 4;   // 0 tiled, 1 z-march, 2 tiled on the shifted grid, 3 z-march on the shifted grid
-    const char *names[K] = {"tiled", "z-march", "tiled x+4", "z-march x+4"};
+    constexpr int K = 2;   // 0 tiled, 1 z-march
+    const char *names[K] = {"tiled", "z-march"};
     float *dx, *dy[K];
     void *dp;
     hipMalloc(&dx, nin * 4); hipMalloc(&dp, pb);
@@ -53,12 +53,10 @@ int main(int argc, char **argv) {
     hipMemcpy(dp, packed.data(), pb, hipMemcpyHostToDevice);
     auto run = [&](int k) {
       if (k == 0) return casmvs_conv0_splitf16_forward_f32(dp, dx, dy[0], s.B, s.cin, s.D, s.H, s.W, 0.01f, 0, st);
-      if (k == 1) return casmvs_conv0_zmarch_forward_f32(dp, dx, dy[1], s.B, s.cin, s.D, s.H, s.W, 0.01f, st);
-      if (k == 2) return casmvs_conv0_splitf16_forward_x_f32(dp, dx, dy[2], s.B, s.cin, s.D, s.H, s.W, 0.01f, 4, st);
-      return casmvs_conv0_zmarch_forward_x_f32(dp, dx, dy[3], s.B, s.cin, s.D, s.H, s.W, 0.01f, 4, st);
+      return casmvs_conv0_zmarch_forward_f32(dp, dx, dy[1], s.B, s.cin, s.D, s.H, s.W, 0.01f, st);
     };
     std::vector<float> y[K], again(nout);
-    double us[K] = {0, 0, 0, 0};
+    double us[K] = {0, 0};
     for (int k = 0; k < K; ++k) {
       hipMemset(dy[k], 0xff, nout * 4);
       if (run(k)) { printf("forward %d: %s\n", k, casmvs_last_error()); return 3; }
@@ -94,11 +92,11 @@ int main(int argc, char **argv) {
       }
     printf("B=%d cin=%d %dx%dx%d:", s.B, s.cin, s.D, s.H, s.W);
     for (int k = 0; k < K; ++k) printf(" %s %.1f us%s", names[k], us[k], k + 1 < K ? "," : "");
-    printf(" (x%.3f / x%.3f / x%.3f); max |diff| / range = %.2e, non-finite %zu, repeat runs %s", us[0] / us[1], us[0] / us[2], us[0] / us[3], diff / range, nan,
+    printf(" (x%.3f); max |diff| / range = %.2e, non-finite %zu, repeat runs %s", us[0] / us[1], diff / range, nan,
            stable ? "equal" : "DIFFERENT");
     bool ok = nan == 0 && stable && diff / range < 2e-6;
     if (s.host) {
-      double err[K] = {0, 0, 0, 0};
+      double err[K] = {0, 0};
       for (int b = 0; b < s.B; ++b)
         for (int co = 0; co < 8; ++co)
           for (int z = 0; z < s.D; ++z)
@@ -118,7 +116,7 @@ int main(int argc, char **argv) {
                 const size_t o = ((size_t)b * 8 + co) * n + ((size_t)z * s.H + yy) * s.W + xx;
                 for (int k = 0; k < K; ++k) err[k] = std::fmax(err[k], std::fabs(v - y[k][o]));
               }
-      printf("; vs float64: %.2e / %.2e / %.2e / %.2e of the range", err[0] / range, err[1] / range, err[2] / range, err[3] / range);
+      printf("; vs float64: %.2e / %.2e of the range", err[0] / range, err[1] / range);
       for (int k = 1; k < K; ++k) ok = ok && err[k] / range < 2e-6;
     }
     printf("  %s\n", ok ? "ok" : "FAILED");

@@ -13,13 +13,13 @@ ap.add_argument("libs", nargs="+")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--steps", type=int, default=10)
-ap.add_argument("--experimental", default="", help="passed to step_runner.py for every library EXCEPT the first (the baseline): e.g. zmarch,deconv11")
+ap.add_argument("--f32-layers", default="", help="passed to step_runner.py for every library EXCEPT the first (the baseline): e.g. conv9,conv11")
 args = ap.parse_args()
 here = os.path.dirname(os.path.abspath(__file__))
 res = {lib: {"ms": [], "stages": []} for lib in args.libs}
 for _ in range(args.rounds):
     for lib in args.libs:
-        extra = ["--experimental", args.experimental] if (args.experimental and lib is not args.libs[0]) else []
+        extra = ["--f32-layers", args.f32_layers] if (args.f32_layers and lib is not args.libs[0]) else []
         out = subprocess.run([sys.executable, os.path.join(here, "step_runner.py"), "--lib", lib, "--batch", str(args.batch), "--steps", str(args.steps)] + extra,
                              capture_output=True, text=True)
         m = re.search(r"step ([0-9.]+) ms", out.stdout)

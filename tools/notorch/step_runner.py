@@ -24,7 +24,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=(512, 640))
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--all-f32", action="store_true", help="every layer on the float32 MFMA kernels (conv0_mode / ci_mode / tail_mode = f32)")
-ap.add_argument("--experimental", default="", help="comma list of the kernels written without a GPU run: zmarch | zmarch32, xshift, deconv9, deconv11, fnet_conv0, tail")
+ap.add_argument("--f32-layers", default="", help="A/B: comma list of CostRegNet layers kept on the float32 MFMA kernel although they have an f16 form: conv0, conv2, conv4, conv6, conv9, conv11")
 args = ap.parse_args()
 if args.lib:
     os.environ["CASMVS_LIB_PATH"] = os.path.abspath(args.lib)
@@ -115,7 +115,7 @@ COSTREG = (("conv0", CONV_S1, None, 8), ("conv1", CONV_S2, 8, 16), ("conv2", CON
 costreg, costreg_w = [], []
 for l in range(3):
     c_in0 = 8 * 2 ** l
-    packed, split = [], [None] * 4
+    packed, split = [], [None] * 6
     costreg_w.append({})
     for name, kind, cin, cout in COSTREG:
         cin = c_in0 if cin is None else cin
@@ -128,27 +128,15 @@ for l in range(3):
         if name in ("conv2", "conv4", "conv6"):
             split[1 + ("conv2", "conv4", "conv6").index(name)] = pack_bytes(lib.casmvs_conv_ci_splitf16_packed_bytes(cin, cout), lib.casmvs_conv_ci_splitf16_pack,
                                                                              cin, cout, hp(w), hp(sc), hp(sh))
+        if name == "conv9":
+            split[4] = pack_bytes(lib.casmvs_deconv9_splitf16_packed_bytes(), lib.casmvs_deconv9_splitf16_pack, hp(w), hp(sc), hp(sh))
+        if name == "conv11":
+            split[5] = pack_bytes(lib.casmvs_deconv11_splitf16_packed_bytes(), lib.casmvs_deconv11_splitf16_pack, hp(w), hp(sc), hp(sh))
     costreg.append((packed, split))
 
-# ---- the experimental layer set (casmvs_*_x_f32): images of the kernels written without a GPU run ----------------------------------
-EXP = set(filter(None, args.experimental.split(",")))
-assert EXP <= {"zmarch", "zmarch32", "xshift", "deconv9", "deconv11", "fnet_conv0", "tail"}, EXP
-assert not (EXP and args.all_f32), "the experimental kernels belong to the split-f16 layer set"
-ZM = (2 if "zmarch32" in EXP else (1 if "zmarch" in EXP else 0)) + (4 if "xshift" in EXP else 0)   # + 4: conv0's tile grid shifted by 4 voxels
-fnet_conv0_img = None
-if "fnet_conv0" in EXP:
-    (w00, s00, b00), (w01, s01, b01) = fw["conv0.0"], fw["conv0.1"]
-    fnet_conv0_img = pack_bytes(lib.casmvs_fnet_conv0_fused_packed_bytes(), lib.casmvs_fnet_conv0_fused_pack, hp(w00), hp(s00), hp(b00), hp(w01), hp(s01), hp(b01))
-deconv_imgs = []
-for l in range(3):
-    d9 = d11 = None
-    if "deconv9" in EXP:
-        w, sc, sh = costreg_w[l]["conv9"]
-        d9 = pack_bytes(lib.casmvs_deconv9_splitf16_packed_bytes(), lib.casmvs_deconv9_splitf16_pack, hp(w), hp(sc), hp(sh))
-    if "deconv11" in EXP or "tail" in EXP:
-        w, sc, sh = costreg_w[l]["conv11"]
-        d11 = pack_bytes(lib.casmvs_deconv11_splitf16_packed_bytes(), lib.casmvs_deconv11_splitf16_pack, hp(w), hp(sc), hp(sh))
-    deconv_imgs.append((d9, d11))
+F32_LAYERS = set(filter(None, args.f32_layers.split(",")))
+SPLIT_ORDER = ("conv0", "conv2", "conv4", "conv6", "conv9", "conv11")   # casmvs_costreg_regress_f32: split_layers[0..5]
+assert F32_LAYERS <= set(SPLIT_ORDER), F32_LAYERS
 
 # ---- inputs: images, the DTU-like rig of synthetic.dtu_like_cameras / make_inputs --------------------------------------------
 imgs = DeviceArray.from_numpy(g.standard_normal((B * V, 3, H, W)).astype(np.float32))
@@ -217,14 +205,9 @@ def run_stage(name, fn, timed):
 
 
 def step(timed=False):
-    if fnet_conv0_img is not None:
-        run_stage("feature", lambda: check(lib.casmvs_featurenet_forward_fused_x_f32(
-            arr13, tail_sf.p, 1, bias9_d.p, ci5, imgs.p, feat[0].p, feat[1].p, feat[2].p,
-            feat_cl[0].p, feat_cl[1].p, feat_cl[2].p, feat_ws.p, N, H, W, ctypes.c_float(0.01), None, st, fnet_conv0_img.p), "featurenet_x"), timed)
-    else:
-        run_stage("feature", lambda: check(lib.casmvs_featurenet_forward_fused_f32(
-            arr13, (tail_f32 if args.all_f32 else tail_sf).p, 0 if args.all_f32 else 1, bias9_d.p, ci5, imgs.p, feat[0].p, feat[1].p, feat[2].p,
-            feat_cl[0].p, feat_cl[1].p, feat_cl[2].p, feat_ws.p, N, H, W, ctypes.c_float(0.01), None, st), "featurenet"), timed)
+    run_stage("feature", lambda: check(lib.casmvs_featurenet_forward_fused_f32(
+        arr13, (tail_f32 if args.all_f32 else tail_sf).p, 0 if args.all_f32 else 1, bias9_d.p, ci5, imgs.p, feat[0].p, feat[1].p, feat[2].p,
+        feat_cl[0].p, feat_cl[1].p, feat_cl[2].p, feat_ws.p, N, H, W, ctypes.c_float(0.01), None, st), "featurenet"), timed)
     prev = None
     for l in (2, 1, 0):
         L = levels[l]
@@ -238,16 +221,11 @@ def step(timed=False):
         run_stage(f"costvol_{l}", lambda: check(cv(feat_cl[l].p, proj_l[l].p, L["dv"].p, L["vol"].p, B, V, C, h, w, D, st), "costvol"), timed)
         packed, split = costreg[l]
         arr11 = (ctypes.c_void_p * 11)(*[p.ptr for p in packed])
-        sp = None if args.all_f32 else (ctypes.c_void_p * 4)(*[None if s is None else s.ptr for s in split])
-        d9, d11 = deconv_imgs[l]
-        if ZM or d9 is not None or d11 is not None:
-            run_stage(f"costreg_{l}", lambda: check(lib.casmvs_costreg_regress_x_f32(
-                arr11, sp, 2, L["vol"].p, L["dv"].p, L["cost"].p, L["depth"].p, L["conf"].p, None, L["ws"].p, B, C, D, h, w,
-                ctypes.c_float(0.01), None, st, ZM, None if d9 is None else d9.p, None if d11 is None else d11.p, 1 if "tail" in EXP else 0), "costreg_regress_x"), timed)
-        else:
-            run_stage(f"costreg_{l}", lambda: check(lib.casmvs_costreg_regress_f32(
-                arr11, sp, 0 if args.all_f32 else 2, L["vol"].p, L["dv"].p, L["cost"].p, L["depth"].p, L["conf"].p, None, L["ws"].p, B, C, D, h, w,
-                ctypes.c_float(0.01), None, st), "costreg_regress"), timed)
+        sp = None if args.all_f32 else (ctypes.c_void_p * 6)(*[None if (s is None or n in F32_LAYERS) else s.ptr for n, s in zip(SPLIT_ORDER, split)])
+        arith = 0 if (args.all_f32 or "conv0" in F32_LAYERS) else 2
+        run_stage(f"costreg_{l}", lambda: check(lib.casmvs_costreg_regress_f32(
+            arr11, sp, arith, L["vol"].p, L["dv"].p, L["cost"].p, L["depth"].p, L["conf"].p, None, L["ws"].p, B, C, D, h, w,
+            ctypes.c_float(0.01), None, st), "costreg_regress"), timed)
         prev = L
 
 
@@ -268,9 +246,9 @@ d0 = levels[0]["depth"].numpy()
 lo, hi = DEPTH_MIN - 200.0, DEPTH_MIN + 192 * DEPTH_INTERVAL + 200.0
 ok = bool(np.isfinite(d0).all() and d0.min() > lo and d0.max() < hi)
 print(f"{hip.device_name()}  lib {os.path.basename(_lib.LIB_PATH)}  batch {B} x {V} views {W}x{H}  {'all-f32' if args.all_f32 else 'split-f16 layer set'}"
-      + (f"  + experimental {sorted(EXP)}" if EXP else ""))
+      + (f"  float32: {sorted(F32_LAYERS)}" if F32_LAYERS else ""))
 d0_sum = float(np.float64(d0).sum())
-print(f"depth_0 checksum {d0_sum:.6f} (compare runs with and without --experimental: the same weights and inputs, results equal to ~1e-5 relative)")
+print(f"depth_0 checksum {d0_sum:.6f} (compare runs of two builds / layer sets: the same weights and inputs, results equal to ~1e-5 relative)")
 print(f"step {ms:.3f} ms  = {B / ms * 1e3:.1f} depth maps/s (kernel by kernel on one stream, {args.steps} steps after {args.warmup})")
 print("stages (one instrumented step, ms): " + "  ".join(f"{s} {stage_ms[s]:.3f}" for s in STAGES))
 print(f"sum of stages {sum(stage_ms.values()):.3f} ms; depth_0 range [{d0.min():.1f}, {d0.max():.1f}] mean {d0.mean():.1f}  {'ok' if ok else 'OUT OF RANGE'}")
