@@ -667,7 +667,7 @@ def test_deconv_splitf16_equals_the_layer(dev, report, which, shape):
 
 @pytest.mark.parametrize("kernel", ["conv0_sf", "conv0_zm", "conv_ci_sf"])
 def test_split_f16_kernels_never_turn_non_finite_inputs_into_finite_wrong_values(dev, kernel):
-    """Round-3 advisor finding (csrc/split_f16.h: tile_scale): a NaN voxel reaches exactly the outputs whose taps touch it (the per-tile maximum skips NaNs);
+    """Round-3 advisor finding (csrc/split_f16.h: tile_scale): a NaN voxel reaches the outputs whose matrix tile multiplies it (the per-tile maximum skips NaNs);
     an INFINITE voxel leaves its staged unit without a finite scaling, so the whole unit is poisoned: every output is either non-finite or bit-equal to the
     clean run's, and every output within the 3 x 3 x 3 reach of the bad voxel is non-finite - never a silently flushed finite value."""
     ops = _ops()
@@ -691,9 +691,9 @@ def test_split_f16_kernels_never_turn_non_finite_inputs_into_finite_wrong_values
         finite = torch.isfinite(got)
         assert torch.equal(got[finite], clean[finite]), (kernel, bad)
         assert not finite[0, :, z - 1:z + 2, y - 1:y + 2, xx - 1:xx + 2].any(), (kernel, bad)
-        if bad != bad:   # NaN: nothing beyond the taps' reach is lost
-            touched = torch.zeros_like(finite)
-            touched[0, :, z - 1:z + 2, y - 1:y + 2, xx - 1:xx + 2] = True
+        if bad != bad:   # NaN: lost outputs stay inside the matrix tile's footprint around the voxel (the zero-weight K slots of the MFMA forms multiply
+            touched = torch.zeros_like(finite)   # the bad value too - NaN x 0 = NaN -, in the float32 MFMA kernels as well), nothing farther away
+            touched[0, :, z - 2:z + 3, y - 2:y + 3, xx - 8:xx + 9] = True
             assert bool(finite[~touched].all()), kernel
         assert float(finite.float().mean()) > 0.5, (kernel, bad)   # the poisoned unit is local
 
