@@ -24,7 +24,8 @@ def _ptr(t):
 
 
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    from . import streams
+    return streams.launch_stream(t)
 
 
 class _HomoWarp(torch.autograd.Function):

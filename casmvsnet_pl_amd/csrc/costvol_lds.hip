@@ -813,11 +813,15 @@ extern "C" int casmvs_costvol_lds_supported(int C, int w, int D, int n_src_views
 
 // Measured on the MI355X (tools/gpu_cv_variants.sh, profiles/r02_s3_costvol_ab.txt): with two source views (V = 3) the
 // LDS-staged variance build beats the gather kernel at every level shape (C = 32 / 16 / 8: 91 / 135 / 84 us against
-// 108 / 227 / 95 at batch 2).  With more source views the boxes of all views no longer fit next to a second workgroup
-// (one workgroup per CU = one wave per SIMD) and the gather kernel wins (V = 5: 513 vs 651 us at level 1); the
-// correlation (G > 1) writes 4-16x fewer bytes and the gather kernel wins at every level.
+// 108 / 227 / 95 at batch 2).  Round 4 (tools/gpu_costvol_probe.py with dirtied caches, profiles/r04_costvol_ab_v5_v7_gwc.txt):
+//   * more source views: the gather kernel stays ahead at every level of the V = 5 (1152 x 864) and V = 7 (768 x 576) workloads - all views
+//     resident leaves one workgroup per CU (524 vs 632 us at level 1, V = 5; V = 7 does not fit at C >= 16), and the views taken two at a time
+//     through the partial-sum kernels (two resident boxes, the occupancy of V = 3: a LOWER bound for a kernel that streams view pairs through
+//     LDS, whose tap / interpolation / accumulation work per (voxel, view) is the same) take 568 us there, 1.1-2.5x the gather kernel elsewhere;
+//   * group-wise correlation, V = 3: the LDS kernel now wins or ties at every level (G = 8, batch 4, noise-like depth: 201 / 297 / 218 us
+//     against 234 / 340 / 245) - the round-3 prologue work moved it past the gather kernel, which it trailed in round 2.
 extern "C" int casmvs_costvol_lds_preferred(int C, int w, int D, int n_src_views, int G) {
-  return (G <= 1 && n_src_views <= 2 && casmvs_costvol_lds_supported(C, w, D, n_src_views, G)) ? 1 : 0;
+  return (n_src_views <= 2 && casmvs_costvol_lds_supported(C, w, D, n_src_views, G)) ? 1 : 0;
 }
 
 extern "C" int casmvs_costvol_var_lds_f32(const float *feats, const float *proj, const float *depth, float *out, int B,

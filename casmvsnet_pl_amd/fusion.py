@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, streams
 
 
 def relative_transform(P_to, P_from):
@@ -75,7 +75,7 @@ def fuse_reference_view(depth_ref, image_ref, proba_ref_quarter, P_world2ref, de
             _ptr(depth_ref), _ptr(image_ref), _ptr(proba), _ptr(depth_src), _ptr(image_src), _ptr(m_r2s), _ptr(m_s2r), _ptr(m_r2w),
             _ptr(out["depth_refined"]), _ptr(out["image_refined"]), _ptr(out["mask_geo_sum"]), _ptr(out["mask_final"]),
             _ptr(out.get("xyz_world")), _ptr(out.get("mask_geo")), _ptr(out.get("depth_ref_reproj")), _ptr(out.get("image_src2ref")),
-            S, H, W, float(conf), int(min_geo_consistent), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            S, H, W, float(conf), int(min_geo_consistent), streams.launch_stream(depth_ref))
     _lib.check(rc, "casmvs_fuse_reference_view")
     out["mask_final"] = out["mask_final"].bool()
     if return_per_view:

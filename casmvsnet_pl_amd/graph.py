@@ -10,6 +10,13 @@ happens in the warm-up calls before the capture.
 """
 import torch
 
+from . import streams
+
+
+def _uses_f16(model):
+    """Does a forward of this model launch kernels with f16 / bf16 matrix instructions (the split layer modes)?"""
+    return any(getattr(m, "conv0_mode", "f32") != "f32" or getattr(m, "ci_mode", "f32") != "f32" or getattr(m, "tail_mode", "f32") != "f32" for m in model.modules())
+
 
 class GraphedForward:
     """model(imgs, proj_mats, init_depth_min, depth_interval) as one hipGraph replay.
@@ -38,6 +45,8 @@ class GraphedForward:
                 model(self.imgs, self.proj_mats, self.init_depth_min, self.depth_interval)
         torch.cuda.current_stream(imgs.device).wait_stream(side)
         torch.cuda.synchronize(imgs.device)
+        self.f16 = _uses_f16(model)
+        streams.reset(imgs.device)   # the device is idle: nothing of the warm-up (another stream) can overlap the capture stream's launches
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = model(self.imgs, self.proj_mats, self.init_depth_min, self.depth_interval)
@@ -66,6 +75,7 @@ class GraphedForward:
             elif float(new) != float(cur):
                 raise ValueError(f"GraphedForward: {name} = {new} differs from the captured constant {cur}; capture a new "
                                  "graph (python floats are baked in) or pass (B,1) tensors when the range varies")
+        streams.note_launch(self.imgs.device, f16=self.f16)   # the replay's kernels run on the current stream: the cross-stream rule of streams.py
         self.graph.replay()
         return self.outputs
 
@@ -104,6 +114,7 @@ class ConcurrentForwards:
 
     def __init__(self, model, imgs, proj_mats, init_depth_min, depth_interval, n_streams=2, warmup=2, mixed_matrix_types=False):
         self.device = imgs.device
+        self.mixed_matrix_types = bool(mixed_matrix_types)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.forwards = []
         for st in self.streams:
@@ -117,7 +128,7 @@ class ConcurrentForwards:
                     if hasattr(m, "tail_mode"):
                         m.tail_mode = "f32"
             st.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(st), streams.stream_guard(not mixed_matrix_types):
                 self.forwards.append(GraphedForward(replica, imgs, proj_mats, init_depth_min, depth_interval, warmup))
         torch.cuda.synchronize(self.device)
 
@@ -134,7 +145,7 @@ class ConcurrentForwards:
         outs = []
         for i, (gf, st) in enumerate(zip(self.forwards, self.streams)):
             st.wait_stream(cur)   # inputs produced on the caller's stream are complete before the copy / replay
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(st), streams.stream_guard(not self.mixed_matrix_types):
                 b = batches[i] if batches is not None else None
                 outs.append(gf(*b) if b is not None else gf())
         for st in self.streams:

@@ -7,7 +7,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, streams
 from ._lib import (CONV_S1, CONV_S2, CONV_T2, CONV2D_K3, CONV2D_K5S2, CONV2D_K1,  # noqa: F401  (re-exported)
                    CONV2D_K1_UP)
 
@@ -27,8 +27,10 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+def _stream(t, f16=False):
+    """hipStream_t of the launch: torch's current stream, after the cross-stream guard of streams.py (f16: the call launches kernels with
+    f16 / bf16 matrix instructions)."""
+    return streams.launch_stream(t, f16)
 
 
 def homo_warp(src_feat, proj_mat, depth_values, impl="auto"):
@@ -294,7 +296,7 @@ def conv0_splitbf16_forward(packed, x, slope=0.01, terms=0):
     out = torch.empty((B, 8, D, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.load().casmvs_conv0_splitbf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W,
-                                                            float(slope), int(terms), _stream(x))
+                                                            float(slope), int(terms), _stream(x, f16=True))
     _lib.check(rc, "casmvs_conv0_splitbf16_forward_f32")
     return out
 
@@ -333,7 +335,7 @@ def conv0_splitf16_forward(packed, x, slope=0.01, terms=0):
     out = torch.empty((B, 8, D, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.load().casmvs_conv0_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W,
-                                                           float(slope), int(terms), _stream(x))
+                                                           float(slope), int(terms), _stream(x, f16=True))
     _lib.check(rc, "casmvs_conv0_splitf16_forward_f32")
     return out
 
@@ -365,7 +367,7 @@ def deconv9_splitf16_forward(packed, x, skip=None, slope=0.01):
         skip = _dev(skip, "skip")
     out = torch.empty((B, 16, 2 * Di, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().casmvs_deconv9_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(skip), _ptr(out), B, Di, Hi, Wi, float(slope), _stream(x))
+        rc = _lib.load().casmvs_deconv9_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(skip), _ptr(out), B, Di, Hi, Wi, float(slope), _stream(x, f16=True))
     _lib.check(rc, "casmvs_deconv9_splitf16_forward_f32")
     return out
 
@@ -397,7 +399,7 @@ def deconv11_splitf16_forward(packed, x, skip=None, slope=0.01):
         skip = _dev(skip, "skip")
     out = torch.empty((B, 8, 2 * Di, 2 * Hi, 2 * Wi), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().casmvs_deconv11_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(skip), _ptr(out), B, Di, Hi, Wi, float(slope), _stream(x))
+        rc = _lib.load().casmvs_deconv11_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(skip), _ptr(out), B, Di, Hi, Wi, float(slope), _stream(x, f16=True))
     _lib.check(rc, "casmvs_deconv11_splitf16_forward_f32")
     return out
 
@@ -411,7 +413,7 @@ def conv0_zmarch_forward(packed, x, slope=0.01):
     B, cin, D, H, W = x.shape
     out = torch.empty((B, 8, D, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _lib.load().casmvs_conv0_zmarch_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W, float(slope), _stream(x))
+        rc = _lib.load().casmvs_conv0_zmarch_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, D, H, W, float(slope), _stream(x, f16=True))
     _lib.check(rc, "casmvs_conv0_zmarch_forward_f32")
     return out
 
@@ -450,7 +452,7 @@ def conv_ci_splitf16_forward(packed, x, cout, slope=0.01):
     out = torch.empty((B, cout, D, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.load().casmvs_conv_ci_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, cout, D, H, W,
-                                                             float(slope), _stream(x))
+                                                             float(slope), _stream(x, f16=True))
     _lib.check(rc, "casmvs_conv_ci_splitf16_forward_f32")
     return out
 
@@ -525,7 +527,7 @@ def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, lay
     with torch.cuda.device(dev):
         rc = _lib.load().casmvs_costreg_regress_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
                                                     _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,
-                                                    float(slope), ev, _stream(vol))
+                                                    float(slope), ev, _stream(vol, f16=split is not None))
     _lib.check(rc, "casmvs_costreg_regress_f32")
     return (cost, depth, conf, index) if return_index else (cost, depth, conf)
 
@@ -645,7 +647,7 @@ def conv2d_ci_splitf16_forward(packed, x, cout=None, slope=0.01, channels_last_c
     out2 = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device) if channels_last_copy else None
     with torch.cuda.device(x.device):
         rc = _lib.load().casmvs_conv2d_ci_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), _ptr(out2), N, cin, cout, H, W,
-                                                               float(slope), _stream(x))
+                                                               float(slope), _stream(x, f16=True))
     _lib.check(rc, "casmvs_conv2d_ci_splitf16_forward_f32")
     return (out, out2) if channels_last_copy else out
 
@@ -676,7 +678,7 @@ def fpn_tail0_splitf16(packed, bias9, conv0, feat1_sum, channels_last_copy=False
     out2 = torch.empty((N, H, W, 8), dtype=torch.float32, device=conv0.device) if channels_last_copy else None
     with torch.cuda.device(conv0.device):
         rc = _lib.load().casmvs_fpn_tail0_splitf16_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(bias9), _ptr(conv0), _ptr(feat1_sum), _ptr(out), _ptr(out2),
-                                                       N, H, W, _stream(conv0))
+                                                       N, H, W, _stream(conv0, f16=True))
     _lib.check(rc, "casmvs_fpn_tail0_splitf16_f32")
     return (out, out2) if channels_last_copy else out
 
@@ -723,7 +725,8 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
             rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
                                                                  ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
                                                                  _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),
-                                                                 ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev, _stream(imgs))
+                                                                 ctypes.c_void_p(workspace.data_ptr()), N, H, W, float(slope), ev,
+                                                                 _stream(imgs, f16=bool(fused0_splitf16) or ci is not None))
         else:
             rc = _lib.load().casmvs_featurenet_forward_f32(arr, _ptr(imgs), _ptr(feat0), _ptr(feat1), _ptr(feat2),
                                                            _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),

@@ -16,7 +16,7 @@ import re
 import numpy as np
 import torch
 
-from . import _io, _lib
+from . import _io, _lib, streams
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)   # dtu.py:135-136
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -374,7 +374,7 @@ def normalize_images_u8(images_u8, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     s = (ctypes.c_float * 3)(*std)
     with torch.cuda.device(x.device):
         rc = _lib.load().casmvs_normalize_images_u8(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, H, W, m, s,
-                                                    ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+                                                    streams.launch_stream(x))
     _lib.check(rc, "casmvs_normalize_images_u8")
     return out
 

@@ -164,6 +164,33 @@ def test_concurrent_forwards_equal_single_stream(dev):
                 assert torch.equal(o[k], w[k]), k
 
 
+def test_stream_guard_keeps_a_float32_layer_correct_beside_f16_kernels_of_another_stream(dev):
+    """casmvsnet_pl_amd/streams.py: the Cout = 8 float32-MFMA layer kernel returns wrong values when it shares SIMDs with another stream's f16 matrix
+    instructions (tools/native/coresidency_lib_victim.cpp: 171 of 200 rounds).  Driven through this package from two streams, the guard makes the
+    float32 launch wait for the f16 work queued on the other stream: every round equals the solo run, bit for bit."""
+    from casmvsnet_pl_amd import ops, streams
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 16, 32, 128, 160, generator=g).to(dev)
+    p0 = ops.conv0_splitf16_pack(torch.randn(8, 16, 3, 3, 3, generator=g) * 0.1).to(dev)
+    xv = (torch.rand(1, 16, 32, 32, 48, generator=g) * 0.3).to(dev)
+    pv = ops.conv3d_pack(ops.CONV_S1, torch.randn(8, 16, 3, 3, 3, generator=g) * 0.2, None, None).to(dev)
+    want = ops.conv3d_forward(ops.CONV_S1, pv, xv, 8).clone()
+    torch.cuda.synchronize()
+    streams.reset()
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    bad = 0
+    for _ in range(40):
+        with torch.cuda.stream(sa):
+            for _ in range(3):
+                ops.conv0_splitf16_forward(p0, x0)
+        with torch.cuda.stream(sb):
+            got = ops.conv3d_forward(ops.CONV_S1, pv, xv, 8)
+        torch.cuda.synchronize()
+        bad += 0 if torch.equal(got, want) else 1
+    streams.reset()
+    assert bad == 0, bad
+
+
 DDP_TRAIN_SCRIPT = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())
