@@ -4,13 +4,15 @@
 //   ci   casmvs_conv3d_forward_f32 S1 16 -> 16  (conv16db_kernel<CI>)
 //   s2   casmvs_conv3d_forward_f32 S2 8 -> 16   (stride 2)
 //   t2   casmvs_conv3d_forward_f32 T2 16 -> 8   (transposed + skip)
-// Each victim launch is compared bit for bit with the victim's output when it ran alone.   coresidency_lib_victim [rounds = 200]
+// Each victim launch is compared bit for bit with the victim's output when it ran alone.   coresidency_lib_victim [rounds = 200 [victims, e.g. px,ciw]]
+// Another build of the library as the victim: LD_PRELOAD=casmvsnet_pl_amd/libcasmvs_trace.so CASMVS_NO_DB=1 ... (the profiling build's A/B switches)
 //   hipcc -O2 --offload-arch=gfx950 tools/native/coresidency_lib_victim.cpp -Iinclude -Lcasmvsnet_pl_amd -lcasmvs_hip -Wl,-rpath,'$ORIGIN/../../../casmvsnet_pl_amd' -o tools/probes/bin/coresidency_lib_victim
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "casmvs.h"
@@ -52,8 +54,11 @@ int main(int argc, char **argv) {
   hipStream_t sa, sb;
   CHECK(hipStreamCreate(&sa)); CHECK(hipStreamCreate(&sb));
   struct Victim { const char *name; int kind, cin, cout, B, D, H, W; };
+  // px / ciw / s2w: the WIDE double-buffered forms (conv16db_kernel<.., CK 4, NT 4 | 2, ..>); ci / s2: the deep forms (NT 1) the small volumes select
   const Victim victims[] = {{"px", CASMVS_CONV_S1, 16, 8, 1, 32, 32, 48}, {"ci", CASMVS_CONV_S1, 16, 16, 1, 16, 32, 48},
-                            {"s2", CASMVS_CONV_S2, 8, 16, 1, 32, 32, 48}, {"t2", CASMVS_CONV_T2, 16, 8, 1, 16, 16, 24}};
+                            {"ciw", CASMVS_CONV_S1, 16, 16, 1, 32, 64, 128}, {"s2", CASMVS_CONV_S2, 8, 16, 1, 32, 32, 48},
+                            {"s2w", CASMVS_CONV_S2, 8, 16, 1, 64, 128, 128}, {"t2", CASMVS_CONV_T2, 16, 8, 1, 16, 16, 24}};
+  const char *only = argc > 2 ? argv[2] : nullptr;   // comma list of victim names
   const char *nnames[5] = {"none", "f32mfma", "f16mfma", "bf16mfma", "valu"};
   float *dsink;
   unsigned *dcounts;
@@ -71,6 +76,10 @@ int main(int argc, char **argv) {
          prop.gcnArchName, cus, rounds);
   int any = 0;
   for (const Victim &v : victims) {
+    if (only) {
+      const std::string list = std::string(",") + only + ",", key = std::string(",") + v.name + ",";
+      if (list.find(key) == std::string::npos) continue;
+    }
     const bool t2 = v.kind == CASMVS_CONV_T2, s2 = v.kind == CASMVS_CONV_S2;
     const size_t nvox = (size_t)v.D * v.H * v.W, nin = (size_t)v.B * v.cin * nvox;
     const size_t nout = (size_t)v.B * v.cout * (t2 ? nvox * 8 : (s2 ? nvox / 8 : nvox));
