@@ -454,7 +454,6 @@ def train_mode(args, dev, world, rank, dist, barrier):
     from casmvsnet_pl_amd import InPlaceABN
     from casmvsnet_pl_amd import training
     from casmvsnet_pl_amd.training import sl1_loss, sl1_loss_masked
-    training.WGRAD_LDS_LAYOUT = int(args.wgrad_layout)
     H, W, V, G, n_depths, ratios, _ = CONFIGS[args.config]
     B = args.batch if args.batch_given else 1   # the reference's default: --batch_size 1
     model = CascadeMVSNet(n_depths=list(n_depths), interval_ratios=list(ratios), num_groups=G, norm_act=InPlaceABN)
@@ -532,7 +531,6 @@ def train_mode(args, dev, world, rank, dist, barrier):
                      {"workload": args.config + "_train", "H": H, "W": W, "views": V, "n_depths": list(n_depths), "num_groups": G,
                       "batch_per_gpu": B, "launch": "one hipGraph replay per step" if use_graph else "kernel by kernel",
                       "zero_grad": "zero-filled gradients + accumulate-adds" if args.zero_fill_grads else "set_to_none",
-                      "wgrad_lds_layout": int(args.wgrad_layout),
                       "parallelism": f"DistributedDataParallel x{world} over RCCL" if world > 1 else "single GPU"}, median)
     line["train_step_ms"] = 1e3 * elapsed / args.steps
     line["peak_memory_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
@@ -587,8 +585,6 @@ def main():
                          "'splitf16' also runs conv2 / conv4 in that arithmetic, the other two keep them in float32; the other modes' throughputs "
                          "are measured and printed beside the headline")
     ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: FeatureNet's full-resolution FPN tail as one kernel (1) or as the reference's three steps (0); default: the model's")
-    ap.add_argument("--wgrad-layout", type=int, default=0, choices=[0, 1],
-                    help="--mode train A/B: 1 = the weight-gradient kernel's conflict-free LDS layout (casmvs_conv_wgrad_x_f32, written without a GPU run)")
     ap.add_argument("--zero-fill-grads", action="store_true", help="--mode train A/B: optimizer.zero_grad(set_to_none=False) as before round 3's last session")
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` object of the default line (20 hipGraph replays of the batch-1 training step)")
     args = ap.parse_args()

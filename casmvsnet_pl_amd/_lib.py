@@ -93,7 +93,6 @@ SYMBOLS = {
     "casmvs_softmax_regress_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 7),
     "casmvs_conv_wgrad_f32": (c_int, [c_int, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "casmvs_conv_wgrad_x_f32": (c_int, [c_int, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_prob_wgrad_supported": (c_int, [c_int] * 4),
     "casmvs_prob_wgrad_workspace_bytes": (c_size_t, [c_int] * 4),
     "casmvs_prob_wgrad_f32": (c_int, [_FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -33,11 +33,10 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 // A workgroup owns one (16 cs, 16 cb) pair and walks tiles of 4 x 16 positions of the small grid; its four waves take four
 // consecutive k-steps (4 positions each) of a tile row and keep one accumulator per tap.  No atomics: every wave
 // writes its partial sums, wgrad_reduce_kernel adds them in a fixed order.
-// PAD2 (opt-in, casmvs_conv_wgrad_x_f32; written without a GPU run): channel strides = 2 mod 32 instead of odd.  The 32 lanes of a ds_read_b32 group are
-// (16 channels) x (2 consecutive positions): with an odd stride o their banks are 16 values of i o and the same + 1 - 2-way conflicts on every operand read
-// (1.9x the conflict-free LDS cycles on the CPU bank model, tools/lds_bank_profile.py run_kernels8: ~8 LDS cycles per matrix instruction against the 8 the
-// four SIMDs leave) -; with stride 2 (mod 32) they are 2 i + {0, 1}: 32 different banks.  (Stride-2 kinds: B positions are 2 apart, their reads stay 2-way.)
-template <int S, int KZ, int KS, bool PAD2 = false>
+// (Rounds 3 / 4: operand tiles with channel strides = 2 mod 32 make the matrix phase's ds_read_b32 conflict-free on the CPU bank model - the odd strides
+// are 2-way conflicted - and give the same bits, but the whole training step was SLOWER with them on the MI355X, 14.61 against 14.17 ms
+// (profiles/r04_bench_train_variants.txt): the kernel is not bound by those reads.  Removed.)
+template <int S, int KZ, int KS>
 struct WgradCfg {
   static constexpr int T = KZ * KS * KS;
   // tile of the small grid: TZ x 4 x 16 positions.  The stride-1 3D layers (the bulk of the FLOPs) take four planes per
@@ -47,17 +46,17 @@ struct WgradCfg {
   static constexpr int PZ = KZ / 2, P = KS / 2;
   static constexpr int IZ = (TZ - 1) * S + KZ, IY = (TY - 1) * S + KS, IX = (TX - 1) * S + KS;
   static constexpr int SY = IX, SZ = IY * IX;
-  static constexpr int SC = PAD2 ? (IZ * SZ + 29) / 32 * 32 + 2 : ((IZ * SZ) | 1);   // odd channel stride: the 16 cb lanes of a B operand hit 16 different banks
-  static constexpr int SS = PAD2 ? (NPOS + 31) / 32 * 32 + 2 : NPOS + 1;             // row stride of the small tile
+  static constexpr int SC = (IZ * SZ) | 1;   // odd channel stride: the 16 cb lanes of a B operand hit 16 different banks
+  static constexpr int SS = NPOS + 1;             // row stride of the small tile
   static constexpr int TILE_FLOATS = 16 * SC + 16 * SS, RED_FLOATS = T * 256;   // the end-of-kernel reduction reuses the buffer
   static constexpr size_t LDS_BYTES = (size_t)(TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS) * sizeof(float);
 };
 
-template <int S, int KZ, int KS, bool VEC, bool PAD2 = false>
+template <int S, int KZ, int KS, bool VEC>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const float *__restrict__ small, const float *__restrict__ big,
                                                              float *__restrict__ partial, int B, int Cs, int Cb, int Zs,
                                                              int Ys, int Xs, int cb_groups, int tiles_z, int tiles_y, int tiles_x) {
-  using Cfg = WgradCfg<S, KZ, KS, PAD2>;
+  using Cfg = WgradCfg<S, KZ, KS>;
   constexpr int T = Cfg::T, IZ = Cfg::IZ, IY = Cfg::IY, IX = Cfg::IX, SY = Cfg::SY, SZ = Cfg::SZ, SC = Cfg::SC, SS = Cfg::SS;
   constexpr int TZ = Cfg::TZ, TY = Cfg::TY, NPOS = Cfg::NPOS, RPW = Cfg::ROWS / 4;
   CASMVS_DYNAMIC_LDS(float, smem);
@@ -786,10 +785,10 @@ bool wgrad_launch(int kind, int B, int cin, int cout, int D, int H, int W, Wgrad
   return true;
 }
 
-template <int S, int KZ, int KS, bool VEC, bool PAD2 = false>
+template <int S, int KZ, int KS, bool VEC>
 int launch_wgrad_v(const WgradLaunch &l, const float *small, const float *big, float *partial, int B, hipStream_t st) {
-  auto kernel = conv_wgrad_kernel<S, KZ, KS, VEC, PAD2>;
-  const size_t lds = WgradCfg<S, KZ, KS, PAD2>::LDS_BYTES;
+  auto kernel = conv_wgrad_kernel<S, KZ, KS, VEC>;
+  const size_t lds = WgradCfg<S, KZ, KS>::LDS_BYTES;
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "conv_wgrad_kernel")) return rc;
   hipLaunchKernelGGL(kernel, dim3((unsigned)l.gx, (unsigned)l.gy), dim3(kThreads), lds, st, small, big, partial, B, l.Cs, l.Cb, l.Zs,
                      l.Ys, l.Xs, l.cb_groups, l.tiles_z, l.tiles_y, l.tiles_x);
@@ -797,13 +796,12 @@ int launch_wgrad_v(const WgradLaunch &l, const float *small, const float *big, f
 }
 
 template <int S, int KZ, int KS>
-int launch_wgrad(const WgradLaunch &l, const float *small, const float *big, float *partial, int B, hipStream_t st, bool pad2 = false) {
+int launch_wgrad(const WgradLaunch &l, const float *small, const float *big, float *partial, int B, hipStream_t st) {
   // 16-byte staging: grid rows that start 16-byte aligned and tensors a 32-bit buffer offset can address
   const size_t small_bytes = (size_t)B * l.Cs * l.Zs * l.Ys * l.Xs * 4;
   const size_t big_bytes = (size_t)B * l.Cb * (KZ == 1 ? 1 : l.Zs * S) * (l.Ys * S) * (l.Xs * S) * 4;
   const bool vec = l.Xs % 4 == 0 && small_bytes <= (1ull << 31) && big_bytes <= (1ull << 31) &&
                    (reinterpret_cast<size_t>(small) & 15) == 0 && (reinterpret_cast<size_t>(big) & 15) == 0;
-  if (pad2 && vec) return launch_wgrad_v<S, KZ, KS, true, true>(l, small, big, partial, B, st);   // (the scalar-staging form keeps the odd strides)
   return vec ? launch_wgrad_v<S, KZ, KS, true>(l, small, big, partial, B, st) : launch_wgrad_v<S, KZ, KS, false>(l, small, big, partial, B, st);
 }
 
@@ -817,7 +815,7 @@ extern "C" size_t casmvs_conv_wgrad_workspace_bytes(int kind, int B, int cin, in
 
 namespace {
 int conv_wgrad_run(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B, int cin, int cout, int D, int H, int W,
-                   bool pad2, void *stream) {
+                   void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(in && grad_out && grad_weight && workspace, "conv_wgrad: null pointer");
   WgradLaunch l;
@@ -829,11 +827,11 @@ int conv_wgrad_run(int kind, const float *in, const float *grad_out, float *grad
   float *partial = static_cast<float *>(workspace);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (g.KZ == 3 && g.S == 1) rc = launch_wgrad<1, 3, 3>(l, small, big, partial, B, st, pad2);
-  else if (g.KZ == 3) rc = launch_wgrad<2, 3, 3>(l, small, big, partial, B, st, pad2);
-  else if (g.KS == 3) rc = launch_wgrad<1, 1, 3>(l, small, big, partial, B, st, pad2);
-  else if (g.KS == 5) rc = launch_wgrad<2, 1, 5>(l, small, big, partial, B, st, pad2);
-  else rc = launch_wgrad<1, 1, 1>(l, small, big, partial, B, st, pad2);
+  if (g.KZ == 3 && g.S == 1) rc = launch_wgrad<1, 3, 3>(l, small, big, partial, B, st);
+  else if (g.KZ == 3) rc = launch_wgrad<2, 3, 3>(l, small, big, partial, B, st);
+  else if (g.KS == 3) rc = launch_wgrad<1, 1, 3>(l, small, big, partial, B, st);
+  else if (g.KS == 5) rc = launch_wgrad<2, 1, 5>(l, small, big, partial, B, st);
+  else rc = launch_wgrad<1, 1, 1>(l, small, big, partial, B, st);
   if (rc) return rc;
   const int n = l.gy * l.T * 256;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(n / kRedElems)), dim3(kThreads), 0, st, partial, grad_weight, l.Cs,
@@ -844,19 +842,9 @@ int conv_wgrad_run(int kind, const float *in, const float *grad_out, float *grad
 
 extern "C" int casmvs_conv_wgrad_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
                                      int cin, int cout, int D, int H, int W, void *stream) {
-  return conv_wgrad_run(kind, in, grad_out, grad_weight, workspace, B, cin, cout, D, H, W, false, stream);
+  return conv_wgrad_run(kind, in, grad_out, grad_weight, workspace, B, cin, cout, D, H, W, stream);
 }
 
-// Experimental (no GPU has run it): lds_layout 1 = the operand tiles with channel strides = 2 mod 32 (WgradCfg: PAD2), 0 = the entry above.  Same sums in
-// the same order: bit-identical results.
-extern "C" int casmvs_conv_wgrad_x_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
-                                       int cin, int cout, int D, int H, int W, int lds_layout, void *stream) {
-  if (lds_layout != 0 && lds_layout != 1) {
-    casmvs::clear_error();
-    return casmvs::fail(CASMVS_ERR_INVALID_ARG, "conv_wgrad_x: lds_layout=%d (0 or 1)", lds_layout);
-  }
-  return conv_wgrad_run(kind, in, grad_out, grad_weight, workspace, B, cin, cout, D, H, W, lds_layout == 1, stream);
-}
 
 extern "C" int casmvs_conv_dgrad_direct_f32(int kind, const float *weight, const float *grad_out, float *grad_in, int B, int cin,
                                             int cout, int D, int H, int W, void *stream) {

@@ -119,9 +119,6 @@ def _conv_raw(kind, weight, bias, x, adjoint=False):
 
 
 PROB_WGRAD_KERNEL = True   # False: the generic matrix-core kernel also for `prob` (A/B runs)
-# 1: the weight-gradient kernel's operand tiles with channel strides = 2 mod 32 (casmvs_conv_wgrad_x_f32: conflict-free ds_read_b32 in the matrix loop, half the
-# LDS cycles on the CPU bank model; bit-identical results).  Written without a GPU run at the end of round 3: opt-in until it has been timed.
-WGRAD_LDS_LAYOUT = 0
 
 
 def conv_wgrad(kind, x, grad_out, weight_shape):
@@ -149,12 +146,7 @@ def conv_wgrad(kind, x, grad_out, weight_shape):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     gw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        if WGRAD_LDS_LAYOUT:
-            rc = lib.casmvs_conv_wgrad_x_f32(kind, _ptr(x), _ptr(grad_out), _ptr(gw), ctypes.c_void_p(ws.data_ptr()), B, cin, cout, D, H, W,
-                                             int(WGRAD_LDS_LAYOUT), _stream(x))
-        else:
-            rc = lib.casmvs_conv_wgrad_f32(kind, _ptr(x), _ptr(grad_out), _ptr(gw), ctypes.c_void_p(ws.data_ptr()), B, cin, cout, D, H, W,
-                                           _stream(x))
+        rc = lib.casmvs_conv_wgrad_f32(kind, _ptr(x), _ptr(grad_out), _ptr(gw), ctypes.c_void_p(ws.data_ptr()), B, cin, cout, D, H, W, _stream(x))
     _lib.check(rc, "casmvs_conv_wgrad_f32")
     return gw
 

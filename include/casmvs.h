@@ -478,11 +478,6 @@ int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_va
 size_t casmvs_conv_wgrad_workspace_bytes(int kind, int B, int cin, int cout, int D, int H, int W);
 int casmvs_conv_wgrad_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
                           int cin, int cout, int D, int H, int W, void *stream);
-/* EXPERIMENTAL (written without a GPU run, opt-in): lds_layout 1 = the operand tiles of the weight-gradient kernel with channel strides = 2 (mod 32)
- * instead of odd ones, which makes every ds_read_b32 of the matrix loop hit 32 different banks (stride-1 kinds; on the CPU bank model the kernel's LDS
- * cycles halve); 0 = casmvs_conv_wgrad_f32.  The same sums in the same order: bit-identical results.  Same workspace. */
-int casmvs_conv_wgrad_x_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
-                            int cin, int cout, int D, int H, int W, int lds_layout, void *stream);
 
 /* Weight gradient of the `prob` layer (Conv3d 8 -> 1, k3 s1 p1; models/mvsnet.py:89) on its own kernel: grad_weight (1, 8, 3, 3, 3)
  * = sum over (b, z, y, x) of grad_out (B, 1, D, H, W) * in (B, 8, D, H, W) shifted by the tap, zero padded.  The generic

@@ -128,8 +128,8 @@ def test_production_plane_sweep_runs_on_the_cpu(built):
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_training_weight_gradient_kernel_runs_on_the_cpu(built):
     """conv_wgrad_kernel (csrc/train.hip: the weight gradient of every convolution kind as a GEMM over the positions on v_mfma_f32_16x16x4_f32 + the
-    fixed-order reduction) for Conv3d s1 and Conv2d k5 s2 (every kind in the driver's `all` mode) against the definition in float64 - with the production LDS layout and with
-    the experimental conflict-free one (casmvs_conv_wgrad_x_f32), which must give the same bits; channel_sums_kernel against float64 sums; costvol_var_bwd_kernel (the scatter transpose of the plane sweep through an LDS
+    fixed-order reduction) for Conv3d s1 and Conv2d k5 s2 (every kind in the driver's `all` mode) against the definition in float64, twice (the fixed-order
+    reduction must reproduce the bits); channel_sums_kernel against float64 sums; costvol_var_bwd_kernel (the scatter transpose of the plane sweep through an LDS
     image with ds_add_f32, the largest kernel of the training step) against the derivative of the variance through the bilinear weights in float64."""
     out = _run(built[("run_kernels8", "plain")], ("wgrad S1", "wgrad K5S2", "channel_sums", "var_backward"))   # (`all`: every kind, profiles/r03_hip_emulation_all.txt)
     assert "DIFFERENT" not in out.stdout and out.stdout.count("bit-identical") >= 2

@@ -98,28 +98,3 @@ def test_prefetcher_with_stager_thread_delivers_the_same_batches(dev):
     assert next(it)["idx"] == [0, 0]
     with pytest.raises(RuntimeError, match="source failed"):
         next(it)
-
-
-@pytest.mark.parametrize("kind_name,shape,cout", [("S1", (2, 8, 8, 12, 20), 8), ("S1", (1, 16, 4, 16, 32), 16), ("T2", (1, 16, 2, 6, 12), 8), ("K3", (2, 16, 18, 36), 16)])
-def test_weight_gradient_with_the_conflict_free_lds_layout_is_bit_identical(dev, kind_name, shape, cout):
-    """casmvs_conv_wgrad_x_f32(lds_layout = 1): operand tiles with channel strides = 2 (mod 32) - the same sums in the same order."""
-    from casmvsnet_pl_amd import training
-    from casmvsnet_pl_amd._lib import CONV2D_K3, CONV_S1, CONV_T2
-    kind = {"S1": CONV_S1, "T2": CONV_T2, "K3": CONV2D_K3}[kind_name]
-    g = torch.Generator().manual_seed(sum(shape))
-    x = torch.randn(*shape, generator=g).to(dev)
-    cin = shape[1]
-    out_shape = (shape[0], cout, *[2 * d for d in shape[2:]]) if kind_name == "T2" else (shape[0], cout, *shape[2:])
-    gy = torch.randn(*out_shape, generator=g).to(dev)
-    wshape = (cin, cout, 3, 3, 3) if kind_name == "T2" else ((cout, cin, 3, 3, 3) if kind_name == "S1" else (cout, cin, 3, 3))
-    prob = training.PROB_WGRAD_KERNEL
-    training.PROB_WGRAD_KERNEL = False
-    try:
-        training.WGRAD_LDS_LAYOUT = 0
-        want = training.conv_wgrad(kind, x, gy, wshape)
-        training.WGRAD_LDS_LAYOUT = 1
-        got = training.conv_wgrad(kind, x, gy, wshape)
-    finally:
-        training.WGRAD_LDS_LAYOUT = 0
-        training.PROB_WGRAD_KERNEL = prob
-    assert torch.equal(got, want)

@@ -10,7 +10,7 @@
 #   configs      bench lines of the other BASELINE configs (gwc8, 1152x864 V5, 768x576 V7), no CPU baseline
 #   suite        python -m pytest tests -m gpu
 #   smoke        __graft_entry__.smoke()
-#   train        bench.py --mode train (+ --zero-fill-grads, --wgrad-layout 1)
+#   train        bench.py --mode train (+ --zero-fill-grads)
 #   files        tools/gpu_files_throughput.py (files -> depth maps, native decoder, batch-8 graph)
 #   pmc          FETCH_SIZE / WRITE_SIZE passes + kernel stats over the step runner (layout of tools/summarize_profile.py)
 #   prof         rocprofv3 --kernel-trace --stats over bench.py --steps 10 --no-cpu-baseline
@@ -68,7 +68,7 @@ stage_smoke () { timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 
 stage_train () {
   timeout 400 python bench.py --mode train --steps 20 --warmup 5 > $OUT/bench_train.json 2> $OUT/bench_train.err
-  for v in ${TRAIN_VARIANTS:-"--zero-fill-grads" "--wgrad-layout 1"}; do
+  for v in ${TRAIN_VARIANTS:-"--zero-fill-grads"}; do
     n=$(echo $v | tr -d ' -'); timeout 400 python bench.py --mode train --steps 20 --warmup 5 $v > $OUT/bench_train_$n.json 2> $OUT/bench_train_$n.err
   done
   grep -ho '"train_step_ms": [0-9.]*' $OUT/bench_train*.json
