@@ -34,8 +34,8 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 // consecutive k-steps (4 positions each) of a tile row and keep one accumulator per tap.  No atomics: every wave
 // writes its partial sums, wgrad_reduce_kernel adds them in a fixed order.
 // (Rounds 3 / 4: operand tiles with channel strides = 2 mod 32 make the matrix phase's ds_read_b32 conflict-free on the CPU bank model - the odd strides
-// are 2-way conflicted - and give the same bits, but the whole training step was SLOWER with them on the MI355X, 14.61 against 14.17 ms
-// (profiles/r04_bench_train_variants.txt): the kernel is not bound by those reads.  Removed.)
+// are 2-way conflicted - and give the same bits, but the whole training step did not move on the MI355X: 14.10 against 14.17 ms, inside the
+// run-to-run noise (profiles/r04_bench_train_variants.txt): the kernel is not bound by those reads.  Removed rather than kept as an option.)
 template <int S, int KZ, int KS>
 struct WgradCfg {
   static constexpr int T = KZ * KS * KS;
