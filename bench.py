@@ -371,8 +371,8 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
     out["roofline"] = {"kernel": {"splitbf16": "conv0_sb_kernel<CIN, 6> (CostRegNet.conv0 on the bf16 matrix cores, float32 operands as three exact "
                                                "bf16 slices; 3 launches per step)",
                                   "splitf16": "CostRegNet.conv0 on the f16 matrix cores (float32 operands as two float16 slices behind exact power-of-two "
-                                              "scalings), 3 launches per step: conv0_sf_kernel<8, 3> (level 0), conv0_zm_kernel<16> (level 1, "
-                                              "input-stationary along z), conv0_sf_kernel<32, 3> (level 2)",
+                                              "scalings), 3 launches per step: conv0_zm_kernel<8> (level 0) and conv0_zm_kernel<16> (level 1): "
+                                              "input-stationary along z on 8 x 64 patches; conv0_sf_kernel<32, 3> (level 2): 4 x 4 x 32 tiles",
                                   None: "conv16db_kernel<PX> (CostRegNet.conv0 on the float32 MFMA: Cout 8, stride 1; 3 launches per step)"}[split],
                        "bound": "hbm" if split else "mfma", "batch": B, "avg_launch_ms": conv0_ms / (3 * n_ev)}
     hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -696,7 +696,7 @@ def main():
                                                             "bf16 matrix cores, float32 accumulation (conv0_splitbf16.hip)",
                                                "splitf16": "float32 operands as two float16 slices (22 significand bits) behind exact power-of-two scalings, "
                                                            "three f16 x f16 partial products per product on the f16 matrix cores, float32 accumulation "
-                                                           "(conv0_splitf16.hip; cin = 16 = cascade level 1 on the z-marching kernel conv0_zmarch.hip); "
+                                                           "(conv0_splitf16.hip; cin = 8 / 16 = cascade levels 0 / 1 on the z-marching kernel conv0_zmarch.hip); "
                                                            "float32-grade: distance to a float64 convolution at or below the float32 MFMA kernel's",
                                                "f32": "float32 MFMA (v_mfma_f32_16x16x4_f32)"}[model.cost_reg_0.conv0_mode],
                           "conv2_conv4_conv6_conv9_conv11_arithmetic": "as conv0's split-f16 (conv_ci_splitf16.hip, deconv9_splitf16.hip, deconv11_splitf16.hip); "

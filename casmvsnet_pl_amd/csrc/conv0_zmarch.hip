@@ -37,9 +37,16 @@ using namespace casmvs::buf;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-struct ZmCfg {
+// WIDE: patches of 8 (y) x 64 (x) instead of 16 x 32.  The kernel is bound by its HBM-side read traffic (PMC, batch 8: 2.3x the input at cin = 16 with
+// 16 x 32 patches - profiles/r04_pmc_traffic.md): a staged row of 40 floats from x0 - 4 touches its own 128-byte line plus a sector of each x neighbour's
+// for one halo float each; a row of 72 floats pays the same two sectors for 256 bytes of its own.  Measured (tools/native/conv0_zm_check.cpp, batch 8,
+// dirtied caches, profiles/r04_conv0_zm_wide_ab.txt): cin 16 830 -> 738 us, cin 8 454 -> 391 us (the tiled kernel: 1116 / 495); cin 32 (one workgroup per
+// CU, W = 160 = 2.5 patches) 709 -> 841: the wide form is the default where cin <= 16.
+template <bool WIDE_>
+struct ZmCfgT {
   static constexpr int THREADS = 256, NT = 4;
-  static constexpr int TY = 16, TX = 32;
+  static constexpr bool WIDE = WIDE_;
+  static constexpr int TY = WIDE ? 8 : 16, TX = WIDE ? 64 : 32;
   static constexpr int IY = TY + 2, IX = TX + 8, ROW = IX + 1;    // x0 - 4 .. x0 + 35 (16-byte aligned global groups); odd row stride
   static constexpr int NV = IY * ROW;                               // 16-byte slots per slice: 738
   static __host__ __device__ constexpr int slot(int x) { return x ^ (((x >> 3) & 1) << 1); }   // as SfCfg::slot
@@ -61,11 +68,11 @@ struct ZmItem {
 };
 
 // in (B, CIN, D, H, W) float32, W % 4 == 0, 16-byte aligned; wpk: the image of casmvs_conv0_splitf16_pack; out (B, 8, D, H, W).
-template <int CIN>
-__global__ __launch_bounds__(ZmCfg::THREADS, 2) void conv0_zm_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
+template <int CIN, bool WIDE>
+__global__ __launch_bounds__(ZmCfgT<WIDE>::THREADS, 2) void conv0_zm_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
                                                                     float *__restrict__ out, int B, int D, int H, int W, int tiles_x,
                                                                     int tiles_y, int nseg, int zlen, float slope) {
-  using Cfg = ZmCfg;
+  using Cfg = ZmCfgT<WIDE>;
   constexpr int NCH = CIN / 8, NT = Cfg::NT, IX = Cfg::IX, ROW = Cfg::ROW, NV = Cfg::NV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4 *act = reinterpret_cast<u32x4 *>(smem_raw);                                              // [2][NV]
@@ -88,8 +95,10 @@ __global__ __launch_bounds__(ZmCfg::THREADS, 2) void conv0_zm_kernel(const float
   // every chunk's lane images, once per workgroup (visible after the first unit's first barrier)
   for (int unit = tid; unit < NCH * Cfg::WUNITS; unit += Cfg::THREADS) wl[unit] = reinterpret_cast<const u32x4 *>(wpk)[unit];
 
-  // lane's B voxel of the wave's first staged row: the wave owns output rows 4 wave .. 4 wave + 3 = staged rows 4 wave .. 4 wave + 5
-  const int vbase = (4 * wave) * ROW + Cfg::slot(2 * jcol + u + 3);
+  // lane's B voxel of the wave's first staged row: the wave owns four output rows (staged rows wy .. wy + 5) of a 32-voxel x range starting at wx:
+  // 16 x 32 patches: rows 4 wave, the whole width; 8 x 64 patches: rows 4 (wave >> 1), x half (wave & 1)
+  const int wy = Cfg::WIDE ? 4 * (wave >> 1) : 4 * wave, wx = Cfg::WIDE ? 32 * (wave & 1) : 0;
+  const int vbase = wy * ROW + Cfg::slot(wx + 2 * jcol + u + 3);
 
   auto decode = [&](int v) {
     int item = xcd_major(v, total);   // x fastest, then the z segment, then y
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(ZmCfg::THREADS, 2) void conv0_zm_kernel(const float
       const bool plane_ok = zo >= cur.zs && zo < cur.ze;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int oy = cur.ty0 + 4 * wave + t, ox = cur.tx0 + 2 * jcol;
+        const int oy = cur.ty0 + wy + t, ox = cur.tx0 + wx + 2 * jcol;
         const bool ok = plane_ok && oy < H && ox < W;   // W even: the pixel pair is inside or outside
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -243,12 +252,12 @@ __global__ __launch_bounds__(ZmCfg::THREADS, 2) void conv0_zm_kernel(const float
   }
 }
 
-template <int CIN>
+template <int CIN, bool WIDE>
 int launch_zm(const void *packed, const float *in, float *out, int B, int D, int H, int W, float slope, hipStream_t st) {
-  using Cfg = ZmCfg;
+  using Cfg = ZmCfgT<WIDE>;
   constexpr int NCH = CIN / 8;
   const int tiles_x = casmvs::ceil_div(W, Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY);
-  auto kernel = conv0_zm_kernel<CIN>;
+  auto kernel = conv0_zm_kernel<CIN, WIDE>;
   const size_t lds = Cfg::lds_bytes(NCH);
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "conv0_zm_kernel")) return rc;
   const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), Cfg::THREADS, lds);
@@ -278,7 +287,7 @@ extern "C" int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *
   CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(packed)) & 15) == 0, "conv0_zmarch_forward: 16-byte aligned pointers");
   CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 29), "conv0_zmarch_forward: one sample's input tensor must hold < 2^29 floats");
   hipStream_t st = (hipStream_t)stream;
-  if (cin == 8) return launch_zm<8>(packed, in, out, B, D, H, W, slope, st);
-  if (cin == 16) return launch_zm<16>(packed, in, out, B, D, H, W, slope, st);
-  return launch_zm<32>(packed, in, out, B, D, H, W, slope, st);   // 95 KiB of LDS: ONE workgroup per CU (measured: 0.74-0.9x the tiled kernel; the engine keeps cin = 32 tiled)
+  if (cin == 8) return launch_zm<8, true>(packed, in, out, B, D, H, W, slope, st);
+  if (cin == 16) return launch_zm<16, true>(packed, in, out, B, D, H, W, slope, st);
+  return launch_zm<32, false>(packed, in, out, B, D, H, W, slope, st);   // 95 KiB of LDS: ONE workgroup per CU (measured: 0.74-0.9x the tiled kernel; the engine keeps cin = 32 tiled)
 }

@@ -263,8 +263,8 @@ class CostRegNet(_PackedWeights, nn.Module):
         # conv0's arithmetic in `regress` (the engine's eval path), all float32-grade (distance to a float64 convolution at or
         # below the float32 MFMA kernel's):
         #   "splitf16":  f16 matrix cores, every float32 operand as two float16 slices behind exact power-of-two scalings (per
-        #                weight tensor / per staged tile), three partial products per product, float32 accumulation; cin = 16 (cascade
-        #                level 1) on the z-marching kernel (conv0_zmarch.hip), cin = 8 / 32 on the tiled one (conv0_splitf16.hip)
+        #                weight tensor / per staged tile), three partial products per product, float32 accumulation; cin = 8 / 16 (cascade
+        #                levels 0 / 1) on the z-marching kernel (conv0_zmarch.hip), cin = 32 on the tiled one (conv0_splitf16.hip)
         #   "splitbf16": bf16 matrix cores, three exact bf16 slices per operand, six partial products
         #   "f32":       the float32 MFMA kernel like every other layer
         self.conv0_mode = "splitf16"

@@ -210,8 +210,9 @@ int casmvs_conv0_splitf16_forward_f32(const void *packed, const float *in, float
  * output planes it touches - half the staged voxels per output voxel of casmvs_conv0_splitf16_forward_f32, whose L1 -> L2 request
  * stream bounds it.  `packed`: the image of casmvs_conv0_splitf16_pack.  cin = 8, 16 (two workgroups per CU) or 32 (one), W % 4 == 0.  Results agree with the other
  * entry to ~1e-6 of the range (both ~3e-7 from a float64 convolution), not bit for bit.
- * Measured on the MI355X (tools/native/conv0_zm_check.cpp, profiles/r04_native_checks_first_run.txt): 1.10-1.15x the tiled kernel at cin = 16
- * (cascade level 1), equal at cin = 8, 0.74-0.9x at cin = 32 - casmvs_costreg_regress_f32 uses it for cin = 16. */
+ * Patches are 8 x 64 for cin = 8 / 16 (fewer partial cache lines per staged row: the kernel is bound by its read traffic), 16 x 32 for cin = 32.
+ * Measured on the MI355X (tools/native/conv0_zm_check.cpp, batch 8, dirtied caches, profiles/r04_conv0_zm_wide_ab.txt): 1.5x the tiled kernel at cin = 16
+ * (cascade level 1), 1.26x at cin = 8, 0.9-1.04x at cin = 32 - casmvs_costreg_regress_f32 uses it for cin = 8 and 16. */
 int casmvs_conv0_zmarch_supported(int cin, int W);
 int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int D, int H, int W, float slope,
                                     void *stream);
