@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 
 #include "buffer_ops.h"
 #include "common.h"
@@ -252,6 +253,261 @@ __global__ __launch_bounds__(ZmCfgT<WIDE>::THREADS, 2) void conv0_zm_kernel(cons
   }
 }
 
+// ---- the same data flow with staging and multiplication overlapped INSIDE one workgroup (round 4) -------------------------------------------------
+// conv0_zm_kernel overlaps the two phases of a unit across the TWO workgroups a CU holds; at cin = 32 the lane images (72 KiB) leave room for one
+// workgroup only and the phases run back to back (0.74-1.04x the tiled kernel).  Here a workgroup is 8 waves: waves 4-7 (producers) load, scale, split
+// and write unit n + 1 into one of TWO plane-patch buffers while waves 0-3 (consumers) multiply unit n out of the other; two workgroup barriers per
+// unit (A: the producers' four wave maxima are published, placed one third into the consumers' matrix phase; B: buffer n + 1 is complete, buffer n is
+// free).  The producers keep the loads of TWO units in flight (two register sets).  Floating-point vector work is done by the producer waves and, outside
+// their matrix phases, by the consumers' folds / epilogues - never between a wave's own matrix instructions.  One workgroup per CU
+// (2 x 23 KiB + 18 KiB x cin / 8 of LDS), two waves per SIMD: a producer beside a consumer.
+// Units, scaling, summation order and therefore the RESULT BITS are those of conv0_zm_kernel with the same patch shape.
+template <int CIN, bool WIDE>
+__global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk, float *__restrict__ out,
+                                                         int B, int D, int H, int W, int tiles_x, int tiles_y, int nseg, int zlen, float slope) {
+  using Cfg = ZmCfgT<WIDE>;
+  constexpr int NCH = CIN / 8, NT = Cfg::NT, IX = Cfg::IX, ROW = Cfg::ROW, NV = Cfg::NV;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4 *act = reinterpret_cast<u32x4 *>(smem_raw);                                                  // [2 buffers][2 slices][NV]
+  u32x4 *wl = reinterpret_cast<u32x4 *>(smem_raw + 2 * Cfg::ACT_BYTES);                              // [chunk][9][2][64]
+  unsigned *wmax = reinterpret_cast<unsigned *>(smem_raw + 2 * Cfg::ACT_BYTES + Cfg::w_bytes(NCH));   // [2 buffers][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;          // wave-uniform
+  const int w4 = wave & 3, t4 = tid & 255;  // wave / thread inside the role's group of four waves
+  const int jcol = lane & 15, u = lane >> 4;
+  const int total = tiles_x * tiles_y * nseg * B;
+  if ((int)blockIdx.x >= total) return;
+  const int HW = H * W, cs = D * HW;
+  const size_t in_ss = (size_t)CIN * cs, out_ss = (size_t)8 * cs;
+  for (int unit = tid; unit < NCH * Cfg::WUNITS; unit += 512) wl[unit] = reinterpret_cast<const u32x4 *>(wpk)[unit];
+
+  auto decode = [&](int v) {
+    int item = xcd_major(v, total);   // x fastest, then the z segment, then y
+    ZmItem t;
+    t.tx0 = (item % tiles_x) * Cfg::TX;
+    item /= tiles_x;
+    const int seg = item % nseg;
+    item /= nseg;
+    t.ty0 = (item % tiles_y) * Cfg::TY;
+    t.b = item / tiles_y;
+    t.zs = seg * zlen;
+    t.ze = min(t.zs + zlen, D);
+    return t;
+  };
+  // units of this workgroup: every (chunk, existing input plane zs - 1 .. ze) of its items item, item + gridDim.x, ...
+  int nunits = 0;
+  for (int it = blockIdx.x; it < total; it += gridDim.x) {
+    const ZmItem t = decode(it);
+    nunits += (min(t.ze, D - 1) - max(t.zs - 1, 0) + 1) * NCH;
+  }
+
+  if (producer) {
+    // ---- producers: unit n -> buffer n & 1 in iteration n; the loads of units n + 1 and n + 2 are in flight meanwhile ----
+    const rsrc_t none = make_rsrc(in, 0);
+    struct Cursor {   // the unit whose loads are issued next
+      int item, zi, ch, zhi;
+      ZmItem t;
+      bool valid;
+    };
+    Cursor pc;
+    pc.item = blockIdx.x;
+    pc.t = decode(pc.item);
+    pc.zi = max(pc.t.zs - 1, 0);
+    pc.zhi = min(pc.t.ze, D - 1);
+    pc.ch = 0;
+    pc.valid = true;
+    int voff;
+    const int e = t4, iy = e / (IX / 4), g = e - iy * (IX / 4);
+    const int vox = e < Cfg::ITEMS ? iy * ROW + 4 * g : -1;
+    const int vxor = ((g >> 1) & 1) << 1;
+    auto plan = [&](const ZmItem &tc) {
+      const int gy = tc.ty0 - 1 + iy, gx = tc.tx0 - 4 + 4 * g;
+      const bool ok = e < Cfg::ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;   // W % 4 == 0
+      voff = ok ? (gy * W + gx) * 4 : kOOB;
+    };
+    plan(pc.t);
+    auto advance = [&]() {   // -> the next unit (chunk, then plane, then the first plane of the next item)
+      if (++pc.ch < NCH) return;
+      pc.ch = 0;
+      if (pc.zi < pc.zhi) { ++pc.zi; return; }
+      pc.item += gridDim.x;
+      pc.valid = pc.item < total;
+      if (pc.valid) {
+        pc.t = decode(pc.item);
+        pc.zi = max(pc.t.zs - 1, 0);
+        pc.zhi = min(pc.t.ze, D - 1);
+        plan(pc.t);
+      }
+    };
+    f32x4v R[2][8];
+    auto issue = [&](auto set_) {   // the loads of the cursor's unit into register set S; then the cursor moves on
+      constexpr int S = decltype(set_)::value;
+      const rsrc_t src = pc.valid ? make_rsrc(in + (size_t)pc.t.b * in_ss, in_ss * 4) : none;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) R[S][c] = buf_load4(src, voff, ((pc.ch * 8 + c) * cs + pc.zi * HW) * 4);
+      if (pc.valid) advance();
+    };
+    issue(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 1>{});
+    auto stage = [&](auto set_, int n) {
+      constexpr int S = decltype(set_)::value;
+      const int par = n & 1;
+      if (n < nunits) {
+        float m = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(R[S][c][j]));
+        const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
+        if (lane == 0) wmax[par * 4 + w4] = wm;
+      }
+      __syncthreads();   // A
+      if (n < nunits) {
+        float mult, inv;
+        casmvs::tile_scale(wmax + par * 4, mult, inv);
+        if (vox >= 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] = R[S][c][j];
+            u32x4 o[2];
+            casmvs::split8_f16(x, mult, o);
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) act[(par * 2 + sl) * NV + vox + (j ^ vxor)] = o[sl];
+          }
+        }
+        issue(set_);   // unit n + 2 into the set that has just been emptied
+      }
+      __syncthreads();   // B
+    };
+    for (int n = 0; n <= nunits; n += 2) {   // nunits + 1 iterations: the last one only keeps the consumers' barriers company
+      stage(std::integral_constant<int, 0>{}, n);
+      if (n + 1 <= nunits) stage(std::integral_constant<int, 1>{}, n + 1);
+    }
+    return;
+  }
+
+  // ---- consumers: unit n out of buffer n & 1 in iteration n + 1 ----
+  const float *tail = reinterpret_cast<const float *>(wpk + Cfg::w_bytes(NCH));
+  float sc[2], sh[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    sc[h] = tail[2 * u + h];
+    sh[h] = tail[8 + 2 * u + h];
+  }
+  const int wy = Cfg::WIDE ? 4 * (w4 >> 1) : 4 * w4, wx = Cfg::WIDE ? 32 * (w4 & 1) : 0;
+  const int vbase = wy * ROW + Cfg::slot(wx + 2 * jcol + u + 3);
+  f32x4 acc[3][NT];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // iteration 0: the producers stage unit 0 (A)
+  __syncthreads();   //                                          (B)
+  int n = 0;
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    const ZmItem cur = decode(item);
+    const rsrc_t dst = make_rsrc(out + (size_t)cur.b * out_ss, out_ss * 4);
+#pragma unroll 1
+    for (int zi = cur.zs - 1; zi <= cur.ze; ++zi) {
+      if (zi >= 0 && zi < D) {
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ++ch, ++n) {
+          const u32x4 *buf = act + (n & 1) * 2 * NV;
+          u32x4 row[NT + 2][2];
+#pragma unroll
+          for (int yr = 0; yr < NT + 2; ++yr)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) row[yr][s] = buf[s * NV + vbase + yr * ROW];
+          f32x4 part[3][NT];
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) part[kz][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              u32x4 a[2];
+#pragma unroll
+              for (int s = 0; s < 2; ++s) a[s] = wl[((ch * 9 + kz * 3 + ky) * 2 + s) * 64 + lane];
+              constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+#pragma unroll
+              for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) part[kz][t] = zm_mfma(a[PA[p]], row[t + ky][PB[p]], part[kz][t]);
+            }
+            if (kz == 0) __syncthreads();   // A of iteration n + 1, a third into the matrix phase
+          }
+          __builtin_amdgcn_sched_barrier(0);   // the folds are floating-point vector work: after the unit's last matrix instruction
+          float mult, inv;
+          casmvs::tile_scale(wmax + (n & 1) * 4, mult, inv);
+#pragma unroll
+          for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[2 - kz][t][q] = fmaf(part[kz][t][q], inv, acc[2 - kz][t][q]);
+          __syncthreads();   // B of iteration n + 1: buffer n & 1 and its maxima are free
+        }
+      }
+      const int zo = zi - 1;
+      const bool plane_ok = zo >= cur.zs && zo < cur.ze;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int oy = cur.ty0 + wy + t, ox = cur.tx0 + wx + 2 * jcol;
+        const bool ok = plane_ok && oy < H && ox < W;   // W even: the pixel pair is inside or outside
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v0 = fmaf(acc[0][t][2 * h], sc[h], sh[h]), v1 = fmaf(acc[0][t][2 * h + 1], sc[h], sh[h]);
+          v0 = v0 > 0.0f ? v0 : v0 * slope;
+          v1 = v1 > 0.0f ? v1 : v1 * slope;
+          buf_store2(f32x2{v0, v1}, dst, ok ? ((2 * u + h) * cs + (zo * H + oy) * W + ox) * 4 : kOOB, 0);
+        }
+        acc[0][t] = acc[1][t];
+        acc[1][t] = acc[2][t];
+        acc[2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// Measured (tools/native/conv0_zm_check.cpp, batch 8, dirtied caches, profiles/r04_conv0_zw_ab.txt): cin 32: tiled 751-771 us, two-phase z-march 704,
+// warp-specialised 651; cin 16: two-phase 794, warp-specialised 819; cin 8: 416 / 480 - where two workgroups fit a CU they overlap the phases better
+// than one workgroup's two wave groups do.  The warp-specialised form is the cin = 32 kernel.
+#ifndef CASMVS_ZM_WS
+#define CASMVS_ZM_WS 4   // which channel counts run the warp-specialised form: bit 0 cin 8, bit 1 cin 16, bit 2 cin 32 (A/B builds)
+#endif
+#ifndef CASMVS_ZM_WS32_WIDE
+#define CASMVS_ZM_WS32_WIDE 0   // A/B builds: 8 x 64 patches for the warp-specialised cin = 32 kernel
+#endif
+
+template <int CIN, bool WIDE>
+int launch_zw(const void *packed, const float *in, float *out, int B, int D, int H, int W, float slope, hipStream_t st) {
+  using Cfg = ZmCfgT<WIDE>;
+  constexpr int NCH = CIN / 8;
+  const int tiles_x = casmvs::ceil_div(W, Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY);
+  auto kernel = conv0_zw_kernel<CIN, WIDE>;
+  const size_t lds = 2 * Cfg::ACT_BYTES + Cfg::w_bytes(NCH) + 32;
+  if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "conv0_zw_kernel")) return rc;
+  const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), 512, lds);
+  const long patches = (long)B * tiles_x * tiles_y;
+  int nseg = 1;
+  while (patches * nseg < 4L * resident && D / (nseg + 1) >= 4) ++nseg;
+  const int zlen = casmvs::ceil_div(D, nseg);
+  nseg = casmvs::ceil_div(D, zlen);
+  const long total = patches * nseg;
+  CASMVS_REQUIRE(total < (1L << 31), "conv0_zmarch_forward: too many items");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(total < resident ? total : resident)), dim3(512), lds, st, in,
+                     reinterpret_cast<const unsigned char *>(packed), out, B, D, H, W, tiles_x, tiles_y, nseg, zlen, slope);
+  return casmvs::check_launch("conv0_zw_kernel");
+}
+
 template <int CIN, bool WIDE>
 int launch_zm(const void *packed, const float *in, float *out, int B, int D, int H, int W, float slope, hipStream_t st) {
   using Cfg = ZmCfgT<WIDE>;
@@ -287,7 +543,14 @@ extern "C" int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *
   CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(packed)) & 15) == 0, "conv0_zmarch_forward: 16-byte aligned pointers");
   CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 29), "conv0_zmarch_forward: one sample's input tensor must hold < 2^29 floats");
   hipStream_t st = (hipStream_t)stream;
-  if (cin == 8) return launch_zm<8, true>(packed, in, out, B, D, H, W, slope, st);
-  if (cin == 16) return launch_zm<16, true>(packed, in, out, B, D, H, W, slope, st);
-  return launch_zm<32, false>(packed, in, out, B, D, H, W, slope, st);   // 95 KiB of LDS: ONE workgroup per CU (measured: 0.74-0.9x the tiled kernel; the engine keeps cin = 32 tiled)
+  if (cin == 8) {
+    if constexpr ((CASMVS_ZM_WS & 1) != 0) return launch_zw<8, true>(packed, in, out, B, D, H, W, slope, st);
+    else return launch_zm<8, true>(packed, in, out, B, D, H, W, slope, st);
+  }
+  if (cin == 16) {
+    if constexpr ((CASMVS_ZM_WS & 2) != 0) return launch_zw<16, true>(packed, in, out, B, D, H, W, slope, st);
+    else return launch_zm<16, true>(packed, in, out, B, D, H, W, slope, st);
+  }
+  if constexpr ((CASMVS_ZM_WS & 4) != 0) return launch_zw<32, CASMVS_ZM_WS32_WIDE != 0>(packed, in, out, B, D, H, W, slope, st);
+  else return launch_zm<32, false>(packed, in, out, B, D, H, W, slope, st);   // 95 KiB of LDS: ONE workgroup per CU (measured: 0.74-0.9x the tiled kernel; the engine keeps cin = 32 tiled)
 }

@@ -2278,13 +2278,16 @@ extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
   return (size_t)B * floats * sizeof(float);
 }
 
+#ifndef CASMVS_ZM_CIN32
+#define CASMVS_ZM_CIN32 1   // conv0 at cin = 32 (cascade level 2) on conv0_zmarch.hip's warp-specialised kernel (0: the tiled kernel, A/B builds)
+#endif
 namespace {
 // conv0 .. conv11 (+ skips) into the workspace, then the `prob` head: on its own (depth == nullptr), or fused with the
 // softmax / regression / confidence that consumes it (casmvs_prob_regress_f32).
 // split_layers (casmvs_costreg_regress_f32): the images of the layers that have a form on the f16 matrix cores - conv0, conv2, conv4, conv6 (stride 1),
-// conv9, conv11 (transposed) - each or nullptr (the float32 MFMA kernel).  With conv0's split-f16 image, cin = 16 and cin = 8 run the z-marching kernel
-// on 8 x 64 patches (conv0_zmarch.hip: 1.5x / 1.26x the tiled one at batch 8 on the MI355X, profiles/r04_conv0_zm_wide_ab.txt); cin = 32 (one
-// workgroup per CU there: 0.9-1.04x) stays tiled.
+// conv9, conv11 (transposed) - each or nullptr (the float32 MFMA kernel).  With conv0's split-f16 image every cin runs a z-marching kernel
+// (conv0_zmarch.hip): cin = 8 / 16 on 8 x 64 patches with two workgroups per CU (1.26x / 1.5x the tiled kernel at batch 8 on the MI355X,
+// profiles/r04_conv0_zm_wide_ab.txt), cin = 32 the warp-specialised form (1.15x, profiles/r04_conv0_zw_ab.txt).
 int costreg_run(const char *who, const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol, const float *depth_values,
                 float *cost, float *depth, float *confidence, int32_t *index, void *workspace, int B, int cin, int D,
                 int h, int w, float slope, void *const *layer_events, void *stream) {
@@ -2327,7 +2330,7 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     ++li;
     rc = casmvs_conv0_splitbf16_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, 0, stream);
     if (rc != CASMVS_OK) return rc;
-  } else if (conv0_arith == CASMVS_CONV0_SPLIT_F16 && (cin == 16 || cin == 8) && split_ok && casmvs_conv0_zmarch_supported(cin, w)) {
+  } else if (conv0_arith == CASMVS_CONV0_SPLIT_F16 && (cin == 16 || cin == 8 || (CASMVS_ZM_CIN32 && cin == 32)) && split_ok && casmvs_conv0_zmarch_supported(cin, w)) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
     rc = casmvs_conv0_zmarch_forward_f32(conv0_split, vol, c0, B, cin, D, h, w, sl, stream);   // the same arithmetic, input-stationary along z

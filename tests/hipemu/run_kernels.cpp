@@ -112,6 +112,7 @@ int main(int argc, char **argv) {
   if (all || quick || which == "conv0_sf") take(conv3d_check("conv0_sf", 8, 1, 5, 9, 36, false));
   if (all || which == "conv0_sf") take(conv3d_check("conv0_sf", 16, 1, 3, 6, 32, false));
   if (all || quick || which == "conv0_zm") take(conv3d_check("conv0_zm", 16, 1, 5, 17, 36, true));
+  if (all || quick || which == "conv0_zw") take(conv3d_check("conv0_zw", 32, 1, 3, 20, 36, true));   // cin = 32: the warp-specialised form (8 waves, two patch buffers)
   if (all || which == "conv0_zm") {
     take(conv3d_check("conv0_zm", 8, 1, 5, 20, 36, true));
     take(conv3d_check("conv0_zm", 16, 2, 9, 17, 44, true));

@@ -88,7 +88,7 @@ def _run(exe, names, mode="quick"):
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_kernels_run_on_the_cpu_against_float64(built):
-    _run(built[("run_kernels", "plain")], ("conv0_sf", "conv0_zm", "deconv11", "deconv9"))
+    _run(built[("run_kernels", "plain")], ("conv0_sf", "conv0_zm", "conv0_zw", "deconv11", "deconv9"))
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
@@ -143,7 +143,7 @@ def test_float32_matrix_core_layers_run_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-@pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")),
+@pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "conv0_zw", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")),
                                           ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion")), ("run_kernels6", ("fpn_tail0",)), ("run_kernels7", ("costvol_lds",)), ("run_kernels8", ("wgrad",)), ("run_kernels9", ("conv3d_f32",))])
 def test_no_lds_race_under_thread_sanitizer(built, source, names):
     """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
@@ -175,7 +175,7 @@ def test_lds_bank_profile_of_the_split_f16_kernels(built, source):
         pytest.skip("this clang++ has no -fsanitize=thread")
     tool = _profile_tool()
     totals = tool.per_kernel(tool.profile(source, "quick", workdir=built["workdir"], exe=built[(source, "profile")]))
-    want = {"run_kernels": ("conv0_sf_kernel", "conv0_zm_kernel", "deconv11_sf_kernel", "deconv9_sf_kernel")}[source]
+    want = {"run_kernels": ("conv0_sf_kernel", "conv0_zm_kernel", "conv0_zw_kernel", "deconv11_sf_kernel", "deconv9_sf_kernel")}[source]
     for name in want:
         kernels = [k for k in totals if k.startswith(name)]
         assert kernels, (name, list(totals))
