@@ -305,8 +305,8 @@ def _timed_op(fn, reps, dirty_mb, dev):
 def homo_warp_roofline(dev, H, W, n_depths, B):
     """The un-fused op models/modules.py:52-92 (north_star names its HBM-roofline fraction) at the three level shapes,
     algorithmic bytes 4 B (C h w + D h w + C D h w), measured four ways:
-      reference signature (NCHW source in, the pixel-major layout pass INCLUDED: ops.homo_warp) and the kernel alone on
-      a pixel-major source (what FeatureNet hands the engine), each hot (10 back-to-back calls) and with dirtied caches
+      reference signature (NCHW source in: ops.homo_warp - since round 4 the box is staged from the channel planes, no layout pass) and the
+      kernel on a pixel-major source (what FeatureNet hands the engine), each hot (10 back-to-back calls) and with dirtied caches
       (a 512 MB fill_ between calls = the state inside the forward).  `frac` is the most conservative of the four:
       reference signature, dirtied caches."""
     from casmvsnet_pl_amd import ops
@@ -331,8 +331,8 @@ def homo_warp_roofline(dev, H, W, n_depths, B):
     fr = {name: tot_b / (sum(v.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS for name, v in ms.items()}
     per_level = {name: {str(l): work[l]["homo_warp_bytes"] / (v[l] * 1e-3) / 1e9 / HBM_PEAK_GBS for l in range(3)} for name, v in ms.items()}
     head = "reference_signature_dirty"
-    return {"kernel": "homo_warp (un-fused op modules.py:52-92): nchw_to_nhwc_kernel + costvol_lds_kernel<MODE_WARP> through the "
-                      "reference signature (ops.homo_warp, NCHW source), one call per level shape, caches dirtied between calls",
+    return {"kernel": "homo_warp (un-fused op modules.py:52-92): costvol_lds_kernel<MODE_WARP_NCHW> through the reference signature "
+                      "(ops.homo_warp: the source box staged straight from the (B, C, H, W) map), one call per level shape, caches dirtied between calls",
             "bound": "hbm", "achieved": fr[head] * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr[head], "traffic": None,
             "frac_by_measurement": fr, "per_level_frac": per_level, "avg_launch_ms": sum(ms[head].values()) / 3}
 

@@ -34,6 +34,8 @@ SYMBOLS = {
     "casmvs_costvol_var_lds_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_gwc_lds_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_homo_warp_nhwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_homo_warp_lds_supported": (c_int, [c_int, c_int, c_int]),
+    "casmvs_homo_warp_lds_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_partial_var_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_partial_gwc_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_var_finalize_f32": (c_int, [_FP, _FP, _FP, c_size_t, c_int, c_void_p]),

@@ -61,7 +61,9 @@ __device__ unsigned long long g_cv_trace[64 * 32];
 #define CV_STAMP() do {} while (0)
 #endif
 
-enum { MODE_VAR = 0, MODE_GWC = 1, MODE_WARP = 2, MODE_VAR_PART = 3, MODE_GWC_PART = 4 };
+enum { MODE_VAR = 0, MODE_GWC = 1, MODE_WARP = 2, MODE_VAR_PART = 3, MODE_GWC_PART = 4,
+       MODE_WARP_NCHW = 5 };   // homo_warp on the reference's own (B, C, H, W) source: the box is staged from the channel planes (no layout pass)
+constexpr bool is_warp(int mode) { return mode == MODE_WARP || mode == MODE_WARP_NCHW; }
 
 struct SweepArgs {
   const float *feats;  // (B, Vtot, h, w, C) pixel-major feature maps; view 0 = reference view (unless MODE_WARP)
@@ -209,7 +211,7 @@ __device__ __forceinline__ Box read_box(const int *prm, int vi) {
 // registers at the merge point, unconditionally) and was slower than the gather kernels.  Hence: the gather
 // branch is wave-uniform (skipped by a scalar branch) and drains its own loads with an explicit s_waitcnt
 // INSIDE the branch, so the steady state carries no vector-memory wait at all.
-template <int C, int CS, bool SQ, int JBM = 2>
+template <int C, int CS, bool SQ, int JBM = 2, bool NCHW = false>
 __device__ __forceinline__ void accumulate_view(const float *P, float xf, float yf, float dvk, int w, int h, bool valid,
                                                 const Box &bx_, const f32x4 *bx, const float *view_map, int view_bytes,
                                                 int c0, f32x2 (&s)[CS / 2], f32x2 (&q)[CS / 2], int abl) {
@@ -248,19 +250,30 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
       const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(view_map), 0, view_bytes, 0x00020000);
       // every lane loads (a valid image address either way), only the lanes outside their box keep the result;
       // one tap at a time: the rare path must not raise the register count of the common one
-      const int on0 = ((t.yn * w + t.xl) * C + c0 + 4 * jb) * 4, os0 = ((t.ys * w + t.xl) * C + c0 + 4 * jb) * 4;
+      // pixel-major map: the 4 channels of a group are one 16-byte load, the right column is C floats on; channel-plane map
+      // (NCHW): four dword loads h * w floats apart, the right column one float on
+      const int chs = NCHW ? h * w * 4 : 4, pxs = NCHW ? 4 : C * 4;   // byte strides of a channel / of a pixel
+      const int on0 = NCHW ? ((c0 + 4 * jb) * h * w + t.yn * w + t.xl) * 4 : ((t.yn * w + t.xl) * C + c0 + 4 * jb) * 4;
+      const int os0 = NCHW ? ((c0 + 4 * jb) * h * w + t.ys * w + t.xl) * 4 : ((t.ys * w + t.xl) * C + c0 + 4 * jb) * 4;
 #define CASMVS_GATHER_TAP(dst, voff, imm)                                        \
       {                                                                          \
         f32x4 g[JB];                                                             \
-        _Pragma("unroll") for (int j = 0; j < JB; ++j) g[j] = buf_load4(src, voff, (imm) + 16 * j); \
+        _Pragma("unroll") for (int j = 0; j < JB; ++j) {                         \
+          if (NCHW) {                                                            \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                        \
+              g[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, voff + (imm) + (4 * j + i) * chs, 0, 0)); \
+          } else {                                                               \
+            g[j] = buf_load4(src, voff, (imm) + 16 * j);                         \
+          }                                                                      \
+        }                                                                        \
         __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) only, INSIDE the branch */ \
         _Pragma("unroll") for (int j = 0; j < JB; ++j)                           \
           _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[j][i] = outside ? g[j][i] : dst[j][i]; \
       }
       CASMVS_GATHER_TAP(n0, on0, 0)
-      CASMVS_GATHER_TAP(n1, on0, C * 4)
+      CASMVS_GATHER_TAP(n1, on0, pxs)
       CASMVS_GATHER_TAP(s0, os0, 0)
-      CASMVS_GATHER_TAP(s1, os0, C * 4)
+      CASMVS_GATHER_TAP(s1, os0, pxs)
 #undef CASMVS_GATHER_TAP
     }
     // Two channels per instruction (v_pk_mul / v_pk_fma / v_pk_add_f32): a wave issues one instruction every ~5
@@ -300,7 +313,7 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
 #define CASMVS_WARP_OCC 3   // waves per SIMD of the one-view (homo_warp) kernels at CS = 16: 136 VGPRs, one box per workgroup (A/B: 2, 4)
 #endif
 constexpr int waves_per_simd(int cs, int mode, int pg) {
-  return pg == 2 ? 4 : (cs == 8 ? 3 : (mode == MODE_WARP && cs == 16 ? CASMVS_WARP_OCC : 2));
+  return pg == 2 ? 4 : (cs == 8 ? 3 : (is_warp(mode) && cs == 16 ? CASMVS_WARP_OCC : 2));
 }
 
 template <int C, int CS, int MODE, int TW, int DC, int NV, int PG>
@@ -319,7 +332,8 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
 #endif
   // tap data in flight: 16 registers per channel group
   constexpr int kJB = waves_per_simd(CS, MODE, PG) >= 4 ? 1 : (waves_per_simd(CS, MODE, PG) == 2 ? CASMVS_JB2 : 2);
-  constexpr bool NEED_REF = MODE != MODE_WARP;
+  constexpr bool NCHW = MODE == MODE_WARP_NCHW;   // `feats` is (B, 1, C, h, w): channel planes
+  constexpr bool NEED_REF = !is_warp(MODE);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int *prm = reinterpret_cast<int *>(smem);                   // [kMaxViews][8]: bx0, by0, bw, bh, q256, r256
   int *red = prm + kMaxViews * 8;                             // [4 waves][kMaxViews][4]
@@ -453,8 +467,10 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
       xmn = min(xmn, r[0]); xmx = max(xmx, r[1]); ymn = min(ymn, r[2]); ymx = max(ymx, r[3]);
     }
     if (xmn > xmx) { xmn = 0; xmx = 1; ymn = 0; ymx = 0; }   // nothing of this tile projects into the view
+    if (NCHW) { xmn &= ~3; xmx |= 3; }   // channel-plane staging moves 4 consecutive x per load: whole quads (w % 4 == 0: still inside the row)
     int bw = xmx - xmn + 1, bh = ymx - ymn + 1;
-    const int maxbw = a.cap_units / L::units_per_px_bound() - 1;   // host guarantees >= 2
+    int maxbw = a.cap_units / L::units_per_px_bound() - 1;   // host guarantees >= 2
+    if (NCHW) maxbw &= ~3;
     if (bw > maxbw) bw = maxbw;
     const int maxbh = a.cap_units / L::row_units(bw);
     if (bh > maxbh) bh = maxbh;
@@ -511,7 +527,41 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
     for (int i = 0; i < NUB; ++i)
       if (s.lo[i] >= 0) s.bx[s.lo[i]] = s.regs[i];
   };
-  if (NV > 0) {
+  if constexpr (NCHW) {
+    // One view (homo_warp).  Item = (box row, quad of 4 x, group of 4 channels): four 16-byte loads - the same 4 x of the group's 4 channel planes -
+    // transposed in registers into four pixel-major 16-byte LDS units.  Two items (8 loads) in flight per thread.
+    const int *p = prm;
+    const int bx0 = uniform_int(p[0]), by0 = uniform_int(p[1]), bw = uniform_int(p[2]), bh = uniform_int(p[3]);
+    const int rowu = L::row_units(bw), qpr = bw >> 2, ipr = qpr * GL, items = bh * ipr;   // quads / items per row
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(uniform_ptr(fb + (size_t)a.v0 * view_floats)), 0, view_bytes, 0x00020000);
+    constexpr int NI = 2;
+#pragma unroll 1
+    for (int base = 0; base < items; base += NT * NI) {
+      f32x4 v[NI][4];
+      int lo[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int it = base + tid + NT * k;
+        const bool ok = it < items;
+        const int r = (int)((unsigned)it / (unsigned)ipr), rem = it - r * ipr;
+        const int q = (int)((unsigned)rem / (unsigned)GL), cg = rem - q * GL;
+        lo[k] = ok ? r * rowu + cg : -1;
+        const int px0 = 4 * q;
+        lo[k] = ok ? lo[k] + (px0 << 16) : -1;   // (LDS row / channel part, first pixel) packed: unit(px) is not linear in px for CS = 8
+        const int gofs = ok ? (((c0 + 4 * cg) * h + by0 + r) * w + bx0 + px0) * 4 : -16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[k][i] = buf_load4(src, ok ? gofs + i * hw * 4 : -16, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        if (lo[k] >= 0) {
+          const int px0 = lo[k] >> 16, rc = lo[k] & 0xffff;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) box[rc + L::unit(px0 + i)] = f32x4{v[k][0][i], v[k][1][i], v[k][2][i], v[k][3][i]};
+        }
+      }
+    }
+  } else if (NV > 0) {
     ViewStage st[NVS];
 #pragma unroll
     for (int vi = 0; vi < NVS; ++vi) { stage_init(st[vi], vi); stage_issue(st[vi]); }
@@ -591,8 +641,8 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
     } else if (NV > 0) {
 #pragma unroll
       for (int vi = 0; vi < NVS; ++vi)
-        accumulate_view<C, CS, SQ, kJB>(Pm[vi], xf, yf, dvk, w, h, valid, boxes[vi], box + (size_t)vi * a.cap_units,
-                                   fb + (size_t)(a.v0 + vi) * view_floats, view_bytes, c0, s2, q2, abl);
+        accumulate_view<C, CS, SQ, kJB, NCHW>(Pm[vi], xf, yf, dvk, w, h, valid, boxes[vi], box + (size_t)vi * a.cap_units,
+                                         fb + (size_t)(a.v0 + vi) * view_floats, view_bytes, c0, s2, q2, abl);
     } else {
 #pragma unroll 1
       for (int vi = 0; vi < nv; ++vi) {
@@ -620,7 +670,7 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
       s[2 * c] = s2[c].x; s[2 * c + 1] = s2[c].y;
       q[2 * c] = q2[c].x; q[2 * c + 1] = q2[c].y;
     }
-    if (MODE == MODE_VAR || MODE == MODE_WARP || MODE == MODE_VAR_PART) {
+    if (MODE == MODE_VAR || is_warp(MODE) || MODE == MODE_VAR_PART) {
       if (!(abl & 1)) store_plane<CS>(s, tr, ps, lane, D, hw, d, w, direct_voff);
       if (MODE == MODE_VAR_PART) store_plane<CS>(q, tr, ps2, lane, D, hw, d, w, direct_voff);
     } else {
@@ -702,7 +752,7 @@ bool make_plan(int C, int w, int D, int nv, int G, int mode, Plan &p) {
 #endif
   if (C % p.cs != 0 || (p.cs != 8 && p.cs != 16 && p.cs != 32)) return false;
   const int upp = p.cs == 8 ? 3 : p.cs / 4 + 1, th = kThreads / p.tw;   // upper bound of the units per staged pixel
-  const int need = ((p.tw + p.dc + 4) * (p.cs == 8 ? 17 : 8 * upp) / 8 + 1) * (th + 2);
+  const int need = ((p.tw + p.dc + 4 + (mode == MODE_WARP_NCHW ? 6 : 0)) * (p.cs == 8 ? 17 : 8 * upp) / 8 + 1) * (th + 2);   // NCHW staging: boxes of whole x quads
   // workgroups per CU the registers allow (waves_per_simd of the kernel that will run): a smaller LDS budget than
   // that buys nothing and only clips boxes earlier
   const int occ = waves_per_simd(p.cs, mode, p.pg) / p.pg;
@@ -742,7 +792,7 @@ int launch_nv(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
 // V = 3 (2 source views); everything else (other V, the partial sums of the view-sharded build) the rolled form.
 template <int C, int CS, int MODE, int TW>
 int launch_cfg(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
-  if constexpr (MODE == MODE_WARP) return launch_nv<C, CS, MODE, TW, 1>(a, p, B, st);
+  if constexpr (is_warp(MODE)) return launch_nv<C, CS, MODE, TW, 1>(a, p, B, st);
   if constexpr (MODE == MODE_VAR || MODE == MODE_GWC) {
     if (a.nv == 2) return launch_nv<C, CS, MODE, TW, 2>(a, p, B, st);
   }
@@ -848,6 +898,20 @@ extern "C" int casmvs_homo_warp_nhwc_f32(const float *src, const float *proj, co
   if (int rc = check_common("homo_warp_nhwc", src, proj, depth, out, B, 1, C, H, W, D)) return rc;
   SweepArgs a{src, proj, depth, out, nullptr, 1, 0, 1, 0, 1, 0, 1, 1, H, W, D, 0, 0, 0, 0, 0};
   return launch_mode<MODE_WARP>(a, C, B, (hipStream_t)stream, "homo_warp_nhwc");
+}
+
+// homo_warp on the reference's own layout (modules.py:52-92: src_feat (B, C, H, W)): the source box is staged from the channel planes, no pixel-major copy
+extern "C" int casmvs_homo_warp_lds_supported(int C, int W, int D) {
+  Plan p;
+  return (C == 8 || C == 16 || C == 32) && make_plan(C, W, D, 1, 1, MODE_WARP_NCHW, p) ? 1 : 0;
+}
+
+extern "C" int casmvs_homo_warp_lds_f32(const float *src, const float *proj, const float *depth, float *out, int B,
+                                        int C, int H, int W, int D, void *stream) {
+  casmvs::clear_error();
+  if (int rc = check_common("homo_warp_lds", src, proj, depth, out, B, 1, C, H, W, D)) return rc;
+  SweepArgs a{src, proj, depth, out, nullptr, 1, 0, 1, 0, 1, 0, 1, 1, H, W, D, 0, 0, 0, 0, 0};
+  return launch_mode<MODE_WARP_NCHW>(a, C, B, (hipStream_t)stream, "homo_warp_lds");
 }
 
 extern "C" int casmvs_costvol_partial_var_f32(const float *feats, const float *proj, const float *depth, float *sum,

@@ -35,8 +35,9 @@ def _stream(t, f16=False):
 
 def homo_warp(src_feat, proj_mat, depth_values, impl="auto"):
     """modules.py:52-92.  (B,C,H,W), (B,3,4), (B,D,H,W) -> (B,C,D,H,W).
-    impl: "lds" = pixel-major copy of src + casmvs_homo_warp_nhwc_f32 (source box staged in LDS), "gather" =
-    casmvs_homo_warp_f32 (NCHW gathers), "auto" = "lds" when the shape has an LDS plan.  Bit-identical results."""
+    impl: "lds" = casmvs_homo_warp_lds_f32 (the source box staged in LDS straight from the channel planes of `src_feat`: no layout pass),
+    "lds_copy" = pixel-major copy of src + casmvs_homo_warp_nhwc_f32 (round 2-3's form, kept for A/B), "gather" = casmvs_homo_warp_f32
+    (NCHW gathers), "auto" = "lds" when the shape has an LDS plan.  Bit-identical results."""
     src_feat, proj_mat, depth_values = _dev(src_feat, "src_feat"), _dev(proj_mat, "proj_mat"), _dev(depth_values, "depth_values")
     B, C, H, W = src_feat.shape
     D = depth_values.shape[1]
@@ -44,10 +45,14 @@ def homo_warp(src_feat, proj_mat, depth_values, impl="auto"):
         raise ValueError(f"homo_warp: shapes {tuple(src_feat.shape)} {tuple(proj_mat.shape)} {tuple(depth_values.shape)}")
     lib = _lib.load()
     if impl == "auto":
-        impl = "lds" if C in (8, 16, 32) and lib.casmvs_costvol_lds_supported(C, W, D, 1, 1) else "gather"
+        impl = "lds" if C in (8, 16, 32) and lib.casmvs_homo_warp_lds_supported(C, W, D) else "gather"
     out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=src_feat.device)
     with torch.cuda.device(src_feat.device):
         if impl == "lds":
+            rc = lib.casmvs_homo_warp_lds_f32(_ptr(src_feat), _ptr(proj_mat), _ptr(depth_values), _ptr(out),
+                                              B, C, H, W, D, _stream(src_feat))
+            _lib.check(rc, "casmvs_homo_warp_lds_f32")
+        elif impl == "lds_copy":
             nhwc = nchw_to_nhwc(src_feat)
             rc = lib.casmvs_homo_warp_nhwc_f32(_ptr(nhwc), _ptr(proj_mat), _ptr(depth_values), _ptr(out),
                                                B, C, H, W, D, _stream(src_feat))

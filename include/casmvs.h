@@ -125,6 +125,12 @@ int casmvs_costvol_gwc_lds_f32(const float *feats, const float *proj, const floa
                                int B, int V, int C, int G, int h, int w, int D, void *stream);
 int casmvs_homo_warp_nhwc_f32(const float *src, const float *proj, const float *depth, float *out,
                               int B, int C, int H, int W, int D, void *stream);
+/* The same LDS-staged sweep on the reference's own layout, src (B, C, H, W) (modules.py:52-92 takes exactly this): the source box is staged from the
+ * channel planes (whole quads of x, transposed in registers) - no pixel-major copy of the map exists.  Bit-identical to the two entries above.
+ * C in {8, 16, 32}, W % 4 == 0, 16-byte aligned tensors; casmvs_homo_warp_lds_supported says whether the shape has an LDS plan. */
+int casmvs_homo_warp_lds_supported(int C, int W, int D);
+int casmvs_homo_warp_lds_f32(const float *src, const float *proj, const float *depth, float *out, int B,
+                             int C, int H, int W, int D, void *stream);
 
 /* ---- view-sharded build (BASELINE configs 4/5) --------------------------------------
  * The sums of models/mvsnet.py:147-167 are linear in the source views: a rank warps the source views

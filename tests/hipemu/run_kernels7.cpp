@@ -72,6 +72,42 @@ static double costvol_check(int B, int V, int C, int D, int h, int w, float slid
   return err / range;
 }
 
+// homo_warp with the source box staged straight from the channel planes (casmvs_homo_warp_lds_f32, the reference's (B, C, H, W) layout) against the same
+// sweep on a pixel-major copy (casmvs_homo_warp_nhwc_f32): the same taps, the same LDS contents, the same arithmetic - equal bits
+static double warp_nchw_check(int B, int C, int D, int h, int w, float slide) {
+  const size_t hw = (size_t)h * w;
+  std::vector<float> nchw((size_t)B * C * hw), nhwc((size_t)B * hw * C), proj((size_t)B * 12, 0.0f), depth((size_t)B * D * hw);
+  for (auto &v : nchw) v = rnd();
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (size_t p = 0; p < hw; ++p) nhwc[((size_t)b * hw + p) * C + c] = nchw[((size_t)b * C + c) * hw + p];
+  for (int b = 0; b < B; ++b) {
+    float *P = proj.data() + (size_t)b * 12;
+    P[0] = 1.0f; P[5] = 1.0f; P[10] = 1.0f; P[1] = 0.002f; P[4] = -0.002f;
+    P[3] = slide / 1.376e-5f;
+    P[2] = -P[3] / 425.0f - 2.0f;
+    P[7] = 0.3f * 425.0f;
+    for (int d = 0; d < D; ++d)
+      for (size_t p = 0; p < hw; ++p) depth[((size_t)b * D + d) * hw + p] = 425.0f + 2.5f * d + 0.02f * (float)(p % 5);
+  }
+  auto dup = [](const std::vector<float> &v) {
+    float *p = (float *)std::aligned_alloc(256, (v.size() * 4 + 255) & ~(size_t)255);
+    std::memcpy(p, v.data(), v.size() * 4);
+    return p;
+  };
+  float *a = dup(nchw), *bp = dup(nhwc), *pa = dup(proj), *da = dup(depth);
+  std::vector<float> nanv((size_t)B * C * D * hw, NAN);
+  float *o1 = dup(nanv), *o2 = dup(nanv);
+  if (!casmvs_homo_warp_lds_supported(C, w, D)) { printf("warp_nchw: shape not supported\n"); return 1e9; }
+  if (casmvs_homo_warp_lds_f32(a, pa, da, o1, B, C, h, w, D, nullptr)) { printf("warp_nchw: %s\n", casmvs_last_error()); return 1e9; }
+  if (casmvs_homo_warp_nhwc_f32(bp, pa, da, o2, B, C, h, w, D, nullptr)) { printf("warp_nhwc: %s\n", casmvs_last_error()); return 1e9; }
+  size_t diff = 0, live = 0;
+  for (size_t i = 0; i < nanv.size(); ++i) { diff += std::memcmp(o1 + i, o2 + i, 4) != 0; live += o1[i] != 0.0f; }
+  std::free(a); std::free(bp); std::free(pa); std::free(da); std::free(o1); std::free(o2);
+  printf("warp_nchw B=%d C=%d %dx%dx%d: %zu of %zu values differ from the pixel-major sweep (%.0f %% non-zero)\n", B, C, D, h, w, diff, nanv.size(), 100.0 * live / nanv.size());
+  return diff ? 1.0 : 0.0;
+}
+
 int main(int argc, char **argv) {
   hipemu::g_lds = smem;
   const std::string which = argc > 1 ? argv[1] : "all";
@@ -80,6 +116,8 @@ int main(int argc, char **argv) {
   const bool all = which == "all", quick = which == "quick";
   if (all || quick) take(costvol_check(1, 3, 8, 8, 10, 64, 0.6f));     // C = 8: 64 x 4 tiles, two full tile rows + a ragged one
   if (all || quick) take(costvol_check(1, 3, 16, 8, 12, 36, 0.6f));    // C = 16: 32 x 8 tiles, ragged in x and y
+  if (all || quick || which == "warp") take(warp_nchw_check(1, 8, 8, 10, 64, 0.6f));    // C = 8 (unit(px) = 2 px + px / 8), ragged rows
+  if (all || which == "warp") { take(warp_nchw_check(2, 16, 8, 12, 36, 0.6f)); take(warp_nchw_check(1, 32, 8, 9, 32, 1.5f)); }
   if (all) {
     take(costvol_check(2, 3, 32, 16, 9, 32, 0.4f));                    // C = 32 as two channel splits, two plane chunks
     take(costvol_check(1, 2, 16, 8, 16, 64, 1.5f));                    // one source view, a fast epipolar slide (wide boxes)

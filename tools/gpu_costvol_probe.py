@@ -101,7 +101,7 @@ for l, (C, D) in {2: (32, 48), 1: (16, 32), 0: (8, 8)}.items():
         P1 = P[:, 0].contiguous()
         bw = 4 * B * (C * h * w + D * h * w + C * D * h * w)
         ow = {}
-        for impl in ("gather", "lds"):
+        for impl in ("gather", "lds", "lds_copy"):   # lds: box staged straight from the NCHW map; lds_copy: layout pass + pixel-major sweep (rounds 2-3)
             fn = lambda impl=impl: ops.homo_warp(src, P1, smooth, impl=impl)
             try:
                 ow[impl] = fn()
@@ -110,5 +110,5 @@ for l, (C, D) in {2: (32, 48), 1: (16, 32), 0: (8, 8)}.items():
                 continue
             ms = timed(fn)
             print(f"level {l} homo_warp (un-fused op) {impl:6s} {ms*1e3:8.1f} us  {bw/ms/1e6:8.1f} GB/s  frac {bw/ms/1e6/8000:.3f}", flush=True)
-        if len(ow) == 2:
-            print("   homo_warp lds == gather bitwise:", torch.equal(ow["gather"], ow["lds"]))
+        if len(ow) == 3:
+            print("   homo_warp lds == lds_copy == gather bitwise:", torch.equal(ow["gather"], ow["lds"]) and torch.equal(ow["gather"], ow["lds_copy"]))
