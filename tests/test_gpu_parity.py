@@ -73,7 +73,7 @@ def test_homo_warp_matches_oracle(dev, report, B, C, H, W, D, geometry):
     assert err < 1.5e-4  # measured 1.3e-5: bilinear is continuous, |d value| <= |grad| * coordinate noise (~1e-5 px)
     assert float(((got != 0) != (want != 0)).float().mean()) < 1e-3  # same in/out-of-bounds pattern
     from casmvsnet_pl_amd import _lib
-    if C in (8, 16, 32) and _lib.load().casmvs_costvol_lds_supported(C, W, D, 1, 1):  # the LDS-staged form: same bits
+    if C in (8, 16, 32) and _lib.load().casmvs_homo_warp_lds_supported(C, W, D):  # the LDS-staged forms: same bits
         assert torch.equal(_ops().homo_warp(src.to(dev), proj.to(dev), depth.to(dev), impl="lds").cpu(), got)        # box staged from the channel planes
         assert torch.equal(_ops().homo_warp(src.to(dev), proj.to(dev), depth.to(dev), impl="lds_copy").cpu(), got)   # pixel-major copy + the same sweep
 
