@@ -493,6 +493,9 @@ def train_mode(args, dev, world, rank, dist, barrier):
                 step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
+        from casmvsnet_pl_amd import streams
+        streams.reset(dev)   # the device is idle: whatever ran before on other streams (the inference legs of the default line) cannot overlap the capture
+
         def capture(zero_fill):
             graph = torch.cuda.CUDAGraph()
             if not zero_fill:

@@ -72,8 +72,11 @@ def note_launch(device, f16=False, stream=None):
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("casmvsnet_pl_amd: library kernels with f16 matrix instructions and kernels of another HIP stream may not overlap "
                                        "(casmvsnet_pl_amd/streams.py), and a hipGraph capture cannot wait for the other stream: capture mixed-type work on ONE "
-                                       "stream, or select the float32 modes (conv0_mode / ci_mode / tail_mode = 'f32') for concurrent captures")
-                s.wait_stream(other)
+                                       "stream, or select the float32 modes (conv0_mode / ci_mode / tail_mode = 'f32') for concurrent captures.  If the other "
+                                       "stream's work is known to be complete (after torch.cuda.synchronize()), call casmvsnet_pl_amd.streams.reset(device) "
+                                       "before the capture")
+                if not other.query():   # work still queued / running there: an event wait (no host synchronisation)
+                    s.wait_stream(other)
                 _seen[(dev, me, ptr)] = (launches, f16_launches)
     entry = table.get(me)
     if entry is None:

@@ -362,6 +362,9 @@ def test_stream_guard_serialises_f16_work_against_other_streams_only(monkeypatch
 
         def wait_stream(self, other):
             self.waited.append(other.cuda_stream)
+
+        def query(self):   # False: work still in flight on this stream
+            return False
     capturing = [False]
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing[0])
     streams.reset()

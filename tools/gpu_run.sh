@@ -77,7 +77,7 @@ stage_train () {
 stage_files () {
   FT_BATCH=8 FT_GRAPH=1 timeout 300 python tools/gpu_files_throughput.py 49 16 32 > $OUT/files_b8_graph.txt 2>&1
   FT_BATCH=8 FT_GRAPH=1 FT_THREADED=1 timeout 300 python tools/gpu_files_throughput.py 49 16 32 > $OUT/files_b8_graph_stager.txt 2>&1
-  tail -4 $OUT/files_b8_graph*.txt
+  for f in $OUT/files_b8_graph*.txt; do tail -n 5 $f; done
 }
 
 stage_pmc () {
