@@ -60,6 +60,14 @@ struct ZmCfgT {
   }
 };
 
+template <int N, class F>
+__device__ __forceinline__ void zm_static_for(F &&f) {
+  if constexpr (N > 0) {
+    zm_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 __device__ __forceinline__ f32x4 zm_mfma(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -256,12 +264,27 @@ __global__ __launch_bounds__(ZmCfgT<WIDE>::THREADS, 2) void conv0_zm_kernel(cons
 // ---- the same data flow with staging and multiplication overlapped INSIDE one workgroup (round 4) -------------------------------------------------
 // conv0_zm_kernel overlaps the two phases of a unit across the TWO workgroups a CU holds; at cin = 32 the lane images (72 KiB) leave room for one
 // workgroup only and the phases run back to back (0.74-1.04x the tiled kernel).  Here a workgroup is 8 waves: waves 4-7 (producers) load, scale, split
-// and write unit n + 1 into one of TWO plane-patch buffers while waves 0-3 (consumers) multiply unit n out of the other; two workgroup barriers per
-// unit (A: the producers' four wave maxima are published, placed one third into the consumers' matrix phase; B: buffer n + 1 is complete, buffer n is
-// free).  The producers keep the loads of TWO units in flight (two register sets).  Floating-point vector work is done by the producer waves and, outside
+// and write unit n + 1 into one of TWO plane-patch buffers while waves 0-3 (consumers) multiply unit n out of the other; ONE workgroup barrier per
+// unit (buffer n + 1 is complete, buffer n is free; the producers' wave maxima travel one iteration ahead through four LDS slots).  The producers keep the loads of CASMVS_ZW_NSET units in flight (one register set each).  Floating-point vector work is done by the producer waves and, outside
 // their matrix phases, by the consumers' folds / epilogues - never between a wave's own matrix instructions.  One workgroup per CU
 // (2 x 23 KiB + 18 KiB x cin / 8 of LDS), two waves per SIMD: a producer beside a consumer.
 // Units, scaling, summation order and therefore the RESULT BITS are those of conv0_zm_kernel with the same patch shape.
+#ifndef CASMVS_ZW_NSET
+#define CASMVS_ZW_NSET 2
+#endif
+#ifndef CASMVS_ZW_PRIO
+#define CASMVS_ZW_PRIO 0
+#endif
+#ifdef CASMVS_ZW_TRACE
+// Profiling builds (tools/native/zw_trace.cpp): wave 0 of each role of workgroup 0 stamps the shader clock at the phase boundaries of its first units.
+__device__ unsigned long long g_zw_trace[2][512];
+#define ZW_STAMP(role)                                                                          \
+  do {                                                                                          \
+    if (blockIdx.x == 0 && w4 == 0 && zw_tn < 512) g_zw_trace[role][zw_tn++] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define ZW_STAMP(role) do {} while (0)
+#endif
 template <int CIN, bool WIDE>
 __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk, float *__restrict__ out,
                                                          int B, int D, int H, int W, int tiles_x, int tiles_y, int nseg, int zlen, float slope) {
@@ -270,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4 *act = reinterpret_cast<u32x4 *>(smem_raw);                                                  // [2 buffers][2 slices][NV]
   u32x4 *wl = reinterpret_cast<u32x4 *>(smem_raw + 2 * Cfg::ACT_BYTES);                              // [chunk][9][2][64]
-  unsigned *wmax = reinterpret_cast<unsigned *>(smem_raw + 2 * Cfg::ACT_BYTES + Cfg::w_bytes(NCH));   // [2 buffers][4]
+  unsigned *wmax = reinterpret_cast<unsigned *>(smem_raw + 2 * Cfg::ACT_BYTES + Cfg::w_bytes(NCH));   // [4 slots][4 waves]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool producer = wave >= 4;          // wave-uniform
   const int w4 = wave & 3, t4 = tid & 255;  // wave / thread inside the role's group of four waves
@@ -301,8 +324,14 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
     nunits += (min(t.ze, D - 1) - max(t.zs - 1, 0) + 1) * NCH;
   }
 
+#ifdef CASMVS_ZW_TRACE
+  int zw_tn = 0;
+#endif
   if (producer) {
     // ---- producers: unit n -> buffer n & 1 in iteration n; the loads of units n + 1 and n + 2 are in flight meanwhile ----
+#if CASMVS_ZW_PRIO
+    __builtin_amdgcn_s_setprio(CASMVS_ZW_PRIO);   // the producer's vector instructions go first: the consumer beside it needs one issue slot per 16 cycles
+#endif
     const rsrc_t none = make_rsrc(in, 0);
     struct Cursor {   // the unit whose loads are issued next
       int item, zi, ch, zhi;
@@ -320,6 +349,7 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
     const int e = t4, iy = e / (IX / 4), g = e - iy * (IX / 4);
     const int vox = e < Cfg::ITEMS ? iy * ROW + 4 * g : -1;
     const int vxor = ((g >> 1) & 1) << 1;
+    const int scratch_unit = (int)((2 * Cfg::ACT_BYTES + Cfg::w_bytes(NCH) + 64) / 16) + 2 * t4;   // two 16-byte units per producer thread, never read
     auto plan = [&](const ZmItem &tc) {
       const int gy = tc.ty0 - 1 + iy, gx = tc.tx0 - 4 + 4 * g;
       const bool ok = e < Cfg::ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;   // W % 4 == 0
@@ -339,7 +369,8 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
         plan(pc.t);
       }
     };
-    f32x4v R[2][8];
+    constexpr int NSET = CASMVS_ZW_NSET;   // register sets = units whose loads are in flight
+    f32x4v R[NSET][8];
     auto issue = [&](auto set_) {   // the loads of the cursor's unit into register set S; then the cursor moves on
       constexpr int S = decltype(set_)::value;
       const rsrc_t src = pc.valid ? make_rsrc(in + (size_t)pc.t.b * in_ss, in_ss * 4) : none;
@@ -347,44 +378,54 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
       for (int c = 0; c < 8; ++c) R[S][c] = buf_load4(src, voff, ((pc.ch * 8 + c) * cs + pc.zi * HW) * 4);
       if (pc.valid) advance();
     };
-    issue(std::integral_constant<int, 0>{});
-    issue(std::integral_constant<int, 1>{});
+    zm_static_for<NSET>([&](auto k_) { issue(k_); });
+    // Every iteration issues exactly the same vector-memory operations on every path (beyond the last unit the loads go through the empty descriptor:
+    // zeros, no memory access - and the zeros are staged into a buffer nobody reads any more): the compiler's wait-count pass can then count
+    // instead of draining everything.  A conditional `issue` - or a branch around the LDS writes - made the number of loads behind a set
+    // path-dependent and the only safe wait vmcnt(0): the memory latency was exposed once per unit (shader-clock trace: 2 200-2 500 of a unit's
+    // 5 800 cycles in "issue", profiles/r04_conv0_zw_trace.txt).
+    // ONE workgroup barrier per unit: iteration n splits unit n with the maxima published one iteration earlier, then takes the maximum of unit
+    // n + 1 (its loads were issued NSET - 1 iterations ago) and publishes it (four slots: the consumers read unit n's maxima during iteration
+    // n + 1).  With a second barrier between "maximum" and "split" the consumers - who have to join every barrier - serialised their first matrix
+    // instructions with the producers' split (trace: 1 400 of a unit's 4 200 cycles waiting).
+    auto unit_max = [&](auto set_, int slot) {
+      constexpr int S = decltype(set_)::value;
+      float m = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(R[S][c][j]));
+      const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
+      if (lane == 0) wmax[(slot & 3) * 4 + w4] = wm;
+    };
+    unit_max(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();   // P: unit 0's maxima (the consumers join)
     auto stage = [&](auto set_, int n) {
       constexpr int S = decltype(set_)::value;
       const int par = n & 1;
-      if (n < nunits) {
-        float m = 0.0f;
+      ZW_STAMP(1);   // p0: top of the iteration
+      float mult, inv;
+      casmvs::tile_scale(wmax + (n & 3) * 4, mult, inv);
+      // threads without a staging item (76 of the 256) split the zeros their out-of-range loads returned into a per-thread scratch slot: no branch
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+      for (int j = 0; j < 4; ++j) {
+        float x[8];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(R[S][c][j]));
-        const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
-        if (lane == 0) wmax[par * 4 + w4] = wm;
+        for (int c = 0; c < 8; ++c) x[c] = R[S][c][j];
+        u32x4 o[2];
+        casmvs::split8_f16(x, mult, o);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) act[(vox >= 0 ? (par * 2 + sl) * NV + vox + (j ^ vxor) : scratch_unit + sl)] = o[sl];
       }
-      __syncthreads();   // A
-      if (n < nunits) {
-        float mult, inv;
-        casmvs::tile_scale(wmax + par * 4, mult, inv);
-        if (vox >= 0) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float x[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) x[c] = R[S][c][j];
-            u32x4 o[2];
-            casmvs::split8_f16(x, mult, o);
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl) act[(par * 2 + sl) * NV + vox + (j ^ vxor)] = o[sl];
-          }
-        }
-        issue(set_);   // unit n + 2 into the set that has just been emptied
-      }
+      ZW_STAMP(1);   // p1: split + LDS writes issued
+      unit_max(std::integral_constant<int, (S + 1) % NSET>{}, n + 1);
+      ZW_STAMP(1);   // p2: the next unit's loads have landed, its maximum is published
+      issue(set_);   // unit n + NSET into the set that has just been emptied
+      ZW_STAMP(1);   // p3: before the barrier
       __syncthreads();   // B
     };
-    for (int n = 0; n <= nunits; n += 2) {   // nunits + 1 iterations: the last one only keeps the consumers' barriers company
-      stage(std::integral_constant<int, 0>{}, n);
-      if (n + 1 <= nunits) stage(std::integral_constant<int, 1>{}, n + 1);
-    }
+    const int iters = (nunits + 1 + NSET - 1) / NSET * NSET;   // nunits + 1 iterations (the last keeps the consumers' final unit company), padded to whole rounds
+    for (int n = 0; n < iters; n += NSET) zm_static_for<NSET>([&](auto k_) { stage(k_, n + decltype(k_)::value); });
     return;
   }
 
@@ -403,8 +444,8 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
   for (int k = 0; k < 3; ++k)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();   // iteration 0: the producers stage unit 0 (A)
-  __syncthreads();   //                                          (B)
+  __syncthreads();   // P: the producers publish unit 0's maxima
+  __syncthreads();   // B of iteration 0: the producers stage unit 0
   int n = 0;
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
     const ZmItem cur = decode(item);
@@ -414,6 +455,7 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
       if (zi >= 0 && zi < D) {
 #pragma unroll 1
         for (int ch = 0; ch < NCH; ++ch, ++n) {
+          ZW_STAMP(0);   // c0: top of the unit
           const u32x4 *buf = act + (n & 1) * 2 * NV;
           u32x4 row[NT + 2][2];
 #pragma unroll
@@ -425,31 +467,38 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
           for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
             for (int t = 0; t < NT; ++t) part[kz][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          // the lane images of group g + 1 are read BEFORE the 12 matrix instructions of group g are issued (pinned): this wave is the only one that
+          // feeds its SIMD's matrix core, an LDS round trip in front of every group (what the compiler's own placement gave) left it idle 9 x per unit
+          u32x4 a[2][2];
 #pragma unroll
-          for (int kz = 0; kz < 3; ++kz) {
+          for (int s = 0; s < 2; ++s) a[0][s] = wl[((ch * 9) * 2 + s) * 64 + lane];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-              u32x4 a[2];
+          for (int g = 0; g < 9; ++g) {
+            const int kz = g / 3, ky = g % 3;
+            if (g + 1 < 9) {
 #pragma unroll
-              for (int s = 0; s < 2; ++s) a[s] = wl[((ch * 9 + kz * 3 + ky) * 2 + s) * 64 + lane];
-              constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
-#pragma unroll
-              for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) part[kz][t] = zm_mfma(a[PA[p]], row[t + ky][PB[p]], part[kz][t]);
+              for (int s = 0; s < 2; ++s) a[(g + 1) & 1][s] = wl[((ch * 9 + g + 1) * 2 + s) * 64 + lane];
             }
-            if (kz == 0) __syncthreads();   // A of iteration n + 1, a third into the matrix phase
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) part[kz][t] = zm_mfma(a[g & 1][PA[p]], row[t + ky][PB[p]], part[kz][t]);
+            __builtin_amdgcn_sched_barrier(0);
           }
+          ZW_STAMP(0);   // c1: all matrix instructions issued
           __builtin_amdgcn_sched_barrier(0);   // the folds are floating-point vector work: after the unit's last matrix instruction
           float mult, inv;
-          casmvs::tile_scale(wmax + (n & 1) * 4, mult, inv);
+          casmvs::tile_scale(wmax + (n & 3) * 4, mult, inv);
 #pragma unroll
           for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
               for (int q = 0; q < 4; ++q) acc[2 - kz][t][q] = fmaf(part[kz][t][q], inv, acc[2 - kz][t][q]);
-          __syncthreads();   // B of iteration n + 1: buffer n & 1 and its maxima are free
+          ZW_STAMP(0);   // c2: folds done (the matrix results have arrived)
+          __syncthreads();   // B of iteration n + 1: buffer n & 1 is free
         }
       }
       const int zo = zi - 1;
@@ -475,13 +524,19 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // the producers run whole rounds of CASMVS_ZW_NSET iterations: keep their padding iterations' barriers company
+  for (int k = (nunits + 1) % CASMVS_ZW_NSET; k != 0 && k < CASMVS_ZW_NSET; ++k) __syncthreads();
 }
 
-// Measured (tools/native/conv0_zm_check.cpp, batch 8, dirtied caches, profiles/r04_conv0_zw_ab.txt): cin 32: tiled 751-771 us, two-phase z-march 704,
-// warp-specialised 651; cin 16: two-phase 794, warp-specialised 819; cin 8: 416 / 480 - where two workgroups fit a CU they overlap the phases better
-// than one workgroup's two wave groups do.  The warp-specialised form is the cin = 32 kernel.
+// Measured (tools/native/conv0_zm_check.cpp, batch 8, dirtied caches): the first version - two barriers per unit, conditional loads - 651 us at cin 32
+// against 704 (two-phase z-march) and 751-771 (tiled), and slower than the two-phase kernel at cin 16 / 8 (profiles/r04_conv0_zw_ab.txt).  A shader-clock
+// trace (tools/native/zw_trace.cpp, profiles/r04_conv0_zw_trace.txt) showed why: s_waitcnt vmcnt(0) in front of every unit's loads (conditional vector-memory
+// operations) and the consumers' matrix phase serialised with the producers' split by the second barrier.  With unconditional iterations and ONE barrier
+// per unit: cin 32 523-530 us (1.44x the tiled kernel), cin 16 685 (two-phase 784, tiled 1109-1120), cin 8 381 (397, 502-522); whole step 7.72 -> 7.57 ms
+// (profiles/r04_conv0_zw_single_barrier_ab.txt).  It is the conv0 kernel of every cascade level; conv0_zm_kernel stays in the source for A/B builds
+// (-DCASMVS_ZM_WS=0) and is not instantiated by default.
 #ifndef CASMVS_ZM_WS
-#define CASMVS_ZM_WS 4   // which channel counts run the warp-specialised form: bit 0 cin 8, bit 1 cin 16, bit 2 cin 32 (A/B builds)
+#define CASMVS_ZM_WS 7   // which channel counts run the warp-specialised form: bit 0 cin 8, bit 1 cin 16, bit 2 cin 32 (A/B builds: other values)
 #endif
 #ifndef CASMVS_ZM_WS32_WIDE
 #define CASMVS_ZM_WS32_WIDE 0   // A/B builds: 8 x 64 patches for the warp-specialised cin = 32 kernel
@@ -493,7 +548,7 @@ int launch_zw(const void *packed, const float *in, float *out, int B, int D, int
   constexpr int NCH = CIN / 8;
   const int tiles_x = casmvs::ceil_div(W, Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY);
   auto kernel = conv0_zw_kernel<CIN, WIDE>;
-  const size_t lds = 2 * Cfg::ACT_BYTES + Cfg::w_bytes(NCH) + 32;
+  const size_t lds = 2 * Cfg::ACT_BYTES + Cfg::w_bytes(NCH) + 64 + 256 * 2 * 16;   // + the producers' scratch units
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "conv0_zw_kernel")) return rc;
   const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), 512, lds);
   const long patches = (long)B * tiles_x * tiles_y;
@@ -554,3 +609,10 @@ extern "C" int casmvs_conv0_zmarch_forward_f32(const void *packed, const float *
   if constexpr ((CASMVS_ZM_WS & 4) != 0) return launch_zw<32, CASMVS_ZM_WS32_WIDE != 0>(packed, in, out, B, D, H, W, slope, st);
   else return launch_zm<32, false>(packed, in, out, B, D, H, W, slope, st);   // 95 KiB of LDS: ONE workgroup per CU (measured: 0.74-0.9x the tiled kernel; the engine keeps cin = 32 tiled)
 }
+
+#ifdef CASMVS_ZW_TRACE
+extern "C" int casmvs_zw_trace_read(unsigned long long *host) {
+  if (hipDeviceSynchronize() != hipSuccess) return -3;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_zw_trace), sizeof(unsigned long long) * 2 * 512) == hipSuccess ? 0 : -3;
+}
+#endif

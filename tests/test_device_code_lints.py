@@ -63,4 +63,4 @@ def test_split_f16_kernels_do_not_spill_and_fit_two_waves_per_simd():
             assert scratch == 0, (f, name, scratch)
             one_per_cu = name.startswith(("conv_ci_sf_kernel<32, 32", "conv_ci_sf_kernel<64, 64"))   # their lane images leave room for one workgroup
             assert vgpr <= (512 if one_per_cu else 256), (f, name, vgpr)
-    assert seen >= 24
+    assert seen >= 22

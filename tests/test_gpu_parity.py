@@ -563,13 +563,13 @@ def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
     g = torch.Generator().manual_seed(0)
     cases = []
     rnd = lambda *shape, amp=1.0: (torch.randn(*shape, generator=g) * amp)
-    # conv0: the tiled kernel at cin 8 / 16 / 32, the z-marching kernels the regulariser runs (cin 8 / 16 two-phase, cin 32 warp-specialised), bf16 form (opt-in mode)
+    # conv0: the tiled kernel at cin 8 / 16 / 32, the warp-specialised z-marching kernel the regulariser runs, bf16 form (opt-in mode)
     for cin, (B, D, H, W) in ((8, (2, 8, 512, 640)), (16, (2, 32, 128, 160)), (32, (2, 48, 128, 160))):
         x0 = rnd(B, cin, D, H, W).to(dev)
         w0 = rnd(8, cin, 3, 3, 3, amp=0.1)
         p0 = ops.conv0_splitf16_pack(w0).to(dev)
         cases.append((f"conv0_sf<{cin}>", lambda p0=p0, x0=x0: ops.conv0_splitf16_forward(p0, x0)))
-        cases.append((f"conv0_z{'w' if cin == 32 else 'm'}<{cin}>", lambda p0=p0, x0=x0: ops.conv0_zmarch_forward(p0, x0)))   # cin 32: warp-specialised
+        cases.append((f"conv0_zw<{cin}>", lambda p0=p0, x0=x0: ops.conv0_zmarch_forward(p0, x0)))   # the warp-specialised z-march kernel: what the regulariser runs
         if cin == 16:
             pb = ops.conv0_splitbf16_pack(w0).to(dev)
             cases.append(("conv0_sb<16>", lambda pb=pb, x0=x0: ops.conv0_splitbf16_forward(pb, x0)))
