@@ -390,12 +390,15 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
     // instructions with the producers' split (trace: 1 400 of a unit's 4 200 cycles waiting).
     auto unit_max = [&](auto set_, int slot) {
       constexpr int S = decltype(set_)::value;
-      float m = 0.0f;
+      float m0 = 0.0f, m1 = 0.0f;   // two chains: the maximum of 32 values is one dependent chain otherwise
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
+      for (int c = 0; c < 8; c += 2)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(R[S][c][j]));
-      const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
+        for (int j = 0; j < 4; ++j) {
+          m0 = fmaxf(m0, fabsf(R[S][c][j]));
+          m1 = fmaxf(m1, fabsf(R[S][c + 1][j]));
+        }
+      const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, fmaxf(m0, m1)));
       if (lane == 0) wmax[(slot & 3) * 4 + w4] = wm;
     };
     unit_max(std::integral_constant<int, 0>{}, 0);
@@ -535,6 +538,10 @@ __global__ __launch_bounds__(512, 1) void conv0_zw_kernel(const float *__restric
 // per unit: cin 32 523-530 us (1.44x the tiled kernel), cin 16 685 (two-phase 784, tiled 1109-1120), cin 8 381 (397, 502-522); whole step 7.72 -> 7.57 ms
 // (profiles/r04_conv0_zw_single_barrier_ab.txt).  It is the conv0 kernel of every cascade level; conv0_zm_kernel stays in the source for A/B builds
 // (-DCASMVS_ZM_WS=0) and is not instantiated by default.
+// Tried on top and rejected (profiles/r04_conv0_zw_producer_ab.txt): the sample's buffer descriptor and a running byte offset kept in the producers'
+// cursor instead of being recomputed per unit (the descriptor then lives in vector registers: a waterfall loop around every load, 573 / 765 us at
+// cin 32 / 16); the two scale multiplies of a pair as one v_pk_mul_f32 (653 / 800 us); raised producer priority (s_setprio 3: +-1 %); three or four
+// register sets in flight instead of two (517-523 us at cin 32: the loads are already hidden).
 #ifndef CASMVS_ZM_WS
 #define CASMVS_ZM_WS 7   // which channel counts run the warp-specialised form: bit 0 cin 8, bit 1 cin 16, bit 2 cin 32 (A/B builds: other values)
 #endif
