@@ -363,7 +363,7 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
     ach = conv0_flops / (conv0_ms * 1e-3) / 1e12
     mode = getattr(model.cost_reg_0, "_conv0_active", None) or "f32"
     split = mode if mode in ("splitbf16", "splitf16") and getattr(model, "fuse_regress", False) and G in (1, 8) else None
-    knames = {"splitbf16": ("conv0_sb_kernel",), "splitf16": ("conv0_sf_kernel", "conv0_zm_kernel"), None: ("conv16db_kernel<2, 4, 4, 4, 4, 32",)}[split]
+    knames = {"splitbf16": ("conv0_sb_kernel",), "splitf16": ("conv0_sf_kernel", "conv0_zm_kernel", "conv0_zw_kernel"), None: ("conv16db_kernel<2, 4, 4, 4, 4, 32",)}[split]
     traffic, traffic_note, src = pmc_traffic(knames, B if cfg_name == HEADLINE else None)
     conv0_alg = sum(4 * B * ((G if G > 1 else 8 * 2 ** l) + 8) * n_depths[l] * (H >> l) * (W >> l) for l in range(3))   # bytes per step: input + output volumes
     gbs = conv0_alg * n_ev / (conv0_ms * 1e-3) / 1e9
@@ -371,8 +371,8 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
     out["roofline"] = {"kernel": {"splitbf16": "conv0_sb_kernel<CIN, 6> (CostRegNet.conv0 on the bf16 matrix cores, float32 operands as three exact "
                                                "bf16 slices; 3 launches per step)",
                                   "splitf16": "CostRegNet.conv0 on the f16 matrix cores (float32 operands as two float16 slices behind exact power-of-two "
-                                              "scalings), 3 launches per step: conv0_zm_kernel<8> (level 0) and conv0_zm_kernel<16> (level 1): "
-                                              "input-stationary along z on 8 x 64 patches; conv0_sf_kernel<32, 3> (level 2): 4 x 4 x 32 tiles",
+                                              "scalings), 3 launches per step: conv0_zw_kernel<8, wide> (level 0), <16, wide> (level 1), <32> (level 2): "
+                                              "input-stationary along z on 8 x 64 / 16 x 32 patches, producer and consumer wave groups in one workgroup",
                                   None: "conv16db_kernel<PX> (CostRegNet.conv0 on the float32 MFMA: Cout 8, stride 1; 3 launches per step)"}[split],
                        "bound": "hbm" if split else "mfma", "batch": B, "avg_launch_ms": conv0_ms / (3 * n_ev)}
     hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

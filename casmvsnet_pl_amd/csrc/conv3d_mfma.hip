@@ -2285,7 +2285,7 @@ namespace {
 // conv0 .. conv11 (+ skips) into the workspace, then the `prob` head: on its own (depth == nullptr), or fused with the
 // softmax / regression / confidence that consumes it (casmvs_prob_regress_f32).
 // split_layers (casmvs_costreg_regress_f32): the images of the layers that have a form on the f16 matrix cores - conv0, conv2, conv4, conv6 (stride 1),
-// conv9, conv11 (transposed) - each or nullptr (the float32 MFMA kernel).  With conv0's split-f16 image every cin runs a z-marching kernel
+// conv9, conv11 (transposed), conv1, conv3 (stride 2) - each or nullptr (the float32 MFMA kernel).  With conv0's split-f16 image every cin runs a z-marching kernel
 // (conv0_zmarch.hip): cin = 8 / 16 on 8 x 64 patches with two workgroups per CU (1.26x / 1.5x the tiled kernel at batch 8 on the MI355X,
 // profiles/r04_conv0_zm_wide_ab.txt), cin = 32 the warp-specialised form (1.15x, profiles/r04_conv0_zw_ab.txt).
 int costreg_run(const char *who, const float *const *packed_layers, const void *const *split_layers, int conv0_arith, const float *vol, const float *depth_values,
@@ -2322,6 +2322,7 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
   const void *conv2_split = split_layers ? split_layers[1] : nullptr, *conv4_split = split_layers ? split_layers[2] : nullptr;
   const void *conv6_split = split_layers ? split_layers[3] : nullptr;
   const void *conv9_split = split_layers ? split_layers[4] : nullptr, *conv11_split = split_layers ? split_layers[5] : nullptr;
+  const void *conv1_split = split_layers ? split_layers[6] : nullptr, *conv3_split = split_layers ? split_layers[7] : nullptr;
   CASMVS_REQUIRE(conv0_arith == CASMVS_CONV0_F32 || conv0_split, "%s: conv0_arith=%d needs the split image of conv0", who, conv0_arith);
   const bool split_ok = (reinterpret_cast<size_t>(vol) & 15) == 0;
   if (conv0_arith == CASMVS_CONV0_SPLIT_BF16 && split_ok && casmvs_conv0_splitbf16_supported(cin, w)) {
@@ -2344,7 +2345,14 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
   } else {
     CASMVS_L(CASMVS_CONV_S1, P[0], vol, nullptr, c0, B, cin, 8, D, h, w, sl, stream);               // conv0
   }
-  CASMVS_L(CASMVS_CONV_S2, P[1], c0, nullptr, c1, B, 8, 16, D, h, w, sl, stream);                   // conv1
+  if (conv1_split && casmvs_conv_s2_splitf16_supported(8, 16, w) && (reinterpret_cast<size_t>(conv1_split) & 15) == 0) {   // conv1 on the f16 matrix cores
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv_s2_splitf16_forward_f32(conv1_split, c0, c1, B, 8, 16, D, h, w, sl, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV_S2, P[1], c0, nullptr, c1, B, 8, 16, D, h, w, sl, stream);                 // conv1
+  }
   if (conv2_split && casmvs_conv_ci_splitf16_supported(16, 16, w / 2)) {                            // conv2 on the f16 matrix cores
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
@@ -2353,7 +2361,14 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
   } else {
     CASMVS_L(CASMVS_CONV_S1, P[2], c1, nullptr, c2, B, 16, 16, D / 2, h / 2, w / 2, sl, stream);    // conv2
   }
-  CASMVS_L(CASMVS_CONV_S2, P[3], c2, nullptr, c3, B, 16, 32, D / 2, h / 2, w / 2, sl, stream);      // conv3
+  if (conv3_split && casmvs_conv_s2_splitf16_supported(16, 32, w / 2) && (reinterpret_cast<size_t>(conv3_split) & 15) == 0) {   // conv3 on the f16 matrix cores
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = casmvs_conv_s2_splitf16_forward_f32(conv3_split, c2, c3, B, 16, 32, D / 2, h / 2, w / 2, sl, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV_S2, P[3], c2, nullptr, c3, B, 16, 32, D / 2, h / 2, w / 2, sl, stream);    // conv3
+  }
   // conv4 on the f16 matrix cores where there are enough of its 256-voxel tiles (4 x 4 x 16, or 2 x 8 x 16 for a 2-plane volume) to
   // fill the chip (measured: 60 tiles are faster on the float32 kernel's deep variant, 120 and more on the f16 one)
   const int tz4 = D / 4 <= 2 ? 2 : 4;

@@ -260,6 +260,9 @@ class CostRegNet(_PackedWeights, nn.Module):
         # conv2 / conv4 / conv6 (conv_ci_splitf16.hip) and the transposed conv9 / conv11 (deconv9_splitf16.hip, deconv11_splitf16.hip) in `regress`:
         # "splitf16" (f16 matrix cores) or "f32"
         self.ci_mode = "splitf16"
+        self._s2_sf = None        # (conv1, conv3) split-f16 images
+        # the stride-2 conv1 / conv3 (conv_s2_splitf16.hip) in `regress`: None (= ci_mode), "splitf16" or "f32"
+        self.s2_mode = None
         # conv0's arithmetic in `regress` (the engine's eval path), all float32-grade (distance to a float64 convolution at or
         # below the float32 MFMA kernel's):
         #   "splitf16":  f16 matrix cores, every float32 operand as two float16 slices behind exact power-of-two scalings (per
@@ -273,6 +276,7 @@ class CostRegNet(_PackedWeights, nn.Module):
         self.timer_name = "costreg"
         self._conv0_active = None   # set by packed_layers: which split image of conv0 is packed and current ("splitf16" / "splitbf16" / None)
         self._ci_active = False     # ... and whether the five images of _ci_sf are
+        self._s2_active = False     # ... and the two of _s2_sf
 
     # -- weight folding / packing -------------------------------------------------------------
     def _layer_tensors(self, name):
@@ -289,7 +293,9 @@ class CostRegNet(_PackedWeights, nn.Module):
             raise ValueError(f"CostRegNet.conv0_mode={self.conv0_mode!r} (splitf16, splitbf16 or f32)")
         if self.ci_mode not in ("splitf16", "f32"):
             raise ValueError(f"CostRegNet.ci_mode={self.ci_mode!r} (splitf16 or f32)")
-        key = self._state_key(device) + (self.conv0_mode, self.ci_mode)
+        if self.s2_mode not in (None, "splitf16", "f32"):
+            raise ValueError(f"CostRegNet.s2_mode={self.s2_mode!r} (None = ci_mode, splitf16 or f32)")
+        key = self._state_key(device) + (self.conv0_mode, self.ci_mode, self.s2_mode)
         if self._packed is not None and key == self._packed_key:
             return self._packed
         packed, slopes = [], set()
@@ -328,6 +334,15 @@ class CostRegNet(_PackedWeights, nn.Module):
             ci.append(ops.deconv11_splitf16_pack(self.conv11[0].weight, s11, b11).to(device))
             return ci
         self._ci_active = self._split_image("_ci_sf", pack_ci, self.ci_mode == "splitf16") is not None
+
+        def pack_s2():
+            s2 = []
+            for name in ("conv1", "conv3"):
+                m = getattr(self, name)
+                sc, sh, _ = _fold_norm(f"CostRegNet.{name}", m.bn)
+                s2.append(ops.conv_s2_splitf16_pack(m.conv.weight, sc, sh).to(device))
+            return s2
+        self._s2_active = self._split_image("_s2_sf", pack_s2, (self.s2_mode or self.ci_mode) == "splitf16") is not None
         self._packed_key = key
         return self._store_packed("_packed", packed)
 
@@ -362,8 +377,10 @@ class CostRegNet(_PackedWeights, nn.Module):
         elif self._conv0_active == "splitbf16":
             split, arith = self._conv0_sb, ops.CONV0_SPLIT_BF16
         c2, c4, c6, c9, c11 = self._ci_sf if self._ci_active else (None,) * 5
+        c1, c3 = self._s2_sf if self._s2_active else (None, None)
         return ops.costreg_regress(packed, x, depth_values, ws, slope=self._slope, layer_events=events, return_index=return_index,
-                                   conv0_split=split, conv0_arith=arith, conv2_split=c2, conv4_split=c4, conv6_split=c6, conv9_split=c9, conv11_split=c11)
+                                   conv0_split=split, conv0_arith=arith, conv2_split=c2, conv4_split=c4, conv6_split=c6, conv9_split=c9, conv11_split=c11,
+                                   conv1_split=c1, conv3_split=c3)
 
 
 class CascadeMVSNet(nn.Module):

@@ -462,6 +462,38 @@ def conv_ci_splitf16_forward(packed, x, cout, slope=0.01):
     return out
 
 
+def conv_s2_splitf16_pack(weight, scale=None, shift=None):
+    """Host-side packing of a stride-2 CostRegNet layer (conv1 8 -> 16, conv3 16 -> 32) for the split-f16 z-marching kernel
+    (casmvs_conv_s2_splitf16_pack): weight (cout, cin, 3,3,3) -> uint8 CPU tensor."""
+    weight = weight.detach().to("cpu", torch.float32).contiguous()
+    cout, cin = weight.shape[:2]
+    lib = _lib.load()
+    n = lib.casmvs_conv_s2_splitf16_packed_bytes(cin, cout)
+    if tuple(weight.shape[2:]) != (3, 3, 3) or n == 0:
+        raise ValueError(f"conv_s2_splitf16_pack: weight {tuple(weight.shape)} (need (16, 8, 3, 3, 3) or (32, 16, 3, 3, 3))")
+    packed = torch.empty(n, dtype=torch.uint8)
+    sc = None if scale is None else scale.detach().to("cpu", torch.float32).contiguous()
+    sh = None if shift is None else shift.detach().to("cpu", torch.float32).contiguous()
+    rc = lib.casmvs_conv_s2_splitf16_pack(cin, cout, _ptr(weight), _ptr(sc), _ptr(sh), ctypes.c_void_p(packed.data_ptr()))
+    _lib.check(rc, "casmvs_conv_s2_splitf16_pack")
+    return packed
+
+
+def conv_s2_splitf16_forward(packed, x, cout, slope=0.01):
+    """conv1 / conv3 (Conv3d k3 s2 p1 + ABN) on the f16 matrix cores with float32-grade arithmetic (casmvs_conv_s2_splitf16_forward_f32):
+    x (B,cin,D,H,W), W % 4 == 0 -> (B,cout,ceil(D/2),ceil(H/2),ceil(W/2))."""
+    x = _dev(x, "x")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("conv_s2_splitf16_forward: `packed` must be the uint8 image on the MI355X")
+    B, cin, D, H, W = x.shape
+    out = torch.empty((B, cout, (D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_conv_s2_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), B, cin, cout, D, H, W,
+                                                             float(slope), _stream(x, f16=True))
+    _lib.check(rc, "casmvs_conv_s2_splitf16_forward_f32")
+    return out
+
+
 def costreg_workspace_bytes(B, D, h, w):
     n = _lib.load().casmvs_costreg_workspace_bytes(B, D, h, w)
     if n == 0:
@@ -498,14 +530,16 @@ CONV0_F32, CONV0_SPLIT_BF16, CONV0_SPLIT_F16 = 0, 1, 2   # casmvs.h: CASMVS_CONV
 
 
 def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, layer_events=None, return_index=False, conv0_split=None,
-                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None, conv6_split=None, conv9_split=None, conv11_split=None):
+                    conv0_arith=CONV0_F32, conv2_split=None, conv4_split=None, conv6_split=None, conv9_split=None, conv11_split=None, conv1_split=None,
+                    conv3_split=None):
     """CostRegNet + softmax / depth regression / confidence in one library call (mvsnet.py:91-104 + :174-193): the `prob`
     head walks the depth axis and, when the whole depth range is one chunk, runs the regression on the cost values it has
     just produced (casmvs_costreg_regress_f32).  -> cost (B,D,h,w), depth (B,h,w), confidence (B,h,w) [, index int32].
     conv0_arith: CONV0_F32 (conv0 on the float32 MFMA kernel), CONV0_SPLIT_BF16 / CONV0_SPLIT_F16 with conv0_split = the device
     image of conv0_splitbf16_pack / conv0_splitf16_pack (conv0 on the bf16 / f16 matrix cores with float32-grade arithmetic).
     conv2_split / conv4_split / conv6_split: device images of conv_ci_splitf16_pack (those layers on the f16 matrix cores) or None;
-    conv9_split / conv11_split: device images of deconv9_splitf16_pack / deconv11_splitf16_pack (the transposed layers there) or None."""
+    conv9_split / conv11_split: device images of deconv9_splitf16_pack / deconv11_splitf16_pack (the transposed layers there) or None;
+    conv1_split / conv3_split: device images of conv_s2_splitf16_pack (the stride-2 layers there) or None."""
     vol, depth_values = _dev(vol, "vol"), _dev(depth_values, "depth_values")
     B, cin, D, h, w = vol.shape
     if tuple(depth_values.shape) != (B, D, h, w):
@@ -526,9 +560,9 @@ def costreg_regress(packed_layers, vol, depth_values, workspace, slope=0.01, lay
             raise ValueError("costreg_regress: need 12 events")
         ev = (ctypes.c_void_p * 12)(*[e.cuda_event for e in layer_events])
     split = None
-    images = (conv0_split, conv2_split, conv4_split, conv6_split, conv9_split, conv11_split)
+    images = (conv0_split, conv2_split, conv4_split, conv6_split, conv9_split, conv11_split, conv1_split, conv3_split)
     if any(t is not None for t in images):
-        split = (ctypes.c_void_p * 6)(*[None if t is None else t.data_ptr() for t in images])
+        split = (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in images])
     with torch.cuda.device(dev):
         rc = _lib.load().casmvs_costreg_regress_f32(arr, split, int(conv0_arith), _ptr(vol), _ptr(depth_values), _ptr(cost), _ptr(depth), _ptr(conf),
                                                     _ptr(index), ctypes.c_void_p(workspace.data_ptr()), B, cin, D, h, w,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CASMVS_ABI_VERSION 2
+#define CASMVS_ABI_VERSION 3
 
 #define CASMVS_OK 0
 #define CASMVS_ERR_INVALID_ARG (-1) /* null pointer / non-positive size / unsupported combination */
@@ -256,6 +256,17 @@ int casmvs_conv_ci_splitf16_supported(int cin, int cout, int W);
 int casmvs_conv_ci_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int cout, int D, int H, int W,
                                         float slope, void *stream);
 
+/* CostRegNet's stride-2 layers conv1 (8 -> 16) and conv3 (16 -> 32) (Conv3d k3 s2 p1 + folded ABN + leaky-relu, mvsnet.py:64-65,67-68) in the same
+ * arithmetic, input-stationary along z (csrc/conv_s2_splitf16.hip): an output patch of 6 x 32 marches over the input planes, every plane patch staged
+ * once.  in (B, cin, D, H, W) -> out (B, cout, (D - 1) / 2 + 1, (H - 1) / 2 + 1, (W - 1) / 2 + 1); (cin, cout) in {(8, 16), (16, 32)}, W % 4 == 0, `in` and
+ * the image 16-byte aligned.  `packed`: HOST image from casmvs_conv_s2_splitf16_pack (weight (cout, cin, 3, 3, 3) finite, scale / shift (cout) or NULL),
+ * copied to the device by the caller.  casmvs_costreg_regress_f32 takes the images as split_layers[6] (conv1) and [7] (conv3). */
+size_t casmvs_conv_s2_splitf16_packed_bytes(int cin, int cout);
+int casmvs_conv_s2_splitf16_pack(int cin, int cout, const float *weight, const float *scale, const float *shift, void *packed);
+int casmvs_conv_s2_splitf16_supported(int cin, int cout, int W);
+int casmvs_conv_s2_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int cin, int cout, int D, int H, int W,
+                                        float slope, void *stream);
+
 /* Whole CostRegNet (mvsnet.py:91-104).  `packed_layers[11]` are the device images of
  * conv0..conv6, conv7, conv9, conv11, prob (in that order).  `workspace` holds the intermediate
  * activations; its size comes from casmvs_costreg_workspace_bytes.
@@ -387,10 +398,11 @@ int casmvs_debug_disturb(int kind, int blocks, int iters, int lds_bytes, float *
  * event 11 after the head INCLUDING the regression).  conv0_arith selects conv0's arithmetic: CASMVS_CONV0_F32 (the float32
  * MFMA kernel on packed_layers[0]), CASMVS_CONV0_SPLIT_BF16 / CASMVS_CONV0_SPLIT_F16 with split_layers[0] = the DEVICE copy of
  * casmvs_conv0_splitbf16_pack's / casmvs_conv0_splitf16_pack's image of conv0 (cin 8 / 16 / 32; any other shape falls back to the
- * float32 kernel; with the split-f16 image cin = 16 runs casmvs_conv0_zmarch_forward_f32).  split_layers: NULL, or SIX pointers { conv0, conv2, conv4,
- * conv6, conv9, conv11 images, each or NULL } (ABI version 2; version 1 read four); a non-NULL conv2 / conv4 / conv6 entry (DEVICE copy of
+ * float32 kernel; with the split-f16 image cin = 16 runs casmvs_conv0_zmarch_forward_f32).  split_layers: NULL, or EIGHT pointers { conv0, conv2, conv4,
+ * conv6, conv9, conv11, conv1, conv3 images, each or NULL } (ABI version 3; version 2 read six, version 1 four); a non-NULL conv2 / conv4 / conv6 entry (DEVICE copy of
  * casmvs_conv_ci_splitf16_pack's image) runs that layer on the f16 matrix cores too (conv4 / conv6 only where the volume gives >= 100 tiles; conv6
- * only with >= 3 planes), a non-NULL conv9 / conv11 entry (casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack) the transposed layers. */
+ * only with >= 3 planes), a non-NULL conv9 / conv11 entry (casmvs_deconv9_splitf16_pack / casmvs_deconv11_splitf16_pack) the transposed layers, a non-NULL conv1 / conv3
+ * entry (casmvs_conv_s2_splitf16_pack) the stride-2 layers. */
 #define CASMVS_CONV0_F32 0
 #define CASMVS_CONV0_SPLIT_BF16 1
 #define CASMVS_CONV0_SPLIT_F16 2

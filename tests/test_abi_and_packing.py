@@ -2,6 +2,7 @@
 include/casmvs.h declares, reports the right ABI version, and its HOST-side functions (packed
 sizes, weight packing, workspace size, argument validation) behave.  No GPU compute is called."""
 import ctypes
+import numpy as np
 import os
 import re
 
@@ -37,7 +38,7 @@ def test_header_symbols_are_all_exported_and_bound():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.casmvs_abi_version() == 2   # 2: casmvs_costreg_regress_f32 reads six split_layers pointers (conv9 / conv11 images added)
+    assert lib.casmvs_abi_version() == 3   # 3: casmvs_costreg_regress_f32 reads eight split_layers pointers (2: six, conv9 / conv11; 3: conv1 / conv3 added)
     rc = lib.casmvs_homo_warp_f32(None, None, None, None, 1, 1, 8, 8, 1, None)
     assert rc == -1 and b"null pointer" in lib.casmvs_last_error()
     rc = lib.casmvs_costvol_gwc_f32(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8),
@@ -473,3 +474,32 @@ def test_deconv9_splitf16_lane_level_transcription():
         ref = (torch.where(ref > 0, ref, ref * 0.01) + skip.double()).numpy()
         got = emulate_deconv9_lanes(packed, x.numpy(), skip.numpy())
         assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-6, (B, Di, Hi, Wi)
+
+
+def test_conv_s2_splitf16_packing():
+    """csrc/conv_s2_splitf16.hip's C packer: lane images [chunk of 8 input channels][kz][ky][block of 16 output channels][slice][lane][8 f16] with
+    lane = (output channel & 15, kx) - the two float16 slices of 2^kw w add up to the weight to 2^-22 of the tensor's maximum, the kx = 3 block is zero,
+    scale carries 2^-kw; non-finite weights and other channel counts are rejected."""
+    from casmvsnet_pl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for cin, cout in ((8, 16), (16, 32)):
+        w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.3
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        packed = ops.conv_s2_splitf16_pack(w, scale, shift).numpy()
+        nimg = (cin // 8) * 9 * (cout // 16)
+        assert packed.size == nimg * 2 * 64 * 16 + 2 * cout * 4
+        img = packed[:nimg * 2048].view(np.float16).astype(np.float64).reshape(cin // 8, 3, 3, cout // 16, 2, 64, 8)
+        tail = packed[nimg * 2048:].view(np.float32)
+        kw = int(round(np.log2(float(scale[0]) / tail[0])))
+        assert np.array_equal(tail[:cout], np.ldexp(scale.numpy(), -kw)) and np.array_equal(tail[cout:], shift.numpy())
+        assert 2.0 ** 13 <= float(w.abs().max()) * 2.0 ** kw < 2.0 ** 14
+        assert not img[..., 48:, :].any()                                   # kx = 3: zero weights
+        got = (img[:, :, :, :, 0] + img[:, :, :, :, 1]).reshape(cin // 8, 3, 3, cout // 16, 4, 16, 8)   # [chunk][kz][ky][rb][kx][co & 15][e]
+        want = np.ldexp(w.double().numpy(), kw).reshape(cout // 16, 16, cin // 8, 8, 3, 3, 3).transpose(2, 4, 5, 0, 6, 1, 3)   # -> [chunk][kz][ky][rb][kx][i][e]
+        assert np.abs(got[:, :, :, :, :3] - want).max() <= 2.0 ** -8          # |w'| < 2^14: two 11-bit slices leave < 2^-8 absolute
+    with pytest.raises(ValueError):
+        ops.conv_s2_splitf16_pack(torch.randn(16, 16, 3, 3, 3))
+    bad = torch.randn(16, 8, 3, 3, 3)
+    bad[3, 2, 1, 1, 1] = float("inf")
+    with pytest.raises(RuntimeError, match="finite"):
+        ops.conv_s2_splitf16_pack(bad)

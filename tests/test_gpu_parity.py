@@ -346,6 +346,48 @@ def test_conv_ci_splitf16_matches_torch_cpu(dev, report, c, B, D, H, W, amp):
     assert e3 < 4 * max(ef, 2e-7)
 
 
+S2_CASES = [(8, 1, 4, 8, 16, 1.0), (8, 2, 6, 10, 72, 1.0), (16, 1, 6, 14, 40, 1.0), (16, 2, 4, 26, 136, 1e-3), (8, 1, 10, 12, 36, 3e4), (16, 1, 4, 4, 16, 1e-30),
+            (8, 1, 5, 27, 132, 1.0), (16, 1, 9, 13, 8, 1.0), (8, 1, 1, 3, 4, 1.0), (8, 8, 32, 256, 320, 1.0), (16, 8, 16, 128, 160, 1.0), (8, 1, 8, 512, 640, 1.0)]
+
+
+@pytest.mark.parametrize("cin,B,D,H,W,amp", S2_CASES)
+def test_conv_s2_splitf16_matches_torch_cpu(dev, report, cin, B, D, H, W, amp):
+    """csrc/conv_s2_splitf16.hip: conv1 (8 -> 16) / conv3 (16 -> 32) of CostRegNet (mvsnet.py:64-65,67-68: Conv3d k3 s2 p1 + ABN) on the f16 matrix cores,
+    input-stationary along z: vs torch CPU float64 at the bound of the float32-MFMA layer kernels and no worse than a few times that kernel's own error;
+    odd sizes along every axis (the float32 kernel needs even ones: compared where it runs), several z segments, the cascade's shapes at batch 8, inputs
+    far outside float16's range; twice for the bits."""
+    ops = _ops()
+    cout = 2 * cin
+    g = torch.Generator().manual_seed(cin * 100 + D + W)
+    x = torch.randn(B, cin, D, H, W, generator=g) * amp
+    x[..., -1:, -1:] *= 1e-6
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.1
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1 * amp
+    if x.numel() > 5e7:   # the cascade's shapes: float64 on the CPU takes minutes - the float32 kernel is the reference there
+        want = None
+    else:
+        want = F.conv3d(x.double(), w.double(), stride=2, padding=1) * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+        want = torch.where(want > 0, want, want * 0.01)
+    packed = ops.conv_s2_splitf16_pack(w, scale, shift).to(dev)
+    xd = x.to(dev)
+    got_d = ops.conv_s2_splitf16_forward(packed, xd, cout, slope=0.01)
+    assert torch.equal(got_d, ops.conv_s2_splitf16_forward(packed, xd, cout, slope=0.01))
+    got = got_d.cpu()
+    assert torch.isfinite(got).all()
+    even = D % 2 == 0 and H % 2 == 0 and W % 2 == 0
+    f32 = ops.conv3d_forward(ops.CONV_S2, ops.conv3d_pack(ops.CONV_S2, w, scale, shift).to(dev), xd, cout, slope=0.01).cpu() if even else None
+    if want is None:
+        e = scaled_err(got, f32.double())
+        report("conv_s2_splitf16", shape=[cin, B, D, H, W], amp=amp, vs_f32_kernel=e)
+        assert e < 3e-6
+        return
+    e3 = scaled_err(got, want)
+    ef = scaled_err(f32, want) if even else None
+    report("conv_s2_splitf16", shape=[cin, B, D, H, W], amp=amp, err_splitf16=e3, err_f32_mfma=ef)
+    assert e3 < 1.2e-5
+    assert ef is None or e3 < 4 * max(ef, 2e-7)
+
+
 PROB_CASES = [(1, 8, 8, 64), (2, 8, 32, 40), (1, 32, 16, 72), (2, 48, 24, 132), (1, 12, 9, 36), (1, 4, 5, 8), (1, 16, 70, 196)]
 
 
@@ -578,6 +620,11 @@ def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
         xc = rnd(B, c, D, H, W).to(dev)
         pc = ops.conv_ci_splitf16_pack(rnd(c, c, 3, 3, 3, amp=0.1)).to(dev)
         cases.append((f"conv_ci_sf<{c},{c},{2 if D <= 2 else 4}>", lambda pc=pc, xc=xc, c=c: ops.conv_ci_splitf16_forward(pc, xc, c)))
+    # conv1 / conv3 (stride 2, z-marching)
+    for cin, (B, D, H, W) in ((8, (2, 32, 256, 320)), (16, (4, 16, 128, 160))):
+        xs = rnd(B, cin, D, H, W).to(dev)
+        ps = ops.conv_s2_splitf16_pack(rnd(2 * cin, cin, 3, 3, 3, amp=0.1)).to(dev)
+        cases.append((f"conv_s2_sf<{cin},{2 * cin}>", lambda ps=ps, xs=xs, cin=cin: ops.conv_s2_splitf16_forward(ps, xs, 2 * cin)))
     # conv9 / conv11 (transposed, with their skip tensors)
     x9, s9 = rnd(4, 32, 8, 64, 80).to(dev), rnd(4, 16, 16, 128, 160).to(dev)
     p9 = ops.deconv9_splitf16_pack(rnd(32, 16, 3, 3, 3, amp=0.1), torch.ones(16), torch.zeros(16)).to(dev)
@@ -618,7 +665,7 @@ def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
         out = gf()
         bad["graph_batch8"] += 0 if all(torch.equal(out[k], ref[k]) for k in ref) else 1
     report("split_f16_bit_stability", launches=launches, differing=bad)
-    assert len(bad) == 19 and not any(bad.values()), bad
+    assert len(bad) == 21 and not any(bad.values()), bad
 
 
 @pytest.mark.parametrize("cin,shape", [(8, (2, 8, 48, 64)), (16, (1, 9, 17, 44)), (32, (1, 12, 32, 40))])
@@ -713,7 +760,7 @@ def test_whole_forward_float32_layers_equal_the_split_f16_layers(dev, report):
         getattr(model, f"cost_reg_{l}").conv0_mode = getattr(model, f"cost_reg_{l}").ci_mode = "f32"
     model.feature.tail_mode = "f32"
     got = model(imgs, proj, dmin, dint)
-    assert model.cost_reg_0._conv0_active is None and not model.cost_reg_0._ci_active and not model.feature._split_active
+    assert model.cost_reg_0._conv0_active is None and not model.cost_reg_0._ci_active and not model.cost_reg_0._s2_active and not model.feature._split_active
     stats = {}
     for k in want:
         if k.startswith("depth"):

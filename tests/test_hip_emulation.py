@@ -3,7 +3,7 @@ the f16 and float32 MFMAs with the lane layouts the MI355X self-tests verified, 
 64 threads, raw buffer addressing with range checking, LDS / global atomics), the drivers include the .hip files as C++ and run them against float64:
 
   run_kernels   conv0 split-f16 (tiled: validates the emulator; z-march, shifted grids), FeatureNet.conv0 fused, deconv9 / deconv11 split-f16
-  run_kernels2  conv_ci_sf / conv2d_ci_sf (production)                 (run_kernels3: the fused tail kernel, removed in round 4)
+  run_kernels2  conv_ci_sf / conv2d_ci_sf (production)                 run_kernels3  conv_s2_sf: the stride-2 layers on the f16 cores (round 4)
   run_kernels4  prob z-walk head (production)                         run_kernels5  prob weight gradient, both fusion kernels (production)
   run_kernels6  FPN tail split-f16 (production)                       run_kernels7  LDS-staged plane sweep / variance volume (production)
   run_kernels8  training: conv_wgrad (all kinds, both LDS layouts), channel sums, variance-volume backward
@@ -24,8 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = os.environ.get("HIPEMU_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
 
 
-DRIVERS = ("run_kernels", "run_kernels2", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7", "run_kernels8", "run_kernels9")
-PROFILED = ("run_kernels",)
+DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7", "run_kernels8", "run_kernels9")
+PROFILED = ("run_kernels", "run_kernels3")
 # costvol_lds.hip instantiates 30 kernels: its ThreadSanitizer build alone takes 80 s - part of the suite only with HIPEMU_FULL=1 (clean when it was added)
 # (run_kernels8: the weight-gradient cases take a minute under the sanitizer; run_kernels9: conv3d_mfma.hip is 2500 lines of templates - clean when added)
 TSAN_DRIVERS = DRIVERS if os.environ.get("HIPEMU_FULL") == "1" else tuple(d for d in DRIVERS if d not in ("run_kernels7", "run_kernels8", "run_kernels9"))
@@ -99,6 +99,13 @@ def test_production_channel_inner_kernels_run_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_stride2_z_march_kernel_runs_on_the_cpu(built):
+    """conv_s2_sf_kernel (CostRegNet conv1 / conv3 on the f16 matrix cores, input-stationary along z; written in round 4 with this run as its first test):
+    8 -> 16 and 16 -> 32 on ragged volumes against the layer in float64 (the driver's `all` mode: odd sizes along every axis, three z segments, rows of 4)."""
+    _run(built[("run_kernels3", "plain")], ("conv_s2    8 -> 16", "conv_s2    16 -> 32"))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_production_prob_head_runs_on_the_cpu(built):
     """prob_zwalk_kernel (Conv3d 8 -> 1 walking the depth axis, regression fused or chunked; the production head): cost, depth, confidence and index against
     float64 - a GPU-free regression test of the kernel the fused tail was derived from."""
@@ -143,7 +150,7 @@ def test_float32_matrix_core_layers_run_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-@pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "conv0_zw", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")),
+@pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "conv0_zw", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")), ("run_kernels3", ("conv_s2",)),
                                           ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion")), ("run_kernels6", ("fpn_tail0",)), ("run_kernels7", ("costvol_lds",)), ("run_kernels8", ("wgrad",)), ("run_kernels9", ("conv3d_f32",))])
 def test_no_lds_race_under_thread_sanitizer(built, source, names):
     """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
@@ -164,7 +171,7 @@ def test_no_lds_race_under_thread_sanitizer(built, source, names):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-@pytest.mark.parametrize("source", ["run_kernels"])
+@pytest.mark.parametrize("source", ["run_kernels", "run_kernels3"])
 def test_lds_bank_profile_of_the_split_f16_kernels(built, source):
     """tools/lds_bank_profile.py: the compiler's memory-access hooks (-fsanitize=thread, linked against tests/hipemu/lds_profile.cpp instead of the sanitizer)
     record every LDS access of the emulated run; the accesses of a wave are regrouped into wave-instructions and priced with the bank rules of
@@ -175,7 +182,7 @@ def test_lds_bank_profile_of_the_split_f16_kernels(built, source):
         pytest.skip("this clang++ has no -fsanitize=thread")
     tool = _profile_tool()
     totals = tool.per_kernel(tool.profile(source, "quick", workdir=built["workdir"], exe=built[(source, "profile")]))
-    want = {"run_kernels": ("conv0_sf_kernel", "conv0_zw_kernel", "deconv11_sf_kernel", "deconv9_sf_kernel")}[source]
+    want = {"run_kernels": ("conv0_sf_kernel", "conv0_zw_kernel", "deconv11_sf_kernel", "deconv9_sf_kernel"), "run_kernels3": ("conv_s2_sf_kernel",)}[source]
     for name in want:
         kernels = [k for k in totals if k.startswith(name)]
         assert kernels, (name, list(totals))

@@ -24,7 +24,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=(512, 640))
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--all-f32", action="store_true", help="every layer on the float32 MFMA kernels (conv0_mode / ci_mode / tail_mode = f32)")
-ap.add_argument("--f32-layers", default="", help="A/B: comma list of CostRegNet layers kept on the float32 MFMA kernel although they have an f16 form: conv0, conv2, conv4, conv6, conv9, conv11")
+ap.add_argument("--f32-layers", default="", help="A/B: comma list of CostRegNet layers kept on the float32 MFMA kernel although they have an f16 form: conv0, conv1, conv2, conv3, conv4, conv6, conv9, conv11")
 args = ap.parse_args()
 if args.lib:
     os.environ["CASMVS_LIB_PATH"] = os.path.abspath(args.lib)
@@ -115,7 +115,7 @@ COSTREG = (("conv0", CONV_S1, None, 8), ("conv1", CONV_S2, 8, 16), ("conv2", CON
 costreg, costreg_w = [], []
 for l in range(3):
     c_in0 = 8 * 2 ** l
-    packed, split = [], [None] * 6
+    packed, split = [], [None] * 8
     costreg_w.append({})
     for name, kind, cin, cout in COSTREG:
         cin = c_in0 if cin is None else cin
@@ -128,6 +128,9 @@ for l in range(3):
         if name in ("conv2", "conv4", "conv6"):
             split[1 + ("conv2", "conv4", "conv6").index(name)] = pack_bytes(lib.casmvs_conv_ci_splitf16_packed_bytes(cin, cout), lib.casmvs_conv_ci_splitf16_pack,
                                                                              cin, cout, hp(w), hp(sc), hp(sh))
+        if name in ("conv1", "conv3"):
+            split[6 + ("conv1", "conv3").index(name)] = pack_bytes(lib.casmvs_conv_s2_splitf16_packed_bytes(cin, cout), lib.casmvs_conv_s2_splitf16_pack,
+                                                                   cin, cout, hp(w), hp(sc), hp(sh))
         if name == "conv9":
             split[4] = pack_bytes(lib.casmvs_deconv9_splitf16_packed_bytes(), lib.casmvs_deconv9_splitf16_pack, hp(w), hp(sc), hp(sh))
         if name == "conv11":
@@ -135,7 +138,7 @@ for l in range(3):
     costreg.append((packed, split))
 
 F32_LAYERS = set(filter(None, args.f32_layers.split(",")))
-SPLIT_ORDER = ("conv0", "conv2", "conv4", "conv6", "conv9", "conv11")   # casmvs_costreg_regress_f32: split_layers[0..5]
+SPLIT_ORDER = ("conv0", "conv2", "conv4", "conv6", "conv9", "conv11", "conv1", "conv3")   # casmvs_costreg_regress_f32: split_layers[0..7]
 assert F32_LAYERS <= set(SPLIT_ORDER), F32_LAYERS
 
 # ---- inputs: images, the DTU-like rig of synthetic.dtu_like_cameras / make_inputs --------------------------------------------
@@ -221,7 +224,7 @@ def step(timed=False):
         run_stage(f"costvol_{l}", lambda: check(cv(feat_cl[l].p, proj_l[l].p, L["dv"].p, L["vol"].p, B, V, C, h, w, D, st), "costvol"), timed)
         packed, split = costreg[l]
         arr11 = (ctypes.c_void_p * 11)(*[p.ptr for p in packed])
-        sp = None if args.all_f32 else (ctypes.c_void_p * 6)(*[None if (s is None or n in F32_LAYERS) else s.ptr for n, s in zip(SPLIT_ORDER, split)])
+        sp = None if args.all_f32 else (ctypes.c_void_p * 8)(*[None if (s is None or n in F32_LAYERS) else s.ptr for n, s in zip(SPLIT_ORDER, split)])
         arith = 0 if (args.all_f32 or "conv0" in F32_LAYERS) else 2
         run_stage(f"costreg_{l}", lambda: check(lib.casmvs_costreg_regress_f32(
             arr11, sp, arith, L["vol"].p, L["dv"].p, L["cost"].p, L["depth"].p, L["conf"].p, None, L["ws"].p, B, C, D, h, w,
