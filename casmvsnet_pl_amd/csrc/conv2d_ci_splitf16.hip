@@ -57,7 +57,7 @@ __device__ __forceinline__ f32x4 mfma_f16_c2(u32x4 a, u32x4 b, f32x4 c) {
 }
 
 // in (N, CIN, H, W) float32, W % 2 == 0, 8-byte aligned; wpk: [chunk][step][row block][slice][lane] 16-byte lane images, then scale[COUT]
-// (ABN scale x 2^-kw), shift[COUT]; out (N, COUT, H, W); out2: NULL or (N, H, W, COUT) pixel-major (16-byte aligned).
+// (ABN scale x 2^-kw), shift[COUT]; out (N, COUT, H, W) or NULL; out2: NULL or (N, H, W, COUT) pixel-major (16-byte aligned); at least one.
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
                                                              float *__restrict__ out, float *__restrict__ out2, int N, int H, int W, int tiles_x,
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__res
           for (int q = 0; q < 4; ++q) acc[t][rb][q] = NCH > 1 ? fmaf(part[t][rb][q], inv, acc[t][rb][q]) : part[t][rb][q] * inv;
     }
     // ---- epilogue: y = lrelu(acc * scale + shift); lane holds rows 4 kb + r (output channel 16 rb + 4 kb + r), column j ----
-    const rsrc_t dst = make_rsrc(out + (size_t)n * oss, oss * 4);
+    const rsrc_t dst = out ? make_rsrc(out + (size_t)n * oss, oss * 4) : make_rsrc(out2, 0);   // out == NULL: an empty range drops the stores
     const rsrc_t dst2 = make_rsrc(out2 ? out2 + (size_t)n * oss : out, oss * 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -332,7 +332,7 @@ extern "C" int casmvs_conv2d_ci_splitf16_supported(int cin, int cout, int W) { r
 extern "C" int casmvs_conv2d_ci_splitf16_forward_f32(const void *packed, const float *in, float *out, float *out_nhwc, int N, int cin, int cout, int H,
                                                      int W, float slope, void *stream) {
   casmvs::clear_error();
-  CASMVS_REQUIRE(packed && in && out, "conv2d_ci_splitf16_forward: null pointer");
+  CASMVS_REQUIRE(packed && in && (out || out_nhwc), "conv2d_ci_splitf16_forward: null pointer (out may be NULL with out_nhwc given)");
   CASMVS_REQUIRE(N > 0 && H > 0 && W > 0 && casmvs_conv2d_ci_splitf16_supported(cin, cout, W), "conv2d_ci_splitf16_forward: N=%d cin=%d cout=%d H=%d W=%d", N, cin, cout, H, W);
   CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out)) & 7) == 0 &&
                  ((reinterpret_cast<size_t>(packed) | reinterpret_cast<size_t>(out_nhwc)) & 15) == 0,

@@ -2153,7 +2153,10 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
                    const float *imgs,
                    float *feat0, float *feat1, float *feat2, float *feat0_nhwc, float *feat1_nhwc, float *feat2_nhwc,
                    void *workspace, int N, int H, int W, float slope, void *const *layer_events, void *stream) {
-  CASMVS_REQUIRE(packed_layers && imgs && feat0 && feat1 && feat2 && workspace, "featurenet_forward: null pointer");
+  CASMVS_REQUIRE(packed_layers && imgs && feat2 && workspace, "featurenet_forward: null pointer");
+  // feat0 / feat1 == NULL with their pixel-major copies given: the engine's own call - nothing downstream of FeatureNet reads the (N, C, h, w) layout of
+  // levels 0 / 1 (the plane sweep gathers pixel-major), so their stores are dropped (0.31 GB per batch-8 step).  feat2 feeds lat1 and is always written.
+  CASMVS_REQUIRE((feat0 || feat0_nhwc) && (feat1 || feat1_nhwc), "featurenet_forward: feat0 / feat1 may be NULL only with feat0_nhwc / feat1_nhwc given");
   CASMVS_REQUIRE(N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0,
                  "featurenet_forward: N=%d H=%d W=%d (H, W must be multiples of 4)", N, H, W);
   for (int i = 0; i < 13; ++i) CASMVS_REQUIRE(packed_layers[i], "featurenet_forward: packed_layers[%d] is null", i);
@@ -2173,6 +2176,8 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
   float *b2 = ws;  ws += 32 * (hw / 16);  // conv2.1
   float *c2 = ws;                         // conv2
   const float *const *P = packed_layers;
+  float *feat0_f32 = feat0 ? feat0 : a0;   // where a float32 layer kernel (which always stores (N, C, h, w)) puts a map the caller did not ask for:
+  float *feat1_f32 = feat1 ? feat1 : a1;   // conv0.0's / conv1.0's buffers are free by then
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
   int rc, li = 0;
 #define CASMVS_EV()                                                                            \
@@ -2223,7 +2228,7 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
   if (fuse0) {   // lat0 + up + smooth0 in one kernel (fpn_fused.hip); the `lat0` interval of layer_events times it, `smooth0` is empty
     CASMVS_EV();
     rc = fused0_arith == 1 ? casmvs_fpn_tail0_splitf16_f32(fused0_packed, fused0_bias9, c0, f1, feat0, feat0_nhwc, N, H, W, stream)
-                           : casmvs_fpn_tail0_f32(reinterpret_cast<const float *>(fused0_packed), fused0_bias9, c0, f1, feat0, feat0_nhwc, N, H, W, stream);   // :50-51,54
+                           : casmvs_fpn_tail0_f32(reinterpret_cast<const float *>(fused0_packed), fused0_bias9, c0, f1, feat0_f32, feat0_nhwc, N, H, W, stream);   // :50-51,54
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV2D_K1_UP, P[10], c0, f1, f0, nullptr, N, 8, 32, H, W, 1.0f, stream);           // lat0 + up :50
@@ -2234,12 +2239,12 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
     rc = casmvs_conv2d_ci_splitf16_forward_f32(ci_layers[4], f1, feat1, feat1_nhwc, N, 32, 16, H2, W2, 1.0f, stream);
     if (rc != CASMVS_OK) return rc;
   } else {
-    CASMVS_L(CASMVS_CONV2D_K3, P[11], f1, nullptr, feat1, feat1_nhwc, N, 32, 16, H2, W2, 1.0f, stream);     // smooth1  :53
+    CASMVS_L(CASMVS_CONV2D_K3, P[11], f1, nullptr, feat1_f32, feat1_nhwc, N, 32, 16, H2, W2, 1.0f, stream); // smooth1  :53
   }
   if (fuse0) {
     CASMVS_EV();
   } else {
-    CASMVS_L(CASMVS_CONV2D_K3, P[12], f0, nullptr, feat0, feat0_nhwc, N, 32, 8, H, W, 1.0f, stream);      // smooth0  :54
+    CASMVS_L(CASMVS_CONV2D_K3, P[12], f0, nullptr, feat0_f32, feat0_nhwc, N, 32, 8, H, W, 1.0f, stream);  // smooth0  :54
   }
 #undef CASMVS_L
 #undef CASMVS_EV
@@ -2361,7 +2366,10 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
   } else {
     CASMVS_L(CASMVS_CONV_S1, P[2], c1, nullptr, c2, B, 16, 16, D / 2, h / 2, w / 2, sl, stream);    // conv2
   }
-  if (conv3_split && casmvs_conv_s2_splitf16_supported(16, 32, w / 2) && (reinterpret_cast<size_t>(conv3_split) & 15) == 0) {   // conv3 on the f16 matrix cores
+  // conv3 on the f16 matrix cores where its 6 x 32 output patches fill the chip (one workgroup per CU: measured 1.13x / 1.43x the float32 kernel at
+  // 264 / 880 patches, 0.97x at 96, 0.8-0.9x at 12-33: profiles/r04_conv_s2_depth_ab.txt)
+  const long conv3_patches = (long)B * casmvs::ceil_div(h / 4, 6) * casmvs::ceil_div(w / 4, 32);
+  if (conv3_split && casmvs_conv_s2_splitf16_supported(16, 32, w / 2) && (reinterpret_cast<size_t>(conv3_split) & 15) == 0 && conv3_patches >= 100) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
     rc = casmvs_conv_s2_splitf16_forward_f32(conv3_split, c2, c3, B, 16, 32, D / 2, h / 2, w / 2, sl, stream);

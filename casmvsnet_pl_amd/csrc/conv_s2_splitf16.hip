@@ -30,6 +30,13 @@
 #include "common.h"
 #include "split_f16.h"
 
+#ifndef CASMVS_S2_DEPTH_CONV1
+#define CASMVS_S2_DEPTH_CONV1 1   // units in flight per workgroup (register sets of 32): conv1 runs three workgroups per CU,
+#endif
+#ifndef CASMVS_S2_DEPTH_CONV3
+#define CASMVS_S2_DEPTH_CONV3 2   // conv3 (72 KiB of lane images) one
+#endif
+
 namespace {
 
 using namespace casmvs::buf;
@@ -78,7 +85,7 @@ __device__ __forceinline__ S2Item s2_decode(int v, int total, int tiles_x, int t
 
 // in (B, CIN, D, H, W) float32, W % 4 == 0, 16-byte aligned; wpk: [chunk][kz][ky][row block][slice][lane] 16-byte lane images, then
 // scale[COUT] (ABN scale x 2^-kw), shift[COUT]; out (B, COUT, Do, Ho, Wo), o = (i - 1) / 2 + 1 per axis.
-template <int CIN, int COUT>
+template <int CIN, int COUT, int DEPTH>
 __global__ __launch_bounds__(256, (S2Cfg<CIN, COUT>::WG_PER_CU)) void conv_s2_sf_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk,
                                                                                    float *__restrict__ out, int B, int D, int H, int W, int tiles_x,
                                                                                    int tiles_y, int segs, int zt, float slope) {
@@ -135,16 +142,37 @@ __global__ __launch_bounds__(256, (S2Cfg<CIN, COUT>::WG_PER_CU)) void conv_s2_sf
   const int srow = tid / IQ, sq = tid - srow * IQ;
   const int sunit = srow * RS + 2 * sq;   // voxel v of the quad -> parity v & 1, index 2 q + (v >> 1)
 
-  f32x4 R[8];
-  // a unit = (item, input plane p, chunk); the loads of the unit: 8 channels x one quad of x per staging thread
-  auto prefetch = [&](const S2Item &it, int p, int ch, bool exists) {
-    const int gy = 2 * it.oy0 - 1 + srow, gx = 2 * it.ox0 - 4 + 4 * sq;
+  // a unit = (item, input plane p, chunk); DEPTH register sets hold the units in flight (the loads of a unit: 8 channels x one quad of x per staging thread)
+  struct Cursor {
+    S2Item it;
+    int item, p, ch;
+    bool valid;
+  };
+  auto advance = [&](const Cursor &c) {
+    Cursor n = c;
+    if (!c.valid) return n;
+    n.ch = c.ch + 1;
+    if (n.ch == NCH) {
+      n.ch = 0;
+      n.p = c.p + 1;
+      if (n.p > 2 * (c.it.oz0 + zt) - 1) {   // past the odd plane that completes the segment's last output plane (planes >= D read as zeros)
+        n.item = c.item + gridDim.x;
+        n.valid = n.item < total;
+        if (n.valid) n.it = s2_decode<Cfg>(n.item, total, tiles_x, tiles_y, segs, zt);
+        n.p = n.it.oz0 == 0 ? 0 : 2 * n.it.oz0 - 1;
+      }
+    }
+    return n;
+  };
+  f32x4 R[DEPTH][8];
+  auto load = [&](f32x4 (&Rs)[8], const Cursor &c) {
+    const int gy = 2 * c.it.oy0 - 1 + srow, gx = 2 * c.it.ox0 - 4 + 4 * sq;
     const bool ok = staged && gy >= 0 && gy < H && gx >= 0 && gx < W;   // W % 4 == 0: whole quads
     const int voff = ok ? (gy * W + gx) * 4 : kOOB;
-    const rsrc_t src = exists && p >= 0 && p < D ? make_rsrc(in + (size_t)it.b * in_ss, in_ss * 4) : none;
-    const int soff = (ch * 8 * cs + (p < 0 ? 0 : p) * HW) * 4;
+    const rsrc_t src = c.valid && c.p < D ? make_rsrc(in + (size_t)c.it.b * in_ss, in_ss * 4) : none;
+    const int soff = (c.ch * 8 * cs + c.p * HW) * 4;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) R[c] = __builtin_bit_cast(f32x4, buf_load4(src, voff, soff + c * cs * 4));
+    for (int k = 0; k < 8; ++k) Rs[k] = __builtin_bit_cast(f32x4, buf_load4(src, voff, soff + k * cs * 4));
   };
 
   f32x4 accA[NT][RB], accB[NT][RB];
@@ -153,30 +181,32 @@ __global__ __launch_bounds__(256, (S2Cfg<CIN, COUT>::WG_PER_CU)) void conv_s2_sf
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) accA[t][rb] = accB[t][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int item = blockIdx.x;
-  S2Item cur = s2_decode<Cfg>(item, total, tiles_x, tiles_y, segs, zt);
-  int p = cur.oz0 == 0 ? 0 : 2 * cur.oz0 - 1, ch = 0;
-  prefetch(cur, p, 0, true);
+  Cursor q[DEPTH];   // q[d]: the unit whose loads set d holds
+  q[0].item = blockIdx.x;
+  q[0].it = s2_decode<Cfg>(q[0].item, total, tiles_x, tiles_y, segs, zt);
+  q[0].p = q[0].it.oz0 == 0 ? 0 : 2 * q[0].it.oz0 - 1;
+  q[0].ch = 0;
+  q[0].valid = true;
+#pragma unroll
+  for (int d = 1; d < DEPTH; ++d) q[d] = advance(q[d - 1]);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(R[d], q[d]);
+  // ONE exit, behind the last set's unit: an exit edge from the middle of the body goes through the loop's latch after structurisation, and the compiler's
+  // wait-count pass then merges "set d was just issued" into the head (every wait becomes vmcnt(0)).  Units past the end of the stream (at most DEPTH - 1 per
+  // workgroup) load zeros and store nothing.
   for (;;) {
-    // ---- the unit after this one (possibly the first of the next item) ----
-    const int plast = 2 * (cur.oz0 + zt) - 1;   // the odd plane that completes the segment's last output plane (planes >= D read as zeros)
-    S2Item nit = cur;
-    int np = p, nch = ch + 1, nitem = item;
-    bool more = true;
-    if (nch == NCH) {
-      nch = 0;
-      np = p + 1;
-      if (np > plast) {
-        nitem = item + gridDim.x;
-        more = nitem < total;
-        nit = more ? s2_decode<Cfg>(nitem, total, tiles_x, tiles_y, segs, zt) : cur;
-        np = nit.oz0 == 0 ? 0 : 2 * nit.oz0 - 1;
-      }
-    }
+#pragma unroll
+   for (int d = 0; d < DEPTH; ++d) {
+    const Cursor c = q[d];
+    const Cursor ahead = advance(q[(d + DEPTH - 1) % DEPTH]);      // the unit DEPTH ahead: set d's next load
+    const Cursor nx = DEPTH == 1 ? ahead : q[(d + 1) % DEPTH];     // the unit consumed next
+    const S2Item cur = c.it;
+    const int p = c.p, ch = c.ch;
+    f32x4 (&Rd)[8] = R[d];
     // ---- the staged unit's largest magnitude (this thread's loads -> wave -> workgroup) ----
     float m = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) m = fmaxf(m, fmaxf(fmaxf(fabsf(R[c][0]), fabsf(R[c][1])), fmaxf(fabsf(R[c][2]), fabsf(R[c][3]))));
+    for (int c = 0; c < 8; ++c) m = fmaxf(m, fmaxf(fmaxf(fabsf(Rd[c][0]), fabsf(Rd[c][1])), fmaxf(fabsf(Rd[c][2]), fabsf(Rd[c][3]))));
     const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
     if (lane == 0) wmax[wave] = wm;
     __syncthreads();   // every wave is done with the previous unit's LDS; the four maxima are visible
@@ -187,7 +217,7 @@ __global__ __launch_bounds__(256, (S2Cfg<CIN, COUT>::WG_PER_CU)) void conv_s2_sf
       for (int v = 0; v < 4; ++v) {
         float x[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = R[c][v];
+        for (int c = 0; c < 8; ++c) x[c] = Rd[c][v];
         casmvs::split_u32x4 o[2];
         casmvs::split8_f16(x, mult, o);
         u32x4 *pl = act + sunit + ((v & 1) ? ODD : 0) + (v >> 1);
@@ -198,7 +228,7 @@ __global__ __launch_bounds__(256, (S2Cfg<CIN, COUT>::WG_PER_CU)) void conv_s2_sf
       }
     }
     __syncthreads();
-    prefetch(nit, np, nch, more);   // in flight behind the matrix phase
+    if (DEPTH == 1) load(Rd, ahead);   // in flight behind the matrix phase (DEPTH > 1: the next unit's loads already are; this set is refilled after it)
     // ---- matrix phase: an even plane is tap kz = 1 of A's output plane; an odd plane tap kz = 2 of A's and tap kz = 0 of B's ----
     const u32x4 *wch = wl + ch * (9 * RB * 2 * 64) + lane;
     constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(256, (S2Cfg<CIN, COUT>::WG_PER_CU)) void conv_s2_sf
       if (ch == NCH - 1) {
         // ---- output plane oz = (p - 1) / 2 is complete: y = lrelu(acc * scale + shift); lane holds channels 16 rb + 4 kb + r, column j ----
         const int oz = (p - 1) >> 1;
-        const bool zok = oz >= cur.oz0 && oz < Do;   // (the segment's first odd plane also feeds the previous segment's last output plane: not ours)
+        const bool zok = c.valid && oz >= cur.oz0 && oz < Do;   // (the segment's first odd plane also feeds the previous segment's last output plane: not ours)
         const rsrc_t dst = zok ? make_rsrc(out + (size_t)cur.b * out_ss, out_ss * 4) : make_rsrc(out, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -297,18 +327,18 @@ __global__ __launch_bounds__(256, (S2Cfg<CIN, COUT>::WG_PER_CU)) void conv_s2_sf
         }
       }
     }
-    if (!more) break;
-    if (nitem != item) {   // a new item starts with empty accumulators (A holds what the last odd plane fed the next segment's first output plane)
+    if (DEPTH > 1) load(Rd, ahead);   // behind the epilogue's stores: the next unit's loads stay the oldest outstanding operations
+    q[d] = ahead;
+    if (d == DEPTH - 1 && !nx.valid) goto done;
+    if (nx.item != c.item) {   // a new item starts with empty accumulators (A holds what the last odd plane fed the next segment's first output plane)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) accA[t][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    item = nitem;
-    cur = nit;
-    p = np;
-    ch = nch;
+   }
   }
+done:;
 }
 
 inline uint16_t f16_bits_s2(float x) {   // round to nearest even (host)
@@ -335,12 +365,20 @@ inline int s2_pick_segments(int Do, long patches, int resident) {
   return best;
 }
 
+#ifdef HIPEMU_LDS_BYTES
+int g_s2_emu_depth = 2;
+#endif
+
 template <int CIN, int COUT>
 int launch_s2(const void *packed, const float *in, float *out, int B, int D, int H, int W, float slope, hipStream_t st) {
   using Cfg = S2Cfg<CIN, COUT>;
   const int Do = (D - 1) / 2 + 1, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int tiles_x = casmvs::ceil_div(Wo, Cfg::TX), tiles_y = casmvs::ceil_div(Ho, Cfg::TY);
-  auto kernel = conv_s2_sf_kernel<CIN, COUT>;
+#ifdef HIPEMU_LDS_BYTES   // tests/hipemu runs every depth
+  auto kernel = g_s2_emu_depth == 1 ? conv_s2_sf_kernel<CIN, COUT, 1> : g_s2_emu_depth == 2 ? conv_s2_sf_kernel<CIN, COUT, 2> : conv_s2_sf_kernel<CIN, COUT, 3>;
+#else
+  auto kernel = conv_s2_sf_kernel<CIN, COUT, (CIN == 8 ? CASMVS_S2_DEPTH_CONV1 : CASMVS_S2_DEPTH_CONV3)>;
+#endif
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), Cfg::LDS_BYTES, "conv_s2_sf_kernel")) return rc;
   const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), Cfg::THREADS, Cfg::LDS_BYTES);
   const int segs = s2_pick_segments(Do, (long)tiles_x * tiles_y * B, resident), zt = casmvs::ceil_div(Do, segs);

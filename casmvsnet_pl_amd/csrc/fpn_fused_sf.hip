@@ -60,7 +60,7 @@ __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
 __device__ __forceinline__ void split8(const float (&x)[8], float mult, u32x4 (&o)[2]) { casmvs::split8_f16(x, mult, o); }   // split_f16.h
 
 // c0 (N, 8, H, W), f1 (N, 32, H/2, W/2); wpk: [chunk][ky][slice][lane] 16-byte lane images, then unscale = 2^-kw (one float);
-// bias9 (3, 3, 8): [row class][column class][co].  out (N, 8, H, W); out2: NULL or (N, H, W, 8) pixel-major.
+// bias9 (3, 3, 8): [row class][column class][co].  out (N, 8, H, W) or NULL; out2: NULL or (N, H, W, 8) pixel-major (at least one).
 __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const float *__restrict__ c0, const float *__restrict__ f1,
                                                                         const unsigned char *__restrict__ wpk, const float *__restrict__ bias9,
                                                                         float *__restrict__ out, float *__restrict__ out2, int N, int H, int W,
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
         for (int q = 0; q < 4; ++q) acc[t][q] = fmaf(part[t][q], inv, acc[t][q]);
     }
     // ---- epilogue: 2^-kw, + bias class of the pixel; lane holds rows 4 u + r = (co = 2 u + (r >> 1), x phase r & 1) of column j ----
-    const rsrc_t dst = make_rsrc(out + (size_t)n * 8 * hw, (size_t)8 * hw * 4);
+    const rsrc_t dst = out ? make_rsrc(out + (size_t)n * 8 * hw, (size_t)8 * hw * 4) : make_rsrc(out2, 0);   // out == NULL: an empty range drops the stores
     const rsrc_t dst2 = make_rsrc(out2 ? out2 + (size_t)n * 8 * hw : out, (size_t)8 * hw * 4);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -333,7 +333,7 @@ extern "C" int casmvs_fpn_tail0_splitf16_pack(const float *weight40, void *packe
 extern "C" int casmvs_fpn_tail0_splitf16_f32(const void *packed, const float *bias9, const float *conv0, const float *feat1_sum,
                                              float *feat0, float *feat0_nhwc, int N, int H, int W, void *stream) {
   casmvs::clear_error();
-  CASMVS_REQUIRE(packed && bias9 && conv0 && feat1_sum && feat0, "fpn_tail0_splitf16: null pointer");
+  CASMVS_REQUIRE(packed && bias9 && conv0 && feat1_sum && (feat0 || feat0_nhwc), "fpn_tail0_splitf16: null pointer (feat0 may be NULL with feat0_nhwc given)");
   CASMVS_REQUIRE(N > 0 && N <= 65535 && H >= 4 && W >= 8 && H % 2 == 0 && W % 4 == 0, "fpn_tail0_splitf16: N=%d H=%d W=%d (H even, W %% 4 == 0, W >= 8)", N, H, W);
   CASMVS_REQUIRE(((reinterpret_cast<size_t>(conv0) | reinterpret_cast<size_t>(feat0) | reinterpret_cast<size_t>(packed)) & 15) == 0 &&
                  (reinterpret_cast<size_t>(feat0_nhwc) & 15) == 0, "fpn_tail0_splitf16: conv0 / feat0 / packed / feat0_nhwc must be 16-byte aligned");

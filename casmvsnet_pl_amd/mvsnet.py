@@ -199,8 +199,10 @@ class FeatureNet(_PackedWeights, nn.Module):
         self._packed_key = key
         return self._store_packed("_packed", packed)
 
-    def forward(self, x):
-        """x (N, 3, H, W) -> {"level_0": (N,8,H,W), "level_1": (N,16,H/2,W/2), "level_2": (N,32,H/4,W/4)}."""
+    def forward(self, x, pixel_major_only=False):
+        """x (N, 3, H, W) -> {"level_0": (N,8,H,W), "level_1": (N,16,H/2,W/2), "level_2": (N,32,H/4,W/4)}.
+        pixel_major_only (eval mode; CascadeMVSNet.forward's own call): -> {"level_l": (N,h,w,C)} - the layout the plane sweep gathers; the (N,C,h,w)
+        stores of levels 0 / 1, which nothing downstream reads, are dropped."""
         if not x.is_cuda:
             raise RuntimeError("casmvsnet_pl_amd.FeatureNet runs on the MI355X only; there is no CPU fallback")
         if self.training:   # batch statistics + autograd graph (training.py); eval mode = the fused engine below
@@ -218,9 +220,12 @@ class FeatureNet(_PackedWeights, nn.Module):
         sf = self._split_active   # fuse_tail and tail_mode == "splitf16" and finite weights (packed_layers)
         fused0 = (self._fused0_sf if sf else self._fused0) if self.fuse_tail else None
         feat0, feat1, feat2, cl = ops.featurenet_forward(packed, x.float(), ws, slope=self._slope, layer_events=events,
-                                                         channels_last_copies=True, fused0=fused0, fused0_splitf16=sf, ci_layers=self._ci2d if sf else None)
+                                                         channels_last_copies=True, fused0=fused0, fused0_splitf16=sf, ci_layers=self._ci2d if sf else None,
+                                                         nchw_outputs=not pixel_major_only)
         # pixel-major copies of the three maps (same kernels, second store): what the cost-volume gather reads
         self.last_channels_last = {"level_0": cl[0], "level_1": cl[1], "level_2": cl[2]}
+        if pixel_major_only:
+            return self.last_channels_last
         return {"level_0": feat0, "level_1": feat1, "level_2": feat2}
 
 
@@ -428,7 +433,10 @@ class CascadeMVSNet(nn.Module):
         feats_channels_last: optional (B,V,h,w,C) copy of feats (FeatureNet writes one): the faster gather."""
         t = self.timer
         with stage(t, f"costvol_{level}"):                                  # mvsnet.py:134-172
-            B, V, C, h, w = feats.shape
+            if feats is None:   # the engine's own call: FeatureNet stored the pixel-major maps only
+                B, V, h, w, C = feats_channels_last.shape
+            else:
+                B, V, C, h, w = feats.shape
             if feats_channels_last is None and C in (8, 16, 32):
                 feats_channels_last = ops.nchw_to_nhwc(feats.reshape(B * V, C, h, w)).view(B, V, h, w, C)
             if self.view_shard_group is not None:
@@ -478,13 +486,19 @@ class CascadeMVSNet(nn.Module):
         proj_mats = proj_mats.float().permute(2, 0, 1, 3, 4).contiguous()  # (levels, B, V-1, 3, 4): one copy, not one per level
         t = self.timer
         with torch.no_grad():
+            engine_feats = type(self.feature) is FeatureNet   # (a user's replacement module returns the reference's (N,C,h,w) dict)
             with stage(t, "feature"):
-                feats = self.feature(imgs)
+                feats = self.feature(imgs, pixel_major_only=True) if engine_feats else self.feature(imgs)
             depth_l = None
             for l in reversed(range(self.levels)):
                 feats_l = feats[f"level_{l}"]
-                C, h, w = feats_l.shape[1:]
-                feats_l = feats_l.reshape(B, V, C, h, w)
+                if engine_feats:
+                    (h, w, C), cl, feats_l = feats_l.shape[1:], feats_l.view(B, V, *feats_l.shape[1:]), None
+                else:
+                    C, h, w = feats_l.shape[1:]
+                    feats_l = feats_l.reshape(B, V, C, h, w)
+                    cl = getattr(self.feature, "last_channels_last", None)
+                    cl = None if cl is None else cl[f"level_{l}"].view(B, V, h, w, C)
                 proj_mats_l = proj_mats[l]
                 D = self.n_depths[l]
                 ratio = self.interval_ratios[l]
@@ -502,7 +516,6 @@ class CascadeMVSNet(nn.Module):
                         depth_values = ops.depth_hypotheses(None, dmin_b, interval_b, None, D, h, w)
                     else:
                         depth_values = ops.depth_hypotheses(depth_l, None, interval_b, half_b, D, h, w)
-                cl = self.feature.last_channels_last[f"level_{l}"].view(B, V, h, w, C)
                 depth_l, confidence_l = self.predict_depth(feats_l, proj_mats_l, depth_values,
                                                            getattr(self, f"cost_reg_{l}"), level=l,
                                                            feats_channels_last=cl)

@@ -723,7 +723,7 @@ def fpn_tail0_splitf16(packed, bias9, conv0, feat1_sum, channels_last_copy=False
 
 
 def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=None, channels_last_copies=False, fused0=None, fused0_splitf16=False,
-                       ci_layers=None):
+                       ci_layers=None, nchw_outputs=True):
     """Whole FeatureNet (mvsnet.py:40-57).  packed_layers: 13 device tensors (conv0.0 .. conv2.2,
     toplayer, lat1, lat0, smooth1, smooth0); imgs (N,3,H,W) -> feat0 (N,8,H,W), feat1 (N,16,H/2,W/2),
     feat2 (N,32,H/4,W/4).  layer_events: optional 14 recorded torch.cuda.Event.
@@ -731,7 +731,9 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
     kernels) -> (feat0, feat1, feat2, (nhwc0, nhwc1, nhwc2)).  fused0: (packed40, bias9) device tensors - the
     full-resolution tail as one kernel (casmvs_featurenet_forward_fused_f32); fused0_splitf16: packed40 is the uint8 image of
     fpn_tail0_splitf16_pack (the tail on the f16 matrix cores) instead of the float32 conv2d_pack image.  ci_layers (with fused0 only):
-    5 device images of conv2d_ci_splitf16_pack for conv1.1, conv1.2, conv2.1, conv2.2, smooth1 (entries may be None) - those layers on the f16 cores."""
+    5 device images of conv2d_ci_splitf16_pack for conv1.1, conv1.2, conv2.1, conv2.2, smooth1 (entries may be None) - those layers on the f16 cores.
+    nchw_outputs=False (with channels_last_copies; the engine's own call): feat0 / feat1 are not stored - nothing downstream reads their (N,C,h,w) layout -
+    and come back as None."""
     imgs = _dev(imgs, "imgs")
     N, c, H, W = imgs.shape
     if c != 3 or len(packed_layers) != 13:
@@ -741,8 +743,10 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
         raise ValueError("featurenet_forward: workspace too small")
     arr = (ctypes.c_void_p * 13)(*[p.data_ptr() for p in packed_layers])
     dev = imgs.device
-    feat0 = torch.empty((N, 8, H, W), dtype=torch.float32, device=dev)
-    feat1 = torch.empty((N, 16, H // 2, W // 2), dtype=torch.float32, device=dev)
+    if not nchw_outputs and not channels_last_copies:
+        raise ValueError("featurenet_forward: nchw_outputs=False needs channels_last_copies=True")
+    feat0 = torch.empty((N, 8, H, W), dtype=torch.float32, device=dev) if nchw_outputs else None
+    feat1 = torch.empty((N, 16, H // 2, W // 2), dtype=torch.float32, device=dev) if nchw_outputs else None
     feat2 = torch.empty((N, 32, H // 4, W // 4), dtype=torch.float32, device=dev)
     cl = (None, None, None)
     if channels_last_copies:

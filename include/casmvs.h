@@ -337,12 +337,14 @@ int casmvs_fpn_tail0_f32(const float *packed40, const float *bias9, const float 
  * casmvs_fpn_tail0_splitf16_f32: the same kernel on the f16 matrix cores in the arithmetic of casmvs_conv0_splitf16_forward_f32).
  * casmvs_fpn_tail0_splitf16_pack: HOST, weight40 (8, 40, 3, 3) float32 finite -> casmvs_fpn_tail0_splitf16_packed_bytes() bytes.
  * ci_layers: NULL, or 5 pointers { conv1.1, conv1.2, conv2.1, conv2.2, smooth1 } to DEVICE copies of casmvs_conv2d_ci_splitf16_pack's images
- * (an entry may be NULL): those layers then run on the f16 matrix cores (casmvs_conv2d_ci_splitf16_forward_f32). */
+ * (an entry may be NULL): those layers then run on the f16 matrix cores (casmvs_conv2d_ci_splitf16_forward_f32).
+ * feat0 / feat1 may be NULL when feat0_nhwc / feat1_nhwc are given (ABI version 3): nothing downstream of FeatureNet reads the (N, C, h, w) layout of
+ * levels 0 / 1 - the plane sweep gathers pixel-major - and the engine's own call drops those stores.  feat2 feeds lat1: never NULL. */
 /* FeatureNet's 3x3 stride-1 layers with 16 / 32 channels (conv1.1, conv1.2: 16 -> 16; conv2.1, conv2.2: 32 -> 32: ConvBnReLU, mvsnet.py:19-20,24-25;
  * smooth1: Conv2d 32 -> 16 with bias, mvsnet.py:32,53) in the split-f16 arithmetic (csrc/conv2d_ci_splitf16.hip).  (cin, cout) in {(16, 16),
  * (32, 32), (32, 16)}, W % 2 == 0, tensors 8-byte aligned.  `packed`: HOST image from casmvs_conv2d_ci_splitf16_pack (weight (cout, cin, 3, 3)
  * finite, scale / shift (cout) or NULL), copied to the device (16-byte aligned).  out_nhwc: NULL or the pixel-major copy (N, H, W, cout),
- * 16-byte aligned.  slope: 0.01 for the ABN layers, 1.0 for smooth1. */
+ * 16-byte aligned; `out` may be NULL when out_nhwc is given (casmvs_fpn_tail0_splitf16_f32: feat0 likewise).  slope: 0.01 for the ABN layers, 1.0 for smooth1. */
 size_t casmvs_conv2d_ci_splitf16_packed_bytes(int cin, int cout);
 int casmvs_conv2d_ci_splitf16_pack(int cin, int cout, const float *weight, const float *scale, const float *shift, void *packed);
 int casmvs_conv2d_ci_splitf16_supported(int cin, int cout, int W);

@@ -526,6 +526,28 @@ def test_featurenet_matches_oracle(dev, report, N, H, W):
     assert max(errs.values()) < 1.4e-5  # measured 1.4e-6
 
 
+@pytest.mark.parametrize("tail_mode", ["splitf16", "f32"])
+def test_featurenet_pixel_major_only_call_equals_the_full_call(dev, tail_mode):
+    """CascadeMVSNet.forward's own FeatureNet call drops the (N, C, h, w) stores of levels 0 / 1 (feat0 / feat1 = NULL at the C ABI): the three pixel-major
+    maps are bit-equal to those of the full call, on the f16 output kernels (the stores fall into an empty buffer range) and on the float32 ones (the
+    layout nobody asked for goes to the workspace)."""
+    from casmvsnet_pl_amd import ABN, FeatureNet
+    from casmvsnet_pl_amd.synthetic import randomize_state_dict
+    net = FeatureNet(ABN)
+    randomize_state_dict({("feature." + k): v for k, v in net.state_dict().items()}, seed=11)
+    net = net.to(dev).eval()
+    net.tail_mode = tail_mode
+    x = (torch.rand(3, 3, 64, 96, generator=torch.Generator().manual_seed(2)) * 2 - 1).to(dev)
+    with torch.no_grad():
+        full = net(x)
+        want = {k: v.clone() for k, v in net.last_channels_last.items()}
+        got = net(x, pixel_major_only=True)
+    assert net._split_active == (tail_mode == "splitf16")
+    for l in range(3):
+        assert torch.equal(got[f"level_{l}"], want[f"level_{l}"])
+        assert torch.equal(got[f"level_{l}"], full[f"level_{l}"].permute(0, 2, 3, 1).contiguous())
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 8, 64), (2, 36, 72), (1, 64, 196), (3, 128, 160)])
 def test_fpn_fused_tail_matches_lat_upsample_smooth(dev, report, N, H, W):
     """csrc/fpn_fused.hip (mvsnet.py:36-38,50-51,54): feat0 = smooth0(lat0(conv0) + interpolate(feat1')) as one kernel over

@@ -24,6 +24,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=(512, 640))
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--all-f32", action="store_true", help="every layer on the float32 MFMA kernels (conv0_mode / ci_mode / tail_mode = f32)")
+ap.add_argument("--nchw-feats", action="store_true", help="A/B: FeatureNet also stores the (N, C, h, w) maps of levels 0 / 1 (nothing in the forward reads them; the engine's call drops them)")
 ap.add_argument("--f32-layers", default="", help="A/B: comma list of CostRegNet layers kept on the float32 MFMA kernel although they have an f16 form: conv0, conv1, conv2, conv3, conv4, conv6, conv9, conv11")
 args = ap.parse_args()
 if args.lib:
@@ -209,7 +210,7 @@ def run_stage(name, fn, timed):
 
 def step(timed=False):
     run_stage("feature", lambda: check(lib.casmvs_featurenet_forward_fused_f32(
-        arr13, (tail_f32 if args.all_f32 else tail_sf).p, 0 if args.all_f32 else 1, bias9_d.p, ci5, imgs.p, feat[0].p, feat[1].p, feat[2].p,
+        arr13, (tail_f32 if args.all_f32 else tail_sf).p, 0 if args.all_f32 else 1, bias9_d.p, ci5, imgs.p, feat[0].p if args.nchw_feats else None, feat[1].p if args.nchw_feats else None, feat[2].p,
         feat_cl[0].p, feat_cl[1].p, feat_cl[2].p, feat_ws.p, N, H, W, ctypes.c_float(0.01), None, st), "featurenet"), timed)
     prev = None
     for l in (2, 1, 0):
