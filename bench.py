@@ -699,12 +699,12 @@ def main():
                                                             "bf16 matrix cores, float32 accumulation (conv0_splitbf16.hip)",
                                                "splitf16": "float32 operands as two float16 slices (22 significand bits) behind exact power-of-two scalings, "
                                                            "three f16 x f16 partial products per product on the f16 matrix cores, float32 accumulation "
-                                                           "(conv0_splitf16.hip; cin = 8 / 16 = cascade levels 0 / 1 on the z-marching kernel conv0_zmarch.hip); "
+                                                           "(conv0_zmarch.hip: input-stationary along z, producer / consumer wave groups); "
                                                            "float32-grade: distance to a float64 convolution at or below the float32 MFMA kernel's",
                                                "f32": "float32 MFMA (v_mfma_f32_16x16x4_f32)"}[model.cost_reg_0.conv0_mode],
-                          "conv2_conv4_conv6_conv9_conv11_arithmetic": "as conv0's split-f16 (conv_ci_splitf16.hip, deconv9_splitf16.hip, deconv11_splitf16.hip); "
-                                                                       "conv4 / conv6 only where the volume gives >= 100 tiles (conv6: >= 3 planes); conv1 / conv3 / "
-                                                                       "conv5 / conv7 and `prob` float32" if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA",
+                          "conv1_to_conv11_arithmetic": "conv1 / conv2 / conv3 / conv4 / conv6 / conv9 / conv11 as conv0's split-f16 (conv_s2_splitf16.hip, conv_ci_splitf16.hip, "
+                                                        "deconv9_splitf16.hip, deconv11_splitf16.hip); conv3 / conv4 / conv6 only where the volume gives >= 100 patches / tiles "
+                                                        "(conv6: >= 3 planes); conv5 / conv7 and `prob` float32" if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA",
                           "per_gpu_engine": f"one stream, batch {B}, one hipGraph replay per step, split-f16 layer set (what every rank of a replica run executes)"
                                             if used_graph and NS == 1 and model.cost_reg_0.conv0_mode == "splitf16" else "see launch / *_arithmetic",
                           "featurenet_arithmetic": ("fused FPN tail, conv1.1 / conv1.2 / conv2.1 / conv2.2 / smooth1 as conv0's split-f16 (fpn_fused_sf.hip, "
