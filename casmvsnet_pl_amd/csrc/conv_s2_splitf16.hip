@@ -20,8 +20,8 @@
 // 2 oz0 - 1 .. 2 (oz0 + ZT) - 1 once.  A staged UNIT = (input plane, chunk of 8 channels): 13 rows x 68 x (x from 2 ox0 - 4: whole 16-byte quads) with its
 // own power-of-two scale, 27.2 KiB as [slice][row][even x | odd x].  An even plane 2 oz is tap kz = 1 of output plane oz; an odd plane 2 oz + 1 is tap
 // kz = 2 of oz and tap kz = 0 of oz + 1 (two accumulator sets; A is stored and B becomes A after every odd plane).  Wave w owns column tiles 3 w .. 3 w + 2
-// of the patch's 12 (row = tile >> 1, half = tile & 1).  The next unit's global loads are issued before the matrix phase and land in registers behind it.
-// All lane images stay in LDS: conv1 18 KiB (46 KiB per workgroup: three per CU), conv3 72 KiB (one per CU).
+// of the patch's 12 (row = tile >> 1, half = tile & 1).  A register set is refilled with the unit DEPTH ahead as soon as the matrix phase of its unit is done.
+// All lane images stay in LDS: conv1 18 KiB (two workgroups per CU), conv3 72 KiB (one per CU); two units in flight per workgroup (two register sets).
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -31,10 +31,10 @@
 #include "split_f16.h"
 
 #ifndef CASMVS_S2_DEPTH_CONV1
-#define CASMVS_S2_DEPTH_CONV1 1   // units in flight per workgroup (register sets of 32): conv1 runs three workgroups per CU,
+#define CASMVS_S2_DEPTH_CONV1 2   // units in flight per workgroup (register sets of 32): conv1 runs two workgroups per CU,
 #endif
 #ifndef CASMVS_S2_DEPTH_CONV3
-#define CASMVS_S2_DEPTH_CONV3 2   // conv3 (72 KiB of lane images) one
+#define CASMVS_S2_DEPTH_CONV3 2   // conv3 (72 KiB of lane images) one; three were slower (profiles/r04_conv_s2_depth_ab.txt)
 #endif
 
 namespace {
@@ -58,8 +58,12 @@ struct S2Cfg {
   static constexpr int WUNITS = NCH * 9 * RB * 2 * 64;               // lane images [chunk][kz][ky][row block][slice][lane]
   static constexpr int NWL = (WUNITS + THREADS - 1) / THREADS;
   static constexpr size_t ACT_BYTES = (size_t)2 * NVOX * 16, W_BYTES = (size_t)WUNITS * 16;   // 27 872 + 18 432 (conv1) / 73 728 (conv3)
-  static constexpr size_t LDS_BYTES = ACT_BYTES + W_BYTES + 16;
-  static constexpr int WG_PER_CU = (int)((size_t)160 * 1024 / LDS_BYTES) > 3 ? 3 : (int)((size_t)160 * 1024 / LDS_BYTES);
+  // At most TWO workgroups per CU, as every split-f16 kernel of the library (conv2d_ci_splitf16.hip: the configuration with three waves per SIMD is the
+  // one in which round 3 saw wrong float32 results): the requested LDS is padded to 56 KiB.  Measured: three workgroups with one unit in flight each
+  // 117 / 230 / 232 us at the three levels (batch 8), two with two units each 120 / 236 / 233 (profiles/r04_conv_s2_depth_ab.txt).
+  static constexpr size_t LDS_USED = ACT_BYTES + W_BYTES + 16;
+  static constexpr size_t LDS_BYTES = LDS_USED < 56 * 1024 ? (size_t)56 * 1024 : LDS_USED;
+  static constexpr int WG_PER_CU = LDS_BYTES * 2 <= (size_t)160 * 1024 ? 2 : 1;
   static_assert(CIN % 8 == 0 && COUT % 16 == 0 && TY * (TX / 16) == WAVES * NT && ITEMS <= THREADS, "shape");
 };
 

@@ -24,6 +24,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=(512, 640))
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--all-f32", action="store_true", help="every layer on the float32 MFMA kernels (conv0_mode / ci_mode / tail_mode = f32)")
+ap.add_argument("--feature-split", type=int, default=1, help="A/B: FeatureNet over this many groups of images in sequence (cache blocking)")
 ap.add_argument("--nchw-feats", action="store_true", help="A/B: FeatureNet also stores the (N, C, h, w) maps of levels 0 / 1 (nothing in the forward reads them; the engine's call drops them)")
 ap.add_argument("--f32-layers", default="", help="A/B: comma list of CostRegNet layers kept on the float32 MFMA kernel although they have an f16 form: conv0, conv1, conv2, conv3, conv4, conv6, conv9, conv11")
 args = ap.parse_args()
@@ -208,10 +209,22 @@ def run_stage(name, fn, timed):
         events[name][1].record(stream)
 
 
+def feature_stage():
+    # --feature-split K: FeatureNet over K groups of images, one after the other through the same workspace (cache blocking: a group's intermediates
+    # - 8 channels at full resolution = 10.5 MB per image - stay in the 256 MB Infinity Cache between the layer that writes and the one that reads them)
+    K = args.feature_split
+    assert N % K == 0, (N, K)
+    n = N // K
+    at = lambda a, i: ctypes.c_void_p(a.ptr + i * n * (a.nbytes // N))
+    for i in range(K):
+        check(lib.casmvs_featurenet_forward_fused_f32(
+            arr13, (tail_f32 if args.all_f32 else tail_sf).p, 0 if args.all_f32 else 1, bias9_d.p, ci5, at(imgs, i), at(feat[0], i) if args.nchw_feats else None,
+            at(feat[1], i) if args.nchw_feats else None, at(feat[2], i), at(feat_cl[0], i), at(feat_cl[1], i), at(feat_cl[2], i), feat_ws.p, n, H, W,
+            ctypes.c_float(0.01), None, st), "featurenet")
+
+
 def step(timed=False):
-    run_stage("feature", lambda: check(lib.casmvs_featurenet_forward_fused_f32(
-        arr13, (tail_f32 if args.all_f32 else tail_sf).p, 0 if args.all_f32 else 1, bias9_d.p, ci5, imgs.p, feat[0].p if args.nchw_feats else None, feat[1].p if args.nchw_feats else None, feat[2].p,
-        feat_cl[0].p, feat_cl[1].p, feat_cl[2].p, feat_ws.p, N, H, W, ctypes.c_float(0.01), None, st), "featurenet"), timed)
+    run_stage("feature", feature_stage, timed)
     prev = None
     for l in (2, 1, 0):
         L = levels[l]
