@@ -2283,6 +2283,9 @@ extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
   return (size_t)B * floats * sizeof(float);
 }
 
+#ifndef CASMVS_ZFUSED_MIN_TILES
+#define CASMVS_ZFUSED_MIN_TILES 180   // conv11 + prob fused from this many 16 x 60 pixel tiles on (A/B builds: a huge value = never)
+#endif
 #ifndef CASMVS_ZM_CIN32
 #define CASMVS_ZM_CIN32 1   // conv0 at cin = 32 (cascade level 2) on conv0_zmarch.hip's warp-specialised kernel (0: the tiled kernel, A/B builds)
 #endif
@@ -2408,6 +2411,22 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV_T2, P[8], u7, c2, u9, B, 32, 16, D / 4, h / 4, w / 4, sl, stream);         // conv2 + conv9
+  }
+  // conv11 + `prob` + regression as ONE depth-walking kernel (conv11_prob_zfused.hip: the 8-channel tensor between them never reaches memory) where its
+  // 16 x 60 pixel tiles fill the chip: measured 1.26x / 1.27x / 1.12x the two kernels at 768 / 2816 / 192 tiles (cascade levels 1 / 0 / 2, batch 8), 1.05x at 352,
+  // 0.7x at 96 (profiles/r04_conv11_prob_zfused_first_run.txt).  The `conv11` interval of layer_events is then empty, `prob` times the fused kernel.
+  const long zf_tiles = (long)B * casmvs::ceil_div(h, 16) * casmvs::ceil_div(w, 60);
+  constexpr long zf_min_tiles = CASMVS_ZFUSED_MIN_TILES;
+  if (conv11_split && depth != nullptr && (reinterpret_cast<size_t>(conv11_split) & 15) == 0 && zf_tiles >= zf_min_tiles &&
+      casmvs_conv11_prob_zfused_supported(D / 2, h / 2, w / 2)) {
+    if (layer_events) {
+      (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);       // conv11
+      (void)hipEventRecord((hipEvent_t)layer_events[li + 1], (hipStream_t)stream);   // prob
+    }
+    rc = casmvs_conv11_prob_zfused_f32(conv11_split, P[10], u9, c0, depth_values, cost, depth, confidence, index, B, D / 2, h / 2, w / 2, sl, 1.0f, stream);
+    if (rc != CASMVS_OK) return rc;
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[11], (hipStream_t)stream);
+    return CASMVS_OK;
   }
   if (conv11_split && casmvs_deconv11_splitf16_supported(w / 2) && (reinterpret_cast<size_t>(conv11_split) & 15) == 0) {
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);

@@ -1,8 +1,8 @@
 // CostRegNet.conv11 = ConvTranspose3d(16 -> 8, k3 s2 p1, output_padding 1, no bias) + ABN + leaky-relu, then `conv0 + ...` (models/mvsnet.py:84-86,
 // 101) on the f16 matrix cores in the float32-grade split arithmetic of conv0_splitf16.hip.
 //
-// *** Written at the end of round 3 WITHOUT a GPU run (the round's GPU minutes were spent): an opt-in entry point, not what the engine
-// *** calls.  tools/native/deconv11_check.cpp is its first test (against casmvs_conv3d_forward_f32(CASMVS_CONV_T2) and a float64 loop).
+// Written at the end of round 3 without a GPU run (CPU emulation only: tests/hipemu); correct on its first launch in round 4
+// (profiles/r04_native_checks_first_run.txt, tools/native/deconv11_check.cpp) and since then the engine's default for this layer.
 //
 // Why.  deconv16_kernel runs this layer on the float32 MFMA at 370 us for the 8 x 32 x 256 x 320 volume (level 1, batch 8) - 0.9 ms of
 // the 8.5 ms step over the three levels - against 190 us of HBM time for what it moves (the 16-channel input at 1/8 of the voxels = 2 n

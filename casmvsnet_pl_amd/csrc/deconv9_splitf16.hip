@@ -1,8 +1,8 @@
 // CostRegNet.conv9 = ConvTranspose3d(32 -> 16, k3 s2 p1, output_padding 1, no bias) + ABN + leaky-relu, then `conv2 + ...` (models/mvsnet.py:80-82,
 // 99) on the f16 matrix cores in the float32-grade split arithmetic of conv0_splitf16.hip.  The sibling of deconv11_splitf16.hip for 16 output channels.
 //
-// *** Written at the end of round 3 WITHOUT a GPU run (the round's GPU minutes were spent): an opt-in entry point, not what the engine
-// *** calls.  tools/native/deconv9_check.cpp is its first test (against casmvs_conv3d_forward_f32(CASMVS_CONV_T2) and a float64 loop).
+// Written at the end of round 3 without a GPU run (CPU emulation only: tests/hipemu); correct on its first launch in round 4
+// (profiles/r04_native_checks_first_run.txt, tools/native/deconv9_check.cpp) and since then the engine's default for this layer.
 //
 // Form.  out[o] += in[i] w[k], o = 2 i - 1 + k per axis (even o: k = 1 from o / 2; odd o: k = 0 from (o + 1) / 2 and k = 2 from (o - 1) / 2).
 // With 16 output channels the MFMA rows are the channels; K = the 32 input channels of ONE input voxel; columns j = 16 consecutive input x

@@ -26,11 +26,8 @@
 
 #include "buffer_ops.h"
 #include "common.h"
+#include "prob_zwalk.h"
 #include "softmax_regress.h"
-
-#ifndef CASMVS_PZ_ABL
-#define CASMVS_PZ_ABL 0   // profiling builds only (WRONG results): 1 no FMAs, 2 no LDS tap reads, 4 no global loads, 8 no LDS staging
-#endif                    // writes, 16 no barriers, 32 no scalar weight loads (constants)
 
 namespace {
 
@@ -57,75 +54,6 @@ struct ProbZCfg {
   // SQ_LDS_IDX_ACTIVE, LDS-active time = the kernel's run time, VALU busy 29 % - profiles/r03_pmc_prob_zwalk.txt.)
   static_assert(RS % 4 == 0, "rows start 16-byte aligned");
 };
-
-// Contribution of the staged plane to the accumulators: A[2 - kz] += sum_{pair, ky, kx} in * w[kz][ky][kx] for the
-// kz in KZM (bit mask).  `rows`: this lane's first row / position inside the slot; wpk: the P1 weight image
-// ([pair][tap (27 + 5 zeros)][channel of the pair], conv3d_mfma.hip pack_weight) read as wave-uniform scalars.
-template <int KZM>
-__device__ __forceinline__ void zwalk_plane(const float *rows, const float *__restrict__ wpk, f32x2 (&A)[3][2]) {
-  using Cfg = ProbZCfg;
-  constexpr int NSTEP = Cfg::NPAIR * 3;  // step i = (pair i / 3, ky = i % 3)
-  // Software pipeline, pinned with sched_barrier: the two LDS rows AND the scalar weight loads of step i + 1 are issued
-  // before the FMAs of step i, so that the one wait a step needs (lgkmcnt(0): scalar loads return out of order, any wait
-  // on them is a full drain) finds everything landed.  (First version: the compiler issued each step's s_load / ds_read
-  // right in front of its own wait - 12 exposed scalar-cache + LDS latencies per plane with 72 FMA cycles between them:
-  // the kernel ran at a third of its VALU time whatever the chunking or the prefetch depth.)
-  f32x4v lo[2], hi[2];
-  f32x2 W[2][3][3];  // [buffer][kz][kx]: (even, odd channel) weights of the step
-  auto fetch = [&](auto buf_, int i) {
-    constexpr int BUF = decltype(buf_)::value;
-    const float *row = rows + (i / 3) * Cfg::SP + (i % 3) * Cfg::RS;
-    if (CASMVS_PZ_ABL & 2) {
-      lo[BUF] = f32x4v{1.f, 2.f, 3.f, (float)i};
-      hi[BUF] = lo[BUF];
-    } else {
-      lo[BUF] = *reinterpret_cast<const f32x4v *>(row);
-      hi[BUF] = *reinterpret_cast<const f32x4v *>(row + 4);
-    }
-    const float *wq = wpk + (i / 3) * 64 + (i % 3) * 6;  // taps (kz, ky, kx = 0..2) x (even, odd channel) at [kz * 18 + 2 kx + c]
-#pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-      if (!((KZM >> kz) & 1)) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
-        W[BUF][kz][kx] = (CASMVS_PZ_ABL & 32) ? f32x2{0.5f + kz, 0.25f * kx} : f32x2{wq[kz * 18 + 2 * kx], wq[kz * 18 + 2 * kx + 1]};
-    }
-  };
-  auto fmas = [&](auto buf_) {
-    constexpr int BUF = decltype(buf_)::value;
-    const f32x2 P[4] = {f32x2{lo[BUF][0], lo[BUF][1]}, f32x2{lo[BUF][2], lo[BUF][3]}, f32x2{hi[BUF][0], hi[BUF][1]}, f32x2{hi[BUF][2], hi[BUF][3]}};
-    if (CASMVS_PZ_ABL & 1) {   // keep the operands live without the 18 FMAs
-      A[1][0] = A[1][0] + P[0] + P[3];
-      if (KZM & 1) A[2][0] = A[2][0] + W[BUF][0][0];
-      if (KZM & 4) A[0][0] = A[0][0] + W[BUF][2][2];
-      return;
-    }
-    // tap by tap over the (up to) six independent accumulators (kz, pixel): no two consecutive FMAs depend on each other
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-      for (int kz = 0; kz < 3; ++kz) {
-        if (!((KZM >> kz) & 1)) continue;
-        A[2 - kz][0] = __builtin_elementwise_fma(P[kx], W[BUF][kz][kx], A[2 - kz][0]);
-        A[2 - kz][1] = __builtin_elementwise_fma(P[kx + 1], W[BUF][kz][kx], A[2 - kz][1]);
-      }
-    }
-  };
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  fetch(B0{}, 0);
-#pragma unroll
-  for (int i = 0; i < NSTEP; i += 2) {
-    fetch(B1{}, i + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    fmas(B0{});
-    __builtin_amdgcn_sched_barrier(0);
-    if (i + 2 < NSTEP) fetch(B0{}, i + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    fmas(B1{});
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
 
 // grid: x = tiles_x * tiles_y * chunks (XCD-major, chunk fastest, then x, then y), y = batch.
 // in (B, 8, Di, Hi, Wi), Wi % 4 == 0, 16-byte aligned; cost (B, Di, Hi, Wi) is always written.
@@ -241,9 +169,9 @@ __global__ __launch_bounds__(kThreads, 3) void prob_zwalk_kernel(
     else load_plane(Mine{}, zin + 1, it + 1 < nplanes && zin + 1 < Di);
     if (zin >= 0 && zin < Di) {
       const float *rows = cur + yi * RS + 4 * xi;
-      if (it == 0) zwalk_plane<1>(rows, wpk, A);                 // only output plane z_lo takes from plane z_lo - 1
-      else if (it == nplanes - 1) zwalk_plane<4>(rows, wpk, A);  // only output plane z_hi - 1 takes from plane z_hi
-      else zwalk_plane<7>(rows, wpk, A);
+      if (it == 0) casmvs::pz::zwalk_plane<1, Cfg::SP, Cfg::RS>(rows, wpk, A);                 // only output plane z_lo takes from plane z_lo - 1
+      else if (it == nplanes - 1) casmvs::pz::zwalk_plane<4, Cfg::SP, Cfg::RS>(rows, wpk, A);  // only output plane z_hi - 1 takes from plane z_hi
+      else casmvs::pz::zwalk_plane<7, Cfg::SP, Cfg::RS>(rows, wpk, A);
     }
     {  // output plane zin - 1 is complete; it lies in [z_lo, z_hi) from step 2 on
       float o0 = fmaf(A[0][0][0] + A[0][0][1], sc0, sh0), o1 = fmaf(A[0][1][0] + A[0][1][1], sc0, sh0);

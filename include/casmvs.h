@@ -395,6 +395,18 @@ int casmvs_prob_regress_f32(const float *packed, const float *in, const float *d
 int casmvs_debug_disturb(int kind, int blocks, int iters, int lds_bytes, float *sink, void *stream);
 #endif
 
+/* CostRegNet's tail as ONE kernel that walks the depth axis (csrc/conv11_prob_zfused.hip): conv11 = ConvTranspose3d(16 -> 8, k3 s2 p1 op1) + ABN +
+ * leaky-relu + skip (mvsnet.py:84-86,101), `prob` = Conv3d(8 -> 1, k3 p1, bias) (:89,104) and the softmax / regression / confidence (:174-193).  The
+ * 8-channel full-resolution tensor between the two layers never reaches memory.  deconv11_packed: DEVICE copy of casmvs_deconv11_splitf16_pack's
+ * image (16-byte aligned); prob_packed: device image of casmvs_conv3d_pack_f32(CASMVS_CONV_S1, 8, 1); in (B, 16, Di, Hi, Wi) (conv9's output), skip
+ * (B, 8, 2 Di, 2 Hi, 2 Wi) (conv0's output), depth_values / cost (B, 2 Di, 2 Hi, 2 Wi), depth / confidence (B, 2 Hi, 2 Wi), index: NULL or int32.
+ * Wi even; tensors 8-byte aligned.  slope: conv11's leaky-relu slope; prob_slope: 1 (no activation).  casmvs_costreg_regress_f32 selects it where the
+ * 16 x 60 pixel tiles fill the chip. */
+int casmvs_conv11_prob_zfused_supported(int Di, int Hi, int Wi);
+int casmvs_conv11_prob_zfused_f32(const void *deconv11_packed, const float *prob_packed, const float *in, const float *skip, const float *depth_values,
+                                  float *cost, float *depth, float *confidence, int32_t *index, int B, int Di, int Hi, int Wi, float slope,
+                                  float prob_slope, void *stream);
+
 /* Whole CostRegNet + regression: casmvs_costreg_forward_f32 with the head replaced by casmvs_prob_regress_f32.
  * `cost` (B, D, h, w) is still produced.  layer_events: as casmvs_costreg_forward_f32 (event 10 before the head,
  * event 11 after the head INCLUDING the regression).  conv0_arith selects conv0's arithmetic: CASMVS_CONV0_F32 (the float32
