@@ -76,6 +76,7 @@ def algorithmic_work(H, W, V, G, n_depths, B=1):
             "softmax_bytes": 4 * B * (2 * n + 2 * h * w),
             # the `prob` head fused with the regression: 8 input channels + hypotheses read, cost + 2 maps written
             "prob_regress_bytes": 4 * B * (8 * n + n + n + 2 * h * w),
+            "tail_bytes": 4 * B * (2 * n + 8 * n + n + n + 2 * h * w),   # conv11 in (16 ch at n / 8 voxels), skip, hypotheses, cost, depth + confidence
             "conv0_flops": 2 * 27 * cin * 8 * n * B,
             "costreg_flops": (2 * 27 * cin * 8 + 6480) * n * B,
         }
@@ -419,12 +420,20 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
                                "ms_per_depth_map": cv_ms / n_ev / B, "batch": B,
                                "per_level_frac": {str(l): work[l]["costvol_bytes"] * n_ev / (summ[f"costvol_{l}"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS for l in range(3)}}
     if fused:
-        pr_ms = max(1e-6, sum(summ[f"costreg_{l}/prob"]["ms"] for l in range(3)))
-        pr_bytes = sum(work[l]["prob_regress_bytes"] for l in range(3)) * n_ev
-        out["roofline_prob_regress"] = {"kernel": "prob_zwalk_kernel (+ softmax_regress_kernel where the depth range is chunked): the `prob` head "
-                                                  "and mvsnet.py:174-193, 3 library calls per step", "bound": "hbm",
+        # the regulariser's tail = conv11 (+ skip) + `prob` + regression: ONE depth-walking kernel where its tiles fill the chip (conv11_prob_zfused.hip; the
+        # `conv11` interval is then empty and `prob` times the fused kernel), else deconv11_sf_kernel + prob_zwalk_kernel.  Algorithmic bytes of the pair WITHOUT
+        # the 8-channel tensor between them (conv9's output: 16 channels at n / 8 voxels = 2 n floats, the skip tensor 8 n, hypotheses n, cost n, two maps): what the
+        # fused kernel has to move; the two-kernel form moves 16 n more.
+        pr_ms = max(1e-6, sum(summ[f"costreg_{l}/prob"]["ms"] + summ[f"costreg_{l}/conv11"]["ms"] for l in range(3)))
+        pr_bytes = sum(work[l]["tail_bytes"] for l in range(3)) * n_ev
+        zf = [B * -(-(H >> l) // 16) * -(-(W >> l) // 60) >= 180 and getattr(getattr(model, f"cost_reg_{l}"), "_ci_active", False) for l in range(3)]
+        out["roofline_prob_regress"] = {"kernel": "CostRegNet's tail (mvsnet.py:84-89,101,104,174-193), per level: " +
+                                                  ", ".join(f"level {l}: " + ("conv11_prob_zfused_kernel" if zf[l] else "deconv11_sf_kernel + prob_zwalk_kernel (+ softmax_regress_kernel)")
+                                                            for l in (2, 1, 0)), "bound": "hbm",
                                         "achieved": pr_bytes / (pr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": pr_bytes / (pr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": pr_ms / n_ev, "batch": B}
+                                        "frac": pr_bytes / (pr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": pr_ms / n_ev, "batch": B,
+                                        "note": "algorithmic bytes = conv9's output + the skip tensor + hypotheses + cost + depth / confidence; the tensor between conv11 and "
+                                                "`prob` (16 n floats of traffic in the two-kernel form) is not counted"}
     else:
         sm_ms = sum(summ[f"softmax_{l}"]["ms"] for l in range(3))
         sm_bytes = sum(work[l]["softmax_bytes"] for l in range(3)) * n_ev

@@ -18,6 +18,13 @@
 //       loads were issued two planes earlier, its maximum published one plane earlier (no extra barrier).
 //   (c) after the barrier: `prob`'s 108 packed FMAs per voxel on slot[z & 1] into three rotating accumulators; output plane z - 1 is complete: cost store.
 // After the walk every thread runs the softmax regression on the cost values of its two pixels (its own stores), as prob_zwalk_kernel does.
+//
+// Measured (MI355X, batch 8; profiles/r04_conv11_prob_zfused_*.txt): 1.26x / 1.27x / 1.12x the two kernels at levels 1 / 0 / 2 (640 -> 509 us), 0.28 ms of the
+// step.  Shader-clock trace of a plane step (-DCASMVS_ZF_TRACE, tools/native/zf_trace.cpp): ~9 350 cycles = matrix phase 750-1 700, epilogue 1 400-2 300,
+// next loads + box ring 800-3 300, barrier 600-2 700, `prob`'s multiply phase 2 000-3 700, cost store 430-540: a chain of vector-issue-bound phases
+// (~1 000 vector instructions per SIMD and step) with the 8 waves in step.  A variant with producer waves (conv11 of plane s) beside consumer waves (`prob` of
+// plane s - 1, two row groups per thread; commit 5dbb662) ran at the same speed (480 / 517 us: the producers' own chain - 9 units' epilogues, all loads - is as
+// long as the whole step) and was removed; what would shorten the step is fewer vector instructions: `prob` on the matrix cores, packed epilogue arithmetic.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -146,8 +153,9 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
   };
 
   // ---- (b) box staging item of this thread: (channel half, box row, pair of columns) ----
-  const bool stager = tid < Cfg::ITEMS;
-  const int s_h = tid / (JY * (JX / 2)), s_rem = tid - s_h * (JY * (JX / 2)), s_r = s_rem / (JX / 2), s_g = s_rem - s_r * (JX / 2);
+  const int s_e = tid - (Cfg::THREADS - Cfg::ITEMS);   // the LAST 360 threads: waves 4-7 own four matrix units each, waves 0-3 five
+  const bool stager = s_e >= 0;
+  const int s_h = s_e / (JY * (JX / 2)), s_rem = s_e - s_h * (JY * (JX / 2)), s_r = s_rem / (JX / 2), s_g = s_rem - s_r * (JX / 2);
   const int s_unit = s_h * NVB + s_r * JX + 2 * s_g;
   int s_voff;
   {
@@ -373,342 +381,9 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
   }
 }
 
-
-// ---- the same walk with the two halves of a step on DIFFERENT wave groups -------------------------------------------------------------------------------
-// conv11_prob_zfused_kernel above runs (a) and (c) of a plane one after the other on all 8 waves: two waves per SIMD, in the same phase at the same
-// time (the barrier keeps them there), so the matrix pipe idles during (c) and the vector pipe stalls on its operand reads alone: 12 700 cycles per plane
-// against ~2 400 of vector issue (first GPU run, 509 us at level 1: profiles/r04_conv11_prob_zfused_first_run.txt).  Here waves 0-3 PRODUCE plane s
-// ((a) + (b)) while waves 4-7 CONSUME plane s - 1 ((c), two row groups per thread): every SIMD holds one wave of each kind, the matrix instructions of the
-// one fill the operand waits of the other.  One barrier per step, Do + 1 steps.
-template <int N, class F>
-__device__ __forceinline__ void fz_static_for(F &&f) {
-  if constexpr (N > 0) {
-    fz_static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
-// a producer wave's 9 matrix units: column tile wave & 1, slot rows 9 HI .. 9 HI + 8 (HI = wave >> 1): both row parities in every wave (13 / 14 taps)
-template <bool HI>
-struct FzUnits {
-  static constexpr int NQ = 9;
-  static constexpr int row(int q) { return (HI ? 9 : 0) + q; }
-  static constexpr bool rodd(int q) { return (row(q) & 1) != 0; }               // odd slot row = even output row: tap ky = 1 only
-  static constexpr int NEVEN = HI ? 4 : 5, NODDR = NQ - NEVEN;
-  static constexpr int NG = 2 * NEVEN + NODDR;                                   // granules: ky = 0 and ky = 2 of the even rows, then ky = 1 of the odd rows
-  static constexpr int gky(int g) { return g < NEVEN ? 0 : (g < 2 * NEVEN ? 2 : 1); }
-  static constexpr int gq(int g) {                                               // the (g mod group)-th unit of the group's row parity
-    const bool want_odd = g >= 2 * NEVEN;
-    int n = want_odd ? g - 2 * NEVEN : (g < NEVEN ? g : g - NEVEN);
-    for (int q = 0; q < NQ; ++q)
-      if (rodd(q) == want_odd && n-- == 0) return q;
-    return 0;
-  }
-  // box row of (unit q, tap ky): odd slot row r: (r + 1) / 2; even: ky = 0 from r / 2 + 1, ky = 2 from r / 2
-  static constexpr int rb(int g) { return rodd(gq(g)) ? (row(gq(g)) + 1) / 2 : (gky(g) == 0 ? row(gq(g)) / 2 + 1 : row(gq(g)) / 2); }
-};
-
-template <int DT>
-__global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zws_kernel(
-    const float *__restrict__ in, const unsigned char *__restrict__ wdc, const float *__restrict__ skip, const float *__restrict__ wpk,
-    const float *__restrict__ dvals, float *cost, float *__restrict__ depth, float *__restrict__ conf, int32_t *__restrict__ index, int Di, int Hi, int Wi,
-    int tiles_x, int tiles_y, float slope, float pslope) {
-  using Cfg = FzCfg;
-  constexpr int RS = Cfg::RS, SP = Cfg::SP, SLOT = Cfg::SLOT, JX = Cfg::JX, JY = Cfg::JY, NVB = Cfg::NVB, BOX = Cfg::BOX;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float *slots = reinterpret_cast<float *>(smem_raw);
-  u32x4 *box = reinterpret_cast<u32x4 *>(smem_raw + 2 * Cfg::SLOT_BYTES);
-  u32x4 *wl = reinterpret_cast<u32x4 *>(smem_raw + 2 * Cfg::SLOT_BYTES + 2 * Cfg::BOX_BYTES);
-  unsigned *wmax = reinterpret_cast<unsigned *>(smem_raw + 2 * Cfg::SLOT_BYTES + 2 * Cfg::BOX_BYTES + Cfg::W_BYTES);   // [2 sets][4 producer waves]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
-  const int iHW = Hi * Wi, ics = Di * iHW, oHW = Ho * Wo, ocs = Do * oHW;
-  const int bid = xcd_major(blockIdx.x, gridDim.x);
-  const int tx0 = (bid % tiles_x) * Cfg::TX, ty0 = (bid / tiles_x) * Cfg::TY;
-  const int b = blockIdx.y;
-  for (int unit = tid; unit < Cfg::WUNITS; unit += Cfg::THREADS) wl[unit] = reinterpret_cast<const u32x4 *>(wdc)[unit];
-
-  if (wave < 4) {
-    // ======================================================= producers: conv11's plane s -> slot[s & 1] =======================================================
-    const int jcol = lane & 15, kb = lane >> 4, half = kb & 1, dx = kb >> 1, u = kb;
-    const int ix0 = tx0 / 2, iy0 = ty0 / 2;
-    const rsrc_t isrc = make_rsrc(in + (size_t)b * 16 * ics, (size_t)16 * ics * 4);
-    const rsrc_t ssrc = make_rsrc(skip + (size_t)b * 8 * ocs, (size_t)8 * ocs * 4);
-    const rsrc_t none = make_rsrc(in, 0);
-    const float *dtail = reinterpret_cast<const float *>(wdc + Cfg::W_BYTES);
-    float sc[2], sh[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      sc[h] = dtail[2 * u + h];
-      sh[h] = dtail[8 + 2 * u + h];
-    }
-    const int tile = wave & 1;
-    const int J = 16 * tile + jcol;
-    const int bcol = half * NVB + J + dx + 1;
-    const int ox = tx0 - 2 + 2 * J;
-    const bool x_in = ox >= 0 && ox < Wo;
-    // box staging item: (box row, pair of columns), all 16 channels
-    const bool stager = tid < JY * (JX / 2);
-    const int s_r = tid / (JX / 2), s_g = tid - s_r * (JX / 2);
-    const int s_unit = s_r * JX + 2 * s_g;
-    int s_voff;
-    {
-      const int gy = iy0 - 1 + s_r, gx = ix0 - 2 + 2 * s_g;
-      const bool ok = stager && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
-      s_voff = ok ? (gy * Wi + gx) * 4 : kOOB;
-    }
-    f32x2 R[16];
-    auto load_box = [&](int iz) {
-      const bool exists = iz < Di;
-      const rsrc_t r = exists ? isrc : none;
-      const int soff = exists ? iz * iHW * 4 : 0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) R[c] = buf_load2(r, s_voff, soff + c * ics * 4);
-    };
-    auto box_max = [&](int set) {
-      float m0 = 0.0f, m1 = 0.0f;
-#pragma unroll
-      for (int c = 0; c < 16; c += 2) {
-        m0 = fmaxf(m0, fmaxf(fabsf(R[c][0]), fabsf(R[c][1])));
-        m1 = fmaxf(m1, fmaxf(fabsf(R[c + 1][0]), fabsf(R[c + 1][1])));
-      }
-      const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, fmaxf(m0, m1)));
-      if (lane == 0) wmax[set * 4 + wave] = wm;
-    };
-    auto box_write = [&](int plane_slot, float mult) {
-      if (stager) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            float x[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) x[c] = R[hf * 8 + c][p];
-            casmvs::split_u32x4 o[2];
-            casmvs::split8_f16(x, mult, o);
-            u32x4 *dst = box + plane_slot * BOX + hf * NVB + s_unit + p;
-            dst[0] = o[0];
-            dst[2 * NVB] = o[1];
-          }
-      }
-    };
-    float inv_b[2];
-    auto produce = [&](auto hi_) {
-      constexpr bool HI = decltype(hi_)::value;
-      using U = FzUnits<HI>;
-      constexpr int NQ = U::NQ, NG = U::NG;
-      int sk_off[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int oy = ty0 - 1 + U::row(q);
-        sk_off[q] = (oy >= 0 && oy < Ho && x_in) ? ((2 * u) * ocs + oy * Wo + ox) * 4 : kOOB;
-      }
-      f32x2 SK[NQ][2];
-      auto load_skip = [&](int z, bool exists) {
-        const rsrc_t r = exists ? ssrc : none;
-        const int soff = exists ? z * oHW * 4 : 0;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) SK[q][h] = buf_load2(r, sk_off[q], soff + h * ocs * 4);
-      };
-      auto pstep = [&](int k, auto odd_) {
-        constexpr bool ODD = decltype(odd_)::value;
-        const int z = 2 * k + (ODD ? 1 : 0);
-        float *slot = slots + (ODD ? SLOT : 0);
-        const int pa = ODD ? ((k + 1) & 1) : (k & 1), pb = k & 1;
-        const float inv0 = pa ? inv_b[1] : inv_b[0], inv1 = pb ? inv_b[1] : inv_b[0];
-        f32x4 acc0[NQ], acc1[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc0[q] = acc1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
-        const u32x4 *b0 = box + pa * BOX + bcol, *b1 = box + pb * BOX + bcol;
-        u32x4 a0[2], a1[2], bvb[2][2][2];   // lane images [slice] of chain 0 / 1 (one tap at a time); B operands [buffer][chain][slice]
-        auto fetch = [&](auto g_) {
-          constexpr int g = decltype(g_)::value, off = U::rb(g) * JX;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            bvb[g & 1][0][s] = b0[s * 2 * NVB + off];
-            if (ODD) bvb[g & 1][1][s] = b1[s * 2 * NVB + off];
-          }
-        };
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(std::integral_constant<int, 0>{});
-        fz_static_for<NG>([&](auto g_) {
-          constexpr int g = decltype(g_)::value, q = U::gq(g), ky = U::gky(g);
-          if constexpr (g == 0 || U::gky(g > 0 ? g - 1 : 0) != ky) {   // the first granule of a tap: its lane images
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              a0[s] = wl[(((ODD ? 0 : 1) * 3 + ky) * 2 + s) * 64 + lane];
-              if (ODD) a1[s] = wl[((2 * 3 + ky) * 2 + s) * 64 + lane];
-            }
-          }
-          if constexpr (g + 1 < NG) fetch(std::integral_constant<int, g + 1>{});
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            acc0[q] = fz_mfma(a0[PA[p]], bvb[g & 1][0][PB[p]], acc0[q]);
-            if (ODD) acc1[q] = fz_mfma(a1[PA[p]], bvb[g & 1][1][PB[p]], acc1[q]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        // epilogue -> slot rows 9 HI + q
-        float *slot_lane = slot + u * SP + U::row(0) * RS + 4 * J;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const bool in_vol = sk_off[q] != kOOB;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float t = acc0[q][r] * inv0;
-            if (ODD) t = t + acc1[q][r] * inv1;
-            t = fmaf(t, sc[r >> 1], sh[r >> 1]);
-            t = t > 0.0f ? t : t * slope;
-            t = t + SK[q][r >> 1][r & 1];
-            v[r] = in_vol ? t : 0.0f;
-          }
-          float *prow = slot_lane + q * RS;
-          if (J >= 1) *reinterpret_cast<f32x2 *>(prow - 2) = f32x2{v[0], v[2]};
-          if (J <= Cfg::TX / 2) *reinterpret_cast<f32x2 *>(prow) = f32x2{v[1], v[3]};
-        }
-        load_skip(z + 1, z + 1 < Do);
-        if (!ODD) {
-          if (k >= 1) {
-            float mult, inv;
-            casmvs::tile_scale(wmax + ((k + 1) & 1) * 4, mult, inv);
-            box_write((k + 1) & 1, mult);
-            if ((k + 1) & 1) inv_b[1] = inv;
-            else inv_b[0] = inv;
-          }
-          load_box(k + 2);
-        } else {
-          box_max(k & 1);
-        }
-        __syncthreads();
-      };
-      // prologue: input planes 0 and 1 into the box ring (three barriers, the consumers join them), the skip values of plane 0
-      load_box(0);
-      load_skip(0, true);
-      box_max(0);
-      __syncthreads();
-      {
-        float mult;
-        casmvs::tile_scale(wmax, mult, inv_b[0]);
-        box_write(0, mult);
-      }
-      load_box(1);
-      box_max(1);
-      __syncthreads();
-      {
-        float mult;
-        casmvs::tile_scale(wmax + 4, mult, inv_b[1]);
-        box_write(1, mult);
-      }
-      __syncthreads();
-      for (int k = 0; k < Di; ++k) {
-        pstep(k, std::false_type{});
-        pstep(k, std::true_type{});
-      }
-      __syncthreads();   // step Do: the consumers' last plane
-    };
-    if (wave >> 1) produce(std::true_type{});
-    else produce(std::false_type{});
-    return;
-  }
-
-  // ========================================================= consumers: `prob` on plane s - 1, two row groups per thread =========================================================
-  const int ct = tid - 256, xi = ct & 31, yi0 = ct >> 5;
-  const rsrc_t cdst = make_rsrc(cost + (size_t)b * ocs, (size_t)ocs * 4);
-  const float *ptail = wpk + 8 * 32;
-  const float psc = ptail[0], psh = ptail[4];
-  const int oxp = tx0 + 2 * xi;
-  int out_voff[2];
-  bool pix_ok[2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int oy = ty0 + yi0 + 8 * g;
-    pix_ok[g] = 2 * xi < Cfg::TX && oy < Ho && oxp < Wo;
-    out_voff[g] = pix_ok[g] ? (oy * Wo + oxp) * 4 : kOOB;
-  }
-  f32x2 A[2][3][2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) A[g][i][0] = A[g][i][1] = f32x2{0.f, 0.f};
-  auto finish = [&](int zout, bool store) {   // output plane zout is complete in A[.][0]
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      float o0 = fmaf(A[g][0][0][0] + A[g][0][0][1], psc, psh), o1 = fmaf(A[g][0][1][0] + A[g][0][1][1], psc, psh);
-      o0 = o0 > 0.0f ? o0 : o0 * pslope;
-      o1 = o1 > 0.0f ? o1 : o1 * pslope;
-      buf_store2(f32x2{o0, o1}, cdst, store ? out_voff[g] : kOOB, store ? zout * oHW * 4 : 0);
-    }
-  };
-  __syncthreads();   // the producers' prologue
-  __syncthreads();
-  __syncthreads();
-  __syncthreads();   // step 0: plane 0 is being produced
-  for (int z = 0; z < Do; ++z) {
-    const float *slot = slots + (z & 1) * SLOT;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      casmvs::pz::zwalk_plane<7, SP, RS>(slot + (yi0 + 8 * g) * RS + 4 * xi, wpk, A[g]);
-#ifndef HIPEMU_LDS_BYTES
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(A[g][i][j]));   // (as in conv11_prob_zfused_kernel: keeps the plane's FMAs here)
-#endif
-    }
-    finish(z - 1, z >= 1);
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      A[g][0][0] = A[g][1][0];
-      A[g][0][1] = A[g][1][1];
-      A[g][1][0] = A[g][2][0];
-      A[g][1][1] = A[g][2][1];
-      A[g][2][0] = A[g][2][1] = f32x2{0.f, 0.f};
-    }
-    __syncthreads();   // step z + 1
-  }
-  finish(Do - 1, true);
-#ifndef HIPEMU_LDS_BYTES
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    if (pix_ok[g]) {
-      const size_t pix = (size_t)(ty0 + yi0 + 8 * g) * Wo + oxp;
-      const float *cp = cost + (size_t)b * ocs + pix, *dp = dvals + (size_t)b * ocs + pix;
-      const size_t o = (size_t)b * oHW + pix;
-#pragma nounroll
-      for (int j = 0; j < 2; ++j) {
-        float d, c;
-        int ix;
-        casmvs::softmax_regress_pixel<DT>(cp + j, dp + j, (size_t)oHW, Do, d, c, ix);
-        depth[o + j] = d;
-        conf[o + j] = c;
-        if (index) index[o + j] = ix;
-      }
-    }
-  }
-}
-
 }  // namespace
 
 // Do = 2 Di planes of Ho x Wo = 2 Hi x 2 Wi pixels; the whole depth range is walked by one workgroup per 16 x 60 pixel tile.
-#ifndef CASMVS_ZF_WS
-#define CASMVS_ZF_WS 1   // 1: producer / consumer wave groups (conv11_prob_zws_kernel); 0: all waves in step (conv11_prob_zfused_kernel; A/B builds)
-#endif
-#ifdef HIPEMU_LDS_BYTES   // tests/hipemu runs both
-static int g_zf_emu_ws = 1;
-#define CASMVS_ZF_KERNEL(DT) (g_zf_emu_ws ? conv11_prob_zws_kernel<DT> : conv11_prob_zfused_kernel<DT>)
-#elif CASMVS_ZF_WS
-#define CASMVS_ZF_KERNEL(DT) conv11_prob_zws_kernel<DT>
-#else
-#define CASMVS_ZF_KERNEL(DT) conv11_prob_zfused_kernel<DT>
-#endif
-
 extern "C" int casmvs_conv11_prob_zfused_supported(int Di, int Hi, int Wi) { return Di >= 1 && Hi >= 1 && Wi >= 2 && Wi % 2 == 0; }
 
 extern "C" int casmvs_conv11_prob_zfused_f32(const void *deconv11_packed, const float *prob_packed, const float *in, const float *skip,
@@ -727,7 +402,7 @@ extern "C" int casmvs_conv11_prob_zfused_f32(const void *deconv11_packed, const 
   dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)B), blk(Cfg::THREADS);
 #define CASMVS_FZ(DT)                                                                                                                        \
   do {                                                                                                                                       \
-    auto kernel = CASMVS_ZF_KERNEL(DT);                                                                                                      \
+    auto kernel = conv11_prob_zfused_kernel<DT>;                                                                                             \
     if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), Cfg::LDS_BYTES, "conv11_prob_zfused_kernel")) return rc; \
     hipLaunchKernelGGL(kernel, grid, blk, Cfg::LDS_BYTES, st, in, reinterpret_cast<const unsigned char *>(deconv11_packed), skip, prob_packed, \
                        depth_values, cost, depth, confidence, index, Di, Hi, Wi, tiles_x, tiles_y, slope, prob_slope);                        \

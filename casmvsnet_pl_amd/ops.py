@@ -393,7 +393,7 @@ def deconv11_splitf16_pack(weight, scale=None, shift=None):
 
 def deconv11_splitf16_forward(packed, x, skip=None, slope=0.01):
     """conv11 (+ ABN + leaky-relu + skip) on the f16 matrix cores (casmvs_deconv11_splitf16_forward_f32): x (B,16,Di,Hi,Wi), skip (B,8,2Di,2Hi,2Wi) or
-    None -> (B,8,2Di,2Hi,2Wi).  Opt-in (added without a GPU run at the end of round 3)."""
+    None -> (B,8,2Di,2Hi,2Wi)."""
     x = _dev(x, "x")
     if not packed.is_cuda or packed.dtype != torch.uint8:
         raise RuntimeError("deconv11_splitf16_forward: `packed` must be the uint8 image on the MI355X")
@@ -592,6 +592,30 @@ def prob_regress(packed, x, depth_values=None, slope=1.0, zchunk=0, return_index
     _lib.check(rc, "casmvs_prob_regress_f32")
     if depth_values is None:
         return cost
+    return (cost, depth, conf, index) if return_index else (cost, depth, conf)
+
+
+def conv11_prob_zfused(deconv11_packed, prob_packed, x, skip, depth_values, slope=0.01, prob_slope=1.0, return_index=False):
+    """CostRegNet's tail as one depth-walking kernel (casmvs_conv11_prob_zfused_f32): conv11 + ABN + leaky-relu + skip, `prob`, softmax / regression /
+    confidence.  deconv11_packed: device uint8 image of deconv11_splitf16_pack; prob_packed: device image of conv3d_pack(CONV_S1, prob weight (1,8,3,3,3), None, bias);
+    x (B,16,Di,Hi,Wi), skip (B,8,2Di,2Hi,2Wi), depth_values (B,2Di,2Hi,2Wi) -> cost (B,2Di,2Hi,2Wi), depth, confidence (B,2Hi,2Wi) [, index]."""
+    x, skip, depth_values, prob_packed = _dev(x, "x"), _dev(skip, "skip"), _dev(depth_values, "depth_values"), _dev(prob_packed, "prob_packed")
+    if not deconv11_packed.is_cuda or deconv11_packed.dtype != torch.uint8:
+        raise RuntimeError("conv11_prob_zfused: `deconv11_packed` must be the uint8 image on the MI355X")
+    B, cin, Di, Hi, Wi = x.shape
+    D, h, w = 2 * Di, 2 * Hi, 2 * Wi
+    if cin != 16 or tuple(skip.shape) != (B, 8, D, h, w) or tuple(depth_values.shape) != (B, D, h, w):
+        raise ValueError(f"conv11_prob_zfused: shapes {tuple(x.shape)} {tuple(skip.shape)} {tuple(depth_values.shape)}")
+    dev = x.device
+    cost = torch.empty((B, D, h, w), dtype=torch.float32, device=dev)
+    depth = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+    conf = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+    index = torch.empty((B, h, w), dtype=torch.int32, device=dev) if return_index else None
+    with torch.cuda.device(dev):
+        rc = _lib.load().casmvs_conv11_prob_zfused_f32(ctypes.c_void_p(deconv11_packed.data_ptr()), _ptr(prob_packed), _ptr(x), _ptr(skip), _ptr(depth_values),
+                                                       _ptr(cost), _ptr(depth), _ptr(conf), _ptr(index), B, Di, Hi, Wi, float(slope), float(prob_slope),
+                                                       _stream(x, f16=True))
+    _lib.check(rc, "casmvs_conv11_prob_zfused_f32")
     return (cost, depth, conf, index) if return_index else (cost, depth, conf)
 
 

@@ -115,9 +115,6 @@ int main(int argc, char **argv) {
   double worst = 0;
   auto take = [&](double e) { worst = std::fmax(worst, e); };
   const bool all = which == "all", quick = which == "quick";
-  g_zf_emu_ws = 0;                                       // all waves in step (the A/B kernel)
-  if (all) { take(fused_check(1, 2, 5, 34)); take(fused_check(1, 3, 9, 32)); }
-  g_zf_emu_ws = 1;                                       // producer / consumer wave groups (production)
   if (all || quick) take(fused_check(1, 2, 5, 34));      // one tile in y (10 of 16 rows), two in x (60 + 8): generic depth (4 planes)
   if (all) {
     take(fused_check(2, 4, 9, 32));                      // depth 8 (compile-time softmax), two tiles in y, 64 = 60 + 4 columns

@@ -654,6 +654,12 @@ def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
     x11, s11 = rnd(2, 16, 16, 128, 160).to(dev), rnd(2, 8, 32, 256, 320).to(dev)
     p11 = ops.deconv11_splitf16_pack(rnd(16, 8, 3, 3, 3, amp=0.1), torch.ones(8), torch.zeros(8)).to(dev)
     cases.append(("deconv11_sf", lambda: ops.deconv11_splitf16_forward(p11, x11, s11)))
+    # conv11 + prob + regression walking the depth axis (levels 1 / 0 of the cascade; level 2's 48 planes run inside the batch-8 graph below)
+    for Di, Hi, Wi in ((16, 64, 80), (4, 128, 160)):
+        xz, sz = rnd(2, 16, Di, Hi, Wi).to(dev), rnd(2, 8, 2 * Di, 2 * Hi, 2 * Wi).to(dev)
+        dz = (400.0 + rnd(2, 2 * Di, 2 * Hi, 2 * Wi).abs()).to(dev)
+        ppz = ops.conv3d_pack(ops.CONV_S1, rnd(1, 8, 3, 3, 3, amp=0.3), None, torch.zeros(1)).to(dev)
+        cases.append((f"conv11_prob_zfused<{2 * Di}>", lambda xz=xz, sz=sz, dz=dz, ppz=ppz: torch.cat([t.flatten() for t in ops.conv11_prob_zfused(p11, ppz, xz, sz, dz)])))
     # FeatureNet: the fused tail and the three 2D channel-inner forms
     lw, lb = rnd(32, 8, 1, 1, amp=0.3), rnd(32)
     sw, sb = rnd(8, 32, 3, 3, amp=0.2), rnd(8)
@@ -687,7 +693,7 @@ def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
         out = gf()
         bad["graph_batch8"] += 0 if all(torch.equal(out[k], ref[k]) for k in ref) else 1
     report("split_f16_bit_stability", launches=launches, differing=bad)
-    assert len(bad) == 21 and not any(bad.values()), bad
+    assert len(bad) == 23 and not any(bad.values()), bad
 
 
 @pytest.mark.parametrize("cin,shape", [(8, (2, 8, 48, 64)), (16, (1, 9, 17, 44)), (32, (1, 12, 32, 40))])
@@ -732,6 +738,45 @@ def test_deconv_splitf16_equals_the_layer(dev, report, which, shape):
     e_sf, e_f32 = scaled_err(got, ref), scaled_err(f32, ref)
     report("deconv_splitf16", which=which, shape=list(shape), err_splitf16=e_sf, err_f32_mfma=e_f32)
     assert torch.isfinite(got).all() and e_sf < 3e-6 and e_sf < 4 * max(e_f32, 2e-7)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 5, 34), (2, 4, 9, 32), (1, 3, 8, 62), (1, 1, 1, 2), (2, 16, 24, 40), (8, 4, 32, 40)])
+def test_conv11_prob_zfused_equals_the_three_layers(dev, report, shape):
+    """csrc/conv11_prob_zfused.hip: conv11 (ConvTranspose3d 16 -> 8 k3 s2 p1 op1 + ABN + leaky-relu, + conv0's output), `prob` (Conv3d 8 -> 1 + bias) and the
+    softmax regression (mvsnet.py:84-89,101,104,174-193) as ONE depth-walking kernel against the layers in float64 (cost, depth, confidence; index away from
+    trunc() boundaries) and against the two kernels it replaces; image borders inside a tile, several tiles, 4 / 8 / 6 / 2 / 32 / 8 planes; twice for the bits."""
+    ops = _ops()
+    B, Di, Hi, Wi = shape
+    D, h, w = 2 * Di, 2 * Hi, 2 * Wi
+    g = torch.Generator().manual_seed(Di * 10 + Wi)
+    x = torch.randn(B, 16, Di, Hi, Wi, generator=g) * 2
+    x[:, :, ::2] *= 25.0                         # neighbouring input planes of very different magnitude: the two chains of an odd plane carry different scales
+    skip = torch.randn(B, 8, D, h, w, generator=g)
+    w11 = torch.randn(16, 8, 3, 3, 3, generator=g) * 0.2
+    sc, sh = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+    wp, bp = torch.randn(1, 8, 3, 3, 3, generator=g) * 0.3, torch.randn(1, generator=g) * 0.1
+    dv = (425.0 + 2.5 * torch.arange(D).view(1, D, 1, 1) + 0.01 * torch.rand(B, 1, h, w, generator=g)).expand(B, D, h, w).contiguous()
+    u11 = F.conv_transpose3d(x.double(), w11.double(), None, stride=2, padding=1, output_padding=1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1)
+    u11 = torch.where(u11 > 0, u11, u11 * 0.01) + skip.double()
+    cref = F.conv3d(u11, wp.double(), bp.double(), padding=1).squeeze(1)
+    p = torch.softmax(cref, 1)
+    dref = (p * dv.double()).sum(1)
+    iref = (p * torch.arange(D, dtype=torch.float64).view(1, D, 1, 1)).sum(1)
+    p11, pp = ops.deconv11_splitf16_pack(w11, sc, sh).to(dev), ops.conv3d_pack(ops.CONV_S1, wp, None, bp).to(dev)
+    xd, sd, dd = x.to(dev), skip.to(dev), dv.to(dev)
+    cost, depth, conf, index = ops.conv11_prob_zfused(p11, pp, xd, sd, dd, return_index=True)
+    again = ops.conv11_prob_zfused(p11, pp, xd, sd, dd, return_index=True)
+    assert all(torch.equal(a, b) for a, b in zip((cost, depth, conf, index), again))
+    c2, d2, f2 = ops.prob_regress(pp, ops.deconv11_splitf16_forward(p11, xd, sd), dd)
+    e_cost, e_two = scaled_err(cost.cpu(), cref), scaled_err(c2.cpu(), cref)
+    e_depth = float(((depth.cpu().double() - dref).abs() / dref).max())
+    settled = (iref - iref.round()).abs() > 1e-3
+    idx_off = int(((index.cpu().long() != iref.floor().clamp(0, D - 1).long()) & settled).sum())
+    report("conv11_prob_zfused", shape=list(shape), err_cost=e_cost, err_cost_two_kernels=e_two, err_depth_rel=e_depth, indices_off=idx_off,
+           vs_two_kernels_depth_rel=float(((depth - d2).abs() / d2.abs()).max()))
+    assert torch.isfinite(cost).all() and torch.isfinite(depth).all() and torch.isfinite(conf).all()
+    assert e_cost < 3e-6 and e_cost < 4 * max(e_two, 2e-7) and e_depth < 2e-5 and idx_off == 0
+    assert float((conf - f2).abs().max()) < 1e-2   # (a window of four probabilities: a trunc() boundary moves it)
 
 
 @pytest.mark.parametrize("kernel", ["conv0_sf", "conv0_zm", "conv_ci_sf", "conv_s2_sf"])

@@ -8,6 +8,7 @@ the f16 and float32 MFMAs with the lane layouts the MI355X self-tests verified, 
   run_kernels6  FPN tail split-f16 (production)                       run_kernels7  LDS-staged plane sweep / variance volume (production)
   run_kernels8  training: conv_wgrad (all kinds, both LDS layouts), channel sums, variance-volume backward
   run_kernels9  the float32 matrix-core layers of conv3d_mfma.hip (3D stride 1 / 2 / transposed + skip, 2D k3 / k5 s2)
+  run_kernels10 conv11 + prob + softmax regression as one depth-walking kernel (round 4; 512-thread workgroups)
 
 The kernels written at the end of round 3 without access to a GPU RUN here for the first time - ragged shapes, persistent workgroups that walk several
 items, z segments.  The same sources under ThreadSanitizer (a missing barrier is a reported race) and under an LDS bank-conflict / cache-line profile built
@@ -24,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = os.environ.get("HIPEMU_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
 
 
-DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7", "run_kernels8", "run_kernels9")
+DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7", "run_kernels8", "run_kernels9", "run_kernels10")
 PROFILED = ("run_kernels", "run_kernels3")
 # costvol_lds.hip instantiates 30 kernels: its ThreadSanitizer build alone takes 80 s - part of the suite only with HIPEMU_FULL=1 (clean when it was added)
 # (run_kernels8: the weight-gradient cases take a minute under the sanitizer; run_kernels9: conv3d_mfma.hip is 2500 lines of templates - clean when added)
@@ -106,6 +107,14 @@ def test_stride2_z_march_kernel_runs_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_fused_regulariser_tail_runs_on_the_cpu(built):
+    """conv11_prob_zfused_kernel (conv11 + skip, `prob`, softmax regression walking the depth axis; written in round 4 with this run as its first test): cost,
+    depth, confidence and index against the three layers in float64 - image borders inside a tile, two tiles in x (the driver's `all` mode: several tiles in
+    y, an odd number of input planes, the smallest volume)."""
+    _run(built[("run_kernels10", "plain")], ("conv11_prob_zfused",))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_production_prob_head_runs_on_the_cpu(built):
     """prob_zwalk_kernel (Conv3d 8 -> 1 walking the depth axis, regression fused or chunked; the production head): cost, depth, confidence and index against
     float64 - a GPU-free regression test of the kernel the fused tail was derived from."""
@@ -150,7 +159,7 @@ def test_float32_matrix_core_layers_run_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-@pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "conv0_zw", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")), ("run_kernels3", ("conv_s2",)),
+@pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "conv0_zw", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")), ("run_kernels3", ("conv_s2",)), ("run_kernels10", ("conv11_prob_zfused",)),
                                           ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion")), ("run_kernels6", ("fpn_tail0",)), ("run_kernels7", ("costvol_lds",)), ("run_kernels8", ("wgrad",)), ("run_kernels9", ("conv3d_f32",))])
 def test_no_lds_race_under_thread_sanitizer(built, source, names):
     """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
