@@ -42,7 +42,7 @@ for r in csv.DictReader(open(os.path.join(src, "pmc_fetch", "pmc_kernel_trace.cs
 table = []
 for k in fetch:
     if not any(s in k[0] for s in ("conv16", "deconv16", "prob_valu", "prob_zwalk", "costvol", "softmax", "hypotheses", "nchw_to", "fpn_lateral", "fpn_tail0",
-                                   "conv0_sf", "conv0_sb", "conv0_zm", "conv0_zw", "conv_ci_sf", "conv_s2_sf", "conv2d_ci_sf", "deconv9_sf", "deconv11_sf")):
+                                   "conv0_sf", "conv0_sb", "conv0_zm", "conv0_zw", "conv_ci_sf", "conv_s2_sf", "conv11_prob_zfused", "conv2d_ci_sf", "deconv9_sf", "deconv11_sf")):
         continue
     f_kb, n = fetch[k]
     w_kb = write.get(k, (0.0, 0))[0]
