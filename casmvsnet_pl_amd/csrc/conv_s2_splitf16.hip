@@ -33,9 +33,6 @@
 #ifndef CASMVS_S2_DEPTH_CONV1
 #define CASMVS_S2_DEPTH_CONV1 2   // units in flight per workgroup (register sets of 32): conv1 runs two workgroups per CU,
 #endif
-#ifndef CASMVS_S1Z_DEPTH
-#define CASMVS_S1Z_DEPTH 1        // conv2 on the stride-1 z-marching kernel: register sets in flight (acc + part + operands leave room for one at two workgroups per CU)
-#endif
 #ifndef CASMVS_S2_DEPTH_CONV3
 #define CASMVS_S2_DEPTH_CONV3 2   // conv3 (72 KiB of lane images) one; three were slower (profiles/r04_conv_s2_depth_ab.txt)
 #endif
@@ -348,229 +345,6 @@ __global__ __launch_bounds__(256, (S2Cfg<CIN, COUT>::WG_PER_CU)) void conv_s2_sf
 done:;
 }
 
-// ---- the stride-1 sibling: conv2 (16 -> 16, k3 s1 p1) input-stationary along z ---------------------------------------------------------------------------
-// conv_ci_splitf16.hip's tile kernel stages a 6 x 6 x 20 halo for 4 x 4 x 16 outputs (2.8 staged voxels per output voxel: its bound - DESIGN.md 2); here
-// a workgroup owns 8 x 32 output pixels and a segment of planes and walks the input planes once: 10 x 40 staged voxels per 8 x 32 outputs (1.56).  Input
-// plane p is tap kz = 0 of output plane p + 1, kz = 1 of p, kz = 2 of p - 1: three accumulator sets, the oldest is stored and the sets rotate after every plane.
-// The same K = (4 x-tap slots x 8 channels) form and the same lane images as the stride-2 kernel above (chunks of 8 input channels, one scale per unit =
-// (plane, chunk)); x is not split by parity: lane (j, kb) reads staged column 16 hf + j + 3 + kb.
-struct S1Cfg {
-  static constexpr int THREADS = 256, WAVES = 4, CIN = 16, COUT = 16;
-  static constexpr int TY = 8, TX = 32, NT = 4;                      // output patch; column tiles per wave (rows 2 w, 2 w + 1 x two halves)
-  static constexpr int IY = TY + 2, IQ = 10, IX = 4 * IQ;            // staged rows y0 - 1 .. y0 + 8, columns x0 - 4 .. x0 + 35 (whole quads)
-  static constexpr int NVOX = IY * IX;                               // units per slice: 400
-  static constexpr int ITEMS = IY * IQ;                              // (row, quad) staging items: 100 of the 256 threads
-  static constexpr int NCH = CIN / 8;
-  static constexpr int WUNITS = NCH * 9 * 2 * 64;                    // lane images [chunk][kz][ky][slice][lane]: 36 KiB
-  static constexpr int NWL = (WUNITS + THREADS - 1) / THREADS;       // 9
-  static constexpr size_t ACT_BYTES = (size_t)2 * NVOX * 16, W_BYTES = (size_t)WUNITS * 16;
-  static constexpr size_t LDS_USED = ACT_BYTES + W_BYTES + 16;       // 49 680
-  static constexpr size_t LDS_BYTES = LDS_USED < 56 * 1024 ? (size_t)56 * 1024 : LDS_USED;   // two workgroups per CU, never three
-  static_assert(WUNITS % THREADS == 0 && ITEMS <= THREADS && TY * (TX / 16) == WAVES * NT, "shape");
-};
-
-struct S1Item {
-  int ox0, oy0, oz0, b;
-};
-__device__ __forceinline__ S1Item s1_decode(int v, int total, int tiles_x, int tiles_y, int segs, int zt) {
-  int item = xcd_major(v, total);   // x fastest, then y, then the z segment
-  S1Item t;
-  t.ox0 = (item % tiles_x) * S1Cfg::TX;
-  item /= tiles_x;
-  t.oy0 = (item % tiles_y) * S1Cfg::TY;
-  item /= tiles_y;
-  t.oz0 = (item % segs) * zt;
-  t.b = item / segs;
-  return t;
-}
-
-// in (B, 16, D, H, W) float32, W % 4 == 0, 16-byte aligned; wpk: [chunk][kz][ky][slice][lane] 16-byte lane images (the stride-2 packer's image for one
-// block of 16 output channels), then scale[16] (ABN scale x 2^-kw), shift[16]; out (B, 16, D, H, W).
-template <int DEPTH>
-__global__ __launch_bounds__(256, 2) void conv_s1z_sf_kernel(const float *__restrict__ in, const unsigned char *__restrict__ wpk, float *__restrict__ out, int B,
-                                                            int D, int H, int W, int tiles_x, int tiles_y, int segs, int zt, float slope) {
-  using Cfg = S1Cfg;
-  constexpr int NCH = Cfg::NCH, NT = Cfg::NT, NWL = Cfg::NWL, NVOX = Cfg::NVOX, IX = Cfg::IX, IQ = Cfg::IQ;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  u32x4 *act = reinterpret_cast<u32x4 *>(smem_raw);                                          // [slice][row][column]
-  u32x4 *wl = reinterpret_cast<u32x4 *>(smem_raw + Cfg::ACT_BYTES);                          // [chunk][kz][ky][slice][64]
-  unsigned *wmax = reinterpret_cast<unsigned *>(smem_raw + Cfg::ACT_BYTES + Cfg::W_BYTES);   // [4]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int jcol = lane & 15, kb = lane >> 4;
-  const int total = tiles_x * tiles_y * segs * B;
-  if ((int)blockIdx.x >= total) return;
-  const int HW = H * W, cs = D * HW;
-  const size_t ss = (size_t)16 * cs;
-  const float *tail = reinterpret_cast<const float *>(wpk + Cfg::W_BYTES);
-  float sc[4], sh[4];   // lane holds output channels 4 kb + r
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    sc[r] = tail[4 * kb + r];
-    sh[r] = tail[16 + 4 * kb + r];
-  }
-  {
-    const rsrc_t wsrc = make_rsrc(reinterpret_cast<const float *>(wpk), Cfg::W_BYTES);
-    u32x4 WR[NWL];
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) WR[i] = __builtin_bit_cast(u32x4, buf_load4(wsrc, (tid + i * Cfg::THREADS) * 16, 0));
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) wl[tid + i * Cfg::THREADS] = WR[i];
-  }
-  const rsrc_t none = make_rsrc(in, 0);
-  // lane's B unit (slice 0, tap ky = 0) of column tile t: patch row 2 wave + (t >> 1), staged column 16 (t & 1) + j + 3 + kb (kb 3: zero weights, staged data)
-  int vb[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) vb[t] = (2 * wave + (t >> 1)) * IX + 16 * (t & 1) + jcol + 3 + kb;
-  const bool staged = tid < Cfg::ITEMS;
-  const int srow = tid / IQ, sq = tid - srow * IQ;
-  const int sunit = srow * IX + 4 * sq;
-
-  struct Cursor {
-    S1Item it;
-    int item, p, ch;
-    bool valid;
-  };
-  auto advance = [&](const Cursor &c) {
-    Cursor n = c;
-    if (!c.valid) return n;
-    n.ch = c.ch + 1;
-    if (n.ch == NCH) {
-      n.ch = 0;
-      n.p = c.p + 1;
-      if (n.p > c.it.oz0 + zt) {   // past the plane behind the segment's last output plane
-        n.item = c.item + gridDim.x;
-        n.valid = n.item < total;
-        if (n.valid) n.it = s1_decode(n.item, total, tiles_x, tiles_y, segs, zt);
-        n.p = n.it.oz0 - 1;
-      }
-    }
-    return n;
-  };
-  f32x4 R[DEPTH][8];
-  auto load = [&](f32x4 (&Rs)[8], const Cursor &c) {
-    const int gy = c.it.oy0 - 1 + srow, gx = c.it.ox0 - 4 + 4 * sq;
-    const bool ok = staged && gy >= 0 && gy < H && gx >= 0 && gx < W;   // W % 4 == 0: whole quads
-    const int voff = ok ? (gy * W + gx) * 4 : kOOB;
-    const bool exists = c.valid && c.p >= 0 && c.p < D;
-    const rsrc_t src = exists ? make_rsrc(in + (size_t)c.it.b * ss, ss * 4) : none;
-    const int soff = exists ? (c.ch * 8 * cs + c.p * HW) * 4 : 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) Rs[k] = __builtin_bit_cast(f32x4, buf_load4(src, voff, soff + k * cs * 4));
-  };
-  f32x4 acc[3][NT];   // [0]: output plane p - 1 (tap kz = 2), [1]: p (kz = 1), [2]: p + 1 (kz = 0)
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  Cursor q[DEPTH];
-  q[0].item = blockIdx.x;
-  q[0].it = s1_decode(q[0].item, total, tiles_x, tiles_y, segs, zt);
-  q[0].p = q[0].it.oz0 - 1;
-  q[0].ch = 0;
-  q[0].valid = true;
-#pragma unroll
-  for (int d = 1; d < DEPTH; ++d) q[d] = advance(q[d - 1]);
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) load(R[d], q[d]);
-  for (;;) {   // (one exit, behind the last register set: see conv_s2_sf_kernel)
-#pragma unroll
-   for (int d = 0; d < DEPTH; ++d) {
-    const Cursor c = q[d];
-    const Cursor ahead = advance(q[(d + DEPTH - 1) % DEPTH]);
-    const Cursor nx = DEPTH == 1 ? ahead : q[(d + 1) % DEPTH];
-    const S1Item cur = c.it;
-    const int p = c.p, ch = c.ch;
-    f32x4 (&Rd)[8] = R[d];
-    float m = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) m = fmaxf(m, fmaxf(fmaxf(fabsf(Rd[k][0]), fabsf(Rd[k][1])), fmaxf(fabsf(Rd[k][2]), fabsf(Rd[k][3]))));
-    const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
-    if (lane == 0) wmax[wave] = wm;
-    __syncthreads();
-    float mult, inv;
-    casmvs::tile_scale(wmax, mult, inv);
-    if (staged) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        float x[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = Rd[k][v];
-        casmvs::split_u32x4 o[2];
-        casmvs::split8_f16(x, mult, o);
-        act[sunit + v] = o[0];
-        act[NVOX + sunit + v] = o[1];
-      }
-    }
-    __syncthreads();
-    if (DEPTH == 1) load(Rd, ahead);
-    // ---- matrix phase: per tap ky the B operands once, the three kz images against them ----
-    const u32x4 *wch = wl + ch * (9 * 2 * 64) + lane;
-    constexpr int PA[3] = {0, 0, 1}, PB[3] = {0, 1, 0};
-    f32x4 part[3][NT];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) part[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      u32x4 bv[NT][2];
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) bv[t][s2] = act[s2 * NVOX + vb[t] + ky * IX];
-#pragma unroll
-      for (int kz = 0; kz < 3; ++kz) {
-        u32x4 a[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) a[s2] = wch[((kz * 3 + ky) * 2 + s2) * 64];
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) part[2 - kz][t] = s2_mfma(a[PA[pr]], bv[t][PB[pr]], part[2 - kz][t]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);   // the folds stay behind the last matrix instruction
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][t][r] = fmaf(part[i][t][r], inv, acc[i][t][r]);
-    if (ch == NCH - 1) {
-      // ---- output plane p - 1 is complete: y = lrelu(acc * scale + shift); lane holds channels 4 kb + r, column j ----
-      const int oz = p - 1;
-      const bool zok = c.valid && oz >= cur.oz0 && oz < cur.oz0 + zt && oz < D;
-      const rsrc_t dst = zok ? make_rsrc(out + (size_t)cur.b * ss, ss * 4) : make_rsrc(out, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int oy = cur.oy0 + 2 * wave + (t >> 1), ox = cur.ox0 + 16 * (t & 1) + jcol;
-        const bool ok = oy < H && ox < W;
-        const int o0 = ok ? (4 * kb * cs + (oz * H + oy) * W + ox) * 4 : kOOB;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = fmaf(acc[0][t][r], sc[r], sh[r]);
-          v = v > 0.0f ? v : v * slope;
-          buf_store(v, dst, o0, r * cs * 4);
-        }
-        acc[0][t] = acc[1][t];
-        acc[1][t] = acc[2][t];
-        acc[2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    if (DEPTH > 1) load(Rd, ahead);
-    q[d] = ahead;
-    if (d == DEPTH - 1 && !nx.valid) goto done;
-    if (nx.item != c.item) {   // a new item starts with empty accumulators
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-   }
-  }
-done:;
-}
-
 inline uint16_t f16_bits_s2(float x) {   // round to nearest even (host)
   const _Float16 h = (_Float16)x;
   uint16_t b;
@@ -686,75 +460,4 @@ extern "C" int casmvs_conv_s2_splitf16_forward_f32(const void *packed, const flo
   CASMVS_REQUIRE((size_t)cin * D * H * W < ((size_t)1 << 29), "conv_s2_splitf16_forward: one sample's input tensor must hold < 2^29 floats");
   if (cin == 8) return launch_s2<8, 16>(packed, in, out, B, D, H, W, slope, (hipStream_t)stream);
   return launch_s2<16, 32>(packed, in, out, B, D, H, W, slope, (hipStream_t)stream);
-}
-
-// ---- conv2 (16 -> 16, stride 1) on the z-marching kernel ----
-extern "C" size_t casmvs_conv_s1z_splitf16_packed_bytes(void) { return S1Cfg::W_BYTES + 2 * 16 * sizeof(float); }
-
-// HOST-side packing: weight (16, 16, 3, 3, 3) float32 -> the stride-2 packer's layout for ONE block of 16 output channels:
-// [chunk of 8 input channels][kz * 3 + ky][slice][lane][8 float16], lane = (co = lane & 15, kx = lane >> 4; kx = 3: zeros); then scale[16] * 2^-kw, shift[16].
-extern "C" int casmvs_conv_s1z_splitf16_pack(const float *weight, const float *scale, const float *shift, void *packed) {
-  casmvs::clear_error();
-  CASMVS_REQUIRE(weight && packed, "conv_s1z_splitf16_pack: null pointer");
-  float wmax = 0.0f;
-  for (int i = 0; i < 16 * 16 * 27; ++i) {
-    CASMVS_REQUIRE(std::isfinite(weight[i]), "conv_s1z_splitf16_pack: weight %d is not finite", i);
-    wmax = std::fmax(wmax, std::fabs(weight[i]));
-  }
-  int ex = 14;
-  if (wmax > 0.0f) (void)std::frexp(wmax, &ex);
-  const int kw = 14 - ex;
-  uint16_t *p = reinterpret_cast<uint16_t *>(packed);
-  for (int chunk = 0; chunk < 2; ++chunk)
-    for (int r9 = 0; r9 < 9; ++r9) {
-      uint16_t img[2][64][8];
-      for (int l = 0; l < 64; ++l) {
-        const int co = l & 15, kx = l >> 4;
-        for (int e = 0; e < 8; ++e) {
-          const int ci = 8 * chunk + e;
-          const float w = kx < 3 ? std::ldexp(weight[(((size_t)co * 16 + ci) * 9 + r9) * 3 + kx], kw) : 0.0f;
-          const float a = (float)(_Float16)w;
-          img[0][l][e] = f16_bits_s2(w);
-          img[1][l][e] = f16_bits_s2(w - a);
-        }
-      }
-      std::memcpy(p, img, sizeof(img));
-      p += 2 * 64 * 8;
-    }
-  float *tail = reinterpret_cast<float *>(p);
-  for (int c = 0; c < 16; ++c) tail[c] = std::ldexp(scale ? scale[c] : 1.0f, -kw);
-  for (int c = 0; c < 16; ++c) tail[16 + c] = shift ? shift[c] : 0.0f;
-  return CASMVS_OK;
-}
-
-extern "C" int casmvs_conv_s1z_splitf16_supported(int W) { return W % 4 == 0 && W >= 4; }
-
-extern "C" int casmvs_conv_s1z_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int D, int H, int W, float slope, void *stream) {
-  casmvs::clear_error();
-  CASMVS_REQUIRE(packed && in && out, "conv_s1z_splitf16_forward: null pointer");
-  CASMVS_REQUIRE(B > 0 && D > 0 && H > 0 && casmvs_conv_s1z_splitf16_supported(W), "conv_s1z_splitf16_forward: B=%d D=%d H=%d W=%d (W a multiple of 4)", B, D, H, W);
-  CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(packed)) & 15) == 0 && (reinterpret_cast<size_t>(out) & 3) == 0,
-                 "conv_s1z_splitf16_forward: 16-byte aligned input and image");
-  CASMVS_REQUIRE((size_t)16 * D * H * W < ((size_t)1 << 29), "conv_s1z_splitf16_forward: one sample's tensor must hold < 2^29 floats");
-  using Cfg = S1Cfg;
-  const int tiles_x = casmvs::ceil_div(W, Cfg::TX), tiles_y = casmvs::ceil_div(H, Cfg::TY);
-  auto kernel = conv_s1z_sf_kernel<CASMVS_S1Z_DEPTH>;
-  if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), Cfg::LDS_BYTES, "conv_s1z_sf_kernel")) return rc;
-  const int resident = casmvs::resident_blocks(reinterpret_cast<const void *>(kernel), Cfg::THREADS, Cfg::LDS_BYTES);
-  // z segments: least (rounds of resident workgroups) x (planes an item walks = its output planes + 2)
-  const long patches = (long)tiles_x * tiles_y * B;
-  int segs = 1;
-  long best = -1;
-  for (int sg = 1; sg <= D; ++sg) {
-    const int zt = casmvs::ceil_div(D, sg);
-    if (casmvs::ceil_div(D, zt) != sg) continue;
-    const long cost = ((patches * sg + resident - 1) / resident) * (zt + 2);
-    if (best < 0 || cost < best) { best = cost; segs = sg; }
-  }
-  const int zt = casmvs::ceil_div(D, segs);
-  const long total = patches * segs;
-  CASMVS_REQUIRE(total < (1L << 31), "conv_s1z_splitf16_forward: too many patches");
-  hipLaunchKernelGGL(kernel, dim3((unsigned)(total < resident ? total : resident)), dim3(Cfg::THREADS), Cfg::LDS_BYTES, (hipStream_t)stream, in,
-                     reinterpret_cast<const unsigned char *>(packed), out, B, D, H, W, tiles_x, tiles_y, segs, zt, slope);
-  return casmvs::check_launch("conv_s1z_sf_kernel");
 }

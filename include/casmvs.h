@@ -395,15 +395,6 @@ int casmvs_prob_regress_f32(const float *packed, const float *in, const float *d
 int casmvs_debug_disturb(int kind, int blocks, int iters, int lds_bytes, float *sink, void *stream);
 #endif
 
-/* conv2 (16 -> 16, Conv3d k3 s1 p1 + folded ABN + leaky-relu, mvsnet.py:66) input-stationary along z: the stride-1 sibling of casmvs_conv_s2_splitf16_forward_f32
- * (same file, same lane-image layout for one block of 16 output channels): 8 x 32 output pixels per workgroup, 1.56 staged voxels per output voxel instead of
- * the tile kernel's 2.8 (casmvs_conv_ci_splitf16_forward_f32).  in / out (B, 16, D, H, W), W % 4 == 0, `in` and the image 16-byte aligned.
- * casmvs_costreg_regress_f32 takes the image as split_layers[8]. */
-size_t casmvs_conv_s1z_splitf16_packed_bytes(void);
-int casmvs_conv_s1z_splitf16_pack(const float *weight, const float *scale, const float *shift, void *packed);
-int casmvs_conv_s1z_splitf16_supported(int W);
-int casmvs_conv_s1z_splitf16_forward_f32(const void *packed, const float *in, float *out, int B, int D, int H, int W, float slope, void *stream);
-
 /* CostRegNet's tail as ONE kernel that walks the depth axis (csrc/conv11_prob_zfused.hip): conv11 = ConvTranspose3d(16 -> 8, k3 s2 p1 op1) + ABN +
  * leaky-relu + skip (mvsnet.py:84-86,101), `prob` = Conv3d(8 -> 1, k3 p1, bias) (:89,104) and the softmax / regression / confidence (:174-193).  The
  * 8-channel full-resolution tensor between the two layers never reaches memory.  deconv11_packed: DEVICE copy of casmvs_deconv11_splitf16_pack's

@@ -126,103 +126,6 @@ int main(int argc, char **argv) {
     }
     hipFree(dpk); hipFree(dpf);
   }
-  {  // conv2 (16 -> 16, stride 1): the z-marching kernel against the tile kernel (casmvs_conv_ci_splitf16_forward_f32) and the float32 MFMA kernel
-    const int c = 16;
-    std::vector<float> w((size_t)c * c * 27), scale(c), shift(c);
-    for (auto &v : w) v = rnd() * 0.2f;
-    for (int i = 0; i < c; ++i) { scale[i] = 0.5f + 0.03f * i; shift[i] = 0.03f * (i - 8); }
-    std::vector<unsigned char> pz(casmvs_conv_s1z_splitf16_packed_bytes()), pt(casmvs_conv_ci_splitf16_packed_bytes(c, c));
-    if (casmvs_conv_s1z_splitf16_pack(w.data(), scale.data(), shift.data(), pz.data()) || casmvs_conv_ci_splitf16_pack(c, c, w.data(), scale.data(), shift.data(), pt.data())) {
-      printf("pack: %s\n", casmvs_last_error());
-      return 3;
-    }
-    std::vector<float> pf(casmvs_conv3d_packed_floats(CASMVS_CONV_S1, c, c));
-    if (casmvs_conv3d_pack_f32(CASMVS_CONV_S1, c, c, w.data(), scale.data(), shift.data(), pf.data())) { printf("pack f32: %s\n", casmvs_last_error()); return 3; }
-    void *dpz, *dpt;
-    float *dpf;
-    hipMalloc(&dpz, pz.size()); hipMalloc(&dpt, pt.size()); hipMalloc(&dpf, pf.size() * 4);
-    hipMemcpy(dpz, pz.data(), pz.size(), hipMemcpyHostToDevice);
-    hipMemcpy(dpt, pt.data(), pt.size(), hipMemcpyHostToDevice);
-    hipMemcpy(dpf, pf.data(), pf.size() * 4, hipMemcpyHostToDevice);
-    struct Shape { int B, D, H, W; bool host; };
-    const Shape shapes[] = {{1, 5, 10, 36, true}, {2, 3, 7, 68, true}, {1, 1, 17, 32, true}, {batch, 24, 64, 80, false}, {batch, 16, 128, 160, false}, {batch, 4, 256, 320, false}};
-    for (const Shape &s : shapes) {
-      const size_t n = (size_t)s.D * s.H * s.W, nt = (size_t)s.B * c * n;
-      std::vector<float> x(nt);
-      for (auto &v : x) v = rnd() * 2.0f + 0.2f;
-      for (size_t i = 0; i < nt; i += 1013) x[i] *= 100.0f;
-      float *dx, *dy[3];
-      hipMalloc(&dx, nt * 4);
-      for (int k = 0; k < 3; ++k) hipMalloc(&dy[k], nt * 4);
-      hipMemcpy(dx, x.data(), nt * 4, hipMemcpyHostToDevice);
-      auto run = [&](int k) {
-        if (k == 0) return casmvs_conv3d_forward_f32(CASMVS_CONV_S1, dpf, dx, nullptr, dy[0], s.B, c, c, s.D, s.H, s.W, 0.01f, st);
-        if (k == 1) return casmvs_conv_ci_splitf16_forward_f32(dpt, dx, dy[1], s.B, c, c, s.D, s.H, s.W, 0.01f, st);
-        return casmvs_conv_s1z_splitf16_forward_f32(dpz, dx, dy[2], s.B, s.D, s.H, s.W, 0.01f, st);
-      };
-      std::vector<float> y[3], again(nt);
-      double us[3] = {0, 0, 0};
-      for (int k = 0; k < 3; ++k) {
-        hipMemset(dy[k], 0xff, nt * 4);
-        if (run(k)) { printf("forward %d: %s\n", k, casmvs_last_error()); return 3; }
-        if (hipStreamSynchronize(st) != hipSuccess) { printf("kernel %d failed: %s\n", k, hipGetErrorString(hipGetLastError())); return 4; }
-        y[k].resize(nt);
-        hipMemcpy(y[k].data(), dy[k], nt * 4, hipMemcpyDeviceToHost);
-        float total = 0;
-        for (int i = 0; i < 6; ++i) {
-          hipMemsetAsync(dirty, i, dirty_bytes, st);
-          hipEventRecord(e0, st);
-          run(k);
-          hipEventRecord(e1, st);
-          hipEventSynchronize(e1);
-          float ms;
-          hipEventElapsedTime(&ms, e0, e1);
-          total += ms;
-        }
-        us[k] = total * 1e3 / 6;
-      }
-      hipMemcpy(again.data(), dy[2], nt * 4, hipMemcpyDeviceToHost);
-      const bool stable = memcmp(again.data(), y[2].data(), nt * 4) == 0;
-      double range = 0, diff = 0;
-      size_t nan = 0;
-      for (size_t i = 0; i < nt; ++i) {
-        range = std::fmax(range, std::fabs((double)y[0][i]));
-        if (!std::isfinite(y[2][i])) ++nan;
-        diff = std::fmax(diff, std::fabs((double)y[1][i] - y[2][i]));
-      }
-      printf("16 -> 16 s1 B=%d %dx%dx%d: float32 MFMA %.1f us, tile kernel %.1f us, z-march %.1f us (x%.3f of the tile kernel, %.2f TB/s algorithmic); max |z-march - tile| / range = %.2e, "
-             "non-finite %zu, repeat run %s", s.B, s.D, s.H, s.W, us[0], us[1], us[2], us[1] / us[2], 2.0 * nt * 4e-9 / (us[2] * 1e-6) * 1e-3, diff / range, nan, stable ? "equal" : "DIFFERENT");
-      bool ok = nan == 0 && stable && diff / range < 3e-6;
-      if (s.host) {
-        double err[3] = {0, 0, 0};
-        for (int b = 0; b < s.B; ++b)
-          for (int co = 0; co < c; ++co)
-            for (int z = 0; z < s.D; ++z)
-              for (int yy = 0; yy < s.H; ++yy)
-                for (int xx = 0; xx < s.W; ++xx) {
-                  double acc = 0;
-                  for (int ci = 0; ci < c; ++ci)
-                    for (int kz = 0; kz < 3; ++kz)
-                      for (int ky = 0; ky < 3; ++ky)
-                        for (int kx = 0; kx < 3; ++kx) {
-                          const int iz = z + kz - 1, iy = yy + ky - 1, ix = xx + kx - 1;
-                          if (iz < 0 || iz >= s.D || iy < 0 || iy >= s.H || ix < 0 || ix >= s.W) continue;
-                          acc += (double)w[((size_t)co * c + ci) * 27 + kz * 9 + ky * 3 + kx] * x[((size_t)b * c + ci) * n + ((size_t)iz * s.H + iy) * s.W + ix];
-                        }
-                  double v = acc * scale[co] + shift[co];
-                  v = v > 0 ? v : v * 0.01f;
-                  const size_t o = ((size_t)b * c + co) * n + ((size_t)z * s.H + yy) * s.W + xx;
-                  for (int k = 0; k < 3; ++k) err[k] = std::fmax(err[k], std::fabs(v - y[k][o]));
-                }
-        printf("; vs float64: float32 MFMA %.2e, tile %.2e, z-march %.2e of the range", err[0] / range, err[1] / range, err[2] / range);
-        ok = ok && err[2] / range < 2e-6;
-      }
-      printf("  %s\n", ok ? "ok" : "FAILED");
-      all_ok = all_ok && ok;
-      hipFree(dx);
-      for (int k = 0; k < 3; ++k) hipFree(dy[k]);
-    }
-  }
   printf(all_ok ? "ALL OK\n" : "FAILED\n");
   return all_ok ? 0 : 1;
 }
