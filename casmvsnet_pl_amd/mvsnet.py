@@ -486,7 +486,8 @@ class CascadeMVSNet(nn.Module):
         proj_mats = proj_mats.float().permute(2, 0, 1, 3, 4).contiguous()  # (levels, B, V-1, 3, 4): one copy, not one per level
         t = self.timer
         with torch.no_grad():
-            engine_feats = type(self.feature) is FeatureNet   # (a user's replacement module returns the reference's (N,C,h,w) dict)
+            # (a user's replacement module, or FeatureNet left in train mode, returns the reference's (N,C,h,w) dict)
+            engine_feats = type(self.feature) is FeatureNet and not self.feature.training
             with stage(t, "feature"):
                 feats = self.feature(imgs, pixel_major_only=True) if engine_feats else self.feature(imgs)
             depth_l = None
