@@ -858,6 +858,45 @@ def test_split_f16_kernels_never_turn_non_finite_inputs_into_finite_wrong_values
         assert float(finite.float().mean()) > 0.5, (kernel, bad)   # the poisoned unit is local
 
 
+@pytest.mark.parametrize("kernel", ["conv_s2_sf<8>", "conv_s2_sf<16>", "conv11_prob_zfused"])
+def test_round4_kernels_never_turn_non_finite_inputs_into_finite_wrong_values(dev, kernel):
+    """The same property for the kernels added in round 4 (the stride-2 z-march, the fused tail): with one NaN / Inf voxel in the input every output value is
+    either non-finite or bit-equal to the clean run's, and every output whose receptive field holds the voxel is non-finite (its reach computed with a
+    ones-kernel convolution of the voxel's indicator).  A poisoned unit (plane patch x 8 channels) stays local."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(23)
+    if kernel.startswith("conv_s2"):
+        cin = int(kernel[len("conv_s2_sf<"):-1])
+        x = torch.randn(1, cin, 8, 32, 72, generator=g)
+        packed = ops.conv_s2_splitf16_pack(torch.randn(2 * cin, cin, 3, 3, 3, generator=g) * 0.2).to(dev)
+        run = lambda t: ops.conv_s2_splitf16_forward(packed, t.to(dev), 2 * cin).cpu()
+        reach = lambda ind: F.conv3d(ind, torch.ones(1, 1, 3, 3, 3), stride=2, padding=1) > 0
+        bad_at = (0, 3, 5, 13, 37)
+    else:
+        x = torch.randn(1, 16, 4, 16, 34, generator=g)
+        skip = torch.randn(1, 8, 8, 32, 68, generator=g).to(dev)
+        dv = (400.0 + torch.arange(8.0).view(1, 8, 1, 1).expand(1, 8, 32, 68)).contiguous().to(dev)
+        p11 = ops.deconv11_splitf16_pack(torch.randn(16, 8, 3, 3, 3, generator=g) * 0.2, torch.ones(8), torch.zeros(8)).to(dev)
+        pp = ops.conv3d_pack(ops.CONV_S1, torch.randn(1, 8, 3, 3, 3, generator=g) * 0.3, None, torch.zeros(1)).to(dev)
+        run = lambda t: ops.conv11_prob_zfused(p11, pp, t.to(dev), skip, dv)[0].cpu().unsqueeze(1)   # the cost volume
+        # conv11 spreads a voxel over outputs 2 i - 1 .. 2 i + 1, `prob` one more voxel each way
+        reach = lambda ind: F.conv3d((F.conv_transpose3d(ind, torch.ones(1, 1, 3, 3, 3), stride=2, padding=1, output_padding=1) > 0).float(), torch.ones(1, 1, 3, 3, 3), padding=1) > 0
+        bad_at = (0, 5, 2, 7, 19)
+    clean = run(x)
+    assert torch.isfinite(clean).all()
+    ind = torch.zeros(1, 1, *x.shape[2:])
+    ind[(0, 0) + bad_at[2:]] = 1.0
+    hit = reach(ind)[0, 0]   # (Do, Ho, Wo)
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        xb = x.clone()
+        xb[bad_at] = bad
+        got = run(xb)
+        finite = torch.isfinite(got)
+        assert torch.equal(got[finite], clean[finite]), (kernel, bad)
+        assert not finite[0, :, hit].any(), (kernel, bad)
+        assert float(finite.float().mean()) > 0.3, (kernel, bad)
+
+
 def test_whole_forward_float32_layers_equal_the_split_f16_layers(dev, report):
     """The engine with every layer on the float32 MFMA kernels against the default layer set (conv0 / 2 / 4 / 6 / 9 / 11 and six FeatureNet layers on the
     f16 matrix cores) on one problem: depths agree to float32 rounding in the median and within the oracle bound everywhere."""
