@@ -8,18 +8,18 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int KIND>   // 0 v_fma_f32, 1 v_pk_fma_f32 (vector operands), 2 v_pk_fma_f32 (scalar multiplier)
+template <int KIND, int NCHAIN = 12>   // 0 v_fma_f32, 1 v_pk_fma_f32 (vector operands), 2 v_pk_fma_f32 (scalar multiplier); NCHAIN independent accumulators
 __global__ __launch_bounds__(256) void rate_kernel(float *sink, const float *wsrc, int iters) {
-  f32x2 acc[12];
+  f32x2 acc[NCHAIN];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) acc[i] = f32x2{(float)(threadIdx.x + i), 1.0f};
+  for (int i = 0; i < NCHAIN; ++i) acc[i] = f32x2{(float)(threadIdx.x + i), 1.0f};
   const f32x2 mv = {1.0f + threadIdx.x * 1e-7f, 1.0f - threadIdx.x * 1e-7f}, c = {1e-3f, -1e-3f};
   const f32x2 ms = {wsrc[0], wsrc[1]};   // wave-uniform: SGPR pair
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int rep = 0; rep < 8; ++rep)
+    for (int rep = 0; rep < 96 / NCHAIN; ++rep)
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
+      for (int i = 0; i < NCHAIN; ++i) {
         if (KIND == 0) { acc[i][0] = fmaf(acc[i][0], mv[0], c[0]); acc[i][1] = fmaf(acc[i][1], mv[1], c[1]); }
         else if (KIND == 1) acc[i] = __builtin_elementwise_fma(acc[i], mv, c);
         else acc[i] = __builtin_elementwise_fma(acc[i], ms, c);
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float *sink, const float *wsr
   }
   float s = 0;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s += acc[i][0] + acc[i][1];
+  for (int i = 0; i < NCHAIN; ++i) s += acc[i][0] + acc[i][1];
   if (s == 12345.678f) sink[0] = s;
 }
 
@@ -64,5 +64,22 @@ int main() {
       const double tflops = 2.0 * 2 * 64 * pair_fmas * 4 * cus / (best * 1e-3) / 1e12;
       printf("%-34s %d wave(s) per SIMD: %.3f ms, %.2f cycles per pair-of-FMAs wave-instruction slot, %.1f TFLOP/s\n", names[kind], waves, best, cycles / pair_fmas, tflops);
     }
+  // dependent-issue latency: the scalar-multiplier form with 1 .. 12 independent accumulator chains, one wave per SIMD (prob_zwalk.h runs six)
+  printf("v_pk_fma_f32 (scalar multiplier), one wave per SIMD, by the number of independent chains:\n");
+  auto chains = [&](auto k, int n) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(k, dim3(cus), dim3(256), 0, 0, sink, w, iters);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best) best = ms;
+    }
+    printf("  %2d chains: %.2f cycles per instruction\n", n, best * 1e-3 * prop.clockRate * 1e3 / (96.0 * iters));
+  };
+  chains(rate_kernel<2, 1>, 1); chains(rate_kernel<2, 2>, 2); chains(rate_kernel<2, 3>, 3); chains(rate_kernel<2, 4>, 4); chains(rate_kernel<2, 6>, 6);
+  chains(rate_kernel<2, 8>, 8); chains(rate_kernel<2, 12>, 12);
   return 0;
 }
