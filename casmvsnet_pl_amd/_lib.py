@@ -67,6 +67,10 @@ SYMBOLS = {
     "casmvs_conv_ci_splitf16_pack": (c_int, [c_int, c_int, _FP, _FP, _FP, c_void_p]),
     "casmvs_conv_ci_splitf16_supported": (c_int, [c_int, c_int, c_int]),
     "casmvs_conv_ci_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "casmvs_conv2d_k5s2_splitf16_packed_bytes": (c_size_t, [c_int, c_int]),
+    "casmvs_conv2d_k5s2_splitf16_pack": (c_int, [c_int, c_int, _FP, _FP, _FP, c_void_p]),
+    "casmvs_conv2d_k5s2_splitf16_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "casmvs_conv2d_k5s2_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_conv11_prob_zfused_supported": (c_int, [c_int, c_int, c_int]),
     "casmvs_conv11_prob_zfused_f32": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "casmvs_conv_s2_splitf16_packed_bytes": (c_size_t, [c_int, c_int]),

@@ -2189,7 +2189,13 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
   if (rc != CASMVS_OK) return rc
   CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, nullptr, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
   CASMVS_L(CASMVS_CONV2D_K3, P[1], a0, nullptr, c0, nullptr, N, 8, 8, H, W, slope, stream);            // conv0.1  :15
-  CASMVS_L(CASMVS_CONV2D_K5S2, P[2], c0, nullptr, a1, nullptr, N, 8, 16, H, W, slope, stream);         // conv1.0  :18
+  if (ci_layers && ci_layers[5] && casmvs_conv2d_k5s2_splitf16_supported(8, 16, H, W) && (reinterpret_cast<size_t>(ci_layers[5]) & 15) == 0) {   // conv1.0 on the f16 matrix cores
+    CASMVS_EV();
+    rc = casmvs_conv2d_k5s2_splitf16_forward_f32(ci_layers[5], c0, a1, N, 8, 16, H, W, slope, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K5S2, P[2], c0, nullptr, a1, nullptr, N, 8, 16, H, W, slope, stream);       // conv1.0  :18
+  }
   if (ci_layers && ci_layers[0] && casmvs_conv2d_ci_splitf16_supported(16, 16, W2)) {   // conv1.1 on the f16 matrix cores (conv2d_ci_splitf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
@@ -2206,7 +2212,13 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
   } else {
     CASMVS_L(CASMVS_CONV2D_K3, P[4], b1, nullptr, c1, nullptr, N, 16, 16, H2, W2, slope, stream);        // conv1.2  :20
   }
-  CASMVS_L(CASMVS_CONV2D_K5S2, P[5], c1, nullptr, a2, nullptr, N, 16, 32, H2, W2, slope, stream);      // conv2.0  :23
+  if (ci_layers && ci_layers[6] && casmvs_conv2d_k5s2_splitf16_supported(16, 32, H2, W2) && (reinterpret_cast<size_t>(ci_layers[6]) & 15) == 0) {   // conv2.0 on the f16 matrix cores
+    CASMVS_EV();
+    rc = casmvs_conv2d_k5s2_splitf16_forward_f32(ci_layers[6], c1, a2, N, 16, 32, H2, W2, slope, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K5S2, P[5], c1, nullptr, a2, nullptr, N, 16, 32, H2, W2, slope, stream);    // conv2.0  :23
+  }
   if (ci_layers && ci_layers[2] && casmvs_conv2d_ci_splitf16_supported(32, 32, W4)) {   // conv2.1 on the f16 matrix cores (conv2d_ci_splitf16.hip)
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;

@@ -193,6 +193,10 @@ class FeatureNet(_PackedWeights, nn.Module):
                 sc, sh, _ = _fold_norm(f"FeatureNet.{name}", m.bn)
                 ci.append(ops.conv2d_ci_splitf16_pack(m.conv.weight, sc, sh).to(device))
             ci.append(ops.conv2d_ci_splitf16_pack(self.smooth1.weight, None, self.smooth1.bias).to(device))   # smooth1: Conv2d 32 -> 16 with bias
+            for name in ("conv1.0", "conv2.0"):   # the 5 x 5 stride-2 layers (conv2d_k5s2_splitf16.hip)
+                m = self.get_submodule(name)
+                sc, sh, _ = _fold_norm(f"FeatureNet.{name}", m.bn)
+                ci.append(ops.conv2d_k5s2_splitf16_pack(m.conv.weight, sc, sh).to(device))
             return ci
         self._split_image("_ci2d", pack_ci, sf)
         self._split_active = sf   # the split-f16 images exist and are current: forward may select them

@@ -715,6 +715,37 @@ def conv2d_ci_splitf16_forward(packed, x, cout=None, slope=0.01, channels_last_c
     return (out, out2) if channels_last_copy else out
 
 
+def conv2d_k5s2_splitf16_pack(weight, scale=None, shift=None):
+    """Host-side packing of a 5x5 stride-2 FeatureNet layer (conv1.0: 8 -> 16, conv2.0: 16 -> 32) for the split-f16 kernel
+    (casmvs_conv2d_k5s2_splitf16_pack): weight (cout, cin, 5, 5) -> uint8 CPU tensor."""
+    weight = weight.detach().to("cpu", torch.float32).contiguous()
+    cout, cin = weight.shape[:2]
+    lib = _lib.load()
+    n = lib.casmvs_conv2d_k5s2_splitf16_packed_bytes(cin, cout)
+    if tuple(weight.shape[2:]) != (5, 5) or n == 0:
+        raise ValueError(f"conv2d_k5s2_splitf16_pack: weight {tuple(weight.shape)} (need (16, 8, 5, 5) or (32, 16, 5, 5))")
+    packed = torch.empty(n, dtype=torch.uint8)
+    sc = None if scale is None else scale.detach().to("cpu", torch.float32).contiguous()
+    sh = None if shift is None else shift.detach().to("cpu", torch.float32).contiguous()
+    rc = lib.casmvs_conv2d_k5s2_splitf16_pack(cin, cout, _ptr(weight), _ptr(sc), _ptr(sh), ctypes.c_void_p(packed.data_ptr()))
+    _lib.check(rc, "casmvs_conv2d_k5s2_splitf16_pack")
+    return packed
+
+
+def conv2d_k5s2_splitf16_forward(packed, x, cout, slope=0.01):
+    """conv1.0 / conv2.0 of FeatureNet on the f16 matrix cores (casmvs_conv2d_k5s2_splitf16_forward_f32): x (N,cin,H,W), H even, W % 4 == 0 -> (N,cout,H/2,W/2)."""
+    x = _dev(x, "x")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("conv2d_k5s2_splitf16_forward: `packed` must be the uint8 image on the MI355X")
+    N, cin, H, W = x.shape
+    out = torch.empty((N, cout, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().casmvs_conv2d_k5s2_splitf16_forward_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(x), _ptr(out), N, cin, cout, H, W, float(slope),
+                                                                 _stream(x, f16=True))
+    _lib.check(rc, "casmvs_conv2d_k5s2_splitf16_forward_f32")
+    return out
+
+
 def fpn_tail0_splitf16_pack(weight40):
     """Host-side packing of the composed 40-channel 3x3 tail (mvsnet.compose_fpn_tail) for the split-f16 kernel
     (casmvs_fpn_tail0_splitf16_pack): weight40 (8, 40, 3, 3) -> uint8 CPU tensor."""
@@ -755,7 +786,8 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
     kernels) -> (feat0, feat1, feat2, (nhwc0, nhwc1, nhwc2)).  fused0: (packed40, bias9) device tensors - the
     full-resolution tail as one kernel (casmvs_featurenet_forward_fused_f32); fused0_splitf16: packed40 is the uint8 image of
     fpn_tail0_splitf16_pack (the tail on the f16 matrix cores) instead of the float32 conv2d_pack image.  ci_layers (with fused0 only):
-    5 device images of conv2d_ci_splitf16_pack for conv1.1, conv1.2, conv2.1, conv2.2, smooth1 (entries may be None) - those layers on the f16 cores.
+    7 device images - conv2d_ci_splitf16_pack's for conv1.1, conv1.2, conv2.1, conv2.2, smooth1, conv2d_k5s2_splitf16_pack's for conv1.0, conv2.0 (entries may be
+    None) - those layers on the f16 cores.
     nchw_outputs=False (with channels_last_copies; the engine's own call): feat0 / feat1 are not stored - nothing downstream reads their (N,C,h,w) layout -
     and come back as None."""
     imgs = _dev(imgs, "imgs")
@@ -786,9 +818,9 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
         if fused0 is not None:   # (packed 40-channel tail, bias classes): lat0 + upsample-add + smooth0 in one kernel
             ci = None
             if ci_layers is not None:
-                if len(ci_layers) != 5:
-                    raise ValueError("featurenet_forward: ci_layers needs 5 entries (conv1.1, conv1.2, conv2.1, conv2.2, smooth1)")
-                ci = (ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in ci_layers])
+                if len(ci_layers) != 7:
+                    raise ValueError("featurenet_forward: ci_layers needs 7 entries (conv1.1, conv1.2, conv2.1, conv2.2, smooth1, conv1.0, conv2.0)")
+                ci = (ctypes.c_void_p * 7)(*[None if t is None else t.data_ptr() for t in ci_layers])
             rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
                                                                  ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
                                                                  _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),

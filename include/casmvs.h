@@ -336,8 +336,9 @@ int casmvs_fpn_tail0_f32(const float *packed40, const float *bias9, const float 
  * composed 40-channel layer, casmvs_fpn_tail0_f32), 1 = the split-f16 image (casmvs_fpn_tail0_splitf16_pack,
  * casmvs_fpn_tail0_splitf16_f32: the same kernel on the f16 matrix cores in the arithmetic of casmvs_conv0_splitf16_forward_f32).
  * casmvs_fpn_tail0_splitf16_pack: HOST, weight40 (8, 40, 3, 3) float32 finite -> casmvs_fpn_tail0_splitf16_packed_bytes() bytes.
- * ci_layers: NULL, or 5 pointers { conv1.1, conv1.2, conv2.1, conv2.2, smooth1 } to DEVICE copies of casmvs_conv2d_ci_splitf16_pack's images
- * (an entry may be NULL): those layers then run on the f16 matrix cores (casmvs_conv2d_ci_splitf16_forward_f32).
+ * ci_layers: NULL, or SEVEN pointers (ABI version 3; version 2 read five) { conv1.1, conv1.2, conv2.1, conv2.2, smooth1: DEVICE copies of
+ * casmvs_conv2d_ci_splitf16_pack's images; conv1.0, conv2.0: of casmvs_conv2d_k5s2_splitf16_pack's } (an entry may be NULL): those layers then run on the f16
+ * matrix cores (casmvs_conv2d_ci_splitf16_forward_f32 / casmvs_conv2d_k5s2_splitf16_forward_f32).
  * feat0 / feat1 may be NULL when feat0_nhwc / feat1_nhwc are given (ABI version 3): nothing downstream of FeatureNet reads the (N, C, h, w) layout of
  * levels 0 / 1 - the plane sweep gathers pixel-major - and the engine's own call drops those stores.  feat2 feeds lat1: never NULL. */
 /* FeatureNet's 3x3 stride-1 layers with 16 / 32 channels (conv1.1, conv1.2: 16 -> 16; conv2.1, conv2.2: 32 -> 32: ConvBnReLU, mvsnet.py:19-20,24-25;
@@ -350,6 +351,13 @@ int casmvs_conv2d_ci_splitf16_pack(int cin, int cout, const float *weight, const
 int casmvs_conv2d_ci_splitf16_supported(int cin, int cout, int W);
 int casmvs_conv2d_ci_splitf16_forward_f32(const void *packed, const float *in, float *out, float *out_nhwc, int N, int cin, int cout, int H, int W,
                                           float slope, void *stream);
+/* FeatureNet's stride-2 layers conv1.0 (8 -> 16) and conv2.0 (16 -> 32): Conv2d k5 s2 p2 + folded ABN + leaky-relu (mvsnet.py:18,23) in the same arithmetic
+ * (csrc/conv2d_k5s2_splitf16.hip).  in (N, cin, H, W) -> out (N, cout, H / 2, W / 2); H even, W % 4 == 0, `in` and the image 16-byte aligned.  `packed`: HOST image
+ * from casmvs_conv2d_k5s2_splitf16_pack (weight (cout, cin, 5, 5) finite, scale / shift (cout) or NULL), copied to the device by the caller. */
+size_t casmvs_conv2d_k5s2_splitf16_packed_bytes(int cin, int cout);
+int casmvs_conv2d_k5s2_splitf16_pack(int cin, int cout, const float *weight, const float *scale, const float *shift, void *packed);
+int casmvs_conv2d_k5s2_splitf16_supported(int cin, int cout, int H, int W);
+int casmvs_conv2d_k5s2_splitf16_forward_f32(const void *packed, const float *in, float *out, int N, int cin, int cout, int H, int W, float slope, void *stream);
 size_t casmvs_fpn_tail0_splitf16_packed_bytes(void);
 int casmvs_fpn_tail0_splitf16_pack(const float *weight40, void *packed);
 int casmvs_fpn_tail0_splitf16_f32(const void *packed, const float *bias9, const float *conv0, const float *feat1_sum,

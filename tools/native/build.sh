@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../.."
 mkdir -p tools/probes/bin
 /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/native/conv0_ab.cpp -Iinclude -ldl -o tools/probes/bin/conv0_ab 2>&1 | grep -E "error" || true
 ls -la tools/probes/bin/conv0_ab
-for name in fusion_check prob_wgrad_check conv0_zm_check deconv11_check deconv9_check conv_s2_check conv11_prob_check; do
+for name in fusion_check prob_wgrad_check conv0_zm_check deconv11_check deconv9_check conv_s2_check conv11_prob_check conv2d_k5s2_check; do
   /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/native/$name.cpp -Iinclude -Lcasmvsnet_pl_amd -lcasmvs_hip \
     -Wl,-rpath,'$ORIGIN/../../../casmvsnet_pl_amd' -o tools/probes/bin/$name 2>&1 | grep -E "error" || true
   ls -la tools/probes/bin/$name

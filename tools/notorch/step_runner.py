@@ -24,6 +24,7 @@ ap.add_argument("--hw", type=int, nargs=2, default=(512, 640))
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--all-f32", action="store_true", help="every layer on the float32 MFMA kernels (conv0_mode / ci_mode / tail_mode = f32)")
+ap.add_argument("--f32-k5s2", action="store_true", help="A/B: FeatureNet's conv1.0 / conv2.0 (5 x 5 stride 2) on the float32 MFMA kernel")
 ap.add_argument("--feature-split", type=int, default=1, help="A/B: FeatureNet over this many groups of images in sequence (cache blocking)")
 ap.add_argument("--nchw-feats", action="store_true", help="A/B: FeatureNet also stores the (N, C, h, w) maps of levels 0 / 1 (nothing in the forward reads them; the engine's call drops them)")
 ap.add_argument("--f32-layers", default="", help="A/B: comma list of CostRegNet layers kept on the float32 MFMA kernel although they have an f16 form: conv0, conv1, conv2, conv3, conv4, conv6, conv9, conv11")
@@ -109,6 +110,10 @@ for name in ("conv1.1", "conv1.2", "conv2.1", "conv2.2", "smooth1"):
     w, sc, sh = fw[name]
     cout, cin = w.shape[:2]
     ci2d.append(pack_bytes(lib.casmvs_conv2d_ci_splitf16_packed_bytes(cin, cout), lib.casmvs_conv2d_ci_splitf16_pack, cin, cout, hp(w), hp(sc), hp(sh)))
+for name in ("conv1.0", "conv2.0"):   # the 5 x 5 stride-2 layers on the f16 cores (ABI 3: ci_layers[5], [6])
+    w, sc, sh = fw[name]
+    cout, cin = w.shape[:2]
+    ci2d.append(pack_bytes(lib.casmvs_conv2d_k5s2_splitf16_packed_bytes(cin, cout), lib.casmvs_conv2d_k5s2_splitf16_pack, cin, cout, hp(w), hp(sc), hp(sh)))
 
 # ---- CostRegNet per level (mvsnet.py:201-326) ----------------------------------------------------------------------------
 COSTREG = (("conv0", CONV_S1, None, 8), ("conv1", CONV_S2, 8, 16), ("conv2", CONV_S1, 16, 16), ("conv3", CONV_S2, 16, 32), ("conv4", CONV_S1, 32, 32),
@@ -196,7 +201,7 @@ dmin = DeviceArray.from_numpy(np.full(B, DEPTH_MIN, np.float32))
 stream = hip.stream_create()
 st = ctypes.c_void_p(stream)
 arr13 = (ctypes.c_void_p * 13)(*[p.ptr for p in feat_packed])
-ci5 = None if args.all_f32 else (ctypes.c_void_p * 5)(*[p.ptr for p in ci2d])
+ci5 = None if args.all_f32 else (ctypes.c_void_p * 7)(*[None if (i >= 5 and args.f32_k5s2) else p.ptr for i, p in enumerate(ci2d)])
 STAGES = ["feature"] + [f"{s}_{l}" for l in (2, 1, 0) for s in ("hypotheses", "costvol", "costreg")]
 events = {s: (hip.Event(), hip.Event()) for s in STAGES}
 
