@@ -716,8 +716,9 @@ def main():
                                                         "(conv6: >= 3 planes); conv5 / conv7 and `prob` float32" if model.cost_reg_0.ci_mode == "splitf16" else "float32 MFMA",
                           "per_gpu_engine": f"one stream, batch {B}, one hipGraph replay per step, split-f16 layer set (what every rank of a replica run executes)"
                                             if used_graph and NS == 1 and model.cost_reg_0.conv0_mode == "splitf16" else "see launch / *_arithmetic",
-                          "featurenet_arithmetic": ("fused FPN tail, conv1.1 / conv1.2 / conv2.1 / conv2.2 / smooth1 as conv0's split-f16 (fpn_fused_sf.hip, "
-                                                    "conv2d_ci_splitf16.hip); the other layers float32 MFMA" if model.feature.tail_mode == "splitf16"
+                          "featurenet_arithmetic": ("fused FPN tail, conv1.1 / conv1.2 / conv2.1 / conv2.2 / smooth1 and the 5x5 stride-2 layers conv1.0 / conv2.0 as conv0's "
+                                                    "split-f16 (fpn_fused_sf.hip, conv2d_ci_splitf16.hip, conv2d_k5s2_splitf16.hip); conv0.0 / conv0.1 and the "
+                                                    "1x1 laterals float32 MFMA" if model.feature.tail_mode == "splitf16"
                                                     else "float32 MFMA (fused FPN tail: fpn_fused.hip)")
                                                    if model.feature.fuse_tail else "float32 MFMA, the FPN tail as three steps (lat0, upsample-add, smooth0)",
                           "every_layer_float32_value": "conv0_other_modes.modes[conv0_mode == 'f32'] of this line"},

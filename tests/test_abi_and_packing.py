@@ -503,3 +503,49 @@ def test_conv_s2_splitf16_packing():
     bad[3, 2, 1, 1, 1] = float("inf")
     with pytest.raises(RuntimeError, match="finite"):
         ops.conv_s2_splitf16_pack(bad)
+
+
+def test_conv2d_k5s2_splitf16_packing():
+    """csrc/conv2d_k5s2_splitf16.hip's C packer: lane images [chunk of 8 input channels][step][block of 16 output channels][slice][lane][8 f16], the 25 taps
+    in 32 (step, k-block) slots - pair p = 2 step + (kb >> 1): kx = p >> 1, ky = 2 (p & 1) + (kb & 1) for p < 10; kx = p - 10, ky = 4 on the even member of
+    pairs 10 .. 14; the other seven slots hold zeros.  Every tap appears exactly once, the two float16 slices of 2^kw w add up to the weight, scale carries
+    2^-kw; non-finite weights and other channel counts are rejected."""
+    from casmvsnet_pl_amd import ops
+    g = torch.Generator().manual_seed(6)
+    slots = {}
+    for s in range(8):
+        for kb in range(4):
+            p, m = 2 * s + (kb >> 1), kb & 1
+            if p < 10:
+                slots[(s, kb)] = (2 * (p & 1) + m, p >> 1)
+            elif p < 15 and m == 0:
+                slots[(s, kb)] = (4, p - 10)
+    assert sorted(slots.values()) == [(ky, kx) for ky in range(5) for kx in range(5)]
+    for cin, cout in ((8, 16), (16, 32)):
+        w = torch.randn(cout, cin, 5, 5, generator=g) * 0.2
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        packed = ops.conv2d_k5s2_splitf16_pack(w, scale, shift).numpy()
+        nimg = (cin // 8) * 8 * (cout // 16)
+        assert packed.size == nimg * 2 * 64 * 16 + 2 * cout * 4
+        img = packed[:nimg * 2048].view(np.float16).astype(np.float64).reshape(cin // 8, 8, cout // 16, 2, 4, 16, 8)   # [chunk][step][rb][slice][kb][co & 15][e]
+        tail = packed[nimg * 2048:].view(np.float32)
+        kw = int(round(np.log2(float(scale[0]) / tail[0])))
+        assert np.array_equal(tail[:cout], np.ldexp(scale.numpy(), -kw)) and np.array_equal(tail[cout:], shift.numpy())
+        assert 2.0 ** 13 <= float(w.abs().max()) * 2.0 ** kw < 2.0 ** 14
+        ws = np.ldexp(w.double().numpy(), kw).reshape(cout // 16, 16, cin // 8, 8, 5, 5)    # [rb][i][chunk][e][ky][kx]
+        for s in range(8):
+            for kb in range(4):
+                got = img[:, s, :, 0, kb] + img[:, s, :, 1, kb]                             # [chunk][rb][i][e]
+                if (s, kb) in slots:
+                    ky, kx = slots[(s, kb)]
+                    assert np.abs(got - ws[:, :, :, :, ky, kx].transpose(2, 0, 1, 3)).max() <= 2.0 ** -8
+                else:
+                    assert not got.any() and not img[:, s, :, :, kb].any()
+    with pytest.raises(ValueError):
+        ops.conv2d_k5s2_splitf16_pack(torch.randn(16, 16, 5, 5))
+    with pytest.raises(ValueError):
+        ops.conv2d_k5s2_splitf16_pack(torch.randn(16, 8, 3, 3))
+    bad = torch.randn(16, 8, 5, 5)
+    bad[3, 2, 1, 1] = float("nan")
+    with pytest.raises(RuntimeError, match="finite"):
+        ops.conv2d_k5s2_splitf16_pack(bad)

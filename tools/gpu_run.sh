@@ -27,7 +27,7 @@ ALL=""
 
 stage_native () {
   [ -x tools/probes/bin/deconv9_check ] || bash tools/native/build.sh > $OUT/native_build.txt 2>&1
-  { for pair in ${NATIVE_CHECKS:-"zmarch:conv0_zm_check:2" "deconv11:deconv11_check:2" "deconv9:deconv9_check:2" "conv_s2:conv_s2_check:8"}; do
+  { for pair in ${NATIVE_CHECKS:-"zmarch:conv0_zm_check:2" "deconv11:deconv11_check:2" "deconv9:deconv9_check:2" "conv_s2:conv_s2_check:8" "conv11_prob:conv11_prob_check:8" "conv2d_k5s2:conv2d_k5s2_check:8"}; do
       name=${pair%%:*}; rest=${pair#*:}; c=${rest%%:*}; arg=${rest#*:}
       [ -x tools/probes/bin/$c ] || continue
       timeout 90 tools/probes/bin/$c $arg; rc=$?; echo "-- $c: exit $rc"; [ $rc -eq 0 ] && PASSED="$PASSED $name"
