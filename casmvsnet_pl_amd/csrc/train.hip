@@ -16,6 +16,7 @@
 // workgroup and summed in a fixed order (double for the statistics): results are run-to-run reproducible.
 #include "common.h"
 #include "plane_sweep.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -557,35 +558,42 @@ __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float *_
 // var = Q / V - (S / V)^2 with S = sum of the V views' values, Q = sum of their squares (mvsnet.py:140-167), so
 // d var / d x_v = 2 x_v / V - 2 S / V^2 for the reference (x_0 = ref feature, every plane) and for each warped view.
 // The source-view gradient is the transpose of the bilinear gather (modules.py:87-89): a scatter.  One workgroup owns
-// (a 32 x 32 tile of reference pixels, 8 planes, CG channels, ONE source view): everything it scatters falls into the
-// bounding box of its taps in that view (the epipolar band of the tile: ~40 x 40 pixels), so the contributions are
-// accumulated in an LDS image of that box (ds_add_f32: no memory traffic, no contention between workgroups) and the box is
-// added to the gradient map once, one fp32 atomic per touched element and channel - ~2 atomics per pixel and channel instead
-// of the ~16 of a per-tap scatter (the per-tap form was 6.7 ms at level 1, 28 % of the whole training step).
-// Phase 1: the tile's taps in the view -> box (wave-uniform after an LDS min / max).  Phase 2: per (pixel, plane) the warped
+// (a 32 x TH tile of reference pixels, 8 planes, CG channels, ONE source view): everything it scatters falls into the
+// bounding box of its taps in that view (the epipolar band of the tile: ~44 x 26 pixels at TH = 16), so the contributions are
+// accumulated in an LDS image of that box and the box is added to the gradient map once, one fp32 atomic per touched element
+// and channel - ~2 atomics per pixel and channel instead of the ~16 of a per-tap scatter.
+// The LDS image is FIXED POINT: 64-bit integers, ds_add_u64.  A wave-instruction of ds_add_f32 retires its lanes one by one
+// (768 ticks for 64 lanes with four waves issuing, 27x a ds_add_u32 / 16-20x a ds_add_u64: profiles/r04_lds_atomic_rates.txt)
+// and bound the float form of this kernel (3.7 of the training step's 14.1 ms).  Scale 2^s per workgroup: 2^e >= 16 G R / V with
+// G = the largest |upstream gradient| of the workgroup's (tile, planes, channels) and R = the largest |reference feature| of the
+// tile (a contribution is at most 4 G F / V for features bounded by F; R stands in for F with 4x slack), s = 45 - e.  Every
+// contribution is CHECKED against 2^e while it is formed: |sum in a cell| < 2^15 adds x 2^46 = 2^61, no overflow by
+// construction; a workgroup that sees a larger (or non-finite) contribution drops its image and scatters that pass straight to
+// global memory with float atomics, as does a box that does not fit.  Units of 2^-45 of the bound: contributions 2^-21 of the
+// largest possible one still carry 24 bits, and the image no longer depends on the order of the adds.
+// Phase 1: the tile's taps in the view -> box (wave-uniform after an LDS min / max), G and R.  Phase 2: per (pixel, plane) the warped
 // values of ALL views are re-gathered (S needs them), the own view's gradient goes into the box; the workgroups of the
 // first source view also accumulate the reference view's gradient in registers.  Phase 3: box -> global.
-// A box that does not fit (degenerate geometry) scatters straight to global memory instead.
 // wave shift by one lane (gfx9 DPP wave_shr:1 / wave_shl:1): lane i reads lane i - 1 / i + 1; the first / last lane reads 0
 __device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int lane_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ float lane_prev(float v) { return __builtin_bit_cast(float, lane_prev(__builtin_bit_cast(int, v))); }
 
-template <int CG>
+template <int CG, int TH, int VS>   // VS: the number of source views when the instantiation fixes it (their gathers are then issued together), 0 = V - 1 at run time
 __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *__restrict__ feats, const float *__restrict__ proj,
                                                                   const float *__restrict__ depth, const float *__restrict__ gvol,
                                                                   float *__restrict__ gfeats, int V, int C, int H, int W, int D,
                                                                   int tiles_x, int DCH, int CAP) {
-  constexpr int TS = 32, RPT = TS * TS / kThreads, RSTEP = kThreads / TS;
-  CASMVS_DYNAMIC_LDS(float, smem);
-  float *box = smem;   // [CG][bh][bw], CAP cells per channel
-  __shared__ int ext[(TS * TS / kThreads + 1) * 4];   // tap boxes of the tile's RPT bands of 8 rows, then their union
+  constexpr int TS = 32, RPT = TS * TH / kThreads, RSTEP = kThreads / TS;   // tile: 32 columns x TH rows, a thread's pixels RSTEP rows apart
+  CASMVS_DYNAMIC_LDS(unsigned long long, box);   // [CG][bh][bw], CAP cells per channel: fixed point, units of 2^(e - 45)
+  __shared__ int ext[(RPT + 1) * 4];   // tap boxes of the tile's RPT bands of 8 rows, then their union
+  __shared__ unsigned wgmax[3];                        // bit patterns of G, R; [2]: a contribution outside the fixed-point range was seen
   const int tid = threadIdx.x, b = blockIdx.z, hw = H * W;
   int r = blockIdx.y;
   const int v = 1 + r % (V - 1); r /= (V - 1);
   const int groups = C / CG, c0 = (r % groups) * CG, d_begin = (r / groups) * DCH, d_end = min(d_begin + DCH, D);
   const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-  const int x = txi * TS + (tid & (TS - 1)), yb = tyi * TS + tid / TS;
+  const int x = txi * TS + (tid & (TS - 1)), yb = tyi * TH + tid / TS;
   const float *fb = feats + (size_t)b * V * C * hw;
   float *gb = gfeats + (size_t)b * V * C * hw;
   const float *Pb = proj + (size_t)b * (V - 1) * 12;
@@ -596,20 +604,27 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   // ---- 1. bounding boxes of this view's live taps: the tile's, and (published only when the tile's does not fit the LDS
   // image) one per band of RSTEP rows (a thread's j-th pixel)
   if (tid < (RPT + 1) * 4) ext[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+  if (tid < 3) wgmax[tid] = 0u;
   __syncthreads();
   int bxmn[RPT], bxmx[RPT], bymn[RPT], bymx[RPT];
   int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
+  unsigned gbits = 0u, rbits = 0u;   // maxima of |.| as bit patterns: monotonic for non-negative floats, NaN above infinity
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     bxmn[j] = INT_MAX; bxmx[j] = INT_MIN; bymn[j] = INT_MAX; bymx[j] = INT_MIN;
     const int y = yb + j * RSTEP;
     if (x < W && y < H) {
+#pragma unroll
+      for (int c = 0; c < CG; ++c) rbits = max(rbits, __builtin_bit_cast(unsigned, fb[(size_t)(c0 + c) * hw + y * W + x]) & 0x7fffffffu);
       for (int d = d_begin; d < d_end; ++d) {
         const Taps t = plane_sweep_taps(Pv, (float)x, (float)y, db[(size_t)d * hw + y * W + x], W, H);
         if (taps_live(t)) {
           bxmn[j] = min(bxmn[j], t.xl); bxmx[j] = max(bxmx[j], t.xl + 1);
           bymn[j] = min(bymn[j], t.yn); bymx[j] = max(bymx[j], t.ys);
         }
+        const float *gv = gvol + (((size_t)b * C + c0) * D + d) * hw + y * W + x;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) gbits = max(gbits, __builtin_bit_cast(unsigned, gv[(size_t)c * D * hw]) & 0x7fffffffu);
       }
     }
     xmn = min(xmn, bxmn[j]); xmx = max(xmx, bxmx[j]);
@@ -619,7 +634,19 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     atomicMin(&ext[RPT * 4 + 0], xmn); atomicMax(&ext[RPT * 4 + 1], xmx);
     atomicMin(&ext[RPT * 4 + 2], ymn); atomicMax(&ext[RPT * 4 + 3], ymx);
   }
+  gbits = casmvs::wave_max_bits(gbits);
+  rbits = casmvs::wave_max_bits(rbits);
+  if ((tid & 63) == 0) { atomicMax(&wgmax[0], gbits); atomicMax(&wgmax[1], rbits); }
   __syncthreads();
+  // the fixed-point scale: 2^e >= 16 G R / V (a normal float, or the workgroup scatters with float atomics), unit 2^(e - 45)
+  const float bound = 16.0f * __builtin_bit_cast(float, wgmax[0]) * __builtin_bit_cast(float, wgmax[1]) / fV;
+  const int be = (int)((__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu) - 126;   // bound = m 2^be, m in [0.5, 1)
+  const bool fixed_ok = wgmax[0] < 0x7f800000u && wgmax[1] < 0x7f800000u && be > -90 && be < 90;   // finite, not zero / denormal / huge
+  const float limit = __builtin_bit_cast(float, (unsigned)(be + 127) << 23);                                      // 2^be
+  const double to_fixed = __builtin_bit_cast(double, (unsigned long long)(1023 + 45 - be) << 52);                 // 2^(45 - be)
+  const double from_fixed = __builtin_bit_cast(double, (unsigned long long)(1023 - 45 + be) << 52);
+  constexpr double kMagic = 6755399441055744.0;   // 1.5 2^52: the low mantissa bits of x + kMagic are round(x) in two's complement, |x| < 2^51
+  auto fx = [&](float v) { return (unsigned long long)(__builtin_bit_cast(long long, __builtin_fma((double)v, to_fixed, kMagic)) - __builtin_bit_cast(long long, kMagic)); };
   // The whole tile's box in one LDS image when it fits; otherwise band by band (noisy depth maps spread a tile's taps over
   // far more than its own extent), and a band whose box still does not fit scatters straight to global memory.
   const bool whole = ext[RPT * 4] > ext[RPT * 4 + 1] ||
@@ -640,10 +667,13 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   const int bx0 = eb[0], by0 = eb[2];
   const bool any = eb[0] <= eb[1];
   const int bw = any ? eb[1] - eb[0] + 1 : 0, bh = any ? eb[3] - eb[2] + 1 : 0;
-  const bool in_lds = bw * bh <= CAP;
   const int cells = bw * bh;
+  // second pass of a segment (rare): a contribution left the fixed-point range - the image is dropped and the pass scatters to global memory
+  for (int pass = 0; pass < 2; ++pass) {
+  const bool in_lds = fixed_ok && pass == 0 && cells <= CAP;
   if (in_lds)
-    for (int e = tid; e < CG * cells; e += kThreads) box[e] = 0.0f;
+    for (int e = tid; e < CG * cells; e += kThreads) box[e] = 0ull;
+  bool outside = false;
   __syncthreads();
 
   // ---- 2. per (pixel, plane): S over the views, own view's gradient into the box
@@ -659,27 +689,69 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
       ref[c] = fb[(size_t)(c0 + c) * hw + p];
       gref[c] = 0.0f;
     }
+    // the plane's hypothesis and upstream gradients are loaded one plane ahead (clamped, unconditional: nothing in the loop waits on a load it has just
+    // issued except the gathers - seven serialised round trips per step before, two now, one with VS)
+    const float *gp = gvol + ((size_t)b * C + c0) * D * hw + p;
+    float dv_next = db[(size_t)d_begin * hw + p], g_next[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) g_next[c] = gp[((size_t)c * D + d_begin) * hw];
+    const int nv = V;
     for (int d = d_begin; d < d_end; ++d) {
-      const float dv = db[(size_t)d * hw + p];
-      float S[CG], xv[CG];
+      const float dv = dv_next;
+      float S[CG], xv[CG], gd[CG];
       Taps tv;
 #pragma unroll
-      for (int c = 0; c < CG; ++c) S[c] = ref[c];
-      for (int u = 1; u < V; ++u) {   // dead voxels: all four weights are 0 and the (clamped) addresses are valid
-        const Taps t = plane_sweep_taps(Pb + (u - 1) * 12, (float)xc, (float)y, dv, W, H);
-        const float *fu = fb + ((size_t)u * C + c0) * hw;
-        const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
-        const bool own = u == v;
-        if (own) tv = t;
+      for (int c = 0; c < CG; ++c) {
+        S[c] = ref[c];
+        gd[c] = valid ? g_next[c] : 0.0f;
+      }
+      const int dn = min(d + 1, d_end - 1);
+      dv_next = db[(size_t)dn * hw + p];
 #pragma unroll
-        for (int c = 0; c < CG; ++c) {
-          const float *fc = fu + (size_t)c * hw;
-          const float val = fmaf(fc[os + 1], t.w_sr, fmaf(fc[os], t.w_sl, fmaf(fc[on + 1], t.w_nr, fc[on] * t.w_nl)));
-          S[c] += val;
-          if (own) xv[c] = val;
+      for (int c = 0; c < CG; ++c) g_next[c] = gp[((size_t)c * D + dn) * hw];
+      if constexpr (VS > 0) {   // every view's taps, then every gather, then the arithmetic: one round trip for all views
+        Taps ts[VS];
+        float raw[VS][CG][4];
+#pragma unroll
+        for (int u = 0; u < VS; ++u) ts[u] = plane_sweep_taps(Pb + u * 12, (float)xc, (float)y, dv, W, H);
+#pragma unroll
+        for (int u = 0; u < VS; ++u) {
+          const float *fu = fb + ((size_t)(u + 1) * C + c0) * hw;
+          const int on = ts[u].yn * W + ts[u].xl, os = ts[u].ys * W + ts[u].xl;
+#pragma unroll
+          for (int c = 0; c < CG; ++c) {
+            const float *fc = fu + (size_t)c * hw;
+            raw[u][c][0] = fc[on]; raw[u][c][1] = fc[on + 1]; raw[u][c][2] = fc[os]; raw[u][c][3] = fc[os + 1];
+          }
+        }
+        asm volatile("" ::: "memory");   // keeps the loads above the first use
+#pragma unroll
+        for (int u = 0; u < VS; ++u) {
+          const bool own = u + 1 == v;
+          if (own) tv = ts[u];
+#pragma unroll
+          for (int c = 0; c < CG; ++c) {
+            const float val = fmaf(raw[u][c][3], ts[u].w_sr, fmaf(raw[u][c][2], ts[u].w_sl, fmaf(raw[u][c][1], ts[u].w_nr, raw[u][c][0] * ts[u].w_nl)));
+            S[c] += val;
+            if (own) xv[c] = val;
+          }
+        }
+      } else {
+        for (int u = 1; u < nv; ++u) {   // dead voxels: all four weights are 0 and the (clamped) addresses are valid
+          const Taps t = plane_sweep_taps(Pb + (u - 1) * 12, (float)xc, (float)y, dv, W, H);
+          const float *fu = fb + ((size_t)u * C + c0) * hw;
+          const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
+          const bool own = u == v;
+          if (own) tv = t;
+#pragma unroll
+          for (int c = 0; c < CG; ++c) {
+            const float *fc = fu + (size_t)c * hw;
+            const float val = fmaf(fc[os + 1], t.w_sr, fmaf(fc[os], t.w_sl, fmaf(fc[on + 1], t.w_nr, fc[on] * t.w_nl)));
+            S[c] += val;
+            if (own) xv[c] = val;
+          }
         }
       }
-      const float *gv = gvol + (((size_t)b * C + c0) * D + d) * hw + p;
       const bool live = valid && taps_live(tv);
       // Neighbouring lanes are neighbouring pixels: lane i's RIGHT tap column is usually lane i + 1's LEFT one.  The right
       // contribution travels one lane up (DPP) and is added to the neighbour's left one: ~2 adds per channel and row pair
@@ -694,20 +766,21 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
       const int go_n = tv.yn * W + tv.xl, go_s = tv.ys * W + tv.xl;
 #pragma unroll
       for (int c = 0; c < CG; ++c) {
-        const float g = valid ? gv[(size_t)c * D * hw] : 0.0f;
+        const float g = gd[c];
         const float common = 2.0f * S[c] / (fV * fV);
         gref[c] += g * (2.0f * ref[c] / fV - common);
         const float gx = g * (2.0f * xv[c] / fV - common);
+        outside = outside || (live && !(fabsf(gx) < limit));   // also NaN
         const float rn = gx * tv.w_nr, rs = gx * tv.w_sr;
         const float prn = lane_prev(rn), prs = lane_prev(rs);
         const float an = gx * tv.w_nl + (mp_n ? prn : 0.0f), as = gx * tv.w_sl + (mp_s ? prs : 0.0f);
         if (live) {
           if (in_lds) {
-            float *q = box + c * cells;
-            atomicAdd(q + lo_n, an);
-            if (!ab_n) atomicAdd(q + lo_n + 1, rn);
-            atomicAdd(q + lo_s, as);
-            if (!ab_s) atomicAdd(q + lo_s + 1, rs);
+            unsigned long long *q = box + c * cells;
+            atomicAdd(q + lo_n, fx(an));
+            if (!ab_n) atomicAdd(q + lo_n + 1, fx(rn));
+            atomicAdd(q + lo_s, fx(as));
+            if (!ab_s) atomicAdd(q + lo_s + 1, fx(rs));
           } else {
             float *q = gsv + (size_t)c * hw;
             unsafeAtomicAdd(q + go_n, an);
@@ -718,24 +791,28 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
         }
       }
     }
-    if (v == 1 && valid) {   // view 0 (the reference features): one add per plane chunk
+    if (v == 1 && valid && pass == 0) {   // view 0 (the reference features): one add per plane chunk
 #pragma unroll
       for (int c = 0; c < CG; ++c) unsafeAtomicAdd(gb + (size_t)(c0 + c) * hw + p, gref[c]);
     }
   }
+  if (in_lds && outside) wgmax[2] = 1u;
   __syncthreads();
+  if (!in_lds) break;             // scattered to global memory: done
+  if (wgmax[2] != 0u) continue;   // uniform: read behind the barrier; the second pass does not write it
 
   // ---- 3. box -> gradient map (lanes = consecutive columns of a box row of one channel plane)
-  if (in_lds) {
-    for (int e = tid; e < CG * cells; e += kThreads) {
-      const float val = box[e];
-      if (val != 0.0f) {
-        const int c = e / cells, cell = e - c * cells, row = cell / bw, col = cell - row * bw;
-        unsafeAtomicAdd(gsv + (size_t)c * hw + (by0 + row) * W + bx0 + col, val);
-      }
+  for (int e = tid; e < CG * cells; e += kThreads) {
+    const long long val = (long long)box[e];
+    if (val != 0) {
+      const int c = e / cells, cell = e - c * cells, row = cell / bw, col = cell - row * bw;
+      unsafeAtomicAdd(gsv + (size_t)c * hw + (by0 + row) * W + bx0 + col, (float)((double)val * from_fixed));
     }
   }
-  __syncthreads();   // the image is zeroed again for the next band
+  break;
+  }
+  __syncthreads();   // the image is zeroed again for the next band; wgmax[2] is read before it can change
+  if (tid == 0) wgmax[2] = 0u;
   }
 }
 
@@ -983,25 +1060,24 @@ extern "C" int casmvs_costvol_var_backward_f32(const float *feats, const float *
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)B * V * C * h * w * sizeof(float), st);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "costvol_var_backward: hipMemsetAsync: %s", hipGetErrorString(e));
-  // 8 planes per workgroup; the LDS image holds 2304 box pixels (a 32 x 32 tile whose taps spread over ~48 x 48) of 8 channels
-  // = 72 KiB: two workgroups per CU
-  constexpr int dch = 8, cap = 2304;
-  const int tiles_x = casmvs::ceil_div(w, 32), tiles_y = casmvs::ceil_div(h, 32), chunks = casmvs::ceil_div(D, dch);
+  // 8 planes per workgroup; the LDS image holds 1152 box pixels (a 32 x 16 tile whose taps spread over ~44 x 26) of 4 channels
+  // in 64-bit fixed point = 36 KiB: four workgroups per CU (the kernel waits on its gathers: 0.92 -> ? ms at level 1 from two to four)
+  constexpr int dch = 8, cap = 1152, th = 16;
+  const int tiles_x = casmvs::ceil_div(w, 32), tiles_y = casmvs::ceil_div(h, th), chunks = casmvs::ceil_div(D, dch);
 #define CASMVS_VB(CG)                                                                                                          \
   {                                                                                                                            \
     const long gy = (long)chunks * (C / CG) * (V - 1);                                                                         \
     CASMVS_REQUIRE(gy <= 65535, "costvol_var_backward: D=%d C=%d V=%d: too many (plane chunk, channel group, view) items", D, C, V); \
-    auto kernel = costvol_var_bwd_kernel<CG>;                                                                                  \
-    const size_t lds = (size_t)CG * cap * sizeof(float);                                                                       \
+    auto kernel = V == 3 ? costvol_var_bwd_kernel<CG, th, 2> : costvol_var_bwd_kernel<CG, th, 0>;                              \
+    const size_t lds = (size_t)CG * cap * sizeof(unsigned long long);                                                          \
     if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "costvol_var_bwd_kernel")) return rc; \
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)gy, (unsigned)B);                                                       \
     hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, feats, proj, depth, grad_vol, grad_feats, V, C, h, w, D, tiles_x, \
                        dch, cap);                                                                                              \
     return casmvs::check_launch("costvol_var_bwd_kernel");                                                                     \
   }
-  if (C % 8 == 0 && C <= 64) CASMVS_VB(8)
-  if (C == 4) CASMVS_VB(4)
+  if (C % 4 == 0 && C <= 64) CASMVS_VB(4)
 #undef CASMVS_VB
-  return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_var_backward: C=%d (4 or a multiple of 8 up to 64)", C);
+  return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_var_backward: C=%d (a multiple of 4 up to 64)", C);
 }
 

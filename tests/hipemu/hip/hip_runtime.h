@@ -92,6 +92,13 @@ inline void __syncthreads() {
 inline float unsafeAtomicAdd(float *p, float v) { return std::atomic_ref<float>(*p).fetch_add(v, std::memory_order_relaxed); }
 inline float atomicAdd(float *p, float v) { return std::atomic_ref<float>(*p).fetch_add(v, std::memory_order_relaxed); }
 inline int atomicAdd(int *p, int v) { return std::atomic_ref<int>(*p).fetch_add(v, std::memory_order_relaxed); }
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return std::atomic_ref<unsigned long long>(*p).fetch_add(v, std::memory_order_relaxed); }
+inline unsigned atomicMax(unsigned *p, unsigned v) {
+  std::atomic_ref<unsigned> a(*p);
+  unsigned cur = a.load(std::memory_order_relaxed);
+  while (v > cur && !a.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+  return cur;
+}
 inline int atomicMin(int *p, int v) {
   std::atomic_ref<int> a(*p);
   int cur = a.load(std::memory_order_relaxed);

@@ -107,11 +107,19 @@ static double sums_check(int N, int C, int n) {
 
 // casmvs_costvol_var_backward_f32 (costvol_var_bwd_kernel: the scatter transpose of the plane sweep through an LDS box image with ds_add_f32, the largest kernel of
 // the training step) against d var / d x_v = 2 x_v / V - 2 sum x / V^2 through the bilinear weights, taps from the shared float32 routine, sums in float64
-static double varbwd_check(int B, int V, int C, int D, int h, int w) {
+// mode 1: the source views' features are 1e4 x the reference view's (contributions outside the fixed-point range of the LDS image: the workgroup's second pass
+// scatters with float atomics); mode 2: reference features all zero (no scale: the float path from the start); mode 3: upstream gradients of 1e-30 (a denormal bound)
+static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 0) {
   const size_t hw = (size_t)h * w;
   std::vector<float> feats((size_t)B * V * C * hw), proj((size_t)B * (V - 1) * 12, 0.0f), depth((size_t)B * D * hw), gvol((size_t)B * C * D * hw);
   for (auto &v : feats) v = rnd();
-  for (auto &v : gvol) v = rnd();
+  for (auto &v : gvol) v = rnd() * (mode == 3 ? 1e-30f : 1.0f);
+  if (mode == 1 || mode == 2)
+    for (int b = 0; b < B; ++b)
+      for (size_t i = 0; i < (size_t)C * hw; ++i) {
+        float &r = feats[(size_t)b * V * C * hw + i];
+        r = mode == 1 ? r * 1e-4f : 0.0f;
+      }
   for (int b = 0; b < B; ++b) {
     for (int v = 0; v < V - 1; ++v) {
       float *P = proj.data() + ((size_t)b * (V - 1) + v) * 12;
@@ -174,7 +182,7 @@ static double varbwd_check(int B, int V, int C, int D, int h, int w) {
     err = std::fmax(err, std::isfinite(out[i]) ? std::fabs(want[i] - out[i]) : 1e30);
   }
   std::free(fa); std::free(pa); std::free(da); std::free(ga); std::free(out);
-  printf("var_backward B=%d V=%d C=%d %dx%dx%d: max error / largest gradient = %.2e\n", B, V, C, D, h, w, err / range);
+  printf("var_backward B=%d V=%d C=%d %dx%dx%d mode %d: max error / largest gradient = %.2e\n", B, V, C, D, h, w, mode, err / range);
   return err / range;
 }
 
@@ -189,6 +197,7 @@ int main(int argc, char **argv) {
     take(wgrad_check("K5S2", CASMVS_CONV2D_K5S2, 1, 8, 16, 1, 8, 16));
     take(sums_check(2, 8, 1000));
     take(varbwd_check(1, 3, 8, 8, 6, 36));                                // two 32 x 32 tiles (ragged), one chunk of 8 planes, two source views
+    take(varbwd_check(1, 3, 4, 8, 6, 36, 1));                             // the second (float-atomic) pass of a workgroup
   }
   if (all) {
     take(wgrad_check("S1", CASMVS_CONV_S1, 1, 8, 8, 5, 6, 20));          // ragged in z (tile 4), y and x
@@ -201,7 +210,9 @@ int main(int argc, char **argv) {
     take(wgrad_check("T2", CASMVS_CONV_T2, 1, 32, 16, 1, 4, 6));
     take(sums_check(1, 16, 70000));
     take(varbwd_check(1, 3, 8, 8, 12, 36));
-    take(varbwd_check(2, 2, 16, 16, 34, 40));                             // two channel groups, two plane chunks, four tiles
+    take(varbwd_check(2, 2, 16, 16, 34, 40));                             // four channel groups, two plane chunks, four tiles
+    take(varbwd_check(1, 3, 8, 8, 6, 36, 2));
+    take(varbwd_check(1, 2, 4, 5, 6, 36, 3));
   }
   printf(worst < 3e-6 ? "ALL OK (worst %.2e)\n" : "FAILED (worst %.2e)\n", worst);
   return worst < 3e-6 ? 0 : 1;

@@ -195,6 +195,53 @@ def test_variance_volume_backward_matches_autograd_of_the_oracle(dev, report, B,
     assert errs["fwd"] < 1e-5 and errs["g_feats"] < 3e-5
 
 
+@pytest.mark.parametrize("case", ["source_views_1e4x", "zero_reference", "tiny_gradients", "huge_gradients", "one_outlier", "nan_gradient"])
+def test_variance_volume_backward_outside_the_fixed_point_range(dev, report, case):
+    """costvol_var_bwd_kernel accumulates a workgroup's scatter in a 64-bit FIXED-POINT LDS image whose scale comes from the largest upstream gradient and the
+    largest reference feature of the workgroup's tile; every contribution is checked against the range while it is formed.  What leaves the range - source
+    views far larger than the reference view, an outlier, no scale at all (zero reference features, gradients of 1e-30 / 1e30) - makes the workgroup scatter
+    with float atomics instead: the same result within the same bound.  A NaN upstream gradient reaches exactly the elements the float form would poison
+    (and no finite element changes)."""
+    from casmvsnet_pl_amd import training as T
+    from casmvsnet_pl_amd.synthetic import make_inputs
+    B, V, C, h, w, D = 1, 3, 8, 48, 72, 10
+    g = torch.Generator().manual_seed(7)
+    _, proj, dmin, dint = make_inputs(B, V, h, w, seed=3, geometry="dtu")
+    P = proj[:, :, 0].contiguous()
+    feats = torch.randn(B, V, C, h, w, generator=g)
+    depth = dmin + torch.rand(B, D, h, w, generator=g) * 400.0
+    gv = torch.randn(B, C, D, h, w, generator=g)
+    if case == "source_views_1e4x":
+        feats[:, 0] *= 1e-4
+    elif case == "zero_reference":
+        feats[:, 0] = 0.0
+    elif case == "tiny_gradients":
+        gv *= 1e-30
+    elif case == "huge_gradients":
+        gv *= 1e30
+        feats *= 1e-3
+    elif case == "one_outlier":
+        feats[0, 1, 3, 20, 30] = 3e5
+    elif case == "nan_gradient":
+        gv[0, 2, 4, 17, 40] = float("nan")
+    fr = feats.clone().requires_grad_(True)
+    want = R.cost_volume(fr, P, depth, 1)
+    want.backward(gv)
+    fd = feats.to(dev).requires_grad_(True)
+    got = T.variance_volume(fd, P.to(dev), depth.to(dev))
+    got.backward(gv.to(dev))
+    gd, gr = fd.grad.cpu(), fr.grad
+    if case == "nan_gradient":
+        bad_ref, bad_got = ~torch.isfinite(gr), ~torch.isfinite(gd)
+        assert bad_ref.any() and torch.equal(bad_ref, bad_got)
+        err = scaled_err(torch.where(bad_ref, torch.zeros_like(gd), gd), torch.where(bad_ref, torch.zeros_like(gr), gr))
+    else:
+        assert torch.isfinite(gd).all()
+        err = scaled_err(gd, gr)
+    report("train_variance_volume_range", case=case, g_feats=err)
+    assert err < 3e-5
+
+
 @pytest.mark.parametrize("B,V,C,h,w,D,G,geometry", [(1, 3, 8, 24, 32, 4, 8, "dtu"), (2, 3, 16, 16, 24, 8, 4, "dtu"), (1, 4, 32, 16, 16, 3, 8, "random"),
                                                        (1, 3, 8, 48, 64, 6, 2, "dtu"), (1, 5, 32, 20, 28, 4, 8, "dtu")])
 def test_groupwise_volume_backward_matches_autograd_of_the_oracle(dev, report, B, V, C, h, w, D, G, geometry):
