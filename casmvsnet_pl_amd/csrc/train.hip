@@ -612,21 +612,33 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     bxmn[j] = INT_MAX; bxmx[j] = INT_MIN; bymn[j] = INT_MAX; bymx[j] = INT_MIN;
-    const int y = yb + j * RSTEP;
-    if (x < W && y < H) {
+    // clamped, unconditional loads, eight planes at a time: every load of a pixel's planes is in flight before the first tap is computed
+    const int yr = yb + j * RSTEP;
+    const bool valid = x < W && yr < H;
+    const int p = min(yr, H - 1) * W + min(x, W - 1);
+    const float *gp = gvol + ((size_t)b * C + c0) * D * hw + p;
+    unsigned rb = 0u, gbt = 0u;
 #pragma unroll
-      for (int c = 0; c < CG; ++c) rbits = max(rbits, __builtin_bit_cast(unsigned, fb[(size_t)(c0 + c) * hw + y * W + x]) & 0x7fffffffu);
-      for (int d = d_begin; d < d_end; ++d) {
-        const Taps t = plane_sweep_taps(Pv, (float)x, (float)y, db[(size_t)d * hw + y * W + x], W, H);
-        if (taps_live(t)) {
+    for (int c = 0; c < CG; ++c) rb = max(rb, __builtin_bit_cast(unsigned, fb[(size_t)(c0 + c) * hw + p]) & 0x7fffffffu);
+    for (int d0 = d_begin; d0 < d_end; d0 += 8) {
+      float dvs[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int d = min(d0 + i, d_end - 1);
+        dvs[i] = db[(size_t)d * hw + p];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) gbt = max(gbt, __builtin_bit_cast(unsigned, gp[((size_t)c * D + d) * hw]) & 0x7fffffffu);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const Taps t = plane_sweep_taps(Pv, (float)x, (float)yr, dvs[i], W, H);
+        if (valid && taps_live(t)) {
           bxmn[j] = min(bxmn[j], t.xl); bxmx[j] = max(bxmx[j], t.xl + 1);
           bymn[j] = min(bymn[j], t.yn); bymx[j] = max(bymx[j], t.ys);
         }
-        const float *gv = gvol + (((size_t)b * C + c0) * D + d) * hw + y * W + x;
-#pragma unroll
-        for (int c = 0; c < CG; ++c) gbits = max(gbits, __builtin_bit_cast(unsigned, gv[(size_t)c * D * hw]) & 0x7fffffffu);
       }
     }
+    if (valid) { rbits = max(rbits, rb); gbits = max(gbits, gbt); }
     xmn = min(xmn, bxmn[j]); xmx = max(xmx, bxmx[j]);
     ymn = min(ymn, bymn[j]); ymx = max(ymx, bymx[j]);
   }
