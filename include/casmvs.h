@@ -515,7 +515,9 @@ int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_va
  *   up (N,C,H/2,W/2) (mvsnet.py:36-38); grad_up = the transpose of the interpolation applied to grad_out (a gather).
  * casmvs_costvol_var_backward_f32: gradient of the variance volume (mvsnet.py:137-167) w.r.t. feats (B,V,C,h,w) given
  *   grad_vol (B,C,D,h,w): d var / d x_v = 2 x_v / V - 2 sum_v x_v / V^2 through the plane sweep's bilinear weights
- *   (reference view: no warp).  grad_feats is zeroed by the call; the hypotheses get no gradient (mvsnet.py:231). */
+ *   (reference view: no warp).  grad_feats is zeroed by the call; the hypotheses get no gradient (mvsnet.py:231).  C: a multiple of
+ *   4 up to 64.  A workgroup accumulates its scatter in a 64-bit fixed-point LDS image (LDS float atomics retire lane by lane on
+ *   gfx950) whose range every contribution is checked against; outside it the workgroup scatters with float atomics (csrc/train.hip). */
 size_t casmvs_conv_wgrad_workspace_bytes(int kind, int B, int cin, int cout, int D, int H, int W);
 int casmvs_conv_wgrad_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
                           int cin, int cout, int D, int H, int W, void *stream);
