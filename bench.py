@@ -724,7 +724,7 @@ def main():
                           "every_layer_float32_value": "conv0_other_modes.modes[conv0_mode == 'f32'] of this line"},
                          median,
                          dtype="f32" if model.cost_reg_0.conv0_mode == "f32" and model.cost_reg_0.ci_mode == "f32" and model.feature.tail_mode == "f32" else
-                               "f32 (tensors and accumulation float32; products of CostRegNet's conv0 / 2 / 4 / 6 / 9 / 11 and six FeatureNet layers formed on the f16 matrix cores from two float16 slices per operand)")
+                               "f32 (tensors and accumulation float32; products of CostRegNet's conv0 - conv4 / 6 / 9 / 11 and eight FeatureNet layers formed on the f16 matrix cores from two float16 slices per operand)")
         line["library_sha16"] = library_sha16()
         line["source_sha16"] = source_sha16()
 
