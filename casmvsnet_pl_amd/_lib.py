@@ -115,6 +115,7 @@ SYMBOLS = {
     "casmvs_abn_backward_sums_f64": (c_int, [_FP] * 6 + [c_int, c_int, c_size_t, c_float, c_void_p]),
     "casmvs_abn_backward_apply_f32": (c_int, [_FP] * 9 + [c_int, c_int, c_size_t, c_float, c_void_p]),
     "casmvs_pack_gather_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "casmvs_pack_gather_batch_f32": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "casmvs_abn_train_finish_f32": (c_int, [_FP, c_int, c_int, c_double, _FP, _FP, c_float, c_float, c_float] + [_FP] * 6 + [c_void_p]),
     "casmvs_abn_backward_finish_f32": (c_int, [_FP, c_int, c_int, c_double, _FP, c_float] + [_FP] * 4 + [c_void_p]),
     "casmvs_upsample2x_add_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),

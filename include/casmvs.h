@@ -544,6 +544,15 @@ int casmvs_abn_backward_apply_f32(const float *grad_y, const float *y, const flo
                                   float slope, void *stream);
 int casmvs_pack_gather_f32(const float *weight, const float *bias, const int *index, float *out, int n_weight, int n_bias,
                            int n_out, void *stream);
+/* The same gather for many layer images in ONE launch (training: every image of a step; casmvsnet_pl_amd/training.py's pack plan).  `segments`: DEVICE
+ * array; segment s is gathered by the workgroups first_block .. first_block + ceil(n_out / 256) - 1 (ascending, no gaps; n_blocks = their total). */
+typedef struct casmvs_pack_segment {
+  const float *weight, *bias; /* bias may be NULL when n_bias == 0 */
+  const int *index;
+  float *out;
+  int n_weight, n_bias, n_out, first_block;
+} casmvs_pack_segment;
+int casmvs_pack_gather_batch_f32(const casmvs_pack_segment *segments, int n_segments, int n_blocks, void *stream);
 int casmvs_abn_train_finish_f32(const double *sums, int blocks, int C, double count, const float *weight, const float *bias,
                                 float abs_eps, float eps, float momentum, float *running_mean, float *running_var, float *scale,
                                 float *shift, float *mean, float *rstd, void *stream);

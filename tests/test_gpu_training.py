@@ -272,6 +272,59 @@ def test_groupwise_volume_backward_matches_autograd_of_the_oracle(dev, report, B
     assert errs["fwd"] < 1e-5 and errs["g_feats"] < 3e-5 and errs["g_ref_view"] < 3e-5 and errs["g_vs_composed"] < 3e-5
 
 
+def test_pack_plan_fills_every_layer_image_of_a_step_in_one_launch(dev, report):
+    """training.PackPlan: the first training step records its packing requests (one casmvs_pack_gather_f32 launch each), every later step fills all of
+    them with ONE casmvs_pack_gather_batch_f32 launch at the start of the forward - the images the batched launch writes are the images the single
+    launches write (bit for bit, after an optimizer step changed every weight), no request of steps 2 / 3 takes a launch of its own, and a parameter
+    modified behind the plan's back (after begin_step) is packed again on its own instead of being served stale."""
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet
+    from casmvsnet_pl_amd import training as T
+    from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
+    model = CascadeMVSNet(norm_act=ABN)
+    randomize_state_dict(model.state_dict(), seed=2)
+    model = model.to(dev).train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4)
+    imgs, proj, dmin, dint = make_inputs(1, 3, 64, 96, seed=0)
+    imgs, proj = imgs.to(dev), proj.to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(imgs, proj, dmin, dint)
+        sum(out[f"depth_{l}"].mean() for l in range(3)).backward()
+        opt.step()
+
+    step()
+    plan = T.pack_plan_of(model)
+    n = len(plan.entries)
+    assert n >= 80 and plan.launches == 0 and plan.hits == 0 and plan.misses == n
+    step()
+    assert plan.launches == 1 and len(plan.entries) == n and plan.hits == n and plan.misses == n
+    step()
+    assert plan.launches == 2 and plan.hits == 2 * n and plan.misses == n
+    # the batched launch against the single launches, on the weights as they are now
+    plan.begin_step()
+    T._ACTIVE_PLAN = None
+    worst = 0
+    for (wt, bz, idx, out, _), key in zip(list(plan.entries.values()), list(plan.entries)):
+        single = T.device_pack(key[2], wt, bz, adjoint=key[3])
+        assert single.data_ptr() != out.data_ptr()
+        worst = max(worst, int((single != out).sum()))
+    assert worst == 0
+    # a weight changed after begin_step: its image is packed again, not served from the plan
+    T._ACTIVE_PLAN = plan
+    plan.begin_step()
+    wt, bz, idx, out, _ = next(iter(plan.entries.values()))
+    key = next(iter(plan.entries))
+    before = (plan.hits, plan.misses)
+    with torch.no_grad():
+        wt.mul_(2.0)
+    again = T.device_pack(key[2], wt, bz, adjoint=key[3])
+    assert (plan.hits, plan.misses) == (before[0], before[1] + 1)
+    T._ACTIVE_PLAN = None
+    assert torch.equal(again, T.device_pack(key[2], wt, bz, adjoint=key[3]))
+    report("train_pack_plan", images=n, batched_launches=plan.launches)
+
+
 def _oracle_train_step(sd0, dtype, imgs, proj, dmin, dint, G):
     """One train-mode forward + backward of the oracle (pinned to the live reference by tests/test_oracle.py) in `dtype`:
     -> outputs, state dict (leaf tensors with .grad, running statistics updated)."""
