@@ -549,3 +549,26 @@ def test_conv2d_k5s2_splitf16_packing():
     bad[3, 2, 1, 1] = float("nan")
     with pytest.raises(RuntimeError, match="finite"):
         ops.conv2d_k5s2_splitf16_pack(bad)
+
+
+def test_pack_segment_layout_matches_the_header():
+    """training.PackPlan writes casmvs_pack_segment records from numpy: four pointers and four int32, 48 bytes, in the order of include/casmvs.h (the C side
+    pins its own mirror against the header with a static_assert)."""
+    import ctypes
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "casmvs.h")).read()
+    body = re.search(r"typedef struct casmvs_pack_segment \{(.*?)\} casmvs_pack_segment;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n.strip(" *") for decl in body.split(";") if decl.strip() for n in decl.split(",")]
+    names = [n.split()[-1].strip("*") for n in names]
+    assert names == ["weight", "bias", "index", "out", "n_weight", "n_bias", "n_out", "first_block"]
+
+    class Seg(ctypes.Structure):
+        _fields_ = [("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("index", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                    ("n_weight", ctypes.c_int), ("n_bias", ctypes.c_int), ("n_out", ctypes.c_int), ("first_block", ctypes.c_int)]
+    dt = np.dtype([("w", "<u8"), ("b", "<u8"), ("idx", "<u8"), ("out", "<u8"), ("n_w", "<i4"), ("n_b", "<i4"), ("n_out", "<i4"), ("first", "<i4")])
+    assert ctypes.sizeof(Seg) == dt.itemsize == 48
+    assert [dt.fields[k][1] for k in dt.names] == [getattr(Seg, f[0]).offset for f in Seg._fields_]
+    import inspect
+    from casmvsnet_pl_amd import training
+    assert '("w", "<u8"), ("b", "<u8"), ("idx", "<u8"), ("out", "<u8"), ("n_w", "<i4"), ("n_b", "<i4")' in inspect.getsource(training.PackPlan.begin_step)
