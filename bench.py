@@ -344,6 +344,8 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
     n_ev = (K + every - 1) // every
     timer = StageTimer()
     timer.reserve((2 * 13 + 14 + 36) * n_ev)
+    for _ in range(2):   # untimed: the eager pass allocates outside the captured graph's pool - at 1152x864 x 5 views the first kernel-by-kernel step
+        model(*inputs)   # spends tens of ms in hipMalloc between the events of a stage (costvol_1 read 22.9 ms for a 4 ms kernel)
     barrier()
     t0 = time.perf_counter()
     for i in range(K):   # events on every `every`-th step: the GPU stays busy in between
