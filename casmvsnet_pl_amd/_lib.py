@@ -118,6 +118,8 @@ SYMBOLS = {
     "casmvs_pack_gather_batch_f32": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "casmvs_abn_train_finish_f32": (c_int, [_FP, c_int, c_int, c_double, _FP, _FP, c_float, c_float, c_float] + [_FP] * 6 + [c_void_p]),
     "casmvs_abn_backward_finish_f32": (c_int, [_FP, c_int, c_int, c_double, _FP, c_float] + [_FP] * 4 + [c_void_p]),
+    "casmvs_abn_train_apply_f32": (c_int, [_FP, _FP, c_int, c_double, _FP, _FP, c_float, c_float, c_float] + [_FP] * 7 + [c_int, c_int, c_size_t, c_float, c_void_p]),
+    "casmvs_abn_backward_apply_fused_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_double, _FP, c_float] + [_FP] * 6 + [c_int, c_int, c_size_t, c_float, c_void_p]),
     "casmvs_upsample2x_add_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_upsample2x_backward_f32": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_var_backward_f32": (c_int, [_FP] * 5 + [c_int] * 6 + [c_void_p]),

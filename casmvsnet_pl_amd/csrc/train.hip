@@ -522,6 +522,119 @@ __global__ __launch_bounds__(64) void abn_bwd_finish_kernel(const double *__rest
   m2[c] = (float)(s1 / M);
 }
 
+// ---- the per-channel epilogue INSIDE the elementwise kernel ----------------------------------------------------------------
+// The two epilogue kernels above are one-workgroup launches between the statistics pass and the elementwise pass of every layer and direction: 76 of
+// them per training step, ~6.3 us each plus the kernel boundary.  These forms let every workgroup of the elementwise pass reduce the channel's <= 256
+// partial sums itself (one per thread, a fixed-order tree in LDS: every workgroup of a channel gets the same bits) and derive the channel's constants;
+// the first workgroup of the channel's first image also writes them out (the backward pass needs them) and updates the running statistics.
+constexpr int kAbnChunk = 2048;   // elements per workgroup: two 16-byte accesses per thread when the plane size allows
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void channel_totals(const double *__restrict__ sums, int blocks, int c, double &t0, double &t1) {
+  __shared__ double red[2][kThreads];
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += kThreads) {
+    s0 += sums[((size_t)c * blocks + b) * 2];
+    s1 += sums[((size_t)c * blocks + b) * 2 + 1];
+  }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+  __syncthreads();
+  for (int st = kThreads / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + st];
+      red[1][threadIdx.x] += red[1][threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  t0 = red[0][0]; t1 = red[1][0];
+}
+
+// y = lrelu(x * a + b) with a, b from the batch statistics of casmvs_channel_sums_f64 (abn_train_finish_kernel's arithmetic)
+__global__ __launch_bounds__(kThreads) void abn_train_apply_kernel(const float *__restrict__ x, const double *__restrict__ sums, int blocks, double M,
+                                                                  const float *__restrict__ weight, const float *__restrict__ bias, float abs_eps,
+                                                                  float eps, float momentum, float *__restrict__ rmean, float *__restrict__ rvar,
+                                                                  float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean,
+                                                                  float *__restrict__ rstd, float *__restrict__ y, int C, size_t n, float slope) {
+  const int nc = blockIdx.y, c = nc % C;
+  double s0, s1;
+  channel_totals(sums, blocks, c, s0, s1);
+  const double mu = s0 / M;
+  double var = s1 / M - mu * mu;   // biased
+  var = var > 0.0 ? var : 0.0;
+  const double rs = 1.0 / sqrt(var + (double)eps);
+  const double g = abs_eps >= 0.0f ? (double)(fabsf(weight[c]) + abs_eps) : (double)weight[c];
+  const float a = (float)(g * rs), bq = (float)((double)bias[c] - mu * g * rs);
+  if (blockIdx.x == 0 && nc == c && threadIdx.x == 0) {
+    scale[c] = a;
+    shift[c] = bq;
+    mean[c] = (float)mu;
+    rstd[c] = (float)rs;
+    if (rmean) {   // F.batch_norm: running = (1 - momentum) * running + momentum * batch (running_var: unbiased)
+      const float keep = (float)(1.0 - (double)momentum);
+      rmean[c] = rmean[c] * keep + momentum * (float)mu;
+      rvar[c] = rvar[c] * keep + momentum * (float)(var * (M / (M > 1.0 ? M - 1.0 : 1.0)));
+    }
+  }
+  const size_t lo = (size_t)blockIdx.x * kAbnChunk, hi = lo + kAbnChunk < n ? lo + kAbnChunk : n;
+  const float *xp = x + (size_t)nc * n;
+  float *yp = y + (size_t)nc * n;
+  if ((n & 3) == 0) {   // planes start on 16-byte boundaries
+    for (size_t e = lo + 4 * (size_t)threadIdx.x; e < hi; e += 4 * kThreads) {
+      vf4 v = *reinterpret_cast<const vf4 *>(xp + e);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float t = fmaf(v[i], a, bq);
+        v[i] = t > 0.0f ? t : t * slope;
+      }
+      *reinterpret_cast<vf4 *>(yp + e) = v;
+    }
+  } else {
+    for (size_t e = lo + threadIdx.x; e < hi; e += kThreads) {
+      const float v = fmaf(xp[e], a, bq);
+      yp[e] = v > 0.0f ? v : v * slope;
+    }
+  }
+}
+
+// gx = a * (g - m1 - xhat * m2) with m1, m2 from the sums of casmvs_abn_backward_sums_f64 (abn_bwd_finish_kernel's arithmetic)
+__global__ __launch_bounds__(kThreads) void abn_bwd_apply_stats_kernel(const float *__restrict__ gy, const float *__restrict__ y, const float *__restrict__ x,
+                                                                      const double *__restrict__ sums, int blocks, double M,
+                                                                      const float *__restrict__ weight, float abs_eps, const float *__restrict__ a,
+                                                                      const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                      float *__restrict__ gweight, float *__restrict__ gbias, float *__restrict__ gx,
+                                                                      int C, size_t n, float slope) {
+  const int nc = blockIdx.y, c = nc % C;
+  double s0, s1;
+  channel_totals(sums, blocks, c, s0, s1);
+  const float m1 = (float)(s0 / M), m2 = (float)(s1 / M);
+  if (blockIdx.x == 0 && nc == c && threadIdx.x == 0) {
+    const float w = weight[c];
+    const float sgn = abs_eps >= 0.0f ? (w > 0.0f ? 1.0f : (w < 0.0f ? -1.0f : 0.0f)) : 1.0f;   // d|w| / dw
+    gweight[c] = (float)s1 * sgn;
+    gbias[c] = (float)s0;
+  }
+  const float ac = a[c], mu = mean[c], rs = rstd[c];
+  const size_t lo = (size_t)blockIdx.x * kAbnChunk, hi = lo + kAbnChunk < n ? lo + kAbnChunk : n;
+  const size_t base = (size_t)nc * n;
+  auto one = [&](float gyv, float yv, float xv) {
+    const float g = gyv * (yv > 0.0f ? 1.0f : slope);
+    const float xhat = (xv - mu) * rs;
+    return ac * (g - m1 - xhat * m2);
+  };
+  if ((n & 3) == 0) {
+    for (size_t e = lo + 4 * (size_t)threadIdx.x; e < hi; e += 4 * kThreads) {
+      const vf4 gv = *reinterpret_cast<const vf4 *>(gy + base + e), yv = *reinterpret_cast<const vf4 *>(y + base + e);
+      const vf4 xv = *reinterpret_cast<const vf4 *>(x + base + e);
+      vf4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = one(gv[i], yv[i], xv[i]);
+      *reinterpret_cast<vf4 *>(gx + base + e) = o;
+    }
+  } else {
+    for (size_t e = lo + threadIdx.x; e < hi; e += kThreads) gx[base + e] = one(gy[base + e], y[base + e], x[base + e]);
+  }
+}
+
 // ---- FPN top-down step ----------------------------------------------------------------------------------------------------
 // ATen upsample_bilinear2d, align_corners = True: src = o * (n_in - 1) / (n_out - 1), i0 = floor(src), i1 = i0 + (i0 < n_in - 1),
 // l1 = src - i0, l0 = 1 - l1; value = l0y * (l0x v00 + l1x v01) + l1y * (l0x v10 + l1x v11)
@@ -1063,6 +1176,35 @@ extern "C" int casmvs_abn_train_finish_f32(const double *sums, int blocks, int C
   hipLaunchKernelGGL(abn_train_finish_kernel, dim3((unsigned)casmvs::ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, blocks, C, count,
                      weight, bias, abs_eps, eps, momentum, running_mean, running_var, scale, shift, mean, rstd);
   return casmvs::check_launch("abn_train_finish_kernel");
+}
+
+// casmvs_abn_train_finish_f32 + casmvs_abn_apply_f32 as one launch
+extern "C" int casmvs_abn_train_apply_f32(const float *x, const double *sums, int blocks, double count, const float *weight, const float *bias,
+                                          float abs_eps, float eps, float momentum, float *running_mean, float *running_var, float *scale,
+                                          float *shift, float *mean, float *rstd, float *y, int N, int C, size_t n, float slope, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(x && y && sums && weight && bias && scale && shift && mean && rstd && blocks > 0 && count > 0.0 && N > 0 && C > 0 &&
+                     (size_t)N * C <= 65535 && n > 0 && (running_mean != nullptr) == (running_var != nullptr),
+                 "abn_train_apply: bad arguments");
+  hipLaunchKernelGGL(abn_train_apply_kernel, dim3((unsigned)((n + kAbnChunk - 1) / kAbnChunk), (unsigned)(N * C)), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, sums, blocks, count, weight, bias, abs_eps, eps, momentum, running_mean, running_var, scale, shift, mean,
+                     rstd, y, C, n, slope);
+  return casmvs::check_launch("abn_train_apply_kernel");
+}
+
+// casmvs_abn_backward_finish_f32 + casmvs_abn_backward_apply_f32 as one launch (m1 / m2 stay inside the kernel)
+extern "C" int casmvs_abn_backward_apply_fused_f32(const float *grad_y, const float *y, const float *x, const double *sums, int blocks, double count,
+                                                   const float *weight, float abs_eps, const float *scale, const float *mean, const float *rstd,
+                                                   float *grad_weight, float *grad_bias, float *grad_x, int N, int C, size_t n, float slope,
+                                                   void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(grad_y && y && x && sums && weight && scale && mean && rstd && grad_weight && grad_bias && grad_x && blocks > 0 && count > 0.0 &&
+                     N > 0 && C > 0 && (size_t)N * C <= 65535 && n > 0,
+                 "abn_backward_apply_fused: bad arguments");
+  hipLaunchKernelGGL(abn_bwd_apply_stats_kernel, dim3((unsigned)((n + kAbnChunk - 1) / kAbnChunk), (unsigned)(N * C)), dim3(kThreads), 0,
+                     (hipStream_t)stream, grad_y, y, x, sums, blocks, count, weight, abs_eps, scale, mean, rstd, grad_weight, grad_bias, grad_x, C, n,
+                     slope);
+  return casmvs::check_launch("abn_bwd_apply_stats_kernel");
 }
 
 // sums: (C, blocks, 2) doubles from casmvs_abn_backward_sums_f64

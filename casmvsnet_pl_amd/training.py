@@ -307,8 +307,8 @@ def conv(x, weight, bias, kind):
 class _ABNTrain(torch.autograd.Function):
     """y = leaky_relu(batch_norm(x) with BATCH statistics); updates the running statistics in place like F.batch_norm.
     `weight` is the module's parameter; abs_eps >= 0 selects InPlaceABN's gamma = |weight| + abs_eps (inplace_abn.py).
-    Per layer: channel sums -> ONE per-channel epilogue kernel (statistics, folded scale / shift, running statistics) ->
-    the elementwise apply; nothing of it is a torch operation."""
+    Per layer: channel sums -> the elementwise apply, whose workgroups derive the statistics, the folded scale / shift and (one of them) the running
+    statistics from the partial sums themselves; nothing of it is a torch operation."""
 
     @staticmethod
     def forward(ctx, x, weight, beta, running_mean, running_var, momentum, eps, slope, abs_eps):
@@ -327,13 +327,12 @@ class _ABNTrain(torch.autograd.Function):
             st = _stream(x)
             rc = lib.casmvs_channel_sums_f64(_ptr(x), _ptr(part), N, C, n, st)
             _lib.check(rc, "casmvs_channel_sums_f64")
-            rc = lib.casmvs_abn_train_finish_f32(_ptr(part), blocks, C, float(M), _ptr(w), _ptr(bta), float(abs_eps), float(eps),
-                                                 float(momentum), _ptr(running_mean) if track else None,
-                                                 _ptr(running_var) if track else None, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
-                                                 _ptr(vec[3]), st)
-            _lib.check(rc, "casmvs_abn_train_finish_f32")
-            rc = lib.casmvs_abn_apply_f32(_ptr(x), _ptr(vec[0]), _ptr(vec[1]), _ptr(y), N, C, n, float(slope), st)
-            _lib.check(rc, "casmvs_abn_apply_f32")
+            # statistics -> folded scale / shift, running statistics AND the elementwise pass in one launch (every workgroup reduces the partial sums)
+            rc = lib.casmvs_abn_train_apply_f32(_ptr(x), _ptr(part), blocks, float(M), _ptr(w), _ptr(bta), float(abs_eps), float(eps),
+                                                float(momentum), _ptr(running_mean) if track else None,
+                                                _ptr(running_var) if track else None, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+                                                _ptr(vec[3]), _ptr(y), N, C, n, float(slope), st)
+            _lib.check(rc, "casmvs_abn_train_apply_f32")
         if track:   # the kernel wrote the buffers behind torch's back: bump their version counters (packed-weight caches key on them)
             torch.autograd.graph.increment_version(running_mean)
             torch.autograd.graph.increment_version(running_var)
@@ -350,19 +349,17 @@ class _ABNTrain(torch.autograd.Function):
         lib = _lib.load()
         blocks = lib.casmvs_channel_sums_blocks(N, n)
         part = torch.empty((C, blocks, 2), dtype=torch.float64, device=x.device)
-        out = torch.empty((4, C), dtype=torch.float32, device=x.device)   # grad_weight, grad_bias, m1, m2
+        out = torch.empty((2, C), dtype=torch.float32, device=x.device)   # grad_weight, grad_bias
         gx = torch.empty_like(x)
         scale, mean, rstd = vec[0], vec[2], vec[3]
         with torch.cuda.device(x.device):
             st = _stream(x)
             rc = lib.casmvs_abn_backward_sums_f64(_ptr(gy), _ptr(y), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(part), N, C, n, ctx.slope, st)
             _lib.check(rc, "casmvs_abn_backward_sums_f64")
-            rc = lib.casmvs_abn_backward_finish_f32(_ptr(part), blocks, C, float(ctx.M), _ptr(w), ctx.abs_eps, _ptr(out[0]), _ptr(out[1]),
-                                                    _ptr(out[2]), _ptr(out[3]), st)
-            _lib.check(rc, "casmvs_abn_backward_finish_f32")
-            rc = lib.casmvs_abn_backward_apply_f32(_ptr(gy), _ptr(y), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(out[2]), _ptr(out[3]),
-                                                   _ptr(gx), N, C, n, ctx.slope, st)
-            _lib.check(rc, "casmvs_abn_backward_apply_f32")
+            rc = lib.casmvs_abn_backward_apply_fused_f32(_ptr(gy), _ptr(y), _ptr(x), _ptr(part), blocks, float(ctx.M), _ptr(w), ctx.abs_eps,
+                                                         _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(out[0]), _ptr(out[1]), _ptr(gx), N, C, n,
+                                                         ctx.slope, st)
+            _lib.check(rc, "casmvs_abn_backward_apply_fused_f32")
         return gx, out[0], out[1], None, None, None, None, None, None
 
 

@@ -558,6 +558,15 @@ int casmvs_abn_train_finish_f32(const double *sums, int blocks, int C, double co
                                 float *shift, float *mean, float *rstd, void *stream);
 int casmvs_abn_backward_finish_f32(const double *sums, int blocks, int C, double count, const float *weight, float abs_eps,
                                    float *grad_weight, float *grad_bias, float *m1, float *m2, void *stream);
+/* The two per-channel epilogues folded into the elementwise passes (what casmvsnet_pl_amd/training.py calls): every workgroup reduces the channel's
+ * partial sums itself; casmvs_abn_train_apply_f32 = casmvs_abn_train_finish_f32 + casmvs_abn_apply_f32, casmvs_abn_backward_apply_fused_f32 =
+ * casmvs_abn_backward_finish_f32 + casmvs_abn_backward_apply_f32 (grad_weight / grad_bias written, m1 / m2 internal): one launch less per layer and pass. */
+int casmvs_abn_train_apply_f32(const float *x, const double *sums, int blocks, double count, const float *weight, const float *bias, float abs_eps,
+                               float eps, float momentum, float *running_mean, float *running_var, float *scale, float *shift, float *mean,
+                               float *rstd, float *y, int N, int C, size_t n, float slope, void *stream);
+int casmvs_abn_backward_apply_fused_f32(const float *grad_y, const float *y, const float *x, const double *sums, int blocks, double count,
+                                        const float *weight, float abs_eps, const float *scale, const float *mean, const float *rstd,
+                                        float *grad_weight, float *grad_bias, float *grad_x, int N, int C, size_t n, float slope, void *stream);
 int casmvs_upsample2x_add_f32(const float *lat, const float *up, float *out, int N, int C, int H, int W, void *stream);
 int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad_up, int N, int C, int H, int W, void *stream);
 int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,

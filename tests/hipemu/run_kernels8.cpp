@@ -105,6 +105,68 @@ static double sums_check(int N, int C, int n) {
   return err;
 }
 
+// Train-mode ABN with the per-channel epilogue inside the elementwise kernels (casmvs_abn_train_apply_f32, casmvs_abn_backward_apply_fused_f32): forward values,
+// folded constants, running statistics, input gradient and parameter gradients against float64 - 16-byte and scalar paths (n % 4), several chunks per plane
+static double abn_check(int N, int C, int n) {
+  const size_t total = (size_t)N * C * n;
+  std::vector<float> x(total), gy(total), w(C), b(C), rm(C, 0.25f), rv(C, 2.0f);
+  for (auto &v : x) v = rnd() * 2.0f + 0.3f;
+  for (auto &v : gy) v = rnd();
+  for (int c = 0; c < C; ++c) { w[c] = (c % 2 ? -1.0f : 1.0f) * (0.5f + 0.1f * c); b[c] = 0.05f * (c - 2); }
+  const float eps = 1e-5f, momentum = 0.1f, slope = 0.01f, abs_eps = 1e-5f;
+  const int blocks = casmvs_channel_sums_blocks(N, (size_t)n);
+  const double M = (double)N * n;
+  auto al = [](size_t floats) { return (float *)std::aligned_alloc(256, (floats * 4 + 255) & ~(size_t)255); };
+  float *xa = al(total), *ga = al(total), *ya = al(total), *gxa = al(total);
+  std::memcpy(xa, x.data(), total * 4); std::memcpy(ga, gy.data(), total * 4);
+  std::vector<double> part((size_t)C * blocks * 2, NAN);
+  std::vector<float> vec(4 * (size_t)C, NAN), pg(2 * (size_t)C, NAN);
+  if (casmvs_channel_sums_f64(xa, part.data(), N, C, (size_t)n, nullptr) ||
+      casmvs_abn_train_apply_f32(xa, part.data(), blocks, M, w.data(), b.data(), abs_eps, eps, momentum, rm.data(), rv.data(), vec.data(), vec.data() + C,
+                                 vec.data() + 2 * C, vec.data() + 3 * C, ya, N, C, (size_t)n, slope, nullptr) ||
+      casmvs_abn_backward_sums_f64(ga, ya, xa, vec.data() + 2 * C, vec.data() + 3 * C, part.data(), N, C, (size_t)n, slope, nullptr) ||
+      casmvs_abn_backward_apply_fused_f32(ga, ya, xa, part.data(), blocks, M, w.data(), abs_eps, vec.data(), vec.data() + 2 * C, vec.data() + 3 * C, pg.data(),
+                                          pg.data() + C, gxa, N, C, (size_t)n, slope, nullptr)) {
+    printf("abn: %s\n", casmvs_last_error());
+    return 1e9;
+  }
+  double err = 0;
+  for (int c = 0; c < C; ++c) {
+    double s0 = 0, s1 = 0;
+    for (int i = 0; i < N; ++i)
+      for (int e = 0; e < n; ++e) { const double v = x[((size_t)i * C + c) * n + e]; s0 += v; s1 += v * v; }
+    const double mu = s0 / M, var = s1 / M - mu * mu, rs = 1.0 / std::sqrt(var + eps), g = std::fabs((double)w[c]) + abs_eps;
+    err = std::fmax(err, std::fabs(vec[2 * C + c] - mu) / (std::fabs(mu) + 1e-3));
+    err = std::fmax(err, std::fabs(vec[3 * C + c] - rs) / rs);
+    err = std::fmax(err, std::fabs(rm[c] - (0.25 * 0.9 + 0.1 * mu)) / 0.25);
+    err = std::fmax(err, std::fabs(rv[c] - (2.0 * 0.9 + 0.1 * var * M / (M - 1))) / 2.0);
+    double gs0 = 0, gs1 = 0, ymax = 0, gmax = 0;
+    std::vector<double> gq((size_t)N * n), xh((size_t)N * n);
+    for (int i = 0; i < N; ++i)
+      for (int e = 0; e < n; ++e) {
+        const size_t o = ((size_t)i * C + c) * n + e;
+        const double xhat = (x[o] - mu) * rs, pre = xhat * g + b[c], yv = pre > 0 ? pre : pre * slope;
+        ymax = std::fmax(ymax, std::fabs(yv));
+        err = std::fmax(err, std::fabs(ya[o] - yv) / (std::fabs(yv) + 1.0));
+        const double gg = gy[o] * (ya[o] > 0 ? 1.0 : slope);
+        gq[(size_t)i * n + e] = gg; xh[(size_t)i * n + e] = xhat;
+        gs0 += gg; gs1 += gg * xhat;
+      }
+    err = std::fmax(err, std::fabs(pg[C + c] - gs0) / (std::fabs(gs0) + 1.0));
+    err = std::fmax(err, std::fabs(pg[c] - gs1 * (w[c] > 0 ? 1.0 : -1.0)) / (std::fabs(gs1) + 1.0));
+    for (int i = 0; i < N; ++i)
+      for (int e = 0; e < n; ++e) {
+        const size_t o = ((size_t)i * C + c) * n + e;
+        const double want = g * rs * (gq[(size_t)i * n + e] - gs0 / M - xh[(size_t)i * n + e] * gs1 / M);
+        gmax = std::fmax(gmax, std::fabs(want));
+        err = std::fmax(err, std::fabs(gxa[o] - want) / (std::fabs(want) + 1.0));
+      }
+  }
+  std::free(xa); std::free(ga); std::free(ya); std::free(gxa);
+  printf("abn_fused N=%d C=%d n=%d (%d blocks): max error = %.2e\n", N, C, n, blocks, err);
+  return err;
+}
+
 // casmvs_costvol_var_backward_f32 (costvol_var_bwd_kernel: the scatter transpose of the plane sweep through an LDS box image with ds_add_f32, the largest kernel of
 // the training step) against d var / d x_v = 2 x_v / V - 2 sum x / V^2 through the bilinear weights, taps from the shared float32 routine, sums in float64
 // mode 1: the source views' features are 1e4 x the reference view's (contributions outside the fixed-point range of the LDS image: the workgroup's second pass
@@ -196,6 +258,8 @@ int main(int argc, char **argv) {
     take(wgrad_check("S1", CASMVS_CONV_S1, 1, 8, 8, 2, 3, 20));          // two tiles, ragged in z (2 of 4 planes), y (3 of 4 rows) and x (20 of 32)
     take(wgrad_check("K5S2", CASMVS_CONV2D_K5S2, 1, 8, 16, 1, 8, 16));
     take(sums_check(2, 8, 1000));
+    take(abn_check(2, 5, 1003));                                          // scalar path, one chunk
+    take(abn_check(1, 3, 4608));                                          // 16-byte path, three chunks (the last one short)
     take(varbwd_check(1, 3, 8, 8, 6, 36));                                // two 32 x 32 tiles (ragged), one chunk of 8 planes, two source views
     take(varbwd_check(1, 3, 4, 8, 6, 36, 1));                             // the second (float-atomic) pass of a workgroup
   }
@@ -209,6 +273,7 @@ int main(int argc, char **argv) {
     take(wgrad_check("K1", CASMVS_CONV2D_K1, 1, 32, 16, 1, 6, 10));
     take(wgrad_check("T2", CASMVS_CONV_T2, 1, 32, 16, 1, 4, 6));
     take(sums_check(1, 16, 70000));
+    take(abn_check(1, 2, 40000));                                         // three partial-sum blocks per channel
     take(varbwd_check(1, 3, 8, 8, 12, 36));
     take(varbwd_check(2, 2, 16, 16, 34, 40));                             // four channel groups, two plane chunks, four tiles
     take(varbwd_check(1, 3, 8, 8, 6, 36, 2));
