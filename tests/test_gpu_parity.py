@@ -935,7 +935,7 @@ def test_round4_kernels_never_turn_non_finite_inputs_into_finite_wrong_values(de
 
 
 def test_whole_forward_float32_layers_equal_the_split_f16_layers(dev, report):
-    """The engine with every layer on the float32 MFMA kernels against the default layer set (conv0 / 2 / 4 / 6 / 9 / 11 and six FeatureNet layers on the
+    """The engine with every layer on the float32 MFMA kernels against the default layer set (conv0 - conv4 / 6 / 9 / 11 and eight FeatureNet layers on the
     f16 matrix cores) on one problem: depths agree to float32 rounding in the median and within the oracle bound everywhere."""
     from casmvsnet_pl_amd import ABN, CascadeMVSNet
     from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
