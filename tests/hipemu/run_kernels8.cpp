@@ -105,6 +105,31 @@ static double sums_check(int N, int C, int n) {
   return err;
 }
 
+// casmvs_pack_gather_batch_f32 (every layer image of a training step in one launch) against casmvs_pack_gather_f32 per segment: ragged segment sizes, a
+// segment without a bias, the constants 0 / 1 of the virtual source vector
+static double pack_batch_check() {
+  const int nseg = 5, sizes[nseg] = {300, 256, 1, 777, 2049}, nw[nseg] = {40, 7, 3, 500, 64}, nb[nseg] = {8, 0, 2, 16, 0};
+  std::vector<std::vector<float>> w(nseg), b(nseg), want(nseg), got(nseg);
+  std::vector<std::vector<int>> idx(nseg);
+  std::vector<casmvs_pack_segment> segs(nseg);
+  int block = 0;
+  for (int s = 0; s < nseg; ++s) {
+    w[s].resize(nw[s]); b[s].resize(nb[s] ? nb[s] : 1); idx[s].resize(sizes[s]); want[s].assign(sizes[s], NAN); got[s].assign(sizes[s], NAN);
+    for (auto &v : w[s]) v = rnd();
+    for (auto &v : b[s]) v = rnd() + 10.0f;
+    for (int i = 0; i < sizes[s]; ++i) idx[s][i] = (int)((unsigned)(i * 2654435761u + s * 97u) % (unsigned)(nw[s] + nb[s] + 2));
+    if (casmvs_pack_gather_f32(w[s].data(), nb[s] ? b[s].data() : nullptr, idx[s].data(), want[s].data(), nw[s], nb[s], sizes[s], nullptr)) return 1e9;
+    segs[s] = casmvs_pack_segment{w[s].data(), nb[s] ? b[s].data() : nullptr, idx[s].data(), got[s].data(), nw[s], nb[s], sizes[s], block};
+    block += (sizes[s] + 255) / 256;
+  }
+  if (casmvs_pack_gather_batch_f32(segs.data(), nseg, block, nullptr)) { printf("pack_gather_batch: %s\n", casmvs_last_error()); return 1e9; }
+  int bad = 0;
+  for (int s = 0; s < nseg; ++s)
+    for (int i = 0; i < sizes[s]; ++i) bad += std::memcmp(&want[s][i], &got[s][i], 4) != 0;
+  printf("pack_gather_batch: %d segments in %d workgroups, %d differing elements\n", nseg, block, bad);
+  return bad ? 1.0 : 0.0;
+}
+
 // Train-mode ABN with the per-channel epilogue inside the elementwise kernels (casmvs_abn_train_apply_f32, casmvs_abn_backward_apply_fused_f32): forward values,
 // folded constants, running statistics, input gradient and parameter gradients against float64 - 16-byte and scalar paths (n % 4), several chunks per plane
 static double abn_check(int N, int C, int n) {
@@ -258,6 +283,7 @@ int main(int argc, char **argv) {
     take(wgrad_check("S1", CASMVS_CONV_S1, 1, 8, 8, 2, 3, 20));          // two tiles, ragged in z (2 of 4 planes), y (3 of 4 rows) and x (20 of 32)
     take(wgrad_check("K5S2", CASMVS_CONV2D_K5S2, 1, 8, 16, 1, 8, 16));
     take(sums_check(2, 8, 1000));
+    take(pack_batch_check());
     take(abn_check(2, 5, 1003));                                          // scalar path, one chunk
     take(abn_check(1, 3, 4608));                                          // 16-byte path, three chunks (the last one short)
     take(varbwd_check(1, 3, 8, 8, 6, 36));                                // two 32 x 32 tiles (ragged), one chunk of 8 planes, two source views
