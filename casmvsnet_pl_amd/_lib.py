@@ -123,6 +123,7 @@ SYMBOLS = {
     "casmvs_upsample2x_add_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_upsample2x_backward_f32": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_costvol_var_backward_f32": (c_int, [_FP] * 5 + [c_int] * 6 + [c_void_p]),
+    "casmvs_costvol_gwc_backward_f32": (c_int, [_FP] * 5 + [c_int] * 7 + [c_void_p]),
     "casmvs_normalize_images_u8": (c_int, [_FP, _FP, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "casmvs_selftest_mfma": (c_int, [_FP]),
     "casmvs_selftest_mfma_rate": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),

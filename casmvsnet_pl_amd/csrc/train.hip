@@ -713,11 +713,15 @@ __device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update
 __device__ __forceinline__ int lane_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ float lane_prev(float v) { return __builtin_bit_cast(float, lane_prev(__builtin_bit_cast(int, v))); }
 
-template <int CG, int TH, int VS>   // VS: the number of source views when the instantiation fixes it (their gathers are then issued together), 0 = V - 1 at run time
+// VS: the number of source views when the instantiation fixes it (their gathers are then issued together), 0 = V - 1 at run time.
+// GWC: the group-wise correlation volume (mvsnet.py:142-144,157-162,169-172) instead of the variance: vol[g] = sum_v mean_{c in g} ref[c] warped_v[c] / (V - 1),
+// gvol (B, G, D, h, w); d / d warped_v[c] = gvol[group of c] ref[c] k and d / d ref[c] = gvol[group of c] k sum_v warped_v[c], k = 1 / ((C / G) (V - 1)):
+// the same scatter with another contribution - only the workgroups of the first source view gather (they own the reference view's gradient).
+template <int CG, int TH, int VS, bool GWC>
 __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *__restrict__ feats, const float *__restrict__ proj,
                                                                   const float *__restrict__ depth, const float *__restrict__ gvol,
                                                                   float *__restrict__ gfeats, int V, int C, int H, int W, int D,
-                                                                  int tiles_x, int DCH, int CAP) {
+                                                                  int tiles_x, int DCH, int CAP, int G) {
   constexpr int TS = 32, RPT = TS * TH / kThreads, RSTEP = kThreads / TS;   // tile: 32 columns x TH rows, a thread's pixels RSTEP rows apart
   CASMVS_DYNAMIC_LDS(unsigned long long, box);   // [CG][bh][bw], CAP cells per channel: fixed point, units of 2^(e - 45)
   __shared__ int ext[(RPT + 1) * 4];   // tap boxes of the tile's RPT bands of 8 rows, then their union
@@ -734,6 +738,11 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   const float *Pv = Pb + (v - 1) * 12;
   const float *db = depth + (size_t)b * D * hw;
   const float fV = (float)V;
+  const int cpg = GWC ? C / G : 1;
+  const float kg = GWC ? 1.0f / ((float)cpg * (float)(V - 1)) : 0.0f;
+  size_t goff[CG];   // the upstream gradient's plane 0 of the channel (variance) / of the channel's group (correlation)
+#pragma unroll
+  for (int c = 0; c < CG; ++c) goff[c] = GWC ? ((size_t)b * G + (c0 + c) / cpg) * D * hw : ((size_t)b * C + c0 + c) * D * hw;
 
   // ---- 1. bounding boxes of this view's live taps: the tile's, and (published only when the tile's does not fit the LDS
   // image) one per band of RSTEP rows (a thread's j-th pixel)
@@ -750,7 +759,7 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     const int yr = yb + j * RSTEP;
     const bool valid = x < W && yr < H;
     const int p = min(yr, H - 1) * W + min(x, W - 1);
-    const float *gp = gvol + ((size_t)b * C + c0) * D * hw + p;
+    const float *gp = gvol + p;
     unsigned rb = 0u, gbt = 0u;
 #pragma unroll
     for (int c = 0; c < CG; ++c) rb = max(rb, __builtin_bit_cast(unsigned, fb[(size_t)(c0 + c) * hw + p]) & 0x7fffffffu);
@@ -761,7 +770,7 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
         const int d = min(d0 + i, d_end - 1);
         dvs[i] = db[(size_t)d * hw + p];
 #pragma unroll
-        for (int c = 0; c < CG; ++c) gbt = max(gbt, __builtin_bit_cast(unsigned, gp[((size_t)c * D + d) * hw]) & 0x7fffffffu);
+        for (int c = 0; c < CG; ++c) gbt = max(gbt, __builtin_bit_cast(unsigned, gp[goff[c] + (size_t)d * hw]) & 0x7fffffffu);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -784,8 +793,9 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   rbits = casmvs::wave_max_bits(rbits);
   if ((tid & 63) == 0) { atomicMax(&wgmax[0], gbits); atomicMax(&wgmax[1], rbits); }
   __syncthreads();
-  // the fixed-point scale: 2^e >= 16 G R / V (a normal float, or the workgroup scatters with float atomics), unit 2^(e - 45)
-  const float bound = 16.0f * __builtin_bit_cast(float, wgmax[0]) * __builtin_bit_cast(float, wgmax[1]) / fV;
+  // the fixed-point scale: 2^e >= 16 G R / V (a normal float, or the workgroup scatters with float atomics), unit 2^(e - 45); correlation: a contribution
+  // is g ref k with the tile's own reference features - 4 G R k bounds it outright
+  const float bound = (GWC ? 4.0f * kg : 16.0f / fV) * __builtin_bit_cast(float, wgmax[0]) * __builtin_bit_cast(float, wgmax[1]);
   const int be = (int)((__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu) - 126;   // bound = m 2^be, m in [0.5, 1)
   const bool fixed_ok = wgmax[0] < 0x7f800000u && wgmax[1] < 0x7f800000u && be > -90 && be < 90;   // finite, not zero / denormal / huge
   const float limit = __builtin_bit_cast(float, (unsigned)(be + 127) << 23);                                      // 2^be
@@ -837,10 +847,11 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     }
     // the plane's hypothesis and upstream gradients are loaded one plane ahead (clamped, unconditional: nothing in the loop waits on a load it has just
     // issued except the gathers - seven serialised round trips per step before, two now, one with VS)
-    const float *gp = gvol + ((size_t)b * C + c0) * D * hw + p;
+    const float *gp = gvol + p;
     float dv_next = db[(size_t)d_begin * hw + p], g_next[CG];
 #pragma unroll
-    for (int c = 0; c < CG; ++c) g_next[c] = gp[((size_t)c * D + d_begin) * hw];
+    for (int c = 0; c < CG; ++c) g_next[c] = gp[goff[c] + (size_t)d_begin * hw];
+    const bool gathers = !GWC || v == 1;   // correlation: the warped values only enter the reference view's gradient
     const int nv = V;
     for (int d = d_begin; d < d_end; ++d) {
       const float dv = dv_next;
@@ -848,14 +859,17 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
       Taps tv;
 #pragma unroll
       for (int c = 0; c < CG; ++c) {
-        S[c] = ref[c];
+        S[c] = GWC ? 0.0f : ref[c];
+        xv[c] = 0.0f;
         gd[c] = valid ? g_next[c] : 0.0f;
       }
       const int dn = min(d + 1, d_end - 1);
       dv_next = db[(size_t)dn * hw + p];
 #pragma unroll
-      for (int c = 0; c < CG; ++c) g_next[c] = gp[((size_t)c * D + dn) * hw];
-      if constexpr (VS > 0) {   // every view's taps, then every gather, then the arithmetic: one round trip for all views
+      for (int c = 0; c < CG; ++c) g_next[c] = gp[goff[c] + (size_t)dn * hw];
+      if (GWC && !gathers) {
+        tv = plane_sweep_taps(Pv, (float)xc, (float)y, dv, W, H);
+      } else if constexpr (VS > 0) {   // every view's taps, then every gather, then the arithmetic: one round trip for all views
         Taps ts[VS];
         float raw[VS][CG][4];
 #pragma unroll
@@ -913,9 +927,15 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
 #pragma unroll
       for (int c = 0; c < CG; ++c) {
         const float g = gd[c];
-        const float common = 2.0f * S[c] / (fV * fV);
-        gref[c] += g * (2.0f * ref[c] / fV - common);
-        const float gx = g * (2.0f * xv[c] / fV - common);
+        float gx;
+        if (GWC) {
+          gref[c] += g * kg * S[c];
+          gx = g * kg * ref[c];
+        } else {
+          const float common = 2.0f * S[c] / (fV * fV);
+          gref[c] += g * (2.0f * ref[c] / fV - common);
+          gx = g * (2.0f * xv[c] / fV - common);
+        }
         outside = outside || (live && !(fabsf(gx) < limit));   // also NaN
         const float rn = gx * tv.w_nr, rs = gx * tv.w_sr;
         const float prn = lane_prev(rn), prs = lane_prev(rs);
@@ -1236,32 +1256,43 @@ extern "C" int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad
   return casmvs::check_launch("upsample2x_bwd_kernel");
 }
 
+namespace {
+// the variance volume's (G = 0) or the correlation volume's (G > 0) gradient w.r.t. the feature maps: one launch behind the zeroing of grad_feats
+int volume_backward(const float *feats, const float *proj, const float *depth, const float *grad_vol, float *grad_feats, int B, int V, int C, int G,
+                    int h, int w, int D, void *stream, const char *what) {
+  CASMVS_REQUIRE(feats && proj && depth && grad_vol && grad_feats, "%s: null pointer", what);
+  CASMVS_REQUIRE(B > 0 && B <= 65535 && V >= 2 && h > 1 && w > 1 && D > 0, "%s: bad shape B=%d V=%d h=%d w=%d D=%d", what, B, V, h, w, D);
+  CASMVS_REQUIRE(C % 4 == 0 && C >= 4 && C <= 64, "%s: C=%d (a multiple of 4 up to 64)", what, C);
+  CASMVS_REQUIRE(G == 0 || (G > 0 && C % G == 0), "%s: G=%d does not divide C=%d", what, G, C);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)B * V * C * h * w * sizeof(float), st);
+  if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "%s: hipMemsetAsync: %s", what, hipGetErrorString(e));
+  // 8 planes per workgroup; the LDS image holds 1152 box pixels (a 32 x 16 tile whose taps spread over ~44 x 26) of 4 channels
+  // in 64-bit fixed point = 36 KiB: four workgroups per CU (the kernel waits on its gathers: 0.92 -> 0.43 ms at level 1 from two to four)
+  constexpr int dch = 8, cap = 1152, th = 16, CG = 4;
+  const int tiles_x = casmvs::ceil_div(w, 32), tiles_y = casmvs::ceil_div(h, th), chunks = casmvs::ceil_div(D, dch);
+  const long gy = (long)chunks * (C / CG) * (V - 1);
+  CASMVS_REQUIRE(gy <= 65535, "%s: D=%d C=%d V=%d: too many (plane chunk, channel group, view) items", what, D, C, V);
+  auto kernel = G > 0 ? (V == 3 ? costvol_var_bwd_kernel<CG, th, 2, true> : costvol_var_bwd_kernel<CG, th, 0, true>)
+                      : (V == 3 ? costvol_var_bwd_kernel<CG, th, 2, false> : costvol_var_bwd_kernel<CG, th, 0, false>);
+  const size_t lds = (size_t)CG * cap * sizeof(unsigned long long);
+  if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "costvol_var_bwd_kernel")) return rc;
+  dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)gy, (unsigned)B);
+  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, feats, proj, depth, grad_vol, grad_feats, V, C, h, w, D, tiles_x, dch, cap, G);
+  return casmvs::check_launch("costvol_var_bwd_kernel");
+}
+}  // namespace
+
 extern "C" int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,
                                                float *grad_feats, int B, int V, int C, int h, int w, int D, void *stream) {
   casmvs::clear_error();
-  CASMVS_REQUIRE(feats && proj && depth && grad_vol && grad_feats, "costvol_var_backward: null pointer");
-  CASMVS_REQUIRE(B > 0 && B <= 65535 && V >= 2 && h > 1 && w > 1 && D > 0, "costvol_var_backward: bad shape B=%d V=%d h=%d w=%d D=%d", B, V, h, w, D);
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)B * V * C * h * w * sizeof(float), st);
-  if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "costvol_var_backward: hipMemsetAsync: %s", hipGetErrorString(e));
-  // 8 planes per workgroup; the LDS image holds 1152 box pixels (a 32 x 16 tile whose taps spread over ~44 x 26) of 4 channels
-  // in 64-bit fixed point = 36 KiB: four workgroups per CU (the kernel waits on its gathers: 0.92 -> ? ms at level 1 from two to four)
-  constexpr int dch = 8, cap = 1152, th = 16;
-  const int tiles_x = casmvs::ceil_div(w, 32), tiles_y = casmvs::ceil_div(h, th), chunks = casmvs::ceil_div(D, dch);
-#define CASMVS_VB(CG)                                                                                                          \
-  {                                                                                                                            \
-    const long gy = (long)chunks * (C / CG) * (V - 1);                                                                         \
-    CASMVS_REQUIRE(gy <= 65535, "costvol_var_backward: D=%d C=%d V=%d: too many (plane chunk, channel group, view) items", D, C, V); \
-    auto kernel = V == 3 ? costvol_var_bwd_kernel<CG, th, 2> : costvol_var_bwd_kernel<CG, th, 0>;                              \
-    const size_t lds = (size_t)CG * cap * sizeof(unsigned long long);                                                          \
-    if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "costvol_var_bwd_kernel")) return rc; \
-    dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)gy, (unsigned)B);                                                       \
-    hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, feats, proj, depth, grad_vol, grad_feats, V, C, h, w, D, tiles_x, \
-                       dch, cap);                                                                                              \
-    return casmvs::check_launch("costvol_var_bwd_kernel");                                                                     \
-  }
-  if (C % 4 == 0 && C <= 64) CASMVS_VB(4)
-#undef CASMVS_VB
-  return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_var_backward: C=%d (a multiple of 4 up to 64)", C);
+  return volume_backward(feats, proj, depth, grad_vol, grad_feats, B, V, C, 0, h, w, D, stream, "costvol_var_backward");
+}
+
+extern "C" int casmvs_costvol_gwc_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,
+                                               float *grad_feats, int B, int V, int C, int G, int h, int w, int D, void *stream) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(G > 0, "costvol_gwc_backward: G=%d", G);
+  return volume_backward(feats, proj, depth, grad_vol, grad_feats, B, V, C, G, h, w, D, stream, "costvol_gwc_backward");
 }
 

@@ -444,9 +444,10 @@ def variance_volume(feats, proj_mats, depth_values):
 
 class _GroupwiseVolume(torch.autograd.Function):
     """mvsnet.py:142-144,157-162,169-172.  Forward: the fused inference kernel (no warped volume is materialised or kept for the
-    backward).  Backward, from the saved features: the gradient of every warped volume is the SAME tensor
-    gw[b,c,d] = g[b,c // (C/G),d] * ref[b,c] / (C/G * (V-1)) (built once), scattered to each source view by the warp's HIP backward
-    kernel; the reference view's gradient needs the sum of the warped volumes, recomputed one view at a time."""
+    backward).  Backward, from the saved features, ONE launch (casmvs_costvol_gwc_backward_f32, the variance backward's kernel with another
+    contribution): d / d warped_v[c] = g[c // (C/G)] * ref[c] / (C/G * (V-1)) scattered through the bilinear weights into a fixed-point LDS image per
+    workgroup, d / d ref[c] = g[c // (C/G)] * sum_v warped_v[c] / (C/G * (V-1)) from re-gathered values - no channel-expanded gradient volume, no warped
+    volume (the previous form built both, per view, with torch operations between the warp's backward launches)."""
 
     @staticmethod
     def forward(ctx, feats, proj_mats, depth_values, G):
@@ -465,22 +466,12 @@ class _GroupwiseVolume(torch.autograd.Function):
         feats, proj_mats, depth_values = ctx.saved_tensors
         B, V, C, h, w = feats.shape
         G, D = ctx.G, depth_values.shape[1]
-        cg = C // G
-        gch = gvol.contiguous().float().repeat_interleave(cg, dim=1).mul_(1.0 / (cg * (V - 1)))   # (B,C,D,h,w): g of the channel's group, scaled
+        gvol = gvol.contiguous().float()
         gfeats = torch.empty_like(feats)
-        gw = gch * feats[:, 0].unsqueeze(2)                                                      # d loss / d warped_v, the same for every view
-        vsum = None
-        lib = _lib.load()
         with torch.cuda.device(feats.device):
-            for v in range(1, V):
-                gsrc = torch.empty((B, C, h, w), dtype=torch.float32, device=feats.device)
-                rc = lib.casmvs_homo_warp_backward_f32(_ptr(gw), _ptr(proj_mats[:, v - 1].contiguous()), _ptr(depth_values), _ptr(gsrc),
-                                                       B, C, h, w, D, _stream(feats))
-                _lib.check(rc, "casmvs_homo_warp_backward_f32")
-                gfeats[:, v] = gsrc
-                warped = ops.homo_warp(feats[:, v].contiguous(), proj_mats[:, v - 1].contiguous(), depth_values)
-                vsum = warped if vsum is None else vsum.add_(warped)
-        gfeats[:, 0] = (gch * vsum).sum(2)
+            rc = _lib.load().casmvs_costvol_gwc_backward_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(gvol), _ptr(gfeats),
+                                                             B, V, C, G, h, w, D, _stream(feats))
+        _lib.check(rc, "casmvs_costvol_gwc_backward_f32")
         return gfeats, None, None, None
 
 

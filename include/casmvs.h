@@ -571,6 +571,10 @@ int casmvs_upsample2x_add_f32(const float *lat, const float *up, float *out, int
 int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad_up, int N, int C, int H, int W, void *stream);
 int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,
                                     float *grad_feats, int B, int V, int C, int h, int w, int D, void *stream);
+/* The same for the group-wise correlation volume (mvsnet.py:142-144,157-162,169-172): grad_vol (B,G,D,h,w), G divides C.  One launch instead of a
+ * channel-expanded gradient volume, one warp backward and one recomputed warped volume per source view. */
+int casmvs_costvol_gwc_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol, float *grad_feats, int B, int V,
+                                    int C, int G, int h, int w, int D, void *stream);
 
 /* ---- self test ------------------------------------------------------------------------------
  * Runs the MFMA lane-mapping probes the conv kernels rely on (v_mfma_f32_16x16x4_f32 operand /

@@ -196,9 +196,11 @@ static double abn_check(int N, int C, int n) {
 // the training step) against d var / d x_v = 2 x_v / V - 2 sum x / V^2 through the bilinear weights, taps from the shared float32 routine, sums in float64
 // mode 1: the source views' features are 1e4 x the reference view's (contributions outside the fixed-point range of the LDS image: the workgroup's second pass
 // scatters with float atomics); mode 2: reference features all zero (no scale: the float path from the start); mode 3: upstream gradients of 1e-30 (a denormal bound)
-static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 0) {
+// G > 0: the group-wise correlation volume's backward (casmvs_costvol_gwc_backward_f32), gvol (B, G, D, h, w)
+static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 0, int G = 0) {
   const size_t hw = (size_t)h * w;
-  std::vector<float> feats((size_t)B * V * C * hw), proj((size_t)B * (V - 1) * 12, 0.0f), depth((size_t)B * D * hw), gvol((size_t)B * C * D * hw);
+  const int GC = G > 0 ? G : C, cpg = G > 0 ? C / G : 1;
+  std::vector<float> feats((size_t)B * V * C * hw), proj((size_t)B * (V - 1) * 12, 0.0f), depth((size_t)B * D * hw), gvol((size_t)B * GC * D * hw);
   for (auto &v : feats) v = rnd();
   for (auto &v : gvol) v = rnd() * (mode == 3 ? 1e-30f : 1.0f);
   if (mode == 1 || mode == 2)
@@ -227,7 +229,8 @@ static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 
   float *fa = dup(feats), *pa = dup(proj), *da = dup(depth), *ga = dup(gvol);
   std::vector<float> nanv(feats.size(), NAN);
   float *out = dup(nanv);
-  if (casmvs_costvol_var_backward_f32(fa, pa, da, ga, out, B, V, C, h, w, D, nullptr)) { printf("var_backward: %s\n", casmvs_last_error()); return 1e9; }
+  if (G > 0 ? casmvs_costvol_gwc_backward_f32(fa, pa, da, ga, out, B, V, C, G, h, w, D, nullptr)
+            : casmvs_costvol_var_backward_f32(fa, pa, da, ga, out, B, V, C, h, w, D, nullptr)) { printf("var_backward: %s\n", casmvs_last_error()); return 1e9; }
   std::vector<double> want(feats.size(), 0.0);
   for (int b = 0; b < B; ++b)
     for (int d = 0; d < D; ++d)
@@ -249,12 +252,13 @@ static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 
             }
           }
           for (int c = 0; c < C; ++c) {
-            const double g = gvol[(((size_t)b * C + c) * D + d) * hw + (size_t)y * w + x];
+            const double g = gvol[(((size_t)b * GC + c / cpg) * D + d) * hw + (size_t)y * w + x];
             const double xr = feats[(((size_t)b * V) * C + c) * hw + (size_t)y * w + x];
-            want[(((size_t)b * V) * C + c) * hw + (size_t)y * w + x] += g * (2.0 * xr / V - 2.0 * S[c] / ((double)V * V));
+            const double kg = 1.0 / ((double)cpg * (V - 1));
+            want[(((size_t)b * V) * C + c) * hw + (size_t)y * w + x] += G > 0 ? g * kg * (S[c] - xr) : g * (2.0 * xr / V - 2.0 * S[c] / ((double)V * V));
             for (int v = 0; v < V - 1; ++v) {
               const casmvs_dev::Taps &t = taps[v];
-              const double k = g * (2.0 * xv[v][c] / V - 2.0 * S[c] / ((double)V * V));
+              const double k = G > 0 ? g * kg * xr : g * (2.0 * xv[v][c] / V - 2.0 * S[c] / ((double)V * V));
               double *q = want.data() + (((size_t)b * V + 1 + v) * C + c) * hw;
               q[(size_t)t.yn * w + t.xl] += k * t.w_nl;
               q[(size_t)t.yn * w + t.xl + 1] += k * t.w_nr;
@@ -269,7 +273,7 @@ static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 
     err = std::fmax(err, std::isfinite(out[i]) ? std::fabs(want[i] - out[i]) : 1e30);
   }
   std::free(fa); std::free(pa); std::free(da); std::free(ga); std::free(out);
-  printf("var_backward B=%d V=%d C=%d %dx%dx%d mode %d: max error / largest gradient = %.2e\n", B, V, C, D, h, w, mode, err / range);
+  printf("%s B=%d V=%d C=%d %dx%dx%d mode %d: max error / largest gradient = %.2e\n", G > 0 ? "gwc_backward" : "var_backward", B, V, C, D, h, w, mode, err / range);
   return err / range;
 }
 
@@ -288,6 +292,7 @@ int main(int argc, char **argv) {
     take(abn_check(1, 3, 4608));                                          // 16-byte path, three chunks (the last one short)
     take(varbwd_check(1, 3, 8, 8, 6, 36));                                // two 32 x 32 tiles (ragged), one chunk of 8 planes, two source views
     take(varbwd_check(1, 3, 4, 8, 6, 36, 1));                             // the second (float-atomic) pass of a workgroup
+    take(varbwd_check(1, 3, 8, 8, 6, 36, 0, 4));                          // group-wise correlation: two channels per group
   }
   if (all) {
     take(wgrad_check("S1", CASMVS_CONV_S1, 1, 8, 8, 5, 6, 20));          // ragged in z (tile 4), y and x
@@ -304,6 +309,8 @@ int main(int argc, char **argv) {
     take(varbwd_check(2, 2, 16, 16, 34, 40));                             // four channel groups, two plane chunks, four tiles
     take(varbwd_check(1, 3, 8, 8, 6, 36, 2));
     take(varbwd_check(1, 2, 4, 5, 6, 36, 3));
+    take(varbwd_check(2, 4, 16, 9, 20, 40, 0, 16));                       // one channel per group, three source views (run-time view loop)
+    take(varbwd_check(1, 3, 8, 8, 12, 36, 0, 1));                         // one group
   }
   printf(worst < 3e-6 ? "ALL OK (worst %.2e)\n" : "FAILED (worst %.2e)\n", worst);
   return worst < 3e-6 ? 0 : 1;

@@ -245,9 +245,9 @@ def test_variance_volume_backward_outside_the_fixed_point_range(dev, report, cas
 @pytest.mark.parametrize("B,V,C,h,w,D,G,geometry", [(1, 3, 8, 24, 32, 4, 8, "dtu"), (2, 3, 16, 16, 24, 8, 4, "dtu"), (1, 4, 32, 16, 16, 3, 8, "random"),
                                                        (1, 3, 8, 48, 64, 6, 2, "dtu"), (1, 5, 32, 20, 28, 4, 8, "dtu")])
 def test_groupwise_volume_backward_matches_autograd_of_the_oracle(dev, report, B, V, C, h, w, D, G, geometry):
-    """training._GroupwiseVolume (mvsnet.py:142-144,157-162,169-172 for G > 1): forward = the fused inference kernel, backward = one
-    shared gradient volume scattered per view by the warp's HIP backward + the reference view's sum - vs autograd of the oracle, and
-    vs the composition of per-view differentiable warps it replaces."""
+    """training._GroupwiseVolume (mvsnet.py:142-144,157-162,169-172 for G > 1): forward = the fused inference kernel, backward = ONE launch
+    (casmvs_costvol_gwc_backward_f32: the variance backward's kernel with the correlation's contribution, fixed-point LDS image) - vs autograd
+    of the oracle, and vs the composition of per-view differentiable warps it replaces."""
     from casmvsnet_pl_amd import training as T
     from casmvsnet_pl_amd.synthetic import make_inputs
     g = torch.Generator().manual_seed(C + D + G)

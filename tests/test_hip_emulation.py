@@ -157,8 +157,9 @@ def test_training_weight_gradient_kernel_runs_on_the_cpu(built):
     reduction must reproduce the bits); channel_sums_kernel against float64 sums; train-mode ABN with the per-channel epilogue inside the elementwise kernels
     (abn_train_apply_kernel / abn_bwd_apply_stats_kernel: values, constants, running statistics, gradients; 16-byte and scalar paths); costvol_var_bwd_kernel (the scatter transpose of the plane sweep through a
     64-bit fixed-point LDS image, ds_add_u64) against the derivative of the variance through the bilinear weights in float64 - also with source views 1e4 x the
-    reference view, where the workgroups leave the fixed-point range and repeat the pass with float atomics (`all`: zero reference features, 1e-30 gradients)."""
-    out = _run(built[("run_kernels8", "plain")], ("wgrad S1", "wgrad K5S2", "channel_sums", "pack_gather_batch", "abn_fused", "var_backward"))   # (`all`: every kind, profiles/r03_hip_emulation_all.txt)
+    reference view, where the workgroups leave the fixed-point range and repeat the pass with float atomics (`all`: zero reference features, 1e-30 gradients),
+    and its group-wise correlation form."""
+    out = _run(built[("run_kernels8", "plain")], ("wgrad S1", "wgrad K5S2", "channel_sums", "pack_gather_batch", "abn_fused", "var_backward", "gwc_backward"))   # (`all`: every kind, profiles/r03_hip_emulation_all.txt)
     assert "DIFFERENT" not in out.stdout and out.stdout.count("bit-identical") >= 2
 
 
