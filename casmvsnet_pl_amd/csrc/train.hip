@@ -962,7 +962,7 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
       for (int c = 0; c < CG; ++c) unsafeAtomicAdd(gb + (size_t)(c0 + c) * hw + p, gref[c]);
     }
   }
-  if (in_lds && outside) wgmax[2] = 1u;
+  if (in_lds && __builtin_amdgcn_ballot_w64(outside) != 0 && lane == 0) atomicMax(&wgmax[2], 1u);   // one integer LDS atomic per wave that saw one
   __syncthreads();
   if (!in_lds) break;             // scattered to global memory: done
   if (wgmax[2] != 0u) continue;   // uniform: read behind the barrier; the second pass does not write it
