@@ -93,8 +93,11 @@ class PackPlan:
     the single-image launch and, for a new request, joins the plan).  Capturable: the batched launch is part of the captured step."""
 
     def __init__(self):
-        self.entries = {}      # (weight ptr, bias ptr, kind, adjoint) -> [weight, bias, index, out, version seen by the last batched launch or None]
+        self.entries = {}      # (weight ptr, bias ptr, kind, adjoint) -> [weight, bias, index, out, version seen by the last batched launch or None,
+        #                          steps since the last request]
         self.table = None      # device copy of the segment array; None = rebuild before the next launch
+        self.table_keys = ()   # the entries the table lists
+        self.retired = []      # earlier tables: a captured hipGraph may still read them (a few KB each)
         self.n_blocks = 0
         self.launches = self.hits = self.misses = 0   # batched launches; images handed out without / with a launch of their own (tests)
 
@@ -107,10 +110,10 @@ class PackPlan:
         e = self.entries.get(key)
         if e is None:
             out = torch.empty(idx.numel(), dtype=torch.float32, device=weight.device)
-            self.entries[key] = [weight, bias, idx, out, None]
-            self.table = None
+            self.entries[key] = [weight, bias, idx, out, None, 0]
             self.misses += 1
             return out, False
+        e[5] = 0
         fresh = e[4] is not None and e[4] == (weight._version, -1 if bias is None else bias._version)
         self.hits += fresh
         self.misses += not fresh
@@ -119,15 +122,24 @@ class PackPlan:
     def begin_step(self):
         """One launch for every recorded image; nothing on the first step (no requests yet)."""
         import numpy as np
-        if not self.entries:
+        # an image nobody asked for during two whole steps (its parameter was replaced: .to(), a re-initialised layer) is no longer packed; its buffer
+        # stays (a captured graph may read it) and it rejoins the table when it is requested again
+        for e in self.entries.values():
+            e[5] += 1
+        keys = tuple(k for k, e in self.entries.items() if e[5] <= 2)
+        if keys != self.table_keys:
+            if self.table is not None:
+                self.retired.append(self.table)
+            self.table, self.table_keys = None, keys
+        if not keys:
             return
-        entries = list(self.entries.values())
+        entries = [self.entries[k] for k in keys]
         dev = entries[0][0].device
         if self.table is None:
             seg = np.zeros(len(entries), dtype=np.dtype([("w", "<u8"), ("b", "<u8"), ("idx", "<u8"), ("out", "<u8"), ("n_w", "<i4"), ("n_b", "<i4"),
                                                           ("n_out", "<i4"), ("first", "<i4")]))
             block = 0
-            for i, (w, bz, idx, out, _) in enumerate(entries):
+            for i, (w, bz, idx, out, _, _) in enumerate(entries):
                 seg[i] = (w.data_ptr(), 0 if bz is None else bz.data_ptr(), idx.data_ptr(), out.data_ptr(), w.numel(), 0 if bz is None else bz.numel(),
                           idx.numel(), block)
                 block += (idx.numel() + 255) // 256

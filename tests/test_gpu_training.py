@@ -305,7 +305,7 @@ def test_pack_plan_fills_every_layer_image_of_a_step_in_one_launch(dev, report):
     plan.begin_step()
     T._ACTIVE_PLAN = None
     worst = 0
-    for (wt, bz, idx, out, _), key in zip(list(plan.entries.values()), list(plan.entries)):
+    for (wt, bz, idx, out, _, _), key in zip(list(plan.entries.values()), list(plan.entries)):
         single = T.device_pack(key[2], wt, bz, adjoint=key[3])
         assert single.data_ptr() != out.data_ptr()
         worst = max(worst, int((single != out).sum()))
@@ -313,7 +313,7 @@ def test_pack_plan_fills_every_layer_image_of_a_step_in_one_launch(dev, report):
     # a weight changed after begin_step: its image is packed again, not served from the plan
     T._ACTIVE_PLAN = plan
     plan.begin_step()
-    wt, bz, idx, out, _ = next(iter(plan.entries.values()))
+    wt, bz, idx, out, _, _ = next(iter(plan.entries.values()))
     key = next(iter(plan.entries))
     before = (plan.hits, plan.misses)
     with torch.no_grad():
@@ -322,6 +322,15 @@ def test_pack_plan_fills_every_layer_image_of_a_step_in_one_launch(dev, report):
     assert (plan.hits, plan.misses) == (before[0], before[1] + 1)
     T._ACTIVE_PLAN = None
     assert torch.equal(again, T.device_pack(key[2], wt, bz, adjoint=key[3]))
+    # images nobody requests any more leave the batched launch (their buffers stay: a captured graph may read them) and come back on request
+    launches = plan.launches
+    for _ in range(4):
+        plan.begin_step()
+    assert plan.table_keys == () and plan.launches <= launches + 2 and len(plan.entries) == n and len(plan.retired) >= 1
+    step()   # every image is requested again (served from its buffer: no weight changed since it was packed) ...
+    assert plan.table_keys == () and plan.launches == launches + 2
+    step()   # ... and is part of the batched launch again from the next step on
+    assert len(plan.table_keys) == n and plan.launches == launches + 3
     report("train_pack_plan", images=n, batched_launches=plan.launches)
 
 
