@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # CASMVS_LIB_PATH: load another BUILD of the same library (profiling: -DCASMVS_TRACE, compiler-flag A/B runs)
 LIB_PATH = os.environ.get("CASMVS_LIB_PATH") or os.path.join(_PKG_DIR, "libcasmvs_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
 CONV2D_K3, CONV2D_K5S2, CONV2D_K1, CONV2D_K1_UP = 3, 4, 5, 6
@@ -101,7 +101,8 @@ SYMBOLS = {
     "casmvs_depth_regression_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_fuse_reference_view": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_fuse_reference_view_paired": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
-    "casmvs_homo_warp_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "casmvs_homo_warp_backward_workspace_bytes": (c_size_t, [c_int] * 4),
+    "casmvs_homo_warp_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_softmax_regress_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 7),
     "casmvs_conv_wgrad_f32": (c_int, [c_int, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -122,8 +123,9 @@ SYMBOLS = {
     "casmvs_abn_backward_apply_fused_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_double, _FP, c_float] + [_FP] * 6 + [c_int, c_int, c_size_t, c_float, c_void_p]),
     "casmvs_upsample2x_add_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_upsample2x_backward_f32": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
-    "casmvs_costvol_var_backward_f32": (c_int, [_FP] * 5 + [c_int] * 6 + [c_void_p]),
-    "casmvs_costvol_gwc_backward_f32": (c_int, [_FP] * 5 + [c_int] * 7 + [c_void_p]),
+    "casmvs_costvol_backward_workspace_bytes": (c_size_t, [c_int] * 6),
+    "casmvs_costvol_var_backward_f32": (c_int, [_FP] * 5 + [c_void_p] + [c_int] * 6 + [c_void_p]),
+    "casmvs_costvol_gwc_backward_f32": (c_int, [_FP] * 5 + [c_void_p] + [c_int] * 7 + [c_void_p]),
     "casmvs_normalize_images_u8": (c_int, [_FP, _FP, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "casmvs_selftest_mfma": (c_int, [_FP]),
     "casmvs_selftest_mfma_rate": (c_int, [c_int, c_int, c_int, POINTER(c_float)]),

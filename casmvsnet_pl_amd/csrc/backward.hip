@@ -6,6 +6,7 @@
 // depth = sum_k p_k d_k; the confidence is computed under torch.no_grad(), mvsnet.py:179-193).
 #include "common.h"
 #include "plane_sweep.h"
+#include "fixed_accum.h"
 
 namespace {
 
@@ -15,11 +16,13 @@ constexpr int kThreads = 256;
 
 // grad_src[b, c, tap] += grad_out[b, c, d, y, x] * w_tap: the transpose of the forward gather is a scatter-add.
 // One thread per (reference pixel, plane), lanes along the row: the taps (same arithmetic as the forward, plane_sweep.h)
-// are computed once and reused for every channel; fp32 hardware atomics (global_atomic_add_f32) - like ATen's own
-// grid_sampler backward the result depends on the order of the atomic adds in the last bits.
+// are computed once and reused for every channel.  The sums are 64-bit fixed point (fixed_accum.h): unlike ATen's own grid_sampler backward (float
+// atomics) the result does NOT depend on the order of the adds - the same bits run to run.  Scale per (sample, channel): a contribution is g w with
+// w <= 1, so 2^be >= 2 G with G the channel's largest finite |grad_out|.
 __global__ __launch_bounds__(kThreads) void homo_warp_bwd_kernel(const float *__restrict__ grad_out, const float *__restrict__ proj,
                                                                 const float *__restrict__ depth, float *__restrict__ grad_src,
-                                                                int C, int H, int W, int D) {
+                                                                unsigned long long *__restrict__ acc, const unsigned *__restrict__ gmax, int C, int H, int W,
+                                                                int D, int U) {
   const int b = blockIdx.z, d = blockIdx.y;
   const int hw = H * W;
   const int p = blockIdx.x * kThreads + threadIdx.x;
@@ -30,15 +33,37 @@ __global__ __launch_bounds__(kThreads) void homo_warp_bwd_kernel(const float *__
   if (!taps_live(t)) return;
   const float *go = grad_out + ((size_t)b * C * D + d) * hw + p;
   float *gs = grad_src + (size_t)b * C * hw;
+  unsigned long long *as = acc + (size_t)b * C * hw;
   const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
+  constexpr unsigned kOne = 0x3f800000u;   // 1.0f: fixed_exponent(G, 1, 2) = the exponent of 2 G
   for (int c = 0; c < C; ++c) {
     const float g = go[(size_t)c * D * hw];
+    int be;
+    const double scale = fixed_exponent(gmax[b * C + c], kOne, 2.0, be) ? pow2_double(U - be) : 0.0;
     float *gc = gs + (size_t)c * hw;
-    if (t.w_nl != 0.0f) unsafeAtomicAdd(gc + on, g * t.w_nl);
-    if (t.w_nr != 0.0f) unsafeAtomicAdd(gc + on + 1, g * t.w_nr);
-    if (t.w_sl != 0.0f) unsafeAtomicAdd(gc + os, g * t.w_sl);
-    if (t.w_sr != 0.0f) unsafeAtomicAdd(gc + os + 1, g * t.w_sr);
+    unsigned long long *ac = as + (size_t)c * hw;
+    auto add = [&](int o, float w) {
+      if (w == 0.0f) return;
+      const float val = g * w;
+      if (is_finite(val)) atomicAdd(ac + o, to_fixed_point(val, scale));
+      else unsafeAtomicAdd(gc + o, val);
+    };
+    add(on, t.w_nl);
+    add(on + 1, t.w_nr);
+    add(os, t.w_sl);
+    add(os + 1, t.w_sr);
   }
+}
+
+// grad_src (zero, or the non-finite contributions) += the fixed-point sums in float32, one rounding per element
+__global__ __launch_bounds__(kThreads) void homo_warp_bwd_finish_kernel(const unsigned long long *__restrict__ acc, const unsigned *__restrict__ gmax,
+                                                                       float *__restrict__ grad_src, int hw, int U) {
+  const int row = blockIdx.y;   // (b, c)
+  int be;
+  const double from_fixed = fixed_exponent(gmax[row], 0x3f800000u, 2.0, be) ? pow2_double(be - U) : 0.0;
+  const size_t base = (size_t)row * hw;
+  for (int p = blockIdx.x * kThreads + threadIdx.x; p < hw; p += gridDim.x * kThreads)
+    grad_src[base + p] += (float)((double)(long long)acc[base + p] * from_fixed);
 }
 
 // depth = sum_k softmax(cost)_k d_k  =>  d depth / d cost_k = p_k (d_k - depth).  One thread per pixel.
@@ -68,17 +93,37 @@ __global__ __launch_bounds__(kThreads) void softmax_regress_bwd_kernel(const flo
 
 }  // namespace
 
-extern "C" int casmvs_homo_warp_backward_f32(const float *grad_out, const float *proj, const float *depth, float *grad_src,
+extern "C" size_t casmvs_homo_warp_backward_workspace_bytes(int B, int C, int H, int W) {
+  if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
+  return (size_t)B * C * H * W * sizeof(unsigned long long) + (((size_t)B * C * sizeof(unsigned) + 15) & ~(size_t)15);
+}
+
+extern "C" int casmvs_homo_warp_backward_f32(const float *grad_out, const float *proj, const float *depth, float *grad_src, void *workspace,
                                              int B, int C, int H, int W, int D, void *stream) {
   casmvs::clear_error();
-  CASMVS_REQUIRE(grad_out && proj && depth && grad_src, "homo_warp_backward: null pointer");
-  CASMVS_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 1 && W > 1 && D > 0 && D <= 65535, "homo_warp_backward: bad shape B=%d C=%d H=%d W=%d D=%d", B, C, H, W, D);
+  CASMVS_REQUIRE(grad_out && proj && depth && grad_src && workspace, "homo_warp_backward: null pointer");
+  CASMVS_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 1 && W > 1 && D > 0 && D <= 65535 && (size_t)B * C <= 65535,
+                 "homo_warp_backward: bad shape B=%d C=%d H=%d W=%d D=%d", B, C, H, W, D);
+  CASMVS_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "homo_warp_backward: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_src, 0, (size_t)B * C * H * W * sizeof(float), st);
+  const int hw = H * W, U = casmvs::fixed_point_bits(D, H, W);
+  const size_t acc_bytes = (size_t)B * C * hw * sizeof(unsigned long long);
+  hipError_t e = hipMemsetAsync(grad_src, 0, (size_t)B * C * hw * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(workspace, 0, casmvs_homo_warp_backward_workspace_bytes(B, C, H, W), st);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "homo_warp_backward: hipMemsetAsync: %s", hipGetErrorString(e));
-  dim3 grid((unsigned)casmvs::ceil_div(H * W, kThreads), (unsigned)D, (unsigned)B);
-  hipLaunchKernelGGL(homo_warp_bwd_kernel, grid, dim3(kThreads), 0, st, grad_out, proj, depth, grad_src, C, H, W, D);
-  return casmvs::check_launch("homo_warp_bwd_kernel");
+  unsigned long long *acc = static_cast<unsigned long long *>(workspace);
+  unsigned *gmax = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + acc_bytes);
+  const size_t n_g = (size_t)D * hw, per_wg = (size_t)kThreads * 32, chunks_g = (n_g + per_wg - 1) / per_wg;
+  CASMVS_REQUIRE((size_t)B * C * chunks_g <= 0x7fffffffull, "homo_warp_backward: volume too large");
+  hipLaunchKernelGGL(volume_absmax_kernel, dim3((unsigned)((size_t)B * C * chunks_g)), dim3(kThreads), 0, st, grad_out, (const float *)nullptr, gmax,
+                     (unsigned *)nullptr, B * C, n_g, (int)chunks_g, 1, C, (size_t)0, 0);
+  if (int rc = casmvs::check_launch("volume_absmax_kernel")) return rc;
+  dim3 grid((unsigned)casmvs::ceil_div(hw, kThreads), (unsigned)D, (unsigned)B);
+  hipLaunchKernelGGL(homo_warp_bwd_kernel, grid, dim3(kThreads), 0, st, grad_out, proj, depth, grad_src, acc, gmax, C, H, W, D, U);
+  if (int rc = casmvs::check_launch("homo_warp_bwd_kernel")) return rc;
+  dim3 fgrid((unsigned)std::min(casmvs::ceil_div(hw, kThreads), 64), (unsigned)(B * C));
+  hipLaunchKernelGGL(homo_warp_bwd_finish_kernel, fgrid, dim3(kThreads), 0, st, acc, gmax, grad_src, hw, U);
+  return casmvs::check_launch("homo_warp_bwd_finish_kernel");
 }
 
 extern "C" int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_values, const float *grad_depth,

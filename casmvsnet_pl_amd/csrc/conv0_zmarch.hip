@@ -1,7 +1,9 @@
 // CostRegNet.conv0 (Conv3d Cin -> 8, k3 s1 p1 + folded ABN + leaky-relu) in split-f16 arithmetic, INPUT-stationary along z.
 //
-// *** Written at the end of round 3 WITHOUT a GPU run (the round's GPU minutes were spent): an opt-in entry point, not what the engine
-// *** calls.  tools/native/conv0_zm_check.cpp is its first test (against conv0_sf_kernel and a float64 convolution).
+// Status: conv0_zw_kernel below (the warp-specialised z-march) is what the engine runs at all three cascade levels - the step's dominant kernel
+// (`roofline` of the bench line); conv0_zm_kernel (two phases per unit, all waves in step) is the -DCASMVS_ZM_WS=0 A/B build.  History:
+// written against the CPU emulation at the end of round 3, first run on the MI355X in round 4 (tools/native/conv0_zm_check.cpp: against conv0_sf_kernel
+// and a float64 convolution; profiles/r04_native_checks_first_run.txt).
 //
 // Why.  conv0_sf_kernel (conv0_splitf16.hip) is bound by its L1 -> L2 request stream: a 4 x 4 x 32 output tile stages a 6 x 6 x 40 halo
 // box per chunk of 8 input channels - 2.8 staged voxels per output voxel, each row of 40 floats touching three cache lines - and without

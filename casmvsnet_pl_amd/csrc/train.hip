@@ -17,6 +17,7 @@
 #include "common.h"
 #include "plane_sweep.h"
 #include "split_f16.h"
+#include "fixed_accum.h"
 
 namespace {
 
@@ -694,24 +695,50 @@ __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float *_
 // The source-view gradient is the transpose of the bilinear gather (modules.py:87-89): a scatter.  One workgroup owns
 // (a 32 x TH tile of reference pixels, 8 planes, CG channels, ONE source view): everything it scatters falls into the
 // bounding box of its taps in that view (the epipolar band of the tile: ~44 x 26 pixels at TH = 16), so the contributions are
-// accumulated in an LDS image of that box and the box is added to the gradient map once, one fp32 atomic per touched element
+// accumulated in an LDS image of that box and the box is added to the gradient map once, one atomic per touched element
 // and channel - ~2 atomics per pixel and channel instead of the ~16 of a per-tap scatter.
-// The LDS image is FIXED POINT: 64-bit integers, ds_add_u64.  A wave-instruction of ds_add_f32 retires its lanes one by one
-// (768 ticks for 64 lanes with four waves issuing, 27x a ds_add_u32 / 16-20x a ds_add_u64: profiles/r04_lds_atomic_rates.txt)
-// and bound the float form of this kernel (3.7 of the training step's 14.1 ms).  Scale 2^s per workgroup: 2^e >= 16 G R / V with
-// G = the largest |upstream gradient| of the workgroup's (tile, planes, channels) and R = the largest |reference feature| of the
-// tile (a contribution is at most 4 G F / V for features bounded by F; R stands in for F with 4x slack), s = 45 - e.  Every
-// contribution is CHECKED against 2^e while it is formed: |sum in a cell| < 2^15 adds x 2^46 = 2^61, no overflow by
-// construction; a workgroup that sees a larger (or non-finite) contribution drops its image and scatters that pass straight to
-// global memory with float atomics, as does a box that does not fit.  Units of 2^-45 of the bound: contributions 2^-21 of the
-// largest possible one still carry 24 bits, and the image no longer depends on the order of the adds.
-// Phase 1: the tile's taps in the view -> box (wave-uniform after an LDS min / max), G and R.  Phase 2: per (pixel, plane) the warped
+//
+// ORDER-INDEPENDENT ACCUMULATION (round 5; train.py:99-127 must be reproducible run to run): every sum of this kernel - the LDS image AND the gradient map
+// the images are flushed into - is a 64-bit INTEGER in fixed point, and integer addition is associative: the result does not depend on the order in which
+// lanes, waves or workgroups add.  (Round 4 kept the LDS image in fixed point with a scale per workgroup and flushed it with float atomics: 18 runs of the same
+// 12 SGD steps gave 18 loss trajectories.)  One scale per (sample, channel), known before the kernel starts:
+//   volume_absmax_kernel   G[b][c] = largest finite |upstream gradient| of the channel's (group's) volume, F[b][c] = largest finite |feature| over all views
+//                          (integer atomicMax on the bit patterns: order-independent as well)
+//   bound[b][c] = 16 G F / V (variance: a contribution is g (2 x_v / V - 2 S / V^2) w with |x_v| <= F, |S| <= V F, w <= 1: at most 4 G F / V, two of them
+//                          merged by the lane exchange below: 8 G F / V) or 4 k G F (correlation: g k ref w <= k G F), a STRICT bound with 2x slack for the
+//                          float32 roundings: 2^be >= bound, unit 2^(be - U)
+//   U = min(44, 62 - ceil log2(D h w)): a cell receives at most one contribution per (pixel, plane), each below 2^(U - 1) units: no overflow by construction
+//                          (44: the conversion below is exact for |x| < 2^51 and the reference view's per-chunk sum is < 2^7 bounds)
+// so a contribution 2^-15 of the bound still carries 24 bits at the LARGEST volumes, and the final value is the exact integer sum rounded ONCE to float32
+// (costvol_fixed_finish_kernel) - closer to the float64 derivative than a float32 accumulation.  Non-finite contributions (a NaN / infinite upstream gradient
+// or feature; the maxima skip them) cannot be integers: they are added to the float32 output map itself with float atomics - a sum of non-finite values is
+// non-finite in any order - and the finish adds the fixed-point sum to it: exactly the elements a float accumulation would poison are poisoned.
+// G F = 0: every finite contribution is exactly zero; the scale is 0 and so is the gradient.
+// Phase 1: the tile's taps in the view -> box (wave-uniform after an LDS min / max).  Phase 2: per (pixel, plane) the warped
 // values of ALL views are re-gathered (S needs them), the own view's gradient goes into the box; the workgroups of the
 // first source view also accumulate the reference view's gradient in registers.  Phase 3: box -> global.
 // wave shift by one lane (gfx9 DPP wave_shr:1 / wave_shl:1): lane i reads lane i - 1 / i + 1; the first / last lane reads 0
 __device__ __forceinline__ int lane_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int lane_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ float lane_prev(float v) { return __builtin_bit_cast(float, lane_prev(__builtin_bit_cast(int, v))); }
+
+// grad_feats (zero, or the non-finite contributions) += the fixed-point sums in float32, one rounding per element
+template <bool GWC>
+__global__ __launch_bounds__(kThreads) void costvol_fixed_finish_kernel(const unsigned long long *__restrict__ acc, const unsigned *__restrict__ gmax,
+                                                                        const unsigned *__restrict__ fmax, float *__restrict__ gfeats, int V, int C, int G, int hw,
+                                                                        int U) {
+  const int row = blockIdx.y;   // (b, v, c)
+  const int b = row / (V * C), c = row % C;
+  const int cpg = GWC ? C / G : 1;
+  int be;
+  const bool ok = fixed_exponent(gmax[GWC ? b * G + c / cpg : b * C + c], fmax[b * C + c], GWC ? 4.0 / ((double)cpg * (double)(V - 1)) : 16.0 / (double)V, be);
+  const double from_fixed = ok ? pow2_double(be - U) : 0.0;
+  const size_t base = (size_t)row * hw;
+  for (int p = blockIdx.x * kThreads + threadIdx.x; p < hw; p += gridDim.x * kThreads) {
+    const long long val = (long long)acc[base + p];
+    gfeats[base + p] += (float)((double)val * from_fixed);
+  }
+}
 
 // VS: the number of source views when the instantiation fixes it (their gathers are then issued together), 0 = V - 1 at run time.
 // GWC: the group-wise correlation volume (mvsnet.py:142-144,157-162,169-172) instead of the variance: vol[g] = sum_v mean_{c in g} ref[c] warped_v[c] / (V - 1),
@@ -720,12 +747,12 @@ __device__ __forceinline__ float lane_prev(float v) { return __builtin_bit_cast(
 template <int CG, int TH, int VS, bool GWC>
 __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *__restrict__ feats, const float *__restrict__ proj,
                                                                   const float *__restrict__ depth, const float *__restrict__ gvol,
-                                                                  float *__restrict__ gfeats, int V, int C, int H, int W, int D,
-                                                                  int tiles_x, int DCH, int CAP, int G) {
+                                                                  float *__restrict__ gfeats, unsigned long long *__restrict__ acc,
+                                                                  const unsigned *__restrict__ gmax, const unsigned *__restrict__ fmax, int V, int C, int H, int W,
+                                                                  int D, int tiles_x, int DCH, int CAP, int G, int U) {
   constexpr int TS = 32, RPT = TS * TH / kThreads, RSTEP = kThreads / TS;   // tile: 32 columns x TH rows, a thread's pixels RSTEP rows apart
-  CASMVS_DYNAMIC_LDS(unsigned long long, box);   // [CG][bh][bw], CAP cells per channel: fixed point, units of 2^(e - 45)
+  CASMVS_DYNAMIC_LDS(unsigned long long, box);   // [CG][bh][bw], CAP cells per channel: fixed point, the gradient map's own units
   __shared__ int ext[(RPT + 1) * 4];   // tap boxes of the tile's RPT bands of 8 rows, then their union
-  __shared__ unsigned wgmax[3];                        // bit patterns of G, R; [2]: a contribution outside the fixed-point range was seen
   const int tid = threadIdx.x, b = blockIdx.z, hw = H * W;
   int r = blockIdx.y;
   const int v = 1 + r % (V - 1); r /= (V - 1);
@@ -734,6 +761,7 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   const int x = txi * TS + (tid & (TS - 1)), yb = tyi * TH + tid / TS;
   const float *fb = feats + (size_t)b * V * C * hw;
   float *gb = gfeats + (size_t)b * V * C * hw;
+  unsigned long long *ab = acc + (size_t)b * V * C * hw;
   const float *Pb = proj + (size_t)b * (V - 1) * 12;
   const float *Pv = Pb + (v - 1) * 12;
   const float *db = depth + (size_t)b * D * hw;
@@ -741,17 +769,23 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   const int cpg = GWC ? C / G : 1;
   const float kg = GWC ? 1.0f / ((float)cpg * (float)(V - 1)) : 0.0f;
   size_t goff[CG];   // the upstream gradient's plane 0 of the channel (variance) / of the channel's group (correlation)
+  double to_fixed[CG];   // 2^(U - be) of the channel, 0 without a scale (then every finite contribution is 0)
 #pragma unroll
-  for (int c = 0; c < CG; ++c) goff[c] = GWC ? ((size_t)b * G + (c0 + c) / cpg) * D * hw : ((size_t)b * C + c0 + c) * D * hw;
+  for (int c = 0; c < CG; ++c) {
+    goff[c] = GWC ? ((size_t)b * G + (c0 + c) / cpg) * D * hw : ((size_t)b * C + c0 + c) * D * hw;
+    int be;
+    const bool ok = fixed_exponent(gmax[GWC ? b * G + (c0 + c) / cpg : b * C + c0 + c], fmax[b * C + c0 + c],
+                                   GWC ? 4.0 / ((double)cpg * (double)(V - 1)) : 16.0 / (double)V, be);
+    to_fixed[c] = ok ? pow2_double(U - be) : 0.0;
+  }
+  auto fx = [](float val, double scale) { return to_fixed_point(val, scale); };
 
   // ---- 1. bounding boxes of this view's live taps: the tile's, and (published only when the tile's does not fit the LDS
   // image) one per band of RSTEP rows (a thread's j-th pixel)
   if (tid < (RPT + 1) * 4) ext[tid] = (tid & 1) ? INT_MIN : INT_MAX;
-  if (tid < 3) wgmax[tid] = 0u;
   __syncthreads();
   int bxmn[RPT], bxmx[RPT], bymn[RPT], bymx[RPT];
   int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
-  unsigned gbits = 0u, rbits = 0u;   // maxima of |.| as bit patterns: monotonic for non-negative floats, NaN above infinity
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     bxmn[j] = INT_MAX; bxmx[j] = INT_MIN; bymn[j] = INT_MAX; bymx[j] = INT_MIN;
@@ -759,19 +793,10 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     const int yr = yb + j * RSTEP;
     const bool valid = x < W && yr < H;
     const int p = min(yr, H - 1) * W + min(x, W - 1);
-    const float *gp = gvol + p;
-    unsigned rb = 0u, gbt = 0u;
-#pragma unroll
-    for (int c = 0; c < CG; ++c) rb = max(rb, __builtin_bit_cast(unsigned, fb[(size_t)(c0 + c) * hw + p]) & 0x7fffffffu);
     for (int d0 = d_begin; d0 < d_end; d0 += 8) {
       float dvs[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int d = min(d0 + i, d_end - 1);
-        dvs[i] = db[(size_t)d * hw + p];
-#pragma unroll
-        for (int c = 0; c < CG; ++c) gbt = max(gbt, __builtin_bit_cast(unsigned, gp[goff[c] + (size_t)d * hw]) & 0x7fffffffu);
-      }
+      for (int i = 0; i < 8; ++i) dvs[i] = db[(size_t)min(d0 + i, d_end - 1) * hw + p];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const Taps t = plane_sweep_taps(Pv, (float)x, (float)yr, dvs[i], W, H);
@@ -781,7 +806,6 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
         }
       }
     }
-    if (valid) { rbits = max(rbits, rb); gbits = max(gbits, gbt); }
     xmn = min(xmn, bxmn[j]); xmx = max(xmx, bxmx[j]);
     ymn = min(ymn, bymn[j]); ymx = max(ymx, bymx[j]);
   }
@@ -789,22 +813,9 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     atomicMin(&ext[RPT * 4 + 0], xmn); atomicMax(&ext[RPT * 4 + 1], xmx);
     atomicMin(&ext[RPT * 4 + 2], ymn); atomicMax(&ext[RPT * 4 + 3], ymx);
   }
-  gbits = casmvs::wave_max_bits(gbits);
-  rbits = casmvs::wave_max_bits(rbits);
-  if ((tid & 63) == 0) { atomicMax(&wgmax[0], gbits); atomicMax(&wgmax[1], rbits); }
   __syncthreads();
-  // the fixed-point scale: 2^e >= 16 G R / V (a normal float, or the workgroup scatters with float atomics), unit 2^(e - 45); correlation: a contribution
-  // is g ref k with the tile's own reference features - 4 G R k bounds it outright
-  const float bound = (GWC ? 4.0f * kg : 16.0f / fV) * __builtin_bit_cast(float, wgmax[0]) * __builtin_bit_cast(float, wgmax[1]);
-  const int be = (int)((__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu) - 126;   // bound = m 2^be, m in [0.5, 1)
-  const bool fixed_ok = wgmax[0] < 0x7f800000u && wgmax[1] < 0x7f800000u && be > -90 && be < 90;   // finite, not zero / denormal / huge
-  const float limit = __builtin_bit_cast(float, (unsigned)(be + 127) << 23);                                      // 2^be
-  const double to_fixed = __builtin_bit_cast(double, (unsigned long long)(1023 + 45 - be) << 52);                 // 2^(45 - be)
-  const double from_fixed = __builtin_bit_cast(double, (unsigned long long)(1023 - 45 + be) << 52);
-  constexpr double kMagic = 6755399441055744.0;   // 1.5 2^52: the low mantissa bits of x + kMagic are round(x) in two's complement, |x| < 2^51
-  auto fx = [&](float v) { return (unsigned long long)(__builtin_bit_cast(long long, __builtin_fma((double)v, to_fixed, kMagic)) - __builtin_bit_cast(long long, kMagic)); };
   // The whole tile's box in one LDS image when it fits; otherwise band by band (noisy depth maps spread a tile's taps over
-  // far more than its own extent), and a band whose box still does not fit scatters straight to global memory.
+  // far more than its own extent), and a band whose box still does not fit adds straight to the gradient map.
   const bool whole = ext[RPT * 4] > ext[RPT * 4 + 1] ||
                      (ext[RPT * 4 + 1] - ext[RPT * 4] + 1) * (ext[RPT * 4 + 3] - ext[RPT * 4 + 2] + 1) <= CAP;
   if (!whole) {
@@ -817,6 +828,7 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     __syncthreads();
   }
   float *gsv = gb + ((size_t)v * C + c0) * hw;
+  unsigned long long *asv = ab + ((size_t)v * C + c0) * hw;
   const int lane = tid & 63;
   for (int seg = 0; seg < (whole ? 1 : RPT); ++seg) {
   const int *eb = ext + (whole ? RPT : seg) * 4;
@@ -824,12 +836,9 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   const bool any = eb[0] <= eb[1];
   const int bw = any ? eb[1] - eb[0] + 1 : 0, bh = any ? eb[3] - eb[2] + 1 : 0;
   const int cells = bw * bh;
-  // second pass of a segment (rare): a contribution left the fixed-point range - the image is dropped and the pass scatters to global memory
-  for (int pass = 0; pass < 2; ++pass) {
-  const bool in_lds = fixed_ok && pass == 0 && cells <= CAP;
+  const bool in_lds = cells <= CAP;
   if (in_lds)
     for (int e = tid; e < CG * cells; e += kThreads) box[e] = 0ull;
-  bool outside = false;
   __syncthreads();
 
   // ---- 2. per (pixel, plane): S over the views, own view's gradient into the box
@@ -915,8 +924,7 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
       const bool live = valid && taps_live(tv);
       // Neighbouring lanes are neighbouring pixels: lane i's RIGHT tap column is usually lane i + 1's LEFT one.  The right
       // contribution travels one lane up (DPP) and is added to the neighbour's left one: ~2 adds per channel and row pair
-      // instead of 4 (LDS fp32 atomics retire ~0.5 lanes per clock and CU: they, not the gathers, bound this kernel).
-      // A lane keeps its right tap only when the next lane does not continue the run; dead lanes (key -100) never match.
+      // instead of 4.  A lane keeps its right tap only when the next lane does not continue the run; dead lanes (key -100) never match.
       const int kxl = live ? tv.xl : -100;
       const int pxl = lane_prev(kxl), pyn = lane_prev(tv.yn), pys = lane_prev(tv.ys);
       const int nxl = lane_next(kxl), nyn = lane_next(tv.yn), nys = lane_next(tv.ys);
@@ -924,61 +932,71 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
       const bool ab_n = lane < 63 && nyn == tv.yn && nxl == tv.xl + 1, ab_s = lane < 63 && nys == tv.ys && nxl == tv.xl + 1;
       const int lo_n = (tv.yn - by0) * bw + (tv.xl - bx0), lo_s = (tv.ys - by0) * bw + (tv.xl - bx0);
       const int go_n = tv.yn * W + tv.xl, go_s = tv.ys * W + tv.xl;
+      float gxs[CG];
+      bool bad = false;
 #pragma unroll
       for (int c = 0; c < CG; ++c) {
         const float g = gd[c];
-        float gx;
         if (GWC) {
           gref[c] += g * kg * S[c];
-          gx = g * kg * ref[c];
+          gxs[c] = g * kg * ref[c];
         } else {
           const float common = 2.0f * S[c] / (fV * fV);
           gref[c] += g * (2.0f * ref[c] / fV - common);
-          gx = g * (2.0f * xv[c] / fV - common);
+          gxs[c] = g * (2.0f * xv[c] / fV - common);
         }
-        outside = outside || (live && !(fabsf(gx) < limit));   // also NaN
+        bad = bad || !is_finite(gxs[c]);
+      }
+      // wave-uniform: a non-finite contribution somewhere in the wave (rare) sends every value of this step through the per-value check
+      const bool slow = __builtin_amdgcn_ballot_w64(live && bad) != 0;
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        const float gx = gxs[c];
         const float rn = gx * tv.w_nr, rs = gx * tv.w_sr;
         const float prn = lane_prev(rn), prs = lane_prev(rs);
         const float an = gx * tv.w_nl + (mp_n ? prn : 0.0f), as = gx * tv.w_sl + (mp_s ? prs : 0.0f);
         if (live) {
-          if (in_lds) {
-            unsigned long long *q = box + c * cells;
-            atomicAdd(q + lo_n, fx(an));
-            if (!ab_n) atomicAdd(q + lo_n + 1, fx(rn));
-            atomicAdd(q + lo_s, fx(as));
-            if (!ab_s) atomicAdd(q + lo_s + 1, fx(rs));
+          unsigned long long *q = in_lds ? box + c * cells : asv + (size_t)c * hw;
+          const int o_n = in_lds ? lo_n : go_n, o_s = in_lds ? lo_s : go_s;
+          if (!slow) {
+            atomicAdd(q + o_n, fx(an, to_fixed[c]));
+            if (!ab_n) atomicAdd(q + o_n + 1, fx(rn, to_fixed[c]));
+            atomicAdd(q + o_s, fx(as, to_fixed[c]));
+            if (!ab_s) atomicAdd(q + o_s + 1, fx(rs, to_fixed[c]));
           } else {
-            float *q = gsv + (size_t)c * hw;
-            unsafeAtomicAdd(q + go_n, an);
-            if (!ab_n) unsafeAtomicAdd(q + go_n + 1, rn);
-            unsafeAtomicAdd(q + go_s, as);
-            if (!ab_s) unsafeAtomicAdd(q + go_s + 1, rs);
+            float *qf = gsv + (size_t)c * hw;
+            auto add = [&](int o, int go, float val) {
+              if (is_finite(val)) atomicAdd(q + o, fx(val, to_fixed[c]));
+              else unsafeAtomicAdd(qf + go, val);
+            };
+            add(o_n, go_n, an);
+            if (!ab_n) add(o_n + 1, go_n + 1, rn);
+            add(o_s, go_s, as);
+            if (!ab_s) add(o_s + 1, go_s + 1, rs);
           }
         }
       }
     }
-    if (v == 1 && valid && pass == 0) {   // view 0 (the reference features): one add per plane chunk
+    if (v == 1 && valid) {   // view 0 (the reference features): one add per plane chunk
 #pragma unroll
-      for (int c = 0; c < CG; ++c) unsafeAtomicAdd(gb + (size_t)(c0 + c) * hw + p, gref[c]);
+      for (int c = 0; c < CG; ++c) {
+        if (is_finite(gref[c])) atomicAdd(ab + (size_t)(c0 + c) * hw + p, fx(gref[c], to_fixed[c]));
+        else unsafeAtomicAdd(gb + (size_t)(c0 + c) * hw + p, gref[c]);
+      }
     }
   }
-  if (in_lds && __builtin_amdgcn_ballot_w64(outside) != 0 && lane == 0) atomicMax(&wgmax[2], 1u);   // one integer LDS atomic per wave that saw one
   __syncthreads();
-  if (!in_lds) break;             // scattered to global memory: done
-  if (wgmax[2] != 0u) continue;   // uniform: read behind the barrier; the second pass does not write it
 
   // ---- 3. box -> gradient map (lanes = consecutive columns of a box row of one channel plane)
-  for (int e = tid; e < CG * cells; e += kThreads) {
-    const long long val = (long long)box[e];
-    if (val != 0) {
-      const int c = e / cells, cell = e - c * cells, row = cell / bw, col = cell - row * bw;
-      unsafeAtomicAdd(gsv + (size_t)c * hw + (by0 + row) * W + bx0 + col, (float)((double)val * from_fixed));
+  if (in_lds)
+    for (int e = tid; e < CG * cells; e += kThreads) {
+      const unsigned long long val = box[e];
+      if (val != 0ull) {
+        const int c = e / cells, cell = e - c * cells, row = cell / bw, col = cell - row * bw;
+        atomicAdd(asv + (size_t)c * hw + (by0 + row) * W + bx0 + col, val);
+      }
     }
-  }
-  break;
-  }
-  __syncthreads();   // the image is zeroed again for the next band; wgmax[2] is read before it can change
-  if (tid == 0) wgmax[2] = 0u;
+  __syncthreads();   // the image is zeroed again for the next band
   }
 }
 
@@ -1257,16 +1275,47 @@ extern "C" int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad
 }
 
 namespace {
-// the variance volume's (G = 0) or the correlation volume's (G > 0) gradient w.r.t. the feature maps: one launch behind the zeroing of grad_feats
-int volume_backward(const float *feats, const float *proj, const float *depth, const float *grad_vol, float *grad_feats, int B, int V, int C, int G,
-                    int h, int w, int D, void *stream, const char *what) {
-  CASMVS_REQUIRE(feats && proj && depth && grad_vol && grad_feats, "%s: null pointer", what);
-  CASMVS_REQUIRE(B > 0 && B <= 65535 && V >= 2 && h > 1 && w > 1 && D > 0, "%s: bad shape B=%d V=%d h=%d w=%d D=%d", what, B, V, h, w, D);
+// workspace of the volume backward: [acc: B V C h w 64-bit fixed-point sums][gmax: B (G | C) uint32][fmax: B C uint32]
+struct VolBwdWs {
+  size_t acc_bytes, gmax_off, fmax_off, total;
+};
+VolBwdWs volume_backward_ws(int B, int V, int C, int G, int h, int w) {
+  VolBwdWs l;
+  l.acc_bytes = (size_t)B * V * C * h * w * sizeof(unsigned long long);
+  l.gmax_off = l.acc_bytes;
+  l.fmax_off = l.gmax_off + (((size_t)B * (G > 0 ? G : C) * sizeof(unsigned) + 15) & ~(size_t)15);
+  l.total = l.fmax_off + (((size_t)B * C * sizeof(unsigned) + 15) & ~(size_t)15);
+  return l;
+}
+// the variance volume's (G = 0) or the correlation volume's (G > 0) gradient w.r.t. the feature maps: zeroing, the channels' largest magnitudes, the
+// scatter into the fixed-point map, the map -> float32
+int volume_backward(const float *feats, const float *proj, const float *depth, const float *grad_vol, float *grad_feats, void *workspace, int B, int V,
+                    int C, int G, int h, int w, int D, void *stream, const char *what) {
+  CASMVS_REQUIRE(feats && proj && depth && grad_vol && grad_feats && workspace, "%s: null pointer", what);
+  CASMVS_REQUIRE(B > 0 && B <= 65535 && V >= 2 && V <= 64 && h > 1 && w > 1 && D > 0, "%s: bad shape B=%d V=%d h=%d w=%d D=%d", what, B, V, h, w, D);
   CASMVS_REQUIRE(C % 4 == 0 && C >= 4 && C <= 64, "%s: C=%d (a multiple of 4 up to 64)", what, C);
   CASMVS_REQUIRE(G == 0 || (G > 0 && C % G == 0), "%s: G=%d does not divide C=%d", what, G, C);
+  CASMVS_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
+  CASMVS_REQUIRE((size_t)B * V * C <= 65535, "%s: B V C = %zu rows", what, (size_t)B * V * C);
   hipStream_t st = (hipStream_t)stream;
+  const VolBwdWs ws = volume_backward_ws(B, V, C, G, h, w);
   hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)B * V * C * h * w * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(workspace, 0, ws.total, st);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "%s: hipMemsetAsync: %s", what, hipGetErrorString(e));
+  unsigned long long *acc = static_cast<unsigned long long *>(workspace);
+  unsigned *gmax = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + ws.gmax_off);
+  unsigned *fmax = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + ws.fmax_off);
+  const int hw = h * w, U = casmvs::fixed_point_bits(D, h, w);
+  {
+    const int rows_g = B * (G > 0 ? G : C), rows_f = B * V * C;
+    const size_t n_g = (size_t)D * hw, n_f = (size_t)hw, per_wg = (size_t)kThreads * 32;
+    const size_t chunks_g = (n_g + per_wg - 1) / per_wg, chunks_f = (n_f + per_wg - 1) / per_wg;
+    const size_t wgs = rows_g * chunks_g + rows_f * chunks_f;
+    CASMVS_REQUIRE(wgs <= 0x7fffffffull, "%s: volume too large", what);
+    hipLaunchKernelGGL(volume_absmax_kernel, dim3((unsigned)wgs), dim3(kThreads), 0, st, grad_vol, feats, gmax, fmax, rows_g, n_g, (int)chunks_g, V, C, n_f,
+                       (int)chunks_f);
+    if (int rc = casmvs::check_launch("volume_absmax_kernel")) return rc;
+  }
   // 8 planes per workgroup; the LDS image holds 1152 box pixels (a 32 x 16 tile whose taps spread over ~44 x 26) of 4 channels
   // in 64-bit fixed point = 36 KiB: four workgroups per CU (the kernel waits on its gathers: 0.92 -> 0.43 ms at level 1 from two to four)
   constexpr int dch = 8, cap = 1152, th = 16, CG = 4;
@@ -1278,21 +1327,30 @@ int volume_backward(const float *feats, const float *proj, const float *depth, c
   const size_t lds = (size_t)CG * cap * sizeof(unsigned long long);
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds, "costvol_var_bwd_kernel")) return rc;
   dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)gy, (unsigned)B);
-  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, feats, proj, depth, grad_vol, grad_feats, V, C, h, w, D, tiles_x, dch, cap, G);
-  return casmvs::check_launch("costvol_var_bwd_kernel");
+  hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, st, feats, proj, depth, grad_vol, grad_feats, acc, gmax, fmax, V, C, h, w, D, tiles_x, dch, cap, G, U);
+  if (int rc = casmvs::check_launch("costvol_var_bwd_kernel")) return rc;
+  dim3 fgrid((unsigned)std::min(casmvs::ceil_div(hw, kThreads), 64), (unsigned)(B * V * C));
+  if (G > 0) hipLaunchKernelGGL(costvol_fixed_finish_kernel<true>, fgrid, dim3(kThreads), 0, st, acc, gmax, fmax, grad_feats, V, C, G, hw, U);
+  else hipLaunchKernelGGL(costvol_fixed_finish_kernel<false>, fgrid, dim3(kThreads), 0, st, acc, gmax, fmax, grad_feats, V, C, G, hw, U);
+  return casmvs::check_launch("costvol_fixed_finish_kernel");
 }
 }  // namespace
 
+extern "C" size_t casmvs_costvol_backward_workspace_bytes(int B, int V, int C, int G, int h, int w) {
+  if (B < 1 || V < 2 || C < 1 || G < 0 || h < 1 || w < 1) return 0;
+  return volume_backward_ws(B, V, C, G, h, w).total;
+}
+
 extern "C" int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,
-                                               float *grad_feats, int B, int V, int C, int h, int w, int D, void *stream) {
+                                               float *grad_feats, void *workspace, int B, int V, int C, int h, int w, int D, void *stream) {
   casmvs::clear_error();
-  return volume_backward(feats, proj, depth, grad_vol, grad_feats, B, V, C, 0, h, w, D, stream, "costvol_var_backward");
+  return volume_backward(feats, proj, depth, grad_vol, grad_feats, workspace, B, V, C, 0, h, w, D, stream, "costvol_var_backward");
 }
 
 extern "C" int casmvs_costvol_gwc_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,
-                                               float *grad_feats, int B, int V, int C, int G, int h, int w, int D, void *stream) {
+                                               float *grad_feats, void *workspace, int B, int V, int C, int G, int h, int w, int D, void *stream) {
   casmvs::clear_error();
   CASMVS_REQUIRE(G > 0, "costvol_gwc_backward: G=%d", G);
-  return volume_backward(feats, proj, depth, grad_vol, grad_feats, B, V, C, G, h, w, D, stream, "costvol_gwc_backward");
+  return volume_backward(feats, proj, depth, grad_vol, grad_feats, workspace, B, V, C, G, h, w, D, stream, "costvol_gwc_backward");
 }
 

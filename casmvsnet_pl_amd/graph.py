@@ -15,7 +15,8 @@ from . import streams
 
 def _uses_f16(model):
     """Does a forward of this model launch kernels with f16 / bf16 matrix instructions (the split layer modes)?"""
-    return any(getattr(m, "conv0_mode", "f32") != "f32" or getattr(m, "ci_mode", "f32") != "f32" or getattr(m, "tail_mode", "f32") != "f32" for m in model.modules())
+    return any(getattr(m, "conv0_mode", "f32") != "f32" or getattr(m, "ci_mode", "f32") != "f32" or getattr(m, "tail_mode", "f32") != "f32" or
+               (getattr(m, "s2_mode", None) or "f32") != "f32" for m in model.modules())
 
 
 class GraphedForward:
@@ -127,6 +128,8 @@ class ConcurrentForwards:
                         m.ci_mode = "f32"
                     if hasattr(m, "tail_mode"):
                         m.tail_mode = "f32"
+                    if hasattr(m, "s2_mode"):   # an explicit "splitf16" on conv1 / conv3 would survive ci_mode = "f32" (s2_mode or ci_mode)
+                        m.s2_mode = "f32"
             st.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(st), streams.stream_guard(not mixed_matrix_types):
                 self.forwards.append(GraphedForward(replica, imgs, proj_mats, init_depth_min, depth_interval, warmup))

@@ -209,6 +209,7 @@ class FeatureNet(_PackedWeights, nn.Module):
         stores of levels 0 / 1, which nothing downstream reads, are dropped."""
         if not x.is_cuda:
             raise RuntimeError("casmvsnet_pl_amd.FeatureNet runs on the MI355X only; there is no CPU fallback")
+        self.last_channels_last = None   # the pixel-major maps of THIS call or none: never those of earlier images (the train-mode branch produces none)
         if self.training:   # batch statistics + autograd graph (training.py); eval mode = the fused engine below
             from .training import feature_net_train
             return feature_net_train(self, x.float())

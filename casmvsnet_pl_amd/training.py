@@ -90,9 +90,16 @@ class PackPlan:
     ~4.7 us.  The plan records the (weight, bias, kind, adjoint) requests of a model's first training step together with persistent output buffers; from
     the second step on `begin_step` fills ALL of them with one launch at the start of the forward and `device_pack` hands the buffers out, as long as the
     parameter's storage and version are the ones the launch saw (anything else - a new request, a parameter replaced or modified after `begin_step` - takes
-    the single-image launch and, for a new request, joins the plan).  Capturable: the batched launch is part of the captured step."""
+    the single-image launch and, for a new request, joins the plan).  Capturable: the batched launch is part of the captured step.
+    A plan serves the parameters of ITS model only (`owned`: the storages of model.parameters() at the last begin_step): a convolution of another model - or
+    a stray device_pack call - that runs while this plan is the active one packs on its own and never joins the table; entries whose parameter the model no
+    longer holds (replaced by .to(), a re-initialised layer, another device) are dropped at the next begin_step together with their buffers (a captured
+    graph that still read them would read a freed parameter as well)."""
 
-    def __init__(self):
+    def __init__(self, model=None):
+        import weakref
+        self.model = None if model is None else weakref.ref(model)
+        self.owned = None      # data_ptr -> device of the model's parameters at the last begin_step (None: no model given, every request is served)
         self.entries = {}      # (weight ptr, bias ptr, kind, adjoint) -> [weight, bias, index, out, version seen by the last batched launch or None,
         #                          steps since the last request]
         self.table = None      # device copy of the segment array; None = rebuild before the next launch
@@ -104,6 +111,9 @@ class PackPlan:
     @staticmethod
     def _key(weight, bias, kind, adjoint):
         return (weight.data_ptr(), 0 if bias is None else bias.data_ptr(), int(kind), bool(adjoint))
+
+    def serves(self, weight):
+        return self.owned is None or self.owned.get(weight.data_ptr()) == weight.device
 
     def lookup(self, kind, weight, bias, adjoint, idx):
         key = self._key(weight, bias, kind, adjoint)
@@ -122,6 +132,11 @@ class PackPlan:
     def begin_step(self):
         """One launch for every recorded image; nothing on the first step (no requests yet)."""
         import numpy as np
+        model = None if self.model is None else self.model()
+        if model is not None:
+            self.owned = {p.data_ptr(): p.device for p in model.parameters()}
+            for k in [k for k, e in self.entries.items() if not self.serves(e[0])]:
+                del self.entries[k]
         # an image nobody asked for during two whole steps (its parameter was replaced: .to(), a re-initialised layer) is no longer packed; its buffer
         # stays (a captured graph may read it) and it rejoins the table when it is requested again
         for e in self.entries.values():
@@ -134,7 +149,7 @@ class PackPlan:
         if not keys:
             return
         entries = [self.entries[k] for k in keys]
-        dev = entries[0][0].device
+        dev = entries[0][0].device   # one device: entries on another one were dropped above
         if self.table is None:
             seg = np.zeros(len(entries), dtype=np.dtype([("w", "<u8"), ("b", "<u8"), ("idx", "<u8"), ("out", "<u8"), ("n_w", "<i4"), ("n_b", "<i4"),
                                                           ("n_out", "<i4"), ("first", "<i4")]))
@@ -146,8 +161,7 @@ class PackPlan:
             self.table = torch.from_numpy(seg.view(np.uint8).copy()).to(dev)
             self.n_blocks = block
         with torch.cuda.device(dev):
-            rc = _lib.load().casmvs_pack_gather_batch_f32(ctypes.c_void_p(self.table.data_ptr()), len(entries), self.n_blocks,
-                                                          ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            rc = _lib.load().casmvs_pack_gather_batch_f32(ctypes.c_void_p(self.table.data_ptr()), len(entries), self.n_blocks, _stream(self.table))
         _lib.check(rc, "casmvs_pack_gather_batch_f32")
         for e in entries:
             e[4] = (e[0]._version, -1 if e[1] is None else e[1]._version)
@@ -161,7 +175,7 @@ def pack_plan_of(model):
     """The model's PackPlan (created on first use; kept on the module object, so it goes away with it)."""
     plan = model.__dict__.get("_casmvs_pack_plan")
     if plan is None:
-        plan = model.__dict__["_casmvs_pack_plan"] = PackPlan()
+        plan = model.__dict__["_casmvs_pack_plan"] = PackPlan(model)
     return plan
 
 
@@ -177,7 +191,7 @@ def device_pack(kind, weight, bias=None, adjoint=False):
     w = weight.detach().contiguous().float()
     bz = None if bias is None else bias.detach().contiguous().float()
     plan = _ACTIVE_PLAN
-    planned = plan is not None and w.data_ptr() == weight.data_ptr() and (bias is None or bz.data_ptr() == bias.data_ptr())
+    planned = plan is not None and w.data_ptr() == weight.data_ptr() and (bias is None or bz.data_ptr() == bias.data_ptr()) and plan.serves(weight)
     if planned:
         out, fresh = plan.lookup(kind, weight.detach(), None if bias is None else bias.detach(), adjoint, idx)
         if fresh:
@@ -422,6 +436,14 @@ def upsample_add(lat, up):
     return _UpsampleAdd.apply(lat, up)
 
 
+def _volume_backward_workspace(feats, G):
+    """Caller-owned scratch of casmvs_costvol_{var,gwc}_backward_f32 (the 64-bit fixed-point gradient map + the channels' largest magnitudes: the backward
+    is order-independent, so a training step gives the same bits run to run); from torch's caching allocator, i.e. stream-ordered and capture-safe."""
+    B, V, C, h, w = feats.shape
+    n = _lib.load().casmvs_costvol_backward_workspace_bytes(B, V, C, int(G), h, w)
+    return torch.empty(n // 8 + 1, dtype=torch.int64, device=feats.device)
+
+
 class _VarianceVolume(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, proj_mats, depth_values):
@@ -441,8 +463,9 @@ class _VarianceVolume(torch.autograd.Function):
         D = depth_values.shape[1]
         gvol = gvol.contiguous().float()
         gfeats = torch.empty_like(feats)
+        ws = _volume_backward_workspace(feats, 0)
         with torch.cuda.device(feats.device):
-            rc = _lib.load().casmvs_costvol_var_backward_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(gvol), _ptr(gfeats),
+            rc = _lib.load().casmvs_costvol_var_backward_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(gvol), _ptr(gfeats), _ptr(ws),
                                                              B, V, C, h, w, D, _stream(feats))
         _lib.check(rc, "casmvs_costvol_var_backward_f32")
         return gfeats, None, None
@@ -480,8 +503,9 @@ class _GroupwiseVolume(torch.autograd.Function):
         G, D = ctx.G, depth_values.shape[1]
         gvol = gvol.contiguous().float()
         gfeats = torch.empty_like(feats)
+        ws = _volume_backward_workspace(feats, G)
         with torch.cuda.device(feats.device):
-            rc = _lib.load().casmvs_costvol_gwc_backward_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(gvol), _ptr(gfeats),
+            rc = _lib.load().casmvs_costvol_gwc_backward_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(gvol), _ptr(gfeats), _ptr(ws),
                                                              B, V, C, G, h, w, D, _stream(feats))
         _lib.check(rc, "casmvs_costvol_gwc_backward_f32")
         return gfeats, None, None, None

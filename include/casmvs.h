@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CASMVS_ABI_VERSION 3
+#define CASMVS_ABI_VERSION 4
 
 #define CASMVS_OK 0
 #define CASMVS_ERR_INVALID_ARG (-1) /* null pointer / non-positive size / unsupported combination */
@@ -476,10 +476,13 @@ int casmvs_fuse_reference_view_paired(const float *depth_ref, const unsigned cha
 /* ---- (f-2) backward of the plane sweep and of the depth regression (training, op by op) -----------
  * casmvs_homo_warp_backward_f32: the gradient of models/modules.py:52-92 with respect to src_feat (the grid depends on
  *   the DETACHED depth hypotheses only, mvsnet.py:231): grad_src (B,C,H,W) = scatter-add of grad_out (B,C,D,H,W) with the
- *   forward's bilinear weights (fp32 hardware atomics).  grad_src is zeroed by the call.
+ *   forward's bilinear weights.  grad_src is zeroed by the call.  The sums are 64-bit fixed point with one scale per (sample, channel)
+ *   (csrc/fixed_accum.h): the result is bit-identical run to run (ABI 4; ABI 3 used float atomics).  workspace: caller-owned, 16-byte aligned,
+ *   casmvs_homo_warp_backward_workspace_bytes(B, C, H, W) bytes (the fixed-point map + the channels' largest magnitudes); contents need not survive the call.
  * casmvs_softmax_regress_backward_f32: depth = sum_k softmax(cost)_k d_k (mvsnet.py:175-177): grad_cost (B,D,h,w) =
  *   grad_depth (B,h,w) * p_k (d_k - depth).  (The confidence is computed under no_grad in the reference.) */
-int casmvs_homo_warp_backward_f32(const float *grad_out, const float *proj, const float *depth, float *grad_src,
+size_t casmvs_homo_warp_backward_workspace_bytes(int B, int C, int H, int W);
+int casmvs_homo_warp_backward_f32(const float *grad_out, const float *proj, const float *depth, float *grad_src, void *workspace,
                                   int B, int C, int H, int W, int D, void *stream);
 int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_values, const float *grad_depth,
                                         float *grad_cost, int B, int D, int h, int w, void *stream);
@@ -516,8 +519,12 @@ int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_va
  * casmvs_costvol_var_backward_f32: gradient of the variance volume (mvsnet.py:137-167) w.r.t. feats (B,V,C,h,w) given
  *   grad_vol (B,C,D,h,w): d var / d x_v = 2 x_v / V - 2 sum_v x_v / V^2 through the plane sweep's bilinear weights
  *   (reference view: no warp).  grad_feats is zeroed by the call; the hypotheses get no gradient (mvsnet.py:231).  C: a multiple of
- *   4 up to 64.  A workgroup accumulates its scatter in a 64-bit fixed-point LDS image (LDS float atomics retire lane by lane on
- *   gfx950) whose range every contribution is checked against; outside it the workgroup scatters with float atomics (csrc/train.hip). */
+ *   4 up to 64, V <= 64.  ORDER-INDEPENDENT (ABI 4): a workgroup accumulates its scatter in a 64-bit fixed-point LDS image (LDS float atomics retire
+ *   lane by lane on gfx950) and adds the image to a 64-bit fixed-point gradient map with integer atomics; one scale per (sample, channel) from the
+ *   channel's largest finite |grad_vol| and |feats| (a strict bound of every contribution: no range check, no fallback); a last pass rounds the sums to
+ *   float32 once.  The result is bit-identical run to run (train.py:99-127 is reproducible); non-finite contributions poison exactly the elements a float
+ *   accumulation would (csrc/fixed_accum.h, csrc/train.hip).  workspace: caller-owned, 16-byte aligned, casmvs_costvol_backward_workspace_bytes(B, V, C,
+ *   G, h, w) bytes (G = 0 for the variance volume); contents need not survive the call. */
 size_t casmvs_conv_wgrad_workspace_bytes(int kind, int B, int cin, int cout, int D, int H, int W);
 int casmvs_conv_wgrad_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
                           int cin, int cout, int D, int H, int W, void *stream);
@@ -569,12 +576,13 @@ int casmvs_abn_backward_apply_fused_f32(const float *grad_y, const float *y, con
                                         float *grad_weight, float *grad_bias, float *grad_x, int N, int C, size_t n, float slope, void *stream);
 int casmvs_upsample2x_add_f32(const float *lat, const float *up, float *out, int N, int C, int H, int W, void *stream);
 int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad_up, int N, int C, int H, int W, void *stream);
+size_t casmvs_costvol_backward_workspace_bytes(int B, int V, int C, int G, int h, int w);
 int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,
-                                    float *grad_feats, int B, int V, int C, int h, int w, int D, void *stream);
+                                    float *grad_feats, void *workspace, int B, int V, int C, int h, int w, int D, void *stream);
 /* The same for the group-wise correlation volume (mvsnet.py:142-144,157-162,169-172): grad_vol (B,G,D,h,w), G divides C.  One launch instead of a
  * channel-expanded gradient volume, one warp backward and one recomputed warped volume per source view. */
-int casmvs_costvol_gwc_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol, float *grad_feats, int B, int V,
-                                    int C, int G, int h, int w, int D, void *stream);
+int casmvs_costvol_gwc_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol, float *grad_feats, void *workspace,
+                                    int B, int V, int C, int G, int h, int w, int D, void *stream);
 
 /* ---- self test ------------------------------------------------------------------------------
  * Runs the MFMA lane-mapping probes the conv kernels rely on (v_mfma_f32_16x16x4_f32 operand /

@@ -250,3 +250,30 @@ def cascade_forward_train(sd, imgs, proj_mats, init_depth_min, depth_interval, n
         results[f"depth_{l}"] = depth_l
         results[f"confidence_{l}"] = confidence_l
     return results
+
+
+def sgd_train_steps(sd0, imgs, proj_mats, init_depth_min, depth_interval, targets, steps, lr=1e-3, momentum=0.9, weight_decay=1e-5,
+                    dtype=torch.float64, abs_weight_eps=None):
+    """train.py:99-127 + opt.py:40-47 / utils/__init__.py:12-14 in miniature: `steps` optimisation steps of torch.optim.SGD(lr, momentum, weight_decay) - the
+    reference's default optimiser - on ONE fixed batch, loss = sum_l SmoothL1(depth_l, targets[l]) * 2^(1 - l) (losses.py:4-19 without masks), in `dtype`
+    (float64: the truth a float32 engine's trajectory is compared with).  SGD as torch implements it: d = grad + weight_decay * p; v = d on the first
+    step, v = momentum * v + d afterwards; p -= lr * v.  abs_weight_eps: train.py:41 builds the model with InPlaceABN, whose scale is |weight| + eps
+    (SURVEY appendix B): the 1-d `.weight` tensors enter the forward as |w| + eps and the gradient reaches w through that expression.
+    -> list of the `steps` loss values (before each update)."""
+    params = {k: v.clone().to(dtype).requires_grad_(True) for k, v in sd0.items() if v.dtype.is_floating_point and "running" not in k}
+    bufs = {k: (v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in sd0.items() if k not in params}
+    velocity, losses = {}, []
+    for _ in range(steps):
+        sd = dict(bufs)
+        for k, p in params.items():
+            sd[k] = (p.abs() + abs_weight_eps) if (abs_weight_eps is not None and k.endswith(".weight") and p.dim() == 1) else p
+        out = cascade_forward_train(sd, imgs.to(dtype), proj_mats.to(dtype), init_depth_min, depth_interval)
+        loss = sum(F.smooth_l1_loss(out[f"depth_{l}"], targets[l].to(dtype)) * 2 ** (1 - l) for l in range(3))
+        grads = torch.autograd.grad(loss, list(params.values()))
+        with torch.no_grad():
+            for (k, p), g in zip(params.items(), grads):
+                d = g + weight_decay * p
+                velocity[k] = d.clone() if k not in velocity else velocity[k] * momentum + d
+                p -= lr * velocity[k]
+        losses.append(float(loss.detach()))
+    return losses

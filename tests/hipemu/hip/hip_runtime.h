@@ -70,7 +70,7 @@ struct float2 {
 // The workgroup's dynamic LDS: the kernels declare `extern __shared__ ... smem_raw[]` inside their anonymous namespace, so the translation unit that
 // includes them defines `namespace { alignas(64) unsigned char smem_raw[HIPEMU_LDS_BYTES]; }` and registers it with hipemu::g_lds.
 #define HIPEMU_LDS_BYTES (160 * 1024 + 64)
-namespace hipemu { inline unsigned char *g_lds = nullptr; }
+namespace hipemu { inline unsigned char *g_lds = nullptr; inline bool g_reverse_blocks = false; }
 
 // LDS bank profile (tests/hipemu/lds_profile.cpp; built with -DHIPEMU_LDS_PROFILE -fsanitize=thread but linked against that file instead of the sanitizer's
 // runtime): the compiler's memory-access hooks record every access that falls into the workgroup's LDS array, these calls tell the recorder who is running
@@ -135,9 +135,12 @@ void hipemu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
   g_gridDim = grid;
   g_blockDim = block;
   const int nthreads = (int)(block.x * block.y * block.z), nwaves = (nthreads + 63) / 64;
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
+  // g_reverse_blocks: the workgroups run in the opposite order - a result that depends on the order in which workgroups add (float atomics) changes
+  // its last bits, an order-independent one (integer atomics, fixed-order reductions) does not
+  for (unsigned bzi = 0; bzi < grid.z; ++bzi)
+    for (unsigned byi = 0; byi < grid.y; ++byi)
+      for (unsigned bxi = 0; bxi < grid.x; ++bxi) {
+        const unsigned bz = g_reverse_blocks ? grid.z - 1 - bzi : bzi, by = g_reverse_blocks ? grid.y - 1 - byi : byi, bx = g_reverse_blocks ? grid.x - 1 - bxi : bxi;
         Block blk;
         blk.bar = std::make_unique<std::barrier<>>(nthreads);
         blk.mfma_a.resize(nwaves);

@@ -192,17 +192,26 @@ static double abn_check(int N, int C, int n) {
   return err;
 }
 
-// casmvs_costvol_var_backward_f32 (costvol_var_bwd_kernel: the scatter transpose of the plane sweep through an LDS box image with ds_add_f32, the largest kernel of
-// the training step) against d var / d x_v = 2 x_v / V - 2 sum x / V^2 through the bilinear weights, taps from the shared float32 routine, sums in float64
-// mode 1: the source views' features are 1e4 x the reference view's (contributions outside the fixed-point range of the LDS image: the workgroup's second pass
-// scatters with float atomics); mode 2: reference features all zero (no scale: the float path from the start); mode 3: upstream gradients of 1e-30 (a denormal bound)
+// casmvs_costvol_var_backward_f32 (volume_absmax_kernel -> costvol_var_bwd_kernel: the scatter transpose of the plane sweep through a 64-bit fixed-point LDS
+// box image into a 64-bit fixed-point gradient map -> costvol_fixed_finish_kernel; the largest kernel of the training step) against
+// d var / d x_v = 2 x_v / V - 2 sum x / V^2 through the bilinear weights, taps from the shared float32 routine, sums in float64 - and a SECOND run with the
+// workgroups in the opposite order, which must give the same bits (integer sums: train.py:99-127 reproducible run to run)
+// mode 1: the source views' features are 1e4 x the reference view's; mode 2: reference features all zero; mode 3: upstream gradients of 1e-30;
+// mode 4: upstream gradients of 1e30 with features of 1e-3; mode 5: one feature of 3e5 (its channel's scale is 1e5 x the others'); mode 6: a NaN upstream
+// gradient and an infinite feature - exactly the elements the float64 sums make non-finite must be non-finite, every other one at the bound
 // G > 0: the group-wise correlation volume's backward (casmvs_costvol_gwc_backward_f32), gvol (B, G, D, h, w)
 static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 0, int G = 0) {
   const size_t hw = (size_t)h * w;
   const int GC = G > 0 ? G : C, cpg = G > 0 ? C / G : 1;
   std::vector<float> feats((size_t)B * V * C * hw), proj((size_t)B * (V - 1) * 12, 0.0f), depth((size_t)B * D * hw), gvol((size_t)B * GC * D * hw);
   for (auto &v : feats) v = rnd();
-  for (auto &v : gvol) v = rnd() * (mode == 3 ? 1e-30f : 1.0f);
+  for (auto &v : gvol) v = rnd() * (mode == 3 ? 1e-30f : mode == 4 ? 1e30f : 1.0f);
+  if (mode == 4) for (auto &v : feats) v *= 1e-3f;
+  if (mode == 5) feats[((size_t)1 * C + 3) * hw + 2 * w + 7] = 3e5f;
+  if (mode == 6) {
+    gvol[((size_t)(GC > 2 ? 2 : 0) * D + 1) * hw + 3 * w + 9] = NAN;
+    feats[((size_t)1 * C + 1) * hw + 4 * w + 20] = INFINITY;
+  }
   if (mode == 1 || mode == 2)
     for (int b = 0; b < B; ++b)
       for (size_t i = 0; i < (size_t)C * hw; ++i) {
@@ -228,9 +237,20 @@ static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 
   };
   float *fa = dup(feats), *pa = dup(proj), *da = dup(depth), *ga = dup(gvol);
   std::vector<float> nanv(feats.size(), NAN);
-  float *out = dup(nanv);
-  if (G > 0 ? casmvs_costvol_gwc_backward_f32(fa, pa, da, ga, out, B, V, C, G, h, w, D, nullptr)
-            : casmvs_costvol_var_backward_f32(fa, pa, da, ga, out, B, V, C, h, w, D, nullptr)) { printf("var_backward: %s\n", casmvs_last_error()); return 1e9; }
+  float *out = dup(nanv), *out2 = dup(nanv);
+  const size_t wsb = casmvs_costvol_backward_workspace_bytes(B, V, C, G, h, w);
+  void *ws = std::aligned_alloc(256, (wsb + 255) & ~(size_t)255);
+  std::memset(ws, 0xCD, wsb);   // the call owns the zeroing
+  auto run = [&](float *o) {
+    return G > 0 ? casmvs_costvol_gwc_backward_f32(fa, pa, da, ga, o, ws, B, V, C, G, h, w, D, nullptr)
+                 : casmvs_costvol_var_backward_f32(fa, pa, da, ga, o, ws, B, V, C, h, w, D, nullptr);
+  };
+  if (run(out)) { printf("var_backward: %s\n", casmvs_last_error()); return 1e9; }
+  hipemu::g_reverse_blocks = true;
+  const int rc2 = run(out2);
+  hipemu::g_reverse_blocks = false;
+  if (rc2) { printf("var_backward (second run): %s\n", casmvs_last_error()); return 1e9; }
+  const bool same = std::memcmp(out, out2, feats.size() * 4) == 0;
   std::vector<double> want(feats.size(), 0.0);
   for (int b = 0; b < B; ++b)
     for (int d = 0; d < D; ++d)
@@ -268,13 +288,20 @@ static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 
           }
         }
   double err = 0, range = 0;
+  size_t poisoned = 0;
   for (size_t i = 0; i < want.size(); ++i) {
+    if (!std::isfinite(want[i])) {   // (mode 6) a non-finite sum: the kernel's element must be non-finite too
+      ++poisoned;
+      if (std::isfinite(out[i])) err = 1e30;
+      continue;
+    }
     range = std::fmax(range, std::fabs(want[i]));
     err = std::fmax(err, std::isfinite(out[i]) ? std::fabs(want[i] - out[i]) : 1e30);
   }
-  std::free(fa); std::free(pa); std::free(da); std::free(ga); std::free(out);
-  printf("%s B=%d V=%d C=%d %dx%dx%d mode %d: max error / largest gradient = %.2e\n", G > 0 ? "gwc_backward" : "var_backward", B, V, C, D, h, w, mode, err / range);
-  return err / range;
+  std::free(fa); std::free(pa); std::free(da); std::free(ga); std::free(out); std::free(out2); std::free(ws);
+  printf("%s B=%d V=%d C=%d %dx%dx%d mode %d: max error / largest gradient = %.2e (%zu non-finite elements), workgroups in reverse order: %s\n",
+         G > 0 ? "gwc_backward" : "var_backward", B, V, C, D, h, w, mode, err / range, poisoned, same ? "bit-identical" : "DIFFERENT");
+  return same ? err / range : 1e9;
 }
 
 int main(int argc, char **argv) {
@@ -291,7 +318,8 @@ int main(int argc, char **argv) {
     take(abn_check(2, 5, 1003));                                          // scalar path, one chunk
     take(abn_check(1, 3, 4608));                                          // 16-byte path, three chunks (the last one short)
     take(varbwd_check(1, 3, 8, 8, 6, 36));                                // two 32 x 32 tiles (ragged), one chunk of 8 planes, two source views
-    take(varbwd_check(1, 3, 4, 8, 6, 36, 1));                             // the second (float-atomic) pass of a workgroup
+    take(varbwd_check(1, 3, 4, 8, 6, 36, 1));                             // source views 1e4 x the reference view
+    take(varbwd_check(1, 3, 8, 8, 6, 36, 6));                             // non-finite contributions: the float map takes them, the finish adds the integer sums
     take(varbwd_check(1, 3, 8, 8, 6, 36, 0, 4));                          // group-wise correlation: two channels per group
   }
   if (all) {
@@ -309,6 +337,9 @@ int main(int argc, char **argv) {
     take(varbwd_check(2, 2, 16, 16, 34, 40));                             // four channel groups, two plane chunks, four tiles
     take(varbwd_check(1, 3, 8, 8, 6, 36, 2));
     take(varbwd_check(1, 2, 4, 5, 6, 36, 3));
+    take(varbwd_check(1, 3, 8, 8, 6, 36, 4));
+    take(varbwd_check(1, 3, 8, 8, 12, 36, 5));
+    take(varbwd_check(1, 3, 8, 8, 6, 36, 6, 4));
     take(varbwd_check(2, 4, 16, 9, 20, 40, 0, 16));                       // one channel per group, three source views (run-time view loop)
     take(varbwd_check(1, 3, 8, 8, 12, 36, 0, 1));                         // one group
   }

@@ -242,6 +242,7 @@ def test_files_to_point_cloud(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.order_tier(2)   # asserts a trend (the loss after four steps is below the first): behind every parity test (tests/conftest.py)
 def test_training_loop_on_files(tmp_path):
     """train.py's loop on a DTU-format tree (training layout): DTUReader -> collate -> prefetcher -> train-mode forward ->
     SL1 loss on the ground-truth depth / mask pyramids -> backward -> SGD; the loss falls."""

@@ -65,6 +65,7 @@ def test_fusion_paired_tap_kernel_equals_the_one_tap_per_load_kernel(dev):
                 assert torch.equal(a, b), (k, H, W, S)
 
 
+@pytest.mark.order_tier(1)   # a subprocess: system tier (tests/conftest.py)
 def test_torch_free_step_runner_runs_the_forward(dev):
     """tools/notorch/step_runner.py: the forward's library calls in mvsnet.py's order from a process without torch; depths finite and
     inside the hypothesis range, every stage timed."""
