@@ -101,7 +101,7 @@ SYMBOLS = {
     "casmvs_depth_regression_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_fuse_reference_view": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "casmvs_fuse_reference_view_paired": (c_int, [_FP] * 16 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
-    "casmvs_homo_warp_backward_workspace_bytes": (c_size_t, [c_int] * 4),
+    "casmvs_homo_warp_backward_workspace_bytes": (c_size_t, [c_int] * 5),
     "casmvs_homo_warp_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_softmax_regress_backward_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 7),
@@ -123,7 +123,7 @@ SYMBOLS = {
     "casmvs_abn_backward_apply_fused_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_double, _FP, c_float] + [_FP] * 6 + [c_int, c_int, c_size_t, c_float, c_void_p]),
     "casmvs_upsample2x_add_f32": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_upsample2x_backward_f32": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
-    "casmvs_costvol_backward_workspace_bytes": (c_size_t, [c_int] * 6),
+    "casmvs_costvol_backward_workspace_bytes": (c_size_t, [c_int] * 7),
     "casmvs_costvol_var_backward_f32": (c_int, [_FP] * 5 + [c_void_p] + [c_int] * 6 + [c_void_p]),
     "casmvs_costvol_gwc_backward_f32": (c_int, [_FP] * 5 + [c_void_p] + [c_int] * 7 + [c_void_p]),
     "casmvs_normalize_images_u8": (c_int, [_FP, _FP, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),

@@ -44,7 +44,7 @@ class _HomoWarp(torch.autograd.Function):
         proj_mat, depth_values = proj_mat.contiguous().float(), depth_values.contiguous().float()
         grad_src = torch.empty((B, C, H, W), dtype=torch.float32, device=grad_out.device)
         # caller-owned scratch: the 64-bit fixed-point map of the order-independent scatter (same bits run to run) + the channels' largest magnitudes
-        ws = torch.empty(_lib.load().casmvs_homo_warp_backward_workspace_bytes(B, C, H, W) // 8 + 1, dtype=torch.int64, device=grad_out.device)
+        ws = torch.empty(_lib.load().casmvs_homo_warp_backward_workspace_bytes(B, C, D, H, W) // 8 + 1, dtype=torch.int64, device=grad_out.device)
         with torch.cuda.device(grad_out.device):
             rc = _lib.load().casmvs_homo_warp_backward_f32(_ptr(grad_out), _ptr(proj_mat), _ptr(depth_values), _ptr(grad_src), _ptr(ws),
                                                            B, C, H, W, D, _stream(grad_out))

@@ -93,9 +93,11 @@ __global__ __launch_bounds__(kThreads) void softmax_regress_bwd_kernel(const flo
 
 }  // namespace
 
-extern "C" size_t casmvs_homo_warp_backward_workspace_bytes(int B, int C, int H, int W) {
-  if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
-  return (size_t)B * C * H * W * sizeof(unsigned long long) + (((size_t)B * C * sizeof(unsigned) + 15) & ~(size_t)15);
+// workspace: [acc: B C H W 64-bit fixed-point sums][gmax: B C uint32][partial maxima of volume_absmax_kernel]
+extern "C" size_t casmvs_homo_warp_backward_workspace_bytes(int B, int C, int D, int H, int W) {
+  if (B < 1 || C < 1 || D < 1 || H < 1 || W < 1) return 0;
+  auto pad = [](size_t n) { return (n + 15) & ~(size_t)15; };
+  return (size_t)B * C * H * W * sizeof(unsigned long long) + pad((size_t)B * C * sizeof(unsigned)) + pad((size_t)B * C * absmax_chunks((size_t)D * H * W) * sizeof(unsigned));
 }
 
 extern "C" int casmvs_homo_warp_backward_f32(const float *grad_out, const float *proj, const float *depth, float *grad_src, void *workspace,
@@ -109,15 +111,12 @@ extern "C" int casmvs_homo_warp_backward_f32(const float *grad_out, const float 
   const int hw = H * W, U = casmvs::fixed_point_bits(D, H, W);
   const size_t acc_bytes = (size_t)B * C * hw * sizeof(unsigned long long);
   hipError_t e = hipMemsetAsync(grad_src, 0, (size_t)B * C * hw * sizeof(float), st);
-  if (e == hipSuccess) e = hipMemsetAsync(workspace, 0, casmvs_homo_warp_backward_workspace_bytes(B, C, H, W), st);
+  if (e == hipSuccess) e = hipMemsetAsync(workspace, 0, acc_bytes, st);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "homo_warp_backward: hipMemsetAsync: %s", hipGetErrorString(e));
   unsigned long long *acc = static_cast<unsigned long long *>(workspace);
   unsigned *gmax = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + acc_bytes);
-  const size_t n_g = (size_t)D * hw, per_wg = (size_t)kThreads * 32, chunks_g = (n_g + per_wg - 1) / per_wg;
-  CASMVS_REQUIRE((size_t)B * C * chunks_g <= 0x7fffffffull, "homo_warp_backward: volume too large");
-  hipLaunchKernelGGL(volume_absmax_kernel, dim3((unsigned)((size_t)B * C * chunks_g)), dim3(kThreads), 0, st, grad_out, (const float *)nullptr, gmax,
-                     (unsigned *)nullptr, B * C, n_g, (int)chunks_g, 1, C, (size_t)0, 0);
-  if (int rc = casmvs::check_launch("volume_absmax_kernel")) return rc;
+  unsigned *partial = gmax + ((((size_t)B * C * sizeof(unsigned) + 15) & ~(size_t)15) / sizeof(unsigned));
+  if (int rc = launch_volume_absmax(grad_out, nullptr, partial, gmax, nullptr, B * C, (size_t)D * hw, B, 0, C, 0, st)) return rc;
   dim3 grid((unsigned)casmvs::ceil_div(hw, kThreads), (unsigned)D, (unsigned)B);
   hipLaunchKernelGGL(homo_warp_bwd_kernel, grid, dim3(kThreads), 0, st, grad_out, proj, depth, grad_src, acc, gmax, C, H, W, D, U);
   if (int rc = casmvs::check_launch("homo_warp_bwd_kernel")) return rc;

@@ -703,7 +703,7 @@ __global__ __launch_bounds__(kThreads) void upsample2x_bwd_kernel(const float *_
 // lanes, waves or workgroups add.  (Round 4 kept the LDS image in fixed point with a scale per workgroup and flushed it with float atomics: 18 runs of the same
 // 12 SGD steps gave 18 loss trajectories.)  One scale per (sample, channel), known before the kernel starts:
 //   volume_absmax_kernel   G[b][c] = largest finite |upstream gradient| of the channel's (group's) volume, F[b][c] = largest finite |feature| over all views
-//                          (integer atomicMax on the bit patterns: order-independent as well)
+//                          (a tree of maxima over the bit patterns, no atomics: fixed_accum.h)
 //   bound[b][c] = 16 G F / V (variance: a contribution is g (2 x_v / V - 2 S / V^2) w with |x_v| <= F, |S| <= V F, w <= 1: at most 4 G F / V, two of them
 //                          merged by the lane exchange below: 8 G F / V) or 4 k G F (correlation: g k ref w <= k G F), a STRICT bound with 2x slack for the
 //                          float32 roundings: 2^be >= bound, unit 2^(be - U)
@@ -770,14 +770,19 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   const float kg = GWC ? 1.0f / ((float)cpg * (float)(V - 1)) : 0.0f;
   size_t goff[CG];   // the upstream gradient's plane 0 of the channel (variance) / of the channel's group (correlation)
   double to_fixed[CG];   // 2^(U - be) of the channel, 0 without a scale (then every finite contribution is 0)
+  bool checked = false;
 #pragma unroll
   for (int c = 0; c < CG; ++c) {
     goff[c] = GWC ? ((size_t)b * G + (c0 + c) / cpg) * D * hw : ((size_t)b * C + c0 + c) * D * hw;
     int be;
-    const bool ok = fixed_exponent(gmax[GWC ? b * G + (c0 + c) / cpg : b * C + c0 + c], fmax[b * C + c0 + c],
-                                   GWC ? 4.0 / ((double)cpg * (double)(V - 1)) : 16.0 / (double)V, be);
+    const unsigned gw = gmax[GWC ? b * G + (c0 + c) / cpg : b * C + c0 + c], fw = fmax[b * C + c0 + c];
+    const bool ok = fixed_exponent(gw, fw, GWC ? 4.0 / ((double)cpg * (double)(V - 1)) : 16.0 / (double)V, be);
     to_fixed[c] = ok ? pow2_double(U - be) : 0.0;
+    checked = checked || needs_finite_check(gw, fw, be);
   }
+  // workgroup-uniform (scalar loads): a non-finite value somewhere in these channels' operands - never in a healthy run - selects the loop that checks
+  // every contribution; the other loop carries no trace of the check (a per-step test inside ONE loop cost 14 % of the kernel: profiles/r05_varbwd_ab.txt)
+  checked = __builtin_amdgcn_readfirstlane((unsigned)checked) != 0u;
   auto fx = [](float val, double scale) { return to_fixed_point(val, scale); };
 
   // ---- 1. bounding boxes of this view's live taps: the tile's, and (published only when the tile's does not fit the LDS
@@ -844,6 +849,8 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
   // ---- 2. per (pixel, plane): S over the views, own view's gradient into the box
   // every lane runs the loops (the lanes exchange tap gradients with their neighbours by DPP below); a lane outside the
   // image works on a clamped pixel with a zero upstream gradient and never adds anything
+  auto scatter = [&](auto checked_c) {
+  constexpr bool CHECKED = decltype(checked_c)::value;
   for (int j = whole ? 0 : seg; j < (whole ? RPT : seg + 1); ++j) {
     const int yr = yb + j * RSTEP;
     const bool valid = x < W && yr < H;
@@ -932,33 +939,25 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
       const bool ab_n = lane < 63 && nyn == tv.yn && nxl == tv.xl + 1, ab_s = lane < 63 && nys == tv.ys && nxl == tv.xl + 1;
       const int lo_n = (tv.yn - by0) * bw + (tv.xl - bx0), lo_s = (tv.ys - by0) * bw + (tv.xl - bx0);
       const int go_n = tv.yn * W + tv.xl, go_s = tv.ys * W + tv.xl;
-      float gxs[CG];
-      bool bad = false;
 #pragma unroll
       for (int c = 0; c < CG; ++c) {
         const float g = gd[c];
+        float gx;
         if (GWC) {
           gref[c] += g * kg * S[c];
-          gxs[c] = g * kg * ref[c];
+          gx = g * kg * ref[c];
         } else {
           const float common = 2.0f * S[c] / (fV * fV);
           gref[c] += g * (2.0f * ref[c] / fV - common);
-          gxs[c] = g * (2.0f * xv[c] / fV - common);
+          gx = g * (2.0f * xv[c] / fV - common);
         }
-        bad = bad || !is_finite(gxs[c]);
-      }
-      // wave-uniform: a non-finite contribution somewhere in the wave (rare) sends every value of this step through the per-value check
-      const bool slow = __builtin_amdgcn_ballot_w64(live && bad) != 0;
-#pragma unroll
-      for (int c = 0; c < CG; ++c) {
-        const float gx = gxs[c];
         const float rn = gx * tv.w_nr, rs = gx * tv.w_sr;
         const float prn = lane_prev(rn), prs = lane_prev(rs);
         const float an = gx * tv.w_nl + (mp_n ? prn : 0.0f), as = gx * tv.w_sl + (mp_s ? prs : 0.0f);
         if (live) {
           unsigned long long *q = in_lds ? box + c * cells : asv + (size_t)c * hw;
           const int o_n = in_lds ? lo_n : go_n, o_s = in_lds ? lo_s : go_s;
-          if (!slow) {
+          if constexpr (!CHECKED) {
             atomicAdd(q + o_n, fx(an, to_fixed[c]));
             if (!ab_n) atomicAdd(q + o_n + 1, fx(rn, to_fixed[c]));
             atomicAdd(q + o_s, fx(as, to_fixed[c]));
@@ -980,11 +979,14 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
     if (v == 1 && valid) {   // view 0 (the reference features): one add per plane chunk
 #pragma unroll
       for (int c = 0; c < CG; ++c) {
-        if (is_finite(gref[c])) atomicAdd(ab + (size_t)(c0 + c) * hw + p, fx(gref[c], to_fixed[c]));
+        if (!CHECKED || is_finite(gref[c])) atomicAdd(ab + (size_t)(c0 + c) * hw + p, fx(gref[c], to_fixed[c]));
         else unsafeAtomicAdd(gb + (size_t)(c0 + c) * hw + p, gref[c]);
       }
     }
   }
+  };
+  if (checked) scatter(std::true_type{});
+  else scatter(std::false_type{});
   __syncthreads();
 
   // ---- 3. box -> gradient map (lanes = consecutive columns of a box row of one channel plane)
@@ -1275,16 +1277,18 @@ extern "C" int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad
 }
 
 namespace {
-// workspace of the volume backward: [acc: B V C h w 64-bit fixed-point sums][gmax: B (G | C) uint32][fmax: B C uint32]
+// workspace of the volume backward: [acc: B V C h w 64-bit fixed-point sums][gmax: B (G | C) uint32][fmax: B C uint32][partial maxima of volume_absmax_kernel]
 struct VolBwdWs {
-  size_t acc_bytes, gmax_off, fmax_off, total;
+  size_t acc_bytes, gmax_off, fmax_off, partial_off, total;
 };
-VolBwdWs volume_backward_ws(int B, int V, int C, int G, int h, int w) {
+VolBwdWs volume_backward_ws(int B, int V, int C, int G, int D, int h, int w) {
   VolBwdWs l;
+  auto pad = [](size_t n) { return (n + 15) & ~(size_t)15; };
   l.acc_bytes = (size_t)B * V * C * h * w * sizeof(unsigned long long);
   l.gmax_off = l.acc_bytes;
-  l.fmax_off = l.gmax_off + (((size_t)B * (G > 0 ? G : C) * sizeof(unsigned) + 15) & ~(size_t)15);
-  l.total = l.fmax_off + (((size_t)B * C * sizeof(unsigned) + 15) & ~(size_t)15);
+  l.fmax_off = l.gmax_off + pad((size_t)B * (G > 0 ? G : C) * sizeof(unsigned));
+  l.partial_off = l.fmax_off + pad((size_t)B * C * sizeof(unsigned));
+  l.total = l.partial_off + pad(((size_t)B * (G > 0 ? G : C) * absmax_chunks((size_t)D * h * w) + (size_t)B * V * C * absmax_chunks((size_t)h * w)) * sizeof(unsigned));
   return l;
 }
 // the variance volume's (G = 0) or the correlation volume's (G > 0) gradient w.r.t. the feature maps: zeroing, the channels' largest magnitudes, the
@@ -1298,24 +1302,16 @@ int volume_backward(const float *feats, const float *proj, const float *depth, c
   CASMVS_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "%s: workspace must be 16-byte aligned", what);
   CASMVS_REQUIRE((size_t)B * V * C <= 65535, "%s: B V C = %zu rows", what, (size_t)B * V * C);
   hipStream_t st = (hipStream_t)stream;
-  const VolBwdWs ws = volume_backward_ws(B, V, C, G, h, w);
+  const VolBwdWs ws = volume_backward_ws(B, V, C, G, D, h, w);
   hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)B * V * C * h * w * sizeof(float), st);
-  if (e == hipSuccess) e = hipMemsetAsync(workspace, 0, ws.total, st);
+  if (e == hipSuccess) e = hipMemsetAsync(workspace, 0, ws.acc_bytes, st);
   if (e != hipSuccess) return casmvs::fail(CASMVS_ERR_HIP, "%s: hipMemsetAsync: %s", what, hipGetErrorString(e));
   unsigned long long *acc = static_cast<unsigned long long *>(workspace);
   unsigned *gmax = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + ws.gmax_off);
   unsigned *fmax = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + ws.fmax_off);
   const int hw = h * w, U = casmvs::fixed_point_bits(D, h, w);
-  {
-    const int rows_g = B * (G > 0 ? G : C), rows_f = B * V * C;
-    const size_t n_g = (size_t)D * hw, n_f = (size_t)hw, per_wg = (size_t)kThreads * 32;
-    const size_t chunks_g = (n_g + per_wg - 1) / per_wg, chunks_f = (n_f + per_wg - 1) / per_wg;
-    const size_t wgs = rows_g * chunks_g + rows_f * chunks_f;
-    CASMVS_REQUIRE(wgs <= 0x7fffffffull, "%s: volume too large", what);
-    hipLaunchKernelGGL(volume_absmax_kernel, dim3((unsigned)wgs), dim3(kThreads), 0, st, grad_vol, feats, gmax, fmax, rows_g, n_g, (int)chunks_g, V, C, n_f,
-                       (int)chunks_f);
-    if (int rc = casmvs::check_launch("volume_absmax_kernel")) return rc;
-  }
+  unsigned *partial = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + ws.partial_off);
+  if (int rc = launch_volume_absmax(grad_vol, feats, partial, gmax, fmax, B * (G > 0 ? G : C), (size_t)D * hw, B, V, C, (size_t)hw, st)) return rc;
   // 8 planes per workgroup; the LDS image holds 1152 box pixels (a 32 x 16 tile whose taps spread over ~44 x 26) of 4 channels
   // in 64-bit fixed point = 36 KiB: four workgroups per CU (the kernel waits on its gathers: 0.92 -> 0.43 ms at level 1 from two to four)
   constexpr int dch = 8, cap = 1152, th = 16, CG = 4;
@@ -1336,9 +1332,9 @@ int volume_backward(const float *feats, const float *proj, const float *depth, c
 }
 }  // namespace
 
-extern "C" size_t casmvs_costvol_backward_workspace_bytes(int B, int V, int C, int G, int h, int w) {
-  if (B < 1 || V < 2 || C < 1 || G < 0 || h < 1 || w < 1) return 0;
-  return volume_backward_ws(B, V, C, G, h, w).total;
+extern "C" size_t casmvs_costvol_backward_workspace_bytes(int B, int V, int C, int G, int D, int h, int w) {
+  if (B < 1 || V < 2 || C < 1 || G < 0 || D < 1 || h < 1 || w < 1) return 0;
+  return volume_backward_ws(B, V, C, G, D, h, w).total;
 }
 
 extern "C" int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,

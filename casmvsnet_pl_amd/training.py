@@ -436,11 +436,11 @@ def upsample_add(lat, up):
     return _UpsampleAdd.apply(lat, up)
 
 
-def _volume_backward_workspace(feats, G):
+def _volume_backward_workspace(feats, G, D):
     """Caller-owned scratch of casmvs_costvol_{var,gwc}_backward_f32 (the 64-bit fixed-point gradient map + the channels' largest magnitudes: the backward
     is order-independent, so a training step gives the same bits run to run); from torch's caching allocator, i.e. stream-ordered and capture-safe."""
     B, V, C, h, w = feats.shape
-    n = _lib.load().casmvs_costvol_backward_workspace_bytes(B, V, C, int(G), h, w)
+    n = _lib.load().casmvs_costvol_backward_workspace_bytes(B, V, C, int(G), int(D), h, w)
     return torch.empty(n // 8 + 1, dtype=torch.int64, device=feats.device)
 
 
@@ -463,7 +463,7 @@ class _VarianceVolume(torch.autograd.Function):
         D = depth_values.shape[1]
         gvol = gvol.contiguous().float()
         gfeats = torch.empty_like(feats)
-        ws = _volume_backward_workspace(feats, 0)
+        ws = _volume_backward_workspace(feats, 0, D)
         with torch.cuda.device(feats.device):
             rc = _lib.load().casmvs_costvol_var_backward_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(gvol), _ptr(gfeats), _ptr(ws),
                                                              B, V, C, h, w, D, _stream(feats))
@@ -503,7 +503,7 @@ class _GroupwiseVolume(torch.autograd.Function):
         G, D = ctx.G, depth_values.shape[1]
         gvol = gvol.contiguous().float()
         gfeats = torch.empty_like(feats)
-        ws = _volume_backward_workspace(feats, G)
+        ws = _volume_backward_workspace(feats, G, D)
         with torch.cuda.device(feats.device):
             rc = _lib.load().casmvs_costvol_gwc_backward_f32(_ptr(feats), _ptr(proj_mats), _ptr(depth_values), _ptr(gvol), _ptr(gfeats), _ptr(ws),
                                                              B, V, C, G, h, w, D, _stream(feats))

@@ -478,10 +478,10 @@ int casmvs_fuse_reference_view_paired(const float *depth_ref, const unsigned cha
  *   the DETACHED depth hypotheses only, mvsnet.py:231): grad_src (B,C,H,W) = scatter-add of grad_out (B,C,D,H,W) with the
  *   forward's bilinear weights.  grad_src is zeroed by the call.  The sums are 64-bit fixed point with one scale per (sample, channel)
  *   (csrc/fixed_accum.h): the result is bit-identical run to run (ABI 4; ABI 3 used float atomics).  workspace: caller-owned, 16-byte aligned,
- *   casmvs_homo_warp_backward_workspace_bytes(B, C, H, W) bytes (the fixed-point map + the channels' largest magnitudes); contents need not survive the call.
+ *   casmvs_homo_warp_backward_workspace_bytes(B, C, D, H, W) bytes (the fixed-point map + the channels' largest magnitudes); contents need not survive the call.
  * casmvs_softmax_regress_backward_f32: depth = sum_k softmax(cost)_k d_k (mvsnet.py:175-177): grad_cost (B,D,h,w) =
  *   grad_depth (B,h,w) * p_k (d_k - depth).  (The confidence is computed under no_grad in the reference.) */
-size_t casmvs_homo_warp_backward_workspace_bytes(int B, int C, int H, int W);
+size_t casmvs_homo_warp_backward_workspace_bytes(int B, int C, int D, int H, int W);
 int casmvs_homo_warp_backward_f32(const float *grad_out, const float *proj, const float *depth, float *grad_src, void *workspace,
                                   int B, int C, int H, int W, int D, void *stream);
 int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_values, const float *grad_depth,
@@ -524,7 +524,7 @@ int casmvs_softmax_regress_backward_f32(const float *cost, const float *depth_va
  *   channel's largest finite |grad_vol| and |feats| (a strict bound of every contribution: no range check, no fallback); a last pass rounds the sums to
  *   float32 once.  The result is bit-identical run to run (train.py:99-127 is reproducible); non-finite contributions poison exactly the elements a float
  *   accumulation would (csrc/fixed_accum.h, csrc/train.hip).  workspace: caller-owned, 16-byte aligned, casmvs_costvol_backward_workspace_bytes(B, V, C,
- *   G, h, w) bytes (G = 0 for the variance volume); contents need not survive the call. */
+ *   G, D, h, w) bytes (G = 0 for the variance volume); contents need not survive the call. */
 size_t casmvs_conv_wgrad_workspace_bytes(int kind, int B, int cin, int cout, int D, int H, int W);
 int casmvs_conv_wgrad_f32(int kind, const float *in, const float *grad_out, float *grad_weight, void *workspace, int B,
                           int cin, int cout, int D, int H, int W, void *stream);
@@ -576,7 +576,7 @@ int casmvs_abn_backward_apply_fused_f32(const float *grad_y, const float *y, con
                                         float *grad_weight, float *grad_bias, float *grad_x, int N, int C, size_t n, float slope, void *stream);
 int casmvs_upsample2x_add_f32(const float *lat, const float *up, float *out, int N, int C, int H, int W, void *stream);
 int casmvs_upsample2x_backward_f32(const float *grad_out, float *grad_up, int N, int C, int H, int W, void *stream);
-size_t casmvs_costvol_backward_workspace_bytes(int B, int V, int C, int G, int h, int w);
+size_t casmvs_costvol_backward_workspace_bytes(int B, int V, int C, int G, int D, int h, int w);
 int casmvs_costvol_var_backward_f32(const float *feats, const float *proj, const float *depth, const float *grad_vol,
                                     float *grad_feats, void *workspace, int B, int V, int C, int h, int w, int D, void *stream);
 /* The same for the group-wise correlation volume (mvsnet.py:142-144,157-162,169-172): grad_vol (B,G,D,h,w), G divides C.  One launch instead of a

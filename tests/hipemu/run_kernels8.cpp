@@ -238,7 +238,7 @@ static double varbwd_check(int B, int V, int C, int D, int h, int w, int mode = 
   float *fa = dup(feats), *pa = dup(proj), *da = dup(depth), *ga = dup(gvol);
   std::vector<float> nanv(feats.size(), NAN);
   float *out = dup(nanv), *out2 = dup(nanv);
-  const size_t wsb = casmvs_costvol_backward_workspace_bytes(B, V, C, G, h, w);
+  const size_t wsb = casmvs_costvol_backward_workspace_bytes(B, V, C, G, D, h, w);
   void *ws = std::aligned_alloc(256, (wsb + 255) & ~(size_t)255);
   std::memset(ws, 0xCD, wsb);   // the call owns the zeroing
   auto run = [&](float *o) {

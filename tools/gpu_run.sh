@@ -15,6 +15,7 @@
 #   pmc          FETCH_SIZE / WRITE_SIZE passes + kernel stats over the step runner (layout of tools/summarize_profile.py)
 #   prof         rocprofv3 --kernel-trace --stats over bench.py --steps 10 --no-cpu-baseline
 #   costvol      tools/gpu_costvol_probe.py at batch 1 and 8 with dirtied caches (all BASELINE configs)
+#   trainprof    rocprofv3 --kernel-trace --stats over bench.py --mode train --steps 10 (per-kernel times of the training step)
 #   cmd          runs "$GPU_RUN_CMD" (one-off experiments without a new script)
 TAG=${1:-run}; shift
 ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -107,12 +108,18 @@ stage_costvol () {
   for b in 1 8; do CV_PROBE_DIRTY=512 timeout 300 python tools/gpu_costvol_probe.py $b > $OUT/costvol_probe_b$b.txt 2>&1; tail -30 $OUT/costvol_probe_b$b.txt; done
 }
 
+stage_trainprof () {
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o stats -- python $ROOTDIR/bench.py --mode train --steps 10 --warmup 3 $TRAIN_ARGS > $OUT/bench_train_prof.json 2> $OUT/bench_train_prof.err )
+  find $OUT/prof_train -name "*.db" -delete 2>/dev/null; find $OUT/prof_train -type f -size +4M -delete 2>/dev/null
+  f=$(find $OUT/prof_train -name "*kernel_stats.csv" | head -1); head -${PROF_TOP:-30} $f | cut -c1-220
+}
+
 stage_cmd () { bash -c "$GPU_RUN_CMD" > $OUT/cmd.txt 2>&1; echo "cmd exit: $?" >> $OUT/cmd.txt; tail -${CMD_TAIL:-60} $OUT/cmd.txt; }
 
 for s in "$@"; do
   echo "===== stage $s ($(date -u +%H:%M:%S))"
   case $s in
-    native|step|probes|bench|configs|suite|smoke|train|files|pmc|prof|costvol|cmd) stage_$s ;;
+    native|step|probes|bench|configs|suite|smoke|train|trainprof|files|pmc|prof|costvol|cmd) stage_$s ;;
     *) echo "unknown stage $s" ;;
   esac
 done
