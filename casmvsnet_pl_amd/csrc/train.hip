@@ -745,7 +745,7 @@ __global__ __launch_bounds__(kThreads) void costvol_fixed_finish_kernel(const un
 // gvol (B, G, D, h, w); d / d warped_v[c] = gvol[group of c] ref[c] k and d / d ref[c] = gvol[group of c] k sum_v warped_v[c], k = 1 / ((C / G) (V - 1)):
 // the same scatter with another contribution - only the workgroups of the first source view gather (they own the reference view's gradient).
 template <int CG, int TH, int VS, bool GWC>
-__global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *__restrict__ feats, const float *__restrict__ proj,
+__global__ __launch_bounds__(kThreads, 4) void costvol_var_bwd_kernel(const float *__restrict__ feats, const float *__restrict__ proj,
                                                                   const float *__restrict__ depth, const float *__restrict__ gvol,
                                                                   float *__restrict__ gfeats, unsigned long long *__restrict__ acc,
                                                                   const unsigned *__restrict__ gmax, const unsigned *__restrict__ fmax, int V, int C, int H, int W,
@@ -955,23 +955,24 @@ __global__ __launch_bounds__(kThreads) void costvol_var_bwd_kernel(const float *
         const float prn = lane_prev(rn), prs = lane_prev(rs);
         const float an = gx * tv.w_nl + (mp_n ? prn : 0.0f), as = gx * tv.w_sl + (mp_s ? prs : 0.0f);
         if (live) {
-          unsigned long long *q = in_lds ? box + c * cells : asv + (size_t)c * hw;
-          const int o_n = in_lds ? lo_n : go_n, o_s = in_lds ? lo_s : go_s;
-          if constexpr (!CHECKED) {
-            atomicAdd(q + o_n, fx(an, to_fixed[c]));
-            if (!ab_n) atomicAdd(q + o_n + 1, fx(rn, to_fixed[c]));
-            atomicAdd(q + o_s, fx(as, to_fixed[c]));
-            if (!ab_s) atomicAdd(q + o_s + 1, fx(rs, to_fixed[c]));
+          // (separate LDS / global code: ONE pointer that may be either compiles to flat atomics - no ds_add_u64 at all, 132 VGPRs)
+          float *qf = gsv + (size_t)c * hw;
+          auto add = [&](unsigned long long *q, int o, int go, float val) {
+            if (!CHECKED || is_finite(val)) atomicAdd(q + o, fx(val, to_fixed[c]));
+            else unsafeAtomicAdd(qf + go, val);
+          };
+          if (in_lds) {
+            unsigned long long *q = box + c * cells;
+            add(q, lo_n, go_n, an);
+            if (!ab_n) add(q, lo_n + 1, go_n + 1, rn);
+            add(q, lo_s, go_s, as);
+            if (!ab_s) add(q, lo_s + 1, go_s + 1, rs);
           } else {
-            float *qf = gsv + (size_t)c * hw;
-            auto add = [&](int o, int go, float val) {
-              if (is_finite(val)) atomicAdd(q + o, fx(val, to_fixed[c]));
-              else unsafeAtomicAdd(qf + go, val);
-            };
-            add(o_n, go_n, an);
-            if (!ab_n) add(o_n + 1, go_n + 1, rn);
-            add(o_s, go_s, as);
-            if (!ab_s) add(o_s + 1, go_s + 1, rs);
+            unsigned long long *q = asv + (size_t)c * hw;
+            add(q, go_n, go_n, an);
+            if (!ab_n) add(q, go_n + 1, go_n + 1, rn);
+            add(q, go_s, go_s, as);
+            if (!ab_s) add(q, go_s + 1, go_s + 1, rs);
           }
         }
       }
