@@ -13,7 +13,8 @@
 // Work item = (tile of TW x TH = 256 reference pixels, chunk of DC depth planes, CS of the C channels):
 //   1. every thread (= pixel) computes its taps at the chunk's first and last plane for every staged source
 //      view; the union over the workgroup is the view's box (the taps move monotonically along the epipolar
-//      line between the two planes).  The box is clipped to the LDS capacity of a view;
+//      line between the two planes), in PADDED image coordinates (columns -1 .. W, rows -1 .. H: positions outside the
+//      image are staged as zeros, which is what ATen's zeros padding reads there).  The box is clipped to the LDS capacity of a view;
 //   2. the boxes are staged: pixel-major, CS channels per pixel, pixel stride padded to an ODD number of
 //      16-byte units so that 16 lanes reading the same channel group of 16 consecutive pixels hit 16 different
 //      bank quads (conflict-free ds_read_b128);
@@ -202,8 +203,18 @@ __device__ __forceinline__ Box read_box(const int *prm, int vi) {
   return Box{uniform_int(p[0]), uniform_int(p[1]), uniform_int(p[2]), uniform_int(p[3])};
 }
 
-// One source view's contribution to one plane of this thread's pixel: taps -> 4 * CS/4 LDS reads (or, for a lane
+// One source view's contribution to one plane of this thread's pixel: coordinates -> 4 * CS/4 LDS reads (or, for a lane
 // whose footprint is not inside the staged box, global gathers) -> s += val, q += val^2.
+//
+// ZERO-PADDED BOXES (round 5).  ATen's grid_sample drops a tap outside the image (modules.py:87-89, zeros padding): the same value as a tap that reads
+// 0 - so the staged box lives in PADDED image coordinates (columns -1 .. W, rows -1 .. H; positions outside the image are staged as zeros) and the
+// plane loop needs no per-tap bounds logic at all: a footprint (x0, x0 + 1) x (y0, y0 + 1) is either inside the box - then its four taps are read with
+// the plain weights (1 - tw)(1 - tn), tw (1 - tn), (1 - tw) tn, tw tn, and the taps outside the image contribute 0 * w = 0 - or it is not, which is
+// wave-uniformly rare.  The per-tap form (plane_sweep.h: taps_from_coords: ~40 compares / selects / clamps per (pixel, plane, view), every one a 4.3-cycle
+// instruction) cost more vector issue than the interpolation of 16 channels; it survives in the fallback, where a lane whose footprint is inside the
+// IMAGE but not inside the box gathers from global memory.  Results: the same products in the same order for every tap inside the image (the weight of an
+// in-image tap is the same product of the same operands), a zero term where the per-tap form has a zero-weight term - equal values, as asserted against
+// the gather kernels.
 //
 // gfx9 has ONE in-order counter (vmcnt) for vector-memory loads AND stores: a wait for a load that was issued
 // after the previous plane's volume stores also waits for those stores to reach HBM.  The first version of this
@@ -218,18 +229,20 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
   constexpr int GL = CS / 4;
   using L = BoxLayout<CS>;
   const int rowu = L::row_units(bx_.bw);
-  Taps t = plane_sweep_taps(P, xf, yf, dvk, w, h);
-  if (!valid) t.w_nl = t.w_nr = t.w_sl = t.w_sr = 0.0f;
-  const bool live = taps_live(t);
-  const int rx = t.xl - bx_.bx0, ryn = t.yn - bx_.by0, rys = t.ys - bx_.by0;
-  const bool in = (rx >= 0) & (rx + 1 < bx_.bw) & (ryn >= 0) & (rys < bx_.bh);   // yn <= ys
-  const bool use_lds = live & in;
-  // a dead voxel (all weights 0) reads the box origin: staged, finite data
-  // left / right pixel of the pair in the north row, and the distance to the south row
-  const int uL = use_lds ? ryn * rowu + L::unit(rx) : 0, uR = use_lds ? ryn * rowu + L::unit(rx + 1) : L::unit(1);
-  const int dS = (use_lds & (rys != ryn)) ? rowu : 0;
-  const bool outside = live & !in;
-  const f32x2 w_nl{t.w_nl, t.w_nl}, w_nr{t.w_nr, t.w_nr}, w_sl{t.w_sl, t.w_sl}, w_sr{t.w_sr, t.w_sr};
+  const SweepCoords sc = plane_sweep_coords(P, xf, yf, dvk, w, h);
+  // box-relative position of the footprint's north-west corner.  NaN / -inf -> -2 (left of every box: bx0 >= -1); +inf / huge saturate: the
+  // unsigned compares fail for all of them
+  const int rx = (int)fmaxf(sc.x0, -2.0f) - bx_.bx0, ry = (int)fmaxf(sc.y0, -2.0f) - bx_.by0;
+  const bool inbox = ((unsigned)rx < (unsigned)(bx_.bw - 1)) & ((unsigned)ry < (unsigned)(bx_.bh - 1)) & valid;   // columns rx, rx + 1 and rows ry, ry + 1 staged
+  // a lane without a staged footprint reads the box origin (staged, finite data) with zero weights
+  // (left, right) column weights as ONE register pair: the two rows' weights are two packed multiplies with a broadcast operand.  Without a staged
+  // footprint all four weights are exactly 0 - also when the coordinates are NaN / inf (0 * NaN is NaN: the row fraction is replaced as well)
+  const f32x2 tlr{inbox ? 1.0f - sc.tw : 0.0f, inbox ? sc.tw : 0.0f};
+  const float tn_ = inbox ? sc.tn : 0.0f, ts_ = 1.0f - tn_;
+  f32x2 wN = tlr * f32x2{ts_, ts_}, wS = tlr * f32x2{tn_, tn_};   // ATen: nw = e * s, ne = w * s | sw = e * n, se = w * n
+  const int uL = inbox ? ry * rowu + L::unit(rx) : 0;
+  const int uR = CS == 8 ? (inbox ? ry * rowu + L::unit(rx + 1) : L::unit(1)) : uL + (GL + 1);   // odd pixel stride GL + 1: the neighbour is a constant away
+  const int dS = rowu;   // the south row is staged whenever the north row is (ry + 1 < bh); the origin's south neighbour exists (bh >= 2)
   // channel groups in batches of JB (8 channels): at most 8 ds_read_b128 = 32 registers of tap data live at a time -
   // what keeps the 8-wave (PG = 2) form inside 128 VGPRs; the scheduling barriers stop the compiler from hoisting the
   // next batch's reads above this batch's arithmetic
@@ -240,42 +253,49 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
       if (abl & 2) {   // ablation: the timing without the LDS tap reads (wrong results)
-        n0[j] = f32x4{t.w_nl, xf, yf, dvk}; n1[j] = n0[j]; s0[j] = n0[j]; s1[j] = n0[j];
+        n0[j] = f32x4{wN.x, xf, yf, dvk}; n1[j] = n0[j]; s0[j] = n0[j]; s1[j] = n0[j];
         continue;
       }
       n0[j] = bx[uL + jb + j]; n1[j] = bx[uR + jb + j];
       s0[j] = bx[uL + dS + jb + j]; s1[j] = bx[uR + dS + jb + j];
     }
-    if (__builtin_amdgcn_ballot_w64(outside) != 0) {   // rare: noise-like depth, or a box clipped by the LDS capacity
-      const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(view_map), 0, view_bytes, 0x00020000);
-      // every lane loads (a valid image address either way), only the lanes outside their box keep the result;
-      // one tap at a time: the rare path must not raise the register count of the common one
-      // pixel-major map: the 4 channels of a group are one 16-byte load, the right column is C floats on; channel-plane map
-      // (NCHW): four dword loads h * w floats apart, the right column one float on
-      const int chs = NCHW ? h * w * 4 : 4, pxs = NCHW ? 4 : C * 4;   // byte strides of a channel / of a pixel
-      const int on0 = NCHW ? ((c0 + 4 * jb) * h * w + t.yn * w + t.xl) * 4 : ((t.yn * w + t.xl) * C + c0 + 4 * jb) * 4;
-      const int os0 = NCHW ? ((c0 + 4 * jb) * h * w + t.ys * w + t.xl) * 4 : ((t.ys * w + t.xl) * C + c0 + 4 * jb) * 4;
+    if (__builtin_amdgcn_ballot_w64(valid & !inbox) != 0) {   // a footprint outside its box: mostly outside the image as well (tiles whose frustum leaves the view)
+      const Taps t = taps_from_coords(sc, w, h);
+      const bool outside = valid & !inbox & taps_live(t);
+      if (__builtin_amdgcn_ballot_w64(outside) != 0) {   // rare: noise-like depth, or a box clipped by the LDS capacity
+        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(view_map), 0, view_bytes, 0x00020000);
+        // every lane loads (a valid image address either way), only the lanes outside their box keep the result - together with ATen's
+        // bounds-checked weights; one tap at a time: the rare path must not raise the register count of the common one
+        // pixel-major map: the 4 channels of a group are one 16-byte load, the right column is C floats on; channel-plane map
+        // (NCHW): four dword loads h * w floats apart, the right column one float on
+        const int chs = NCHW ? h * w * 4 : 4, pxs = NCHW ? 4 : C * 4;   // byte strides of a channel / of a pixel
+        const int on0 = NCHW ? ((c0 + 4 * jb) * h * w + t.yn * w + t.xl) * 4 : ((t.yn * w + t.xl) * C + c0 + 4 * jb) * 4;
+        const int os0 = NCHW ? ((c0 + 4 * jb) * h * w + t.ys * w + t.xl) * 4 : ((t.ys * w + t.xl) * C + c0 + 4 * jb) * 4;
 #define CASMVS_GATHER_TAP(dst, voff, imm)                                        \
-      {                                                                          \
-        f32x4 g[JB];                                                             \
-        _Pragma("unroll") for (int j = 0; j < JB; ++j) {                         \
-          if (NCHW) {                                                            \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                        \
-              g[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, voff + (imm) + (4 * j + i) * chs, 0, 0)); \
-          } else {                                                               \
-            g[j] = buf_load4(src, voff, (imm) + 16 * j);                         \
-          }                                                                      \
-        }                                                                        \
-        __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) only, INSIDE the branch */ \
-        _Pragma("unroll") for (int j = 0; j < JB; ++j)                           \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[j][i] = outside ? g[j][i] : dst[j][i]; \
-      }
-      CASMVS_GATHER_TAP(n0, on0, 0)
-      CASMVS_GATHER_TAP(n1, on0, pxs)
-      CASMVS_GATHER_TAP(s0, os0, 0)
-      CASMVS_GATHER_TAP(s1, os0, pxs)
+        {                                                                          \
+          f32x4 g[JB];                                                             \
+          _Pragma("unroll") for (int j = 0; j < JB; ++j) {                         \
+            if (NCHW) {                                                            \
+              _Pragma("unroll") for (int i = 0; i < 4; ++i)                        \
+                g[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, voff + (imm) + (4 * j + i) * chs, 0, 0)); \
+            } else {                                                               \
+              g[j] = buf_load4(src, voff, (imm) + 16 * j);                         \
+            }                                                                      \
+          }                                                                        \
+          __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) only, INSIDE the branch */ \
+          _Pragma("unroll") for (int j = 0; j < JB; ++j)                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) dst[j][i] = outside ? g[j][i] : dst[j][i]; \
+        }
+        CASMVS_GATHER_TAP(n0, on0, 0)
+        CASMVS_GATHER_TAP(n1, on0, pxs)
+        CASMVS_GATHER_TAP(s0, os0, 0)
+        CASMVS_GATHER_TAP(s1, os0, pxs)
 #undef CASMVS_GATHER_TAP
+        wN = f32x2{outside ? t.w_nl : wN.x, outside ? t.w_nr : wN.y};
+        wS = f32x2{outside ? t.w_sl : wS.x, outside ? t.w_sr : wS.y};
+      }
     }
+    const f32x2 w_nl{wN.x, wN.x}, w_nr{wN.y, wN.y}, w_sl{wS.x, wS.x}, w_sr{wS.y, wS.y};
     // Two channels per instruction (v_pk_mul / v_pk_fma / v_pk_add_f32): a wave issues one instruction every ~5
     // cycles whatever it is, so the instruction COUNT is the wave's run time.  Per lane and channel the operations
     // and their order are those of the scalar form: val = fma(s1, w_sr, fma(s0, w_sl, fma(n1, w_nr, n0 * w_nl))),
@@ -435,10 +455,12 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
     int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const Taps t = plane_sweep_taps(P, xf, yf, e == 0 ? dv_first : dv_last, w, h);
-      if (valid && taps_live(t)) {
-        xmn = min(xmn, t.xl); xmx = max(xmx, t.xl + 1);
-        ymn = min(ymn, t.yn); ymx = max(ymx, t.ys);
+      // footprints that touch the image, in PADDED coordinates (x0 in [-1, W - 1], y0 in [-1, H - 1]; NaN / inf fail the compares)
+      const SweepCoords c = plane_sweep_coords(P, xf, yf, e == 0 ? dv_first : dv_last, w, h);
+      if (valid && c.x0 >= -1.0f && c.x0 <= (float)(w - 1) && c.y0 >= -1.0f && c.y0 <= (float)(h - 1)) {
+        const int x0 = (int)c.x0, y0 = (int)c.y0;
+        xmn = min(xmn, x0); xmx = max(xmx, x0 + 1);
+        ymn = min(ymn, y0); ymx = max(ymx, y0 + 1);
       }
     }
     xmn = wave_min(xmn); xmx = wave_max(xmx); ymn = wave_min(ymn); ymx = wave_max(ymx);
@@ -466,13 +488,15 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
       const int *r = red + (wv * kMaxViews + tid) * 4;
       xmn = min(xmn, r[0]); xmx = max(xmx, r[1]); ymn = min(ymn, r[2]); ymx = max(ymx, r[3]);
     }
-    if (xmn > xmx) { xmn = 0; xmx = 1; ymn = 0; ymx = 0; }   // nothing of this tile projects into the view
-    if (NCHW) { xmn &= ~3; xmx |= 3; }   // channel-plane staging moves 4 consecutive x per load: whole quads (w % 4 == 0: still inside the row)
+    if (xmn > xmx) { xmn = 0; xmx = 1; ymn = 0; ymx = 1; }   // nothing of this tile projects into the view
+    if (NCHW) { xmn &= ~3; xmx |= 3; }   // channel-plane staging moves 4 consecutive x per load: whole quads (w % 4 == 0: a quad is image or padding)
+    // every box has >= 2 columns and >= 2 rows (a footprint spans two of each; lanes without a staged footprint read the origin's 2 x 2 pixels with
+    // zero weights): the clipped width leaves room for two rows
     int bw = xmx - xmn + 1, bh = ymx - ymn + 1;
-    int maxbw = a.cap_units / L::units_per_px_bound() - 1;   // host guarantees >= 2
+    int maxbw = a.cap_units / (2 * L::units_per_px_bound()) - 1;   // host guarantees >= 4
     if (NCHW) maxbw &= ~3;
     if (bw > maxbw) bw = maxbw;
-    const int maxbh = a.cap_units / L::row_units(bw);
+    const int maxbh = a.cap_units / L::row_units(bw);          // >= 2
     if (bh > maxbh) bh = maxbh;
     const int nsu = bw * GL, q256 = NT / nsu;
     int *p = prm + tid * 8;
@@ -486,6 +510,8 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
   // is waited for (one memory latency for all the boxes; a box of the expected size is one pass).
   struct ViewStage {
     int nsu, total, rowu, base;
+    int q256;
+    int bx0, yrow;               // the box's first column / the image row of this thread's next unit (padded coordinates: either may be outside the image)
     int ru, lofs, gofs;          // this thread's next unit: index inside its box row, LDS unit of the row, global byte offset of the row
     int r256, dL, dG, gW;        // per step of NT units: ru += r256, the row advances by q256 (+ 1 when ru wraps)
     __amdgpu_buffer_rsrc_t src;
@@ -503,6 +529,7 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
     s.bx = box + (size_t)vi * a.cap_units;
     const int row = tid / s.nsu;
     s.ru = tid - row * s.nsu; s.base = 0;
+    s.bx0 = bx0; s.yrow = by0 + row; s.q256 = q256;
     s.gW = w * C * 4;
     s.lofs = row * s.rowu; s.gofs = ((by0 + row) * w + bx0) * (C * 4) + c0 * 4;
     s.dL = q256 * s.rowu; s.dG = q256 * s.gW;
@@ -514,11 +541,13 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
       const bool ok = s.base + tid + NT * i < s.total;
       const int pxx = (int)((unsigned)s.ru / (unsigned)GL), ch = (int)((unsigned)s.ru % (unsigned)GL);
       s.lo[i] = ok ? s.lofs + L::unit(pxx) + ch : -1;
-      // a lane past the end of the box addresses beyond the buffer: the hardware returns 0 without a memory access
-      s.regs[i] = buf_load4(s.src, ok ? s.gofs + (pxx * C + 4 * ch) * 4 : -16, 0);
-      s.ru += s.r256; s.lofs += s.dL; s.gofs += s.dG;
+      // a lane past the end of the box, or at a box position outside the image (the zero padding), addresses beyond the buffer: the hardware
+      // returns 0 without a memory access
+      const bool in_img = ((unsigned)(s.bx0 + pxx) < (unsigned)w) & ((unsigned)s.yrow < (unsigned)h);
+      s.regs[i] = buf_load4(s.src, (ok & in_img) ? s.gofs + (pxx * C + 4 * ch) * 4 : -16, 0);
+      s.ru += s.r256; s.lofs += s.dL; s.gofs += s.dG; s.yrow += s.q256;
       const bool wrap = s.ru >= s.nsu;
-      s.ru -= wrap ? s.nsu : 0; s.lofs += wrap ? s.rowu : 0; s.gofs += wrap ? s.gW : 0;
+      s.ru -= wrap ? s.nsu : 0; s.lofs += wrap ? s.rowu : 0; s.gofs += wrap ? s.gW : 0; s.yrow += wrap ? 1 : 0;
     }
     s.base += NT * NUB;
   };
@@ -548,9 +577,11 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
         lo[k] = ok ? r * rowu + cg : -1;
         const int px0 = 4 * q;
         lo[k] = ok ? lo[k] + (px0 << 16) : -1;   // (LDS row / channel part, first pixel) packed: unit(px) is not linear in px for CS = 8
-        const int gofs = ok ? (((c0 + 4 * cg) * h + by0 + r) * w + bx0 + px0) * 4 : -16;
+        // whole quads of x (bx0 and w are multiples of 4): a quad is inside the image or it is padding
+        const bool in_img = ((unsigned)(bx0 + px0) < (unsigned)w) & ((unsigned)(by0 + r) < (unsigned)h);
+        const int gofs = (ok & in_img) ? (((c0 + 4 * cg) * h + by0 + r) * w + bx0 + px0) * 4 : -16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[k][i] = buf_load4(src, ok ? gofs + i * hw * 4 : -16, 0);
+        for (int i = 0; i < 4; ++i) v[k][i] = buf_load4(src, gofs >= 0 ? gofs + i * hw * 4 : -16, 0);
       }
 #pragma unroll
       for (int k = 0; k < NI; ++k) {

@@ -36,10 +36,14 @@ __device__ __forceinline__ float div_by(float a, float b, float rcp_b) {
 #endif
 }
 
-// Coordinates + bilinear taps of ref pixel (x, y) at depth dv in the source view whose
-// (P_src @ inv(P_ref))[:3] is P (12 floats, row-major 3x4).
-__device__ __forceinline__ Taps plane_sweep_taps(const float *__restrict__ P, float xf, float yf,
-                                                 float dv, int W, int H) {
+// Where ref pixel (x, y) at depth dv lands in the source view whose (P_src @ inv(P_ref))[:3] is P (12 floats, row-major 3x4): the integer part of
+// ATen's un-normalised sampling position and the fractions.  Everything may be NaN / +-inf (depth ~ 0): the consumers' bounds tests drop such taps.
+struct SweepCoords {
+  float x0, y0;   // floor(ix), floor(iy)
+  float tw, tn;   // ix - x0, iy - y0: the weights of column x0 + 1 / row y0 + 1 (ATen: e = 1 - w, s = 1 - n for column x0 / row y0)
+};
+
+__device__ __forceinline__ SweepCoords plane_sweep_coords(const float *__restrict__ P, float xf, float yf, float dv, int W, int H) {
   // src_grid_d = R @ (x, y, 1)^T + T / depth                       (modules.py:72)
   float rx = fmaf(P[2], 1.0f, fmaf(P[1], yf, P[0] * xf));
   float ry = fmaf(P[6], 1.0f, fmaf(P[5], yf, P[4] * xf));
@@ -63,9 +67,19 @@ __device__ __forceinline__ Taps plane_sweep_taps(const float *__restrict__ P, fl
   float gy = div_by(v, hy, __builtin_amdgcn_rcpf(hy)) - 1.0f;
   float ix = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
   float iy = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
-  float x0 = floorf(ix), y0 = floorf(iy);
-  float tw = ix - x0, te = 1.0f - tw;  // ATen CPU kernel: w = x - x_w, e = 1 - w
-  float tn = iy - y0, ts = 1.0f - tn;
+  SweepCoords c;
+  c.x0 = floorf(ix);
+  c.y0 = floorf(iy);
+  c.tw = ix - c.x0;   // ATen CPU kernel: w = x - x_w, e = 1 - w
+  c.tn = iy - c.y0;
+  return c;
+}
+
+// ATen's bounds-checked taps from the coordinates: every tap inside the image with its weight, every other one with weight 0 at a valid address.
+__device__ __forceinline__ Taps taps_from_coords(const SweepCoords &c, int W, int H) {
+  const float x0 = c.x0, y0 = c.y0;
+  const float tw = c.tw, te = 1.0f - tw;
+  const float tn = c.tn, ts = 1.0f - tn;
   // Bounds tests in float: NaN / +-inf / huge coordinates fail every comparison, so the tap is
   // dropped exactly like ATen's zeros padding (its int index below is never used with a non-zero weight).
   // x: left element of the pair is column xl = clamp(x0, 0, W-2); columns x0 and x0+1 carry
@@ -94,6 +108,13 @@ __device__ __forceinline__ Taps plane_sweep_taps(const float *__restrict__ P, fl
   t.w_sl = wl * wsth;
   t.w_sr = wr * wsth;
   return t;
+}
+
+// Coordinates + bilinear taps of ref pixel (x, y) at depth dv in the source view whose
+// (P_src @ inv(P_ref))[:3] is P (12 floats, row-major 3x4).
+__device__ __forceinline__ Taps plane_sweep_taps(const float *__restrict__ P, float xf, float yf,
+                                                 float dv, int W, int H) {
+  return taps_from_coords(plane_sweep_coords(P, xf, yf, dv, W, H), W, H);
 }
 
 // true when at least one tap of the footprint carries weight (the voxel projects into the source image)

@@ -27,6 +27,14 @@ static double costvol_check(int B, int V, int C, int D, int h, int w, float slid
     }
     for (int d = 0; d < D; ++d)
       for (size_t p = 0; p < hw; ++p) depth[((size_t)b * D + d) * hw + p] = 425.0f + 2.5f * d + 0.02f * (float)(p % 5);
+    // hypotheses of 0 / denormal / negative depth (modules.py:72 divides by them): NaN / inf coordinates, whose taps ATen drops - and so must the
+    // zero-padded boxes' plain weights (0 * NaN is NaN)
+    if (hw > 40 && D > 2) {
+      depth[((size_t)b * D + 1) * hw + 17] = 0.0f;
+      depth[((size_t)b * D + 2) * hw + 18] = 1e-42f;
+      depth[((size_t)b * D + 0) * hw + 19] = -3.0f;
+      depth[((size_t)b * D + 1) * hw + 40] = INFINITY;
+    }
   }
   auto dup = [](const std::vector<float> &v) {
     float *p = (float *)std::aligned_alloc(256, (v.size() * 4 + 255) & ~(size_t)255);
