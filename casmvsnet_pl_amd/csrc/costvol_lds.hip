@@ -156,6 +156,15 @@ __device__ __forceinline__ void store_plane_transposed(const float (&vals)[CS], 
     const f32x4 o = RS % 4 == 0 ? *reinterpret_cast<const f32x4 *>(row) : f32x4{row[0], row[1], row[2], row[3]};
     const int soff = uniform_int((4 * j * D + d) * hw * 4);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ps.rsrc, ps.voff, soff, CASMVS_CV_STORE_AUX);   // w % 4 == 0 (host)
+    // STORE-DATA HAZARD (found in round 5, profiles/r05_store_data_hazard.md): the store reads its 16 bytes per lane over several cycles after issue, and a
+    // VALU write of one of its data registers in the very next issue slot lands in some lanes of the stored value (here: the depth register rotation put a
+    // hypothesis into element 1 of lanes 12-15 of every 16 - channels 12-15 of four pixels per wave and plane, different ones every run).  The ISA lists
+    // the pair (wide store, then a write of its data registers) as needing wait states and LLVM pads it - except for a store whose soffset is a scalar
+    // REGISTER (GCNHazardRecognizer::createsVALUHazard), the form used here.  Two wait states that no write of `o` can move in front of (the statement
+    // reads the registers; the memory clobber keeps it behind the store); tools/store_hazard_lint.py checks the whole library's device code for the pair.
+#ifndef HIPEMU_LDS_BYTES   // (tests/hipemu: the host has no such instruction, and needs none)
+    asm volatile("s_nop 1" ::"v"(o) : "memory");
+#endif
     wave_lds_fence();  // the rows are rewritten by the next channel group
   }
 }
@@ -181,16 +190,21 @@ __device__ __forceinline__ void store_plane(const float (&vals)[CS], float *tr, 
 // LDS layout of a staged box row, in 16-byte units: pixel px (box-relative) starts at unit(px), its CS/4 channel
 // groups follow contiguously, a row takes row_units(bw).  Measured with tools/probes/lds_probe.hip (ds_read_b128,
 // lane i reads pixel p + i): a pixel stride of 2 or 4 units is 2- / 4-way bank conflicted, any ODD stride is
-// conflict free, and so is stride 2 with one extra unit every 8 pixels.
+// conflict free, and so is stride 2 with one extra unit every 8 pixels / stride 4 with one extra unit every 4 pixels
+// (pixel 4 a + r starts at unit 17 a + 4 r: 16 consecutive pixels cover the 16 bank quads; MI355X_MICROARCH.md: a ds_read_b128 is served in four groups
+// of 16 lanes).
 //   CS = 8 : unit(px) = 2 px + (px >> 3)    (6 % padding: what lets four workgroups share a CU's LDS)
-//   CS = 16: unit(px) = 5 px,  CS = 32: unit(px) = 9 px    (odd stride: 25 % / 12.5 % padding)
+//   CS = 16: unit(px) = 4 px + (px >> 2)    (6 % padding - round 5; the odd stride 5 px was 25 %: the difference is what lets a workgroup sweep 16
+//                                            planes of a tile instead of 8 on the same 2 x 35 KiB, i.e. half the prologues per volume)
+//   CS = 32: unit(px) = 9 px                (odd stride: 12.5 % padding)
 template <int CS>
 struct BoxLayout {
   static constexpr int GL = CS / 4;
-  static __device__ __forceinline__ int unit(int px) { return CS == 8 ? 2 * px + (px >> 3) : px * (GL + 1); }
-  static __device__ __forceinline__ int row_units(int bw) { return CS == 8 ? 2 * bw + (bw >> 3) + 1 : bw * (GL + 1); }
+  static __device__ __forceinline__ int unit(int px) { return CS == 8 ? 2 * px + (px >> 3) : (CS == 16 ? 4 * px + (px >> 2) : px * (GL + 1)); }
+  static __device__ __forceinline__ int row_units(int bw) { return CS == 8 ? 2 * bw + (bw >> 3) + 1 : (CS == 16 ? 4 * bw + (bw >> 2) + 1 : bw * (GL + 1)); }
   // widest box of a given capacity (units) that still has one row; rows of a box of width bw
   static __host__ __device__ constexpr int units_per_px_bound() { return CS == 8 ? 3 : GL + 1; }
+  static constexpr bool kConstantNeighbour = CS == 32;   // unit(px + 1) - unit(px) is a constant (an immediate offset of the right column's reads)
 };
 
 // Box of one staged view, wave-uniform (SGPRs).
@@ -241,7 +255,7 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
   const float tn_ = inbox ? sc.tn : 0.0f, ts_ = 1.0f - tn_;
   f32x2 wN = tlr * f32x2{ts_, ts_}, wS = tlr * f32x2{tn_, tn_};   // ATen: nw = e * s, ne = w * s | sw = e * n, se = w * n
   const int uL = inbox ? ry * rowu + L::unit(rx) : 0;
-  const int uR = CS == 8 ? (inbox ? ry * rowu + L::unit(rx + 1) : L::unit(1)) : uL + (GL + 1);   // odd pixel stride GL + 1: the neighbour is a constant away
+  const int uR = L::kConstantNeighbour ? uL + (GL + 1) : (inbox ? ry * rowu + L::unit(rx + 1) : L::unit(1));   // (odd pixel stride: the neighbour is a constant away)
   const int dS = rowu;   // the south row is staged whenever the north row is (ry + 1 < bh); the origin's south neighbour exists (bh >= 2)
   // channel groups in batches of JB (8 channels): at most 8 ds_read_b128 = 32 registers of tap data live at a time -
   // what keeps the 8-wave (PG = 2) form inside 128 VGPRs; the scheduling barriers stop the compiler from hoisting the
@@ -260,6 +274,7 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
       s0[j] = bx[uL + dS + jb + j]; s1[j] = bx[uR + dS + jb + j];
     }
     if (__builtin_amdgcn_ballot_w64(valid & !inbox) != 0) {   // a footprint outside its box: mostly outside the image as well (tiles whose frustum leaves the view)
+      asm volatile("" ::: "memory");   // (a side effect: keeps the ~35 instructions of the bounds logic INSIDE the branch - the compiler speculated them into the plane loop)
       const Taps t = taps_from_coords(sc, w, h);
       const bool outside = valid & !inbox & taps_live(t);
       if (__builtin_amdgcn_ballot_w64(outside) != 0) {   // rare: noise-like depth, or a box clipped by the LDS capacity
@@ -766,9 +781,11 @@ struct Plan {
 
 // LDS plan: the highest occupancy (3, 2, 1 workgroups per CU) whose per-view capacity still holds the box a
 // tile is expected to need ((TW + DC + 4) x (TH + 2) pixels: ~0.6 px of epipolar slide per plane + slack).
-bool make_plan(int C, int w, int D, int nv, int G, int mode, Plan &p) {
+// dc: planes per workgroup, 8 or 16 (16: half the prologues - box extents, staging, two memory round trips, 35 % of a workgroup's life at 8 planes,
+// tools/gpu_cv_trace.py - on a box ~8 px wider; the kernels exist for the CS = 16 forms with a compile-time view count)
+bool make_plan(int C, int w, int D, int nv, int G, int mode, Plan &p, int dc = 8) {
   if (nv < 1 || nv > kMaxViews) return false;
-  p.dc = 8;
+  p.dc = dc;
   if (D % p.dc != 0) return false;
   if (w % 4 != 0) return false;                 // 16-byte volume stores
   p.tw = (C == 8 && w % 64 == 0) ? 64 : 32;   // A/B (tools/gpu_cv_ab.sh): 32 x 8 tiles win at C = 16, no difference at C = 8
@@ -782,8 +799,9 @@ bool make_plan(int C, int w, int D, int nv, int G, int mode, Plan &p) {
   if (const char *e = getenv("CASMVS_CV_CS")) p.cs = atoi(e);
 #endif
   if (C % p.cs != 0 || (p.cs != 8 && p.cs != 16 && p.cs != 32)) return false;
-  const int upp = p.cs == 8 ? 3 : p.cs / 4 + 1, th = kThreads / p.tw;   // upper bound of the units per staged pixel
-  const int need = ((p.tw + p.dc + 4 + (mode == MODE_WARP_NCHW ? 6 : 0)) * (p.cs == 8 ? 17 : 8 * upp) / 8 + 1) * (th + 2);   // NCHW staging: boxes of whole x quads
+  const int th = kThreads / p.tw;
+  const int units_per_8px = p.cs == 8 ? 17 : (p.cs == 16 ? 34 : 8 * (p.cs / 4 + 1));   // BoxLayout
+  const int need = ((p.tw + p.dc + 4 + (mode == MODE_WARP_NCHW ? 6 : 0)) * units_per_8px / 8 + 1) * (th + 2);   // NCHW staging: boxes of whole x quads
   // workgroups per CU the registers allow (waves_per_simd of the kernel that will run): a smaller LDS budget than
   // that buys nothing and only clips boxes earlier
   const int occ = waves_per_simd(p.cs, mode, p.pg) / p.pg;
@@ -799,14 +817,26 @@ bool make_plan(int C, int w, int D, int nv, int G, int mode, Plan &p) {
   return false;
 }
 
-template <int C, int CS, int MODE, int TW, int NV, int PG>
-int launch_pg(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
-  auto kernel = costvol_lds_kernel<C, CS, MODE, TW, 8, NV, PG>;
+template <int C, int CS, int MODE, int TW, int NV, int PG, int DC>
+int launch_dc(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
+  auto kernel = costvol_lds_kernel<C, CS, MODE, TW, DC, NV, PG>;
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), 158 * 1024, "costvol_lds_kernel")) return rc;
-  const int inner = (a.D / 8) * (C / CS);
+  const int inner = (a.D / DC) * (C / CS);
   dim3 grid((unsigned)(8 * a.tiles_per_xcd * inner), (unsigned)B);
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads * PG), (size_t)p.lds_bytes, st, a);
   return casmvs::check_launch("costvol_lds_kernel");
+}
+
+long g_dc16_min_rounds = 4;   // (internal linkage; the CPU emulation's driver, which includes this file, sets 0 to run the 16-plane form on its small volumes)
+constexpr bool has_dc16(int cs, int mode, int nv, int pg) { return cs == 16 && nv > 0 && pg == 1 && (mode == MODE_VAR || mode == MODE_GWC || is_warp(mode)); }
+
+template <int C, int CS, int MODE, int TW, int NV, int PG>
+int launch_pg(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
+  if constexpr (has_dc16(CS, MODE, NV, PG)) {
+    if (p.dc == 16) return launch_dc<C, CS, MODE, TW, NV, PG, 16>(a, p, B, st);
+  }
+  if (p.dc != 8) return casmvs::fail(CASMVS_ERR_UNSUPPORTED, "costvol_lds: no kernel sweeps %d planes per workgroup in this form", p.dc);
+  return launch_dc<C, CS, MODE, TW, NV, PG, 8>(a, p, B, st);
 }
 
 template <int C, int CS, int MODE, int TW, int NV>
@@ -849,6 +879,19 @@ int launch_mode(SweepArgs a, int C, int B, hipStream_t st, const char *what) {
   const int th = kThreads / p.tw;
   a.tiles_x = casmvs::ceil_div(a.w, p.tw);
   a.tiles = a.tiles_x * casmvs::ceil_div(a.h, th);
+  {
+    // 16 planes per workgroup where that form exists (has_dc16: the compile-time view counts - V = 3 fused, the un-fused warp) and the launch still
+    // has >= 4 rounds of the chip's 512 resident workgroups (2 per CU): fewer, longer workgroups otherwise lose to the tail of the last round
+    const int nv_static = is_warp(MODE) ? 1 : ((MODE == MODE_VAR || MODE == MODE_GWC) && a.nv == 2 ? 2 : 0);
+    Plan p16;
+    long min_rounds = g_dc16_min_rounds;
+#ifdef CASMVS_TRACE
+    if (const char *e = getenv("CASMVS_CV_DC16_ROUNDS")) min_rounds = atol(e);   // A/B: 0 = always, 1000000 = never
+#endif
+    if (p.cs == 16 && has_dc16(p.cs, MODE, nv_static, p.pg) && a.D % 16 == 0 && make_plan(C, a.w, a.D, a.nv, a.G, MODE, p16, 16) && p16.cs == p.cs && p16.tw == p.tw &&
+        p16.lds_bytes <= 79 * 1024 && (long)a.tiles * (a.D / 16) * (C / p.cs) * B >= min_rounds * 512)
+      p = p16;
+  }
   a.tiles_per_xcd = casmvs::ceil_div(a.tiles, 8);
   a.cap_units = p.cap_units;
   a.ablate = 0;

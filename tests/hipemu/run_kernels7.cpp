@@ -126,6 +126,12 @@ int main(int argc, char **argv) {
   if (all || quick) take(costvol_check(1, 3, 16, 8, 12, 36, 0.6f));    // C = 16: 32 x 8 tiles, ragged in x and y
   if (all || quick || which == "warp") take(warp_nchw_check(1, 8, 8, 10, 64, 0.6f));    // C = 8 (unit(px) = 2 px + px / 8), ragged rows
   if (all || which == "warp") { take(warp_nchw_check(2, 16, 8, 12, 36, 0.6f)); take(warp_nchw_check(1, 32, 8, 9, 32, 1.5f)); }
+  if (all || quick) {   // 16 planes per workgroup (production: only where the launch keeps >= 4 rounds of workgroups)
+    g_dc16_min_rounds = 0;
+    take(costvol_check(1, 3, 16, 16, 12, 36, 0.6f));
+    if (all) take(warp_nchw_check(1, 16, 32, 9, 36, 0.5f));
+    g_dc16_min_rounds = 4;
+  }
   if (all) {
     take(costvol_check(2, 3, 32, 16, 9, 32, 0.4f));                    // C = 32 as two channel splits, two plane chunks
     take(costvol_check(1, 2, 16, 8, 16, 64, 1.5f));                    // one source view, a fast epipolar slide (wide boxes)

@@ -64,3 +64,17 @@ def test_split_f16_kernels_do_not_spill_and_fit_two_waves_per_simd():
             one_per_cu = name.startswith(("conv_ci_sf_kernel<32, 32", "conv_ci_sf_kernel<64, 64"))   # their lane images leave room for one workgroup
             assert vgpr <= (512 if one_per_cu else 256), (f, name, vgpr)
     assert seen >= 30
+
+
+def test_no_wide_store_is_followed_by_a_write_of_its_data_registers():
+    """tools/store_hazard_lint.py over every kernel of the library: no vector-memory store of 12 / 16 bytes per lane has a VALU write of one of its data
+    registers within the next two issue slots.  The MI355X stores the NEW value in some lanes then (round 5: a depth hypothesis in channels 12-15 of the
+    16-plane homo_warp kernel, different lanes every run); the ISA lists the pair as needing wait states, and LLVM pads it except where the store's soffset
+    operand is a scalar register - the form of the plane sweep's volume stores, which therefore carry their own `s_nop 1` tied to the data registers
+    (csrc/costvol_lds.hip: store_plane_transposed).  Whether a kernel is hit is a matter of register allocation: this pins it for every build."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("store_hazard_lint", os.path.join(ROOT, "tools", "store_hazard_lint.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    report = tool.lint(window=2)
+    assert not report, report

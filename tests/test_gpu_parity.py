@@ -127,6 +127,40 @@ def test_costvol_lds_with_taps_outside_the_box(dev, report, C, G, h, w, D):
     assert max_abs(b.cpu(), want) < 5e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("B,C,G,h,w,D,depth_kind", [(4, 16, 1, 256, 320, 32, "smooth"), (8, 32, 1, 128, 160, 48, "smooth"), (4, 16, 1, 256, 320, 32, "noisy"),
+                                                       (4, 16, 8, 256, 320, 32, "smooth")])
+def test_plane_sweep_16_planes_per_workgroup_equals_the_gather_kernels(dev, report, B, C, G, h, w, D, depth_kind):
+    """The LDS plane sweep takes 16 planes per workgroup (half the prologues) only where the launch keeps >= 4 rounds of resident workgroups, i.e. at
+    the cascade's level-1 / level-2 shapes from batch 4 on - sizes no other parity test reaches.  Fused variance / correlation volume and the un-fused
+    homo_warp (box staged from the channel planes, and from the pixel-major copy) against the gather kernels, bit for bit, three launches each: the
+    first 16-plane build passed every small-shape test and stored a depth hypothesis into channels 12-15 of four pixels per wave and plane at these
+    sizes - a store-data hazard the compiler does not pad (csrc/costvol_lds.hip: store_plane_transposed; tools/store_hazard_lint.py) - differently
+    in every run."""
+    ops = _ops()
+    V = 3
+    g = torch.Generator().manual_seed(C + D + G)
+    feats = torch.randn(B, V, C, h, w, generator=g)
+    proj, dmin, dint = _proj_like(B, V, h, w, seed=5, level=1)
+    k = torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)
+    if depth_kind == "smooth":
+        base = 680.0 - D / 2 * dint * 2 + 60.0 * torch.sin(torch.linspace(0, 6.0, w)).view(1, 1, 1, w)
+        depth = (base + k * dint * 2).expand(B, D, h, w).contiguous()
+    else:   # what the previous level's regression gives with random weights: taps of a tile spread beyond its box
+        coarse = 680.0 + 40.0 * torch.randn(B, 1, h // 2, w // 2, generator=g)
+        depth = (torch.nn.functional.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True) - D / 2 * dint * 2 + k * dint * 2).contiguous()
+    fd, P, dv = feats.to(dev), proj.to(dev), depth.to(dev)
+    nhwc = ops.nchw_to_nhwc(fd.reshape(B * V, C, h, w)).view(B, V, h, w, C)
+    want = ops.costvol(nhwc, P, dv, G, channels_last=True, impl="gather")
+    bad = {"fused": sum(0 if torch.equal(ops.costvol(nhwc, P, dv, G, channels_last=True, impl="lds"), want) else 1 for _ in range(3))}
+    if G == 1:
+        src, P1 = fd[:, 1].contiguous(), P[:, 0].contiguous()
+        wwant = ops.homo_warp(src, P1, dv, impl="gather")
+        for impl in ("lds", "lds_copy"):
+            bad["warp_" + impl] = sum(0 if torch.equal(ops.homo_warp(src, P1, dv, impl=impl), wwant) else 1 for _ in range(3))
+    report("plane_sweep_16_planes", shape=[B, C, G, h, w, D], depth=depth_kind, differing_launches=bad)
+    assert not any(bad.values()), bad
+
+
 @pytest.mark.parametrize("V,C,G,h,w,D", [(3, 16, 1, 32, 64, 16), (5, 8, 1, 24, 32, 8), (5, 32, 8, 16, 32, 8), (4, 16, 4, 24, 40, 8)])
 def test_view_sharded_partial_sums(dev, report, V, C, G, h, w, D):
     """Sum x / Sum x^2 (and the correlation) are linear in the source views.  One rank (all views,
