@@ -92,6 +92,33 @@ def feature_flops(H, W):
     return full + half + quarter
 
 
+def feature_flops_f32_layers(H, W):
+    """The FeatureNet layers that stay on the float32 MFMA in the split-f16 layer set: conv0.0, conv0.1, lat1, toplayer."""
+    hw = H * W
+    return 2 * hw * (9 * 3 * 8 + 9 * 8 * 8) + 2 * (hw // 4) * (16 * 32) + 2 * (hw // 16) * (32 * 32)
+
+
+COSTREG_F32_FLOPS_PER_VOXEL = 216 + 216 + 432   # conv5, conv7, `prob`: the CostRegNet layers that stay float32 in the split-f16 layer set (of 6480 + conv0's)
+
+
+def mixed_mfma_roofline(flops, flops_f32_layers, ms, split):
+    """Roofline object of a stage that runs some layers on the f16 matrix cores (float32 operands as two float16 slices: 3 partial products x 4/3 K padding
+    = 4 executed FLOPs per algorithmic FLOP) and the rest on the float32 MFMA.  `frac` is quoted against the peak of what EXECUTES: the stage's ideal
+    time - executed f16 FLOPs at the dense f16 peak plus float32 FLOPs at the float32 MFMA peak - over its measured time.  The float32-peak RATIO of the
+    algorithmic FLOPs (comparable across rounds, > 1 is possible) is `fp32_equivalent`, not a fraction.  split False: every layer float32, frac = that ratio."""
+    t = ms * 1e-3
+    fp32_eq = {"achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "ratio": flops / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
+               "note": "ALGORITHMIC float32 FLOPs / time over the float32 MFMA peak: a roofline fraction only when every layer runs on the float32 MFMA"}
+    if not split:
+        return {"bound": "mfma", "dtype": "f32", "achieved": fp32_eq["achieved"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp32_eq["ratio"], "fp32_equivalent": fp32_eq}
+    f16_exec = 4.0 * (flops - flops_f32_layers)
+    ideal = f16_exec / (MFMA_F16_PEAK_TFLOPS * 1e12) + flops_f32_layers / (MFMA_F32_PEAK_TFLOPS * 1e12)
+    return {"bound": "mfma", "dtype": "f16 matrix instructions (4 executed FLOPs per algorithmic FLOP) on the layers with a split-f16 form, f32 MFMA on the rest",
+            "achieved": (f16_exec + flops_f32_layers) / t / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s (executed)", "frac": ideal / t,
+            "frac_note": "ideal time (executed f16 FLOPs / 2500 TFLOP/s + float32-layer FLOPs / 157.3 TFLOP/s) / measured time",
+            "executed_f16_tflops": f16_exec / t / 1e12, "float32_layers_share_of_algorithmic_flops": flops_f32_layers / flops, "fp32_equivalent": fp32_eq}
+
+
 def library_sha16():
     """First 16 hex digits of the sha256 of the HIP library this process runs (stamps the PMC files and the bench line)."""
     from casmvsnet_pl_amd import _lib
@@ -402,12 +429,13 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
     cr_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("costreg_"))
     cr_flops = sum(work[l]["costreg_flops"] for l in range(3)) * n_ev
     fused = getattr(model, "fuse_regress", False)
+    cr_split = getattr(model.cost_reg_0, "ci_mode", "f32") == "splitf16" and split is not None
+    cr_f32_flops = sum(COSTREG_F32_FLOPS_PER_VOXEL * n_depths[l] * (H >> l) * (W >> l) * B for l in range(3)) * n_ev
     out["roofline_costreg"] = {"kernel": "all 33 CostRegNet launches" + (" (the `prob` interval includes the fused softmax regression)" if fused else ""),
-                               "bound": "mfma", "achieved": cr_flops / (cr_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": cr_flops / (cr_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                               "ms_per_depth_map": cr_ms / n_ev / B, "batch": B}
+                               **mixed_mfma_roofline(cr_flops, cr_f32_flops, cr_ms, cr_split), "ms_per_depth_map": cr_ms / n_ev / B, "ms_per_step": cr_ms / n_ev, "batch": B}
     rest_ms = cr_ms - conv0_ms
-    out["roofline_costreg"]["without_conv0"] = {"ms_per_step": rest_ms / n_ev, "frac": (cr_flops - conv0_flops) / (rest_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    out["roofline_costreg"]["without_conv0"] = {"ms_per_step": rest_ms / n_ev, **{k: v for k, v in mixed_mfma_roofline(cr_flops - conv0_flops, cr_f32_flops, rest_ms, cr_split).items()
+                                                                                    if k in ("frac", "achieved", "fp32_equivalent")}}
     out["roofline_costreg"]["conv3_to_conv9_ms_per_step"] = sum(per_step[f"costreg_{l}/{n}"] for l in range(3) for n in ("conv3", "conv4", "conv5", "conv6", "conv7", "conv9"))
     cv_ms = sum(summ[f"costvol_{l}"]["ms"] for l in range(3))
     cv_bytes = sum(work[l]["costvol_bytes"] for l in range(3)) * n_ev
@@ -445,9 +473,8 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
     ft_ms = sum(v["ms"] for k, v in summ.items() if k.startswith("feature/"))
     if ft_ms > 0:
         ft_flops = feature_flops(H, W) * V * B * n_ev
-        out["roofline_feature"] = {"kernel": "all FeatureNet launches", "bound": "mfma",
-                                   "achieved": ft_flops / (ft_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": ft_flops / (ft_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+        ft_split = getattr(model.feature, "tail_mode", "f32") == "splitf16" and getattr(model.feature, "fuse_tail", False)
+        out["roofline_feature"] = {"kernel": "all FeatureNet launches", **mixed_mfma_roofline(ft_flops, feature_flops_f32_layers(H, W) * V * B * n_ev, ft_ms, ft_split),
                                    "ms_per_depth_map": ft_ms / n_ev / B, "ms_per_step": ft_ms / n_ev, "batch": B}
     if with_homo_warp:
         out["roofline_homo_warp"] = homo_warp_roofline(dev, H, W, n_depths, B)
@@ -735,6 +762,25 @@ def main():
         res = instrumented_pass(model, inputs, args.config, B, K, max(1, args.event_every), barrier, dev)
         if rank == 0:
             line.update(res)
+            # what north_star names, as top-level scalars (they survive a parser that keeps scalars only)
+            line["roofline_homo_warp_frac"] = res["roofline_homo_warp"]["frac"]                                       # reference signature, caches dirtied
+            line["roofline_homo_warp_frac_hot"] = res["roofline_homo_warp"]["frac_by_measurement"]["reference_signature_hot"]
+            line["roofline_costvol_frac"] = res["roofline_costvol"]["frac"]
+        if (args.conv0_mode or "splitf16") != "f32" and not args.no_batch1:
+            # the MEASURED float32-MFMA fraction of CostRegNet / FeatureNet (north_star: >= 0.4 MFMA utilisation on CostRegNet): the same launch with every
+            # layer on the float32 MFMA kernels, kernel by kernel under HIP events - a fraction of the peak those kernels run on
+            conv0_mode[0] = "f32"
+            m32, in32 = build(B)[0], inputs
+            for _ in range(2):
+                m32(*in32)
+            r32 = instrumented_pass(m32, in32, args.config, B, max(4, K // 2), max(1, args.event_every), barrier, dev, with_homo_warp=False)
+            conv0_mode[0] = None
+            del m32
+            if rank == 0:
+                for key in ("roofline_costreg", "roofline_feature"):
+                    line[key]["all_float32"] = {k: r32[key][k] for k in ("frac", "achieved", "peak", "unit", "ms_per_step") if k in r32[key]}
+                    line[key]["all_float32"]["note"] = "the same stage with every layer on the float32 MFMA kernels (conv0_mode = ci_mode = tail_mode = f32), measured"
+                line["roofline_costreg_frac_all_float32"] = r32["roofline_costreg"]["frac"]
     del model
     # ---- one forward per step (no concurrency), and the reference's eval.py loop: one reference view per step --------
     if NS > 1:
