@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -102,7 +103,7 @@ int main(int argc, char **argv) {
     CHECK(hipStreamSynchronize(sb));
     CHECK(hipMemcpy(dref, dout, nout * 4, hipMemcpyDeviceToDevice));
     for (int k = 0; k < 5; ++k) {
-      int bad = 0;
+      int bad = 0, dumps = 0;
       unsigned long long wrong = 0;
       for (int r = 0; r < rounds; ++r) {
         CHECK(hipMemsetAsync(dcounts, 0, 4, sb));
@@ -115,6 +116,26 @@ int main(int argc, char **argv) {
         CHECK(hipStreamSynchronize(sa));
         bad += c > 0;
         wrong += c;
+        if (c > 0 && getenv("CORES_DUMP") && dumps < atoi(getenv("CORES_DUMP"))) {   // where and how wrong: the first mismatches of a failing round + histograms
+          ++dumps;
+          std::vector<float> got(nout), ref(nout);
+          CHECK(hipMemcpy(got.data(), dout, nout * 4, hipMemcpyDeviceToHost));
+          CHECK(hipMemcpy(ref.data(), dref, nout * 4, hipMemcpyDeviceToHost));
+          const int Wd = v.W, Hd = v.H, Dd = v.D;
+          std::vector<int> hc(v.cout, 0), hx(32, 0), hy(8, 0), hz(8, 0);
+          int shown = 0;
+          for (size_t i = 0; i < nout; ++i) {
+            if (memcmp(&got[i], &ref[i], 4) == 0) continue;
+            const int x = (int)(i % Wd), y = (int)((i / Wd) % Hd), z = (int)((i / ((size_t)Wd * Hd)) % Dd), ch = (int)(i / ((size_t)Wd * Hd * Dd));
+            ++hc[ch]; ++hx[x % 32]; ++hy[y % 8]; ++hz[z % 8];
+            if (shown++ < 12) printf("    c %d z %d y %d x %d: got %.6g want %.6g diff %.3g\n", ch, z, y, x, got[i], ref[i], got[i] - ref[i]);
+          }
+          printf("    by channel:"); for (int e : hc) printf(" %d", e);
+          printf("\n    by x %% 32:"); for (int e : hx) printf(" %d", e);
+          printf("\n    by y %% 8:"); for (int e : hy) printf(" %d", e);
+          printf("\n    by z %% 8:"); for (int e : hz) printf(" %d", e);
+          printf("\n");
+        }
       }
       printf("victim %-3s (kind %d, %d -> %d, %dx%dx%d) beside %-8s: %4d of %4d rounds differ from the solo run", v.name, v.kind, v.cin, v.cout, v.D, v.H, v.W, nnames[k], bad, rounds);
       if (bad) printf("  (%llu wrong values)", wrong);
