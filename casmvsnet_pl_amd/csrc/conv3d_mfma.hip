@@ -41,6 +41,12 @@
 
 namespace {
 
+#ifndef CASMVS_MFMA_HOLD
+#define CASMVS_MFMA_HOLD 0
+#endif
+#ifndef CASMVS_PX_EXP
+#define CASMVS_PX_EXP 0   // co-residency experiments on the PX epilogue (tools/build_variant.py)
+#endif
 #ifndef CASMVS_MFMA_DRAIN_NOPS
 #define CASMVS_MFMA_DRAIN_NOPS 0
 #endif
@@ -1015,6 +1021,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       constexpr int i = decltype(i_)::value;
       ring[i] = bptr[b_tile(i)][RD + b_off(i)];
     });
+    // operand hold (CASMVS_MFMA_HOLD = K steps, 0 = off): a matrix instruction's A / B registers stay allocated for K further steps
+    [[maybe_unused]] float held_b[CASMVS_MFMA_HOLD > 0 ? CASMVS_MFMA_HOLD : 1], held_a[NA];
     // one flattened, fully unrolled loop over the NITER * NS steps: every index and every LDS
     // offset below is a compile-time constant
     static_for<TOTAL_STEPS>([&](auto g_) {
@@ -1028,7 +1036,42 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       }
       const float bcur = ring[g % P];
       ring[g % P] = bptr[b_tile(g + P)][RD + b_off(g + P)];
+#if CASMVS_PX_EXP == 3   // co-residency experiment: accumulators IN PLACE (destination tied to srcC) - the compiler renames the last round of a chunk so that an
+                         // MFMA's destination is the srcC of the MFMA issued just before it
+      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(a_cur[a]), "v"(bcur));
+#else
       acc[t] = mfma16(a_cur[a], bcur, acc[t]);
+#endif
+#if CASMVS_MFMA_HOLD > 0
+      {
+        constexpr int K = CASMVS_MFMA_HOLD;
+        if constexpr (g >= K - 1) asm volatile("" ::"v"(held_b[(g + 1) % K]));   // the B operand consumed K - 1 steps ago: only now may its register be reloaded
+        held_b[g % K] = bcur;
+        if constexpr (it > 0 && i == (K - 1 < NS - 1 ? K - 1 : NS - 1)) {
+#pragma unroll
+          for (int aa = 0; aa < NA; ++aa) asm volatile("" ::"v"(held_a[aa]));         // the previous iteration's A operands
+        }
+        if constexpr (i == NS - 1) {
+#pragma unroll
+          for (int aa = 0; aa < NA; ++aa) held_a[aa] = a_cur[aa];
+        }
+      }
+#endif
+#if CASMVS_PX_EXP == 4 || (CASMVS_PX_EXP == 10 && 0)
+      asm volatile("s_nop 7" ::: "memory");
+#elif CASMVS_PX_EXP == 10   // eight wait states behind every matrix instruction of the Cout = 8 (PX) form only
+      if constexpr (MODE == FMT_PX) asm volatile("s_nop 7" ::: "memory");
+#elif CASMVS_PX_EXP == 5
+      asm volatile("s_nop 1" ::: "memory");
+#elif CASMVS_PX_EXP == 6
+      asm volatile("s_nop 3" ::: "memory");
+#elif CASMVS_PX_EXP == 7   // only in the steps that carry staging work (a global load or an LDS store of the next chunk)
+      if constexpr ((g >= 1 && g <= NOPS) || (g >= ST0 && (g - ST0) % SST == 0 && (g - ST0) / SST < NOPS)) asm volatile("s_nop 7" ::: "memory");
+#elif CASMVS_PX_EXP == 8   // only in the steps WITHOUT staging work
+      if constexpr (!((g >= 1 && g <= NOPS) || (g >= ST0 && (g - ST0) % SST == 0 && (g - ST0) / SST < NOPS))) asm volatile("s_nop 7" ::: "memory");
+#elif CASMVS_PX_EXP == 9   // only behind the last matrix instruction of a group of NT (the next group switches the A operand)
+      if constexpr (t == NT - 1) asm volatile("s_nop 7" ::: "memory");
+#endif
       // ---- side work in this step's spare issue slots ----
       // (issued unconditionally - a dead set loads with out-of-range offsets and its stores land in
       // the buffer nobody reads - so that the code stays branch-free and the compiler can emit
@@ -1047,6 +1090,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
     if (++cur_chunk == nstages) {  // tile finished: epilogue, then switch to the next tile
 #pragma unroll
       for (int dn = 0; dn < CASMVS_MFMA_DRAIN_NOPS; ++dn) asm volatile("s_nop 15");   // debug builds (co-residency experiment)
+#if CASMVS_PX_EXP == 3
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the compiler does not know the statements above are matrix instructions: no hazard padding of its own)
+#endif
+#if CASMVS_PX_EXP == 1   // co-residency experiment: nothing pending (vector memory, LDS, scalar loads) when the epilogue starts
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
       const rsrc_t dst = make_rsrc(out + cur.b * out_ss, out_ss * 4);
       const rsrc_t skp = make_rsrc((skip && !OUT2) ? skip + cur.b * out_ss : out, out_ss * 4);
       [[maybe_unused]] const rsrc_t d2 = make_rsrc(OUT2 ? const_cast<float *>(skip) + cur.b * out_ss : out, out_ss * 4);
@@ -1063,7 +1112,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
           const int voff = ok ? (2 * kq * out_cs + (oz * Ho + oy) * Wo + ox) * 4 : kOOB;
           [[maybe_unused]] float o2[2][2];  // [x phase][channel 2*kq + h]
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
+          for (int hh = 0; hh < 2; ++hh) {
+            const int h = CASMVS_PX_EXP == 2 ? 1 - hh : hh;   // (experiment 2: channel 2 kq + 1 first)
             float v0 = fmaf(av[2 * h], sc[h % NCO], sh[h % NCO]);
             float v1 = fmaf(av[2 * h + 1], sc[h % NCO], sh[h % NCO]);
             v0 = v0 > 0.0f ? v0 : v0 * slope;
