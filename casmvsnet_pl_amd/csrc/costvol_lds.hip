@@ -23,6 +23,7 @@
 //      global map by that lane alone: the result never depends on the box;
 //   4. the plane's C values per pixel leave through a wave-private LDS transpose as 16-byte stores.
 // Results are bit-identical to the gather kernels (same operations in the same order per channel).
+#include <algorithm>
 #include <climits>
 
 #include "common.h"
@@ -79,6 +80,7 @@ struct SweepArgs {
   int nviews_total;    // V of the variance formula / V - 1 of the correlation (final modes)
   int G, h, w, D;
   int tiles_x, tiles, tiles_per_xcd;
+  int B;               // batch elements (the persistent workgroups walk (batch element, tile, chunk, split) items)
   int cap_units;       // LDS capacity of one view's box in 16-byte units
   int ablate;          // profiling build only (-DCASMVS_TRACE): bit 0 no volume stores, 1 no LDS tap reads, 2 taps of plane 0, 3 stores only
 };
@@ -383,35 +385,73 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
   // ---- work item ----------------------------------------------------------------------------------------
   // XCD-aware order (block b runs on XCD b % 8; speed only): XCD k owns the tiles [k, k + 1) * tiles_per_xcd,
   // and all depth chunks / channel splits of a tile - which read the same source region - are adjacent.
+  // PERSISTENT workgroups (round 5): the launch holds as many workgroups as the chip keeps resident; each walks the items seq, seq + step, ... of its XCD and
+  // loads the NEXT item's first / last hypotheses before it enters the plane loop of the current one: the box extents of the next item - the head of the
+  // prologue's chain depth -> extents -> boxes -> staging, two dependent memory round trips, a third of an item's time - start without waiting for memory.
   const int nchunk = a.D / DC;
   const int inner = nchunk * NSPLIT;
-  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int tile_local = seq / inner, rem = seq - tile_local * inner;
-  const int tile = xcd * a.tiles_per_xcd + tile_local;
-  if (tile >= a.tiles) return;
-  const int d0 = (rem / NSPLIT) * DC, c0 = (rem % NSPLIT) * CS;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-  const int b = blockIdx.y;
+  const int xcd = blockIdx.x & 7;
+  const int per_xcd = a.tiles_per_xcd * inner;   // work items of one batch element on this XCD (tiles past a.tiles are empty slots)
+  const int n_seq = per_xcd * a.B, seq_step = gridDim.x >> 3;
   const int h = a.h, w = a.w, hw = h * w, D = a.D;
   const int nv = NV > 0 ? NV : a.nv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tp = tid % kThreads, pg = tid / kThreads;   // pixel of the tile, plane group
+  const size_t view_floats = (size_t)hw * C;
+  const int view_bytes = uniform_int((int)(view_floats * 4));
+  struct Item {
+    int b, tile, d0, c0;
+    bool live;
+  };
+  auto decode = [&](int sq) {
+    Item it;
+    it.live = sq < n_seq;
+    const int sqc = it.live ? sq : 0;
+    it.b = sqc / per_xcd;
+    const int sl = sqc - it.b * per_xcd;
+    const int tile_local = sl / inner, rem = sl - tile_local * inner;
+    it.tile = xcd * a.tiles_per_xcd + tile_local;
+    it.live = it.live && it.tile < a.tiles;
+    it.d0 = (rem / NSPLIT) * DC;
+    it.c0 = (rem % NSPLIT) * CS;
+    return it;
+  };
+  // the chunk's first / last hypothesis of this thread's pixel in item `it` (zeros through an empty descriptor for an empty slot)
+  auto load_end_depths = [&](const Item &it, float &first, float &last) {
+    const int ty_ = it.tile / a.tiles_x, tx_ = it.tile - ty_ * a.tiles_x;
+    const int px_ = tx_ * TW + tp % TW, py_ = ty_ * TH + tp / TW;
+    const int pcl_ = (px_ < w && py_ < h) ? py_ * w + px_ : 0;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(uniform_ptr(a.depth + (size_t)(it.live ? it.b : 0) * D * hw)), 0,
+                                                                        uniform_int(it.live ? D * hw * 4 : 0), 0x00020000);
+    first = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pcl_ * 4, uniform_int(it.d0 * hw * 4), 0));
+    last = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, pcl_ * 4, uniform_int((it.d0 + DC - 1) * hw * 4), 0));
+  };
+  int seq = blockIdx.x >> 3;
+  Item cur = decode(seq);
+  float dv_first_pf, dv_last_pf;
+  load_end_depths(cur, dv_first_pf, dv_last_pf);
+  for (; seq < n_seq; seq += seq_step) {
+  const Item nxt = decode(seq + seq_step);
+  const float dv_first = dv_first_pf, dv_last = dv_last_pf;
+  if (!cur.live) {   // an empty slot (workgroup-uniform): nothing to do, the next item's hypotheses still have to be requested
+    load_end_depths(nxt, dv_first_pf, dv_last_pf);
+    cur = nxt;
+    continue;
+  }
+  const int tile = cur.tile, d0 = cur.d0, c0 = cur.c0, b = cur.b;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int px = tx * TW + tp % TW, py = ty * TH + tp / TW;
   const bool valid = px < w && py < h;
   const int pcl = valid ? py * w + px : 0;
   const float xf = (float)px, yf = (float)py;
-  const size_t view_floats = (size_t)hw * C;
-  const int view_bytes = uniform_int((int)(view_floats * 4));
   const float *fb = uniform_ptr(a.feats + (size_t)b * a.Vtot * view_floats);
   const float *pb = uniform_ptr(a.proj + ((size_t)b * a.pstride + a.pv0) * 12);
 
-  // depth hypotheses of this pixel: the chunk's first and last plane now (boxes), the others one plane ahead
+  // depth hypotheses of this pixel: the chunk's first and last plane were requested one item ahead (boxes), the others one plane ahead
   // inside the plane loop (a load issued BEFORE a plane's volume stores only waits for the stores of the plane
   // before: gfx9's vmcnt is in order - and it costs one register instead of DC)
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(uniform_ptr(a.depth + (size_t)b * D * hw)), 0, uniform_int(D * hw * 4), 0x00020000);
-  const float dv_first = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int(d0 * hw * 4), 0));
-  const float dv_last = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, pcl * 4, uniform_int((d0 + DC - 1) * hw * 4), 0));
 
   // ---- every global load the prologue and the plane loop need is issued HERE, together: the matrices, the reference
   // features, the chunk's depths.  (Round 2 issued them where they were used: three exposed memory latencies -
@@ -658,6 +698,7 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
   // for the depth registers in EVERY iteration - and vmcnt(0) also waits for the previous plane's volume stores.
   __builtin_amdgcn_s_waitcnt(0x0f70);
 #endif
+  load_end_depths(nxt, dv_first_pf, dv_last_pf);   // the next item's box extents will not wait for memory (consumed behind this item's plane loop)
   CV_STAMP();   // 6: plane loop begins
 #pragma unroll 1
   for (int k = k0; k < k0 + KP; ++k) {
@@ -750,6 +791,9 @@ __global__ __launch_bounds__(kThreads * PG, waves_per_simd(CS, MODE, PG)) void c
   __builtin_amdgcn_s_waitcnt(0x0f70);
   CV_STAMP();   // last: this wave's stores acknowledged
 #endif
+  cur = nxt;
+  __syncthreads();   // every wave is out of the plane loop: the boxes and the box table may be rewritten
+  }   // items
 }
 
 // sum / sum-of-squares -> variance (mvsnet.py:167), and the scaling of the all-reduced correlation
@@ -773,6 +817,20 @@ __global__ __launch_bounds__(kThreads) void gwc_finalize_kernel(const f32x4 *__r
   if (i >= n4) return;
   const f32x4 s = in[i];
   out[i] = f32x4{s[0] / fv, s[1] / fv, s[2] / fv, s[3] / fv};
+}
+
+bool g_persistent = true;   // (internal linkage; false = one workgroup per item as before round 5: the A/B switch of the trace build, CASMVS_CV_PERSIST=0)
+int compute_units() {
+#ifdef HIPEMU_LDS_BYTES
+  return 8;   // (tests/hipemu: one CU per XCD, so that its small volumes give every workgroup several items)
+#else
+  static const int n = [] {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 8) cu = 256;
+    return cu;
+  }();
+  return n;
+#endif
 }
 
 struct Plan {
@@ -822,7 +880,14 @@ int launch_dc(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
   auto kernel = costvol_lds_kernel<C, CS, MODE, TW, DC, NV, PG>;
   if (int rc = casmvs::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), 158 * 1024, "costvol_lds_kernel")) return rc;
   const int inner = (a.D / DC) * (C / CS);
-  dim3 grid((unsigned)(8 * a.tiles_per_xcd * inner), (unsigned)B);
+  // persistent launch: per XCD as many workgroups as its CUs keep resident (registers: waves_per_simd; LDS: the plan's budget follows the same number),
+  // or one per work item when there are fewer
+  const long items_per_xcd = (long)a.tiles_per_xcd * inner * B;
+  const long resident_per_xcd = (long)(compute_units() / 8) * (waves_per_simd(CS, MODE, PG) / PG);
+  const long wg_per_xcd = g_persistent ? std::min(items_per_xcd, resident_per_xcd) : items_per_xcd;
+  CASMVS_REQUIRE(8 * wg_per_xcd <= 0x7fffffffL, "costvol_lds: too many workgroups");
+  dim3 grid((unsigned)(8 * wg_per_xcd), 1u);
+  (void)B;
   hipLaunchKernelGGL(kernel, grid, dim3(kThreads * PG), (size_t)p.lds_bytes, st, a);
   return casmvs::check_launch("costvol_lds_kernel");
 }
@@ -893,6 +958,10 @@ int launch_mode(SweepArgs a, int C, int B, hipStream_t st, const char *what) {
       p = p16;
   }
   a.tiles_per_xcd = casmvs::ceil_div(a.tiles, 8);
+  a.B = B;
+#ifdef CASMVS_TRACE
+  if (const char *e = getenv("CASMVS_CV_PERSIST")) g_persistent = atoi(e) != 0;
+#endif
   a.cap_units = p.cap_units;
   a.ablate = 0;
 #ifdef CASMVS_TRACE

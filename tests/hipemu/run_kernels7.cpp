@@ -124,6 +124,9 @@ int main(int argc, char **argv) {
   const bool all = which == "all", quick = which == "quick";
   if (all || quick) take(costvol_check(1, 3, 8, 8, 10, 64, 0.6f));     // C = 8: 64 x 4 tiles, two full tile rows + a ragged one
   if (all || quick) take(costvol_check(1, 3, 16, 8, 12, 36, 0.6f));    // C = 16: 32 x 8 tiles, ragged in x and y
+  // persistent workgroups: 4 tiles x 2 chunks x 2 batch elements on the emulation's one-CU-per-XCD chip = every workgroup walks two items (and the XCDs
+  // without a tile walk empty slots); under ThreadSanitizer: the barrier between an item's plane loop and the next item's box table / staging
+  if (all || quick) take(costvol_check(2, 3, 16, 16, 9, 40, 0.6f));
   if (all || quick || which == "warp") take(warp_nchw_check(1, 8, 8, 10, 64, 0.6f));    // C = 8 (unit(px) = 2 px + px / 8), ragged rows
   if (all || which == "warp") { take(warp_nchw_check(2, 16, 8, 12, 36, 0.6f)); take(warp_nchw_check(1, 32, 8, 9, 32, 1.5f)); }
   if (all || quick) {   // 16 planes per workgroup (production: only where the launch keeps >= 4 rounds of workgroups)
