@@ -503,7 +503,7 @@ def test_sgd_steps_track_the_float64_oracle_and_reduce_the_loss(dev, report):
     want = R.sgd_train_steps(sd0, imgs, proj, dmin, dint, gt, steps=4, abs_weight_eps=1e-5)
     rel = [abs(a - b) / b for a, b in zip(losses, want)]
     report("train_sgd_steps", losses=[round(x, 3) for x in losses], oracle_float64=[round(x, 3) for x in want], rel_to_oracle=rel)
-    assert all(r < tol for r, tol in zip(rel, (1e-4, 3e-4, 1e-2, 5e-2))), (rel, losses, want)
+    assert all(r < tol for r, tol in zip(rel, (1e-4, 1e-3, 1e-2, 5e-2))), (rel, losses, want)   # measured 3.8e-7 / 1.6e-4 / 1.2e-3 / 1.4e-2 (the same bits on every run)
     assert losses[-1] < 0.5 * losses[0], losses
     # and the trained weights serve the eval-mode engine (packed images are rebuilt from the updated parameters)
     model.eval()

@@ -118,3 +118,34 @@ def test_sum4_window_and_index():
     want = sum(float(p[k]) for k in range(i - 1, i + 3) if 0 <= k < D) / float(p.sum())
     assert abs(float(conf) - want) < 1e-6
     assert abs(float(depth) - (10.0 + 2.0 * e)) < 1e-4
+
+
+def test_sgd_restatement_equals_torch_optim_sgd():
+    """oracle.cpu_restatement.sgd_train_steps (what the GPU training test compares the engine's loss trajectory with) restates torch.optim.SGD(lr, momentum,
+    weight_decay) - the reference's default optimiser (opt.py:40-47, utils/__init__.py:12-14) - around the train-mode oracle: three steps in float64 against
+    torch.optim.SGD itself on the same graph, loss for loss, with the InPlaceABN parametrisation |weight| + eps of train.py:41."""
+    import torch.nn.functional as F
+    from casmvsnet_pl_amd import CascadeMVSNet, InPlaceABN
+    from casmvsnet_pl_amd.synthetic import make_inputs, randomize_state_dict
+    model = CascadeMVSNet(norm_act=InPlaceABN)
+    sd0 = {k: v.clone() for k, v in randomize_state_dict(model.state_dict(), seed=4).items()}
+    imgs, proj, dmin, dint = make_inputs(1, 3, 32, 64, seed=2)
+    g = torch.Generator().manual_seed(1)
+    gt = {l: 560.0 + 30.0 * torch.randn(1, 32 >> l, 64 >> l, generator=g) for l in range(3)}
+    got = R.sgd_train_steps(sd0, imgs, proj, dmin, dint, gt, steps=3, abs_weight_eps=1e-5)
+    params = {k: v.clone().double().requires_grad_(True) for k, v in sd0.items() if v.dtype.is_floating_point and "running" not in k}
+    bufs = {k: (v.clone().double() if v.dtype.is_floating_point else v.clone()) for k, v in sd0.items() if k not in params}
+    opt = torch.optim.SGD(list(params.values()), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+    want = []
+    for _ in range(3):
+        opt.zero_grad()
+        sd = dict(bufs)
+        for k, p in params.items():
+            sd[k] = (p.abs() + 1e-5) if (k.endswith(".weight") and p.dim() == 1) else p
+        out = R.cascade_forward_train(sd, imgs.double(), proj.double(), dmin, dint)
+        loss = sum(F.smooth_l1_loss(out[f"depth_{l}"], gt[l].double()) * 2 ** (1 - l) for l in range(3))
+        loss.backward()
+        opt.step()
+        want.append(float(loss.detach()))
+    assert len(got) == 3 and all(abs(a - b) <= 1e-9 * abs(b) for a, b in zip(got, want)), (got, want)
+    assert want[1] < want[0]
