@@ -899,8 +899,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   }
   const float *aptr = smem + CK * SC + lane;
   f32x4 acc[NT];
+  // co-residency experiment 11: the accumulators start at 1024 (first tile) / 2048 (every later tile) and the epilogue subtracts that base: a wrong
+  // output then says whether the register held 0, its start value, or a sum
+  constexpr float kAccInit = CASMVS_PX_EXP == 11 ? 1024.f : 0.f, kAccReset = CASMVS_PX_EXP == 11 ? 2048.f : 0.f;
+  [[maybe_unused]] float px_snap = 0.f;   // experiments 13 / 14: accumulator [0][2] part-way through the last chunk
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{kAccInit, kAccInit, kAccInit, kAccInit};
 
   const int in_cs = Di * Hi * Wi, out_cs = Do * Ho * Wo;
   const size_t in_ss = (size_t)cin * in_cs, out_ss = (size_t)cout * out_cs;
@@ -926,7 +930,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   // flattened, so the look-ahead may span iterations: the small tiles (NS = 1, 2) get 8 steps too.
   // (NS = 4 keeps P = 4: 8 measured no faster and costs the wide CI tile a wave of occupancy.)
   constexpr int P = NS % 8 == 0 ? 8 : (NS % 4 == 0 ? 4 : (TOTAL_STEPS >= 16 ? 8 : 2));
-  constexpr auto b_tile = [](int g) constexpr -> int { return ((g < TOTAL_STEPS ? g : TOTAL_STEPS - 1) % NS) % NT; };
+  // (co-residency experiment 12: the column tiles of a group in the order NT - 1 .. 0)
+  constexpr auto t_of = [](int i) constexpr -> int { return CASMVS_PX_EXP == 12 ? NT - 1 - i % NT : i % NT; };
+  constexpr auto b_tile = [t_of](int g) constexpr -> int { return t_of((g < TOTAL_STEPS ? g : TOTAL_STEPS - 1) % NS); };
   constexpr auto b_off = [it_off](int g) constexpr -> int {
     const int gg = g < TOTAL_STEPS ? g : TOTAL_STEPS - 1;  // beyond the chunk: harmless re-read of the last operand
     return it_off(gg / NS) + ((gg % NS) / NT) * ASTEP;
@@ -1028,7 +1034,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
     static_for<TOTAL_STEPS>([&](auto g_) {
       constexpr int g = decltype(g_)::value;
       constexpr int it = g / NS, i = g % NS;
-      constexpr int a = i / NT, t = i % NT;
+      constexpr int a = i / NT, t = t_of(i);
       constexpr int itn = it < NITER - 1 ? it + 1 : NITER - 1;
       if constexpr (i == 0) {
 #pragma unroll
@@ -1056,6 +1062,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
           for (int aa = 0; aa < NA; ++aa) held_a[aa] = a_cur[aa];
         }
       }
+#endif
+#if CASMVS_PX_EXP == 13   // accumulator [0][2] half-way through the chunk (the last chunk's value reaches the epilogue)
+      if constexpr (MODE == FMT_PX && g == TOTAL_STEPS / 2) px_snap = acc[0][2];
+#elif CASMVS_PX_EXP == 14   // ... right in front of the chunk's last matrix instruction into accumulator 0
+      if constexpr (MODE == FMT_PX && g == TOTAL_STEPS - NT) px_snap = acc[0][2];
 #endif
 #if CASMVS_PX_EXP == 4 || (CASMVS_PX_EXP == 10 && 0)
       asm volatile("s_nop 7" ::: "memory");
@@ -1104,8 +1115,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
         const int ct = wave * NT + t;
         const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
         const int oz = cur.tz0 + cz, oy = cur.ty0 + cy;
-        const f32x4 av = acc[t];
-        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 av = acc[t];
+        if constexpr (CASMVS_PX_EXP == 11) av -= (tiles_done == 0 ? kAccInit : kAccReset);
+        if constexpr ((CASMVS_PX_EXP == 13 || CASMVS_PX_EXP == 14) && MODE == FMT_PX) {
+          if (t == 0) av[3] = px_snap;   // the odd-x output of channel 2 kq + 1 carries the snapshot of the even-x accumulator
+        }
+        acc[t] = f32x4{kAccReset, kAccReset, kAccReset, kAccReset};
         if (MODE == FMT_PX) {
           const int ox = cur.tx0 + cx * 32 + 2 * jcol;
           const bool ok = oz < Do && oy < Ho && ox < Wo;  // Wo % 4 == 0 here: the pair is in range
@@ -1114,8 +1129,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             const int h = CASMVS_PX_EXP == 2 ? 1 - hh : hh;   // (experiment 2: channel 2 kq + 1 first)
+#if CASMVS_PX_EXP == 16   // co-residency experiment: EVERY column tile's channel 2 kq + 1 through the packed form the compiler picks for tile 0 only
+            float v0, v1;
+            if (h == 1) {
+              const f32x2 a2{av[2], av[3]}, s2{sc[0], sc[1]}, b2{sh[0], sh[1]};
+              f32x2 r2;
+              asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1]" : "=&v"(r2) : "v"(a2), "v"(s2), "v"(b2));
+              v0 = r2[0];
+              v1 = r2[1];
+            } else {
+              v0 = fmaf(av[0], sc[0], sh[0]);
+              v1 = fmaf(av[1], sc[0], sh[0]);
+            }
+#else
             float v0 = fmaf(av[2 * h], sc[h % NCO], sh[h % NCO]);
+#if CASMVS_PX_EXP == 15   // co-residency experiment: the two multiply-adds of a pair as two scalar instructions (no v_pk_fma_f32)
+            asm volatile("" : "+v"(v0));
+#endif
             float v1 = fmaf(av[2 * h + 1], sc[h % NCO], sh[h % NCO]);
+#endif
             v0 = v0 > 0.0f ? v0 : v0 * slope;
             v1 = v1 > 0.0f ? v1 : v1 * slope;
             const int soff = h * out_cs * 4;
