@@ -10,8 +10,8 @@ reference views batched like the reference's train.py --batch_size; `--batch 1` 
 printed as "batch1", with its own roofline objects) with their source views: DTU 640x512, 3 views, n_depths [8,32,48], variance
 cost volume, float32 tensors, synthetic inputs already resident in HBM, random-init weights.  The timed steps replay the forward as
 ONE hipGraph on ONE stream (casmvsnet_pl_amd/graph.py; `--no-graph` launches kernel by kernel).  `--streams N` > 1 puts N independent
-forwards in flight, each on its own HIP stream - those replicas run every layer on the float32 MFMA kernels (graph.ConcurrentForwards);
-that configuration (2 streams x batch 2) is measured and printed beside the headline as `two_streams_float32`.
+forwards of --batch views in flight, each on its own HIP stream with the model's own split-f16 layers (graph.ConcurrentForwards); the default
+line carries that launch as `two_streams` (2 x half the batch) and `batch1.two_streams` (2 x 1 view: the eval.py loop two views at a time).
 
 `value` = depth maps of all ranks / the max-over-ranks wall time of EXACTLY K steps (barrier + synchronize on both
 sides); `median_ms_per_step` (the median of the timed iterations) comes from one HIP event per step recorded
@@ -605,12 +605,13 @@ def main():
     ap.add_argument("--mode", default="replica", choices=["replica", "view_sharded", "train"])
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying one hipGraph")
     ap.add_argument("--streams", type=int, default=1,
-                    help="independent forwards in flight per GPU, one HIP stream + hipGraph each (a step = one round of all of them).  Default 1: "
-                         "with more than one stream every layer runs on the float32 MFMA kernels (graph.ConcurrentForwards: f16 / bf16 matrix "
-                         "instructions beside another stream's float32 matrix instructions corrupt the latter on the MI355X); that configuration "
-                         "(2 streams x batch 2, float32) is measured and printed beside the headline as `two_streams_float32`.")
-    ap.add_argument("--unsafe-mixed-streams", action="store_true",
-                    help="experiments only: with --streams > 1 keep the split-f16 / split-bf16 layers in the replicas (results are NOT reliable)")
+                    help="independent forwards in flight per GPU, one HIP stream + hipGraph each (a step = one round of all of them; --batch is per "
+                         "forward).  The replicas keep the model's split-f16 layers: the library carries no packed-float32 instruction of the class that "
+                         "is wrong beside f16 matrix instructions on the MI355X (casmvsnet_pl_amd/streams.py).  With the default single stream, 2 "
+                         "streams x half the batch and 2 streams x batch 1 are measured beside the headline (`two_streams`, `batch1.two_streams`).")
+    ap.add_argument("--float32-replicas", action="store_true",
+                    help="with --streams > 1: every layer of the replicas on the float32 MFMA kernels (the round 2-4 configuration)")
+    ap.add_argument("--unsafe-mixed-streams", action="store_true", help="(obsolete: the replicas keep the split-f16 layers by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stock-pytorch", action="store_true",
                     help="also time the restated reference forward on stock PyTorch-ROCm operators on this GPU (adds ~1 min of MIOpen search)")
@@ -697,8 +698,8 @@ def main():
             model(imgs, proj, dmin, dint)
         use_graph = not args.no_graph and not view_sharded   # a collective inside a capture is not attempted
         if use_graph and streams > 1:
-            cf = ConcurrentForwards(model, imgs, proj, dmin, dint, n_streams=streams, mixed_matrix_types=args.unsafe_mixed_streams)
-            if not args.unsafe_mixed_streams:   # what the replicas run (and what the instrumented pass below should time)
+            cf = ConcurrentForwards(model, imgs, proj, dmin, dint, n_streams=streams, mixed_matrix_types=False if args.float32_replicas else None)
+            if not cf.mixed_matrix_types:   # what the replicas run (and what the instrumented pass below should time)
                 for l in range(3):
                     getattr(model, f"cost_reg_{l}").conv0_mode = getattr(model, f"cost_reg_{l}").ci_mode = "f32"
                 model.feature.tail_mode = "f32"
@@ -784,19 +785,20 @@ def main():
     del model
     # ---- one forward per step (no concurrency), and the reference's eval.py loop: one reference view per step --------
     if NS > 1:
-        _, _, els, ms1, med1, _ = measure(B, K, max(2, args.warmup // 2), 1)
+        _, _, els, ms1, med1, _ = measure(B * NS, K, max(2, args.warmup // 2), 1)
         if rank == 0:
             line["single_stream"] = {"value": ms1 / els, "unit": "depth-maps/s", "ms_per_step": 1e3 * els / K, "median_ms_per_step": med1, "steps": K,
-                                     "note": f"one forward of batch {B} per step (one stream, one hipGraph replay)"}
-    if NS == 1 and used_graph and not args.no_batch1 and (args.conv0_mode or "splitf16") != "f32":
-        # round 2's launch configuration: two concurrent forwards of batch 2, which must run all-float32 (graph.ConcurrentForwards)
-        _, _, el2, ms2, med2, _ = measure(2, K, max(2, args.warmup // 2), 2)
+                                     "note": f"the same {B * NS} depth maps per step as ONE forward (one stream, one hipGraph replay)"}
+    if NS == 1 and used_graph and not args.no_batch1 and B % 2 == 0:
+        # the same depth maps per step as TWO concurrent forwards of half the batch (graph.ConcurrentForwards: the split-f16 layers on both streams)
+        _, _, el2, ms2, med2, _ = measure(B // 2, K, max(2, args.warmup // 2), 2)
         if rank == 0:
-            line["two_streams_float32"] = {"value": ms2 / el2, "unit": "depth-maps/s", "ms_per_step": 1e3 * el2 / K, "median_ms_per_step": med2, "steps": K,
-                                           "note": "2 independent forwards of batch 2 per step, one hipGraph + HIP stream each, every layer on the float32 MFMA "
-                                                   "kernels: f16 / bf16 matrix instructions of one stream's kernels corrupt the float32 matrix instructions "
-                                                   "of the other's when they share a SIMD (profiles/r03_mfma_coresidency.txt), so the split-f16 layers "
-                                                   "are used in single-stream launches only"}
+            line["two_streams"] = {"value": ms2 / el2, "unit": "depth-maps/s", "ms_per_step": 1e3 * el2 / K, "median_ms_per_step": med2, "steps": K,
+                                   "note": f"2 independent forwards of batch {B // 2} per step, one hipGraph + HIP stream each, the model's own (split-f16) layers on both "
+                                           "streams; rounds 2-4 had to run such replicas all-float32 (705 depth-maps/s): float32 kernels returned wrong values beside "
+                                           "another stream's f16 matrix instructions - one packed-float32 instruction form (tools/probes/pk_fma_opsel_repro.hip), which "
+                                           "the library is now assembled without (casmvsnet_pl_amd/build.py); bit equality with the single-stream forward: "
+                                           "tests/test_gpu_system.py, tools/gpu_mixed_streams.py"}
     if not args.no_batch1:   # the same configuration with conv0 in the OTHER arithmetics, beside the headline (not instead of it)
         this_mode = args.conv0_mode or "splitf16"
         others = []
@@ -825,11 +827,13 @@ def main():
                     if k in r1:
                         line["batch1"][k] = r1[k]
         del m1
-        if NS > 1:
-            _, _, el1s, mp1s, _, _ = measure(1, K, max(2, args.warmup // 2), NS)
+        if g1:
+            n1 = max(2, NS)
+            _, _, el1s, mp1s, _, _ = measure(1, K, max(2, args.warmup // 2), n1)
             if rank == 0:
-                line["batch1"]["concurrent"] = {"value": mp1s / el1s, "unit": "depth-maps/s", "ms_per_step": 1e3 * el1s / K,
-                                                "note": f"{NS} single-view forwards in flight, one stream each"}
+                line["batch1"]["two_streams" if n1 == 2 else "concurrent"] = {
+                    "value": mp1s / el1s, "unit": "depth-maps/s", "ms_per_step": 1e3 * el1s / K,
+                    "note": f"{n1} single-view forwards in flight, one stream + hipGraph each (the eval.py loop over independent reference views, two at a time)"}
     if world == 1 and args.mode == "replica" and args.config == HEADLINE and not args.no_train_step:
         # f-2 (train.py:99-127) in the driver's line: the batch-1 training step as one hipGraph replay, 20 timed replays (~0.3 s)
         torch.cuda.empty_cache()

@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # CASMVS_LIB_PATH: load another BUILD of the same library (profiling: -DCASMVS_TRACE, compiler-flag A/B runs)
 LIB_PATH = os.environ.get("CASMVS_LIB_PATH") or os.path.join(_PKG_DIR, "libcasmvs_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
 CONV2D_K3, CONV2D_K5S2, CONV2D_K1, CONV2D_K1_UP = 3, 4, 5, 6
@@ -21,6 +21,7 @@ CONV2D_K3, CONV2D_K5S2, CONV2D_K1, CONV2D_K1_UP = 3, 4, 5, 6
 _FP = c_void_p  # device / host float* passed as integer addresses
 SYMBOLS = {
     "casmvs_abi_version": (c_int, []),
+    "casmvs_packed_opsel_safe": (c_int, []),
     "casmvs_last_error": (c_char_p, []),
     "casmvs_depth_hypotheses_f32": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "casmvs_homo_warp_f32": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -29,6 +29,7 @@ IO_HEADERS = [os.path.join(REPO_ROOT, "include", "casmvs_io.h")]
 IO_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra"]
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+# (+ -DCASMVS_PACKED_OPSEL_SAFE=1 on every source: _compile_source rewrites the device assembly, and casmvs_packed_opsel_safe() says so)
 
 
 # ---- the packed-float32 operand-selection fault of gfx950 (tools/probes/pk_fma_opsel_repro.hip) -------------------------
@@ -99,6 +100,7 @@ def _compile_source(hipcc, flags, inc, src, obj, verbose=False):
         if res.returncode != 0:
             raise RuntimeError(f"build step failed on {src}:\n{' '.join(cmd)}\n{res.stdout}")
 
+    flags = list(flags) + ["-DCASMVS_PACKED_OPSEL_SAFE=1"]
     run([hipcc] + flags + inc + ["--cuda-device-only", "-S", src, "-o", stem + ".s"])
     with open(stem + ".s") as f:
         text, count = rewrite_unsafe_packed(f.read())

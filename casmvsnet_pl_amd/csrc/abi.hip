@@ -69,4 +69,9 @@ int resident_blocks(const void *kernel, int threads, size_t lds_bytes) {
 
 extern "C" int casmvs_abi_version(void) { return CASMVS_ABI_VERSION; }
 
+#ifndef CASMVS_PACKED_OPSEL_SAFE
+#define CASMVS_PACKED_OPSEL_SAFE 0   // casmvsnet_pl_amd/build.py defines 1: it assembles the device code with the unsafe packed-float32 forms rewritten
+#endif
+extern "C" int casmvs_packed_opsel_safe(void) { return CASMVS_PACKED_OPSEL_SAFE; }
+
 extern "C" const char *casmvs_last_error(void) { return casmvs::error_buffer(); }

@@ -15,6 +15,13 @@
 #define CASMVS_DYNAMIC_LDS(T, name) extern __shared__ T name[]
 #endif
 
+// LDS request floor of the split-f16 kernels whose own need is below 56 KiB: at most two workgroups (two waves per SIMD) per CU.  Rounds 3-4 chose it
+// because float32 staging arithmetic beside two waves' f16 matrix instructions came out wrong (lanes 48-63) - the packed-float32 op_sel fault that
+// casmvsnet_pl_amd/build.py now assembles away; kept as the measured-best occupancy (profiles/r05_sf_lds_floor_ab.txt), 0 = none.
+#ifndef CASMVS_SF_LDS_FLOOR
+#define CASMVS_SF_LDS_FLOOR (56 * 1024)
+#endif
+
 namespace casmvs {
 
 char *error_buffer();  // thread-local, 512 bytes

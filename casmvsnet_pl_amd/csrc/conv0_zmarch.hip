@@ -58,7 +58,7 @@ struct ZmCfgT {
   static constexpr size_t ACT_BYTES = (size_t)2 * NV * 16;          // 23 616
   static __host__ __device__ constexpr size_t w_bytes(int nch) { return (size_t)nch * WUNITS * 16; }
   static __host__ __device__ constexpr size_t lds_bytes(int nch) {
-    return ACT_BYTES + w_bytes(nch) + 16 < 56 * 1024 ? (size_t)56 * 1024 : ACT_BYTES + w_bytes(nch) + 16;
+    return ACT_BYTES + w_bytes(nch) + 16 < CASMVS_SF_LDS_FLOOR ? (size_t)CASMVS_SF_LDS_FLOOR : ACT_BYTES + w_bytes(nch) + 16;
   }
 };
 

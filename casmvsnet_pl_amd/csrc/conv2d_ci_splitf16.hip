@@ -49,7 +49,7 @@ struct C2Cfg {
   // came out wrong on this GPU; with two waves per SIMD, and no floating-point work between a wave's own matrix
   // instructions, a staging wave never meets more than one stream of them.
   static constexpr size_t LDS_USED = ACT_BYTES + W_BYTES + 16;       // 33 808 / 43 936 / 64 528
-  static constexpr size_t LDS_BYTES = LDS_USED < 56 * 1024 ? 56 * 1024 : LDS_USED;
+  static constexpr size_t LDS_BYTES = LDS_USED < CASMVS_SF_LDS_FLOOR ? CASMVS_SF_LDS_FLOOR : LDS_USED;
 };
 
 __device__ __forceinline__ f32x4 mfma_f16_c2(u32x4 a, u32x4 b, f32x4 c) {

@@ -62,7 +62,7 @@ struct S2Cfg {
   // one in which round 3 saw wrong float32 results): the requested LDS is padded to 56 KiB.  Measured: three workgroups with one unit in flight each
   // 117 / 230 / 232 us at the three levels (batch 8), two with two units each 120 / 236 / 233 (profiles/r04_conv_s2_depth_ab.txt).
   static constexpr size_t LDS_USED = ACT_BYTES + W_BYTES + 16;
-  static constexpr size_t LDS_BYTES = LDS_USED < 56 * 1024 ? (size_t)56 * 1024 : LDS_USED;
+  static constexpr size_t LDS_BYTES = LDS_USED < CASMVS_SF_LDS_FLOOR ? (size_t)CASMVS_SF_LDS_FLOOR : LDS_USED;
   static constexpr int WG_PER_CU = LDS_BYTES * 2 <= (size_t)160 * 1024 ? 2 : 1;
   static_assert(CIN % 8 == 0 && COUT % 16 == 0 && TY * (TX / 16) == WAVES * NT && ITEMS <= THREADS, "shape");
 };

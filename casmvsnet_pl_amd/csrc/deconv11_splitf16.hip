@@ -44,7 +44,7 @@ struct DcCfg {
   static constexpr int WUNITS = 9 * 2 * 64;                           // lane images [kz * 3 + ky][slice][lane]
   static constexpr size_t ACT_BYTES = (size_t)4 * NVOX * 16, W_BYTES = (size_t)WUNITS * 16;   // 17 408 + 18 432
   static constexpr size_t LDS_USED = ACT_BYTES + W_BYTES + 16;
-  static constexpr size_t LDS_BYTES = LDS_USED < 56 * 1024 ? (size_t)56 * 1024 : LDS_USED;    // at most two workgroups per CU
+  static constexpr size_t LDS_BYTES = LDS_USED < CASMVS_SF_LDS_FLOOR ? (size_t)CASMVS_SF_LDS_FLOOR : LDS_USED;    // at most two workgroups per CU
 };
 
 __device__ __forceinline__ f32x4 dc_mfma(u32x4 a, u32x4 b, f32x4 c) {

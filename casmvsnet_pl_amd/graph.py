@@ -105,17 +105,20 @@ class ConcurrentForwards:
     `run(batches)` takes one (imgs, proj_mats) pair per stream (None = reuse the captured inputs), replays the graphs
     concurrently and returns the list of STATIC output dicts after making the caller's stream wait for all of them.
 
-    MATRIX-INSTRUCTION TYPES MUST NOT MIX ACROSS THE STREAMS.  Measured on the MI355X (tools/debug/disturber.py, disturber_valu.py,
-    profiles/r03_mfma_coresidency*.txt): while waves of another kernel issue v_mfma_f32_16x16x32_f16 / _bf16 on a SIMD, a
-    float32 layer kernel (v_mfma_f32_16x16x4_f32) co-resident on that SIMD returns a few wrong accumulator values (row 14 of
-    the 16 x 16 tile) - 800 of 800 replays with a pure f16-MFMA loop as the neighbour, none with a float32-MFMA, LDS or VALU
-    neighbour - and so does the packed-float32 arithmetic of the cost-volume kernel (91 of 400).  Inside ONE stream kernels never overlap, so the split-f16 / split-bf16 layers (CostRegNet.conv0_mode, ci_mode) are
-    safe there; across streams they would run beside the other forward's float32 layers.  The replicas therefore run every layer
-    on the float32 MFMA kernels unless `mixed_matrix_types=True` (experiments only: results are NOT reliable)."""
+    MATRIX-INSTRUCTION TYPES ACROSS THE STREAMS.  Rounds 3-4 measured wrong float32 values in kernels that shared SIMDs with another stream's f16 /
+    bf16 matrix instructions (800 of 800 replays for the Cout = 8 float32 layer kernel, 91 of 400 for the cost-volume kernel) and ran the replicas
+    all-float32.  Round 5 found the cause - ONE instruction form, packed float32 with op_sel:[0,1,..] (casmvsnet_pl_amd/streams.py,
+    tools/probes/pk_fma_opsel_repro.hip) - and the library is now assembled without it: with such a library (`casmvs_packed_opsel_safe()`) the
+    replicas keep the model's own layer modes (split-f16) and every replay equals the single-stream forward bit for bit
+    (tools/gpu_mixed_streams.py: 0 of 5 640 output tensors differ on 2-4 streams; 2 streams x batch 1: 990 depth maps/s vs 752 on one stream).
+    `mixed_matrix_types=False` forces the all-float32 replicas (what a library built without the rewrite gets by default), True forces the model's
+    modes."""
 
-    def __init__(self, model, imgs, proj_mats, init_depth_min, depth_interval, n_streams=2, warmup=2, mixed_matrix_types=False):
+    def __init__(self, model, imgs, proj_mats, init_depth_min, depth_interval, n_streams=2, warmup=2, mixed_matrix_types=None):
         self.device = imgs.device
-        self.mixed_matrix_types = bool(mixed_matrix_types)
+        if mixed_matrix_types is None:
+            mixed_matrix_types = not streams.enabled()   # a library without the unsafe packed-float32 form: nothing to keep apart
+        self.mixed_matrix_types = mixed_matrix_types = bool(mixed_matrix_types)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.forwards = []
         for st in self.streams:

@@ -1,28 +1,33 @@
-"""Process-wide stream guard for the split-f16 kernels.
+"""Process-wide stream guard for the split-f16 kernels - OFF for a library whose device code carries no unsafe packed-float32 instruction.
 
-Measured on the MI355X (profiles/r03_mfma_coresidency*.txt, profiles/r04_coresidency_lib_victim.txt): while waves of one kernel
-issue f16 / bf16 matrix instructions, some float32 kernels of ANOTHER stream that are co-resident on the same SIMDs return a few wrong values -
-the Cout = 8 float32-MFMA layer kernel (conv16db_kernel<PX>: 171 of 200 rounds in a torch-free reproducer) and the packed-float32 plane loop of
-the LDS cost-volume kernel; the other float32 layer kernels, the normalisation and softmax kernels were clean in the same experiments.  The cause
-is not known (a stand-alone synthetic victim does not reproduce it: tools/probes/mfma_coresidency_repro.hip), so the rule is conservative:
+The fault behind it (root cause found in round 5: tools/probes/pk_fma_opsel_repro.hip, profiles/r05_packed_opsel_fault_matrix.txt): on
+gfx950, v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 whose low result takes src0's LOW half and a vector-register src1's HIGH half (op_sel:[0,1,..])
+read that src1 half as zero in lanes 48-63 while another wave of the same SIMD issues f16 / bf16 matrix instructions.  That is what rounds 3-4 saw as
+"float32 kernels return a few wrong values beside another stream's f16 kernels": the Cout = 8 float32-MFMA layer kernel (its epilogue has exactly one
+such instruction: channel 7 of column tile 0, the element that was wrong in 171 of 200 rounds) and the packed-float32 plane loop of the LDS
+cost-volume kernel (520 of them).  casmvsnet_pl_amd/build.py assembles the library with src0 / src1 of every such instruction exchanged (a clean form,
+the same arithmetic bit for bit), `casmvs_packed_opsel_safe()` reports it, and with such a library this guard does nothing by default: its kernels run
+beside each other on any number of streams (tools/gpu_mixed_streams.py: 0 of 5 640 output tensors of concurrent split-f16 forwards differ).
+
+With a library built WITHOUT the rewrite (a plain `hipcc -c` of csrc/) the round-4 rule is applied:
 
     library kernels with f16 / bf16 matrix instructions never overlap library kernels of another stream.
 
-Inside one stream kernels never overlap, so the engine's default launch (one stream, one hipGraph) is unaffected and never waits here.  When the
-library is driven from several streams of one device, every launch goes through `launch_stream`: an f16-class launch first makes its stream wait for
-what the library has queued on every other stream, and any launch first waits for the f16-class work queued on other streams (`Stream.wait_stream`:
-an event, no host synchronisation).  All-float32 work on several streams - graph.ConcurrentForwards - is never serialised.  Inside a hipGraph
-capture a cross-stream wait cannot be inserted: that combination raises.
+Inside one stream kernels never overlap, so the engine's default launch (one stream, one hipGraph) never waits here.  When the library is driven from
+several streams of one device, every launch goes through `launch_stream`: an f16-class launch first makes its stream wait for what the library has
+queued on every other stream, and any launch first waits for the f16-class work queued on other streams (`Stream.wait_stream`: an event, no host
+synchronisation).  Inside a hipGraph capture a cross-stream wait cannot be inserted: that combination raises.
 
-What this cannot see: another process on the same GPU, kernels of other libraries (rocBLAS / MIOpen float32 GEMMs, RCCL) on other streams, and
-callers of the C ABI that bypass this package.  `stream_guard(False)` switches it off (experiments: bench.py --unsafe-mixed-streams).
+What neither the rewrite nor the guard can see: kernels of OTHER code (torch, rocBLAS / MIOpen, RCCL) on other streams or processes of the same GPU that
+contain the unsafe form - they are the victims then, whenever any f16 / bf16 matrix kernel (this library's or anyone's) shares their SIMDs.
+`stream_guard(True / False)` forces the rule on / off.
 """
 import contextlib
 import ctypes
 
 import torch
 
-_enabled = True
+_enabled = None   # None: decided by the loaded library on first use (casmvs_packed_opsel_safe); stream_guard() forces it
 # device index -> {stream pointer: [torch stream, launches so far, f16-class launches so far]}
 _streams = {}
 # (device index, waiting stream pointer, other stream pointer) -> (launches, f16 launches) of the other stream already waited for
@@ -31,13 +36,22 @@ _seen = {}
 
 @contextlib.contextmanager
 def stream_guard(enabled):
-    """Temporarily switch the guard (False: mixed-type work may overlap across streams - results are NOT reliable)."""
+    """Temporarily force the guard on / off (off with a library built without the packed-float32 rewrite: results are NOT reliable)."""
     global _enabled
     old, _enabled = _enabled, bool(enabled)
     try:
         yield
     finally:
         _enabled = old
+
+
+def enabled():
+    """Whether the cross-stream rule is being applied: forced by stream_guard, else on exactly when the loaded library may contain the unsafe form."""
+    global _enabled
+    if _enabled is None:
+        from . import _lib
+        _enabled = not _lib.load().casmvs_packed_opsel_safe()
+    return _enabled
 
 
 def reset(device=None):
@@ -57,7 +71,7 @@ def note_launch(device, f16=False, stream=None):
     """Book a library launch (or a hipGraph replay of library kernels) on `stream` (default: torch's current stream of `device`) and insert the
     cross-stream waits the rule asks for.  -> the torch stream."""
     s = stream if stream is not None else torch.cuda.current_stream(device)
-    if not _enabled:
+    if not enabled():
         return s
     dev = s.device.index if s.device.index is not None else torch.cuda.current_device()
     table = _streams.setdefault(dev, {})

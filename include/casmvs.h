@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CASMVS_ABI_VERSION 4
+#define CASMVS_ABI_VERSION 5
 
 #define CASMVS_OK 0
 #define CASMVS_ERR_INVALID_ARG (-1) /* null pointer / non-positive size / unsupported combination */
@@ -48,6 +48,14 @@ int casmvs_abi_version(void);
 
 /* Thread-local message describing the last non-zero return on this thread ("" if none). */
 const char *casmvs_last_error(void);
+
+/* 1 when the library's device code was assembled with the packed-float32 operand exchange of casmvsnet_pl_amd/build.py (rewrite_unsafe_packed), 0 for
+ * a plain `hipcc -c` build.  gfx950: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel:[0,1,..] (low result from src0's low and a vector src1's
+ * high half) read that half as zero in lanes 48-63 while another wave of the SIMD issues f16 / bf16 matrix instructions - another kernel on another
+ * stream, or other waves of the same kernel (tools/probes/pk_fma_opsel_repro.hip).  A library that returns 1 contains no such
+ * instruction (tests/test_device_code_lints.py disassembles the shipped .so): its kernels may run beside each other on any number of streams.  With
+ * 0 the caller keeps kernels with f16 matrix instructions from overlapping float32 kernels of other streams (casmvsnet_pl_amd/streams.py does). */
+int casmvs_packed_opsel_safe(void);
 
 /* ---- (a3)/(a4) depth hypotheses ------------------------------------------------------------
  * Replaces: models/mvsnet.py:213-229 (coarsest level: d_k = init_depth_min + k*interval) and

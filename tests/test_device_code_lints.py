@@ -78,3 +78,48 @@ def test_no_wide_store_is_followed_by_a_write_of_its_data_registers():
     spec.loader.exec_module(tool)
     report = tool.lint(window=2)
     assert not report, report
+
+
+def test_packed_float32_rewrite_exchanges_the_sources_of_the_faulty_class_only():
+    """casmvsnet_pl_amd/build.py rewrite_unsafe_packed on assembly lines: the faulty class of the MI355X (tools/probes/pk_fma_opsel_repro.hip: low result from
+    src0's low half and a VECTOR src1's high half) gets src0 / src1 and every per-source modifier bit exchanged - the same arithmetic, a clean form; everything
+    else passes through untouched."""
+    sys.path.insert(0, ROOT)
+    from casmvsnet_pl_amd import build
+    cases = {
+        "\tv_pk_fma_f32 v[12:13], v[14:15], v[92:93], v[94:95] op_sel:[0,1,1]": "\tv_pk_fma_f32 v[12:13], v[92:93], v[14:15], v[94:95] op_sel:[1,0,1]",
+        "\tv_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[0,1] op_sel_hi:[1,0]": "\tv_pk_mul_f32 v[2:3], v[6:7], v[4:5] op_sel:[1,0] op_sel_hi:[0,1]",
+        "\tv_pk_add_f32 v[2:3], v[4:5], v[6:7] op_sel:[0,1]": "\tv_pk_add_f32 v[2:3], v[6:7], v[4:5] op_sel:[1,0]",
+        "\tv_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9] op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0] clamp":
+            "\tv_pk_fma_f32 v[2:3], v[6:7], v[4:5], v[8:9] op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0] clamp",
+    }
+    untouched = ["\tv_pk_fma_f32 v[0:1], v[0:1], v[2:3], 0.5 op_sel_hi:[1,1,0]", "\tv_pk_mul_f32 v[20:21], s[74:75], v[12:13]",
+                 "\tv_pk_fma_f32 v[2:3], v[4:5], s[6:7], v[8:9] op_sel:[0,1,0]",            # src1 in scalar registers: measured clean
+                 "\tv_pk_add_f32 v[2:3], v[4:5], v[6:7] op_sel:[1,0] op_sel_hi:[0,1]", "\tv_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9] op_sel:[1,1,1]",
+                 "\tv_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[0,1]", "\tv_fma_mix_f32 v1, v2, v3, -v4 op_sel:[0,1,0] op_sel_hi:[0,1,0]", "\ts_nop 0"]
+    for before, after in cases.items():
+        assert build.packed_f32_is_unsafe(before) and not build.packed_f32_is_unsafe(after)
+        assert build.rewrite_unsafe_packed(before) == (after, 1)
+    for line in untouched:
+        assert not build.packed_f32_is_unsafe(line)
+        assert build.rewrite_unsafe_packed(line) == (line, 0)
+    text = "\n".join(list(cases) + untouched)
+    fixed, n = build.rewrite_unsafe_packed(text)
+    assert n == len(cases) and fixed == "\n".join(list(cases.values()) + untouched)
+
+
+@pytest.mark.skipif(not os.path.isfile(HIPCC), reason="needs hipcc and llvm-objdump")
+def test_the_built_library_contains_no_packed_float32_instruction_of_the_faulty_class():
+    """The SHIPPED artefact: the gfx950 code objects inside casmvsnet_pl_amd/libcasmvs_hip.so (built here if it is not), disassembled - thousands of packed
+    float32 instructions, none with op_sel:[0,1,..] on a vector src1.  That is what lets kernels with f16 matrix instructions run beside the float32
+    kernels of other streams (casmvsnet_pl_amd/streams.py: the guard is off for a library that says casmvs_packed_opsel_safe() == 1)."""
+    import importlib.util
+    sys.path.insert(0, ROOT)
+    from casmvsnet_pl_amd import build
+    lib = build.build_library()
+    spec = importlib.util.spec_from_file_location("packed_opsel_lint", os.path.join(ROOT, "tools", "packed_opsel_lint.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    objects, packed, unsafe = tool.lint_library(lib)
+    assert objects >= 20 and packed > 10000, (objects, packed)
+    assert not unsafe, unsafe[:10]

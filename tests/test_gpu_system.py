@@ -139,35 +139,67 @@ def test_view_sharded_model_equals_fused_world1():
 
 
 def test_concurrent_forwards_equal_single_stream(dev):
-    """Two captured forwards on two streams give the same bits as the kernel-by-kernel forward, on different inputs.  The replicas run
-    every layer on the float32 MFMA kernels (matrix-instruction types must not mix across streams: graph.py), so the reference is
-    the model in its all-float32 modes."""
+    """Two captured forwards on two streams give the same bits as the kernel-by-kernel forward, on different inputs - with the split-f16 layers of
+    the default modes on BOTH streams (the combination rounds 3-4 had to forbid: casmvsnet_pl_amd/streams.py; the library is assembled without the
+    packed-float32 form that made float32 kernels wrong beside f16 matrix instructions), and with the all-float32 replicas."""
+    from casmvsnet_pl_amd import streams
     from casmvsnet_pl_amd.graph import ConcurrentForwards
     from casmvsnet_pl_amd.synthetic import make_inputs
+    assert not streams.enabled()   # the in-tree library reports casmvs_packed_opsel_safe() == 1
     model = _model(dev)
     ins = [make_inputs(1, 3, 64, 96, seed=s) for s in (1, 2)]
     dmin, dint = ins[0][2], ins[0][3]
     cf = ConcurrentForwards(model, ins[0][0].to(dev), ins[0][1].to(dev), dmin, dint, n_streams=2)
-    for gf in cf.forwards:
+    assert cf.mixed_matrix_types
+    for gf in cf.forwards:   # the replicas keep the model's own (split-f16) modes
+        assert all(getattr(gf.model, f"cost_reg_{l}").conv0_mode == getattr(model, f"cost_reg_{l}").conv0_mode != "f32" for l in range(3))
+        assert gf.model.feature.tail_mode == model.feature.tail_mode != "f32"
+    want = [{k: v.clone() for k, v in model(i[0].to(dev), i[1].to(dev), dmin, dint).items()} for i in ins]
+    for _ in range(30):
+        outs = cf.run([(i[0].to(dev), i[1].to(dev)) for i in ins])
+        torch.cuda.synchronize()
+        for o, w in zip(outs, want):
+            for k in w:
+                assert torch.equal(o[k], w[k]), k
+    cf32 = ConcurrentForwards(model, ins[0][0].to(dev), ins[0][1].to(dev), dmin, dint, n_streams=2, mixed_matrix_types=False)
+    for gf in cf32.forwards:
         assert all(getattr(gf.model, f"cost_reg_{l}").conv0_mode == "f32" and getattr(gf.model, f"cost_reg_{l}").ci_mode == "f32" for l in range(3))
         assert gf.model.feature.tail_mode == "f32"
-    assert model.cost_reg_0.conv0_mode != "f32"   # the source model keeps its own (single-stream) arithmetic
+    assert model.cost_reg_0.conv0_mode != "f32"   # the source model keeps its own arithmetic
     for l in range(3):
         getattr(model, f"cost_reg_{l}").conv0_mode = getattr(model, f"cost_reg_{l}").ci_mode = "f32"
     model.feature.tail_mode = "f32"
     want = [{k: v.clone() for k, v in model(i[0].to(dev), i[1].to(dev), dmin, dint).items()} for i in ins]
-    for _ in range(20):
-        outs = cf.run([(i[0].to(dev), i[1].to(dev)) for i in ins])
+    for _ in range(10):
+        outs = cf32.run([(i[0].to(dev), i[1].to(dev)) for i in ins])
         torch.cuda.synchronize()
         for o, w in zip(outs, want):
             for k in w:
                 assert torch.equal(o[k], w[k]), k
 
 
-def test_stream_guard_keeps_a_float32_layer_correct_beside_f16_kernels_of_another_stream(dev):
-    """casmvsnet_pl_amd/streams.py: the Cout = 8 float32-MFMA layer kernel returns wrong values when it shares SIMDs with another stream's f16 matrix
-    instructions (tools/native/coresidency_lib_victim.cpp: 171 of 200 rounds).  Driven through this package from two streams, the guard makes the
-    float32 launch wait for the f16 work queued on the other stream: every round equals the solo run, bit for bit."""
+def test_concurrent_split_f16_forwards_at_full_size_equal_the_single_stream_forward(dev):
+    """The same at 640 x 512 (kernels that fill the chip and share SIMDs across the streams for most of their run): 2 streams x batch 1, 40 rounds."""
+    from casmvsnet_pl_amd.graph import ConcurrentForwards
+    from casmvsnet_pl_amd.synthetic import make_inputs
+    model = _model(dev)
+    ins = [make_inputs(1, 3, 512, 640, seed=s) for s in (11, 12)]
+    dmin, dint = ins[0][2], ins[0][3]
+    want = [{k: v.clone() for k, v in model(i[0].to(dev), i[1].to(dev), dmin, dint).items()} for i in ins]
+    cf = ConcurrentForwards(model, ins[0][0].to(dev), ins[0][1].to(dev), dmin, dint, n_streams=2)
+    batches = [(i[0].to(dev), i[1].to(dev)) for i in ins]
+    bad = 0
+    for _ in range(40):
+        outs = cf.run(batches)
+        torch.cuda.synchronize()
+        bad += sum(0 if torch.equal(o[k], w[k]) else 1 for o, w in zip(outs, want) for k in w)
+    assert bad == 0, bad
+
+
+def test_a_float32_layer_stays_correct_beside_f16_kernels_of_another_stream(dev):
+    """The Cout = 8 float32-MFMA layer kernel beside another stream's f16 matrix instructions, NO stream guard: before round 5 its epilogue carried
+    v_pk_fma_f32 ... op_sel:[0,1,1], which reads src1's high half as zero in lanes 48-63 in that situation (tools/probes/pk_fma_opsel_repro.hip) - 171
+    of 200 rounds wrong (tools/native/coresidency_lib_victim.cpp).  The library is assembled with that form rewritten: every round equals the solo run."""
     from casmvsnet_pl_amd import ops, streams
     g = torch.Generator().manual_seed(5)
     x0 = torch.randn(2, 16, 32, 128, 160, generator=g).to(dev)
@@ -176,18 +208,17 @@ def test_stream_guard_keeps_a_float32_layer_correct_beside_f16_kernels_of_anothe
     pv = ops.conv3d_pack(ops.CONV_S1, torch.randn(8, 16, 3, 3, 3, generator=g) * 0.2, None, None).to(dev)
     want = ops.conv3d_forward(ops.CONV_S1, pv, xv, 8).clone()
     torch.cuda.synchronize()
-    streams.reset()
     sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     bad = 0
-    for _ in range(40):
-        with torch.cuda.stream(sa):
-            for _ in range(3):
-                ops.conv0_splitf16_forward(p0, x0)
-        with torch.cuda.stream(sb):
-            got = ops.conv3d_forward(ops.CONV_S1, pv, xv, 8)
-        torch.cuda.synchronize()
-        bad += 0 if torch.equal(got, want) else 1
-    streams.reset()
+    with streams.stream_guard(False):
+        for _ in range(60):
+            with torch.cuda.stream(sa):
+                for _ in range(3):
+                    ops.conv0_splitf16_forward(p0, x0)
+            with torch.cuda.stream(sb):
+                got = ops.conv3d_forward(ops.CONV_S1, pv, xv, 8)
+            torch.cuda.synchronize()
+            bad += 0 if torch.equal(got, want) else 1
     assert bad == 0, bad
 
 

@@ -348,9 +348,10 @@ def test_split_images_are_packed_only_for_the_selected_modes_and_non_finite_weig
 
 
 def test_stream_guard_serialises_f16_work_against_other_streams_only(monkeypatch):
-    """casmvsnet_pl_amd/streams.py (round-3 advisor, medium): kernels with f16 matrix instructions never overlap library kernels of another stream.
-    One stream: never a wait.  All-float32 work on several streams (ConcurrentForwards): never a wait.  An f16 launch waits for everything queued on
-    the other streams, any launch waits for the f16 work queued elsewhere; inside a capture the needed wait is an error."""
+    """casmvsnet_pl_amd/streams.py, the rule for a library built WITHOUT the packed-float32 rewrite (forced on here): kernels with f16 matrix
+    instructions never overlap library kernels of another stream.  One stream: never a wait.  All-float32 work on several streams: never a wait.  An
+    f16 launch waits for everything queued on the other streams, any launch waits for the f16 work queued elsewhere; inside a capture the needed wait
+    is an error.  With the in-tree library (casmvs_packed_opsel_safe() == 1) the guard is off by default: no launch ever waits."""
     from casmvsnet_pl_amd import streams
 
     class Dev:
@@ -367,31 +368,37 @@ def test_stream_guard_serialises_f16_work_against_other_streams_only(monkeypatch
             return False
     capturing = [False]
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing[0])
-    streams.reset()
-    a, b, c = FakeStream(1), FakeStream(2), FakeStream(3)
-    for _ in range(5):
+    assert streams.enabled() is False   # the in-tree build: nothing to guard
+    d, e = FakeStream(7), FakeStream(8)
+    streams.note_launch(None, f16=True, stream=d)
+    streams.note_launch(None, f16=False, stream=e)
+    assert d.waited == e.waited == []
+    with streams.stream_guard(True):
+        streams.reset()
+        a, b, c = FakeStream(1), FakeStream(2), FakeStream(3)
+        for _ in range(5):
+            streams.note_launch(None, f16=True, stream=a)
+        assert a.waited == []                                   # one stream
+        streams.note_launch(None, f16=False, stream=b)
+        assert b.waited == [1]                                  # float32 work on another stream waits for the f16 work queued on a
+        streams.note_launch(None, f16=False, stream=b)
+        assert b.waited == [1]                                  # ... once: nothing new on a since
         streams.note_launch(None, f16=True, stream=a)
-    assert a.waited == []                                   # one stream
-    streams.note_launch(None, f16=False, stream=b)
-    assert b.waited == [1]                                  # float32 work on another stream waits for the f16 work queued on a
-    streams.note_launch(None, f16=False, stream=b)
-    assert b.waited == [1]                                  # ... once: nothing new on a since
-    streams.note_launch(None, f16=True, stream=a)
-    assert a.waited == [2]                                  # the next f16 launch waits for b's work
-    streams.note_launch(None, f16=False, stream=b)
-    assert b.waited == [1, 1]
-    streams.reset()
-    for s in (a, b, c):
-        s.waited.clear()
-    for _ in range(3):                                      # all-float32 on three streams: free to overlap
+        assert a.waited == [2]                                  # the next f16 launch waits for b's work
+        streams.note_launch(None, f16=False, stream=b)
+        assert b.waited == [1, 1]
+        streams.reset()
         for s in (a, b, c):
-            streams.note_launch(None, f16=False, stream=s)
-    assert a.waited == b.waited == c.waited == []
-    streams.note_launch(None, f16=True, stream=c)
-    assert sorted(c.waited) == [1, 2]
-    capturing[0] = True
-    with pytest.raises(RuntimeError, match="hipGraph capture"):
-        streams.note_launch(None, f16=False, stream=a)      # would have to wait for c's f16 work: impossible inside a capture
-    with streams.stream_guard(False):
-        streams.note_launch(None, f16=False, stream=a)      # switched off: no wait, no error
-    streams.reset()
+            s.waited.clear()
+        for _ in range(3):                                      # all-float32 on three streams: free to overlap
+            for s in (a, b, c):
+                streams.note_launch(None, f16=False, stream=s)
+        assert a.waited == b.waited == c.waited == []
+        streams.note_launch(None, f16=True, stream=c)
+        assert sorted(c.waited) == [1, 2]
+        capturing[0] = True
+        with pytest.raises(RuntimeError, match="hipGraph capture"):
+            streams.note_launch(None, f16=False, stream=a)      # would have to wait for c's f16 work: impossible inside a capture
+        with streams.stream_guard(False):
+            streams.note_launch(None, f16=False, stream=a)      # switched off: no wait, no error
+        streams.reset()
