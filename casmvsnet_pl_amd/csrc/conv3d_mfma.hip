@@ -41,12 +41,6 @@
 
 namespace {
 
-#ifndef CASMVS_MFMA_HOLD
-#define CASMVS_MFMA_HOLD 0
-#endif
-#ifndef CASMVS_PX_EXP
-#define CASMVS_PX_EXP 0   // co-residency experiments on the PX epilogue (tools/build_variant.py)
-#endif
 #ifndef CASMVS_MFMA_DRAIN_NOPS
 #define CASMVS_MFMA_DRAIN_NOPS 0
 #endif
@@ -899,12 +893,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   }
   const float *aptr = smem + CK * SC + lane;
   f32x4 acc[NT];
-  // co-residency experiment 11: the accumulators start at 1024 (first tile) / 2048 (every later tile) and the epilogue subtracts that base: a wrong
-  // output then says whether the register held 0, its start value, or a sum
-  constexpr float kAccInit = CASMVS_PX_EXP == 11 ? 1024.f : 0.f, kAccReset = CASMVS_PX_EXP == 11 ? 2048.f : 0.f;
-  [[maybe_unused]] float px_snap = 0.f;   // experiments 13 / 14: accumulator [0][2] part-way through the last chunk
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{kAccInit, kAccInit, kAccInit, kAccInit};
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int in_cs = Di * Hi * Wi, out_cs = Do * Ho * Wo;
   const size_t in_ss = (size_t)cin * in_cs, out_ss = (size_t)cout * out_cs;
@@ -930,9 +920,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
   // flattened, so the look-ahead may span iterations: the small tiles (NS = 1, 2) get 8 steps too.
   // (NS = 4 keeps P = 4: 8 measured no faster and costs the wide CI tile a wave of occupancy.)
   constexpr int P = NS % 8 == 0 ? 8 : (NS % 4 == 0 ? 4 : (TOTAL_STEPS >= 16 ? 8 : 2));
-  // (co-residency experiment 12: the column tiles of a group in the order NT - 1 .. 0)
-  constexpr auto t_of = [](int i) constexpr -> int { return CASMVS_PX_EXP == 12 ? NT - 1 - i % NT : i % NT; };
-  constexpr auto b_tile = [t_of](int g) constexpr -> int { return t_of((g < TOTAL_STEPS ? g : TOTAL_STEPS - 1) % NS); };
+  constexpr auto b_tile = [](int g) constexpr -> int { return ((g < TOTAL_STEPS ? g : TOTAL_STEPS - 1) % NS) % NT; };
   constexpr auto b_off = [it_off](int g) constexpr -> int {
     const int gg = g < TOTAL_STEPS ? g : TOTAL_STEPS - 1;  // beyond the chunk: harmless re-read of the last operand
     return it_off(gg / NS) + ((gg % NS) / NT) * ASTEP;
@@ -1027,14 +1015,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       constexpr int i = decltype(i_)::value;
       ring[i] = bptr[b_tile(i)][RD + b_off(i)];
     });
-    // operand hold (CASMVS_MFMA_HOLD = K steps, 0 = off): a matrix instruction's A / B registers stay allocated for K further steps
-    [[maybe_unused]] float held_b[CASMVS_MFMA_HOLD > 0 ? CASMVS_MFMA_HOLD : 1], held_a[NA];
     // one flattened, fully unrolled loop over the NITER * NS steps: every index and every LDS
     // offset below is a compile-time constant
     static_for<TOTAL_STEPS>([&](auto g_) {
       constexpr int g = decltype(g_)::value;
       constexpr int it = g / NS, i = g % NS;
-      constexpr int a = i / NT, t = t_of(i);
+      constexpr int a = i / NT, t = i % NT;
       constexpr int itn = it < NITER - 1 ? it + 1 : NITER - 1;
       if constexpr (i == 0) {
 #pragma unroll
@@ -1042,47 +1028,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
       }
       const float bcur = ring[g % P];
       ring[g % P] = bptr[b_tile(g + P)][RD + b_off(g + P)];
-#if CASMVS_PX_EXP == 3   // co-residency experiment: accumulators IN PLACE (destination tied to srcC) - the compiler renames the last round of a chunk so that an
-                         // MFMA's destination is the srcC of the MFMA issued just before it
-      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(a_cur[a]), "v"(bcur));
-#else
       acc[t] = mfma16(a_cur[a], bcur, acc[t]);
-#endif
-#if CASMVS_MFMA_HOLD > 0
-      {
-        constexpr int K = CASMVS_MFMA_HOLD;
-        if constexpr (g >= K - 1) asm volatile("" ::"v"(held_b[(g + 1) % K]));   // the B operand consumed K - 1 steps ago: only now may its register be reloaded
-        held_b[g % K] = bcur;
-        if constexpr (it > 0 && i == (K - 1 < NS - 1 ? K - 1 : NS - 1)) {
-#pragma unroll
-          for (int aa = 0; aa < NA; ++aa) asm volatile("" ::"v"(held_a[aa]));         // the previous iteration's A operands
-        }
-        if constexpr (i == NS - 1) {
-#pragma unroll
-          for (int aa = 0; aa < NA; ++aa) held_a[aa] = a_cur[aa];
-        }
-      }
-#endif
-#if CASMVS_PX_EXP == 13   // accumulator [0][2] half-way through the chunk (the last chunk's value reaches the epilogue)
-      if constexpr (MODE == FMT_PX && g == TOTAL_STEPS / 2) px_snap = acc[0][2];
-#elif CASMVS_PX_EXP == 14   // ... right in front of the chunk's last matrix instruction into accumulator 0
-      if constexpr (MODE == FMT_PX && g == TOTAL_STEPS - NT) px_snap = acc[0][2];
-#endif
-#if CASMVS_PX_EXP == 4 || (CASMVS_PX_EXP == 10 && 0)
-      asm volatile("s_nop 7" ::: "memory");
-#elif CASMVS_PX_EXP == 10   // eight wait states behind every matrix instruction of the Cout = 8 (PX) form only
-      if constexpr (MODE == FMT_PX) asm volatile("s_nop 7" ::: "memory");
-#elif CASMVS_PX_EXP == 5
-      asm volatile("s_nop 1" ::: "memory");
-#elif CASMVS_PX_EXP == 6
-      asm volatile("s_nop 3" ::: "memory");
-#elif CASMVS_PX_EXP == 7   // only in the steps that carry staging work (a global load or an LDS store of the next chunk)
-      if constexpr ((g >= 1 && g <= NOPS) || (g >= ST0 && (g - ST0) % SST == 0 && (g - ST0) / SST < NOPS)) asm volatile("s_nop 7" ::: "memory");
-#elif CASMVS_PX_EXP == 8   // only in the steps WITHOUT staging work
-      if constexpr (!((g >= 1 && g <= NOPS) || (g >= ST0 && (g - ST0) % SST == 0 && (g - ST0) / SST < NOPS))) asm volatile("s_nop 7" ::: "memory");
-#elif CASMVS_PX_EXP == 9   // only behind the last matrix instruction of a group of NT (the next group switches the A operand)
-      if constexpr (t == NT - 1) asm volatile("s_nop 7" ::: "memory");
-#endif
       // ---- side work in this step's spare issue slots ----
       // (issued unconditionally - a dead set loads with out-of-range offsets and its stores land in
       // the buffer nobody reads - so that the code stays branch-free and the compiler can emit
@@ -1101,12 +1047,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
     if (++cur_chunk == nstages) {  // tile finished: epilogue, then switch to the next tile
 #pragma unroll
       for (int dn = 0; dn < CASMVS_MFMA_DRAIN_NOPS; ++dn) asm volatile("s_nop 15");   // debug builds (co-residency experiment)
-#if CASMVS_PX_EXP == 3
-      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the compiler does not know the statements above are matrix instructions: no hazard padding of its own)
-#endif
-#if CASMVS_PX_EXP == 1   // co-residency experiment: nothing pending (vector memory, LDS, scalar loads) when the epilogue starts
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
       const rsrc_t dst = make_rsrc(out + cur.b * out_ss, out_ss * 4);
       const rsrc_t skp = make_rsrc((skip && !OUT2) ? skip + cur.b * out_ss : out, out_ss * 4);
       [[maybe_unused]] const rsrc_t d2 = make_rsrc(OUT2 ? const_cast<float *>(skip) + cur.b * out_ss : out, out_ss * 4);
@@ -1115,39 +1055,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv16db_kernel(
         const int ct = wave * NT + t;
         const int cx = ct % NXG, cy = (ct / NXG) % TY, cz = ct / (NXG * TY);
         const int oz = cur.tz0 + cz, oy = cur.ty0 + cy;
-        f32x4 av = acc[t];
-        if constexpr (CASMVS_PX_EXP == 11) av -= (tiles_done == 0 ? kAccInit : kAccReset);
-        if constexpr ((CASMVS_PX_EXP == 13 || CASMVS_PX_EXP == 14) && MODE == FMT_PX) {
-          if (t == 0) av[3] = px_snap;   // the odd-x output of channel 2 kq + 1 carries the snapshot of the even-x accumulator
-        }
-        acc[t] = f32x4{kAccReset, kAccReset, kAccReset, kAccReset};
+        const f32x4 av = acc[t];
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (MODE == FMT_PX) {
           const int ox = cur.tx0 + cx * 32 + 2 * jcol;
           const bool ok = oz < Do && oy < Ho && ox < Wo;  // Wo % 4 == 0 here: the pair is in range
           const int voff = ok ? (2 * kq * out_cs + (oz * Ho + oy) * Wo + ox) * 4 : kOOB;
           [[maybe_unused]] float o2[2][2];  // [x phase][channel 2*kq + h]
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const int h = CASMVS_PX_EXP == 2 ? 1 - hh : hh;   // (experiment 2: channel 2 kq + 1 first)
-#if CASMVS_PX_EXP == 16   // co-residency experiment: EVERY column tile's channel 2 kq + 1 through the packed form the compiler picks for tile 0 only
-            float v0, v1;
-            if (h == 1) {
-              const f32x2 a2{av[2], av[3]}, s2{sc[0], sc[1]}, b2{sh[0], sh[1]};
-              f32x2 r2;
-              asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1]" : "=&v"(r2) : "v"(a2), "v"(s2), "v"(b2));
-              v0 = r2[0];
-              v1 = r2[1];
-            } else {
-              v0 = fmaf(av[0], sc[0], sh[0]);
-              v1 = fmaf(av[1], sc[0], sh[0]);
-            }
-#else
+          for (int h = 0; h < 2; ++h) {
             float v0 = fmaf(av[2 * h], sc[h % NCO], sh[h % NCO]);
-#if CASMVS_PX_EXP == 15   // co-residency experiment: the two multiply-adds of a pair as two scalar instructions (no v_pk_fma_f32)
-            asm volatile("" : "+v"(v0));
-#endif
             float v1 = fmaf(av[2 * h + 1], sc[h % NCO], sh[h % NCO]);
-#endif
             v0 = v0 > 0.0f ? v0 : v0 * slope;
             v1 = v1 > 0.0f ? v1 : v1 * slope;
             const int soff = h * out_cs * 4;

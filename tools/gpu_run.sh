@@ -16,6 +16,8 @@
 #   prof         rocprofv3 --kernel-trace --stats over bench.py --steps 10 --no-cpu-baseline
 #   costvol      tools/gpu_costvol_probe.py at batch 1 and 8 with dirtied caches (all BASELINE configs)
 #   trainprof    rocprofv3 --kernel-trace --stats over bench.py --mode train --steps 10 (per-kernel times of the training step)
+#   coresidency  the packed-float32 op_sel fault: stand-alone reproducer matrix, the library's float32 kernels beside f16 / bf16 neighbours
+#                (tools/native/coresidency_lib_victim.cpp), concurrent split-f16 forwards on 2 streams (tools/gpu_mixed_streams.py)
 #   cmd          runs "$GPU_RUN_CMD" (one-off experiments without a new script)
 TAG=${1:-run}; shift
 ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -114,12 +116,21 @@ stage_trainprof () {
   f=$(find $OUT/prof_train -name "*kernel_stats.csv" | head -1); head -${PROF_TOP:-30} $f | cut -c1-220
 }
 
+stage_coresidency () {
+  [ -x tools/probes/bin/pk_fma_opsel_repro ] && timeout 300 tools/probes/bin/pk_fma_opsel_repro ${OPSEL_ROUNDS:-4} > $OUT/packed_opsel_matrix.txt 2>&1
+  grep -c "f16mfma [1-9]" $OUT/packed_opsel_matrix.txt | sed 's/^/forms that fail beside f16 matrix instructions: /'
+  [ -x tools/probes/bin/coresidency_lib_victim ] && timeout 500 tools/probes/bin/coresidency_lib_victim ${CORES_ROUNDS:-500} px,ci,ciw,s2,t2 2>&1 | grep -E "beside|REPRODUCED|not reproduced" > $OUT/coresidency_lib_victim.txt
+  tail -1 $OUT/coresidency_lib_victim.txt
+  { timeout 400 python tools/gpu_mixed_streams.py 2 1 ${MIXED_ROUNDS:-200}; timeout 300 python tools/gpu_mixed_streams.py 2 4 60; timeout 300 python tools/gpu_mixed_streams.py 4 2 60; } 2>&1 | grep -v Warning > $OUT/mixed_streams.txt
+  grep -E "differ|depth maps/s" $OUT/mixed_streams.txt
+}
+
 stage_cmd () { bash -c "$GPU_RUN_CMD" > $OUT/cmd.txt 2>&1; echo "cmd exit: $?" >> $OUT/cmd.txt; tail -${CMD_TAIL:-60} $OUT/cmd.txt; }
 
 for s in "$@"; do
   echo "===== stage $s ($(date -u +%H:%M:%S))"
   case $s in
-    native|step|probes|bench|configs|suite|smoke|train|trainprof|files|pmc|prof|costvol|cmd) stage_$s ;;
+    native|step|probes|bench|configs|suite|smoke|train|trainprof|files|pmc|prof|costvol|coresidency|cmd) stage_$s ;;
     *) echo "unknown stage $s" ;;
   esac
 done

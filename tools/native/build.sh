@@ -12,3 +12,8 @@ for name in fusion_check prob_wgrad_check conv0_zm_check deconv11_check deconv9_
     -Wl,-rpath,'$ORIGIN/../../../casmvsnet_pl_amd' -o tools/probes/bin/$name 2>&1 | grep -E "error" || true
   ls -la tools/probes/bin/$name
 done
+# the co-residency programs (gpu_run.sh stage `coresidency`): the library's float32 kernels beside synthetic neighbours, and the stand-alone reproducer
+/opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/native/coresidency_lib_victim.cpp -Iinclude -Lcasmvsnet_pl_amd -lcasmvs_hip \
+  -Wl,-rpath,'$ORIGIN/../../../casmvsnet_pl_amd' -o tools/probes/bin/coresidency_lib_victim 2>&1 | grep -E "error" || true
+/opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 tools/probes/pk_fma_opsel_repro.hip -o tools/probes/bin/pk_fma_opsel_repro 2>&1 | grep -E "error" || true
+ls -la tools/probes/bin/coresidency_lib_victim tools/probes/bin/pk_fma_opsel_repro
