@@ -2315,6 +2315,11 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
   CASMVS_REQUIRE(B > 0 && cin > 0 && D > 0 && h > 0 && w > 0 && D % 8 == 0 && h % 8 == 0 && w % 8 == 0,
                  "%s: B=%d cin=%d D=%d h=%d w=%d (D, h, w must be multiples of 8)", who, B, cin, D, h, w);
   for (int i = 0; i < 11; ++i) CASMVS_REQUIRE(packed_layers[i], "%s: packed_layers[%d] is null", who, i);
+  // every layer form - float32 MFMA and split-f16 alike - addresses one sample's tensor with 32-bit byte offsets: say so here, once, instead of from
+  // whichever layer a volume past the limit reaches first (there is no form to fall back to; the batch is not limited)
+  CASMVS_REQUIRE((size_t)(cin > 8 ? cin : 8) * D * h * w < ((size_t)1 << 29),
+                 "%s: one sample's tensors must hold < 2^29 floats each (cin=%d D=%d h=%d w=%d: %zu); split the volume along D or the image into tiles", who, cin, D,
+                 h, w, (size_t)(cin > 8 ? cin : 8) * D * h * w);
   const size_t n = (size_t)B * D * h * w;
   float *ws = (float *)workspace;
   float *c0 = ws;            ws += 8 * n;

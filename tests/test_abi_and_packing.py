@@ -47,6 +47,11 @@ def test_abi_version_and_error_string():
     rc = lib.casmvs_costvol_gwc_f32(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8),
                                     1, 3, 12, 5, 8, 8, 4, None)
     assert rc == -2 and b"C=12" in lib.casmvs_last_error()
+    # a volume whose per-sample tensors pass 2^29 floats: refused at the entry with the limit spelled out (no layer form - float32 or split-f16 - can address it)
+    layers = (ctypes.c_void_p * 11)(*([8] * 11))
+    fp = ctypes.cast(ctypes.c_void_p(8), ctypes.POINTER(ctypes.c_float))
+    rc = lib.casmvs_costreg_regress_f32(layers, None, 0, fp, fp, fp, fp, fp, None, ctypes.c_void_p(8), 1, 8, 256, 512, 640, 0.01, None, None)
+    assert rc != 0 and b"2^29" in lib.casmvs_last_error() and b"D=256" in lib.casmvs_last_error()
 
 
 def test_packed_sizes_and_workspace():
