@@ -4,13 +4,14 @@
 // term is lost) in lanes 48-63.  This is the instruction the compiler picks for the Cout = 8 float32 layer kernel's epilogue (conv16db_kernel<PX>,
 // csrc/conv3d_mfma.hip: channel 2 kq + 1 of column tile 0 - exactly the element that was wrong in every failing round).
 //   hipcc -O2 --offload-arch=gfx950 tools/probes/pk_fma_opsel_repro.hip -o tools/probes/bin/pk_fma_opsel_repro
-//   pk_fma_opsel_repro [rounds = 5]
+//   pk_fma_opsel_repro [rounds = 5 [more]]      (more: three further matrix-instruction neighbours)
 // Per packed form (FORMS below) x neighbour (none, f32 MFMA, f16 MFMA, bf16 MFMA, VALU): wrong results by lane quarter and half; the last two lines add matrix
 // instructions of the wave itself in front of every packed instruction (the fault does not need them).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -19,9 +20,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
-template <int KIND>   // 1 f32 MFMA, 2 f16 MFMA, 3 bf16 MFMA, 4 VALU
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// 1 f32 MFMA 16x16x4 (32-bit A / B operands), 2 f16 16x16x32 (128-bit), 3 bf16 16x16x32 (128-bit), 4 VALU; argv[2] = "more" adds 5 f16 16x16x16 (64-bit
+// operands), 6 f16 32x32x16 (128-bit, 16 passes), 7 i8 16x16x64 (128-bit)
+template <int KIND>
 __global__ __launch_bounds__(256) void neighbour(float *sink, int iters) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (KIND >= 5) {
+    f32x16 c16 = {};
+    i32x4 ic = {0, 0, 0, 0};
+    const f16x4 h4 = {(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
+    const u32x4 ub = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    for (int it = 0; it < iters; ++it) {
+      if (KIND == 5) acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h4, h4, acc, 0, 0, 0);
+      else if (KIND == 6) c16 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ub), __builtin_bit_cast(f16x8, ub), c16, 0, 0, 0);
+      else ic = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, ub), __builtin_bit_cast(i32x4, ub), ic, 0, 0, 0);
+    }
+    if (acc[0] + c16[0] + c16[15] + (float)ic[0] == 12345.678f) sink[0] = acc[0];
+    return;
+  }
   const float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
   const u32x4 ua = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
   for (int it = 0; it < iters; ++it) {
@@ -106,12 +125,14 @@ __global__ __launch_bounds__(256, 2) void victim(unsigned *counts, float *sink, 
   if (s == 12345.678f) sink[0] = s + lds[lane];
 }
 
+static int g_neighbours = 5;
+
 template <int OP, int LO, int HI, int OWN>
 static void run(const char *fname, int rounds, int cus, hipStream_t sa, hipStream_t sb, unsigned *counts, float *sink) {
-  const char *nnames[] = {"none", "f32mfma", "f16mfma", "bf16mfma", "valu"};
+  const char *nnames[] = {"none", "f32mfma", "f16mfma", "bf16mfma", "valu", "f16mfma_16x16x16(64-bit operands)", "f16mfma_32x32x16", "i8mfma_16x16x64"};
   CHECK(hipFuncSetAttribute((const void *)victim<OP, LO, HI, OWN>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
   printf("%-58s own MFMA %2d:", fname, OWN);
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < g_neighbours; ++k) {
     CHECK(hipMemset(counts, 0, 9 * sizeof(unsigned)));
     for (int r = 0; r < rounds; ++r) {
       for (int i = 0; i < 6 && k; ++i) {
@@ -119,6 +140,9 @@ static void run(const char *fname, int rounds, int cus, hipStream_t sa, hipStrea
         if (k == 2) neighbour<2><<<cus * 2, 256, 0, sa>>>(sink, 20000);
         if (k == 3) neighbour<3><<<cus * 2, 256, 0, sa>>>(sink, 20000);
         if (k == 4) neighbour<4><<<cus * 2, 256, 0, sa>>>(sink, 20000);
+        if (k == 5) neighbour<5><<<cus * 2, 256, 0, sa>>>(sink, 20000);
+        if (k == 6) neighbour<6><<<cus * 2, 256, 0, sa>>>(sink, 10000);
+        if (k == 7) neighbour<7><<<cus * 2, 256, 0, sa>>>(sink, 20000);
       }
       for (int i = 0; i < 4; ++i) victim<OP, LO, HI, OWN><<<cus, 256, 48 * 1024, sb>>>(counts, sink, 500);
       CHECK(hipDeviceSynchronize());
@@ -135,6 +159,7 @@ static void run(const char *fname, int rounds, int cus, hipStream_t sa, hipStrea
 
 int main(int argc, char **argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+  if (argc > 2 && !strcmp(argv[2], "more")) g_neighbours = 8;
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
