@@ -62,7 +62,7 @@ def packed_f32_is_unsafe(line):
         return False
     _, _, operands, mods, _, _ = p
     sel = mods.get("op_sel", [0] * (len(operands) - 1))
-    return sel[0] == 0 and sel[1] == 1 and operands[2].startswith("v")
+    return sel[0] == 0 and sel[1] == 1 and operands[2][:1] in ("v", "a")   # (accumulation registers as a source: not measured, treated as vector registers)
 
 
 def rewrite_unsafe_packed(asm_text):
