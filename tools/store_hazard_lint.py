@@ -40,10 +40,18 @@ def regs(tok):
 
 
 def device_asm(path):
+    """The device assembly the library is assembled from: the build's own `<source>.fixed.s` when it is newer than the source, the headers and the build script
+    (casmvsnet_pl_amd/build.py keeps it beside the object), else a fresh compile passed through the same packed-float32 rewrite."""
+    from casmvsnet_pl_amd import build
+    fixed = os.path.join(build.PKG_DIR, "build", os.path.basename(path)[:-4] + ".fixed.s")
+    if os.path.dirname(os.path.abspath(path)) == build.CSRC and os.path.isfile(fixed):
+        newest = max([os.path.getmtime(path), os.path.getmtime(build.__file__)] + [os.path.getmtime(h) for h in build.HEADERS])
+        if os.path.getmtime(fixed) >= newest:
+            return open(fixed).read()
     with tempfile.TemporaryDirectory() as wd:
         subprocess.run([HIPCC, *[f for f in FLAGS], "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(os.path.abspath(path)), "--cuda-device-only", "-S",
                         os.path.abspath(path), "-o", "k.s"], cwd=wd, check=True, capture_output=True, text=True)
-        return open(os.path.join(wd, "k.s")).read()
+        return build.rewrite_unsafe_packed(open(os.path.join(wd, "k.s")).read())[0]
 
 
 def kernels(asm):
