@@ -1,6 +1,6 @@
 """Profiling only (needs a -DCASMVS_TRACE build selected with CASMVS_LIB_PATH): shader-clock phase timeline of
 costvol_lds_kernel workgroups (thread 0 of every 32nd workgroup of batch element 0).
-   python tools/gpu_cv_trace.py [level [batch [op]]]     op: var (fused variance build) | warp (un-fused homo_warp)"""
+   python tools/gpu_cv_trace.py [level [batch [op]]]     op: var (fused variance build) | warp (un-fused homo_warp); CV_TRACE_NOISY=1: noise-like hypotheses"""
 import ctypes
 import os
 import sys
@@ -28,6 +28,10 @@ k = torch.arange(D, device=dev, dtype=torch.float32).view(1, D, 1, 1)
 step = dint * 2 ** level
 base = 680.0 - D / 2 * step + 60.0 * torch.sin(torch.linspace(0, 6.0, w, device=dev)).view(1, 1, 1, w)
 dv = (base + k * step).expand(B, D, h, w).contiguous()
+if os.environ.get("CV_TRACE_NOISY") == "1":   # the noise-like hypotheses of random weights (tools/gpu_costvol_probe.py: |d depth / dx| ~ 15 units)
+    coarse = 680.0 + 40.0 * torch.randn(B, 1, h // 2, w // 2, generator=g).to(dev)
+    up = torch.nn.functional.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=True)
+    dv = (up - D / 2 * step + k * step).contiguous()
 nhwc = ops.nchw_to_nhwc(feats.view(B * V, C, h, w)).view(B, V, h, w, C)
 if op == "warp":
     src, P1 = feats[:, 1].contiguous(), P[:, 0].contiguous()
