@@ -191,6 +191,130 @@ def base_line(metric, unit, value, world, steps, warmup, elapsed, scaling, confi
     return line
 
 
+# ---- the line the driver parses -------------------------------------------------------------------------------------------------------
+# Round 5's stdout line had grown to 21.5 kB and the driver could not parse it (BENCH_r05.json: parsed null).  stdout now carries ONE line
+# of at most COMPACT_LIMIT bytes: the contract's keys, `config` (short values), `roofline`, `cpu_baseline` and scalars.  The FULL object
+# (stage table, batch-1 copies of every roofline object, notes) goes to --full-out (default gpurun_out/bench_full.json) and to stderr.
+COMPACT_LIMIT = 4096
+_CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+
+
+def _r(x, digits=5):
+    """Floats at `digits` significant digits (what the line is read for), everything else as is."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{digits}g}")
+
+
+def _get(obj, *path):
+    for k in path:
+        if not isinstance(obj, dict) or k not in obj:
+            return None
+        obj = obj[k]
+    return obj
+
+
+def compact_line(full):
+    """The <= 4 kB stdout line from the full result object: contract keys first, short `config`, `roofline` (dominant kernel) and `cpu_baseline`
+    as objects, every other figure worth surfacing as a top-level scalar.  No prose: the notes live in DESIGN.md section 5."""
+    line = {k: _r(full[k]) for k in _CONTRACT_KEYS if k in full}
+    line["dtype"] = str(full.get("dtype", "f32"))[:120]
+    cfg = full.get("config", {})
+    short = {}
+    for k in ("workload", "H", "W", "views", "n_depths", "num_groups", "batch_per_forward", "concurrent_forwards_per_gpu", "depth_interval", "init_depth_min",
+              "launch", "parallelism", "arithmetic", "batch_per_gpu", "zero_grad"):
+        if k in cfg:
+            v = cfg[k]
+            short[k] = v[:48] if isinstance(v, str) else _r(v)
+    line["config"] = short
+    if "median_ms_per_step" in full:
+        line["median_ms_per_step"] = _r(full["median_ms_per_step"])
+    rf = full.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = {"kernel": str(rf.get("kernel_short") or rf.get("kernel", ""))[:80], "bound": rf.get("bound"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"),
+                            "unit": rf.get("unit"), "frac": _r(rf.get("frac")), "traffic": _r(rf.get("traffic"), 6),
+                            "traffic_over_algorithmic": _r(rf.get("traffic_over_algorithmic")), "avg_launch_ms": _r(rf.get("avg_launch_ms")),
+                            "algorithmic_bytes_per_launch": _r(rf.get("algorithmic_bytes_per_launch"), 6), "launches_per_step": rf.get("launches_per_step"),
+                            "mfma_executed_frac": _r(_get(rf, "mfma", "executed", "frac"))}
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "median_s": _r(cb.get("median_s")), "sample": str(cb.get("sample_short") or cb.get("sample", ""))[:100]}
+    scalars = {
+        "roofline_homo_warp_frac": _get(full, "roofline_homo_warp", "frac"),
+        "roofline_homo_warp_frac_hot": _get(full, "roofline_homo_warp", "frac_by_measurement", "reference_signature_hot"),
+        "roofline_homo_warp_frac_level0": _get(full, "roofline_homo_warp", "per_level_frac", "reference_signature_dirty", "0"),
+        "roofline_costvol_frac": _get(full, "roofline_costvol", "frac"),
+        "roofline_costvol_traffic": _get(full, "roofline_costvol", "traffic"),
+        "roofline_costreg_frac_executed": _get(full, "roofline_costreg", "frac"),
+        "roofline_costreg_frac_all_float32": _get(full, "roofline_costreg", "all_float32", "frac"),
+        "roofline_costreg_fp32_equivalent_ratio": _get(full, "roofline_costreg", "fp32_equivalent", "ratio"),
+        "roofline_prob_regress_frac": _get(full, "roofline_prob_regress", "frac"),
+        "roofline_feature_frac_executed": _get(full, "roofline_feature", "frac"),
+        "roofline_feature_frac_all_float32": _get(full, "roofline_feature", "all_float32", "frac"),
+        "costvol_ms_per_step": None, "costreg_ms_per_step": _get(full, "roofline_costreg", "ms_per_step"),
+        "feature_ms_per_step": _get(full, "roofline_feature", "ms_per_step"),
+        "tail_ms_per_step": _get(full, "roofline_prob_regress", "ms_per_step"),
+        "conv3_to_conv9_ms_per_step": _get(full, "roofline_costreg", "conv3_to_conv9_ms_per_step"),
+        "instrumented_ms_per_step": _get(full, "instrumented_pass", "ms_per_step"),
+        "two_streams_value": _get(full, "two_streams", "value"),
+        "single_stream_value": _get(full, "single_stream", "value"),
+        "batch1_value": _get(full, "batch1", "value"),
+        "batch1_ms_per_step": _get(full, "batch1", "ms_per_step"),
+        "batch1_two_streams_value": _get(full, "batch1", "two_streams", "value"),
+        "batch1_roofline_frac": _get(full, "batch1", "roofline", "frac"),
+        "batch1_roofline_homo_warp_frac": _get(full, "batch1", "roofline_homo_warp", "frac"),
+        "batch1_roofline_costvol_frac": _get(full, "batch1", "roofline_costvol", "frac"),
+        "batch1_roofline_costreg_frac_executed": _get(full, "batch1", "roofline_costreg", "frac"),
+        "train_step_ms": _get(full, "train_step", "train_step_ms"),
+        "train_samples_per_s": _get(full, "train_step", "samples_per_s"),
+        "train_peak_memory_gib": _get(full, "train_step", "peak_memory_gib"),
+        "stock_pytorch_rocm_value": _get(full, "stock_pytorch_rocm", "value"),
+        "peak_memory_gib": full.get("peak_memory_gib"),
+        "library_sha16": full.get("library_sha16"), "source_sha16": full.get("source_sha16"),
+    }
+    st = full.get("stage_ms_per_step")
+    if isinstance(st, dict):
+        cv = [st.get(f"costvol_{l}") for l in range(3)]
+        if all(v is not None for v in cv):
+            scalars["costvol_ms_per_step"] = sum(cv)
+    for m in _get(full, "conv0_other_modes", "modes") or []:
+        if m.get("conv0_mode") == "f32":
+            scalars["all_float32_value"] = m.get("value")
+    for k in ("train_step_ms", "train_samples_per_s"):   # --mode train prints these at top level
+        if scalars.get(k) is None and k in full:
+            scalars[k] = full[k]
+    if _get(full, "train_step", "error"):
+        scalars["train_step_error"] = str(full["train_step"]["error"])[:120]
+    for k, v in scalars.items():
+        if v is not None:
+            line[k] = _r(v)
+    # last resort (a future field grows): drop scalars from the back until the line fits; the contract keys, roofline and cpu_baseline stay
+    keys = [k for k in line if k not in _CONTRACT_KEYS and k not in ("config", "roofline", "cpu_baseline")]
+    while len(json.dumps(line)) > COMPACT_LIMIT and keys:
+        line.pop(keys.pop())
+    return line
+
+
+def emit(full, full_out):
+    """stdout: the compact line (<= COMPACT_LIMIT bytes).  The full object: `full_out` (best effort: a read-only tree must not lose the line) + stderr."""
+    text = json.dumps(full)
+    if full_out:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(full_out)), exist_ok=True)
+            with open(full_out, "w") as f:
+                f.write(text + "\n")
+        except OSError as e:
+            print(f"warning: could not write {full_out}: {e}", file=sys.stderr)
+    print("bench_full: " + text, file=sys.stderr, flush=True)
+    line = compact_line(full)
+    out = json.dumps(line)
+    assert len(out) <= COMPACT_LIMIT, len(out)
+    print(out, flush=True)
+
+
 def cpu_baseline(cfg_name):
     """The reference's forward on the same synthetic workload on this host's cores, at the best of a sweep over the thread
     count (all 256 hardware threads of the GPU box are 25x slower than 8: oversubscription).  With /root/reference
@@ -241,7 +365,8 @@ def cpu_baseline(cfg_name):
     med = times[len(times) // 2]
     what = "the unmodified /root/reference models/mvsnet.py (import shims: inplace_abn, kornia)" if kind == "reference" else \
            "oracle/cpu_restatement.py (the reference tree is not on this machine)"
-    return {"value": 1.0 / med, "unit": "depth-maps/s", "cores": best, "kind": kind,
+    return {"value": 1.0 / med, "unit": "depth-maps/s", "cores": best, "kind": kind, "median_s": med,
+            "sample_short": f"3 forwards of 1 depth map, {cfg_name}, torch CPU fp32, best of a thread sweep",
             "sample": f"3 timed forwards of ONE depth map each (median {med:.3f} s) of {what} on the same {cfg_name} inputs / weights, "
                       f"torch CPU fp32 at {best} threads = the best of a sweep {({k: round(v, 2) for k, v in per_threads.items()})} s over "
                       f"{ncpu} hardware threads"}
@@ -404,7 +529,9 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
                                               "scalings), 3 launches per step: conv0_zw_kernel<8, wide> (level 0), <16, wide> (level 1), <32> (level 2): "
                                               "input-stationary along z on 8 x 64 / 16 x 32 patches, producer and consumer wave groups in one workgroup",
                                   None: "conv16db_kernel<PX> (CostRegNet.conv0 on the float32 MFMA: Cout 8, stride 1; 3 launches per step)"}[split],
-                       "bound": "hbm" if split else "mfma", "batch": B, "avg_launch_ms": conv0_ms / (3 * n_ev)}
+                       "kernel_short": {"splitbf16": "conv0_sb_kernel<CIN,6> (CostRegNet.conv0, bf16 slices)", "splitf16": "conv0_zw_kernel<CIN,WIDE> (CostRegNet.conv0, split-f16)",
+                                        None: "conv16db_kernel<PX> (CostRegNet.conv0, f32 MFMA)"}[split],
+                       "launches_per_step": 3, "bound": "hbm" if split else "mfma", "batch": B, "avg_launch_ms": conv0_ms / (3 * n_ev)}
     hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": conv0_alg / 3,
            "note": "achieved = ALGORITHMIC bytes (each launch reads its input volume and writes its 8-channel output once; mean of the 3 levels) / HIP-event time"}
@@ -628,6 +755,8 @@ def main():
                          "are measured and printed beside the headline")
     ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: FeatureNet's full-resolution FPN tail as one kernel (1) or as the reference's three steps (0); default: the model's")
     ap.add_argument("--zero-fill-grads", action="store_true", help="--mode train A/B: optimizer.zero_grad(set_to_none=False) as before round 3's last session")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="where the FULL result object goes (stage table, batch-1 roofline copies, notes); stdout carries the compact line only; '' = nowhere")
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` object of the default line (20 hipGraph replays of the batch-1 training step)")
     args = ap.parse_args()
     args.batch_given = args.batch is not None
@@ -662,7 +791,7 @@ def main():
         line = train_mode(args, dev, world, rank, dist, barrier)
         if rank == 0:
             line["library_sha16"] = library_sha16()
-            print(json.dumps(line), flush=True)
+            emit(line, args.full_out)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -727,11 +856,12 @@ def main():
                           "interval_ratios": list(ratios), "num_groups": G, "depth_maps_per_step_per_gpu": B * NS,
                           "batch_per_forward": B, "concurrent_forwards_per_gpu": NS,
                           "depth_interval": inputs[3], "init_depth_min": inputs[2],
-                          "launch": (f"{NS} independent forwards per step, each one hipGraph replay on its own HIP stream" if NS > 1 else
-                                     "one hipGraph replay per step") if used_graph else "kernel by kernel",
-                          "parallelism": (f"view-sharded x{world}: source views split over the ranks, one RCCL all-reduce of the sum / "
-                                          "sum-of-squares volumes per level, every rank regularises") if view_sharded else
-                                         f"replica x{world} (one depth map stream per GPU, no data-path collective)",
+                          "launch": (f"{NS} hipGraphs on {NS} streams per step" if NS > 1 else "one hipGraph replay per step") if used_graph else "kernel by kernel",
+                          "parallelism": f"view-sharded x{world}, 1 all-reduce per level" if view_sharded else f"replica x{world}, no collective",
+                          "arithmetic": "split-f16" if model.cost_reg_0.conv0_mode == "splitf16" else model.cost_reg_0.conv0_mode,
+                          "parallelism_note": (f"view-sharded x{world}: source views split over the ranks, one RCCL all-reduce of the sum / "
+                                               "sum-of-squares volumes per level, every rank regularises") if view_sharded else
+                                              f"replica x{world} (one depth map stream per GPU, no data-path collective)",
                           "feature_net": "HIP MFMA kernels (casmvs_featurenet_forward_f32)",
                           "regression": "fused into the `prob` head's library call (casmvs_costreg_regress_f32)" if model.fuse_regress else "separate launch",
                           "conv0_arithmetic": {"splitbf16": "float32 operands as three exact bf16 slices, six bf16 x bf16 partial products per product on the "
@@ -754,7 +884,7 @@ def main():
                           "every_layer_float32_value": "conv0_other_modes.modes[conv0_mode == 'f32'] of this line"},
                          median,
                          dtype="f32" if model.cost_reg_0.conv0_mode == "f32" and model.cost_reg_0.ci_mode == "f32" and model.feature.tail_mode == "f32" else
-                               "f32 (tensors and accumulation float32; products of CostRegNet's conv0 - conv4 / 6 / 9 / 11 and eight FeatureNet layers formed on the f16 matrix cores from two float16 slices per operand)")
+                               "f32 (tensors + accumulation f32; products of 17 layers on the f16 MFMA from 2 f16 slices per operand)")
         line["library_sha16"] = library_sha16()
         line["source_sha16"] = source_sha16()
 
@@ -853,7 +983,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.config)
         if world == 1 and args.stock_pytorch:
             line["stock_pytorch_rocm"] = stock_pytorch_rocm(args.config, dev)
-        print(json.dumps(line), flush=True)
+        emit(line, args.full_out)
     if dist is not None:
         dist.destroy_process_group()
 

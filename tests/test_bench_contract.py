@@ -131,3 +131,67 @@ def test_dominant_kernel_roofline_never_exceeds_its_roof(bench):
     f16_frac = 4.0 * flops / sum(t.values()) / 1e12 / bench.MFMA_F16_PEAK_TFLOPS
     assert 0.2 < hbm_frac < 0.3 and 0.2 < f16_frac < 0.3
     assert flops / sum(t.values()) / 1e12 / bench.MFMA_F32_PEAK_TFLOPS > 0.9   # the old headline ratio: why it is no longer called `frac`
+
+
+def _worst_case_full_line():
+    """Round 5's full bench object (the 21.5 kB line the driver could not parse), with every string doubled and extra objects added: a line that only grows."""
+    import json
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+
+    def grow(o):
+        if isinstance(o, dict):
+            return {k: grow(v) for k, v in o.items()}
+        if isinstance(o, str) and len(o) > 24:   # prose and kernel descriptions, not the enumerations ("hbm", "GB/s", "port")
+            return o + " " + o
+        return o
+    full = grow(full)
+    full["single_stream"] = dict(full["two_streams"])
+    full["stock_pytorch_rocm"] = {"value": 12.3, "unit": "depth-maps/s", "sample": "x" * 500}
+    full["train_step"]["error"] = "RuntimeError: " + "y" * 1000
+    for i in range(50):
+        full[f"future_object_{i}"] = {"note": "z" * 300}
+    return full
+
+
+def test_stdout_line_stays_under_4_kb_and_keeps_what_the_driver_reads(bench):
+    """BENCH_r05.json.parsed was null: the stdout line had grown to 21.5 kB.  The line is now built by compact_line(): at most 4 kB whatever the full
+    object holds, with the contract keys, `roofline` (frac, traffic), `cpu_baseline` and `config.workload`; the full object goes to a side file."""
+    import json
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    for obj in (full, _worst_case_full_line()):
+        line = bench.compact_line(obj)
+        text = json.dumps(line)
+        assert len(text) < 4096, len(text)
+        assert "\n" not in text
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert key in line, key
+        assert line["config"]["workload"] == "dtu_640x512_v3_var" and "model" not in line["config"]
+        assert len(line["dtype"]) <= 120 and line["dtype"].startswith("f32")
+        rf = line["roofline"]
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and len(rf["kernel"]) <= 80
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and 0.0 < rf["frac"] < 1.0
+        assert rf["traffic"] is None or rf["traffic"] >= 0.95 * rf["algorithmic_bytes_per_launch"]
+        cb = line["cpu_baseline"]
+        assert cb["value"] > 0 and cb["unit"] == "depth-maps/s" and cb["cores"] >= 1 and cb["kind"] in ("port", "reference")
+        assert abs(line["value"] - full["value"]) / full["value"] < 1e-4          # 5 significant digits
+        assert abs(line["ms_per_step"] * line["value"] / 1e3 - 8.0) < 1e-2        # value = batch / time: the driver's consistency check
+        for key in ("roofline_homo_warp_frac", "roofline_homo_warp_frac_hot", "roofline_costvol_frac", "roofline_costreg_frac_executed",
+                    "roofline_costreg_frac_all_float32", "batch1_value", "batch1_two_streams_value", "all_float32_value", "train_step_ms"):
+            assert isinstance(line[key], float), key
+        assert all(not isinstance(v, (dict, list)) for k, v in line.items() if k not in ("config", "roofline", "cpu_baseline"))
+
+
+def test_emit_prints_one_parsable_line_and_writes_the_full_object(bench, tmp_path, capsys):
+    import json
+    full = _worst_case_full_line()
+    path = tmp_path / "sub" / "bench_full.json"
+    bench.emit(full, str(path))
+    out, err = capsys.readouterr()
+    lines = [l for l in out.split("\n") if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    assert json.loads(lines[0])["roofline"]["frac"] > 0
+    assert json.load(open(path))["stage_ms_per_step"]            # the stage table lives in the side file
+    assert err.startswith("bench_full: ")
+    bench.emit(full, "/proc/definitely/not/writable.json")        # a read-only tree does not lose the line
+    out, err = capsys.readouterr()
+    assert json.loads(out.strip())["value"] > 0 and "warning: could not write" in err

@@ -52,14 +52,15 @@ stage_probes () {
 
 stage_bench () {
   nproc > $OUT/host.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host.txt 2>/dev/null; lscpu | grep -E "Model name|^CPU\(s\)" | cut -c1-200 >> $OUT/host.txt
-  timeout 600 python bench.py --steps 20 --warmup 5 $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err
-  echo "bench exit: $?"; tail -3 $OUT/bench.err; cut -c1-1500 $OUT/bench.json
+  # stdout = the compact line the driver parses (<= 4 kB: bench.py compact_line), bench_full.json = the full object (tools/show_bench.py reads either)
+  timeout 600 python bench.py --steps 20 --warmup 5 --full-out $OUT/bench_full.json $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err
+  echo "bench exit: $?"; grep -v "^bench_full: " $OUT/bench.err | tail -3; wc -c $OUT/bench.json; cat $OUT/bench.json
 }
 
 stage_configs () {
   for cfg in dtu_640x512_v3_gwc8 dtu_1152x864_v5_var blended_768x576_v7_var; do
-    timeout 400 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline $CONFIG_ARGS > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
-    cut -c1-400 $OUT/bench_$cfg.json
+    timeout 400 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --full-out $OUT/bench_full_$cfg.json $CONFIG_ARGS > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
+    cut -c1-1200 $OUT/bench_$cfg.json
   done
 }
 
@@ -71,9 +72,9 @@ stage_suite () {
 stage_smoke () { timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke exit: $?" >> $OUT/smoke.txt; tail -4 $OUT/smoke.txt; }
 
 stage_train () {
-  timeout 400 python bench.py --mode train --steps 20 --warmup 5 > $OUT/bench_train.json 2> $OUT/bench_train.err
+  timeout 400 python bench.py --mode train --steps 20 --warmup 5 --full-out "" > $OUT/bench_train.json 2> $OUT/bench_train.err
   for v in ${TRAIN_VARIANTS:-"--zero-fill-grads"}; do
-    n=$(echo $v | tr -d ' -'); timeout 400 python bench.py --mode train --steps 20 --warmup 5 $v > $OUT/bench_train_$n.json 2> $OUT/bench_train_$n.err
+    n=$(echo $v | tr -d ' -'); timeout 400 python bench.py --mode train --steps 20 --warmup 5 --full-out "" $v > $OUT/bench_train_$n.json 2> $OUT/bench_train_$n.err
   done
   grep -ho '"train_step_ms": [0-9.]*' $OUT/bench_train*.json
 }
@@ -102,7 +103,7 @@ stage_pmc () {
 }
 
 stage_prof () {
-  (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o stats -- python $ROOTDIR/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch1 > $OUT/bench_under_rocprof.json 2> $OUT/prof_bench.log)
+  (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o stats -- python $ROOTDIR/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch1 --full-out $OUT/bench_under_rocprof_full.json > $OUT/bench_under_rocprof.json 2> $OUT/prof_bench.log)
   find $OUT/prof_bench -name "*.db" -delete 2>/dev/null; find $OUT/prof_bench -type f -size +4M -delete 2>/dev/null
   cut -c1-300 $OUT/bench_under_rocprof.json
 }
@@ -112,7 +113,7 @@ stage_costvol () {
 }
 
 stage_trainprof () {
-  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o stats -- python $ROOTDIR/bench.py --mode train --steps 10 --warmup 3 $TRAIN_ARGS > $OUT/bench_train_prof.json 2> $OUT/bench_train_prof.err )
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o stats -- python $ROOTDIR/bench.py --mode train --steps 10 --warmup 3 --full-out "" $TRAIN_ARGS > $OUT/bench_train_prof.json 2> $OUT/bench_train_prof.err )
   find $OUT/prof_train -name "*.db" -delete 2>/dev/null; find $OUT/prof_train -type f -size +4M -delete 2>/dev/null
   f=$(find $OUT/prof_train -name "*kernel_stats.csv" | head -1); head -${PROF_TOP:-30} $f | cut -c1-220
 }
