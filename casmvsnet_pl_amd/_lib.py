@@ -79,6 +79,8 @@ SYMBOLS = {
     "casmvs_conv_s2_splitf16_supported": (c_int, [c_int, c_int, c_int]),
     "casmvs_conv_s2_splitf16_forward_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_costreg_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "casmvs_costreg_packed_floats": (c_size_t, [c_int, c_void_p]),
+    "casmvs_costreg_pack_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "casmvs_costreg_forward_f32": (c_int, [POINTER(c_void_p), _FP, _FP, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
     "casmvs_conv2d_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "casmvs_conv2d_pack_f32": (c_int, [c_int, c_int, c_int, _FP, _FP, _FP, _FP]),

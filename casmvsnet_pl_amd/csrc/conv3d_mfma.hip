@@ -1998,6 +1998,44 @@ extern "C" int casmvs_conv3d_pack_f32(int kind, int cin, int cout, const float *
   return pack_layer("conv3d_pack", kind, cin, cout, weight, scale, shift, packed);
 }
 
+// Whole CostRegNet (models/mvsnet.py:60-89): the eleven layers of casmvs_costreg_forward_f32's `packed_layers`, in that order
+namespace {
+struct CostRegLayer { int kind, cin, cout; };
+inline void costreg_layers(int cin, CostRegLayer (&L)[11]) {
+  const CostRegLayer t[11] = {{CASMVS_CONV_S1, cin, 8},  {CASMVS_CONV_S2, 8, 16},  {CASMVS_CONV_S1, 16, 16}, {CASMVS_CONV_S2, 16, 32},
+                              {CASMVS_CONV_S1, 32, 32},  {CASMVS_CONV_S2, 32, 64}, {CASMVS_CONV_S1, 64, 64}, {CASMVS_CONV_T2, 64, 32},
+                              {CASMVS_CONV_T2, 32, 16},  {CASMVS_CONV_T2, 16, 8},  {CASMVS_CONV_S1, 8, 1}};
+  for (int i = 0; i < 11; ++i) L[i] = t[i];
+}
+}  // namespace
+
+extern "C" size_t casmvs_costreg_packed_floats(int cin, size_t *layer_offsets) {
+  if (cin < 1) return 0;
+  CostRegLayer L[11];
+  costreg_layers(cin, L);
+  size_t total = 0;
+  for (int i = 0; i < 11; ++i) {
+    if (layer_offsets) layer_offsets[i] = total;
+    total += (packed_floats(L[i].kind, L[i].cin, L[i].cout) + 3) & ~(size_t)3;   // every image starts 16-byte aligned
+  }
+  return total;
+}
+
+extern "C" int casmvs_costreg_pack_f32(int cin, const float *const *weights, const float *const *scales, const float *const *shifts, float *packed) {
+  casmvs::clear_error();
+  CASMVS_REQUIRE(cin >= 1 && weights && packed, "costreg_pack: cin=%d or null pointer", cin);
+  CostRegLayer L[11];
+  costreg_layers(cin, L);
+  size_t off[11];
+  const size_t total = casmvs_costreg_packed_floats(cin, off);
+  for (size_t i = 0; i < total; ++i) packed[i] = 0.0f;
+  for (int i = 0; i < 11; ++i) {
+    CASMVS_REQUIRE(weights[i], "costreg_pack: weights[%d] is null", i);
+    if (int rc = pack_layer("costreg_pack", L[i].kind, L[i].cin, L[i].cout, weights[i], scales ? scales[i] : nullptr, shifts ? shifts[i] : nullptr, packed + off[i])) return rc;
+  }
+  return CASMVS_OK;
+}
+
 extern "C" size_t casmvs_conv2d_packed_floats(int kind, int cin, int cout) {
   return is_2d_kind(kind) ? packed_floats(kind, cin, cout) : 0;
 }

@@ -246,9 +246,10 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
   using L = BoxLayout<CS>;
   const int rowu = L::row_units(bx_.bw);
   const SweepCoords sc = plane_sweep_coords(P, xf, yf, dvk, w, h);
-  // box-relative position of the footprint's north-west corner.  NaN / -inf -> -2 (left of every box: bx0 >= -1); +inf / huge saturate: the
-  // unsigned compares fail for all of them
-  const int rx = (int)fmaxf(sc.x0, -2.0f) - bx_.bx0, ry = (int)fmaxf(sc.y0, -2.0f) - bx_.by0;
+  // box-relative position of the footprint's north-west corner.  NaN / -inf -> -8 in x, -2 in y: left of / above every box (by0 >= -1; bx0 >= -1, and >= -4
+  // where the channel-plane staging rounds the box down to a quad of x: a clamp at -2 would put a NaN column INSIDE such a box with NaN weights); +inf / huge
+  // saturate: the unsigned compares fail for all of them.  A finite x0 in [-8, -2) of a quad-rounded box reads its staged zero padding, as before
+  const int rx = (int)fmaxf(sc.x0, -8.0f) - bx_.bx0, ry = (int)fmaxf(sc.y0, -2.0f) - bx_.by0;
   const bool inbox = ((unsigned)rx < (unsigned)(bx_.bw - 1)) & ((unsigned)ry < (unsigned)(bx_.bh - 1)) & valid;   // columns rx, rx + 1 and rows ry, ry + 1 staged
   // a lane without a staged footprint reads the box origin (staged, finite data) with zero weights
   // (left, right) column weights as ONE register pair: the two rows' weights are two packed multiplies with a broadcast operand.  Without a staged

@@ -252,6 +252,28 @@ def conv3d_pack(kind, weight, scale=None, shift=None):
     return packed
 
 
+def costreg_pack(weights, scales=None, shifts=None):
+    """Host-side packing of a whole CostRegNet in one call (casmvs_costreg_pack_f32): `weights` = the eleven torch-layout weights of conv0..conv6, conv7,
+    conv9, conv11, prob; scales / shifts = per-layer folded ABN (entries may be None).  -> (CPU blob, [float offset of every layer image])."""
+    import ctypes
+    if len(weights) != 11:
+        raise ValueError(f"costreg_pack: {len(weights)} weights, CostRegNet has 11 layers")
+    ws = [w.detach().to("cpu", torch.float32).contiguous() for w in weights]
+    cin = ws[0].shape[1]
+    vec = lambda seq: [None if (seq is None or t is None) else t.detach().to("cpu", torch.float32).contiguous() for t in (seq if seq is not None else [None] * 11)]
+    scs, shs = vec(scales), vec(shifts)
+    lib = _lib.load()
+    offs = (ctypes.c_size_t * 11)()
+    n = lib.casmvs_costreg_packed_floats(cin, ctypes.cast(offs, ctypes.c_void_p))
+    if n == 0:
+        raise RuntimeError(f"costreg_pack: unsupported cin={cin}")
+    arr = lambda ts: (ctypes.c_void_p * 11)(*[None if t is None else t.data_ptr() for t in ts])
+    packed = torch.empty(n, dtype=torch.float32)
+    rc = lib.casmvs_costreg_pack_f32(cin, ctypes.cast(arr(ws), ctypes.c_void_p), ctypes.cast(arr(scs), ctypes.c_void_p), ctypes.cast(arr(shs), ctypes.c_void_p), _ptr(packed))
+    _lib.check(rc, "casmvs_costreg_pack_f32")
+    return packed, [int(o) for o in offs]
+
+
 def conv3d_forward(kind, packed, x, cout, skip=None, slope=0.01):
     """One CostRegNet layer on the matrix cores (casmvs_conv3d_forward_f32)."""
     x, packed = _dev(x, "x"), _dev(packed, "packed")

@@ -25,6 +25,8 @@ contain the unsafe form - they are the victims then, whenever any f16 / bf16 mat
 import contextlib
 import ctypes
 
+import os
+
 import torch
 
 _enabled = None   # None: decided by the loaded library on first use (casmvs_packed_opsel_safe); stream_guard() forces it
@@ -49,8 +51,15 @@ def enabled():
     """Whether the cross-stream rule is being applied: forced by stream_guard, else on exactly when the loaded library may contain the unsafe form."""
     global _enabled
     if _enabled is None:
-        from . import _lib
-        _enabled = not _lib.load().casmvs_packed_opsel_safe()
+        # CASMVS_STREAM_GUARD=1 forces the rule on (and with it all-float32 replicas in graph.ConcurrentForwards), =0 off, whatever the library reports.
+        # What casmvs_packed_opsel_safe() covers is THIS library's device code: float32 kernels of other code on other streams of the GPU (torch / MIOpen /
+        # rocBLAS operators during a training step, RCCL) may contain the op_sel:[0,1,..] packed form and are not protected by it - INTEGRATION.md section 4.
+        env = os.environ.get("CASMVS_STREAM_GUARD")
+        if env in ("0", "1"):
+            _enabled = env == "1"
+        else:
+            from . import _lib
+            _enabled = not _lib.load().casmvs_packed_opsel_safe()
     return _enabled
 
 

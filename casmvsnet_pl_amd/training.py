@@ -18,6 +18,7 @@ torch is the autograd tape and the allocator; the skip additions of the U-Net an
 times (18 ms per step at the reference's default training configuration, 15 ms captured as one hipGraph).
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -168,7 +169,20 @@ class PackPlan:
         self.launches += 1
 
 
-_ACTIVE_PLAN = None   # the plan of the training step in flight (set by cascade_forward_train; its backward runs under the same plan)
+# The plan of the training step in flight (set by cascade_forward_train; its backward runs under the same plan), as a WEAK reference: the plan lives on its
+# model (pack_plan_of), so the module global neither keeps a dropped model's weights and packed images alive nor serves them to another model's step
+# (PackPlan.serves also checks ownership).  release_plan() clears it once a step's graph is consumed (train_steps does, after optimizer.step()).
+_ACTIVE_PLAN = None
+
+
+def _active_plan():
+    return None if _ACTIVE_PLAN is None else _ACTIVE_PLAN()
+
+
+def release_plan():
+    """Forget the training step in flight: later device_pack calls pack on their own until the next train-mode forward."""
+    global _ACTIVE_PLAN
+    _ACTIVE_PLAN = None
 
 
 def pack_plan_of(model):
@@ -190,7 +204,7 @@ def device_pack(kind, weight, bias=None, adjoint=False):
     idx = _pack_map(kind, cin, cout, bias is not None, weight.device, adjoint)
     w = weight.detach().contiguous().float()
     bz = None if bias is None else bias.detach().contiguous().float()
-    plan = _ACTIVE_PLAN
+    plan = _active_plan()
     planned = plan is not None and w.data_ptr() == weight.data_ptr() and (bias is None or bz.data_ptr() == bias.data_ptr()) and plan.serves(weight)
     if planned:
         out, fresh = plan.lookup(kind, weight.detach(), None if bias is None else bias.detach(), adjoint, idx)
@@ -589,8 +603,9 @@ def cascade_forward_train(model, imgs, proj_mats, init_depth_min, depth_interval
     global _ACTIVE_PLAN
     B, V, _, H, W = imgs.shape
     dev = imgs.device
-    _ACTIVE_PLAN = pack_plan_of(model)   # this step's forward AND backward take their layer images from the plan
-    _ACTIVE_PLAN.begin_step()
+    plan = pack_plan_of(model)
+    _ACTIVE_PLAN = weakref.ref(plan)   # this step's forward AND backward take their layer images from the plan
+    plan.begin_step()
     feats = feature_net_train(model.feature, imgs.reshape(B * V, 3, H, W).float())
     proj = proj_mats.float()
     results = {}
@@ -660,5 +675,6 @@ def train_steps(model, batches, optimizer, device="cuda"):
         loss = sl1_loss(results, depths, masks)
         loss.backward()
         optimizer.step()
+        release_plan()   # the step's graph is consumed
         losses.append(float(loss.detach()))
     return losses

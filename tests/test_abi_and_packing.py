@@ -69,6 +69,28 @@ def test_packed_sizes_and_workspace():
     assert lib.casmvs_costreg_workspace_bytes(1, 8, 16, 20) == 0  # w not a multiple of 8
 
 
+@pytest.mark.parametrize("cin", [8, 16, 32])
+def test_whole_costreg_pack_equals_the_per_layer_packs(cin):
+    """casmvs_costreg_pack_f32 (SURVEY 8b's export list: ONE call for the regulariser's eleven layers) = eleven casmvs_conv3d_pack_f32 images back to back,
+    each 16-byte aligned, at the offsets casmvs_costreg_packed_floats reports."""
+    g = torch.Generator().manual_seed(cin)
+    layers = [(ops.CONV_S1, cin, 8), (ops.CONV_S2, 8, 16), (ops.CONV_S1, 16, 16), (ops.CONV_S2, 16, 32), (ops.CONV_S1, 32, 32), (ops.CONV_S2, 32, 64),
+              (ops.CONV_S1, 64, 64), (ops.CONV_T2, 64, 32), (ops.CONV_T2, 32, 16), (ops.CONV_T2, 16, 8), (ops.CONV_S1, 8, 1)]
+    ws = [torch.randn((ci, co) if k == ops.CONV_T2 else (co, ci), generator=g).reshape(*((ci, co) if k == ops.CONV_T2 else (co, ci)), 1, 1, 1).repeat(1, 1, 3, 3, 3)
+          * torch.randn(1, 1, 3, 3, 3, generator=g) for k, ci, co in layers]
+    scs = [torch.rand(co, generator=g) + 0.5 for _, _, co in layers[:-1]] + [None]
+    shs = [torch.randn(co, generator=g) for _, _, co in layers]
+    blob, offs = ops.costreg_pack(ws, scs, shs)
+    assert offs[0] == 0 and all(o % 4 == 0 for o in offs) and offs == sorted(offs)
+    for i, (k, ci, co) in enumerate(layers):
+        one = ops.conv3d_pack(k, ws[i], scs[i], shs[i])
+        assert torch.equal(blob[offs[i]:offs[i] + one.numel()], one), i
+        end = offs[i + 1] if i < 10 else blob.numel()
+        assert end - offs[i] - one.numel() < 4 and not blob[offs[i] + one.numel():end].any()
+    with pytest.raises(ValueError):
+        ops.costreg_pack(ws[:10])
+
+
 CASES = [(ops.CONV_S1, 32, 8), (ops.CONV_S1, 5, 8), (ops.CONV_S1, 8, 1), (ops.CONV_S1, 16, 16), (ops.CONV_S1, 20, 32),
          (ops.CONV_S2, 8, 16), (ops.CONV_S2, 6, 32), (ops.CONV_T2, 16, 8), (ops.CONV_T2, 12, 32)]
 

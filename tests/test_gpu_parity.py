@@ -78,6 +78,29 @@ def test_homo_warp_matches_oracle(dev, report, B, C, H, W, D, geometry):
         assert torch.equal(_ops().homo_warp(src.to(dev), proj.to(dev), depth.to(dev), impl="lds_copy").cpu(), got)   # pixel-major copy + the same sweep
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), float("-inf")])
+def test_homo_warp_degenerate_x_row_gives_zeros_in_every_implementation(dev, bad):
+    """A projection matrix whose x row is NaN / inf while y and z stay finite (round-5 advisor finding): bounds-checked taps contribute nothing, the warped
+    volume is 0.  The LDS form that stages its box from the channel planes rounds the box down to a quad of x (bx0 down to -4): its NaN clamp must stay left
+    of THAT box, else the lane reads a staged column with NaN weights."""
+    from casmvsnet_pl_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W, D = 2, 16, 32, 48, 8
+    src = torch.randn(B, C, H, W, generator=g)
+    proj, dmin, dint = _proj_like(B, 2, H, W, seed=3)
+    proj = proj[:, 0].clone()
+    depth = dmin + torch.rand(B, D, H, W, generator=g) * 300.0
+    proj[1, 0, 3] = bad          # sample 1: x = R p + T / d is NaN / inf everywhere, y finite and inside the image
+    # (torch's CPU grid_sample, the oracle, propagates the NaN weights of such a sample; its GPU kernel - what the reference runs on - bounds-checks every
+    # tap on the truncated integer and writes 0, and so do this library's kernels: the sample is compared between implementations, not with the oracle)
+    want = R.homo_warp(src[:1], proj[:1], depth[:1])
+    got = _ops().homo_warp(src.to(dev), proj.to(dev), depth.to(dev), impl="gather").cpu()
+    assert not got[1].any() and want.any() and max_abs(got[:1], want) < 1.5e-4
+    assert _lib.load().casmvs_homo_warp_lds_supported(C, W, D)
+    for impl in ("lds", "lds_copy"):
+        assert torch.equal(_ops().homo_warp(src.to(dev), proj.to(dev), depth.to(dev), impl=impl).cpu(), got), impl
+
+
 @pytest.mark.parametrize("B,V,C,G,h,w,D,geometry", [
     (1, 3, 8, 1, 32, 40, 8, "dtu"), (1, 3, 16, 1, 32, 48, 32, "dtu"), (2, 5, 32, 1, 16, 24, 48, "dtu"),
     (1, 2, 4, 1, 20, 28, 3, "dtu"), (1, 3, 6, 1, 20, 28, 3, "random"), (1, 7, 8, 1, 24, 32, 8, "dtu"),
@@ -1047,9 +1070,10 @@ def _expected_index(cost):
 
 def _check_levels(report, name, got, model, want, want_index, want_cost, extra=None, boundary_tol=1e-3):
     """Asserts the per-level parity contract of the module docstring and reports every index flip."""
-    stats, flips = dict(extra or {}), []
+    stats, flips, mism_pixels = dict(extra or {}), [], {}
     for l in (2, 1, 0):
         d, c = got[f"depth_{l}"].cpu(), got[f"confidence_{l}"].cpu()
+        mism_pixels[l] = d.numel()
         gi, wi = model.last_index[l].cpu().long(), want_index[l]
         mism = gi != wi
         e = _expected_index(want_cost[l])
@@ -1060,10 +1084,31 @@ def _check_levels(report, name, got, model, want, want_index, want_cost, extra=N
         stats[f"conf_abs_{l}"] = max_abs(c[~mism], want[f"confidence_{l}"][~mism]) if (~mism).any() else 0.0
         stats[f"flip_max_boundary_dist_{l}"] = float(dist[mism].max()) if mism.any() else 0.0
         stats[f"pixels_within_tol_of_boundary_{l}"] = int((dist < boundary_tol).sum())
+        # (b) a flipped pixel is not exempt from the confidence check: there the engine must return the ORACLE's 4-plane window sum (mvsnet.py:179-183:
+        # 4 * avg_pool3d of pad(1, 2) = p[i-1] + p[i] + p[i+1] + p[i+2]) evaluated at the ENGINE's index - the window moved by one plane, nothing else
+        if mism.any():
+            p = F.softmax(want_cost[l].double(), 1)
+            pp = F.pad(p, (0, 0, 0, 0, 1, 2))
+            sum4 = pp[:, :-3] + pp[:, 1:-2] + pp[:, 2:-1] + pp[:, 3:]
+            at_engine_index = sum4.gather(1, gi.unsqueeze(1)).squeeze(1)
+            stats[f"conf_abs_on_flips_{l}"] = float((c.double() - at_engine_index)[mism].abs().max())
+        else:
+            stats[f"conf_abs_on_flips_{l}"] = 0.0
         if l in model.last_cost:  # the engine's own cost volume: its error, and the noise it puts on e
             gc = model.last_cost[l].cpu()
             stats[f"cost_scaled_err_{l}"] = scaled_err(gc, want_cost[l])
             stats[f"e_noise_{l}"] = float((_expected_index(gc) - e).abs().max())
+            # (a) north_star's words are "identical argmax-depth indices": argmax_D of the engine's cost volume against argmax_D of the oracle's.  The argmax
+            # of two volumes that differ by at most E everywhere can only differ where the oracle's best two planes are closer than 2 E.
+            cost_err = float((gc.double() - want_cost[l].double()).abs().max())
+            top2 = want_cost[l].double().topk(2, dim=1).values
+            gap = top2[:, 0] - top2[:, 1]
+            am = gc.argmax(1) != want_cost[l].argmax(1)
+            stats[f"argmax_match_{l}"] = float((~am).float().mean())
+            stats[f"argmax_flips_{l}"] = int(am.sum())
+            stats[f"argmax_flip_max_gap_{l}"] = float(gap[am].max()) if am.any() else 0.0
+            stats[f"cost_abs_err_{l}"] = cost_err
+            stats[f"pixels_with_top2_gap_below_2x_cost_err_{l}"] = int((gap <= 2 * cost_err).sum())
         for b, y, x in mism.nonzero()[:32].tolist():
             flips.append(dict(level=l, b=b, y=y, x=x, got=int(gi[b, y, x]), want=int(wi[b, y, x]),
                               expected_index=float(e[b, y, x]), boundary_dist=float(dist[b, y, x])))
@@ -1074,6 +1119,11 @@ def _check_levels(report, name, got, model, want, want_index, want_cost, extra=N
         assert stats[f"flip_max_boundary_dist_{l}"] < boundary_tol, (l, flips)        # every flip sits ON a trunc() boundary
         assert stats[f"index_flips_{l}"] <= stats[f"pixels_within_tol_of_boundary_{l}"]
         assert stats[f"conf_abs_{l}"] < 5 * boundary_tol, (l, stats[f"conf_abs_{l}"])  # measured 1.4e-4 (1.6e-3 for gwc8)
+        assert stats[f"conf_abs_on_flips_{l}"] < 0.5 * boundary_tol, (l, stats[f"conf_abs_on_flips_{l}"])   # 5e-4: the window moved, the probabilities did not
+        if f"argmax_flips_{l}" in stats:
+            assert stats[f"argmax_flip_max_gap_{l}"] <= 2 * stats[f"cost_abs_err_{l}"], (l, stats[f"argmax_flip_max_gap_{l}"], stats[f"cost_abs_err_{l}"])
+            assert stats[f"argmax_flips_{l}"] <= stats[f"pixels_with_top2_gap_below_2x_cost_err_{l}"]
+            assert stats[f"argmax_flips_{l}"] <= max(3, 5e-4 * mism_pixels[l]), (l, stats[f"argmax_match_{l}"], stats[f"argmax_flips_{l}"])
         if f"cost_scaled_err_{l}" in stats:
             # level 2 is pure kernel error (measured 5e-6); a finer level's cost also carries the coarser levels' depth
             # error - its hypotheses are shifted by it - (measured up to 6.5e-4 at 1152x864)
@@ -1129,9 +1179,19 @@ def test_full_size_config_matches_oracle(dev, report, config):
     model = model.to(dev).eval()
     model.keep_index = model.keep_cost = True
     got = model(imgs.to(dev), proj.to(dev), dmin, dint)
-    _check_levels(report, "e2e_full_size", got, model, want, {l: inter[f"index_{l}"] for l in (2, 1, 0)},
-                  {l: inter[f"cost_{l}"] for l in (2, 1, 0)}, extra=dict(config=config),
-                  boundary_tol=1e-2 if G == 8 else 1e-3)   # G = 8: one channel per group at level 0 (module docstring)
+    tol = 1e-2 if G == 8 else 1e-3   # G = 8: one channel per group at level 0 (module docstring)
+    split = _check_levels(report, "e2e_full_size", got, model, want, {l: inter[f"index_{l}"] for l in (2, 1, 0)},
+                          {l: inter[f"cost_{l}"] for l in (2, 1, 0)}, extra=dict(config=config, layers="split-f16 (default)"), boundary_tol=tol)
+    # (c) which arithmetic owns the noise on the expected index e: the same forward with EVERY layer on the float32 MFMA kernels, same checks, same report
+    for l in range(3):
+        getattr(model, f"cost_reg_{l}").conv0_mode = getattr(model, f"cost_reg_{l}").ci_mode = "f32"
+    model.feature.tail_mode = "f32"
+    got32 = model(imgs.to(dev), proj.to(dev), dmin, dint)
+    assert model.cost_reg_0._conv0_active is None and not model.cost_reg_0._ci_active and not model.feature._split_active
+    f32 = _check_levels(report, "e2e_full_size_all_float32", got32, model, want, {l: inter[f"index_{l}"] for l in (2, 1, 0)},
+                        {l: inter[f"cost_{l}"] for l in (2, 1, 0)}, extra=dict(config=config, layers="all float32 MFMA"), boundary_tol=tol)
+    report("e2e_full_size_noise_owner", config=config,
+           **{f"{k}_{l}": [split[f"{k}_{l}"], f32[f"{k}_{l}"]] for l in (2, 1, 0) for k in ("index_flips", "e_noise", "argmax_flips", "cost_scaled_err")})
 
 
 def test_benched_launch_matches_oracle(dev, report):
