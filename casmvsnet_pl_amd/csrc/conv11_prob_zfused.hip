@@ -58,7 +58,8 @@ struct FzCfg {
   static constexpr int NU = (UNITS + WAVES - 1) / WAVES;               // per wave: 5 (waves 0-3) / 4
   static constexpr int WUNITS = 9 * 2 * 64;                            // lane images [kz * 3 + ky][slice][lane] (deconv11_splitf16.hip's image)
   static constexpr size_t SLOT_BYTES = (size_t)SLOT * 4, BOX_BYTES = (size_t)BOX * 16, W_BYTES = (size_t)WUNITS * 16;
-  static constexpr size_t LDS_BYTES = 2 * SLOT_BYTES + 2 * BOX_BYTES + W_BYTES + 64;   // 141 632: one workgroup of 8 waves per CU
+  static constexpr size_t FRONT = 16;                                  // bytes in front of slot 0: the epilogue's unmasked store of position -1 of its first row lands here
+  static constexpr size_t LDS_BYTES = FRONT + 2 * SLOT_BYTES + 2 * BOX_BYTES + W_BYTES + 64;   // 141 648: one workgroup of 8 waves per CU
   static_assert(TX % 4 == 0 && TY % 2 == 0 && ITEMS <= THREADS && TX / 2 + 2 <= 32, "shape");
 };
 
@@ -98,11 +99,13 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
   using Cfg = FzCfg;
   constexpr int RS = Cfg::RS, SP = Cfg::SP, SLOT = Cfg::SLOT, JX = Cfg::JX, JY = Cfg::JY, NVB = Cfg::NVB, BOX = Cfg::BOX, NU = Cfg::NU;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float *slots = reinterpret_cast<float *>(smem_raw);                                                      // [2][SLOT]
-  u32x4 *box = reinterpret_cast<u32x4 *>(smem_raw + 2 * Cfg::SLOT_BYTES);                                   // [2 planes][slice][half][NVB]
-  u32x4 *wl = reinterpret_cast<u32x4 *>(smem_raw + 2 * Cfg::SLOT_BYTES + 2 * Cfg::BOX_BYTES);               // [9][slice][64]
-  unsigned *wmax = reinterpret_cast<unsigned *>(smem_raw + 2 * Cfg::SLOT_BYTES + 2 * Cfg::BOX_BYTES + Cfg::W_BYTES);   // [2 sets][8]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *slots = reinterpret_cast<float *>(smem_raw + Cfg::FRONT);                                                      // [2][SLOT]
+  u32x4 *box = reinterpret_cast<u32x4 *>(smem_raw + Cfg::FRONT + 2 * Cfg::SLOT_BYTES);                                   // [2 planes][slice][half][NVB]
+  u32x4 *wl = reinterpret_cast<u32x4 *>(smem_raw + Cfg::FRONT + 2 * Cfg::SLOT_BYTES + 2 * Cfg::BOX_BYTES);               // [9][slice][64]
+  unsigned *wmax = reinterpret_cast<unsigned *>(smem_raw + Cfg::FRONT + 2 * Cfg::SLOT_BYTES + 2 * Cfg::BOX_BYTES + Cfg::W_BYTES);   // [2 sets][8]
+  // `wave` as a SCALAR: the compiler cannot see that threadIdx.x >> 6 is uniform, and every branch on a value derived from it (row parity of the wave's units,
+  // whether its last unit exists, whether it stages) became exec-mask control flow with the masks carried - and spilled - across the whole walk
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int jcol = lane & 15, kb = lane >> 4, half = kb & 1, dx = kb >> 1, u = kb;
   const int Do = 2 * Di, Ho = 2 * Hi, Wo = 2 * Wi;
   const int iHW = Hi * Wi, ics = Di * iHW, oHW = Ho * Wo, ocs = Do * oHW;
@@ -113,7 +116,6 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
   const rsrc_t isrc = make_rsrc(in + (size_t)b * 16 * ics, (size_t)16 * ics * 4);
   const rsrc_t ssrc = make_rsrc(skip + (size_t)b * 8 * ocs, (size_t)8 * ocs * 4);
   const rsrc_t cdst = make_rsrc(cost + (size_t)b * ocs, (size_t)ocs * 4);
-  const rsrc_t none = make_rsrc(in, 0);
   const float *dtail = reinterpret_cast<const float *>(wdc + Cfg::W_BYTES);
   float sc[2], sh[2];   // conv11's folded ABN of the lane's channel pair (2 u, 2 u + 1)
 #pragma unroll
@@ -135,26 +137,34 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
   const int ox = tx0 - 2 + 2 * J;                 // even; the pair (ox, ox + 1) is inside or outside the row (Wo even)
   const bool x_in = ox >= 0 && ox < Wo;
   int sk_off[NU];                                 // byte offset of (channel 2 u, plane 0, row, ox) or kOOB
+  unsigned vmask[NU];                             // ~0 inside the volume, 0 outside: ANDed onto the epilogue's values (a select on a loop-invariant per-lane
+                                                  // predicate is hoisted by the compiler as a 64-bit lane mask in two scalar registers - five of them, and
+                                                  // the exec juggling of every masked store, were most of the 112 scalar spills of round 5's build)
   const bool last_unit = row0 + 4 * (NU - 1) < Cfg::IY;   // unit NU - 1 exists for waves 0-3 (slot rows 16, 17); wave-uniform
 #pragma unroll
   for (int q = 0; q < NU; ++q) {
     const int row = row0 + 4 * q, oy = ty0 - 1 + row;
     const bool in_vol = row < Cfg::IY && oy >= 0 && oy < Ho && x_in;
     sk_off[q] = in_vol ? ((2 * u) * ocs + oy * Wo + ox) * 4 : kOOB;
+    vmask[q] = in_vol ? 0xffffffffu : 0u;
+#ifndef HIPEMU_LDS_BYTES
+    asm volatile("" : "+v"(vmask[q]));   // opaque: the optimiser otherwise folds `t & (in_vol ? ~0 : 0)` back into a select on the hoisted lane mask
+#endif
   }
   f32x2 SK[NU][2];
-  auto load_skip = [&](int z, bool exists) {      // the skip values of plane z: unconditional issue (a missing plane reads through the empty descriptor)
-    const rsrc_t r = exists ? ssrc : none;
-    const int soff = exists ? z * oHW * 4 : 0;
+  auto load_skip = [&](int z) {                   // the skip values of plane min(z, Do - 1): unconditional issue (plane Do is never computed: its values are
+    const int soff = min(z, Do - 1) * oHW * 4;    // never used - re-reading the last plane keeps ONE descriptor and the same loads on every path)
 #pragma unroll
     for (int q = 0; q < NU; ++q)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) SK[q][h] = buf_load2(r, sk_off[q], soff + h * ocs * 4);
+      for (int h = 0; h < 2; ++h) SK[q][h] = buf_load2(ssrc, sk_off[q], soff + h * ocs * 4);
   };
 
   // ---- (b) box staging item of this thread: (channel half, box row, pair of columns) ----
-  const int s_e = tid - (Cfg::THREADS - Cfg::ITEMS);   // the LAST 360 threads: waves 4-7 own four matrix units each, waves 0-3 five
-  const bool stager = s_e >= 0;
+  // waves 2-7 stage (384 threads for 360 items: the last 24 repeat item 359 - the same loads, the same values to the same addresses): a wave-uniform
+  // predicate is a scalar branch, a per-lane one a lane mask carried in scalar registers across the whole walk
+  const bool stager = wave >= 2;
+  const int s_e = min(tid - 128, Cfg::ITEMS - 1);
   const int s_h = s_e / (JY * (JX / 2)), s_rem = s_e - s_h * (JY * (JX / 2)), s_r = s_rem / (JX / 2), s_g = s_rem - s_r * (JX / 2);
   const int s_unit = s_h * NVB + s_r * JX + 2 * s_g;
   int s_voff;
@@ -164,12 +174,11 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
     s_voff = ok ? ((8 * s_h) * ics + gy * Wi + gx) * 4 : kOOB;
   }
   f32x2 R[8];
-  auto load_box = [&](int iz) {
-    const bool exists = iz < Di;
-    const rsrc_t r = exists ? isrc : none;
-    const int soff = exists ? iz * iHW * 4 : 0;
+  auto load_box = [&](int iz) {                   // input plane iz; a plane behind the volume (taps kz = 0 of the last odd output plane) reads zeros: every
+    const int voff = iz < Di ? s_voff : kOOB;     // lane's offset out of range - one descriptor, the same loads on every path
+    const int soff = min(iz, Di - 1) * iHW * 4;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) R[c] = buf_load2(r, s_voff, soff + c * ics * 4);
+    for (int c = 0; c < 8; ++c) R[c] = buf_load2(isrc, voff, soff + c * ics * 4);
   };
   auto box_max = [&](int set) {
     float m = 0.0f;
@@ -274,24 +283,25 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
 #pragma unroll
     for (int q = 0; q < NU; ++q) {
       if (q == NU - 1 && !last_unit) continue;
-      const bool in_vol = sk_off[q] != kOOB;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float t = acc0[q][r] * inv0;
         if (ODD) t = t + acc1[q][r] * inv1;
         t = fmaf(t, sc[r >> 1], sh[r >> 1]);
-        t = t > 0.0f ? t : t * slope;
+        t = fmaxf(t, t * slope);    // leaky-relu for 0 <= slope <= 1 (checked on the host): t > 0 ? t : t * slope, the same product, no compare + select
         t = t + SK[q][r >> 1][r & 1];
-        v[r] = in_vol ? t : 0.0f;   // outside the volume: `prob`'s zero padding
+        v[r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, t) & vmask[q]);   // outside the volume: `prob`'s zero padding
       }
       float *prow = slot_lane + q * 4 * RS;                                                    // slot + u SP + row RS + 4 J
-      if (J >= 1) *reinterpret_cast<f32x2 *>(prow - 2) = f32x2{v[0], v[2]};                   // position 2 J - 1: (channel 2 u, 2 u + 1)
-      if (J <= Cfg::TX / 2) *reinterpret_cast<f32x2 *>(prow) = f32x2{v[1], v[3]};             // position 2 J <= TX
+      // both stores unmasked: position -1 of column J = 0 is the previous row's unused tail (floats 130, 131 of its 132; in front of slot 0: Cfg::FRONT),
+      // position 62 of J = 31 this row's (floats 124, 125) - nothing reads either
+      *reinterpret_cast<f32x2 *>(prow - 2) = f32x2{v[0], v[2]};                               // position 2 J - 1: (channel 2 u, 2 u + 1)
+      *reinterpret_cast<f32x2 *>(prow) = f32x2{v[1], v[3]};                                   // position 2 J
     }
     ZF_STAMP();   // t2: epilogue (skip values landed, slot written)
     // the next plane's skip values: in flight across the `prob` phase
-    load_skip(z + 1, z + 1 < Do);
+    load_skip(z + 1);
     // -- (b) the box ring: an even step writes input plane k + 1 (first read by step 2 k + 1) and puts plane k + 2 in flight; an odd step publishes its maximum --
     if (!ODD) {
       if (k >= 1) {   // (planes 0 and 1: the prologue)
@@ -323,7 +333,9 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
       float o0 = fmaf(A[0][0][0] + A[0][0][1], psc, psh), o1 = fmaf(A[0][1][0] + A[0][1][1], psc, psh);
       o0 = o0 > 0.0f ? o0 : o0 * pslope;
       o1 = o1 > 0.0f ? o1 : o1 * pslope;
-      buf_store2(f32x2{o0, o1}, cdst, z >= 1 ? out_voff : kOOB, z >= 1 ? (z - 1) * oHW * 4 : 0);
+      // (step z = 0 has no finished plane: it stores its value - the bias through the activation - into plane Do - 1, which the store behind the walk
+      // overwrites: vmcnt retires in order, and every step in between waits for loads issued after this store)
+      buf_store2(f32x2{o0, o1}, cdst, out_voff, (z >= 1 ? z - 1 : Do - 1) * oHW * 4);
     }
     A[0][0] = A[1][0];
     A[0][1] = A[1][1];
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
 
   // ---- prologue: input planes 0 and 1 into the box ring, the skip values of plane 0 ----
   load_box(0);
-  load_skip(0, true);
+  load_skip(0);
   box_max(0);
   __syncthreads();   // (also publishes the lane images)
   {
@@ -392,6 +404,7 @@ extern "C" int casmvs_conv11_prob_zfused_f32(const void *deconv11_packed, const 
   casmvs::clear_error();
   CASMVS_REQUIRE(deconv11_packed && prob_packed && in && skip && depth_values && cost && depth && confidence, "conv11_prob_zfused: null pointer");
   CASMVS_REQUIRE(B > 0 && B <= 65535 && casmvs_conv11_prob_zfused_supported(Di, Hi, Wi), "conv11_prob_zfused: B=%d Di=%d Hi=%d Wi=%d (Wi even)", B, Di, Hi, Wi);
+  CASMVS_REQUIRE(slope >= 0.0f && slope <= 1.0f && prob_slope >= 0.0f && prob_slope <= 1.0f, "conv11_prob_zfused: leaky-relu slopes %g / %g outside [0, 1] (the kernel forms max(t, slope t))", slope, prob_slope);
   CASMVS_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(skip) | reinterpret_cast<size_t>(cost) | reinterpret_cast<size_t>(depth) |
                    reinterpret_cast<size_t>(confidence)) & 7) == 0 && (reinterpret_cast<size_t>(deconv11_packed) & 15) == 0,
                  "conv11_prob_zfused: 8-byte aligned tensors, 16-byte aligned image");
