@@ -923,6 +923,12 @@ int launch_cfg(const SweepArgs &a, const Plan &p, int B, hipStream_t st) {
   if constexpr (MODE == MODE_VAR || MODE == MODE_GWC) {
     if (a.nv == 2) return launch_nv<C, CS, MODE, TW, 2>(a, p, B, st);
   }
+#ifdef CASMVS_CV_UNROLL46   // A/B build (round 6): the variance volume of V = 5 / V = 7 with a compile-time view count (profiles/r06_costvol_v5_v7_unrolled.txt)
+  if constexpr (MODE == MODE_VAR) {
+    if (a.nv == 4) return launch_nv<C, CS, MODE, TW, 4>(a, p, B, st);
+    if (a.nv == 6) return launch_nv<C, CS, MODE, TW, 6>(a, p, B, st);
+  }
+#endif
   return launch_nv<C, CS, MODE, TW, 0>(a, p, B, st);
 }
 

@@ -27,6 +27,9 @@
 #ifndef CASMVS_FS_PAIR
 #define CASMVS_FS_PAIR 0
 #endif
+#ifndef CASMVS_FS_EARLY_PREFETCH
+#define CASMVS_FS_EARLY_PREFETCH 0   // A/B builds: 1 = the next chunk's loads issued as soon as V exists, before both barriers (round 6: 448-467 us against 454: no gain, profiles/r06_costvol_v5_v7_unrolled_and_fpn_prefetch.txt)
+#endif
 
 namespace {
 
@@ -197,6 +200,23 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
           for (int j = 0; j < 4; ++j) V[c][j] = fmaf(T[j][3], w[3], fmaf(T[j][2], w[2], fmaf(T[j][1], w[1], T[j][0] * w[0])));
         }
       }
+#if CASMVS_FS_EARLY_PREFETCH
+      // the loads of the NEXT chunk (or of the next tile's chunk 0) go out here - their registers are free as soon as V exists - instead of behind the
+      // second barrier: they then have the reduction, both barriers, the split and the matrix phase to land, not the matrix phase alone (SQ counters,
+      // round 5: this kernel's waves were parked 35 % of their time; one chunk's matrix phase is ~400 cycles, a memory round trip 2 000+)
+      int nvox = vox, nvxor = vxor;
+      if (ch + 1 < NCH) {
+        prefetch(n, ch + 1, true);
+      } else {
+        const int cvox = vox, cvxor = vxor;
+        if (!(CASMVS_FS_DEBUG & 2)) plan_int(nty0, ntx0);   // (rewrites voff_d / vox / vxor: the current tile's LDS slots are kept for the stores below)
+        nvox = vox;
+        nvxor = vxor;
+        vox = cvox;
+        vxor = cvxor;
+        prefetch(nn, 0, have_next);
+      }
+#endif
       float m = 0.0f;
 #pragma unroll
       for (int c = 0; c < 8; ++c)
@@ -220,12 +240,17 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
         }
       }
       __syncthreads();
+#if CASMVS_FS_EARLY_PREFETCH
+      vox = nvox;
+      vxor = nvxor;
+#else
       if (ch + 1 < NCH) {
         prefetch(n, ch + 1, true);
       } else {
         if (!(CASMVS_FS_DEBUG & 2)) plan_int(nty0, ntx0);
         prefetch(nn, 0, have_next);
       }
+#endif
       // ---- matrix phase: the wave's six staged rows read once, 3 ky x 4 output rows x 3 partial products ----
       f32x4 part[NT];
 #pragma unroll
