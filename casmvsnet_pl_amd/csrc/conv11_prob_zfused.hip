@@ -59,7 +59,11 @@ struct FzCfg {
   static constexpr int WUNITS = 9 * 2 * 64;                            // lane images [kz * 3 + ky][slice][lane] (deconv11_splitf16.hip's image)
   static constexpr size_t SLOT_BYTES = (size_t)SLOT * 4, BOX_BYTES = (size_t)BOX * 16, W_BYTES = (size_t)WUNITS * 16;
   static constexpr size_t FRONT = 16;                                  // bytes in front of slot 0: the epilogue's unmasked store of position -1 of its first row lands here
-  static constexpr size_t LDS_BYTES = FRONT + 2 * SLOT_BYTES + 2 * BOX_BYTES + W_BYTES + 64;   // 141 648: one workgroup of 8 waves per CU
+#ifndef CASMVS_ZF_WLDS
+#define CASMVS_ZF_WLDS 0   // A/B builds: 1 = `prob`'s weights from an LDS image through wave-uniform 16-byte reads (round 6: scalar spills 112 -> 39, counted waits - and 3 % SLOWER, 219 / 510 / 520 us against 213 / 490 / 500: the LDS pipe is the scarcer resource)
+#endif
+  static constexpr size_t PW_BYTES = CASMVS_ZF_WLDS ? 12 * 20 * 4 : 0;   // `prob`'s weights, [step][20]
+  static constexpr size_t LDS_BYTES = FRONT + 2 * SLOT_BYTES + 2 * BOX_BYTES + W_BYTES + 64 + PW_BYTES;   // 142 608: one workgroup of 8 waves per CU
   static_assert(TX % 4 == 0 && TY % 2 == 0 && ITEMS <= THREADS && TX / 2 + 2 <= 32, "shape");
 };
 
@@ -126,6 +130,13 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
   const float *ptail = wpk + 8 * 32;  // `prob`: scale[4] | shift[4] after the [pair][64] weight rows
   const float psc = ptail[0], psh = ptail[4];
   for (int unit = tid; unit < Cfg::WUNITS; unit += Cfg::THREADS) wl[unit] = reinterpret_cast<const u32x4 *>(wdc)[unit];
+#if CASMVS_ZF_WLDS
+  float *pwl = reinterpret_cast<float *>(smem_raw + Cfg::FRONT + 2 * Cfg::SLOT_BYTES + 2 * Cfg::BOX_BYTES + Cfg::W_BYTES + 64);   // [12 steps][20]
+  if (tid < 12 * 20) {   // step i = (pair i / 3, ky i % 3); entry e = 2 (3 kz + kx) + c  <-  the P1 image's wpk[pair * 64 + kz * 18 + ky * 6 + 2 kx + c]
+    const int i = tid / 20, e = tid - i * 20, kz = e / 6, r = e - kz * 6;
+    pwl[tid] = e < 18 ? wpk[(i / 3) * 64 + kz * 18 + (i % 3) * 6 + r] : 0.0f;
+  }
+#endif
 
   // ---- (a) this wave's matrix units: q -> slot row (wave >> 1) + 4 q (one row parity per wave), column tile wave & 1 ----
   const int tile = wave & 1, row0 = wave >> 1;
@@ -319,7 +330,11 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
     __syncthreads();   // slot[z & 1] and the box are published; the other slot is free
     ZF_STAMP();   // t4: past the barrier
     // -- (c) `prob`: plane z feeds output planes z - 1, z, z + 1 --
+#if CASMVS_ZF_WLDS
+    casmvs::pz::zwalk_plane<7, SP, RS, true>(slot + yi * RS + 4 * xi, pwl, A);
+#else
     casmvs::pz::zwalk_plane<7, SP, RS>(slot + yi * RS + 4 * xi, wpk, A);
+#endif
 #ifndef HIPEMU_LDS_BYTES
     // pin the accumulators here: two thirds of the plane's FMAs feed A[1] / A[2], whose next use is behind the NEXT plane's matrix phase - the optimiser sank
     // them (and their 100 operand registers) across it, which spilled

@@ -18,7 +18,10 @@ using namespace casmvs::buf;
 // kz in KZM (bit mask).  `rows`: this lane's first row / position inside the slot; wpk: the P1 weight image
 // ([pair][tap (27 + 5 zeros)][channel of the pair], conv3d_mfma.hip pack_weight) read as wave-uniform scalars.
 // SP / RS: floats per channel pair of a plane slot / per staged row (ProbZCfg; the slot layout [pair][row][position][channel of the pair]).
-template <int KZM, int SP, int RS>
+// WLDS: `wpk` is an LDS image [step (pair, ky)][20 floats: (kz, kx) -> (even, odd channel) at 2 (3 kz + kx), 2 unused] read with wave-uniform
+// 16-byte LDS loads into vector registers instead of scalar loads from memory: LDS returns in order, so the step's wait is a COUNTED wait that leaves the
+// next step's reads in flight (a scalar load's wait is always a full drain), and the 36 scalar registers of the two weight buffers are free (conv11_prob_zfused.hip).
+template <int KZM, int SP, int RS, bool WLDS = false>
 __device__ __forceinline__ void zwalk_plane(const float *rows, const float *__restrict__ wpk, f32x2 (&A)[3][2]) {
   constexpr int NSTEP = 4 * 3;  // step i = (pair i / 3, ky = i % 3); 8 input channels = 4 pairs
   // Software pipeline, pinned with sched_barrier: the two LDS rows AND the scalar weight loads of step i + 1 are issued
@@ -37,6 +40,22 @@ __device__ __forceinline__ void zwalk_plane(const float *rows, const float *__re
     } else {
       lo[BUF] = *reinterpret_cast<const f32x4v *>(row);
       hi[BUF] = *reinterpret_cast<const f32x4v *>(row + 4);
+    }
+    if constexpr (WLDS) {
+      const f32x4v *wv = reinterpret_cast<const f32x4v *>(wpk + i * 20);
+      f32x4v q[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) q[j] = wv[j];
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        if (!((KZM >> kz) & 1)) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int e = 2 * (3 * kz + kx);
+          W[BUF][kz][kx] = f32x2{q[e / 4][e % 4], q[e / 4][e % 4 + 1]};
+        }
+      }
+      return;
     }
     const float *wq = wpk + (i / 3) * 64 + (i % 3) * 6;  // taps (kz, ky, kx = 0..2) x (even, odd channel) at [kz * 18 + 2 kx + c]
 #pragma unroll

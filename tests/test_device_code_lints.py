@@ -78,6 +78,15 @@ def test_no_wide_store_is_followed_by_a_write_of_its_data_registers():
     spec.loader.exec_module(tool)
     report = tool.lint(window=2)
     assert not report, report
+    # the scan follows control flow (round-5 advisor finding: it used to stop at any label or branch): a wide store at the end of a loop body is checked against
+    # the head of the loop its back edge lands on, an unconditional branch against its target, a label is fallen through; s_nop N pads N + 1 slots
+    st = "buffer_store_dwordx4 v[4:7], v9, s[0:3], s8 offen"
+    assert not tool.find(["LABEL .L0", "v_mov_b32 v1, v2", st, "s_cbranch_scc1 .L0", "s_endpgm"], 2)
+    assert tool.find(["LABEL .L0", "v_mov_b32 v5, v2", st, "s_cbranch_scc1 .L0", "s_endpgm"], 2)[0][2] == "v_mov_b32 v5, v2"      # through the back edge
+    assert tool.find([st, "s_branch .L1", "v_mov_b32 v4, 0", "LABEL .L1", "v_mov_b32 v6, 0"], 2)[0][2] == "v_mov_b32 v6, 0"          # at the branch target only
+    assert tool.find([st, "LABEL .L1", "v_mov_b32 v6, 0"], 2) and not tool.find([st, "s_nop 1", "LABEL .L1", "v_mov_b32 v6, 0"], 2)   # labels take no slot
+    assert tool.find([st, "s_cbranch_vccz .L1", "s_nop 0", "LABEL .L1", "v_mov_b32 v7, 0"], 2)                                      # taken side of a conditional branch
+    assert not tool.find([st, "s_cbranch_vccz .L1", "s_nop 0", "v_mov_b32 v7, 0", "LABEL .L1", "s_endpgm"], 2)                       # 3 slots on the fall-through side
 
 
 def test_packed_float32_rewrite_exchanges_the_sources_of_the_faulty_class_only():

@@ -69,11 +69,16 @@ def kernels(asm):
         elif t and not t.startswith(".") and not t.endswith(":"):
             cur.append(t)
         elif t.endswith(":"):
-            cur.append("LABEL")
+            cur.append("LABEL " + t[:-1])
     return out
 
 
 def find(stream, window):
+    """Pairs (store, VALU writer of its data registers within `window` issue slots).  The scan FOLLOWS control flow: a label takes no slot and is fallen through,
+    an unconditional branch takes one slot and continues at its target, a conditional branch takes one slot and continues on BOTH sides - a wide store that is
+    the last vector-memory instruction of a loop body is checked against the head of the loop its back edge lands on (round-5 advisor finding: the scan used to
+    stop at any label or branch)."""
+    labels = {ins.split()[1]: i for i, ins in enumerate(stream) if ins.startswith("LABEL ")}
     hits = []
     for i, ins in enumerate(stream):
         if not STORE.match(ins):
@@ -82,22 +87,38 @@ def find(stream, window):
         data = regs(ops[0]) if ins.startswith(("buffer", "scratch")) else (regs(ops[1]) if len(ops) > 1 else set())   # global / flat: vaddr, vdata
         if len(data) < 3:
             continue
-        slots, j = 0, i + 1
-        while j < len(stream) and slots < window:
-            nxt = stream[j]
-            j += 1
-            if nxt == "LABEL" or nxt.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
-                break   # (a loop's back edge lands on other code: check the head of the loop by hand when the store is the last instruction)
-            op = nxt.split()[0]
-            if op == "s_nop":
-                slots += int(nxt.split()[1], 0) + 1
-                continue
-            slots += 1
-            if op.startswith("v_") and not op.startswith(("v_cmp", "v_cmpx")) or op.startswith("v_cmp") and False:
-                dst = regs(nxt.split(None, 1)[1].split(",")[0].strip())
-                if dst & data:
-                    hits.append((i, ins, nxt, slots))
+        work, seen, found = [(i + 1, 0)], set(), None
+        while work and found is None:
+            j, slots = work.pop()
+            while j < len(stream) and slots < window:
+                if (j, slots) in seen:
                     break
+                seen.add((j, slots))
+                nxt = stream[j]
+                j += 1
+                if nxt.startswith("LABEL "):
+                    continue
+                op = nxt.split()[0]
+                if op in ("s_endpgm", "s_setpc_b64", "s_swappc_b64", "s_trap"):
+                    break
+                if op == "s_nop":
+                    slots += int(nxt.split()[1], 0) + 1
+                    continue
+                slots += 1
+                if op == "s_branch" or op.startswith("s_cbranch"):
+                    target = labels.get(nxt.split()[1])
+                    if target is not None:
+                        work.append((target, slots))
+                    if op == "s_branch":
+                        break
+                    continue
+                if op.startswith("v_") and not op.startswith(("v_cmp", "v_cmpx")):
+                    dst = regs(nxt.split(None, 1)[1].split(",")[0].strip())
+                    if dst & data:
+                        found = (i, ins, nxt, slots)
+                        break
+        if found:
+            hits.append(found)
     return hits
 
 
