@@ -2333,6 +2333,24 @@ extern "C" size_t casmvs_costreg_workspace_bytes(int B, int D, int h, int w) {
   return (size_t)B * floats * sizeof(float);
 }
 
+// The middle z slice (kz = 1) of a 3D channel-inner image as the image of the 2D layer with the same (ky, kx) taps: [slice][quad][27 taps][64] ->
+// [slice][quad][9 taps][64], then the scale / shift / zero tail unchanged.  A volume of ONE plane (conv6 at cascade level 0: D / 8 = 1) multiplies the taps
+// kz = 0 and kz = 2 with zero padding only: the layer IS the 2D convolution with this image, at a third of the matrix instructions.
+namespace {
+__global__ __launch_bounds__(kThreads) void extract_kz1_image_kernel(const float *__restrict__ src, float *__restrict__ dst, int blocks, int tail) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < blocks * 576) {
+    const int blk = i / 576, r = i - blk * 576;
+    dst[i] = src[(size_t)blk * 27 * 64 + 9 * 64 + r];
+  } else if (i < blocks * 576 + tail) {
+    dst[i] = src[(size_t)blocks * 27 * 64 + (i - blocks * 576)];
+  }
+}
+}  // namespace
+
+#ifndef CASMVS_CONV6_2D
+#define CASMVS_CONV6_2D 1   // conv6 of a one-plane volume as a 2D layer (A/B builds: 0 = the 3D kernel over its zero padding, rounds 1-5)
+#endif
 #ifndef CASMVS_ZFUSED_MIN_TILES
 #define CASMVS_ZFUSED_MIN_TILES 180   // conv11 + prob fused from this many 16 x 60 pixel tiles on (A/B builds: a huge value = never)
 #endif
@@ -2454,6 +2472,18 @@ int costreg_run(const char *who, const float *const *packed_layers, const void *
     if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
     ++li;
     rc = casmvs_conv_ci_splitf16_forward_f32(conv6_split, c5, c6, B, 64, 64, D / 8, h / 8, w / 8, sl, stream);
+    if (rc != CASMVS_OK) return rc;
+  } else if (CASMVS_CONV6_2D && D / 8 == 1 && packed_floats(CASMVS_CONV2D_K3, 64, 64) <= 8 * n) {
+    // one plane (cascade level 0, D = 8): two of the three z taps multiply zero padding - the layer as the 2D convolution of its middle z slice.  The 2D
+    // image is cut out of the 3D one on the device, into conv11's output buffer (free until conv11; never written at all on the fused-tail path): no new
+    // operand in the ABI.  Same taps in the same order on the same float32 MFMA: the 3D kernel's result bit for bit.
+    LayerCfg c3;
+    (void)layer_cfg(CASMVS_CONV_S1, 64, 64, c3);
+    const int blocks = c3.slices * c3.units, tail = 2 * c3.slices * c3.coutb + 64, total = blocks * 576 + tail;
+    hipLaunchKernelGGL(extract_kz1_image_kernel, dim3((unsigned)casmvs::ceil_div(total, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, P[6], u11, blocks, tail);
+    if (layer_events) (void)hipEventRecord((hipEvent_t)layer_events[li], (hipStream_t)stream);
+    ++li;
+    rc = conv2d_forward(CASMVS_CONV2D_K3, u11, c5, nullptr, c6, nullptr, B, 64, 64, h / 8, w / 8, sl, stream);
     if (rc != CASMVS_OK) return rc;
   } else {
     CASMVS_L(CASMVS_CONV_S1, P[6], c5, nullptr, c6, B, 64, 64, D / 8, h / 8, w / 8, sl, stream);      // conv6

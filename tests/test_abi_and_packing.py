@@ -91,6 +91,20 @@ def test_whole_costreg_pack_equals_the_per_layer_packs(cin):
         ops.costreg_pack(ws[:10])
 
 
+def test_middle_z_slice_of_a_3d_image_is_the_2d_layers_image():
+    """csrc/conv3d_mfma.hip extract_kz1_image_kernel (conv6 of a one-plane volume runs as a 2D layer, cascade level 0): blocks of 9 x 64 floats at tap 9 of every
+    (slice, quad) of the 3D channel-inner image, then the tail - exactly casmvs_conv2d_pack_f32 of the weight's middle z slice."""
+    g = torch.Generator().manual_seed(6)
+    w = torch.randn(64, 64, 3, 3, 3, generator=g)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    img3 = ops.conv3d_pack(ops.CONV_S1, w, sc, sh)
+    img2 = ops.conv2d_pack(ops.CONV2D_K3, w[:, :, 1].contiguous(), sc, sh)
+    blocks, tail = 4 * 16, 2 * 64 + 64      # 4 slices of 16 output channels x 16 quads of input channels; scale | shift | 64 zero words
+    assert img3.numel() == blocks * 27 * 64 + tail and img2.numel() == blocks * 9 * 64 + tail
+    cut = torch.cat([img3[:blocks * 27 * 64].view(blocks, 27, 64)[:, 9:18].reshape(-1), img3[blocks * 27 * 64:]])
+    assert torch.equal(cut, img2)
+
+
 CASES = [(ops.CONV_S1, 32, 8), (ops.CONV_S1, 5, 8), (ops.CONV_S1, 8, 1), (ops.CONV_S1, 16, 16), (ops.CONV_S1, 20, 32),
          (ops.CONV_S2, 8, 16), (ops.CONV_S2, 6, 32), (ops.CONV_T2, 16, 8), (ops.CONV_T2, 12, 32)]
 

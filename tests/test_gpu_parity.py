@@ -544,6 +544,22 @@ def test_costreg_matches_oracle(dev, report, cin, B, D, h, w):
     assert err < 1.2e-5  # measured 1.1e-6
 
 
+def test_one_plane_conv6_as_a_2d_layer_equals_the_3d_kernel(dev):
+    """CostRegNet.conv6 at cascade level 0 (D / 8 = 1: mvsnet.py:72 on a one-plane volume) runs as the 2D convolution of the weight's middle z slice (the taps
+    kz = 0 / 2 multiply zero padding only; csrc/conv3d_mfma.hip costreg_run).  Same taps, same order, same float32 MFMA: the 3D kernel's result bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(66)
+    B, h, w = 2, 16, 24
+    x = torch.randn(B, 64, 1, h, w, generator=g)
+    wt = torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    y3 = ops.conv3d_forward(ops.CONV_S1, ops.conv3d_pack(ops.CONV_S1, wt, sc, sh).to(dev), x.to(dev), 64).cpu()
+    y2 = ops.conv2d_forward(ops.CONV2D_K3, ops.conv2d_pack(ops.CONV2D_K3, wt[:, :, 1].contiguous(), sc, sh).to(dev), x[:, :, 0].contiguous().to(dev), 64, None, 0.01).cpu()
+    assert torch.equal(y3[:, :, 0], y2)
+    want = F.leaky_relu(F.conv3d(x.double(), wt.double(), padding=1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1), 0.01)
+    assert scaled_err(y2.unsqueeze(2), want.float()) < 3e-6
+
+
 CONV2D_CASES = [  # kind, cin, cout, N, H, W
     (3, 3, 8, 3, 64, 96), (3, 8, 8, 2, 40, 72), (3, 32, 8, 1, 37, 50), (3, 16, 16, 2, 32, 48), (3, 32, 16, 1, 24, 70),
     (3, 32, 32, 3, 16, 20), (3, 5, 16, 1, 9, 21), (3, 8, 8, 1, 10, 23), (4, 8, 16, 2, 64, 96), (4, 16, 32, 1, 36, 52), (5, 32, 32, 2, 16, 24),
