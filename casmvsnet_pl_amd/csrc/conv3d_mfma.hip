@@ -2096,8 +2096,13 @@ extern "C" int casmvs_conv3d_forward_f32(int kind, const float *packed, const fl
     // (1, 16, 16) x 4 - the small tile wins by 7 % (5 resident workgroups per CU instead of 3)
     static const int db_s2 = trace_env_int("CASMVS_DB_S2", 3);  // A/B switch (profiling); default: double-buffered form
     const bool al2 = W % 4 == 0 && (reinterpret_cast<size_t>(in) & 15) == 0;
-    if (wide_blocks >= 512 && (db_s2 & 1) && al2) return launch_conv16db<FMT_CI, 4, 2, 2, 4, 16, 2>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
-    if (wide_blocks < 512 && (db_s2 & 2) && al2) return launch_conv16db<FMT_CI, 4, 1, 1, 4, 16, 2>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+#ifndef CASMVS_S2_ONE_PLANE_SMALL
+#define CASMVS_S2_ONE_PLANE_SMALL 1   // A/B builds: 0 = the two-plane tile also for a single output plane (rounds 1-5)
+#endif
+    // ONE output plane (conv5 at cascade level 0: D / 4 = 2 -> 1): the wide tile's second z plane would be computed and masked - the one-plane tile instead
+    const bool one_plane = CASMVS_S2_ONE_PLANE_SMALL && D / 2 == 1;
+    if (wide_blocks >= 512 && !one_plane && (db_s2 & 1) && al2) return launch_conv16db<FMT_CI, 4, 2, 2, 4, 16, 2>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
+    if ((wide_blocks < 512 || one_plane) && (db_s2 & 2) && al2) return launch_conv16db<FMT_CI, 4, 1, 1, 4, 16, 2>(c, packed, in, skip, out, B, cin, cout, D, H, W, slope, st);
     if (wide_blocks >= 512) return launch_conv16<FMT_CI, 2, 4, 2, 2, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
     return launch_conv16<FMT_CI, 2, 8, 1, 1, 4, 16>(c, packed, in, skip, out, B, cin, cout, D, H, W, D / 2, H / 2, W / 2, slope, st);
   }
