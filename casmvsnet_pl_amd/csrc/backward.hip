@@ -25,6 +25,14 @@ __global__ __launch_bounds__(kThreads) void homo_warp_bwd_kernel(const float *__
                                                                 int D, int U) {
   const int b = blockIdx.z, d = blockIdx.y;
   const int hw = H * W;
+  // the scale of a (sample, channel) does not depend on the pixel: once per workgroup into LDS (round-5 advisor finding: every thread rebuilt it - two
+  // float-to-double conversions, two double multiplies, a power of two - for every channel inside the scatter loop)
+  extern __shared__ double ch_scale[];   // [C]
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    int be;
+    ch_scale[c] = fixed_exponent(gmax[b * C + c], 0x3f800000u, 2.0, be) ? pow2_double(U - be) : 0.0;   // 1.0f: fixed_exponent(G, 1, 2) = the exponent of 2 G
+  }
+  __syncthreads();
   const int p = blockIdx.x * kThreads + threadIdx.x;
   if (p >= hw) return;
   const int y = p / W, x = p - y * W;
@@ -35,11 +43,9 @@ __global__ __launch_bounds__(kThreads) void homo_warp_bwd_kernel(const float *__
   float *gs = grad_src + (size_t)b * C * hw;
   unsigned long long *as = acc + (size_t)b * C * hw;
   const int on = t.yn * W + t.xl, os = t.ys * W + t.xl;
-  constexpr unsigned kOne = 0x3f800000u;   // 1.0f: fixed_exponent(G, 1, 2) = the exponent of 2 G
   for (int c = 0; c < C; ++c) {
     const float g = go[(size_t)c * D * hw];
-    int be;
-    const double scale = fixed_exponent(gmax[b * C + c], kOne, 2.0, be) ? pow2_double(U - be) : 0.0;
+    const double scale = ch_scale[c];
     float *gc = gs + (size_t)c * hw;
     unsigned long long *ac = as + (size_t)c * hw;
     auto add = [&](int o, float w) {
@@ -118,7 +124,8 @@ extern "C" int casmvs_homo_warp_backward_f32(const float *grad_out, const float 
   unsigned *partial = gmax + ((((size_t)B * C * sizeof(unsigned) + 15) & ~(size_t)15) / sizeof(unsigned));
   if (int rc = launch_volume_absmax(grad_out, nullptr, partial, gmax, nullptr, B * C, (size_t)D * hw, B, 0, C, 0, st)) return rc;
   dim3 grid((unsigned)casmvs::ceil_div(hw, kThreads), (unsigned)D, (unsigned)B);
-  hipLaunchKernelGGL(homo_warp_bwd_kernel, grid, dim3(kThreads), 0, st, grad_out, proj, depth, grad_src, acc, gmax, C, H, W, D, U);
+  CASMVS_REQUIRE((size_t)C * sizeof(double) <= 48 * 1024, "homo_warp_backward: C=%d (the per-channel scales are kept in LDS)", C);
+  hipLaunchKernelGGL(homo_warp_bwd_kernel, grid, dim3(kThreads), (size_t)C * sizeof(double), st, grad_out, proj, depth, grad_src, acc, gmax, C, H, W, D, U);
   if (int rc = casmvs::check_launch("homo_warp_bwd_kernel")) return rc;
   dim3 fgrid((unsigned)std::min(casmvs::ceil_div(hw, kThreads), 64), (unsigned)(B * C));
   hipLaunchKernelGGL(homo_warp_bwd_finish_kernel, fgrid, dim3(kThreads), 0, st, acc, gmax, grad_src, hw, U);
