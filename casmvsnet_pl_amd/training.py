@@ -179,6 +179,12 @@ def _active_plan():
     return None if _ACTIVE_PLAN is None else _ACTIVE_PLAN()
 
 
+def set_active_plan(plan):
+    """Make `plan` (a PackPlan, or None) the plan device_pack consults; held weakly."""
+    global _ACTIVE_PLAN
+    _ACTIVE_PLAN = None if plan is None else weakref.ref(plan)
+
+
 def release_plan():
     """Forget the training step in flight: later device_pack calls pack on their own until the next train-mode forward."""
     global _ACTIVE_PLAN
@@ -600,11 +606,10 @@ def cascade_forward_train(model, imgs, proj_mats, init_depth_min, depth_interval
     """mvsnet.py:197-244 in train mode (what train.py:99-103 calls): the same loop as the inference forward, on the
     differentiable ops.  Depth hypotheses come from the DETACHED previous depth (mvsnet.py:231)."""
     from .modules import _per_sample
-    global _ACTIVE_PLAN
     B, V, _, H, W = imgs.shape
     dev = imgs.device
     plan = pack_plan_of(model)
-    _ACTIVE_PLAN = weakref.ref(plan)   # this step's forward AND backward take their layer images from the plan
+    set_active_plan(plan)   # this step's forward AND backward take their layer images from the plan
     plan.begin_step()
     feats = feature_net_train(model.feature, imgs.reshape(B * V, 3, H, W).float())
     proj = proj_mats.float()

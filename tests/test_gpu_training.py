@@ -303,7 +303,7 @@ def test_pack_plan_fills_every_layer_image_of_a_step_in_one_launch(dev, report):
     assert plan.launches == 2 and plan.hits == 2 * n and plan.misses == n
     # the batched launch against the single launches, on the weights as they are now
     plan.begin_step()
-    T._ACTIVE_PLAN = None
+    T.release_plan()
     worst = 0
     for (wt, bz, idx, out, _, _), key in zip(list(plan.entries.values()), list(plan.entries)):
         single = T.device_pack(key[2], wt, bz, adjoint=key[3])
@@ -311,7 +311,7 @@ def test_pack_plan_fills_every_layer_image_of_a_step_in_one_launch(dev, report):
         worst = max(worst, int((single != out).sum()))
     assert worst == 0
     # a weight changed after begin_step: its image is packed again, not served from the plan
-    T._ACTIVE_PLAN = plan
+    T.set_active_plan(plan)
     plan.begin_step()
     wt, bz, idx, out, _, _ = next(iter(plan.entries.values()))
     key = next(iter(plan.entries))
@@ -320,7 +320,7 @@ def test_pack_plan_fills_every_layer_image_of_a_step_in_one_launch(dev, report):
         wt.mul_(2.0)
     again = T.device_pack(key[2], wt, bz, adjoint=key[3])
     assert (plan.hits, plan.misses) == (before[0], before[1] + 1)
-    T._ACTIVE_PLAN = None
+    T.release_plan()
     assert torch.equal(again, T.device_pack(key[2], wt, bz, adjoint=key[3]))
     # images nobody requests any more leave the batched launch (their buffers stay: a captured graph may read them) and come back on request
     launches = plan.launches

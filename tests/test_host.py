@@ -402,3 +402,22 @@ def test_stream_guard_serialises_f16_work_against_other_streams_only(monkeypatch
         with streams.stream_guard(False):
             streams.note_launch(None, f16=False, stream=a)      # switched off: no wait, no error
         streams.reset()
+
+
+def test_active_pack_plan_is_held_weakly():
+    """training._ACTIVE_PLAN (round-4 advisor item): the plan of the training step in flight lives on its model; the module global only refers to it weakly, so
+    dropping the model drops its plan (and the packed images and weights it references), and release_plan() forgets it at once."""
+    import gc
+    from casmvsnet_pl_amd import ABN, CascadeMVSNet, training as T
+    model = CascadeMVSNet(norm_act=ABN)
+    plan = T.pack_plan_of(model)
+    assert T.pack_plan_of(model) is plan
+    T.set_active_plan(plan)
+    assert T._active_plan() is plan
+    T.release_plan()
+    assert T._active_plan() is None
+    T.set_active_plan(plan)
+    del model, plan
+    gc.collect()
+    assert T._active_plan() is None
+    T.release_plan()
