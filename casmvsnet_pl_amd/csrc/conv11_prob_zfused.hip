@@ -194,7 +194,7 @@ __global__ __launch_bounds__(FzCfg::THREADS, 1) void conv11_prob_zfused_kernel(
   auto box_max = [&](int set) {
     float m = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) m = fmaxf(m, fmaxf(fabsf(R[c][0]), fabsf(R[c][1])));
+    for (int c = 0; c < 8; ++c) m = casmvs::absmax3(m, R[c][0], R[c][1]);
     const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
     if (lane == 0) wmax[set * 8 + wave] = wm;
   };

@@ -26,6 +26,10 @@
 #define CASMVS_C2_PAIR 0
 #endif
 
+#ifndef CASMVS_CI_SWP
+#define CASMVS_CI_SWP 1   // A/B builds: 0 = the two voxels of a staging item written in plain order (2-way conflicted 16-byte writes, no selects)
+#endif
+
 namespace {
 
 using namespace casmvs::buf;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__res
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc[t][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int swp = (lane >> 2) & 1;   // write order of an item's two voxels (conv_ci_splitf16.hip): conflict-free staging writes
+  const int swp = CASMVS_CI_SWP ? (lane >> 2) & 1 : 0;   // write order of an item's two voxels (conv_ci_splitf16.hip): conflict-free staging writes
 
   int item = blockIdx.x, n, ty0, tx0;
   decode(item, n, ty0, tx0);
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_ci_sf_kernel(const float *__res
     for (int ch = 0; ch < NCH; ++ch) {
       float m = 0.0f;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) m = fmaxf(m, fmaxf(fabsf(R[c][0]), fabsf(R[c][1])));
+      for (int c = 0; c < 16; ++c) m = casmvs::absmax3(m, R[c][0], R[c][1]);
       const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
       if (lane == 0) wmax[wave] = wm;
       __syncthreads();   // every wave is done with the previous chunk's LDS; the four maxima (first time: the lane images) are visible

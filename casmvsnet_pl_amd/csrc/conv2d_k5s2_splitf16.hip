@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256, (K5Cfg<CIN, COUT>::WG_PER_CU)) void conv2d_k5s
     for (int r = 0; r < NR; ++r)
 #pragma unroll
       for (int k = 0; k < 8; k += 2) {
-        m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(R[r][k][0]), fabsf(R[r][k][1])), fmaxf(fabsf(R[r][k][2]), fabsf(R[r][k][3]))));
-        m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(R[r][k + 1][0]), fabsf(R[r][k + 1][1])), fmaxf(fabsf(R[r][k + 1][2]), fabsf(R[r][k + 1][3]))));
+        m0 = casmvs::absmax3(casmvs::absmax3(m0, R[r][k][0], R[r][k][1]), R[r][k][2], R[r][k][3]);
+        m1 = casmvs::absmax3(casmvs::absmax3(m1, R[r][k + 1][0], R[r][k + 1][1]), R[r][k + 1][2], R[r][k + 1][3]);
       }
     const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, fmaxf(m0, m1)));
     if (lane == 0) wmax[wave] = wm;

@@ -42,6 +42,10 @@
 #define CASMVS_CI_STORE_AUX 0
 #endif
 
+#ifndef CASMVS_CI_SWP
+#define CASMVS_CI_SWP 1   // A/B builds: 0 = the two voxels of a staging item written in plain order (2-way conflicted 16-byte writes, no selects)
+#endif
+
 namespace {
 
 using namespace casmvs::buf;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, (CiCfg<CIN, COUT, TZ>::WG_PER_CU)) void conv_c
 
   // the two voxels of an item go out in the order that keeps 8 consecutive lanes on 8 different 16-byte bank groups:
   // lanes 0-3 of every 8 write their even voxel first, lanes 4-7 their odd one
-  const int swp = (lane >> 2) & 1;
+  const int swp = CASMVS_CI_SWP ? (lane >> 2) & 1 : 0;
 
   int item = blockIdx.x;
   CiTile cur = ci_decode<Cfg>(item, total, tiles_x, tiles_y, tiles_z);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256, (CiCfg<CIN, COUT, TZ>::WG_PER_CU)) void conv_c
 #pragma unroll
       for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) m = fmaxf(m, fmaxf(fabsf(R[r][c][0]), fabsf(R[r][c][1])));
+        for (int c = 0; c < 16; ++c) m = casmvs::absmax3(m, R[r][c][0], R[r][c][1]);
       const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
       if (lane == 0) wmax[wave] = wm;
       __syncthreads();   // every wave is done with the previous chunk's LDS; the four maxima are visible

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, (S2Cfg<CIN, COUT>::WG_PER_CU)) void conv_s2_sf
     // ---- the staged unit's largest magnitude (this thread's loads -> wave -> workgroup) ----
     float m = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) m = fmaxf(m, fmaxf(fmaxf(fabsf(Rd[c][0]), fabsf(Rd[c][1])), fmaxf(fabsf(Rd[c][2]), fabsf(Rd[c][3]))));
+    for (int c = 0; c < 8; ++c) m = casmvs::absmax3(casmvs::absmax3(m, Rd[c][0], Rd[c][1]), Rd[c][2], Rd[c][3]);
     const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
     if (lane == 0) wmax[wave] = wm;
     __syncthreads();   // every wave is done with the previous unit's LDS; the four maxima are visible

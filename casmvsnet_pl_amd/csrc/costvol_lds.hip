@@ -350,8 +350,11 @@ __device__ __forceinline__ void accumulate_view(const float *P, float xf, float 
 #ifndef CASMVS_WARP_OCC
 #define CASMVS_WARP_OCC 3   // waves per SIMD of the one-view (homo_warp) kernels at CS = 16: 136 VGPRs, one box per workgroup (A/B: 2, 4)
 #endif
+#ifndef CASMVS_WARP_OCC8
+#define CASMVS_WARP_OCC8 4   // the same at CS = 8 (cascade level 0): 111 VGPRs, four 39 KiB workgroups per CU.  Round 6, batch 8, dirtied caches: 268 -> 252 us through the reference signature (0.39 -> 0.42 of HBM), 214 -> 206 pixel-major; batch 1 and hot caches: equal (A/B: 3)
+#endif
 constexpr int waves_per_simd(int cs, int mode, int pg) {
-  return pg == 2 ? 4 : (cs == 8 ? 3 : (is_warp(mode) && cs == 16 ? CASMVS_WARP_OCC : 2));
+  return pg == 2 ? 4 : (cs == 8 ? (is_warp(mode) ? CASMVS_WARP_OCC8 : 3) : (is_warp(mode) && cs == 16 ? CASMVS_WARP_OCC : 2));
 }
 
 template <int C, int CS, int MODE, int TW, int DC, int NV, int PG>

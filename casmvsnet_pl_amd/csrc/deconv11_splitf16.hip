@@ -142,7 +142,7 @@ __global__ __launch_bounds__(DcCfg::THREADS, 2) void deconv11_sf_kernel(const fl
     // ---- the staged box's largest magnitude ----
     float m = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) m = fmaxf(m, fmaxf(fabsf(R[c][0]), fabsf(R[c][1])));
+    for (int c = 0; c < 16; ++c) m = casmvs::absmax3(m, R[c][0], R[c][1]);
     const unsigned wm = casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
     if (lane == 0) wmax[wave] = wm;
     __syncthreads();   // every wave is done with the previous tile's LDS; the four maxima are visible

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
   // the tent matrix issued between the wave's own f16 MFMAs, staged values of lanes 48-63 came out wrong in ~1 of 500 tiles,
   // only with two workgroups per CU - tools/debug/fpn_sf_check.py)
   int voff_d, voff_u0, voff_u1, vox, vxor;
-  float ly0, ly1, T[4][4];
+  float ly0, ly1;
+  f32x2 T2[2][4];   // the horizontal tent of the item's pixel PAIRS (2 jp, 2 jp + 1): weight of window column m
   auto plan_int = [&](int ty0, int tx0) {
     const int e = tid;
     const int iy = e / (IX / 4), g = e - iy * (IX / 4);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
       const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
       if (j == 0) xb = x0 < wc - 4 ? x0 : wc - 4;   // the 4-column window [xb, xb + 4) holds every column the 4 pixels use
 #pragma unroll
-      for (int m = 0; m < 4; ++m) T[j][m] = (m == x0 - xb ? lx0 : 0.0f) + (m == x1 - xb ? lx1 : 0.0f);
+      for (int m = 0; m < 4; ++m) T2[j >> 1][m][j & 1] = (m == x0 - xb ? lx0 : 0.0f) + (m == x1 - xb ? lx1 : 0.0f);
     }
     voff_u0 = ok ? (y0 * wc + xb) * 4 : kOOB;
     voff_u1 = ok ? (y1 * wc + xb) * 4 : kOOB;
@@ -178,26 +179,32 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       // ---- interpolate (chunks 1..4), find the staged tile's largest magnitude ----
-      float V[8][4];
+      // Two x per register pair (round 6): a staged value lives in the pair it was LOADED in (x, x + 1 of one channel), the vertical blend, the tent and the
+      // scaling are packed float32 instructions along x.  (The scalar form was vectorised by the compiler along CHANNEL pairs - the pairs the split's
+      // conversions take - at the price of 82 register moves per chunk, a fifth of the chunk's vector instructions.)  Same operations, same order per value.
+      f32x2 V2[8][2];
 #ifndef CASMVS_FS_DEBUG
 #define CASMVS_FS_DEBUG 0   // debug builds (WRONG results): 1 = no interpolation (every chunk staged like chunk 0), 2 = the next tile's plan from the
 #endif                      // first tile's (no per-tile plan arithmetic), 4 = no DPP reduction (every tile scaled by 2^0)
       if (ch == 0 || (CASMVS_FS_DEBUG & 1)) {   // conv0's channels as they are
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) V[c][j] = ra[c][j];
+        for (int c = 0; c < 8; ++c) {
+          V2[c][0] = f32x2{ra[c][0], ra[c][1]};
+          V2[c][1] = f32x2{ra[c][2], ra[c][3]};
+        }
       } else {
         // bilinear 2x, align_corners: the vertical blend of the two source rows first (4 window columns), then the horizontal tent
         // (two non-zero weights per pixel; the exact zeros of T add nothing).  ATen blends horizontally first: the two orders differ
         // by float32 roundings of the interpolated value - below this kernel's own 2^-22 slice error.
+        const f32x2 l0{ly0, ly0}, l1{ly1, ly1};
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          float w[4];
+          const f32x2 w01 = __builtin_elementwise_fma(l1, f32x2{rb[c][0], rb[c][1]}, l0 * f32x2{ra[c][0], ra[c][1]});
+          const f32x2 w23 = __builtin_elementwise_fma(l1, f32x2{rb[c][2], rb[c][3]}, l0 * f32x2{ra[c][2], ra[c][3]});
+          const f32x2 w0{w01.x, w01.x}, w1{w01.y, w01.y}, w2{w23.x, w23.x}, w3{w23.y, w23.y};
 #pragma unroll
-          for (int mm = 0; mm < 4; ++mm) w[mm] = fmaf(ly1, rb[c][mm], ly0 * ra[c][mm]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) V[c][j] = fmaf(T[j][3], w[3], fmaf(T[j][2], w[2], fmaf(T[j][1], w[1], T[j][0] * w[0])));
+          for (int jp = 0; jp < 2; ++jp)
+            V2[c][jp] = __builtin_elementwise_fma(T2[jp][3], w3, __builtin_elementwise_fma(T2[jp][2], w2, __builtin_elementwise_fma(T2[jp][1], w1, T2[jp][0] * w0)));
         }
       }
 #if CASMVS_FS_EARLY_PREFETCH
@@ -221,20 +228,25 @@ __global__ __launch_bounds__(FsCfg::THREADS, 2) void fpn_tail0_sf_kernel(const f
 #pragma unroll
       for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(V[c][j]));
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(V2[c][j >> 1][j & 1]));
       const unsigned wm = (CASMVS_FS_DEBUG & 4) ? 0x47000000u : casmvs::wave_max_bits(__builtin_bit_cast(unsigned, m));
       if (lane == 0) wmax[wave] = wm;
       __syncthreads();   // every wave is done with the previous chunk's LDS; the four maxima (and, first time, the lane images) are visible
       float mult, inv;   // max |x| 2^kx in [2^14, 2^15); 2^-kx
       casmvs::tile_scale(wmax, mult, inv);
       if (vox >= 0) {
+        const f32x2 mult2{mult, mult};
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) V2[c][jp] = V2[c][jp] * mult2;   // exact (a power of two); the split takes the scaled values
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float x[8];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) x[c] = V[c][j];
+          for (int c = 0; c < 8; ++c) x[c] = V2[c][j >> 1][j & 1];
           u32x4 o[2];
-          split8(x, mult, o);
+          casmvs::split8_scaled_f16(x, o);
 #pragma unroll
           for (int s = 0; s < 2; ++s) act[s * NV + vox + (j ^ vxor)] = o[s];
         }

@@ -28,6 +28,24 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, float mult, u
   b_bits = __builtin_bit_cast(unsigned, b);
 }
 
+// The same split of a pair that is ALREADY scaled (s = x * mult, an exact product): r = s * 1 - a, the same exact difference - for callers whose
+// scaling is a packed multiply along another axis than the channel pair (fpn_fused_sf.hip: two x per instruction, no register shuffles).
+__device__ __forceinline__ void split_scaled_pair_f16(float s0, float s1, unsigned &a_bits, unsigned &b_bits) {
+  const split_f16x2 a = {(_Float16)s0, (_Float16)s1};             // round to nearest even
+  const unsigned ab = __builtin_bit_cast(unsigned, a);
+  float r0, r1;
+#ifdef CASMVS_SPLIT_NOASM
+  r0 = s0 - (float)a[0];
+  r1 = s1 - (float)a[1];
+#else
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(s0), "v"(ab));                 // s0 - a.lo
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(s1), "v"(ab));   // s1 - a.hi
+#endif
+  const split_f16x2 b = {(_Float16)r0, (_Float16)r1};
+  a_bits = ab;
+  b_bits = __builtin_bit_cast(unsigned, b);
+}
+
 // 8 channels of one voxel -> the two 16-byte float16 vectors (slice a, slice b)
 __device__ __forceinline__ void split8_f16(const float (&x)[8], float mult, split_u32x4 (&o)[2]) {
 #pragma unroll
@@ -38,6 +56,21 @@ __device__ __forceinline__ void split8_f16(const float (&x)[8], float mult, spli
     o[1][p] = b;
   }
 }
+
+// 8 scaled channels of one voxel (s = x * mult) -> the two slices
+__device__ __forceinline__ void split8_scaled_f16(const float (&sv)[8], split_u32x4 (&o)[2]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned a, b;
+    split_scaled_pair_f16(sv[2 * p], sv[2 * p + 1], a, b);
+    o[0][p] = a;
+    o[1][p] = b;
+  }
+}
+
+// max(m, |a|, |b|) as ONE v_max3_f32 with source modifiers (the nested form fmaxf(m, fmaxf(|a|, |b|)) compiles to two instructions: the compiler does not
+// re-associate maxima).  fmaxf skips NaNs in either form: the same value.
+__device__ __forceinline__ float absmax3(float m, float a, float b) { return fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); }
 
 // maximum over the wave of a non-negative float's bit pattern (DPP inside rows of 16, scalar across the four rows)
 __device__ __forceinline__ unsigned wave_max_bits(unsigned v) {

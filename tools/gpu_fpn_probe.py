@@ -39,5 +39,7 @@ for N in ([int(sys.argv[3])] if len(sys.argv) > 3 else [6, 24]):
     t32 = timed(lambda: ops.fpn_tail0(p32, b9, x, y, channels_last_copy=True))
     tsf = timed(lambda: ops.fpn_tail0_splitf16(psf, b9, x, y, channels_last_copy=True))
     a, b = ops.fpn_tail0(p32, b9, x, y), ops.fpn_tail0_splitf16(psf, b9, x, y)
+    import hashlib
+    print("   sha256 of the split-f16 output:", hashlib.sha256(b.cpu().numpy().tobytes()).hexdigest()[:16])
     byt = 4 * (x.numel() * 3 + y.numel())
     print(f"N {N} {H}x{W}: fused float32 {t32:.1f} us, fused split-f16 {tsf:.1f} us ({byt / tsf / 1e3:.0f} GB/s of its {byt / 1e6:.0f} MB), max diff / range {float((a - b).abs().max() / a.abs().max()):.1e}", flush=True)
