@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # CASMVS_LIB_PATH: load another BUILD of the same library (profiling: -DCASMVS_TRACE, compiler-flag A/B runs)
 LIB_PATH = os.environ.get("CASMVS_LIB_PATH") or os.path.join(_PKG_DIR, "libcasmvs_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
 CONV2D_K3, CONV2D_K5S2, CONV2D_K1, CONV2D_K1_UP = 3, 4, 5, 6
@@ -89,6 +89,10 @@ SYMBOLS = {
     "casmvs_featurenet_forward_f32": (c_int, [POINTER(c_void_p), _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_void_p, c_int, c_int, c_int, c_float, POINTER(c_void_p), c_void_p]),
     "casmvs_fpn_tail0_supported": (c_int, [c_int, c_int]),
     "casmvs_fpn_tail0_f32": (c_int, [_FP] * 6 + [c_int, c_int, c_int, c_void_p]),
+    "casmvs_fnet_conv0_mm_packed_bytes": (c_size_t, []),
+    "casmvs_fnet_conv0_mm_pack": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "casmvs_fnet_conv0_mm_supported": (c_int, [c_int]),
+    "casmvs_fnet_conv0_mm_f32": (c_int, [c_void_p, _FP, _FP, c_int, c_int, c_int, c_float, c_void_p]),
     "casmvs_fpn_tail0_splitf16_packed_bytes": (c_size_t, []),
     "casmvs_fpn_tail0_splitf16_pack": (c_int, [_FP, c_void_p]),
     "casmvs_fpn_tail0_splitf16_f32": (c_int, [c_void_p, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),

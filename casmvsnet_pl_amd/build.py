@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcasmvs_hip.so")
-SOURCES = ["abi.hip", "costvol.hip", "costvol_lds.hip", "depth_ops.hip", "fusion.hip", "backward.hip", "train.hip", "prob_wgrad.hip", "prob_regress.hip", "conv11_prob_zfused.hip", "fpn_fused.hip", "fpn_fused_sf.hip", "conv0_splitbf16.hip", "conv0_splitf16.hip", "conv0_zmarch.hip", "deconv11_splitf16.hip", "deconv9_splitf16.hip", "conv_ci_splitf16.hip", "conv_s2_splitf16.hip", "conv2d_ci_splitf16.hip", "conv2d_k5s2_splitf16.hip", "debug_disturb.hip", "conv3d_mfma.hip"]
+SOURCES = ["abi.hip", "costvol.hip", "costvol_lds.hip", "depth_ops.hip", "fusion.hip", "backward.hip", "train.hip", "prob_wgrad.hip", "prob_regress.hip", "conv11_prob_zfused.hip", "fpn_fused.hip", "fpn_fused_sf.hip", "conv0_splitbf16.hip", "conv0_splitf16.hip", "conv0_zmarch.hip", "deconv11_splitf16.hip", "deconv9_splitf16.hip", "conv_ci_splitf16.hip", "conv_s2_splitf16.hip", "conv2d_ci_splitf16.hip", "conv2d_k5s2_splitf16.hip", "fnet_conv0_mm.hip", "debug_disturb.hip", "conv3d_mfma.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "plane_sweep.h", "buffer_ops.h", "softmax_regress.h", "split_f16.h", "fixed_accum.h")] + [os.path.join(REPO_ROOT, "include", "casmvs.h")]
 
 

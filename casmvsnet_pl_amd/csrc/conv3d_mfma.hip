@@ -2230,8 +2230,15 @@ int featurenet_run(const float *const *packed_layers, const void *fused0_packed,
   CASMVS_EV();                                                                                 \
   rc = conv2d_forward(__VA_ARGS__);                                                            \
   if (rc != CASMVS_OK) return rc
-  CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, nullptr, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
-  CASMVS_L(CASMVS_CONV2D_K3, P[1], a0, nullptr, c0, nullptr, N, 8, 8, H, W, slope, stream);            // conv0.1  :15
+  if (ci_layers && ci_layers[7] && casmvs_fnet_conv0_mm_supported(W) && (reinterpret_cast<size_t>(ci_layers[7]) & 15) == 0) {   // conv0.0 + conv0.1 as one kernel on the f16 matrix cores (fnet_conv0_mm.hip)
+    CASMVS_EV();   // the `conv0.0` interval of layer_events times the fused kernel, `conv0.1` is empty
+    rc = casmvs_fnet_conv0_mm_f32(ci_layers[7], imgs, c0, N, H, W, slope, stream);
+    if (rc != CASMVS_OK) return rc;
+    CASMVS_EV();
+  } else {
+    CASMVS_L(CASMVS_CONV2D_K3, P[0], imgs, nullptr, a0, nullptr, N, 3, 8, H, W, slope, stream);          // conv0.0  mvsnet.py:14
+    CASMVS_L(CASMVS_CONV2D_K3, P[1], a0, nullptr, c0, nullptr, N, 8, 8, H, W, slope, stream);            // conv0.1  :15
+  }
   if (ci_layers && ci_layers[5] && casmvs_conv2d_k5s2_splitf16_supported(8, 16, H, W) && (reinterpret_cast<size_t>(ci_layers[5]) & 15) == 0) {   // conv1.0 on the f16 matrix cores
     CASMVS_EV();
     rc = casmvs_conv2d_k5s2_splitf16_forward_f32(ci_layers[5], c0, a1, N, 8, 16, H, W, slope, stream);

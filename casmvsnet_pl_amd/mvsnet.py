@@ -86,9 +86,11 @@ class _PackedWeights:
         old = getattr(self, attr, None)
         olds = list(old) if isinstance(old, (list, tuple)) else ([old] if isinstance(old, torch.Tensor) else None)
         news = list(new) if isinstance(new, (list, tuple)) else [new]
-        if olds is not None and len(olds) == len(news) and all(o.shape == n.shape and o.device == n.device and o.dtype == n.dtype for o, n in zip(olds, news)):
+        same = lambda o, n: (o is None and n is None) or (o is not None and n is not None and o.shape == n.shape and o.device == n.device and o.dtype == n.dtype)
+        if olds is not None and len(olds) == len(news) and all(same(o, n) for o, n in zip(olds, news)):   # (an entry may be None: a layer without that image)
             for o, n in zip(olds, news):
-                o.copy_(n)
+                if o is not None:
+                    o.copy_(n)
             return old
         setattr(self, attr, new)
         return new
@@ -154,8 +156,9 @@ class FeatureNet(_PackedWeights, nn.Module):
         self._fused0 = None       # (packed 40-channel 3x3 layer, bias classes) of the fused full-resolution tail
         self.fuse_tail = True     # lat0 + upsample-add + smooth0 as one kernel (False: the reference's three steps, A/B and tests)
         self._fused0_sf = None    # the same tail as the split-f16 image
+        self.fuse_conv0 = True    # conv0.0 + conv0.1 as one kernel on the f16 matrix cores (with tail_mode "splitf16"; False: two float32-MFMA layers, A/B and tests)
         self.tail_mode = "splitf16"   # arithmetic of the fused tail: "splitf16" (f16 matrix cores, fpn_fused_sf.hip) or "f32"
-        self._ci2d = None         # split-f16 images of conv1.1, conv1.2, conv2.1, conv2.2, smooth1 (conv2d_ci_splitf16.hip; follow tail_mode)
+        self._ci2d = None         # split-f16 images of conv1.1, conv1.2, conv2.1, conv2.2, smooth1 (conv2d_ci_splitf16.hip), conv1.0, conv2.0, conv0 (follow tail_mode)
         self._split_active = False   # set by packed_layers: the split-f16 images are packed and current
         self.timer = None         # optional profiling.StageTimer (bench.py)
         self.last_channels_last = None
@@ -163,7 +166,7 @@ class FeatureNet(_PackedWeights, nn.Module):
     def packed_layers(self, device):
         """Folded + packed parameter images on `device` (re-packed whenever a tensor changed)."""
         sf = self.fuse_tail and self.tail_mode == "splitf16"
-        key = self._state_key(device) + (bool(self.fuse_tail), sf)
+        key = self._state_key(device) + (bool(self.fuse_tail), sf, bool(self.fuse_conv0))
         if self._packed is not None and key == self._packed_key:
             return self._packed
         packed, slopes = [], set()
@@ -197,6 +200,9 @@ class FeatureNet(_PackedWeights, nn.Module):
                 m = self.get_submodule(name)
                 sc, sh, _ = _fold_norm(f"FeatureNet.{name}", m.bn)
                 ci.append(ops.conv2d_k5s2_splitf16_pack(m.conv.weight, sc, sh).to(device))
+            # conv0.0 + conv0.1 as one kernel (fnet_conv0_mm.hip): the 8-channel map between them never reaches memory
+            (sc0, sh0, _), (sc1, sh1, _) = _fold_norm("FeatureNet.conv0.0", self.conv0[0].bn), _fold_norm("FeatureNet.conv0.1", self.conv0[1].bn)
+            ci.append(ops.fnet_conv0_mm_pack(self.conv0[0].conv.weight, sc0, sh0, self.conv0[1].conv.weight, sc1, sh1).to(device) if self.fuse_conv0 else None)
             return ci
         self._split_image("_ci2d", pack_ci, sf)
         self._split_active = sf   # the split-f16 images exist and are current: forward may select them

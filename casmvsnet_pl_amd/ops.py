@@ -768,6 +768,39 @@ def conv2d_k5s2_splitf16_forward(packed, x, cout, slope=0.01):
     return out
 
 
+def fnet_conv0_mm_pack(w0, scale0, shift0, w1, scale1, shift1):
+    """Host-side packing of FeatureNet.conv0's two layers for the fused kernel (casmvs_fnet_conv0_mm_pack): w0 (8, 3, 3, 3), w1 (8, 8, 3, 3), the layers'
+    folded eval-mode ABN scale / shift (8) or None -> uint8 CPU tensor."""
+    w0, w1 = w0.detach().to("cpu", torch.float32).contiguous(), w1.detach().to("cpu", torch.float32).contiguous()
+    if tuple(w0.shape) != (8, 3, 3, 3) or tuple(w1.shape) != (8, 8, 3, 3):
+        raise ValueError(f"fnet_conv0_mm_pack: weights {tuple(w0.shape)} {tuple(w1.shape)} (need (8, 3, 3, 3) and (8, 8, 3, 3))")
+    vec = [None if v is None else v.detach().to("cpu", torch.float32).contiguous() for v in (scale0, shift0, scale1, shift1)]
+    for v in vec:
+        if v is not None and tuple(v.shape) != (8,):
+            raise ValueError("fnet_conv0_mm_pack: scale / shift must hold 8 values")
+    lib = _lib.load()
+    packed = torch.empty(lib.casmvs_fnet_conv0_mm_packed_bytes(), dtype=torch.uint8)
+    rc = lib.casmvs_fnet_conv0_mm_pack(_ptr(w0), _ptr(vec[0]), _ptr(vec[1]), _ptr(w1), _ptr(vec[2]), _ptr(vec[3]), ctypes.c_void_p(packed.data_ptr()))
+    _lib.check(rc, "casmvs_fnet_conv0_mm_pack")
+    return packed
+
+
+def fnet_conv0_mm(packed, imgs, slope=0.01):
+    """FeatureNet.conv0 (ConvBnReLU 3 -> 8 -> 8, mvsnet.py:14-16) as one kernel on the f16 matrix cores (casmvs_fnet_conv0_mm_f32); packed: device uint8
+    image of fnet_conv0_mm_pack.  imgs (N, 3, H, W) -> (N, 8, H, W)."""
+    imgs = _dev(imgs, "imgs")
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("fnet_conv0_mm: `packed` must be the uint8 image on the MI355X")
+    N, c, H, W = imgs.shape
+    if c != 3 or not _lib.load().casmvs_fnet_conv0_mm_supported(W):
+        raise ValueError(f"fnet_conv0_mm: imgs {tuple(imgs.shape)} (3 channels, W even)")
+    out = torch.empty((N, 8, H, W), dtype=torch.float32, device=imgs.device)
+    with torch.cuda.device(imgs.device):
+        rc = _lib.load().casmvs_fnet_conv0_mm_f32(ctypes.c_void_p(packed.data_ptr()), _ptr(imgs), _ptr(out), N, H, W, float(slope), _stream(imgs, f16=True))
+    _lib.check(rc, "casmvs_fnet_conv0_mm_f32")
+    return out
+
+
 def fpn_tail0_splitf16_pack(weight40):
     """Host-side packing of the composed 40-channel 3x3 tail (mvsnet.compose_fpn_tail) for the split-f16 kernel
     (casmvs_fpn_tail0_splitf16_pack): weight40 (8, 40, 3, 3) -> uint8 CPU tensor."""
@@ -808,8 +841,8 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
     kernels) -> (feat0, feat1, feat2, (nhwc0, nhwc1, nhwc2)).  fused0: (packed40, bias9) device tensors - the
     full-resolution tail as one kernel (casmvs_featurenet_forward_fused_f32); fused0_splitf16: packed40 is the uint8 image of
     fpn_tail0_splitf16_pack (the tail on the f16 matrix cores) instead of the float32 conv2d_pack image.  ci_layers (with fused0 only):
-    7 device images - conv2d_ci_splitf16_pack's for conv1.1, conv1.2, conv2.1, conv2.2, smooth1, conv2d_k5s2_splitf16_pack's for conv1.0, conv2.0 (entries may be
-    None) - those layers on the f16 cores.
+    8 device images - conv2d_ci_splitf16_pack's for conv1.1, conv1.2, conv2.1, conv2.2, smooth1, conv2d_k5s2_splitf16_pack's for conv1.0, conv2.0,
+    fnet_conv0_mm_pack's for conv0 (conv0.0 + conv0.1 as one kernel) (entries may be None) - those layers on the f16 cores.
     nchw_outputs=False (with channels_last_copies; the engine's own call): feat0 / feat1 are not stored - nothing downstream reads their (N,C,h,w) layout -
     and come back as None."""
     imgs = _dev(imgs, "imgs")
@@ -840,9 +873,9 @@ def featurenet_forward(packed_layers, imgs, workspace, slope=0.01, layer_events=
         if fused0 is not None:   # (packed 40-channel tail, bias classes): lat0 + upsample-add + smooth0 in one kernel
             ci = None
             if ci_layers is not None:
-                if len(ci_layers) != 7:
-                    raise ValueError("featurenet_forward: ci_layers needs 7 entries (conv1.1, conv1.2, conv2.1, conv2.2, smooth1, conv1.0, conv2.0)")
-                ci = (ctypes.c_void_p * 7)(*[None if t is None else t.data_ptr() for t in ci_layers])
+                if len(ci_layers) != 8:
+                    raise ValueError("featurenet_forward: ci_layers needs 8 entries (conv1.1, conv1.2, conv2.1, conv2.2, smooth1, conv1.0, conv2.0, conv0)")
+                ci = (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in ci_layers])
             rc = _lib.load().casmvs_featurenet_forward_fused_f32(arr, ctypes.c_void_p(fused0[0].data_ptr()), 1 if fused0_splitf16 else 0, _ptr(fused0[1]),
                                                                  ci, _ptr(imgs), _ptr(feat0), _ptr(feat1),
                                                                  _ptr(feat2), _ptr(cl[0]), _ptr(cl[1]), _ptr(cl[2]),

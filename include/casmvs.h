@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CASMVS_ABI_VERSION 5
+#define CASMVS_ABI_VERSION 6
 
 #define CASMVS_OK 0
 #define CASMVS_ERR_INVALID_ARG (-1) /* null pointer / non-positive size / unsupported combination */
@@ -365,9 +365,10 @@ int casmvs_fpn_tail0_f32(const float *packed40, const float *bias9, const float 
  * composed 40-channel layer, casmvs_fpn_tail0_f32), 1 = the split-f16 image (casmvs_fpn_tail0_splitf16_pack,
  * casmvs_fpn_tail0_splitf16_f32: the same kernel on the f16 matrix cores in the arithmetic of casmvs_conv0_splitf16_forward_f32).
  * casmvs_fpn_tail0_splitf16_pack: HOST, weight40 (8, 40, 3, 3) float32 finite -> casmvs_fpn_tail0_splitf16_packed_bytes() bytes.
- * ci_layers: NULL, or SEVEN pointers (ABI version 3; version 2 read five) { conv1.1, conv1.2, conv2.1, conv2.2, smooth1: DEVICE copies of
- * casmvs_conv2d_ci_splitf16_pack's images; conv1.0, conv2.0: of casmvs_conv2d_k5s2_splitf16_pack's } (an entry may be NULL): those layers then run on the f16
- * matrix cores (casmvs_conv2d_ci_splitf16_forward_f32 / casmvs_conv2d_k5s2_splitf16_forward_f32).
+ * ci_layers: NULL, or EIGHT pointers (ABI version 6; versions 3-5 read seven, version 2 five) { conv1.1, conv1.2, conv2.1, conv2.2, smooth1: DEVICE copies of
+ * casmvs_conv2d_ci_splitf16_pack's images; conv1.0, conv2.0: of casmvs_conv2d_k5s2_splitf16_pack's; conv0 (= conv0.0 + conv0.1): of casmvs_fnet_conv0_mm_pack's }
+ * (an entry may be NULL): those layers then run on the f16 matrix cores (casmvs_conv2d_ci_splitf16_forward_f32 / casmvs_conv2d_k5s2_splitf16_forward_f32 /
+ * casmvs_fnet_conv0_mm_f32: one launch for the two layers - the `conv0.0` interval of layer_events times it, `conv0.1` is empty).
  * feat0 / feat1 may be NULL when feat0_nhwc / feat1_nhwc are given (ABI version 3): nothing downstream of FeatureNet reads the (N, C, h, w) layout of
  * levels 0 / 1 - the plane sweep gathers pixel-major - and the engine's own call drops those stores.  feat2 feeds lat1: never NULL. */
 /* FeatureNet's 3x3 stride-1 layers with 16 / 32 channels (conv1.1, conv1.2: 16 -> 16; conv2.1, conv2.2: 32 -> 32: ConvBnReLU, mvsnet.py:19-20,24-25;
@@ -387,6 +388,14 @@ size_t casmvs_conv2d_k5s2_splitf16_packed_bytes(int cin, int cout);
 int casmvs_conv2d_k5s2_splitf16_pack(int cin, int cout, const float *weight, const float *scale, const float *shift, void *packed);
 int casmvs_conv2d_k5s2_splitf16_supported(int cin, int cout, int H, int W);
 int casmvs_conv2d_k5s2_splitf16_forward_f32(const void *packed, const float *in, float *out, int N, int cin, int cout, int H, int W, float slope, void *stream);
+/* FeatureNet.conv0 = ConvBnReLU(3, 8, 3) -> ConvBnReLU(8, 8, 3) (models/mvsnet.py:14-16) as ONE kernel, both layers on the f16 matrix cores in the same
+ * arithmetic (csrc/fnet_conv0_mm.hip): the 8-channel map between the two layers never reaches memory.  imgs (N, 3, H, W) -> out (N, 8, H, W); W even, both
+ * 8-byte aligned.  `packed`: HOST image from casmvs_fnet_conv0_mm_pack (w0 (8, 3, 3, 3), w1 (8, 8, 3, 3) finite; scale / shift (8) = the layers' folded
+ * eval-mode ABN, or NULL = 1 / 0), copied to the device by the caller (16-byte aligned).  slope: the ABN leaky-relu slope of both layers. */
+size_t casmvs_fnet_conv0_mm_packed_bytes(void);
+int casmvs_fnet_conv0_mm_pack(const float *w0, const float *scale0, const float *shift0, const float *w1, const float *scale1, const float *shift1, void *packed);
+int casmvs_fnet_conv0_mm_supported(int W);
+int casmvs_fnet_conv0_mm_f32(const void *packed, const float *imgs, float *out, int N, int H, int W, float slope, void *stream);
 size_t casmvs_fpn_tail0_splitf16_packed_bytes(void);
 int casmvs_fpn_tail0_splitf16_pack(const float *weight40, void *packed);
 int casmvs_fpn_tail0_splitf16_f32(const void *packed, const float *bias9, const float *conv0, const float *feat1_sum,

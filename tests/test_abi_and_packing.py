@@ -40,7 +40,7 @@ def test_abi_version_and_error_string():
     lib = _lib.load()
     # 4: the scatter backwards (casmvs_costvol_{var,gwc}_backward_f32, casmvs_homo_warp_backward_f32) take a caller-owned workspace - their sums are 64-bit
     # fixed point, bit-identical run to run; 3: casmvs_costreg_regress_f32 reads eight split_layers pointers (2: six, conv9 / conv11; 3: conv1 / conv3 added)
-    assert lib.casmvs_abi_version() == 5
+    assert lib.casmvs_abi_version() == 6
     assert lib.casmvs_packed_opsel_safe() == 1   # the in-tree build assembles the device code with the unsafe packed-float32 forms rewritten (build.py)
     rc = lib.casmvs_homo_warp_f32(None, None, None, None, 1, 1, 8, 8, 1, None)
     assert rc == -1 and b"null pointer" in lib.casmvs_last_error()

@@ -477,6 +477,62 @@ def test_conv2d_k5s2_splitf16_matches_torch_cpu(dev, report, cin, N, H, W, amp):
     assert e3 < 4 * max(ef, 2e-7)
 
 
+FNET0_CASES = [(1, 22, 64, 1.0), (2, 6, 8, 1.0), (3, 44, 92, 1e-3), (1, 2, 2, 1.0), (1, 20, 30, 1e-30), (1, 24, 36, 3e4), (24, 512, 640, 1.0), (3, 1184, 1600, 1.0), (5, 864, 1152, 1.0)]
+
+
+@pytest.mark.parametrize("N,H,W,amp", FNET0_CASES)
+def test_fnet_conv0_mm_matches_torch_cpu(dev, report, N, H, W, amp):
+    """csrc/fnet_conv0_mm.hip: FeatureNet.conv0 = ConvBnReLU(3, 8, 3) -> ConvBnReLU(8, 8, 3) (mvsnet.py:14-16) as ONE kernel with both layers on the f16
+    matrix cores: vs the two layers in torch CPU float64 at the bound of the float32-MFMA layer kernels and no worse than a few times the error of the two
+    float32-MFMA launches it replaces; borders inside a tile, tiles 4 pixels wide, images below one tile, the benched shape at batch 8 x 3 views, full-resolution
+    DTU images, inputs far outside float16's range; twice for the bits."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(N, 3, H, W, generator=g) * amp
+    x[..., -1:, -1:] *= 1e-6
+    w0, w1 = torch.randn(8, 3, 3, 3, generator=g) * 0.3, torch.randn(8, 8, 3, 3, generator=g) * 0.2
+    sc0, sh0 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1 * amp
+    sc1, sh1 = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1 * amp
+    big = N * H * W > 4_000_000   # float64 on the CPU for 24 images takes a while: the first three images
+    xs = x[:3] if big else x
+    mid = F.conv2d(xs.double(), w0.double(), padding=1) * sc0.double().view(1, -1, 1, 1) + sh0.double().view(1, -1, 1, 1)
+    mid = torch.where(mid > 0, mid, mid * 0.01)
+    want = F.conv2d(mid, w1.double(), padding=1) * sc1.double().view(1, -1, 1, 1) + sh1.double().view(1, -1, 1, 1)
+    want = torch.where(want > 0, want, want * 0.01)
+    packed = ops.fnet_conv0_mm_pack(w0, sc0, sh0, w1, sc1, sh1).to(dev)
+    xd = x.to(dev)
+    got_d = ops.fnet_conv0_mm(packed, xd, slope=0.01)
+    assert torch.equal(got_d, ops.fnet_conv0_mm(packed, xd, slope=0.01))
+    got = got_d[:xs.shape[0]].cpu()
+    assert torch.isfinite(got_d).all()
+    p0, p1 = ops.conv2d_pack(ops.CONV2D_K3, w0, sc0, sh0).to(dev), ops.conv2d_pack(ops.CONV2D_K3, w1, sc1, sh1).to(dev)
+    f32 = ops.conv2d_forward(ops.CONV2D_K3, p1, ops.conv2d_forward(ops.CONV2D_K3, p0, xd[:xs.shape[0]].contiguous(), 8, slope=0.01), 8, slope=0.01).cpu()
+    e3, ef = scaled_err(got, want), scaled_err(f32, want)
+    report("fnet_conv0_mm", shape=[N, H, W], amp=amp, err_fused_f16=e3, err_two_f32_mfma_layers=ef)
+    assert e3 < 1.2e-5
+    assert e3 < 4 * max(ef, 2e-7)
+
+
+def test_featurenet_with_the_fused_conv0_equals_the_two_layer_form(dev, report):
+    """FeatureNet.fuse_conv0 (the engine's default): the three feature maps with conv0.0 + conv0.1 as one f16 kernel against the same module running the two
+    float32-MFMA layers - both inside the float32-MFMA kernels' own distance from a float64 FeatureNet (asserted against the oracle elsewhere)."""
+    from casmvsnet_pl_amd import ABN
+    from casmvsnet_pl_amd.mvsnet import FeatureNet
+    from casmvsnet_pl_amd.synthetic import randomize_state_dict
+    net = FeatureNet(ABN)
+    randomize_state_dict(net.state_dict(), seed=3)
+    net = net.to(dev).eval()
+    x = torch.randn(3, 3, 128, 160, generator=torch.Generator().manual_seed(1)).to(dev)
+    a = {k: v.clone() for k, v in net(x).items()}
+    assert net._ci2d is not None and net._ci2d[7] is not None
+    net.fuse_conv0 = False
+    b = net(x)
+    assert net._ci2d[7] is None
+    errs = {k: scaled_err(a[k].cpu(), b[k].cpu().double()) for k in a}
+    report("featurenet_fused_conv0_vs_two_layers", errs=errs)
+    assert all(e < 5e-6 for e in errs.values()), errs
+
+
 PROB_CASES = [(1, 8, 8, 64), (2, 8, 32, 40), (1, 32, 16, 72), (2, 48, 24, 132), (1, 12, 9, 36), (1, 4, 5, 8), (1, 16, 70, 196)]
 
 
@@ -781,6 +837,10 @@ def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
         x5 = rnd(N, cin, H, W).to(dev)
         p5 = ops.conv2d_k5s2_splitf16_pack(rnd(2 * cin, cin, 5, 5, amp=0.1)).to(dev)
         cases.append((f"conv2d_k5s2_sf<{cin},{2 * cin}>", lambda p5=p5, x5=x5, cin=cin: ops.conv2d_k5s2_splitf16_forward(p5, x5, 2 * cin)))
+    # FeatureNet.conv0 as one kernel (both layers on the f16 cores)
+    xm = rnd(6, 3, 512, 640).to(dev)
+    pm = ops.fnet_conv0_mm_pack(rnd(8, 3, 3, 3, amp=0.3), None, None, rnd(8, 8, 3, 3, amp=0.2), None, None).to(dev)
+    cases.append(("fnet_conv0_mm", lambda: ops.fnet_conv0_mm(pm, xm)))
     launches = 30
     bad = {}
     for name, fn in cases:
@@ -803,7 +863,7 @@ def test_split_f16_kernels_are_bit_stable_at_full_occupancy(dev, report):
         out = gf()
         bad["graph_batch8"] += 0 if all(torch.equal(out[k], ref[k]) for k in ref) else 1
     report("split_f16_bit_stability", launches=launches, differing=bad)
-    assert len(bad) == 25 and not any(bad.values()), bad
+    assert len(bad) == 26 and not any(bad.values()), bad
 
 
 @pytest.mark.parametrize("cin,shape", [(8, (2, 8, 48, 64)), (16, (1, 9, 17, 44)), (32, (1, 12, 32, 40))])

@@ -10,6 +10,7 @@ the f16 and float32 MFMAs with the lane layouts the MI355X self-tests verified, 
   run_kernels9  the float32 matrix-core layers of conv3d_mfma.hip (3D stride 1 / 2 / transposed + skip, 2D k3 / k5 s2)
   run_kernels10 conv11 + prob + softmax regression as one depth-walking kernel (round 4; 512-thread workgroups)
   run_kernels11 conv2d_k5s2_sf: FeatureNet's stride-2 layers (conv1.0 / conv2.0) on the f16 cores (round 4)
+  run_kernels12 fnet_conv0_mm: FeatureNet.conv0 (conv0.0 + conv0.1) as one kernel, both layers on the f16 cores (round 6)
 
 The kernels written at the end of round 3 without access to a GPU RUN here for the first time - ragged shapes, persistent workgroups that walk several
 items, z segments.  The same sources under ThreadSanitizer (a missing barrier is a reported race) and under an LDS bank-conflict / cache-line profile built
@@ -26,8 +27,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = os.environ.get("HIPEMU_CXX") or "/opt/rocm/lib/llvm/bin/clang++"
 
 
-DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7", "run_kernels8", "run_kernels9", "run_kernels10", "run_kernels11")
-PROFILED = ("run_kernels", "run_kernels3", "run_kernels11")
+DRIVERS = ("run_kernels", "run_kernels2", "run_kernels3", "run_kernels4", "run_kernels5", "run_kernels6", "run_kernels7", "run_kernels8", "run_kernels9", "run_kernels10", "run_kernels11", "run_kernels12")
+PROFILED = ("run_kernels", "run_kernels3", "run_kernels11", "run_kernels12")
 # costvol_lds.hip instantiates 30 kernels: its ThreadSanitizer build alone takes 80 s - part of the suite only with HIPEMU_FULL=1 (clean when it was added)
 # (run_kernels8: the weight-gradient cases take a minute under the sanitizer; run_kernels9: conv3d_mfma.hip is 2500 lines of templates - clean when added)
 TSAN_DRIVERS = DRIVERS if os.environ.get("HIPEMU_FULL") == "1" else tuple(d for d in DRIVERS if d not in ("run_kernels7", "run_kernels8", "run_kernels9"))
@@ -124,6 +125,14 @@ def test_featurenet_stride2_kernel_runs_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
+def test_fused_featurenet_conv0_runs_on_the_cpu(built):
+    """fnet_conv0_mm_kernel (FeatureNet.conv0 = ConvBnReLU 3 -> 8 -> 8 as ONE kernel, both layers on the f16 matrix cores, the 8-channel map between them in
+    LDS only; round 6): against the two layers in float64 - borders inside a tile, two tiles in y, three in x (the last one 4 pixels wide), images smaller
+    than a tile (the driver's `all` mode: three images of 44 x 92, a 2 x 2 image, amplitudes 1e-20 and 3e4)."""
+    _run(built[("run_kernels12", "plain")], ("fnet_conv0_mm N=1 22x64", "fnet_conv0_mm N=2 6x8"))
+
+
+@pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
 def test_production_prob_head_runs_on_the_cpu(built):
     """prob_zwalk_kernel (Conv3d 8 -> 1 walking the depth axis, regression fused or chunked; the production head): cost, depth, confidence and index against
     float64 - a GPU-free regression test of the kernel the fused tail was derived from."""
@@ -171,7 +180,7 @@ def test_float32_matrix_core_layers_run_on_the_cpu(built):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-@pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "conv0_zw", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")), ("run_kernels3", ("conv_s2",)), ("run_kernels10", ("conv11_prob_zfused",)), ("run_kernels11", ("conv2d_k5s2",)),
+@pytest.mark.parametrize("source,names", [("run_kernels", ("conv0_zm", "conv0_zw", "deconv11", "deconv9")), ("run_kernels2", ("conv_ci", "conv2d_ci")), ("run_kernels3", ("conv_s2",)), ("run_kernels10", ("conv11_prob_zfused",)), ("run_kernels11", ("conv2d_k5s2",)), ("run_kernels12", ("fnet_conv0_mm",)),
                                           ("run_kernels4", ("prob_zwalk",)), ("run_kernels5", ("prob_wgrad", "fusion")), ("run_kernels6", ("fpn_tail0",)), ("run_kernels7", ("costvol_lds",)), ("run_kernels8", ("wgrad",)), ("run_kernels9", ("conv3d_f32",))])
 def test_no_lds_race_under_thread_sanitizer(built, source, names):
     """A missing __syncthreads() rarely shows in the results of an emulated run (the threads happen to be scheduled kindly): ThreadSanitizer sees it anyway.
@@ -192,7 +201,7 @@ def test_no_lds_race_under_thread_sanitizer(built, source, names):
 
 
 @pytest.mark.skipif(not (os.path.isfile(CLANG) or shutil.which(CLANG)), reason="needs a clang++ with ext_vector_type / _Float16 (ROCm's)")
-@pytest.mark.parametrize("source", ["run_kernels", "run_kernels3", "run_kernels11"])
+@pytest.mark.parametrize("source", ["run_kernels", "run_kernels3", "run_kernels11", "run_kernels12"])
 def test_lds_bank_profile_of_the_split_f16_kernels(built, source):
     """tools/lds_bank_profile.py: the compiler's memory-access hooks (-fsanitize=thread, linked against tests/hipemu/lds_profile.cpp instead of the sanitizer)
     record every LDS access of the emulated run; the accesses of a wave are regrouped into wave-instructions and priced with the bank rules of
@@ -203,7 +212,7 @@ def test_lds_bank_profile_of_the_split_f16_kernels(built, source):
         pytest.skip("this clang++ has no -fsanitize=thread")
     tool = _profile_tool()
     totals = tool.per_kernel(tool.profile(source, "quick", workdir=built["workdir"], exe=built[(source, "profile")]))
-    want = {"run_kernels": ("conv0_sf_kernel", "conv0_zw_kernel", "deconv11_sf_kernel", "deconv9_sf_kernel"), "run_kernels3": ("conv_s2_sf_kernel",), "run_kernels11": ("conv2d_k5s2_sf_kernel",)}[source]
+    want = {"run_kernels": ("conv0_sf_kernel", "conv0_zw_kernel", "deconv11_sf_kernel", "deconv9_sf_kernel"), "run_kernels3": ("conv_s2_sf_kernel",), "run_kernels11": ("conv2d_k5s2_sf_kernel",), "run_kernels12": ("fnet_conv0_mm_kernel",)}[source]
     for name in want:
         kernels = [k for k in totals if k.startswith(name)]
         assert kernels, (name, list(totals))
@@ -211,7 +220,10 @@ def test_lds_bank_profile_of_the_split_f16_kernels(built, source):
             n, cyc, ideal, _, _ = totals[k]["R"]
             assert n > 0 and cyc <= 1.0 * ideal, (k, "reads", cyc, ideal)
             n, _, _, eff, eff_ideal = totals[k]["W"]
-            assert n > 0 and eff <= 1.4 * eff_ideal, (k, "writes", eff, eff_ideal)
+            # fnet_conv0_mm_kernel: layer 1's results leave the accumulators as one dword (a channel pair) per pixel and lane - pixels 32 bytes apart, so
+            # lanes j, j + 4, j + 8, j + 12 share a bank (4-way, 24 stores per lane and tile: ~3 % of a tile's time; the unit layout is what keeps layer 2's
+            # operand READS conflict-free, which is what matters)
+            assert n > 0 and eff <= (1.6 if name == "fnet_conv0_mm_kernel" else 1.4) * eff_ideal, (k, "writes", eff, eff_ideal)
     if source == "run_kernels":   # the model against the hardware: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of conv0_sf_kernel<8, 3> on the MI355X = 0.184
         t = totals[next(k for k in totals if k.startswith("conv0_sf_kernel<8"))]   # (profiles/r03_pmc_conv0_split_kernels.txt)
         cycles, ideal = t["R"][1] + t["W"][1], t["R"][2] + t["W"][2]

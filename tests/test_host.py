@@ -344,7 +344,14 @@ def test_split_images_are_packed_only_for_the_selected_modes_and_non_finite_weig
     assert feat._fused0 is not None and feat._fused0_sf is None and feat._ci2d is None and not feat._split_active
     feat.tail_mode = "splitf16"
     feat.packed_layers(cpu)
-    assert feat._split_active and len(feat._ci2d) == 7   # conv1.1, conv1.2, conv2.1, conv2.2, smooth1 + the stride-2 layers conv1.0, conv2.0
+    assert feat._split_active and len(feat._ci2d) == 8   # conv1.1, conv1.2, conv2.1, conv2.2, smooth1 + the stride-2 layers conv1.0, conv2.0 + the fused conv0
+    assert feat._ci2d[7] is not None
+    feat.fuse_conv0 = False                              # A/B switch: the two float32-MFMA layers; the other images stay where they are
+    feat.packed_layers(cpu)
+    assert feat._ci2d[7] is None and len(feat._ci2d) == 8
+    feat.fuse_conv0 = True
+    feat.packed_layers(cpu)
+    assert feat._ci2d[7] is not None
 
 
 def test_stream_guard_serialises_f16_work_against_other_streams_only(monkeypatch):

@@ -27,6 +27,7 @@ ap.add_argument("--all-f32", action="store_true", help="every layer on the float
 ap.add_argument("--f32-k5s2", action="store_true", help="A/B: FeatureNet's conv1.0 / conv2.0 (5 x 5 stride 2) on the float32 MFMA kernel")
 ap.add_argument("--feature-split", type=int, default=1, help="A/B: FeatureNet over this many groups of images in sequence (cache blocking)")
 ap.add_argument("--nchw-feats", action="store_true", help="A/B: FeatureNet also stores the (N, C, h, w) maps of levels 0 / 1 (nothing in the forward reads them; the engine's call drops them)")
+ap.add_argument("--two-layer-conv0", action="store_true", help="A/B: FeatureNet's conv0.0 / conv0.1 as two float32-MFMA launches (rounds 1-5) instead of the fused f16 kernel")
 ap.add_argument("--f32-layers", default="", help="A/B: comma list of CostRegNet layers kept on the float32 MFMA kernel although they have an f16 form: conv0, conv1, conv2, conv3, conv4, conv6, conv9, conv11")
 args = ap.parse_args()
 if args.lib:
@@ -115,6 +116,10 @@ for name in ("conv1.0", "conv2.0"):   # the 5 x 5 stride-2 layers on the f16 cor
     cout, cin = w.shape[:2]
     ci2d.append(pack_bytes(lib.casmvs_conv2d_k5s2_splitf16_packed_bytes(cin, cout), lib.casmvs_conv2d_k5s2_splitf16_pack, cin, cout, hp(w), hp(sc), hp(sh)))
 
+w0_, sc0_, sh0_ = fw["conv0.0"]
+w1_, sc1_, sh1_ = fw["conv0.1"]
+ci2d.append(None if args.two_layer_conv0 else pack_bytes(lib.casmvs_fnet_conv0_mm_packed_bytes(), lib.casmvs_fnet_conv0_mm_pack, hp(w0_), hp(sc0_), hp(sh0_), hp(w1_), hp(sc1_), hp(sh1_)))   # ABI 6: ci_layers[7]
+
 # ---- CostRegNet per level (mvsnet.py:201-326) ----------------------------------------------------------------------------
 COSTREG = (("conv0", CONV_S1, None, 8), ("conv1", CONV_S2, 8, 16), ("conv2", CONV_S1, 16, 16), ("conv3", CONV_S2, 16, 32), ("conv4", CONV_S1, 32, 32),
            ("conv5", CONV_S2, 32, 64), ("conv6", CONV_S1, 64, 64), ("conv7", CONV_T2, 64, 32), ("conv9", CONV_T2, 32, 16), ("conv11", CONV_T2, 16, 8),
@@ -201,7 +206,7 @@ dmin = DeviceArray.from_numpy(np.full(B, DEPTH_MIN, np.float32))
 stream = hip.stream_create()
 st = ctypes.c_void_p(stream)
 arr13 = (ctypes.c_void_p * 13)(*[p.ptr for p in feat_packed])
-ci5 = None if args.all_f32 else (ctypes.c_void_p * 7)(*[None if (i >= 5 and args.f32_k5s2) else p.ptr for i, p in enumerate(ci2d)])
+ci5 = None if args.all_f32 else (ctypes.c_void_p * 8)(*[None if (p is None or (i in (5, 6) and args.f32_k5s2)) else p.ptr for i, p in enumerate(ci2d)])
 STAGES = ["feature"] + [f"{s}_{l}" for l in (2, 1, 0) for s in ("hypotheses", "costvol", "costreg")]
 events = {s: (hip.Event(), hip.Event()) for s in STAGES}
 
