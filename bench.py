@@ -92,10 +92,11 @@ def feature_flops(H, W):
     return full + half + quarter
 
 
-def feature_flops_f32_layers(H, W):
-    """The FeatureNet layers that stay on the float32 MFMA in the split-f16 layer set: conv0.0, conv0.1, lat1, toplayer."""
+def feature_flops_f32_layers(H, W, fused_conv0=True):
+    """The FeatureNet layers that stay on the float32 MFMA in the split-f16 layer set: lat1, toplayer - and conv0.0 / conv0.1 unless they run as the fused
+    f16 kernel (fnet_conv0_mm.hip, round 6; FeatureNet.fuse_conv0)."""
     hw = H * W
-    return 2 * hw * (9 * 3 * 8 + 9 * 8 * 8) + 2 * (hw // 4) * (16 * 32) + 2 * (hw // 16) * (32 * 32)
+    return (0 if fused_conv0 else 2 * hw * (9 * 3 * 8 + 9 * 8 * 8)) + 2 * (hw // 4) * (16 * 32) + 2 * (hw // 16) * (32 * 32)
 
 
 COSTREG_F32_FLOPS_PER_VOXEL = 216 + 216 + 432   # conv5, conv7, `prob`: the CostRegNet layers that stay float32 in the split-f16 layer set (of 6480 + conv0's)
@@ -601,7 +602,7 @@ def instrumented_pass(model, inputs, cfg_name, B, K, every, barrier, dev, with_h
     if ft_ms > 0:
         ft_flops = feature_flops(H, W) * V * B * n_ev
         ft_split = getattr(model.feature, "tail_mode", "f32") == "splitf16" and getattr(model.feature, "fuse_tail", False)
-        out["roofline_feature"] = {"kernel": "all FeatureNet launches", **mixed_mfma_roofline(ft_flops, feature_flops_f32_layers(H, W) * V * B * n_ev, ft_ms, ft_split),
+        out["roofline_feature"] = {"kernel": "all FeatureNet launches", **mixed_mfma_roofline(ft_flops, feature_flops_f32_layers(H, W, bool(getattr(model.feature, "fuse_conv0", False))) * V * B * n_ev, ft_ms, ft_split),
                                    "ms_per_depth_map": ft_ms / n_ev / B, "ms_per_step": ft_ms / n_ev, "batch": B}
     if with_homo_warp:
         out["roofline_homo_warp"] = homo_warp_roofline(dev, H, W, n_depths, B)
@@ -877,14 +878,14 @@ def main():
                           "per_gpu_engine": f"one stream, batch {B}, one hipGraph replay per step, split-f16 layer set (what every rank of a replica run executes)"
                                             if used_graph and NS == 1 and model.cost_reg_0.conv0_mode == "splitf16" else "see launch / *_arithmetic",
                           "featurenet_arithmetic": ("fused FPN tail, conv1.1 / conv1.2 / conv2.1 / conv2.2 / smooth1 and the 5x5 stride-2 layers conv1.0 / conv2.0 as conv0's "
-                                                    "split-f16 (fpn_fused_sf.hip, conv2d_ci_splitf16.hip, conv2d_k5s2_splitf16.hip); conv0.0 / conv0.1 and the "
+                                                    "split-f16 (fpn_fused_sf.hip, conv2d_ci_splitf16.hip, conv2d_k5s2_splitf16.hip), conv0.0 + conv0.1 as one f16 kernel (fnet_conv0_mm.hip); the "
                                                     "1x1 laterals float32 MFMA" if model.feature.tail_mode == "splitf16"
                                                     else "float32 MFMA (fused FPN tail: fpn_fused.hip)")
                                                    if model.feature.fuse_tail else "float32 MFMA, the FPN tail as three steps (lat0, upsample-add, smooth0)",
                           "every_layer_float32_value": "conv0_other_modes.modes[conv0_mode == 'f32'] of this line"},
                          median,
                          dtype="f32" if model.cost_reg_0.conv0_mode == "f32" and model.cost_reg_0.ci_mode == "f32" and model.feature.tail_mode == "f32" else
-                               "f32 (tensors + accumulation f32; products of 17 layers on the f16 MFMA from 2 f16 slices per operand)")
+                               "f32 (tensors + accumulation f32; products of 19 layers on the f16 MFMA from 2 f16 slices per operand)")
         line["library_sha16"] = library_sha16()
         line["source_sha16"] = source_sha16()
 
