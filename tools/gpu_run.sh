@@ -17,6 +17,7 @@
 #   costvol      tools/gpu_costvol_probe.py at batch 1 and 8 with dirtied caches (all BASELINE configs)
 #   trainprof    rocprofv3 --kernel-trace --stats over bench.py --mode train --steps 10 (per-kernel times of the training step)
 #   sq           SQ wave-state counters of every kernel of the step (two PMC passes over the step runner; tools/summarize_sq.py <dir> -> profiles/*_sq_counters_step.md)
+#   mfma         matrix-pipe busy cycles, MFMA operation counts and LDS bank conflicts of every kernel of the step (three PMC passes; tools/summarize_mfma.py)
 #   coresidency  the packed-float32 op_sel fault: stand-alone reproducer matrix, the library's float32 kernels beside f16 / bf16 neighbours
 #                (tools/native/coresidency_lib_victim.cpp), concurrent split-f16 forwards on 2 streams (tools/gpu_mixed_streams.py)
 #   cmd          runs "$GPU_RUN_CMD" (one-off experiments without a new script)
@@ -129,6 +130,18 @@ stage_sq () {
   ls $OUT/sq_state $OUT/sq_units | head -8; tail -2 $OUT/sq_state.log
 }
 
+stage_mfma () {   # matrix-pipe and LDS counters of every kernel of the step (three PMC passes over the step runner; tools/summarize_mfma.py <dir> -> profiles/*_mfma_lds_counters.md)
+  RUN="python $ROOTDIR/tools/notorch/step_runner.py --batch ${PMC_BATCH:-8} --steps 3 --warmup 1 $STEP_ARGS"
+  run_m () { name=$1; shift
+    (cd /tmp && timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o pmc -- $RUN > $OUT/$name.log 2>&1)
+    find $OUT/$name -type f -size +8M -delete 2>/dev/null; }
+  run_m mfma_busy SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES
+  run_m mfma_ops SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA
+  run_m lds_bank SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES
+  date -u +%Y-%m-%dT%H:%MZ > $OUT/collected_mfma.txt
+  ls $OUT/mfma_busy $OUT/mfma_ops $OUT/lds_bank | head -8; tail -2 $OUT/mfma_busy.log
+}
+
 stage_coresidency () {
   [ -x tools/probes/bin/pk_fma_opsel_repro ] && timeout 300 tools/probes/bin/pk_fma_opsel_repro ${OPSEL_ROUNDS:-4} > $OUT/packed_opsel_matrix.txt 2>&1
   grep -c "f16mfma [1-9]" $OUT/packed_opsel_matrix.txt | sed 's/^/forms that fail beside f16 matrix instructions: /'
@@ -143,7 +156,7 @@ stage_cmd () { bash -c "$GPU_RUN_CMD" > $OUT/cmd.txt 2>&1; echo "cmd exit: $?" >
 for s in "$@"; do
   echo "===== stage $s ($(date -u +%H:%M:%S))"
   case $s in
-    native|step|probes|bench|configs|suite|smoke|train|trainprof|files|pmc|sq|prof|costvol|coresidency|cmd) stage_$s ;;
+    native|step|probes|bench|configs|suite|smoke|train|trainprof|files|pmc|sq|mfma|prof|costvol|coresidency|cmd) stage_$s ;;
     *) echo "unknown stage $s" ;;
   esac
 done
