@@ -824,9 +824,9 @@ def main():
 
     def measure(B, steps, warmup, streams=1):
         model, imgs, proj, dmin, dint = build(B)
-        for _ in range(warmup):
-            model(imgs, proj, dmin, dint)
         use_graph = not args.no_graph and not view_sharded   # a collective inside a capture is not attempted
+        if use_graph:
+            model(imgs, proj, dmin, dint)   # lazy packing / workspaces before the capture (GraphedForward warms up again on its capture stream)
         if use_graph and streams > 1:
             cf = ConcurrentForwards(model, imgs, proj, dmin, dint, n_streams=streams, mixed_matrix_types=False if args.float32_replicas else None)
             if not cf.mixed_matrix_types:   # what the replicas run (and what the instrumented pass below should time)
@@ -839,6 +839,10 @@ def main():
             step = lambda: gf(imgs, proj)
         else:
             step = lambda: model(imgs, proj, dmin, dint)
+        # the W untimed warm-up steps are steps of the SAME kind as the timed ones (round 6: they were eager forwards before the capture, which left the first
+        # replays of the hipGraph - its upload - inside the timed region: mean 6.72 ms against a median of 6.61)
+        for _ in range(warmup):
+            step()
         elapsed, out, median = timed_steps(step, steps, barrier)
         maps_local = B * (streams if use_graph else 1) * steps
         elapsed, maps = aggregate(elapsed, maps_local, dist, dev, sum_maps=not view_sharded)
